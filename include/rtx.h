@@ -1,0 +1,141 @@
+/*
+ * rtx.h — C-ABI of the MI355X wavefront path tracer (librtx_hip.so).
+ *
+ * This is the drop-in boundary for the path-tracing inner loop of ML200/RoyalTracer-DX.
+ * The reference has no FFI; its de-facto boundary is "Renderer (C++) <-> shader resource
+ * bindings" (Pathtracer/rdn/Renderer.cpp:953-976, 983-1008, heap built at :1195-1581).
+ * Every entry point below replaces one of those bindings / host steps and cites it.
+ * Plain pointers and sizes only; no C++/torch types; no exceptions cross this boundary.
+ *
+ * Conventions
+ *   - 4x4 matrices: 16 floats, element (row r, col c) of the column-vector matrix at m[c*4+r].
+ *     These are exactly the bytes the reference memcpy's into its constant/structured buffers
+ *     (DirectXMath row-vector matrices stored row-major == glm column-major; Renderer.cpp:1722-1768,
+ *     2091-2121) and that HLSL consumes as `mul(M, float4(p,1))`.
+ *   - Material = 128 B (Pathtracer/src/Components/Vertex.h:14-23), Vertex = 28 B (Vertex.h:25-35),
+ *     LightTriangle = 80 B (Renderer.h:113-124).
+ *   - Return value 0 = ok, negative = RTX_ERR_*; message via rtx_last_error().
+ *     (reference: ThrowIfFailed -> std::exception, DXSampleHelper.h:17-23)
+ *   - A context is bound to ONE GPU and is not thread-safe; different contexts may be driven from
+ *     different threads/processes (reference: single thread, one in-flight frame, Renderer.cpp:717-735).
+ *   - There is NO CPU fallback: rtx_create fails with RTX_ERR_NO_DEVICE when HIP cannot open the device.
+ */
+#ifndef RTX_H
+#define RTX_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTX_OK               0
+#define RTX_ERR_INVALID     -1   /* bad argument / inconsistent scene arrays */
+#define RTX_ERR_NO_DEVICE   -2   /* HIP runtime or device not available */
+#define RTX_ERR_HIP         -3   /* a HIP call failed (message has the HIP error string) */
+#define RTX_ERR_STATE       -4   /* call order violated (e.g. render before commit/camera) */
+#define RTX_ERR_OOM         -5
+
+typedef struct rtx_ctx rtx_ctx;   /* one per GPU; opaque */
+
+/* Compile-time shader #defines of the reference (Common_v6.hlsl:1-28) + hard-wired host values
+   (Main.cpp:25, Renderer.cpp:1730) become one POD handed to rtx_render. */
+typedef struct rtx_params {
+    uint32_t width, height;   /* DispatchRays dims == image size (Renderer.cpp:646-654) */
+    uint32_t spp;             /* samples per pixel added by this call */
+    uint32_t sample_base;     /* first sample id s in the seed formula (RayGen_v6_pass1.hlsl:76-77 uses 1) */
+    uint32_t max_bounces;     /* path segments per sample (`bounces`, RayGen.hlsl:68,99) */
+    uint32_t nee_samples;     /* light samples per bounce (`nee_samples`, Common_v6.hlsl:8) */
+    uint32_t rr_start;        /* Russian roulette when bounce index > rr_start (`rr_threshold`, RayGen.hlsl:69,118) */
+    uint32_t frame_seed;      /* stands in for uint(time) (RayGen_v6_pass1.hlsl:76-77; Renderer.cpp:1754-1760) */
+    uint32_t flags;           /* RTX_FLAG_* */
+    uint32_t tile_size;       /* shard tile edge in pixels, multiple of 8 (0 => 64) */
+    uint32_t shard_rank;      /* this context renders tiles t (row-major tile index) with t % shard_count == shard_rank */
+    uint32_t shard_count;     /* 0 or 1 => whole image */
+} rtx_params;
+
+#define RTX_FLAG_LAMBERT_ONLY 1u  /* strategy 0 only, p_d = 1 (BRDF_v6.hlsl:7-70 bypassed) */
+#define RTX_FLAG_JITTER       2u  /* legacy sub-pixel jitter (RayGen.hlsl:84-87); v6 shoots pixel corners (pass1:80-82) */
+
+/* kernel classes for rtx_stats */
+enum { RTX_K_RAYGEN = 0, RTX_K_TRACE = 1, RTX_K_SHADE = 2, RTX_K_SHADOW = 3, RTX_K_ACCUM = 4, RTX_K_SORT = 5, RTX_K_COUNT = 8 };
+
+typedef struct rtx_stats {
+    uint64_t rays_primary, rays_extension, rays_shadow;  /* BVH queries issued by the last rtx_render */
+    uint64_t paths;                                       /* pixel-samples started */
+    double   kernel_ms[RTX_K_COUNT];                      /* summed hipEvent time per kernel class (timing option on) */
+    uint64_t kernel_launches[RTX_K_COUNT];
+    uint64_t kernel_items[RTX_K_COUNT];                   /* work items (rays / paths) processed per class */
+    double   render_ms;                                   /* hipEvent time of the whole rtx_render on its stream */
+    uint32_t bvh_nodes, triangles, lights, materials;
+} rtx_stats;
+
+enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents (rtx_stats.kernel_ms) */
+       RTX_OPT_PATHS_PER_BATCH = 2,  /* max pixel-samples in flight (queue capacity) */
+       RTX_OPT_SORT_MATERIALS = 3,   /* 0/1: material-sorted shading queue */
+       RTX_OPT_LDS_NODES = 4         /* BVH nodes staged in LDS per workgroup (top of tree) */ };
+
+/* lifetime: replaces LoadPipeline/device creation (Renderer.cpp:106-254) and OnDestroy (:546-552) */
+int  rtx_create(int device_ordinal, rtx_ctx** out);
+void rtx_destroy(rtx_ctx*);
+const char* rtx_last_error(rtx_ctx*);          /* ctx may be NULL: last create error */
+int  rtx_set_option(rtx_ctx*, int option, int64_t value);
+/* run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream.
+   replaces the single m_commandQueue (Renderer.cpp:192-199) */
+int  rtx_set_stream(rtx_ctx*, void* hip_stream);
+
+/* t5 `materials` StructuredBuffer<Material>, 128 B stride (Renderer.cpp:373-389, 1287-1296) */
+int  rtx_set_materials(rtx_ctx*, const void* mats128, uint32_t count);
+/* t2 `BTriVertex` (28 B stride) + t1 `indices` (u32) per model (CreateVB, Renderer.cpp:1973-2072) and the
+   model's slice of t4 `materialIDs` (one id per index, Renderer.cpp:391-407).  Vertex.normal.w must equal the
+   number of material ids added before this mesh (ObjLoader.h:466 / Hit_v6.hlsl:17). */
+int  rtx_add_mesh(rtx_ctx*, const void* verts28, uint32_t nverts, const uint32_t* indices, uint32_t nidx,
+                  const uint32_t* material_ids, uint32_t* mesh_out);
+/* m_instances.push_back({BLAS, matrix}) (Renderer.cpp:908-921); instance id = order of insertion (:843-845) */
+int  rtx_add_instance(rtx_ctx*, uint32_t mesh, const float o2w[16], uint32_t* inst_out);
+/* t3 `instanceProps` update (UpdateInstancePropertiesBuffer, Renderer.cpp:2091-2121); needs rtx_commit_scene again */
+int  rtx_set_instance_transform(rtx_ctx*, uint32_t inst, const float o2w[16]);
+/* CreateAccelerationStructures (Renderer.cpp:893-946) + CollectEmissiveTriangles (:2123-2213) +
+   CreateEmissiveTrianglesBuffer (:2237-2280): BVH build, emissive CDF, upload */
+int  rtx_commit_scene(rtx_ctx*);
+/* b0 `CameraParams` (UpdateCameraBuffer, Renderer.cpp:1722-1768): view + projection; inverses computed inside */
+int  rtx_set_camera(rtx_ctx*, const float view[16], const float proj[16]);
+
+/* u1 `gPermanentData` RGBA32F W x H (Renderer.cpp:1167-1186): xyz running sum, w sample count.
+   rtx_bind_accum lets the caller own the device buffer (W*H*16 bytes, e.g. a torch tensor); NULL = internal. */
+int  rtx_bind_accum(rtx_ctx*, void* device_rgba32f, size_t bytes);
+int  rtx_clear_accum(rtx_ctx*, uint32_t width, uint32_t height);   /* view-change reset (RayGen_v6_pass3.hlsl:407-423) */
+/* 3x DispatchRays (PopulateCommandList, Renderer.cpp:646-673) -> here: the wavefront loop; synchronous on return */
+int  rtx_render(rtx_ctx*, const rtx_params*);
+int  rtx_read_accum(rtx_ctx*, float* rgba32f, size_t bytes);       /* copy of u1 to the host */
+/* u0 `gOutput` layer 0, RGBA8 UNORM after sRGB OETF (RayGen_v6_pass3.hlsl:405,428-441; Common_v6.hlsl:353-376) */
+int  rtx_read_srgb8(rtx_ctx*, uint8_t* rgba8, size_t bytes);
+int  rtx_get_stats(rtx_ctx*, rtx_stats* out);
+/* t6 `g_EmissiveTriangles` as built by rtx_commit_scene (80 B records, Renderer.h:113-124) */
+int  rtx_get_lights(rtx_ctx*, void* out80, uint32_t max_count, uint32_t* count_out);
+
+/* multi-GPU (new; the reference is single-GPU): owned tiles of the accumulation buffer <-> compact
+   [tiles_per_shard][tile_size^2] float4 slab for one RCCL (all)gather.  Pointers are DEVICE pointers. */
+int  rtx_shard_slab_bytes(const rtx_params*, size_t* bytes_per_shard);
+int  rtx_pack_tiles(rtx_ctx*, const rtx_params*, void* device_slab);
+int  rtx_unpack_tiles(rtx_ctx*, const rtx_params*, const void* device_slabs_all_shards);
+
+/* kernel-level entry points used by the parity tests (host arrays in/out; run the SAME device kernels
+   the render loop uses).  rays8 = (ox,oy,oz,tmin, dx,dy,dz,tmax) per ray.
+   hits4 = (t,u,v, global triangle id as uint bits; 0xFFFFFFFF = miss) — TraceRay closest hit, a11. */
+int  rtx_debug_primary_rays(rtx_ctx*, const rtx_params*, uint32_t sample_id, float* rays8 /* W*H*8 */);
+int  rtx_debug_trace_closest(rtx_ctx*, const float* rays8, uint32_t n, float* hits4);
+int  rtx_debug_trace_any(rtx_ctx*, const float* rays8, uint32_t n, uint8_t* occluded);
+/* out16 per hit = pos3, matID bits, normal3, area, inst bits, flat3, pad4 (ClosestHit, Hit_v6.hlsl:12-61) */
+int  rtx_debug_surface(rtx_ctx*, const float* rays8, const float* hits4, uint32_t n, float* out16);
+/* in9 = n(3) wo(3) wi(3); out8 = f(3), pdf, p_d, p_s, 0, 0 */
+int  rtx_debug_bsdf_eval(rtx_ctx*, uint32_t mat_id, uint32_t flags, const float* in9, uint32_t n, float* out8);
+/* in8 = n(3) wo(3) seed(2 uint bits); out8 = wi(3), strategy bits, seed_out(2), 0, 0 */
+int  rtx_debug_bsdf_sample(rtx_ctx*, uint32_t mat_id, uint32_t flags, const float* in8, uint32_t n, float* out8);
+/* TEA RNG on the device: n draws from one seed (Common_v6.hlsl:119-138) */
+int  rtx_debug_tea(rtx_ctx*, uint32_t seed[2], uint32_t n, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,66 @@
+/*
+ * rtx_host.h — C entry points of the HOST layer that sits above include/rtx.h: the reference's scene-loader /
+ * material / camera surface (ObjLoader::loadObjFile, Material, Vertex, Manipulator, Renderer; see
+ * the headers under royaltracer-dx_amd/host/ for the C++ classes with the reference's own names) and the synthetic scenes
+ * BASELINE.json names.  These exist so that Python (tests, bench.py) and other FFI callers can build the same
+ * scenes the C++ facade builds; none of them touches the GPU except rtxh_scene_upload.
+ */
+#ifndef RTX_HOST_H
+#define RTX_HOST_H
+#include "rtx.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtxh_scene rtxh_scene;
+
+rtxh_scene* rtxh_scene_cornell(void);                                      /* SURVEY §8d Cornell Box, 32 triangles */
+rtxh_scene* rtxh_scene_sponza_class(uint32_t target_tris, uint32_t seed);  /* C3/C4 */
+rtxh_scene* rtxh_scene_bistro_class(uint32_t target_tris, uint32_t seed);  /* C5 */
+/* files: nfiles OBJ paths, each loaded through ObjLoader::loadObjFile (ObjLoader.h:393-495) as the reference's
+   Renderer does (Renderer.cpp:363-407); returns NULL on parse error (message via rtxh_last_error) */
+rtxh_scene* rtxh_scene_from_obj(const char* const* files, uint32_t nfiles, const char* mtl_dir);
+void        rtxh_scene_free(rtxh_scene*);
+const char* rtxh_last_error(void);
+
+uint32_t    rtxh_scene_num_materials(const rtxh_scene*);
+const void* rtxh_scene_materials(const rtxh_scene*);                       /* 128-byte Material records */
+uint32_t    rtxh_scene_num_meshes(const rtxh_scene*);
+int         rtxh_scene_mesh(const rtxh_scene*, uint32_t i, const void** verts28, uint32_t* nverts,
+                            const uint32_t** indices, uint32_t* nidx, const uint32_t** material_ids);
+uint32_t    rtxh_scene_num_instances(const rtxh_scene*);
+int         rtxh_scene_instance(const rtxh_scene*, uint32_t i, uint32_t* mesh, float o2w[16]);
+uint64_t    rtxh_scene_num_triangles(const rtxh_scene*);
+/* eye[3], center[3], up[3], fovY in degrees, znear, zfar (Renderer.cpp:46-48, 1730-1731) */
+int         rtxh_scene_camera(const rtxh_scene*, float eye[3], float center[3], float up[3], float* fovy_deg, float* zn, float* zf);
+/* view (Manipulator::setLookat -> getMatrix) and projection (XMMatrixPerspectiveFovRH) for an aspect ratio */
+int         rtxh_scene_view_proj(const rtxh_scene*, float aspect, float view[16], float proj[16]);
+/* rtx_set_materials / rtx_add_mesh / rtx_add_instance / rtx_commit_scene / rtx_set_camera */
+int         rtxh_scene_upload(const rtxh_scene*, rtx_ctx*, float aspect);
+
+/* leaf helpers of the host layer */
+void rtxh_lookat(const float eye[3], const float center[3], const float up[3], float view16[16]);      /* manipulator.cpp:305-314 */
+void rtxh_perspective_fov_rh(float fovy_rad, float aspect, float zn, float zf, float proj16[16]);      /* Renderer.cpp:1730-1731 */
+void rtxh_generate_ess_lut(float roughness, float lut16[16]);                                          /* ObjLoader.h:351-387 */
+void rtxh_mat4_inverse(const float m16[16], float out16[16]);
+float rtxh_half_round(float x);
+/* BVH builder invariants for tests: returns 0 when every triangle is in exactly one leaf and every child box
+   contains its subtree; fills nodes / depth / max leaf size */
+int  rtxh_bvh_check(const float* world_tris9, uint32_t ntris, uint32_t* nodes_out, uint32_t* depth_out, uint32_t* max_leaf_out);
+
+/* the headless Renderer facade (Renderer.h:46-51) for FFI callers */
+typedef struct rtxh_renderer rtxh_renderer;
+rtxh_renderer* rtxh_renderer_create(uint32_t width, uint32_t height, const char* name, int device);
+int  rtxh_renderer_set_scene(rtxh_renderer*, const rtxh_scene*);
+rtx_params* rtxh_renderer_params(rtxh_renderer*);
+int  rtxh_renderer_on_init(rtxh_renderer*);
+int  rtxh_renderer_on_update(rtxh_renderer*);
+int  rtxh_renderer_on_render(rtxh_renderer*);
+int  rtxh_renderer_read_accum(rtxh_renderer*, float* rgba32f, size_t bytes);
+int  rtxh_renderer_read_output(rtxh_renderer*, uint8_t* rgba8, size_t bytes);
+void rtxh_renderer_destroy(rtxh_renderer*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,897 @@
+/*
+ * rt_oracle.c — CPU ORACLE (test infrastructure, NOT product code; see rt_oracle.h).
+ *
+ * PARITY UNPINNED for the shader math: the reference has no golden vectors and
+ * cannot be built here.  This file restates, in scalar C with a fixed IEEE-754
+ * binary32 operation order (compile with -ffp-contract=off, no fast-math):
+ *
+ *   leaf math      = the live v6 shader set  (Pathtracer/include/ *_v6.hlsl under /root/reference)
+ *   loop structure = the legacy bounce loop  (include/RayGen.hlsl:99-133, include/Hit.hlsl:126-174,340-369)
+ *
+ * as SURVEY.md §8(a) prescribes.  Every function cites the reference lines it
+ * follows; deliberate deviations are tagged DEVIATION and listed in DESIGN.md.
+ *
+ * Transcendentals (sin/cos/pow) are implemented here with +,-,*,/ only so that
+ * the HIP path can execute the identical operation sequence (the HLSL intrinsics
+ * are implementation-defined to a few ULP anyway).
+ */
+#include "rt_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- constants: Common_v6.hlsl:1-3 ---- */
+#define PI_REF   3.1415f          /* Common_v6.hlsl:1 (sic) */
+#define S_BIAS   0.00002f         /* Common_v6.hlsl:2 */
+#define EPSILON_ 0.000001f        /* Common_v6.hlsl:3 */
+#define TWO_PI_F 6.28318548202514648f /* float(2.0 * 3.14159265358979323846): Lambertian_v6.hlsl:10 */
+#define MISS_PRIM 0xFFFFFFFFu
+
+typedef struct { float x, y, z; } v3;
+
+static inline v3 V3(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 add3(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 sub3(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 mul3(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 scale3(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+static inline v3 neg3(v3 a) { return V3(-a.x, -a.y, -a.z); }
+static inline float dot3(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline v3 cross3(v3 a, v3 b) {
+    return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline float length3(v3 a) { return sqrtf(dot3(a, a)); }
+/* HLSL normalize(v) = v * rsqrt(dot(v,v)); restated with IEEE sqrt and divide */
+static inline v3 normalize3(v3 a) { float inv = 1.0f / sqrtf(dot3(a, a)); return scale3(a, inv); }
+static inline float saturatef(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
+static inline float maxf(float a, float b) { return a > b ? a : b; }
+static inline float minf(float a, float b) { return a < b ? a : b; }
+static inline int is_nan(float x) { return x != x; }
+static inline int is_inf(float x) { return fabsf(x) == INFINITY; }
+static inline int finite3(v3 a) { return !(is_nan(a.x) || is_nan(a.y) || is_nan(a.z) || is_inf(a.x) || is_inf(a.y) || is_inf(a.z)); }
+
+/* Common_v6.hlsl:151-160 */
+static inline v3 safe_mul3(float s, v3 v) { v3 r = scale3(v, s); return finite3(r) ? r : V3(0, 0, 0); }
+static inline float safe_mul1(float s, float v) { float r = s * v; return (is_nan(r) || is_inf(r)) ? 0.0f : r; }
+
+/* ---- TEA-4 RNG: Common_v6.hlsl:119-138 ---- */
+static inline float rnd(uint32_t seed[2]) {
+    uint32_t v0 = seed[0], v1 = seed[1], sum = 0u;
+    for (int i = 0; i < 4; i++) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xA341316Cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xC8013EA4u);
+        v1 += ((v0 << 4) + 0xAD90777Du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7E95761Eu);
+    }
+    seed[0] = v0; seed[1] = v1;
+    return (float)v0 * (1.0f / 4294967296.0f);   /* float(v0)/2^32; may return exactly 1.0f */
+}
+void orc_tea(uint32_t seed[2], uint32_t n, float* out) { for (uint32_t i = 0; i < n; i++) out[i] = rnd(seed); }
+
+/* RayGen_v6_pass1.hlsl:63-77 (s = sample id; uint(time) := frame_seed) */
+void orc_seed_init(uint32_t x, uint32_t y, uint32_t s, uint32_t frame_seed, uint32_t out[2]) {
+    out[0] = (y * 73856093u) ^ (x * 19349663u) ^ (s * 83492791u) ^ (frame_seed * 293803u);
+    out[1] = (x * 37623481u) ^ (y * 51964263u) ^ (s * 68250729u) ^ (frame_seed * 423977u);
+}
+
+/* ---- own transcendentals (replace HLSL sin/cos/pow; see file header) ---- */
+/* sin & cos for x in [0, 8): Cody-Waite reduction by pi/4 octants + degree-7/8 minimax polynomials */
+void orc_sincos(float x, float* sn, float* cs) {
+    int j = (int)(x * 1.27323954473516f);       /* x * 4/pi, truncation (x >= 0) */
+    j = (j + 1) & ~1;                           /* round up to even octant */
+    float y = (float)j;
+    float r = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    float z = r * r;
+    float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+    switch ((j >> 1) & 3) {
+    case 0: *sn = ps;  *cs = pc;  break;
+    case 1: *sn = pc;  *cs = -ps; break;
+    case 2: *sn = -ps; *cs = -pc; break;
+    default: *sn = -pc; *cs = ps; break;
+    }
+}
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+/* pow(x,y) for x > 0 via exp2(y*log2(x)); ~1e-6 relative; only used for the sRGB OETF (Common_v6.hlsl:353-376) */
+float orc_pow(float x, float y) {
+    if (!(x > 0.0f)) return 0.0f;
+    uint32_t ux = f2u(x);
+    int e = (int)((ux >> 23) & 0xFF) - 127;
+    float m = u2f((ux & 0x007FFFFFu) | 0x3F800000u);         /* [1,2) */
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }           /* [0.707,1.414) */
+    float t = (m - 1.0f) / (m + 1.0f);
+    float t2 = t * t;
+    float ln = 2.0f * t * (1.0f + t2 * (0.333333333f + t2 * (0.2f + t2 * (0.142857143f + t2 * 0.111111111f))));
+    float l2 = (float)e + ln * 1.44269504089f;
+    float p = y * l2;
+    if (p < -126.0f) return 0.0f;
+    if (p > 127.0f) return INFINITY;
+    float fl = floorf(p + 0.5f);
+    float f = p - fl;                                        /* [-0.5,0.5] */
+    float g = f * 0.693147180560f;
+    float ex = 1.0f + g * (1.0f + g * (0.5f + g * (0.166666667f + g * (0.0416666667f + g * (0.00833333333f + g * 0.00138888889f)))));
+    return ex * u2f((uint32_t)((int)fl + 127) << 23);
+}
+/* float -> binary16 (round to nearest even) -> float: half4(mat.Kd) etc., Sampler_v6.hlsl:71-83 */
+float orc_half_round(float x) {
+    uint32_t u = f2u(x), sign = u & 0x80000000u, a = u & 0x7FFFFFFFu;
+    if (a >= 0x7F800000u) return x;                            /* inf / nan */
+    if (a >= 0x477FF000u) return u2f(sign | 0x7F800000u);      /* >= 65520 -> inf */
+    if (a < 0x33000001u) return u2f(sign);                     /* <= 2^-25 -> 0 */
+    if (a < 0x38800000u) {                                     /* subnormal half: quantum 2^-24 */
+        float q = u2f(a) * 16777216.0f;                        /* exact scaling */
+        float r = nearbyintf(q);                               /* default rounding mode: RNE */
+        return u2f(sign | f2u(r * (1.0f / 16777216.0f)));
+    }
+    uint32_t rem = a & 0x1FFFu, base = a & ~0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (base & 0x2000u))) base += 0x2000u;
+    return u2f(sign | base);
+}
+
+/* ---- matrices: column-major storage of column-vector matrices ---- */
+/* general 4x4 inverse by cofactors, evaluated in double then rounded (stands in for XMMatrixInverse,
+   Renderer.cpp:1735-1736, 2101-2118) */
+void orc_mat4_inverse(const float* mf, float* out) {
+    double m[16], inv[16];
+    for (int i = 0; i < 16; i++) m[i] = (double)mf[i];
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    double id = 1.0 / det;
+    for (int i = 0; i < 16; i++) out[i] = (float)(inv[i] * id);
+}
+/* mul(M, float4(p,1)).xyz */
+static inline v3 xform_point(const float* m, v3 p) {
+    return V3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
+              m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+              m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
+}
+/* mul(M, float4(v,0)).xyz */
+static inline v3 xform_dir(const float* m, v3 p) {
+    return V3(m[0] * p.x + m[4] * p.y + m[8] * p.z,
+              m[1] * p.x + m[5] * p.y + m[9] * p.z,
+              m[2] * p.x + m[6] * p.y + m[10] * p.z);
+}
+
+/* ---- scene ---- */
+typedef struct {            /* fp16-rounded working copy: MaterialOptimized, Common_v6.hlsl:62-74 */
+    v3 Kd; float alpha;
+    float Pr, Pm, Ps, Pc;
+    v3 Ks; v3 Ke;
+    float Ke_len;           /* length(Ke) of the rounded copy */
+} matopt_t;
+
+typedef struct { float* verts; uint32_t nverts; uint32_t* idx; uint32_t nidx; uint32_t matid_base; } mesh_t;
+typedef struct { uint32_t mesh; float o2w[16]; float nrm[16]; uint32_t tri_base; } inst_t;
+typedef struct { float bmin[3], bmax[3]; uint32_t left, right, first, count; } node_t;   /* count>0 => leaf */
+
+struct orc_ctx {
+    float* mats; matopt_t* mopt; uint32_t nmat;
+    mesh_t* meshes; uint32_t nmesh;
+    uint32_t* matids; uint32_t nmatids;
+    inst_t* insts; uint32_t ninst;
+    /* flattened world-space triangles */
+    uint32_t ntri; float* wtri; uint32_t* tri_inst; uint32_t* tri_prim;
+    /* lights (80-byte records as 20 floats) */
+    float* lights; uint32_t nlights; float total_weight;
+    /* bvh */
+    node_t* nodes; uint32_t nnodes; uint32_t* order;
+    float view[16], proj[16], viewI[16], projI[16];
+    int nthreads;
+};
+
+orc_ctx* orc_create(void) { return (orc_ctx*)calloc(1, sizeof(orc_ctx)); }
+void orc_destroy(orc_ctx* c) {
+    if (!c) return;
+    free(c->mats); free(c->mopt);
+    for (uint32_t i = 0; i < c->nmesh; i++) { free(c->meshes[i].verts); free(c->meshes[i].idx); }
+    free(c->meshes); free(c->matids); free(c->insts);
+    free(c->wtri); free(c->tri_inst); free(c->tri_prim); free(c->lights); free(c->nodes); free(c->order);
+    free(c);
+}
+int orc_set_threads(orc_ctx* c, int n) { c->nthreads = n; return 0; }
+
+int orc_set_materials(orc_ctx* c, const void* mats128, uint32_t count) {
+    free(c->mats); free(c->mopt);
+    c->mats = (float*)malloc((size_t)count * 128);
+    c->mopt = (matopt_t*)malloc((size_t)count * sizeof(matopt_t));
+    memcpy(c->mats, mats128, (size_t)count * 128);
+    c->nmat = count;
+    for (uint32_t i = 0; i < count; i++) {
+        const float* m = c->mats + i * 32;  /* Kd[4] Ks[3] Ni Ke[3] pad Pr_Pm_Ps_Pc[4] LUT[16]: Vertex.h:14-23 */
+        matopt_t* o = &c->mopt[i];
+        o->Kd = V3(orc_half_round(m[0]), orc_half_round(m[1]), orc_half_round(m[2])); o->alpha = orc_half_round(m[3]);
+        o->Ks = V3(orc_half_round(m[4]), orc_half_round(m[5]), orc_half_round(m[6]));
+        o->Ke = V3(orc_half_round(m[8]), orc_half_round(m[9]), orc_half_round(m[10]));
+        o->Pr = orc_half_round(m[12]); o->Pm = orc_half_round(m[13]); o->Ps = orc_half_round(m[14]); o->Pc = orc_half_round(m[15]);
+        o->Ke_len = length3(o->Ke);
+    }
+    return 0;
+}
+
+int orc_add_mesh(orc_ctx* c, const void* verts28, uint32_t nverts, const uint32_t* indices, uint32_t nidx,
+                 const uint32_t* material_ids, uint32_t* mesh_out) {
+    if (nidx % 3) return -1;
+    const float* v = (const float*)verts28;
+    for (uint32_t i = 0; i < nidx; i++) if (indices[i] >= nverts) return -2;
+    /* Vertex.normal.w is the base of this model inside the global materialIDs[] (ObjLoader.h:466, Hit_v6.hlsl:17) */
+    for (uint32_t i = 0; i < nverts; i++) if ((uint32_t)v[i * 7 + 6] != c->nmatids) return -3;
+    c->meshes = (mesh_t*)realloc(c->meshes, (c->nmesh + 1) * sizeof(mesh_t));
+    mesh_t* m = &c->meshes[c->nmesh];
+    m->verts = (float*)malloc((size_t)nverts * 28); memcpy(m->verts, v, (size_t)nverts * 28);
+    m->idx = (uint32_t*)malloc((size_t)nidx * 4); memcpy(m->idx, indices, (size_t)nidx * 4);
+    m->nverts = nverts; m->nidx = nidx; m->matid_base = c->nmatids;
+    c->matids = (uint32_t*)realloc(c->matids, (size_t)(c->nmatids + nidx) * 4);
+    memcpy(c->matids + c->nmatids, material_ids, (size_t)nidx * 4);
+    c->nmatids += nidx;
+    if (mesh_out) *mesh_out = c->nmesh;
+    c->nmesh++;
+    return 0;
+}
+
+/* Renderer.cpp:2091-2121: normal matrix = transpose(inverse(upper 3x3, rest identity)) */
+static void normal_matrix(const float* o2w, float* out) {
+    float u[16], inv[16];
+    memcpy(u, o2w, 64);
+    u[3] = u[7] = u[11] = 0.0f; u[12] = u[13] = u[14] = 0.0f; u[15] = 1.0f;
+    orc_mat4_inverse(u, inv);
+    for (int r = 0; r < 4; r++) for (int cc = 0; cc < 4; cc++) out[cc * 4 + r] = inv[r * 4 + cc];
+}
+
+int orc_add_instance(orc_ctx* c, uint32_t mesh, const float* o2w16, uint32_t* inst_out) {
+    if (mesh >= c->nmesh) return -1;
+    c->insts = (inst_t*)realloc(c->insts, (c->ninst + 1) * sizeof(inst_t));
+    inst_t* in = &c->insts[c->ninst];
+    in->mesh = mesh; memcpy(in->o2w, o2w16, 64); normal_matrix(o2w16, in->nrm); in->tri_base = 0;
+    if (inst_out) *inst_out = c->ninst;
+    c->ninst++;
+    return 0;
+}
+
+static inline v3 mesh_pos(const mesh_t* m, uint32_t vi) { const float* p = m->verts + (size_t)vi * 7; return V3(p[0], p[1], p[2]); }
+static inline v3 mesh_nrm(const mesh_t* m, uint32_t vi) { const float* p = m->verts + (size_t)vi * 7; return V3(p[3], p[4], p[5]); }
+
+/* ---- light list: Renderer.cpp:2123-2233, 2237-2243 ---- */
+typedef struct { float w; uint32_t order; float rec[20]; } lt_tmp;
+static int lt_cmp(const void* a, const void* b) {
+    const lt_tmp* x = (const lt_tmp*)a; const lt_tmp* y = (const lt_tmp*)b;
+    if (x->w > y->w) return -1;
+    if (x->w < y->w) return 1;
+    return (x->order > y->order) - (x->order < y->order);   /* DEVIATION: std::sort is unstable; ties broken by collection order */
+}
+static void build_lights(orc_ctx* c) {
+    free(c->lights); c->lights = NULL; c->nlights = 0; c->total_weight = 0.0f;
+    uint32_t cap = 0, n = 0; lt_tmp* tmp = NULL;
+    for (uint32_t ii = 0; ii < c->ninst; ii++) {
+        const mesh_t* m = &c->meshes[c->insts[ii].mesh];
+        for (uint32_t t = 0; t < m->nidx / 3; t++) {
+            uint32_t m0 = c->matids[m->matid_base + t * 3], m1 = c->matids[m->matid_base + t * 3 + 1], m2 = c->matids[m->matid_base + t * 3 + 2];
+            if (m0 != m1 || m0 != m2) continue;                     /* Renderer.cpp:2153-2156 */
+            if (m0 >= c->nmat) continue;
+            const float* mat = c->mats + (size_t)m0 * 32;
+            if (!(mat[8] + mat[9] + mat[10] > 0.0f)) continue;      /* :2162 */
+            v3 p0 = mesh_pos(m, m->idx[t * 3]), p1 = mesh_pos(m, m->idx[t * 3 + 1]), p2 = mesh_pos(m, m->idx[t * 3 + 2]);
+            /* ComputeTriangleWeight :2217-2233 */
+            float area = 0.5f * length3(cross3(sub3(p1, p0), sub3(p2, p0)));
+            float inten = (mat[8] + mat[9] + mat[10]) / 3.0f;
+            if (n == cap) { cap = cap ? cap * 2 : 64; tmp = (lt_tmp*)realloc(tmp, cap * sizeof(lt_tmp)); }
+            lt_tmp* L = &tmp[n];
+            memset(L, 0, sizeof(*L));
+            L->w = area * inten; L->order = n;
+            L->rec[0] = p0.x; L->rec[1] = p0.y; L->rec[2] = p0.z;
+            L->rec[4] = p1.x; L->rec[5] = p1.y; L->rec[6] = p1.z; memcpy(&L->rec[7], &ii, 4);
+            L->rec[8] = p2.x; L->rec[9] = p2.y; L->rec[10] = p2.z; L->rec[11] = L->w;
+            L->rec[12] = mat[8]; L->rec[13] = mat[9]; L->rec[14] = mat[10];
+            n++;
+        }
+    }
+    if (!n) { free(tmp); return; }
+    qsort(tmp, n, sizeof(lt_tmp), lt_cmp);
+    float total = 0.0f;
+    for (uint32_t i = 0; i < n; i++) total += tmp[i].rec[11];
+    float cum = 0.0f;
+    c->lights = (float*)malloc((size_t)n * 80);
+    for (uint32_t i = 0; i < n; i++) {
+        float* r = tmp[i].rec;
+        r[11] = r[11] / total; cum += r[11]; r[3] = cum; r[16] = total;
+        memcpy(&r[15], &n, 4);                                         /* triCount :2240-2243 */
+        memcpy(c->lights + (size_t)i * 20, r, 80);
+    }
+    c->lights[(size_t)(n - 1) * 20 + 3] = 1.0f;                        /* :2208-2210 */
+    c->nlights = n; c->total_weight = total;
+    free(tmp);
+}
+
+/* ---- the oracle's own BVH (median split); purely an accelerator, results must equal brute force ---- */
+static void tri_bounds(const float* t, float* mn, float* mx) {
+    for (int a = 0; a < 3; a++) {
+        mn[a] = minf(t[a], minf(t[3 + a], t[6 + a]));
+        mx[a] = maxf(t[a], maxf(t[3 + a], t[6 + a]));
+    }
+}
+typedef struct { const orc_ctx* c; int axis; } sortctx;
+static const float* g_sort_wtri; static int g_sort_axis;
+static int cen_cmp(const void* a, const void* b) {
+    uint32_t i = *(const uint32_t*)a, j = *(const uint32_t*)b;
+    const float* ti = g_sort_wtri + (size_t)i * 9; const float* tj = g_sort_wtri + (size_t)j * 9;
+    float ci = ti[g_sort_axis] + ti[3 + g_sort_axis] + ti[6 + g_sort_axis];
+    float cj = tj[g_sort_axis] + tj[3 + g_sort_axis] + tj[6 + g_sort_axis];
+    if (ci < cj) return -1;
+    if (ci > cj) return 1;
+    return (i > j) - (i < j);
+}
+static uint32_t build_node(orc_ctx* c, uint32_t first, uint32_t count, float pad) {
+    uint32_t id = c->nnodes++;
+    node_t* nd = &c->nodes[id];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = 0; i < count; i++) {
+        float a[3], b[3]; tri_bounds(c->wtri + (size_t)c->order[first + i] * 9, a, b);
+        for (int k = 0; k < 3; k++) { mn[k] = minf(mn[k], a[k]); mx[k] = maxf(mx[k], b[k]); }
+    }
+    for (int k = 0; k < 3; k++) { nd->bmin[k] = mn[k] - pad; nd->bmax[k] = mx[k] + pad; }
+    if (count <= 4) { nd->first = first; nd->count = count; nd->left = nd->right = 0; return id; }
+    int axis = 0; float ext = mx[0] - mn[0];
+    if (mx[1] - mn[1] > ext) { axis = 1; ext = mx[1] - mn[1]; }
+    if (mx[2] - mn[2] > ext) axis = 2;
+    g_sort_wtri = c->wtri; g_sort_axis = axis;
+    qsort(c->order + first, count, 4, cen_cmp);
+    uint32_t half = count / 2;
+    nd->count = 0; nd->first = 0;
+    uint32_t l = build_node(c, first, half, pad);
+    uint32_t r = build_node(c, first + half, count - half, pad);
+    c->nodes[id].left = l; c->nodes[id].right = r;
+    return id;
+}
+
+int orc_commit(orc_ctx* c) {
+    uint32_t nt = 0;
+    for (uint32_t i = 0; i < c->ninst; i++) { c->insts[i].tri_base = nt; nt += c->meshes[c->insts[i].mesh].nidx / 3; }
+    free(c->wtri); free(c->tri_inst); free(c->tri_prim); free(c->nodes); free(c->order);
+    c->ntri = nt;
+    c->wtri = (float*)malloc((size_t)(nt ? nt : 1) * 36);
+    c->tri_inst = (uint32_t*)malloc((size_t)(nt ? nt : 1) * 4);
+    c->tri_prim = (uint32_t*)malloc((size_t)(nt ? nt : 1) * 4);
+    float scale = 1.0f;
+    for (uint32_t i = 0; i < c->ninst; i++) {
+        const inst_t* in = &c->insts[i]; const mesh_t* m = &c->meshes[in->mesh];
+        for (uint32_t t = 0; t < m->nidx / 3; t++) {
+            uint32_t g = in->tri_base + t;
+            for (int k = 0; k < 3; k++) {
+                v3 w = xform_point(in->o2w, mesh_pos(m, m->idx[t * 3 + k]));
+                c->wtri[(size_t)g * 9 + k * 3] = w.x; c->wtri[(size_t)g * 9 + k * 3 + 1] = w.y; c->wtri[(size_t)g * 9 + k * 3 + 2] = w.z;
+                scale = maxf(scale, maxf(fabsf(w.x), maxf(fabsf(w.y), fabsf(w.z))));
+            }
+            c->tri_inst[g] = i; c->tri_prim[g] = t;
+        }
+    }
+    build_lights(c);
+    c->order = (uint32_t*)malloc((size_t)(nt ? nt : 1) * 4);
+    for (uint32_t i = 0; i < nt; i++) c->order[i] = i;
+    c->nodes = (node_t*)malloc((size_t)(2 * (nt ? nt : 1)) * sizeof(node_t));
+    c->nnodes = 0;
+    if (nt) build_node(c, 0, nt, 1e-6f * scale);
+    return 0;
+}
+
+int orc_set_camera(orc_ctx* c, const float* view16, const float* proj16) {
+    memcpy(c->view, view16, 64); memcpy(c->proj, proj16, 64);
+    orc_mat4_inverse(view16, c->viewI); orc_mat4_inverse(proj16, c->projI);   /* Renderer.cpp:1735-1736 */
+    return 0;
+}
+uint32_t orc_num_triangles(orc_ctx* c) { return c->ntri; }
+uint32_t orc_num_lights(orc_ctx* c) { return c->nlights; }
+int orc_get_lights(orc_ctx* c, void* out80, uint32_t max_count) {
+    uint32_t n = c->nlights < max_count ? c->nlights : max_count;
+    memcpy(out80, c->lights, (size_t)n * 80);
+    return (int)n;
+}
+
+/* ---- ray / triangle (a11: TraceRay closest hit; DXR range is exclusive TMin < t < TMax) ---- */
+typedef struct { float t, u, v; uint32_t prim; } hit_t;
+
+/* Moeller-Trumbore, no culling (geometry opaque, RAY_FLAG_NONE).  The BVH format and the intersection
+   arithmetic of DXR are driver-opaque; this fixed operation order IS the definition both backends share. */
+static inline int tri_hit(v3 o, v3 d, const float* t9, float tmin, float tmax, float* to, float* uo, float* vo) {
+    v3 v0 = V3(t9[0], t9[1], t9[2]);
+    v3 e1 = sub3(V3(t9[3], t9[4], t9[5]), v0), e2 = sub3(V3(t9[6], t9[7], t9[8]), v0);
+    v3 p = cross3(d, e2);
+    float det = dot3(e1, p);
+    if (det == 0.0f) return 0;
+    float inv = 1.0f / det;
+    v3 s = sub3(o, v0);
+    float u = dot3(s, p) * inv;
+    if (!(u >= 0.0f && u <= 1.0f)) return 0;
+    v3 q = cross3(s, e1);
+    float v = dot3(d, q) * inv;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return 0;
+    float t = dot3(e2, q) * inv;
+    if (!(t > tmin && t < tmax)) return 0;
+    *to = t; *uo = u; *vo = v;
+    return 1;
+}
+/* closest = min t, ties -> lowest global triangle id: order-independent */
+static inline void closest_update(hit_t* h, float t, float u, float v, uint32_t prim) {
+    if (t < h->t || (t == h->t && prim < h->prim)) { h->t = t; h->u = u; h->v = v; h->prim = prim; }
+}
+static hit_t closest_brute(const orc_ctx* c, v3 o, v3 d, float tmin, float tmax) {
+    hit_t h = {tmax, 0, 0, MISS_PRIM};
+    for (uint32_t i = 0; i < c->ntri; i++) {
+        float t, u, v;
+        if (tri_hit(o, d, c->wtri + (size_t)i * 9, tmin, tmax, &t, &u, &v)) closest_update(&h, t, u, v, i);
+    }
+    return h;
+}
+/* conservative slab test: relative padding of the interval so that no accepted triangle hit is culled */
+static inline int box_hit(const node_t* n, v3 o, v3 d, v3 inv, float tmin, float tbest) {
+    float te = -INFINITY, tx = INFINITY;
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, ii[3] = {inv.x, inv.y, inv.z};
+    for (int a = 0; a < 3; a++) {
+        if (dd[a] == 0.0f) { if (oo[a] < n->bmin[a] || oo[a] > n->bmax[a]) return 0; continue; }
+        float t1 = (n->bmin[a] - oo[a]) * ii[a], t2 = (n->bmax[a] - oo[a]) * ii[a];
+        float lo = minf(t1, t2), hi = maxf(t1, t2);
+        te = maxf(te, lo); tx = minf(tx, hi);
+    }
+    te = te - fabsf(te) * 1e-6f; tx = tx + fabsf(tx) * 1e-6f;
+    return te <= tx && tx >= tmin && te <= tbest;
+}
+static hit_t closest_bvh(const orc_ctx* c, v3 o, v3 d, float tmin, float tmax) {
+    hit_t h = {tmax, 0, 0, MISS_PRIM};
+    if (!c->ntri) return h;
+    v3 inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint32_t stack[128]; int sp = 0; stack[sp++] = 0;
+    while (sp) {
+        const node_t* n = &c->nodes[stack[--sp]];
+        if (!box_hit(n, o, d, inv, tmin, h.t)) continue;
+        if (n->count) {
+            for (uint32_t i = 0; i < n->count; i++) {
+                uint32_t g = c->order[n->first + i]; float t, u, v;
+                if (tri_hit(o, d, c->wtri + (size_t)g * 9, tmin, tmax, &t, &u, &v)) closest_update(&h, t, u, v, g);
+            }
+        } else { stack[sp++] = n->left; stack[sp++] = n->right; }
+    }
+    return h;
+}
+static int any_brute(const orc_ctx* c, v3 o, v3 d, float tmin, float tmax) {
+    for (uint32_t i = 0; i < c->ntri; i++) { float t, u, v; if (tri_hit(o, d, c->wtri + (size_t)i * 9, tmin, tmax, &t, &u, &v)) return 1; }
+    return 0;
+}
+static int any_bvh(const orc_ctx* c, v3 o, v3 d, float tmin, float tmax) {
+    if (!c->ntri) return 0;
+    v3 inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint32_t stack[128]; int sp = 0; stack[sp++] = 0;
+    while (sp) {
+        const node_t* n = &c->nodes[stack[--sp]];
+        if (!box_hit(n, o, d, inv, tmin, tmax)) continue;
+        if (n->count) {
+            for (uint32_t i = 0; i < n->count; i++) {
+                float t, u, v;
+                if (tri_hit(o, d, c->wtri + (size_t)c->order[n->first + i] * 9, tmin, tmax, &t, &u, &v)) return 1;
+            }
+        } else { stack[sp++] = n->left; stack[sp++] = n->right; }
+    }
+    return 0;
+}
+
+int orc_trace_closest(orc_ctx* c, const float* r, uint32_t n, int mode, float* hits4) {
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < (int64_t)n; i++) {
+        const float* q = r + i * 8;
+        hit_t h = mode ? closest_bvh(c, V3(q[0], q[1], q[2]), V3(q[4], q[5], q[6]), q[3], q[7])
+                       : closest_brute(c, V3(q[0], q[1], q[2]), V3(q[4], q[5], q[6]), q[3], q[7]);
+        hits4[i * 4] = h.t; hits4[i * 4 + 1] = h.u; hits4[i * 4 + 2] = h.v; memcpy(&hits4[i * 4 + 3], &h.prim, 4);
+    }
+    return 0;
+}
+int orc_trace_any(orc_ctx* c, const float* r, uint32_t n, int mode, uint8_t* occ) {
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < (int64_t)n; i++) {
+        const float* q = r + i * 8;
+        occ[i] = (uint8_t)(mode ? any_bvh(c, V3(q[0], q[1], q[2]), V3(q[4], q[5], q[6]), q[3], q[7])
+                                : any_brute(c, V3(q[0], q[1], q[2]), V3(q[4], q[5], q[6]), q[3], q[7]));
+    }
+    return 0;
+}
+
+/* ---- ClosestHit: Hit_v6.hlsl:12-61 ---- */
+typedef struct { v3 pos; uint32_t mat; v3 normal; float area; uint32_t inst; v3 flat; } surf_t;
+static surf_t surface(const orc_ctx* c, v3 o, v3 d, hit_t h) {
+    surf_t s;
+    uint32_t ii = c->tri_inst[h.prim], prim = c->tri_prim[h.prim];
+    const inst_t* in = &c->insts[ii]; const mesh_t* m = &c->meshes[in->mesh];
+    s.inst = ii;
+    s.pos = V3(o.x + h.t * d.x, o.y + h.t * d.y, o.z + h.t * d.z);            /* :15,60 */
+    uint32_t vert = 3 * prim;
+    uint32_t i0 = m->idx[vert], i1 = m->idx[vert + 1], i2 = m->idx[vert + 2];
+    s.mat = c->matids[vert + (uint32_t)m->verts[(size_t)i0 * 7 + 6]];          /* :17 */
+    float bary[3] = {1.0f - h.u - h.v, h.u, h.v};                              /* :18 */
+    v3 p0 = mesh_pos(m, i0);
+    v3 e1 = sub3(mesh_pos(m, i1), p0), e2 = sub3(mesh_pos(m, i2), p0);         /* :28-29 */
+    v3 cr = cross3(e1, e2);
+    s.area = fabsf(length3(cr) * 0.5f);                                        /* :31 */
+    v3 flat = normalize3(cr);                                                  /* :32 */
+    s.flat = flat;
+    v3 smooth = V3(0, 0, 0);
+    const uint32_t vi[3] = {i0, i1, i2};
+    for (int k = 0; k < 3; k++) {                                              /* :40-46, all(n != 0) is per component */
+        v3 nk = mesh_nrm(m, vi[k]);
+        v3 use = (nk.x != 0.0f && nk.y != 0.0f && nk.z != 0.0f) ? nk : flat;
+        smooth = add3(smooth, scale3(use, bary[k]));
+    }
+    v3 n = (length3(smooth) > 0.0001f) ? normalize3(smooth) : flat;            /* :49-54 */
+    s.normal = normalize3(xform_dir(in->nrm, n));                              /* :56 */
+    return s;
+}
+int orc_surface(orc_ctx* c, const float* rays8, const float* hits4, uint32_t n, float* out16) {
+    for (uint32_t i = 0; i < n; i++) {
+        hit_t h; h.t = hits4[i * 4]; h.u = hits4[i * 4 + 1]; h.v = hits4[i * 4 + 2]; memcpy(&h.prim, &hits4[i * 4 + 3], 4);
+        float* o = out16 + (size_t)i * 16; memset(o, 0, 64);
+        if (h.prim == MISS_PRIM) { uint32_t m = 0xFFFFFFFEu; memcpy(&o[3], &m, 4); continue; }   /* Miss_v6.hlsl:3-7 */
+        const float* q = rays8 + (size_t)i * 8;
+        surf_t s = surface(c, V3(q[0], q[1], q[2]), V3(q[4], q[5], q[6]), h);
+        o[0] = s.pos.x; o[1] = s.pos.y; o[2] = s.pos.z; memcpy(&o[3], &s.mat, 4);
+        o[4] = s.normal.x; o[5] = s.normal.y; o[6] = s.normal.z; o[7] = s.area; memcpy(&o[8], &s.inst, 4);
+        o[9] = s.flat.x; o[10] = s.flat.y; o[11] = s.flat.z;
+    }
+    return 0;
+}
+
+/* ---- BSDF leaf math ---- */
+/* GGX_v6.hlsl:26-29; pow(abs(1-c),5) restated as repeated multiplication */
+static inline v3 schlick(v3 F0, float cosT) {
+    float x = fabsf(1.0f - cosT);
+    float x2 = x * x; float x5 = x2 * x2 * x;
+    return V3(saturatef(F0.x + (1.0f - F0.x) * x5), saturatef(F0.y + (1.0f - F0.y) * x5), saturatef(F0.z + (1.0f - F0.z) * x5));
+}
+/* GGX_v6.hlsl:31-40 */
+static inline float d_ggx(float NdotH, float rough) {
+    float alpha = rough * rough, alpha2 = alpha * alpha, nh2 = NdotH * NdotH;
+    float den = nh2 * (alpha2 - 1.0f) + 1.0f;
+    return alpha2 / (PI_REF * den * den);
+}
+/* GGX_v6.hlsl:43-52 */
+static inline float g2_smith(float NdotV, float NdotL, float alpha) {
+    float a2 = alpha * alpha;
+    float dA = NdotV * sqrtf(a2 + (1.0f - a2) * NdotL * NdotL);
+    float dB = NdotL * sqrtf(a2 + (1.0f - a2) * NdotV * NdotV);
+    return 2.0f * NdotL * NdotV / (dA + dB);
+}
+/* GGX_v6.hlsl:55-61 */
+static inline float g1_smith(float NdotV, float alpha) {
+    float a2 = alpha * alpha;
+    float dC = sqrtf(a2 + (1.0f - a2) * NdotV * NdotV) + NdotV;
+    return 2.0f * NdotV / dC;
+}
+/* GGX_v6.hlsl:1-23 (LUT from the full-precision Material record) */
+static inline float ess_lut(const float* mat, float NdotV) {
+    NdotV = saturatef(NdotV);
+    float f = NdotV * 15.0f;
+    int i0 = (int)floorf(f);
+    int i1 = i0 + 1 < 15 ? i0 + 1 : 15;
+    float w = f - (float)i0;
+    float v0 = mat[16 + i0], v1 = mat[16 + i1];
+    return v0 + w * (v1 - v0);                                   /* lerp */
+}
+/* Lambertian_v6.hlsl:54-58 */
+static inline v3 lambert_eval(const matopt_t* m) { return V3(m->Kd.x / PI_REF, m->Kd.y / PI_REF, m->Kd.z / PI_REF); }
+/* Lambertian_v6.hlsl:61-64: max(dot(n, -incoming), EPS)/PI, with L = -incoming */
+static inline float lambert_pdf(v3 n, v3 L) { return maxf(dot3(n, L), EPSILON_) / PI_REF; }
+/* GGX_v6.hlsl:174-206; V = outgoing, L = -incoming (dots NOT clamped) */
+static v3 ggx_eval(const matopt_t* m, const float* mat, v3 normal, v3 Lin, v3 Vin) {
+    v3 N = normalize3(normal), V = normalize3(Vin), L = normalize3(Lin);
+    v3 H = normalize3(add3(V, L));
+    float NdotV = dot3(N, V), NdotL = dot3(N, L), NdotH = dot3(N, H), VdotH = dot3(V, H);
+    v3 F = schlick(m->Ks, VdotH);
+    float D = d_ggx(NdotH, m->Pr);
+    float G = g2_smith(NdotV, NdotL, m->Pr * m->Pr);
+    float den = 4.0f * NdotV * NdotL;
+    if (den < EPSILON_) return V3(0, 0, 0);
+    v3 spec = V3(F.x * D * G / den, F.y * D * G / den, F.z * D * G / den);
+    float Ess = ess_lut(mat, NdotV);
+    float kms = (1.0f - Ess) / Ess;
+    v3 r = V3(spec.x * (1.0f + m->Ks.x * kms), spec.y * (1.0f + m->Ks.y * kms), spec.z * (1.0f + m->Ks.z * kms));
+    return finite3(r) ? r : V3(0, 0, 0);
+}
+/* GGX_v6.hlsl:209-224 */
+static float ggx_pdf(const matopt_t* m, v3 normal, v3 Lin, v3 Vin) {
+    v3 N = normalize3(normal), V = normalize3(Vin), L = normalize3(Lin);
+    v3 H = normalize3(add3(V, L));
+    float NdotH = dot3(N, H), NdotV = dot3(N, V);
+    float alpha = m->Pr * m->Pr;
+    return g1_smith(NdotV, alpha) * d_ggx(NdotH, m->Pr) / (NdotV * 4.0f);
+}
+/* BRDF_v6.hlsl:50-70 -> (p_d, p_s) */
+static inline void strategy_probs(const matopt_t* m, v3 outgoing, v3 normal, uint32_t flags, float* pd, float* ps) {
+    if (flags & ORC_FLAG_LAMBERT_ONLY) { *pd = 1.0f; *ps = 0.0f; return; }
+    v3 fr = schlick(m->Ks, dot3(normal, outgoing));
+    float p_s = minf(1.0f, (fr.x + fr.y + fr.z) / 3.0f + m->Pm);
+    *ps = p_s; *pd = 1.0f - p_s;
+}
+/* BRDF_v6.hlsl:7-48; LAMBERT_ONLY consumes no random number */
+static inline uint32_t select_strategy(const matopt_t* m, v3 outgoing, v3 normal, uint32_t flags, uint32_t seed[2]) {
+    if (flags & ORC_FLAG_LAMBERT_ONLY) return 0;
+    float r = rnd(seed);
+    v3 fr = schlick(m->Ks, dot3(normal, outgoing));
+    float p_s = minf(1.0f, (fr.x + fr.y + fr.z) / 3.0f + m->Pm);
+    if (r <= p_s) return m->Pr < 0.04f ? 0u : 1u;
+    return 0;
+}
+/* mixture F = p_d f_lambert + p_s f_ggx and P likewise: Sampler_v6.hlsl:443-457, Path_Sampler_v6.hlsl:66-80 */
+static inline void bsdf_mixture(const orc_ctx* c, uint32_t mid, uint32_t flags, v3 normal, v3 L, v3 outgoing, v3* F, float* P, float* pd_o, float* ps_o) {
+    const matopt_t* m = &c->mopt[mid];
+    float pd, ps; strategy_probs(m, outgoing, normal, flags, &pd, &ps);
+    v3 f0 = lambert_eval(m); float q0 = lambert_pdf(normal, L);
+    if (flags & ORC_FLAG_LAMBERT_ONLY) { *F = safe_mul3(pd, f0); *P = safe_mul1(pd, q0); }
+    else {
+        v3 f1 = ggx_eval(m, c->mats + (size_t)mid * 32, normal, L, outgoing);
+        float q1 = ggx_pdf(m, normal, L, outgoing);
+        *F = add3(safe_mul3(pd, f0), safe_mul3(ps, f1));
+        *P = safe_mul1(pd, q0) + safe_mul1(ps, q1);
+    }
+    if (pd_o) *pd_o = pd;
+    if (ps_o) *ps_o = ps;
+}
+/* Lambertian_v6.hlsl:2-38 */
+static v3 sample_lambert(v3 normal, uint32_t seed[2]) {
+    float u1 = rnd(seed), u2 = rnd(seed);
+    float r = sqrtf(u1);
+    float theta = TWO_PI_F * u2;
+    float sn, cs; orc_sincos(theta, &sn, &cs);
+    float x = r * cs, y = r * sn;
+    float z = sqrtf(maxf(0.0f, 1.0f - x * x - y * y));
+    v3 h = normal;
+    v3 up = fabsf(normal.z) < 0.999f ? V3(0, 0, 1) : V3(1, 0, 0);
+    v3 right = normalize3(cross3(up, h));
+    v3 fwd = cross3(h, right);
+    v3 s = V3(x * right.x + y * fwd.x + z * h.x, x * right.y + y * fwd.y + z * h.y, x * right.z + y * fwd.z + z * h.z);
+    s = normalize3(s);
+    if (dot3(s, normal) < 0.0f) s = neg3(s);
+    return s;
+}
+/* GGX_v6.hlsl:65-76 */
+static inline void coord_system(v3 N, v3* T, v3* B) {
+    if (fabsf(N.z) < 0.999f) *T = normalize3(cross3(V3(0, 0, 1), N));
+    else *T = normalize3(cross3(V3(1, 0, 0), N));
+    *B = cross3(N, *T);
+}
+/* GGX_v6.hlsl:93-169 */
+static v3 sample_ggx(const matopt_t* m, v3 outgoing, v3 normal, uint32_t seed[2]) {
+    float alpha = m->Pr * m->Pr;
+    v3 N = normalize3(normal), V = normalize3(outgoing), T1, T2;
+    coord_system(N, &T1, &T2);
+    float vx = dot3(T1, V), vy = dot3(T2, V), vz = dot3(N, V);
+    v3 Ve = normalize3(V3(alpha * vx, alpha * vy, vz));
+    float lensq = Ve.x * Ve.x + Ve.y * Ve.y;
+    v3 T1h;
+    if (lensq > 0.0f) { float rs = 1.0f / sqrtf(lensq); T1h = V3(-Ve.y * rs, Ve.x * rs, 0.0f * rs); }
+    else T1h = V3(1, 0, 0);
+    v3 T2h = cross3(Ve, T1h);
+    float U1 = rnd(seed), U2 = rnd(seed);
+    float r = sqrtf(U1);
+    float phi = 2.0f * PI_REF * U2;
+    float sn, cs; orc_sincos(phi, &sn, &cs);
+    float t1 = r * cs, t2 = r * sn;
+    float s = 0.5f * (1.0f + Ve.z);
+    t2 = (1.0f - s) * sqrtf(saturatef(1.0f - t1 * t1)) + s * t2;
+    float w = sqrtf(saturatef(1.0f - t1 * t1 - t2 * t2));
+    v3 Nh = V3(t1 * T1h.x + t2 * T2h.x + w * Ve.x, t1 * T1h.y + t2 * T2h.y + w * Ve.y, t1 * T1h.z + t2 * T2h.z + w * Ve.z);
+    v3 Ne = normalize3(V3(alpha * Nh.x, alpha * Nh.y, maxf(0.0f, Nh.z)));
+    v3 H = V3(Ne.x * T1.x + Ne.y * T2.x + Ne.z * N.x, Ne.x * T1.y + Ne.y * T2.y + Ne.z * N.y, Ne.x * T1.z + Ne.y * T2.z + Ne.z * N.z);
+    v3 I = neg3(V);                                   /* reflect(-V, H) = I - 2 dot(H,I) H */
+    float k = 2.0f * dot3(H, I);
+    v3 smp = V3(I.x - k * H.x, I.y - k * H.y, I.z - k * H.z);
+    if (dot3(smp, normal) < 0.0f) smp = neg3(smp);    /* :164-165 flipped, not rejected */
+    return smp;
+}
+static inline v3 sample_bsdf(const orc_ctx* c, uint32_t mid, uint32_t strategy, v3 outgoing, v3 normal, uint32_t seed[2]) {
+    return strategy == 1 ? sample_ggx(&c->mopt[mid], outgoing, normal, seed) : sample_lambert(normal, seed);   /* BRDF_v6.hlsl:74-88 */
+}
+
+int orc_bsdf_eval(orc_ctx* c, uint32_t mid, uint32_t flags, const float* in9, uint32_t n, float* out8) {
+    if (mid >= c->nmat) return -1;
+    for (uint32_t i = 0; i < n; i++) {
+        const float* q = in9 + (size_t)i * 9; float* o = out8 + (size_t)i * 8;
+        v3 F; float P, pd, ps;
+        bsdf_mixture(c, mid, flags, V3(q[0], q[1], q[2]), V3(q[6], q[7], q[8]), V3(q[3], q[4], q[5]), &F, &P, &pd, &ps);
+        o[0] = F.x; o[1] = F.y; o[2] = F.z; o[3] = P; o[4] = pd; o[5] = ps; o[6] = o[7] = 0.0f;
+    }
+    return 0;
+}
+int orc_bsdf_sample(orc_ctx* c, uint32_t mid, uint32_t flags, const float* in8, uint32_t n, float* out8) {
+    if (mid >= c->nmat) return -1;
+    for (uint32_t i = 0; i < n; i++) {
+        const float* q = in8 + (size_t)i * 8; float* o = out8 + (size_t)i * 8;
+        uint32_t seed[2]; memcpy(seed, &q[6], 8);
+        v3 nrm = V3(q[0], q[1], q[2]), wo = V3(q[3], q[4], q[5]);
+        uint32_t st = select_strategy(&c->mopt[mid], wo, nrm, flags, seed);
+        v3 wi = sample_bsdf(c, mid, st, wo, nrm, seed);
+        o[0] = wi.x; o[1] = wi.y; o[2] = wi.z; memcpy(&o[3], &st, 4); memcpy(&o[4], seed, 8); o[6] = o[7] = 0.0f;
+    }
+    return 0;
+}
+
+/* ---- primary rays: RayGen_v6_pass1.hlsl:51-95 ---- */
+static inline void primary_ray(const orc_ctx* c, uint32_t W, uint32_t H, uint32_t x, uint32_t y, float jx, float jy, v3* o, v3* d) {
+    float dx = (((float)x + jx) / (float)W) * 2.0f - 1.0f;
+    float dy = (((float)y + jy) / (float)H) * 2.0f - 1.0f;
+    const float* P = c->projI; const float* Vi = c->viewI;
+    float ndy = -dy;
+    v3 tg = V3(P[0] * dx + P[4] * ndy + P[8] + P[12], P[1] * dx + P[5] * ndy + P[9] + P[13], P[2] * dx + P[6] * ndy + P[10] + P[14]);
+    *d = normalize3(xform_dir(Vi, tg));
+    *o = V3(Vi[12], Vi[13], Vi[14]);
+}
+static inline int owns_pixel(const orc_params* p, uint32_t x, uint32_t y) {
+    if (p->shard_count <= 1) return 1;
+    uint32_t ts = p->tile_size ? p->tile_size : 64;
+    uint32_t tiles_x = (p->width + ts - 1) / ts;
+    uint32_t t = (y / ts) * tiles_x + (x / ts);
+    return (t % p->shard_count) == p->shard_rank;
+}
+int orc_primary_rays(orc_ctx* c, const orc_params* p, uint32_t s, float* rays8) {
+    for (uint32_t y = 0; y < p->height; y++) for (uint32_t x = 0; x < p->width; x++) {
+        uint32_t seed[2]; orc_seed_init(x, y, s, p->frame_seed, seed);
+        float jx = 0.0f, jy = 0.0f;
+        if (p->flags & ORC_FLAG_JITTER) { jx = rnd(seed); jy = rnd(seed); }
+        v3 o, d; primary_ray(c, p->width, p->height, x, y, jx, jy, &o, &d);
+        float* r = rays8 + ((size_t)y * p->width + x) * 8;
+        r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = 0.0001f; r[4] = d.x; r[5] = d.y; r[6] = d.z; r[7] = 10000.0f;
+    }
+    return 0;
+}
+
+/* ---- one path sample: loop of RayGen.hlsl:99-133 with the v6 leaf math ---- */
+static v3 trace_path(const orc_ctx* c, const orc_params* p, uint32_t x, uint32_t y, uint32_t s, uint64_t cnt[3]) {
+    uint32_t seed[2]; orc_seed_init(x, y, s, p->frame_seed, seed);
+    const uint32_t flags = p->flags, nee = c->nlights ? p->nee_samples : 0;
+    float jx = 0.0f, jy = 0.0f;
+    if (flags & ORC_FLAG_JITTER) { jx = rnd(seed); jy = rnd(seed); }          /* RayGen.hlsl:84-85 */
+    v3 origin, dir; primary_ray(c, p->width, p->height, x, y, jx, jy, &origin, &dir);
+    float tmin = 0.0001f;                                                      /* pass1:95 */
+    v3 thr = V3(1, 1, 1), rad = V3(0, 0, 0);
+    float prev_pdf = 1.0f;
+    for (uint32_t b = 0; b < p->max_bounces; b++) {
+        hit_t h = closest_bvh(c, origin, dir, tmin, 10000.0f);
+        cnt[b == 0 ? 0 : 1]++;
+        if (h.prim == MISS_PRIM) break;                                        /* Miss.hlsl:3-11: black, terminate */
+        surf_t sf = surface(c, origin, dir, h);
+        if (sf.mat >= c->nmat) break;
+        const matopt_t* m = &c->mopt[sf.mat];
+        if (m->Ke_len > 0.0f) {                                                /* Hit.hlsl:126, Sampler_v6.hlsl:457 */
+            if (b == 0) rad = add3(rad, m->Ke);                                /* Hit.hlsl:128-131 */
+            else {
+                float mi = 1.0f;
+                if (nee) {                                                     /* Sampler_v6.hlsl:459-465, Path_Sampler_v6.hlsl:241 */
+                    v3 Lv = sub3(sf.pos, origin);
+                    float dist = length3(Lv), dist2 = dist * dist;
+                    float cos_t = fabsf(dot3(sf.normal, neg3(dir)));           /* DEVIATION: abs (two-sided lights, as NEE does) */
+                    float pdf_light = (((m->Ke.x + m->Ke.y + m->Ke.z) / 3.0f) / c->total_weight) * dist2 / maxf(cos_t, EPSILON_);
+                    mi = prev_pdf / ((float)nee * pdf_light + prev_pdf);
+                }
+                v3 e = V3(m->Ke.x * thr.x * mi, m->Ke.y * thr.y * mi, m->Ke.z * thr.z * mi);   /* Hit.hlsl:173 */
+                if (finite3(e)) rad = add3(rad, e);
+            }
+            break;
+        }
+        v3 outgoing = neg3(dir);
+        v3 normal = sf.normal;
+        /* ---- NEE: SampleLightNEE_GI, Sampler_v6.hlsl:508-647, with its visibility ray enabled ---- */
+        for (uint32_t j = 0; j < nee; j++) {
+            float rv = rnd(seed);
+            int left = 0, right = (int)c->nlights - 1, sel = 0;
+            while (left <= right) {                                            /* :523-537 */
+                int mid = left + (right - left) / 2;
+                if (rv < c->lights[(size_t)mid * 20 + 3]) { sel = mid; right = mid - 1; } else left = mid + 1;
+            }
+            const float* lt = c->lights + (size_t)sel * 20;
+            uint32_t li; memcpy(&li, &lt[7], 4);
+            const float* M = c->insts[li].o2w;
+            v3 xv = xform_point(M, V3(lt[0], lt[1], lt[2])), yv = xform_point(M, V3(lt[4], lt[5], lt[6])), zv = xform_point(M, V3(lt[8], lt[9], lt[10]));
+            float xi1 = rnd(seed), xi2 = rnd(seed);
+            if (xi1 + xi2 > 1.0f) { xi1 = 1.0f - xi1; xi2 = 1.0f - xi2; }
+            float u = 1.0f - xi1 - xi2, v = xi1, w = xi2;
+            v3 sp = V3(u * xv.x + v * yv.x + w * zv.x, u * xv.y + v * yv.y + w * zv.y, u * xv.z + v * yv.z + w * zv.z);
+            v3 Lv = sub3(sp, sf.pos);
+            float dist2 = dot3(Lv, Lv);
+            float dist = sqrtf(maxf(dist2, EPSILON_));
+            v3 Ln = normalize3(Lv);
+            v3 cl = cross3(sub3(yv, xv), sub3(zv, xv));
+            v3 nl = normalize3(cl);
+            if (dot3(nl, neg3(Ln)) < 0.0f) nl = neg3(nl);
+            float area_l = fabsf(length3(cl) * 0.5f);
+            float pdf_l = lt[11] / maxf(area_l, EPSILON_);
+            float cos_x = dot3(normal, Ln);                                    /* DEVIATION: clamped like ReconnectDI (:117), v6 GI uses abs (:579) */
+            float cos_y = fabsf(dot3(nl, neg3(Ln)));
+            if (cos_x < EPSILON_ || cos_y < EPSILON_) continue;                /* :580-585; no shadow ray is traced */
+            float pdf_light = maxf(EPSILON_, pdf_l) * dist2 / cos_y;           /* :629-630 */
+            v3 F; float P; bsdf_mixture(c, sf.mat, flags, normal, Ln, outgoing, &F, &P, NULL, NULL);
+            float mi = pdf_light / ((float)nee * pdf_light + P);               /* Path_Sampler_v6.hlsl:164 */
+            float g = cos_x / pdf_light * mi;
+            v3 con = V3(lt[12] * (thr.x * F.x) * g, lt[13] * (thr.y * F.y) * g, lt[14] * (thr.z * F.z) * g);
+            if (!finite3(con) || (con.x == 0.0f && con.y == 0.0f && con.z == 0.0f)) continue;
+            /* visibility: Sampler_v6.hlsl:616-628 */
+            v3 so = add3(sf.pos, scale3(normalize3(normal), S_BIAS));
+            float smax = maxf(S_BIAS, dist - S_BIAS * 5.0f);
+            cnt[2]++;
+            if (!any_bvh(c, so, Ln, 0.5f * S_BIAS, smax)) rad = add3(rad, con);
+        }
+        if (b + 1 == p->max_bounces) break;
+        /* ---- BSDF sampling: Path_Sampler_v6.hlsl:205-229, Sampler_v6.hlsl:423-457,482-497 ---- */
+        uint32_t st = select_strategy(m, outgoing, normal, flags, seed);
+        v3 smp = sample_bsdf(c, sf.mat, st, outgoing, normal, seed);
+        v3 F; float P; bsdf_mixture(c, sf.mat, flags, normal, smp, outgoing, &F, &P, NULL, NULL);
+        float NdotL = dot3(normal, smp);                                       /* unclamped: Sampler_v6.hlsl:455 */
+        if (!(P > 0.0f)) break;
+        float wgt = NdotL / P;                                                 /* Hit.hlsl:366 */
+        thr = V3(thr.x * (F.x * wgt), thr.y * (F.y * wgt), thr.z * (F.z * wgt));
+        if (!finite3(thr) || (thr.x == 0.0f && thr.y == 0.0f && thr.z == 0.0f)) break;
+        prev_pdf = P;                                                          /* Hit.hlsl:369 */
+        if (b > p->rr_start) {                                                 /* RayGen.hlsl:118-130 */
+            float mx = maxf(thr.x, maxf(thr.y, thr.z));
+            float q = minf(maxf(mx, 0.05f), 1.0f);
+            float r = rnd(seed);
+            if (r > q) break;
+            float iq = 1.0f / q;
+            thr = scale3(thr, iq);
+        }
+        origin = sf.pos; dir = smp; tmin = S_BIAS;                             /* Sampler_v6.hlsl:224-227 */
+    }
+    return rad;
+}
+
+int orc_render(orc_ctx* c, const orc_params* p, float* accum, uint64_t ray_counts[3]) {
+    uint64_t c0 = 0, c1 = 0, c2 = 0;
+    int nth = c->nthreads;
+#ifdef _OPENMP
+    if (nth <= 0) nth = omp_get_max_threads();
+#else
+    nth = 1;
+#endif
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nth) reduction(+ : c0, c1, c2)
+    for (int64_t y = 0; y < (int64_t)p->height; y++) {
+        uint64_t cnt[3] = {0, 0, 0};
+        for (uint32_t x = 0; x < p->width; x++) {
+            if (!owns_pixel(p, x, (uint32_t)y)) continue;
+            float* a = accum + ((size_t)y * p->width + x) * 4;
+            for (uint32_t s = 0; s < p->spp; s++) {
+                v3 r = trace_path(c, p, x, (uint32_t)y, p->sample_base + s, cnt);
+                if (finite3(r)) { a[0] += r.x; a[1] += r.y; a[2] += r.z; a[3] += 1.0f; }   /* pass3:383-405 */
+            }
+        }
+        c0 += cnt[0]; c1 += cnt[1]; c2 += cnt[2];
+    }
+    if (ray_counts) { ray_counts[0] = c0; ray_counts[1] = c1; ray_counts[2] = c2; }
+    return 0;
+}
+
+/* RayGen_v6_pass3.hlsl:405,428-441 + Common_v6.hlsl:353-376; RGBA8 UNORM store */
+void orc_srgb8(const float* accum, uint32_t npix, uint8_t* out) {
+    for (uint32_t i = 0; i < npix; i++) {
+        const float* a = accum + (size_t)i * 4;
+        float cnt = maxf(a[3], 1.0f);
+        float c[3] = {a[0] / cnt, a[1] / cnt, a[2] / cnt};
+        if (is_nan(c[0]) || is_nan(c[1]) || is_nan(c[2])) { c[0] = 1; c[1] = 0; c[2] = 1; }
+        if (is_inf(c[0]) || is_inf(c[1]) || is_inf(c[2])) { c[0] = 0; c[1] = 1; c[2] = 1; }
+        for (int k = 0; k < 3; k++) {
+            float v = c[k] <= 0.0031308f ? 12.92f * c[k] : 1.055f * orc_pow(c[k], 1.0f / 2.4f) - 0.055f;
+            v = saturatef(v);
+            out[(size_t)i * 4 + k] = (uint8_t)(int)(v * 255.0f + 0.5f);
+        }
+        out[(size_t)i * 4 + 3] = 255;
+    }
+}

@@ -1,0 +1,450 @@
+"""royaltracer-dx_amd — ctypes binding of the MI355X wavefront path tracer (librtx_hip.so).
+
+The product path is the HIP library only.  Importing this package raises ImportError if
+librtx_hip.so has not been built, and Context() raises RtxError if no GPU can be opened:
+there is no CPU fallback and nothing under oracle/ is ever imported from here.
+
+The C-ABI is declared in include/rtx.h (hot path) and include/rtx_host.h (scene-loader /
+material / camera layer mirroring the reference's ObjLoader / Manipulator / Renderer).
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtx_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C {_HERE}` (hipcc --offload-arch=gfx950) "
+        "or `python -c 'import __graft_entry__ as g; g.build()'`.  There is no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH)
+
+RTX_OK = 0
+FLAG_LAMBERT_ONLY = 1
+FLAG_JITTER = 2
+K_RAYGEN, K_TRACE, K_SHADE, K_SHADOW, K_ACCUM, K_SORT, K_COUNT = 0, 1, 2, 3, 4, 5, 8
+KERNEL_NAMES = {K_RAYGEN: "raygen", K_TRACE: "trace_closest", K_SHADE: "shade", K_SHADOW: "trace_shadow", K_ACCUM: "accumulate", K_SORT: "sort"}
+OPT_KERNEL_TIMING, OPT_PATHS_PER_BATCH, OPT_SORT_MATERIALS, OPT_LDS_NODES = 1, 2, 3, 4
+
+
+class RtxError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """rtx_params (include/rtx.h)."""
+    _fields_ = [(n, C.c_uint32) for n in (
+        "width", "height", "spp", "sample_base", "max_bounces", "nee_samples", "rr_start",
+        "frame_seed", "flags", "tile_size", "shard_rank", "shard_count")]
+
+    def __init__(self, width=1920, height=1080, spp=1, sample_base=1, max_bounces=8, nee_samples=1,
+                 rr_start=3, frame_seed=1, flags=0, tile_size=64, shard_rank=0, shard_count=1):
+        super().__init__(width, height, spp, sample_base, max_bounces, nee_samples, rr_start,
+                         frame_seed, flags, tile_size, shard_rank, shard_count)
+
+    def copy(self, **kw):
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d.update(kw)
+        return Params(**d)
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays_primary", C.c_uint64), ("rays_extension", C.c_uint64), ("rays_shadow", C.c_uint64),
+                ("paths", C.c_uint64), ("kernel_ms", C.c_double * K_COUNT), ("kernel_launches", C.c_uint64 * K_COUNT),
+                ("kernel_items", C.c_uint64 * K_COUNT), ("render_ms", C.c_double),
+                ("bvh_nodes", C.c_uint32), ("triangles", C.c_uint32), ("lights", C.c_uint32), ("materials", C.c_uint32)]
+
+    @property
+    def rays(self):
+        return self.rays_primary + self.rays_extension + self.rays_shadow
+
+
+_vp, _u32, _fp = C.c_void_p, C.c_uint32, C.POINTER(C.c_float)
+_u32p = C.POINTER(C.c_uint32)
+
+
+def _sig(name, restype, *argtypes):
+    f = getattr(lib, name)
+    f.restype = restype
+    f.argtypes = list(argtypes)
+    return f
+
+
+# ---- include/rtx.h ----
+_sig("rtx_create", C.c_int, C.c_int, C.POINTER(_vp))
+_sig("rtx_destroy", None, _vp)
+_sig("rtx_last_error", C.c_char_p, _vp)
+_sig("rtx_set_option", C.c_int, _vp, C.c_int, C.c_int64)
+_sig("rtx_set_stream", C.c_int, _vp, _vp)
+_sig("rtx_set_materials", C.c_int, _vp, _vp, _u32)
+_sig("rtx_add_mesh", C.c_int, _vp, _vp, _u32, _vp, _u32, _vp, _u32p)
+_sig("rtx_add_instance", C.c_int, _vp, _u32, _fp, _u32p)
+_sig("rtx_set_instance_transform", C.c_int, _vp, _u32, _fp)
+_sig("rtx_commit_scene", C.c_int, _vp)
+_sig("rtx_set_camera", C.c_int, _vp, _fp, _fp)
+_sig("rtx_bind_accum", C.c_int, _vp, _vp, C.c_size_t)
+_sig("rtx_clear_accum", C.c_int, _vp, _u32, _u32)
+_sig("rtx_render", C.c_int, _vp, C.POINTER(Params))
+_sig("rtx_read_accum", C.c_int, _vp, _vp, C.c_size_t)
+_sig("rtx_read_srgb8", C.c_int, _vp, _vp, C.c_size_t)
+_sig("rtx_get_stats", C.c_int, _vp, C.POINTER(Stats))
+_sig("rtx_get_lights", C.c_int, _vp, _vp, _u32, _u32p)
+_sig("rtx_shard_slab_bytes", C.c_int, C.POINTER(Params), C.POINTER(C.c_size_t))
+_sig("rtx_pack_tiles", C.c_int, _vp, C.POINTER(Params), _vp)
+_sig("rtx_unpack_tiles", C.c_int, _vp, C.POINTER(Params), _vp)
+_sig("rtx_debug_primary_rays", C.c_int, _vp, C.POINTER(Params), _u32, _vp)
+_sig("rtx_debug_trace_closest", C.c_int, _vp, _vp, _u32, _vp)
+_sig("rtx_debug_trace_any", C.c_int, _vp, _vp, _u32, _vp)
+_sig("rtx_debug_surface", C.c_int, _vp, _vp, _vp, _u32, _vp)
+_sig("rtx_debug_bsdf_eval", C.c_int, _vp, _u32, _u32, _vp, _u32, _vp)
+_sig("rtx_debug_bsdf_sample", C.c_int, _vp, _u32, _u32, _vp, _u32, _vp)
+_sig("rtx_debug_tea", C.c_int, _vp, _u32p, _u32, _vp)
+# ---- include/rtx_host.h ----
+_sig("rtxh_scene_cornell", _vp)
+_sig("rtxh_scene_sponza_class", _vp, _u32, _u32)
+_sig("rtxh_scene_bistro_class", _vp, _u32, _u32)
+_sig("rtxh_scene_from_obj", _vp, C.POINTER(C.c_char_p), _u32, C.c_char_p)
+_sig("rtxh_scene_free", None, _vp)
+_sig("rtxh_last_error", C.c_char_p)
+_sig("rtxh_scene_num_materials", _u32, _vp)
+_sig("rtxh_scene_materials", _vp, _vp)
+_sig("rtxh_scene_num_meshes", _u32, _vp)
+_sig("rtxh_scene_mesh", C.c_int, _vp, _u32, C.POINTER(_vp), _u32p, C.POINTER(_vp), _u32p, C.POINTER(_vp))
+_sig("rtxh_scene_num_instances", _u32, _vp)
+_sig("rtxh_scene_instance", C.c_int, _vp, _u32, _u32p, _fp)
+_sig("rtxh_scene_num_triangles", C.c_uint64, _vp)
+_sig("rtxh_scene_camera", C.c_int, _vp, _fp, _fp, _fp, _fp, _fp, _fp)
+_sig("rtxh_scene_view_proj", C.c_int, _vp, C.c_float, _fp, _fp)
+_sig("rtxh_scene_upload", C.c_int, _vp, _vp, C.c_float)
+_sig("rtxh_lookat", None, _fp, _fp, _fp, _fp)
+_sig("rtxh_perspective_fov_rh", None, C.c_float, C.c_float, C.c_float, C.c_float, _fp)
+_sig("rtxh_generate_ess_lut", None, C.c_float, _fp)
+_sig("rtxh_mat4_inverse", None, _fp, _fp)
+_sig("rtxh_half_round", C.c_float, C.c_float)
+_sig("rtxh_bvh_check", C.c_int, _vp, _u32, _u32p, _u32p, _u32p)
+_sig("rtxh_renderer_create", _vp, _u32, _u32, C.c_char_p, C.c_int)
+_sig("rtxh_renderer_set_scene", C.c_int, _vp, _vp)
+_sig("rtxh_renderer_params", C.POINTER(Params), _vp)
+_sig("rtxh_renderer_on_init", C.c_int, _vp)
+_sig("rtxh_renderer_on_update", C.c_int, _vp)
+_sig("rtxh_renderer_on_render", C.c_int, _vp)
+_sig("rtxh_renderer_read_accum", C.c_int, _vp, _vp, C.c_size_t)
+_sig("rtxh_renderer_read_output", C.c_int, _vp, _vp, C.c_size_t)
+_sig("rtxh_renderer_destroy", None, _vp)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_vp)
+
+
+def _fptr(a):
+    return a.ctypes.data_as(_fp)
+
+
+# ------------------------------------------------------------------------------------------------
+# host layer
+# ------------------------------------------------------------------------------------------------
+class Scene:
+    """A host-side scene in the reference's data model (global Material table, per-model
+    Vertex / index / materialID arrays, instance list).  Arrays are numpy copies."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise RtxError("scene creation failed: " + lib.rtxh_last_error().decode())
+        self._h = handle
+        n = lib.rtxh_scene_num_materials(handle)
+        buf = (C.c_float * (n * 32)).from_address(lib.rtxh_scene_materials(handle)) if n else []
+        self.materials = np.array(buf, dtype=np.float32).reshape(n, 32)
+        self.meshes = []
+        for i in range(lib.rtxh_scene_num_meshes(handle)):
+            v, idx, mid = _vp(), _vp(), _vp()
+            nv, ni = _u32(), _u32()
+            lib.rtxh_scene_mesh(handle, i, C.byref(v), C.byref(nv), C.byref(idx), C.byref(ni), C.byref(mid))
+            verts = np.array((C.c_float * (nv.value * 7)).from_address(v.value), dtype=np.float32).reshape(-1, 7) if nv.value else np.zeros((0, 7), np.float32)
+            indices = np.array((C.c_uint32 * ni.value).from_address(idx.value), dtype=np.uint32) if ni.value else np.zeros(0, np.uint32)
+            matids = np.array((C.c_uint32 * ni.value).from_address(mid.value), dtype=np.uint32) if ni.value else np.zeros(0, np.uint32)
+            self.meshes.append((verts, indices, matids))
+        self.instances = []
+        for i in range(lib.rtxh_scene_num_instances(handle)):
+            mesh = _u32()
+            m = np.zeros(16, np.float32)
+            lib.rtxh_scene_instance(handle, i, C.byref(mesh), _fptr(m))
+            self.instances.append((mesh.value, m))
+        self.num_triangles = lib.rtxh_scene_num_triangles(handle)
+        e, c, u = np.zeros(3, np.float32), np.zeros(3, np.float32), np.zeros(3, np.float32)
+        fov, zn, zf = C.c_float(), C.c_float(), C.c_float()
+        lib.rtxh_scene_camera(handle, _fptr(e), _fptr(c), _fptr(u), C.byref(fov), C.byref(zn), C.byref(zf))
+        self.eye, self.center, self.up, self.fovy_deg, self.znear, self.zfar = e, c, u, fov.value, zn.value, zf.value
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.rtxh_scene_free(h)
+
+    @classmethod
+    def cornell(cls):
+        return cls(lib.rtxh_scene_cornell())
+
+    @classmethod
+    def sponza_class(cls, target_tris=262144, seed=260):
+        return cls(lib.rtxh_scene_sponza_class(target_tris, seed))
+
+    @classmethod
+    def bistro_class(cls, target_tris=3800000, seed=3800):
+        return cls(lib.rtxh_scene_bistro_class(target_tris, seed))
+
+    @classmethod
+    def from_obj(cls, files, mtl_dir):
+        arr = (C.c_char_p * len(files))(*[f.encode() for f in files])
+        return cls(lib.rtxh_scene_from_obj(arr, len(files), mtl_dir.encode()))
+
+    def view_proj(self, aspect):
+        v, p = np.zeros(16, np.float32), np.zeros(16, np.float32)
+        lib.rtxh_scene_view_proj(self._h, C.c_float(aspect), _fptr(v), _fptr(p))
+        return v, p
+
+
+def lookat(eye, center, up):
+    e, c, u, v = _f32(eye), _f32(center), _f32(up), np.zeros(16, np.float32)
+    lib.rtxh_lookat(_fptr(e), _fptr(c), _fptr(u), _fptr(v))
+    return v
+
+
+def perspective_fov_rh(fovy_rad, aspect, zn, zf):
+    p = np.zeros(16, np.float32)
+    lib.rtxh_perspective_fov_rh(fovy_rad, aspect, zn, zf, _fptr(p))
+    return p
+
+
+def generate_ess_lut(roughness):
+    lut = np.zeros(16, np.float32)
+    lib.rtxh_generate_ess_lut(roughness, _fptr(lut))
+    return lut
+
+
+def mat4_inverse(m):
+    m, o = _f32(m).reshape(16), np.zeros(16, np.float32)
+    lib.rtxh_mat4_inverse(_fptr(m), _fptr(o))
+    return o
+
+
+def half_round(x):
+    return lib.rtxh_half_round(C.c_float(x))
+
+
+def bvh_check(world_tris):
+    w = _f32(world_tris).reshape(-1, 9)
+    nodes, depth, leaf = _u32(), _u32(), _u32()
+    rc = lib.rtxh_bvh_check(_ptr(w), len(w), C.byref(nodes), C.byref(depth), C.byref(leaf))
+    return rc, nodes.value, depth.value, leaf.value
+
+
+# ------------------------------------------------------------------------------------------------
+# the hot path
+# ------------------------------------------------------------------------------------------------
+class Context:
+    """One rtx_ctx (one GPU)."""
+
+    def __init__(self, device=0):
+        h = _vp()
+        rc = lib.rtx_create(device, C.byref(h))
+        if rc != RTX_OK:
+            raise RtxError(f"rtx_create({device}) failed ({rc}): {lib.rtx_last_error(None).decode()}")
+        self._h = h
+        self.device = device
+        self.width = self.height = 0
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.rtx_destroy(h)
+
+    __del__ = close
+
+    def _ck(self, rc, what):
+        if rc != RTX_OK:
+            raise RtxError(f"{what} failed ({rc}): {lib.rtx_last_error(self._h).decode()}")
+
+    def set_option(self, opt, value):
+        self._ck(lib.rtx_set_option(self._h, opt, int(value)), "rtx_set_option")
+
+    def set_stream(self, stream_handle):
+        self._ck(lib.rtx_set_stream(self._h, _vp(stream_handle) if stream_handle else None), "rtx_set_stream")
+
+    def set_materials(self, mats):
+        m = _f32(mats).reshape(-1, 32)
+        self._ck(lib.rtx_set_materials(self._h, _ptr(m), len(m)), "rtx_set_materials")
+
+    def add_mesh(self, verts, indices, matids):
+        v = _f32(verts).reshape(-1, 7)
+        i = np.ascontiguousarray(indices, dtype=np.uint32)
+        m = np.ascontiguousarray(matids, dtype=np.uint32)
+        out = _u32()
+        self._ck(lib.rtx_add_mesh(self._h, _ptr(v), len(v), _ptr(i), len(i), _ptr(m), C.byref(out)), "rtx_add_mesh")
+        return out.value
+
+    def add_instance(self, mesh, o2w):
+        m = _f32(o2w).reshape(16)
+        out = _u32()
+        self._ck(lib.rtx_add_instance(self._h, mesh, _fptr(m), C.byref(out)), "rtx_add_instance")
+        return out.value
+
+    def set_instance_transform(self, inst, o2w):
+        m = _f32(o2w).reshape(16)
+        self._ck(lib.rtx_set_instance_transform(self._h, inst, _fptr(m)), "rtx_set_instance_transform")
+
+    def commit(self):
+        self._ck(lib.rtx_commit_scene(self._h), "rtx_commit_scene")
+
+    def set_camera(self, view, proj):
+        v, p = _f32(view).reshape(16), _f32(proj).reshape(16)
+        self._ck(lib.rtx_set_camera(self._h, _fptr(v), _fptr(p)), "rtx_set_camera")
+
+    def upload(self, scene, aspect):
+        """rtx_set_materials / add_mesh / add_instance / commit / set_camera from a Scene (array path)."""
+        self.set_materials(scene.materials)
+        for v, i, m in scene.meshes:
+            self.add_mesh(v, i, m)
+        for mesh, o2w in scene.instances:
+            self.add_instance(mesh, o2w)
+        self.commit()
+        self.set_camera(*scene.view_proj(aspect))
+
+    def bind_accum(self, device_ptr, nbytes):
+        self._ck(lib.rtx_bind_accum(self._h, _vp(device_ptr) if device_ptr else None, nbytes), "rtx_bind_accum")
+
+    def clear(self, width, height):
+        self.width, self.height = width, height
+        self._ck(lib.rtx_clear_accum(self._h, width, height), "rtx_clear_accum")
+
+    def render(self, params):
+        self.width, self.height = params.width, params.height
+        self._ck(lib.rtx_render(self._h, C.byref(params)), "rtx_render")
+
+    def read_accum(self):
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        self._ck(lib.rtx_read_accum(self._h, _ptr(out), out.nbytes), "rtx_read_accum")
+        return out
+
+    def read_srgb8(self):
+        out = np.zeros((self.height, self.width, 4), np.uint8)
+        self._ck(lib.rtx_read_srgb8(self._h, _ptr(out), out.nbytes), "rtx_read_srgb8")
+        return out
+
+    def stats(self):
+        s = Stats()
+        self._ck(lib.rtx_get_stats(self._h, C.byref(s)), "rtx_get_stats")
+        return s
+
+    def lights(self):
+        n = _u32()
+        self._ck(lib.rtx_get_lights(self._h, None, 0, C.byref(n)), "rtx_get_lights")
+        out = np.zeros((n.value, 20), np.float32)
+        if n.value:
+            self._ck(lib.rtx_get_lights(self._h, _ptr(out), n.value, C.byref(n)), "rtx_get_lights")
+        return out
+
+    def slab_bytes(self, params):
+        b = C.c_size_t()
+        self._ck(lib.rtx_shard_slab_bytes(C.byref(params), C.byref(b)), "rtx_shard_slab_bytes")
+        return b.value
+
+    def pack_tiles(self, params, device_ptr):
+        self._ck(lib.rtx_pack_tiles(self._h, C.byref(params), _vp(device_ptr)), "rtx_pack_tiles")
+
+    def unpack_tiles(self, params, device_ptr):
+        self.width, self.height = params.width, params.height
+        self._ck(lib.rtx_unpack_tiles(self._h, C.byref(params), _vp(device_ptr)), "rtx_unpack_tiles")
+
+    # kernel-level entry points
+    def primary_rays(self, params, sample_id=1):
+        out = np.zeros((params.height * params.width, 8), np.float32)
+        self._ck(lib.rtx_debug_primary_rays(self._h, C.byref(params), sample_id, _ptr(out)), "rtx_debug_primary_rays")
+        return out
+
+    def trace_closest(self, rays8):
+        r = _f32(rays8).reshape(-1, 8)
+        out = np.zeros((len(r), 4), np.float32)
+        self._ck(lib.rtx_debug_trace_closest(self._h, _ptr(r), len(r), _ptr(out)), "rtx_debug_trace_closest")
+        return out
+
+    def trace_any(self, rays8):
+        r = _f32(rays8).reshape(-1, 8)
+        out = np.zeros(len(r), np.uint8)
+        self._ck(lib.rtx_debug_trace_any(self._h, _ptr(r), len(r), _ptr(out)), "rtx_debug_trace_any")
+        return out
+
+    def surface(self, rays8, hits4):
+        r, h = _f32(rays8).reshape(-1, 8), _f32(hits4).reshape(-1, 4)
+        out = np.zeros((len(r), 16), np.float32)
+        self._ck(lib.rtx_debug_surface(self._h, _ptr(r), _ptr(h), len(r), _ptr(out)), "rtx_debug_surface")
+        return out
+
+    def bsdf_eval(self, mat_id, flags, n_wo_wi):
+        q = _f32(n_wo_wi).reshape(-1, 9)
+        out = np.zeros((len(q), 8), np.float32)
+        self._ck(lib.rtx_debug_bsdf_eval(self._h, mat_id, flags, _ptr(q), len(q), _ptr(out)), "rtx_debug_bsdf_eval")
+        return out
+
+    def bsdf_sample(self, mat_id, flags, n_wo_seed):
+        q = _f32(n_wo_seed).reshape(-1, 8)
+        out = np.zeros((len(q), 8), np.float32)
+        self._ck(lib.rtx_debug_bsdf_sample(self._h, mat_id, flags, _ptr(q), len(q), _ptr(out)), "rtx_debug_bsdf_sample")
+        return out
+
+    def tea(self, seed, n):
+        s = (C.c_uint32 * 2)(*seed)
+        out = np.zeros(n, np.float32)
+        self._ck(lib.rtx_debug_tea(self._h, s, n, _ptr(out)), "rtx_debug_tea")
+        return out, (s[0], s[1])
+
+
+class Renderer:
+    """The headless Renderer facade (host/Renderer.h) through its C entry points."""
+
+    def __init__(self, width, height, name="rtx", device=0):
+        self._h = lib.rtxh_renderer_create(width, height, name.encode(), device)
+        self.width, self.height = width, height
+
+    def _ck(self, rc, what):
+        if rc != RTX_OK:
+            raise RtxError(f"{what} failed: {lib.rtxh_last_error().decode()}")
+
+    def set_scene(self, scene):
+        self._ck(lib.rtxh_renderer_set_scene(self._h, scene._h), "set_scene")
+
+    @property
+    def params(self):
+        return lib.rtxh_renderer_params(self._h).contents
+
+    def on_init(self):
+        self._ck(lib.rtxh_renderer_on_init(self._h), "OnInit")
+
+    def on_update(self):
+        self._ck(lib.rtxh_renderer_on_update(self._h), "OnUpdate")
+
+    def on_render(self):
+        self._ck(lib.rtxh_renderer_on_render(self._h), "OnRender")
+
+    def read_accum(self):
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        self._ck(lib.rtxh_renderer_read_accum(self._h, _ptr(out), out.nbytes), "read_accum")
+        return out
+
+    def read_output(self):
+        out = np.zeros((self.height, self.width, 4), np.uint8)
+        self._ck(lib.rtxh_renderer_read_output(self._h, _ptr(out), out.nbytes), "read_output")
+        return out
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.rtxh_renderer_destroy(h)
+
+    __del__ = close

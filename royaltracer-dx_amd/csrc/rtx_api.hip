@@ -1,0 +1,490 @@
+// rtx_api.hip — the C-ABI of include/rtx.h: context, scene upload, the wavefront render loop.
+// Host code only (kernels are in rtx_kernels.hip).  No CPU rendering path exists here by design.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/rtx.h"
+#include "rtx_kernels.hpp"
+#include "rtx_scene_host.hpp"
+
+using namespace rtx;
+
+static std::string g_create_err;
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= bytes && p) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        if (!n) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct TimedLaunch { int cls; hipEvent_t a, b; };
+
+struct rtx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    int num_cus = 256;
+    SceneHost host; BuiltScene built;
+    bool committed = false, camera_set = false;
+    DevBuf d_nodes, d_tris, d_shade, d_mats, d_insts, d_lights, d_cam;
+    DevScene dsc{};
+    float view[16], proj[16];
+    // path state
+    uint32_t cap = 0, cap_nee = 0;
+    DevBuf d_ray_o, d_ray_d, d_thr, d_rad, d_hit, d_sh_o, d_sh_d, d_sh_c, d_queue[2], d_counters;
+    uint32_t* h_counters = nullptr; size_t h_counters_words = 0;
+    // accumulation
+    DevBuf d_accum; void* ext_accum = nullptr; size_t ext_accum_bytes = 0; uint32_t acc_w = 0, acc_h = 0;
+    DevBuf d_srgb;
+    // options
+    bool timing = false; uint64_t paths_per_batch = 8u << 20; int sort_mats = 0; int lds_nodes_opt = -1;
+    std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+    std::vector<TimedLaunch> timed;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    rtx_stats stats{};
+    std::string err;
+    F4* accum_ptr() { return (F4*)(ext_accum ? ext_accum : d_accum.p); }
+};
+
+#define HIPCHK(c, call)                                                                          \
+    do { hipError_t e_ = (call);                                                                 \
+         if (e_ != hipSuccess) { (c)->err = std::string(#call) + ": " + hipGetErrorString(e_);  \
+                                 return e_ == hipErrorOutOfMemory ? RTX_ERR_OOM : RTX_ERR_HIP; } } while (0)
+#define BIND(c) do { if (!(c)) return RTX_ERR_INVALID; HIPCHK(c, hipSetDevice((c)->device)); } while (0)
+
+template <class T> static int upload(rtx_ctx* c, DevBuf& b, const std::vector<T>& v) {
+    HIPCHK(c, b.ensure(v.size() * sizeof(T)));
+    if (!v.empty()) HIPCHK(c, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return RTX_OK;
+}
+
+extern "C" {
+
+int rtx_create(int device_ordinal, rtx_ctx** out) {
+    if (!out) return RTX_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_err = std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") +
+                       " (this library has no CPU fallback)";
+        return RTX_ERR_NO_DEVICE;
+    }
+    if (device_ordinal < 0 || device_ordinal >= n) { g_create_err = "device ordinal out of range"; return RTX_ERR_NO_DEVICE; }
+    if ((e = hipSetDevice(device_ordinal)) != hipSuccess) { g_create_err = hipGetErrorString(e); return RTX_ERR_NO_DEVICE; }
+    rtx_ctx* c = new rtx_ctx();
+    c->device = device_ordinal;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_err = hipGetErrorString(e); delete c; return RTX_ERR_HIP;
+    }
+    c->own_stream = true;
+    (void)hipEventCreate(&c->ev_begin); (void)hipEventCreate(&c->ev_end);
+    *out = c;
+    return RTX_OK;
+}
+
+void rtx_destroy(rtx_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
+                     &c->d_thr, &c->d_rad, &c->d_hit, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
+                     &c->d_accum, &c->d_srgb};
+    for (DevBuf* b : all) b->release();
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* rtx_last_error(rtx_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
+    if (!c) return RTX_ERR_INVALID;
+    switch (option) {
+    case RTX_OPT_KERNEL_TIMING: c->timing = value != 0; return RTX_OK;
+    case RTX_OPT_PATHS_PER_BATCH: if (value < 4096) { c->err = "paths_per_batch must be >= 4096"; return RTX_ERR_INVALID; } c->paths_per_batch = (uint64_t)value; return RTX_OK;
+    case RTX_OPT_SORT_MATERIALS: c->sort_mats = value != 0; return RTX_OK;
+    case RTX_OPT_LDS_NODES: c->lds_nodes_opt = (int)value; c->committed = false; return RTX_OK;
+    default: c->err = "unknown option"; return RTX_ERR_INVALID;
+    }
+}
+
+int rtx_set_stream(rtx_ctx* c, void* s) {
+    BIND(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; c->own_stream = false; }
+    if (s) { c->stream = (hipStream_t)s; c->own_stream = false; }
+    else { HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    return RTX_OK;
+}
+
+int rtx_set_materials(rtx_ctx* c, const void* mats128, uint32_t count) {
+    if (!c) return RTX_ERR_INVALID;
+    if (!c->host.set_materials(mats128, count)) { c->err = c->host.err; return RTX_ERR_INVALID; }
+    c->committed = false; return RTX_OK;
+}
+int rtx_add_mesh(rtx_ctx* c, const void* verts28, uint32_t nverts, const uint32_t* indices, uint32_t nidx, const uint32_t* material_ids, uint32_t* mesh_out) {
+    if (!c) return RTX_ERR_INVALID;
+    if (!c->host.add_mesh(verts28, nverts, indices, nidx, material_ids, mesh_out)) { c->err = c->host.err; return RTX_ERR_INVALID; }
+    c->committed = false; return RTX_OK;
+}
+int rtx_add_instance(rtx_ctx* c, uint32_t mesh, const float o2w[16], uint32_t* inst_out) {
+    if (!c || !o2w) return RTX_ERR_INVALID;
+    if (!c->host.add_instance(mesh, o2w, inst_out)) { c->err = c->host.err; return RTX_ERR_INVALID; }
+    c->committed = false; return RTX_OK;
+}
+int rtx_set_instance_transform(rtx_ctx* c, uint32_t inst, const float o2w[16]) {
+    if (!c || !o2w) return RTX_ERR_INVALID;
+    if (!c->host.set_instance_transform(inst, o2w)) { c->err = c->host.err; return RTX_ERR_INVALID; }
+    c->committed = false; return RTX_OK;
+}
+
+int rtx_commit_scene(rtx_ctx* c) {
+    BIND(c);
+    for (size_t i = 0; i < c->host.matids.size(); i++)
+        if (c->host.matids[i] >= c->host.mats128.size() / 32) { c->err = "commit: material id out of range"; return RTX_ERR_INVALID; }
+    if (!c->host.build(c->built)) { c->err = c->host.err; return RTX_ERR_INVALID; }
+    BuiltScene& B = c->built;
+    int r;
+    if ((r = upload(c, c->d_nodes, B.nodes))) return r;
+    if ((r = upload(c, c->d_tris, B.tris))) return r;
+    if ((r = upload(c, c->d_shade, B.shade))) return r;
+    if ((r = upload(c, c->d_mats, B.mats))) return r;
+    if ((r = upload(c, c->d_insts, B.insts))) return r;
+    if ((r = upload(c, c->d_lights, B.lights))) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    DevScene& s = c->dsc;
+    s.nodes = (const NodeGPU*)c->d_nodes.p; s.nnodes = (uint32_t)B.nodes.size();
+    s.tris = (const TriGPU*)c->d_tris.p; s.ntris = (uint32_t)B.tris.size();
+    s.shade = (const TriShade*)c->d_shade.p;
+    s.mats = (const MatGPU*)c->d_mats.p; s.nmat = (uint32_t)B.mats.size();
+    s.insts = (const InstGPU*)c->d_insts.p;
+    s.lights = (const LightGPU*)c->d_lights.p; s.nlights = (uint32_t)B.lights.size();
+    s.total_weight = B.total_weight;
+    // LDS budget per workgroup: stack + top of tree + first triangles, kept <= 64 KiB
+    s.stack_depth = B.max_depth + 2;
+    const size_t stack_bytes = (size_t)s.stack_depth * 256 * 4;
+    size_t budget = 64 * 1024 > stack_bytes ? 64 * 1024 - stack_bytes : 0;
+    uint32_t want_nodes = c->lds_nodes_opt >= 0 ? (uint32_t)c->lds_nodes_opt : 256u;
+    if (s.nnodes <= 512 && c->lds_nodes_opt < 0) want_nodes = s.nnodes;    // small scene: whole tree
+    s.lds_nodes = std::min<uint32_t>(std::min<uint32_t>(want_nodes, s.nnodes), (uint32_t)(budget / 64));
+    budget -= (size_t)s.lds_nodes * 64;
+    uint32_t want_tris = s.ntris <= 256 ? s.ntris : 0u;                    // triangles only when ALL of them fit
+    s.lds_tris = (size_t)want_tris * 48 <= budget ? want_tris : 0u;
+    if (trace_lds_bytes(s) > 64 * 1024) { c->err = "commit: BVH too deep for the LDS traversal stack"; return RTX_ERR_INVALID; }
+    c->stats.bvh_nodes = s.nnodes; c->stats.triangles = s.ntris; c->stats.lights = s.nlights; c->stats.materials = s.nmat;
+    c->committed = true;
+    return RTX_OK;
+}
+
+int rtx_set_camera(rtx_ctx* c, const float view[16], const float proj[16]) {
+    BIND(c);
+    if (!view || !proj) return RTX_ERR_INVALID;
+    memcpy(c->view, view, 64); memcpy(c->proj, proj, 64);
+    CameraGPU cam;
+    mat4_inverse(view, cam.viewI); mat4_inverse(proj, cam.projI);     // Renderer.cpp:1735-1736
+    HIPCHK(c, c->d_cam.ensure(sizeof(cam)));
+    HIPCHK(c, hipMemcpyAsync(c->d_cam.p, &cam, sizeof(cam), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->camera_set = true;
+    return RTX_OK;
+}
+
+int rtx_bind_accum(rtx_ctx* c, void* dev, size_t bytes) {
+    if (!c) return RTX_ERR_INVALID;
+    c->ext_accum = dev; c->ext_accum_bytes = dev ? bytes : 0;
+    return RTX_OK;
+}
+
+static int ensure_accum(rtx_ctx* c, uint32_t w, uint32_t h, bool clear) {
+    const size_t need = (size_t)w * h * 16;
+    if (c->ext_accum) {
+        if (c->ext_accum_bytes < need) { c->err = "bound accumulation buffer is smaller than width*height*16 bytes"; return RTX_ERR_INVALID; }
+    } else {
+        const bool fresh = !c->d_accum.p || c->acc_w != w || c->acc_h != h;
+        HIPCHK(c, c->d_accum.ensure(need));
+        clear = clear || fresh;
+    }
+    c->acc_w = w; c->acc_h = h;
+    if (clear) HIPCHK(c, hipMemsetAsync(c->accum_ptr(), 0, need, c->stream));
+    return RTX_OK;
+}
+
+int rtx_clear_accum(rtx_ctx* c, uint32_t w, uint32_t h) {
+    BIND(c);
+    if (!w || !h) return RTX_ERR_INVALID;
+    int r = ensure_accum(c, w, h, true);
+    if (r) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RTX_OK;
+}
+
+static int make_frame(rtx_ctx* c, const rtx_params* p, DevFrame& f) {
+    if (!p || !p->width || !p->height) { c->err = "params: width/height must be non-zero"; return RTX_ERR_INVALID; }
+    const uint32_t ts = p->tile_size ? p->tile_size : 64;
+    if (ts % 8 || ts > 1024) { c->err = "params: tile_size must be a multiple of 8 (<= 1024)"; return RTX_ERR_INVALID; }
+    const uint32_t cnt = p->shard_count ? p->shard_count : 1;
+    if (p->shard_rank >= cnt) { c->err = "params: shard_rank >= shard_count"; return RTX_ERR_INVALID; }
+    f.width = p->width; f.height = p->height; f.tile_size = ts;
+    f.tiles_x = (p->width + ts - 1) / ts; f.tiles_y = (p->height + ts - 1) / ts;
+    f.shard_rank = p->shard_rank; f.shard_count = cnt;
+    const uint32_t total = f.tiles_x * f.tiles_y;
+    const uint32_t per = (total + cnt - 1) / cnt;
+    const uint64_t npl = (uint64_t)per * ts * ts;
+    if (npl > 0x7FFFFFFFull) { c->err = "params: image too large"; return RTX_ERR_INVALID; }
+    f.npl = (uint32_t)npl;
+    f.batch_spp = 1; f.sample_first = p->sample_base;
+    f.max_bounces = p->max_bounces; f.nee_samples = p->nee_samples; f.rr_start = p->rr_start;
+    f.frame_seed = p->frame_seed; f.flags = p->flags;
+    return RTX_OK;
+}
+
+static hipEvent_t take_event(rtx_ctx* c) {
+    if (c->ev_used == c->ev_pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; c->ev_pool.push_back(e); }
+    return c->ev_pool[c->ev_used++];
+}
+struct Timed {
+    rtx_ctx* c; int cls; hipEvent_t a = nullptr, b = nullptr;
+    Timed(rtx_ctx* c_, int cls_) : c(c_), cls(cls_) { c->stats.kernel_launches[cls]++; if (c->timing) { a = take_event(c); b = take_event(c); if (a) (void)hipEventRecord(a, c->stream); } }
+    ~Timed() { if (c->timing && a && b) { (void)hipEventRecord(b, c->stream); c->timed.push_back({cls, a, b}); } }
+};
+
+int rtx_render(rtx_ctx* c, const rtx_params* p) {
+    BIND(c);
+    if (!c->committed) { c->err = "render: scene not committed"; return RTX_ERR_STATE; }
+    if (!c->camera_set) { c->err = "render: camera not set"; return RTX_ERR_STATE; }
+    DevFrame f;
+    int r = make_frame(c, p, f);
+    if (r) return r;
+    if (p->max_bounces == 0 || p->max_bounces > 64) { c->err = "params: max_bounces must be in [1, 64]"; return RTX_ERR_INVALID; }
+    if (p->nee_samples > 16) { c->err = "params: nee_samples must be <= 16"; return RTX_ERR_INVALID; }
+    if ((r = ensure_accum(c, p->width, p->height, false))) return r;
+    memset(c->stats.kernel_ms, 0, sizeof(c->stats.kernel_ms));
+    memset(c->stats.kernel_launches, 0, sizeof(c->stats.kernel_launches));
+    memset(c->stats.kernel_items, 0, sizeof(c->stats.kernel_items));
+    c->stats.rays_primary = c->stats.rays_extension = c->stats.rays_shadow = c->stats.paths = 0; c->stats.render_ms = 0;
+    if (p->spp == 0) return RTX_OK;
+
+    const uint32_t nee = c->dsc.nlights ? p->nee_samples : 0;
+    uint32_t bspp = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->spp, c->paths_per_batch / f.npl));
+    const uint64_t cap64 = (uint64_t)f.npl * bspp;
+    if (cap64 > 0x7FFFFFFFull) { c->err = "render: batch too large"; return RTX_ERR_INVALID; }
+    const uint32_t cap = (uint32_t)cap64;
+    HIPCHK(c, c->d_ray_o.ensure((size_t)cap * 16)); HIPCHK(c, c->d_ray_d.ensure((size_t)cap * 16));
+    HIPCHK(c, c->d_thr.ensure((size_t)cap * 16)); HIPCHK(c, c->d_rad.ensure((size_t)cap * 16)); HIPCHK(c, c->d_hit.ensure((size_t)cap * 16));
+    HIPCHK(c, c->d_queue[0].ensure((size_t)cap * 4)); HIPCHK(c, c->d_queue[1].ensure((size_t)cap * 4));
+    const size_t shn = (size_t)cap * std::max<uint32_t>(nee, 1);
+    HIPCHK(c, c->d_sh_o.ensure(shn * 16)); HIPCHK(c, c->d_sh_d.ensure(shn * 16)); HIPCHK(c, c->d_sh_c.ensure(shn * 16));
+    DevPaths P;
+    P.ray_o = (F4*)c->d_ray_o.p; P.ray_d = (F4*)c->d_ray_d.p; P.thr = (F4*)c->d_thr.p; P.rad = (F4*)c->d_rad.p; P.hit = (F4*)c->d_hit.p;
+    P.sh_o = (F4*)c->d_sh_o.p; P.sh_d = (F4*)c->d_sh_d.p; P.sh_c = (F4*)c->d_sh_c.p;
+    uint32_t* queue[2] = {(uint32_t*)c->d_queue[0].p, (uint32_t*)c->d_queue[1].p};
+
+    // counters of one batch: Q[0..mb] queue lengths entering each bounce, S[b*nee + j] shadow queue lengths
+    const uint32_t mb = p->max_bounces;
+    const size_t ncnt = (size_t)(mb + 1) + (size_t)mb * std::max<uint32_t>(nee, 1);
+    const uint32_t nbatches = (p->spp + bspp - 1) / bspp;
+    HIPCHK(c, c->d_counters.ensure(ncnt * 4));
+    if (c->h_counters_words < ncnt * nbatches) {
+        if (c->h_counters) (void)hipHostFree(c->h_counters);
+        c->h_counters = nullptr; c->h_counters_words = 0;
+        HIPCHK(c, hipHostMalloc((void**)&c->h_counters, ncnt * nbatches * 4, hipHostMallocDefault));
+        c->h_counters_words = ncnt * nbatches;
+    }
+    uint32_t* cnt = (uint32_t*)c->d_counters.p;
+    const uint32_t max_blocks = (uint32_t)c->num_cus * 8u;
+    const CameraGPU* cam = (const CameraGPU*)c->d_cam.p;
+    c->ev_used = 0; c->timed.clear();
+    hipStream_t st = c->stream;
+
+    HIPCHK(c, hipEventRecord(c->ev_begin, st));
+    for (uint32_t bi = 0; bi < nbatches; bi++) {
+        DevFrame fb = f;
+        fb.sample_first = p->sample_base + bi * bspp;
+        fb.batch_spp = std::min(bspp, p->spp - bi * bspp);
+        HIPCHK(c, hipMemsetAsync(cnt, 0, ncnt * 4, st));
+        { Timed t(c, RTX_K_RAYGEN); launch_raygen(st, max_blocks, fb, P, cam, queue[0], cnt + 0); }
+        for (uint32_t b = 0; b < mb; b++) {
+            uint32_t* q = queue[b & 1]; uint32_t* qn = queue[(b + 1) & 1];
+            uint32_t* shc = cnt + (mb + 1) + (size_t)b * std::max<uint32_t>(nee, 1);
+            { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, max_blocks, cap, c->dsc, P, q, cnt + b); }
+            { Timed t(c, RTX_K_SHADE); launch_shade(st, max_blocks, cap, c->dsc, fb, P, b, q, cnt + b, qn, cnt + b + 1, shc); }
+            for (uint32_t j = 0; j < nee; j++) { Timed t(c, RTX_K_SHADOW); launch_trace_shadow(st, max_blocks, cap, c->dsc, P, j, shc + j); }
+        }
+        { Timed t(c, RTX_K_ACCUM); launch_accumulate(st, max_blocks, fb, P, c->accum_ptr()); }
+        HIPCHK(c, hipMemcpyAsync(c->h_counters + (size_t)bi * ncnt, cnt, ncnt * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(c, hipEventRecord(c->ev_end, st));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(st));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) c->stats.render_ms = ms;
+    for (const TimedLaunch& t : c->timed) { float m = 0.0f; if (hipEventElapsedTime(&m, t.a, t.b) == hipSuccess) c->stats.kernel_ms[t.cls] += m; }
+    for (uint32_t bi = 0; bi < nbatches; bi++) {
+        const uint32_t* h = c->h_counters + (size_t)bi * ncnt;
+        c->stats.rays_primary += h[0]; c->stats.paths += h[0];
+        for (uint32_t b = 1; b < mb; b++) c->stats.rays_extension += h[b];
+        for (uint32_t b = 0; b < mb; b++) for (uint32_t j = 0; j < nee; j++) c->stats.rays_shadow += h[(mb + 1) + (size_t)b * std::max<uint32_t>(nee, 1) + j];
+    }
+    c->stats.kernel_items[RTX_K_RAYGEN] = c->stats.paths;
+    c->stats.kernel_items[RTX_K_TRACE] = c->stats.rays_primary + c->stats.rays_extension;
+    c->stats.kernel_items[RTX_K_SHADE] = c->stats.rays_primary + c->stats.rays_extension;
+    c->stats.kernel_items[RTX_K_SHADOW] = c->stats.rays_shadow;
+    c->stats.kernel_items[RTX_K_ACCUM] = c->stats.paths;
+    return RTX_OK;
+}
+
+int rtx_read_accum(rtx_ctx* c, float* out, size_t bytes) {
+    BIND(c);
+    const size_t need = (size_t)c->acc_w * c->acc_h * 16;
+    if (!out || !need || bytes < need || !c->accum_ptr()) { c->err = "read_accum: no image or buffer too small"; return RTX_ERR_INVALID; }
+    HIPCHK(c, hipMemcpyAsync(out, c->accum_ptr(), need, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RTX_OK;
+}
+
+int rtx_read_srgb8(rtx_ctx* c, uint8_t* out, size_t bytes) {
+    BIND(c);
+    const uint32_t npix = c->acc_w * c->acc_h;
+    if (!out || !npix || bytes < (size_t)npix * 4 || !c->accum_ptr()) { c->err = "read_srgb8: no image or buffer too small"; return RTX_ERR_INVALID; }
+    HIPCHK(c, c->d_srgb.ensure((size_t)npix * 4));
+    launch_srgb8(c->stream, c->accum_ptr(), npix, (uint32_t*)c->d_srgb.p);
+    HIPCHK(c, hipMemcpyAsync(out, c->d_srgb.p, (size_t)npix * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RTX_OK;
+}
+
+int rtx_get_stats(rtx_ctx* c, rtx_stats* out) { if (!c || !out) return RTX_ERR_INVALID; *out = c->stats; return RTX_OK; }
+
+int rtx_get_lights(rtx_ctx* c, void* out80, uint32_t max_count, uint32_t* count_out) {
+    if (!c) return RTX_ERR_INVALID;
+    if (!c->committed) { c->err = "get_lights: scene not committed"; return RTX_ERR_STATE; }
+    const uint32_t n = (uint32_t)(c->built.lights80.size() / 20);
+    if (count_out) *count_out = n;
+    if (out80) memcpy(out80, c->built.lights80.data(), (size_t)std::min(n, max_count) * 80);
+    return RTX_OK;
+}
+
+int rtx_shard_slab_bytes(const rtx_params* p, size_t* bytes) {
+    if (!p || !bytes || !p->width || !p->height) return RTX_ERR_INVALID;
+    const uint32_t ts = p->tile_size ? p->tile_size : 64, cnt = p->shard_count ? p->shard_count : 1;
+    const uint32_t total = ((p->width + ts - 1) / ts) * ((p->height + ts - 1) / ts);
+    *bytes = (size_t)((total + cnt - 1) / cnt) * ts * ts * 16;
+    return RTX_OK;
+}
+int rtx_pack_tiles(rtx_ctx* c, const rtx_params* p, void* slab) {
+    BIND(c);
+    DevFrame f; int r = make_frame(c, p, f); if (r) return r;
+    if (!slab || !c->accum_ptr() || c->acc_w != p->width || c->acc_h != p->height) { c->err = "pack_tiles: no accumulation buffer of that size"; return RTX_ERR_STATE; }
+    launch_pack_tiles(c->stream, (uint32_t)c->num_cus * 8u, f, c->accum_ptr(), (F4*)slab);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RTX_OK;
+}
+int rtx_unpack_tiles(rtx_ctx* c, const rtx_params* p, const void* slabs) {
+    BIND(c);
+    DevFrame f; int r = make_frame(c, p, f); if (r) return r;
+    if (!slabs) return RTX_ERR_INVALID;
+    if ((r = ensure_accum(c, p->width, p->height, false))) return r;
+    launch_unpack_tiles(c->stream, (uint32_t)c->num_cus * 8u, f, f.shard_count, (const F4*)slabs, c->accum_ptr());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RTX_OK;
+}
+
+// ---- kernel-level debug entry points ----
+struct Scratch { DevBuf a, b, c; ~Scratch() { a.release(); b.release(); c.release(); } };
+
+int rtx_debug_primary_rays(rtx_ctx* c, const rtx_params* p, uint32_t sample_id, float* rays8) {
+    BIND(c);
+    if (!c->camera_set) { c->err = "camera not set"; return RTX_ERR_STATE; }
+    DevFrame f; int r = make_frame(c, p, f); if (r) return r;
+    Scratch s; const size_t n = (size_t)p->width * p->height;
+    HIPCHK(c, s.a.ensure(n * 32));
+    launch_dbg_primary(c->stream, f, (const CameraGPU*)c->d_cam.p, sample_id, (F4*)s.a.p);
+    HIPCHK(c, hipMemcpyAsync(rays8, s.a.p, n * 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RTX_OK;
+}
+static int dbg_trace(rtx_ctx* c, const float* rays8, uint32_t n, int any, float* hits4, uint8_t* occ) {
+    BIND(c);
+    if (!c->committed) { c->err = "scene not committed"; return RTX_ERR_STATE; }
+    if (!n) return RTX_OK;
+    Scratch s;
+    HIPCHK(c, s.a.ensure((size_t)n * 32)); HIPCHK(c, s.b.ensure((size_t)n * 16));
+    HIPCHK(c, hipMemcpyAsync(s.a.p, rays8, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+    launch_dbg_trace(c->stream, c->dsc, (const F4*)s.a.p, n, any, (F4*)s.b.p);
+    HIPCHK(c, hipGetLastError());
+    std::vector<float> h((size_t)n * 4);
+    HIPCHK(c, hipMemcpyAsync(h.data(), s.b.p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (hits4) memcpy(hits4, h.data(), (size_t)n * 16);
+    if (occ) for (uint32_t i = 0; i < n; i++) { uint32_t prim; memcpy(&prim, &h[(size_t)i * 4 + 3], 4); occ[i] = prim != kMissPrim; }
+    return RTX_OK;
+}
+int rtx_debug_trace_closest(rtx_ctx* c, const float* rays8, uint32_t n, float* hits4) { return dbg_trace(c, rays8, n, 0, hits4, nullptr); }
+int rtx_debug_trace_any(rtx_ctx* c, const float* rays8, uint32_t n, uint8_t* occluded) { return dbg_trace(c, rays8, n, 1, nullptr, occluded); }
+
+int rtx_debug_surface(rtx_ctx* c, const float* rays8, const float* hits4, uint32_t n, float* out16) {
+    BIND(c);
+    if (!c->committed) { c->err = "scene not committed"; return RTX_ERR_STATE; }
+    if (!n) return RTX_OK;
+    Scratch s;
+    HIPCHK(c, s.a.ensure((size_t)n * 32)); HIPCHK(c, s.b.ensure((size_t)n * 16)); HIPCHK(c, s.c.ensure((size_t)n * 64));
+    HIPCHK(c, hipMemcpyAsync(s.a.p, rays8, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(s.b.p, hits4, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    launch_dbg_surface(c->stream, c->dsc, (const F4*)s.a.p, (const F4*)s.b.p, n, (F4*)s.c.p);
+    HIPCHK(c, hipGetLastError());
+    std::vector<float> h((size_t)n * 16);
+    HIPCHK(c, hipMemcpyAsync(h.data(), s.c.p, (size_t)n * 64, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // device layout: pos3,mat | normal3,area | inst,flat3 | 0  ->  API layout: pos3,mat,normal3,area,inst,flat3,pad4
+    memcpy(out16, h.data(), (size_t)n * 64);
+    return RTX_OK;
+}
+static int dbg_bsdf(rtx_ctx* c, bool sample, uint32_t mat, uint32_t flags, const float* in, uint32_t stride_in, uint32_t n, float* out8) {
+    BIND(c);
+    if (!c->committed) { c->err = "scene not committed"; return RTX_ERR_STATE; }
+    if (mat >= c->dsc.nmat) { c->err = "material id out of range"; return RTX_ERR_INVALID; }
+    if (!n) return RTX_OK;
+    Scratch s;
+    HIPCHK(c, s.a.ensure((size_t)n * stride_in * 4)); HIPCHK(c, s.b.ensure((size_t)n * 32));
+    HIPCHK(c, hipMemcpyAsync(s.a.p, in, (size_t)n * stride_in * 4, hipMemcpyHostToDevice, c->stream));
+    if (sample) launch_dbg_bsdf_sample(c->stream, c->dsc, mat, flags, (const float*)s.a.p, n, (float*)s.b.p);
+    else launch_dbg_bsdf_eval(c->stream, c->dsc, mat, flags, (const float*)s.a.p, n, (float*)s.b.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out8, s.b.p, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RTX_OK;
+}
+int rtx_debug_bsdf_eval(rtx_ctx* c, uint32_t mat, uint32_t flags, const float* in9, uint32_t n, float* out8) { return dbg_bsdf(c, false, mat, flags, in9, 9, n, out8); }
+int rtx_debug_bsdf_sample(rtx_ctx* c, uint32_t mat, uint32_t flags, const float* in8, uint32_t n, float* out8) { return dbg_bsdf(c, true, mat, flags, in8, 8, n, out8); }
+
+int rtx_debug_tea(rtx_ctx* c, uint32_t seed[2], uint32_t n, float* out) {
+    BIND(c);
+    if (!seed || !out) return RTX_ERR_INVALID;
+    Scratch s;
+    HIPCHK(c, s.a.ensure((size_t)std::max<uint32_t>(n, 1) * 4)); HIPCHK(c, s.b.ensure(8));
+    launch_dbg_tea(c->stream, seed[0], seed[1], n, (float*)s.a.p, (uint32_t*)s.b.p);
+    HIPCHK(c, hipGetLastError());
+    if (n) HIPCHK(c, hipMemcpyAsync(out, s.a.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(seed, s.b.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RTX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,576 @@
+// rtx_kernels.hip — the wavefront path-tracing kernels for gfx950 (CDNA4, wave64).
+//
+// One sample batch is a set of paths with fixed slots ("pid"); per-path state lives in SoA float4
+// arrays in HBM; each bounce runs   trace_closest -> shade -> trace_shadow[j]   over an index queue
+// that shade re-compacts with a wave ballot + prefix sum (one atomic per wave).  The top of the BVH
+// and the first triangles are staged in LDS per workgroup; the per-lane traversal stack is in LDS too.
+// MFMA is unused on purpose: nothing here is a dense contraction.
+//
+// Parity-critical arithmetic (ray/triangle test, surface reconstruction, BSDF, light sampling, path
+// throughput) follows rtx_math.hpp / rtx_bsdf.hpp with the library-wide -ffp-contract=off.  Ray/box
+// tests are NOT parity-critical (closest hit is defined as the minimum over all triangles with a
+// lowest-id tie break, any-hit as existence), they only have to be conservative.
+#include <hip/hip_runtime.h>
+#include "rtx_kernels.hpp"
+
+namespace rtx {
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------------------------
+// wave-level helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Stream compaction: every lane of the wave must call this (convergent).  Returns the slot for lanes
+// with pred set.  One atomicAdd per wave.
+__device__ __forceinline__ uint32_t wave_push(bool pred, uint32_t* counter) {
+    const unsigned long long mask = __ballot(pred);
+    const uint32_t cnt = (uint32_t)__popcll(mask);
+    if (cnt == 0) return 0xFFFFFFFFu;                    // wave-uniform
+    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    uint32_t base = 0;
+    if (lane_id() == 0) base = atomicAdd(counter, cnt);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    return base + prefix;
+}
+
+__device__ __forceinline__ F4 ld4(const F4* p) { return *p; }
+
+// ---------------------------------------------------------------------------------------------
+// pixel <-> local path-slot mapping (shard tiles, 8x8 pixel blocks inside a tile so that one wave
+// covers a compact screen region)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool slot_to_pixel(const DevFrame& f, uint32_t pl, uint32_t& x, uint32_t& y) {
+    const uint32_t tpix = f.tile_size * f.tile_size;
+    const uint32_t k = pl / tpix, r = pl - k * tpix;
+    const uint32_t t = f.shard_rank + k * f.shard_count;
+    if (t >= f.tiles_x * f.tiles_y) return false;
+    const uint32_t tx = t % f.tiles_x, ty = t / f.tiles_x;
+    const uint32_t bpr = f.tile_size >> 3;
+    const uint32_t blk = r >> 6, ln = r & 63u;
+    const uint32_t bx = blk % bpr, by = blk / bpr;
+    x = tx * f.tile_size + bx * 8u + (ln & 7u);
+    y = ty * f.tile_size + by * 8u + (ln >> 3);
+    return x < f.width && y < f.height;
+}
+
+// primary ray, RayGen_v6_pass1.hlsl:51-95
+__device__ __forceinline__ void primary_ray(const CameraGPU& cam, uint32_t W, uint32_t H, uint32_t x, uint32_t y, float jx, float jy, f3& o, f3& d) {
+    const float dx = (((float)x + jx) / (float)W) * 2.0f - 1.0f;
+    const float dy = (((float)y + jy) / (float)H) * 2.0f - 1.0f;
+    const float* P = cam.projI; const float* Vi = cam.viewI;
+    const float ndy = -dy;
+    f3 tg = mk3(P[0] * dx + P[4] * ndy + P[8] + P[12], P[1] * dx + P[5] * ndy + P[9] + P[13], P[2] * dx + P[6] * ndy + P[10] + P[14]);
+    d = normalize(xform_dir(Vi, tg));
+    o = mk3(Vi[12], Vi[13], Vi[14]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// raygen: one thread per path slot of the batch
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_raygen(DevFrame f, DevPaths p, const CameraGPU* __restrict__ cam_p, uint32_t* __restrict__ queue, uint32_t* __restrict__ qcount) {
+    __shared__ CameraGPU cam;
+    if (threadIdx.x < 32) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
+    __syncthreads();
+    const uint32_t npaths = f.npl * f.batch_spp;
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t base = blockIdx.x * kBlock + (threadIdx.x & ~63u); base < npaths; base += stride) {
+        const uint32_t pid = base + (threadIdx.x & 63u);
+        bool valid = pid < npaths;
+        uint32_t x = 0, y = 0;
+        if (valid) {
+            const uint32_t sl = pid / f.npl, pl = pid - sl * f.npl;
+            valid = slot_to_pixel(f, pl, x, y);
+            if (valid) {
+                uint32_t s0, s1; seed_init(x, y, f.sample_first + sl, f.frame_seed, s0, s1);
+                float jx = 0.0f, jy = 0.0f;
+                if (f.flags & 2u) { jx = tea_next(s0, s1); jy = tea_next(s0, s1); }   // RayGen.hlsl:84-85
+                f3 o, d; primary_ray(cam, f.width, f.height, x, y, jx, jy, o, d);
+                p.ray_o[pid] = {o.x, o.y, o.z, kTMinCam};
+                p.ray_d[pid] = {d.x, d.y, d.z, 1.0f};
+                p.thr[pid] = {1.0f, 1.0f, 1.0f, u2f(s0)};
+                p.rad[pid] = {0.0f, 0.0f, 0.0f, u2f(s1)};
+            }
+        }
+        const uint32_t slot = wave_push(valid, qcount);
+        if (valid) queue[slot] = pid;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BVH traversal
+// ---------------------------------------------------------------------------------------------
+struct TraceLds {
+    const F4* nodes;     // LDS copy of nodes [0, lds_nodes)
+    const F4* tris;      // LDS copy of tris  [0, lds_tris)
+    uint32_t* stack;     // [depth][kBlock]
+};
+
+// stage the top of the BVH and the first triangles into LDS (coalesced 16-B copies)
+__device__ __forceinline__ TraceLds stage_lds(const DevScene& sc, F4* lds) {
+    TraceLds L;
+    F4* ln = lds; F4* lt = lds + (size_t)sc.lds_nodes * 4;
+    const F4* gn = (const F4*)sc.nodes; const F4* gt = (const F4*)sc.tris;
+    for (uint32_t i = threadIdx.x; i < sc.lds_nodes * 4u; i += kBlock) ln[i] = gn[i];
+    for (uint32_t i = threadIdx.x; i < sc.lds_tris * 3u; i += kBlock) lt[i] = gt[i];
+    L.nodes = ln; L.tris = lt;
+    L.stack = (uint32_t*)(lt + (size_t)sc.lds_tris * 3);
+    return L;
+}
+
+// Moeller-Trumbore with the fixed operation order shared with the oracle (a11).  Exclusive (tmin, tmax).
+__device__ __forceinline__ bool tri_test(f3 o, f3 d, F4 v0w, F4 e1w, F4 e2w, float tmin, float tmax, float& t, float& u, float& v) {
+    const f3 v0 = mk3(v0w.x, v0w.y, v0w.z), e1 = mk3(e1w.x, e1w.y, e1w.z), e2 = mk3(e2w.x, e2w.y, e2w.z);
+    const f3 p = cross(d, e2);
+    const float det = dot(e1, p);
+    if (det == 0.0f) return false;
+    const float inv = 1.0f / det;
+    const f3 s = o - v0;
+    u = dot(s, p) * inv;
+    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    const f3 q = cross(s, e1);
+    v = dot(d, q) * inv;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
+    t = dot(e2, q) * inv;
+    return t > tmin && t < tmax;
+}
+
+// conservative slab test for one child box; returns entry distance in tn
+__device__ __forceinline__ bool box_test(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz,
+                                         f3 o, f3 idir, float tmin, float tbest, float& tn) {
+    const float tx0 = (bminx - o.x) * idir.x, tx1 = (bmaxx - o.x) * idir.x;
+    const float ty0 = (bminy - o.y) * idir.y, ty1 = (bmaxy - o.y) * idir.y;
+    const float tz0 = (bminz - o.z) * idir.z, tz1 = (bmaxz - o.z) * idir.z;
+    const float lo = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
+    const float hi = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
+    tn = lo;
+    return lo * 0.999998f <= hi * 1.000002f;     // lo, hi >= tmin >= 0 here
+}
+
+template <bool ANY>
+__device__ __forceinline__ void traverse(const DevScene& sc, const TraceLds& L, f3 o, f3 d, float tmin, float tmax,
+                                         float& bt, float& bu, float& bv, uint32_t& bprim) {
+    // zero direction components -> huge finite reciprocal (keeps the slab test NaN-free and conservative)
+    const float dxs = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
+    const float dys = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
+    const float dzs = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
+    const f3 idir = mk3(__builtin_amdgcn_rcpf(dxs), __builtin_amdgcn_rcpf(dys), __builtin_amdgcn_rcpf(dzs));
+    bt = tmax; bu = 0.0f; bv = 0.0f; bprim = kMissPrim;
+    uint32_t* stk = L.stack + threadIdx.x;
+    int sp = 0;
+    int32_t cur = 0;
+    while (true) {
+        if (cur >= 0) {
+            F4 a, b, c, dd;
+            if ((uint32_t)cur < sc.lds_nodes) { const F4* n = L.nodes + (size_t)cur * 4; a = n[0]; b = n[1]; c = n[2]; dd = n[3]; }
+            else { const F4* n = (const F4*)(sc.nodes + cur); a = n[0]; b = n[1]; c = n[2]; dd = n[3]; }
+            float t0, t1;
+            const bool h0 = box_test(a.x, a.y, a.z, a.w, b.x, b.y, o, idir, tmin, bt, t0);
+            const bool h1 = box_test(b.z, b.w, c.x, c.y, c.z, c.w, o, idir, tmin, bt, t1);
+            int32_t c0 = (int32_t)f2u(dd.x), c1 = (int32_t)f2u(dd.y);
+            if (h0 && h1) {
+                if (t1 < t0) { int32_t tmp = c0; c0 = c1; c1 = tmp; }
+                stk[sp * kBlock] = (uint32_t)c1; sp++;
+                cur = c0;
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else { if (sp == 0) break; sp--; cur = (int32_t)stk[sp * kBlock]; }
+        } else {
+            const uint32_t v = ~(uint32_t)cur;
+            const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
+            bool done = false;
+            for (uint32_t k = 0; k < cnt; k++) {
+                const uint32_t slot = first + k;
+                F4 v0, e1, e2;
+                if (slot < sc.lds_tris) { const F4* t = L.tris + (size_t)slot * 3; v0 = t[0]; e1 = t[1]; e2 = t[2]; }
+                else { const F4* t = (const F4*)(sc.tris + slot); v0 = t[0]; e1 = t[1]; e2 = t[2]; }
+                float t, u, w;
+                if (tri_test(o, d, v0, e1, e2, tmin, tmax, t, u, w)) {
+                    if (ANY) { bprim = 0u; done = true; break; }
+                    const uint32_t gid = f2u(v0.w);
+                    if (t < bt || (t == bt && gid < bprim)) { bt = t; bu = u; bv = w; bprim = gid; }
+                }
+            }
+            if (ANY && done) break;
+            if (sp == 0) break;
+            sp--; cur = (int32_t)stk[sp * kBlock];
+        }
+    }
+}
+
+// closest hit for every queued path: reads ray_o/ray_d, writes hit
+__global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount) {
+    extern __shared__ F4 lds[];
+    const uint32_t n = *qcount;
+    if (blockIdx.x * kBlock >= n) return;
+    const TraceLds L = stage_lds(sc, lds);
+    __syncthreads();
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint32_t pid = queue[i];
+        const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
+        float t, u, v; uint32_t prim;
+        traverse<false>(sc, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, kTMax, t, u, v, prim);
+        p.hit[pid] = {t, u, v, u2f(prim)};
+    }
+}
+
+// any-hit for NEE slot j: visible contributions are added to the path's radiance (one thread per path)
+__global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, DevPaths p, const F4* __restrict__ sh_o, const F4* __restrict__ sh_d,
+                                                         const F4* __restrict__ sh_c, const uint32_t* __restrict__ shcount) {
+    extern __shared__ F4 lds[];
+    const uint32_t n = *shcount;
+    if (blockIdx.x * kBlock >= n) return;
+    const TraceLds L = stage_lds(sc, lds);
+    __syncthreads();
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const F4 so = sh_o[i], sd = sh_d[i];
+        float t, u, v; uint32_t prim;
+        traverse<true>(sc, L, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, t, u, v, prim);
+        if (prim == kMissPrim) {
+            const F4 c = sh_c[i];
+            const uint32_t pid = f2u(c.w);
+            F4 r = p.rad[pid];
+            r.x = r.x + c.x; r.y = r.y + c.y; r.z = r.z + c.z;
+            p.rad[pid] = r;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// surface reconstruction: ClosestHit, Hit_v6.hlsl:12-61, from the pre-gathered TriShade record
+// ---------------------------------------------------------------------------------------------
+struct Surf { f3 pos; f3 normal; uint32_t mat; uint32_t inst; float area; f3 flat; };
+__device__ __forceinline__ Surf surface(const DevScene& sc, f3 o, f3 d, float t, float u, float v, uint32_t gid) {
+    Surf s;
+    const F4* rec = (const F4*)(sc.shade + gid);
+    const F4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+    s.mat = f2u(r0.x); s.inst = f2u(r0.y);
+    const f3 flat = mk3(r0.z, r0.w, r1.x);
+    const f3 n0 = mk3(r1.y, r1.z, r1.w), n1 = mk3(r2.x, r2.y, r2.z), n2 = mk3(r2.w, r3.x, r3.y);
+    s.area = r3.z; s.flat = flat;
+    s.pos = mk3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);                 // :15,60
+    const float b0 = 1.0f - u - v;                                            // :18
+    f3 smooth = mk3(0.0f, 0.0f, 0.0f);
+    smooth = smooth + n0 * b0; smooth = smooth + n1 * u; smooth = smooth + n2 * v;   // :40-46
+    const f3 n = (length(smooth) > 0.0001f) ? normalize(smooth) : flat;       // :49-54
+    s.normal = normalize(xform_dir(sc.insts[s.inst].nrm, n));                 // :56
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// shade: one thread per queued path.  Loop body of RayGen.hlsl:99-133 + Hit.hlsl:126-174,340-369 with
+// the v6 leaf math; the same statement order as oracle/rt_oracle.c:trace_path.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPaths p, uint32_t bounce,
+                                                  const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount,
+                                                  uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count,
+                                                  uint32_t* __restrict__ shcounts /* [nee] */) {
+    const uint32_t n = *qcount;
+    const uint32_t stride = gridDim.x * kBlock;
+    const uint32_t flags = f.flags;
+    const uint32_t nee = sc.nlights ? f.nee_samples : 0u;
+    const bool last = (bounce + 1u == f.max_bounces);
+    for (uint32_t base = blockIdx.x * kBlock + (threadIdx.x & ~63u); base < n; base += stride) {
+        const uint32_t i = base + (threadIdx.x & 63u);
+        bool active = i < n;
+        uint32_t pid = 0;
+        f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), thr = mk3(0, 0, 0), outgoing, normal, pos;
+        float prev_pdf = 1.0f; uint32_t s0 = 0, s1 = 0;
+        Surf sf; sf.mat = 0; sf.normal = mk3(0, 0, 1); sf.pos = mk3(0, 0, 0);
+        F4 radv = {0, 0, 0, 0};
+        bool shading = false;
+        if (active) {
+            pid = queue[i];
+            const F4 h = p.hit[pid];
+            const uint32_t prim = f2u(h.w);
+            if (prim != kMissPrim) {                                          // miss: Miss.hlsl:3-11 -> black, terminate
+                const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
+                o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z); prev_pdf = rd.w;
+                sf = surface(sc, o, d, h.x, h.y, h.z, prim);
+                if (sf.mat < sc.nmat) {
+                    const F4 tv = p.thr[pid]; radv = p.rad[pid];
+                    thr = mk3(tv.x, tv.y, tv.z); s0 = f2u(tv.w); s1 = f2u(radv.w);
+                    const MatGPU& m = sc.mats[sf.mat];
+                    if (m.Ke_len > 0.0f) {                                    // Hit.hlsl:126, Sampler_v6.hlsl:457
+                        const f3 Ke = mk3(m.Ke[0], m.Ke[1], m.Ke[2]);
+                        if (bounce == 0) { radv.x = radv.x + Ke.x; radv.y = radv.y + Ke.y; radv.z = radv.z + Ke.z; }   // Hit.hlsl:128-131
+                        else {
+                            float mi = 1.0f;
+                            if (nee) {                                        // Sampler_v6.hlsl:459-465, Path_Sampler_v6.hlsl:241
+                                const f3 Lv = sf.pos - o;
+                                const float dist = length(Lv), dist2 = dist * dist;
+                                const float cos_t = fabsf(dot(sf.normal, -d));
+                                const float pdf_light = (((Ke.x + Ke.y + Ke.z) / 3.0f) / sc.total_weight) * dist2 / maxf_(cos_t, kEps);
+                                mi = prev_pdf / ((float)nee * pdf_light + prev_pdf);
+                            }
+                            const f3 e = mk3(Ke.x * thr.x * mi, Ke.y * thr.y * mi, Ke.z * thr.z * mi);   // Hit.hlsl:173
+                            if (finite3(e)) { radv.x = radv.x + e.x; radv.y = radv.y + e.y; radv.z = radv.z + e.z; }
+                        }
+                        p.rad[pid] = radv;
+                    } else shading = true;
+                }
+            }
+        }
+        outgoing = -d; normal = sf.normal; pos = sf.pos;
+        const MatGPU* mp = sc.mats + (shading ? sf.mat : 0u);
+        // ---- NEE: SampleLightNEE_GI, Sampler_v6.hlsl:508-647, visibility ray deferred to k_trace_shadow ----
+        for (uint32_t j = 0; j < nee; j++) {
+            bool push = false;
+            F4 so = {0, 0, 0, 0}, sd = {0, 0, 0, 0}, scn = {0, 0, 0, 0};
+            if (shading) {
+                const float rv = tea_next(s0, s1);
+                int left = 0, right = (int)sc.nlights - 1, sel = 0;
+                while (left <= right) {                                       // :523-537
+                    const int mid = left + (right - left) / 2;
+                    if (rv < sc.lights[mid].cdf) { sel = mid; right = mid - 1; } else left = mid + 1;
+                }
+                const LightGPU& lt = sc.lights[sel];
+                const f3 xv = mk3(lt.xv[0], lt.xv[1], lt.xv[2]), yv = mk3(lt.yv[0], lt.yv[1], lt.yv[2]), zv = mk3(lt.zv[0], lt.zv[1], lt.zv[2]);
+                float xi1 = tea_next(s0, s1), xi2 = tea_next(s0, s1);
+                if (xi1 + xi2 > 1.0f) { xi1 = 1.0f - xi1; xi2 = 1.0f - xi2; }
+                const float u = 1.0f - xi1 - xi2, v = xi1, w = xi2;
+                const f3 sp = mk3(u * xv.x + v * yv.x + w * zv.x, u * xv.y + v * yv.y + w * zv.y, u * xv.z + v * yv.z + w * zv.z);
+                const f3 Lv = sp - pos;
+                const float dist2 = dot(Lv, Lv);
+                const float dist = sqrtf(maxf_(dist2, kEps));
+                const f3 Ln = normalize(Lv);
+                f3 nl = mk3(lt.nl[0], lt.nl[1], lt.nl[2]);
+                if (dot(nl, -Ln) < 0.0f) nl = -nl;
+                const float cos_x = dot(normal, Ln);
+                const float cos_y = fabsf(dot(nl, -Ln));
+                if (!(cos_x < kEps || cos_y < kEps)) {                        // :580-585
+                    const float pdf_light = lt.pdf_l * dist2 / cos_y;         // :629-630
+                    f3 F; float P, pd, ps; bsdf_mixture(*mp, flags, normal, Ln, outgoing, F, P, pd, ps);
+                    const float mi = pdf_light / ((float)nee * pdf_light + P);   // Path_Sampler_v6.hlsl:164
+                    const float g = cos_x / pdf_light * mi;
+                    const f3 con = mk3(lt.em[0] * (thr.x * F.x) * g, lt.em[1] * (thr.y * F.y) * g, lt.em[2] * (thr.z * F.z) * g);
+                    if (finite3(con) && !is_zero3(con)) {
+                        const f3 sorg = pos + normalize(normal) * kSBias;     // :616-621
+                        so = {sorg.x, sorg.y, sorg.z, 0.5f * kSBias};
+                        sd = {Ln.x, Ln.y, Ln.z, maxf_(kSBias, dist - kSBias * 5.0f)};
+                        scn = {con.x, con.y, con.z, u2f(pid)};
+                        push = true;
+                    }
+                }
+            }
+            const uint32_t cap = f.npl * f.batch_spp;
+            const uint32_t slot = wave_push(push, shcounts + j);
+            if (push) { p.sh_o[(size_t)j * cap + slot] = so; p.sh_d[(size_t)j * cap + slot] = sd; p.sh_c[(size_t)j * cap + slot] = scn; }
+        }
+        // ---- BSDF sampling: Path_Sampler_v6.hlsl:205-229, Sampler_v6.hlsl:423-457,482-497 ----
+        bool alive = false;
+        f3 smp = mk3(0, 0, 1); float P = 0.0f;
+        if (shading && !last) {
+            const uint32_t st = select_strategy(*mp, outgoing, normal, flags, s0, s1);
+            smp = sample_bsdf(*mp, st, outgoing, normal, s0, s1);
+            f3 F; float pd, ps; bsdf_mixture(*mp, flags, normal, smp, outgoing, F, P, pd, ps);
+            const float NdotL = dot(normal, smp);                             // unclamped, Sampler_v6.hlsl:455
+            if (P > 0.0f) {
+                const float wgt = NdotL / P;                                  // Hit.hlsl:366
+                thr = mk3(thr.x * (F.x * wgt), thr.y * (F.y * wgt), thr.z * (F.z * wgt));
+                if (finite3(thr) && !is_zero3(thr)) {
+                    alive = true;
+                    if (bounce > f.rr_start) {                                // RayGen.hlsl:118-130
+                        const float mx = maxf_(thr.x, maxf_(thr.y, thr.z));
+                        const float q = minf_(maxf_(mx, 0.05f), 1.0f);
+                        const float r = tea_next(s0, s1);
+                        if (r > q) alive = false;
+                        else { const float iq = 1.0f / q; thr = thr * iq; }
+                    }
+                }
+            }
+        }
+        if (alive) {
+            p.ray_o[pid] = {pos.x, pos.y, pos.z, kSBias};                     // Sampler_v6.hlsl:224-227
+            p.ray_d[pid] = {smp.x, smp.y, smp.z, P};                          // prev_pdf, Hit.hlsl:369
+            p.thr[pid] = {thr.x, thr.y, thr.z, u2f(s0)};
+            radv.w = u2f(s1);
+            p.rad[pid] = radv;
+        }
+        const uint32_t slot = wave_push(alive, next_count);
+        if (alive) next_queue[slot] = pid;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// accumulate: gPermanentData running sum + count, RayGen_v6_pass3.hlsl:383-405.  Fixed order: the
+// batch's samples are added in sample order, batches run in order on the stream.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_accumulate(DevFrame f, DevPaths p, F4* __restrict__ accum) {
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < f.npl; pl += stride) {
+        uint32_t x, y;
+        if (!slot_to_pixel(f, pl, x, y)) continue;
+        F4 a = accum[(size_t)y * f.width + x];
+        for (uint32_t s = 0; s < f.batch_spp; s++) {
+            const F4 r = p.rad[(size_t)s * f.npl + pl];
+            const f3 rv = mk3(r.x, r.y, r.z);
+            if (finite3(rv)) { a.x = a.x + rv.x; a.y = a.y + rv.y; a.z = a.z + rv.z; a.w = a.w + 1.0f; }
+        }
+        accum[(size_t)y * f.width + x] = a;
+    }
+}
+
+// sRGB8 output: RayGen_v6_pass3.hlsl:405,428-441 + Common_v6.hlsl:353-376
+__global__ __launch_bounds__(kBlock) void k_srgb8(const F4* __restrict__ accum, uint32_t npix, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= npix) return;
+    const F4 a = accum[i];
+    const float cnt = maxf_(a.w, 1.0f);
+    float c[3] = {a.x / cnt, a.y / cnt, a.z / cnt};
+    if (is_nan(c[0]) || is_nan(c[1]) || is_nan(c[2])) { c[0] = 1.0f; c[1] = 0.0f; c[2] = 1.0f; }
+    if (is_inf(c[0]) || is_inf(c[1]) || is_inf(c[2])) { c[0] = 0.0f; c[1] = 1.0f; c[2] = 1.0f; }
+    uint32_t px = 0xFF000000u;
+    for (int k = 0; k < 3; k++) {
+        float v = c[k] <= 0.0031308f ? 12.92f * c[k] : 1.055f * pow_(c[k], 1.0f / 2.4f) - 0.055f;
+        v = saturate(v);
+        px |= ((uint32_t)(int)(v * 255.0f + 0.5f)) << (8 * k);
+    }
+    out[i] = px;
+}
+
+// tile slabs for the multi-GPU gather
+__global__ __launch_bounds__(kBlock) void k_pack_tiles(DevFrame f, const F4* __restrict__ accum, F4* __restrict__ slab) {
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < f.npl; pl += stride) {
+        uint32_t x, y;
+        F4 v = {0, 0, 0, 0};
+        if (slot_to_pixel(f, pl, x, y)) v = accum[(size_t)y * f.width + x];
+        slab[pl] = v;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_unpack_tiles(DevFrame f, uint32_t nshards, const F4* __restrict__ slabs, F4* __restrict__ accum) {
+    const uint32_t stride = gridDim.x * kBlock;
+    const uint32_t total = f.npl * nshards;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
+        DevFrame g = f; g.shard_rank = i / f.npl; g.shard_count = nshards;
+        uint32_t x, y;
+        if (slot_to_pixel(g, i - g.shard_rank * f.npl, x, y)) accum[(size_t)y * f.width + x] = slabs[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel-level debug entry points (parity tests): same device functions as the render loop
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_dbg_trace(DevScene sc, const F4* __restrict__ rays, uint32_t n, int any, F4* __restrict__ hits) {
+    extern __shared__ F4 lds[];
+    const TraceLds L = stage_lds(sc, lds);
+    __syncthreads();
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const F4 ro = rays[2 * i], rd = rays[2 * i + 1];
+        float t, u, v; uint32_t prim;
+        if (any) traverse<true>(sc, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w, t, u, v, prim);
+        else traverse<false>(sc, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w, t, u, v, prim);
+        hits[i] = {t, u, v, u2f(prim)};
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_dbg_surface(DevScene sc, const F4* __restrict__ rays, const F4* __restrict__ hits, uint32_t n, F4* __restrict__ out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const F4 h = hits[i];
+    F4 z = {0, 0, 0, 0};
+    out[4 * i] = z; out[4 * i + 1] = z; out[4 * i + 2] = z; out[4 * i + 3] = z;
+    if (f2u(h.w) == kMissPrim) { out[4 * i].w = u2f(kMissMat); return; }
+    const F4 ro = rays[2 * i], rd = rays[2 * i + 1];
+    const Surf s = surface(sc, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), h.x, h.y, h.z, f2u(h.w));
+    out[4 * i] = {s.pos.x, s.pos.y, s.pos.z, u2f(s.mat)};
+    out[4 * i + 1] = {s.normal.x, s.normal.y, s.normal.z, s.area};
+    out[4 * i + 2] = {u2f(s.inst), s.flat.x, s.flat.y, s.flat.z};
+}
+__global__ __launch_bounds__(kBlock) void k_dbg_bsdf_eval(DevScene sc, uint32_t mat, uint32_t flags, const float* __restrict__ in9, uint32_t n, float* __restrict__ out8) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float* q = in9 + (size_t)i * 9; float* o = out8 + (size_t)i * 8;
+    f3 F; float P, pd, ps;
+    bsdf_mixture(sc.mats[mat], flags, mk3(q[0], q[1], q[2]), mk3(q[6], q[7], q[8]), mk3(q[3], q[4], q[5]), F, P, pd, ps);
+    o[0] = F.x; o[1] = F.y; o[2] = F.z; o[3] = P; o[4] = pd; o[5] = ps; o[6] = 0.0f; o[7] = 0.0f;
+}
+__global__ __launch_bounds__(kBlock) void k_dbg_bsdf_sample(DevScene sc, uint32_t mat, uint32_t flags, const float* __restrict__ in8, uint32_t n, float* __restrict__ out8) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float* q = in8 + (size_t)i * 8; float* o = out8 + (size_t)i * 8;
+    uint32_t s0 = f2u(q[6]), s1 = f2u(q[7]);
+    const f3 nrm = mk3(q[0], q[1], q[2]), wo = mk3(q[3], q[4], q[5]);
+    const uint32_t st = select_strategy(sc.mats[mat], wo, nrm, flags, s0, s1);
+    const f3 wi = sample_bsdf(sc.mats[mat], st, wo, nrm, s0, s1);
+    o[0] = wi.x; o[1] = wi.y; o[2] = wi.z; o[3] = u2f(st); o[4] = u2f(s0); o[5] = u2f(s1); o[6] = 0.0f; o[7] = 0.0f;
+}
+__global__ void k_dbg_tea(uint32_t s0, uint32_t s1, uint32_t n, float* __restrict__ out, uint32_t* __restrict__ seed_out) {
+    if (threadIdx.x || blockIdx.x) return;
+    for (uint32_t i = 0; i < n; i++) out[i] = tea_next(s0, s1);
+    seed_out[0] = s0; seed_out[1] = s1;
+}
+__global__ __launch_bounds__(kBlock) void k_dbg_primary(DevFrame f, const CameraGPU* __restrict__ cam, uint32_t sample_id, F4* __restrict__ rays) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= f.width * f.height) return;
+    const uint32_t x = i % f.width, y = i / f.width;
+    uint32_t s0, s1; seed_init(x, y, sample_id, f.frame_seed, s0, s1);
+    float jx = 0.0f, jy = 0.0f;
+    if (f.flags & 2u) { jx = tea_next(s0, s1); jy = tea_next(s0, s1); }
+    f3 o, d; primary_ray(*cam, f.width, f.height, x, y, jx, jy, o, d);
+    rays[2 * i] = {o.x, o.y, o.z, kTMinCam};
+    rays[2 * i + 1] = {d.x, d.y, d.z, kTMax};
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+static inline uint32_t grid_for(uint32_t items, uint32_t max_blocks) {
+    uint32_t b = (items + kBlock - 1) / kBlock;
+    if (b < 1) b = 1;
+    return b < max_blocks ? b : max_blocks;
+}
+size_t trace_lds_bytes(const DevScene& sc) {
+    return (size_t)sc.lds_nodes * 64 + (size_t)sc.lds_tris * 48 + (size_t)sc.stack_depth * kBlock * 4;
+}
+
+void launch_raygen(hipStream_t st, uint32_t max_blocks, const DevFrame& f, const DevPaths& p, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount) {
+    hipLaunchKernelGGL(k_raygen, dim3(grid_for(f.npl * f.batch_spp, max_blocks)), dim3(kBlock), 0, st, f, p, cam, queue, qcount);
+}
+void launch_trace_closest(hipStream_t st, uint32_t max_blocks, uint32_t cap, const DevScene& sc, const DevPaths& p, const uint32_t* queue, const uint32_t* qcount) {
+    hipLaunchKernelGGL(k_trace_closest, dim3(grid_for(cap, max_blocks)), dim3(kBlock), trace_lds_bytes(sc), st, sc, p, queue, qcount);
+}
+void launch_trace_shadow(hipStream_t st, uint32_t max_blocks, uint32_t cap, const DevScene& sc, const DevPaths& p, uint32_t j, const uint32_t* shcount) {
+    hipLaunchKernelGGL(k_trace_shadow, dim3(grid_for(cap, max_blocks)), dim3(kBlock), trace_lds_bytes(sc), st, sc, p,
+                       p.sh_o + (size_t)j * cap, p.sh_d + (size_t)j * cap, p.sh_c + (size_t)j * cap, shcount);
+}
+void launch_shade(hipStream_t st, uint32_t max_blocks, uint32_t cap, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce,
+                  const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts) {
+    hipLaunchKernelGGL(k_shade, dim3(grid_for(cap, max_blocks)), dim3(kBlock), 0, st, sc, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);
+}
+void launch_accumulate(hipStream_t st, uint32_t max_blocks, const DevFrame& f, const DevPaths& p, F4* accum) {
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(f.npl, max_blocks)), dim3(kBlock), 0, st, f, p, accum);
+}
+void launch_srgb8(hipStream_t st, const F4* accum, uint32_t npix, uint32_t* out) {
+    hipLaunchKernelGGL(k_srgb8, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, st, accum, npix, out);
+}
+void launch_pack_tiles(hipStream_t st, uint32_t max_blocks, const DevFrame& f, const F4* accum, F4* slab) {
+    hipLaunchKernelGGL(k_pack_tiles, dim3(grid_for(f.npl, max_blocks)), dim3(kBlock), 0, st, f, accum, slab);
+}
+void launch_unpack_tiles(hipStream_t st, uint32_t max_blocks, const DevFrame& f, uint32_t nshards, const F4* slabs, F4* accum) {
+    hipLaunchKernelGGL(k_unpack_tiles, dim3(grid_for(f.npl * nshards, max_blocks)), dim3(kBlock), 0, st, f, nshards, slabs, accum);
+}
+void launch_dbg_trace(hipStream_t st, const DevScene& sc, const F4* rays, uint32_t n, int any, F4* hits) {
+    hipLaunchKernelGGL(k_dbg_trace, dim3(grid_for(n, 2048)), dim3(kBlock), trace_lds_bytes(sc), st, sc, rays, n, any, hits);
+}
+void launch_dbg_surface(hipStream_t st, const DevScene& sc, const F4* rays, const F4* hits, uint32_t n, F4* out) {
+    hipLaunchKernelGGL(k_dbg_surface, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, sc, rays, hits, n, out);
+}
+void launch_dbg_bsdf_eval(hipStream_t st, const DevScene& sc, uint32_t mat, uint32_t flags, const float* in9, uint32_t n, float* out8) {
+    hipLaunchKernelGGL(k_dbg_bsdf_eval, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, sc, mat, flags, in9, n, out8);
+}
+void launch_dbg_bsdf_sample(hipStream_t st, const DevScene& sc, uint32_t mat, uint32_t flags, const float* in8, uint32_t n, float* out8) {
+    hipLaunchKernelGGL(k_dbg_bsdf_sample, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, sc, mat, flags, in8, n, out8);
+}
+void launch_dbg_tea(hipStream_t st, uint32_t s0, uint32_t s1, uint32_t n, float* out, uint32_t* seed_out) {
+    hipLaunchKernelGGL(k_dbg_tea, dim3(1), dim3(64), 0, st, s0, s1, n, out, seed_out);
+}
+void launch_dbg_primary(hipStream_t st, const DevFrame& f, const CameraGPU* cam, uint32_t sample_id, F4* rays) {
+    hipLaunchKernelGGL(k_dbg_primary, dim3((f.width * f.height + kBlock - 1) / kBlock), dim3(kBlock), 0, st, f, cam, sample_id, rays);
+}
+
+}  // namespace rtx

@@ -1,0 +1,62 @@
+// rtx_kernels.hpp — kernel argument blocks and host-side launchers (implemented in rtx_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rtx_types.hpp"
+
+namespace rtx {
+
+// read-only scene in HBM
+struct DevScene {
+    const NodeGPU*  nodes;  uint32_t nnodes;
+    const TriGPU*   tris;   uint32_t ntris;
+    const TriShade* shade;
+    const MatGPU*   mats;   uint32_t nmat;
+    const InstGPU*  insts;
+    const LightGPU* lights; uint32_t nlights;
+    float total_weight;
+    uint32_t lds_nodes, lds_tris;   // how many nodes / triangles each workgroup stages in LDS
+    uint32_t stack_depth;           // per-lane traversal stack entries (LDS)
+};
+
+// one sample batch of one frame
+struct DevFrame {
+    uint32_t width, height;
+    uint32_t tile_size, tiles_x, tiles_y;
+    uint32_t shard_rank, shard_count;
+    uint32_t npl;            // local pixel slots = tiles_per_shard * tile_size^2
+    uint32_t batch_spp;      // samples in this batch
+    uint32_t sample_first;   // sample id of the first one
+    uint32_t max_bounces, nee_samples, rr_start, frame_seed, flags;
+};
+
+// per-path state, SoA float4 streams indexed by path slot (pid = s_local * npl + pl)
+struct DevPaths {
+    F4* ray_o;   // origin.xyz, tmin
+    F4* ray_d;   // dir.xyz, pdf of the BSDF sample that produced this ray
+    F4* thr;     // throughput.xyz, seed.x bits
+    F4* rad;     // radiance.xyz, seed.y bits
+    F4* hit;     // t, u, v, global triangle id bits
+    // shadow queues, one segment of `cap` entries per NEE sample slot
+    F4* sh_o;    // origin.xyz, tmin
+    F4* sh_d;    // dir.xyz, tmax
+    F4* sh_c;    // contribution.xyz, pid bits
+};
+
+size_t trace_lds_bytes(const DevScene& sc);
+void launch_raygen(hipStream_t, uint32_t max_blocks, const DevFrame&, const DevPaths&, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount);
+void launch_trace_closest(hipStream_t, uint32_t max_blocks, uint32_t cap, const DevScene&, const DevPaths&, const uint32_t* queue, const uint32_t* qcount);
+void launch_trace_shadow(hipStream_t, uint32_t max_blocks, uint32_t cap, const DevScene&, const DevPaths&, uint32_t j, const uint32_t* shcount);
+void launch_shade(hipStream_t, uint32_t max_blocks, uint32_t cap, const DevScene&, const DevFrame&, const DevPaths&, uint32_t bounce,
+                  const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts);
+void launch_accumulate(hipStream_t, uint32_t max_blocks, const DevFrame&, const DevPaths&, F4* accum);
+void launch_srgb8(hipStream_t, const F4* accum, uint32_t npix, uint32_t* out);
+void launch_pack_tiles(hipStream_t, uint32_t max_blocks, const DevFrame&, const F4* accum, F4* slab);
+void launch_unpack_tiles(hipStream_t, uint32_t max_blocks, const DevFrame&, uint32_t nshards, const F4* slabs, F4* accum);
+void launch_dbg_trace(hipStream_t, const DevScene&, const F4* rays, uint32_t n, int any, F4* hits);
+void launch_dbg_surface(hipStream_t, const DevScene&, const F4* rays, const F4* hits, uint32_t n, F4* out);
+void launch_dbg_bsdf_eval(hipStream_t, const DevScene&, uint32_t mat, uint32_t flags, const float* in9, uint32_t n, float* out8);
+void launch_dbg_bsdf_sample(hipStream_t, const DevScene&, uint32_t mat, uint32_t flags, const float* in8, uint32_t n, float* out8);
+void launch_dbg_tea(hipStream_t, uint32_t s0, uint32_t s1, uint32_t n, float* out, uint32_t* seed_out);
+void launch_dbg_primary(hipStream_t, const DevFrame&, const CameraGPU* cam, uint32_t sample_id, F4* rays);
+
+}  // namespace rtx

@@ -1,0 +1,359 @@
+// rtx_scene_host.cpp — host-side scene assembly: material packing, world-space flattening, shade records,
+// emissive-triangle CDF and the binned-SAH BVH build.  No HIP calls in this file.
+#include "rtx_scene_host.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace rtx {
+
+// float -> binary16 (round to nearest even) -> float.  `-enable-16bit-types` makes HLSL `half` a true
+// binary16 (DXRHelper.h:125), so half4(mat.Kd) etc. round (Sampler_v6.hlsl:71-83).
+float half_round(float x) {
+    uint32_t u = f2u(x), sign = u & 0x80000000u, a = u & 0x7FFFFFFFu;
+    if (a >= 0x7F800000u) return x;
+    if (a >= 0x477FF000u) return u2f(sign | 0x7F800000u);
+    if (a < 0x33000001u) return u2f(sign);
+    if (a < 0x38800000u) {
+        float r = nearbyintf(u2f(a) * 16777216.0f);
+        return u2f(sign | f2u(r * (1.0f / 16777216.0f)));
+    }
+    uint32_t rem = a & 0x1FFFu, base = a & ~0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (base & 0x2000u))) base += 0x2000u;
+    return u2f(sign | base);
+}
+
+// General 4x4 inverse by cofactors in double, rounded to float once (XMMatrixInverse stand-in:
+// Renderer.cpp:1735-1736, 2101-2118).
+void mat4_inverse(const float* mf, float* out) {
+    double m[16], inv[16];
+    for (int i = 0; i < 16; i++) m[i] = (double)mf[i];
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    double id = 1.0 / det;
+    for (int i = 0; i < 16; i++) out[i] = (float)(inv[i] * id);
+}
+
+// objectToWorldNormal = transpose(inverse(upper 3x3, rest identity)): Renderer.cpp:2104-2116
+void normal_matrix(const float* o2w, float* out) {
+    float u[16], inv[16];
+    memcpy(u, o2w, 64);
+    u[3] = u[7] = u[11] = 0.0f; u[12] = u[13] = u[14] = 0.0f; u[15] = 1.0f;
+    mat4_inverse(u, inv);
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) out[c * 4 + r] = inv[r * 4 + c];
+}
+
+bool SceneHost::set_materials(const void* mats, uint32_t count) {
+    if (!mats && count) { err = "materials pointer is null"; return false; }
+    mats128.assign((const float*)mats, (const float*)mats + (size_t)count * 32);
+    return true;
+}
+
+bool SceneHost::add_mesh(const void* verts28, uint32_t nverts, const uint32_t* idx, uint32_t nidx, const uint32_t* mids, uint32_t* out) {
+    if (!verts28 || !idx || !mids) { err = "add_mesh: null array"; return false; }
+    if (nidx % 3) { err = "add_mesh: index count is not a multiple of 3"; return false; }
+    const float* v = (const float*)verts28;
+    for (uint32_t i = 0; i < nidx; i++) if (idx[i] >= nverts) { err = "add_mesh: index out of range"; return false; }
+    // Vertex.normal.w is the model's base offset inside the global materialIDs[] (ObjLoader.h:466; Hit_v6.hlsl:17)
+    for (uint32_t i = 0; i < nverts; i++)
+        if ((uint32_t)v[(size_t)i * 7 + 6] != (uint32_t)matids.size()) { err = "add_mesh: Vertex.normal.w != materialIDs base offset of this mesh"; return false; }
+    MeshHost m;
+    m.verts.assign(v, v + (size_t)nverts * 7);
+    m.idx.assign(idx, idx + nidx);
+    m.matid_base = (uint32_t)matids.size();
+    matids.insert(matids.end(), mids, mids + nidx);
+    if (out) *out = (uint32_t)meshes.size();
+    meshes.push_back(std::move(m));
+    return true;
+}
+
+bool SceneHost::add_instance(uint32_t mesh, const float* o2w, uint32_t* out) {
+    if (mesh >= meshes.size()) { err = "add_instance: unknown mesh"; return false; }
+    InstHost in; in.mesh = mesh; memcpy(in.o2w, o2w, 64); normal_matrix(o2w, in.nrm); in.tri_base = 0;
+    if (out) *out = (uint32_t)insts.size();
+    insts.push_back(in);
+    return true;
+}
+
+bool SceneHost::set_instance_transform(uint32_t inst, const float* o2w) {
+    if (inst >= insts.size()) { err = "set_instance_transform: unknown instance"; return false; }
+    memcpy(insts[inst].o2w, o2w, 64); normal_matrix(o2w, insts[inst].nrm);
+    return true;
+}
+
+static inline f3 vpos(const MeshHost& m, uint32_t vi) { const float* p = &m.verts[(size_t)vi * 7]; return mk3(p[0], p[1], p[2]); }
+static inline f3 vnrm(const MeshHost& m, uint32_t vi) { const float* p = &m.verts[(size_t)vi * 7]; return mk3(p[3], p[4], p[5]); }
+
+bool SceneHost::build(BuiltScene& B) {
+    const uint32_t nmat = (uint32_t)(mats128.size() / 32);
+    // ---- materials: MaterialOptimized rounding (Common_v6.hlsl:62-74) ----
+    B.mats.resize(nmat);
+    for (uint32_t i = 0; i < nmat; i++) {
+        const float* m = &mats128[(size_t)i * 32];   // Kd[4] Ks[3] Ni Ke[3] pad Pr_Pm_Ps_Pc[4] LUT[16]
+        MatGPU& g = B.mats[i];
+        for (int k = 0; k < 3; k++) { g.Kd[k] = half_round(m[k]); g.Ks[k] = half_round(m[4 + k]); g.Ke[k] = half_round(m[8 + k]); }
+        g.alpha = half_round(m[3]); g.Pr = half_round(m[12]); g.Pm = half_round(m[13]); g.Ps = half_round(m[14]); g.Pc = half_round(m[15]); g.pad = 0.0f;
+        g.Ke_len = length(mk3(g.Ke[0], g.Ke[1], g.Ke[2]));
+        memcpy(g.LUT, m + 16, 64);
+    }
+    // ---- flatten instances to world-space triangles; per-triangle shade records (Hit_v6.hlsl:12-61) ----
+    uint32_t nt = 0;
+    for (auto& in : insts) { in.tri_base = nt; nt += (uint32_t)(meshes[in.mesh].idx.size() / 3); }
+    std::vector<float> wtri((size_t)nt * 9);
+    B.shade.resize(nt);
+    B.insts.resize(insts.size());
+    float scale = 1.0f;
+    for (size_t ii = 0; ii < insts.size(); ii++) {
+        const InstHost& in = insts[ii]; const MeshHost& m = meshes[in.mesh];
+        memcpy(B.insts[ii].o2w, in.o2w, 64); memcpy(B.insts[ii].nrm, in.nrm, 64);
+        for (uint32_t t = 0; t < m.idx.size() / 3; t++) {
+            uint32_t g = in.tri_base + t;
+            uint32_t i0 = m.idx[t * 3], i1 = m.idx[t * 3 + 1], i2 = m.idx[t * 3 + 2];
+            const uint32_t vi[3] = {i0, i1, i2};
+            for (int k = 0; k < 3; k++) {
+                f3 w = xform_point(in.o2w, vpos(m, vi[k]));
+                wtri[(size_t)g * 9 + k * 3] = w.x; wtri[(size_t)g * 9 + k * 3 + 1] = w.y; wtri[(size_t)g * 9 + k * 3 + 2] = w.z;
+                scale = std::max(scale, std::max(fabsf(w.x), std::max(fabsf(w.y), fabsf(w.z))));
+            }
+            TriShade& s = B.shade[g];
+            uint32_t mi = m.matid_base + 3 * t;    // == 3*PrimitiveIndex() + uint(v0.normal.w), Hit_v6.hlsl:16-17
+            s.mat = mi < matids.size() ? matids[mi] : kMissMat;
+            s.inst = (uint32_t)ii;
+            f3 p0 = vpos(m, i0);
+            f3 cr = cross(vpos(m, i1) - p0, vpos(m, i2) - p0);      // :28-30
+            s.area = fabsf(length(cr) * 0.5f);                      // :31
+            f3 flat = normalize(cr);                                // :32
+            s.flat[0] = flat.x; s.flat[1] = flat.y; s.flat[2] = flat.z;
+            float* dst[3] = {s.n0, s.n1, s.n2};
+            for (int k = 0; k < 3; k++) {                           // :40-46 (all(n != 0) is per component)
+                f3 nk = vnrm(m, vi[k]);
+                f3 use = (nk.x != 0.0f && nk.y != 0.0f && nk.z != 0.0f) ? nk : flat;
+                dst[k][0] = use.x; dst[k][1] = use.y; dst[k][2] = use.z;
+            }
+            s.pad = 0.0f;
+        }
+    }
+    // ---- emissive triangle list + CDF: Renderer.cpp:2123-2233, 2237-2243 ----
+    struct Tmp { float w; uint32_t order; uint32_t inst; f3 p0, p1, p2; float em[3]; };
+    std::vector<Tmp> tmp;
+    for (size_t ii = 0; ii < insts.size(); ii++) {
+        const MeshHost& m = meshes[insts[ii].mesh];
+        for (uint32_t t = 0; t < m.idx.size() / 3; t++) {
+            uint32_t m0 = matids[m.matid_base + t * 3], m1 = matids[m.matid_base + t * 3 + 1], m2 = matids[m.matid_base + t * 3 + 2];
+            if (m0 != m1 || m0 != m2) continue;                      // :2153-2156
+            if (m0 >= nmat) continue;
+            const float* mat = &mats128[(size_t)m0 * 32];
+            if (!(mat[8] + mat[9] + mat[10] > 0.0f)) continue;       // :2162
+            Tmp L;
+            L.p0 = vpos(m, m.idx[t * 3]); L.p1 = vpos(m, m.idx[t * 3 + 1]); L.p2 = vpos(m, m.idx[t * 3 + 2]);
+            float area = 0.5f * length(cross(L.p1 - L.p0, L.p2 - L.p0));   // ComputeTriangleWeight :2217-2233
+            float inten = (mat[8] + mat[9] + mat[10]) / 3.0f;
+            L.w = area * inten; L.order = (uint32_t)tmp.size(); L.inst = (uint32_t)ii;
+            L.em[0] = mat[8]; L.em[1] = mat[9]; L.em[2] = mat[10];
+            tmp.push_back(L);
+        }
+    }
+    // :2187-2190 sorts descending by weight with std::sort (unstable); ties are broken here by collection order
+    std::sort(tmp.begin(), tmp.end(), [](const Tmp& a, const Tmp& b) { return a.w > b.w || (a.w == b.w && a.order < b.order); });
+    float total = 0.0f;
+    for (auto& L : tmp) total += L.w;
+    B.total_weight = total;
+    B.lights.resize(tmp.size()); B.lights80.assign(tmp.size() * 20, 0.0f);
+    float cum = 0.0f;
+    const uint32_t nl = (uint32_t)tmp.size();
+    for (size_t i = 0; i < tmp.size(); i++) {
+        Tmp& L = tmp[i];
+        float wn = L.w / total; cum += wn;
+        float cdf = (i + 1 == tmp.size()) ? 1.0f : cum;             // :2208-2210
+        float* r = &B.lights80[i * 20];
+        r[0] = L.p0.x; r[1] = L.p0.y; r[2] = L.p0.z; r[3] = cdf;
+        r[4] = L.p1.x; r[5] = L.p1.y; r[6] = L.p1.z; memcpy(&r[7], &L.inst, 4);
+        r[8] = L.p2.x; r[9] = L.p2.y; r[10] = L.p2.z; r[11] = wn;
+        r[12] = L.em[0]; r[13] = L.em[1]; r[14] = L.em[2]; memcpy(&r[15], &nl, 4);
+        r[16] = total;
+        // sample-independent part of SampleLightNEE_GI (Sampler_v6.hlsl:540-545, 566-575)
+        LightGPU& G = B.lights[i];
+        const float* M = insts[L.inst].o2w;
+        f3 xv = xform_point(M, L.p0), yv = xform_point(M, L.p1), zv = xform_point(M, L.p2);
+        f3 cl = cross(yv - xv, zv - xv);
+        f3 nrm = normalize(cl);
+        float area_l = fabsf(length(cl) * 0.5f);
+        G.xv[0] = xv.x; G.xv[1] = xv.y; G.xv[2] = xv.z; G.cdf = cdf;
+        G.yv[0] = yv.x; G.yv[1] = yv.y; G.yv[2] = yv.z; G.pdf_l = maxf_(kEps, wn / maxf_(area_l, kEps));
+        G.zv[0] = zv.x; G.zv[1] = zv.y; G.zv[2] = zv.z; G.pad0 = 0.0f;
+        G.em[0] = L.em[0]; G.em[1] = L.em[1]; G.em[2] = L.em[2]; G.pad1 = 0.0f;
+        G.nl[0] = nrm.x; G.nl[1] = nrm.y; G.nl[2] = nrm.z; G.pad2 = 0.0f;
+    }
+    // ---- BVH ----
+    std::vector<uint32_t> leaf_order;
+    build_bvh(wtri, 1e-6f * scale, B.nodes, leaf_order, B.max_depth);
+    B.tris.resize(leaf_order.size());
+    for (size_t s = 0; s < leaf_order.size(); s++) {
+        uint32_t g = leaf_order[s];
+        const float* t = &wtri[(size_t)g * 9];
+        f3 v0 = mk3(t[0], t[1], t[2]);
+        f3 e1 = mk3(t[3], t[4], t[5]) - v0, e2 = mk3(t[6], t[7], t[8]) - v0;
+        TriGPU& T = B.tris[s];
+        T.v0 = {v0.x, v0.y, v0.z, u2f(g)};
+        T.e1 = {e1.x, e1.y, e1.z, 0.0f};
+        T.e2 = {e2.x, e2.y, e2.z, 0.0f};
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// binned SAH BVH2 (16 bins, leaves of <= 4 triangles unless a split is impossible, hard cap 8)
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Box { float mn[3], mx[3]; };
+inline Box empty_box() { Box b; for (int a = 0; a < 3; a++) { b.mn[a] = INFINITY; b.mx[a] = -INFINITY; } return b; }
+inline void grow(Box& b, const Box& o) { for (int a = 0; a < 3; a++) { b.mn[a] = std::min(b.mn[a], o.mn[a]); b.mx[a] = std::max(b.mx[a], o.mx[a]); } }
+inline float half_area(const Box& b) {
+    float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+    if (dx < 0) return 0.0f;
+    return dx * dy + dy * dz + dz * dx;
+}
+struct TmpNode { Box box; int32_t left = -1, right = -1; uint32_t first = 0, count = 0; };
+}
+
+void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGPU>& nodes, std::vector<uint32_t>& order, uint32_t& max_depth) {
+    const uint32_t nt = (uint32_t)(wtri.size() / 9);
+    std::vector<Box> tb(nt); std::vector<float> cen((size_t)nt * 3);
+    for (uint32_t i = 0; i < nt; i++) {
+        const float* t = &wtri[(size_t)i * 9];
+        for (int a = 0; a < 3; a++) {
+            tb[i].mn[a] = std::min(t[a], std::min(t[3 + a], t[6 + a]));
+            tb[i].mx[a] = std::max(t[a], std::max(t[3 + a], t[6 + a]));
+            cen[(size_t)i * 3 + a] = 0.5f * (tb[i].mn[a] + tb[i].mx[a]);
+        }
+    }
+    order.resize(nt);
+    std::iota(order.begin(), order.end(), 0u);
+    std::vector<TmpNode> tn; tn.reserve((size_t)2 * nt + 2);
+    max_depth = 0;
+    struct Job { int32_t node; uint32_t first, count, depth; };
+    std::vector<Job> st;
+    tn.emplace_back();
+    st.push_back({0, 0u, nt, 0u});
+    constexpr int NB = 16;
+    while (!st.empty()) {
+        Job j = st.back(); st.pop_back();
+        max_depth = std::max(max_depth, j.depth);
+        Box nb = empty_box(), cb = empty_box();
+        for (uint32_t i = 0; i < j.count; i++) {
+            uint32_t g = order[j.first + i];
+            grow(nb, tb[g]);
+            for (int a = 0; a < 3; a++) { cb.mn[a] = std::min(cb.mn[a], cen[(size_t)g * 3 + a]); cb.mx[a] = std::max(cb.mx[a], cen[(size_t)g * 3 + a]); }
+        }
+        tn[j.node].box = nb;
+        auto make_leaf = [&]() { tn[j.node].first = j.first; tn[j.node].count = j.count; };
+        if (j.count <= 2) { make_leaf(); continue; }
+        // best binned split over 3 axes
+        float best_cost = INFINITY; int best_axis = -1, best_bin = -1;
+        for (int a = 0; a < 3; a++) {
+            float lo = cb.mn[a], ext = cb.mx[a] - cb.mn[a];
+            if (!(ext > 0.0f)) continue;
+            Box bb[NB]; uint32_t bc[NB];
+            for (int b = 0; b < NB; b++) { bb[b] = empty_box(); bc[b] = 0; }
+            float k = (float)NB / ext;
+            for (uint32_t i = 0; i < j.count; i++) {
+                uint32_t g = order[j.first + i];
+                int b = (int)((cen[(size_t)g * 3 + a] - lo) * k); if (b >= NB) b = NB - 1; if (b < 0) b = 0;
+                grow(bb[b], tb[g]); bc[b]++;
+            }
+            float ra[NB]; uint32_t rc[NB]; Box acc = empty_box(); uint32_t c = 0;
+            for (int b = NB - 1; b > 0; b--) { grow(acc, bb[b]); c += bc[b]; ra[b] = half_area(acc); rc[b] = c; }
+            acc = empty_box(); c = 0;
+            for (int b = 0; b < NB - 1; b++) {
+                grow(acc, bb[b]); c += bc[b];
+                if (!c || !rc[b + 1]) continue;
+                float cost = half_area(acc) * (float)c + ra[b + 1] * (float)rc[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+            }
+        }
+        uint32_t mid = 0;
+        bool split = false;
+        if (best_axis >= 0) {
+            float leaf_cost = half_area(nb) * (float)j.count;
+            if (j.count > 4 || best_cost + half_area(nb) * 1.0f < leaf_cost) {
+                float lo = cb.mn[best_axis], k = (float)NB / (cb.mx[best_axis] - cb.mn[best_axis]);
+                auto it = std::partition(order.begin() + j.first, order.begin() + j.first + j.count, [&](uint32_t g) {
+                    int b = (int)((cen[(size_t)g * 3 + best_axis] - lo) * k); if (b >= NB) b = NB - 1; if (b < 0) b = 0;
+                    return b <= best_bin;
+                });
+                mid = (uint32_t)(it - (order.begin() + j.first));
+                split = mid > 0 && mid < j.count;
+            }
+        }
+        if (!split) {
+            if (j.count <= 8 && (best_axis < 0 || j.count <= 4)) { make_leaf(); continue; }
+            // degenerate (all centroids equal) or forced: median split by index
+            mid = j.count / 2;
+        }
+        int32_t l = (int32_t)tn.size(); tn.emplace_back();
+        int32_t r = (int32_t)tn.size(); tn.emplace_back();
+        tn[j.node].left = l; tn[j.node].right = r;
+        st.push_back({r, j.first + mid, j.count - mid, j.depth + 1});
+        st.push_back({l, j.first, mid, j.depth + 1});
+    }
+    // ---- breadth-first relayout with children boxes stored in the parent ----
+    nodes.clear();
+    auto enc_leaf = [](const TmpNode& n) -> int32_t { return (int32_t)~((n.first << 3) | (n.count - 1)); };
+    auto put_box = [&](NodeGPU& N, int which, const Box* b) {
+        float mn[3], mx[3];
+        for (int a = 0; a < 3; a++) { mn[a] = b ? b->mn[a] - pad_abs : INFINITY; mx[a] = b ? b->mx[a] + pad_abs : -INFINITY; }
+        if (which == 0) { N.a = {mn[0], mn[1], mn[2], mx[0]}; N.b.x = mx[1]; N.b.y = mx[2]; }
+        else { N.b.z = mn[0]; N.b.w = mn[1]; N.c = {mn[2], mx[0], mx[1], mx[2]}; }
+    };
+    if (nt == 0) {
+        NodeGPU N{}; put_box(N, 0, nullptr); put_box(N, 1, nullptr);
+        N.d = {u2f((uint32_t)kEmptyChild), u2f((uint32_t)kEmptyChild), 0.0f, 0.0f};
+        nodes.push_back(N); return;
+    }
+    if (tn[0].count) {   // root is a leaf: wrap it
+        NodeGPU N{}; put_box(N, 0, &tn[0].box); put_box(N, 1, nullptr);
+        N.d = {u2f((uint32_t)enc_leaf(tn[0])), u2f((uint32_t)kEmptyChild), 0.0f, 0.0f};
+        nodes.push_back(N); return;
+    }
+    std::vector<int32_t> bfs; bfs.push_back(0);            // internal nodes only
+    std::vector<int32_t> gpu_index(tn.size(), -1);
+    for (size_t h = 0; h < bfs.size(); h++) {
+        const TmpNode& n = tn[bfs[h]];
+        gpu_index[bfs[h]] = (int32_t)h;
+        if (!tn[n.left].count) bfs.push_back(n.left);
+        if (!tn[n.right].count) bfs.push_back(n.right);
+    }
+    // second pass needs the final indices of children: recompute in the same order
+    nodes.resize(bfs.size());
+    {
+        std::vector<int32_t> idx_of(tn.size(), -1);
+        for (size_t h = 0; h < bfs.size(); h++) idx_of[bfs[h]] = (int32_t)h;
+        for (size_t h = 0; h < bfs.size(); h++) {
+            const TmpNode& n = tn[bfs[h]];
+            NodeGPU N{};
+            put_box(N, 0, &tn[n.left].box); put_box(N, 1, &tn[n.right].box);
+            int32_t c0 = tn[n.left].count ? enc_leaf(tn[n.left]) : idx_of[n.left];
+            int32_t c1 = tn[n.right].count ? enc_leaf(tn[n.right]) : idx_of[n.right];
+            N.d = {u2f((uint32_t)c0), u2f((uint32_t)c1), 0.0f, 0.0f};
+            nodes[h] = N;
+        }
+    }
+}
+
+}  // namespace rtx

@@ -1,0 +1,50 @@
+// rtx_scene_host.hpp — host-side scene state behind the C-ABI: what the reference's Renderer keeps in
+// m_materials / m_materialIDs / m_VB / m_IB / m_instances / m_emissiveTriangles (Renderer.h:100-141),
+// plus the BVH build that replaces the driver's BLAS/TLAS (Renderer.cpp:772-946).
+#pragma once
+#include <vector>
+#include <string>
+#include <stdint.h>
+#include "rtx_types.hpp"
+
+namespace rtx {
+
+float half_round(float x);                               // binary16 round trip (MaterialOptimized)
+void  mat4_inverse(const float* m16, float* out16);      // XMMatrixInverse stand-in
+void  normal_matrix(const float* o2w16, float* out16);   // Renderer.cpp:2104-2116
+
+struct MeshHost { std::vector<float> verts; std::vector<uint32_t> idx; uint32_t matid_base = 0; };
+struct InstHost { uint32_t mesh; float o2w[16]; float nrm[16]; uint32_t tri_base; };
+
+struct BuiltScene {
+    std::vector<MatGPU>   mats;
+    std::vector<NodeGPU>  nodes;
+    std::vector<TriGPU>   tris;       // leaf order
+    std::vector<TriShade> shade;      // global triangle id order
+    std::vector<InstGPU>  insts;
+    std::vector<LightGPU> lights;
+    std::vector<float>    lights80;   // reference-layout LightTriangle records (20 floats each)
+    float total_weight = 0.0f;
+    uint32_t max_depth = 0;
+};
+
+struct SceneHost {
+    std::vector<float> mats128;                 // count * 32 floats
+    std::vector<MeshHost> meshes;
+    std::vector<uint32_t> matids;               // global materialIDs[]
+    std::vector<InstHost> insts;
+    std::string err;
+
+    bool set_materials(const void* mats, uint32_t count);
+    bool add_mesh(const void* verts28, uint32_t nverts, const uint32_t* idx, uint32_t nidx, const uint32_t* matids, uint32_t* out);
+    bool add_instance(uint32_t mesh, const float* o2w, uint32_t* out);
+    bool set_instance_transform(uint32_t inst, const float* o2w);
+    bool build(BuiltScene& out);
+};
+
+// binned-SAH BVH2 over world-space triangles (9 floats each); fills nodes (breadth-first, children boxes in
+// parent) and the leaf-ordered triangle permutation.
+void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGPU>& nodes,
+               std::vector<uint32_t>& leaf_order, uint32_t& max_depth);
+
+}  // namespace rtx

@@ -1,0 +1,44 @@
+// Renderer.h — headless counterpart of the reference's Renderer class (Pathtracer/rdn/Renderer.h:46-51):
+// same construction and OnInit / OnUpdate / OnRender / OnDestroy life cycle, no window, no DX12.  Everything
+// the reference's Renderer feeds its shaders goes through the C-ABI of include/rtx.h instead.
+#pragma once
+#include <string>
+#include <vector>
+#include "Scenes.h"
+#include "manipulator.h"
+
+class Renderer {
+public:
+    Renderer(UINT width, UINT height, std::string name);
+    ~Renderer();
+    // headless configuration (the reference hard-codes these: Renderer.cpp:363, 46-48; Common_v6.hlsl:8-12)
+    void SetModels(const std::vector<std::string>& obj_files, const std::string& mtl_dir) { m_models = obj_files; m_mtlDir = mtl_dir; m_haveScene = false; }
+    void SetScene(const Scene& s) { m_scene = s; m_haveScene = true; }
+    void SetDevice(int ordinal) { m_device = ordinal; }
+    rtx_params& Params() { return m_params; }
+
+    void OnInit();      // Renderer.cpp:44-103: camera lookat, load models, build acceleration structures, upload
+    void OnUpdate();    // Renderer.cpp:431-452: camera buffer, instance 1 rotation, instance properties
+    void OnRender();    // Renderer.cpp:468-506 / 556-715: one frame = Params().spp samples per pixel, accumulated
+    void OnDestroy();   // Renderer.cpp:546-552
+
+    UINT GetWidth() const { return m_width; }
+    UINT GetHeight() const { return m_height; }
+    const std::string& GetTitle() const { return m_title; }
+    uint32_t FrameIndex() const { return m_time; }
+    std::vector<float> ReadAccumulation();          // gPermanentData (RGBA32F)
+    std::vector<uint8_t> ReadOutput();              // gOutput layer 0 (RGBA8, sRGB)
+    rtx_stats Stats();
+    rtx_ctx* Context() { return m_ctx; }
+private:
+    void UpdateCameraBuffer();                      // Renderer.cpp:1722-1768
+    void Check(int rc, const char* what);
+    UINT m_width, m_height; float m_aspectRatio; std::string m_title;
+    std::vector<std::string> m_models; std::string m_mtlDir;
+    Scene m_scene; bool m_haveScene = false;
+    int m_device = 0;
+    rtx_ctx* m_ctx = nullptr;
+    rtx_params m_params{};
+    uint32_t m_time = 0;                             // Renderer.h: m_time
+    float m_prevView[16]; bool m_havePrev = false;   // m_prevViewMatrix
+};

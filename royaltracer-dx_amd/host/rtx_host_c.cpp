@@ -1,0 +1,138 @@
+// rtx_host_c.cpp — C entry points of include/rtx_host.h over the C++ host layer.
+#include "../../include/rtx_host.h"
+#include <cstring>
+#include <exception>
+#include <stdexcept>
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include "../csrc/rtx_scene_host.hpp"
+#include "ObjLoader.h"
+#include "Renderer.h"
+#include "Scenes.h"
+#include "manipulator.h"
+
+struct rtxh_scene { Scene s; };
+struct rtxh_renderer { Renderer* r; };
+static thread_local std::string g_err;
+
+template <class F> static rtxh_scene* guarded(F&& f) {
+    try { rtxh_scene* h = new rtxh_scene(); h->s = f(); return h; }
+    catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+template <class F> static int guarded_rc(F&& f) {
+    try { f(); return RTX_OK; } catch (const std::exception& e) { g_err = e.what(); return RTX_ERR_INVALID; }
+}
+
+extern "C" {
+
+rtxh_scene* rtxh_scene_cornell(void) { return guarded([] { return MakeCornellBox(); }); }
+rtxh_scene* rtxh_scene_sponza_class(uint32_t t, uint32_t seed) { return guarded([=] { return MakeSponzaClass(t, seed); }); }
+rtxh_scene* rtxh_scene_bistro_class(uint32_t t, uint32_t seed) { return guarded([=] { return MakeBistroClass(t, seed); }); }
+rtxh_scene* rtxh_scene_from_obj(const char* const* files, uint32_t n, const char* mtl_dir) {
+    std::vector<std::string> f; for (uint32_t i = 0; i < n; i++) f.emplace_back(files[i]);
+    std::string dir = mtl_dir ? mtl_dir : "./";
+    return guarded([&] { return LoadObjScene(f, dir); });
+}
+void rtxh_scene_free(rtxh_scene* s) { delete s; }
+const char* rtxh_last_error(void) { return g_err.c_str(); }
+
+uint32_t rtxh_scene_num_materials(const rtxh_scene* s) { return (uint32_t)s->s.materials.size(); }
+const void* rtxh_scene_materials(const rtxh_scene* s) { return s->s.materials.data(); }
+uint32_t rtxh_scene_num_meshes(const rtxh_scene* s) { return (uint32_t)s->s.models.size(); }
+int rtxh_scene_mesh(const rtxh_scene* s, uint32_t i, const void** v, uint32_t* nv, const uint32_t** idx, uint32_t* nidx, const uint32_t** mids) {
+    if (i >= s->s.models.size()) return RTX_ERR_INVALID;
+    const SceneModel& m = s->s.models[i];
+    *v = m.vertices.data(); *nv = (uint32_t)m.vertices.size(); *idx = m.indices.data(); *nidx = (uint32_t)m.indices.size(); *mids = m.materialIDs.data();
+    return RTX_OK;
+}
+uint32_t rtxh_scene_num_instances(const rtxh_scene* s) { return (uint32_t)s->s.instances.size(); }
+int rtxh_scene_instance(const rtxh_scene* s, uint32_t i, uint32_t* mesh, float o2w[16]) {
+    if (i >= s->s.instances.size()) return RTX_ERR_INVALID;
+    *mesh = s->s.instances[i].model; memcpy(o2w, s->s.instances[i].transform.data(), 64);
+    return RTX_OK;
+}
+uint64_t rtxh_scene_num_triangles(const rtxh_scene* s) { return s->s.triangles(); }
+int rtxh_scene_camera(const rtxh_scene* s, float eye[3], float center[3], float up[3], float* fov, float* zn, float* zf) {
+    eye[0] = s->s.eye.x; eye[1] = s->s.eye.y; eye[2] = s->s.eye.z;
+    center[0] = s->s.center.x; center[1] = s->s.center.y; center[2] = s->s.center.z;
+    up[0] = s->s.up.x; up[1] = s->s.up.y; up[2] = s->s.up.z;
+    *fov = s->s.fovY_deg; *zn = s->s.zn; *zf = s->s.zf;
+    return RTX_OK;
+}
+int rtxh_scene_view_proj(const rtxh_scene* s, float aspect, float view[16], float proj[16]) { SceneViewProj(s->s, aspect, view, proj); return RTX_OK; }
+int rtxh_scene_upload(const rtxh_scene* s, rtx_ctx* c, float aspect) { return UploadScene(s->s, c, aspect); }
+
+void rtxh_lookat(const float e[3], const float c[3], const float u[3], float view[16]) {
+    nv_helpers_dx12::Manipulator m;
+    m.setLookat(XMFLOAT3(e), XMFLOAT3(c), XMFLOAT3(u));
+    memcpy(view, m.getMatrix(), 64);
+}
+void rtxh_perspective_fov_rh(float fovy, float aspect, float zn, float zf, float proj[16]) {
+    XMMATRIX P = XMMatrixPerspectiveFovRH(fovy, aspect, zn, zf); memcpy(proj, P.data(), 64);
+}
+void rtxh_generate_ess_lut(float roughness, float lut[16]) {
+    Material m(XMFLOAT4(1, 1, 1, 1), XMFLOAT4(roughness, 0, 0, 0)); GenerateEssLUT(m); memcpy(lut, m.LUT, 64);
+}
+void rtxh_mat4_inverse(const float m[16], float out[16]) { rtx::mat4_inverse(m, out); }
+float rtxh_half_round(float x) { return rtx::half_round(x); }
+
+int rtxh_bvh_check(const float* wt, uint32_t ntris, uint32_t* nodes_out, uint32_t* depth_out, uint32_t* max_leaf_out) {
+    std::vector<float> w(wt, wt + (size_t)ntris * 9);
+    std::vector<rtx::NodeGPU> nodes; std::vector<uint32_t> order; uint32_t depth = 0;
+    rtx::build_bvh(w, 0.0f, nodes, order, depth);
+    if (nodes_out) *nodes_out = (uint32_t)nodes.size();
+    if (depth_out) *depth_out = depth;
+    if (order.size() != ntris) return 1;
+    std::vector<uint8_t> seen(ntris, 0);
+    for (uint32_t g : order) { if (g >= ntris || seen[g]) return 2; seen[g] = 1; }
+    // walk the tree: every leaf triangle must lie inside every ancestor child box on the way down
+    struct It { int32_t child; float mn[3], mx[3]; };
+    std::vector<uint8_t> covered(ntris, 0);
+    uint32_t max_leaf = 0;
+    std::vector<It> st;
+    auto push_children = [&](const rtx::NodeGPU& N, const float* pmn, const float* pmx) {
+        It a, b;
+        a.child = (int32_t)rtx::f2u(N.d.x); b.child = (int32_t)rtx::f2u(N.d.y);
+        float amn[3] = {N.a.x, N.a.y, N.a.z}, amx[3] = {N.a.w, N.b.x, N.b.y}, bmn[3] = {N.b.z, N.b.w, N.c.x}, bmx[3] = {N.c.y, N.c.z, N.c.w};
+        for (int k = 0; k < 3; k++) { a.mn[k] = std::max(amn[k], pmn[k]); a.mx[k] = std::min(amx[k], pmx[k]); b.mn[k] = std::max(bmn[k], pmn[k]); b.mx[k] = std::min(bmx[k], pmx[k]); }
+        if (a.child != rtx::kEmptyChild) st.push_back(a);
+        if (b.child != rtx::kEmptyChild) st.push_back(b);
+    };
+    const float inf = INFINITY; float rmn[3] = {-inf, -inf, -inf}, rmx[3] = {inf, inf, inf};
+    push_children(nodes[0], rmn, rmx);
+    while (!st.empty()) {
+        It it = st.back(); st.pop_back();
+        if (it.child >= 0) { if ((size_t)it.child >= nodes.size()) return 3; push_children(nodes[it.child], it.mn, it.mx); continue; }
+        uint32_t v = ~(uint32_t)it.child, first = v >> 3, cnt = (v & 7u) + 1u;
+        max_leaf = std::max(max_leaf, cnt);
+        for (uint32_t k = 0; k < cnt; k++) {
+            if (first + k >= ntris) return 4;
+            uint32_t g = order[first + k];
+            if (covered[g]) return 5;
+            covered[g] = 1;
+            for (int vtx = 0; vtx < 3; vtx++) for (int a = 0; a < 3; a++) { float c = w[(size_t)g * 9 + vtx * 3 + a]; if (c < it.mn[a] || c > it.mx[a]) return 6; }
+        }
+    }
+    for (uint32_t i = 0; i < ntris; i++) if (!covered[i]) return 7;
+    if (max_leaf_out) *max_leaf_out = max_leaf;
+    return 0;
+}
+
+rtxh_renderer* rtxh_renderer_create(uint32_t w, uint32_t h, const char* name, int device) {
+    rtxh_renderer* r = new rtxh_renderer(); r->r = new Renderer(w, h, name ? name : "rtx"); r->r->SetDevice(device); return r;
+}
+int rtxh_renderer_set_scene(rtxh_renderer* r, const rtxh_scene* s) { r->r->SetScene(s->s); return RTX_OK; }
+rtx_params* rtxh_renderer_params(rtxh_renderer* r) { return &r->r->Params(); }
+int rtxh_renderer_on_init(rtxh_renderer* r) { return guarded_rc([&] { r->r->OnInit(); }); }
+int rtxh_renderer_on_update(rtxh_renderer* r) { return guarded_rc([&] { r->r->OnUpdate(); }); }
+int rtxh_renderer_on_render(rtxh_renderer* r) { return guarded_rc([&] { r->r->OnRender(); }); }
+int rtxh_renderer_read_accum(rtxh_renderer* r, float* out, size_t bytes) {
+    return guarded_rc([&] { auto v = r->r->ReadAccumulation(); if (bytes < v.size() * 4) throw std::runtime_error("buffer too small"); memcpy(out, v.data(), v.size() * 4); });
+}
+int rtxh_renderer_read_output(rtxh_renderer* r, uint8_t* out, size_t bytes) {
+    return guarded_rc([&] { auto v = r->r->ReadOutput(); if (bytes < v.size()) throw std::runtime_error("buffer too small"); memcpy(out, v.data(), v.size()); });
+}
+void rtxh_renderer_destroy(rtxh_renderer* r) { if (r) { delete r->r; delete r; } }
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+// rtx_render — headless CLI over the Renderer facade (replaces the Win32 window loop, Main.cpp:18-27).
+// usage: rtx_render [--scene cornell|sponza|bistro|obj] [--obj a.obj,b.obj --mtl dir] [--w 1920 --h 1080]
+//                   [--spp 64] [--frames 1] [--bounces 8] [--nee 1] [--lambert] [--out image.ppm] [--device 0]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include "Renderer.h"
+
+int main(int argc, char** argv) {
+    std::string scene = "cornell", out, objs, mtl = "./";
+    UINT w = 1920, h = 1080, spp = 1, frames = 1, bounces = 8, nee = 1; int device = 0; bool lambert = false;
+    for (int i = 1; i < argc; i++) {
+        auto arg = [&](const char* k) { return !strcmp(argv[i], k) && i + 1 < argc; };
+        if (arg("--scene")) scene = argv[++i]; else if (arg("--obj")) { objs = argv[++i]; scene = "obj"; } else if (arg("--mtl")) mtl = argv[++i];
+        else if (arg("--w")) w = atoi(argv[++i]); else if (arg("--h")) h = atoi(argv[++i]); else if (arg("--spp")) spp = atoi(argv[++i]);
+        else if (arg("--frames")) frames = atoi(argv[++i]); else if (arg("--bounces")) bounces = atoi(argv[++i]); else if (arg("--nee")) nee = atoi(argv[++i]);
+        else if (arg("--out")) out = argv[++i]; else if (arg("--device")) device = atoi(argv[++i]); else if (!strcmp(argv[i], "--lambert")) lambert = true;
+        else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
+    }
+    try {
+        Renderer r(w, h, "rtx_render");
+        r.SetDevice(device);
+        if (scene == "cornell") { r.SetScene(MakeCornellBox()); lambert = true; }
+        else if (scene == "sponza") r.SetScene(MakeSponzaClass());
+        else if (scene == "bistro") r.SetScene(MakeBistroClass());
+        else { std::vector<std::string> f; std::stringstream ss(objs); std::string t; while (std::getline(ss, t, ',')) f.push_back(t); r.SetModels(f, mtl); }
+        r.Params().spp = spp; r.Params().max_bounces = bounces; r.Params().nee_samples = nee; r.Params().flags = lambert ? RTX_FLAG_LAMBERT_ONLY : 0;
+        r.OnInit();
+        for (UINT f = 0; f < frames; f++) {
+            r.OnUpdate(); r.Params().sample_base = 1 + f * spp; r.OnRender();
+            rtx_stats s = r.Stats();
+            double rays = (double)(s.rays_primary + s.rays_extension + s.rays_shadow);
+            printf("frame %u: %.3f ms, %.1f Mrays/s (primary %llu, extension %llu, shadow %llu)\n", f, s.render_ms, rays / (s.render_ms * 1e3),
+                   (unsigned long long)s.rays_primary, (unsigned long long)s.rays_extension, (unsigned long long)s.rays_shadow);
+        }
+        if (!out.empty()) {
+            std::vector<uint8_t> px = r.ReadOutput();
+            std::ofstream f(out, std::ios::binary); f << "P6\n" << w << " " << h << "\n255\n";
+            for (size_t i = 0; i < (size_t)w * h; i++) f.write((const char*)&px[i * 4], 3);
+        }
+        r.OnDestroy();
+    } catch (const std::exception& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
+    return 0;
+}
