@@ -236,10 +236,12 @@ int rtx_clear_accum(rtx_ctx* c, uint32_t w, uint32_t h) {
 static int make_frame(rtx_ctx* c, const rtx_params* p, DevFrame& f) {
     if (!p || !p->width || !p->height) { c->err = "params: width/height must be non-zero"; return RTX_ERR_INVALID; }
     const uint32_t ts = p->tile_size ? p->tile_size : 64;
-    if (ts % 8 || ts > 1024) { c->err = "params: tile_size must be a multiple of 8 (<= 1024)"; return RTX_ERR_INVALID; }
+    if (ts < 16 || ts > 1024 || (ts & (ts - 1))) { c->err = "params: tile_size must be a power of two in [16, 1024]"; return RTX_ERR_INVALID; }
     const uint32_t cnt = p->shard_count ? p->shard_count : 1;
     if (p->shard_rank >= cnt) { c->err = "params: shard_rank >= shard_count"; return RTX_ERR_INVALID; }
     f.width = p->width; f.height = p->height; f.tile_size = ts;
+    f.tile_shift = 0; while ((1u << f.tile_shift) < ts) f.tile_shift++;
+    f.nblocks = 1; f.qcap = 0; f.chunks_per_sample = 0;
     f.tiles_x = (p->width + ts - 1) / ts; f.tiles_y = (p->height + ts - 1) / ts;
     f.shard_rank = p->shard_rank; f.shard_count = cnt;
     const uint32_t total = f.tiles_x * f.tiles_y;
@@ -247,6 +249,7 @@ static int make_frame(rtx_ctx* c, const rtx_params* p, DevFrame& f) {
     const uint64_t npl = (uint64_t)per * ts * ts;
     if (npl > 0x7FFFFFFFull) { c->err = "params: image too large"; return RTX_ERR_INVALID; }
     f.npl = (uint32_t)npl;
+    f.chunks_per_sample = f.npl / 256;          // tile_size >= 16 makes npl a multiple of 256
     f.batch_spp = 1; f.sample_first = p->sample_base;
     f.max_bounces = p->max_bounces; f.nee_samples = p->nee_samples; f.rr_start = p->rr_start;
     f.frame_seed = p->frame_seed; f.flags = p->flags;
@@ -286,17 +289,26 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     const uint32_t cap = (uint32_t)cap64;
     HIPCHK(c, c->d_ray_o.ensure((size_t)cap * 16)); HIPCHK(c, c->d_ray_d.ensure((size_t)cap * 16));
     HIPCHK(c, c->d_thr.ensure((size_t)cap * 16)); HIPCHK(c, c->d_rad.ensure((size_t)cap * 16)); HIPCHK(c, c->d_hit.ensure((size_t)cap * 16));
-    HIPCHK(c, c->d_queue[0].ensure((size_t)cap * 4)); HIPCHK(c, c->d_queue[1].ensure((size_t)cap * 4));
-    const size_t shn = (size_t)cap * std::max<uint32_t>(nee, 1);
+    // work distribution: G workgroups, each with a private sub-queue (no global atomics in the loop)
+    const uint32_t max_blocks = (uint32_t)c->num_cus * 8u;
+    const uint32_t nchunks = f.chunks_per_sample * bspp;
+    const uint32_t G = std::max<uint32_t>(1, std::min<uint32_t>(nchunks, (uint32_t)c->num_cus * 8u));
+    const uint32_t qcap = ((nchunks + G - 1) / G) * 256u;
+    f.nblocks = G; f.qcap = qcap;
+    const size_t qtot = (size_t)G * qcap;
+    HIPCHK(c, c->d_queue[0].ensure(qtot * 4)); HIPCHK(c, c->d_queue[1].ensure(qtot * 4));
+    const uint32_t nee1 = std::max<uint32_t>(nee, 1);
+    const size_t shn = qtot * nee1;
     HIPCHK(c, c->d_sh_o.ensure(shn * 16)); HIPCHK(c, c->d_sh_d.ensure(shn * 16)); HIPCHK(c, c->d_sh_c.ensure(shn * 16));
     DevPaths P;
     P.ray_o = (F4*)c->d_ray_o.p; P.ray_d = (F4*)c->d_ray_d.p; P.thr = (F4*)c->d_thr.p; P.rad = (F4*)c->d_rad.p; P.hit = (F4*)c->d_hit.p;
     P.sh_o = (F4*)c->d_sh_o.p; P.sh_d = (F4*)c->d_sh_d.p; P.sh_c = (F4*)c->d_sh_c.p;
     uint32_t* queue[2] = {(uint32_t*)c->d_queue[0].p, (uint32_t*)c->d_queue[1].p};
 
-    // counters of one batch: Q[0..mb] queue lengths entering each bounce, S[b*nee + j] shadow queue lengths
+    // per-workgroup counters of one batch: Q[b][G] queue lengths entering bounce b (b = 0..mb),
+    // S[b][j][G] shadow queue lengths; every workgroup stores its own entry, so nothing needs zeroing per batch
     const uint32_t mb = p->max_bounces;
-    const size_t ncnt = (size_t)(mb + 1) + (size_t)mb * std::max<uint32_t>(nee, 1);
+    const size_t ncnt = ((size_t)(mb + 1) + (size_t)mb * nee1) * G;
     const uint32_t nbatches = (p->spp + bspp - 1) / bspp;
     HIPCHK(c, c->d_counters.ensure(ncnt * 4));
     if (c->h_counters_words < ncnt * nbatches) {
@@ -306,24 +318,24 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
         c->h_counters_words = ncnt * nbatches;
     }
     uint32_t* cnt = (uint32_t*)c->d_counters.p;
-    const uint32_t max_blocks = (uint32_t)c->num_cus * 8u;
     const CameraGPU* cam = (const CameraGPU*)c->d_cam.p;
     c->ev_used = 0; c->timed.clear();
     hipStream_t st = c->stream;
+    auto Q = [&](uint32_t b) { return cnt + (size_t)b * G; };
+    auto S = [&](uint32_t b, uint32_t j) { return cnt + ((size_t)(mb + 1) + (size_t)b * nee1 + j) * G; };
 
     HIPCHK(c, hipEventRecord(c->ev_begin, st));
+    HIPCHK(c, hipMemsetAsync(cnt, 0, ncnt * 4, st));
     for (uint32_t bi = 0; bi < nbatches; bi++) {
         DevFrame fb = f;
         fb.sample_first = p->sample_base + bi * bspp;
         fb.batch_spp = std::min(bspp, p->spp - bi * bspp);
-        HIPCHK(c, hipMemsetAsync(cnt, 0, ncnt * 4, st));
-        { Timed t(c, RTX_K_RAYGEN); launch_raygen(st, max_blocks, fb, P, cam, queue[0], cnt + 0); }
+        { Timed t(c, RTX_K_RAYGEN); launch_raygen(st, fb, P, cam, queue[0], Q(0)); }
         for (uint32_t b = 0; b < mb; b++) {
             uint32_t* q = queue[b & 1]; uint32_t* qn = queue[(b + 1) & 1];
-            uint32_t* shc = cnt + (mb + 1) + (size_t)b * std::max<uint32_t>(nee, 1);
-            { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, max_blocks, cap, c->dsc, P, q, cnt + b); }
-            { Timed t(c, RTX_K_SHADE); launch_shade(st, max_blocks, cap, c->dsc, fb, P, b, q, cnt + b, qn, cnt + b + 1, shc); }
-            for (uint32_t j = 0; j < nee; j++) { Timed t(c, RTX_K_SHADOW); launch_trace_shadow(st, max_blocks, cap, c->dsc, P, j, shc + j); }
+            { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, fb, c->dsc, P, q, Q(b)); }
+            { Timed t(c, RTX_K_SHADE); launch_shade(st, c->dsc, fb, P, b, q, Q(b), qn, Q(b + 1), S(b, 0)); }
+            for (uint32_t j = 0; j < nee; j++) { Timed t(c, RTX_K_SHADOW); launch_trace_shadow(st, fb, c->dsc, P, j, S(b, j)); }
         }
         { Timed t(c, RTX_K_ACCUM); launch_accumulate(st, max_blocks, fb, P, c->accum_ptr()); }
         HIPCHK(c, hipMemcpyAsync(c->h_counters + (size_t)bi * ncnt, cnt, ncnt * 4, hipMemcpyDeviceToHost, st));
@@ -336,9 +348,11 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     for (const TimedLaunch& t : c->timed) { float m = 0.0f; if (hipEventElapsedTime(&m, t.a, t.b) == hipSuccess) c->stats.kernel_ms[t.cls] += m; }
     for (uint32_t bi = 0; bi < nbatches; bi++) {
         const uint32_t* h = c->h_counters + (size_t)bi * ncnt;
-        c->stats.rays_primary += h[0]; c->stats.paths += h[0];
-        for (uint32_t b = 1; b < mb; b++) c->stats.rays_extension += h[b];
-        for (uint32_t b = 0; b < mb; b++) for (uint32_t j = 0; j < nee; j++) c->stats.rays_shadow += h[(mb + 1) + (size_t)b * std::max<uint32_t>(nee, 1) + j];
+        auto sumG = [&](size_t row) { uint64_t s = 0; for (uint32_t g = 0; g < G; g++) s += h[row * G + g]; return s; };
+        const uint64_t prim = sumG(0);
+        c->stats.rays_primary += prim; c->stats.paths += prim;
+        for (uint32_t b = 1; b < mb; b++) c->stats.rays_extension += sumG(b);
+        for (uint32_t b = 0; b < mb; b++) for (uint32_t j = 0; j < nee; j++) c->stats.rays_shadow += sumG((size_t)(mb + 1) + (size_t)b * nee1 + j);
     }
     c->stats.kernel_items[RTX_K_RAYGEN] = c->stats.paths;
     c->stats.kernel_items[RTX_K_TRACE] = c->stats.rays_primary + c->stats.rays_extension;

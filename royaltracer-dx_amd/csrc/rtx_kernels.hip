@@ -16,21 +16,24 @@
 namespace rtx {
 
 constexpr int kBlock = 256;
+constexpr uint32_t kMaxNee = 16;
 
 // ---------------------------------------------------------------------------------------------
 // wave-level helpers
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// Stream compaction: every lane of the wave must call this (convergent).  Returns the slot for lanes
-// with pred set.  One atomicAdd per wave.
-__device__ __forceinline__ uint32_t wave_push(bool pred, uint32_t* counter) {
+// Stream compaction into a WORKGROUP-PRIVATE sub-queue: every lane of the wave must call this (convergent).
+// The counter lives in LDS (one ds_add per wave); there are no global atomics anywhere in the render loop —
+// a single global counter saturates at ~88 returning atomics/us on MI355X and was the first bottleneck found
+// (profiles/r01_cornell_c2_v1.md).
+__device__ __forceinline__ uint32_t block_push(bool pred, uint32_t* lds_counter) {
     const unsigned long long mask = __ballot(pred);
     const uint32_t cnt = (uint32_t)__popcll(mask);
     if (cnt == 0) return 0xFFFFFFFFu;                    // wave-uniform
     const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     uint32_t base = 0;
-    if (lane_id() == 0) base = atomicAdd(counter, cnt);
+    if (lane_id() == 0) base = atomicAdd(lds_counter, cnt);
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     return base + prefix;
 }
@@ -42,16 +45,16 @@ __device__ __forceinline__ F4 ld4(const F4* p) { return *p; }
 // covers a compact screen region)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool slot_to_pixel(const DevFrame& f, uint32_t pl, uint32_t& x, uint32_t& y) {
-    const uint32_t tpix = f.tile_size * f.tile_size;
-    const uint32_t k = pl / tpix, r = pl - k * tpix;
+    const uint32_t ts2 = 2u * f.tile_shift;                  // tile_size is a power of two
+    const uint32_t k = pl >> ts2, r = pl & ((1u << ts2) - 1u);
     const uint32_t t = f.shard_rank + k * f.shard_count;
     if (t >= f.tiles_x * f.tiles_y) return false;
-    const uint32_t tx = t % f.tiles_x, ty = t / f.tiles_x;
-    const uint32_t bpr = f.tile_size >> 3;
+    const uint32_t ty = t / f.tiles_x, tx = t - ty * f.tiles_x;
+    const uint32_t bshift = f.tile_shift - 3u;               // 8x8 pixel blocks per tile row = 2^bshift
     const uint32_t blk = r >> 6, ln = r & 63u;
-    const uint32_t bx = blk % bpr, by = blk / bpr;
-    x = tx * f.tile_size + bx * 8u + (ln & 7u);
-    y = ty * f.tile_size + by * 8u + (ln >> 3);
+    const uint32_t bx = blk & ((1u << bshift) - 1u), by = blk >> bshift;
+    x = (tx << f.tile_shift) + bx * 8u + (ln & 7u);
+    y = (ty << f.tile_shift) + by * 8u + (ln >> 3);
     return x < f.width && y < f.height;
 }
 
@@ -71,31 +74,35 @@ __device__ __forceinline__ void primary_ray(const CameraGPU& cam, uint32_t W, ui
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_raygen(DevFrame f, DevPaths p, const CameraGPU* __restrict__ cam_p, uint32_t* __restrict__ queue, uint32_t* __restrict__ qcount) {
     __shared__ CameraGPU cam;
+    __shared__ uint32_t s_n;
     if (threadIdx.x < 32) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
+    if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    const uint32_t npaths = f.npl * f.batch_spp;
-    const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t base = blockIdx.x * kBlock + (threadIdx.x & ~63u); base < npaths; base += stride) {
-        const uint32_t pid = base + (threadIdx.x & 63u);
-        bool valid = pid < npaths;
+    uint32_t* myq = queue + (size_t)blockIdx.x * f.qcap;
+    // chunk c = 256 consecutive path slots of ONE sample; chunks are dealt round-robin to workgroups so that
+    // every workgroup's sub-queue holds a representative sample of the image (load balance across bounces)
+    const uint32_t nchunks = f.chunks_per_sample * f.batch_spp;
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const uint32_t sl = c / f.chunks_per_sample, cl = c - sl * f.chunks_per_sample;   // wave-uniform (SALU)
+        const uint32_t pl = cl * kBlock + threadIdx.x;
+        const uint32_t pid = sl * f.npl + pl;
         uint32_t x = 0, y = 0;
+        const bool valid = slot_to_pixel(f, pl, x, y);
         if (valid) {
-            const uint32_t sl = pid / f.npl, pl = pid - sl * f.npl;
-            valid = slot_to_pixel(f, pl, x, y);
-            if (valid) {
-                uint32_t s0, s1; seed_init(x, y, f.sample_first + sl, f.frame_seed, s0, s1);
-                float jx = 0.0f, jy = 0.0f;
-                if (f.flags & 2u) { jx = tea_next(s0, s1); jy = tea_next(s0, s1); }   // RayGen.hlsl:84-85
-                f3 o, d; primary_ray(cam, f.width, f.height, x, y, jx, jy, o, d);
-                p.ray_o[pid] = {o.x, o.y, o.z, kTMinCam};
-                p.ray_d[pid] = {d.x, d.y, d.z, 1.0f};
-                p.thr[pid] = {1.0f, 1.0f, 1.0f, u2f(s0)};
-                p.rad[pid] = {0.0f, 0.0f, 0.0f, u2f(s1)};
-            }
+            uint32_t s0, s1; seed_init(x, y, f.sample_first + sl, f.frame_seed, s0, s1);
+            float jx = 0.0f, jy = 0.0f;
+            if (f.flags & 2u) { jx = tea_next(s0, s1); jy = tea_next(s0, s1); }   // RayGen.hlsl:84-85
+            f3 o, d; primary_ray(cam, f.width, f.height, x, y, jx, jy, o, d);
+            p.ray_o[pid] = {o.x, o.y, o.z, kTMinCam};
+            p.ray_d[pid] = {d.x, d.y, d.z, 1.0f};
+            p.thr[pid] = {1.0f, 1.0f, 1.0f, u2f(s0)};
+            p.rad[pid] = {0.0f, 0.0f, 0.0f, u2f(s1)};
         }
-        const uint32_t slot = wave_push(valid, qcount);
-        if (valid) queue[slot] = pid;
+        const uint32_t slot = block_push(valid, &s_n);
+        if (valid) myq[slot] = pid;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) qcount[blockIdx.x] = s_n;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -199,16 +206,16 @@ __device__ __forceinline__ void traverse(const DevScene& sc, const TraceLds& L, 
     }
 }
 
-// closest hit for every queued path: reads ray_o/ray_d, writes hit
-__global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount) {
+// closest hit for every path in this workgroup's sub-queue: reads ray_o/ray_d, writes hit
+__global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap) {
     extern __shared__ F4 lds[];
-    const uint32_t n = *qcount;
-    if (blockIdx.x * kBlock >= n) return;
+    const uint32_t n = qcount[blockIdx.x];
+    if (n == 0) return;
     const TraceLds L = stage_lds(sc, lds);
     __syncthreads();
-    const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const uint32_t pid = queue[i];
+    const uint32_t* myq = queue + (size_t)blockIdx.x * qcap;
+    for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+        const uint32_t pid = myq[i];
         const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
         float t, u, v; uint32_t prim;
         traverse<false>(sc, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, kTMax, t, u, v, prim);
@@ -216,21 +223,22 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, DevPaths 
     }
 }
 
-// any-hit for NEE slot j: visible contributions are added to the path's radiance (one thread per path)
+// any-hit for NEE slot j: visible contributions are added to the path's radiance (a path appears at most once
+// per slot, so the read-modify-write needs no atomic and the order of additions per path is fixed)
 __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, DevPaths p, const F4* __restrict__ sh_o, const F4* __restrict__ sh_d,
-                                                         const F4* __restrict__ sh_c, const uint32_t* __restrict__ shcount) {
+                                                         const F4* __restrict__ sh_c, const uint32_t* __restrict__ shcount, uint32_t qcap) {
     extern __shared__ F4 lds[];
-    const uint32_t n = *shcount;
-    if (blockIdx.x * kBlock >= n) return;
+    const uint32_t n = shcount[blockIdx.x];
+    if (n == 0) return;
     const TraceLds L = stage_lds(sc, lds);
     __syncthreads();
-    const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const F4 so = sh_o[i], sd = sh_d[i];
+    const size_t qb = (size_t)blockIdx.x * qcap;
+    for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+        const F4 so = sh_o[qb + i], sd = sh_d[qb + i];
         float t, u, v; uint32_t prim;
         traverse<true>(sc, L, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, t, u, v, prim);
         if (prim == kMissPrim) {
-            const F4 c = sh_c[i];
+            const F4 c = sh_c[qb + i];
             const uint32_t pid = f2u(c.w);
             F4 r = p.rad[pid];
             r.x = r.x + c.x; r.y = r.y + c.y; r.z = r.z + c.z;
@@ -267,13 +275,18 @@ __device__ __forceinline__ Surf surface(const DevScene& sc, f3 o, f3 d, float t,
 __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPaths p, uint32_t bounce,
                                                   const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount,
                                                   uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count,
-                                                  uint32_t* __restrict__ shcounts /* [nee] */) {
-    const uint32_t n = *qcount;
-    const uint32_t stride = gridDim.x * kBlock;
+                                                  uint32_t* __restrict__ shcounts /* [nee][gridDim.x] */) {
+    __shared__ uint32_t s_cnt[1 + kMaxNee];                 // [0] next-queue length, [1 + j] shadow queue j length
+    if (threadIdx.x <= kMaxNee) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t n = qcount[blockIdx.x];
     const uint32_t flags = f.flags;
     const uint32_t nee = sc.nlights ? f.nee_samples : 0u;
     const bool last = (bounce + 1u == f.max_bounces);
-    for (uint32_t base = blockIdx.x * kBlock + (threadIdx.x & ~63u); base < n; base += stride) {
+    const size_t qb = (size_t)blockIdx.x * f.qcap;
+    const uint32_t* myq = queue + qb;
+    uint32_t* mynext = next_queue + qb;
+    for (uint32_t base = threadIdx.x & ~63u; base < n; base += kBlock) {
         const uint32_t i = base + (threadIdx.x & 63u);
         bool active = i < n;
         uint32_t pid = 0;
@@ -283,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPa
         F4 radv = {0, 0, 0, 0};
         bool shading = false;
         if (active) {
-            pid = queue[i];
+            pid = myq[i];
             const F4 h = p.hit[pid];
             const uint32_t prim = f2u(h.w);
             if (prim != kMissPrim) {                                          // miss: Miss.hlsl:3-11 -> black, terminate
@@ -356,9 +369,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPa
                     }
                 }
             }
-            const uint32_t cap = f.npl * f.batch_spp;
-            const uint32_t slot = wave_push(push, shcounts + j);
-            if (push) { p.sh_o[(size_t)j * cap + slot] = so; p.sh_d[(size_t)j * cap + slot] = sd; p.sh_c[(size_t)j * cap + slot] = scn; }
+            const size_t seg = (size_t)j * f.qcap * gridDim.x + qb;      // NEE slot j, this workgroup's sub-queue
+            const uint32_t slot = block_push(push, &s_cnt[1 + j]);
+            if (push) { p.sh_o[seg + slot] = so; p.sh_d[seg + slot] = sd; p.sh_c[seg + slot] = scn; }
         }
         // ---- BSDF sampling: Path_Sampler_v6.hlsl:205-229, Sampler_v6.hlsl:423-457,482-497 ----
         bool alive = false;
@@ -390,9 +403,12 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPa
             radv.w = u2f(s1);
             p.rad[pid] = radv;
         }
-        const uint32_t slot = wave_push(alive, next_count);
-        if (alive) next_queue[slot] = pid;
+        const uint32_t slot = block_push(alive, &s_cnt[0]);
+        if (alive) mynext[slot] = pid;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) next_count[blockIdx.x] = s_cnt[0];
+    if (threadIdx.x >= 1 && threadIdx.x <= nee) shcounts[(size_t)(threadIdx.x - 1) * gridDim.x + blockIdx.x] = s_cnt[threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -528,19 +544,19 @@ size_t trace_lds_bytes(const DevScene& sc) {
     return (size_t)sc.lds_nodes * 64 + (size_t)sc.lds_tris * 48 + (size_t)sc.stack_depth * kBlock * 4;
 }
 
-void launch_raygen(hipStream_t st, uint32_t max_blocks, const DevFrame& f, const DevPaths& p, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount) {
-    hipLaunchKernelGGL(k_raygen, dim3(grid_for(f.npl * f.batch_spp, max_blocks)), dim3(kBlock), 0, st, f, p, cam, queue, qcount);
+void launch_raygen(hipStream_t st, const DevFrame& f, const DevPaths& p, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount) {
+    hipLaunchKernelGGL(k_raygen, dim3(f.nblocks), dim3(kBlock), 0, st, f, p, cam, queue, qcount);
 }
-void launch_trace_closest(hipStream_t st, uint32_t max_blocks, uint32_t cap, const DevScene& sc, const DevPaths& p, const uint32_t* queue, const uint32_t* qcount) {
-    hipLaunchKernelGGL(k_trace_closest, dim3(grid_for(cap, max_blocks)), dim3(kBlock), trace_lds_bytes(sc), st, sc, p, queue, qcount);
+void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, const uint32_t* queue, const uint32_t* qcount) {
+    hipLaunchKernelGGL(k_trace_closest, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, p, queue, qcount, f.qcap);
 }
-void launch_trace_shadow(hipStream_t st, uint32_t max_blocks, uint32_t cap, const DevScene& sc, const DevPaths& p, uint32_t j, const uint32_t* shcount) {
-    hipLaunchKernelGGL(k_trace_shadow, dim3(grid_for(cap, max_blocks)), dim3(kBlock), trace_lds_bytes(sc), st, sc, p,
-                       p.sh_o + (size_t)j * cap, p.sh_d + (size_t)j * cap, p.sh_c + (size_t)j * cap, shcount);
+void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t j, const uint32_t* shcount) {
+    const size_t seg = (size_t)j * f.qcap * f.nblocks;
+    hipLaunchKernelGGL(k_trace_shadow, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap);
 }
-void launch_shade(hipStream_t st, uint32_t max_blocks, uint32_t cap, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce,
+void launch_shade(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce,
                   const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts) {
-    hipLaunchKernelGGL(k_shade, dim3(grid_for(cap, max_blocks)), dim3(kBlock), 0, st, sc, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);
+    hipLaunchKernelGGL(k_shade, dim3(f.nblocks), dim3(kBlock), 0, st, sc, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);
 }
 void launch_accumulate(hipStream_t st, uint32_t max_blocks, const DevFrame& f, const DevPaths& p, F4* accum) {
     hipLaunchKernelGGL(k_accumulate, dim3(grid_for(f.npl, max_blocks)), dim3(kBlock), 0, st, f, p, accum);

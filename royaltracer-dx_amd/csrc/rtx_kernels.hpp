@@ -21,12 +21,14 @@ struct DevScene {
 // one sample batch of one frame
 struct DevFrame {
     uint32_t width, height;
-    uint32_t tile_size, tiles_x, tiles_y;
+    uint32_t tile_size, tile_shift, tiles_x, tiles_y;   // tile_size = 1 << tile_shift
     uint32_t shard_rank, shard_count;
     uint32_t npl;            // local pixel slots = tiles_per_shard * tile_size^2
     uint32_t batch_spp;      // samples in this batch
     uint32_t sample_first;   // sample id of the first one
     uint32_t max_bounces, nee_samples, rr_start, frame_seed, flags;
+    // work distribution: `nblocks` workgroups, each owning a private sub-queue of `qcap` entries
+    uint32_t nblocks, qcap, chunks_per_sample;   // chunks_per_sample = npl / 256
 };
 
 // per-path state, SoA float4 streams indexed by path slot (pid = s_local * npl + pl)
@@ -36,17 +38,17 @@ struct DevPaths {
     F4* thr;     // throughput.xyz, seed.x bits
     F4* rad;     // radiance.xyz, seed.y bits
     F4* hit;     // t, u, v, global triangle id bits
-    // shadow queues, one segment of `cap` entries per NEE sample slot
+    // shadow queues: [nee slot j][workgroup b][qcap] entries
     F4* sh_o;    // origin.xyz, tmin
     F4* sh_d;    // dir.xyz, tmax
     F4* sh_c;    // contribution.xyz, pid bits
 };
 
 size_t trace_lds_bytes(const DevScene& sc);
-void launch_raygen(hipStream_t, uint32_t max_blocks, const DevFrame&, const DevPaths&, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount);
-void launch_trace_closest(hipStream_t, uint32_t max_blocks, uint32_t cap, const DevScene&, const DevPaths&, const uint32_t* queue, const uint32_t* qcount);
-void launch_trace_shadow(hipStream_t, uint32_t max_blocks, uint32_t cap, const DevScene&, const DevPaths&, uint32_t j, const uint32_t* shcount);
-void launch_shade(hipStream_t, uint32_t max_blocks, uint32_t cap, const DevScene&, const DevFrame&, const DevPaths&, uint32_t bounce,
+void launch_raygen(hipStream_t, const DevFrame&, const DevPaths&, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount);
+void launch_trace_closest(hipStream_t, const DevFrame&, const DevScene&, const DevPaths&, const uint32_t* queue, const uint32_t* qcount);
+void launch_trace_shadow(hipStream_t, const DevFrame&, const DevScene&, const DevPaths&, uint32_t j, const uint32_t* shcount);
+void launch_shade(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, uint32_t bounce,
                   const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts);
 void launch_accumulate(hipStream_t, uint32_t max_blocks, const DevFrame&, const DevPaths&, F4* accum);
 void launch_srgb8(hipStream_t, const F4* accum, uint32_t npix, uint32_t* out);
