@@ -25,6 +25,7 @@ import __graft_entry__ as graft  # noqa: E402
 # by trace_shadow; 32 B per pixel-sample accumulation)
 ALG_BYTES = {"trace_closest": 48, "shade": 176, "trace_shadow": 48, "accumulate": 32, "raygen": 64}
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+TRAFFIC_PROFILE = "r01_cornell_c2_latest.json"   # written by tools/rocprof_summary.py from separate --pmc passes
 
 WORKLOADS = {
     # name: (scene ctor, width, height, spp, bounces, nee, flags)
@@ -64,15 +65,13 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-
     rt = graft.load_package()
+    from royaltracer_dx_amd import sharding
+    dist = None
+    if world > 1:
+        dist, rank, world = sharding.init_process_group("nccl", dev)     # backend "nccl" is RCCL on ROCm
     kind, W, H, spp, bounces, nee, flags = WORKLOADS[args.workload]
     scene = make_scene(rt, kind)
     ctx = rt.Context(local_rank)
@@ -97,7 +96,7 @@ def main():
         ctx.render(params)                                   # synchronous on the bound stream
         if world > 1:                                        # final framebuffer gather over xGMI (RCCL)
             ctx.pack_tiles(params, slab.data_ptr())
-            dist.all_gather_into_tensor(gathered, slab)
+            sharding.gather_slabs(dist, slab, gathered)
             ctx.unpack_tiles(params, gathered.data_ptr())
         return ctx.stats()
 
@@ -119,12 +118,10 @@ def main():
         rays += np.array([st.rays_primary, st.rays_extension, st.rays_shadow], dtype=np.float64)
     barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    r = torch.tensor(rays, dtype=torch.float64, device=dev)
+    dt_max, rays_all = dt, rays
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-    dt_max = float(t.item()); rays_all = r.cpu().numpy()
+        dt_max = sharding.max_over_ranks(dist, dt, dev)
+        rays_all = sharding.sum_over_ranks(dist, rays, dev)
     ms_per_step = dt_max * 1e3 / max(args.steps, 1)
     value = float(rays_all.sum()) / dt_max / 1e6 if dt_max > 0 else 0.0
 
@@ -138,8 +135,16 @@ def main():
             bytes_per_launch = ALG_BYTES[name] * kitems[k] / max(klaunch[k], 1)
             avg_ms = kms[k] / max(klaunch[k], 1)
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            traffic = None
+            try:    # HBM bytes per launch from the rocprofv3 PMC passes of this same command (tools/rocprof_summary.py)
+                prof = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)))
+                if args.workload == "cornell_1080p_64spp_8b" and world == 1:
+                    traffic = prof["kernels"]["k_" + name]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
             roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "alg_bytes_per_launch": round(bytes_per_launch),
                     "alg_bytes_per_item": ALG_BYTES[name], "items_per_launch": round(kitems[k] / max(klaunch[k], 1), 1),
                     "avg_launch_ms": round(avg_ms, 5), "launches": int(klaunch[k]),
                     "kernel_ms_by_class": {rt.KERNEL_NAMES[i]: round(float(kms[i]), 3) for i in rt.KERNEL_NAMES if klaunch[i] > 0}}

@@ -19,6 +19,15 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it with `make -C {_HERE}` (hipcc --offload-arch=gfx950) "
         "or `python -c 'import __graft_entry__ as g; g.build()'`.  There is no CPU fallback.")
 
+# PyTorch wheels bundle their own libamdhip64.so.7.  A process must hold ONE HIP runtime, otherwise the second
+# one to initialise sees no devices and stream / device-pointer interop (rtx_set_stream, rtx_bind_accum) is
+# meaningless.  Import torch first (when present) so that librtx_hip.so binds to the runtime torch uses.
+if os.environ.get("RTX_NO_TORCH_PRELOAD", "0") != "1":
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is optional: the library only needs the HIP runtime
+        pass
+
 lib = C.CDLL(LIB_PATH)
 
 RTX_OK = 0

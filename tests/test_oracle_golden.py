@@ -1,0 +1,257 @@
+"""CPU suite, part 1: the oracle against (a) independent re-derivations written here in numpy / pure
+Python, (b) the committed golden vectors, (c) physical properties of the math it restates."""
+import os
+import numpy as np
+import pytest
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "oracle_golden.npz"))
+
+
+# ---- independent known answers ----------------------------------------------------------------
+def tea_py(v0, v1):
+    """TEA-4 written from Common_v6.hlsl:119-138 with Python integers (hand-checkable)."""
+    M, s = 0xFFFFFFFF, 0
+    for _ in range(4):
+        s = (s + 0x9E3779B9) & M
+        v0 = (v0 + ((((v1 << 4) & M) + 0xA341316C & M) ^ ((v1 + s) & M) ^ (((v1 >> 5) + 0xC8013EA4) & M))) & M
+        v1 = (v1 + ((((v0 << 4) & M) + 0xAD90777D & M) ^ ((v0 + s) & M) ^ (((v0 >> 5) + 0x7E95761E) & M))) & M
+    return v0, v1
+
+
+def test_tea_matches_pure_python(orc):
+    for seed in [(0, 0), (1, 2), (0xDEADBEEF, 0x12345678), (0xFFFFFFFF, 0xFFFFFFFF)]:
+        vals, end = orc.tea(seed, 16)
+        v0, v1 = seed
+        for k in range(16):
+            v0, v1 = tea_py(v0, v1)
+            assert bits(vals[k]) == bits(np.float32(v0) / np.float32(4294967296.0))
+        assert end == (v0, v1)
+
+
+def test_tea_can_return_one(orc):
+    # float(v0) rounds to nearest: v0 >= 0xFFFFFF80 gives exactly 1.0f
+    assert np.float32(0xFFFFFF80) / np.float32(4294967296.0) == np.float32(1.0)
+
+
+def test_seed_formula(orc):
+    M = 0xFFFFFFFF
+    for x, y, s, t in [(0, 0, 1, 0), (1919, 1079, 1, 12345), (7, 3, 2, 0xFFFFFFFF), (123, 456, 64, 9)]:
+        e0 = ((y * 73856093) & M) ^ ((x * 19349663) & M) ^ ((s * 83492791) & M) ^ ((t * 293803) & M)
+        e1 = ((x * 37623481) & M) ^ ((y * 51964263) & M) ^ ((s * 68250729) & M) ^ ((t * 423977) & M)
+        assert orc.seed_init(x, y, s, t) == (e0, e1)
+
+
+def test_half_round_matches_numpy_float16(orc):
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.uniform(-70000, 70000, 2000), rng.uniform(-1, 1, 2000), 10.0 ** rng.uniform(-9, 5, 2000),
+                         [0.0, 0.6, 0.73, 5.0, 17.0, 65504.0, 65519.0, 65520.0, 1e-8, 6e-8, 2.0 ** -24, 2.0 ** -25, 3 * 2.0 ** -25]]).astype(np.float32)
+    with np.errstate(over="ignore"):
+        expect = xs.astype(np.float16).astype(np.float32)
+    got = np.array([orc.half_round(float(x)) for x in xs], np.float32)
+    assert np.array_equal(bits(got), bits(expect))
+
+
+def test_sincos_and_pow_accuracy(orc):
+    xs = np.linspace(0.0, 6.2831855, 4001, dtype=np.float32)
+    sc = np.array([orc.sincos(float(x)) for x in xs])
+    assert np.abs(sc[:, 0] - np.sin(xs.astype(np.float64))).max() < 3e-7
+    assert np.abs(sc[:, 1] - np.cos(xs.astype(np.float64))).max() < 3e-7
+    xs = np.concatenate([np.linspace(0.0032, 1.0, 500), np.linspace(1.0, 40.0, 200)]).astype(np.float32)
+    got = np.array([orc.pow_(float(x), 1.0 / 2.4) for x in xs])
+    assert np.abs(got / np.power(xs.astype(np.float64), 1.0 / 2.4) - 1.0).max() < 2e-6
+
+
+def test_mat4_inverse_vs_numpy(orc):
+    rng = np.random.default_rng(1)
+    for _ in range(50):
+        m = rng.normal(size=(4, 4)).astype(np.float32)
+        inv = orc.mat4_inverse(m.T.reshape(16)).reshape(4, 4).T      # column-major storage
+        assert np.allclose(inv, np.linalg.inv(m.astype(np.float64)), rtol=2e-4, atol=2e-5)
+
+
+def test_srgb8(orc):
+    acc = np.zeros((1, 6, 4), np.float32)
+    acc[0, :, 3] = 2.0
+    acc[0, 0, :3] = 0.0; acc[0, 1, :3] = 2.0 * 0.0031308; acc[0, 2, :3] = 2.0 * 0.5; acc[0, 3, :3] = 2.0 * 7.0
+    acc[0, 4, 0] = np.nan; acc[0, 5, 1] = np.inf
+    out = orc.srgb8(acc)[0]
+    lin = np.array([0.0, 0.0031308, 0.5, 1.0])
+    enc = np.where(lin <= 0.0031308, 12.92 * lin, 1.055 * lin ** (1 / 2.4) - 0.055)
+    assert np.array_equal(out[:4, 0], np.floor(enc * 255 + 0.5).astype(np.uint8))
+    assert tuple(out[4, :3]) == (255, 0, 255) and tuple(out[5, :3]) == (0, 255, 255)     # NaN -> magenta, Inf -> cyan
+    assert (out[:, 3] == 255).all()
+
+
+# ---- committed golden vectors ------------------------------------------------------------------
+def test_golden_tea(orc, gold):
+    for i in range(3):
+        vals, end = orc.tea(tuple(int(v) for v in gold[f"tea{i}_seed"]), 8)
+        assert np.array_equal(bits(vals), bits(gold[f"tea{i}_vals"])) and end == tuple(int(v) for v in gold[f"tea{i}_end"])
+
+
+@pytest.fixture(scope="module")
+def cornell_oracle(rt, orc, cornell):
+    return orc.Oracle().load(cornell, 16 / 9)
+
+
+@pytest.fixture(scope="module")
+def garage_scene(rt, golden_dir):
+    return rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")
+
+
+@pytest.fixture(scope="module")
+def garage_oracle(orc, garage_scene):
+    return orc.Oracle().load(garage_scene, 16 / 9)
+
+
+def test_golden_cornell_geometry(rt, cornell_oracle, gold):
+    o = cornell_oracle
+    assert np.array_equal(bits(o.lights()), bits(gold["cornell_lights"]))
+    rays = o.primary_rays(rt.Params(width=1920, height=1080), 1)
+    assert np.array_equal(bits(rays[[0, 960 + 540 * 1920, 1919 + 1079 * 1920]]), bits(gold["cornell_primary_pick"]))
+    r = gold["cornell_rays"]
+    for mode in (0, 1):                                # brute force and the oracle's BVH agree with the fixture
+        assert np.array_equal(bits(o.trace_closest(r, mode)), bits(gold["cornell_hits"]))
+        assert np.array_equal(o.trace_any(gold["cornell_shadow_rays"], mode), gold["cornell_shadow_occ"])
+    assert np.array_equal(bits(o.surface(r, gold["cornell_hits"])), bits(gold["cornell_surface"]))
+
+
+@pytest.mark.parametrize("tag,kw", [("c1", dict(spp=1, max_bounces=4)), ("c2", dict(spp=4, max_bounces=8))])
+def test_golden_cornell_images(rt, orc, cornell, gold, tag, kw):
+    o = orc.Oracle().load(cornell, 64 / 36)
+    acc, cnt = o.render(rt.Params(width=64, height=36, nee_samples=1, flags=1, **kw))
+    assert np.array_equal(bits(acc), bits(gold[f"cornell_{tag}_accum"]))
+    assert tuple(int(v) for v in gold[f"cornell_{tag}_rays"]) == cnt
+
+
+def test_golden_garage(rt, orc, garage_scene, garage_oracle, gold):
+    og = garage_oracle
+    assert len(og.lights()) == int(gold["garage_num_lights"][0])
+    assert np.array_equal(bits(og.lights()[:8]), bits(gold["garage_lights_head"]))
+    assert np.array_equal(bits(og.trace_closest(gold["garage_rays"], 0)), bits(gold["garage_hits"]))
+    assert np.array_equal(bits(og.trace_closest(gold["garage_rays"], 1)), bits(gold["garage_hits"]))
+    assert np.array_equal(bits(og.surface(gold["garage_rays"], gold["garage_hits"])), bits(gold["garage_surface"]))
+    for flags in (1, 0):
+        for mat in (1, 2, 5):
+            assert np.array_equal(bits(og.bsdf_eval(mat, flags, gold["bsdf_in_eval"])), bits(gold[f"bsdf_eval_f{flags}_m{mat}"]))
+            assert np.array_equal(bits(og.bsdf_sample(mat, flags, gold["bsdf_in_sample"])), bits(gold[f"bsdf_sample_f{flags}_m{mat}"]))
+    o2 = orc.Oracle().load(garage_scene, 64 / 36)
+    acc, cnt = o2.render(rt.Params(width=64, height=36, spp=2, max_bounces=6, nee_samples=2, flags=0))
+    assert np.array_equal(bits(acc), bits(gold["garage_accum"])) and tuple(int(v) for v in gold["garage_rays_count"]) == cnt
+
+
+# ---- properties --------------------------------------------------------------------------------
+def test_bvh_equals_brute_force_random_rays(rt, cornell_oracle, garage_oracle):
+    rng = np.random.default_rng(3)
+    for o, lo, hi in ((cornell_oracle, -0.3, 1.3), (garage_oracle, -6, 6)):
+        n = 20000
+        r = np.zeros((n, 8), np.float32)
+        r[:, 0:3] = rng.uniform(lo, hi, (n, 3)); d = rng.normal(size=(n, 3)); r[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+        r[:, 3], r[:, 7] = 1e-4, 1e4
+        assert np.array_equal(bits(o.trace_closest(r, 0)), bits(o.trace_closest(r, 1)))
+        r[:, 7] = 0.5 * (hi - lo)
+        assert np.array_equal(o.trace_any(r, 0), o.trace_any(r, 1))
+
+
+def test_axis_aligned_and_degenerate_rays(rt, cornell_oracle):
+    """zero direction components, rays along edges / in wall planes: BVH must still equal brute force"""
+    o = cornell_oracle
+    rays = []
+    for org in [(0.5, 0.5, -0.5), (0.5, 0.0, 0.5), (0.0, 0.5, 0.5), (0.5, 0.5, 0.5), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0)]:
+        for d in [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1), (1, 1, 0), (0, 1, 1), (1, 0, 1), (-1, 1, 0)]:
+            dn = np.array(d, np.float64) / np.linalg.norm(d)
+            rays.append(list(org) + [1e-4] + list(dn) + [1e4])
+    r = np.array(rays, np.float32)
+    assert np.array_equal(bits(o.trace_closest(r, 0)), bits(o.trace_closest(r, 1)))
+    assert np.array_equal(o.trace_any(r, 0), o.trace_any(r, 1))
+
+
+def test_empty_scene_and_no_lights(rt, orc):
+    class Empty:
+        materials = np.zeros((1, 32), np.float32); meshes = []; instances = []
+        def view_proj(self, aspect):
+            return rt.lookat((0, 0, 1), (0, 0, 0), (0, 1, 0)), rt.perspective_fov_rh(1.0, aspect, 0.1, 100.0)
+    o = orc.Oracle().load(Empty(), 1.0)
+    acc, cnt = o.render(rt.Params(width=8, height=8, spp=2, max_bounces=3))
+    assert cnt == (128, 0, 0) and not acc[..., :3].any() and (acc[..., 3] == 2).all()
+    assert o.num_triangles == 0 and len(o.lights()) == 0
+
+
+def test_lambert_sampling_is_cosine_weighted(rt, cornell_oracle):
+    """E[1/pdf] over the sampler = hemisphere solid angle 2*pi*(3.1415/pi): pdf uses PI = 3.1415 (Common_v6.hlsl:1)"""
+    o = cornell_oracle
+    rng = np.random.default_rng(4)
+    n = 40000
+    nrm = np.tile(np.array([[0.0, 0.6, 0.8]], np.float32), (n, 1)); wo = np.tile(np.array([[0.0, 1.0, 0.0]], np.float32), (n, 1))
+    seeds = rng.integers(0, 2**32, size=(n, 2), dtype=np.uint64).astype(np.uint32).view(np.float32)
+    s = o.bsdf_sample(1, 1, np.concatenate([nrm, wo, seeds], 1))
+    wi = s[:, :3]
+    assert np.allclose(np.linalg.norm(wi, axis=1), 1.0, atol=1e-5) and ((wi * nrm).sum(1) >= 0).all()
+    e = o.bsdf_eval(1, 1, np.concatenate([nrm, wo, wi], 1))
+    f, pdf = e[:, :3], e[:, 3]
+    cos = (wi * nrm).sum(1)
+    assert np.allclose(pdf, np.maximum(cos, 1e-6) / np.float32(3.1415), rtol=1e-5)
+    assert abs((1.0 / pdf).mean() / (2 * 3.1415) - 1.0) < 0.02                      # mean of 1/pdf = solid angle
+    kd = np.float32(np.float16(0.73))                                                # fp16-rounded Kd (MaterialOptimized)
+    assert np.allclose(f, kd / np.float32(3.1415), rtol=1e-6)
+    assert np.allclose((f[:, 0] * cos / pdf), kd, rtol=1e-4)                          # albedo estimator is exact for Lambert
+
+
+def test_ggx_mixture_is_finite_and_energy_bounded(rt, garage_oracle):
+    og = garage_oracle
+    rng = np.random.default_rng(5)
+    n = 20000
+    nrm = np.tile(np.array([[0.0, 1.0, 0.0]], np.float32), (n, 1))
+    wo = rng.normal(size=(n, 3)); wo[:, 1] = np.abs(wo[:, 1]) + 0.05; wo = (wo / np.linalg.norm(wo, axis=1, keepdims=True)).astype(np.float32)
+    seeds = rng.integers(0, 2**32, size=(n, 2), dtype=np.uint64).astype(np.uint32).view(np.float32)
+    for mat in (1, 2, 5):
+        s = og.bsdf_sample(mat, 0, np.concatenate([nrm, wo, seeds], 1))
+        wi = s[:, :3]
+        assert np.isfinite(wi).all() and ((wi * nrm).sum(1) >= -1e-6).all()
+        e = og.bsdf_eval(mat, 0, np.concatenate([nrm, wo, wi], 1))
+        assert np.isfinite(e).all() and (e[:, :4] >= 0).all()
+        assert np.allclose(e[:, 4] + e[:, 5], 1.0, atol=1e-6)                        # p_d + p_s = 1
+        w = e[:, :3] * (wi * nrm).sum(1)[:, None] / np.maximum(e[:, 3:4], 1e-12)
+        assert np.median(w) < 1.5                                                    # throughput weights are O(1)
+
+
+def test_light_list_follows_reference_rules(rt, garage_oracle, garage_scene):
+    L = garage_oracle.lights()
+    n = len(L)
+    assert n > 0 and (L.view(np.uint32)[:, 15] == n).all()                           # triCount on every record
+    w = L[:, 11]
+    assert (np.diff(w) <= 1e-12).all()                                               # sorted by weight, descending
+    assert abs(w.sum() - 1.0) < 1e-4 and L[-1, 3] == 1.0                             # normalised; last cdf forced to 1
+    assert np.allclose(np.cumsum(w)[:-1], L[:-1, 3], atol=1e-5)
+    assert (L[:, 12:15] == 5.0).all() and (L[:, 16] == L[0, 16]).all()               # `lights` material Ke = 5; totalWeight everywhere
+
+
+def test_progressive_accumulation_is_order_stable(rt, orc, cornell):
+    o = orc.Oracle().load(cornell, 48 / 27)
+    base = dict(width=48, height=27, max_bounces=5, nee_samples=1, flags=1)
+    one, _ = o.render(rt.Params(spp=4, **base))
+    two, _ = o.render(rt.Params(spp=1, sample_base=1, **base))
+    two, _ = o.render(rt.Params(spp=3, sample_base=2, **base), two)
+    assert np.array_equal(bits(one), bits(two))
+    o.set_threads(1); a1, _ = o.render(rt.Params(spp=2, **base))
+    o.set_threads(4); a4, _ = o.render(rt.Params(spp=2, **base))
+    assert np.array_equal(bits(a1), bits(a4))                                        # thread count does not change bits
+
+
+def test_shards_partition_the_image(rt, orc, cornell):
+    o = orc.Oracle().load(cornell, 100 / 60)
+    base = dict(width=100, height=60, spp=1, max_bounces=3, nee_samples=1, flags=1, tile_size=16)
+    whole, cw = o.render(rt.Params(**base))
+    parts = np.zeros_like(whole); tot = np.zeros(3, np.uint64)
+    for r in range(3):
+        a, c = o.render(rt.Params(shard_rank=r, shard_count=3, **base))
+        assert not (parts[..., 3] * a[..., 3]).any()                                 # disjoint ownership
+        parts += a; tot += np.array(c, np.uint64)
+    assert np.array_equal(bits(parts), bits(whole)) and tuple(int(v) for v in tot) == cw
