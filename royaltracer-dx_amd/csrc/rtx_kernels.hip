@@ -108,26 +108,32 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DevFrame f, DevPaths p, const
 // ---------------------------------------------------------------------------------------------
 // BVH traversal
 // ---------------------------------------------------------------------------------------------
+// LDS pointers carry their address space in the type: through a generic pointer hipcc emits flat_load /
+// flat_store for the staged nodes and the traversal stack instead of ds_read_b128 / ds_write_b32 (found with
+// SQ_INSTS_LDS vs SQ_INSTS_VMEM_RD in profiles/r01_pmc_v2.md).
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4f lds_v4f;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 struct TraceLds {
-    const F4* nodes;     // LDS copy of nodes [0, lds_nodes)
-    const F4* tris;      // LDS copy of tris  [0, lds_tris)
-    uint32_t* stack;     // [depth][kBlock]
+    const lds_v4f* nodes;   // LDS copy of nodes [0, lds_nodes)
+    const lds_v4f* tris;    // LDS copy of tris  [0, lds_tris)
+    lds_u32* stack;         // [depth][kBlock]
 };
 
 // stage the top of the BVH and the first triangles into LDS (coalesced 16-B copies)
-__device__ __forceinline__ TraceLds stage_lds(const DevScene& sc, F4* lds) {
+__device__ __forceinline__ TraceLds stage_lds(const DevScene& sc, F4* lds_generic) {
     TraceLds L;
-    F4* ln = lds; F4* lt = lds + (size_t)sc.lds_nodes * 4;
-    const F4* gn = (const F4*)sc.nodes; const F4* gt = (const F4*)sc.tris;
+    lds_v4f* ln = (lds_v4f*)lds_generic; lds_v4f* lt = ln + (size_t)sc.lds_nodes * 4;
+    const v4f* gn = (const v4f*)sc.nodes; const v4f* gt = (const v4f*)sc.tris;
     for (uint32_t i = threadIdx.x; i < sc.lds_nodes * 4u; i += kBlock) ln[i] = gn[i];
     for (uint32_t i = threadIdx.x; i < sc.lds_tris * 3u; i += kBlock) lt[i] = gt[i];
     L.nodes = ln; L.tris = lt;
-    L.stack = (uint32_t*)(lt + (size_t)sc.lds_tris * 3);
+    L.stack = (lds_u32*)(lt + (size_t)sc.lds_tris * 3);
     return L;
 }
 
 // Moeller-Trumbore with the fixed operation order shared with the oracle (a11).  Exclusive (tmin, tmax).
-__device__ __forceinline__ bool tri_test(f3 o, f3 d, F4 v0w, F4 e1w, F4 e2w, float tmin, float tmax, float& t, float& u, float& v) {
+__device__ __forceinline__ bool tri_test(f3 o, f3 d, v4f v0w, v4f e1w, v4f e2w, float tmin, float tmax, float& t, float& u, float& v) {
     const f3 v0 = mk3(v0w.x, v0w.y, v0w.z), e1 = mk3(e1w.x, e1w.y, e1w.z), e2 = mk3(e2w.x, e2w.y, e2w.z);
     const f3 p = cross(d, e2);
     const float det = dot(e1, p);
@@ -164,14 +170,14 @@ __device__ __forceinline__ void traverse(const DevScene& sc, const TraceLds& L, 
     const float dzs = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
     const f3 idir = mk3(__builtin_amdgcn_rcpf(dxs), __builtin_amdgcn_rcpf(dys), __builtin_amdgcn_rcpf(dzs));
     bt = tmax; bu = 0.0f; bv = 0.0f; bprim = kMissPrim;
-    uint32_t* stk = L.stack + threadIdx.x;
+    lds_u32* stk = L.stack + threadIdx.x;
     int sp = 0;
     int32_t cur = 0;
     while (true) {
         if (cur >= 0) {
-            F4 a, b, c, dd;
-            if ((uint32_t)cur < sc.lds_nodes) { const F4* n = L.nodes + (size_t)cur * 4; a = n[0]; b = n[1]; c = n[2]; dd = n[3]; }
-            else { const F4* n = (const F4*)(sc.nodes + cur); a = n[0]; b = n[1]; c = n[2]; dd = n[3]; }
+            v4f a, b, c, dd;
+            if ((uint32_t)cur < sc.lds_nodes) { const lds_v4f* n = L.nodes + (uint32_t)cur * 4u; a = n[0]; b = n[1]; c = n[2]; dd = n[3]; }
+            else { const v4f* n = (const v4f*)(sc.nodes + cur); a = n[0]; b = n[1]; c = n[2]; dd = n[3]; }
             float t0, t1;
             const bool h0 = box_test(a.x, a.y, a.z, a.w, b.x, b.y, o, idir, tmin, bt, t0);
             const bool h1 = box_test(b.z, b.w, c.x, c.y, c.z, c.w, o, idir, tmin, bt, t1);
@@ -189,9 +195,9 @@ __device__ __forceinline__ void traverse(const DevScene& sc, const TraceLds& L, 
             bool done = false;
             for (uint32_t k = 0; k < cnt; k++) {
                 const uint32_t slot = first + k;
-                F4 v0, e1, e2;
-                if (slot < sc.lds_tris) { const F4* t = L.tris + (size_t)slot * 3; v0 = t[0]; e1 = t[1]; e2 = t[2]; }
-                else { const F4* t = (const F4*)(sc.tris + slot); v0 = t[0]; e1 = t[1]; e2 = t[2]; }
+                v4f v0, e1, e2;
+                if (slot < sc.lds_tris) { const lds_v4f* t = L.tris + slot * 3u; v0 = t[0]; e1 = t[1]; e2 = t[2]; }
+                else { const v4f* t = (const v4f*)(sc.tris + slot); v0 = t[0]; e1 = t[1]; e2 = t[2]; }
                 float t, u, w;
                 if (tri_test(o, d, v0, e1, e2, tmin, tmax, t, u, w)) {
                     if (ANY) { bprim = 0u; done = true; break; }
