@@ -23,7 +23,8 @@ import __graft_entry__ as graft  # noqa: E402
 # algorithmic bytes per work item of each kernel (DESIGN.md "Bytes model"; SURVEY.md §8d:
 # 224 B per extension ray = 48 (trace) + 176 (shade); 96 B per shadow ray = 48 written by shade + 48 read
 # by trace_shadow; 32 B per pixel-sample accumulation)
-ALG_BYTES = {"trace_closest": 48, "shade": 176, "trace_shadow": 48, "accumulate": 32, "raygen": 64}
+ALG_BYTES = {"trace_closest": 48, "shade": 176, "trace_shadow": 48, "accumulate": 32, "raygen": 64,
+             "bounce_fused": 224}   # fused trace+shade+shadow kernel: 224 B per extension ray + 96 B per shadow ray it traces
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 TRAFFIC_PROFILE = "r01_cornell_c2_latest.json"   # written by tools/rocprof_summary.py from separate --pmc passes
 
@@ -133,6 +134,8 @@ def main():
             k = int(np.argmax(kms))
             name = rt.KERNEL_NAMES[k]
             bytes_per_launch = ALG_BYTES[name] * kitems[k] / max(klaunch[k], 1)
+            if name == "bounce_fused":
+                bytes_per_launch += 96.0 * rays[2] / max(klaunch[k], 1)
             avg_ms = kms[k] / max(klaunch[k], 1)
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             traffic = None

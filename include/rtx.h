@@ -58,7 +58,8 @@ typedef struct rtx_params {
 #define RTX_FLAG_JITTER       2u  /* legacy sub-pixel jitter (RayGen.hlsl:84-87); v6 shoots pixel corners (pass1:80-82) */
 
 /* kernel classes for rtx_stats */
-enum { RTX_K_RAYGEN = 0, RTX_K_TRACE = 1, RTX_K_SHADE = 2, RTX_K_SHADOW = 3, RTX_K_ACCUM = 4, RTX_K_SORT = 5, RTX_K_COUNT = 8 };
+enum { RTX_K_RAYGEN = 0, RTX_K_TRACE = 1, RTX_K_SHADE = 2, RTX_K_SHADOW = 3, RTX_K_ACCUM = 4, RTX_K_SORT = 5,
+       RTX_K_BOUNCE = 6 /* fused trace+shade+shadow kernel of the tiny-scene path */, RTX_K_COUNT = 8 };
 
 typedef struct rtx_stats {
     uint64_t rays_primary, rays_extension, rays_shadow;  /* BVH queries issued by the last rtx_render */
@@ -73,7 +74,9 @@ typedef struct rtx_stats {
 enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents (rtx_stats.kernel_ms) */
        RTX_OPT_PATHS_PER_BATCH = 2,  /* max pixel-samples in flight (queue capacity) */
        RTX_OPT_SORT_MATERIALS = 3,   /* 0/1: material-sorted shading queue */
-       RTX_OPT_LDS_NODES = 4         /* BVH nodes staged in LDS per workgroup (top of tree) */ };
+       RTX_OPT_LDS_NODES = 4,        /* BVH nodes staged in LDS per workgroup (top of tree) */
+       RTX_OPT_SMALL_SCENE = 5,      /* 0/1: brute-force pre-test path for scenes of <= 64 triangles (default 1) */
+       RTX_OPT_FUSED_BOUNCE = 6      /* 0/1: with SMALL_SCENE, fuse trace+shade+shadow into one kernel per bounce (default 1) */ };
 
 /* lifetime: replaces LoadPipeline/device creation (Renderer.cpp:106-254) and OnDestroy (:546-552) */
 int  rtx_create(int device_ordinal, rtx_ctx** out);

@@ -35,7 +35,7 @@ struct rtx_ctx {
     int num_cus = 256;
     SceneHost host; BuiltScene built;
     bool committed = false, camera_set = false;
-    DevBuf d_nodes, d_tris, d_shade, d_mats, d_insts, d_lights, d_cam;
+    DevBuf d_nodes, d_tris, d_small, d_shade, d_mats, d_insts, d_lights, d_cam;
     DevScene dsc{};
     float view[16], proj[16];
     // path state
@@ -46,7 +46,7 @@ struct rtx_ctx {
     DevBuf d_accum; void* ext_accum = nullptr; size_t ext_accum_bytes = 0; uint32_t acc_w = 0, acc_h = 0;
     DevBuf d_srgb;
     // options
-    bool timing = false; uint64_t paths_per_batch = 8u << 20; int sort_mats = 0; int lds_nodes_opt = -1;
+    bool timing = false; uint64_t paths_per_batch = 8u << 20; int sort_mats = 0; int lds_nodes_opt = -1; bool small_scene = true; bool fused = true;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     std::vector<TimedLaunch> timed;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -98,7 +98,7 @@ void rtx_destroy(rtx_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
+    DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
                      &c->d_thr, &c->d_rad, &c->d_hit, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
                      &c->d_accum, &c->d_srgb};
     for (DevBuf* b : all) b->release();
@@ -119,6 +119,8 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_PATHS_PER_BATCH: if (value < 4096) { c->err = "paths_per_batch must be >= 4096"; return RTX_ERR_INVALID; } c->paths_per_batch = (uint64_t)value; return RTX_OK;
     case RTX_OPT_SORT_MATERIALS: c->sort_mats = value != 0; return RTX_OK;
     case RTX_OPT_LDS_NODES: c->lds_nodes_opt = (int)value; c->committed = false; return RTX_OK;
+    case RTX_OPT_SMALL_SCENE: c->small_scene = value != 0; c->committed = false; return RTX_OK;
+    case RTX_OPT_FUSED_BOUNCE: c->fused = value != 0; return RTX_OK;
     default: c->err = "unknown option"; return RTX_ERR_INVALID;
     }
 }
@@ -163,6 +165,7 @@ int rtx_commit_scene(rtx_ctx* c) {
     if ((r = upload(c, c->d_nodes, B.nodes))) return r;
     if ((r = upload(c, c->d_tris, B.tris))) return r;
     if ((r = upload(c, c->d_shade, B.shade))) return r;
+    if ((r = upload(c, c->d_small, B.small))) return r;
     if ((r = upload(c, c->d_mats, B.mats))) return r;
     if ((r = upload(c, c->d_insts, B.insts))) return r;
     if ((r = upload(c, c->d_lights, B.lights))) return r;
@@ -171,6 +174,7 @@ int rtx_commit_scene(rtx_ctx* c) {
     s.nodes = (const NodeGPU*)c->d_nodes.p; s.nnodes = (uint32_t)B.nodes.size();
     s.tris = (const TriGPU*)c->d_tris.p; s.ntris = (uint32_t)B.tris.size();
     s.shade = (const TriShade*)c->d_shade.p;
+    s.small = (const SmallTri*)c->d_small.p;
     s.mats = (const MatGPU*)c->d_mats.p; s.nmat = (uint32_t)B.mats.size();
     s.insts = (const InstGPU*)c->d_insts.p;
     s.lights = (const LightGPU*)c->d_lights.p; s.nlights = (uint32_t)B.lights.size();
@@ -185,6 +189,7 @@ int rtx_commit_scene(rtx_ctx* c) {
     budget -= (size_t)s.lds_nodes * 64;
     uint32_t want_tris = s.ntris <= 256 ? s.ntris : 0u;                    // triangles only when ALL of them fit
     s.lds_tris = (size_t)want_tris * 48 <= budget ? want_tris : 0u;
+    s.nsmall = (c->small_scene && !B.small.empty() && s.lds_tris == s.ntris) ? (uint32_t)B.small.size() : 0u;
     if (trace_lds_bytes(s) > 64 * 1024) { c->err = "commit: BVH too deep for the LDS traversal stack"; return RTX_ERR_INVALID; }
     c->stats.bvh_nodes = s.nnodes; c->stats.triangles = s.ntris; c->stats.lights = s.nlights; c->stats.materials = s.nmat;
     c->committed = true;
@@ -333,7 +338,11 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
         { Timed t(c, RTX_K_RAYGEN); launch_raygen(st, fb, P, cam, queue[0], Q(0)); }
         for (uint32_t b = 0; b < mb; b++) {
             uint32_t* q = queue[b & 1]; uint32_t* qn = queue[(b + 1) & 1];
-            { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, fb, c->dsc, P, q, Q(b)); }
+            if (c->dsc.nsmall && c->fused) {      // tiny scene: trace + shade + shadow fused into one kernel per bounce
+                Timed t(c, RTX_K_BOUNCE); launch_bounce_small(st, c->dsc, fb, P, b, q, Q(b), qn, Q(b + 1), S(b, 0));
+                continue;
+            }
+            { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, fb, c->dsc, P, b, q, Q(b)); }
             { Timed t(c, RTX_K_SHADE); launch_shade(st, c->dsc, fb, P, b, q, Q(b), qn, Q(b + 1), S(b, 0)); }
             for (uint32_t j = 0; j < nee; j++) { Timed t(c, RTX_K_SHADOW); launch_trace_shadow(st, fb, c->dsc, P, j, S(b, j)); }
         }
@@ -355,9 +364,11 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
         for (uint32_t b = 0; b < mb; b++) for (uint32_t j = 0; j < nee; j++) c->stats.rays_shadow += sumG((size_t)(mb + 1) + (size_t)b * nee1 + j);
     }
     c->stats.kernel_items[RTX_K_RAYGEN] = c->stats.paths;
-    c->stats.kernel_items[RTX_K_TRACE] = c->stats.rays_primary + c->stats.rays_extension;
-    c->stats.kernel_items[RTX_K_SHADE] = c->stats.rays_primary + c->stats.rays_extension;
-    c->stats.kernel_items[RTX_K_SHADOW] = c->stats.rays_shadow;
+    const bool fused = c->dsc.nsmall && c->fused;
+    c->stats.kernel_items[RTX_K_BOUNCE] = fused ? c->stats.rays_primary + c->stats.rays_extension : 0;
+    c->stats.kernel_items[RTX_K_TRACE] = fused ? 0 : c->stats.rays_primary + c->stats.rays_extension;
+    c->stats.kernel_items[RTX_K_SHADE] = fused ? 0 : c->stats.rays_primary + c->stats.rays_extension;
+    c->stats.kernel_items[RTX_K_SHADOW] = fused ? 0 : c->stats.rays_shadow;
     c->stats.kernel_items[RTX_K_ACCUM] = c->stats.paths;
     return RTX_OK;
 }

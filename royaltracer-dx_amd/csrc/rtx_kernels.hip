@@ -93,10 +93,10 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DevFrame f, DevPaths p, const
             float jx = 0.0f, jy = 0.0f;
             if (f.flags & 2u) { jx = tea_next(s0, s1); jy = tea_next(s0, s1); }   // RayGen.hlsl:84-85
             f3 o, d; primary_ray(cam, f.width, f.height, x, y, jx, jy, o, d);
-            p.ray_o[pid] = {o.x, o.y, o.z, kTMinCam};
+            p.ray_o[pid] = {o.x, o.y, o.z, u2f(s1)};
             p.ray_d[pid] = {d.x, d.y, d.z, 1.0f};
             p.thr[pid] = {1.0f, 1.0f, 1.0f, u2f(s0)};
-            p.rad[pid] = {0.0f, 0.0f, 0.0f, u2f(s1)};
+            p.rad[pid] = {0.0f, 0.0f, 0.0f, 0.0f};
         }
         const uint32_t slot = block_push(valid, &s_n);
         if (valid) myq[slot] = pid;
@@ -212,8 +212,62 @@ __device__ __forceinline__ void traverse(const DevScene& sc, const TraceLds& L, 
     }
 }
 
+// Tiny-scene path (sc.nsmall != 0, all triangles staged in LDS): no BVH.  Phase 1 runs a CONSERVATIVE plane-form
+// pre-test of every triangle in a wave-uniform loop (triangle records are wave-uniform -> scalar loads, no
+// divergence) and collects a per-lane candidate bit mask; "certain" hits also shrink the search interval.
+// Phase 2 runs the exact Moeller-Trumbore test on the few candidates of each lane.  The result is the same
+// minimum-over-all-triangles as the BVH path and the oracle's brute force: phase 1 only removes triangles that
+// the exact test would reject (tolerances: SmallTri.eps, built in rtx_scene_host.cpp).
+template <bool ANY>
+__device__ __forceinline__ void traverse_small(const DevScene& sc, const SmallTri* __restrict__ st, const TraceLds& L, f3 o, f3 d, float tmin, float tmax,
+                                               float& bt, float& bu, float& bv, uint32_t& bprim) {
+    bt = tmax; bu = 0.0f; bv = 0.0f; bprim = kMissPrim;
+    unsigned long long cand = 0ull;
+    float tb = tmax;                                   // upper bound of the interval still worth testing
+    const uint32_t n = sc.nsmall;
+#pragma unroll 4
+    for (uint32_t k = 0; k < n; k++) {                 // wave-uniform: scalar loads, issued ahead by the unroll
+        const F4 pl = st[k].pl, pu = st[k].pu, pv = st[k].pv, ep = st[k].eps;
+        const float nd = __builtin_fmaf(pl.z, d.z, __builtin_fmaf(pl.y, d.y, pl.x * d.x));
+        const float no = pl.w - __builtin_fmaf(pl.z, o.z, __builtin_fmaf(pl.y, o.y, pl.x * o.x));
+        const float ind = __builtin_amdgcn_rcpf(nd);
+        const float t = no * ind;
+        const float px = __builtin_fmaf(t, d.x, o.x), py = __builtin_fmaf(t, d.y, o.y), pz = __builtin_fmaf(t, d.z, o.z);
+        const float u = __builtin_fmaf(pu.z, pz, __builtin_fmaf(pu.y, py, __builtin_fmaf(pu.x, px, pu.w)));
+        const float v = __builtin_fmaf(pv.z, pz, __builtin_fmaf(pv.y, py, __builtin_fmaf(pv.x, px, pv.w)));
+        const float mt = __builtin_fmaf(4e-6f * 1.0f, fabsf(ind) * ep.w * 5e4f, 1e-5f * fabsf(t));   // delta-scaled distance tolerance
+        const bool graze = !(fabsf(nd) >= 1e-3f);      // also catches NaN
+        const bool in_t = (t + mt >= tmin) && (t - mt <= tb);
+        const bool maybe = graze || (in_t && u >= -ep.x && v >= -ep.y && u + v <= 1.0f + ep.z);
+        if (maybe) cand |= 1ull << k;
+        if (!ANY) {
+            const bool sure = !graze && u >= 4.0f * ep.x && v >= 4.0f * ep.y && u + v <= 1.0f - 4.0f * ep.z && (t - mt > tmin) && (t + mt < tmax);
+            if (sure) tb = fminf(tb, t + mt);
+        }
+    }
+    while (cand) {                                     // per-lane: exact test of the candidates
+        const uint32_t k = (uint32_t)__builtin_ctzll(cand);
+        cand &= cand - 1ull;
+        const lds_v4f* tp = L.tris + k * 3u;
+        const v4f v0 = tp[0], e1 = tp[1], e2 = tp[2];
+        float t, u, w;
+        if (tri_test(o, d, v0, e1, e2, tmin, tmax, t, u, w)) {
+            if (ANY) { bprim = 0u; return; }
+            const uint32_t gid = f2u(v0.w);
+            if (t < bt || (t == bt && gid < bprim)) { bt = t; bu = u; bv = w; bprim = gid; }
+        }
+    }
+}
+
+template <bool ANY>
+__device__ __forceinline__ void trace_ray(const DevScene& sc, const SmallTri* __restrict__ small, const TraceLds& L, f3 o, f3 d, float tmin, float tmax,
+                                          float& bt, float& bu, float& bv, uint32_t& bprim) {
+    if (sc.nsmall) traverse_small<ANY>(sc, small, L, o, d, tmin, tmax, bt, bu, bv, bprim);
+    else traverse<ANY>(sc, L, o, d, tmin, tmax, bt, bu, bv, bprim);
+}
+
 // closest hit for every path in this workgroup's sub-queue: reads ray_o/ray_d, writes hit
-__global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap) {
+__global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const SmallTri* __restrict__ small, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin) {
     extern __shared__ F4 lds[];
     const uint32_t n = qcount[blockIdx.x];
     if (n == 0) return;
@@ -224,14 +278,14 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, DevPaths 
         const uint32_t pid = myq[i];
         const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
         float t, u, v; uint32_t prim;
-        traverse<false>(sc, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, kTMax, t, u, v, prim);
+        trace_ray<false>(sc, small, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, t, u, v, prim);
         p.hit[pid] = {t, u, v, u2f(prim)};
     }
 }
 
 // any-hit for NEE slot j: visible contributions are added to the path's radiance (a path appears at most once
 // per slot, so the read-modify-write needs no atomic and the order of additions per path is fixed)
-__global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, DevPaths p, const F4* __restrict__ sh_o, const F4* __restrict__ sh_d,
+__global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const SmallTri* __restrict__ small, DevPaths p, const F4* __restrict__ sh_o, const F4* __restrict__ sh_d,
                                                          const F4* __restrict__ sh_c, const uint32_t* __restrict__ shcount, uint32_t qcap) {
     extern __shared__ F4 lds[];
     const uint32_t n = shcount[blockIdx.x];
@@ -242,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, DevPaths p
     for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
         const F4 so = sh_o[qb + i], sd = sh_d[qb + i];
         float t, u, v; uint32_t prim;
-        traverse<true>(sc, L, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, t, u, v, prim);
+        trace_ray<true>(sc, small, L, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, t, u, v, prim);
         if (prim == kMissPrim) {
             const F4 c = sh_c[qb + i];
             const uint32_t pid = f2u(c.w);
@@ -275,9 +329,113 @@ __device__ __forceinline__ Surf surface(const DevScene& sc, f3 o, f3 d, float t,
 }
 
 // ---------------------------------------------------------------------------------------------
-// shade: one thread per queued path.  Loop body of RayGen.hlsl:99-133 + Hit.hlsl:126-174,340-369 with
-// the v6 leaf math; the same statement order as oracle/rt_oracle.c:trace_path.
+// shading building blocks.  Loop body of RayGen.hlsl:99-133 + Hit.hlsl:126-174,340-369 with the v6 leaf math,
+// in the same statement order as oracle/rt_oracle.c:trace_path.  Shared by k_shade (separate trace / shade /
+// shadow kernels: general BVH scenes) and k_bounce_small (one fused kernel per bounce: tiny scenes).
+//
+// Per-path state in HBM (48 B read + 48 B written per bounce):
+//   ray_o = (origin.xyz, seed.y bits)   ray_d = (dir.xyz, pdf of the sampled direction)   thr = (throughput.xyz, seed.x bits)
+// tmin is a function of the bounce index (camera rays 1e-4, pass1:94; later rays s_bias, Sampler_v6.hlsl:226),
+// rad = (radiance.xyz, -) is only touched when something is added.
 // ---------------------------------------------------------------------------------------------
+struct PathState { uint32_t pid; f3 o, d; float prev_pdf; f3 thr; uint32_t s0, s1; };
+
+__device__ __forceinline__ float bounce_tmin(uint32_t bounce) { return bounce == 0 ? kTMinCam : kSBias; }
+
+__device__ __forceinline__ PathState load_path(const DevPaths& p, uint32_t pid) {
+    PathState S; S.pid = pid;
+    const F4 ro = p.ray_o[pid], rd = p.ray_d[pid], tv = p.thr[pid];
+    S.o = mk3(ro.x, ro.y, ro.z); S.s1 = f2u(ro.w);
+    S.d = mk3(rd.x, rd.y, rd.z); S.prev_pdf = rd.w;
+    S.thr = mk3(tv.x, tv.y, tv.z); S.s0 = f2u(tv.w);
+    return S;
+}
+
+// hit on an emissive surface: Hit.hlsl:126-174 with the v6 pdf conventions (Sampler_v6.hlsl:459-465)
+__device__ __forceinline__ void add_emissive(const DevScene& sc, const DevPaths& p, const PathState& S, const Surf& sf, const MatGPU& m, uint32_t bounce, uint32_t nee) {
+    const f3 Ke = mk3(m.Ke[0], m.Ke[1], m.Ke[2]);
+    F4 radv = p.rad[S.pid];
+    if (bounce == 0) { radv.x = radv.x + Ke.x; radv.y = radv.y + Ke.y; radv.z = radv.z + Ke.z; }   // Hit.hlsl:128-131
+    else {
+        float mi = 1.0f;
+        if (nee) {                                            // Path_Sampler_v6.hlsl:241
+            const f3 Lv = sf.pos - S.o;
+            const float dist = length(Lv), dist2 = dist * dist;
+            const float cos_t = fabsf(dot(sf.normal, -S.d));
+            const float pdf_light = (((Ke.x + Ke.y + Ke.z) / 3.0f) / sc.total_weight) * dist2 / maxf_(cos_t, kEps);
+            mi = S.prev_pdf / ((float)nee * pdf_light + S.prev_pdf);
+        }
+        const f3 e = mk3(Ke.x * S.thr.x * mi, Ke.y * S.thr.y * mi, Ke.z * S.thr.z * mi);   // Hit.hlsl:173
+        if (finite3(e)) { radv.x = radv.x + e.x; radv.y = radv.y + e.y; radv.z = radv.z + e.z; }
+    }
+    p.rad[S.pid] = radv;
+}
+
+// one NEE sample: SampleLightNEE_GI, Sampler_v6.hlsl:508-647.  Returns true when a shadow ray is needed.
+__device__ __forceinline__ bool nee_sample(const DevScene& sc, const MatGPU& m, uint32_t flags, uint32_t nee, PathState& S, f3 pos, f3 normal, f3 outgoing,
+                                           F4& so, F4& sd, f3& con) {
+    const float rv = tea_next(S.s0, S.s1);
+    int left = 0, right = (int)sc.nlights - 1, sel = 0;
+    while (left <= right) {                                   // :523-537
+        const int mid = left + (right - left) / 2;
+        if (rv < sc.lights[mid].cdf) { sel = mid; right = mid - 1; } else left = mid + 1;
+    }
+    const LightGPU& lt = sc.lights[sel];
+    const f3 xv = mk3(lt.xv[0], lt.xv[1], lt.xv[2]), yv = mk3(lt.yv[0], lt.yv[1], lt.yv[2]), zv = mk3(lt.zv[0], lt.zv[1], lt.zv[2]);
+    float xi1 = tea_next(S.s0, S.s1), xi2 = tea_next(S.s0, S.s1);
+    if (xi1 + xi2 > 1.0f) { xi1 = 1.0f - xi1; xi2 = 1.0f - xi2; }
+    const float u = 1.0f - xi1 - xi2, v = xi1, w = xi2;
+    const f3 sp = mk3(u * xv.x + v * yv.x + w * zv.x, u * xv.y + v * yv.y + w * zv.y, u * xv.z + v * yv.z + w * zv.z);
+    const f3 Lv = sp - pos;
+    const float dist2 = dot(Lv, Lv);
+    const float dist = sqrtf(maxf_(dist2, kEps));
+    const f3 Ln = normalize(Lv);
+    f3 nl = mk3(lt.nl[0], lt.nl[1], lt.nl[2]);
+    if (dot(nl, -Ln) < 0.0f) nl = -nl;
+    const float cos_x = dot(normal, Ln);
+    const float cos_y = fabsf(dot(nl, -Ln));
+    if (cos_x < kEps || cos_y < kEps) return false;           // :580-585
+    const float pdf_light = lt.pdf_l * dist2 / cos_y;         // :629-630
+    f3 F; float P, pd, ps; bsdf_mixture(m, flags, normal, Ln, outgoing, F, P, pd, ps);
+    const float mi = pdf_light / ((float)nee * pdf_light + P);   // Path_Sampler_v6.hlsl:164
+    const float g = cos_x / pdf_light * mi;
+    con = mk3(lt.em[0] * (S.thr.x * F.x) * g, lt.em[1] * (S.thr.y * F.y) * g, lt.em[2] * (S.thr.z * F.z) * g);
+    if (!finite3(con) || is_zero3(con)) return false;
+    const f3 sorg = pos + normalize(normal) * kSBias;         // :616-621
+    so = {sorg.x, sorg.y, sorg.z, 0.5f * kSBias};
+    sd = {Ln.x, Ln.y, Ln.z, maxf_(kSBias, dist - kSBias * 5.0f)};
+    return true;
+}
+
+// BSDF sampling + throughput + Russian roulette: Path_Sampler_v6.hlsl:205-229, Sampler_v6.hlsl:423-457,482-497,
+// Hit.hlsl:366-369, RayGen.hlsl:118-130.  Returns true when the path continues (state updated in S, smp, P).
+__device__ __forceinline__ bool bsdf_continue(const MatGPU& m, const DevFrame& f, uint32_t bounce, PathState& S, f3 normal, f3 outgoing, f3& smp, float& P) {
+    const uint32_t st = select_strategy(m, outgoing, normal, f.flags, S.s0, S.s1);
+    smp = sample_bsdf(m, st, outgoing, normal, S.s0, S.s1);
+    f3 F; float pd, ps; bsdf_mixture(m, f.flags, normal, smp, outgoing, F, P, pd, ps);
+    const float NdotL = dot(normal, smp);                     // unclamped, Sampler_v6.hlsl:455
+    if (!(P > 0.0f)) return false;
+    const float wgt = NdotL / P;                              // Hit.hlsl:366
+    S.thr = mk3(S.thr.x * (F.x * wgt), S.thr.y * (F.y * wgt), S.thr.z * (F.z * wgt));
+    if (!finite3(S.thr) || is_zero3(S.thr)) return false;
+    if (bounce > f.rr_start) {                                // RayGen.hlsl:118-130
+        const float mx = maxf_(S.thr.x, maxf_(S.thr.y, S.thr.z));
+        const float q = minf_(maxf_(mx, 0.05f), 1.0f);
+        const float r = tea_next(S.s0, S.s1);
+        if (r > q) return false;
+        const float iq = 1.0f / q;
+        S.thr = S.thr * iq;
+    }
+    return true;
+}
+
+__device__ __forceinline__ void store_path(const DevPaths& p, const PathState& S, f3 pos, f3 smp, float P) {
+    p.ray_o[S.pid] = {pos.x, pos.y, pos.z, u2f(S.s1)};       // un-offset origin, Sampler_v6.hlsl:224-227
+    p.ray_d[S.pid] = {smp.x, smp.y, smp.z, P};                // pdf for the MIS at the next emissive hit, Hit.hlsl:369
+    p.thr[S.pid] = {S.thr.x, S.thr.y, S.thr.z, u2f(S.s0)};
+}
+
+// shade: one thread per queued path (general path: hits come from k_trace_closest, shadow rays go to queues)
 __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPaths p, uint32_t bounce,
                                                   const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount,
                                                   uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count,
@@ -286,7 +444,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPa
     if (threadIdx.x <= kMaxNee) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t n = qcount[blockIdx.x];
-    const uint32_t flags = f.flags;
     const uint32_t nee = sc.nlights ? f.nee_samples : 0u;
     const bool last = (bounce + 1u == f.max_bounces);
     const size_t qb = (size_t)blockIdx.x * f.qcap;
@@ -294,123 +451,107 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPa
     uint32_t* mynext = next_queue + qb;
     for (uint32_t base = threadIdx.x & ~63u; base < n; base += kBlock) {
         const uint32_t i = base + (threadIdx.x & 63u);
-        bool active = i < n;
-        uint32_t pid = 0;
-        f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), thr = mk3(0, 0, 0), outgoing, normal, pos;
-        float prev_pdf = 1.0f; uint32_t s0 = 0, s1 = 0;
+        PathState S; S.pid = 0; S.o = mk3(0, 0, 0); S.d = mk3(0, 0, 1); S.thr = mk3(0, 0, 0); S.prev_pdf = 1.0f; S.s0 = S.s1 = 0;
         Surf sf; sf.mat = 0; sf.normal = mk3(0, 0, 1); sf.pos = mk3(0, 0, 0);
-        F4 radv = {0, 0, 0, 0};
         bool shading = false;
-        if (active) {
-            pid = myq[i];
+        if (i < n) {
+            const uint32_t pid = myq[i];
             const F4 h = p.hit[pid];
             const uint32_t prim = f2u(h.w);
             if (prim != kMissPrim) {                                          // miss: Miss.hlsl:3-11 -> black, terminate
-                const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
-                o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z); prev_pdf = rd.w;
-                sf = surface(sc, o, d, h.x, h.y, h.z, prim);
+                S = load_path(p, pid);
+                sf = surface(sc, S.o, S.d, h.x, h.y, h.z, prim);
                 if (sf.mat < sc.nmat) {
-                    const F4 tv = p.thr[pid]; radv = p.rad[pid];
-                    thr = mk3(tv.x, tv.y, tv.z); s0 = f2u(tv.w); s1 = f2u(radv.w);
                     const MatGPU& m = sc.mats[sf.mat];
-                    if (m.Ke_len > 0.0f) {                                    // Hit.hlsl:126, Sampler_v6.hlsl:457
-                        const f3 Ke = mk3(m.Ke[0], m.Ke[1], m.Ke[2]);
-                        if (bounce == 0) { radv.x = radv.x + Ke.x; radv.y = radv.y + Ke.y; radv.z = radv.z + Ke.z; }   // Hit.hlsl:128-131
-                        else {
-                            float mi = 1.0f;
-                            if (nee) {                                        // Sampler_v6.hlsl:459-465, Path_Sampler_v6.hlsl:241
-                                const f3 Lv = sf.pos - o;
-                                const float dist = length(Lv), dist2 = dist * dist;
-                                const float cos_t = fabsf(dot(sf.normal, -d));
-                                const float pdf_light = (((Ke.x + Ke.y + Ke.z) / 3.0f) / sc.total_weight) * dist2 / maxf_(cos_t, kEps);
-                                mi = prev_pdf / ((float)nee * pdf_light + prev_pdf);
-                            }
-                            const f3 e = mk3(Ke.x * thr.x * mi, Ke.y * thr.y * mi, Ke.z * thr.z * mi);   // Hit.hlsl:173
-                            if (finite3(e)) { radv.x = radv.x + e.x; radv.y = radv.y + e.y; radv.z = radv.z + e.z; }
-                        }
-                        p.rad[pid] = radv;
-                    } else shading = true;
+                    if (m.Ke_len > 0.0f) add_emissive(sc, p, S, sf, m, bounce, nee);   // Hit.hlsl:126, Sampler_v6.hlsl:457
+                    else shading = true;
                 }
             }
         }
-        outgoing = -d; normal = sf.normal; pos = sf.pos;
+        const f3 outgoing = -S.d, normal = sf.normal, pos = sf.pos;
         const MatGPU* mp = sc.mats + (shading ? sf.mat : 0u);
-        // ---- NEE: SampleLightNEE_GI, Sampler_v6.hlsl:508-647, visibility ray deferred to k_trace_shadow ----
-        for (uint32_t j = 0; j < nee; j++) {
+        for (uint32_t j = 0; j < nee; j++) {                                  // NEE: visibility deferred to k_trace_shadow
             bool push = false;
-            F4 so = {0, 0, 0, 0}, sd = {0, 0, 0, 0}, scn = {0, 0, 0, 0};
-            if (shading) {
-                const float rv = tea_next(s0, s1);
-                int left = 0, right = (int)sc.nlights - 1, sel = 0;
-                while (left <= right) {                                       // :523-537
-                    const int mid = left + (right - left) / 2;
-                    if (rv < sc.lights[mid].cdf) { sel = mid; right = mid - 1; } else left = mid + 1;
-                }
-                const LightGPU& lt = sc.lights[sel];
-                const f3 xv = mk3(lt.xv[0], lt.xv[1], lt.xv[2]), yv = mk3(lt.yv[0], lt.yv[1], lt.yv[2]), zv = mk3(lt.zv[0], lt.zv[1], lt.zv[2]);
-                float xi1 = tea_next(s0, s1), xi2 = tea_next(s0, s1);
-                if (xi1 + xi2 > 1.0f) { xi1 = 1.0f - xi1; xi2 = 1.0f - xi2; }
-                const float u = 1.0f - xi1 - xi2, v = xi1, w = xi2;
-                const f3 sp = mk3(u * xv.x + v * yv.x + w * zv.x, u * xv.y + v * yv.y + w * zv.y, u * xv.z + v * yv.z + w * zv.z);
-                const f3 Lv = sp - pos;
-                const float dist2 = dot(Lv, Lv);
-                const float dist = sqrtf(maxf_(dist2, kEps));
-                const f3 Ln = normalize(Lv);
-                f3 nl = mk3(lt.nl[0], lt.nl[1], lt.nl[2]);
-                if (dot(nl, -Ln) < 0.0f) nl = -nl;
-                const float cos_x = dot(normal, Ln);
-                const float cos_y = fabsf(dot(nl, -Ln));
-                if (!(cos_x < kEps || cos_y < kEps)) {                        // :580-585
-                    const float pdf_light = lt.pdf_l * dist2 / cos_y;         // :629-630
-                    f3 F; float P, pd, ps; bsdf_mixture(*mp, flags, normal, Ln, outgoing, F, P, pd, ps);
-                    const float mi = pdf_light / ((float)nee * pdf_light + P);   // Path_Sampler_v6.hlsl:164
-                    const float g = cos_x / pdf_light * mi;
-                    const f3 con = mk3(lt.em[0] * (thr.x * F.x) * g, lt.em[1] * (thr.y * F.y) * g, lt.em[2] * (thr.z * F.z) * g);
-                    if (finite3(con) && !is_zero3(con)) {
-                        const f3 sorg = pos + normalize(normal) * kSBias;     // :616-621
-                        so = {sorg.x, sorg.y, sorg.z, 0.5f * kSBias};
-                        sd = {Ln.x, Ln.y, Ln.z, maxf_(kSBias, dist - kSBias * 5.0f)};
-                        scn = {con.x, con.y, con.z, u2f(pid)};
-                        push = true;
-                    }
-                }
-            }
-            const size_t seg = (size_t)j * f.qcap * gridDim.x + qb;      // NEE slot j, this workgroup's sub-queue
+            F4 so = {0, 0, 0, 0}, sd = {0, 0, 0, 0}; f3 con = mk3(0, 0, 0);
+            if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con);
+            const size_t seg = (size_t)j * f.qcap * gridDim.x + qb;           // NEE slot j, this workgroup's sub-queue
             const uint32_t slot = block_push(push, &s_cnt[1 + j]);
-            if (push) { p.sh_o[seg + slot] = so; p.sh_d[seg + slot] = sd; p.sh_c[seg + slot] = scn; }
+            if (push) { p.sh_o[seg + slot] = so; p.sh_d[seg + slot] = sd; p.sh_c[seg + slot] = {con.x, con.y, con.z, u2f(S.pid)}; }
         }
-        // ---- BSDF sampling: Path_Sampler_v6.hlsl:205-229, Sampler_v6.hlsl:423-457,482-497 ----
         bool alive = false;
         f3 smp = mk3(0, 0, 1); float P = 0.0f;
-        if (shading && !last) {
-            const uint32_t st = select_strategy(*mp, outgoing, normal, flags, s0, s1);
-            smp = sample_bsdf(*mp, st, outgoing, normal, s0, s1);
-            f3 F; float pd, ps; bsdf_mixture(*mp, flags, normal, smp, outgoing, F, P, pd, ps);
-            const float NdotL = dot(normal, smp);                             // unclamped, Sampler_v6.hlsl:455
-            if (P > 0.0f) {
-                const float wgt = NdotL / P;                                  // Hit.hlsl:366
-                thr = mk3(thr.x * (F.x * wgt), thr.y * (F.y * wgt), thr.z * (F.z * wgt));
-                if (finite3(thr) && !is_zero3(thr)) {
-                    alive = true;
-                    if (bounce > f.rr_start) {                                // RayGen.hlsl:118-130
-                        const float mx = maxf_(thr.x, maxf_(thr.y, thr.z));
-                        const float q = minf_(maxf_(mx, 0.05f), 1.0f);
-                        const float r = tea_next(s0, s1);
-                        if (r > q) alive = false;
-                        else { const float iq = 1.0f / q; thr = thr * iq; }
-                    }
-                }
+        if (shading && !last) alive = bsdf_continue(*mp, f, bounce, S, normal, outgoing, smp, P);
+        if (alive) store_path(p, S, pos, smp, P);
+        const uint32_t slot = block_push(alive, &s_cnt[0]);
+        if (alive) mynext[slot] = S.pid;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) next_count[blockIdx.x] = s_cnt[0];
+    if (threadIdx.x >= 1 && threadIdx.x <= nee) shcounts[(size_t)(threadIdx.x - 1) * gridDim.x + blockIdx.x] = s_cnt[threadIdx.x];
+}
+
+// Fused bounce kernel for tiny scenes (sc.nsmall != 0): trace the extension ray, shade, trace the NEE shadow
+// rays and add their contributions, sample the BSDF, compact — all in one pass over the workgroup's sub-queue.
+// Nothing but the 48-B path state and the queue index moves through HBM; hit records and shadow-ray entries
+// stay in registers.  Radiance additions happen in the oracle's order (emissive, then NEE slot 0, 1, ...).
+__global__ __launch_bounds__(kBlock) void k_bounce_small(DevScene sc, const SmallTri* __restrict__ small, DevFrame f, DevPaths p, uint32_t bounce,
+                                                         const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount,
+                                                         uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count,
+                                                         uint32_t* __restrict__ shcounts /* [nee][gridDim.x]: shadow rays traced (statistics) */) {
+    extern __shared__ F4 lds[];
+    __shared__ uint32_t s_cnt[1 + kMaxNee];
+    if (threadIdx.x <= kMaxNee) s_cnt[threadIdx.x] = 0;
+    const uint32_t n = qcount[blockIdx.x];
+    const uint32_t nee = sc.nlights ? f.nee_samples : 0u;
+    const TraceLds L = stage_lds(sc, lds);
+    __syncthreads();
+    const bool last = (bounce + 1u == f.max_bounces);
+    const float tmin = bounce_tmin(bounce);
+    const size_t qb = (size_t)blockIdx.x * f.qcap;
+    const uint32_t* myq = queue + qb;
+    uint32_t* mynext = next_queue + qb;
+    for (uint32_t base = threadIdx.x & ~63u; base < n; base += kBlock) {
+        const uint32_t i = base + (threadIdx.x & 63u);
+        const bool active = i < n;
+        PathState S; S.pid = 0; S.o = mk3(0, 0, 0); S.d = mk3(0, 0, 1); S.thr = mk3(0, 0, 0); S.prev_pdf = 1.0f; S.s0 = S.s1 = 0;
+        if (active) S = load_path(p, myq[i]);
+        float t, u, v; uint32_t prim;
+        traverse_small<false>(sc, small, L, S.o, S.d, tmin, active ? kTMax : 0.0f, t, u, v, prim);   // inactive lanes: empty interval
+        Surf sf; sf.mat = 0; sf.normal = mk3(0, 0, 1); sf.pos = mk3(0, 0, 0);
+        bool shading = false;
+        if (active && prim != kMissPrim) {
+            sf = surface(sc, S.o, S.d, t, u, v, prim);
+            if (sf.mat < sc.nmat) {
+                const MatGPU& m = sc.mats[sf.mat];
+                if (m.Ke_len > 0.0f) add_emissive(sc, p, S, sf, m, bounce, nee);
+                else shading = true;
             }
         }
-        if (alive) {
-            p.ray_o[pid] = {pos.x, pos.y, pos.z, kSBias};                     // Sampler_v6.hlsl:224-227
-            p.ray_d[pid] = {smp.x, smp.y, smp.z, P};                          // prev_pdf, Hit.hlsl:369
-            p.thr[pid] = {thr.x, thr.y, thr.z, u2f(s0)};
-            radv.w = u2f(s1);
-            p.rad[pid] = radv;
+        const f3 outgoing = -S.d, normal = sf.normal, pos = sf.pos;
+        const MatGPU* mp = sc.mats + (shading ? sf.mat : 0u);
+        bool loaded = false; F4 radv = {0, 0, 0, 0};
+        for (uint32_t j = 0; j < nee; j++) {
+            bool push = false;
+            F4 so = {0, 0, 0, 0}, sd = {0, 0, 1, 0}; f3 con = mk3(0, 0, 0);
+            if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con);
+            const unsigned long long pm = __ballot(push);
+            if (pm) {                                                          // wave-uniform
+                float st_, su_, sv_; uint32_t sprim;
+                traverse_small<true>(sc, small, L, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, push ? sd.w : 0.0f, st_, su_, sv_, sprim);
+                if (push && sprim == kMissPrim) {
+                    if (!loaded) { radv = p.rad[S.pid]; loaded = true; }
+                    radv.x = radv.x + con.x; radv.y = radv.y + con.y; radv.z = radv.z + con.z;
+                }
+                if (lane_id() == 0) atomicAdd(&s_cnt[1 + j], (uint32_t)__popcll(pm));
+            }
         }
+        if (loaded) p.rad[S.pid] = radv;
+        bool alive = false;
+        f3 smp = mk3(0, 0, 1); float P = 0.0f;
+        if (shading && !last) alive = bsdf_continue(*mp, f, bounce, S, normal, outgoing, smp, P);
+        if (alive) store_path(p, S, pos, smp, P);
         const uint32_t slot = block_push(alive, &s_cnt[0]);
-        if (alive) mynext[slot] = pid;
+        if (alive) mynext[slot] = S.pid;
     }
     __syncthreads();
     if (threadIdx.x == 0) next_count[blockIdx.x] = s_cnt[0];
@@ -477,7 +618,7 @@ __global__ __launch_bounds__(kBlock) void k_unpack_tiles(DevFrame f, uint32_t ns
 // ---------------------------------------------------------------------------------------------
 // kernel-level debug entry points (parity tests): same device functions as the render loop
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_dbg_trace(DevScene sc, const F4* __restrict__ rays, uint32_t n, int any, F4* __restrict__ hits) {
+__global__ __launch_bounds__(kBlock) void k_dbg_trace(DevScene sc, const SmallTri* __restrict__ small, const F4* __restrict__ rays, uint32_t n, int any, F4* __restrict__ hits) {
     extern __shared__ F4 lds[];
     const TraceLds L = stage_lds(sc, lds);
     __syncthreads();
@@ -485,8 +626,8 @@ __global__ __launch_bounds__(kBlock) void k_dbg_trace(DevScene sc, const F4* __r
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const F4 ro = rays[2 * i], rd = rays[2 * i + 1];
         float t, u, v; uint32_t prim;
-        if (any) traverse<true>(sc, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w, t, u, v, prim);
-        else traverse<false>(sc, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w, t, u, v, prim);
+        if (any) trace_ray<true>(sc, small, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w, t, u, v, prim);
+        else trace_ray<false>(sc, small, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w, t, u, v, prim);
         hits[i] = {t, u, v, u2f(prim)};
     }
 }
@@ -553,12 +694,16 @@ size_t trace_lds_bytes(const DevScene& sc) {
 void launch_raygen(hipStream_t st, const DevFrame& f, const DevPaths& p, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount) {
     hipLaunchKernelGGL(k_raygen, dim3(f.nblocks), dim3(kBlock), 0, st, f, p, cam, queue, qcount);
 }
-void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, const uint32_t* queue, const uint32_t* qcount) {
-    hipLaunchKernelGGL(k_trace_closest, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, p, queue, qcount, f.qcap);
+void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t bounce, const uint32_t* queue, const uint32_t* qcount) {
+    hipLaunchKernelGGL(k_trace_closest, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, queue, qcount, f.qcap, bounce == 0 ? kTMinCam : kSBias);
+}
+void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce,
+                         const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts) {
+    hipLaunchKernelGGL(k_bounce_small, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);
 }
 void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t j, const uint32_t* shcount) {
     const size_t seg = (size_t)j * f.qcap * f.nblocks;
-    hipLaunchKernelGGL(k_trace_shadow, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap);
+    hipLaunchKernelGGL(k_trace_shadow, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap);
 }
 void launch_shade(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce,
                   const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts) {
@@ -577,7 +722,7 @@ void launch_unpack_tiles(hipStream_t st, uint32_t max_blocks, const DevFrame& f,
     hipLaunchKernelGGL(k_unpack_tiles, dim3(grid_for(f.npl * nshards, max_blocks)), dim3(kBlock), 0, st, f, nshards, slabs, accum);
 }
 void launch_dbg_trace(hipStream_t st, const DevScene& sc, const F4* rays, uint32_t n, int any, F4* hits) {
-    hipLaunchKernelGGL(k_dbg_trace, dim3(grid_for(n, 2048)), dim3(kBlock), trace_lds_bytes(sc), st, sc, rays, n, any, hits);
+    hipLaunchKernelGGL(k_dbg_trace, dim3(grid_for(n, 2048)), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, rays, n, any, hits);
 }
 void launch_dbg_surface(hipStream_t st, const DevScene& sc, const F4* rays, const F4* hits, uint32_t n, F4* out) {
     hipLaunchKernelGGL(k_dbg_surface, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, sc, rays, hits, n, out);

@@ -10,6 +10,7 @@ struct DevScene {
     const NodeGPU*  nodes;  uint32_t nnodes;
     const TriGPU*   tris;   uint32_t ntris;
     const TriShade* shade;
+    const SmallTri* small;  uint32_t nsmall;   // != 0: tiny scene, brute-force pre-test path (all triangles in LDS)
     const MatGPU*   mats;   uint32_t nmat;
     const InstGPU*  insts;
     const LightGPU* lights; uint32_t nlights;
@@ -33,10 +34,10 @@ struct DevFrame {
 
 // per-path state, SoA float4 streams indexed by path slot (pid = s_local * npl + pl)
 struct DevPaths {
-    F4* ray_o;   // origin.xyz, tmin
+    F4* ray_o;   // origin.xyz, seed.y bits   (tmin is a function of the bounce index)
     F4* ray_d;   // dir.xyz, pdf of the BSDF sample that produced this ray
     F4* thr;     // throughput.xyz, seed.x bits
-    F4* rad;     // radiance.xyz, seed.y bits
+    F4* rad;     // radiance.xyz, -           (touched only when something is added)
     F4* hit;     // t, u, v, global triangle id bits
     // shadow queues: [nee slot j][workgroup b][qcap] entries
     F4* sh_o;    // origin.xyz, tmin
@@ -46,7 +47,9 @@ struct DevPaths {
 
 size_t trace_lds_bytes(const DevScene& sc);
 void launch_raygen(hipStream_t, const DevFrame&, const DevPaths&, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount);
-void launch_trace_closest(hipStream_t, const DevFrame&, const DevScene&, const DevPaths&, const uint32_t* queue, const uint32_t* qcount);
+void launch_trace_closest(hipStream_t, const DevFrame&, const DevScene&, const DevPaths&, uint32_t bounce, const uint32_t* queue, const uint32_t* qcount);
+void launch_bounce_small(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, uint32_t bounce,
+                         const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts);
 void launch_trace_shadow(hipStream_t, const DevFrame&, const DevScene&, const DevPaths&, uint32_t j, const uint32_t* shcount);
 void launch_shade(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, uint32_t bounce,
                   const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts);

@@ -214,6 +214,31 @@ bool SceneHost::build(BuiltScene& B) {
         T.e1 = {e1.x, e1.y, e1.z, 0.0f};
         T.e2 = {e2.x, e2.y, e2.z, 0.0f};
     }
+    // ---- plane-form pre-test records for tiny scenes (double precision, then rounded) ----
+    B.small.clear();
+    if (!leaf_order.empty() && leaf_order.size() <= kSmallSceneMaxTris) {
+        const double delta = 2e-5 * (double)scale;
+        B.small.resize(leaf_order.size());
+        for (size_t s = 0; s < leaf_order.size(); s++) {
+            const float* t = &wtri[(size_t)leaf_order[s] * 9];
+            double v0[3] = {t[0], t[1], t[2]}, e1[3], e2[3], n[3], a[3], b[3];
+            for (int k = 0; k < 3; k++) { e1[k] = (double)t[3 + k] - v0[k]; e2[k] = (double)t[6 + k] - v0[k]; }
+            auto crs = [](const double* x, const double* y, double* o) { o[0] = x[1] * y[2] - x[2] * y[1]; o[1] = x[2] * y[0] - x[0] * y[2]; o[2] = x[0] * y[1] - x[1] * y[0]; };
+            auto dt = [](const double* x, const double* y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
+            crs(e1, e2, n);
+            const double nn = sqrt(dt(n, n));
+            SmallTri& S = B.small[s];
+            if (!(nn > 0.0)) { S.pl = {0, 0, 0, 0}; S.pu = {0, 0, 0, -1e30f}; S.pv = {0, 0, 0, -1e30f}; S.eps = {0, 0, 0, (float)delta}; continue; }
+            double nu[3] = {n[0] / nn, n[1] / nn, n[2] / nn};
+            crs(e2, n, a); crs(n, e1, b);
+            const double da = dt(e1, a), db = dt(e2, b);
+            double n1[3] = {a[0] / da, a[1] / da, a[2] / da}, n2[3] = {b[0] / db, b[1] / db, b[2] / db}, n12[3] = {n1[0] + n2[0], n1[1] + n2[1], n1[2] + n2[2]};
+            S.pl = {(float)nu[0], (float)nu[1], (float)nu[2], (float)dt(nu, v0)};
+            S.pu = {(float)n1[0], (float)n1[1], (float)n1[2], (float)-dt(v0, n1)};
+            S.pv = {(float)n2[0], (float)n2[1], (float)n2[2], (float)-dt(v0, n2)};
+            S.eps = {(float)(delta * sqrt(dt(n1, n1)) + 1e-5), (float)(delta * sqrt(dt(n2, n2)) + 1e-5), (float)(delta * sqrt(dt(n12, n12)) + 2e-5), (float)delta};
+        }
+    }
     return true;
 }
 

@@ -20,6 +20,7 @@ struct BuiltScene {
     std::vector<MatGPU>   mats;
     std::vector<NodeGPU>  nodes;
     std::vector<TriGPU>   tris;       // leaf order
+    std::vector<SmallTri> small;      // leaf order, only when the scene has <= kSmallSceneMaxTris triangles
     std::vector<TriShade> shade;      // global triangle id order
     std::vector<InstGPU>  insts;
     std::vector<LightGPU> lights;

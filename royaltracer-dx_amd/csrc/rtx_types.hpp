@@ -19,6 +19,13 @@ constexpr int32_t kEmptyChild = 0x7FFFFFFF;   // never visited (box is inverted)
 // World-space triangle in leaf order: v0 (w = global triangle id bits), e1 = v1 - v0, e2 = v2 - v0.
 struct alignas(16) TriGPU { F4 v0, e1, e2; };
 
+// Tiny scenes (<= 64 triangles, e.g. the Cornell Box): a CONSERVATIVE plane-form pre-test per triangle, evaluated
+// for all triangles in a wave-uniform loop (no BVH, no divergence); survivors go through the exact test.
+//   t = (pl.w - pl.xyz . o) / (pl.xyz . d),  P = o + t d,  u = pu.xyz . P + pu.w,  v = pv.xyz . P + pv.w
+// eps = barycentric tolerances (u, v, u+v) for a distance tolerance delta; eps.w = delta.
+struct alignas(16) SmallTri { F4 pl, pu, pv, eps; };
+constexpr uint32_t kSmallSceneMaxTris = 64;
+
 // What ClosestHit (Hit_v6.hlsl:12-61) needs about a triangle, pre-gathered per GLOBAL triangle id:
 // object-space flat normal + area, and the three per-vertex normals with the "all(n != 0) else flat"
 // substitution (Hit_v6.hlsl:40-46) already applied.  One 64-B record instead of ~12 dependent gathers.

@@ -24,10 +24,16 @@ def ctx(rt):
     c.close()
 
 
-@pytest.fixture(scope="module")
-def cornell_pair(rt, orc, cornell, ctx):
-    ctx.upload(cornell, 16 / 9)
-    return ctx, orc.Oracle().load(cornell, 16 / 9)
+@pytest.fixture(scope="module", params=["fused_small", "separate_small", "separate_bvh"])
+def cornell_pair(request, rt, orc, cornell):
+    """Cornell through every kernel path: fused bounce kernel (default for tiny scenes), separate
+    trace / shade / shadow kernels with the tiny-scene traversal, and the general BVH traversal"""
+    c = rt.Context(0)
+    c.set_option(rt.OPT_SMALL_SCENE, 0 if request.param == "separate_bvh" else 1)
+    c.set_option(rt.OPT_FUSED_BOUNCE, 1 if request.param == "fused_small" else 0)
+    c.upload(cornell, 16 / 9)
+    yield c, orc.Oracle().load(cornell, 16 / 9)
+    c.close()
 
 
 def random_rays(n, seed, lo=-0.2, hi=1.2, tmax=1e4):
@@ -54,10 +60,27 @@ def test_primary_rays_bit_exact(rt, cornell_pair):
         assert np.array_equal(bits(ctx.primary_rays(p, 3)), bits(o.primary_rays(p, 3)))
 
 
-def test_trace_closest_equals_brute_force(rt, cornell_pair):
-    ctx, o = cornell_pair
+@pytest.fixture(params=["small_scene_path", "bvh_path"])
+def cornell_variant(request, rt, orc, cornell):
+    """Cornell through both traversal paths: the tiny-scene brute-force pre-test and the general BVH"""
+    c = rt.Context(0)
+    c.set_option(rt.OPT_SMALL_SCENE, 1 if request.param == "small_scene_path" else 0)
+    c.upload(cornell, 16 / 9)
+    yield c, orc.Oracle().load(cornell, 16 / 9)
+    c.close()
+
+
+def test_trace_closest_equals_brute_force(rt, cornell_variant):
+    ctx, o = cornell_variant
     p = rt.Params(width=160, height=90)
-    rays = np.concatenate([o.primary_rays(p), random_rays(60000, 1)])
+    rng = np.random.default_rng(17)
+    # rays that start ON surfaces (like every secondary ray) and graze / run inside wall planes
+    on = o.primary_rays(p); h0 = o.trace_closest(on, 1); hit0 = bits(h0)[:, 3] != 0xFFFFFFFF
+    sec = random_rays(int(hit0.sum()), 4)
+    sec[:, 0:3] = on[hit0, 0:3] + h0[hit0, 0:1] * on[hit0, 4:7]; sec[:, 3] = 2e-5
+    graz = random_rays(4000, 5); graz[:, 5] = rng.uniform(-1e-4, 1e-4, 4000).astype(np.float32); graz[:, 1] = rng.choice([0.0, 0.3, 0.98883], 4000)
+    graz[:, 4:7] /= np.linalg.norm(graz[:, 4:7], axis=1, keepdims=True)
+    rays = np.concatenate([on, random_rays(200000, 1), sec, graz])
     g = ctx.trace_closest(rays)
     c = o.trace_closest(rays, mode=0)       # brute force over all triangles
     assert np.array_equal(bits(g)[:, 3], bits(c)[:, 3]), "hit triangle ids differ"
@@ -66,9 +89,9 @@ def test_trace_closest_equals_brute_force(rt, cornell_pair):
     assert hit.mean() > 0.3
 
 
-def test_trace_any_equals_brute_force(rt, cornell_pair):
-    ctx, o = cornell_pair
-    rays = random_rays(60000, 2, lo=0.05, hi=0.95, tmax=0.6)
+def test_trace_any_equals_brute_force(rt, cornell_variant):
+    ctx, o = cornell_variant
+    rays = np.concatenate([random_rays(200000, 2, lo=0.05, hi=0.95, tmax=0.6), random_rays(50000, 6, lo=-0.1, hi=1.1, tmax=0.05)])
     g = ctx.trace_any(rays)
     c = o.trace_any(rays, mode=0)
     assert np.array_equal(g, c)
