@@ -46,7 +46,7 @@ struct rtx_ctx {
     DevBuf d_accum; void* ext_accum = nullptr; size_t ext_accum_bytes = 0; uint32_t acc_w = 0, acc_h = 0;
     DevBuf d_srgb;
     // options
-    bool timing = false; uint64_t paths_per_batch = 8u << 20; int sort_mats = 0; int lds_nodes_opt = -1; bool small_scene = true; bool fused = true;
+    bool timing = false; uint64_t paths_per_batch = 64u << 20; int sort_mats = 0; int lds_nodes_opt = -1; bool small_scene = true; bool fused = true;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     std::vector<TimedLaunch> timed;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -165,7 +165,7 @@ int rtx_commit_scene(rtx_ctx* c) {
     if ((r = upload(c, c->d_nodes, B.nodes))) return r;
     if ((r = upload(c, c->d_tris, B.tris))) return r;
     if ((r = upload(c, c->d_shade, B.shade))) return r;
-    if ((r = upload(c, c->d_small, B.small))) return r;
+    if ((r = upload(c, c->d_small, B.small_pairs))) return r;
     if ((r = upload(c, c->d_mats, B.mats))) return r;
     if ((r = upload(c, c->d_insts, B.insts))) return r;
     if ((r = upload(c, c->d_lights, B.lights))) return r;
@@ -174,7 +174,7 @@ int rtx_commit_scene(rtx_ctx* c) {
     s.nodes = (const NodeGPU*)c->d_nodes.p; s.nnodes = (uint32_t)B.nodes.size();
     s.tris = (const TriGPU*)c->d_tris.p; s.ntris = (uint32_t)B.tris.size();
     s.shade = (const TriShade*)c->d_shade.p;
-    s.small = (const SmallTri*)c->d_small.p;
+    s.small = (const SmallPair*)c->d_small.p; s.small_cm = B.small_cm;
     s.mats = (const MatGPU*)c->d_mats.p; s.nmat = (uint32_t)B.mats.size();
     s.insts = (const InstGPU*)c->d_insts.p;
     s.lights = (const LightGPU*)c->d_lights.p; s.nlights = (uint32_t)B.lights.size();

@@ -213,38 +213,47 @@ __device__ __forceinline__ void traverse(const DevScene& sc, const TraceLds& L, 
 }
 
 // Tiny-scene path (sc.nsmall != 0, all triangles staged in LDS): no BVH.  Phase 1 runs a CONSERVATIVE plane-form
-// pre-test of every triangle in a wave-uniform loop (triangle records are wave-uniform -> scalar loads, no
-// divergence) and collects a per-lane candidate bit mask; "certain" hits also shrink the search interval.
-// Phase 2 runs the exact Moeller-Trumbore test on the few candidates of each lane.  The result is the same
-// minimum-over-all-triangles as the BVH path and the oracle's brute force: phase 1 only removes triangles that
-// the exact test would reject (tolerances: SmallTri.eps, built in rtx_scene_host.cpp).
+// pre-test of every triangle in a wave-uniform loop — two triangles per iteration on packed-FP32 instructions,
+// their coefficients wave-uniform (one s_load_dwordx16 pair per iteration, no LDS/VMEM traffic, no divergence) —
+// and collects a per-lane candidate bit mask.  Phase 2 runs the exact Moeller-Trumbore test on the few
+// candidates of each lane.  The result is the same minimum-over-all-triangles as the BVH path and the oracle's
+// brute force: phase 1 only removes triangles that the exact test would reject (tolerances: SmallTri.eps and
+// the distance margin, built in rtx_scene_host.cpp).
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v fma2(f2v a, f2v b, f2v c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2v splat2(float x) { f2v r = {x, x}; return r; }
+
 template <bool ANY>
-__device__ __forceinline__ void traverse_small(const DevScene& sc, const SmallTri* __restrict__ st, const TraceLds& L, f3 o, f3 d, float tmin, float tmax,
+__device__ __forceinline__ void traverse_small(const DevScene& sc, const SmallPair* __restrict__ sp, const TraceLds& L, f3 o, f3 d, float tmin, float tmax,
                                                float& bt, float& bu, float& bv, uint32_t& bprim) {
     bt = tmax; bu = 0.0f; bv = 0.0f; bprim = kMissPrim;
-    unsigned long long cand = 0ull;
-    float tb = tmax;                                   // upper bound of the interval still worth testing
-    const uint32_t n = sc.nsmall;
-#pragma unroll 4
-    for (uint32_t k = 0; k < n; k++) {                 // wave-uniform: scalar loads, issued ahead by the unroll
-        const F4 pl = st[k].pl, pu = st[k].pu, pv = st[k].pv, ep = st[k].eps;
-        const float nd = __builtin_fmaf(pl.z, d.z, __builtin_fmaf(pl.y, d.y, pl.x * d.x));
-        const float no = pl.w - __builtin_fmaf(pl.z, o.z, __builtin_fmaf(pl.y, o.y, pl.x * o.x));
-        const float ind = __builtin_amdgcn_rcpf(nd);
-        const float t = no * ind;
-        const float px = __builtin_fmaf(t, d.x, o.x), py = __builtin_fmaf(t, d.y, o.y), pz = __builtin_fmaf(t, d.z, o.z);
-        const float u = __builtin_fmaf(pu.z, pz, __builtin_fmaf(pu.y, py, __builtin_fmaf(pu.x, px, pu.w)));
-        const float v = __builtin_fmaf(pv.z, pz, __builtin_fmaf(pv.y, py, __builtin_fmaf(pv.x, px, pv.w)));
-        const float mt = __builtin_fmaf(4e-6f * 1.0f, fabsf(ind) * ep.w * 5e4f, 1e-5f * fabsf(t));   // delta-scaled distance tolerance
-        const bool graze = !(fabsf(nd) >= 1e-3f);      // also catches NaN
-        const bool in_t = (t + mt >= tmin) && (t - mt <= tb);
-        const bool maybe = graze || (in_t && u >= -ep.x && v >= -ep.y && u + v <= 1.0f + ep.z);
-        if (maybe) cand |= 1ull << k;
-        if (!ANY) {
-            const bool sure = !graze && u >= 4.0f * ep.x && v >= 4.0f * ep.y && u + v <= 1.0f - 4.0f * ep.z && (t - mt > tmin) && (t + mt < tmax);
-            if (sure) tb = fminf(tb, t + mt);
-        }
+    uint32_t cand_lo = 0u, cand_hi = 0u;
+    const uint32_t npairs = (sc.nsmall + 1u) >> 1;
+    const f2v dx = splat2(d.x), dy = splat2(d.y), dz = splat2(d.z), ox = splat2(o.x), oy = splat2(o.y), oz = splat2(o.z);
+    const f2v cm = splat2(sc.small_cm), c5 = splat2(1e-5f), vtmin = splat2(tmin), vtmax = splat2(tmax);
+#pragma unroll 2
+    for (uint32_t kp = 0; kp < npairs; kp++) {          // wave-uniform
+        const f2v* __restrict__ R = (const f2v*)sp[kp].r;
+        const f2v nd = fma2(R[2], dz, fma2(R[1], dy, R[0] * dx));
+        const f2v no = R[3] - fma2(R[2], oz, fma2(R[1], oy, R[0] * ox));
+        f2v ind; ind.x = __builtin_amdgcn_rcpf(nd.x); ind.y = __builtin_amdgcn_rcpf(nd.y);
+        const f2v t = no * ind;
+        const f2v px = fma2(t, dx, ox), py = fma2(t, dy, oy), pz = fma2(t, dz, oz);
+        const f2v u = fma2(R[6], pz, fma2(R[5], py, fma2(R[4], px, R[7])));
+        const f2v v = fma2(R[10], pz, fma2(R[9], py, fma2(R[8], px, R[11])));
+        const f2v mt = fma2(cm, __builtin_elementwise_abs(ind), c5 * __builtin_elementwise_abs(t));
+        // all five slack values must be >= 0: t in [tmin - mt, tmax + mt], u >= -eu, v >= -ev, u + v <= 1 + ew
+        const f2v a0 = (t + mt) - vtmin, a1 = (vtmax + mt) - t, a2 = u + R[12], a3 = v + R[13], a4 = R[14] - (u + v);
+        const float m0 = fminf(fminf(fminf(a0.x, a1.x), fminf(a2.x, a3.x)), a4.x);
+        const float m1 = fminf(fminf(fminf(a0.y, a1.y), fminf(a2.y, a3.y)), a4.y);
+        const f2v g = R[15];
+        const bool c0 = (m0 >= 0.0f) || (fabsf(nd.x) < g.x);      // grazing rays always go to the exact test
+        const bool c1 = (m1 >= 0.0f) || (fabsf(nd.y) < g.y);
+        const uint32_t bit = 1u << ((2u * kp) & 31u);
+        const uint32_t add = (c0 ? bit : 0u) | (c1 ? (bit << 1) : 0u);
+        if (kp < 16u) cand_lo |= add; else cand_hi |= add;
     }
+    unsigned long long cand = ((unsigned long long)cand_hi << 32) | cand_lo;
     while (cand) {                                     // per-lane: exact test of the candidates
         const uint32_t k = (uint32_t)__builtin_ctzll(cand);
         cand &= cand - 1ull;
@@ -260,14 +269,14 @@ __device__ __forceinline__ void traverse_small(const DevScene& sc, const SmallTr
 }
 
 template <bool ANY>
-__device__ __forceinline__ void trace_ray(const DevScene& sc, const SmallTri* __restrict__ small, const TraceLds& L, f3 o, f3 d, float tmin, float tmax,
+__device__ __forceinline__ void trace_ray(const DevScene& sc, const SmallPair* __restrict__ small, const TraceLds& L, f3 o, f3 d, float tmin, float tmax,
                                           float& bt, float& bu, float& bv, uint32_t& bprim) {
     if (sc.nsmall) traverse_small<ANY>(sc, small, L, o, d, tmin, tmax, bt, bu, bv, bprim);
     else traverse<ANY>(sc, L, o, d, tmin, tmax, bt, bu, bv, bprim);
 }
 
 // closest hit for every path in this workgroup's sub-queue: reads ray_o/ray_d, writes hit
-__global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const SmallTri* __restrict__ small, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin) {
+__global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const SmallPair* __restrict__ small, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin) {
     extern __shared__ F4 lds[];
     const uint32_t n = qcount[blockIdx.x];
     if (n == 0) return;
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
 
 // any-hit for NEE slot j: visible contributions are added to the path's radiance (a path appears at most once
 // per slot, so the read-modify-write needs no atomic and the order of additions per path is fixed)
-__global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const SmallTri* __restrict__ small, DevPaths p, const F4* __restrict__ sh_o, const F4* __restrict__ sh_d,
+__global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const SmallPair* __restrict__ small, DevPaths p, const F4* __restrict__ sh_o, const F4* __restrict__ sh_d,
                                                          const F4* __restrict__ sh_c, const uint32_t* __restrict__ shcount, uint32_t qcap) {
     extern __shared__ F4 lds[];
     const uint32_t n = shcount[blockIdx.x];
@@ -494,7 +503,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPa
 // rays and add their contributions, sample the BSDF, compact — all in one pass over the workgroup's sub-queue.
 // Nothing but the 48-B path state and the queue index moves through HBM; hit records and shadow-ray entries
 // stay in registers.  Radiance additions happen in the oracle's order (emissive, then NEE slot 0, 1, ...).
-__global__ __launch_bounds__(kBlock) void k_bounce_small(DevScene sc, const SmallTri* __restrict__ small, DevFrame f, DevPaths p, uint32_t bounce,
+__global__ __launch_bounds__(kBlock) void k_bounce_small(DevScene sc, const SmallPair* __restrict__ small, DevFrame f, DevPaths p, uint32_t bounce,
                                                          const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount,
                                                          uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count,
                                                          uint32_t* __restrict__ shcounts /* [nee][gridDim.x]: shadow rays traced (statistics) */) {
@@ -618,7 +627,7 @@ __global__ __launch_bounds__(kBlock) void k_unpack_tiles(DevFrame f, uint32_t ns
 // ---------------------------------------------------------------------------------------------
 // kernel-level debug entry points (parity tests): same device functions as the render loop
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_dbg_trace(DevScene sc, const SmallTri* __restrict__ small, const F4* __restrict__ rays, uint32_t n, int any, F4* __restrict__ hits) {
+__global__ __launch_bounds__(kBlock) void k_dbg_trace(DevScene sc, const SmallPair* __restrict__ small, const F4* __restrict__ rays, uint32_t n, int any, F4* __restrict__ hits) {
     extern __shared__ F4 lds[];
     const TraceLds L = stage_lds(sc, lds);
     __syncthreads();

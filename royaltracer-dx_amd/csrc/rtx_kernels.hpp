@@ -10,7 +10,8 @@ struct DevScene {
     const NodeGPU*  nodes;  uint32_t nnodes;
     const TriGPU*   tris;   uint32_t ntris;
     const TriShade* shade;
-    const SmallTri* small;  uint32_t nsmall;   // != 0: tiny scene, brute-force pre-test path (all triangles in LDS)
+    const SmallPair* small; uint32_t nsmall;   // nsmall != 0: tiny scene (nsmall triangles, all staged in LDS), brute-force pre-test path
+    float small_cm;                            // distance-margin coefficient of the pre-test
     const MatGPU*   mats;   uint32_t nmat;
     const InstGPU*  insts;
     const LightGPU* lights; uint32_t nlights;

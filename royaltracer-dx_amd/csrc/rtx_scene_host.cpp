@@ -239,6 +239,19 @@ bool SceneHost::build(BuiltScene& B) {
             S.eps = {(float)(delta * sqrt(dt(n1, n1)) + 1e-5), (float)(delta * sqrt(dt(n2, n2)) + 1e-5), (float)(delta * sqrt(dt(n12, n12)) + 2e-5), (float)delta};
         }
     }
+    B.small_pairs.clear();
+    B.small_cm = 4e-6f * scale;
+    for (size_t s = 0; s < B.small.size(); s += 2) {
+        SmallPair P;
+        for (int e = 0; e < 2; e++) {
+            const bool have = s + e < B.small.size();
+            const SmallTri T = have ? B.small[s + e] : SmallTri{{0, 0, 1, 0}, {0, 0, 0, -1e30f}, {0, 0, 0, -1e30f}, {0, 0, 0, 0}};
+            const float rows[16] = {T.pl.x, T.pl.y, T.pl.z, T.pl.w, T.pu.x, T.pu.y, T.pu.z, T.pu.w, T.pv.x, T.pv.y, T.pv.z, T.pv.w,
+                                    T.eps.x, T.eps.y, 1.0f + T.eps.z, have ? 1e-3f : -1.0f};
+            for (int r = 0; r < 16; r++) P.r[r][e] = rows[r];
+        }
+        B.small_pairs.push_back(P);
+    }
     return true;
 }
 

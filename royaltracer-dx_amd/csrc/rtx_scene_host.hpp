@@ -21,6 +21,7 @@ struct BuiltScene {
     std::vector<NodeGPU>  nodes;
     std::vector<TriGPU>   tris;       // leaf order
     std::vector<SmallTri> small;      // leaf order, only when the scene has <= kSmallSceneMaxTris triangles
+    std::vector<SmallPair> small_pairs; float small_cm = 0.0f;   // device form of `small`; distance-margin coefficient
     std::vector<TriShade> shade;      // global triangle id order
     std::vector<InstGPU>  insts;
     std::vector<LightGPU> lights;

@@ -25,6 +25,11 @@ struct alignas(16) TriGPU { F4 v0, e1, e2; };
 // eps = barycentric tolerances (u, v, u+v) for a distance tolerance delta; eps.w = delta.
 struct alignas(16) SmallTri { F4 pl, pu, pv, eps; };
 constexpr uint32_t kSmallSceneMaxTris = 64;
+// Device form: two consecutive triangles transposed into 16 float2 rows so that the pre-test of both runs on
+// packed-FP32 instructions (v_pk_fma_f32) with wave-uniform (scalar-loaded) operands.  Rows:
+//  0-3 pl.xyzw | 4-7 pu.xyzw | 8-11 pv.xyzw | 12 eps_u | 13 eps_v | 14 1+eps_w | 15 grazing threshold (-1 = padding)
+struct alignas(16) SmallPair { float r[16][2]; };
+static_assert(sizeof(SmallPair) == 128, "SmallPair must be 128 bytes");
 
 // What ClosestHit (Hit_v6.hlsl:12-61) needs about a triangle, pre-gathered per GLOBAL triangle id:
 // object-space flat normal + area, and the three per-vertex normals with the "all(n != 0) else flat"
