@@ -142,7 +142,8 @@ def main():
             try:    # HBM bytes per launch from the rocprofv3 PMC passes of this same command (tools/rocprof_summary.py)
                 prof = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)))
                 if args.workload == "cornell_1080p_64spp_8b" and world == 1:
-                    traffic = prof["kernels"]["k_" + name]["hbm_bytes_per_launch"]
+                    sym = {"bounce_fused": "k_bounce_small"}.get(name, "k_" + name)
+                    traffic = prof["kernels"][sym]["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
             roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -294,3 +294,34 @@ def test_error_paths(rt, cornell):
         c.add_mesh(np.zeros((3, 7), np.float32), [0, 1, 5], [0, 0, 0])   # index out of range
     c.render(rt.Params(width=8, height=8, spp=0))                    # empty work is fine
     c.close()
+
+
+@pytest.mark.parametrize("kind,tris,cfg", [
+    ("sponza", 262144, dict(width=160, height=90, spp=2, max_bounces=8, nee_samples=1, flags=1)),          # C3 settings, small image
+    ("bistro", 300000, dict(width=128, height=72, spp=2, max_bounces=8, nee_samples=1, flags=0)),          # C5 materials (GGX + NEE), reduced triangle count
+])
+def test_large_scene_parity(rt, orc, kind, tris, cfg):
+    """deep-BVH scenes through the general traversal path: hit records equal the oracle's, images within 1e-4"""
+    sc = rt.Scene.sponza_class(tris, 260) if kind == "sponza" else rt.Scene.bistro_class(tris, 3800)
+    p = rt.Params(**cfg)
+    aspect = p.width / p.height
+    c = rt.Context(0); c.upload(sc, aspect)
+    o = orc.Oracle().load(sc, aspect)
+    st0 = None
+    rays = np.concatenate([o.primary_rays(p), random_rays(40000, 31, -1.5, 1.5)])
+    g, b = c.trace_closest(rays), o.trace_closest(rays, 1)
+    assert np.array_equal(bits(g)[:, 3], bits(b)[:, 3]), f"{int((bits(g)[:, 3] != bits(b)[:, 3]).sum())} hit ids differ"
+    hit = bits(b)[:, 3] != 0xFFFFFFFF
+    assert np.array_equal(bits(g)[hit], bits(b)[hit])
+    sr = random_rays(40000, 32, -1.0, 1.0, tmax=0.7)
+    assert np.array_equal(c.trace_any(sr), o.trace_any(sr, 1))
+    assert np.array_equal(bits(c.surface(rays, b)), bits(o.surface(rays, b)))
+    c.clear(p.width, p.height); c.render(p)
+    ga = c.read_accum(); ca, cnt = o.render(p)
+    st = c.stats()
+    print(kind, "tris", st.triangles, "nodes", st.bvh_nodes, "lights", st.lights, "rays", cnt, "render_ms", round(st.render_ms, 2))
+    assert (st.rays_primary, st.rays_extension, st.rays_shadow) == cnt
+    r = rel_l2(ga[..., :3], ca[..., :3])
+    print("rel_l2", r, "pixels not bit exact:", int((bits(ga) != bits(ca)).any(-1).sum()))
+    assert r <= REL_L2_TOL
+    c.close()
