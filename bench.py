@@ -57,6 +57,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--paths-per-batch", type=int, default=0)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo: host-staged gather, for testing the N>1 flow on one GPU")
+    ap.add_argument("--device", type=int, default=-1, help="force this CUDA device on every rank (testing only)")
+    ap.add_argument("--checksum", action="store_true", help="add a checksum of the final accumulation buffer to the JSON line")
+    ap.add_argument("--opt", action="append", default=[], help="tuning: rtx option id=value (repeatable)")
     args = ap.parse_args()
 
     import torch
@@ -66,19 +70,23 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = args.device if args.device >= 0 else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     rt = graft.load_package()
     from royaltracer_dx_amd import sharding
     dist = None
     if world > 1:
-        dist, rank, world = sharding.init_process_group("nccl", dev)     # backend "nccl" is RCCL on ROCm
+        dist, rank, world = sharding.init_process_group(args.dist_backend, dev)     # backend "nccl" is RCCL on ROCm
     kind, W, H, spp, bounces, nee, flags = WORKLOADS[args.workload]
     scene = make_scene(rt, kind)
-    ctx = rt.Context(local_rank)
+    ctx = rt.Context(dev_index)
     ctx.upload(scene, W / H)
     if args.paths_per_batch:
         ctx.set_option(rt.OPT_PATHS_PER_BATCH, args.paths_per_batch)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(int(k), int(v))
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
@@ -97,7 +105,11 @@ def main():
         ctx.render(params)                                   # synchronous on the bound stream
         if world > 1:                                        # final framebuffer gather over xGMI (RCCL)
             ctx.pack_tiles(params, slab.data_ptr())
-            sharding.gather_slabs(dist, slab, gathered)
+            if args.dist_backend == "gloo":                  # testing path: stage through the host
+                g = sharding.gather_slabs(dist, slab.cpu())
+                gathered.copy_(g)
+            else:
+                sharding.gather_slabs(dist, slab, gathered)
             ctx.unpack_tiles(params, gathered.data_ptr())
         return ctx.stats()
 
@@ -110,19 +122,21 @@ def main():
         frame(i)
     ctx.set_option(rt.OPT_KERNEL_TIMING, 0 if args.no_kernel_timing else 1)
     kms = np.zeros(rt.K_COUNT); kitems = np.zeros(rt.K_COUNT); klaunch = np.zeros(rt.K_COUNT)
-    rays = np.zeros(3)
+    rays = np.zeros(3); phits = 0.0
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         st = frame(args.warmup + i)
         kms += np.array(st.kernel_ms[:]); kitems += np.array(st.kernel_items[:], dtype=np.float64); klaunch += np.array(st.kernel_launches[:], dtype=np.float64)
-        rays += np.array([st.rays_primary, st.rays_extension, st.rays_shadow], dtype=np.float64)
+        rays += np.array([st.rays_primary, st.rays_extension, st.rays_shadow], dtype=np.float64); phits += st.primary_hits
     barrier()
     dt = time.perf_counter() - t0
     dt_max, rays_all = dt, rays
     if world > 1:
-        dt_max = sharding.max_over_ranks(dist, dt, dev)
-        rays_all = sharding.sum_over_ranks(dist, rays, dev)
+        cdev = dev if args.dist_backend == "nccl" else None
+        dt_max = sharding.max_over_ranks(dist, dt, cdev)
+        rays_all = sharding.sum_over_ranks(dist, rays, cdev)
+        # (phits stays rank-local: it only prices rank 0's own kernel launches below)
     ms_per_step = dt_max * 1e3 / max(args.steps, 1)
     value = float(rays_all.sum()) / dt_max / 1e6 if dt_max > 0 else 0.0
 
@@ -134,8 +148,8 @@ def main():
             k = int(np.argmax(kms))
             name = rt.KERNEL_NAMES[k]
             bytes_per_launch = ALG_BYTES[name] * kitems[k] / max(klaunch[k], 1)
-            if name == "bounce_fused":
-                bytes_per_launch += 96.0 * rays[2] / max(klaunch[k], 1)
+            if name == "bounce_fused":      # bounce 0 items were traced by raygen (their 48 B belong to it); + 96 B per shadow ray
+                bytes_per_launch += (96.0 * rays[2] - 48.0 * phits) / max(klaunch[k], 1)
             avg_ms = kms[k] / max(klaunch[k], 1)
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             traffic = None
@@ -183,6 +197,9 @@ def main():
                           "rays_per_frame": {"primary": int(rays_all[0] / max(args.steps, 1)), "extension": int(rays_all[1] / max(args.steps, 1)),
                                              "shadow": int(rays_all[2] / max(args.steps, 1))}},
                "roofline": roof, "cpu_baseline": cpu}
+        if args.checksum:
+            import hashlib
+            out["accum_sha1"] = hashlib.sha1(accum.cpu().numpy().tobytes()).hexdigest()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -69,6 +69,7 @@ typedef struct rtx_stats {
     uint64_t kernel_items[RTX_K_COUNT];                   /* work items (rays / paths) processed per class */
     double   render_ms;                                   /* hipEvent time of the whole rtx_render on its stream */
     uint32_t bvh_nodes, triangles, lights, materials;
+    uint64_t primary_hits;                                /* camera rays that hit the scene (items of the bounce-0 shading launch) */
 } rtx_stats;
 
 enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents (rtx_stats.kernel_ms) */
@@ -76,7 +77,8 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
        RTX_OPT_SORT_MATERIALS = 3,   /* 0/1: material-sorted shading queue */
        RTX_OPT_LDS_NODES = 4,        /* BVH nodes staged in LDS per workgroup (top of tree) */
        RTX_OPT_SMALL_SCENE = 5,      /* 0/1: brute-force pre-test path for scenes of <= 64 triangles (default 1) */
-       RTX_OPT_FUSED_BOUNCE = 6      /* 0/1: with SMALL_SCENE, fuse trace+shade+shadow into one kernel per bounce (default 1) */ };
+       RTX_OPT_FUSED_BOUNCE = 6,     /* 0/1: with SMALL_SCENE, fuse trace+shade+shadow into one kernel per bounce (default 1) */
+       RTX_OPT_BOUNCE_VARIANT = 7    /* tuning: register budget of the fused kernel as waves/SIMD (4, 5 or 6) */ };
 
 /* lifetime: replaces LoadPipeline/device creation (Renderer.cpp:106-254) and OnDestroy (:546-552) */
 int  rtx_create(int device_ordinal, rtx_ctx** out);

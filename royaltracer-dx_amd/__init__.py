@@ -35,7 +35,7 @@ FLAG_LAMBERT_ONLY = 1
 FLAG_JITTER = 2
 K_RAYGEN, K_TRACE, K_SHADE, K_SHADOW, K_ACCUM, K_SORT, K_BOUNCE, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 8
 KERNEL_NAMES = {K_RAYGEN: "raygen", K_TRACE: "trace_closest", K_SHADE: "shade", K_SHADOW: "trace_shadow", K_ACCUM: "accumulate", K_SORT: "sort", K_BOUNCE: "bounce_fused"}
-OPT_KERNEL_TIMING, OPT_PATHS_PER_BATCH, OPT_SORT_MATERIALS, OPT_LDS_NODES, OPT_SMALL_SCENE, OPT_FUSED_BOUNCE = 1, 2, 3, 4, 5, 6
+OPT_KERNEL_TIMING, OPT_PATHS_PER_BATCH, OPT_SORT_MATERIALS, OPT_LDS_NODES, OPT_SMALL_SCENE, OPT_FUSED_BOUNCE, OPT_BOUNCE_VARIANT = 1, 2, 3, 4, 5, 6, 7
 
 
 class RtxError(RuntimeError):
@@ -63,7 +63,8 @@ class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_extension", C.c_uint64), ("rays_shadow", C.c_uint64),
                 ("paths", C.c_uint64), ("kernel_ms", C.c_double * K_COUNT), ("kernel_launches", C.c_uint64 * K_COUNT),
                 ("kernel_items", C.c_uint64 * K_COUNT), ("render_ms", C.c_double),
-                ("bvh_nodes", C.c_uint32), ("triangles", C.c_uint32), ("lights", C.c_uint32), ("materials", C.c_uint32)]
+                ("bvh_nodes", C.c_uint32), ("triangles", C.c_uint32), ("lights", C.c_uint32), ("materials", C.c_uint32),
+                ("primary_hits", C.c_uint64)]
 
     @property
     def rays(self):

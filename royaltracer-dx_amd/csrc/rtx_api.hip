@@ -121,6 +121,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_LDS_NODES: c->lds_nodes_opt = (int)value; c->committed = false; return RTX_OK;
     case RTX_OPT_SMALL_SCENE: c->small_scene = value != 0; c->committed = false; return RTX_OK;
     case RTX_OPT_FUSED_BOUNCE: c->fused = value != 0; return RTX_OK;
+    case RTX_OPT_BOUNCE_VARIANT: g_bounce_variant = (int)value; return RTX_OK;
     default: c->err = "unknown option"; return RTX_ERR_INVALID;
     }
 }
@@ -284,7 +285,7 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     memset(c->stats.kernel_ms, 0, sizeof(c->stats.kernel_ms));
     memset(c->stats.kernel_launches, 0, sizeof(c->stats.kernel_launches));
     memset(c->stats.kernel_items, 0, sizeof(c->stats.kernel_items));
-    c->stats.rays_primary = c->stats.rays_extension = c->stats.rays_shadow = c->stats.paths = 0; c->stats.render_ms = 0;
+    c->stats.rays_primary = c->stats.rays_extension = c->stats.rays_shadow = c->stats.paths = c->stats.primary_hits = 0; c->stats.render_ms = 0;
     if (p->spp == 0) return RTX_OK;
 
     const uint32_t nee = c->dsc.nlights ? p->nee_samples : 0;
@@ -313,7 +314,7 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     // per-workgroup counters of one batch: Q[b][G] queue lengths entering bounce b (b = 0..mb),
     // S[b][j][G] shadow queue lengths; every workgroup stores its own entry, so nothing needs zeroing per batch
     const uint32_t mb = p->max_bounces;
-    const size_t ncnt = ((size_t)(mb + 1) + (size_t)mb * nee1) * G;
+    const size_t ncnt = ((size_t)(mb + 1) + (size_t)mb * nee1 + 1) * G;    // + one row: paths generated (fused raygen+trace)
     const uint32_t nbatches = (p->spp + bspp - 1) / bspp;
     HIPCHK(c, c->d_counters.ensure(ncnt * 4));
     if (c->h_counters_words < ncnt * nbatches) {
@@ -335,11 +336,14 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
         DevFrame fb = f;
         fb.sample_first = p->sample_base + bi * bspp;
         fb.batch_spp = std::min(bspp, p->spp - bi * bspp);
-        { Timed t(c, RTX_K_RAYGEN); launch_raygen(st, fb, P, cam, queue[0], Q(0)); }
+        const bool fused = c->dsc.nsmall && c->fused;
+        uint32_t* gen_row = cnt + ((size_t)(mb + 1) + (size_t)mb * nee1) * G;
+        if (fused) { Timed t(c, RTX_K_RAYGEN); launch_raygen_trace_small(st, c->dsc, fb, P, cam, queue[0], Q(0), gen_row); }
+        else { Timed t(c, RTX_K_RAYGEN); launch_raygen(st, fb, P, cam, queue[0], Q(0)); }
         for (uint32_t b = 0; b < mb; b++) {
             uint32_t* q = queue[b & 1]; uint32_t* qn = queue[(b + 1) & 1];
-            if (c->dsc.nsmall && c->fused) {      // tiny scene: trace + shade + shadow fused into one kernel per bounce
-                Timed t(c, RTX_K_BOUNCE); launch_bounce_small(st, c->dsc, fb, P, b, q, Q(b), qn, Q(b + 1), S(b, 0));
+            if (fused) {      // tiny scene: trace + shade + shadow fused into one kernel per bounce (bounce 0 was traced by raygen)
+                Timed t(c, RTX_K_BOUNCE); launch_bounce_small(st, c->dsc, fb, P, b, b == 0, q, Q(b), qn, Q(b + 1), S(b, 0));
                 continue;
             }
             { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, fb, c->dsc, P, b, q, Q(b)); }
@@ -358,14 +362,16 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     for (uint32_t bi = 0; bi < nbatches; bi++) {
         const uint32_t* h = c->h_counters + (size_t)bi * ncnt;
         auto sumG = [&](size_t row) { uint64_t s = 0; for (uint32_t g = 0; g < G; g++) s += h[row * G + g]; return s; };
-        const uint64_t prim = sumG(0);
+        const bool fusedb = c->dsc.nsmall && c->fused;
+        const uint64_t prim = fusedb ? sumG((size_t)(mb + 1) + (size_t)mb * nee1) : sumG(0);
         c->stats.rays_primary += prim; c->stats.paths += prim;
+        c->stats.primary_hits += fusedb ? sumG(0) : 0;
         for (uint32_t b = 1; b < mb; b++) c->stats.rays_extension += sumG(b);
         for (uint32_t b = 0; b < mb; b++) for (uint32_t j = 0; j < nee; j++) c->stats.rays_shadow += sumG((size_t)(mb + 1) + (size_t)b * nee1 + j);
     }
     c->stats.kernel_items[RTX_K_RAYGEN] = c->stats.paths;
     const bool fused = c->dsc.nsmall && c->fused;
-    c->stats.kernel_items[RTX_K_BOUNCE] = fused ? c->stats.rays_primary + c->stats.rays_extension : 0;
+    c->stats.kernel_items[RTX_K_BOUNCE] = fused ? c->stats.primary_hits + c->stats.rays_extension : 0;   // bounce 0 shades the primary hits only
     c->stats.kernel_items[RTX_K_TRACE] = fused ? 0 : c->stats.rays_primary + c->stats.rays_extension;
     c->stats.kernel_items[RTX_K_SHADE] = fused ? 0 : c->stats.rays_primary + c->stats.rays_extension;
     c->stats.kernel_items[RTX_K_SHADOW] = fused ? 0 : c->stats.rays_shadow;

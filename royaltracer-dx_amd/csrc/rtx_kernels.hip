@@ -275,6 +275,53 @@ __device__ __forceinline__ void trace_ray(const DevScene& sc, const SmallPair* _
     else traverse<ANY>(sc, L, o, d, tmin, tmax, bt, bu, bv, bprim);
 }
 
+// Tiny-scene bounce 0: generate the primary ray AND trace it; only paths that hit something are enqueued (their
+// hit record goes to p.hit), so the bounce-0 shading kernel runs without the idle lanes of the camera rays that
+// leave the scene (43 % of them on the Cornell view).  Missed paths only get their radiance slot zeroed.
+__global__ __launch_bounds__(kBlock) void k_raygen_trace_small(DevScene sc, const SmallPair* __restrict__ small, DevFrame f, DevPaths p, const CameraGPU* __restrict__ cam_p,
+                                                               uint32_t* __restrict__ queue, uint32_t* __restrict__ qcount, uint32_t* __restrict__ gencount) {
+    extern __shared__ F4 lds[];
+    __shared__ CameraGPU cam;
+    __shared__ uint32_t s_n[2];
+    if (threadIdx.x < 32) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
+    if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+    const TraceLds L = stage_lds(sc, lds);
+    __syncthreads();
+    uint32_t* myq = queue + (size_t)blockIdx.x * f.qcap;
+    const uint32_t nchunks = f.chunks_per_sample * f.batch_spp;
+    uint32_t generated = 0;
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const uint32_t sl = c / f.chunks_per_sample, cl = c - sl * f.chunks_per_sample;
+        const uint32_t pl = cl * kBlock + threadIdx.x;
+        const uint32_t pid = sl * f.npl + pl;
+        uint32_t x = 0, y = 0, s0 = 0, s1 = 0;
+        const bool valid = slot_to_pixel(f, pl, x, y);
+        f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
+        if (valid) {
+            seed_init(x, y, f.sample_first + sl, f.frame_seed, s0, s1);
+            float jx = 0.0f, jy = 0.0f;
+            if (f.flags & 2u) { jx = tea_next(s0, s1); jy = tea_next(s0, s1); }
+            primary_ray(cam, f.width, f.height, x, y, jx, jy, o, d);
+            generated++;
+        }
+        float t, u, v; uint32_t prim;
+        traverse_small<false>(sc, small, L, o, d, kTMinCam, valid ? kTMax : 0.0f, t, u, v, prim);
+        const bool hit = valid && prim != kMissPrim;
+        if (valid) p.rad[pid] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (hit) {
+            p.ray_o[pid] = {o.x, o.y, o.z, u2f(s1)};
+            p.ray_d[pid] = {d.x, d.y, d.z, 1.0f};
+            p.thr[pid] = {1.0f, 1.0f, 1.0f, u2f(s0)};
+            p.hit[pid] = {t, u, v, u2f(prim)};
+        }
+        const uint32_t slot = block_push(hit, &s_n[0]);
+        if (hit) myq[slot] = pid;
+    }
+    atomicAdd(&s_n[1], generated);
+    __syncthreads();
+    if (threadIdx.x == 0) { qcount[blockIdx.x] = s_n[0]; gencount[blockIdx.x] = s_n[1]; }
+}
+
 // closest hit for every path in this workgroup's sub-queue: reads ray_o/ray_d, writes hit
 __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const SmallPair* __restrict__ small, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin) {
     extern __shared__ F4 lds[];
@@ -503,7 +550,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPa
 // rays and add their contributions, sample the BSDF, compact — all in one pass over the workgroup's sub-queue.
 // Nothing but the 48-B path state and the queue index moves through HBM; hit records and shadow-ray entries
 // stay in registers.  Radiance additions happen in the oracle's order (emissive, then NEE slot 0, 1, ...).
-__global__ __launch_bounds__(kBlock) void k_bounce_small(DevScene sc, const SmallPair* __restrict__ small, DevFrame f, DevPaths p, uint32_t bounce,
+template <int WAVES, bool HAVE_HIT>
+__global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, const SmallPair* __restrict__ small, DevFrame f, DevPaths p, uint32_t bounce,
                                                          const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount,
                                                          uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count,
                                                          uint32_t* __restrict__ shcounts /* [nee][gridDim.x]: shadow rays traced (statistics) */) {
@@ -524,8 +572,10 @@ __global__ __launch_bounds__(kBlock) void k_bounce_small(DevScene sc, const Smal
         const bool active = i < n;
         PathState S; S.pid = 0; S.o = mk3(0, 0, 0); S.d = mk3(0, 0, 1); S.thr = mk3(0, 0, 0); S.prev_pdf = 1.0f; S.s0 = S.s1 = 0;
         if (active) S = load_path(p, myq[i]);
-        float t, u, v; uint32_t prim;
-        traverse_small<false>(sc, small, L, S.o, S.d, tmin, active ? kTMax : 0.0f, t, u, v, prim);   // inactive lanes: empty interval
+        float t = 0.0f, u = 0.0f, v = 0.0f; uint32_t prim = kMissPrim;
+        if (HAVE_HIT) {                                   // bounce 0: the primary hit comes from k_raygen_trace_small
+            if (active) { const F4 h = p.hit[S.pid]; t = h.x; u = h.y; v = h.z; prim = f2u(h.w); }
+        } else traverse_small<false>(sc, small, L, S.o, S.d, tmin, active ? kTMax : 0.0f, t, u, v, prim);   // inactive lanes: empty interval
         Surf sf; sf.mat = 0; sf.normal = mk3(0, 0, 1); sf.pos = mk3(0, 0, 0);
         bool shading = false;
         if (active && prim != kMissPrim) {
@@ -688,6 +738,8 @@ __global__ __launch_bounds__(kBlock) void k_dbg_primary(DevFrame f, const Camera
     rays[2 * i + 1] = {d.x, d.y, d.z, kTMax};
 }
 
+int g_bounce_variant = 4;
+
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
@@ -703,12 +755,17 @@ size_t trace_lds_bytes(const DevScene& sc) {
 void launch_raygen(hipStream_t st, const DevFrame& f, const DevPaths& p, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount) {
     hipLaunchKernelGGL(k_raygen, dim3(f.nblocks), dim3(kBlock), 0, st, f, p, cam, queue, qcount);
 }
+void launch_raygen_trace_small(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount, uint32_t* gencount) {
+    hipLaunchKernelGGL(k_raygen_trace_small, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, cam, queue, qcount, gencount);
+}
 void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t bounce, const uint32_t* queue, const uint32_t* qcount) {
     hipLaunchKernelGGL(k_trace_closest, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, queue, qcount, f.qcap, bounce == 0 ? kTMinCam : kSBias);
 }
-void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce,
+void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce, bool have_hit,
                          const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts) {
-    hipLaunchKernelGGL(k_bounce_small, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);
+    // 4 waves/SIMD (114 VGPRs, no spills); forcing 5 or 6 spills to scratch and measured 6 % / 16 % slower
+    if (have_hit) hipLaunchKernelGGL((k_bounce_small<4, true>), dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);
+    else hipLaunchKernelGGL((k_bounce_small<4, false>), dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);
 }
 void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t j, const uint32_t* shcount) {
     const size_t seg = (size_t)j * f.qcap * f.nblocks;

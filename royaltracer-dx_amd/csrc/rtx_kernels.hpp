@@ -46,10 +46,12 @@ struct DevPaths {
     F4* sh_c;    // contribution.xyz, pid bits
 };
 
+extern int g_bounce_variant;   // tuning knob: waves/SIMD the fused kernel is compiled for (4, 5 or 6)
 size_t trace_lds_bytes(const DevScene& sc);
 void launch_raygen(hipStream_t, const DevFrame&, const DevPaths&, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount);
 void launch_trace_closest(hipStream_t, const DevFrame&, const DevScene&, const DevPaths&, uint32_t bounce, const uint32_t* queue, const uint32_t* qcount);
-void launch_bounce_small(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, uint32_t bounce,
+void launch_raygen_trace_small(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount, uint32_t* gencount);
+void launch_bounce_small(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, uint32_t bounce, bool have_hit,
                          const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts);
 void launch_trace_shadow(hipStream_t, const DevFrame&, const DevScene&, const DevPaths&, uint32_t j, const uint32_t* shcount);
 void launch_shade(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, uint32_t bounce,
