@@ -112,6 +112,15 @@ int  rtx_bind_accum(rtx_ctx*, void* device_rgba32f, size_t bytes);
 int  rtx_clear_accum(rtx_ctx*, uint32_t width, uint32_t height);   /* view-change reset (RayGen_v6_pass3.hlsl:407-423) */
 /* 3x DispatchRays (PopulateCommandList, Renderer.cpp:646-673) -> here: the wavefront loop; synchronous on return */
 int  rtx_render(rtx_ctx*, const rtx_params*);
+/* The reference's OWN first pass, literally: RayGen of RayGen_v6_pass1.hlsl:48-190 (first DispatchRays,
+   Renderer.cpp:651-654): primary hit, SampleRIS (Sampler_v6.hlsl:653-736), visibility, SamplePathSimple
+   (Path_Sampler_v6.hlsl:3-286).  params: nee_samples = nee_samples_DI = nee_samples (Common_v6.hlsl:8-9, reference 4),
+   max_bounces = `bounces` (:11, reference 3), spp samples are run one after the other; sdata.debug (or L1 on emissive
+   primary hits) is added to u1.  The pass-1 outputs u2 `g_Reservoirs_current` / u4 `g_Reservoirs_current_gi` (40 B) and
+   u6 `g_sample_current` (60 B) keep the last sample, in MapPixelID order (Common_v6.hlsl:173-198). */
+int  rtx_render_v6_pass1(rtx_ctx*, const rtx_params*);
+size_t rtx_pass1_slots(uint32_t width, uint32_t height);            /* records per buffer: ceil(w/4)*ceil(h/4)*16 */
+int  rtx_read_pass1_buffers(rtx_ctx*, void* reservoirs_di40, void* reservoirs_gi40, void* samples60, size_t slots);
 int  rtx_read_accum(rtx_ctx*, float* rgba32f, size_t bytes);       /* copy of u1 to the host */
 /* u0 `gOutput` layer 0, RGBA8 UNORM after sRGB OETF (RayGen_v6_pass3.hlsl:405,428-441; Common_v6.hlsl:353-376) */
 int  rtx_read_srgb8(rtx_ctx*, uint8_t* rgba8, size_t bytes);

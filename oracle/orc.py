@@ -51,6 +51,9 @@ _sig("orc_set_camera", C.c_int, _vp, _fp, _fp)
 _sig("orc_set_threads", C.c_int, _vp, C.c_int)
 _sig("orc_render", C.c_int, _vp, C.POINTER(Params), _vp, C.POINTER(C.c_uint64))
 _sig("orc_srgb8", None, _vp, _u32, _vp)
+_sig("orc_render_v6_pass1", C.c_int, _vp, C.POINTER(Params), _vp, _vp, _vp, _vp, C.POINTER(C.c_uint64))
+_sig("orc_pass1_slots", C.c_size_t, _u32, _u32)
+_sig("orc_map_pixel_id", _u32, _u32, _u32, _u32)
 _sig("orc_tea", None, _u32p, _u32, _vp)
 _sig("orc_seed_init", None, _u32, _u32, _u32, _u32, _u32p)
 _sig("orc_sincos", None, C.c_float, _fp, _fp)
@@ -82,7 +85,7 @@ class Oracle:
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and lib is not None:
             lib.orc_destroy(h)
 
     __del__ = close
@@ -117,6 +120,17 @@ class Oracle:
         cnt = (C.c_uint64 * 3)()
         assert lib.orc_render(self._h, C.byref(p), _p(accum), cnt) == 0
         return accum, (cnt[0], cnt[1], cnt[2])
+
+    def render_v6_pass1(self, params, accum=None):
+        """-> accum, (res_di (n,40) u8, res_gi (n,40) u8, sdata (n,60) u8), ray counts"""
+        p = params_from(params)
+        if accum is None:
+            accum = np.zeros((p.height, p.width, 4), np.float32)
+        n = lib.orc_pass1_slots(p.width, p.height)
+        di, gi, sd = np.zeros((n, 40), np.uint8), np.zeros((n, 40), np.uint8), np.zeros((n, 60), np.uint8)
+        cnt = (C.c_uint64 * 3)()
+        assert lib.orc_render_v6_pass1(self._h, C.byref(p), _p(accum), _p(di), _p(gi), _p(sd), cnt) == 0
+        return accum, (di, gi, sd), (cnt[0], cnt[1], cnt[2])
 
     def primary_rays(self, params, sample_id=1):
         p = params_from(params)

@@ -879,6 +879,327 @@ int orc_render(orc_ctx* c, const orc_params* p, float* accum, uint64_t ray_count
     return 0;
 }
 
+/* =====================================================================================================
+ * The v6 PASS-1 estimator, restated literally: RayGen_v6_pass1.hlsl:48-190 = primary hit, RIS for direct
+ * light (SampleRIS, Sampler_v6.hlsl:653-736, a21), its visibility ray, and SamplePathSimple
+ * (Path_Sampler_v6.hlsl:3-286, a22) with its quirks kept: abs cosines and unshadowed NEE inside the loop,
+ * two SelectSamplingStrategy draws per bounce, reservoir updates that consume random numbers, half-precision
+ * L2 / E3 / L1, the `pdf_light = 1` initial value.  Outputs are the reference's own buffers:
+ * Reservoir_DI / Reservoir_GI (40 B) and SampleData (60 B) at MapPixelID order (Reservoir_v6.hlsl:1-33,
+ * Common_v6.hlsl:173-198); the accumulated radiance is sdata.debug (pass1:173-174), or L1 for emissive
+ * primary hits (pass3:457-462).
+ * DEVIATIONS: a ray that misses ends the estimator at that point with zero contribution (v6 reads an
+ * uninitialised payload); uint(time) := frame_seed and the literal sample id 1 := s.
+ * ===================================================================================================== */
+static inline uint16_t half_bits(float x) {          /* x is already half-representable after orc_half_round */
+    float r = orc_half_round(x);
+    uint32_t u = f2u(r), sign = (u >> 16) & 0x8000u, a = u & 0x7FFFFFFFu;
+    if (a >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | ((a & 0x007FFFFFu) ? 0x200u : 0u));
+    if (a == 0) return (uint16_t)sign;
+    int e = (int)(a >> 23) - 127;
+    if (e < -14) { float q = u2f(a) * 16777216.0f; return (uint16_t)(sign | (uint32_t)q); }    /* subnormal half */
+    return (uint16_t)(sign | (uint32_t)((e + 15) << 10) | ((a >> 13) & 0x3FFu));
+}
+static inline v3 half3(v3 a) { return V3(orc_half_round(a.x), orc_half_round(a.y), orc_half_round(a.z)); }
+
+typedef struct { v3 x2; float w_sum; v3 n2; float W; v3 L2; uint32_t M; } res_t;     /* L2 holds half-rounded values */
+
+/* raw lobes for a direction L (= -incidence): f0,f1 / q0,q1 / (p_d,p_s) */
+static inline void lobes(const orc_ctx* c, uint32_t mid, uint32_t flags, v3 normal, v3 L, v3 outgoing_eval, v3 outgoing_pdf,
+                         v3* f0, v3* f1, float* q0, float* q1, float* pd, float* ps) {
+    const matopt_t* m = &c->mopt[mid];
+    strategy_probs(m, outgoing_eval, normal, flags, pd, ps);
+    *f0 = lambert_eval(m); *q0 = lambert_pdf(normal, L);
+    if (flags & ORC_FLAG_LAMBERT_ONLY) { *f1 = V3(0, 0, 0); *q1 = 0.0f; }
+    else { *f1 = ggx_eval(m, c->mats + (size_t)mid * 32, normal, L, outgoing_eval); *q1 = ggx_pdf(m, normal, L, outgoing_pdf); }
+}
+/* light triangle by CDF: Sampler_v6.hlsl:291-307 */
+static inline const float* pick_light(const orc_ctx* c, float rv) {
+    int left = 0, right = (int)c->nlights - 1, sel = 0;
+    while (left <= right) { int mid = left + (right - left) / 2; if (rv < c->lights[(size_t)mid * 20 + 3]) { sel = mid; right = mid - 1; } else left = mid + 1; }
+    return c->lights + (size_t)sel * 20;
+}
+typedef struct { v3 sp, Ln, nl; float dist2, dist, pdf_l; const float* lt; } lsample_t;
+/* shared front part of SampleLightNEE / SampleLightNEE_GI: :291-331 / :523-573 */
+static inline lsample_t light_point(const orc_ctx* c, v3 origin, uint32_t seed[2]) {
+    lsample_t r;
+    r.lt = pick_light(c, rnd(seed));
+    uint32_t li; memcpy(&li, &r.lt[7], 4);
+    const float* M = c->insts[li].o2w;
+    v3 xv = xform_point(M, V3(r.lt[0], r.lt[1], r.lt[2])), yv = xform_point(M, V3(r.lt[4], r.lt[5], r.lt[6])), zv = xform_point(M, V3(r.lt[8], r.lt[9], r.lt[10]));
+    float xi1 = rnd(seed), xi2 = rnd(seed);
+    if (xi1 + xi2 > 1.0f) { xi1 = 1.0f - xi1; xi2 = 1.0f - xi2; }
+    float u = 1.0f - xi1 - xi2, v = xi1, w = xi2;
+    r.sp = V3(u * xv.x + v * yv.x + w * zv.x, u * xv.y + v * yv.y + w * zv.y, u * xv.z + v * yv.z + w * zv.z);
+    v3 Lv = sub3(r.sp, origin);
+    r.dist2 = dot3(Lv, Lv); r.dist = sqrtf(maxf(r.dist2, EPSILON_)); r.Ln = normalize3(Lv);
+    v3 cl = cross3(sub3(yv, xv), sub3(zv, xv));
+    r.nl = normalize3(cl);
+    if (dot3(r.nl, neg3(r.Ln)) < 0.0f) r.nl = neg3(r.nl);
+    r.pdf_l = r.lt[11] / maxf(fabsf(length3(cl) * 0.5f), EPSILON_);
+    return r;
+}
+/* UpdateReservoir / UpdateReservoir_GI: Reservoir_v6.hlsl:36-80 */
+static inline int res_update(res_t* r, float wi, v3 x, v3 n, v3 L, uint32_t seed[2]) {
+    r->w_sum += wi;
+    if (rnd(seed) < wi / r->w_sum) { r->x2 = x; r->n2 = n; r->L2 = half3(L); return 1; }
+    return 0;
+}
+/* ReconnectDI: Sampler_v6.hlsl:106-131 */
+static v3 reconnect_di(const orc_ctx* c, uint32_t mid, uint32_t flags, v3 x1, v3 n1, v3 x2, v3 n2, v3 L, v3 outgoing) {
+    v3 dir = sub3(x2, x1);
+    float dist = length3(dir);
+    float cos1 = maxf(0.0f, dot3(n1, normalize3(dir)));
+    if (dot3(n2, normalize3(neg3(dir))) < 0.0f) n2 = neg3(n2);
+    float cos2 = maxf(0.0f, dot3(n2, normalize3(neg3(dir))));
+    v3 f0, f1; float q0, q1, pd, ps;
+    lobes(c, mid, flags, n1, normalize3(dir), normalize3(outgoing), normalize3(outgoing), &f0, &f1, &q0, &q1, &pd, &ps);
+    v3 F = add3(safe_mul3(pd, f0), safe_mul3(ps, f1));
+    float d2 = dist * dist;
+    return V3(F.x * L.x * cos1 * cos2 / d2, F.y * L.y * cos1 * cos2 / d2, F.z * L.z * cos1 * cos2 / d2);
+}
+/* VisibilityCheck: Sampler_v6.hlsl:86-104 */
+static float visibility(const orc_ctx* c, v3 x1, v3 n1, v3 dir, float dist, uint64_t cnt[3]) {
+    v3 o = add3(x1, scale3(normalize3(n1), S_BIAS));
+    cnt[2]++;
+    return any_bvh(c, o, dir, 0.0f, maxf(dist - 10.0f * S_BIAS, 2.0f * S_BIAS)) ? 0.0f : 1.0f;
+}
+/* MaterialOptimized of a hit; returns 0 for a miss */
+static inline int hit_material(const orc_ctx* c, v3 o, v3 d, float tmin, surf_t* sf, uint64_t cnt[3], int primary) {
+    hit_t h = closest_bvh(c, o, d, tmin, 10000.0f);
+    cnt[primary ? 0 : 1]++;
+    if (h.prim == MISS_PRIM) return 0;
+    *sf = surface(c, o, d, h);
+    return sf->mat < c->nmat;
+}
+static inline float full_ke_len(const orc_ctx* c, uint32_t mid) { const float* m = c->mats + (size_t)mid * 32; return length3(V3(m[8], m[9], m[10])); }
+
+/* SampleRIS: Sampler_v6.hlsl:653-736 with SampleLightNEE (:273-396) and SampleLightBSDF (:199-271) inlined */
+static void sample_ris(const orc_ctx* c, uint32_t M1, uint32_t M2, uint32_t flags, v3 outgoing, res_t* rs, const surf_t* pay, uint32_t seed[2], uint64_t cnt[3]) {
+    const matopt_t* m = &c->mopt[pay->mat];
+    uint32_t strategy = select_strategy(m, outgoing, pay->normal, flags, seed);
+    v3 origin = pay->pos, normal = pay->normal;
+    for (uint32_t i = 0; i < M1 && c->nlights; i++) {
+        lsample_t ls = light_point(c, origin, seed);
+        float cos_x = dot3(normal, ls.Ln), cos_y = dot3(ls.nl, neg3(ls.Ln));
+        float G = maxf(cos_y * cos_x / ls.dist2, EPSILON_);                                  /* :347 */
+        v3 em = V3(ls.lt[12], ls.lt[13], ls.lt[14]);
+        v3 f0, f1; float q0, q1, pd, ps;
+        lobes(c, pay->mat, flags, normal, ls.Ln, normalize3(outgoing), normalize3(outgoing), &f0, &f1, &q0, &q1, &pd, &ps);
+        v3 F = add3(safe_mul3(pd, f0), safe_mul3(ps, f1));
+        float P = safe_mul1(pd, q0 * cos_y / ls.dist2) + safe_mul1(ps, q1 * cos_y / ls.dist2);   /* :357-366 area measure */
+        float p_hat = length3(V3(em.x * F.x * G * 1.0f, em.y * F.y * G * 1.0f, em.z * F.z * G * 1.0f));   /* :383 */
+        float pdf_light = maxf(EPSILON_, ls.pdf_l);
+        float mi = pdf_light / ((float)M1 * pdf_light + (float)M2 * P);
+        float wi = mi * p_hat / pdf_light;
+        if (p_hat > 0.0f) res_update(rs, wi, ls.sp, ls.nl, em, seed);
+    }
+    for (uint32_t j = 0; j < M2; j++) {
+        float pdf_light = 0.0f, pdf_bsdf = 0.0f, p_hat = 0.0f;
+        v3 em = V3(0, 0, 0), x2 = V3(0, 0, 0), n2 = V3(0, 0, 0);
+        v3 smp = sample_bsdf(c, pay->mat, strategy, outgoing, normal, seed);
+        surf_t h2;
+        if (hit_material(c, origin, smp, S_BIAS, &h2, cnt, 0)) {
+            const float* mk = c->mats + (size_t)h2.mat * 32;
+            float Ke = mk[8] + mk[9] + mk[10];
+            em = V3(mk[8], mk[9], mk[10]); x2 = h2.pos; n2 = h2.normal;
+            if (Ke > EPSILON_ && c->nlights) {
+                float dist = length3(sub3(h2.pos, origin)), dist2 = dist * dist;
+                float cos_t = dot3(h2.normal, neg3(smp));
+                pdf_light = (Ke / 3.0f) / c->total_weight;
+                v3 f0, f1; float q0, q1, pd, ps;
+                lobes(c, pay->mat, flags, normal, smp, normalize3(outgoing), outgoing, &f0, &f1, &q0, &q1, &pd, &ps);
+                v3 F = add3(safe_mul3(pd, f0), safe_mul3(ps, f1));
+                pdf_bsdf = safe_mul1(pd, q0 * cos_t / dist2) + safe_mul1(ps, q1 * cos_t / dist2);
+                float ndot = dot3(normal, smp);
+                p_hat = length3(V3(F.x * em.x * ndot * cos_t / dist2, F.y * em.y * ndot * cos_t / dist2, F.z * em.z * ndot * cos_t / dist2));
+            }
+        }
+        float mi = pdf_bsdf / ((float)M1 * pdf_light + (float)M2 * pdf_bsdf);
+        float wi = mi * p_hat / pdf_bsdf;
+        if (p_hat > 0.0f) res_update(rs, wi, x2, n2, em, seed);
+    }
+    rs->M = 1;
+}
+
+/* SamplePathSimple: Path_Sampler_v6.hlsl:3-286 with SampleLightNEE_GI (Sampler_v6.hlsl:508-647) and
+   SampleLightBSDF_GI (:399-505) inlined, visibility flags as the reference passes them (false) */
+static v3 sample_path_simple(const orc_ctx* c, const orc_params* p, res_t* rs, v3 init_point, v3 init_normal, v3 init_outgoing, uint32_t init_mat,
+                             uint32_t seed[2], uint64_t cnt[3]) {
+    const uint32_t flags = p->flags, nee = c->nlights ? p->nee_samples : 0;
+    v3 acc_f = V3(1, 1, 1), acc_f_rec = V3(1, 1, 1), acc_L = V3(0, 0, 0);
+    float acc_pdf = 1.0f;
+    v3 x1s = V3(0, 0, 0), x2s = V3(0, 0, 0);
+    v3 origin = init_point, normal = init_normal, outgoing = normalize3(init_outgoing);
+    uint32_t mat = init_mat;
+    {   /* 1) first BSDF bounce, :37-99 */
+        uint32_t st = select_strategy(&c->mopt[mat], outgoing, normal, flags, seed);
+        v3 smp = sample_bsdf(c, mat, st, outgoing, normal, seed);
+        surf_t h;
+        if (!hit_material(c, origin, smp, S_BIAS, &h, cnt, 0)) return V3(0, 0, 0);
+        if (full_ke_len(c, h.mat) > 0.0f) return V3(0, 0, 0);                                  /* :55-60 */
+        v3 incoming = normalize3(neg3(smp));
+        v3 f0, f1; float q0, q1, pd, ps;
+        lobes(c, mat, flags, normal, neg3(incoming), outgoing, outgoing, &f0, &f1, &q0, &q1, &pd, &ps);
+        v3 F = add3(safe_mul3(pd, f0), safe_mul3(ps, f1));
+        float P = safe_mul1(pd, q0) + safe_mul1(ps, q1);
+        float NdotL = dot3(normal, smp);
+        acc_pdf *= P;
+        acc_f = V3(acc_f.x * (F.x * NdotL), acc_f.y * (F.y * NdotL), acc_f.z * (F.z * NdotL));
+        outgoing = incoming; mat = h.mat; normal = h.normal; origin = h.pos;
+    }
+    const v3 xn = origin, nn = normalize3(normal);                                              /* :104-106 */
+    for (uint32_t i = 0; i < p->max_bounces; i++) {
+        (void)select_strategy(&c->mopt[mat], outgoing, normal, flags, seed);                     /* :118 (its result only feeds dead code) */
+        for (uint32_t j = 0; j < nee; j++) {                                                    /* 3a) :123-195 */
+            lsample_t ls = light_point(c, origin, seed);
+            float cos_x = fabsf(dot3(normal, ls.Ln)); if (cos_x < EPSILON_) cos_x = 0.0f;       /* :579-581 */
+            float cos_y = fabsf(dot3(ls.nl, neg3(ls.Ln))); if (cos_y < EPSILON_) cos_y = 0.0f;
+            v3 em = V3(ls.lt[12], ls.lt[13], ls.lt[14]);
+            v3 f0, f1; float q0, q1, pd, ps;
+            lobes(c, mat, flags, normal, ls.Ln, normalize3(outgoing), normalize3(outgoing), &f0, &f1, &q0, &q1, &pd, &ps);
+            v3 F = add3(safe_mul3(pd, f0), safe_mul3(ps, f1));
+            float pdf_bsdf = safe_mul1(pd, q0) + safe_mul1(ps, q1);
+            float pdf_light = 1.0f;                                                             /* caller's initial value, :125 */
+            if (cos_y > 0.0f) pdf_light = maxf(EPSILON_, ls.pdf_l) * ls.dist2 / cos_y;          /* :629-630 */
+            float a_pdf = acc_pdf * pdf_light;
+            v3 thr = V3(F.x * cos_x * 1.0f, F.y * cos_x * 1.0f, F.z * cos_x * 1.0f);            /* brdf_light * G * V, V = 1 */
+            v3 a_l = mul3(acc_f, thr);
+            v3 contribution = a_pdf > 0.0f ? V3(em.x * a_l.x / a_pdf, em.y * a_l.y / a_pdf, em.z * a_l.z / a_pdf) : V3(0, 0, 0);
+            float mi = pdf_light / ((float)nee * pdf_light + pdf_bsdf);                         /* :164 */
+            v3 E_rec = V3(acc_f_rec.x * mi * em.x * thr.x, acc_f_rec.y * mi * em.y * thr.y, acc_f_rec.z * mi * em.z * thr.z);
+            v3 E_path = scale3(contribution, mi);
+            float wi = length3(E_path);
+            acc_L = add3(acc_L, E_path);
+            if (is_nan(wi) || is_inf(wi)) wi = 0.0f;
+            if (res_update(rs, wi, xn, normalize3(nn), E_rec, seed)) { x1s = add3(origin, scale3(normalize3(normal), S_BIAS)); x2s = ls.sp; }
+        }
+        uint32_t st = select_strategy(&c->mopt[mat], outgoing, normal, flags, seed);            /* :205 */
+        v3 smp = sample_bsdf(c, mat, st, outgoing, normal, seed);                               /* SampleLightBSDF_GI :423-434 */
+        surf_t h;
+        if (!hit_material(c, origin, smp, S_BIAS, &h, cnt, 0)) break;
+        v3 f0, f1; float q0, q1, pd, ps;
+        lobes(c, mat, flags, normal, smp, normalize3(outgoing), outgoing, &f0, &f1, &q0, &q1, &pd, &ps);
+        v3 F = add3(safe_mul3(pd, f0), safe_mul3(ps, f1));
+        float pdf_bsdf = safe_mul1(pd, q0) + safe_mul1(ps, q1);
+        float NdotL = dot3(normal, smp);
+        const matopt_t* mk = &c->mopt[h.mat];
+        v3 thr = V3(F.x * NdotL, F.y * NdotL, F.z * NdotL);
+        acc_pdf *= pdf_bsdf;
+        acc_f = mul3(acc_f, thr);
+        acc_f_rec = mul3(acc_f_rec, thr);                                                       /* :233 */
+        if (mk->Ke_len > 0.0f) {                                                                /* light hit: :457-479 */
+            float dist = length3(sub3(h.pos, origin)), dist2 = dist * dist;
+            float cos_t = dot3(h.normal, neg3(smp));
+            float pdf_light = c->nlights ? (((mk->Ke.x + mk->Ke.y + mk->Ke.z) / 3.0f) / c->total_weight) * dist2 / cos_t : 0.0f;
+            v3 contribution = V3(mk->Ke.x * acc_f.x / acc_pdf, mk->Ke.y * acc_f.y / acc_pdf, mk->Ke.z * acc_f.z / acc_pdf);
+            if (length3(contribution) > 0.0f) {                                                 /* :236-262 */
+                float mi = pdf_bsdf / ((float)nee * pdf_light + pdf_bsdf);
+                v3 E_rec = V3(acc_f_rec.x * mi * mk->Ke.x, acc_f_rec.y * mi * mk->Ke.y, acc_f_rec.z * mi * mk->Ke.z);
+                v3 E_path = scale3(contribution, mi);
+                float wi = length3(E_path);
+                acc_L = add3(acc_L, E_path);
+                if (is_nan(wi) || is_inf(wi)) wi = 0.0f;
+                res_update(rs, wi, xn, normalize3(nn), E_rec, seed);
+                break;
+            }
+        }
+        origin = h.pos; mat = h.mat; outgoing = neg3(smp); normal = h.normal;                   /* :263-269 */
+    }
+    if (nee > 0 && length3(sub3(x2s, x1s)) > EPSILON_) {                                        /* :271-283 */
+        v3 dv = sub3(x2s, x1s);
+        cnt[2]++;
+        if (any_bvh(c, x1s, normalize3(dv), 0.5f * S_BIAS, maxf(S_BIAS, length3(dv) - S_BIAS * 5.0f))) rs->w_sum *= 0.0f;
+        else rs->w_sum *= 1.0f;
+    }
+    return acc_L;
+}
+
+/* MapPixelID: Common_v6.hlsl:173-198 */
+static inline uint32_t map_pixel_id(uint32_t w, uint32_t x, uint32_t y) {
+    const uint32_t ts = 4, tcx = (w + ts - 1) / ts;
+    return ((y / ts) * tcx + (x / ts)) * (ts * ts) + (y % ts) * ts + (x % ts);
+}
+uint32_t orc_map_pixel_id(uint32_t w, uint32_t x, uint32_t y) { return map_pixel_id(w, x, y); }
+size_t orc_pass1_slots(uint32_t w, uint32_t h) { return (size_t)((w + 3) / 4) * ((h + 3) / 4) * 16; }
+
+static void store_res(uint8_t* dst, const res_t* r) {             /* 40 bytes: Reservoir_v6.hlsl:16-29 */
+    float f[8] = {r->x2.x, r->x2.y, r->x2.z, r->w_sum, r->n2.x, r->n2.y, r->n2.z, r->W};
+    uint16_t h[4] = {half_bits(r->L2.x), half_bits(r->L2.y), half_bits(r->L2.z), (uint16_t)r->M};
+    memcpy(dst, f, 32); memcpy(dst + 32, h, 8);
+}
+
+/* one pass-1 sample for every owned pixel; the buffers receive the state of the LAST sample of the call */
+int orc_render_v6_pass1(orc_ctx* c, const orc_params* p, float* accum, void* res_di40, void* res_gi40, void* sample60, uint64_t ray_counts[3]) {
+    uint64_t c0 = 0, c1 = 0, c2 = 0;
+    int nth = c->nthreads;
+#ifdef _OPENMP
+    if (nth <= 0) nth = omp_get_max_threads();
+#else
+    nth = 1;
+#endif
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nth) reduction(+ : c0, c1, c2)
+    for (int64_t y = 0; y < (int64_t)p->height; y++) {
+        uint64_t cnt[3] = {0, 0, 0};
+        for (uint32_t x = 0; x < p->width; x++) {
+            if (!owns_pixel(p, x, (uint32_t)y)) continue;
+            for (uint32_t si = 0; si < p->spp; si++) {
+                uint32_t seed[2]; orc_seed_init(x, (uint32_t)y, p->sample_base + si, p->frame_seed, seed);
+                v3 origin, dir; primary_ray(c, p->width, p->height, x, (uint32_t)y, 0.0f, 0.0f, &origin, &dir);   /* jitter = 0, pass1:80-82 */
+                res_t rdi; memset(&rdi, 0, sizeof(rdi)); res_t rgi; memset(&rgi, 0, sizeof(rgi));
+                v3 x1 = V3(0, 0, 0), n1 = V3(0, 0, 0), ov = V3(0, 0, 0), debug = V3(0, 0, 0), L1 = V3(0, 0, 0);
+                uint32_t mID = 0xFFFFFFFEu, objID = 0;
+                surf_t pay;
+                v3 out = V3(0, 0, 0);
+                if (hit_material(c, origin, dir, 0.0001f, &pay, cnt, 1)) {
+                    mID = pay.mat; objID = pay.inst;
+                    L1 = c->mopt[mID].Ke;
+                    if (!(full_ke_len(c, mID) > 0.0f)) {                                         /* performSampling, pass1:102-106 */
+                        v3 outgoing = neg3(dir);
+                        sample_ris(c, c->nlights ? p->nee_samples : 0, 1, p->flags, outgoing, &rdi, &pay, seed, cnt);   /* nee_samples_DI, bsdf_samples_DI */
+                        x1 = pay.pos; n1 = normalize3(pay.normal); ov = outgoing;
+                        float f_g = length3(reconnect_di(c, mID, p->flags, x1, n1, rdi.x2, rdi.n2, rdi.L2, ov));
+                        v3 dv = sub3(rdi.x2, x1);
+                        float vis = visibility(c, x1, n1, normalize3(dv), length3(dv), cnt);     /* GetP_Hat(..., true), :163-171 */
+                        float p_hat = f_g * vis;
+                        rdi.W = p_hat > EPSILON_ ? rdi.w_sum / p_hat : 0.0f;                     /* GetW :183-188 */
+                        debug = sample_path_simple(c, p, &rgi, pay.pos, pay.normal, outgoing, mID, seed, cnt);
+                        v3 rc = reconnect_di(c, mID, p->flags, x1, n1, rdi.x2, rdi.n2, rdi.L2, ov);
+                        debug = add3(debug, scale3(rc, rdi.W));                                  /* pass1:174 */
+                        {   /* ReconnectGI + GetW_GI: Sampler_v6.hlsl:134-160, 173-181; pass1:176-180 */
+                            v3 dg = sub3(rgi.x2, x1);
+                            float cos1 = fabsf(dot3(n1, normalize3(dg)));
+                            v3 f0, f1; float q0, q1, pd, ps;
+                            lobes(c, mID, p->flags, n1, normalize3(dg), normalize3(ov), normalize3(ov), &f0, &f1, &q0, &q1, &pd, &ps);
+                            v3 Fx = add3(safe_mul3(pd, f0), safe_mul3(ps, f1));
+                            v3 fr = V3(Fx.x * cos1 * rgi.L2.x, Fx.y * cos1 * rgi.L2.y, Fx.z * cos1 * rgi.L2.z);
+                            if (!finite3(fr)) fr = V3(0, 0, 0);
+                            float fc = length3(fr);
+                            rgi.W = fc > EPSILON_ ? rgi.w_sum / fc : 0.0f;
+                            rgi.M = 1;
+                        }
+                        out = debug;
+                    } else out = L1;                                                             /* pass3:457-462 shows L1 */
+                }
+                size_t slot = map_pixel_id(p->width, x, (uint32_t)y);
+                if (res_di40) store_res((uint8_t*)res_di40 + slot * 40, &rdi);
+                if (res_gi40) store_res((uint8_t*)res_gi40 + slot * 40, &rgi);
+                if (sample60) {                                                                  /* SampleData, Reservoir_v6.hlsl:2-11 */
+                    uint8_t* d = (uint8_t*)sample60 + slot * 60;
+                    uint16_t m16 = (uint16_t)mID, h[3] = {half_bits(L1.x), half_bits(L1.y), half_bits(L1.z)};
+                    memcpy(d, &x1, 12); memcpy(d + 12, &m16, 2); memcpy(d + 14, h, 6); memcpy(d + 20, &n1, 12); memcpy(d + 32, &ov, 12);
+                    memcpy(d + 44, &objID, 4); memcpy(d + 48, &debug, 12);
+                }
+                float* a = accum + ((size_t)y * p->width + x) * 4;
+                if (finite3(out)) { a[0] += out.x; a[1] += out.y; a[2] += out.z; a[3] += 1.0f; }
+            }
+        }
+        c0 += cnt[0]; c1 += cnt[1]; c2 += cnt[2];
+    }
+    if (ray_counts) { ray_counts[0] = c0; ray_counts[1] = c1; ray_counts[2] = c2; }
+    return 0;
+}
+
 /* RayGen_v6_pass3.hlsl:405,428-441 + Common_v6.hlsl:353-376; RGBA8 UNORM store */
 void orc_srgb8(const float* accum, uint32_t npix, uint8_t* out) {
     for (uint32_t i = 0; i < npix; i++) {

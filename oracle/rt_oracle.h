@@ -60,6 +60,12 @@ int  orc_set_threads(orc_ctx*, int nthreads);     /* OpenMP threads for orc_rend
 int  orc_render(orc_ctx*, const orc_params*, float* accum_rgba /* W*H*4, added into */,
                 uint64_t ray_counts[3] /* primary, extension, shadow; may be NULL */);
 void orc_srgb8(const float* accum_rgba, uint32_t npix, uint8_t* out_rgba8);
+/* the v6 pass-1 estimator (RayGen_v6_pass1.hlsl:48-190): RIS direct light + SamplePathSimple; nee_samples plays
+   nee_samples_DI and nee_samples, max_bounces plays `bounces` (reference: 4, 4, 3).  Buffers use MapPixelID order and
+   hold orc_pass1_slots(w,h) records of 40 / 40 / 60 bytes (Reservoir_DI, Reservoir_GI, SampleData). */
+int  orc_render_v6_pass1(orc_ctx*, const orc_params*, float* accum_rgba, void* res_di40, void* res_gi40, void* sample60, uint64_t ray_counts[3]);
+uint32_t orc_map_pixel_id(uint32_t width, uint32_t x, uint32_t y);
+size_t orc_pass1_slots(uint32_t width, uint32_t height);
 
 /* unit-level entry points (golden vectors / GPU parity of the individual kernels) */
 void orc_tea(uint32_t seed[2], uint32_t n, float* out);

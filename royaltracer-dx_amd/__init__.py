@@ -98,6 +98,9 @@ _sig("rtx_bind_accum", C.c_int, _vp, _vp, C.c_size_t)
 _sig("rtx_clear_accum", C.c_int, _vp, _u32, _u32)
 _sig("rtx_render", C.c_int, _vp, C.POINTER(Params))
 _sig("rtx_read_accum", C.c_int, _vp, _vp, C.c_size_t)
+_sig("rtx_render_v6_pass1", C.c_int, _vp, C.POINTER(Params))
+_sig("rtx_pass1_slots", C.c_size_t, _u32, _u32)
+_sig("rtx_read_pass1_buffers", C.c_int, _vp, _vp, _vp, _vp, C.c_size_t)
 _sig("rtx_read_srgb8", C.c_int, _vp, _vp, C.c_size_t)
 _sig("rtx_get_stats", C.c_int, _vp, C.POINTER(Stats))
 _sig("rtx_get_lights", C.c_int, _vp, _vp, _u32, _u32p)
@@ -341,6 +344,17 @@ class Context:
         out = np.zeros((self.height, self.width, 4), np.float32)
         self._ck(lib.rtx_read_accum(self._h, _ptr(out), out.nbytes), "rtx_read_accum")
         return out
+
+    def render_v6_pass1(self, params):
+        """the reference's own pass 1 (RIS direct light + SamplePathSimple); see rtx_render_v6_pass1"""
+        self.width, self.height = params.width, params.height
+        self._ck(lib.rtx_render_v6_pass1(self._h, C.byref(params)), "rtx_render_v6_pass1")
+
+    def read_pass1_buffers(self):
+        n = lib.rtx_pass1_slots(self.width, self.height)
+        di, gi, sd = np.zeros((n, 40), np.uint8), np.zeros((n, 40), np.uint8), np.zeros((n, 60), np.uint8)
+        self._ck(lib.rtx_read_pass1_buffers(self._h, _ptr(di), _ptr(gi), _ptr(sd), n), "rtx_read_pass1_buffers")
+        return di, gi, sd
 
     def read_srgb8(self):
         out = np.zeros((self.height, self.width, 4), np.uint8)

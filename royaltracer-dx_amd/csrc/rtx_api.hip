@@ -44,7 +44,7 @@ struct rtx_ctx {
     uint32_t* h_counters = nullptr; size_t h_counters_words = 0;
     // accumulation
     DevBuf d_accum; void* ext_accum = nullptr; size_t ext_accum_bytes = 0; uint32_t acc_w = 0, acc_h = 0;
-    DevBuf d_srgb;
+    DevBuf d_srgb, d_res_di, d_res_gi, d_sdata, d_p1cnt; size_t p1_slots = 0;
     // options
     bool timing = false; uint64_t paths_per_batch = 64u << 20; int sort_mats = 0; int lds_nodes_opt = -1; bool small_scene = true; bool fused = true;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
@@ -100,7 +100,7 @@ void rtx_destroy(rtx_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
                      &c->d_thr, &c->d_rad, &c->d_hit, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
-                     &c->d_accum, &c->d_srgb};
+                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_p1cnt};
     for (DevBuf* b : all) b->release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
@@ -376,6 +376,52 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     c->stats.kernel_items[RTX_K_SHADE] = fused ? 0 : c->stats.rays_primary + c->stats.rays_extension;
     c->stats.kernel_items[RTX_K_SHADOW] = fused ? 0 : c->stats.rays_shadow;
     c->stats.kernel_items[RTX_K_ACCUM] = c->stats.paths;
+    return RTX_OK;
+}
+
+size_t rtx_pass1_slots(uint32_t w, uint32_t h) { return (size_t)((w + 3) / 4) * ((h + 3) / 4) * 16; }
+
+int rtx_render_v6_pass1(rtx_ctx* c, const rtx_params* p) {
+    BIND(c);
+    if (!c->committed) { c->err = "render: scene not committed"; return RTX_ERR_STATE; }
+    if (!c->camera_set) { c->err = "render: camera not set"; return RTX_ERR_STATE; }
+    DevFrame f;
+    int r = make_frame(c, p, f);
+    if (r) return r;
+    if (p->max_bounces > 64 || p->nee_samples > 16) { c->err = "params: max_bounces <= 64, nee_samples <= 16"; return RTX_ERR_INVALID; }
+    if ((r = ensure_accum(c, p->width, p->height, false))) return r;
+    const size_t slots = rtx_pass1_slots(p->width, p->height);
+    HIPCHK(c, c->d_res_di.ensure(slots * 40)); HIPCHK(c, c->d_res_gi.ensure(slots * 40)); HIPCHK(c, c->d_sdata.ensure(slots * 60));
+    HIPCHK(c, c->d_p1cnt.ensure(24));
+    if (c->p1_slots != slots) {
+        HIPCHK(c, hipMemsetAsync(c->d_res_di.p, 0, slots * 40, c->stream)); HIPCHK(c, hipMemsetAsync(c->d_res_gi.p, 0, slots * 40, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_sdata.p, 0, slots * 60, c->stream));
+        c->p1_slots = slots;
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_p1cnt.p, 0, 24, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_begin, c->stream));
+    for (uint32_t s = 0; s < p->spp; s++)
+        launch_v6_pass1(c->stream, (uint32_t)c->num_cus * 8u, c->dsc, f, (const CameraGPU*)c->d_cam.p, p->sample_base + s, c->accum_ptr(),
+                        (uint32_t*)c->d_res_di.p, (uint32_t*)c->d_res_gi.p, (uint32_t*)c->d_sdata.p, (unsigned long long*)c->d_p1cnt.p);
+    HIPCHK(c, hipEventRecord(c->ev_end, c->stream));
+    HIPCHK(c, hipGetLastError());
+    unsigned long long cnt[3] = {0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(cnt, c->d_p1cnt.p, 24, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memset(c->stats.kernel_ms, 0, sizeof(c->stats.kernel_ms)); memset(c->stats.kernel_launches, 0, sizeof(c->stats.kernel_launches)); memset(c->stats.kernel_items, 0, sizeof(c->stats.kernel_items));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) c->stats.render_ms = ms;
+    c->stats.rays_primary = cnt[0]; c->stats.rays_extension = cnt[1]; c->stats.rays_shadow = cnt[2]; c->stats.paths = cnt[0]; c->stats.primary_hits = 0;
+    return RTX_OK;
+}
+
+int rtx_read_pass1_buffers(rtx_ctx* c, void* di, void* gi, void* sd, size_t slots) {
+    BIND(c);
+    if (!c->p1_slots || slots < c->p1_slots) { c->err = "read_pass1_buffers: no pass-1 data or too few slots"; return RTX_ERR_INVALID; }
+    if (di) HIPCHK(c, hipMemcpyAsync(di, c->d_res_di.p, c->p1_slots * 40, hipMemcpyDeviceToHost, c->stream));
+    if (gi) HIPCHK(c, hipMemcpyAsync(gi, c->d_res_gi.p, c->p1_slots * 40, hipMemcpyDeviceToHost, c->stream));
+    if (sd) HIPCHK(c, hipMemcpyAsync(sd, c->d_sdata.p, c->p1_slots * 60, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return RTX_OK;
 }
 

@@ -12,7 +12,7 @@ struct MatGPU {
     float Kd[3]; float Pr;
     float Ks[3]; float Pm;
     float Ke[3]; float Ke_len;      // length(Ke) of the rounded copy
-    float alpha, Ps, Pc, pad;
+    float KeFull[3]; float KeFullLen;   // full-precision Ke and its length: `length(materials[mID].Ke) > 0` tests (pass1:104, Path_Sampler_v6.hlsl:55)
     float LUT[16];
 };
 

@@ -56,6 +56,8 @@ void launch_bounce_small(hipStream_t, const DevScene&, const DevFrame&, const De
 void launch_trace_shadow(hipStream_t, const DevFrame&, const DevScene&, const DevPaths&, uint32_t j, const uint32_t* shcount);
 void launch_shade(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, uint32_t bounce,
                   const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts);
+void launch_v6_pass1(hipStream_t, uint32_t max_blocks, const DevScene&, const DevFrame&, const CameraGPU* cam, uint32_t sample_id,
+                     F4* accum, uint32_t* res_di, uint32_t* res_gi, uint32_t* sdata, unsigned long long* counters);
 void launch_accumulate(hipStream_t, uint32_t max_blocks, const DevFrame&, const DevPaths&, F4* accum);
 void launch_srgb8(hipStream_t, const F4* accum, uint32_t npix, uint32_t* out);
 void launch_pack_tiles(hipStream_t, uint32_t max_blocks, const DevFrame&, const F4* accum, F4* slab);

@@ -108,7 +108,8 @@ bool SceneHost::build(BuiltScene& B) {
         const float* m = &mats128[(size_t)i * 32];   // Kd[4] Ks[3] Ni Ke[3] pad Pr_Pm_Ps_Pc[4] LUT[16]
         MatGPU& g = B.mats[i];
         for (int k = 0; k < 3; k++) { g.Kd[k] = half_round(m[k]); g.Ks[k] = half_round(m[4 + k]); g.Ke[k] = half_round(m[8 + k]); }
-        g.alpha = half_round(m[3]); g.Pr = half_round(m[12]); g.Pm = half_round(m[13]); g.Ps = half_round(m[14]); g.Pc = half_round(m[15]); g.pad = 0.0f;
+        g.Pr = half_round(m[12]); g.Pm = half_round(m[13]);
+        g.KeFull[0] = m[8]; g.KeFull[1] = m[9]; g.KeFull[2] = m[10]; g.KeFullLen = length(mk3(m[8], m[9], m[10]));
         g.Ke_len = length(mk3(g.Ke[0], g.Ke[1], g.Ke[2]));
         memcpy(g.LUT, m + 16, 64);
     }

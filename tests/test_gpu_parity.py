@@ -325,3 +325,39 @@ def test_large_scene_parity(rt, orc, kind, tris, cfg):
     print("rel_l2", r, "pixels not bit exact:", int((bits(ga) != bits(ca)).any(-1).sum()))
     assert r <= REL_L2_TOL
     c.close()
+
+
+@pytest.mark.parametrize("flags,nee,bounces", [(1, 4, 3), (0, 4, 3), (0, 1, 2), (1, 0, 3)])
+def test_v6_pass1_estimator_parity(rt, cornell_pair, flags, nee, bounces):
+    """the reference's own pass 1 (SampleRIS + SamplePathSimple, RayGen_v6_pass1.hlsl:48-190): reservoirs,
+    sample data (reference byte layouts, MapPixelID order) and radiance, bit for bit against the oracle"""
+    ctx, o = cornell_pair
+    W, H = 100, 58                                        # not a multiple of the 4x4 MapPixelID tile
+    p = rt.Params(width=W, height=H, spp=2, max_bounces=bounces, nee_samples=nee, flags=flags, frame_seed=5)
+    ctx.set_camera(*rt.Scene.cornell().view_proj(W / H)); o.set_camera(*rt.Scene.cornell().view_proj(W / H))
+    ctx.clear(W, H); ctx.render_v6_pass1(p)
+    g = ctx.read_accum(); gd, gg, gs = ctx.read_pass1_buffers()
+    c, (cd, cg, cs), cnt = o.render_v6_pass1(p)
+    st = ctx.stats()
+    assert (st.rays_primary, st.rays_extension, st.rays_shadow) == cnt
+    assert np.array_equal(gs, cs), f"SampleData differs in {int((gs != cs).any(1).sum())} records"
+    assert np.array_equal(gd, cd), f"Reservoir_DI differs in {int((gd != cd).any(1).sum())} records"
+    assert np.array_equal(gg, cg), f"Reservoir_GI differs in {int((gg != cg).any(1).sum())} records"
+    assert np.array_equal(bits(g), bits(c))
+    assert g[..., :3].sum() > 0 and (g[..., 3] == 2).all()
+
+
+def test_v6_pass1_garage(rt, orc, golden_dir):
+    import os
+    sc = rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")
+    c = rt.Context(0); c.upload(sc, 96 / 54)
+    o = orc.Oracle().load(sc, 96 / 54)
+    p = rt.Params(width=96, height=54, spp=1, max_bounces=3, nee_samples=4, flags=0)     # the reference's defines (Common_v6.hlsl:8-12)
+    c.clear(96, 54); c.render_v6_pass1(p)
+    g = c.read_accum(); gd, gg, gs = c.read_pass1_buffers()
+    ca, (cd, cg, cs), cnt = o.render_v6_pass1(p)
+    st = c.stats()
+    assert (st.rays_primary, st.rays_extension, st.rays_shadow) == cnt
+    assert np.array_equal(gs, cs) and np.array_equal(gd, cd) and np.array_equal(gg, cg)
+    assert rel_l2(g[..., :3], ca[..., :3]) <= REL_L2_TOL
+    c.close()

@@ -255,3 +255,26 @@ def test_shards_partition_the_image(rt, orc, cornell):
         assert not (parts[..., 3] * a[..., 3]).any()                                 # disjoint ownership
         parts += a; tot += np.array(c, np.uint64)
     assert np.array_equal(bits(parts), bits(whole)) and tuple(int(v) for v in tot) == cw
+
+
+def test_v6_pass1_oracle_properties(rt, orc, cornell):
+    """the literal pass-1 estimator: MapPixelID layout, reservoir invariants, and agreement in the mean with the
+    unbiased bounce-loop estimator (pass 1 adds unshadowed NEE inside SamplePathSimple, so it is brighter)"""
+    W, H = 64, 36
+    o = orc.Oracle().load(cornell, W / H)
+    p = rt.Params(width=W, height=H, spp=8, max_bounces=3, nee_samples=4, flags=1)
+    acc, (di, gi, sd), cnt = o.render_v6_pass1(p)
+    assert np.isfinite(acc).all() and (acc[..., 3] == 8).all()
+    slots = ((W + 3) // 4) * ((H + 3) // 4) * 16
+    assert len(di) == len(gi) == len(sd) == slots
+    assert orc.lib.orc_map_pixel_id(W, 5, 6) == ((6 // 4) * 16 + 5 // 4) * 16 + (6 % 4) * 4 + 5 % 4      # Common_v6.hlsl:173-198
+    M = di.view(np.uint16).reshape(slots, 20)[:, 19]
+    sdf = sd.copy().view(np.uint8)
+    mid = sd[:, 12:14].copy().view(np.uint16)[:, 0]
+    hit_nonemissive = (mid != 0xFFFE) & (mid != 4)
+    assert set(np.unique(M[hit_nonemissive])) <= {1} and (M[mid == 0xFFFE] == 0).all()             # reservoir.M = 1 after SampleRIS
+    wsum = di[:, 12:16].copy().view(np.float32)[:, 0]
+    assert (wsum[hit_nonemissive] >= 0).all() and wsum[hit_nonemissive].mean() > 0
+    pt, _ = o.render(rt.Params(width=W, height=H, spp=8, max_bounces=5, nee_samples=1, flags=1))
+    m1, m2 = acc[..., :3].mean() , pt[..., :3].mean()
+    assert 0.9 < m1 / m2 < 1.5
