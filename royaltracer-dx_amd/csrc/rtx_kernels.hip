@@ -322,20 +322,124 @@ __global__ __launch_bounds__(kBlock) void k_raygen_trace_small(DevScene sc, cons
     if (threadIdx.x == 0) { qcount[blockIdx.x] = s_n[0]; gencount[blockIdx.x] = s_n[1]; }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Persistent-wave BVH traversal with dynamic ray fetch (general scenes).  Lane utilisation of the plain
+// one-ray-per-lane loop on a 262 k-triangle scene was 8/64 (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU,
+// profiles/r01_pmc_sponza.md): traversal lengths have a heavy tail and internal / leaf phases diverge.  Here a
+// wave keeps its lanes busy: finished lanes are re-filled from the workgroup's sub-queue with a wave ballot +
+// mbcnt prefix sum and ONE LDS atomic per refill, and every outer iteration runs "all lanes walk internal nodes
+// until each holds a leaf (or is done)" followed by "all lanes with a leaf test its triangles" (while-while).
+// Exit: a wave leaves when the sub-queue is exhausted and no lane holds a ray — every wave reaches that.
+// ---------------------------------------------------------------------------------------------
+constexpr int32_t kDone = (int32_t)0x80000000;       // traversal finished (distinct from every leaf code)
+constexpr uint32_t kRefillMin = 20;                   // refill when at least this many lanes are idle
+
+struct RayLane {                                       // per-lane traversal state
+    f3 o, d, idir; float tmin, tmax, bt, bu, bv; uint32_t bprim; int32_t cur; int sp; uint32_t item; bool has;
+};
+__device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, float tmax, uint32_t item) {
+    R.o = o; R.d = d; R.tmin = tmin; R.tmax = tmax; R.item = item;
+    const float dxs = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
+    const float dys = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
+    const float dzs = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
+    R.idir = mk3(__builtin_amdgcn_rcpf(dxs), __builtin_amdgcn_rcpf(dys), __builtin_amdgcn_rcpf(dzs));
+    R.bt = tmax; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.cur = 0; R.sp = 0; R.has = true;
+}
+// all lanes holding an internal node walk down until they hold a leaf or are done
+template <bool ANY>
+__device__ __forceinline__ void walk_internal(const DevScene& sc, const TraceLds& L, RayLane& R, lds_u32* stk) {
+    while (R.has && R.cur >= 0) {
+        v4f a, b, c, dd;
+        if ((uint32_t)R.cur < sc.lds_nodes) { const lds_v4f* n = L.nodes + (uint32_t)R.cur * 4u; a = n[0]; b = n[1]; c = n[2]; dd = n[3]; }
+        else { const v4f* n = (const v4f*)(sc.nodes + R.cur); a = n[0]; b = n[1]; c = n[2]; dd = n[3]; }
+        float t0, t1;
+        const bool h0 = box_test(a.x, a.y, a.z, a.w, b.x, b.y, R.o, R.idir, R.tmin, R.bt, t0);
+        const bool h1 = box_test(b.z, b.w, c.x, c.y, c.z, c.w, R.o, R.idir, R.tmin, R.bt, t1);
+        int32_t c0 = (int32_t)f2u(dd.x), c1 = (int32_t)f2u(dd.y);
+        if (h0 && h1) {
+            if (t1 < t0) { const int32_t tmp = c0; c0 = c1; c1 = tmp; }
+            stk[R.sp * kBlock] = (uint32_t)c1; R.sp++;
+            R.cur = c0;
+        } else if (h0) R.cur = c0;
+        else if (h1) R.cur = c1;
+        else if (R.sp == 0) R.cur = kDone;
+        else { R.sp--; R.cur = (int32_t)stk[R.sp * kBlock]; }
+    }
+}
+template <bool ANY>
+__device__ __forceinline__ void process_leaf(const DevScene& sc, const TraceLds& L, RayLane& R, lds_u32* stk) {
+    if (R.has && R.cur < 0 && R.cur != kDone) {
+        const uint32_t v = ~(uint32_t)R.cur;
+        const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
+        bool occluded = false;
+        for (uint32_t k = 0; k < cnt; k++) {
+            const uint32_t slot = first + k;
+            v4f v0, e1, e2;
+            if (slot < sc.lds_tris) { const lds_v4f* t = L.tris + slot * 3u; v0 = t[0]; e1 = t[1]; e2 = t[2]; }
+            else { const v4f* t = (const v4f*)(sc.tris + slot); v0 = t[0]; e1 = t[1]; e2 = t[2]; }
+            float t, u, w;
+            if (tri_test(R.o, R.d, v0, e1, e2, R.tmin, R.tmax, t, u, w)) {
+                if (ANY) { occluded = true; break; }
+                const uint32_t gid = f2u(v0.w);
+                if (t < R.bt || (t == R.bt && gid < R.bprim)) { R.bt = t; R.bu = u; R.bv = w; R.bprim = gid; }
+            }
+        }
+        if (ANY && occluded) { R.bprim = 0u; R.cur = kDone; }
+        else if (R.sp == 0) R.cur = kDone;
+        else { R.sp--; R.cur = (int32_t)stk[R.sp * kBlock]; }
+    }
+}
+// wave-level refill: returns false when the wave may exit (queue exhausted and nothing in flight)
+template <class Fetch>
+__device__ __forceinline__ bool refill(RayLane& R, uint32_t* s_head, uint32_t n, bool& drained, Fetch fetch) {
+    const unsigned long long idle = __ballot(!R.has);
+    const uint32_t nidle = (uint32_t)__popcll(idle);
+    if (!drained && (nidle >= kRefillMin || nidle == 64u)) {            // wave-uniform
+        uint32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(s_head, nidle);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= n) drained = true;
+        else {
+            const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            if (!R.has && idx < n) fetch(idx);
+            if (base + nidle >= n) drained = true;
+        }
+    }
+    return __ballot(R.has) != 0ull;
+}
+
 // closest hit for every path in this workgroup's sub-queue: reads ray_o/ray_d, writes hit
 __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const SmallPair* __restrict__ small, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin) {
     extern __shared__ F4 lds[];
+    __shared__ uint32_t s_head;
     const uint32_t n = qcount[blockIdx.x];
     if (n == 0) return;
+    if (threadIdx.x == 0) s_head = 0;
     const TraceLds L = stage_lds(sc, lds);
     __syncthreads();
     const uint32_t* myq = queue + (size_t)blockIdx.x * qcap;
-    for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
-        const uint32_t pid = myq[i];
-        const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
-        float t, u, v; uint32_t prim;
-        trace_ray<false>(sc, small, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, t, u, v, prim);
-        p.hit[pid] = {t, u, v, u2f(prim)};
+    if (sc.nsmall) {                                       // tiny scene, un-fused kernels (test path)
+        for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+            const uint32_t pid = myq[i];
+            const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
+            float t, u, v; uint32_t prim;
+            traverse_small<false>(sc, small, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, t, u, v, prim);
+            p.hit[pid] = {t, u, v, u2f(prim)};
+        }
+        return;
+    }
+    lds_u32* stk = L.stack + threadIdx.x;
+    RayLane R; R.has = false; R.cur = kDone; R.sp = 0; R.item = 0; R.o = mk3(0, 0, 0); R.d = mk3(0, 0, 1); R.idir = mk3(0, 0, 1);
+    R.tmin = 0.0f; R.tmax = 0.0f; R.bt = 0.0f; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim;
+    bool drained = false;
+    while (refill(R, &s_head, n, drained, [&](uint32_t idx) {
+               const uint32_t pid = myq[idx];
+               const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
+               ray_begin(R, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, pid);
+           })) {
+        walk_internal<false>(sc, L, R, stk);
+        process_leaf<false>(sc, L, R, stk);
+        if (R.has && R.cur == kDone) { p.hit[R.item] = {R.bt, R.bu, R.bv, u2f(R.bprim)}; R.has = false; }
     }
 }
 
@@ -344,22 +448,42 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
 __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const SmallPair* __restrict__ small, DevPaths p, const F4* __restrict__ sh_o, const F4* __restrict__ sh_d,
                                                          const F4* __restrict__ sh_c, const uint32_t* __restrict__ shcount, uint32_t qcap) {
     extern __shared__ F4 lds[];
+    __shared__ uint32_t s_head;
     const uint32_t n = shcount[blockIdx.x];
     if (n == 0) return;
+    if (threadIdx.x == 0) s_head = 0;
     const TraceLds L = stage_lds(sc, lds);
     __syncthreads();
     const size_t qb = (size_t)blockIdx.x * qcap;
-    for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
-        const F4 so = sh_o[qb + i], sd = sh_d[qb + i];
-        float t, u, v; uint32_t prim;
-        trace_ray<true>(sc, small, L, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, t, u, v, prim);
-        if (prim == kMissPrim) {
+    auto finish = [&](uint32_t i, bool occluded) {
+        if (!occluded) {
             const F4 c = sh_c[qb + i];
             const uint32_t pid = f2u(c.w);
             F4 r = p.rad[pid];
             r.x = r.x + c.x; r.y = r.y + c.y; r.z = r.z + c.z;
             p.rad[pid] = r;
         }
+    };
+    if (sc.nsmall) {
+        for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+            const F4 so = sh_o[qb + i], sd = sh_d[qb + i];
+            float t, u, v; uint32_t prim;
+            traverse_small<true>(sc, small, L, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, t, u, v, prim);
+            finish(i, prim != kMissPrim);
+        }
+        return;
+    }
+    lds_u32* stk = L.stack + threadIdx.x;
+    RayLane R; R.has = false; R.cur = kDone; R.sp = 0; R.item = 0; R.o = mk3(0, 0, 0); R.d = mk3(0, 0, 1); R.idir = mk3(0, 0, 1);
+    R.tmin = 0.0f; R.tmax = 0.0f; R.bt = 0.0f; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim;
+    bool drained = false;
+    while (refill(R, &s_head, n, drained, [&](uint32_t idx) {
+               const F4 so = sh_o[qb + idx], sd = sh_d[qb + idx];
+               ray_begin(R, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, idx);
+           })) {
+        walk_internal<true>(sc, L, R, stk);
+        process_leaf<true>(sc, L, R, stk);
+        if (R.has && R.cur == kDone) { finish(R.item, R.bprim != kMissPrim); R.has = false; }
     }
 }
 
