@@ -81,12 +81,12 @@ def main():
     kind, W, H, spp, bounces, nee, flags = WORKLOADS[args.workload]
     scene = make_scene(rt, kind)
     ctx = rt.Context(dev_index)
+    for kv in args.opt:                      # tuning knobs must be set before the scene is committed
+        k, v = kv.split("=")
+        ctx.set_option(int(k), int(v))
     ctx.upload(scene, W / H)
     if args.paths_per_batch:
         ctx.set_option(rt.OPT_PATHS_PER_BATCH, args.paths_per_batch)
-    for kv in args.opt:
-        k, v = kv.split("=")
-        ctx.set_option(int(k), int(v))
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)

@@ -46,7 +46,7 @@ struct rtx_ctx {
     DevBuf d_accum; void* ext_accum = nullptr; size_t ext_accum_bytes = 0; uint32_t acc_w = 0, acc_h = 0;
     DevBuf d_srgb, d_res_di, d_res_gi, d_sdata, d_p1cnt; size_t p1_slots = 0;
     // options
-    bool timing = false; uint64_t paths_per_batch = 64u << 20; int sort_mats = 0; int lds_nodes_opt = -1; bool small_scene = true; bool fused = true;
+    bool timing = false; uint64_t paths_per_batch = 64u << 20; int sort_mats = 0; int lds_nodes_opt = -1; bool small_scene = true; bool fused = true; int stack_private = -1;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     std::vector<TimedLaunch> timed;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -122,6 +122,8 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_SMALL_SCENE: c->small_scene = value != 0; c->committed = false; return RTX_OK;
     case RTX_OPT_FUSED_BOUNCE: c->fused = value != 0; return RTX_OK;
     case RTX_OPT_BOUNCE_VARIANT: g_bounce_variant = (int)value; return RTX_OK;
+    case RTX_OPT_STACK_PRIVATE: c->stack_private = (int)value; c->committed = false; return RTX_OK;
+    case RTX_OPT_REFILL_MIN: if (value < 1 || value > 64) { c->err = "refill_min must be in [1, 64]"; return RTX_ERR_INVALID; } g_refill_min = (int)value; return RTX_OK;
     default: c->err = "unknown option"; return RTX_ERR_INVALID;
     }
 }
@@ -182,10 +184,18 @@ int rtx_commit_scene(rtx_ctx* c) {
     s.total_weight = B.total_weight;
     // LDS budget per workgroup: stack + top of tree + first triangles, kept <= 64 KiB
     s.stack_depth = B.max_depth + 2;
+    s.stack_private = c->stack_private > 0 ? 1u : 0u;   // measured slower than the LDS column stack (Sponza-class: 95 vs 72 ms); kept as a knob
+    if (s.stack_depth > 64) { c->err = "commit: BVH deeper than 62 levels"; return RTX_ERR_INVALID; }
+    // LDS per workgroup = traversal stack + top of the tree (+ all triangles of a tiny scene).  Occupancy matters more
+    // than cached nodes: on the 262 k-triangle atrium 64 staged nodes (31 KB total, 5 workgroups/CU) beat 256 (88 -> 72 ms)
+    // and 0 (79 ms), so the default keeps the total near 32 KB; never above 64 KB.
     const size_t stack_bytes = (size_t)s.stack_depth * 256 * 4;
-    size_t budget = 64 * 1024 > stack_bytes ? 64 * 1024 - stack_bytes : 0;
-    uint32_t want_nodes = c->lds_nodes_opt >= 0 ? (uint32_t)c->lds_nodes_opt : 256u;
-    if (s.nnodes <= 512 && c->lds_nodes_opt < 0) want_nodes = s.nnodes;    // small scene: whole tree
+    const size_t soft = 32 * 1024, hard = 64 * 1024;
+    size_t budget = hard > stack_bytes ? hard - stack_bytes : 0;
+    uint32_t want_nodes;
+    if (c->lds_nodes_opt >= 0) want_nodes = (uint32_t)c->lds_nodes_opt;
+    else if (s.nnodes <= 64) want_nodes = s.nnodes;
+    else want_nodes = (uint32_t)std::max<size_t>(32, std::min<size_t>(256, (soft > stack_bytes ? soft - stack_bytes : 0) / 64));
     s.lds_nodes = std::min<uint32_t>(std::min<uint32_t>(want_nodes, s.nnodes), (uint32_t)(budget / 64));
     budget -= (size_t)s.lds_nodes * 64;
     uint32_t want_tris = s.ntris <= 256 ? s.ntris : 0u;                    // triangles only when ALL of them fit

@@ -11,6 +11,7 @@
 // tests are NOT parity-critical (closest hit is defined as the minimum over all triangles with a
 // lowest-id tie break, any-hit as existence), they only have to be conservative.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "rtx_kernels.hpp"
 
 namespace rtx {
@@ -332,7 +333,13 @@ __global__ __launch_bounds__(kBlock) void k_raygen_trace_small(DevScene sc, cons
 // Exit: a wave leaves when the sub-queue is exhausted and no lane holds a ray — every wave reaches that.
 // ---------------------------------------------------------------------------------------------
 constexpr int32_t kDone = (int32_t)0x80000000;       // traversal finished (distinct from every leaf code)
-constexpr uint32_t kRefillMin = 20;                   // refill when at least this many lanes are idle
+int g_refill_min = 20;                                // refill when at least this many lanes are idle (tuning knob)
+
+// traversal stack: per-lane column in LDS (conflict-free, but its footprint limits occupancy on deep trees), or a
+// private array that hipcc places in scratch (lane-interleaved, so a wave-level push is one contiguous 256-B store)
+struct StackLds { lds_u32* col; __device__ __forceinline__ void put(int i, uint32_t v) { col[i * kBlock] = v; } __device__ __forceinline__ uint32_t get(int i) const { return col[i * kBlock]; } };
+constexpr int kPrivStack = 64;
+struct StackPriv { uint32_t a[kPrivStack]; __device__ __forceinline__ void put(int i, uint32_t v) { a[i] = v; } __device__ __forceinline__ uint32_t get(int i) const { return a[i]; } };
 
 struct RayLane {                                       // per-lane traversal state
     f3 o, d, idir; float tmin, tmax, bt, bu, bv; uint32_t bprim; int32_t cur; int sp; uint32_t item; bool has;
@@ -346,8 +353,8 @@ __device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, fl
     R.bt = tmax; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.cur = 0; R.sp = 0; R.has = true;
 }
 // all lanes holding an internal node walk down until they hold a leaf or are done
-template <bool ANY>
-__device__ __forceinline__ void walk_internal(const DevScene& sc, const TraceLds& L, RayLane& R, lds_u32* stk) {
+template <bool ANY, class STK>
+__device__ __forceinline__ void walk_internal(const DevScene& sc, const TraceLds& L, RayLane& R, STK& stk) {
     while (R.has && R.cur >= 0) {
         v4f a, b, c, dd;
         if ((uint32_t)R.cur < sc.lds_nodes) { const lds_v4f* n = L.nodes + (uint32_t)R.cur * 4u; a = n[0]; b = n[1]; c = n[2]; dd = n[3]; }
@@ -358,16 +365,16 @@ __device__ __forceinline__ void walk_internal(const DevScene& sc, const TraceLds
         int32_t c0 = (int32_t)f2u(dd.x), c1 = (int32_t)f2u(dd.y);
         if (h0 && h1) {
             if (t1 < t0) { const int32_t tmp = c0; c0 = c1; c1 = tmp; }
-            stk[R.sp * kBlock] = (uint32_t)c1; R.sp++;
+            stk.put(R.sp, (uint32_t)c1); R.sp++;
             R.cur = c0;
         } else if (h0) R.cur = c0;
         else if (h1) R.cur = c1;
         else if (R.sp == 0) R.cur = kDone;
-        else { R.sp--; R.cur = (int32_t)stk[R.sp * kBlock]; }
+        else { R.sp--; R.cur = (int32_t)stk.get(R.sp); }
     }
 }
-template <bool ANY>
-__device__ __forceinline__ void process_leaf(const DevScene& sc, const TraceLds& L, RayLane& R, lds_u32* stk) {
+template <bool ANY, class STK>
+__device__ __forceinline__ void process_leaf(const DevScene& sc, const TraceLds& L, RayLane& R, STK& stk) {
     if (R.has && R.cur < 0 && R.cur != kDone) {
         const uint32_t v = ~(uint32_t)R.cur;
         const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
@@ -386,15 +393,15 @@ __device__ __forceinline__ void process_leaf(const DevScene& sc, const TraceLds&
         }
         if (ANY && occluded) { R.bprim = 0u; R.cur = kDone; }
         else if (R.sp == 0) R.cur = kDone;
-        else { R.sp--; R.cur = (int32_t)stk[R.sp * kBlock]; }
+        else { R.sp--; R.cur = (int32_t)stk.get(R.sp); }
     }
 }
 // wave-level refill: returns false when the wave may exit (queue exhausted and nothing in flight)
 template <class Fetch>
-__device__ __forceinline__ bool refill(RayLane& R, uint32_t* s_head, uint32_t n, bool& drained, Fetch fetch) {
+__device__ __forceinline__ bool refill(RayLane& R, uint32_t* s_head, uint32_t n, bool& drained, uint32_t refill_min, Fetch fetch) {
     const unsigned long long idle = __ballot(!R.has);
     const uint32_t nidle = (uint32_t)__popcll(idle);
-    if (!drained && (nidle >= kRefillMin || nidle == 64u)) {            // wave-uniform
+    if (!drained && (nidle >= refill_min || nidle == 64u)) {            // wave-uniform
         uint32_t base = 0;
         if (lane_id() == 0) base = atomicAdd(s_head, nidle);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -409,7 +416,8 @@ __device__ __forceinline__ bool refill(RayLane& R, uint32_t* s_head, uint32_t n,
 }
 
 // closest hit for every path in this workgroup's sub-queue: reads ray_o/ray_d, writes hit
-__global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const SmallPair* __restrict__ small, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin) {
+template <bool PRIV>
+__global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const SmallPair* __restrict__ small, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin, uint32_t refill_min) {
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_head;
     const uint32_t n = qcount[blockIdx.x];
@@ -428,11 +436,12 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
         }
         return;
     }
-    lds_u32* stk = L.stack + threadIdx.x;
+    typename std::conditional<PRIV, StackPriv, StackLds>::type stk;
+    if constexpr (!PRIV) stk.col = L.stack + threadIdx.x;
     RayLane R; R.has = false; R.cur = kDone; R.sp = 0; R.item = 0; R.o = mk3(0, 0, 0); R.d = mk3(0, 0, 1); R.idir = mk3(0, 0, 1);
     R.tmin = 0.0f; R.tmax = 0.0f; R.bt = 0.0f; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim;
     bool drained = false;
-    while (refill(R, &s_head, n, drained, [&](uint32_t idx) {
+    while (refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) {
                const uint32_t pid = myq[idx];
                const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
                ray_begin(R, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, pid);
@@ -445,8 +454,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
 
 // any-hit for NEE slot j: visible contributions are added to the path's radiance (a path appears at most once
 // per slot, so the read-modify-write needs no atomic and the order of additions per path is fixed)
+template <bool PRIV>
 __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const SmallPair* __restrict__ small, DevPaths p, const F4* __restrict__ sh_o, const F4* __restrict__ sh_d,
-                                                         const F4* __restrict__ sh_c, const uint32_t* __restrict__ shcount, uint32_t qcap) {
+                                                         const F4* __restrict__ sh_c, const uint32_t* __restrict__ shcount, uint32_t qcap, uint32_t refill_min) {
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_head;
     const uint32_t n = shcount[blockIdx.x];
@@ -473,11 +483,12 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const Smal
         }
         return;
     }
-    lds_u32* stk = L.stack + threadIdx.x;
+    typename std::conditional<PRIV, StackPriv, StackLds>::type stk;
+    if constexpr (!PRIV) stk.col = L.stack + threadIdx.x;
     RayLane R; R.has = false; R.cur = kDone; R.sp = 0; R.item = 0; R.o = mk3(0, 0, 0); R.d = mk3(0, 0, 1); R.idir = mk3(0, 0, 1);
     R.tmin = 0.0f; R.tmax = 0.0f; R.bt = 0.0f; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim;
     bool drained = false;
-    while (refill(R, &s_head, n, drained, [&](uint32_t idx) {
+    while (refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) {
                const F4 so = sh_o[qb + idx], sd = sh_d[qb + idx];
                ray_begin(R, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, idx);
            })) {
@@ -1178,8 +1189,11 @@ static inline uint32_t grid_for(uint32_t items, uint32_t max_blocks) {
     if (b < 1) b = 1;
     return b < max_blocks ? b : max_blocks;
 }
-size_t trace_lds_bytes(const DevScene& sc) {
+size_t trace_lds_bytes(const DevScene& sc) {      // the LDS column stack is always reserved: debug / pass-1 kernels use it
     return (size_t)sc.lds_nodes * 64 + (size_t)sc.lds_tris * 48 + (size_t)sc.stack_depth * kBlock * 4;
+}
+size_t trace_lds_bytes_queue(const DevScene& sc) {   // queue kernels with a private stack need no LDS stack
+    return (size_t)sc.lds_nodes * 64 + (size_t)sc.lds_tris * 48 + (sc.stack_private ? 0 : (size_t)sc.stack_depth * kBlock * 4);
 }
 
 void launch_raygen(hipStream_t st, const DevFrame& f, const DevPaths& p, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount) {
@@ -1189,7 +1203,9 @@ void launch_raygen_trace_small(hipStream_t st, const DevScene& sc, const DevFram
     hipLaunchKernelGGL(k_raygen_trace_small, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, cam, queue, qcount, gencount);
 }
 void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t bounce, const uint32_t* queue, const uint32_t* qcount) {
-    hipLaunchKernelGGL(k_trace_closest, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, queue, qcount, f.qcap, bounce == 0 ? kTMinCam : kSBias);
+    const float tmin = bounce == 0 ? kTMinCam : kSBias;
+    if (sc.stack_private) hipLaunchKernelGGL(k_trace_closest<true>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, (uint32_t)g_refill_min);
+    else hipLaunchKernelGGL(k_trace_closest<false>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, (uint32_t)g_refill_min);
 }
 void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce, bool have_hit,
                          const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts) {
@@ -1199,7 +1215,8 @@ void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, 
 }
 void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t j, const uint32_t* shcount) {
     const size_t seg = (size_t)j * f.qcap * f.nblocks;
-    hipLaunchKernelGGL(k_trace_shadow, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap);
+    if (sc.stack_private) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, (uint32_t)g_refill_min);
+    else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, (uint32_t)g_refill_min);
 }
 void launch_shade(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce,
                   const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts) {

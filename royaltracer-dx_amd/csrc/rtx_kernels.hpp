@@ -18,6 +18,7 @@ struct DevScene {
     float total_weight;
     uint32_t lds_nodes, lds_tris;   // how many nodes / triangles each workgroup stages in LDS
     uint32_t stack_depth;           // per-lane traversal stack entries (LDS)
+    uint32_t stack_private;         // queue kernels keep the stack in a private (scratch) array instead: higher occupancy on deep trees
 };
 
 // one sample batch of one frame
@@ -46,6 +47,7 @@ struct DevPaths {
     F4* sh_c;    // contribution.xyz, pid bits
 };
 
+extern int g_refill_min;       // tuning knob: idle lanes that trigger a refill in the persistent traversal
 extern int g_bounce_variant;   // tuning knob: waves/SIMD the fused kernel is compiled for (4, 5 or 6)
 size_t trace_lds_bytes(const DevScene& sc);
 void launch_raygen(hipStream_t, const DevFrame&, const DevPaths&, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount);
