@@ -48,6 +48,10 @@ float rtxh_half_round(float x);
    contains its subtree; fills nodes / depth / max leaf size */
 int  rtxh_bvh_check(const float* world_tris9, uint32_t ntris, uint32_t* nodes_out, uint32_t* depth_out, uint32_t* max_leaf_out);
 
+/* the tiny-scene pre-test records rtx_commit_scene would build for this scene: per record 20 floats (plane xyz d,
+   4 edge planes xyz c) and the global ids of its 1-2 triangles (-1 = none); for host-side conservativeness tests */
+int  rtxh_scene_small_records(const rtxh_scene*, float* recs20, int32_t* tri_ids2, uint32_t max_recs, uint32_t* nrec_out, float* delta_out, float* cm_out);
+
 /* the headless Renderer facade (Renderer.h:46-51) for FFI callers */
 typedef struct rtxh_renderer rtxh_renderer;
 rtxh_renderer* rtxh_renderer_create(uint32_t width, uint32_t height, const char* name, int device);

@@ -137,6 +137,7 @@ _sig("rtxh_generate_ess_lut", None, C.c_float, _fp)
 _sig("rtxh_mat4_inverse", None, _fp, _fp)
 _sig("rtxh_half_round", C.c_float, C.c_float)
 _sig("rtxh_bvh_check", C.c_int, _vp, _u32, _u32p, _u32p, _u32p)
+_sig("rtxh_scene_small_records", C.c_int, _vp, _vp, _vp, _u32, _u32p, _fp, _fp)
 _sig("rtxh_renderer_create", _vp, _u32, _u32, C.c_char_p, C.c_int)
 _sig("rtxh_renderer_set_scene", C.c_int, _vp, _vp)
 _sig("rtxh_renderer_params", C.POINTER(Params), _vp)
@@ -216,6 +217,14 @@ class Scene:
     def from_obj(cls, files, mtl_dir):
         arr = (C.c_char_p * len(files))(*[f.encode() for f in files])
         return cls(lib.rtxh_scene_from_obj(arr, len(files), mtl_dir.encode()))
+
+    def small_records(self):
+        """-> (records (n,20) f32, triangle ids (n,2) i32, delta, cm) of the tiny-scene pre-test, or None"""
+        recs, ids = np.zeros((64, 20), np.float32), np.zeros((64, 2), np.int32)
+        n, d, cm = _u32(), C.c_float(), C.c_float()
+        if lib.rtxh_scene_small_records(self._h, _ptr(recs), _ptr(ids), 64, C.byref(n), C.byref(d), C.byref(cm)) != RTX_OK or n.value == 0:
+            return None
+        return recs[:n.value], ids[:n.value], d.value, cm.value
 
     def view_proj(self, aspect):
         v, p = np.zeros(16, np.float32), np.zeros(16, np.float32)

@@ -35,7 +35,7 @@ struct rtx_ctx {
     int num_cus = 256;
     SceneHost host; BuiltScene built;
     bool committed = false, camera_set = false;
-    DevBuf d_nodes, d_tris, d_small, d_shade, d_mats, d_insts, d_lights, d_cam;
+    DevBuf d_nodes, d_tris, d_small, d_small_tris, d_shade, d_mats, d_insts, d_lights, d_cam;
     DevScene dsc{};
     float view[16], proj[16];
     // path state
@@ -98,7 +98,7 @@ void rtx_destroy(rtx_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
+    DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
                      &c->d_thr, &c->d_rad, &c->d_hit, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
                      &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_p1cnt};
     for (DevBuf* b : all) b->release();
@@ -168,7 +168,8 @@ int rtx_commit_scene(rtx_ctx* c) {
     if ((r = upload(c, c->d_nodes, B.nodes))) return r;
     if ((r = upload(c, c->d_tris, B.tris))) return r;
     if ((r = upload(c, c->d_shade, B.shade))) return r;
-    if ((r = upload(c, c->d_small, B.small_pairs))) return r;
+    if ((r = upload(c, c->d_small, B.small_recs))) return r;
+    if ((r = upload(c, c->d_small_tris, B.small_tris))) return r;
     if ((r = upload(c, c->d_mats, B.mats))) return r;
     if ((r = upload(c, c->d_insts, B.insts))) return r;
     if ((r = upload(c, c->d_lights, B.lights))) return r;
@@ -177,7 +178,7 @@ int rtx_commit_scene(rtx_ctx* c) {
     s.nodes = (const NodeGPU*)c->d_nodes.p; s.nnodes = (uint32_t)B.nodes.size();
     s.tris = (const TriGPU*)c->d_tris.p; s.ntris = (uint32_t)B.tris.size();
     s.shade = (const TriShade*)c->d_shade.p;
-    s.small = (const SmallPair*)c->d_small.p; s.small_cm = B.small_cm;
+    s.small = (const SmallRecPair*)c->d_small.p; s.small_tris = (const TriGPU*)c->d_small_tris.p; s.small_cm = B.small_cm; s.small_delta = B.small_delta;
     s.mats = (const MatGPU*)c->d_mats.p; s.nmat = (uint32_t)B.mats.size();
     s.insts = (const InstGPU*)c->d_insts.p;
     s.lights = (const LightGPU*)c->d_lights.p; s.nlights = (uint32_t)B.lights.size();
@@ -200,7 +201,10 @@ int rtx_commit_scene(rtx_ctx* c) {
     budget -= (size_t)s.lds_nodes * 64;
     uint32_t want_tris = s.ntris <= 256 ? s.ntris : 0u;                    // triangles only when ALL of them fit
     s.lds_tris = (size_t)want_tris * 48 <= budget ? want_tris : 0u;
-    s.nsmall = (c->small_scene && !B.small.empty() && s.lds_tris == s.ntris) ? (uint32_t)B.small.size() : 0u;
+    s.nsmall = 0;
+    if (c->small_scene && B.small_nrec && B.small_tris.size() * 48 <= budget + (size_t)s.lds_tris * 48) {
+        s.nsmall = B.small_nrec; s.lds_tris = (uint32_t)B.small_tris.size();   // LDS holds the records' triangles instead of the leaf-ordered ones
+    }
     if (trace_lds_bytes(s) > 64 * 1024) { c->err = "commit: BVH too deep for the LDS traversal stack"; return RTX_ERR_INVALID; }
     c->stats.bvh_nodes = s.nnodes; c->stats.triangles = s.ntris; c->stats.lights = s.nlights; c->stats.materials = s.nmat;
     c->committed = true;

@@ -10,8 +10,9 @@ struct DevScene {
     const NodeGPU*  nodes;  uint32_t nnodes;
     const TriGPU*   tris;   uint32_t ntris;
     const TriShade* shade;
-    const SmallPair* small; uint32_t nsmall;   // nsmall != 0: tiny scene (nsmall triangles, all staged in LDS), brute-force pre-test path
-    float small_cm;                            // distance-margin coefficient of the pre-test
+    const SmallRecPair* small; uint32_t nsmall;   // nsmall != 0: tiny scene: nsmall pre-test records (planar polygons), no BVH
+    const TriGPU* small_tris;                     // 2 triangles per record (staged in LDS instead of `tris`)
+    float small_cm, small_delta;                  // t-margin coefficient, distance tolerance of the edge planes
     const MatGPU*   mats;   uint32_t nmat;
     const InstGPU*  insts;
     const LightGPU* lights; uint32_t nlights;

@@ -2,6 +2,7 @@
 // emissive-triangle CDF and the binned-SAH BVH build.  No HIP calls in this file.
 #include "rtx_scene_host.hpp"
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -215,43 +216,83 @@ bool SceneHost::build(BuiltScene& B) {
         T.e1 = {e1.x, e1.y, e1.z, 0.0f};
         T.e2 = {e2.x, e2.y, e2.z, 0.0f};
     }
-    // ---- plane-form pre-test records for tiny scenes (double precision, then rounded) ----
-    B.small.clear();
+    // ---- tiny scenes: merge triangles into planar convex quads and build the conservative pre-test records ----
+    B.small_recs.clear(); B.small_tris.clear(); B.small_nrec = 0;
     if (!leaf_order.empty() && leaf_order.size() <= kSmallSceneMaxTris) {
-        const double delta = 2e-5 * (double)scale;
-        B.small.resize(leaf_order.size());
-        for (size_t s = 0; s < leaf_order.size(); s++) {
-            const float* t = &wtri[(size_t)leaf_order[s] * 9];
-            double v0[3] = {t[0], t[1], t[2]}, e1[3], e2[3], n[3], a[3], b[3];
-            for (int k = 0; k < 3; k++) { e1[k] = (double)t[3 + k] - v0[k]; e2[k] = (double)t[6 + k] - v0[k]; }
-            auto crs = [](const double* x, const double* y, double* o) { o[0] = x[1] * y[2] - x[2] * y[1]; o[1] = x[2] * y[0] - x[0] * y[2]; o[2] = x[0] * y[1] - x[1] * y[0]; };
-            auto dt = [](const double* x, const double* y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
-            crs(e1, e2, n);
-            const double nn = sqrt(dt(n, n));
-            SmallTri& S = B.small[s];
-            if (!(nn > 0.0)) { S.pl = {0, 0, 0, 0}; S.pu = {0, 0, 0, -1e30f}; S.pv = {0, 0, 0, -1e30f}; S.eps = {0, 0, 0, (float)delta}; continue; }
-            double nu[3] = {n[0] / nn, n[1] / nn, n[2] / nn};
-            crs(e2, n, a); crs(n, e1, b);
-            const double da = dt(e1, a), db = dt(e2, b);
-            double n1[3] = {a[0] / da, a[1] / da, a[2] / da}, n2[3] = {b[0] / db, b[1] / db, b[2] / db}, n12[3] = {n1[0] + n2[0], n1[1] + n2[1], n1[2] + n2[2]};
-            S.pl = {(float)nu[0], (float)nu[1], (float)nu[2], (float)dt(nu, v0)};
-            S.pu = {(float)n1[0], (float)n1[1], (float)n1[2], (float)-dt(v0, n1)};
-            S.pv = {(float)n2[0], (float)n2[1], (float)n2[2], (float)-dt(v0, n2)};
-            S.eps = {(float)(delta * sqrt(dt(n1, n1)) + 1e-5), (float)(delta * sqrt(dt(n2, n2)) + 1e-5), (float)(delta * sqrt(dt(n12, n12)) + 2e-5), (float)delta};
+        const double delta = 2e-5 * (double)scale, tol = 1e-6 * (double)scale;
+        B.small_delta = (float)delta; B.small_cm = 4e-6f * scale;
+        struct D3 { double x, y, z; };
+        auto sub = [](D3 a, D3 b) { return D3{a.x - b.x, a.y - b.y, a.z - b.z}; };
+        auto crs = [](D3 a, D3 b) { return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; };
+        auto dt = [](D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; };
+        auto nrm = [&](D3 a) { double l = sqrt(dt(a, a)); return l > 0 ? D3{a.x / l, a.y / l, a.z / l} : D3{0, 0, 0}; };
+        const size_t n = leaf_order.size();
+        std::vector<std::array<D3, 3>> V(n);
+        for (size_t s = 0; s < n; s++) { const float* t = &wtri[(size_t)leaf_order[s] * 9]; for (int k = 0; k < 3; k++) V[s][k] = D3{t[k * 3], t[k * 3 + 1], t[k * 3 + 2]}; }
+        auto same = [](D3 a, D3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; };
+        struct Rec { double pl[4]; double e[4][4]; int s0, s1; };
+        std::vector<Rec> recs; std::vector<uint8_t> used(n, 0);
+        auto make_rec = [&](const std::vector<D3>& poly, D3 nu, int s0, int s1) {
+            Rec R; R.s0 = s0; R.s1 = s1;
+            R.pl[0] = nu.x; R.pl[1] = nu.y; R.pl[2] = nu.z; R.pl[3] = dt(nu, poly[0]);
+            for (int k = 0; k < 4; k++) { R.e[k][0] = R.e[k][1] = R.e[k][2] = 0.0; R.e[k][3] = 1e30; }     // always inside
+            for (size_t k = 0; k < poly.size(); k++) {
+                D3 A = poly[k], Bv = poly[(k + 1) % poly.size()];
+                D3 m = nrm(crs(nu, sub(Bv, A)));                     // in-plane, pointing inside for a polygon wound CCW about nu
+                R.e[k][0] = m.x; R.e[k][1] = m.y; R.e[k][2] = m.z; R.e[k][3] = -dt(m, A);
+            }
+            return R;
+        };
+        for (size_t i = 0; i < n; i++) {
+            if (used[i]) continue;
+            used[i] = 1;
+            D3 ni = crs(sub(V[i][1], V[i][0]), sub(V[i][2], V[i][0]));
+            const double nn = sqrt(dt(ni, ni));
+            if (!(nn > 0.0)) {                                       // zero-area triangle: the exact test always rejects it
+                Rec R; R.s0 = (int)i; R.s1 = -1; for (int k = 0; k < 4; k++) { R.pl[k] = 0; R.e[k][0] = R.e[k][1] = R.e[k][2] = 0; R.e[k][3] = -1e30; }
+                recs.push_back(R); continue;
+            }
+            D3 nu = nrm(ni);
+            int partner = -1; std::vector<D3> quad;
+            for (size_t j = i + 1; j < n && partner < 0; j++) {
+                if (used[j]) continue;
+                for (int a = 0; a < 3 && partner < 0; a++) {         // apex of i = vertex a, shared edge (a+1, a+2)
+                    D3 r = V[i][a], pp = V[i][(a + 1) % 3], q = V[i][(a + 2) % 3];
+                    for (int bb = 0; bb < 3; bb++) {
+                        D3 sA = V[j][bb], j1 = V[j][(bb + 1) % 3], j2 = V[j][(bb + 2) % 3];
+                        if (!((same(j1, pp) && same(j2, q)) || (same(j1, q) && same(j2, pp)))) continue;
+                        if (fabs(dt(nu, sub(sA, r))) > tol) continue;                       // coplanar
+                        std::vector<D3> poly = {r, pp, sA, q};                                // around the quad, CCW about nu
+                        bool convex = true;
+                        for (int k = 0; k < 4 && convex; k++) {
+                            D3 m = nrm(crs(nu, sub(poly[(k + 1) % 4], poly[k])));
+                            for (int v = 0; v < 4; v++) if (dt(m, sub(poly[v], poly[k])) < -1e-7 * (double)scale) { convex = false; break; }
+                        }
+                        if (!convex) continue;
+                        partner = (int)j; quad = poly; break;
+                    }
+                }
+            }
+            if (partner >= 0) { used[partner] = 1; recs.push_back(make_rec(quad, nu, (int)i, partner)); }
+            else recs.push_back(make_rec({V[i][0], V[i][1], V[i][2]}, nu, (int)i, -1));
         }
-    }
-    B.small_pairs.clear();
-    B.small_cm = 4e-6f * scale;
-    for (size_t s = 0; s < B.small.size(); s += 2) {
-        SmallPair P;
-        for (int e = 0; e < 2; e++) {
-            const bool have = s + e < B.small.size();
-            const SmallTri T = have ? B.small[s + e] : SmallTri{{0, 0, 1, 0}, {0, 0, 0, -1e30f}, {0, 0, 0, -1e30f}, {0, 0, 0, 0}};
-            const float rows[16] = {T.pl.x, T.pl.y, T.pl.z, T.pl.w, T.pu.x, T.pu.y, T.pu.z, T.pu.w, T.pv.x, T.pv.y, T.pv.z, T.pv.w,
-                                    T.eps.x, T.eps.y, 1.0f + T.eps.z, have ? 1e-3f : -1.0f};
-            for (int r = 0; r < 16; r++) P.r[r][e] = rows[r];
+        B.small_nrec = (uint32_t)recs.size();
+        B.small_tris.assign(((recs.size() + 1) & ~(size_t)1) * 2, TriGPU{{0, 0, 0, u2f(kMissPrim)}, {0, 0, 0, 0}, {0, 0, 0, 0}});   // the padding record of an odd count owns two zero-area triangles
+        const TriGPU none{{0, 0, 0, u2f(kMissPrim)}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        for (size_t r = 0; r < recs.size(); r++) { B.small_tris[2 * r] = B.tris[recs[r].s0]; B.small_tris[2 * r + 1] = recs[r].s1 >= 0 ? B.tris[recs[r].s1] : none; }
+        for (size_t r = 0; r < recs.size(); r += 2) {
+            SmallRecPair P;
+            for (int e = 0; e < 2; e++) {
+                const bool have = r + e < recs.size();
+                for (int row = 0; row < 20; row++) {
+                    double v;
+                    if (!have) v = (row == 7 || row == 11 || row == 15 || row == 19) ? -1e30 : 0.0;       // padding: never inside
+                    else v = row < 4 ? recs[r + e].pl[row] : recs[r + e].e[(row - 4) / 4][(row - 4) % 4];
+                    P.r[row][e] = (float)v;
+                }
+            }
+            B.small_recs.push_back(P);
         }
-        B.small_pairs.push_back(P);
     }
     return true;
 }

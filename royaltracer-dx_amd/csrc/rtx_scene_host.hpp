@@ -20,8 +20,9 @@ struct BuiltScene {
     std::vector<MatGPU>   mats;
     std::vector<NodeGPU>  nodes;
     std::vector<TriGPU>   tris;       // leaf order
-    std::vector<SmallTri> small;      // leaf order, only when the scene has <= kSmallSceneMaxTris triangles
-    std::vector<SmallPair> small_pairs; float small_cm = 0.0f;   // device form of `small`; distance-margin coefficient
+    // tiny-scene path (only when the scene has <= kSmallSceneMaxTris triangles): pre-test records + their triangles
+    std::vector<SmallRecPair> small_recs; std::vector<TriGPU> small_tris; uint32_t small_nrec = 0;
+    float small_cm = 0.0f, small_delta = 0.0f;   // margin coefficient for t, distance tolerance of the edge planes
     std::vector<TriShade> shade;      // global triangle id order
     std::vector<InstGPU>  insts;
     std::vector<LightGPU> lights;

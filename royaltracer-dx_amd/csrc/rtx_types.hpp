@@ -19,17 +19,16 @@ constexpr int32_t kEmptyChild = 0x7FFFFFFF;   // never visited (box is inverted)
 // World-space triangle in leaf order: v0 (w = global triangle id bits), e1 = v1 - v0, e2 = v2 - v0.
 struct alignas(16) TriGPU { F4 v0, e1, e2; };
 
-// Tiny scenes (<= 64 triangles, e.g. the Cornell Box): a CONSERVATIVE plane-form pre-test per triangle, evaluated
-// for all triangles in a wave-uniform loop (no BVH, no divergence); survivors go through the exact test.
-//   t = (pl.w - pl.xyz . o) / (pl.xyz . d),  P = o + t d,  u = pu.xyz . P + pu.w,  v = pv.xyz . P + pv.w
-// eps = barycentric tolerances (u, v, u+v) for a distance tolerance delta; eps.w = delta.
-struct alignas(16) SmallTri { F4 pl, pu, pv, eps; };
+// Tiny scenes (<= 64 triangles, e.g. the Cornell Box): no BVH.  Triangles are merged, where possible, into planar
+// convex quads; each record is a CONSERVATIVE pre-test "ray hits the supporting plane inside the polygon":
+//   t = (pl.w - pl.xyz . o) / (pl.xyz . d),  P = o + t d,  inside <=> m_i . P + c_i >= -delta for the 4 edge planes
+// (unit in-plane edge normals, so one world-space distance tolerance delta serves all).  Records are evaluated for
+// all rays in a wave-uniform loop, two records per iteration on packed-FP32 instructions, coefficients scalar-loaded.
+// Device form: two records transposed into 20 float2 rows: 0-3 plane | 4-7 edge 0 | 8-11 edge 1 | 12-15 edge 2 | 16-19 edge 3.
+// Record r owns triangles 2r and 2r+1 of `small_tris` (a missing partner is a zero-area triangle).
+struct alignas(16) SmallRecPair { float r[20][2]; };
+static_assert(sizeof(SmallRecPair) == 160, "SmallRecPair must be 160 bytes");
 constexpr uint32_t kSmallSceneMaxTris = 64;
-// Device form: two consecutive triangles transposed into 16 float2 rows so that the pre-test of both runs on
-// packed-FP32 instructions (v_pk_fma_f32) with wave-uniform (scalar-loaded) operands.  Rows:
-//  0-3 pl.xyzw | 4-7 pu.xyzw | 8-11 pv.xyzw | 12 eps_u | 13 eps_v | 14 1+eps_w | 15 grazing threshold (-1 = padding)
-struct alignas(16) SmallPair { float r[16][2]; };
-static_assert(sizeof(SmallPair) == 128, "SmallPair must be 128 bytes");
 
 // What ClosestHit (Hit_v6.hlsl:12-61) needs about a triangle, pre-gathered per GLOBAL triangle id:
 // object-space flat normal + area, and the three per-vertex normals with the "all(n != 0) else flat"

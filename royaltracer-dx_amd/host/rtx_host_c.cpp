@@ -119,6 +119,24 @@ int rtxh_bvh_check(const float* wt, uint32_t ntris, uint32_t* nodes_out, uint32_
     return 0;
 }
 
+// the tiny-scene pre-test records as rtx_commit_scene builds them (for host-side conservativeness tests)
+int rtxh_scene_small_records(const rtxh_scene* sc, float* recs20, int32_t* tri_ids2, uint32_t max_recs, uint32_t* nrec_out, float* delta_out, float* cm_out) {
+    rtx::SceneHost H; rtx::BuiltScene B;
+    const Scene& s = sc->s;
+    if (!H.set_materials(s.materials.data(), (uint32_t)s.materials.size())) return RTX_ERR_INVALID;
+    for (const SceneModel& m : s.models) { uint32_t id; if (!H.add_mesh(m.vertices.data(), (uint32_t)m.vertices.size(), m.indices.data(), (uint32_t)m.indices.size(), m.materialIDs.data(), &id)) return RTX_ERR_INVALID; }
+    for (const SceneInstance& in : s.instances) { uint32_t id; if (!H.add_instance(in.model, in.transform.data(), &id)) return RTX_ERR_INVALID; }
+    if (!H.build(B)) return RTX_ERR_INVALID;
+    if (nrec_out) *nrec_out = B.small_nrec;
+    if (delta_out) *delta_out = B.small_delta;
+    if (cm_out) *cm_out = B.small_cm;
+    for (uint32_t r = 0; r < B.small_nrec && r < max_recs; r++) {
+        for (int row = 0; row < 20; row++) recs20[(size_t)r * 20 + row] = B.small_recs[r / 2].r[row][r & 1];
+        for (int h = 0; h < 2; h++) { uint32_t g = rtx::f2u(B.small_tris[2 * r + h].v0.w); tri_ids2[2 * r + h] = g == rtx::kMissPrim ? -1 : (int32_t)g; }
+    }
+    return RTX_OK;
+}
+
 rtxh_renderer* rtxh_renderer_create(uint32_t w, uint32_t h, const char* name, int device) {
     rtxh_renderer* r = new rtxh_renderer(); r->r = new Renderer(w, h, name ? name : "rtx"); r->r->SetDevice(device); return r;
 }

@@ -177,3 +177,36 @@ def test_product_never_references_the_oracle():
 def test_params_struct_layout(rt, orc):
     assert ctypes.sizeof(rt.Params) == ctypes.sizeof(orc.Params) == 48
     assert [n for n, _ in rt.Params._fields_] == [n for n, _ in orc.Params._fields_]
+
+
+def test_tiny_scene_pretest_records_are_conservative(rt, orc, cornell):
+    """The plane/edge pre-test of the tiny-scene path (rtx_scene_host.cpp) may only discard triangles the exact test
+    rejects: emulate it in float64 for every brute-force hit of 100 k rays (camera, random, from-surface, grazing)."""
+    recs, ids, delta, cm = cornell.small_records()
+    assert len(recs) == 17 and (ids[:, 1] >= 0).sum() == 15                    # 15 planar quads + 2 single triangles (the twisted red wall)
+    assert sorted(int(v) for v in ids.ravel() if v >= 0) == list(range(32))    # every triangle in exactly one record
+    o = orc.Oracle().load(cornell, 16 / 9)
+    rng = np.random.default_rng(3)
+    n = 60000
+    r = np.zeros((n, 8), np.float32); r[:, 0:3] = rng.uniform(-0.2, 1.2, (n, 3)); d = rng.normal(size=(n, 3)); r[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    r[:, 3], r[:, 7] = 1e-4, 1e4
+    cam = o.primary_rays(rt.Params(width=160, height=90)); hc = o.trace_closest(cam, 1); hitc = hc.view(np.uint32)[:, 3] != 0xFFFFFFFF
+    sec = np.zeros((int(hitc.sum()), 8), np.float32); sec[:, 0:3] = cam[hitc, 0:3] + hc[hitc, 0:1] * cam[hitc, 4:7]
+    d = rng.normal(size=(len(sec), 3)); sec[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True); sec[:, 3], sec[:, 7] = 2e-5, 1e4
+    graz = r[:8000].copy(); graz[:, 5] = rng.uniform(-2e-4, 2e-4, len(graz)); graz[:, 4:7] /= np.linalg.norm(graz[:, 4:7], axis=1, keepdims=True)
+    rays = np.concatenate([cam, r, sec, graz])
+    h = o.trace_closest(rays, 0); prim = h.view(np.uint32)[:, 3]; hit = prim != 0xFFFFFFFF
+    owner = np.full(32, -1); owner[ids[:, 0]] = np.arange(len(ids)); two = ids[:, 1] >= 0; owner[ids[two, 1]] = np.arange(len(ids))[two]
+    R = recs.astype(np.float64)[owner[prim[hit]]]
+    oo, dd = rays[hit, 0:3].astype(np.float64), rays[hit, 4:7].astype(np.float64)
+    nd = (R[:, 0:3] * dd).sum(1); no = R[:, 3] - (R[:, 0:3] * oo).sum(1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = no / nd
+        P = oo + t[:, None] * dd
+        e = np.stack([(R[:, 4 + 4 * j:7 + 4 * j] * P).sum(1) + R[:, 7 + 4 * j] for j in range(4)], 1)
+        mt = cm * np.abs(1 / nd) + 1e-5 * np.abs(t)
+        tmin, tmax = rays[hit, 3].astype(np.float64), rays[hit, 7].astype(np.float64)
+        ok = (t + mt >= tmin) & (tmax + mt - t >= 0) & (e.min(1) + delta >= 0)
+    passes = ok | (np.abs(nd) < 1e-3)
+    assert passes.all(), f"{int((~passes).sum())} true hits would be discarded by the pre-test"
+    assert hit.sum() > 40000
