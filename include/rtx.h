@@ -123,6 +123,15 @@ int  rtx_render(rtx_ctx*, const rtx_params*);
 int  rtx_render_v6_pass1(rtx_ctx*, const rtx_params*);
 size_t rtx_pass1_slots(uint32_t width, uint32_t height);            /* records per buffer: ceil(w/4)*ceil(h/4)*16 */
 int  rtx_read_pass1_buffers(rtx_ctx*, void* reservoirs_di40, void* reservoirs_gi40, void* samples60, size_t slots);
+/* The reference's full frame: pass 1, then RayGen2 = temporal reuse (RayGen_v6_pass2.hlsl:46-204, second DispatchRays,
+   Renderer.cpp:662-664) and RayGen3 = spatial reuse + final shade (RayGen_v6_pass3.hlsl:46-441, third DispatchRays, :671-673)
+   with the pairwise MIS of MIS_v6.hlsl / MIS_GI_v6.hlsl.  `spp` = number of consecutive frames (frame_seed, frame_seed+1, ...)
+   rendered with the current camera; each adds ReconnectDI*W + f_gi*W_gi to u1.  u3/u5/u7 (`g_*_last`) persist in the context
+   between calls; rtx_set_camera keeps the previous view/projection for the reprojection; rtx_restir_reset zeroes the history.
+   Needs the whole image in one context (shard_count = 1): pass 3 reads neighbours within 20 px. */
+int  rtx_render_restir(rtx_ctx*, const rtx_params*);
+int  rtx_restir_reset(rtx_ctx*);
+int  rtx_read_restir_last(rtx_ctx*, void* reservoirs_di40, void* reservoirs_gi40, void* samples60, size_t slots);   /* u3 / u5 / u7 */
 int  rtx_read_accum(rtx_ctx*, float* rgba32f, size_t bytes);       /* copy of u1 to the host */
 /* u0 `gOutput` layer 0, RGBA8 UNORM after sRGB OETF (RayGen_v6_pass3.hlsl:405,428-441; Common_v6.hlsl:353-376) */
 int  rtx_read_srgb8(rtx_ctx*, uint8_t* rgba8, size_t bytes);

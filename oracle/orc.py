@@ -53,6 +53,7 @@ _sig("orc_render", C.c_int, _vp, C.POINTER(Params), _vp, C.POINTER(C.c_uint64))
 _sig("orc_srgb8", None, _vp, _u32, _vp)
 _sig("orc_render_v6_pass1", C.c_int, _vp, C.POINTER(Params), _vp, _vp, _vp, _vp, C.POINTER(C.c_uint64))
 _sig("orc_pass1_slots", C.c_size_t, _u32, _u32)
+_sig("orc_restir_frame", C.c_int, _vp, C.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint64))
 _sig("orc_map_pixel_id", _u32, _u32, _u32, _u32)
 _sig("orc_tea", None, _u32p, _u32, _vp)
 _sig("orc_seed_init", None, _u32, _u32, _u32, _u32, _u32p)
@@ -131,6 +132,22 @@ class Oracle:
         cnt = (C.c_uint64 * 3)()
         assert lib.orc_render_v6_pass1(self._h, C.byref(p), _p(accum), _p(di), _p(gi), _p(sd), cnt) == 0
         return accum, (di, gi, sd), (cnt[0], cnt[1], cnt[2])
+
+    def restir_frames(self, params, accum=None, state=None):
+        """`params.spp` consecutive ReSTIR frames; state = (cur_di, cur_gi, cur_sd, last_di, last_gi, last_sd) carried between calls"""
+        p = params_from(params)
+        if accum is None:
+            accum = np.zeros((p.height, p.width, 4), np.float32)
+        n = lib.orc_pass1_slots(p.width, p.height)
+        if state is None:
+            state = tuple(np.zeros((n, k), np.uint8) for k in (40, 40, 60, 40, 40, 60))
+        tot = np.zeros(3, np.uint64)
+        for fr in range(p.spp):
+            q = params_from(params); q.spp = 1; q.frame_seed = p.frame_seed + fr
+            cnt = (C.c_uint64 * 3)()
+            assert lib.orc_restir_frame(self._h, C.byref(q), _p(accum), *[_p(b) for b in state], cnt) == 0
+            tot += np.array([cnt[0], cnt[1], cnt[2]], np.uint64)
+        return accum, state, tuple(int(v) for v in tot)
 
     def primary_rays(self, params, sample_id=1):
         p = params_from(params)

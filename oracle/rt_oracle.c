@@ -179,7 +179,7 @@ typedef struct {            /* fp16-rounded working copy: MaterialOptimized, Com
 } matopt_t;
 
 typedef struct { float* verts; uint32_t nverts; uint32_t* idx; uint32_t nidx; uint32_t matid_base; } mesh_t;
-typedef struct { uint32_t mesh; float o2w[16]; float nrm[16]; uint32_t tri_base; } inst_t;
+typedef struct { uint32_t mesh; float o2w[16]; float nrm[16]; float o2w_inv[16]; float prev_o2w[16]; uint32_t tri_base; } inst_t;
 typedef struct { float bmin[3], bmax[3]; uint32_t left, right, first, count; } node_t;   /* count>0 => leaf */
 
 struct orc_ctx {
@@ -194,6 +194,7 @@ struct orc_ctx {
     /* bvh */
     node_t* nodes; uint32_t nnodes; uint32_t* order;
     float view[16], proj[16], viewI[16], projI[16];
+    float prev_view[16], prev_proj[16]; int have_cam;      /* m_prevViewMatrix / m_prevProjMatrix, Renderer.cpp:1766-1767 */
     int nthreads;
 };
 
@@ -260,6 +261,7 @@ int orc_add_instance(orc_ctx* c, uint32_t mesh, const float* o2w16, uint32_t* in
     c->insts = (inst_t*)realloc(c->insts, (c->ninst + 1) * sizeof(inst_t));
     inst_t* in = &c->insts[c->ninst];
     in->mesh = mesh; memcpy(in->o2w, o2w16, 64); normal_matrix(o2w16, in->nrm); in->tri_base = 0;
+    orc_mat4_inverse(o2w16, in->o2w_inv); memcpy(in->prev_o2w, o2w16, 64);      /* Renderer.cpp:2098-2102 (static scene: prev = current) */
     if (inst_out) *inst_out = c->ninst;
     c->ninst++;
     return 0;
@@ -391,6 +393,8 @@ int orc_commit(orc_ctx* c) {
 }
 
 int orc_set_camera(orc_ctx* c, const float* view16, const float* proj16) {
+    if (c->have_cam) { memcpy(c->prev_view, c->view, 64); memcpy(c->prev_proj, c->proj, 64); }
+    else { memcpy(c->prev_view, view16, 64); memcpy(c->prev_proj, proj16, 64); c->have_cam = 1; }
     memcpy(c->view, view16, 64); memcpy(c->proj, proj16, 64);
     orc_mat4_inverse(view16, c->viewI); orc_mat4_inverse(proj16, c->projI);   /* Renderer.cpp:1735-1736 */
     return 0;
@@ -1195,6 +1199,296 @@ int orc_render_v6_pass1(orc_ctx* c, const orc_params* p, float* accum, void* res
             }
         }
         c0 += cnt[0]; c1 += cnt[1]; c2 += cnt[2];
+    }
+    if (ray_counts) { ray_counts[0] = c0; ray_counts[1] = c1; ray_counts[2] = c2; }
+    return 0;
+}
+
+/* =====================================================================================================
+ * ReSTIR temporal reuse (pass 2, RayGen_v6_pass2.hlsl:46-204) and spatial reuse + final shade (pass 3,
+ * RayGen_v6_pass3.hlsl:46-441) with the pairwise-MIS helpers of MIS_v6.hlsl / MIS_GI_v6.hlsl, restated
+ * literally on the reference's packed buffers.  Constants: Common_v6.hlsl:14-26.
+ * DEVIATIONS: pixels whose primary ray missed (mID = 0xFFFE) are skipped by both passes (v6 runs them on
+ * zero-filled out-of-bounds reads); a reprojected pixel outside the image reads as a zero record (D3D
+ * out-of-bounds read); sin/cos as everywhere; uint(time) := frame_seed.  The view-change reset of
+ * gPermanentData (pass3:407-423) is the caller's job (rtx_clear_accum / Renderer facade).
+ * ===================================================================================================== */
+#define SPATIAL_CANDIDATES 3
+#define SPATIAL_MAX_TRIES 9
+#define SPATIAL_RADIUS 20
+#define SPATIAL_M_CAP 128
+#define TEMPORAL_M_CAP 16
+#define W_SUM_THRESHOLD 5.0f
+#define J_THRESHOLD 5.0f
+
+static inline float half_to_float(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+    if (e == 0) { float f = (float)m * (1.0f / 16777216.0f); return u2f(f2u(f) | sign); }
+    if (e == 31) return u2f(sign | 0x7F800000u | (m << 13));
+    return u2f(sign | ((e + 112u) << 23) | (m << 13));
+}
+typedef struct { v3 x1; uint32_t mID; v3 L1; v3 n1; v3 o; uint32_t objID; v3 debug; } sdata_t;
+static res_t load_res(const uint8_t* p) {
+    res_t r; float f[8]; uint16_t h[4]; memcpy(f, p, 32); memcpy(h, p + 32, 8);
+    r.x2 = V3(f[0], f[1], f[2]); r.w_sum = f[3]; r.n2 = V3(f[4], f[5], f[6]); r.W = f[7];
+    r.L2 = V3(half_to_float(h[0]), half_to_float(h[1]), half_to_float(h[2])); r.M = h[3];
+    return r;
+}
+static sdata_t load_sd(const uint8_t* d) {
+    sdata_t s; uint16_t m16, h[3];
+    memcpy(&s.x1, d, 12); memcpy(&m16, d + 12, 2); memcpy(h, d + 14, 6); memcpy(&s.n1, d + 20, 12); memcpy(&s.o, d + 32, 12);
+    memcpy(&s.objID, d + 44, 4); memcpy(&s.debug, d + 48, 12);
+    s.mID = m16; s.L1 = V3(half_to_float(h[0]), half_to_float(h[1]), half_to_float(h[2]));
+    return s;
+}
+static const uint8_t g_zero60[60] = {0};
+static inline float minf_u(float cap, uint32_t m) { return (float)(m < (uint32_t)cap ? m : (uint32_t)cap); }
+
+/* GetP_Hat / GetP_Hat_GI: Sampler_v6.hlsl:163-181 with ReconnectGI :134-160 */
+static float get_p_hat(const orc_ctx* c, uint32_t mid, uint32_t flags, v3 x1, v3 n1, v3 x2, v3 n2, v3 L2, v3 o, int vis, uint64_t cnt[3]) {
+    float f_g = length3(reconnect_di(c, mid, flags, x1, n1, x2, n2, L2, o));
+    float v = 1.0f;
+    if (vis) { v3 dv = sub3(x2, x1); v = visibility(c, x1, n1, normalize3(dv), length3(dv), cnt); }
+    return f_g * v;
+}
+static v3 get_p_hat_gi(const orc_ctx* c, uint32_t mid, uint32_t flags, v3 x1, v3 n1, v3 x2, v3 L, v3 o, int vis, uint64_t cnt[3]) {
+    v3 dir = sub3(x2, x1);
+    float cos1 = fabsf(dot3(n1, normalize3(dir)));
+    v3 f0, f1; float q0, q1, pd, ps;
+    lobes(c, mid, flags, n1, normalize3(dir), normalize3(o), normalize3(o), &f0, &f1, &q0, &q1, &pd, &ps);
+    v3 Fx = add3(safe_mul3(pd, f0), safe_mul3(ps, f1));
+    v3 fr = V3(Fx.x * cos1 * L.x, Fx.y * cos1 * L.y, Fx.z * cos1 * L.z);
+    if (!finite3(fr)) fr = V3(0, 0, 0);
+    float v = 1.0f;
+    if (vis) v = visibility(c, x1, n1, normalize3(dir), length3(dir), cnt);
+    return scale3(fr, v);
+}
+static inline float get_w(float w_sum, float p_hat) { return p_hat > EPSILON_ ? w_sum / p_hat : 0.0f; }
+/* Jacobian_Reconnection: Sampler_v6.hlsl:48-68 */
+static float jacobian(const sdata_t* r, const sdata_t* q, v3 x2q, v3 n2q) {
+    v3 vq = sub3(x2q, q->x1), vr = sub3(x2q, r->x1);
+    float cq = fabsf(dot3(normalize3(neg3(vq)), normalize3(n2q))), cr = fabsf(dot3(normalize3(neg3(vr)), normalize3(n2q)));
+    return (cq / cr) * (dot3(vr, vr) / dot3(vq, vq));
+}
+static inline int valid_res(const res_t* r) { return length3(r->n2) > 0.0f && length3(r->L2) > 0.0f && r->w_sum > 0.0f && r->M > 0; }   /* Sampler_v6.hlsl:7-14 */
+static inline int valid_res_gi(const res_t* r) { return r->w_sum > 0.0f && r->M > 0; }                                                  /* :17-22 */
+static inline int reject_distance(v3 x1, v3 x2, v3 cam, float thr) {                                                                     /* Common_v6.hlsl:342-350 */
+    float d1 = length3(sub3(x1, cam)), d2 = length3(sub3(x2, cam));
+    return fabsf(d1 - d2) / maxf(d1, d2) > thr;
+}
+static inline int reject_jacobian(float J, float thr) { return J > thr || J < 1.0f / thr || is_nan(J) || is_inf(J); }                 /* :316-320 */
+static inline v3 mul44(const float* m, v3 p, float w, float* ow) {
+    *ow = m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15] * w;
+    return V3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12] * w, m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13] * w, m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14] * w);
+}
+/* GetBestReprojectedPixel_d: Sampler_v6.hlsl:738-785 */
+static void reproject(const orc_ctx* c, v3 world, uint32_t objID, float W, float H, int* px, int* py) {
+    float w0, w1, w2, w3;
+    const inst_t* in = &c->insts[objID < c->ninst ? objID : 0];
+    v3 lp = mul44(in->o2w_inv, world, 1.0f, &w0);
+    v3 pw = mul44(in->prev_o2w, lp, w0, &w1);
+    v3 vp = mul44(c->prev_view, pw, w1, &w2);
+    v3 cp = mul44(c->prev_proj, vp, w2, &w3);
+    if (w3 <= 0.0f) { *px = -1; *py = -1; return; }
+    float ux = (cp.x / w3) * 0.5f + 0.5f, uy = (cp.y / w3) * 0.5f + 0.5f;
+    uy = 1.0f - uy;
+    *px = (int)rintf(ux * W); *py = (int)rintf(uy * H);
+}
+/* GetRandomPixelCircleWeighted: Common_v6.hlsl:202-244 (spatial_exponent = 1) */
+static void random_pixel(uint32_t radius, uint32_t w, uint32_t h, uint32_t x, uint32_t y, uint32_t seed[2], int* ox, int* oy) {
+    int nx, ny;
+    do {
+        float u = rnd(seed);
+        float r = (float)radius * u;
+        float ang = rnd(seed) * 6.2831853f;
+        float sn, cs; orc_sincos(ang, &sn, &cs);
+        nx = (int)x + (int)(cs * r); ny = (int)y + (int)(sn * r);
+        while (nx < 0 || nx >= (int)w) { if (nx < 0) nx = -nx; else nx = 2 * (int)w - nx - 2; }
+        while (ny < 0 || ny >= (int)h) { if (ny < 0) ny = -ny; else ny = 2 * (int)h - ny - 2; }
+    } while (nx == (int)x && ny == (int)y);
+    *ox = nx; *oy = ny;
+}
+
+typedef struct { uint8_t *cur_di, *cur_gi, *cur_sd, *last_di, *last_gi, *last_sd; } restir_bufs;
+
+static void restir_pass2_pixel(const orc_ctx* c, const orc_params* p, const restir_bufs* B, uint32_t x, uint32_t y, uint64_t cnt[3]) {
+    const uint32_t flags = p->flags;
+    size_t slot = map_pixel_id(p->width, x, y);
+    res_t rc = load_res(B->cur_di + slot * 40), gc = load_res(B->cur_gi + slot * 40);
+    sdata_t sc = load_sd(B->cur_sd + slot * 60);
+    if (!(sc.L1.x == 0.0f && sc.L1.y == 0.0f && sc.L1.z == 0.0f) || sc.mID == 0xFFFEu || sc.mID >= c->nmat) return;
+    v3 cam = V3(c->viewI[12], c->viewI[13], c->viewI[14]);
+    uint32_t seed[2]; orc_seed_init(x, y, 2, p->frame_seed, seed);                              /* pass2:78-79 */
+    int px, py; reproject(c, sc.x1, sc.objID, (float)p->width, (float)p->height, &px, &py);
+    int inside = px >= 0 && py >= 0 && px < (int)p->width && py < (int)p->height;
+    size_t ts = inside ? map_pixel_id(p->width, (uint32_t)px, (uint32_t)py) : 0;
+    static const uint8_t zero40[40] = {0};
+    res_t rl = load_res(inside ? B->last_di + ts * 40 : zero40), gl = load_res(inside ? B->last_gi + ts * 40 : zero40);
+    sdata_t sl = load_sd(inside ? B->last_sd + ts * 60 : g_zero60);
+    int base_ok = (px != -1 && py != -1) && length3(sl.L1) == 0.0f && !reject_distance(sc.x1, sl.x1, cam, 0.1f) && sl.mID == sc.mID;
+    int acc_di = base_ok && valid_res(&rl) && (rl.x2.x != 0.0f && rl.x2.y != 0.0f && rl.x2.z != 0.0f);
+    int acc_gi = base_ok && !(gl.w_sum > W_SUM_THRESHOLD) && valid_res_gi(&gl);
+    uint32_t mid = sc.mID;
+    if (acc_di) {                                                                                 /* pass2:112-152 */
+        float M_sum = minf_u(TEMPORAL_M_CAP, rc.M) + minf_u(TEMPORAL_M_CAP, rl.M);
+        float mc = minf_u(TEMPORAL_M_CAP, rc.M), ml = minf_u(TEMPORAL_M_CAP, rl.M);
+        float mi_c = mc / M_sum;                                                                  /* MIS_v6.hlsl:62-70 */
+        { float m_num = mc, m_den = m_num + (M_sum - mc); if (m_den > 0.0f) mi_c += (ml / M_sum) * (m_num / m_den); }
+        float mi_t;                                                                               /* :72-79 */
+        { float m_num = M_sum - mc, m_den = m_num + mc; mi_t = m_den > 0.0f ? (ml / M_sum) * m_num / m_den : 0.0f; }
+        if (length3(rl.n2) == 0.0f) { mi_c = 1.0f; mi_t = 0.0f; }
+        float w_c = mi_c * get_p_hat(c, mid, flags, sc.x1, sc.n1, rc.x2, rc.n2, rc.L2, sc.o, 0, cnt) * rc.W;
+        float w_t = mi_t * get_p_hat(c, mid, flags, sc.x1, sc.n1, rl.x2, rl.n2, rl.L2, sc.o, 1, cnt) * rl.W;
+        rc.M = (uint32_t)mc; rc.w_sum = w_c;
+        rc.w_sum += w_t; rc.M = (rc.M + (uint32_t)ml) & 0xFFFFu;                                  /* UpdateReservoir */
+        if (rnd(seed) < w_t / rc.w_sum) { rc.x2 = rl.x2; rc.n2 = rl.n2; rc.L2 = rl.L2; }
+        float p_hat = get_p_hat(c, mid, flags, sc.x1, sc.n1, rc.x2, rc.n2, rc.L2, sc.o, 0, cnt);
+        rc.W = get_w(rc.w_sum, p_hat);
+    }
+    if (acc_gi) {                                                                                 /* pass2:155-198 */
+        float mc = minf_u(TEMPORAL_M_CAP, gc.M), ml = minf_u(TEMPORAL_M_CAP, gl.M), M_sum = mc + ml;
+        float mi_c = mc / M_sum;
+        { float m_num = mc, m_den = m_num + (M_sum - mc); if (m_den > 0.0f) mi_c += (ml / M_sum) * (m_num / m_den); }
+        float mi_t;
+        { float m_num = M_sum - mc, m_den = m_num + mc; mi_t = m_den > 0.0f ? (ml / M_sum) * m_num / m_den : 0.0f; }
+        float w_c = mi_c * length3(get_p_hat_gi(c, mid, flags, sc.x1, sc.n1, gc.x2, gc.L2, sc.o, 0, cnt)) * gc.W;
+        float w_t = mi_t * length3(get_p_hat_gi(c, mid, flags, sc.x1, sc.n1, gl.x2, gl.L2, sc.o, 1, cnt)) * gl.W;
+        gc.M = (uint32_t)mc; gc.w_sum = w_c;
+        gc.w_sum += w_t; gc.M = (gc.M + (uint32_t)ml) & 0xFFFFu;
+        if (rnd(seed) < w_t / gc.w_sum) { gc.x2 = gl.x2; gc.n2 = gl.n2; gc.L2 = gl.L2; }
+        gc.W = get_w(gc.w_sum, length3(get_p_hat_gi(c, mid, flags, sc.x1, sc.n1, gc.x2, gc.L2, sc.o, 0, cnt)));
+    }
+    store_res(B->cur_di + slot * 40, &rc); store_res(B->cur_gi + slot * 40, &gc);
+}
+
+/* pass 3 reads only `cur_*` of other pixels (written by pass 2) and writes `last_*` of its own pixel */
+static int restir_pass3_pixel(const orc_ctx* c, const orc_params* p, const restir_bufs* B, uint32_t x, uint32_t y, v3* out, uint64_t cnt[3]) {
+    const uint32_t flags = p->flags, W = p->width, H = p->height;
+    size_t slot = map_pixel_id(W, x, y);
+    sdata_t sc = load_sd(B->cur_sd + slot * 60);
+    if (!(sc.L1.x == 0.0f && sc.L1.y == 0.0f && sc.L1.z == 0.0f)) { *out = sc.L1; return 1; }   /* pass3:457-462 */
+    if (sc.mID == 0xFFFEu || sc.mID >= c->nmat) { *out = V3(0, 0, 0); return 1; }
+    v3 cam = V3(c->viewI[12], c->viewI[13], c->viewI[14]);
+    uint32_t seed[2]; orc_seed_init(x, y, 3, p->frame_seed, seed);
+    const uint32_t mid = sc.mID; const matopt_t* m = &c->mopt[mid];
+    res_t rcur = load_res(B->cur_di + slot * 40), gcur = load_res(B->cur_gi + slot * 40);
+    size_t cand_di[SPATIAL_CANDIDATES], cand_gi[SPATIAL_CANDIDATES]; int n_di = 0, n_gi = 0;
+    float M_sum_DI = minf_u(SPATIAL_M_CAP, rcur.M), M_sum_GI = minf_u(SPATIAL_M_CAP, gcur.M);
+    for (int a = 0; a < SPATIAL_MAX_TRIES && n_di < SPATIAL_CANDIDATES; a++) {                    /* pass3:106-135 */
+        int nx, ny; random_pixel(SPATIAL_RADIUS, W, H, x, y, seed, &nx, &ny);
+        size_t pr = map_pixel_id(W, (uint32_t)nx, (uint32_t)ny);
+        sdata_t sn = load_sd(B->cur_sd + pr * 60); res_t rn = load_res(B->cur_di + pr * 40);
+        int ok = !(dot3(sc.n1, sn.n1) < 0.9f) && !reject_distance(sc.x1, sn.x1, cam, 0.1f) && valid_res(&rn) && length3(sn.L1) == 0.0f && sn.mID == sc.mID;
+        if (ok) { cand_di[n_di++] = pr; M_sum_DI += minf_u(SPATIAL_M_CAP, rn.M); }
+    }
+    for (int a = 0; a < SPATIAL_MAX_TRIES && n_gi < SPATIAL_CANDIDATES; a++) {                    /* pass3:146-186 */
+        int nx, ny; random_pixel(SPATIAL_RADIUS, W, H, x, y, seed, &nx, &ny);
+        size_t pr = map_pixel_id(W, (uint32_t)nx, (uint32_t)ny);
+        sdata_t sn = load_sd(B->cur_sd + pr * 60); res_t gn = load_res(B->cur_gi + pr * 40);
+        int ok = m->Pr > 0.3f && !reject_distance(sc.x1, sn.x1, cam, 0.1f) && !(dot3(normalize3(sub3(gn.x2, sc.x1)), sc.n1) < 0.0f) &&
+                 !(gn.w_sum > W_SUM_THRESHOLD) && valid_res_gi(&gn) && !reject_jacobian(jacobian(&sn, &sc, gn.x2, gn.n2), J_THRESHOLD) &&
+                 length3(sn.L1) == 0.0f && sn.mID == sc.mID;
+        if (ok) { cand_gi[n_gi++] = pr; M_sum_GI += minf_u(SPATIAL_M_CAP, gn.M); }
+    }
+    const res_t can = rcur, can_gi = gcur;
+    /* GenPairwiseMIS_canonical: MIS_v6.hlsl:2-37 */
+    float cMmin = minf_u(SPATIAL_M_CAP, can.M), cMmax = M_sum_DI - cMmin;
+    float p_c = get_p_hat(c, mid, flags, sc.x1, sc.n1, can.x2, can.n2, can.L2, sc.o, 0, cnt);
+    float c_m_num = cMmin * p_c, mi_c = cMmin / M_sum_DI;
+    for (int j = 0; j < n_di; j++) {
+        sdata_t sn = load_sd(B->cur_sd + cand_di[j] * 60); res_t rn = load_res(B->cur_di + cand_di[j] * 40);
+        float nM = minf_u(SPATIAL_M_CAP, rn.M);
+        float p_from = get_p_hat(c, mid, flags, sn.x1, sn.n1, can.x2, can.n2, can.L2, sn.o, 1, cnt);
+        float m_den = c_m_num + (cMmax * p_from);
+        if (m_den > 0.0f) mi_c += (nM / M_sum_DI) * (c_m_num / m_den);
+    }
+    float w_c = mi_c * get_p_hat(c, mid, flags, sc.x1, sc.n1, can.x2, can.n2, can.L2, sc.o, 0, cnt) * can.W;
+    /* GenPairwiseMIS_canonical_GI: MIS_GI_v6.hlsl:2-41 */
+    float gMmin = minf_u(SPATIAL_M_CAP, can_gi.M), gMmax = M_sum_GI - gMmin;
+    float pg_c = length3(get_p_hat_gi(c, mid, flags, sc.x1, sc.n1, can_gi.x2, can_gi.L2, sc.o, 0, cnt));
+    float g_m_num = gMmin * pg_c, mi_c_gi = gMmin / M_sum_GI;
+    for (int j = 0; j < n_gi; j++) {
+        sdata_t sn = load_sd(B->cur_sd + cand_gi[j] * 60); res_t gn = load_res(B->cur_gi + cand_gi[j] * 40);
+        float nM = minf_u(SPATIAL_M_CAP, gn.M);
+        float j_gi = jacobian(&sc, &sn, can_gi.x2, can_gi.n2);
+        float p_from = length3(get_p_hat_gi(c, mid, flags, sn.x1, sn.n1, can_gi.x2, can_gi.L2, sn.o, 1, cnt)) * j_gi;
+        float m_den = g_m_num + (gMmax * p_from);
+        if (m_den > 0.0f) mi_c_gi += (nM / M_sum_GI) * (g_m_num / m_den);
+    }
+    mi_c_gi = minf(maxf(mi_c_gi, 0.0f), 1.0f);
+    float w_c_gi = mi_c_gi * length3(get_p_hat_gi(c, mid, flags, sc.x1, sc.n1, can_gi.x2, can_gi.L2, sc.o, 0, cnt)) * can_gi.W;
+    rcur.M = (uint32_t)cMmin; rcur.w_sum = w_c;
+    gcur.M = (uint32_t)gMmin; gcur.w_sum = w_c_gi;
+    for (int v = 0; v < n_di; v++) {                                                              /* pass3:247-283 + MIS_v6.hlsl:40-59 */
+        sdata_t sn = load_sd(B->cur_sd + cand_di[v] * 60); res_t rn = load_res(B->cur_di + cand_di[v] * 40);
+        float pc2 = get_p_hat(c, mid, flags, sc.x1, sc.n1, can.x2, can.n2, can.L2, sc.o, 0, cnt);
+        float p_from = get_p_hat(c, mid, flags, sn.x1, sn.n1, can.x2, can.n2, can.L2, sn.o, 0, cnt);
+        float m_num = (M_sum_DI - cMmin) * p_from, m_den = m_num + (cMmin * pc2);
+        float mi_s = m_den > 0.0f ? (minf_u(SPATIAL_M_CAP, rn.M) / M_sum_DI) * (m_num / m_den) : 0.0f;
+        float w_s = mi_s * get_p_hat(c, mid, flags, sc.x1, sc.n1, rn.x2, rn.n2, rn.L2, sc.o, 0, cnt) * rn.W;
+        rcur.w_sum += w_s; rcur.M = (rcur.M + (uint32_t)minf_u(SPATIAL_M_CAP, rn.M)) & 0xFFFFu;
+        if (rnd(seed) < w_s / rcur.w_sum) { rcur.x2 = rn.x2; rcur.n2 = rn.n2; rcur.L2 = rn.L2; }
+    }
+    for (int v = 0; v < n_gi; v++) {                                                              /* pass3:286-334 + MIS_GI_v6.hlsl:44-75 */
+        sdata_t sn = load_sd(B->cur_sd + cand_gi[v] * 60); res_t gn = load_res(B->cur_gi + cand_gi[v] * 40);
+        float pc2 = length3(get_p_hat_gi(c, mid, flags, sc.x1, sc.n1, can_gi.x2, can_gi.L2, sc.o, 0, cnt));
+        float jj = jacobian(&sc, &sn, can_gi.x2, can_gi.n2);
+        float p_from = length3(get_p_hat_gi(c, mid, flags, sn.x1, sn.n1, can_gi.x2, can_gi.L2, sn.o, 0, cnt)) * jj;
+        float m_num = (M_sum_GI - gMmin) * p_from, m_den = m_num + (gMmin * pc2);
+        float mi_s = m_den > 0.0f ? minf(maxf((minf_u(SPATIAL_M_CAP, gn.M) / M_sum_GI) * (m_num / m_den), 0.0f), 1.0f) : 0.0f;
+        float j_gi = jacobian(&sn, &sc, gn.x2, gn.n2);
+        v3 f_gi = get_p_hat_gi(c, mid, flags, sc.x1, sc.n1, gn.x2, gn.L2, sc.o, 1, cnt);
+        float w_s = mi_s * length3(f_gi) * gn.W * j_gi;
+        if (j_gi != 0.0f) {
+            gcur.w_sum += w_s; gcur.M = (gcur.M + (uint32_t)minf_u(SPATIAL_M_CAP, gn.M)) & 0xFFFFu;
+            if (rnd(seed) < w_s / gcur.w_sum) { gcur.x2 = gn.x2; gcur.n2 = gn.n2; gcur.L2 = gn.L2; }
+        }
+    }
+    float p_hat = get_p_hat(c, mid, flags, sc.x1, sc.n1, rcur.x2, rcur.n2, rcur.L2, sc.o, 1, cnt);                 /* pass3:336-347 */
+    rcur.W = get_w(rcur.w_sum, p_hat);
+    v3 acc = scale3(reconnect_di(c, mid, flags, sc.x1, sc.n1, rcur.x2, rcur.n2, rcur.L2, sc.o), rcur.W);
+    v3 f_fin = get_p_hat_gi(c, mid, flags, sc.x1, sc.n1, gcur.x2, gcur.L2, sc.o, 0, cnt);                          /* :361-372 */
+    gcur.W = get_w(gcur.w_sum, length3(f_fin));
+    acc = add3(acc, scale3(f_fin, gcur.W));
+    store_res(B->last_di + slot * 40, &rcur); store_res(B->last_gi + slot * 40, &gcur);                             /* :434-436 */
+    memcpy(B->last_sd + slot * 60, B->cur_sd + slot * 60, 60);
+    *out = acc;
+    return 1;
+}
+
+/* one ReSTIR frame = pass 1 (one sample, id 1) + pass 2 + pass 3; `last_*` carry the state to the next frame */
+int orc_restir_frame(orc_ctx* c, const orc_params* p, float* accum, void* cur_di, void* cur_gi, void* cur_sd, void* last_di, void* last_gi, void* last_sd, uint64_t ray_counts[3]) {
+    restir_bufs B = {(uint8_t*)cur_di, (uint8_t*)cur_gi, (uint8_t*)cur_sd, (uint8_t*)last_di, (uint8_t*)last_gi, (uint8_t*)last_sd};
+    orc_params p1 = *p; p1.spp = 1; p1.sample_base = 1;
+    float* scratch = (float*)calloc((size_t)p->width * p->height * 4, sizeof(float));
+    uint64_t cnt1[3];
+    orc_render_v6_pass1(c, &p1, scratch, cur_di, cur_gi, cur_sd, cnt1);
+    free(scratch);
+    uint64_t c0 = cnt1[0], c1 = cnt1[1], c2 = cnt1[2];
+    int nth = c->nthreads;
+#ifdef _OPENMP
+    if (nth <= 0) nth = omp_get_max_threads();
+#else
+    nth = 1;
+#endif
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nth) reduction(+ : c2)
+    for (int64_t y = 0; y < (int64_t)p->height; y++) {
+        uint64_t cnt[3] = {0, 0, 0};
+        for (uint32_t x = 0; x < p->width; x++) if (owns_pixel(p, x, (uint32_t)y)) restir_pass2_pixel(c, p, &B, x, (uint32_t)y, cnt);
+        c2 += cnt[2];
+    }
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nth) reduction(+ : c2)
+    for (int64_t y = 0; y < (int64_t)p->height; y++) {
+        uint64_t cnt[3] = {0, 0, 0};
+        for (uint32_t x = 0; x < p->width; x++) {
+            if (!owns_pixel(p, x, (uint32_t)y)) continue;
+            v3 out;
+            if (restir_pass3_pixel(c, p, &B, x, (uint32_t)y, &out, cnt)) {
+                float* a = accum + ((size_t)y * p->width + x) * 4;
+                if (finite3(out)) { a[0] += out.x; a[1] += out.y; a[2] += out.z; a[3] += 1.0f; }    /* pass3:388-405 */
+            }
+        }
+        c2 += cnt[2];
     }
     if (ray_counts) { ray_counts[0] = c0; ray_counts[1] = c1; ray_counts[2] = c2; }
     return 0;

@@ -64,6 +64,12 @@ void orc_srgb8(const float* accum_rgba, uint32_t npix, uint8_t* out_rgba8);
    nee_samples_DI and nee_samples, max_bounces plays `bounces` (reference: 4, 4, 3).  Buffers use MapPixelID order and
    hold orc_pass1_slots(w,h) records of 40 / 40 / 60 bytes (Reservoir_DI, Reservoir_GI, SampleData). */
 int  orc_render_v6_pass1(orc_ctx*, const orc_params*, float* accum_rgba, void* res_di40, void* res_gi40, void* sample60, uint64_t ray_counts[3]);
+/* one full ReSTIR frame of the reference: pass 1 + temporal reuse (RayGen_v6_pass2.hlsl:46-204) + spatial reuse and final
+   shade (RayGen_v6_pass3.hlsl:46-441).  cur_* / last_* are the u2..u7 buffers (40/40/60-byte records, orc_pass1_slots
+   of them, MapPixelID order); last_* carry the state between frames (zero them for the first frame).  orc_set_camera
+   keeps the previous view / projection like UpdateCameraBuffer does. */
+int  orc_restir_frame(orc_ctx*, const orc_params*, float* accum_rgba, void* cur_di, void* cur_gi, void* cur_sd,
+                      void* last_di, void* last_gi, void* last_sd, uint64_t ray_counts[3]);
 uint32_t orc_map_pixel_id(uint32_t width, uint32_t x, uint32_t y);
 size_t orc_pass1_slots(uint32_t width, uint32_t height);
 

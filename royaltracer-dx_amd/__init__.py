@@ -99,6 +99,9 @@ _sig("rtx_clear_accum", C.c_int, _vp, _u32, _u32)
 _sig("rtx_render", C.c_int, _vp, C.POINTER(Params))
 _sig("rtx_read_accum", C.c_int, _vp, _vp, C.c_size_t)
 _sig("rtx_render_v6_pass1", C.c_int, _vp, C.POINTER(Params))
+_sig("rtx_render_restir", C.c_int, _vp, C.POINTER(Params))
+_sig("rtx_restir_reset", C.c_int, _vp)
+_sig("rtx_read_restir_last", C.c_int, _vp, _vp, _vp, _vp, C.c_size_t)
 _sig("rtx_pass1_slots", C.c_size_t, _u32, _u32)
 _sig("rtx_read_pass1_buffers", C.c_int, _vp, _vp, _vp, _vp, C.c_size_t)
 _sig("rtx_read_srgb8", C.c_int, _vp, _vp, C.c_size_t)
@@ -358,6 +361,20 @@ class Context:
         """the reference's own pass 1 (RIS direct light + SamplePathSimple); see rtx_render_v6_pass1"""
         self.width, self.height = params.width, params.height
         self._ck(lib.rtx_render_v6_pass1(self._h, C.byref(params)), "rtx_render_v6_pass1")
+
+    def render_restir(self, params):
+        """`params.spp` consecutive ReSTIR frames (pass 1 + temporal + spatial) with the current camera"""
+        self.width, self.height = params.width, params.height
+        self._ck(lib.rtx_render_restir(self._h, C.byref(params)), "rtx_render_restir")
+
+    def restir_reset(self):
+        self._ck(lib.rtx_restir_reset(self._h), "rtx_restir_reset")
+
+    def read_restir_last(self):
+        n = lib.rtx_pass1_slots(self.width, self.height)
+        di, gi, sd = np.zeros((n, 40), np.uint8), np.zeros((n, 40), np.uint8), np.zeros((n, 60), np.uint8)
+        self._ck(lib.rtx_read_restir_last(self._h, _ptr(di), _ptr(gi), _ptr(sd), n), "rtx_read_restir_last")
+        return di, gi, sd
 
     def read_pass1_buffers(self):
         n = lib.rtx_pass1_slots(self.width, self.height)

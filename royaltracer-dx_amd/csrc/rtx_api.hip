@@ -44,7 +44,8 @@ struct rtx_ctx {
     uint32_t* h_counters = nullptr; size_t h_counters_words = 0;
     // accumulation
     DevBuf d_accum; void* ext_accum = nullptr; size_t ext_accum_bytes = 0; uint32_t acc_w = 0, acc_h = 0;
-    DevBuf d_srgb, d_res_di, d_res_gi, d_sdata, d_p1cnt; size_t p1_slots = 0;
+    DevBuf d_srgb, d_res_di, d_res_gi, d_sdata, d_last_di, d_last_gi, d_last_sd, d_p1cnt; size_t p1_slots = 0, last_slots = 0;
+    float prev_view[16], prev_proj[16];
     // options
     bool timing = false; uint64_t paths_per_batch = 64u << 20; int sort_mats = 0; int lds_nodes_opt = -1; bool small_scene = true; bool fused = true; int stack_private = -1;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
@@ -100,7 +101,7 @@ void rtx_destroy(rtx_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
                      &c->d_thr, &c->d_rad, &c->d_hit, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
-                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_p1cnt};
+                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt};
     for (DevBuf* b : all) b->release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
@@ -180,7 +181,7 @@ int rtx_commit_scene(rtx_ctx* c) {
     s.shade = (const TriShade*)c->d_shade.p;
     s.small = (const SmallRecPair*)c->d_small.p; s.small_tris = (const TriGPU*)c->d_small_tris.p; s.small_cm = B.small_cm; s.small_delta = B.small_delta;
     s.mats = (const MatGPU*)c->d_mats.p; s.nmat = (uint32_t)B.mats.size();
-    s.insts = (const InstGPU*)c->d_insts.p;
+    s.insts = (const InstGPU*)c->d_insts.p; s.ninst = (uint32_t)B.insts.size();
     s.lights = (const LightGPU*)c->d_lights.p; s.nlights = (uint32_t)B.lights.size();
     s.total_weight = B.total_weight;
     // LDS budget per workgroup: stack + top of tree + first triangles, kept <= 64 KiB
@@ -214,9 +215,13 @@ int rtx_commit_scene(rtx_ctx* c) {
 int rtx_set_camera(rtx_ctx* c, const float view[16], const float proj[16]) {
     BIND(c);
     if (!view || !proj) return RTX_ERR_INVALID;
+    // previous-frame matrices for the temporal pass (m_prevViewMatrix / m_prevProjMatrix, Renderer.cpp:1738-1740, 1766-1767)
+    if (c->camera_set) { memcpy(c->prev_view, c->view, 64); memcpy(c->prev_proj, c->proj, 64); }
+    else { memcpy(c->prev_view, view, 64); memcpy(c->prev_proj, proj, 64); }
     memcpy(c->view, view, 64); memcpy(c->proj, proj, 64);
     CameraGPU cam;
     mat4_inverse(view, cam.viewI); mat4_inverse(proj, cam.projI);     // Renderer.cpp:1735-1736
+    memcpy(cam.prev_view, c->prev_view, 64); memcpy(cam.prev_proj, c->prev_proj, 64);
     HIPCHK(c, c->d_cam.ensure(sizeof(cam)));
     HIPCHK(c, hipMemcpyAsync(c->d_cam.p, &cam, sizeof(cam), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -394,6 +399,7 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
 }
 
 size_t rtx_pass1_slots(uint32_t w, uint32_t h) { return (size_t)((w + 3) / 4) * ((h + 3) / 4) * 16; }
+static int p1_alloc(rtx_ctx* c, size_t slots);
 
 int rtx_render_v6_pass1(rtx_ctx* c, const rtx_params* p) {
     BIND(c);
@@ -405,13 +411,7 @@ int rtx_render_v6_pass1(rtx_ctx* c, const rtx_params* p) {
     if (p->max_bounces > 64 || p->nee_samples > 16) { c->err = "params: max_bounces <= 64, nee_samples <= 16"; return RTX_ERR_INVALID; }
     if ((r = ensure_accum(c, p->width, p->height, false))) return r;
     const size_t slots = rtx_pass1_slots(p->width, p->height);
-    HIPCHK(c, c->d_res_di.ensure(slots * 40)); HIPCHK(c, c->d_res_gi.ensure(slots * 40)); HIPCHK(c, c->d_sdata.ensure(slots * 60));
-    HIPCHK(c, c->d_p1cnt.ensure(24));
-    if (c->p1_slots != slots) {
-        HIPCHK(c, hipMemsetAsync(c->d_res_di.p, 0, slots * 40, c->stream)); HIPCHK(c, hipMemsetAsync(c->d_res_gi.p, 0, slots * 40, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_sdata.p, 0, slots * 60, c->stream));
-        c->p1_slots = slots;
-    }
+    if ((r = p1_alloc(c, slots))) return r;
     HIPCHK(c, hipMemsetAsync(c->d_p1cnt.p, 0, 24, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_begin, c->stream));
     for (uint32_t s = 0; s < p->spp; s++)
@@ -426,6 +426,78 @@ int rtx_render_v6_pass1(rtx_ctx* c, const rtx_params* p) {
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) c->stats.render_ms = ms;
     c->stats.rays_primary = cnt[0]; c->stats.rays_extension = cnt[1]; c->stats.rays_shadow = cnt[2]; c->stats.paths = cnt[0]; c->stats.primary_hits = 0;
+    return RTX_OK;
+}
+
+static int p1_alloc(rtx_ctx* c, size_t slots) {
+    HIPCHK(c, c->d_res_di.ensure(slots * 40)); HIPCHK(c, c->d_res_gi.ensure(slots * 40)); HIPCHK(c, c->d_sdata.ensure(slots * 60));
+    HIPCHK(c, c->d_p1cnt.ensure(24));
+    if (c->p1_slots != slots) {
+        HIPCHK(c, hipMemsetAsync(c->d_res_di.p, 0, slots * 40, c->stream)); HIPCHK(c, hipMemsetAsync(c->d_res_gi.p, 0, slots * 40, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_sdata.p, 0, slots * 60, c->stream));
+        c->p1_slots = slots;
+    }
+    return RTX_OK;
+}
+
+int rtx_restir_reset(rtx_ctx* c) {
+    BIND(c);
+    c->last_slots = 0;           // the next frame starts from zeroed g_*_last buffers
+    return RTX_OK;
+}
+
+int rtx_render_restir(rtx_ctx* c, const rtx_params* p) {
+    BIND(c);
+    if (!c->committed) { c->err = "render: scene not committed"; return RTX_ERR_STATE; }
+    if (!c->camera_set) { c->err = "render: camera not set"; return RTX_ERR_STATE; }
+    DevFrame f;
+    int r = make_frame(c, p, f);
+    if (r) return r;
+    if (p->max_bounces > 64 || p->nee_samples > 16) { c->err = "params: max_bounces <= 64, nee_samples <= 16"; return RTX_ERR_INVALID; }
+    if (p->shard_count > 1) { c->err = "render_restir: the spatial pass reads neighbouring pixels; shard_count must be 1"; return RTX_ERR_INVALID; }
+    if ((r = ensure_accum(c, p->width, p->height, false))) return r;
+    const size_t slots = rtx_pass1_slots(p->width, p->height);
+    if ((r = p1_alloc(c, slots))) return r;
+    HIPCHK(c, c->d_last_di.ensure(slots * 40)); HIPCHK(c, c->d_last_gi.ensure(slots * 40)); HIPCHK(c, c->d_last_sd.ensure(slots * 60));
+    if (c->last_slots != slots) {
+        HIPCHK(c, hipMemsetAsync(c->d_last_di.p, 0, slots * 40, c->stream)); HIPCHK(c, hipMemsetAsync(c->d_last_gi.p, 0, slots * 40, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_last_sd.p, 0, slots * 60, c->stream));
+        c->last_slots = slots;
+    }
+    // pass 1 writes its debug estimate into a scratch image (the displayed image is pass 3's)
+    DevBuf scratch; HIPCHK(c, scratch.ensure((size_t)p->width * p->height * 16));
+    HIPCHK(c, hipMemsetAsync(c->d_p1cnt.p, 0, 24, c->stream));
+    uint32_t* bufs[6] = {(uint32_t*)c->d_res_di.p, (uint32_t*)c->d_res_gi.p, (uint32_t*)c->d_sdata.p, (uint32_t*)c->d_last_di.p, (uint32_t*)c->d_last_gi.p, (uint32_t*)c->d_last_sd.p};
+    const uint32_t mbk = (uint32_t)c->num_cus * 8u;
+    const CameraGPU* cam = (const CameraGPU*)c->d_cam.p;
+    HIPCHK(c, hipEventRecord(c->ev_begin, c->stream));
+    for (uint32_t fr = 0; fr < p->spp; fr++) {                       // spp = number of consecutive frames with this camera
+        DevFrame ff = f; ff.frame_seed = p->frame_seed + fr;
+        HIPCHK(c, hipMemsetAsync(scratch.p, 0, (size_t)p->width * p->height * 16, c->stream));
+        launch_v6_pass1(c->stream, mbk, c->dsc, ff, cam, 1u, (F4*)scratch.p, bufs[0], bufs[1], bufs[2], (unsigned long long*)c->d_p1cnt.p);   // Renderer.cpp:651-654
+        launch_restir_pass2(c->stream, mbk, c->dsc, ff, cam, bufs, (unsigned long long*)c->d_p1cnt.p);                                       // :662-664
+        launch_restir_pass3(c->stream, mbk, c->dsc, ff, cam, bufs, c->accum_ptr(), (unsigned long long*)c->d_p1cnt.p);                       // :671-673
+    }
+    HIPCHK(c, hipEventRecord(c->ev_end, c->stream));
+    HIPCHK(c, hipGetLastError());
+    unsigned long long cnt[3] = {0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(cnt, c->d_p1cnt.p, 24, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    scratch.release();
+    memset(c->stats.kernel_ms, 0, sizeof(c->stats.kernel_ms)); memset(c->stats.kernel_launches, 0, sizeof(c->stats.kernel_launches)); memset(c->stats.kernel_items, 0, sizeof(c->stats.kernel_items));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) c->stats.render_ms = ms;
+    c->stats.rays_primary = cnt[0]; c->stats.rays_extension = cnt[1]; c->stats.rays_shadow = cnt[2]; c->stats.paths = cnt[0]; c->stats.primary_hits = 0;
+    return RTX_OK;
+}
+
+int rtx_read_restir_last(rtx_ctx* c, void* di, void* gi, void* sd, size_t slots) {
+    BIND(c);
+    if (!c->last_slots || slots < c->last_slots) { c->err = "read_restir_last: no ReSTIR state or too few slots"; return RTX_ERR_INVALID; }
+    if (di) HIPCHK(c, hipMemcpyAsync(di, c->d_last_di.p, c->last_slots * 40, hipMemcpyDeviceToHost, c->stream));
+    if (gi) HIPCHK(c, hipMemcpyAsync(gi, c->d_last_gi.p, c->last_slots * 40, hipMemcpyDeviceToHost, c->stream));
+    if (sd) HIPCHK(c, hipMemcpyAsync(sd, c->d_last_sd.p, c->last_slots * 60, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return RTX_OK;
 }
 

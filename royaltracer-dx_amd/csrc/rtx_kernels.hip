@@ -76,7 +76,7 @@ __device__ __forceinline__ void primary_ray(const CameraGPU& cam, uint32_t W, ui
 __global__ __launch_bounds__(kBlock) void k_raygen(DevFrame f, DevPaths p, const CameraGPU* __restrict__ cam_p, uint32_t* __restrict__ queue, uint32_t* __restrict__ qcount) {
     __shared__ CameraGPU cam;
     __shared__ uint32_t s_n;
-    if (threadIdx.x < 32) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
+    if (threadIdx.x < 64) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     uint32_t* myq = queue + (size_t)blockIdx.x * f.qcap;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen_trace_small(DevScene sc, cons
     extern __shared__ F4 lds[];
     __shared__ CameraGPU cam;
     __shared__ uint32_t s_n[2];
-    if (threadIdx.x < 32) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
+    if (threadIdx.x < 64) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
     if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
     const TraceLds L = stage_lds(sc, lds);
     __syncthreads();
@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(kBlock) void k_v6_pass1(DevScene sc, const SmallRec
                                                      unsigned long long* __restrict__ counters /* primary, extension, shadow */) {
     extern __shared__ F4 lds[];
     __shared__ CameraGPU cam;
-    if (threadIdx.x < 32) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
+    if (threadIdx.x < 64) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
     const TraceLds L = stage_lds(sc, lds);
     __syncthreads();
     uint32_t n_prim = 0, n_ext = 0, n_sh = 0;
@@ -1061,6 +1061,267 @@ __global__ __launch_bounds__(kBlock) void k_v6_pass1(DevScene sc, const SmallRec
         if (finite3(out)) { F4 a = accum[(size_t)y * f.width + x]; a.x = a.x + out.x; a.y = a.y + out.y; a.z = a.z + out.z; a.w = a.w + 1.0f; accum[(size_t)y * f.width + x] = a; }
     }
     atomicAdd(&counters[0], (unsigned long long)n_prim); atomicAdd(&counters[1], (unsigned long long)n_ext); atomicAdd(&counters[2], (unsigned long long)n_sh);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ReSTIR temporal reuse (pass 2, RayGen_v6_pass2.hlsl:46-204) and spatial reuse + final shade (pass 3,
+// RayGen_v6_pass3.hlsl:46-441) with the pairwise MIS of MIS_v6.hlsl / MIS_GI_v6.hlsl, on the reference's packed
+// buffers; one thread per pixel like the reference's raygen shaders.  Statement order = oracle/rt_oracle.c.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float half_to_float_dev(uint32_t h) {
+    const uint32_t sign = (h & 0x8000u) << 16, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+    if (e == 0) { const float f = (float)m * (1.0f / 16777216.0f); return u2f(f2u(f) | sign); }
+    if (e == 31) return u2f(sign | 0x7F800000u | (m << 13));
+    return u2f(sign | ((e + 112u) << 23) | (m << 13));
+}
+struct SData { f3 x1; uint32_t mID; f3 L1; f3 n1; f3 o; uint32_t objID; };
+__device__ __forceinline__ Res load_res_dev(const uint32_t* p) {
+    Res r;
+    r.x2 = mk3(u2f(p[0]), u2f(p[1]), u2f(p[2])); r.w_sum = u2f(p[3]); r.n2 = mk3(u2f(p[4]), u2f(p[5]), u2f(p[6])); r.W = u2f(p[7]);
+    r.L2 = mk3(half_to_float_dev(p[8] & 0xFFFFu), half_to_float_dev(p[8] >> 16), half_to_float_dev(p[9] & 0xFFFFu)); r.M = p[9] >> 16;
+    return r;
+}
+__device__ __forceinline__ Res zero_res() { Res r; r.x2 = mk3(0, 0, 0); r.w_sum = 0.0f; r.n2 = mk3(0, 0, 0); r.W = 0.0f; r.L2 = mk3(0, 0, 0); r.M = 0; return r; }
+__device__ __forceinline__ SData load_sd_dev(const uint32_t* d) {
+    SData s;
+    s.x1 = mk3(u2f(d[0]), u2f(d[1]), u2f(d[2])); s.mID = d[3] & 0xFFFFu;
+    s.L1 = mk3(half_to_float_dev(d[3] >> 16), half_to_float_dev(d[4] & 0xFFFFu), half_to_float_dev(d[4] >> 16));
+    s.n1 = mk3(u2f(d[5]), u2f(d[6]), u2f(d[7])); s.o = mk3(u2f(d[8]), u2f(d[9]), u2f(d[10])); s.objID = d[11];
+    return s;
+}
+__device__ __forceinline__ SData zero_sd() { SData s; s.x1 = mk3(0, 0, 0); s.mID = 0; s.L1 = mk3(0, 0, 0); s.n1 = mk3(0, 0, 0); s.o = mk3(0, 0, 0); s.objID = 0; return s; }
+__device__ __forceinline__ float minf_u(float cap, uint32_t m) { return (float)(m < (uint32_t)cap ? m : (uint32_t)cap); }
+
+__device__ __forceinline__ float get_p_hat_dev(P1Ctx& C, const MatGPU& m, f3 x1, f3 n1, f3 x2, f3 n2, f3 L2, f3 o, bool vis) {
+    const float f_g = length(reconnect_di_dev(m, C.flags, x1, n1, x2, n2, L2, o));
+    float v = 1.0f;
+    if (vis) { const f3 dv = x2 - x1; v = p1_any(C, x1 + normalize(n1) * kSBias, normalize(dv), 0.0f, maxf_(length(dv) - 10.0f * kSBias, 2.0f * kSBias)) ? 0.0f : 1.0f; }
+    return f_g * v;
+}
+__device__ __forceinline__ f3 get_p_hat_gi_dev(P1Ctx& C, const MatGPU& m, f3 x1, f3 n1, f3 x2, f3 L, f3 o, bool vis) {
+    const f3 dir = x2 - x1;
+    const float cos1 = fabsf(dot(n1, normalize(dir)));
+    f3 f0, f1; float q0, q1, pd, ps;
+    lobes_dev(m, C.flags, n1, normalize(dir), normalize(o), normalize(o), f0, f1, q0, q1, pd, ps);
+    const f3 Fx = safe_mul(pd, f0) + safe_mul(ps, f1);
+    f3 fr = mk3(Fx.x * cos1 * L.x, Fx.y * cos1 * L.y, Fx.z * cos1 * L.z);
+    if (!finite3(fr)) fr = mk3(0, 0, 0);
+    float v = 1.0f;
+    if (vis) v = p1_any(C, x1 + normalize(n1) * kSBias, normalize(dir), 0.0f, maxf_(length(dir) - 10.0f * kSBias, 2.0f * kSBias)) ? 0.0f : 1.0f;
+    return fr * v;
+}
+__device__ __forceinline__ float get_w_dev(float w_sum, float p_hat) { return p_hat > kEps ? w_sum / p_hat : 0.0f; }
+__device__ __forceinline__ float jacobian_dev(const SData& r, const SData& q, f3 x2q, f3 n2q) {
+    const f3 vq = x2q - q.x1, vr = x2q - r.x1;
+    const float cq = fabsf(dot(normalize(-vq), normalize(n2q))), cr = fabsf(dot(normalize(-vr), normalize(n2q)));
+    return (cq / cr) * (dot(vr, vr) / dot(vq, vq));
+}
+__device__ __forceinline__ bool valid_res_dev(const Res& r) { return length(r.n2) > 0.0f && length(r.L2) > 0.0f && r.w_sum > 0.0f && r.M > 0; }
+__device__ __forceinline__ bool valid_res_gi_dev(const Res& r) { return r.w_sum > 0.0f && r.M > 0; }
+__device__ __forceinline__ bool reject_distance_dev(f3 x1, f3 x2, f3 cam, float thr) {
+    const float d1 = length(x1 - cam), d2 = length(x2 - cam);
+    return fabsf(d1 - d2) / maxf_(d1, d2) > thr;
+}
+__device__ __forceinline__ bool reject_jacobian_dev(float J, float thr) { return J > thr || J < 1.0f / thr || is_nan(J) || is_inf(J); }
+__device__ __forceinline__ f3 mul44_dev(const float* m, f3 p, float w, float& ow) {
+    ow = m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15] * w;
+    return mk3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12] * w, m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13] * w, m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14] * w);
+}
+__device__ __forceinline__ void random_pixel_dev(uint32_t radius, uint32_t w, uint32_t h, uint32_t x, uint32_t y, uint32_t& s0, uint32_t& s1, int& ox, int& oy) {
+    int nx, ny;
+    do {
+        const float u = tea_next(s0, s1);
+        const float r = (float)radius * u;
+        const float ang = tea_next(s0, s1) * 6.2831853f;
+        float sn, cs; sincos_(ang, sn, cs);
+        nx = (int)x + (int)(cs * r); ny = (int)y + (int)(sn * r);
+        while (nx < 0 || nx >= (int)w) { if (nx < 0) nx = -nx; else nx = 2 * (int)w - nx - 2; }
+        while (ny < 0 || ny >= (int)h) { if (ny < 0) ny = -ny; else ny = 2 * (int)h - ny - 2; }
+    } while (nx == (int)x && ny == (int)y);
+    ox = nx; oy = ny;
+}
+
+struct RestirBufs { uint32_t *cur_di, *cur_gi, *cur_sd, *last_di, *last_gi, *last_sd; };
+
+__global__ __launch_bounds__(kBlock) void k_restir_pass2(DevScene sc, const SmallRecPair* __restrict__ small, DevFrame f, const CameraGPU* __restrict__ cam_p, RestirBufs B,
+                                                         unsigned long long* __restrict__ counters) {
+    extern __shared__ F4 lds[];
+    __shared__ CameraGPU cam;
+    if (threadIdx.x < 64) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
+    const TraceLds L = stage_lds(sc, lds);
+    __syncthreads();
+    uint32_t n_sh = 0;
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < f.npl; pl += stride) {
+        uint32_t x, y;
+        if (!slot_to_pixel(f, pl, x, y)) continue;
+        const size_t slot = map_pixel_id(f.width, x, y);
+        Res rc = load_res_dev(B.cur_di + slot * 10), gc = load_res_dev(B.cur_gi + slot * 10);
+        const SData sd = load_sd_dev(B.cur_sd + slot * 15);
+        if (!(sd.L1.x == 0.0f && sd.L1.y == 0.0f && sd.L1.z == 0.0f) || sd.mID == 0xFFFEu || sd.mID >= sc.nmat) continue;
+        P1Ctx C; C.sc = &sc; C.small = small; C.L = &L; C.flags = f.flags; C.cnt_ext = 0; C.cnt_sh = 0;
+        const f3 camo = mk3(cam.viewI[12], cam.viewI[13], cam.viewI[14]);
+        uint32_t s0, s1; seed_init(x, y, 2u, f.frame_seed, s0, s1);
+        int px, py;
+        {   // GetBestReprojectedPixel_d, Sampler_v6.hlsl:738-785
+            float w0, w1, w2, w3;
+            const InstGPU& in = sc.insts[sd.objID < sc.ninst ? sd.objID : 0u];
+            const f3 lp = mul44_dev(in.o2w_inv, sd.x1, 1.0f, w0);
+            const f3 pw = mul44_dev(in.prev_o2w, lp, w0, w1);
+            const f3 vp = mul44_dev(cam.prev_view, pw, w1, w2);
+            const f3 cp = mul44_dev(cam.prev_proj, vp, w2, w3);
+            if (w3 <= 0.0f) { px = -1; py = -1; }
+            else { const float ux = (cp.x / w3) * 0.5f + 0.5f; float uy = (cp.y / w3) * 0.5f + 0.5f; uy = 1.0f - uy; px = (int)rintf(ux * (float)f.width); py = (int)rintf(uy * (float)f.height); }
+        }
+        const bool inside = px >= 0 && py >= 0 && px < (int)f.width && py < (int)f.height;
+        const size_t ts = inside ? map_pixel_id(f.width, (uint32_t)px, (uint32_t)py) : 0;
+        const Res rl = inside ? load_res_dev(B.last_di + ts * 10) : zero_res(), gl = inside ? load_res_dev(B.last_gi + ts * 10) : zero_res();
+        const SData sl = inside ? load_sd_dev(B.last_sd + ts * 15) : zero_sd();
+        const bool base_ok = (px != -1 && py != -1) && length(sl.L1) == 0.0f && !reject_distance_dev(sd.x1, sl.x1, camo, 0.1f) && sl.mID == sd.mID;
+        const bool acc_di = base_ok && valid_res_dev(rl) && (rl.x2.x != 0.0f && rl.x2.y != 0.0f && rl.x2.z != 0.0f);
+        const bool acc_gi = base_ok && !(gl.w_sum > 5.0f) && valid_res_gi_dev(gl);
+        const MatGPU& m = sc.mats[sd.mID];
+        if (acc_di) {
+            const float mc = minf_u(16.0f, rc.M), ml = minf_u(16.0f, rl.M), M_sum = mc + ml;
+            float mi_c = mc / M_sum;
+            { const float m_num = mc, m_den = m_num + (M_sum - mc); if (m_den > 0.0f) mi_c += (ml / M_sum) * (m_num / m_den); }
+            float mi_t;
+            { const float m_num = M_sum - mc, m_den = m_num + mc; mi_t = m_den > 0.0f ? (ml / M_sum) * m_num / m_den : 0.0f; }
+            if (length(rl.n2) == 0.0f) { mi_c = 1.0f; mi_t = 0.0f; }
+            const float w_c = mi_c * get_p_hat_dev(C, m, sd.x1, sd.n1, rc.x2, rc.n2, rc.L2, sd.o, false) * rc.W;
+            const float w_t = mi_t * get_p_hat_dev(C, m, sd.x1, sd.n1, rl.x2, rl.n2, rl.L2, sd.o, true) * rl.W;
+            rc.M = (uint32_t)mc; rc.w_sum = w_c;
+            rc.w_sum += w_t; rc.M = (rc.M + (uint32_t)ml) & 0xFFFFu;
+            if (tea_next(s0, s1) < w_t / rc.w_sum) { rc.x2 = rl.x2; rc.n2 = rl.n2; rc.L2 = rl.L2; }
+            const float p_hat = get_p_hat_dev(C, m, sd.x1, sd.n1, rc.x2, rc.n2, rc.L2, sd.o, false);
+            rc.W = get_w_dev(rc.w_sum, p_hat);
+        }
+        if (acc_gi) {
+            const float mc = minf_u(16.0f, gc.M), ml = minf_u(16.0f, gl.M), M_sum = mc + ml;
+            float mi_c = mc / M_sum;
+            { const float m_num = mc, m_den = m_num + (M_sum - mc); if (m_den > 0.0f) mi_c += (ml / M_sum) * (m_num / m_den); }
+            float mi_t;
+            { const float m_num = M_sum - mc, m_den = m_num + mc; mi_t = m_den > 0.0f ? (ml / M_sum) * m_num / m_den : 0.0f; }
+            const float w_c = mi_c * length(get_p_hat_gi_dev(C, m, sd.x1, sd.n1, gc.x2, gc.L2, sd.o, false)) * gc.W;
+            const float w_t = mi_t * length(get_p_hat_gi_dev(C, m, sd.x1, sd.n1, gl.x2, gl.L2, sd.o, true)) * gl.W;
+            gc.M = (uint32_t)mc; gc.w_sum = w_c;
+            gc.w_sum += w_t; gc.M = (gc.M + (uint32_t)ml) & 0xFFFFu;
+            if (tea_next(s0, s1) < w_t / gc.w_sum) { gc.x2 = gl.x2; gc.n2 = gl.n2; gc.L2 = gl.L2; }
+            gc.W = get_w_dev(gc.w_sum, length(get_p_hat_gi_dev(C, m, sd.x1, sd.n1, gc.x2, gc.L2, sd.o, false)));
+        }
+        store_res(B.cur_di + slot * 10, rc); store_res(B.cur_gi + slot * 10, gc);
+        n_sh += C.cnt_sh;
+    }
+    atomicAdd(&counters[2], (unsigned long long)n_sh);
+}
+
+__global__ __launch_bounds__(kBlock) void k_restir_pass3(DevScene sc, const SmallRecPair* __restrict__ small, DevFrame f, const CameraGPU* __restrict__ cam_p, RestirBufs B,
+                                                         F4* __restrict__ accum, unsigned long long* __restrict__ counters) {
+    extern __shared__ F4 lds[];
+    __shared__ CameraGPU cam;
+    if (threadIdx.x < 64) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
+    const TraceLds L = stage_lds(sc, lds);
+    __syncthreads();
+    uint32_t n_sh = 0;
+    const uint32_t stride = gridDim.x * kBlock;
+    const uint32_t W = f.width, H = f.height;
+    for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < f.npl; pl += stride) {
+        uint32_t x, y;
+        if (!slot_to_pixel(f, pl, x, y)) continue;
+        const size_t slot = map_pixel_id(W, x, y);
+        const SData sd = load_sd_dev(B.cur_sd + slot * 15);
+        f3 out = mk3(0, 0, 0);
+        if (!(sd.L1.x == 0.0f && sd.L1.y == 0.0f && sd.L1.z == 0.0f)) out = sd.L1;                      // pass3:457-462
+        else if (!(sd.mID == 0xFFFEu || sd.mID >= sc.nmat)) {
+            P1Ctx C; C.sc = &sc; C.small = small; C.L = &L; C.flags = f.flags; C.cnt_ext = 0; C.cnt_sh = 0;
+            const f3 camo = mk3(cam.viewI[12], cam.viewI[13], cam.viewI[14]);
+            uint32_t s0, s1; seed_init(x, y, 3u, f.frame_seed, s0, s1);
+            const MatGPU& m = sc.mats[sd.mID];
+            Res rcur = load_res_dev(B.cur_di + slot * 10), gcur = load_res_dev(B.cur_gi + slot * 10);
+            size_t cand_di[3], cand_gi[3]; int n_di = 0, n_gi = 0;
+            float M_sum_DI = minf_u(128.0f, rcur.M), M_sum_GI = minf_u(128.0f, gcur.M);
+            for (int a = 0; a < 9 && n_di < 3; a++) {
+                int nx, ny; random_pixel_dev(20u, W, H, x, y, s0, s1, nx, ny);
+                const size_t pr = map_pixel_id(W, (uint32_t)nx, (uint32_t)ny);
+                const SData sn = load_sd_dev(B.cur_sd + pr * 15); const Res rn = load_res_dev(B.cur_di + pr * 10);
+                const bool ok = !(dot(sd.n1, sn.n1) < 0.9f) && !reject_distance_dev(sd.x1, sn.x1, camo, 0.1f) && valid_res_dev(rn) && length(sn.L1) == 0.0f && sn.mID == sd.mID;
+                if (ok) { cand_di[n_di++] = pr; M_sum_DI += minf_u(128.0f, rn.M); }
+            }
+            for (int a = 0; a < 9 && n_gi < 3; a++) {
+                int nx, ny; random_pixel_dev(20u, W, H, x, y, s0, s1, nx, ny);
+                const size_t pr = map_pixel_id(W, (uint32_t)nx, (uint32_t)ny);
+                const SData sn = load_sd_dev(B.cur_sd + pr * 15); const Res gn = load_res_dev(B.cur_gi + pr * 10);
+                const bool ok = m.Pr > 0.3f && !reject_distance_dev(sd.x1, sn.x1, camo, 0.1f) && !(dot(normalize(gn.x2 - sd.x1), sd.n1) < 0.0f) &&
+                                !(gn.w_sum > 5.0f) && valid_res_gi_dev(gn) && !reject_jacobian_dev(jacobian_dev(sn, sd, gn.x2, gn.n2), 5.0f) &&
+                                length(sn.L1) == 0.0f && sn.mID == sd.mID;
+                if (ok) { cand_gi[n_gi++] = pr; M_sum_GI += minf_u(128.0f, gn.M); }
+            }
+            const Res can = rcur, can_gi = gcur;
+            const float cMmin = minf_u(128.0f, can.M), cMmax = M_sum_DI - cMmin;
+            const float p_c = get_p_hat_dev(C, m, sd.x1, sd.n1, can.x2, can.n2, can.L2, sd.o, false);
+            const float c_m_num = cMmin * p_c; float mi_c = cMmin / M_sum_DI;
+            for (int j = 0; j < n_di; j++) {
+                const SData sn = load_sd_dev(B.cur_sd + cand_di[j] * 15); const Res rn = load_res_dev(B.cur_di + cand_di[j] * 10);
+                const float nM = minf_u(128.0f, rn.M);
+                const float p_from = get_p_hat_dev(C, m, sn.x1, sn.n1, can.x2, can.n2, can.L2, sn.o, true);
+                const float m_den = c_m_num + (cMmax * p_from);
+                if (m_den > 0.0f) mi_c += (nM / M_sum_DI) * (c_m_num / m_den);
+            }
+            const float w_c = mi_c * get_p_hat_dev(C, m, sd.x1, sd.n1, can.x2, can.n2, can.L2, sd.o, false) * can.W;
+            const float gMmin = minf_u(128.0f, can_gi.M), gMmax = M_sum_GI - gMmin;
+            const float pg_c = length(get_p_hat_gi_dev(C, m, sd.x1, sd.n1, can_gi.x2, can_gi.L2, sd.o, false));
+            const float g_m_num = gMmin * pg_c; float mi_c_gi = gMmin / M_sum_GI;
+            for (int j = 0; j < n_gi; j++) {
+                const SData sn = load_sd_dev(B.cur_sd + cand_gi[j] * 15); const Res gn = load_res_dev(B.cur_gi + cand_gi[j] * 10);
+                const float nM = minf_u(128.0f, gn.M);
+                const float j_gi = jacobian_dev(sd, sn, can_gi.x2, can_gi.n2);
+                const float p_from = length(get_p_hat_gi_dev(C, m, sn.x1, sn.n1, can_gi.x2, can_gi.L2, sn.o, true)) * j_gi;
+                const float m_den = g_m_num + (gMmax * p_from);
+                if (m_den > 0.0f) mi_c_gi += (nM / M_sum_GI) * (g_m_num / m_den);
+            }
+            mi_c_gi = minf_(maxf_(mi_c_gi, 0.0f), 1.0f);
+            const float w_c_gi = mi_c_gi * length(get_p_hat_gi_dev(C, m, sd.x1, sd.n1, can_gi.x2, can_gi.L2, sd.o, false)) * can_gi.W;
+            rcur.M = (uint32_t)cMmin; rcur.w_sum = w_c;
+            gcur.M = (uint32_t)gMmin; gcur.w_sum = w_c_gi;
+            for (int v = 0; v < n_di; v++) {
+                const SData sn = load_sd_dev(B.cur_sd + cand_di[v] * 15); const Res rn = load_res_dev(B.cur_di + cand_di[v] * 10);
+                const float pc2 = get_p_hat_dev(C, m, sd.x1, sd.n1, can.x2, can.n2, can.L2, sd.o, false);
+                const float p_from = get_p_hat_dev(C, m, sn.x1, sn.n1, can.x2, can.n2, can.L2, sn.o, false);
+                const float m_num = (M_sum_DI - cMmin) * p_from, m_den = m_num + (cMmin * pc2);
+                const float mi_s = m_den > 0.0f ? (minf_u(128.0f, rn.M) / M_sum_DI) * (m_num / m_den) : 0.0f;
+                const float w_s = mi_s * get_p_hat_dev(C, m, sd.x1, sd.n1, rn.x2, rn.n2, rn.L2, sd.o, false) * rn.W;
+                rcur.w_sum += w_s; rcur.M = (rcur.M + (uint32_t)minf_u(128.0f, rn.M)) & 0xFFFFu;
+                if (tea_next(s0, s1) < w_s / rcur.w_sum) { rcur.x2 = rn.x2; rcur.n2 = rn.n2; rcur.L2 = rn.L2; }
+            }
+            for (int v = 0; v < n_gi; v++) {
+                const SData sn = load_sd_dev(B.cur_sd + cand_gi[v] * 15); const Res gn = load_res_dev(B.cur_gi + cand_gi[v] * 10);
+                const float pc2 = length(get_p_hat_gi_dev(C, m, sd.x1, sd.n1, can_gi.x2, can_gi.L2, sd.o, false));
+                const float jj = jacobian_dev(sd, sn, can_gi.x2, can_gi.n2);
+                const float p_from = length(get_p_hat_gi_dev(C, m, sn.x1, sn.n1, can_gi.x2, can_gi.L2, sn.o, false)) * jj;
+                const float m_num = (M_sum_GI - gMmin) * p_from, m_den = m_num + (gMmin * pc2);
+                const float mi_s = m_den > 0.0f ? minf_(maxf_((minf_u(128.0f, gn.M) / M_sum_GI) * (m_num / m_den), 0.0f), 1.0f) : 0.0f;
+                const float j_gi = jacobian_dev(sn, sd, gn.x2, gn.n2);
+                const f3 f_gi = get_p_hat_gi_dev(C, m, sd.x1, sd.n1, gn.x2, gn.L2, sd.o, true);
+                const float w_s = mi_s * length(f_gi) * gn.W * j_gi;
+                if (j_gi != 0.0f) {
+                    gcur.w_sum += w_s; gcur.M = (gcur.M + (uint32_t)minf_u(128.0f, gn.M)) & 0xFFFFu;
+                    if (tea_next(s0, s1) < w_s / gcur.w_sum) { gcur.x2 = gn.x2; gcur.n2 = gn.n2; gcur.L2 = gn.L2; }
+                }
+            }
+            const float p_hat = get_p_hat_dev(C, m, sd.x1, sd.n1, rcur.x2, rcur.n2, rcur.L2, sd.o, true);
+            rcur.W = get_w_dev(rcur.w_sum, p_hat);
+            f3 acc = reconnect_di_dev(m, f.flags, sd.x1, sd.n1, rcur.x2, rcur.n2, rcur.L2, sd.o) * rcur.W;
+            const f3 f_fin = get_p_hat_gi_dev(C, m, sd.x1, sd.n1, gcur.x2, gcur.L2, sd.o, false);
+            gcur.W = get_w_dev(gcur.w_sum, length(f_fin));
+            acc = acc + f_fin * gcur.W;
+            store_res(B.last_di + slot * 10, rcur); store_res(B.last_gi + slot * 10, gcur);
+            for (int k = 0; k < 15; k++) B.last_sd[slot * 15 + k] = B.cur_sd[slot * 15 + k];
+            out = acc;
+            n_sh += C.cnt_sh;
+        }
+        if (finite3(out)) { F4 a = accum[(size_t)y * W + x]; a.x = a.x + out.x; a.y = a.y + out.y; a.z = a.z + out.z; a.w = a.w + 1.0f; accum[(size_t)y * W + x] = a; }
+    }
+    atomicAdd(&counters[2], (unsigned long long)n_sh);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1230,6 +1491,14 @@ void launch_shade(hipStream_t st, const DevScene& sc, const DevFrame& f, const D
 void launch_v6_pass1(hipStream_t st, uint32_t max_blocks, const DevScene& sc, const DevFrame& f, const CameraGPU* cam, uint32_t sample_id,
                      F4* accum, uint32_t* res_di, uint32_t* res_gi, uint32_t* sdata, unsigned long long* counters) {
     hipLaunchKernelGGL(k_v6_pass1, dim3(grid_for(f.npl, max_blocks)), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, cam, sample_id, accum, res_di, res_gi, sdata, counters);
+}
+void launch_restir_pass2(hipStream_t st, uint32_t max_blocks, const DevScene& sc, const DevFrame& f, const CameraGPU* cam, uint32_t* const bufs[6], unsigned long long* counters) {
+    RestirBufs B = {bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], bufs[5]};
+    hipLaunchKernelGGL(k_restir_pass2, dim3(grid_for(f.npl, max_blocks)), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, cam, B, counters);
+}
+void launch_restir_pass3(hipStream_t st, uint32_t max_blocks, const DevScene& sc, const DevFrame& f, const CameraGPU* cam, uint32_t* const bufs[6], F4* accum, unsigned long long* counters) {
+    RestirBufs B = {bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], bufs[5]};
+    hipLaunchKernelGGL(k_restir_pass3, dim3(grid_for(f.npl, max_blocks)), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, cam, B, accum, counters);
 }
 void launch_accumulate(hipStream_t st, uint32_t max_blocks, const DevFrame& f, const DevPaths& p, F4* accum) {
     hipLaunchKernelGGL(k_accumulate, dim3(grid_for(f.npl, max_blocks)), dim3(kBlock), 0, st, f, p, accum);

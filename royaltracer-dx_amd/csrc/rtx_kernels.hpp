@@ -14,7 +14,7 @@ struct DevScene {
     const TriGPU* small_tris;                     // 2 triangles per record (staged in LDS instead of `tris`)
     float small_cm, small_delta;                  // t-margin coefficient, distance tolerance of the edge planes
     const MatGPU*   mats;   uint32_t nmat;
-    const InstGPU*  insts;
+    const InstGPU*  insts;  uint32_t ninst;
     const LightGPU* lights; uint32_t nlights;
     float total_weight;
     uint32_t lds_nodes, lds_tris;   // how many nodes / triangles each workgroup stages in LDS
@@ -61,6 +61,8 @@ void launch_shade(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&
                   const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts);
 void launch_v6_pass1(hipStream_t, uint32_t max_blocks, const DevScene&, const DevFrame&, const CameraGPU* cam, uint32_t sample_id,
                      F4* accum, uint32_t* res_di, uint32_t* res_gi, uint32_t* sdata, unsigned long long* counters);
+void launch_restir_pass2(hipStream_t, uint32_t max_blocks, const DevScene&, const DevFrame&, const CameraGPU* cam, uint32_t* const bufs[6], unsigned long long* counters);
+void launch_restir_pass3(hipStream_t, uint32_t max_blocks, const DevScene&, const DevFrame&, const CameraGPU* cam, uint32_t* const bufs[6], F4* accum, unsigned long long* counters);
 void launch_accumulate(hipStream_t, uint32_t max_blocks, const DevFrame&, const DevPaths&, F4* accum);
 void launch_srgb8(hipStream_t, const F4* accum, uint32_t npix, uint32_t* out);
 void launch_pack_tiles(hipStream_t, uint32_t max_blocks, const DevFrame&, const F4* accum, F4* slab);

@@ -87,6 +87,7 @@ bool SceneHost::add_mesh(const void* verts28, uint32_t nverts, const uint32_t* i
 bool SceneHost::add_instance(uint32_t mesh, const float* o2w, uint32_t* out) {
     if (mesh >= meshes.size()) { err = "add_instance: unknown mesh"; return false; }
     InstHost in; in.mesh = mesh; memcpy(in.o2w, o2w, 64); normal_matrix(o2w, in.nrm); in.tri_base = 0;
+    mat4_inverse(o2w, in.o2w_inv); memcpy(in.prev_o2w, o2w, 64);          // Renderer.cpp:2098-2102
     if (out) *out = (uint32_t)insts.size();
     insts.push_back(in);
     return true;
@@ -94,7 +95,8 @@ bool SceneHost::add_instance(uint32_t mesh, const float* o2w, uint32_t* out) {
 
 bool SceneHost::set_instance_transform(uint32_t inst, const float* o2w) {
     if (inst >= insts.size()) { err = "set_instance_transform: unknown instance"; return false; }
-    memcpy(insts[inst].o2w, o2w, 64); normal_matrix(o2w, insts[inst].nrm);
+    memcpy(insts[inst].prev_o2w, insts[inst].o2w, 64);                        // prevObjectToWorld = last frame's objectToWorld
+    memcpy(insts[inst].o2w, o2w, 64); normal_matrix(o2w, insts[inst].nrm); mat4_inverse(o2w, insts[inst].o2w_inv);
     return true;
 }
 
@@ -123,7 +125,7 @@ bool SceneHost::build(BuiltScene& B) {
     float scale = 1.0f;
     for (size_t ii = 0; ii < insts.size(); ii++) {
         const InstHost& in = insts[ii]; const MeshHost& m = meshes[in.mesh];
-        memcpy(B.insts[ii].o2w, in.o2w, 64); memcpy(B.insts[ii].nrm, in.nrm, 64);
+        memcpy(B.insts[ii].o2w, in.o2w, 64); memcpy(B.insts[ii].nrm, in.nrm, 64); memcpy(B.insts[ii].o2w_inv, in.o2w_inv, 64); memcpy(B.insts[ii].prev_o2w, in.prev_o2w, 64);
         for (uint32_t t = 0; t < m.idx.size() / 3; t++) {
             uint32_t g = in.tri_base + t;
             uint32_t i0 = m.idx[t * 3], i1 = m.idx[t * 3 + 1], i2 = m.idx[t * 3 + 2];

@@ -14,7 +14,7 @@ void  mat4_inverse(const float* m16, float* out16);      // XMMatrixInverse stan
 void  normal_matrix(const float* o2w16, float* out16);   // Renderer.cpp:2104-2116
 
 struct MeshHost { std::vector<float> verts; std::vector<uint32_t> idx; uint32_t matid_base = 0; };
-struct InstHost { uint32_t mesh; float o2w[16]; float nrm[16]; uint32_t tri_base; };
+struct InstHost { uint32_t mesh; float o2w[16]; float nrm[16]; float o2w_inv[16]; float prev_o2w[16]; uint32_t tri_base; };
 
 struct BuiltScene {
     std::vector<MatGPU>   mats;

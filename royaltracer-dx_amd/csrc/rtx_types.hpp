@@ -42,7 +42,7 @@ struct alignas(16) TriShade {
 };
 static_assert(sizeof(TriShade) == 64, "TriShade must be 64 bytes");
 
-struct alignas(16) InstGPU { float o2w[16]; float nrm[16]; };   // a5: objectToWorld, objectToWorldNormal
+struct alignas(16) InstGPU { float o2w[16]; float nrm[16]; float o2w_inv[16]; float prev_o2w[16]; };   // a5: objectToWorld, objectToWorldNormal, objectToWorldInverse, prevObjectToWorld
 
 // LightTriangle (Renderer.h:113-124) with the sample-independent part of SampleLightNEE_GI
 // (Sampler_v6.hlsl:540-575) hoisted to the host: world-space vertices, light normal, clamped area pdf.
@@ -55,6 +55,6 @@ struct alignas(16) LightGPU {
 };
 static_assert(sizeof(LightGPU) == 80, "LightGPU must be 80 bytes");
 
-struct CameraGPU { float viewI[16]; float projI[16]; };
+struct CameraGPU { float viewI[16]; float projI[16]; float prev_view[16]; float prev_proj[16]; };   // a7 (+ prevView / prevProjection for the temporal pass)
 
 }  // namespace rtx

@@ -361,3 +361,49 @@ def test_v6_pass1_garage(rt, orc, golden_dir):
     assert np.array_equal(gs, cs) and np.array_equal(gd, cd) and np.array_equal(gg, cg)
     assert rel_l2(g[..., :3], ca[..., :3]) <= REL_L2_TOL
     c.close()
+
+
+@pytest.mark.parametrize("flags", [1, 0])
+def test_restir_frames_parity(rt, cornell_pair, flags):
+    """the reference's shipping pipeline: pass 1 + temporal reuse (pass 2) + spatial reuse and shade (pass 3), three
+    consecutive frames so that the temporal history is exercised; all six reservoir / sample buffers and the image"""
+    ctx, o = cornell_pair
+    W, H = 96, 56
+    vp = rt.Scene.cornell().view_proj(W / H)
+    ctx.set_camera(*vp); ctx.set_camera(*vp); o.set_camera(*vp); o.set_camera(*vp)      # previous view = current view
+    p = rt.Params(width=W, height=H, spp=3, max_bounces=3, nee_samples=4, flags=flags, frame_seed=11)
+    ctx.restir_reset(); ctx.clear(W, H); ctx.render_restir(p)
+    g = ctx.read_accum(); gd, gg, gs = ctx.read_pass1_buffers(); ld, lg, ls = ctx.read_restir_last()
+    c, st, cnt = o.restir_frames(p)
+    s = ctx.stats()
+    assert (s.rays_primary, s.rays_extension, s.rays_shadow) == cnt
+    for name, a, b in (("cur_di", gd, st[0]), ("cur_gi", gg, st[1]), ("cur_sd", gs, st[2]), ("last_di", ld, st[3]), ("last_gi", lg, st[4]), ("last_sd", ls, st[5])):
+        assert np.array_equal(a, b), f"{name} differs in {int((a != b).any(1).sum())} records"
+    assert np.array_equal(bits(g), bits(c))
+    M = ld.view(np.uint16).reshape(len(ld), 20)[:, 19]
+    assert M.max() > 1                                               # temporal / spatial merges happened
+    assert g[..., :3].sum() > 0
+
+
+def test_restir_garage_with_camera_motion(rt, orc, golden_dir):
+    """GGX scene with two instances; the camera moves between frames so the reprojection path is taken"""
+    import os
+    sc = rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")
+    W, H = 80, 48
+    c = rt.Context(0); c.upload(sc, W / H)
+    o = orc.Oracle().load(sc, W / H)
+    acc_o, st = np.zeros((H, W, 4), np.float32), None
+    c.restir_reset(); c.clear(W, H)
+    proj = rt.perspective_fov_rh(np.float32(np.pi / 3), W / H, 0.1, 1000.0)
+    tot = np.zeros(3, np.uint64)
+    for k, eye in enumerate([(-1.5, 1.5, 3.5), (-1.45, 1.5, 3.5), (-1.4, 1.52, 3.48)]):
+        view = rt.lookat(eye, (0, 1, 0), (0, 1, 0))
+        c.set_camera(view, proj); o.set_camera(view, proj)
+        p = rt.Params(width=W, height=H, spp=1, max_bounces=3, nee_samples=4, flags=0, frame_seed=100 + k)
+        c.render_restir(p)
+        acc_o, st, cnt = o.restir_frames(p, acc_o, st)
+        s = c.stats(); assert (s.rays_primary, s.rays_extension, s.rays_shadow) == cnt
+    ld, lg, ls = c.read_restir_last()
+    assert np.array_equal(ld, st[3]) and np.array_equal(lg, st[4]) and np.array_equal(ls, st[5])
+    assert rel_l2(c.read_accum()[..., :3], acc_o[..., :3]) <= REL_L2_TOL
+    c.close()
