@@ -112,6 +112,13 @@ def oracle_fixtures():
     og.set_camera(*gs.view_proj(64 / 36))
     acc, cnt = og.render(rt.Params(width=64, height=36, spp=2, max_bounces=6, nee_samples=2, flags=0))
     g["garage_accum"], g["garage_rays_count"] = acc, np.array(cnt, np.uint64)
+    # 5. the reference's own pipeline: pass-1 estimator and two ReSTIR frames (pass 1 + temporal + spatial)
+    o.set_camera(*sc.view_proj(48 / 28)); o.set_camera(*sc.view_proj(48 / 28))
+    p1 = rt.Params(width=48, height=28, spp=1, max_bounces=3, nee_samples=4, flags=0, frame_seed=3)
+    acc, (di, gi, sd), cnt = o.render_v6_pass1(p1)
+    g["pass1_accum"], g["pass1_di"], g["pass1_gi"], g["pass1_sd"], g["pass1_rays"] = acc, di, gi, sd, np.array(cnt, np.uint64)
+    acc, st, cnt = o.restir_frames(rt.Params(width=48, height=28, spp=2, max_bounces=3, nee_samples=4, flags=0, frame_seed=3))
+    g["restir_accum"], g["restir_last_di"], g["restir_last_gi"], g["restir_last_sd"], g["restir_rays"] = acc, st[3], st[4], st[5], np.array(cnt, np.uint64)
     np.savez_compressed(os.path.join(HERE, "oracle_golden.npz"), **g)
     print({k: v.shape for k, v in g.items()})
 

@@ -258,6 +258,15 @@ def test_golden_fixtures_on_gpu(rt, golden_dir, cornell_pair):
     for i in range(3):
         vals, end = ctx.tea(tuple(int(v) for v in g[f"tea{i}_seed"]), 8)
         assert np.array_equal(bits(vals), bits(g[f"tea{i}_vals"])) and end == tuple(int(v) for v in g[f"tea{i}_end"])
+    vp = rt.Scene.cornell().view_proj(48 / 28)
+    ctx.set_camera(*vp); ctx.set_camera(*vp)
+    ctx.clear(48, 28); ctx.render_v6_pass1(rt.Params(width=48, height=28, spp=1, max_bounces=3, nee_samples=4, flags=0, frame_seed=3))
+    di, gi, sd = ctx.read_pass1_buffers()
+    assert np.array_equal(bits(ctx.read_accum()), bits(g["pass1_accum"])) and np.array_equal(di, g["pass1_di"]) and np.array_equal(gi, g["pass1_gi"]) and np.array_equal(sd, g["pass1_sd"])
+    ctx.restir_reset(); ctx.clear(48, 28); ctx.render_restir(rt.Params(width=48, height=28, spp=2, max_bounces=3, nee_samples=4, flags=0, frame_seed=3))
+    ld, lg, ls = ctx.read_restir_last()
+    assert np.array_equal(bits(ctx.read_accum()), bits(g["restir_accum"]))
+    assert np.array_equal(ld, g["restir_last_di"]) and np.array_equal(lg, g["restir_last_gi"]) and np.array_equal(ls, g["restir_last_sd"])
     ctx.set_camera(*rt.Scene.cornell().view_proj(64 / 36))
     for tag, kw in (("c1", dict(spp=1, max_bounces=4)), ("c2", dict(spp=4, max_bounces=8))):
         ctx.clear(64, 36); ctx.render(rt.Params(width=64, height=36, nee_samples=1, flags=1, **kw))

@@ -278,3 +278,26 @@ def test_v6_pass1_oracle_properties(rt, orc, cornell):
     pt, _ = o.render(rt.Params(width=W, height=H, spp=8, max_bounces=5, nee_samples=1, flags=1))
     m1, m2 = acc[..., :3].mean() , pt[..., :3].mean()
     assert 0.9 < m1 / m2 < 1.5
+
+
+def test_golden_reference_pipeline(rt, orc, cornell, gold):
+    """pass-1 estimator and two ReSTIR frames against the committed vectors"""
+    o = orc.Oracle().load(cornell, 48 / 28); o.set_camera(*cornell.view_proj(48 / 28))
+    acc, (di, gi, sd), cnt = o.render_v6_pass1(rt.Params(width=48, height=28, spp=1, max_bounces=3, nee_samples=4, flags=0, frame_seed=3))
+    assert np.array_equal(bits(acc), bits(gold["pass1_accum"])) and np.array_equal(di, gold["pass1_di"]) and np.array_equal(gi, gold["pass1_gi"]) and np.array_equal(sd, gold["pass1_sd"])
+    assert cnt == tuple(int(v) for v in gold["pass1_rays"])
+    acc, st, cnt = o.restir_frames(rt.Params(width=48, height=28, spp=2, max_bounces=3, nee_samples=4, flags=0, frame_seed=3))
+    assert np.array_equal(bits(acc), bits(gold["restir_accum"])) and cnt == tuple(int(v) for v in gold["restir_rays"])
+    assert np.array_equal(st[3], gold["restir_last_di"]) and np.array_equal(st[4], gold["restir_last_gi"]) and np.array_equal(st[5], gold["restir_last_sd"])
+
+
+def test_restir_agrees_with_the_path_tracer_in_the_mean(rt, orc, cornell):
+    """ReSTIR DI + GI (pass 1-3) and the bounce-loop estimator estimate the same image: means within a few percent"""
+    W, H = 64, 36
+    o = orc.Oracle().load(cornell, W / H); o.set_camera(*cornell.view_proj(W / H))
+    acc, st, _ = o.restir_frames(rt.Params(width=W, height=H, spp=6, max_bounces=3, nee_samples=4, flags=1, frame_seed=1))
+    pt, _ = o.render(rt.Params(width=W, height=H, spp=24, max_bounces=5, nee_samples=1, flags=1))
+    a, b = acc[..., :3].sum((0, 1)) / 6, pt[..., :3].sum((0, 1)) / 24
+    assert np.allclose(a, b, rtol=0.08), (a, b)
+    M = st[3].view(np.uint16).reshape(len(st[3]), 20)[:, 19]
+    assert M.max() > 16                                  # history accumulates beyond one frame's cap
