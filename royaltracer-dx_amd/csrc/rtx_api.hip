@@ -118,7 +118,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     switch (option) {
     case RTX_OPT_KERNEL_TIMING: c->timing = value != 0; return RTX_OK;
     case RTX_OPT_PATHS_PER_BATCH: if (value < 4096) { c->err = "paths_per_batch must be >= 4096"; return RTX_ERR_INVALID; } c->paths_per_batch = (uint64_t)value; return RTX_OK;
-    case RTX_OPT_SORT_MATERIALS: c->sort_mats = value != 0; return RTX_OK;
+    case RTX_OPT_SORT_MATERIALS: c->sort_mats = value != 0; g_sort_materials = value != 0; return RTX_OK;
     case RTX_OPT_LDS_NODES: c->lds_nodes_opt = (int)value; c->committed = false; return RTX_OK;
     case RTX_OPT_SMALL_SCENE: c->small_scene = value != 0; c->committed = false; return RTX_OK;
     case RTX_OPT_FUSED_BOUNCE: c->fused = value != 0; return RTX_OK;

@@ -631,12 +631,24 @@ __device__ __forceinline__ void store_path(const DevPaths& p, const PathState& S
     p.thr[S.pid] = {S.thr.x, S.thr.y, S.thr.z, u2f(S.s0)};
 }
 
-// shade: one thread per queued path (general path: hits come from k_trace_closest, shadow rays go to queues)
+// shade: one thread per queued path (general path: hits come from k_trace_closest, shadow rays go to queues).
+// SORT = material-sorted shading: the workgroup's sub-queue is consumed in chunks of kSortChunk entries; each chunk is
+// counting-sorted in LDS by the material id of the hit (misses last), so that a wave shades ONE material and its
+// branches (emissive / Lambert / GGX strategy, miss) are wave-uniform.  The sort never leaves LDS: the queue index and
+// the hit record it reads are needed by the shading anyway.  Results do not depend on the order (per-path state only).
+// MEASURED (MI355X, 1080p 16 spp 8 bounces, ms per 2 frames in k_shade): Bistro-class (30 % GGX) 18.1 unsorted vs 23.3
+// sorted, Sponza-class 16.1 vs 32.1 — k_shade is HBM-bound, not divergence-bound, and the permutation turns its
+// coalesced per-path state streams into gathers; k_trace_shadow gains 4-8 % from the more coherent shadow rays, the
+// frame loses 1-10 %.  Hence RTX_OPT_SORT_MATERIALS defaults to 0.
+constexpr uint32_t kSortChunk = 2048, kSortKeys = 64;
+template <bool SORT>
 __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPaths p, uint32_t bounce,
                                                   const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount,
                                                   uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count,
                                                   uint32_t* __restrict__ shcounts /* [nee][gridDim.x] */) {
     __shared__ uint32_t s_cnt[1 + kMaxNee];                 // [0] next-queue length, [1 + j] shadow queue j length
+    __shared__ uint32_t s_pid[SORT ? kSortChunk : 1], s_sorted[SORT ? kSortChunk : 1], s_hist[SORT ? kSortKeys : 1];
+    __shared__ uint8_t s_key[SORT ? kSortChunk : 1];
     if (threadIdx.x <= kMaxNee) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t n = qcount[blockIdx.x];
@@ -645,41 +657,68 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPa
     const size_t qb = (size_t)blockIdx.x * f.qcap;
     const uint32_t* myq = queue + qb;
     uint32_t* mynext = next_queue + qb;
-    for (uint32_t base = threadIdx.x & ~63u; base < n; base += kBlock) {
-        const uint32_t i = base + (threadIdx.x & 63u);
-        PathState S; S.pid = 0; S.o = mk3(0, 0, 0); S.d = mk3(0, 0, 1); S.thr = mk3(0, 0, 0); S.prev_pdf = 1.0f; S.s0 = S.s1 = 0;
-        Surf sf; sf.mat = 0; sf.normal = mk3(0, 0, 1); sf.pos = mk3(0, 0, 0);
-        bool shading = false;
-        if (i < n) {
-            const uint32_t pid = myq[i];
-            const F4 h = p.hit[pid];
-            const uint32_t prim = f2u(h.w);
-            if (prim != kMissPrim) {                                          // miss: Miss.hlsl:3-11 -> black, terminate
-                S = load_path(p, pid);
-                sf = surface(sc, S.o, S.d, h.x, h.y, h.z, prim);
-                if (sf.mat < sc.nmat) {
-                    const MatGPU& m = sc.mats[sf.mat];
-                    if (m.Ke_len > 0.0f) add_emissive(sc, p, S, sf, m, bounce, nee);   // Hit.hlsl:126, Sampler_v6.hlsl:457
-                    else shading = true;
+    const uint32_t chunk = SORT ? kSortChunk : n;
+    for (uint32_t cb = 0; cb < n; cb += chunk) {
+        const uint32_t cn = (n - cb < chunk) ? n - cb : chunk;
+        if (SORT) {
+            if (threadIdx.x < kSortKeys) s_hist[threadIdx.x] = 0;
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < cn; i += kBlock) {
+                const uint32_t pid = myq[cb + i];
+                const uint32_t prim = f2u(p.hit[pid].w);
+                const uint32_t key = prim == kMissPrim ? kSortKeys - 1u : (sc.shade[prim].mat % (kSortKeys - 1u));
+                s_pid[i] = pid; s_key[i] = (uint8_t)key;
+                atomicAdd(&s_hist[key], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x < 64) {                             // exclusive scan of the 64 bucket counts by one wave
+                const uint32_t c = s_hist[threadIdx.x];
+                uint32_t incl = c;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if ((int)threadIdx.x >= d) incl += t; }
+                s_hist[threadIdx.x] = incl - c;
+            }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < cn; i += kBlock) s_sorted[atomicAdd(&s_hist[s_key[i]], 1u)] = s_pid[i];
+            __syncthreads();
+        }
+        for (uint32_t base = threadIdx.x & ~63u; base < cn; base += kBlock) {
+            const uint32_t i = base + (threadIdx.x & 63u);
+            PathState S; S.pid = 0; S.o = mk3(0, 0, 0); S.d = mk3(0, 0, 1); S.thr = mk3(0, 0, 0); S.prev_pdf = 1.0f; S.s0 = S.s1 = 0;
+            Surf sf; sf.mat = 0; sf.normal = mk3(0, 0, 1); sf.pos = mk3(0, 0, 0);
+            bool shading = false;
+            if (i < cn) {
+                const uint32_t pid = SORT ? s_sorted[i] : myq[cb + i];
+                const F4 h = p.hit[pid];
+                const uint32_t prim = f2u(h.w);
+                if (prim != kMissPrim) {                                          // miss: Miss.hlsl:3-11 -> black, terminate
+                    S = load_path(p, pid);
+                    sf = surface(sc, S.o, S.d, h.x, h.y, h.z, prim);
+                    if (sf.mat < sc.nmat) {
+                        const MatGPU& m = sc.mats[sf.mat];
+                        if (m.Ke_len > 0.0f) add_emissive(sc, p, S, sf, m, bounce, nee);   // Hit.hlsl:126, Sampler_v6.hlsl:457
+                        else shading = true;
+                    }
                 }
             }
+            const f3 outgoing = -S.d, normal = sf.normal, pos = sf.pos;
+            const MatGPU* mp = sc.mats + (shading ? sf.mat : 0u);
+            for (uint32_t j = 0; j < nee; j++) {                                  // NEE: visibility deferred to k_trace_shadow
+                bool push = false;
+                F4 so = {0, 0, 0, 0}, sd = {0, 0, 0, 0}; f3 con = mk3(0, 0, 0);
+                if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con);
+                const size_t seg = (size_t)j * f.qcap * gridDim.x + qb;           // NEE slot j, this workgroup's sub-queue
+                const uint32_t slot = block_push(push, &s_cnt[1 + j]);
+                if (push) { p.sh_o[seg + slot] = so; p.sh_d[seg + slot] = sd; p.sh_c[seg + slot] = {con.x, con.y, con.z, u2f(S.pid)}; }
+            }
+            bool alive = false;
+            f3 smp = mk3(0, 0, 1); float P = 0.0f;
+            if (shading && !last) alive = bsdf_continue(*mp, f, bounce, S, normal, outgoing, smp, P);
+            if (alive) store_path(p, S, pos, smp, P);
+            const uint32_t slot = block_push(alive, &s_cnt[0]);
+            if (alive) mynext[slot] = S.pid;
         }
-        const f3 outgoing = -S.d, normal = sf.normal, pos = sf.pos;
-        const MatGPU* mp = sc.mats + (shading ? sf.mat : 0u);
-        for (uint32_t j = 0; j < nee; j++) {                                  // NEE: visibility deferred to k_trace_shadow
-            bool push = false;
-            F4 so = {0, 0, 0, 0}, sd = {0, 0, 0, 0}; f3 con = mk3(0, 0, 0);
-            if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con);
-            const size_t seg = (size_t)j * f.qcap * gridDim.x + qb;           // NEE slot j, this workgroup's sub-queue
-            const uint32_t slot = block_push(push, &s_cnt[1 + j]);
-            if (push) { p.sh_o[seg + slot] = so; p.sh_d[seg + slot] = sd; p.sh_c[seg + slot] = {con.x, con.y, con.z, u2f(S.pid)}; }
-        }
-        bool alive = false;
-        f3 smp = mk3(0, 0, 1); float P = 0.0f;
-        if (shading && !last) alive = bsdf_continue(*mp, f, bounce, S, normal, outgoing, smp, P);
-        if (alive) store_path(p, S, pos, smp, P);
-        const uint32_t slot = block_push(alive, &s_cnt[0]);
-        if (alive) mynext[slot] = S.pid;
+        if (SORT) __syncthreads();                              // the next chunk overwrites the LDS buffers
     }
     __syncthreads();
     if (threadIdx.x == 0) next_count[blockIdx.x] = s_cnt[0];
@@ -1446,6 +1485,7 @@ __global__ __launch_bounds__(kBlock) void k_dbg_primary(DevFrame f, const Camera
 }
 
 int g_bounce_variant = 4;
+int g_sort_materials = 0;     // measured slower (see k_shade): the permutation un-coalesces the per-path state streams
 
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
@@ -1486,7 +1526,8 @@ void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, 
 }
 void launch_shade(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce,
                   const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts) {
-    hipLaunchKernelGGL(k_shade, dim3(f.nblocks), dim3(kBlock), 0, st, sc, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);
+    if (g_sort_materials) hipLaunchKernelGGL(k_shade<true>, dim3(f.nblocks), dim3(kBlock), 0, st, sc, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(f.nblocks), dim3(kBlock), 0, st, sc, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);
 }
 void launch_v6_pass1(hipStream_t st, uint32_t max_blocks, const DevScene& sc, const DevFrame& f, const CameraGPU* cam, uint32_t sample_id,
                      F4* accum, uint32_t* res_di, uint32_t* res_gi, uint32_t* sdata, unsigned long long* counters) {

@@ -49,6 +49,7 @@ struct DevPaths {
 };
 
 extern int g_refill_min;       // tuning knob: idle lanes that trigger a refill in the persistent traversal
+extern int g_sort_materials;   // 1 = material-sorted shading in k_shade (general path)
 extern int g_bounce_variant;   // tuning knob: waves/SIMD the fused kernel is compiled for (4, 5 or 6)
 size_t trace_lds_bytes(const DevScene& sc);
 void launch_raygen(hipStream_t, const DevFrame&, const DevPaths&, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount);
