@@ -157,7 +157,8 @@ def main():
                 prof = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)))
                 if args.workload == "cornell_1080p_64spp_8b" and world == 1:
                     sym = {"bounce_fused": "k_bounce_small"}.get(name, "k_" + name)
-                    traffic = prof["kernels"][sym]["hbm_bytes_per_launch"]
+                    rows = [v for k, v in prof["kernels"].items() if k.split("<")[0] == sym]      # template instantiations of one kernel
+                    traffic = round(sum(v["hbm_bytes_per_launch"] * v["calls"] for v in rows) / sum(v["calls"] for v in rows))
             except Exception:
                 traffic = None
             roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -18,8 +18,8 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"(k_[a-z_0-9]+|__amd_rocclr_\w+|vectorized_elementwise_kernel)", name)
-    return m.group(1) if m else name[:40]
+    m = re.search(r"(k_[a-z_0-9]+(<[^>(]*>)?|__amd_rocclr_\w+|vectorized_elementwise_kernel)", name)
+    return m.group(1).replace(" ", "") if m else name[:40]
 
 
 def load_counter(d, counter):
@@ -37,8 +37,10 @@ def main():
     stats = {}
     for f in glob.glob(os.path.join(kt, "*kernel_stats.csv")):
         for r in csv.DictReader(open(f)):
-            stats[short(r["Name"])] = {"calls": int(r["Calls"]), "total_ms": float(r["TotalDurationNs"]) / 1e6,
-                                       "avg_us": float(r["AverageNs"]) / 1e3, "pct": float(r["Percentage"])}
+            k = short(r["Name"])
+            e = stats.setdefault(k, {"calls": 0, "total_ms": 0.0, "pct": 0.0})
+            e["calls"] += int(r["Calls"]); e["total_ms"] += float(r["TotalDurationNs"]) / 1e6; e["pct"] += float(r["Percentage"])
+            e["avg_us"] = e["total_ms"] * 1e3 / e["calls"]
     regs = {}
     for f in glob.glob(os.path.join(kt, "*kernel_trace.csv")):
         for r in csv.DictReader(open(f)):
