@@ -70,6 +70,7 @@ typedef struct rtx_stats {
     double   render_ms;                                   /* hipEvent time of the whole rtx_render on its stream */
     uint32_t bvh_nodes, triangles, lights, materials;
     uint64_t primary_hits;                                /* camera rays that hit the scene (items of the bounce-0 shading launch) */
+    uint32_t bvh_refits, reserved;                        /* commits since the last full BVH build that only refitted boxes */
 } rtx_stats;
 
 enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents (rtx_stats.kernel_ms) */
@@ -100,7 +101,8 @@ int  rtx_add_mesh(rtx_ctx*, const void* verts28, uint32_t nverts, const uint32_t
                   const uint32_t* material_ids, uint32_t* mesh_out);
 /* m_instances.push_back({BLAS, matrix}) (Renderer.cpp:908-921); instance id = order of insertion (:843-845) */
 int  rtx_add_instance(rtx_ctx*, uint32_t mesh, const float o2w[16], uint32_t* inst_out);
-/* t3 `instanceProps` update (UpdateInstancePropertiesBuffer, Renderer.cpp:2091-2121); needs rtx_commit_scene again */
+/* t3 `instanceProps` update (UpdateInstancePropertiesBuffer, Renderer.cpp:2091-2121; prevObjectToWorld := the old matrix);
+   needs rtx_commit_scene again, which then only REFITS the BVH boxes (TLAS refit, Renderer.cpp:594) instead of rebuilding */
 int  rtx_set_instance_transform(rtx_ctx*, uint32_t inst, const float o2w[16]);
 /* CreateAccelerationStructures (Renderer.cpp:893-946) + CollectEmissiveTriangles (:2123-2213) +
    CreateEmissiveTrianglesBuffer (:2237-2280): BVH build, emissive CDF, upload */

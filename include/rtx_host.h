@@ -47,6 +47,8 @@ float rtxh_half_round(float x);
 /* BVH builder invariants for tests: returns 0 when every triangle is in exactly one leaf and every child box
    contains its subtree; fills nodes / depth / max leaf size */
 int  rtxh_bvh_check(const float* world_tris9, uint32_t ntris, uint32_t* nodes_out, uint32_t* depth_out, uint32_t* max_leaf_out);
+/* same invariants after building on `before` and REFITTING (topology kept) to `after` (TLAS refit, Renderer.cpp:594) */
+int  rtxh_bvh_refit_check(const float* before_tris9, const float* after_tris9, uint32_t ntris);
 
 /* the tiny-scene pre-test records rtx_commit_scene would build for this scene: per record 20 floats (plane xyz d,
    4 edge planes xyz c) and the global ids of its 1-2 triangles (-1 = none); for host-side conservativeness tests */

@@ -47,6 +47,7 @@ _sig("orc_set_materials", C.c_int, _vp, _vp, _u32)
 _sig("orc_add_mesh", C.c_int, _vp, _vp, _u32, _vp, _u32, _vp, _u32p)
 _sig("orc_add_instance", C.c_int, _vp, _u32, _fp, _u32p)
 _sig("orc_commit", C.c_int, _vp)
+_sig("orc_set_instance_transform", C.c_int, _vp, _u32, _fp)
 _sig("orc_set_camera", C.c_int, _vp, _fp, _fp)
 _sig("orc_set_threads", C.c_int, _vp, C.c_int)
 _sig("orc_render", C.c_int, _vp, C.POINTER(Params), _vp, C.POINTER(C.c_uint64))
@@ -106,6 +107,11 @@ class Oracle:
         v, p = scene.view_proj(aspect)
         self.set_camera(v, p)
         return self
+
+    def set_instance_transform(self, inst, o2w):
+        o = _f32(o2w).reshape(16)
+        assert lib.orc_set_instance_transform(self._h, inst, o.ctypes.data_as(_fp)) == 0
+        assert lib.orc_commit(self._h) == 0
 
     def set_camera(self, view, proj):
         v, p = _f32(view).reshape(16), _f32(proj).reshape(16)

@@ -267,6 +267,15 @@ int orc_add_instance(orc_ctx* c, uint32_t mesh, const float* o2w16, uint32_t* in
     return 0;
 }
 
+/* UpdateInstancePropertiesBuffer, Renderer.cpp:2091-2121: prev := current, then the new matrix; call orc_commit afterwards */
+int orc_set_instance_transform(orc_ctx* c, uint32_t inst, const float* o2w16) {
+    if (inst >= c->ninst) return -1;
+    inst_t* in = &c->insts[inst];
+    memcpy(in->prev_o2w, in->o2w, 64);
+    memcpy(in->o2w, o2w16, 64); normal_matrix(o2w16, in->nrm); orc_mat4_inverse(o2w16, in->o2w_inv);
+    return 0;
+}
+
 static inline v3 mesh_pos(const mesh_t* m, uint32_t vi) { const float* p = m->verts + (size_t)vi * 7; return V3(p[0], p[1], p[2]); }
 static inline v3 mesh_nrm(const mesh_t* m, uint32_t vi) { const float* p = m->verts + (size_t)vi * 7; return V3(p[3], p[4], p[5]); }
 

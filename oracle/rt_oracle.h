@@ -54,6 +54,7 @@ int  orc_set_materials(orc_ctx*, const void* mats128, uint32_t count);
 int  orc_add_mesh(orc_ctx*, const void* verts28, uint32_t nverts, const uint32_t* indices,
                   uint32_t nidx, const uint32_t* material_ids, uint32_t* mesh_out);
 int  orc_add_instance(orc_ctx*, uint32_t mesh, const float* o2w16, uint32_t* inst_out);
+int  orc_set_instance_transform(orc_ctx*, uint32_t inst, const float* o2w16);   /* then orc_commit */
 int  orc_commit(orc_ctx*);
 int  orc_set_camera(orc_ctx*, const float* view16, const float* proj16);
 int  orc_set_threads(orc_ctx*, int nthreads);     /* OpenMP threads for orc_render (0 = all) */

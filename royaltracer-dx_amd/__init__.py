@@ -64,7 +64,7 @@ class Stats(C.Structure):
                 ("paths", C.c_uint64), ("kernel_ms", C.c_double * K_COUNT), ("kernel_launches", C.c_uint64 * K_COUNT),
                 ("kernel_items", C.c_uint64 * K_COUNT), ("render_ms", C.c_double),
                 ("bvh_nodes", C.c_uint32), ("triangles", C.c_uint32), ("lights", C.c_uint32), ("materials", C.c_uint32),
-                ("primary_hits", C.c_uint64)]
+                ("primary_hits", C.c_uint64), ("bvh_refits", C.c_uint32), ("reserved", C.c_uint32)]
 
     @property
     def rays(self):
@@ -140,6 +140,7 @@ _sig("rtxh_generate_ess_lut", None, C.c_float, _fp)
 _sig("rtxh_mat4_inverse", None, _fp, _fp)
 _sig("rtxh_half_round", C.c_float, C.c_float)
 _sig("rtxh_bvh_check", C.c_int, _vp, _u32, _u32p, _u32p, _u32p)
+_sig("rtxh_bvh_refit_check", C.c_int, _vp, _vp, _u32)
 _sig("rtxh_scene_small_records", C.c_int, _vp, _vp, _vp, _u32, _u32p, _fp, _fp)
 _sig("rtxh_renderer_create", _vp, _u32, _u32, C.c_char_p, C.c_int)
 _sig("rtxh_renderer_set_scene", C.c_int, _vp, _vp)
@@ -261,6 +262,11 @@ def mat4_inverse(m):
 
 def half_round(x):
     return lib.rtxh_half_round(C.c_float(x))
+
+
+def bvh_refit_check(before, after):
+    a, b = _f32(before).reshape(-1, 9), _f32(after).reshape(-1, 9)
+    return lib.rtxh_bvh_refit_check(_ptr(a), _ptr(b), len(a))
 
 
 def bvh_check(world_tris):

@@ -39,7 +39,6 @@ struct rtx_ctx {
     DevScene dsc{};
     float view[16], proj[16];
     // path state
-    uint32_t cap = 0, cap_nee = 0;
     DevBuf d_ray_o, d_ray_d, d_thr, d_rad, d_hit, d_sh_o, d_sh_d, d_sh_c, d_queue[2], d_counters;
     uint32_t* h_counters = nullptr; size_t h_counters_words = 0;
     // accumulation
@@ -47,7 +46,7 @@ struct rtx_ctx {
     DevBuf d_srgb, d_res_di, d_res_gi, d_sdata, d_last_di, d_last_gi, d_last_sd, d_p1cnt; size_t p1_slots = 0, last_slots = 0;
     float prev_view[16], prev_proj[16];
     // options
-    bool timing = false; uint64_t paths_per_batch = 64u << 20; int sort_mats = 0; int lds_nodes_opt = -1; bool small_scene = true; bool fused = true; int stack_private = -1;
+    bool timing = false; uint64_t paths_per_batch = 64u << 20; int lds_nodes_opt = -1; bool small_scene = true; bool fused = true; int stack_private = -1;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     std::vector<TimedLaunch> timed;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -118,7 +117,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     switch (option) {
     case RTX_OPT_KERNEL_TIMING: c->timing = value != 0; return RTX_OK;
     case RTX_OPT_PATHS_PER_BATCH: if (value < 4096) { c->err = "paths_per_batch must be >= 4096"; return RTX_ERR_INVALID; } c->paths_per_batch = (uint64_t)value; return RTX_OK;
-    case RTX_OPT_SORT_MATERIALS: c->sort_mats = value != 0; g_sort_materials = value != 0; return RTX_OK;
+    case RTX_OPT_SORT_MATERIALS: g_sort_materials = value != 0; return RTX_OK;
     case RTX_OPT_LDS_NODES: c->lds_nodes_opt = (int)value; c->committed = false; return RTX_OK;
     case RTX_OPT_SMALL_SCENE: c->small_scene = value != 0; c->committed = false; return RTX_OK;
     case RTX_OPT_FUSED_BOUNCE: c->fused = value != 0; return RTX_OK;
@@ -207,7 +206,7 @@ int rtx_commit_scene(rtx_ctx* c) {
         s.nsmall = B.small_nrec; s.lds_tris = (uint32_t)B.small_tris.size();   // LDS holds the records' triangles instead of the leaf-ordered ones
     }
     if (trace_lds_bytes(s) > 64 * 1024) { c->err = "commit: BVH too deep for the LDS traversal stack"; return RTX_ERR_INVALID; }
-    c->stats.bvh_nodes = s.nnodes; c->stats.triangles = s.ntris; c->stats.lights = s.nlights; c->stats.materials = s.nmat;
+    c->stats.bvh_refits = B.refit_count; c->stats.bvh_nodes = s.nnodes; c->stats.triangles = s.ntris; c->stats.lights = s.nlights; c->stats.materials = s.nmat;
     c->committed = true;
     return RTX_OK;
 }

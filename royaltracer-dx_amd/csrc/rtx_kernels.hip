@@ -1,10 +1,13 @@
 // rtx_kernels.hip — the wavefront path-tracing kernels for gfx950 (CDNA4, wave64).
 //
-// One sample batch is a set of paths with fixed slots ("pid"); per-path state lives in SoA float4
-// arrays in HBM; each bounce runs   trace_closest -> shade -> trace_shadow[j]   over an index queue
-// that shade re-compacts with a wave ballot + prefix sum (one atomic per wave).  The top of the BVH
-// and the first triangles are staged in LDS per workgroup; the per-lane traversal stack is in LDS too.
-// MFMA is unused on purpose: nothing here is a dense contraction.
+// One sample batch is a set of paths with fixed slots ("pid"); per-path state lives in SoA float4 arrays in HBM.
+// General scenes: each bounce runs  k_trace_closest -> k_shade -> k_trace_shadow[j]  over workgroup-private index
+// sub-queues that k_shade re-compacts with a wave ballot + prefix sum (one LDS atomic per wave, no global atomics);
+// the traversal kernels are persistent waves with dynamic ray fetch, the top of the BVH and the per-lane stack live
+// in LDS.  Tiny scenes (<= 64 triangles, the Cornell Box): no BVH, a packed-FP32 plane/edge pre-test with
+// scalar-loaded coefficients, and ONE fused kernel per bounce (k_bounce_small).  The reference's own passes
+// (k_v6_pass1, k_restir_pass2/3) are thread-per-pixel kernels.  MFMA is unused on purpose: nothing here is a dense
+// contraction.
 //
 // Parity-critical arithmetic (ray/triangle test, surface reconstruction, BSDF, light sampling, path
 // throughput) follows rtx_math.hpp / rtx_bsdf.hpp with the library-wide -ffp-contract=off.  Ray/box
@@ -38,8 +41,6 @@ __device__ __forceinline__ uint32_t block_push(bool pred, uint32_t* lds_counter)
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     return base + prefix;
 }
-
-__device__ __forceinline__ F4 ld4(const F4* p) { return *p; }
 
 // ---------------------------------------------------------------------------------------------
 // pixel <-> local path-slot mapping (shard tiles, 8x8 pixel blocks inside a tile so that one wave
@@ -219,8 +220,8 @@ __device__ __forceinline__ void traverse(const DevScene& sc, const TraceLds& L, 
 // their coefficients wave-uniform (one s_load_dwordx16 pair per iteration, no LDS/VMEM traffic, no divergence) —
 // and collects a per-lane candidate bit mask.  Phase 2 runs the exact Moeller-Trumbore test on the few
 // candidates of each lane.  The result is the same minimum-over-all-triangles as the BVH path and the oracle's
-// brute force: phase 1 only removes triangles that the exact test would reject (tolerances: SmallTri.eps and
-// the distance margin, built in rtx_scene_host.cpp).
+// brute force: phase 1 only removes triangles that the exact test would reject (tolerances: the edge-plane distance
+// delta and the t margin, built in rtx_scene_host.cpp).
 typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2v fma2(f2v a, f2v b, f2v c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2v splat2(float x) { f2v r = {x, x}; return r; }

@@ -81,6 +81,7 @@ bool SceneHost::add_mesh(const void* verts28, uint32_t nverts, const uint32_t* i
     matids.insert(matids.end(), mids, mids + nidx);
     if (out) *out = (uint32_t)meshes.size();
     meshes.push_back(std::move(m));
+    topo_dirty = true;
     return true;
 }
 
@@ -90,6 +91,7 @@ bool SceneHost::add_instance(uint32_t mesh, const float* o2w, uint32_t* out) {
     mat4_inverse(o2w, in.o2w_inv); memcpy(in.prev_o2w, o2w, 64);          // Renderer.cpp:2098-2102
     if (out) *out = (uint32_t)insts.size();
     insts.push_back(in);
+    topo_dirty = true;
     return true;
 }
 
@@ -204,9 +206,14 @@ bool SceneHost::build(BuiltScene& B) {
         G.em[0] = L.em[0]; G.em[1] = L.em[1]; G.em[2] = L.em[2]; G.pad1 = 0.0f;
         G.nl[0] = nrm.x; G.nl[1] = nrm.y; G.nl[2] = nrm.z; G.pad2 = 0.0f;
     }
-    // ---- BVH ----
-    std::vector<uint32_t> leaf_order;
-    build_bvh(wtri, 1e-6f * scale, B.nodes, leaf_order, B.max_depth);
+    // ---- BVH: full binned-SAH build, or a REFIT when only instance transforms changed since the last build
+    //      (the reference refits its TLAS every frame: Renderer.cpp:594, TopLevelASGenerator.cpp:149-250) ----
+    std::vector<uint32_t>& leaf_order = B.leaf_order;
+    const bool refit = !topo_dirty && B.leaf_order.size() == (size_t)nt && !B.nodes.empty();
+    if (refit) refit_bvh(wtri, 1e-6f * scale, B.nodes, leaf_order);
+    else build_bvh(wtri, 1e-6f * scale, B.nodes, leaf_order, B.max_depth);
+    B.refit_count = refit ? B.refit_count + 1 : 0;
+    topo_dirty = false;
     B.tris.resize(leaf_order.size());
     for (size_t s = 0; s < leaf_order.size(); s++) {
         uint32_t g = leaf_order[s];
@@ -312,6 +319,35 @@ inline float half_area(const Box& b) {
     return dx * dy + dy * dz + dz * dx;
 }
 struct TmpNode { Box box; int32_t left = -1, right = -1; uint32_t first = 0, count = 0; };
+}
+
+// Refit: keep the topology (node links, leaf order), recompute every child box bottom-up.  Nodes are stored
+// breadth-first, so a child always has a larger index than its parent: one reverse sweep suffices.
+void refit_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGPU>& nodes, const std::vector<uint32_t>& order) {
+    auto child_box = [&](int32_t child, float* mn, float* mx) {
+        for (int a = 0; a < 3; a++) { mn[a] = INFINITY; mx[a] = -INFINITY; }
+        if (child == kEmptyChild) return;
+        if (child < 0) {                                  // leaf: bounds of its triangles
+            const uint32_t v = ~(uint32_t)child, first = v >> 3, cnt = (v & 7u) + 1u;
+            for (uint32_t k = 0; k < cnt; k++) {
+                const float* t = &wtri[(size_t)order[first + k] * 9];
+                for (int vtx = 0; vtx < 3; vtx++) for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], t[vtx * 3 + a]); mx[a] = std::max(mx[a], t[vtx * 3 + a]); }
+            }
+            for (int a = 0; a < 3; a++) { mn[a] -= pad_abs; mx[a] += pad_abs; }
+        } else {                                          // internal: union of its two (already refitted, already padded) child boxes
+            const NodeGPU& N = nodes[child];
+            const float amn[3] = {N.a.x, N.a.y, N.a.z}, amx[3] = {N.a.w, N.b.x, N.b.y}, bmn[3] = {N.b.z, N.b.w, N.c.x}, bmx[3] = {N.c.y, N.c.z, N.c.w};
+            for (int a = 0; a < 3; a++) { mn[a] = std::min(amn[a], bmn[a]); mx[a] = std::max(amx[a], bmx[a]); }
+        }
+    };
+    for (size_t i = nodes.size(); i-- > 0;) {
+        NodeGPU& N = nodes[i];
+        float mn[3], mx[3];
+        child_box((int32_t)f2u(N.d.x), mn, mx);
+        N.a = {mn[0], mn[1], mn[2], mx[0]}; N.b.x = mx[1]; N.b.y = mx[2];
+        child_box((int32_t)f2u(N.d.y), mn, mx);
+        N.b.z = mn[0]; N.b.w = mn[1]; N.c = {mn[2], mx[0], mx[1], mx[2]};
+    }
 }
 
 void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGPU>& nodes, std::vector<uint32_t>& order, uint32_t& max_depth) {

@@ -27,8 +27,10 @@ struct BuiltScene {
     std::vector<InstGPU>  insts;
     std::vector<LightGPU> lights;
     std::vector<float>    lights80;   // reference-layout LightTriangle records (20 floats each)
+    std::vector<uint32_t> leaf_order;   // BVH leaf order (kept for refits)
     float total_weight = 0.0f;
     uint32_t max_depth = 0;
+    uint32_t refit_count = 0;           // commits since the last full build that only refitted the boxes
 };
 
 struct SceneHost {
@@ -37,6 +39,7 @@ struct SceneHost {
     std::vector<uint32_t> matids;               // global materialIDs[]
     std::vector<InstHost> insts;
     std::string err;
+    bool topo_dirty = true;                     // meshes / instances added since the last build (a transform change alone refits)
 
     bool set_materials(const void* mats, uint32_t count);
     bool add_mesh(const void* verts28, uint32_t nverts, const uint32_t* idx, uint32_t nidx, const uint32_t* matids, uint32_t* out);
@@ -47,6 +50,7 @@ struct SceneHost {
 
 // binned-SAH BVH2 over world-space triangles (9 floats each); fills nodes (breadth-first, children boxes in
 // parent) and the leaf-ordered triangle permutation.
+void refit_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGPU>& nodes, const std::vector<uint32_t>& leaf_order);
 void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGPU>& nodes,
                std::vector<uint32_t>& leaf_order, uint32_t& max_depth);
 

@@ -77,16 +77,12 @@ void rtxh_generate_ess_lut(float roughness, float lut[16]) {
 void rtxh_mat4_inverse(const float m[16], float out[16]) { rtx::mat4_inverse(m, out); }
 float rtxh_half_round(float x) { return rtx::half_round(x); }
 
-int rtxh_bvh_check(const float* wt, uint32_t ntris, uint32_t* nodes_out, uint32_t* depth_out, uint32_t* max_leaf_out) {
-    std::vector<float> w(wt, wt + (size_t)ntris * 9);
-    std::vector<rtx::NodeGPU> nodes; std::vector<uint32_t> order; uint32_t depth = 0;
-    rtx::build_bvh(w, 0.0f, nodes, order, depth);
-    if (nodes_out) *nodes_out = (uint32_t)nodes.size();
-    if (depth_out) *depth_out = depth;
+// every triangle in exactly one leaf, every child box contains its subtree
+static int bvh_validate(const std::vector<float>& w, const std::vector<rtx::NodeGPU>& nodes, const std::vector<uint32_t>& order, uint32_t* max_leaf_out) {
+    const uint32_t ntris = (uint32_t)(w.size() / 9);
     if (order.size() != ntris) return 1;
     std::vector<uint8_t> seen(ntris, 0);
     for (uint32_t g : order) { if (g >= ntris || seen[g]) return 2; seen[g] = 1; }
-    // walk the tree: every leaf triangle must lie inside every ancestor child box on the way down
     struct It { int32_t child; float mn[3], mx[3]; };
     std::vector<uint8_t> covered(ntris, 0);
     uint32_t max_leaf = 0;
@@ -117,6 +113,24 @@ int rtxh_bvh_check(const float* wt, uint32_t ntris, uint32_t* nodes_out, uint32_
     for (uint32_t i = 0; i < ntris; i++) if (!covered[i]) return 7;
     if (max_leaf_out) *max_leaf_out = max_leaf;
     return 0;
+}
+
+int rtxh_bvh_check(const float* wt, uint32_t ntris, uint32_t* nodes_out, uint32_t* depth_out, uint32_t* max_leaf_out) {
+    std::vector<float> w(wt, wt + (size_t)ntris * 9);
+    std::vector<rtx::NodeGPU> nodes; std::vector<uint32_t> order; uint32_t depth = 0;
+    rtx::build_bvh(w, 0.0f, nodes, order, depth);
+    if (nodes_out) *nodes_out = (uint32_t)nodes.size();
+    if (depth_out) *depth_out = depth;
+    return bvh_validate(w, nodes, order, max_leaf_out);
+}
+
+// build on `before`, refit (topology kept) to `after`: the refitted boxes must contain the moved triangles
+int rtxh_bvh_refit_check(const float* before, const float* after, uint32_t ntris) {
+    std::vector<float> a(before, before + (size_t)ntris * 9), b(after, after + (size_t)ntris * 9);
+    std::vector<rtx::NodeGPU> nodes; std::vector<uint32_t> order; uint32_t depth = 0;
+    rtx::build_bvh(a, 0.0f, nodes, order, depth);
+    rtx::refit_bvh(b, 0.0f, nodes, order);
+    return bvh_validate(b, nodes, order, nullptr);
 }
 
 // the tiny-scene pre-test records as rtx_commit_scene builds them (for host-side conservativeness tests)

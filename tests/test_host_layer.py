@@ -210,3 +210,13 @@ def test_tiny_scene_pretest_records_are_conservative(rt, orc, cornell):
     passes = ok | (np.abs(nd) < 1e-3)
     assert passes.all(), f"{int((~passes).sum())} true hits would be discarded by the pre-test"
     assert hit.sum() > 40000
+
+
+def test_bvh_refit_keeps_invariants(rt):
+    rng = np.random.default_rng(12)
+    n = 3000
+    c = rng.uniform(-1, 1, (n, 1, 3)); a = (c + rng.normal(scale=0.03, size=(n, 3, 3))).astype(np.float32)
+    ang = 0.7; R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+    b = a.copy(); b[: n // 2] = b[: n // 2] @ R.T + np.float32([0.3, -0.2, 0.1])      # half of the triangles move rigidly
+    assert rt.bvh_refit_check(a.reshape(-1, 9), b.reshape(-1, 9)) == 0
+    assert rt.bvh_refit_check(a.reshape(-1, 9), a.reshape(-1, 9)) == 0
