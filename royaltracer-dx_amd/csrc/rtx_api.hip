@@ -185,7 +185,7 @@ int rtx_commit_scene(rtx_ctx* c) {
     s.total_weight = B.total_weight;
     // LDS budget per workgroup: stack + top of tree + first triangles, kept <= 64 KiB
     s.stack_depth = B.max_depth + 2;
-    s.stack_private = c->stack_private > 0 ? 1u : 0u;   // measured slower than the LDS column stack (Sponza-class: 95 vs 72 ms); kept as a knob
+    s.stack_private = c->stack_private > 0 ? (uint32_t)c->stack_private : 0u;   // 1 (all private) measured slower than the LDS column (Sponza-class: 95 vs 72 ms)
     if (s.stack_depth > 64) { c->err = "commit: BVH deeper than 62 levels"; return RTX_ERR_INVALID; }
     // LDS per workgroup = traversal stack + top of the tree (+ all triangles of a tiny scene).  Occupancy matters more
     // than cached nodes: on the 262 k-triangle atrium 64 staged nodes (31 KB total, 5 workgroups/CU) beat 256 (88 -> 72 ms)

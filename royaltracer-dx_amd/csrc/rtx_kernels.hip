@@ -346,6 +346,15 @@ int g_refill_min = 20;                                // refill when at least th
 struct StackLds { lds_u32* col; __device__ __forceinline__ void put(int i, uint32_t v) { col[i * kBlock] = v; } __device__ __forceinline__ uint32_t get(int i) const { return col[i * kBlock]; } };
 constexpr int kPrivStack = 64;
 struct StackPriv { uint32_t a[kPrivStack]; __device__ __forceinline__ void put(int i, uint32_t v) { a[i] = v; } __device__ __forceinline__ uint32_t get(int i) const { return a[i]; } };
+// hybrid: the first kHybridLds entries (what a nearest-first traversal normally uses) in the LDS column, the rare overflow of
+// deep trees in a private array — LDS per workgroup drops to 16 KB + staged nodes, so register-limited occupancy (8 waves/SIMD).
+// MEASURED slower than the plain LDS column (Sponza-class 74.8 vs 69.1 ms, Bistro-class 72.2 vs 69.2 ms): kept as a knob only.
+constexpr int kHybridLds = 16;
+struct StackHybrid {
+    lds_u32* col; uint32_t a[kPrivStack - kHybridLds];
+    __device__ __forceinline__ void put(int i, uint32_t v) { if (i < kHybridLds) col[i * kBlock] = v; else a[i - kHybridLds] = v; }
+    __device__ __forceinline__ uint32_t get(int i) const { return i < kHybridLds ? col[i * kBlock] : a[i - kHybridLds]; }
+};
 
 struct RayLane {                                       // per-lane traversal state
     f3 o, d, idir; float tmin, tmax, bt, bu, bv; uint32_t bprim; int32_t cur; int sp; uint32_t item; bool has;
@@ -422,7 +431,7 @@ __device__ __forceinline__ bool refill(RayLane& R, uint32_t* s_head, uint32_t n,
 }
 
 // closest hit for every path in this workgroup's sub-queue: reads ray_o/ray_d, writes hit
-template <bool PRIV>
+template <int STK>   // traversal stack: 0 = LDS column, 1 = private (scratch), 2 = hybrid
 __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin, uint32_t refill_min) {
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_head;
@@ -442,8 +451,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
         }
         return;
     }
-    typename std::conditional<PRIV, StackPriv, StackLds>::type stk;
-    if constexpr (!PRIV) stk.col = L.stack + threadIdx.x;
+    typename std::conditional<STK == 1, StackPriv, typename std::conditional<STK == 2, StackHybrid, StackLds>::type>::type stk;
+    if constexpr (STK != 1) stk.col = L.stack + threadIdx.x;
     RayLane R; R.has = false; R.cur = kDone; R.sp = 0; R.item = 0; R.o = mk3(0, 0, 0); R.d = mk3(0, 0, 1); R.idir = mk3(0, 0, 1);
     R.tmin = 0.0f; R.tmax = 0.0f; R.bt = 0.0f; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim;
     bool drained = false;
@@ -460,7 +469,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
 
 // any-hit for NEE slot j: visible contributions are added to the path's radiance (a path appears at most once
 // per slot, so the read-modify-write needs no atomic and the order of additions per path is fixed)
-template <bool PRIV>
+template <int STK>
 __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const F4* __restrict__ sh_o, const F4* __restrict__ sh_d,
                                                          const F4* __restrict__ sh_c, const uint32_t* __restrict__ shcount, uint32_t qcap, uint32_t refill_min) {
     extern __shared__ F4 lds[];
@@ -489,8 +498,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const Smal
         }
         return;
     }
-    typename std::conditional<PRIV, StackPriv, StackLds>::type stk;
-    if constexpr (!PRIV) stk.col = L.stack + threadIdx.x;
+    typename std::conditional<STK == 1, StackPriv, typename std::conditional<STK == 2, StackHybrid, StackLds>::type>::type stk;
+    if constexpr (STK != 1) stk.col = L.stack + threadIdx.x;
     RayLane R; R.has = false; R.cur = kDone; R.sp = 0; R.item = 0; R.o = mk3(0, 0, 0); R.d = mk3(0, 0, 1); R.idir = mk3(0, 0, 1);
     R.tmin = 0.0f; R.tmax = 0.0f; R.bt = 0.0f; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim;
     bool drained = false;
@@ -1500,7 +1509,8 @@ size_t trace_lds_bytes(const DevScene& sc) {      // the LDS column stack is alw
     return (size_t)sc.lds_nodes * 64 + (size_t)sc.lds_tris * 48 + (size_t)sc.stack_depth * kBlock * 4;
 }
 size_t trace_lds_bytes_queue(const DevScene& sc) {   // queue kernels with a private stack need no LDS stack
-    return (size_t)sc.lds_nodes * 64 + (size_t)sc.lds_tris * 48 + (sc.stack_private ? 0 : (size_t)sc.stack_depth * kBlock * 4);
+    const size_t stack = sc.stack_private == 1 ? 0 : sc.stack_private == 2 ? (size_t)kHybridLds * kBlock * 4 : (size_t)sc.stack_depth * kBlock * 4;
+    return (size_t)sc.lds_nodes * 64 + (size_t)sc.lds_tris * 48 + stack;
 }
 
 void launch_raygen(hipStream_t st, const DevFrame& f, const DevPaths& p, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount) {
@@ -1511,8 +1521,9 @@ void launch_raygen_trace_small(hipStream_t st, const DevScene& sc, const DevFram
 }
 void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t bounce, const uint32_t* queue, const uint32_t* qcount) {
     const float tmin = bounce == 0 ? kTMinCam : kSBias;
-    if (sc.stack_private) hipLaunchKernelGGL(k_trace_closest<true>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, (uint32_t)g_refill_min);
-    else hipLaunchKernelGGL(k_trace_closest<false>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, (uint32_t)g_refill_min);
+    if (sc.stack_private == 1) hipLaunchKernelGGL(k_trace_closest<1>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, (uint32_t)g_refill_min);
+    else if (sc.stack_private == 2) hipLaunchKernelGGL(k_trace_closest<2>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, (uint32_t)g_refill_min);
+    else hipLaunchKernelGGL(k_trace_closest<0>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, (uint32_t)g_refill_min);
 }
 void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce, bool have_hit,
                          const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts) {
@@ -1522,8 +1533,9 @@ void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, 
 }
 void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t j, const uint32_t* shcount) {
     const size_t seg = (size_t)j * f.qcap * f.nblocks;
-    if (sc.stack_private) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, (uint32_t)g_refill_min);
-    else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, (uint32_t)g_refill_min);
+    if (sc.stack_private == 1) hipLaunchKernelGGL(k_trace_shadow<1>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, (uint32_t)g_refill_min);
+    else if (sc.stack_private == 2) hipLaunchKernelGGL(k_trace_shadow<2>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, (uint32_t)g_refill_min);
+    else hipLaunchKernelGGL(k_trace_shadow<0>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, (uint32_t)g_refill_min);
 }
 void launch_shade(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce,
                   const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts) {

@@ -19,7 +19,7 @@ struct DevScene {
     float total_weight;
     uint32_t lds_nodes, lds_tris;   // how many nodes / triangles each workgroup stages in LDS
     uint32_t stack_depth;           // per-lane traversal stack entries (LDS)
-    uint32_t stack_private;         // queue kernels keep the stack in a private (scratch) array instead: higher occupancy on deep trees
+    uint32_t stack_private;         // queue kernels: 0 = stack in the LDS column, 1 = private (scratch) array, 2 = hybrid (16 LDS entries + private overflow)
 };
 
 // one sample batch of one frame

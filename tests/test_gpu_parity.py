@@ -451,3 +451,25 @@ def test_animated_instance_refit_parity(rt, orc, golden_dir):
     ref, _ = o.render(pt)
     assert rel_l2(c.read_accum()[..., :3], ref[..., :3]) <= REL_L2_TOL
     c.close()
+
+
+def test_c4_sizes_4k_shards_and_stack_variants(rt, orc):
+    """C4-shaped run (Sponza-class, 3840x2160, pixel-tile shards) at 1 spp: memory sizing of the queues at 8.3 M pixels,
+    shard reassembly at full size, and the alternative traversal-stack placements give identical images"""
+    sc = rt.Scene.sponza_class(262144, 260)
+    W, H = 3840, 2160
+    base = dict(width=W, height=H, spp=1, max_bounces=3, nee_samples=1, flags=1)
+    imgs = []
+    for stack in (0, 2, 1):
+        c = rt.Context(0); c.set_option(rt.OPT_STACK_PRIVATE, stack); c.upload(sc, W / H)
+        c.clear(W, H); c.render(rt.Params(**base)); imgs.append(c.read_accum())
+        if stack == 0:
+            st = c.stats(); assert st.rays_primary == W * H
+            c.clear(W, H)
+            for r in range(8):
+                c.render(rt.Params(shard_rank=r, shard_count=8, **base))
+            assert np.array_equal(bits(c.read_accum()), bits(imgs[0]))
+        c.close()
+    assert np.array_equal(bits(imgs[0]), bits(imgs[1])) and np.array_equal(bits(imgs[0]), bits(imgs[2]))
+    # a 64 x 36 crop-sized oracle check is done elsewhere; here: plausibility + determinism
+    assert np.isfinite(imgs[0]).all() and (imgs[0][..., 3] == 1).all() and imgs[0][..., :3].mean() > 0.01
