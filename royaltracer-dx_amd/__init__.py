@@ -36,7 +36,7 @@ FLAG_JITTER = 2
 K_RAYGEN, K_TRACE, K_SHADE, K_SHADOW, K_ACCUM, K_SORT, K_BOUNCE, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 8
 KERNEL_NAMES = {K_RAYGEN: "raygen", K_TRACE: "trace_closest", K_SHADE: "shade", K_SHADOW: "trace_shadow", K_ACCUM: "accumulate", K_SORT: "sort", K_BOUNCE: "bounce_fused"}
 OPT_KERNEL_TIMING, OPT_PATHS_PER_BATCH, OPT_SORT_MATERIALS, OPT_LDS_NODES, OPT_SMALL_SCENE, OPT_FUSED_BOUNCE, OPT_BOUNCE_VARIANT = 1, 2, 3, 4, 5, 6, 7
-OPT_REFILL_MIN, OPT_STACK_PRIVATE = 8, 9
+OPT_REFILL_MIN, OPT_STACK_PRIVATE, OPT_TRACE_SCHED = 8, 9, 10
 
 
 class RtxError(RuntimeError):
@@ -142,6 +142,7 @@ _sig("rtxh_mat4_inverse", None, _fp, _fp)
 _sig("rtxh_half_round", C.c_float, C.c_float)
 _sig("rtxh_bvh_check", C.c_int, _vp, _u32, _u32p, _u32p, _u32p)
 _sig("rtxh_bvh_refit_check", C.c_int, _vp, _vp, _u32)
+_sig("rtxh_bvh4_check", C.c_int, _vp, _u32, _u32p, _u32p)
 _sig("rtxh_scene_small_records", C.c_int, _vp, _vp, _vp, _u32, _u32p, _fp, _fp)
 _sig("rtxh_renderer_create", _vp, _u32, _u32, C.c_char_p, C.c_int)
 _sig("rtxh_renderer_set_scene", C.c_int, _vp, _vp)
@@ -275,6 +276,13 @@ def bvh_check(world_tris):
     nodes, depth, leaf = _u32(), _u32(), _u32()
     rc = lib.rtxh_bvh_check(_ptr(w), len(w), C.byref(nodes), C.byref(depth), C.byref(leaf))
     return rc, nodes.value, depth.value, leaf.value
+
+
+def bvh4_check(world_tris):
+    w = _f32(world_tris).reshape(-1, 9)
+    nodes, stack = _u32(), _u32()
+    rc = lib.rtxh_bvh4_check(_ptr(w), len(w), C.byref(nodes), C.byref(stack))
+    return rc, nodes.value, stack.value
 
 
 # ------------------------------------------------------------------------------------------------

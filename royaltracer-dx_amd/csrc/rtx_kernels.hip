@@ -125,9 +125,9 @@ struct TraceLds {
 // stage the top of the BVH and the first triangles into LDS (coalesced 16-B copies)
 __device__ __forceinline__ TraceLds stage_lds(const DevScene& sc, F4* lds_generic) {
     TraceLds L;
-    lds_v4f* ln = (lds_v4f*)lds_generic; lds_v4f* lt = ln + (size_t)sc.lds_nodes * 4;
+    lds_v4f* ln = (lds_v4f*)lds_generic; lds_v4f* lt = ln + (size_t)sc.lds_nodes * 8;
     const v4f* gn = (const v4f*)sc.nodes; const v4f* gt = (const v4f*)(sc.nsmall ? sc.small_tris : sc.tris);
-    for (uint32_t i = threadIdx.x; i < sc.lds_nodes * 4u; i += kBlock) ln[i] = gn[i];
+    for (uint32_t i = threadIdx.x; i < sc.lds_nodes * 8u; i += kBlock) ln[i] = gn[i];
     for (uint32_t i = threadIdx.x; i < sc.lds_tris * 3u; i += kBlock) lt[i] = gt[i];
     L.nodes = ln; L.tris = lt;
     L.stack = (lds_u32*)(lt + (size_t)sc.lds_tris * 3);
@@ -152,17 +152,57 @@ __device__ __forceinline__ bool tri_test(f3 o, f3 d, v4f v0w, v4f e1w, v4f e2w, 
     return t > tmin && t < tmax;
 }
 
-// conservative slab test for one child box; returns entry distance in tn
-__device__ __forceinline__ bool box_test(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz,
-                                         f3 o, f3 idir, float tmin, float tbest, float& tn) {
-    const float tx0 = (bminx - o.x) * idir.x, tx1 = (bmaxx - o.x) * idir.x;
-    const float ty0 = (bminy - o.y) * idir.y, ty1 = (bmaxy - o.y) * idir.y;
-    const float tz0 = (bminz - o.z) * idir.z, tz1 = (bmaxz - o.z) * idir.z;
-    const float lo = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
-    const float hi = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
-    tn = lo;
-    return lo * 0.999998f <= hi * 1.000002f;     // lo, hi >= tmin >= 0 here
+// ---- 4-wide node step ------------------------------------------------------------------------------------------
+// One traversal step fetches a whole Node4GPU (one 128-B line, or 7 ds_read_b128 for the staged top of the tree), runs the
+// conservative slab test on its four child boxes at once (the SoA rows make every operation a 4-vector one: packed
+// sub / mul, v_min / v_max, v_max3 / v_min3), sorts the hit children by entry distance with a 5-exchange network, pushes the
+// farther ones far-to-near and returns the nearest.  The slab test is the padded one of the binary walk: children that
+// the exact triangle tests could accept are never culled, so the closest hit stays the minimum over ALL triangles.
+typedef int v4i __attribute__((ext_vector_type(4)));
+struct Node4R { v4f mnx, mny, mnz, mxx, mxy, mxz; v4i ch; };
+constexpr int32_t kDone = (int32_t)0x80000000;       // traversal finished (distinct from every leaf code)
+
+__device__ __forceinline__ Node4R load_node4(const DevScene& sc, const TraceLds& L, uint32_t idx) {
+    Node4R N;
+    if (idx < sc.lds_nodes) { const lds_v4f* n = L.nodes + idx * 8u; N.mnx = n[0]; N.mny = n[1]; N.mnz = n[2]; N.mxx = n[3]; N.mxy = n[4]; N.mxz = n[5]; N.ch = (v4i)n[6]; }
+    else { const v4f* n = (const v4f*)(sc.nodes + idx); N.mnx = n[0]; N.mny = n[1]; N.mnz = n[2]; N.mxx = n[3]; N.mxy = n[4]; N.mxz = n[5]; N.ch = (v4i)n[6]; }
+    return N;
 }
+__device__ __forceinline__ void cmp_swap(float& ka, int32_t& ca, float& kb, int32_t& cb) {
+    const bool sw = kb < ka;
+    const float k0 = sw ? kb : ka, k1 = sw ? ka : kb;
+    const int32_t c0 = sw ? cb : ca, c1 = sw ? ca : cb;
+    ka = k0; kb = k1; ca = c0; cb = c1;
+}
+template <class STK>
+__device__ __forceinline__ int32_t node4_step(const Node4R& N, f3 o, f3 idir, float tmin, float tbest, STK& stk, int& sp) {
+    const v4f tx0 = (N.mnx - o.x) * idir.x, tx1 = (N.mxx - o.x) * idir.x;
+    const v4f ty0 = (N.mny - o.y) * idir.y, ty1 = (N.mxy - o.y) * idir.y;
+    const v4f tz0 = (N.mnz - o.z) * idir.z, tz1 = (N.mxz - o.z) * idir.z;
+    const v4f vmin = {tmin, tmin, tmin, tmin}, vbest = {tbest, tbest, tbest, tbest};
+    const v4f lo = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(tx0, tx1), __builtin_elementwise_min(ty0, ty1)),
+                                             __builtin_elementwise_max(__builtin_elementwise_min(tz0, tz1), vmin));
+    const v4f hi = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(tx0, tx1), __builtin_elementwise_max(ty0, ty1)),
+                                             __builtin_elementwise_min(__builtin_elementwise_max(tz0, tz1), vbest));
+    const v4f lo_s = lo * 0.999998f, hi_s = hi * 1.000002f;     // lo, hi >= tmin >= 0 here
+    const float inf = __builtin_inff();
+    float k0 = (lo_s.x <= hi_s.x && N.ch.x != kEmptyChild) ? lo.x : inf;
+    float k1 = (lo_s.y <= hi_s.y && N.ch.y != kEmptyChild) ? lo.y : inf;
+    float k2 = (lo_s.z <= hi_s.z && N.ch.z != kEmptyChild) ? lo.z : inf;
+    float k3 = (lo_s.w <= hi_s.w && N.ch.w != kEmptyChild) ? lo.w : inf;
+    int32_t c0 = N.ch.x, c1 = N.ch.y, c2 = N.ch.z, c3 = N.ch.w;
+    cmp_swap(k0, c0, k1, c1); cmp_swap(k2, c2, k3, c3); cmp_swap(k0, c0, k2, c2); cmp_swap(k1, c1, k3, c3); cmp_swap(k1, c1, k2, c2);
+    if (k3 < inf) { stk.put(sp, (uint32_t)c3); sp++; }
+    if (k2 < inf) { stk.put(sp, (uint32_t)c2); sp++; }
+    if (k1 < inf) { stk.put(sp, (uint32_t)c1); sp++; }
+    if (k0 < inf) return c0;
+    if (sp == 0) return kDone;
+    sp--; return (int32_t)stk.get(sp);
+}
+
+// traversal stack: per-lane column in LDS (conflict-free, but its footprint limits occupancy on deep trees), or a
+// private array that hipcc places in scratch (lane-interleaved, so a wave-level push is one contiguous 256-B store)
+struct StackLds { lds_u32* col; __device__ __forceinline__ void put(int i, uint32_t v) { col[i * kBlock] = v; } __device__ __forceinline__ uint32_t get(int i) const { return col[i * kBlock]; } };
 
 template <bool ANY>
 __device__ __forceinline__ void traverse(const DevScene& sc, const TraceLds& L, f3 o, f3 d, float tmin, float tmax,
@@ -173,29 +213,16 @@ __device__ __forceinline__ void traverse(const DevScene& sc, const TraceLds& L, 
     const float dzs = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
     const f3 idir = mk3(__builtin_amdgcn_rcpf(dxs), __builtin_amdgcn_rcpf(dys), __builtin_amdgcn_rcpf(dzs));
     bt = tmax; bu = 0.0f; bv = 0.0f; bprim = kMissPrim;
-    lds_u32* stk = L.stack + threadIdx.x;
+    StackLds stk; stk.col = L.stack + threadIdx.x;
     int sp = 0;
     int32_t cur = 0;
-    while (true) {
+    while (cur != kDone) {
         if (cur >= 0) {
-            v4f a, b, c, dd;
-            if ((uint32_t)cur < sc.lds_nodes) { const lds_v4f* n = L.nodes + (uint32_t)cur * 4u; a = n[0]; b = n[1]; c = n[2]; dd = n[3]; }
-            else { const v4f* n = (const v4f*)(sc.nodes + cur); a = n[0]; b = n[1]; c = n[2]; dd = n[3]; }
-            float t0, t1;
-            const bool h0 = box_test(a.x, a.y, a.z, a.w, b.x, b.y, o, idir, tmin, bt, t0);
-            const bool h1 = box_test(b.z, b.w, c.x, c.y, c.z, c.w, o, idir, tmin, bt, t1);
-            int32_t c0 = (int32_t)f2u(dd.x), c1 = (int32_t)f2u(dd.y);
-            if (h0 && h1) {
-                if (t1 < t0) { int32_t tmp = c0; c0 = c1; c1 = tmp; }
-                stk[sp * kBlock] = (uint32_t)c1; sp++;
-                cur = c0;
-            } else if (h0) cur = c0;
-            else if (h1) cur = c1;
-            else { if (sp == 0) break; sp--; cur = (int32_t)stk[sp * kBlock]; }
+            const Node4R N = load_node4(sc, L, (uint32_t)cur);
+            cur = node4_step(N, o, idir, tmin, bt, stk, sp);
         } else {
             const uint32_t v = ~(uint32_t)cur;
             const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
-            bool done = false;
             for (uint32_t k = 0; k < cnt; k++) {
                 const uint32_t slot = first + k;
                 v4f v0, e1, e2;
@@ -203,14 +230,13 @@ __device__ __forceinline__ void traverse(const DevScene& sc, const TraceLds& L, 
                 else { const v4f* t = (const v4f*)(sc.tris + slot); v0 = t[0]; e1 = t[1]; e2 = t[2]; }
                 float t, u, w;
                 if (tri_test(o, d, v0, e1, e2, tmin, tmax, t, u, w)) {
-                    if (ANY) { bprim = 0u; done = true; break; }
+                    if (ANY) { bprim = 0u; return; }
                     const uint32_t gid = f2u(v0.w);
                     if (t < bt || (t == bt && gid < bprim)) { bt = t; bu = u; bv = w; bprim = gid; }
                 }
             }
-            if (ANY && done) break;
             if (sp == 0) break;
-            sp--; cur = (int32_t)stk[sp * kBlock];
+            sp--; cur = (int32_t)stk.get(sp);
         }
     }
 }
@@ -338,12 +364,10 @@ __global__ __launch_bounds__(kBlock) void k_raygen_trace_small(DevScene sc, cons
 // until each holds a leaf (or is done)" followed by "all lanes with a leaf test its triangles" (while-while).
 // Exit: a wave leaves when the sub-queue is exhausted and no lane holds a ray — every wave reaches that.
 // ---------------------------------------------------------------------------------------------
-constexpr int32_t kDone = (int32_t)0x80000000;       // traversal finished (distinct from every leaf code)
-int g_refill_min = 20;                                // refill when at least this many lanes are idle (tuning knob)
+int g_refill_min = 20;
+int g_trace_sched = 0;                                // 0 = while-while, 1 = voted node / triangle steps (MEASURED slower: 101 vs 72 ms, the
+                                                      // traversal is bound by the texture addresser / L1, not by VALU lanes: profiles/r01_pmc_bvh.md)                                // refill when at least this many lanes are idle (tuning knob)
 
-// traversal stack: per-lane column in LDS (conflict-free, but its footprint limits occupancy on deep trees), or a
-// private array that hipcc places in scratch (lane-interleaved, so a wave-level push is one contiguous 256-B store)
-struct StackLds { lds_u32* col; __device__ __forceinline__ void put(int i, uint32_t v) { col[i * kBlock] = v; } __device__ __forceinline__ uint32_t get(int i) const { return col[i * kBlock]; } };
 constexpr int kPrivStack = 64;
 struct StackPriv { uint32_t a[kPrivStack]; __device__ __forceinline__ void put(int i, uint32_t v) { a[i] = v; } __device__ __forceinline__ uint32_t get(int i) const { return a[i]; } };
 // hybrid: the first kHybridLds entries (what a nearest-first traversal normally uses) in the LDS column, the rare overflow of
@@ -358,6 +382,7 @@ struct StackHybrid {
 
 struct RayLane {                                       // per-lane traversal state
     f3 o, d, idir; float tmin, tmax, bt, bu, bv; uint32_t bprim; int32_t cur; int sp; uint32_t item; bool has;
+    uint32_t lk;                                       // triangles of the current leaf already tested (voted schedule)
 };
 __device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, float tmax, uint32_t item) {
     R.o = o; R.d = d; R.tmin = tmin; R.tmax = tmax; R.item = item;
@@ -365,27 +390,14 @@ __device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, fl
     const float dys = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
     const float dzs = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
     R.idir = mk3(__builtin_amdgcn_rcpf(dxs), __builtin_amdgcn_rcpf(dys), __builtin_amdgcn_rcpf(dzs));
-    R.bt = tmax; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.cur = 0; R.sp = 0; R.has = true;
+    R.bt = tmax; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.cur = 0; R.sp = 0; R.has = true; R.lk = 0;
 }
 // all lanes holding an internal node walk down until they hold a leaf or are done
 template <bool ANY, class STK>
 __device__ __forceinline__ void walk_internal(const DevScene& sc, const TraceLds& L, RayLane& R, STK& stk) {
     while (R.has && R.cur >= 0) {
-        v4f a, b, c, dd;
-        if ((uint32_t)R.cur < sc.lds_nodes) { const lds_v4f* n = L.nodes + (uint32_t)R.cur * 4u; a = n[0]; b = n[1]; c = n[2]; dd = n[3]; }
-        else { const v4f* n = (const v4f*)(sc.nodes + R.cur); a = n[0]; b = n[1]; c = n[2]; dd = n[3]; }
-        float t0, t1;
-        const bool h0 = box_test(a.x, a.y, a.z, a.w, b.x, b.y, R.o, R.idir, R.tmin, R.bt, t0);
-        const bool h1 = box_test(b.z, b.w, c.x, c.y, c.z, c.w, R.o, R.idir, R.tmin, R.bt, t1);
-        int32_t c0 = (int32_t)f2u(dd.x), c1 = (int32_t)f2u(dd.y);
-        if (h0 && h1) {
-            if (t1 < t0) { const int32_t tmp = c0; c0 = c1; c1 = tmp; }
-            stk.put(R.sp, (uint32_t)c1); R.sp++;
-            R.cur = c0;
-        } else if (h0) R.cur = c0;
-        else if (h1) R.cur = c1;
-        else if (R.sp == 0) R.cur = kDone;
-        else { R.sp--; R.cur = (int32_t)stk.get(R.sp); }
+        const Node4R N = load_node4(sc, L, (uint32_t)R.cur);
+        R.cur = node4_step(N, R.o, R.idir, R.tmin, R.bt, stk, R.sp);
     }
 }
 template <bool ANY, class STK>
@@ -411,6 +423,44 @@ __device__ __forceinline__ void process_leaf(const DevScene& sc, const TraceLds&
         else { R.sp--; R.cur = (int32_t)stk.get(R.sp); }
     }
 }
+// Voted schedule (g_trace_sched = 1): instead of "walk until EVERY lane holds a leaf, then test every lane's whole leaf" —
+// whose node loop runs for the slowest of 64 lanes — each iteration the wave votes for the step most of its busy lanes are
+// waiting for: one 4-wide node step, or one triangle test.  Lanes in the minority state keep their state and wait; node
+// steps keep turning node lanes into leaf lanes, so the minority always gets its turn.
+template <bool ANY, class STK>
+__device__ __forceinline__ void voted_step(const DevScene& sc, const TraceLds& L, RayLane& R, STK& stk) {
+    const bool in_node = R.has && R.cur >= 0;
+    const bool in_leaf = R.has && R.cur < 0 && R.cur != kDone;
+    const uint32_t ni = (uint32_t)__popcll(__ballot(in_node)), nl = (uint32_t)__popcll(__ballot(in_leaf));
+    if (ni >= nl) {
+        if (in_node) {
+            const Node4R N = load_node4(sc, L, (uint32_t)R.cur);
+            R.cur = node4_step(N, R.o, R.idir, R.tmin, R.bt, stk, R.sp);
+        }
+    } else if (in_leaf) {
+        const uint32_t v = ~(uint32_t)R.cur;
+        const uint32_t slot = (v >> 3) + R.lk, cnt = (v & 7u) + 1u;
+        v4f v0, e1, e2;
+        if (slot < sc.lds_tris) { const lds_v4f* t = L.tris + slot * 3u; v0 = t[0]; e1 = t[1]; e2 = t[2]; }
+        else { const v4f* t = (const v4f*)(sc.tris + slot); v0 = t[0]; e1 = t[1]; e2 = t[2]; }
+        float t, u, w;
+        bool occluded = false;
+        if (tri_test(R.o, R.d, v0, e1, e2, R.tmin, R.tmax, t, u, w)) {
+            if (ANY) occluded = true;
+            else {
+                const uint32_t gid = f2u(v0.w);
+                if (t < R.bt || (t == R.bt && gid < R.bprim)) { R.bt = t; R.bu = u; R.bv = w; R.bprim = gid; }
+            }
+        }
+        R.lk++;
+        if (ANY && occluded) { R.bprim = 0u; R.cur = kDone; }
+        else if (R.lk == cnt) {
+            R.lk = 0;
+            if (R.sp == 0) R.cur = kDone;
+            else { R.sp--; R.cur = (int32_t)stk.get(R.sp); }
+        }
+    }
+}
 // wave-level refill: returns false when the wave may exit (queue exhausted and nothing in flight)
 template <class Fetch>
 __device__ __forceinline__ bool refill(RayLane& R, uint32_t* s_head, uint32_t n, bool& drained, uint32_t refill_min, Fetch fetch) {
@@ -432,7 +482,7 @@ __device__ __forceinline__ bool refill(RayLane& R, uint32_t* s_head, uint32_t n,
 
 // closest hit for every path in this workgroup's sub-queue: reads ray_o/ray_d, writes hit
 template <int STK>   // traversal stack: 0 = LDS column, 1 = private (scratch), 2 = hybrid
-__global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin, uint32_t refill_min) {
+__global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin, uint32_t refill_min, uint32_t sched) {
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_head;
     const uint32_t n = qcount[blockIdx.x];
@@ -454,15 +504,15 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
     typename std::conditional<STK == 1, StackPriv, typename std::conditional<STK == 2, StackHybrid, StackLds>::type>::type stk;
     if constexpr (STK != 1) stk.col = L.stack + threadIdx.x;
     RayLane R; R.has = false; R.cur = kDone; R.sp = 0; R.item = 0; R.o = mk3(0, 0, 0); R.d = mk3(0, 0, 1); R.idir = mk3(0, 0, 1);
-    R.tmin = 0.0f; R.tmax = 0.0f; R.bt = 0.0f; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim;
+    R.tmin = 0.0f; R.tmax = 0.0f; R.bt = 0.0f; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.lk = 0;
     bool drained = false;
     while (refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) {
                const uint32_t pid = myq[idx];
                const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
                ray_begin(R, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, pid);
            })) {
-        walk_internal<false>(sc, L, R, stk);
-        process_leaf<false>(sc, L, R, stk);
+        if (sched) voted_step<false>(sc, L, R, stk);
+        else { walk_internal<false>(sc, L, R, stk); process_leaf<false>(sc, L, R, stk); }
         if (R.has && R.cur == kDone) { p.hit[R.item] = {R.bt, R.bu, R.bv, u2f(R.bprim)}; R.has = false; }
     }
 }
@@ -471,7 +521,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
 // per slot, so the read-modify-write needs no atomic and the order of additions per path is fixed)
 template <int STK>
 __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const F4* __restrict__ sh_o, const F4* __restrict__ sh_d,
-                                                         const F4* __restrict__ sh_c, const uint32_t* __restrict__ shcount, uint32_t qcap, uint32_t refill_min) {
+                                                         const F4* __restrict__ sh_c, const uint32_t* __restrict__ shcount, uint32_t qcap, uint32_t refill_min, uint32_t sched) {
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_head;
     const uint32_t n = shcount[blockIdx.x];
@@ -501,14 +551,14 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const Smal
     typename std::conditional<STK == 1, StackPriv, typename std::conditional<STK == 2, StackHybrid, StackLds>::type>::type stk;
     if constexpr (STK != 1) stk.col = L.stack + threadIdx.x;
     RayLane R; R.has = false; R.cur = kDone; R.sp = 0; R.item = 0; R.o = mk3(0, 0, 0); R.d = mk3(0, 0, 1); R.idir = mk3(0, 0, 1);
-    R.tmin = 0.0f; R.tmax = 0.0f; R.bt = 0.0f; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim;
+    R.tmin = 0.0f; R.tmax = 0.0f; R.bt = 0.0f; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.lk = 0;
     bool drained = false;
     while (refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) {
                const F4 so = sh_o[qb + idx], sd = sh_d[qb + idx];
                ray_begin(R, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, idx);
            })) {
-        walk_internal<true>(sc, L, R, stk);
-        process_leaf<true>(sc, L, R, stk);
+        if (sched) voted_step<true>(sc, L, R, stk);
+        else { walk_internal<true>(sc, L, R, stk); process_leaf<true>(sc, L, R, stk); }
         if (R.has && R.cur == kDone) { finish(R.item, R.bprim != kMissPrim); R.has = false; }
     }
 }
@@ -1506,11 +1556,11 @@ static inline uint32_t grid_for(uint32_t items, uint32_t max_blocks) {
     return b < max_blocks ? b : max_blocks;
 }
 size_t trace_lds_bytes(const DevScene& sc) {      // the LDS column stack is always reserved: debug / pass-1 kernels use it
-    return (size_t)sc.lds_nodes * 64 + (size_t)sc.lds_tris * 48 + (size_t)sc.stack_depth * kBlock * 4;
+    return (size_t)sc.lds_nodes * 128 + (size_t)sc.lds_tris * 48 + (size_t)sc.stack_depth * kBlock * 4;
 }
 size_t trace_lds_bytes_queue(const DevScene& sc) {   // queue kernels with a private stack need no LDS stack
     const size_t stack = sc.stack_private == 1 ? 0 : sc.stack_private == 2 ? (size_t)kHybridLds * kBlock * 4 : (size_t)sc.stack_depth * kBlock * 4;
-    return (size_t)sc.lds_nodes * 64 + (size_t)sc.lds_tris * 48 + stack;
+    return (size_t)sc.lds_nodes * 128 + (size_t)sc.lds_tris * 48 + stack;
 }
 
 void launch_raygen(hipStream_t st, const DevFrame& f, const DevPaths& p, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount) {
@@ -1521,9 +1571,9 @@ void launch_raygen_trace_small(hipStream_t st, const DevScene& sc, const DevFram
 }
 void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t bounce, const uint32_t* queue, const uint32_t* qcount) {
     const float tmin = bounce == 0 ? kTMinCam : kSBias;
-    if (sc.stack_private == 1) hipLaunchKernelGGL(k_trace_closest<1>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, (uint32_t)g_refill_min);
-    else if (sc.stack_private == 2) hipLaunchKernelGGL(k_trace_closest<2>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, (uint32_t)g_refill_min);
-    else hipLaunchKernelGGL(k_trace_closest<0>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, (uint32_t)g_refill_min);
+    if (sc.stack_private == 1) hipLaunchKernelGGL(k_trace_closest<1>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, (uint32_t)g_refill_min, (uint32_t)g_trace_sched);
+    else if (sc.stack_private == 2) hipLaunchKernelGGL(k_trace_closest<2>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, (uint32_t)g_refill_min, (uint32_t)g_trace_sched);
+    else hipLaunchKernelGGL(k_trace_closest<0>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, (uint32_t)g_refill_min, (uint32_t)g_trace_sched);
 }
 void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce, bool have_hit,
                          const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts) {
@@ -1533,9 +1583,9 @@ void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, 
 }
 void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t j, const uint32_t* shcount) {
     const size_t seg = (size_t)j * f.qcap * f.nblocks;
-    if (sc.stack_private == 1) hipLaunchKernelGGL(k_trace_shadow<1>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, (uint32_t)g_refill_min);
-    else if (sc.stack_private == 2) hipLaunchKernelGGL(k_trace_shadow<2>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, (uint32_t)g_refill_min);
-    else hipLaunchKernelGGL(k_trace_shadow<0>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, (uint32_t)g_refill_min);
+    if (sc.stack_private == 1) hipLaunchKernelGGL(k_trace_shadow<1>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, (uint32_t)g_refill_min, (uint32_t)g_trace_sched);
+    else if (sc.stack_private == 2) hipLaunchKernelGGL(k_trace_shadow<2>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, (uint32_t)g_refill_min, (uint32_t)g_trace_sched);
+    else hipLaunchKernelGGL(k_trace_shadow<0>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, (uint32_t)g_refill_min, (uint32_t)g_trace_sched);
 }
 void launch_shade(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce,
                   const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts) {

@@ -7,7 +7,7 @@ namespace rtx {
 
 // read-only scene in HBM
 struct DevScene {
-    const NodeGPU*  nodes;  uint32_t nnodes;
+    const Node4GPU* nodes;  uint32_t nnodes;
     const TriGPU*   tris;   uint32_t ntris;
     const TriShade* shade;
     const SmallRecPair* small; uint32_t nsmall;   // nsmall != 0: tiny scene: nsmall pre-test records (planar polygons), no BVH
@@ -48,7 +48,8 @@ struct DevPaths {
     F4* sh_c;    // contribution.xyz, pid bits
 };
 
-extern int g_refill_min;       // tuning knob: idle lanes that trigger a refill in the persistent traversal
+extern int g_refill_min;
+extern int g_trace_sched;       // tuning knob: idle lanes that trigger a refill in the persistent traversal
 extern int g_sort_materials;   // 1 = material-sorted shading in k_shade (general path)
 extern int g_bounce_variant;   // tuning knob: waves/SIMD the fused kernel is compiled for (4, 5 or 6)
 size_t trace_lds_bytes(const DevScene& sc);

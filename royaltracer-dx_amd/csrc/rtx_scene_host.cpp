@@ -213,6 +213,7 @@ bool SceneHost::build(BuiltScene& B) {
     if (refit) refit_bvh(wtri, 1e-6f * scale, B.nodes, leaf_order);
     else build_bvh(wtri, 1e-6f * scale, B.nodes, leaf_order, B.max_depth);
     B.refit_count = refit ? B.refit_count + 1 : 0;
+    collapse_bvh4(B.nodes, B.nodes4, B.stack4);          // derived data: redone after a refit too (O(nodes))
     topo_dirty = false;
     B.tris.resize(leaf_order.size());
     for (size_t s = 0; s < leaf_order.size(); s++) {
@@ -472,6 +473,55 @@ void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGP
             nodes[h] = N;
         }
     }
+}
+
+// 4-wide collapse.  Each wide node starts from a binary node's two children and repeatedly replaces the internal child of
+// largest surface area by that child's two children until it has four (or only leaves are left).  The child boxes are the
+// binary tree's (already padded) boxes, copied bit for bit, so the wide tree is exactly as conservative as the binary one.
+void collapse_bvh4(const std::vector<NodeGPU>& n2, std::vector<Node4GPU>& n4, uint32_t& max_stack) {
+    struct Ch { float mn[3], mx[3]; int32_t c; };
+    auto get = [](const NodeGPU& N, int which) {
+        Ch r;
+        if (which == 0) { r.mn[0] = N.a.x; r.mn[1] = N.a.y; r.mn[2] = N.a.z; r.mx[0] = N.a.w; r.mx[1] = N.b.x; r.mx[2] = N.b.y; r.c = (int32_t)f2u(N.d.x); }
+        else            { r.mn[0] = N.b.z; r.mn[1] = N.b.w; r.mn[2] = N.c.x; r.mx[0] = N.c.y; r.mx[1] = N.c.z; r.mx[2] = N.c.w; r.c = (int32_t)f2u(N.d.y); }
+        return r;
+    };
+    auto area = [](const Ch& b) { const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2]; return dx * dy + dy * dz + dz * dx; };
+    n4.clear(); max_stack = 0;
+    if (n2.empty()) return;
+    std::vector<int32_t> src; src.push_back(0);            // binary node behind each wide node, breadth-first
+    for (size_t h = 0; h < src.size(); h++) {
+        Ch ch[4]; int m = 0;
+        const NodeGPU& N = n2[(size_t)src[h]];
+        for (int w = 0; w < 2; w++) { Ch c = get(N, w); if (c.c != kEmptyChild) ch[m++] = c; }
+        while (m < 4) {
+            int best = -1; float ba = -1.0f;
+            for (int k = 0; k < m; k++) if (ch[k].c >= 0) { const float a = area(ch[k]); if (best < 0 || a > ba) { ba = a; best = k; } }
+            if (best < 0) break;
+            const NodeGPU& C = n2[(size_t)ch[best].c];
+            const Ch a = get(C, 0), b = get(C, 1);           // internal nodes below the root always have two children
+            ch[best] = a; ch[m++] = b;
+        }
+        Node4GPU W{};
+        float* rows[6] = {&W.mnx.x, &W.mny.x, &W.mnz.x, &W.mxx.x, &W.mxy.x, &W.mxz.x};
+        for (int k = 0; k < 4; k++) {
+            if (k < m) {
+                for (int a = 0; a < 3; a++) { rows[a][k] = ch[k].mn[a]; rows[3 + a][k] = ch[k].mx[a]; }
+                if (ch[k].c >= 0) { W.child[k] = (int32_t)src.size(); src.push_back(ch[k].c); } else W.child[k] = ch[k].c;
+            } else {
+                for (int a = 0; a < 3; a++) { rows[a][k] = INFINITY; rows[3 + a][k] = -INFINITY; }
+                W.child[k] = kEmptyChild;
+            }
+        }
+        n4.push_back(W);
+    }
+    std::vector<uint32_t> need(n4.size(), 0);                // children have larger indices: one reverse sweep
+    for (size_t i = n4.size(); i-- > 0;) {
+        uint32_t m = 0, deep = 0;
+        for (int k = 0; k < 4; k++) { const int32_t c = n4[i].child[k]; if (c == kEmptyChild) continue; m++; if (c >= 0) deep = std::max(deep, need[(size_t)c]); }
+        need[i] = (m ? m - 1 : 0) + deep;
+    }
+    max_stack = need[0];
 }
 
 }  // namespace rtx

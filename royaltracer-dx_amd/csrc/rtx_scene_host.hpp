@@ -18,7 +18,9 @@ struct InstHost { uint32_t mesh; float o2w[16]; float nrm[16]; float o2w_inv[16]
 
 struct BuiltScene {
     std::vector<MatGPU>   mats;
-    std::vector<NodeGPU>  nodes;
+    std::vector<NodeGPU>  nodes;      // binary tree (build / refit form, host only)
+    std::vector<Node4GPU> nodes4;     // 4-wide collapse of `nodes` (device traversal form)
+    uint32_t stack4 = 0;              // traversal stack entries the 4-wide tree can need
     std::vector<TriGPU>   tris;       // leaf order
     // tiny-scene path (only when the scene has <= kSmallSceneMaxTris triangles): pre-test records + their triangles
     std::vector<SmallRecPair> small_recs; std::vector<TriGPU> small_tris; uint32_t small_nrec = 0;
@@ -53,5 +55,8 @@ struct SceneHost {
 void refit_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGPU>& nodes, const std::vector<uint32_t>& leaf_order);
 void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGPU>& nodes,
                std::vector<uint32_t>& leaf_order, uint32_t& max_depth);
+// collapse the binary tree into the 4-wide device form (largest-area internal child opened first); max_stack = bound on the
+// entries a nearest-first traversal can hold (up to 3 pushes per level)
+void collapse_bvh4(const std::vector<NodeGPU>& nodes2, std::vector<Node4GPU>& nodes4, uint32_t& max_stack);
 
 }  // namespace rtx

@@ -16,6 +16,13 @@ struct alignas(16) F4 { float x, y, z, w; };
 struct alignas(16) NodeGPU { F4 a, b, c, d; };
 constexpr int32_t kEmptyChild = 0x7FFFFFFF;   // never visited (box is inverted)
 
+// Device traversal format: 4-wide node collapsed from the binary tree (one 128-B fetch = one L2 line per step, half the
+// dependent fetches of the binary walk).  Child boxes are stored SoA so that one 16-B load brings the same plane of all
+// four children; `child` uses the NodeGPU codes (internal index / leaf / kEmptyChild for unused slots, whose box is
+// NOT relied upon).  Breadth-first order: children have larger indices than their parent, [0, K) is the top of the tree.
+struct alignas(16) Node4GPU { F4 mnx, mny, mnz, mxx, mxy, mxz; int32_t child[4]; uint32_t pad[4]; };
+static_assert(sizeof(Node4GPU) == 128, "Node4GPU must be one 128-byte line");
+
 // World-space triangle in leaf order: v0 (w = global triangle id bits), e1 = v1 - v0, e2 = v2 - v0.
 struct alignas(16) TriGPU { F4 v0, e1, e2; };
 

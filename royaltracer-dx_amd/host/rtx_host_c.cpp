@@ -115,6 +115,67 @@ static int bvh_validate(const std::vector<float>& w, const std::vector<rtx::Node
     return 0;
 }
 
+// the 4-wide collapse: same coverage properties, checked on the wide nodes themselves
+static int bvh4_validate(const std::vector<float>& w, const std::vector<rtx::Node4GPU>& nodes, const std::vector<uint32_t>& order, uint32_t* max_stack_seen) {
+    const uint32_t ntris = (uint32_t)(w.size() / 9);
+    struct It { int32_t child; float mn[3], mx[3]; uint32_t depth_pushes; };
+    std::vector<uint8_t> covered(ntris, 0), visited(nodes.size(), 0);
+    std::vector<It> st;
+    const float inf = INFINITY;
+    uint32_t deepest = 0;
+    auto push_children = [&](size_t ni, const float* pmn, const float* pmx, uint32_t pushes) -> int {
+        const rtx::Node4GPU& N = nodes[ni];
+        if (visited[ni]) return 11;
+        visited[ni] = 1;
+        const float* rows[6] = {&N.mnx.x, &N.mny.x, &N.mnz.x, &N.mxx.x, &N.mxy.x, &N.mxz.x};
+        uint32_t m = 0;
+        for (int k = 0; k < 4; k++) if (N.child[k] != rtx::kEmptyChild) m++;
+        for (int k = 0; k < 4; k++) {
+            if (N.child[k] == rtx::kEmptyChild) continue;
+            if (N.child[k] >= 0 && (size_t)N.child[k] <= ni) return 12;      // breadth-first: children after parents
+            It it; it.child = N.child[k]; it.depth_pushes = pushes + m - 1;
+            for (int a = 0; a < 3; a++) { it.mn[a] = std::max(rows[a][k], pmn[a]); it.mx[a] = std::min(rows[3 + a][k], pmx[a]); }
+            st.push_back(it);
+        }
+        deepest = std::max(deepest, pushes + (m ? m - 1 : 0));
+        return 0;
+    };
+    if (nodes.empty()) return ntris ? 10 : 0;
+    float rmn[3] = {-inf, -inf, -inf}, rmx[3] = {inf, inf, inf};
+    if (int r = push_children(0, rmn, rmx, 0)) return r;
+    while (!st.empty()) {
+        It it = st.back(); st.pop_back();
+        if (it.child >= 0) { if ((size_t)it.child >= nodes.size()) return 13; if (int r = push_children((size_t)it.child, it.mn, it.mx, it.depth_pushes)) return r; continue; }
+        uint32_t v = ~(uint32_t)it.child, first = v >> 3, cnt = (v & 7u) + 1u;
+        for (uint32_t k = 0; k < cnt; k++) {
+            if (first + k >= ntris) return 14;
+            uint32_t g = order[first + k];
+            if (covered[g]) return 15;
+            covered[g] = 1;
+            for (int vtx = 0; vtx < 3; vtx++) for (int a = 0; a < 3; a++) { float c = w[(size_t)g * 9 + vtx * 3 + a]; if (c < it.mn[a] || c > it.mx[a]) return 16; }
+        }
+    }
+    for (uint32_t i = 0; i < ntris; i++) if (!covered[i]) return 17;
+    for (size_t i = 0; i < nodes.size(); i++) if (!visited[i]) return 18;
+    if (max_stack_seen) *max_stack_seen = deepest;
+    return 0;
+}
+
+// build + collapse; returns 0 when the wide tree covers every triangle exactly once inside its boxes and the reported stack
+// bound is what the deepest root-to-leaf path can push
+int rtxh_bvh4_check(const float* wt, uint32_t ntris, uint32_t* nodes4_out, uint32_t* stack_out) {
+    std::vector<float> w(wt, wt + (size_t)ntris * 9);
+    std::vector<rtx::NodeGPU> nodes; std::vector<uint32_t> order; uint32_t depth = 0;
+    rtx::build_bvh(w, 0.0f, nodes, order, depth);
+    std::vector<rtx::Node4GPU> n4; uint32_t stack = 0;
+    rtx::collapse_bvh4(nodes, n4, stack);
+    if (nodes4_out) *nodes4_out = (uint32_t)n4.size();
+    if (stack_out) *stack_out = stack;
+    uint32_t seen = 0;
+    if (int r = bvh4_validate(w, n4, order, &seen)) return r;
+    return seen == stack ? 0 : 19;
+}
+
 int rtxh_bvh_check(const float* wt, uint32_t ntris, uint32_t* nodes_out, uint32_t* depth_out, uint32_t* max_leaf_out) {
     std::vector<float> w(wt, wt + (size_t)ntris * 9);
     std::vector<rtx::NodeGPU> nodes; std::vector<uint32_t> order; uint32_t depth = 0;
@@ -130,7 +191,10 @@ int rtxh_bvh_refit_check(const float* before, const float* after, uint32_t ntris
     std::vector<rtx::NodeGPU> nodes; std::vector<uint32_t> order; uint32_t depth = 0;
     rtx::build_bvh(a, 0.0f, nodes, order, depth);
     rtx::refit_bvh(b, 0.0f, nodes, order);
-    return bvh_validate(b, nodes, order, nullptr);
+    if (int r = bvh_validate(b, nodes, order, nullptr)) return r;
+    std::vector<rtx::Node4GPU> n4; uint32_t stack = 0;
+    rtx::collapse_bvh4(nodes, n4, stack);
+    return bvh4_validate(b, n4, order, nullptr);
 }
 
 // the tiny-scene pre-test records as rtx_commit_scene builds them (for host-side conservativeness tests)
