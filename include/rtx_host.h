@@ -47,9 +47,10 @@ float rtxh_half_round(float x);
 /* BVH builder invariants for tests: returns 0 when every triangle is in exactly one leaf and every child box
    contains its subtree; fills nodes / depth / max leaf size */
 int  rtxh_bvh_check(const float* world_tris9, uint32_t ntris, uint32_t* nodes_out, uint32_t* depth_out, uint32_t* max_leaf_out);
-/* the 4-wide collapse of that tree (the device traversal form): same coverage invariants on the wide nodes, children
-   stored after their parents, and *stack_out = the exact number of entries the deepest root-to-leaf path can push */
-int  rtxh_bvh4_check(const float* world_tris9, uint32_t ntris, uint32_t* nodes4_out, uint32_t* stack_out);
+/* the compressed 8-wide collapse of that tree (the device traversal form): same coverage invariants on the DECODED byte-grid
+   boxes of the wide nodes, children stored after their parents, <= 4 triangles per leaf slot, and *stack_out = the exact
+   number of sibling-group entries the deepest root-to-leaf path can push */
+int  rtxh_bvh8_check(const float* world_tris9, uint32_t ntris, uint32_t* nodes8_out, uint32_t* stack_out);
 /* same invariants after building on `before` and REFITTING (topology kept) to `after` (TLAS refit, Renderer.cpp:594) */
 int  rtxh_bvh_refit_check(const float* before_tris9, const float* after_tris9, uint32_t ntris);
 

@@ -142,7 +142,7 @@ _sig("rtxh_mat4_inverse", None, _fp, _fp)
 _sig("rtxh_half_round", C.c_float, C.c_float)
 _sig("rtxh_bvh_check", C.c_int, _vp, _u32, _u32p, _u32p, _u32p)
 _sig("rtxh_bvh_refit_check", C.c_int, _vp, _vp, _u32)
-_sig("rtxh_bvh4_check", C.c_int, _vp, _u32, _u32p, _u32p)
+_sig("rtxh_bvh8_check", C.c_int, _vp, _u32, _u32p, _u32p)
 _sig("rtxh_scene_small_records", C.c_int, _vp, _vp, _vp, _u32, _u32p, _fp, _fp)
 _sig("rtxh_renderer_create", _vp, _u32, _u32, C.c_char_p, C.c_int)
 _sig("rtxh_renderer_set_scene", C.c_int, _vp, _vp)
@@ -278,10 +278,10 @@ def bvh_check(world_tris):
     return rc, nodes.value, depth.value, leaf.value
 
 
-def bvh4_check(world_tris):
+def bvh8_check(world_tris):
     w = _f32(world_tris).reshape(-1, 9)
     nodes, stack = _u32(), _u32()
-    rc = lib.rtxh_bvh4_check(_ptr(w), len(w), C.byref(nodes), C.byref(stack))
+    rc = lib.rtxh_bvh8_check(_ptr(w), len(w), C.byref(nodes), C.byref(stack))
     return rc, nodes.value, stack.value
 
 

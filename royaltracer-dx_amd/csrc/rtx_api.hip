@@ -166,8 +166,8 @@ int rtx_commit_scene(rtx_ctx* c) {
     if (!c->host.build(c->built)) { c->err = c->host.err; return RTX_ERR_INVALID; }
     BuiltScene& B = c->built;
     int r;
-    if ((r = upload(c, c->d_nodes, B.nodes4))) return r;
-    if ((r = upload(c, c->d_tris, B.tris))) return r;
+    if ((r = upload(c, c->d_nodes, B.nodes8))) return r;
+    if ((r = upload(c, c->d_tris, B.tris8))) return r;
     if ((r = upload(c, c->d_shade, B.shade))) return r;
     if ((r = upload(c, c->d_small, B.small_recs))) return r;
     if ((r = upload(c, c->d_small_tris, B.small_tris))) return r;
@@ -176,8 +176,8 @@ int rtx_commit_scene(rtx_ctx* c) {
     if ((r = upload(c, c->d_lights, B.lights))) return r;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     DevScene& s = c->dsc;
-    s.nodes = (const Node4GPU*)c->d_nodes.p; s.nnodes = (uint32_t)B.nodes4.size();
-    s.tris = (const TriGPU*)c->d_tris.p; s.ntris = (uint32_t)B.tris.size();
+    s.nodes = (const Node8GPU*)c->d_nodes.p; s.nnodes = (uint32_t)B.nodes8.size();
+    s.tris = (const TriGPU*)c->d_tris.p; s.ntris = (uint32_t)B.tris8.size();
     s.shade = (const TriShade*)c->d_shade.p;
     s.small = (const SmallRecPair*)c->d_small.p; s.small_tris = (const TriGPU*)c->d_small_tris.p; s.small_cm = B.small_cm; s.small_delta = B.small_delta;
     s.mats = (const MatGPU*)c->d_mats.p; s.nmat = (uint32_t)B.mats.size();
@@ -185,21 +185,18 @@ int rtx_commit_scene(rtx_ctx* c) {
     s.lights = (const LightGPU*)c->d_lights.p; s.nlights = (uint32_t)B.lights.size();
     s.total_weight = B.total_weight;
     // LDS budget per workgroup: stack + top of tree + first triangles, kept <= 64 KiB
-    s.stack_depth = B.stack4 + 2;                         // exact bound of the 4-wide tree (up to 3 pushes per level) + slack
-    s.stack_private = c->stack_private >= 0 ? (uint32_t)c->stack_private : 2u;   // default hybrid: the 4-wide tree can need ~40 entries, a full LDS column of that costs occupancy (Sponza-class 80.6 vs 71.6 ms)
-    if (s.stack_depth > 62) { c->err = "commit: BVH too deep for the traversal stack (more than 60 entries)"; return RTX_ERR_INVALID; }
-    // LDS per workgroup = traversal stack + top of the tree (+ all triangles of a tiny scene).  Occupancy matters more
-    // than cached nodes: on the 262 k-triangle atrium 64 staged nodes (31 KB total, 5 workgroups/CU) beat 256 (88 -> 72 ms)
-    // and 0 (79 ms), so the default keeps the total near 32 KB; never above 64 KB.
-    const size_t stack_bytes = (size_t)s.stack_depth * 256 * 4;
-    const size_t soft = 32 * 1024, hard = 64 * 1024;
+    s.stack_depth = B.stack8 + 2;                         // exact bound of the 8-wide tree (one sibling group per level) + slack
+    s.stack_private = c->stack_private == 1 ? 1u : 0u;    // 1 (private / scratch) is a tuning knob; it measured slower than the LDS column
+    if (s.stack_depth > 30) { c->err = "commit: BVH too deep for the traversal stack (more than 28 levels of 8-wide nodes)"; return RTX_ERR_INVALID; }
+    // LDS per workgroup = traversal stack (8 B per entry and lane) + top of the tree (+ all triangles of a small scene), <= 64 KiB.
+    const size_t stack_bytes = (size_t)s.stack_depth * 256 * 8;
+    const size_t hard = 64 * 1024;
     size_t budget = hard > stack_bytes ? hard - stack_bytes : 0;
     uint32_t want_nodes;
     if (c->lds_nodes_opt >= 0) want_nodes = (uint32_t)c->lds_nodes_opt;
-    else if (s.nnodes <= 64) want_nodes = s.nnodes;
-    else want_nodes = (uint32_t)std::max<size_t>(32, std::min<size_t>(256, (soft > stack_bytes ? soft - stack_bytes : 0) / 128));
-    s.lds_nodes = std::min<uint32_t>(std::min<uint32_t>(want_nodes, s.nnodes), (uint32_t)(budget / 128));
-    budget -= (size_t)s.lds_nodes * 128;
+    else want_nodes = 73;                                  // root + 8 + 64: the first three levels of the wide tree
+    s.lds_nodes = std::min<uint32_t>(std::min<uint32_t>(want_nodes, s.nnodes), (uint32_t)(budget / 80));
+    budget -= (size_t)s.lds_nodes * 80;
     uint32_t want_tris = s.ntris <= 256 ? s.ntris : 0u;                    // triangles only when ALL of them fit
     s.lds_tris = (size_t)want_tris * 48 <= budget ? want_tris : 0u;
     s.nsmall = 0;

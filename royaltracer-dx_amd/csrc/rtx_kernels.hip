@@ -116,21 +116,24 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DevFrame f, DevPaths p, const
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4f lds_v4f;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v2u lds_u2;
 struct TraceLds {
     const lds_v4f* nodes;   // LDS copy of nodes [0, lds_nodes)
     const lds_v4f* tris;    // LDS copy of tris  [0, lds_tris)
-    lds_u32* stack;         // [depth][kBlock]
+    lds_u2* stack;          // [depth][kBlock] sibling-group entries
 };
 
 // stage the top of the BVH and the first triangles into LDS (coalesced 16-B copies)
 __device__ __forceinline__ TraceLds stage_lds(const DevScene& sc, F4* lds_generic) {
     TraceLds L;
-    lds_v4f* ln = (lds_v4f*)lds_generic; lds_v4f* lt = ln + (size_t)sc.lds_nodes * 8;
+    lds_v4f* ln = (lds_v4f*)lds_generic; lds_v4f* lt = ln + (size_t)sc.lds_nodes * 5;
     const v4f* gn = (const v4f*)sc.nodes; const v4f* gt = (const v4f*)(sc.nsmall ? sc.small_tris : sc.tris);
-    for (uint32_t i = threadIdx.x; i < sc.lds_nodes * 8u; i += kBlock) ln[i] = gn[i];
+    for (uint32_t i = threadIdx.x; i < sc.lds_nodes * 5u; i += kBlock) ln[i] = gn[i];
     for (uint32_t i = threadIdx.x; i < sc.lds_tris * 3u; i += kBlock) lt[i] = gt[i];
     L.nodes = ln; L.tris = lt;
-    L.stack = (lds_u32*)(lt + (size_t)sc.lds_tris * 3);
+    L.stack = (lds_u2*)(lt + (size_t)sc.lds_tris * 3);
     return L;
 }
 
@@ -152,57 +155,88 @@ __device__ __forceinline__ bool tri_test(f3 o, f3 d, v4f v0w, v4f e1w, v4f e2w, 
     return t > tmin && t < tmax;
 }
 
-// ---- 4-wide node step ------------------------------------------------------------------------------------------
-// One traversal step fetches a whole Node4GPU (one 128-B line, or 7 ds_read_b128 for the staged top of the tree), runs the
-// conservative slab test on its four child boxes at once (the SoA rows make every operation a 4-vector one: packed
-// sub / mul, v_min / v_max, v_max3 / v_min3), sorts the hit children by entry distance with a 5-exchange network, pushes the
-// farther ones far-to-near and returns the nearest.  The slab test is the padded one of the binary walk: children that
-// the exact triangle tests could accept are never culled, so the closest hit stays the minimum over ALL triangles.
-typedef int v4i __attribute__((ext_vector_type(4)));
-struct Node4R { v4f mnx, mny, mnz, mxx, mxy, mxz; v4i ch; };
-constexpr int32_t kDone = (int32_t)0x80000000;       // traversal finished (distinct from every leaf code)
+// ---- compressed 8-wide node step ---------------------------------------------------------------------------------
+// One traversal step fetches a Node8GPU (five 16-B loads, or five ds_read_b128 for the staged top of the tree) and tests its
+// eight child boxes.  Planes are byte offsets on the node's power-of-two grid, so
+//     t_plane = q * (2^e * idir) + (p - o) * idir        (cvt + fma per plane; near / far rows picked by the ray's octant)
+// CONSERVATIVENESS (the closest hit must stay the minimum over ALL triangles): the builder rounds the boxes outward in exact
+// arithmetic; 2^e * idir is exact; a = fl(fl(p - o) * idir) carries a relative error <= 2^-23, so the near planes use
+// a - |a| 2^-22 and the far planes a + |a| 2^-22; what is left is relative to t and covered by the same 2e-6 margins as
+// before.  Hit children are visited in increasing (slot ^ octant) order; the rest of a node's hit children stay together in
+// ONE stack entry (base index + hit bits + internal mask), so the stack holds one entry per level.
+struct Node8R { v4f h0; v4u h1, q0, q1, q2; };
+struct Grp { uint32_t base, bits; };                 // node group: child_base, ordered internal hits (bits 0-7) | imask << 8
+struct TriGrp { uint32_t base, bits, valid; };        // triangle group: tri_base, hit triangle bits, the node's trivalid
+constexpr float kPlaneEps = 2.384185791015625e-07f;   // 2^-22
 
-__device__ __forceinline__ Node4R load_node4(const DevScene& sc, const TraceLds& L, uint32_t idx) {
-    Node4R N;
-    if (idx < sc.lds_nodes) { const lds_v4f* n = L.nodes + idx * 8u; N.mnx = n[0]; N.mny = n[1]; N.mnz = n[2]; N.mxx = n[3]; N.mxy = n[4]; N.mxz = n[5]; N.ch = (v4i)n[6]; }
-    else { const v4f* n = (const v4f*)(sc.nodes + idx); N.mnx = n[0]; N.mny = n[1]; N.mnz = n[2]; N.mxx = n[3]; N.mxy = n[4]; N.mxz = n[5]; N.ch = (v4i)n[6]; }
+__device__ __forceinline__ Node8R load_node8(const DevScene& sc, const TraceLds& L, uint32_t idx) {
+    Node8R N;
+    if (idx < sc.lds_nodes) { const lds_v4f* n = L.nodes + idx * 5u; N.h0 = n[0]; N.h1 = (v4u)n[1]; N.q0 = (v4u)n[2]; N.q1 = (v4u)n[3]; N.q2 = (v4u)n[4]; }
+    else { const v4f* n = (const v4f*)sc.nodes + (size_t)idx * 5u; N.h0 = n[0]; N.h1 = (v4u)n[1]; N.q0 = (v4u)n[2]; N.q1 = (v4u)n[3]; N.q2 = (v4u)n[4]; }
     return N;
 }
-__device__ __forceinline__ void cmp_swap(float& ka, int32_t& ca, float& kb, int32_t& cb) {
-    const bool sw = kb < ka;
-    const float k0 = sw ? kb : ka, k1 = sw ? ka : kb;
-    const int32_t c0 = sw ? cb : ca, c1 = sw ? ca : cb;
-    ka = k0; kb = k1; ca = c0; cb = c1;
-}
-template <class STK>
-__device__ __forceinline__ int32_t node4_step(const Node4R& N, f3 o, f3 idir, float tmin, float tbest, STK& stk, int& sp) {
-    const v4f tx0 = (N.mnx - o.x) * idir.x, tx1 = (N.mxx - o.x) * idir.x;
-    const v4f ty0 = (N.mny - o.y) * idir.y, ty1 = (N.mxy - o.y) * idir.y;
-    const v4f tz0 = (N.mnz - o.z) * idir.z, tz1 = (N.mxz - o.z) * idir.z;
-    const v4f vmin = {tmin, tmin, tmin, tmin}, vbest = {tbest, tbest, tbest, tbest};
-    const v4f lo = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(tx0, tx1), __builtin_elementwise_min(ty0, ty1)),
-                                             __builtin_elementwise_max(__builtin_elementwise_min(tz0, tz1), vmin));
-    const v4f hi = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(tx0, tx1), __builtin_elementwise_max(ty0, ty1)),
-                                             __builtin_elementwise_min(__builtin_elementwise_max(tz0, tz1), vbest));
-    const v4f lo_s = lo * 0.999998f, hi_s = hi * 1.000002f;     // lo, hi >= tmin >= 0 here
-    const float inf = __builtin_inff();
-    float k0 = (lo_s.x <= hi_s.x && N.ch.x != kEmptyChild) ? lo.x : inf;
-    float k1 = (lo_s.y <= hi_s.y && N.ch.y != kEmptyChild) ? lo.y : inf;
-    float k2 = (lo_s.z <= hi_s.z && N.ch.z != kEmptyChild) ? lo.z : inf;
-    float k3 = (lo_s.w <= hi_s.w && N.ch.w != kEmptyChild) ? lo.w : inf;
-    int32_t c0 = N.ch.x, c1 = N.ch.y, c2 = N.ch.z, c3 = N.ch.w;
-    cmp_swap(k0, c0, k1, c1); cmp_swap(k2, c2, k3, c3); cmp_swap(k0, c0, k2, c2); cmp_swap(k1, c1, k3, c3); cmp_swap(k1, c1, k2, c2);
-    if (k3 < inf) { stk.put(sp, (uint32_t)c3); sp++; }
-    if (k2 < inf) { stk.put(sp, (uint32_t)c2); sp++; }
-    if (k1 < inf) { stk.put(sp, (uint32_t)c1); sp++; }
-    if (k0 < inf) return c0;
-    if (sp == 0) return kDone;
-    sp--; return (int32_t)stk.get(sp);
+__device__ __forceinline__ uint32_t ray_octant(f3 idir) { return (idir.x < 0.0f ? 1u : 0u) | (idir.y < 0.0f ? 2u : 0u) | (idir.z < 0.0f ? 4u : 0u); }
+__device__ __forceinline__ float byte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyteK
+
+// tests the 8 children; G = this node's internal hits in octant order, T = the triangles of its hit leaf children
+__device__ __forceinline__ void node8_hits(const Node8R& N, f3 o, f3 idir, uint32_t oct, float tmin, float tbest, Grp& G, TriGrp& T) {
+    const uint32_t w = f2u(N.h0.w);
+    const float sx = u2f((w & 0xffu) << 23) * idir.x, sy = u2f((w & 0xff00u) << 15) * idir.y, sz = u2f((w & 0xff0000u) << 7) * idir.z;
+    const float ax = (N.h0.x - o.x) * idir.x, ay = (N.h0.y - o.y) * idir.y, az = (N.h0.z - o.z) * idir.z;
+    const float anx = __builtin_fmaf(-fabsf(ax), kPlaneEps, ax), afx = __builtin_fmaf(fabsf(ax), kPlaneEps, ax);
+    const float any_ = __builtin_fmaf(-fabsf(ay), kPlaneEps, ay), afy = __builtin_fmaf(fabsf(ay), kPlaneEps, ay);
+    const float anz = __builtin_fmaf(-fabsf(az), kPlaneEps, az), afz = __builtin_fmaf(fabsf(az), kPlaneEps, az);
+    const bool nx = (oct & 1u) != 0u, ny = (oct & 2u) != 0u, nz = (oct & 4u) != 0u;
+    // rows: q0 = (lox0, lox1, loy0, loy1)  q1 = (loz0, loz1, hix0, hix1)  q2 = (hiy0, hiy1, hiz0, hiz1)
+    const uint32_t qnx[2] = {nx ? N.q1.z : N.q0.x, nx ? N.q1.w : N.q0.y}, qfx[2] = {nx ? N.q0.x : N.q1.z, nx ? N.q0.y : N.q1.w};
+    const uint32_t qny[2] = {ny ? N.q2.x : N.q0.z, ny ? N.q2.y : N.q0.w}, qfy[2] = {ny ? N.q0.z : N.q2.x, ny ? N.q0.w : N.q2.y};
+    const uint32_t qnz[2] = {nz ? N.q2.z : N.q1.x, nz ? N.q2.w : N.q1.y}, qfz[2] = {nz ? N.q1.x : N.q2.z, nz ? N.q1.y : N.q2.w};
+    uint32_t hits = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int h = k >> 2, b = k & 3;
+        const float tnx = __builtin_fmaf(byte_f(qnx[h], b), sx, anx), tny = __builtin_fmaf(byte_f(qny[h], b), sy, any_), tnz = __builtin_fmaf(byte_f(qnz[h], b), sz, anz);
+        const float tfx = __builtin_fmaf(byte_f(qfx[h], b), sx, afx), tfy = __builtin_fmaf(byte_f(qfy[h], b), sy, afy), tfz = __builtin_fmaf(byte_f(qfz[h], b), sz, afz);
+        const float lo = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+        const float hi = fminf(fminf(tfx, tfy), fminf(tfz, tbest));
+        if (lo * 0.999998f <= hi * 1.000002f) hits |= 1u << k;       // lo >= tmin >= 0
+    }
+    const uint32_t imask = w >> 24;
+    // internal hits, permuted so that bit j = slot (j ^ oct): lowest set bit = first child to visit
+    uint32_t m = hits & imask;
+    if (nx) m = ((m & 0x55u) << 1) | ((m >> 1) & 0x55u);
+    if (ny) m = ((m & 0x33u) << 2) | ((m >> 2) & 0x33u);
+    if (nz) m = ((m & 0x0fu) << 4) | ((m >> 4) & 0x0fu);
+    G.base = N.h1.x; G.bits = m | (imask << 8);
+    // leaf hits: spread each bit to its nibble and keep the triangles that exist
+    uint32_t x = hits & ~imask;
+    x = (x | (x << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    T.base = N.h1.y; T.valid = N.h1.z; T.bits = (x * 15u) & N.h1.z;
 }
 
-// traversal stack: per-lane column in LDS (conflict-free, but its footprint limits occupancy on deep trees), or a
-// private array that hipcc places in scratch (lane-interleaved, so a wave-level push is one contiguous 256-B store)
-struct StackLds { lds_u32* col; __device__ __forceinline__ void put(int i, uint32_t v) { col[i * kBlock] = v; } __device__ __forceinline__ uint32_t get(int i) const { return col[i * kBlock]; } };
+// traversal stack of sibling groups: per-lane column in LDS (conflict-free 8-byte accesses), or a private array (scratch)
+struct StackLds { lds_u2* col; __device__ __forceinline__ void put(int i, Grp g) { v2u v = {g.base, g.bits}; col[i * kBlock] = v; }
+                  __device__ __forceinline__ Grp get(int i) const { const v2u v = col[i * kBlock]; return Grp{v.x, v.y}; } };
+constexpr int kPrivStack = 32;
+struct StackPriv { Grp a[kPrivStack]; __device__ __forceinline__ void put(int i, Grp g) { a[i] = g; } __device__ __forceinline__ Grp get(int i) const { return a[i]; } };
+
+// pick the first child of group G (which has internal hits), keep the remaining siblings on the stack, test the child's
+// eight children: G / T become the child's groups
+template <class STK>
+__device__ __forceinline__ void descend8(const DevScene& sc, const TraceLds& L, f3 o, f3 idir, uint32_t oct, float tmin, float tbest,
+                                         Grp& G, TriGrp& T, STK& stk, int& sp) {
+    const uint32_t k = (uint32_t)__builtin_ctz(G.bits);
+    const uint32_t rest = G.bits & (G.bits - 1u);
+    if (rest & 0xffu) { stk.put(sp, Grp{G.base, rest}); sp++; }
+    const uint32_t slot = k ^ oct;
+    const uint32_t idx = G.base + (uint32_t)__builtin_popcount((G.bits >> 8) & ((1u << slot) - 1u));
+    const Node8R N = load_node8(sc, L, idx);
+    node8_hits(N, o, idir, oct, tmin, tbest, G, T);
+}
+// index of the triangle behind bit `bit` of a triangle group
+__device__ __forceinline__ uint32_t tri_slot8(const TriGrp& T, uint32_t bit) { return T.base + (uint32_t)__builtin_popcount(T.valid & ((1u << bit) - 1u)); }
 
 template <bool ANY>
 __device__ __forceinline__ void traverse(const DevScene& sc, const TraceLds& L, f3 o, f3 d, float tmin, float tmax,
@@ -212,31 +246,31 @@ __device__ __forceinline__ void traverse(const DevScene& sc, const TraceLds& L, 
     const float dys = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
     const float dzs = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
     const f3 idir = mk3(__builtin_amdgcn_rcpf(dxs), __builtin_amdgcn_rcpf(dys), __builtin_amdgcn_rcpf(dzs));
+    const uint32_t oct = ray_octant(idir);
     bt = tmax; bu = 0.0f; bv = 0.0f; bprim = kMissPrim;
     StackLds stk; stk.col = L.stack + threadIdx.x;
     int sp = 0;
-    int32_t cur = 0;
-    while (cur != kDone) {
-        if (cur >= 0) {
-            const Node4R N = load_node4(sc, L, (uint32_t)cur);
-            cur = node4_step(N, o, idir, tmin, bt, stk, sp);
-        } else {
-            const uint32_t v = ~(uint32_t)cur;
-            const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
-            for (uint32_t k = 0; k < cnt; k++) {
-                const uint32_t slot = first + k;
-                v4f v0, e1, e2;
-                if (slot < sc.lds_tris) { const lds_v4f* t = L.tris + slot * 3u; v0 = t[0]; e1 = t[1]; e2 = t[2]; }
-                else { const v4f* t = (const v4f*)(sc.tris + slot); v0 = t[0]; e1 = t[1]; e2 = t[2]; }
-                float t, u, w;
-                if (tri_test(o, d, v0, e1, e2, tmin, tmax, t, u, w)) {
-                    if (ANY) { bprim = 0u; return; }
-                    const uint32_t gid = f2u(v0.w);
-                    if (t < bt || (t == bt && gid < bprim)) { bt = t; bu = u; bv = w; bprim = gid; }
-                }
+    Grp G{0u, (1u << oct) | (1u << 8)};                 // the root as slot 0 of a virtual parent
+    TriGrp T{0u, 0u, 0u};
+    while (true) {
+        if (G.bits & 0xffu) descend8(sc, L, o, idir, oct, tmin, bt, G, T, stk, sp);
+        while (T.bits) {
+            const uint32_t bit = (uint32_t)__builtin_ctz(T.bits);
+            T.bits &= T.bits - 1u;
+            const uint32_t slot = tri_slot8(T, bit);
+            v4f v0, e1, e2;
+            if (slot < sc.lds_tris) { const lds_v4f* t = L.tris + slot * 3u; v0 = t[0]; e1 = t[1]; e2 = t[2]; }
+            else { const v4f* t = (const v4f*)(sc.tris + slot); v0 = t[0]; e1 = t[1]; e2 = t[2]; }
+            float t, u, w;
+            if (tri_test(o, d, v0, e1, e2, tmin, tmax, t, u, w)) {
+                if (ANY) { bprim = 0u; return; }
+                const uint32_t gid = f2u(v0.w);
+                if (t < bt || (t == bt && gid < bprim)) { bt = t; bu = u; bv = w; bprim = gid; }
             }
+        }
+        if (!(G.bits & 0xffu)) {
             if (sp == 0) break;
-            sp--; cur = (int32_t)stk.get(sp);
+            sp--; G = stk.get(sp);
         }
     }
 }
@@ -365,24 +399,12 @@ __global__ __launch_bounds__(kBlock) void k_raygen_trace_small(DevScene sc, cons
 // Exit: a wave leaves when the sub-queue is exhausted and no lane holds a ray — every wave reaches that.
 // ---------------------------------------------------------------------------------------------
 int g_refill_min = 20;
-int g_trace_sched = 0;                                // 0 = while-while, 1 = voted node / triangle steps (MEASURED slower: 101 vs 72 ms, the
-                                                      // traversal is bound by the texture addresser / L1, not by VALU lanes: profiles/r01_pmc_bvh.md)                                // refill when at least this many lanes are idle (tuning knob)
-
-constexpr int kPrivStack = 64;
-struct StackPriv { uint32_t a[kPrivStack]; __device__ __forceinline__ void put(int i, uint32_t v) { a[i] = v; } __device__ __forceinline__ uint32_t get(int i) const { return a[i]; } };
-// hybrid: the first kHybridLds entries (what a nearest-first traversal normally uses) in the LDS column, the rare overflow of
-// deep trees in a private array — LDS per workgroup drops to 16 KB + staged nodes, so register-limited occupancy (8 waves/SIMD).
-// MEASURED slower than the plain LDS column (Sponza-class 74.8 vs 69.1 ms, Bistro-class 72.2 vs 69.2 ms): kept as a knob only.
-constexpr int kHybridLds = 16;
-struct StackHybrid {
-    lds_u32* col; uint32_t a[kPrivStack - kHybridLds];
-    __device__ __forceinline__ void put(int i, uint32_t v) { if (i < kHybridLds) col[i * kBlock] = v; else a[i - kHybridLds] = v; }
-    __device__ __forceinline__ uint32_t get(int i) const { return i < kHybridLds ? col[i * kBlock] : a[i - kHybridLds]; }
-};
+int g_trace_sched = 1;                                // 0 = while-while, 1 = voted node / triangle steps.  With the 128-B 4-wide nodes the voted schedule
+                                                      // was slower (texture-addresser bound, profiles/r01_pmc_bvh.md); with the 80-B 8-wide nodes it wins
+                                                      // (Sponza-class 59.2 vs 67.7 ms, Bistro-class 47.8 vs 56.2 ms)
 
 struct RayLane {                                       // per-lane traversal state
-    f3 o, d, idir; float tmin, tmax, bt, bu, bv; uint32_t bprim; int32_t cur; int sp; uint32_t item; bool has;
-    uint32_t lk;                                       // triangles of the current leaf already tested (voted schedule)
+    f3 o, d, idir; float tmin, tmax, bt, bu, bv; uint32_t bprim; uint32_t oct; Grp G; TriGrp T; int sp; uint32_t item; bool has, done;
 };
 __device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, float tmax, uint32_t item) {
     R.o = o; R.d = d; R.tmin = tmin; R.tmax = tmax; R.item = item;
@@ -390,75 +412,65 @@ __device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, fl
     const float dys = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
     const float dzs = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
     R.idir = mk3(__builtin_amdgcn_rcpf(dxs), __builtin_amdgcn_rcpf(dys), __builtin_amdgcn_rcpf(dzs));
-    R.bt = tmax; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.cur = 0; R.sp = 0; R.has = true; R.lk = 0;
+    R.oct = ray_octant(R.idir);
+    R.bt = tmax; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.sp = 0; R.has = true; R.done = false;
+    R.G = Grp{0u, (1u << R.oct) | (1u << 8)}; R.T = TriGrp{0u, 0u, 0u};
 }
-// all lanes holding an internal node walk down until they hold a leaf or are done
+__device__ __forceinline__ void ray_idle(RayLane& R) {
+    R.has = false; R.done = false; R.sp = 0; R.item = 0; R.o = mk3(0, 0, 0); R.d = mk3(0, 0, 1); R.idir = mk3(0, 0, 1); R.oct = 0;
+    R.tmin = 0.0f; R.tmax = 0.0f; R.bt = 0.0f; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.G = Grp{0u, 0u}; R.T = TriGrp{0u, 0u, 0u};
+}
+// after a node step or a finished triangle group: continue with the node's own internal hits, else pop, else done
+template <class STK>
+__device__ __forceinline__ void next_group(RayLane& R, STK& stk) {
+    if (!(R.G.bits & 0xffu) && !R.T.bits) {
+        if (R.sp == 0) R.done = true;
+        else { R.sp--; R.G = stk.get(R.sp); }
+    }
+}
+// all lanes with a node group walk down until they hold triangles to test or are done
 template <bool ANY, class STK>
 __device__ __forceinline__ void walk_internal(const DevScene& sc, const TraceLds& L, RayLane& R, STK& stk) {
-    while (R.has && R.cur >= 0) {
-        const Node4R N = load_node4(sc, L, (uint32_t)R.cur);
-        R.cur = node4_step(N, R.o, R.idir, R.tmin, R.bt, stk, R.sp);
+    while (R.has && !R.done && !R.T.bits) {
+        descend8(sc, L, R.o, R.idir, R.oct, R.tmin, R.bt, R.G, R.T, stk, R.sp);
+        next_group(R, stk);
+    }
+}
+template <bool ANY>
+__device__ __forceinline__ void tri_step(const DevScene& sc, const TraceLds& L, RayLane& R) {
+    const uint32_t bit = (uint32_t)__builtin_ctz(R.T.bits);
+    R.T.bits &= R.T.bits - 1u;
+    const uint32_t slot = tri_slot8(R.T, bit);
+    v4f v0, e1, e2;
+    if (slot < sc.lds_tris) { const lds_v4f* t = L.tris + slot * 3u; v0 = t[0]; e1 = t[1]; e2 = t[2]; }
+    else { const v4f* t = (const v4f*)(sc.tris + slot); v0 = t[0]; e1 = t[1]; e2 = t[2]; }
+    float t, u, w;
+    if (tri_test(R.o, R.d, v0, e1, e2, R.tmin, R.tmax, t, u, w)) {
+        if (ANY) { R.bprim = 0u; R.done = true; R.T.bits = 0u; }
+        else {
+            const uint32_t gid = f2u(v0.w);
+            if (t < R.bt || (t == R.bt && gid < R.bprim)) { R.bt = t; R.bu = u; R.bv = w; R.bprim = gid; }
+        }
     }
 }
 template <bool ANY, class STK>
 __device__ __forceinline__ void process_leaf(const DevScene& sc, const TraceLds& L, RayLane& R, STK& stk) {
-    if (R.has && R.cur < 0 && R.cur != kDone) {
-        const uint32_t v = ~(uint32_t)R.cur;
-        const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
-        bool occluded = false;
-        for (uint32_t k = 0; k < cnt; k++) {
-            const uint32_t slot = first + k;
-            v4f v0, e1, e2;
-            if (slot < sc.lds_tris) { const lds_v4f* t = L.tris + slot * 3u; v0 = t[0]; e1 = t[1]; e2 = t[2]; }
-            else { const v4f* t = (const v4f*)(sc.tris + slot); v0 = t[0]; e1 = t[1]; e2 = t[2]; }
-            float t, u, w;
-            if (tri_test(R.o, R.d, v0, e1, e2, R.tmin, R.tmax, t, u, w)) {
-                if (ANY) { occluded = true; break; }
-                const uint32_t gid = f2u(v0.w);
-                if (t < R.bt || (t == R.bt && gid < R.bprim)) { R.bt = t; R.bu = u; R.bv = w; R.bprim = gid; }
-            }
-        }
-        if (ANY && occluded) { R.bprim = 0u; R.cur = kDone; }
-        else if (R.sp == 0) R.cur = kDone;
-        else { R.sp--; R.cur = (int32_t)stk.get(R.sp); }
-    }
+    while (R.has && !R.done && R.T.bits) tri_step<ANY>(sc, L, R);
+    if (R.has && !R.done) next_group(R, stk);
 }
-// Voted schedule (g_trace_sched = 1): instead of "walk until EVERY lane holds a leaf, then test every lane's whole leaf" —
-// whose node loop runs for the slowest of 64 lanes — each iteration the wave votes for the step most of its busy lanes are
-// waiting for: one 4-wide node step, or one triangle test.  Lanes in the minority state keep their state and wait; node
-// steps keep turning node lanes into leaf lanes, so the minority always gets its turn.
+// Voted schedule (g_trace_sched = 1): instead of "walk until EVERY lane holds triangles, then test every lane's triangles"
+// each iteration the wave votes for the step most of its busy lanes are waiting for: one node step, or one triangle test.
 template <bool ANY, class STK>
 __device__ __forceinline__ void voted_step(const DevScene& sc, const TraceLds& L, RayLane& R, STK& stk) {
-    const bool in_node = R.has && R.cur >= 0;
-    const bool in_leaf = R.has && R.cur < 0 && R.cur != kDone;
-    const uint32_t ni = (uint32_t)__popcll(__ballot(in_node)), nl = (uint32_t)__popcll(__ballot(in_leaf));
+    const bool busy = R.has && !R.done;
+    const bool in_tri = busy && R.T.bits != 0u;
+    const bool in_node = busy && !in_tri;
+    const uint32_t ni = (uint32_t)__popcll(__ballot(in_node)), nl = (uint32_t)__popcll(__ballot(in_tri));
     if (ni >= nl) {
-        if (in_node) {
-            const Node4R N = load_node4(sc, L, (uint32_t)R.cur);
-            R.cur = node4_step(N, R.o, R.idir, R.tmin, R.bt, stk, R.sp);
-        }
-    } else if (in_leaf) {
-        const uint32_t v = ~(uint32_t)R.cur;
-        const uint32_t slot = (v >> 3) + R.lk, cnt = (v & 7u) + 1u;
-        v4f v0, e1, e2;
-        if (slot < sc.lds_tris) { const lds_v4f* t = L.tris + slot * 3u; v0 = t[0]; e1 = t[1]; e2 = t[2]; }
-        else { const v4f* t = (const v4f*)(sc.tris + slot); v0 = t[0]; e1 = t[1]; e2 = t[2]; }
-        float t, u, w;
-        bool occluded = false;
-        if (tri_test(R.o, R.d, v0, e1, e2, R.tmin, R.tmax, t, u, w)) {
-            if (ANY) occluded = true;
-            else {
-                const uint32_t gid = f2u(v0.w);
-                if (t < R.bt || (t == R.bt && gid < R.bprim)) { R.bt = t; R.bu = u; R.bv = w; R.bprim = gid; }
-            }
-        }
-        R.lk++;
-        if (ANY && occluded) { R.bprim = 0u; R.cur = kDone; }
-        else if (R.lk == cnt) {
-            R.lk = 0;
-            if (R.sp == 0) R.cur = kDone;
-            else { R.sp--; R.cur = (int32_t)stk.get(R.sp); }
-        }
+        if (in_node) { descend8(sc, L, R.o, R.idir, R.oct, R.tmin, R.bt, R.G, R.T, stk, R.sp); next_group(R, stk); }
+    } else if (in_tri) {
+        tri_step<ANY>(sc, L, R);
+        if (!R.done) next_group(R, stk);
     }
 }
 // wave-level refill: returns false when the wave may exit (queue exhausted and nothing in flight)
@@ -481,7 +493,7 @@ __device__ __forceinline__ bool refill(RayLane& R, uint32_t* s_head, uint32_t n,
 }
 
 // closest hit for every path in this workgroup's sub-queue: reads ray_o/ray_d, writes hit
-template <int STK>   // traversal stack: 0 = LDS column, 1 = private (scratch), 2 = hybrid
+template <int STK>   // traversal stack: 0 = LDS column, 1 = private (scratch)
 __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin, uint32_t refill_min, uint32_t sched) {
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_head;
@@ -501,10 +513,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
         }
         return;
     }
-    typename std::conditional<STK == 1, StackPriv, typename std::conditional<STK == 2, StackHybrid, StackLds>::type>::type stk;
+    typename std::conditional<STK == 1, StackPriv, StackLds>::type stk;
     if constexpr (STK != 1) stk.col = L.stack + threadIdx.x;
-    RayLane R; R.has = false; R.cur = kDone; R.sp = 0; R.item = 0; R.o = mk3(0, 0, 0); R.d = mk3(0, 0, 1); R.idir = mk3(0, 0, 1);
-    R.tmin = 0.0f; R.tmax = 0.0f; R.bt = 0.0f; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.lk = 0;
+    RayLane R; ray_idle(R);
     bool drained = false;
     while (refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) {
                const uint32_t pid = myq[idx];
@@ -513,7 +524,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
            })) {
         if (sched) voted_step<false>(sc, L, R, stk);
         else { walk_internal<false>(sc, L, R, stk); process_leaf<false>(sc, L, R, stk); }
-        if (R.has && R.cur == kDone) { p.hit[R.item] = {R.bt, R.bu, R.bv, u2f(R.bprim)}; R.has = false; }
+        if (R.has && R.done) { p.hit[R.item] = {R.bt, R.bu, R.bv, u2f(R.bprim)}; R.has = false; }
     }
 }
 
@@ -548,10 +559,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const Smal
         }
         return;
     }
-    typename std::conditional<STK == 1, StackPriv, typename std::conditional<STK == 2, StackHybrid, StackLds>::type>::type stk;
+    typename std::conditional<STK == 1, StackPriv, StackLds>::type stk;
     if constexpr (STK != 1) stk.col = L.stack + threadIdx.x;
-    RayLane R; R.has = false; R.cur = kDone; R.sp = 0; R.item = 0; R.o = mk3(0, 0, 0); R.d = mk3(0, 0, 1); R.idir = mk3(0, 0, 1);
-    R.tmin = 0.0f; R.tmax = 0.0f; R.bt = 0.0f; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.lk = 0;
+    RayLane R; ray_idle(R);
     bool drained = false;
     while (refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) {
                const F4 so = sh_o[qb + idx], sd = sh_d[qb + idx];
@@ -559,7 +569,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const Smal
            })) {
         if (sched) voted_step<true>(sc, L, R, stk);
         else { walk_internal<true>(sc, L, R, stk); process_leaf<true>(sc, L, R, stk); }
-        if (R.has && R.cur == kDone) { finish(R.item, R.bprim != kMissPrim); R.has = false; }
+        if (R.has && R.done) { finish(R.item, R.bprim != kMissPrim); R.has = false; }
     }
 }
 
@@ -1556,11 +1566,11 @@ static inline uint32_t grid_for(uint32_t items, uint32_t max_blocks) {
     return b < max_blocks ? b : max_blocks;
 }
 size_t trace_lds_bytes(const DevScene& sc) {      // the LDS column stack is always reserved: debug / pass-1 kernels use it
-    return (size_t)sc.lds_nodes * 128 + (size_t)sc.lds_tris * 48 + (size_t)sc.stack_depth * kBlock * 4;
+    return (size_t)sc.lds_nodes * 80 + (size_t)sc.lds_tris * 48 + (size_t)sc.stack_depth * kBlock * 8;
 }
 size_t trace_lds_bytes_queue(const DevScene& sc) {   // queue kernels with a private stack need no LDS stack
-    const size_t stack = sc.stack_private == 1 ? 0 : sc.stack_private == 2 ? (size_t)kHybridLds * kBlock * 4 : (size_t)sc.stack_depth * kBlock * 4;
-    return (size_t)sc.lds_nodes * 128 + (size_t)sc.lds_tris * 48 + stack;
+    const size_t stack = sc.stack_private == 1 ? 0 : (size_t)sc.stack_depth * kBlock * 8;
+    return (size_t)sc.lds_nodes * 80 + (size_t)sc.lds_tris * 48 + stack;
 }
 
 void launch_raygen(hipStream_t st, const DevFrame& f, const DevPaths& p, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount) {
@@ -1572,7 +1582,6 @@ void launch_raygen_trace_small(hipStream_t st, const DevScene& sc, const DevFram
 void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t bounce, const uint32_t* queue, const uint32_t* qcount) {
     const float tmin = bounce == 0 ? kTMinCam : kSBias;
     if (sc.stack_private == 1) hipLaunchKernelGGL(k_trace_closest<1>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, (uint32_t)g_refill_min, (uint32_t)g_trace_sched);
-    else if (sc.stack_private == 2) hipLaunchKernelGGL(k_trace_closest<2>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, (uint32_t)g_refill_min, (uint32_t)g_trace_sched);
     else hipLaunchKernelGGL(k_trace_closest<0>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, (uint32_t)g_refill_min, (uint32_t)g_trace_sched);
 }
 void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce, bool have_hit,
@@ -1584,7 +1593,6 @@ void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, 
 void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t j, const uint32_t* shcount) {
     const size_t seg = (size_t)j * f.qcap * f.nblocks;
     if (sc.stack_private == 1) hipLaunchKernelGGL(k_trace_shadow<1>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, (uint32_t)g_refill_min, (uint32_t)g_trace_sched);
-    else if (sc.stack_private == 2) hipLaunchKernelGGL(k_trace_shadow<2>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, (uint32_t)g_refill_min, (uint32_t)g_trace_sched);
     else hipLaunchKernelGGL(k_trace_shadow<0>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, (uint32_t)g_refill_min, (uint32_t)g_trace_sched);
 }
 void launch_shade(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce,

@@ -7,7 +7,7 @@ namespace rtx {
 
 // read-only scene in HBM
 struct DevScene {
-    const Node4GPU* nodes;  uint32_t nnodes;
+    const Node8GPU* nodes;  uint32_t nnodes;
     const TriGPU*   tris;   uint32_t ntris;
     const TriShade* shade;
     const SmallRecPair* small; uint32_t nsmall;   // nsmall != 0: tiny scene: nsmall pre-test records (planar polygons), no BVH

@@ -213,7 +213,6 @@ bool SceneHost::build(BuiltScene& B) {
     if (refit) refit_bvh(wtri, 1e-6f * scale, B.nodes, leaf_order);
     else build_bvh(wtri, 1e-6f * scale, B.nodes, leaf_order, B.max_depth);
     B.refit_count = refit ? B.refit_count + 1 : 0;
-    collapse_bvh4(B.nodes, B.nodes4, B.stack4);          // derived data: redone after a refit too (O(nodes))
     topo_dirty = false;
     B.tris.resize(leaf_order.size());
     for (size_t s = 0; s < leaf_order.size(); s++) {
@@ -226,6 +225,10 @@ bool SceneHost::build(BuiltScene& B) {
         T.e1 = {e1.x, e1.y, e1.z, 0.0f};
         T.e2 = {e2.x, e2.y, e2.z, 0.0f};
     }
+    // device traversal form: derived data, redone after a refit too (O(nodes))
+    if (!collapse_bvh8(B.nodes, B.nodes8, B.tri_slots8, B.stack8)) { err = "build: BVH collapse failed"; return false; }
+    B.tris8.resize(B.tri_slots8.size());
+    for (size_t i = 0; i < B.tri_slots8.size(); i++) B.tris8[i] = B.tris[B.tri_slots8[i]];
     // ---- tiny scenes: merge triangles into planar convex quads and build the conservative pre-test records ----
     B.small_recs.clear(); B.small_tris.clear(); B.small_nrec = 0;
     if (!leaf_order.empty() && leaf_order.size() <= kSmallSceneMaxTris) {
@@ -421,7 +424,7 @@ void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGP
             }
         }
         if (!split) {
-            if (j.count <= 8 && (best_axis < 0 || j.count <= 4)) { make_leaf(); continue; }
+            if (j.count <= 4) { make_leaf(); continue; }            // leaves hold at most 4 triangles (the wide node's 4-bit slots)
             // degenerate (all centroids equal) or forced: median split by index
             mid = j.count / 2;
         }
@@ -475,10 +478,11 @@ void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGP
     }
 }
 
-// 4-wide collapse.  Each wide node starts from a binary node's two children and repeatedly replaces the internal child of
-// largest surface area by that child's two children until it has four (or only leaves are left).  The child boxes are the
-// binary tree's (already padded) boxes, copied bit for bit, so the wide tree is exactly as conservative as the binary one.
-void collapse_bvh4(const std::vector<NodeGPU>& n2, std::vector<Node4GPU>& n4, uint32_t& max_stack) {
+// Compressed 8-wide collapse.  Each wide node starts from a binary node's two children and repeatedly replaces the internal
+// child of largest surface area by that child's two children until it has eight (or only leaves are left).  The child boxes
+// are the binary tree's padded boxes rounded OUTWARD onto the node's byte grid (checked in exact double arithmetic), so the
+// wide tree is conservative whenever the binary one is.
+bool collapse_bvh8(const std::vector<NodeGPU>& n2, std::vector<Node8GPU>& n8, std::vector<uint32_t>& tri_slots, uint32_t& max_stack) {
     struct Ch { float mn[3], mx[3]; int32_t c; };
     auto get = [](const NodeGPU& N, int which) {
         Ch r;
@@ -487,41 +491,107 @@ void collapse_bvh4(const std::vector<NodeGPU>& n2, std::vector<Node4GPU>& n4, ui
         return r;
     };
     auto area = [](const Ch& b) { const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2]; return dx * dy + dy * dz + dz * dx; };
-    n4.clear(); max_stack = 0;
-    if (n2.empty()) return;
+    n8.clear(); tri_slots.clear(); max_stack = 0;
+    if (n2.empty()) return true;
     std::vector<int32_t> src; src.push_back(0);            // binary node behind each wide node, breadth-first
     for (size_t h = 0; h < src.size(); h++) {
-        Ch ch[4]; int m = 0;
+        Ch ch[8]; int m = 0;
         const NodeGPU& N = n2[(size_t)src[h]];
         for (int w = 0; w < 2; w++) { Ch c = get(N, w); if (c.c != kEmptyChild) ch[m++] = c; }
-        while (m < 4) {
+        while (m < 8) {
             int best = -1; float ba = -1.0f;
             for (int k = 0; k < m; k++) if (ch[k].c >= 0) { const float a = area(ch[k]); if (best < 0 || a > ba) { ba = a; best = k; } }
             if (best < 0) break;
+            if ((size_t)ch[best].c >= n2.size()) return false;
             const NodeGPU& C = n2[(size_t)ch[best].c];
             const Ch a = get(C, 0), b = get(C, 1);           // internal nodes below the root always have two children
+            if (a.c == kEmptyChild || b.c == kEmptyChild) return false;
             ch[best] = a; ch[m++] = b;
         }
-        Node4GPU W{};
-        float* rows[6] = {&W.mnx.x, &W.mny.x, &W.mnz.x, &W.mxx.x, &W.mxy.x, &W.mxz.x};
-        for (int k = 0; k < 4; k++) {
-            if (k < m) {
-                for (int a = 0; a < 3; a++) { rows[a][k] = ch[k].mn[a]; rows[3 + a][k] = ch[k].mx[a]; }
-                if (ch[k].c >= 0) { W.child[k] = (int32_t)src.size(); src.push_back(ch[k].c); } else W.child[k] = ch[k].c;
-            } else {
-                for (int a = 0; a < 3; a++) { rows[a][k] = INFINITY; rows[3 + a][k] = -INFINITY; }
-                W.child[k] = kEmptyChild;
+        Node8GPU W{};
+        float bmn[3] = {0, 0, 0}, bmx[3] = {0, 0, 0};
+        for (int a = 0; a < 3; a++) {
+            float lo = INFINITY, hi = -INFINITY;
+            for (int k = 0; k < m; k++) { lo = std::min(lo, ch[k].mn[a]); hi = std::max(hi, ch[k].mx[a]); }
+            if (m == 0) { lo = 0.0f; hi = 0.0f; }
+            bmn[a] = lo; bmx[a] = hi;
+        }
+        // ---- slots: child with the largest projection on an octant's diagonal gets that octant's slot (greedy assignment) ----
+        int slot_of[8]; bool slot_used[8] = {false, false, false, false, false, false, false, false};
+        {
+            double cost[8][8];
+            for (int k = 0; k < m; k++) for (int sl = 0; sl < 8; sl++) {
+                double c = 0.0;
+                for (int a = 0; a < 3; a++) {
+                    const double rel = 0.5 * ((double)ch[k].mn[a] + (double)ch[k].mx[a]) - 0.5 * ((double)bmn[a] + (double)bmx[a]);
+                    c += ((sl >> a) & 1) ? rel : -rel;
+                }
+                cost[k][sl] = c;
+            }
+            bool done[8] = {false, false, false, false, false, false, false, false};
+            for (int it = 0; it < m; it++) {
+                int bk = -1, bs = -1; double bc = 0.0;
+                for (int k = 0; k < m; k++) if (!done[k]) for (int sl = 0; sl < 8; sl++) if (!slot_used[sl]) if (bk < 0 || cost[k][sl] > bc) { bc = cost[k][sl]; bk = k; bs = sl; }
+                done[bk] = true; slot_used[bs] = true; slot_of[bk] = bs;
             }
         }
-        n4.push_back(W);
+        int child_at[8]; for (int sl = 0; sl < 8; sl++) child_at[sl] = -1;
+        for (int k = 0; k < m; k++) child_at[slot_of[k]] = k;
+        // ---- byte grid per axis: smallest power of two with 255 steps covering the node ----
+        W.px = bmn[0]; W.py = bmn[1]; W.pz = bmn[2];
+        int eb[3]; double step[3];
+        for (int a = 0; a < 3; a++) {
+            const double ext = (double)bmx[a] - (double)bmn[a];
+            int e = -120;
+            if (ext > 0.0) { e = std::max(-120, (int)std::ilogb(ext / 255.0)); while (std::ldexp(255.0, e) < ext) e++; }
+            if (e > 120 || !std::isfinite(ext)) return false;
+            eb[a] = e + 127; step[a] = std::ldexp(1.0, e);
+        }
+        uint32_t imask = 0, trivalid = 0;
+        uint8_t qb[6][8];
+        for (int sl = 0; sl < 8; sl++) {
+            for (int r = 0; r < 6; r++) qb[r][sl] = 0;
+            const int k = child_at[sl];
+            if (k < 0) continue;
+            const float p[3] = {W.px, W.py, W.pz};
+            for (int a = 0; a < 3; a++) {
+                double qlo = std::floor(((double)ch[k].mn[a] - (double)p[a]) / step[a]), qhi = std::ceil(((double)ch[k].mx[a] - (double)p[a]) / step[a]);
+                qlo = std::min(255.0, std::max(0.0, qlo)); qhi = std::min(255.0, std::max(0.0, qhi));
+                // exact check: the decoded planes bracket the source box
+                if ((double)p[a] + qlo * step[a] > (double)ch[k].mn[a] || (double)p[a] + qhi * step[a] < (double)ch[k].mx[a]) return false;
+                qb[a][sl] = (uint8_t)qlo; qb[3 + a][sl] = (uint8_t)qhi;
+            }
+            if (ch[k].c >= 0) imask |= 1u << sl;
+        }
+        W.child_base = (uint32_t)src.size();
+        for (int sl = 0; sl < 8; sl++) if (imask & (1u << sl)) src.push_back(ch[child_at[sl]].c);
+        W.tri_base = (uint32_t)tri_slots.size();
+        for (int sl = 0; sl < 8; sl++) {
+            const int k = child_at[sl];
+            if (k < 0 || ch[k].c >= 0) continue;
+            const uint32_t v = ~(uint32_t)ch[k].c, first = v >> 3, cnt = (v & 7u) + 1u;
+            if (cnt > 4) return false;
+            trivalid |= ((1u << cnt) - 1u) << (4 * sl);
+            for (uint32_t t = 0; t < cnt; t++) tri_slots.push_back(first + t);
+        }
+        W.e_imask = (uint32_t)eb[0] | (uint32_t)eb[1] << 8 | (uint32_t)eb[2] << 16 | imask << 24;
+        W.trivalid = trivalid; W.pad = 0;
+        for (int r = 0; r < 6; r++) {
+            W.q[2 * r]     = (uint32_t)qb[r][0] | (uint32_t)qb[r][1] << 8 | (uint32_t)qb[r][2] << 16 | (uint32_t)qb[r][3] << 24;
+            W.q[2 * r + 1] = (uint32_t)qb[r][4] | (uint32_t)qb[r][5] << 8 | (uint32_t)qb[r][6] << 16 | (uint32_t)qb[r][7] << 24;
+        }
+        n8.push_back(W);
+        if (n8.size() >= (1u << 28)) return false;
     }
-    std::vector<uint32_t> need(n4.size(), 0);                // children have larger indices: one reverse sweep
-    for (size_t i = n4.size(); i-- > 0;) {
-        uint32_t m = 0, deep = 0;
-        for (int k = 0; k < 4; k++) { const int32_t c = n4[i].child[k]; if (c == kEmptyChild) continue; m++; if (c >= 0) deep = std::max(deep, need[(size_t)c]); }
-        need[i] = (m ? m - 1 : 0) + deep;
+    std::vector<uint32_t> need(n8.size(), 0);                // children have larger indices: one reverse sweep
+    for (size_t i = n8.size(); i-- > 0;) {
+        const uint32_t imask = n8[i].e_imask >> 24, nint = (uint32_t)__builtin_popcount(imask);
+        uint32_t deep = 0;
+        for (uint32_t r = 0; r < nint; r++) deep = std::max(deep, need[(size_t)n8[i].child_base + r]);
+        need[i] = (nint > 1 ? 1u : 0u) + deep;
     }
     max_stack = need[0];
+    return true;
 }
 
 }  // namespace rtx

@@ -19,8 +19,10 @@ struct InstHost { uint32_t mesh; float o2w[16]; float nrm[16]; float o2w_inv[16]
 struct BuiltScene {
     std::vector<MatGPU>   mats;
     std::vector<NodeGPU>  nodes;      // binary tree (build / refit form, host only)
-    std::vector<Node4GPU> nodes4;     // 4-wide collapse of `nodes` (device traversal form)
-    uint32_t stack4 = 0;              // traversal stack entries the 4-wide tree can need
+    std::vector<Node8GPU> nodes8;     // compressed 8-wide collapse of `nodes` (device traversal form)
+    std::vector<uint32_t> tri_slots8; // leaf-order slot of each triangle in the wide tree's order
+    std::vector<TriGPU>   tris8;      // `tris` permuted into that order (device copy)
+    uint32_t stack8 = 0;              // traversal stack entries (sibling groups) the wide tree can need
     std::vector<TriGPU>   tris;       // leaf order
     // tiny-scene path (only when the scene has <= kSmallSceneMaxTris triangles): pre-test records + their triangles
     std::vector<SmallRecPair> small_recs; std::vector<TriGPU> small_tris; uint32_t small_nrec = 0;
@@ -55,8 +57,9 @@ struct SceneHost {
 void refit_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGPU>& nodes, const std::vector<uint32_t>& leaf_order);
 void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGPU>& nodes,
                std::vector<uint32_t>& leaf_order, uint32_t& max_depth);
-// collapse the binary tree into the 4-wide device form (largest-area internal child opened first); max_stack = bound on the
-// entries a nearest-first traversal can hold (up to 3 pushes per level)
-void collapse_bvh4(const std::vector<NodeGPU>& nodes2, std::vector<Node4GPU>& nodes4, uint32_t& max_stack);
+// collapse the binary tree into the compressed 8-wide device form (largest-area internal child opened first, octant-ordered
+// slots, outward-rounded byte quantisation); tri_slots = leaf-order slots in the wide tree's triangle order; max_stack =
+// bound on the sibling-group entries a traversal can hold (one per level).  Returns false on a malformed input tree.
+bool collapse_bvh8(const std::vector<NodeGPU>& nodes2, std::vector<Node8GPU>& nodes8, std::vector<uint32_t>& tri_slots, uint32_t& max_stack);
 
 }  // namespace rtx

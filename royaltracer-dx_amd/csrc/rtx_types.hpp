@@ -16,14 +16,21 @@ struct alignas(16) F4 { float x, y, z, w; };
 struct alignas(16) NodeGPU { F4 a, b, c, d; };
 constexpr int32_t kEmptyChild = 0x7FFFFFFF;   // never visited (box is inverted)
 
-// Device traversal format: 4-wide node collapsed from the binary tree (one 128-B fetch = one L2 line per step, half the
-// dependent fetches of the binary walk).  Child boxes are stored SoA so that one 16-B load brings the same plane of all
-// four children; `child` uses the NodeGPU codes (internal index / leaf / kEmptyChild for unused slots, whose box is
-// NOT relied upon).  Breadth-first order: children have larger indices than their parent, [0, K) is the top of the tree.
-struct alignas(16) Node4GPU { F4 mnx, mny, mnz, mxx, mxy, mxz; int32_t child[4]; uint32_t pad[4]; };
-static_assert(sizeof(Node4GPU) == 128, "Node4GPU must be one 128-byte line");
+// Device traversal format: compressed 8-wide node, 80 bytes = five 16-B loads per traversal step (the traversal kernels are
+// bound by the number of per-lane loads, profiles/r01_pmc_bvh.md).  After Ylitie, Karras, Laine, "Efficient Incoherent Ray
+// Traversal on GPUs Through Compressed Wide BVHs" (HPG 2017), re-derived for this renderer's exactness contract:
+//   child box plane = p + q * 2^e per axis, q an unsigned byte, rounded OUTWARD from the binary tree's padded boxes
+//   e_imask   = (ex + 127) | (ey + 127) << 8 | (ez + 127) << 16 | imask << 24      imask bit s: slot s is an internal node
+//   child_base: index of the first internal child; internal children are consecutive in slot order (rank = popcount)
+//   tri_base  : first triangle of this node's leaf children, consecutive in slot order, <= 4 per child
+//   trivalid  : nibble s = (1 << count_s) - 1 for a leaf child in slot s, 0 otherwise
+//   q[12]     : qlo_x, qlo_y, qlo_z, qhi_x, qhi_y, qhi_z as two dwords each (byte k of the pair = slot k)
+// Slots are assigned so that visiting hit children in increasing (slot ^ octant) — octant bit a = ray goes negative
+// along axis a — approximates front-to-back order without sorting.  Breadth-first: children follow their parents.
+struct alignas(16) Node8GPU { float px, py, pz; uint32_t e_imask; uint32_t child_base, tri_base, trivalid, pad; uint32_t q[12]; };
+static_assert(sizeof(Node8GPU) == 80, "Node8GPU must be 80 bytes");
 
-// World-space triangle in leaf order: v0 (w = global triangle id bits), e1 = v1 - v0, e2 = v2 - v0.
+// World-space triangle (device copy: in the wide tree's order, rtx_scene_host.cpp): v0 (w = global triangle id bits), e1 = v1 - v0, e2 = v2 - v0.
 struct alignas(16) TriGPU { F4 v0, e1, e2; };
 
 // Tiny scenes (<= 64 triangles, e.g. the Cornell Box): no BVH.  Triangles are merged, where possible, into planar

@@ -115,44 +115,59 @@ static int bvh_validate(const std::vector<float>& w, const std::vector<rtx::Node
     return 0;
 }
 
-// the 4-wide collapse: same coverage properties, checked on the wide nodes themselves
-static int bvh4_validate(const std::vector<float>& w, const std::vector<rtx::Node4GPU>& nodes, const std::vector<uint32_t>& order, uint32_t* max_stack_seen) {
+// the compressed 8-wide collapse: same coverage properties, checked on the DECODED byte-grid boxes of the wide nodes
+static int bvh8_validate(const std::vector<float>& w, const std::vector<rtx::Node8GPU>& nodes, const std::vector<uint32_t>& order,
+                         const std::vector<uint32_t>& tri_slots, uint32_t* max_stack_seen) {
     const uint32_t ntris = (uint32_t)(w.size() / 9);
-    struct It { int32_t child; float mn[3], mx[3]; uint32_t depth_pushes; };
+    if (tri_slots.size() != ntris) return 20;
+    struct It { uint32_t node; double mn[3], mx[3]; uint32_t pushes; };
     std::vector<uint8_t> covered(ntris, 0), visited(nodes.size(), 0);
-    std::vector<It> st;
-    const float inf = INFINITY;
-    uint32_t deepest = 0;
-    auto push_children = [&](size_t ni, const float* pmn, const float* pmx, uint32_t pushes) -> int {
-        const rtx::Node4GPU& N = nodes[ni];
-        if (visited[ni]) return 11;
-        visited[ni] = 1;
-        const float* rows[6] = {&N.mnx.x, &N.mny.x, &N.mnz.x, &N.mxx.x, &N.mxy.x, &N.mxz.x};
-        uint32_t m = 0;
-        for (int k = 0; k < 4; k++) if (N.child[k] != rtx::kEmptyChild) m++;
-        for (int k = 0; k < 4; k++) {
-            if (N.child[k] == rtx::kEmptyChild) continue;
-            if (N.child[k] >= 0 && (size_t)N.child[k] <= ni) return 12;      // breadth-first: children after parents
-            It it; it.child = N.child[k]; it.depth_pushes = pushes + m - 1;
-            for (int a = 0; a < 3; a++) { it.mn[a] = std::max(rows[a][k], pmn[a]); it.mx[a] = std::min(rows[3 + a][k], pmx[a]); }
-            st.push_back(it);
-        }
-        deepest = std::max(deepest, pushes + (m ? m - 1 : 0));
-        return 0;
-    };
     if (nodes.empty()) return ntris ? 10 : 0;
-    float rmn[3] = {-inf, -inf, -inf}, rmx[3] = {inf, inf, inf};
-    if (int r = push_children(0, rmn, rmx, 0)) return r;
+    std::vector<It> st;
+    const double inf = INFINITY;
+    st.push_back({0u, {-inf, -inf, -inf}, {inf, inf, inf}, 0u});
+    uint32_t deepest = 0;
     while (!st.empty()) {
-        It it = st.back(); st.pop_back();
-        if (it.child >= 0) { if ((size_t)it.child >= nodes.size()) return 13; if (int r = push_children((size_t)it.child, it.mn, it.mx, it.depth_pushes)) return r; continue; }
-        uint32_t v = ~(uint32_t)it.child, first = v >> 3, cnt = (v & 7u) + 1u;
-        for (uint32_t k = 0; k < cnt; k++) {
-            if (first + k >= ntris) return 14;
-            uint32_t g = order[first + k];
-            if (covered[g]) return 15;
-            covered[g] = 1;
-            for (int vtx = 0; vtx < 3; vtx++) for (int a = 0; a < 3; a++) { float c = w[(size_t)g * 9 + vtx * 3 + a]; if (c < it.mn[a] || c > it.mx[a]) return 16; }
+        const It it = st.back(); st.pop_back();
+        if (it.node >= nodes.size()) return 13;
+        if (visited[it.node]) return 11;
+        visited[it.node] = 1;
+        const rtx::Node8GPU& N = nodes[it.node];
+        const double p[3] = {N.px, N.py, N.pz};
+        double step[3];
+        for (int a = 0; a < 3; a++) { const int eb = (int)((N.e_imask >> (8 * a)) & 0xffu); if (eb < 1 || eb > 254) return 21; step[a] = std::ldexp(1.0, eb - 127); }
+        const uint32_t imask = N.e_imask >> 24;
+        const uint32_t nint = (uint32_t)__builtin_popcount(imask);
+        const uint32_t pushes = it.pushes + (nint > 1 ? 1u : 0u);
+        deepest = std::max(deepest, pushes);
+        uint32_t rank = 0, tri_at = N.tri_base;
+        for (int sl = 0; sl < 8; sl++) {
+            const uint32_t nib = (N.trivalid >> (4 * sl)) & 0xfu;
+            const bool internal = (imask >> sl) & 1u;
+            if (internal && nib) return 22;
+            if (!internal && !nib) continue;
+            double mn[3], mx[3];
+            for (int a = 0; a < 3; a++) {
+                const uint32_t qlo = (N.q[2 * a + (sl >> 2)] >> (8 * (sl & 3))) & 0xffu, qhi = (N.q[2 * (3 + a) + (sl >> 2)] >> (8 * (sl & 3))) & 0xffu;
+                mn[a] = std::max(p[a] + qlo * step[a], it.mn[a]); mx[a] = std::min(p[a] + qhi * step[a], it.mx[a]);
+            }
+            if (internal) {
+                const uint32_t c = N.child_base + rank++;
+                if (c <= it.node) return 12;                                     // breadth-first: children after parents
+                It nx; nx.node = c; nx.pushes = pushes;
+                for (int a = 0; a < 3; a++) { nx.mn[a] = mn[a]; nx.mx[a] = mx[a]; }
+                st.push_back(nx);
+            } else {
+                if (nib != 1 && nib != 3 && nib != 7 && nib != 15) return 23;
+                const uint32_t cnt = (uint32_t)__builtin_popcount(nib);
+                for (uint32_t k = 0; k < cnt; k++, tri_at++) {
+                    if (tri_at >= ntris || tri_slots[tri_at] >= ntris) return 14;
+                    const uint32_t g = order[tri_slots[tri_at]];
+                    if (covered[g]) return 15;
+                    covered[g] = 1;
+                    for (int vtx = 0; vtx < 3; vtx++) for (int a = 0; a < 3; a++) { const double c = w[(size_t)g * 9 + vtx * 3 + a]; if (c < mn[a] || c > mx[a]) return 16; }
+                }
+            }
         }
     }
     for (uint32_t i = 0; i < ntris; i++) if (!covered[i]) return 17;
@@ -161,18 +176,18 @@ static int bvh4_validate(const std::vector<float>& w, const std::vector<rtx::Nod
     return 0;
 }
 
-// build + collapse; returns 0 when the wide tree covers every triangle exactly once inside its boxes and the reported stack
-// bound is what the deepest root-to-leaf path can push
-int rtxh_bvh4_check(const float* wt, uint32_t ntris, uint32_t* nodes4_out, uint32_t* stack_out) {
+// build + collapse; returns 0 when the wide tree covers every triangle exactly once inside its decoded boxes and the reported
+// stack bound is what the deepest root-to-leaf path can push
+int rtxh_bvh8_check(const float* wt, uint32_t ntris, uint32_t* nodes8_out, uint32_t* stack_out) {
     std::vector<float> w(wt, wt + (size_t)ntris * 9);
     std::vector<rtx::NodeGPU> nodes; std::vector<uint32_t> order; uint32_t depth = 0;
     rtx::build_bvh(w, 0.0f, nodes, order, depth);
-    std::vector<rtx::Node4GPU> n4; uint32_t stack = 0;
-    rtx::collapse_bvh4(nodes, n4, stack);
-    if (nodes4_out) *nodes4_out = (uint32_t)n4.size();
+    std::vector<rtx::Node8GPU> n8; std::vector<uint32_t> slots; uint32_t stack = 0;
+    if (!rtx::collapse_bvh8(nodes, n8, slots, stack)) return 30;
+    if (nodes8_out) *nodes8_out = (uint32_t)n8.size();
     if (stack_out) *stack_out = stack;
     uint32_t seen = 0;
-    if (int r = bvh4_validate(w, n4, order, &seen)) return r;
+    if (int r = bvh8_validate(w, n8, order, slots, &seen)) return r;
     return seen == stack ? 0 : 19;
 }
 
@@ -192,9 +207,9 @@ int rtxh_bvh_refit_check(const float* before, const float* after, uint32_t ntris
     rtx::build_bvh(a, 0.0f, nodes, order, depth);
     rtx::refit_bvh(b, 0.0f, nodes, order);
     if (int r = bvh_validate(b, nodes, order, nullptr)) return r;
-    std::vector<rtx::Node4GPU> n4; uint32_t stack = 0;
-    rtx::collapse_bvh4(nodes, n4, stack);
-    return bvh4_validate(b, n4, order, nullptr);
+    std::vector<rtx::Node8GPU> n8; std::vector<uint32_t> slots; uint32_t stack = 0;
+    if (!rtx::collapse_bvh8(nodes, n8, slots, stack)) return 30;
+    return bvh8_validate(b, n8, order, slots, nullptr);
 }
 
 // the tiny-scene pre-test records as rtx_commit_scene builds them (for host-side conservativeness tests)

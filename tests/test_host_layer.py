@@ -119,9 +119,9 @@ def test_sponza_class_scene(rt):
     assert np.isfinite(tri).all() and np.abs(tri).max() < 3.0
     w = tri.reshape(-1, 9)
     rc, nodes, depth, leaf = rt.bvh_check(w)
-    assert rc == 0 and leaf <= 8 and depth < 60 and nodes >= len(w) // 8
-    rc4, nodes4, stack4 = rt.bvh4_check(w)                              # the 4-wide device form of the same tree
-    assert rc4 == 0 and nodes4 < nodes and stack4 <= 62, (rc4, nodes4, stack4)
+    assert rc == 0 and leaf <= 4 and depth < 60 and nodes >= len(w) // 8
+    rc8, nodes8, stack8 = rt.bvh8_check(w)                              # the compressed 8-wide device form of the same tree
+    assert rc8 == 0 and nodes8 < nodes // 2 and stack8 <= 24, (rc8, nodes8, stack8)
     sc2 = rt.Scene.sponza_class(262144, 260)
     assert np.array_equal(sc2.meshes[0][0], v)                          # deterministic
 
@@ -134,11 +134,11 @@ def test_bvh_builder_invariants(rt, cornell):
     for n in (1, 2, 3, 7, 100, 5000):
         c = rng.uniform(-1, 1, (n, 1, 3)); t = (c + rng.normal(scale=0.02, size=(n, 3, 3))).astype(np.float32)
         assert rt.bvh_check(t.reshape(-1, 9))[0] == 0
-        assert rt.bvh4_check(t.reshape(-1, 9))[0] == 0
+        assert rt.bvh8_check(t.reshape(-1, 9))[0] == 0
     same = np.tile(np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], np.float32), (37, 1))     # 37 identical triangles
     assert rt.bvh_check(same)[0] == 0
-    assert rt.bvh4_check(same)[0] == 0
-    assert rt.bvh4_check(np.zeros((0, 9), np.float32))[0] == 0
+    assert rt.bvh8_check(same)[0] == 0
+    assert rt.bvh8_check(np.zeros((0, 9), np.float32))[0] == 0
 
 
 # ---- the C-ABI library -------------------------------------------------------------------------
