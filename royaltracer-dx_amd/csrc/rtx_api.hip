@@ -123,7 +123,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_FUSED_BOUNCE: c->fused = value != 0; return RTX_OK;
     case RTX_OPT_BOUNCE_VARIANT: g_bounce_variant = (int)value; return RTX_OK;
     case RTX_OPT_STACK_PRIVATE: c->stack_private = (int)value; c->committed = false; return RTX_OK;
-    case RTX_OPT_TRACE_SCHED: g_trace_sched = value ? 1 : 0; return RTX_OK;
+    case RTX_OPT_TRACE_SCHED: g_trace_sched = (int)value; return RTX_OK;
     case RTX_OPT_REFILL_MIN: if (value < 1 || value > 64) { c->err = "refill_min must be in [1, 64]"; return RTX_ERR_INVALID; } g_refill_min = (int)value; return RTX_OK;
     default: c->err = "unknown option"; return RTX_ERR_INVALID;
     }

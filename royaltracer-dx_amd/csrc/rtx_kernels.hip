@@ -116,6 +116,9 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DevFrame f, DevPaths p, const
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4f lds_v4f;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v fma2(f2v a, f2v b, f2v c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2v splat2(float x) { f2v r = {x, x}; return r; }
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v2u lds_u2;
@@ -192,14 +195,19 @@ __device__ __forceinline__ void node8_hits(const Node8R& N, f3 o, f3 idir, uint3
     const uint32_t qny[2] = {ny ? N.q2.x : N.q0.z, ny ? N.q2.y : N.q0.w}, qfy[2] = {ny ? N.q0.z : N.q2.x, ny ? N.q0.w : N.q2.y};
     const uint32_t qnz[2] = {nz ? N.q2.z : N.q1.x, nz ? N.q2.w : N.q1.y}, qfz[2] = {nz ? N.q1.x : N.q2.z, nz ? N.q1.y : N.q2.w};
     uint32_t hits = 0;
+    const f2v vsx = splat2(sx), vsy = splat2(sy), vsz = splat2(sz);
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < 8; k += 2) {                     // two children per iteration on packed FP32 (v_pk_fma_f32 / v_pk_mul_f32)
         const int h = k >> 2, b = k & 3;
-        const float tnx = __builtin_fmaf(byte_f(qnx[h], b), sx, anx), tny = __builtin_fmaf(byte_f(qny[h], b), sy, any_), tnz = __builtin_fmaf(byte_f(qnz[h], b), sz, anz);
-        const float tfx = __builtin_fmaf(byte_f(qfx[h], b), sx, afx), tfy = __builtin_fmaf(byte_f(qfy[h], b), sy, afy), tfz = __builtin_fmaf(byte_f(qfz[h], b), sz, afz);
-        const float lo = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
-        const float hi = fminf(fminf(tfx, tfy), fminf(tfz, tbest));
-        if (lo * 0.999998f <= hi * 1.000002f) hits |= 1u << k;       // lo >= tmin >= 0
+        const f2v bnx = {byte_f(qnx[h], b), byte_f(qnx[h], b + 1)}, bny = {byte_f(qny[h], b), byte_f(qny[h], b + 1)}, bnz = {byte_f(qnz[h], b), byte_f(qnz[h], b + 1)};
+        const f2v bfx = {byte_f(qfx[h], b), byte_f(qfx[h], b + 1)}, bfy = {byte_f(qfy[h], b), byte_f(qfy[h], b + 1)}, bfz = {byte_f(qfz[h], b), byte_f(qfz[h], b + 1)};
+        const f2v tnx = fma2(bnx, vsx, splat2(anx)), tny = fma2(bny, vsy, splat2(any_)), tnz = fma2(bnz, vsz, splat2(anz));
+        const f2v tfx = fma2(bfx, vsx, splat2(afx)), tfy = fma2(bfy, vsy, splat2(afy)), tfz = fma2(bfz, vsz, splat2(afz));
+        const f2v lo = {fmaxf(fmaxf(tnx.x, tny.x), fmaxf(tnz.x, tmin)), fmaxf(fmaxf(tnx.y, tny.y), fmaxf(tnz.y, tmin))};
+        const f2v hi = {fminf(fminf(tfx.x, tfy.x), fminf(tfz.x, tbest)), fminf(fminf(tfx.y, tfy.y), fminf(tfz.y, tbest))};
+        const f2v los = lo * 0.999998f, his = hi * 1.000002f;       // lo >= tmin >= 0
+        if (los.x <= his.x) hits |= 1u << k;
+        if (los.y <= his.y) hits |= 2u << k;
     }
     const uint32_t imask = w >> 24;
     // internal hits, permuted so that bit j = slot (j ^ oct): lowest set bit = first child to visit
@@ -282,9 +290,6 @@ __device__ __forceinline__ void traverse(const DevScene& sc, const TraceLds& L, 
 // candidates of each lane.  The result is the same minimum-over-all-triangles as the BVH path and the oracle's
 // brute force: phase 1 only removes triangles that the exact test would reject (tolerances: the edge-plane distance
 // delta and the t margin, built in rtx_scene_host.cpp).
-typedef float f2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2v fma2(f2v a, f2v b, f2v c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f2v splat2(float x) { f2v r = {x, x}; return r; }
 
 template <bool ANY>
 __device__ __forceinline__ void traverse_small(const DevScene& sc, const SmallRecPair* __restrict__ sp, const TraceLds& L, f3 o, f3 d, float tmin, float tmax,
@@ -398,8 +403,8 @@ __global__ __launch_bounds__(kBlock) void k_raygen_trace_small(DevScene sc, cons
 // until each holds a leaf (or is done)" followed by "all lanes with a leaf test its triangles" (while-while).
 // Exit: a wave leaves when the sub-queue is exhausted and no lane holds a ray — every wave reaches that.
 // ---------------------------------------------------------------------------------------------
-int g_refill_min = 20;
-int g_trace_sched = 1;                                // 0 = while-while, 1 = voted node / triangle steps.  With the 128-B 4-wide nodes the voted schedule
+int g_refill_min = 12;
+int g_trace_sched = 2;                                // 0 = while-while, 1 = voted node / triangle steps.  With the 128-B 4-wide nodes the voted schedule
                                                       // was slower (texture-addresser bound, profiles/r01_pmc_bvh.md); with the 80-B 8-wide nodes it wins
                                                       // (Sponza-class 59.2 vs 67.7 ms, Bistro-class 47.8 vs 56.2 ms)
 
@@ -461,12 +466,13 @@ __device__ __forceinline__ void process_leaf(const DevScene& sc, const TraceLds&
 // Voted schedule (g_trace_sched = 1): instead of "walk until EVERY lane holds triangles, then test every lane's triangles"
 // each iteration the wave votes for the step most of its busy lanes are waiting for: one node step, or one triangle test.
 template <bool ANY, class STK>
-__device__ __forceinline__ void voted_step(const DevScene& sc, const TraceLds& L, RayLane& R, STK& stk) {
+__device__ __forceinline__ void voted_step(const DevScene& sc, const TraceLds& L, RayLane& R, STK& stk, uint32_t sched) {
     const bool busy = R.has && !R.done;
     const bool in_tri = busy && R.T.bits != 0u;
     const bool in_node = busy && !in_tri;
     const uint32_t ni = (uint32_t)__popcll(__ballot(in_node)), nl = (uint32_t)__popcll(__ballot(in_tri));
-    if (ni >= nl) {
+    const uint32_t wn = sched == 3u ? 2u : 1u, wl = sched == 2u ? 2u : sched == 4u ? 3u : 1u;    // experiment: weighted vote
+    if (ni * wn >= nl * wl) {
         if (in_node) { descend8(sc, L, R.o, R.idir, R.oct, R.tmin, R.bt, R.G, R.T, stk, R.sp); next_group(R, stk); }
     } else if (in_tri) {
         tri_step<ANY>(sc, L, R);
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
                const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
                ray_begin(R, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, pid);
            })) {
-        if (sched) voted_step<false>(sc, L, R, stk);
+        if (sched) voted_step<false>(sc, L, R, stk, sched);
         else { walk_internal<false>(sc, L, R, stk); process_leaf<false>(sc, L, R, stk); }
         if (R.has && R.done) { p.hit[R.item] = {R.bt, R.bu, R.bv, u2f(R.bprim)}; R.has = false; }
     }
@@ -567,7 +573,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const Smal
                const F4 so = sh_o[qb + idx], sd = sh_d[qb + idx];
                ray_begin(R, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, idx);
            })) {
-        if (sched) voted_step<true>(sc, L, R, stk);
+        if (sched) voted_step<true>(sc, L, R, stk, sched);
         else { walk_internal<true>(sc, L, R, stk); process_leaf<true>(sc, L, R, stk); }
         if (R.has && R.done) { finish(R.item, R.bprim != kMissPrim); R.has = false; }
     }
