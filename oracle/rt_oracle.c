@@ -397,7 +397,7 @@ int orc_commit(orc_ctx* c) {
     for (uint32_t i = 0; i < nt; i++) c->order[i] = i;
     c->nodes = (node_t*)malloc((size_t)(2 * (nt ? nt : 1)) * sizeof(node_t));
     c->nnodes = 0;
-    if (nt) build_node(c, 0, nt, 1e-6f * scale);
+    if (nt) build_node(c, 0, nt, 1e-5f * scale);
     return 0;
 }
 
@@ -461,7 +461,9 @@ static inline int box_hit(const node_t* n, v3 o, v3 d, v3 inv, float tmin, float
         float lo = minf(t1, t2), hi = maxf(t1, t2);
         te = maxf(te, lo); tx = minf(tx, hi);
     }
-    te = te - fabsf(te) * 1e-6f; tx = tx + fabsf(tx) * 1e-6f;
+    /* generous: the margins must cover the error of tri_hit's t (up to ~1e-5 relative next to a vertex of a small far
+       triangle), not only the slab arithmetic; the oracle's BVH only has to be conservative, not fast */
+    te = te - fabsf(te) * 1e-4f; tx = tx + fabsf(tx) * 1e-4f;
     return te <= tx && tx >= tmin && te <= tbest;
 }
 static hit_t closest_bvh(const orc_ctx* c, v3 o, v3 d, float tmin, float tmax) {

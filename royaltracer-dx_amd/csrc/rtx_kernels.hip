@@ -164,13 +164,17 @@ __device__ __forceinline__ bool tri_test(f3 o, f3 d, v4f v0w, v4f e1w, v4f e2w, 
 //     t_plane = q * (2^e * idir) + (p - o) * idir        (cvt + fma per plane; near / far rows picked by the ray's octant)
 // CONSERVATIVENESS (the closest hit must stay the minimum over ALL triangles): the builder rounds the boxes outward in exact
 // arithmetic; 2^e * idir is exact; a = fl(fl(p - o) * idir) carries a relative error <= 2^-23, so the near planes use
-// a - |a| 2^-22 and the far planes a + |a| 2^-22; what is left is relative to t and covered by the same 2e-6 margins as
-// before.  Hit children are visited in increasing (slot ^ octant) order; the rest of a node's hit children stay together in
+// a - |a| 2^-22 and the far planes a + |a| 2^-22; what is left is relative to t and covered by kSlabLo / kSlabHi.
+// Hit children are visited in increasing (slot ^ octant) order; the rest of a node's hit children stay together in
 // ONE stack entry (base index + hit bits + internal mask), so the stack holds one entry per level.
 struct Node8R { v4f h0; v4u h1, q0, q1, q2; };
 struct Grp { uint32_t base, bits; };                 // node group: child_base, ordered internal hits (bits 0-7) | imask << 8
 struct TriGrp { uint32_t base, bits, valid; };        // triangle group: tri_base, hit triangle bits, the node's trivalid
 constexpr float kPlaneEps = 2.384185791015625e-07f;   // 2^-22
+// relative widening of the slab interval.  It must cover the error of the TRIANGLE test's t, not only the slab arithmetic: a
+// hit next to a vertex of a small triangle seen from far away has a Moeller-Trumbore t that is off by ~1e-5 relative (found by
+// test_wide_bvh_equals_brute_force_on_hostile_soups: coincident duplicates lost their lowest-id tie at 2e-6), so 5e-5.
+constexpr float kSlabLo = 0.99995f, kSlabHi = 1.00005f;
 
 __device__ __forceinline__ Node8R load_node8(const DevScene& sc, const TraceLds& L, uint32_t idx) {
     Node8R N;
@@ -205,7 +209,7 @@ __device__ __forceinline__ void node8_hits(const Node8R& N, f3 o, f3 idir, uint3
         const f2v tfx = fma2(bfx, vsx, splat2(afx)), tfy = fma2(bfy, vsy, splat2(afy)), tfz = fma2(bfz, vsz, splat2(afz));
         const f2v lo = {fmaxf(fmaxf(tnx.x, tny.x), fmaxf(tnz.x, tmin)), fmaxf(fmaxf(tnx.y, tny.y), fmaxf(tnz.y, tmin))};
         const f2v hi = {fminf(fminf(tfx.x, tfy.x), fminf(tfz.x, tbest)), fminf(fminf(tfx.y, tfy.y), fminf(tfz.y, tbest))};
-        const f2v los = lo * 0.999998f, his = hi * 1.000002f;       // lo >= tmin >= 0
+        const f2v los = lo * kSlabLo, his = hi * kSlabHi;                 // lo >= tmin >= 0
         if (los.x <= his.x) hits |= 1u << k;
         if (los.y <= his.y) hits |= 2u << k;
     }

@@ -210,8 +210,9 @@ bool SceneHost::build(BuiltScene& B) {
     //      (the reference refits its TLAS every frame: Renderer.cpp:594, TopLevelASGenerator.cpp:149-250) ----
     std::vector<uint32_t>& leaf_order = B.leaf_order;
     const bool refit = !topo_dirty && B.leaf_order.size() == (size_t)nt && !B.nodes.empty();
-    if (refit) refit_bvh(wtri, 1e-6f * scale, B.nodes, leaf_order);
-    else build_bvh(wtri, 1e-6f * scale, B.nodes, leaf_order, B.max_depth);
+    const float bvh_pad = 2e-6f * scale;                  // absolute box padding (1e-5 measured 3 % slower; the relative margins kSlabLo / kSlabHi carry the triangle-test error)
+    if (refit) refit_bvh(wtri, bvh_pad, B.nodes, leaf_order);
+    else build_bvh(wtri, bvh_pad, B.nodes, leaf_order, B.max_depth);
     B.refit_count = refit ? B.refit_count + 1 : 0;
     topo_dirty = false;
     B.tris.resize(leaf_order.size());
