@@ -154,6 +154,9 @@ int  rtx_unpack_tiles(rtx_ctx*, const rtx_params*, const void* device_slabs_all_
 int  rtx_debug_primary_rays(rtx_ctx*, const rtx_params*, uint32_t sample_id, float* rays8 /* W*H*8 */);
 int  rtx_debug_trace_closest(rtx_ctx*, const float* rays8, uint32_t n, float* hits4);
 int  rtx_debug_trace_any(rtx_ctx*, const float* rays8, uint32_t n, uint8_t* occluded);
+/* closest-hit traversal of the BVH (never the tiny-scene path) that reports its work: stats4 = n * (t, node steps, triangle tests,
+   prim bits) — tree-quality measurements for DESIGN.md, not part of the reference boundary */
+int  rtx_debug_trace_stats(rtx_ctx*, const float* rays8, uint32_t n, float* stats4);
 /* out16 per hit = pos3, matID bits, normal3, area, inst bits, flat3, pad4 (ClosestHit, Hit_v6.hlsl:12-61) */
 int  rtx_debug_surface(rtx_ctx*, const float* rays8, const float* hits4, uint32_t n, float* out16);
 /* in9 = n(3) wo(3) wi(3); out8 = f(3), pdf, p_d, p_s, 0, 0 */

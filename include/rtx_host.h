@@ -51,6 +51,8 @@ int  rtxh_bvh_check(const float* world_tris9, uint32_t ntris, uint32_t* nodes_ou
    boxes of the wide nodes, children stored after their parents, <= 4 triangles per leaf slot, and *stack_out = the exact
    number of sibling-group entries the deepest root-to-leaf path can push */
 int  rtxh_bvh8_check(const float* world_tris9, uint32_t ntris, uint32_t* nodes8_out, uint32_t* stack_out);
+/* shape of that tree: hist[0..4] = leaf slots with 0 (unused) / 1 / 2 / 3 / 4 triangles, hist[5] = internal child slots */
+int  rtxh_bvh8_stats(const float* world_tris9, uint32_t ntris, uint32_t hist[6], uint32_t* nodes8_out);
 /* same invariants after building on `before` and REFITTING (topology kept) to `after` (TLAS refit, Renderer.cpp:594) */
 int  rtxh_bvh_refit_check(const float* before_tris9, const float* after_tris9, uint32_t ntris);
 

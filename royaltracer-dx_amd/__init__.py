@@ -114,6 +114,7 @@ _sig("rtx_unpack_tiles", C.c_int, _vp, C.POINTER(Params), _vp)
 _sig("rtx_debug_primary_rays", C.c_int, _vp, C.POINTER(Params), _u32, _vp)
 _sig("rtx_debug_trace_closest", C.c_int, _vp, _vp, _u32, _vp)
 _sig("rtx_debug_trace_any", C.c_int, _vp, _vp, _u32, _vp)
+_sig("rtx_debug_trace_stats", C.c_int, _vp, _vp, _u32, _vp)
 _sig("rtx_debug_surface", C.c_int, _vp, _vp, _vp, _u32, _vp)
 _sig("rtx_debug_bsdf_eval", C.c_int, _vp, _u32, _u32, _vp, _u32, _vp)
 _sig("rtx_debug_bsdf_sample", C.c_int, _vp, _u32, _u32, _vp, _u32, _vp)
@@ -143,6 +144,7 @@ _sig("rtxh_half_round", C.c_float, C.c_float)
 _sig("rtxh_bvh_check", C.c_int, _vp, _u32, _u32p, _u32p, _u32p)
 _sig("rtxh_bvh_refit_check", C.c_int, _vp, _vp, _u32)
 _sig("rtxh_bvh8_check", C.c_int, _vp, _u32, _u32p, _u32p)
+_sig("rtxh_bvh8_stats", C.c_int, _vp, _u32, _vp, _u32p)
 _sig("rtxh_scene_small_records", C.c_int, _vp, _vp, _vp, _u32, _u32p, _fp, _fp)
 _sig("rtxh_renderer_create", _vp, _u32, _u32, C.c_char_p, C.c_int)
 _sig("rtxh_renderer_set_scene", C.c_int, _vp, _vp)
@@ -276,6 +278,14 @@ def bvh_check(world_tris):
     nodes, depth, leaf = _u32(), _u32(), _u32()
     rc = lib.rtxh_bvh_check(_ptr(w), len(w), C.byref(nodes), C.byref(depth), C.byref(leaf))
     return rc, nodes.value, depth.value, leaf.value
+
+
+def bvh8_stats(world_tris):
+    """(hist of leaf-slot sizes 0..4 + internal slots, wide node count) of the device tree built for these triangles"""
+    w = _f32(world_tris).reshape(-1, 9)
+    hist = np.zeros(6, np.uint32); nodes = _u32()
+    rc = lib.rtxh_bvh8_stats(_ptr(w), len(w), _ptr(hist), C.byref(nodes))
+    return rc, hist, nodes.value
 
 
 def bvh8_check(world_tris):
@@ -443,6 +453,13 @@ class Context:
         r = _f32(rays8).reshape(-1, 8)
         out = np.zeros(len(r), np.uint8)
         self._ck(lib.rtx_debug_trace_any(self._h, _ptr(r), len(r), _ptr(out)), "rtx_debug_trace_any")
+        return out
+
+    def trace_stats(self, rays8):
+        """(n,4): t, node steps, triangle tests, prim bits of a closest-hit BVH traversal"""
+        r = _f32(rays8).reshape(-1, 8)
+        out = np.zeros((len(r), 4), np.float32)
+        self._ck(lib.rtx_debug_trace_stats(self._h, _ptr(r), len(r), _ptr(out)), "rtx_debug_trace_stats")
         return out
 
     def surface(self, rays8, hits4):

@@ -598,6 +598,7 @@ static int dbg_trace(rtx_ctx* c, const float* rays8, uint32_t n, int any, float*
 }
 int rtx_debug_trace_closest(rtx_ctx* c, const float* rays8, uint32_t n, float* hits4) { return dbg_trace(c, rays8, n, 0, hits4, nullptr); }
 int rtx_debug_trace_any(rtx_ctx* c, const float* rays8, uint32_t n, uint8_t* occluded) { return dbg_trace(c, rays8, n, 1, nullptr, occluded); }
+int rtx_debug_trace_stats(rtx_ctx* c, const float* rays8, uint32_t n, float* stats4) { return dbg_trace(c, rays8, n, 2, stats4, nullptr); }
 
 int rtx_debug_surface(rtx_ctx* c, const float* rays8, const float* hits4, uint32_t n, float* out16) {
     BIND(c);

@@ -287,6 +287,46 @@ __device__ __forceinline__ void traverse(const DevScene& sc, const TraceLds& L, 
     }
 }
 
+// closest-hit traversal that also counts node steps and triangle tests (rtx_debug_trace_stats: tree-quality measurements)
+__device__ __forceinline__ void traverse_stats(const DevScene& sc, const TraceLds& L, f3 o, f3 d, float tmin, float tmax,
+                                         float& bt, float& bu, float& bv, uint32_t& bprim) {
+    constexpr bool ANY = false;
+    uint32_t nsteps = 0, ntris = 0;
+    // zero direction components -> huge finite reciprocal (keeps the slab test NaN-free and conservative)
+    const float dxs = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
+    const float dys = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
+    const float dzs = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
+    const f3 idir = mk3(__builtin_amdgcn_rcpf(dxs), __builtin_amdgcn_rcpf(dys), __builtin_amdgcn_rcpf(dzs));
+    const uint32_t oct = ray_octant(idir);
+    bt = tmax; bu = 0.0f; bv = 0.0f; bprim = kMissPrim;
+    StackLds stk; stk.col = L.stack + threadIdx.x;
+    int sp = 0;
+    Grp G{0u, (1u << oct) | (1u << 8)};                 // the root as slot 0 of a virtual parent
+    TriGrp T{0u, 0u, 0u};
+    while (true) {
+        if (G.bits & 0xffu) { descend8(sc, L, o, idir, oct, tmin, bt, G, T, stk, sp); nsteps++; }
+        while (T.bits) {
+            const uint32_t bit = (uint32_t)__builtin_ctz(T.bits);
+            T.bits &= T.bits - 1u; ntris++;
+            const uint32_t slot = tri_slot8(T, bit);
+            v4f v0, e1, e2;
+            if (slot < sc.lds_tris) { const lds_v4f* t = L.tris + slot * 3u; v0 = t[0]; e1 = t[1]; e2 = t[2]; }
+            else { const v4f* t = (const v4f*)(sc.tris + slot); v0 = t[0]; e1 = t[1]; e2 = t[2]; }
+            float t, u, w;
+            if (tri_test(o, d, v0, e1, e2, tmin, tmax, t, u, w)) {
+                if (ANY) { bprim = 0u; return; }
+                const uint32_t gid = f2u(v0.w);
+                if (t < bt || (t == bt && gid < bprim)) { bt = t; bu = u; bv = w; bprim = gid; }
+            }
+        }
+        if (!(G.bits & 0xffu)) {
+            if (sp == 0) break;
+            sp--; G = stk.get(sp);
+        }
+    }
+    bu = (float)nsteps; bv = (float)ntris;
+}
+
 // Tiny-scene path (sc.nsmall != 0, all triangles staged in LDS): no BVH.  Phase 1 runs a CONSERVATIVE plane-form
 // pre-test of every triangle in a wave-uniform loop — two triangles per iteration on packed-FP32 instructions,
 // their coefficients wave-uniform (one s_load_dwordx16 pair per iteration, no LDS/VMEM traffic, no divergence) —
@@ -1511,7 +1551,8 @@ __global__ __launch_bounds__(kBlock) void k_dbg_trace(DevScene sc, const SmallRe
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const F4 ro = rays[2 * i], rd = rays[2 * i + 1];
         float t, u, v; uint32_t prim;
-        if (any) trace_ray<true>(sc, small, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w, t, u, v, prim);
+        if (any == 2) traverse_stats(sc, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w, t, u, v, prim);
+        else if (any) trace_ray<true>(sc, small, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w, t, u, v, prim);
         else trace_ray<false>(sc, small, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w, t, u, v, prim);
         hits[i] = {t, u, v, u2f(prim)};
     }

@@ -479,8 +479,8 @@ void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGP
     }
 }
 
-// Compressed 8-wide collapse.  Each wide node starts from a binary node's two children and repeatedly replaces the internal
-// child of largest surface area by that child's two children until it has eight (or only leaves are left).  The child boxes
+// Compressed 8-wide collapse.  Which binary subtrees become wide nodes or leaf slots is chosen by a surface-area-heuristic
+// dynamic program (below).  The child boxes
 // are the binary tree's padded boxes rounded OUTWARD onto the node's byte grid (checked in exact double arithmetic), so the
 // wide tree is conservative whenever the binary one is.
 bool collapse_bvh8(const std::vector<NodeGPU>& n2, std::vector<Node8GPU>& n8, std::vector<uint32_t>& tri_slots, uint32_t& max_stack) {
@@ -494,20 +494,77 @@ bool collapse_bvh8(const std::vector<NodeGPU>& n2, std::vector<Node8GPU>& n8, st
     auto area = [](const Ch& b) { const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2]; return dx * dy + dy * dz + dz * dx; };
     n8.clear(); tri_slots.clear(); max_stack = 0;
     if (n2.empty()) return true;
+    // ---- which binary subtrees become wide nodes / leaf slots: surface-area-heuristic dynamic program (Ylitie et al. 2017,
+    //      section 3.1).  cost[n][i] = cheapest way to represent binary subtree n with at most i child slots of its wide
+    //      parent: as ONE slot (a leaf slot holding all its <= 4 triangles, or an internal slot = a wide node of its own with 8
+    //      slots to distribute), or split between its two children.  Greedy "open the largest child" filled 4.1 of 8 slots. ----
+    const size_t nn = n2.size();
+    constexpr double kNodeCost = 1.0, kTriCost = 0.45;     // a triangle test costs ~0.45 node steps (VALU counts 95 : 207)
+    struct Sub { double area; uint32_t prims, first; };
+    std::vector<Sub> sub(nn);
+    std::vector<std::array<double, 8>> cost(nn);           // index 1..7
+    std::vector<std::array<uint8_t, 9>> choice(nn);        // [1]: 0 leaf slot / 1 internal slot; [i >= 2]: 0 = as i-1, k = left gets k slots; [8]: split of the node's own 8 slots
+    auto is_leaf = [](int32_t c) { return c < 0; };
+    auto leaf_cnt = [](int32_t c) { return ((~(uint32_t)c) & 7u) + 1u; };
+    auto leaf_first = [](int32_t c) { return (~(uint32_t)c) >> 3; };
+    auto child_cost = [&](const Ch& c, int i) -> double {   // cost of a child reference given i slots
+        if (is_leaf(c.c)) return (double)area(c) * kTriCost * leaf_cnt(c.c);
+        return cost[(size_t)c.c][std::min(i, 7)];
+    };
+    for (size_t n = nn; n-- > 0;) {
+        const Ch L = get(n2[n], 0), R = get(n2[n], 1);
+        if (L.c == kEmptyChild || R.c == kEmptyChild) {      // only the root may have an unused child (scenes with < 2 leaves)
+            if (n != 0) return false;
+            sub[n] = Sub{0.0, 0u, 0u}; cost[n].fill(0.0); choice[n].fill(0); continue;
+        }
+        if ((L.c >= 0 && (size_t)L.c <= n) || (R.c >= 0 && (size_t)R.c <= n) || (L.c >= 0 && (size_t)L.c >= nn) || (R.c >= 0 && (size_t)R.c >= nn)) return false;
+        Ch U = L; for (int a = 0; a < 3; a++) { U.mn[a] = std::min(L.mn[a], R.mn[a]); U.mx[a] = std::max(L.mx[a], R.mx[a]); }
+        const uint32_t pl = is_leaf(L.c) ? leaf_cnt(L.c) : sub[(size_t)L.c].prims, pr = is_leaf(R.c) ? leaf_cnt(R.c) : sub[(size_t)R.c].prims;
+        sub[n] = Sub{(double)area(U), pl + pr, is_leaf(L.c) ? leaf_first(L.c) : sub[(size_t)L.c].first};
+        auto distribute = [&](int j, uint8_t& kbest) {
+            double best = INFINITY; kbest = 1;
+            for (int k = 1; k < j; k++) { const double c = child_cost(L, k) + child_cost(R, j - k); if (c < best) { best = c; kbest = (uint8_t)k; } }
+            return best;
+        };
+        const double c_int = distribute(8, choice[n][8]) + sub[n].area * kNodeCost;
+        const double c_leaf = sub[n].prims <= 4 ? sub[n].area * kTriCost * sub[n].prims : INFINITY;
+        cost[n][1] = std::min(c_leaf, c_int); choice[n][1] = c_leaf <= c_int ? 0 : 1;
+        for (int i = 2; i <= 7; i++) {
+            uint8_t k; const double d = distribute(i, k);
+            if (d < cost[n][i - 1]) { cost[n][i] = d; choice[n][i] = k; } else { cost[n][i] = cost[n][i - 1]; choice[n][i] = 0; }
+        }
+    }
+    // children of the wide node made from binary node x, following the recorded decisions
+    struct Gather {
+        const std::vector<NodeGPU>& n2; const std::vector<Sub>& sub; const std::vector<std::array<uint8_t, 9>>& choice;
+        Ch* out; int m = 0;
+        void add(const Ch& c, int budget, const decltype(get)& get_) {
+            if (c.c < 0) { out[m++] = c; return; }
+            int i = std::min(budget, 7);
+            while (i > 1 && choice[(size_t)c.c][i] == 0) i--;
+            if (i == 1) {
+                Ch r = c;
+                if (choice[(size_t)c.c][1] == 0) r.c = (int32_t)~((sub[(size_t)c.c].first << 3) | (sub[(size_t)c.c].prims - 1u));   // merged leaf slot
+                out[m++] = r; return;
+            }
+            const int k = choice[(size_t)c.c][i];
+            add(get_(n2[(size_t)c.c], 0), k, get_); add(get_(n2[(size_t)c.c], 1), i - k, get_);
+        }
+    };
     std::vector<int32_t> src; src.push_back(0);            // binary node behind each wide node, breadth-first
     for (size_t h = 0; h < src.size(); h++) {
         Ch ch[8]; int m = 0;
         const NodeGPU& N = n2[(size_t)src[h]];
-        for (int w = 0; w < 2; w++) { Ch c = get(N, w); if (c.c != kEmptyChild) ch[m++] = c; }
-        while (m < 8) {
-            int best = -1; float ba = -1.0f;
-            for (int k = 0; k < m; k++) if (ch[k].c >= 0) { const float a = area(ch[k]); if (best < 0 || a > ba) { ba = a; best = k; } }
-            if (best < 0) break;
-            if ((size_t)ch[best].c >= n2.size()) return false;
-            const NodeGPU& C = n2[(size_t)ch[best].c];
-            const Ch a = get(C, 0), b = get(C, 1);           // internal nodes below the root always have two children
-            if (a.c == kEmptyChild || b.c == kEmptyChild) return false;
-            ch[best] = a; ch[m++] = b;
+        {
+            const Ch L = get(N, 0), R = get(N, 1);
+            if (L.c == kEmptyChild || R.c == kEmptyChild) { if (L.c != kEmptyChild) ch[m++] = L; if (R.c != kEmptyChild) ch[m++] = R; }
+            else {
+                Gather G{n2, sub, choice, ch};
+                const int k = choice[(size_t)src[h]][8];
+                G.add(L, k, get); G.add(R, 8 - k, get);
+                m = G.m;
+            }
+            if (m > 8) return false;
         }
         Node8GPU W{};
         float bmn[3] = {0, 0, 0}, bmx[3] = {0, 0, 0};

@@ -191,6 +191,25 @@ int rtxh_bvh8_check(const float* wt, uint32_t ntris, uint32_t* nodes8_out, uint3
     return seen == stack ? 0 : 19;
 }
 
+// shape of the wide tree: hist[0..4] = leaf slots holding 0 (unused slot) / 1 / 2 / 3 / 4 triangles, hist[5] = internal child slots
+int rtxh_bvh8_stats(const float* wt, uint32_t ntris, uint32_t hist[6], uint32_t* nodes8_out) {
+    std::vector<float> w(wt, wt + (size_t)ntris * 9);
+    std::vector<rtx::NodeGPU> nodes; std::vector<uint32_t> order; uint32_t depth = 0;
+    rtx::build_bvh(w, 0.0f, nodes, order, depth);
+    std::vector<rtx::Node8GPU> n8; std::vector<uint32_t> slots; uint32_t stack = 0;
+    if (!rtx::collapse_bvh8(nodes, n8, slots, stack)) return 30;
+    for (int i = 0; i < 6; i++) hist[i] = 0;
+    for (const rtx::Node8GPU& N : n8) {
+        const uint32_t imask = N.e_imask >> 24;
+        for (int sl = 0; sl < 8; sl++) {
+            if ((imask >> sl) & 1u) { hist[5]++; continue; }
+            hist[__builtin_popcount((N.trivalid >> (4 * sl)) & 0xfu)]++;
+        }
+    }
+    if (nodes8_out) *nodes8_out = (uint32_t)n8.size();
+    return 0;
+}
+
 int rtxh_bvh_check(const float* wt, uint32_t ntris, uint32_t* nodes_out, uint32_t* depth_out, uint32_t* max_leaf_out) {
     std::vector<float> w(wt, wt + (size_t)ntris * 9);
     std::vector<rtx::NodeGPU> nodes; std::vector<uint32_t> order; uint32_t depth = 0;
