@@ -82,7 +82,8 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
        RTX_OPT_BOUNCE_VARIANT = 7,   /* tuning: register budget of the fused kernel as waves/SIMD (4, 5 or 6) */
        RTX_OPT_REFILL_MIN = 8,       /* tuning: idle lanes that trigger a refill in the persistent BVH traversal (default 20) */
        RTX_OPT_STACK_PRIVATE = 9,    /* tuning: traversal stack 0 = LDS column, 1 = private (scratch) memory, (2 is accepted and means 0) */
-       RTX_OPT_TRACE_SCHED = 10      /* tuning: wave schedule of the BVH traversal, 0 = while-while, 1 = voted node / triangle steps (default) */ };
+       RTX_OPT_TRACE_SCHED = 10,     /* tuning: wave schedule of the BVH traversal, 0 = while-while, 1 = voted node / triangle steps (default) */
+       RTX_OPT_GPU_REFIT = 11        /* 1 (default): a transform-only rtx_commit_scene refits the resident BVH on the GPU; 0: host refit + upload */ };
 
 /* lifetime: replaces LoadPipeline/device creation (Renderer.cpp:106-254) and OnDestroy (:546-552) */
 int  rtx_create(int device_ordinal, rtx_ctx** out);
@@ -157,6 +158,9 @@ int  rtx_debug_trace_any(rtx_ctx*, const float* rays8, uint32_t n, uint8_t* occl
 /* closest-hit traversal of the BVH (never the tiny-scene path) that reports its work: stats4 = n * (t, node steps, triangle tests,
    prim bits) — tree-quality measurements for DESIGN.md, not part of the reference boundary */
 int  rtx_debug_trace_stats(rtx_ctx*, const float* rays8, uint32_t n, float* stats4);
+/* downloads the resident wide BVH and checks it on the host: 0 = every triangle is in exactly one leaf slot and inside all the
+   decoded boxes above it (what the GPU refit must preserve); > 0 = validator code; < 0 = RTX_ERR_* */
+int  rtx_debug_validate_bvh(rtx_ctx*);
 /* out16 per hit = pos3, matID bits, normal3, area, inst bits, flat3, pad4 (ClosestHit, Hit_v6.hlsl:12-61) */
 int  rtx_debug_surface(rtx_ctx*, const float* rays8, const float* hits4, uint32_t n, float* out16);
 /* in9 = n(3) wo(3) wi(3); out8 = f(3), pdf, p_d, p_s, 0, 0 */

@@ -36,7 +36,7 @@ FLAG_JITTER = 2
 K_RAYGEN, K_TRACE, K_SHADE, K_SHADOW, K_ACCUM, K_SORT, K_BOUNCE, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 8
 KERNEL_NAMES = {K_RAYGEN: "raygen", K_TRACE: "trace_closest", K_SHADE: "shade", K_SHADOW: "trace_shadow", K_ACCUM: "accumulate", K_SORT: "sort", K_BOUNCE: "bounce_fused"}
 OPT_KERNEL_TIMING, OPT_PATHS_PER_BATCH, OPT_SORT_MATERIALS, OPT_LDS_NODES, OPT_SMALL_SCENE, OPT_FUSED_BOUNCE, OPT_BOUNCE_VARIANT = 1, 2, 3, 4, 5, 6, 7
-OPT_REFILL_MIN, OPT_STACK_PRIVATE, OPT_TRACE_SCHED = 8, 9, 10
+OPT_REFILL_MIN, OPT_STACK_PRIVATE, OPT_TRACE_SCHED, OPT_GPU_REFIT = 8, 9, 10, 11
 
 
 class RtxError(RuntimeError):
@@ -115,6 +115,7 @@ _sig("rtx_debug_primary_rays", C.c_int, _vp, C.POINTER(Params), _u32, _vp)
 _sig("rtx_debug_trace_closest", C.c_int, _vp, _vp, _u32, _vp)
 _sig("rtx_debug_trace_any", C.c_int, _vp, _vp, _u32, _vp)
 _sig("rtx_debug_trace_stats", C.c_int, _vp, _vp, _u32, _vp)
+_sig("rtx_debug_validate_bvh", C.c_int, _vp)
 _sig("rtx_debug_surface", C.c_int, _vp, _vp, _vp, _u32, _vp)
 _sig("rtx_debug_bsdf_eval", C.c_int, _vp, _u32, _u32, _vp, _u32, _vp)
 _sig("rtx_debug_bsdf_sample", C.c_int, _vp, _u32, _u32, _vp, _u32, _vp)
@@ -206,7 +207,7 @@ class Scene:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and lib is not None:                      # module globals are gone at interpreter shutdown
             lib.rtxh_scene_free(h)
 
     @classmethod
@@ -454,6 +455,10 @@ class Context:
         out = np.zeros(len(r), np.uint8)
         self._ck(lib.rtx_debug_trace_any(self._h, _ptr(r), len(r), _ptr(out)), "rtx_debug_trace_any")
         return out
+
+    def validate_bvh(self):
+        """0 when the resident wide BVH (as built, or as refitted on the GPU) covers every triangle inside its decoded boxes"""
+        return lib.rtx_debug_validate_bvh(self._h)
 
     def trace_stats(self, rays8):
         """(n,4): t, node steps, triangle tests, prim bits of a closest-hit BVH traversal"""

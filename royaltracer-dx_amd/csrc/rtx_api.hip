@@ -36,6 +36,8 @@ struct rtx_ctx {
     SceneHost host; BuiltScene built;
     bool committed = false, camera_set = false;
     DevBuf d_nodes, d_tris, d_small, d_small_tris, d_shade, d_mats, d_insts, d_lights, d_cam;
+    DevBuf d_objtris, d_node_aabb, d_scale;          // GPU refit: object-space vertices (uploaded on first use), per-node float boxes, max |coordinate|
+    bool gpu_refit = true, device_scene_valid = false, objtris_uploaded = false;
     DevScene dsc{};
     float view[16], proj[16];
     // path state
@@ -123,6 +125,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_FUSED_BOUNCE: c->fused = value != 0; return RTX_OK;
     case RTX_OPT_BOUNCE_VARIANT: g_bounce_variant = (int)value; return RTX_OK;
     case RTX_OPT_STACK_PRIVATE: c->stack_private = (int)value; c->committed = false; return RTX_OK;
+    case RTX_OPT_GPU_REFIT: c->gpu_refit = value != 0; return RTX_OK;
     case RTX_OPT_TRACE_SCHED: g_trace_sched = (int)value; return RTX_OK;
     case RTX_OPT_REFILL_MIN: if (value < 1 || value > 64) { c->err = "refill_min must be in [1, 64]"; return RTX_ERR_INVALID; } g_refill_min = (int)value; return RTX_OK;
     default: c->err = "unknown option"; return RTX_ERR_INVALID;
@@ -163,18 +166,37 @@ int rtx_commit_scene(rtx_ctx* c) {
     BIND(c);
     for (size_t i = 0; i < c->host.matids.size(); i++)
         if (c->host.matids[i] >= c->host.mats128.size() / 32) { c->err = "commit: material id out of range"; return RTX_ERR_INVALID; }
-    if (!c->host.build(c->built)) { c->err = c->host.err; return RTX_ERR_INVALID; }
     BuiltScene& B = c->built;
     int r;
-    if ((r = upload(c, c->d_nodes, B.nodes8))) return r;
-    if ((r = upload(c, c->d_tris, B.tris8))) return r;
-    if ((r = upload(c, c->d_shade, B.shade))) return r;
-    if ((r = upload(c, c->d_small, B.small_recs))) return r;
-    if ((r = upload(c, c->d_small_tris, B.small_tris))) return r;
-    if ((r = upload(c, c->d_mats, B.mats))) return r;
-    if ((r = upload(c, c->d_insts, B.insts))) return r;
-    if ((r = upload(c, c->d_lights, B.lights))) return r;
+    // Transform-only commit of a scene that is already resident (and not a tiny one, whose pre-test records depend on world
+    // positions): refit ON THE GPU — the kernels re-derive the world triangles and re-quantise the wide nodes bottom-up; the host
+    // only re-derives the instance matrices and the light list.  Anything else: host build (or host refit) + upload.
+    const bool gpu_path = c->gpu_refit && c->device_scene_valid && !c->host.topo_dirty && B.small_nrec == 0 && !B.nodes8.empty() && B.level_start8.size() >= 2;
+    if (gpu_path) {
+        if (!c->host.refresh_transforms(B)) { c->err = c->host.err; return RTX_ERR_INVALID; }
+        if ((r = upload(c, c->d_insts, B.insts))) return r;
+        if ((r = upload(c, c->d_lights, B.lights))) return r;
+        if (!c->objtris_uploaded) { if ((r = upload(c, c->d_objtris, B.objtris))) return r; c->objtris_uploaded = true; }
+        HIPCHK(c, c->d_node_aabb.ensure(B.nodes8.size() * 32));
+        const std::vector<uint32_t> one(1, 0x3f800000u);      // scale starts at 1.0 like the host's max(1, |coordinates|)
+        if ((r = upload(c, c->d_scale, one))) return r;
+        launch_refit(c->stream, (Node8GPU*)c->d_nodes.p, B.level_start8.data(), (uint32_t)B.level_start8.size() - 1, (TriGPU*)c->d_tris.p, (uint32_t)B.tris8.size(),
+                     (const TriShade*)c->d_shade.p, (const InstGPU*)c->d_insts.p, (const F4*)c->d_objtris.p, (F4*)c->d_node_aabb.p, (uint32_t*)c->d_scale.p);
+        HIPCHK(c, hipGetLastError());
+    } else {
+        c->device_scene_valid = false; c->objtris_uploaded = false;
+        if (!c->host.build(B)) { c->err = c->host.err; return RTX_ERR_INVALID; }
+        if ((r = upload(c, c->d_nodes, B.nodes8))) return r;
+        if ((r = upload(c, c->d_tris, B.tris8))) return r;
+        if ((r = upload(c, c->d_shade, B.shade))) return r;
+        if ((r = upload(c, c->d_small, B.small_recs))) return r;
+        if ((r = upload(c, c->d_small_tris, B.small_tris))) return r;
+        if ((r = upload(c, c->d_mats, B.mats))) return r;
+        if ((r = upload(c, c->d_insts, B.insts))) return r;
+        if ((r = upload(c, c->d_lights, B.lights))) return r;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->device_scene_valid = true;
     DevScene& s = c->dsc;
     s.nodes = (const Node8GPU*)c->d_nodes.p; s.nnodes = (uint32_t)B.nodes8.size();
     s.tris = (const TriGPU*)c->d_tris.p; s.ntris = (uint32_t)B.tris8.size();
@@ -598,6 +620,20 @@ static int dbg_trace(rtx_ctx* c, const float* rays8, uint32_t n, int any, float*
 }
 int rtx_debug_trace_closest(rtx_ctx* c, const float* rays8, uint32_t n, float* hits4) { return dbg_trace(c, rays8, n, 0, hits4, nullptr); }
 int rtx_debug_trace_any(rtx_ctx* c, const float* rays8, uint32_t n, uint8_t* occluded) { return dbg_trace(c, rays8, n, 1, nullptr, occluded); }
+int rtx_debug_validate_bvh(rtx_ctx* c) {
+    BIND(c);
+    if (!c->committed) { c->err = "scene not committed"; return RTX_ERR_STATE; }
+    std::vector<Node8GPU> nodes(c->dsc.nnodes); std::vector<TriGPU> tris(c->dsc.ntris);
+    if (!nodes.empty()) HIPCHK(c, hipMemcpyAsync(nodes.data(), c->d_nodes.p, nodes.size() * sizeof(Node8GPU), hipMemcpyDeviceToHost, c->stream));
+    if (!tris.empty()) HIPCHK(c, hipMemcpyAsync(tris.data(), c->d_tris.p, tris.size() * sizeof(TriGPU), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<float> w(tris.size() * 9); std::vector<uint32_t> ident(tris.size());
+    for (size_t i = 0; i < tris.size(); i++) {                 // the triangle the kernels intersect: (v0, v0 + e1, v0 + e2)
+        const TriGPU& T = tris[i]; float* o = &w[i * 9]; ident[i] = (uint32_t)i;
+        o[0] = T.v0.x; o[1] = T.v0.y; o[2] = T.v0.z; o[3] = T.v0.x + T.e1.x; o[4] = T.v0.y + T.e1.y; o[5] = T.v0.z + T.e1.z; o[6] = T.v0.x + T.e2.x; o[7] = T.v0.y + T.e2.y; o[8] = T.v0.z + T.e2.z;
+    }
+    return validate_bvh8(w, nodes, ident, ident, nullptr);
+}
 int rtx_debug_trace_stats(rtx_ctx* c, const float* rays8, uint32_t n, float* stats4) { return dbg_trace(c, rays8, n, 2, stats4, nullptr); }
 
 int rtx_debug_surface(rtx_ctx* c, const float* rays8, const float* hits4, uint32_t n, float* out16) {

@@ -1611,6 +1611,108 @@ int g_sort_materials = 0;     // measured slower (see k_shade): the permutation 
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
+// GPU refit of the wide BVH after a transform-only commit (the reference refits its TLAS every frame: Renderer.cpp:594,
+// TopLevelASGenerator.cpp:149-250).  Topology, slot assignment and triangle order stay; k_refit_tris re-derives the world-space
+// triangles from the object-space vertices with the host's operation order (xform_point: bit-identical TriGPU records, so the
+// triangle tests still match the oracle's), k_refit_nodes re-derives and re-quantises the child boxes level by level, deepest
+// first.  Quantisation is conservative by construction: lo - p is rounded DOWN before floor(), hi - p UP before ceil(), and
+// 2^e is chosen with 255 * 2^e >= extent, so the decoded planes bracket the float boxes exactly as the host's double-checked
+// build does.
+// ---------------------------------------------------------------------------------------------
+// directed-rounding stand-ins (HIP has no __fsub_rd / __fsub_ru here): the neighbours of the round-to-nearest result bracket the
+// exact difference (|exact - fl| <= half a spacing), at the price of at most one extra spacing of slack
+__device__ __forceinline__ float next_below(float x) { uint32_t b = f2u(x); if (x > 0.0f) b--; else if (x < 0.0f) b++; else b = 0x80000001u; return u2f(b); }
+__device__ __forceinline__ float next_above(float x) { uint32_t b = f2u(x); if (x > 0.0f) b++; else if (x < 0.0f) b--; else b = 0x00000001u; return u2f(b); }
+__device__ __forceinline__ float sub_down(float a, float b) { return next_below(a - b); }
+__device__ __forceinline__ float sub_up(float a, float b) { return next_above(a - b); }
+
+__global__ __launch_bounds__(kBlock) void k_refit_tris(TriGPU* __restrict__ tris, uint32_t ntris, const TriShade* __restrict__ shade, const InstGPU* __restrict__ insts,
+                                                       const F4* __restrict__ objtris, uint32_t* __restrict__ scale_bits) {
+    __shared__ uint32_t s_max;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+    float amax = 0.0f;
+    if (s < ntris) {
+        const uint32_t g = f2u(tris[s].v0.w);
+        const float* M = insts[shade[g].inst].o2w;
+        const F4 a = objtris[(size_t)g * 3], b = objtris[(size_t)g * 3 + 1], c = objtris[(size_t)g * 3 + 2];
+        const f3 w0 = xform_point(M, mk3(a.x, a.y, a.z)), w1 = xform_point(M, mk3(b.x, b.y, b.z)), w2 = xform_point(M, mk3(c.x, c.y, c.z));
+        const f3 e1 = w1 - w0, e2 = w2 - w0;
+        tris[s].v0 = {w0.x, w0.y, w0.z, u2f(g)};
+        tris[s].e1 = {e1.x, e1.y, e1.z, 0.0f};
+        tris[s].e2 = {e2.x, e2.y, e2.z, 0.0f};
+        amax = fmaxf(fmaxf(fmaxf(fabsf(w0.x), fabsf(w0.y)), fmaxf(fabsf(w0.z), fabsf(w1.x))), fmaxf(fmaxf(fabsf(w1.y), fabsf(w1.z)), fmaxf(fmaxf(fabsf(w2.x), fabsf(w2.y)), fabsf(w2.z))));
+    }
+    atomicMax(&s_max, f2u(amax));                      // non-negative floats order like their bit patterns
+    __syncthreads();
+    if (threadIdx.x == 0 && s_max) atomicMax(scale_bits, s_max);
+}
+
+__global__ __launch_bounds__(kBlock) void k_refit_nodes(Node8GPU* __restrict__ nodes, uint32_t first, uint32_t count, const TriGPU* __restrict__ tris,
+                                                        F4* __restrict__ node_aabb /* 2 per node: min, max */, const uint32_t* __restrict__ scale_bits) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t n = first + i;
+    Node8GPU N = nodes[n];
+    const float pad = 2e-6f * u2f(*scale_bits);          // the host build's bvh_pad (rtx_scene_host.cpp)
+    const uint32_t imask = N.e_imask >> 24;
+    float cmn[8][3], cmx[8][3];
+    float bmn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, bmx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    uint32_t rank = 0, tri_at = N.tri_base, used = 0;
+#pragma unroll
+    for (int sl = 0; sl < 8; sl++) {
+        const uint32_t nib = (N.trivalid >> (4 * sl)) & 0xfu;
+        for (int a = 0; a < 3; a++) { cmn[sl][a] = 0.0f; cmx[sl][a] = 0.0f; }
+        if ((imask >> sl) & 1u) {
+            const F4 mn = node_aabb[2 * (size_t)(N.child_base + rank)], mx = node_aabb[2 * (size_t)(N.child_base + rank) + 1];
+            rank++;
+            cmn[sl][0] = mn.x; cmn[sl][1] = mn.y; cmn[sl][2] = mn.z; cmx[sl][0] = mx.x; cmx[sl][1] = mx.y; cmx[sl][2] = mx.z;
+        } else if (nib) {
+            float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+            const uint32_t cnt = (uint32_t)__builtin_popcount(nib);
+            for (uint32_t k = 0; k < cnt; k++, tri_at++) {
+                const TriGPU T = tris[tri_at];
+                const float v[3][3] = {{T.v0.x, T.v0.y, T.v0.z}, {T.v0.x + T.e1.x, T.v0.y + T.e1.y, T.v0.z + T.e1.z}, {T.v0.x + T.e2.x, T.v0.y + T.e2.y, T.v0.z + T.e2.z}};
+                for (int a = 0; a < 3; a++) { mn[a] = fminf(mn[a], fminf(v[0][a], fminf(v[1][a], v[2][a]))); mx[a] = fmaxf(mx[a], fmaxf(v[0][a], fmaxf(v[1][a], v[2][a]))); }
+            }
+            for (int a = 0; a < 3; a++) { cmn[sl][a] = mn[a] - pad; cmx[sl][a] = mx[a] + pad; }
+        } else continue;
+        used |= 1u << sl;
+        for (int a = 0; a < 3; a++) { bmn[a] = fminf(bmn[a], cmn[sl][a]); bmx[a] = fmaxf(bmx[a], cmx[sl][a]); }
+    }
+    if (!used) { for (int a = 0; a < 3; a++) { bmn[a] = 0.0f; bmx[a] = 0.0f; } }
+    node_aabb[2 * (size_t)n] = {bmn[0], bmn[1], bmn[2], 0.0f}; node_aabb[2 * (size_t)n + 1] = {bmx[0], bmx[1], bmx[2], 0.0f};
+    // byte grid: p = box minimum, smallest power of two with 255 steps covering the (upward-rounded) extent
+    uint32_t eb[3]; float inv_step[3];
+    for (int a = 0; a < 3; a++) {
+        const float ext = sub_up(bmx[a], bmn[a]);
+        int e = -120;
+        if (ext > 0.0f) {
+            int k; const float m = frexpf(ext, &k);            // ext = m * 2^k, m in [0.5, 1)
+            e = m <= 0.99609375f ? k - 8 : k - 7;               // 255 * 2^(k-8) = 0.99609375 * 2^k
+            if (e < -120) e = -120;
+            if (e > 120) e = 120;                               // (cannot cover; such coordinates are rejected at commit)
+        }
+        eb[a] = (uint32_t)(e + 127); inv_step[a] = u2f((uint32_t)(127 - e) << 23);
+    }
+    N.px = bmn[0]; N.py = bmn[1]; N.pz = bmn[2];
+    N.e_imask = eb[0] | eb[1] << 8 | eb[2] << 16 | imask << 24;
+    for (int r = 0; r < 12; r++) N.q[r] = 0;
+#pragma unroll
+    for (int sl = 0; sl < 8; sl++) {
+        if (!((used >> sl) & 1u)) continue;
+        for (int a = 0; a < 3; a++) {
+            float qlo = floorf(sub_down(cmn[sl][a], bmn[a]) * inv_step[a]), qhi = ceilf(sub_up(cmx[sl][a], bmn[a]) * inv_step[a]);
+            qlo = fminf(255.0f, fmaxf(0.0f, qlo)); qhi = fminf(255.0f, fmaxf(0.0f, qhi));
+            N.q[2 * a + (sl >> 2)] |= (uint32_t)qlo << (8 * (sl & 3));
+            N.q[2 * (3 + a) + (sl >> 2)] |= (uint32_t)qhi << (8 * (sl & 3));
+        }
+    }
+    nodes[n] = N;
+}
+
+// ---------------------------------------------------------------------------------------------
 static inline uint32_t grid_for(uint32_t items, uint32_t max_blocks) {
     uint32_t b = (items + kBlock - 1) / kBlock;
     if (b < 1) b = 1;
@@ -1674,6 +1776,14 @@ void launch_pack_tiles(hipStream_t st, uint32_t max_blocks, const DevFrame& f, c
 }
 void launch_unpack_tiles(hipStream_t st, uint32_t max_blocks, const DevFrame& f, uint32_t nshards, const F4* slabs, F4* accum) {
     hipLaunchKernelGGL(k_unpack_tiles, dim3(grid_for(f.npl * nshards, max_blocks)), dim3(kBlock), 0, st, f, nshards, slabs, accum);
+}
+void launch_refit(hipStream_t st, Node8GPU* nodes, const uint32_t* level_start, uint32_t nlevels, TriGPU* tris, uint32_t ntris, const TriShade* shade,
+                  const InstGPU* insts, const F4* objtris, F4* node_aabb, uint32_t* scale_bits) {
+    if (ntris) hipLaunchKernelGGL(k_refit_tris, dim3((ntris + kBlock - 1) / kBlock), dim3(kBlock), 0, st, tris, ntris, shade, insts, objtris, scale_bits);
+    for (uint32_t l = nlevels; l-- > 0;) {                       // deepest level first: children are refitted before their parents
+        const uint32_t first = level_start[l], count = level_start[l + 1] - first;
+        if (count) hipLaunchKernelGGL(k_refit_nodes, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, st, nodes, first, count, tris, node_aabb, scale_bits);
+    }
 }
 void launch_dbg_trace(hipStream_t st, const DevScene& sc, const F4* rays, uint32_t n, int any, F4* hits) {
     hipLaunchKernelGGL(k_dbg_trace, dim3(grid_for(n, 2048)), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, rays, n, any, hits);

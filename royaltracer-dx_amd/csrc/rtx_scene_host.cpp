@@ -105,56 +105,8 @@ bool SceneHost::set_instance_transform(uint32_t inst, const float* o2w) {
 static inline f3 vpos(const MeshHost& m, uint32_t vi) { const float* p = &m.verts[(size_t)vi * 7]; return mk3(p[0], p[1], p[2]); }
 static inline f3 vnrm(const MeshHost& m, uint32_t vi) { const float* p = &m.verts[(size_t)vi * 7]; return mk3(p[3], p[4], p[5]); }
 
-bool SceneHost::build(BuiltScene& B) {
+void SceneHost::build_lights(BuiltScene& B) const {
     const uint32_t nmat = (uint32_t)(mats128.size() / 32);
-    // ---- materials: MaterialOptimized rounding (Common_v6.hlsl:62-74) ----
-    B.mats.resize(nmat);
-    for (uint32_t i = 0; i < nmat; i++) {
-        const float* m = &mats128[(size_t)i * 32];   // Kd[4] Ks[3] Ni Ke[3] pad Pr_Pm_Ps_Pc[4] LUT[16]
-        MatGPU& g = B.mats[i];
-        for (int k = 0; k < 3; k++) { g.Kd[k] = half_round(m[k]); g.Ks[k] = half_round(m[4 + k]); g.Ke[k] = half_round(m[8 + k]); }
-        g.Pr = half_round(m[12]); g.Pm = half_round(m[13]);
-        g.KeFull[0] = m[8]; g.KeFull[1] = m[9]; g.KeFull[2] = m[10]; g.KeFullLen = length(mk3(m[8], m[9], m[10]));
-        g.Ke_len = length(mk3(g.Ke[0], g.Ke[1], g.Ke[2]));
-        memcpy(g.LUT, m + 16, 64);
-    }
-    // ---- flatten instances to world-space triangles; per-triangle shade records (Hit_v6.hlsl:12-61) ----
-    uint32_t nt = 0;
-    for (auto& in : insts) { in.tri_base = nt; nt += (uint32_t)(meshes[in.mesh].idx.size() / 3); }
-    std::vector<float> wtri((size_t)nt * 9);
-    B.shade.resize(nt);
-    B.insts.resize(insts.size());
-    float scale = 1.0f;
-    for (size_t ii = 0; ii < insts.size(); ii++) {
-        const InstHost& in = insts[ii]; const MeshHost& m = meshes[in.mesh];
-        memcpy(B.insts[ii].o2w, in.o2w, 64); memcpy(B.insts[ii].nrm, in.nrm, 64); memcpy(B.insts[ii].o2w_inv, in.o2w_inv, 64); memcpy(B.insts[ii].prev_o2w, in.prev_o2w, 64);
-        for (uint32_t t = 0; t < m.idx.size() / 3; t++) {
-            uint32_t g = in.tri_base + t;
-            uint32_t i0 = m.idx[t * 3], i1 = m.idx[t * 3 + 1], i2 = m.idx[t * 3 + 2];
-            const uint32_t vi[3] = {i0, i1, i2};
-            for (int k = 0; k < 3; k++) {
-                f3 w = xform_point(in.o2w, vpos(m, vi[k]));
-                wtri[(size_t)g * 9 + k * 3] = w.x; wtri[(size_t)g * 9 + k * 3 + 1] = w.y; wtri[(size_t)g * 9 + k * 3 + 2] = w.z;
-                scale = std::max(scale, std::max(fabsf(w.x), std::max(fabsf(w.y), fabsf(w.z))));
-            }
-            TriShade& s = B.shade[g];
-            uint32_t mi = m.matid_base + 3 * t;    // == 3*PrimitiveIndex() + uint(v0.normal.w), Hit_v6.hlsl:16-17
-            s.mat = mi < matids.size() ? matids[mi] : kMissMat;
-            s.inst = (uint32_t)ii;
-            f3 p0 = vpos(m, i0);
-            f3 cr = cross(vpos(m, i1) - p0, vpos(m, i2) - p0);      // :28-30
-            s.area = fabsf(length(cr) * 0.5f);                      // :31
-            f3 flat = normalize(cr);                                // :32
-            s.flat[0] = flat.x; s.flat[1] = flat.y; s.flat[2] = flat.z;
-            float* dst[3] = {s.n0, s.n1, s.n2};
-            for (int k = 0; k < 3; k++) {                           // :40-46 (all(n != 0) is per component)
-                f3 nk = vnrm(m, vi[k]);
-                f3 use = (nk.x != 0.0f && nk.y != 0.0f && nk.z != 0.0f) ? nk : flat;
-                dst[k][0] = use.x; dst[k][1] = use.y; dst[k][2] = use.z;
-            }
-            s.pad = 0.0f;
-        }
-    }
     // ---- emissive triangle list + CDF: Renderer.cpp:2123-2233, 2237-2243 ----
     struct Tmp { float w; uint32_t order; uint32_t inst; f3 p0, p1, p2; float em[3]; };
     std::vector<Tmp> tmp;
@@ -206,11 +158,79 @@ bool SceneHost::build(BuiltScene& B) {
         G.em[0] = L.em[0]; G.em[1] = L.em[1]; G.em[2] = L.em[2]; G.pad1 = 0.0f;
         G.nl[0] = nrm.x; G.nl[1] = nrm.y; G.nl[2] = nrm.z; G.pad2 = 0.0f;
     }
+}
+
+// transform-only commit on the GPU-refit path: the kernels re-derive triangles and boxes; the host re-derives what is small
+bool SceneHost::refresh_transforms(BuiltScene& B) {
+    if (topo_dirty || B.insts.size() != insts.size()) { err = "refresh_transforms: topology changed"; return false; }
+    for (size_t ii = 0; ii < insts.size(); ii++) {
+        const InstHost& in = insts[ii];
+        memcpy(B.insts[ii].o2w, in.o2w, 64); memcpy(B.insts[ii].nrm, in.nrm, 64); memcpy(B.insts[ii].o2w_inv, in.o2w_inv, 64); memcpy(B.insts[ii].prev_o2w, in.prev_o2w, 64);
+    }
+    build_lights(B);
+    B.refit_count++;
+    return true;
+}
+
+bool SceneHost::build(BuiltScene& B) {
+    const uint32_t nmat = (uint32_t)(mats128.size() / 32);
+    // ---- materials: MaterialOptimized rounding (Common_v6.hlsl:62-74) ----
+    B.mats.resize(nmat);
+    for (uint32_t i = 0; i < nmat; i++) {
+        const float* m = &mats128[(size_t)i * 32];   // Kd[4] Ks[3] Ni Ke[3] pad Pr_Pm_Ps_Pc[4] LUT[16]
+        MatGPU& g = B.mats[i];
+        for (int k = 0; k < 3; k++) { g.Kd[k] = half_round(m[k]); g.Ks[k] = half_round(m[4 + k]); g.Ke[k] = half_round(m[8 + k]); }
+        g.Pr = half_round(m[12]); g.Pm = half_round(m[13]);
+        g.KeFull[0] = m[8]; g.KeFull[1] = m[9]; g.KeFull[2] = m[10]; g.KeFullLen = length(mk3(m[8], m[9], m[10]));
+        g.Ke_len = length(mk3(g.Ke[0], g.Ke[1], g.Ke[2]));
+        memcpy(g.LUT, m + 16, 64);
+    }
+    // ---- flatten instances to world-space triangles; per-triangle shade records (Hit_v6.hlsl:12-61) ----
+    uint32_t nt = 0;
+    for (auto& in : insts) { in.tri_base = nt; nt += (uint32_t)(meshes[in.mesh].idx.size() / 3); }
+    std::vector<float> wtri((size_t)nt * 9);
+    B.shade.resize(nt);
+    B.insts.resize(insts.size());
+    B.objtris.resize((size_t)nt * 3);
+    float scale = 1.0f;
+    for (size_t ii = 0; ii < insts.size(); ii++) {
+        const InstHost& in = insts[ii]; const MeshHost& m = meshes[in.mesh];
+        memcpy(B.insts[ii].o2w, in.o2w, 64); memcpy(B.insts[ii].nrm, in.nrm, 64); memcpy(B.insts[ii].o2w_inv, in.o2w_inv, 64); memcpy(B.insts[ii].prev_o2w, in.prev_o2w, 64);
+        for (uint32_t t = 0; t < m.idx.size() / 3; t++) {
+            uint32_t g = in.tri_base + t;
+            uint32_t i0 = m.idx[t * 3], i1 = m.idx[t * 3 + 1], i2 = m.idx[t * 3 + 2];
+            const uint32_t vi[3] = {i0, i1, i2};
+            for (int k = 0; k < 3; k++) {
+                const f3 op = vpos(m, vi[k]);
+                B.objtris[(size_t)g * 3 + k] = {op.x, op.y, op.z, 0.0f};
+                f3 w = xform_point(in.o2w, op);
+                wtri[(size_t)g * 9 + k * 3] = w.x; wtri[(size_t)g * 9 + k * 3 + 1] = w.y; wtri[(size_t)g * 9 + k * 3 + 2] = w.z;
+                scale = std::max(scale, std::max(fabsf(w.x), std::max(fabsf(w.y), fabsf(w.z))));
+            }
+            TriShade& s = B.shade[g];
+            uint32_t mi = m.matid_base + 3 * t;    // == 3*PrimitiveIndex() + uint(v0.normal.w), Hit_v6.hlsl:16-17
+            s.mat = mi < matids.size() ? matids[mi] : kMissMat;
+            s.inst = (uint32_t)ii;
+            f3 p0 = vpos(m, i0);
+            f3 cr = cross(vpos(m, i1) - p0, vpos(m, i2) - p0);      // :28-30
+            s.area = fabsf(length(cr) * 0.5f);                      // :31
+            f3 flat = normalize(cr);                                // :32
+            s.flat[0] = flat.x; s.flat[1] = flat.y; s.flat[2] = flat.z;
+            float* dst[3] = {s.n0, s.n1, s.n2};
+            for (int k = 0; k < 3; k++) {                           // :40-46 (all(n != 0) is per component)
+                f3 nk = vnrm(m, vi[k]);
+                f3 use = (nk.x != 0.0f && nk.y != 0.0f && nk.z != 0.0f) ? nk : flat;
+                dst[k][0] = use.x; dst[k][1] = use.y; dst[k][2] = use.z;
+            }
+            s.pad = 0.0f;
+        }
+    }
+    build_lights(B);
     // ---- BVH: full binned-SAH build, or a REFIT when only instance transforms changed since the last build
     //      (the reference refits its TLAS every frame: Renderer.cpp:594, TopLevelASGenerator.cpp:149-250) ----
     std::vector<uint32_t>& leaf_order = B.leaf_order;
     const bool refit = !topo_dirty && B.leaf_order.size() == (size_t)nt && !B.nodes.empty();
-    const float bvh_pad = 2e-6f * scale;                  // absolute box padding (1e-5 measured 3 % slower; the relative margins kSlabLo / kSlabHi carry the triangle-test error)
+    const float bvh_pad = 2e-6f * scale; B.bvh_pad = bvh_pad;                  // absolute box padding (1e-5 measured 3 % slower; the relative margins kSlabLo / kSlabHi carry the triangle-test error)
     if (refit) refit_bvh(wtri, bvh_pad, B.nodes, leaf_order);
     else build_bvh(wtri, bvh_pad, B.nodes, leaf_order, B.max_depth);
     B.refit_count = refit ? B.refit_count + 1 : 0;
@@ -227,7 +247,7 @@ bool SceneHost::build(BuiltScene& B) {
         T.e2 = {e2.x, e2.y, e2.z, 0.0f};
     }
     // device traversal form: derived data, redone after a refit too (O(nodes))
-    if (!collapse_bvh8(B.nodes, B.nodes8, B.tri_slots8, B.stack8)) { err = "build: BVH collapse failed"; return false; }
+    if (!collapse_bvh8(B.nodes, B.nodes8, B.tri_slots8, B.stack8, &B.level_start8)) { err = "build: BVH collapse failed"; return false; }
     B.tris8.resize(B.tri_slots8.size());
     for (size_t i = 0; i < B.tri_slots8.size(); i++) B.tris8[i] = B.tris[B.tri_slots8[i]];
     // ---- tiny scenes: merge triangles into planar convex quads and build the conservative pre-test records ----
@@ -483,7 +503,8 @@ void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGP
 // dynamic program (below).  The child boxes
 // are the binary tree's padded boxes rounded OUTWARD onto the node's byte grid (checked in exact double arithmetic), so the
 // wide tree is conservative whenever the binary one is.
-bool collapse_bvh8(const std::vector<NodeGPU>& n2, std::vector<Node8GPU>& n8, std::vector<uint32_t>& tri_slots, uint32_t& max_stack) {
+bool collapse_bvh8(const std::vector<NodeGPU>& n2, std::vector<Node8GPU>& n8, std::vector<uint32_t>& tri_slots, uint32_t& max_stack,
+                   std::vector<uint32_t>* level_start) {
     struct Ch { float mn[3], mx[3]; int32_t c; };
     auto get = [](const NodeGPU& N, int which) {
         Ch r;
@@ -493,6 +514,7 @@ bool collapse_bvh8(const std::vector<NodeGPU>& n2, std::vector<Node8GPU>& n8, st
     };
     auto area = [](const Ch& b) { const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2]; return dx * dy + dy * dz + dz * dx; };
     n8.clear(); tri_slots.clear(); max_stack = 0;
+    if (level_start) level_start->clear();
     if (n2.empty()) return true;
     // ---- which binary subtrees become wide nodes / leaf slots: surface-area-heuristic dynamic program (Ylitie et al. 2017,
     //      section 3.1).  cost[n][i] = cheapest way to represent binary subtree n with at most i child slots of its wide
@@ -649,7 +671,81 @@ bool collapse_bvh8(const std::vector<NodeGPU>& n2, std::vector<Node8GPU>& n8, st
         need[i] = (nint > 1 ? 1u : 0u) + deep;
     }
     max_stack = need[0];
+    if (level_start) {                                       // breadth-first order: a level is a contiguous index range
+        std::vector<uint32_t> level(n8.size(), 0);
+        for (size_t i = 0; i < n8.size(); i++) {
+            const uint32_t nint = (uint32_t)__builtin_popcount(n8[i].e_imask >> 24);
+            for (uint32_t r = 0; r < nint; r++) level[(size_t)n8[i].child_base + r] = level[i] + 1;
+        }
+        for (size_t i = 0; i < n8.size(); i++) {
+            if (i && level[i] < level[i - 1]) return false;
+            if (i == 0 || level[i] != level[i - 1]) level_start->push_back((uint32_t)i);
+        }
+        level_start->push_back((uint32_t)n8.size());
+    }
     return true;
 }
+
+// the compressed 8-wide collapse: same coverage properties, checked on the DECODED byte-grid boxes of the wide nodes
+int validate_bvh8(const std::vector<float>& w, const std::vector<Node8GPU>& nodes, const std::vector<uint32_t>& order,
+                  const std::vector<uint32_t>& tri_slots, uint32_t* max_stack_seen) {
+    const uint32_t ntris = (uint32_t)(w.size() / 9);
+    if (tri_slots.size() != ntris) return 20;
+    struct It { uint32_t node; double mn[3], mx[3]; uint32_t pushes; };
+    std::vector<uint8_t> covered(ntris, 0), visited(nodes.size(), 0);
+    if (nodes.empty()) return ntris ? 10 : 0;
+    std::vector<It> st;
+    const double inf = INFINITY;
+    st.push_back({0u, {-inf, -inf, -inf}, {inf, inf, inf}, 0u});
+    uint32_t deepest = 0;
+    while (!st.empty()) {
+        const It it = st.back(); st.pop_back();
+        if (it.node >= nodes.size()) return 13;
+        if (visited[it.node]) return 11;
+        visited[it.node] = 1;
+        const Node8GPU& N = nodes[it.node];
+        const double p[3] = {N.px, N.py, N.pz};
+        double step[3];
+        for (int a = 0; a < 3; a++) { const int eb = (int)((N.e_imask >> (8 * a)) & 0xffu); if (eb < 1 || eb > 254) return 21; step[a] = std::ldexp(1.0, eb - 127); }
+        const uint32_t imask = N.e_imask >> 24;
+        const uint32_t nint = (uint32_t)__builtin_popcount(imask);
+        const uint32_t pushes = it.pushes + (nint > 1 ? 1u : 0u);
+        deepest = std::max(deepest, pushes);
+        uint32_t rank = 0, tri_at = N.tri_base;
+        for (int sl = 0; sl < 8; sl++) {
+            const uint32_t nib = (N.trivalid >> (4 * sl)) & 0xfu;
+            const bool internal = (imask >> sl) & 1u;
+            if (internal && nib) return 22;
+            if (!internal && !nib) continue;
+            double mn[3], mx[3];
+            for (int a = 0; a < 3; a++) {
+                const uint32_t qlo = (N.q[2 * a + (sl >> 2)] >> (8 * (sl & 3))) & 0xffu, qhi = (N.q[2 * (3 + a) + (sl >> 2)] >> (8 * (sl & 3))) & 0xffu;
+                mn[a] = std::max(p[a] + qlo * step[a], it.mn[a]); mx[a] = std::min(p[a] + qhi * step[a], it.mx[a]);
+            }
+            if (internal) {
+                const uint32_t c = N.child_base + rank++;
+                if (c <= it.node) return 12;                                     // breadth-first: children after parents
+                It nx; nx.node = c; nx.pushes = pushes;
+                for (int a = 0; a < 3; a++) { nx.mn[a] = mn[a]; nx.mx[a] = mx[a]; }
+                st.push_back(nx);
+            } else {
+                if (nib != 1 && nib != 3 && nib != 7 && nib != 15) return 23;
+                const uint32_t cnt = (uint32_t)__builtin_popcount(nib);
+                for (uint32_t k = 0; k < cnt; k++, tri_at++) {
+                    if (tri_at >= ntris || tri_slots[tri_at] >= ntris) return 14;
+                    const uint32_t g = order[tri_slots[tri_at]];
+                    if (covered[g]) return 15;
+                    covered[g] = 1;
+                    for (int vtx = 0; vtx < 3; vtx++) for (int a = 0; a < 3; a++) { const double c = w[(size_t)g * 9 + vtx * 3 + a]; if (c < mn[a] || c > mx[a]) return 16; }
+                }
+            }
+        }
+    }
+    for (uint32_t i = 0; i < ntris; i++) if (!covered[i]) return 17;
+    for (size_t i = 0; i < nodes.size(); i++) if (!visited[i]) return 18;
+    if (max_stack_seen) *max_stack_seen = deepest;
+    return 0;
+}
+
 
 }  // namespace rtx

@@ -23,6 +23,9 @@ struct BuiltScene {
     std::vector<uint32_t> tri_slots8; // leaf-order slot of each triangle in the wide tree's order
     std::vector<TriGPU>   tris8;      // `tris` permuted into that order (device copy)
     uint32_t stack8 = 0;              // traversal stack entries (sibling groups) the wide tree can need
+    std::vector<uint32_t> level_start8; // breadth-first levels of nodes8: level l = [level_start8[l], level_start8[l+1]) (GPU refit sweeps them bottom-up)
+    std::vector<F4>       objtris;    // object-space vertex positions, 3 per GLOBAL triangle id (input of the GPU refit)
+    float bvh_pad = 0.0f;             // absolute padding of the leaf boxes used by the last host build
     std::vector<TriGPU>   tris;       // leaf order
     // tiny-scene path (only when the scene has <= kSmallSceneMaxTris triangles): pre-test records + their triangles
     std::vector<SmallRecPair> small_recs; std::vector<TriGPU> small_tris; uint32_t small_nrec = 0;
@@ -50,6 +53,9 @@ struct SceneHost {
     bool add_instance(uint32_t mesh, const float* o2w, uint32_t* out);
     bool set_instance_transform(uint32_t inst, const float* o2w);
     bool build(BuiltScene& out);
+    // transform-only update of the records the GPU refit does not derive itself: instance matrices and the light list
+    bool refresh_transforms(BuiltScene& out);
+    void build_lights(BuiltScene& out) const;
 };
 
 // binned-SAH BVH2 over world-space triangles (9 floats each); fills nodes (breadth-first, children boxes in
@@ -60,6 +66,11 @@ void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGP
 // collapse the binary tree into the compressed 8-wide device form (largest-area internal child opened first, octant-ordered
 // slots, outward-rounded byte quantisation); tri_slots = leaf-order slots in the wide tree's triangle order; max_stack =
 // bound on the sibling-group entries a traversal can hold (one per level).  Returns false on a malformed input tree.
-bool collapse_bvh8(const std::vector<NodeGPU>& nodes2, std::vector<Node8GPU>& nodes8, std::vector<uint32_t>& tri_slots, uint32_t& max_stack);
+bool collapse_bvh8(const std::vector<NodeGPU>& nodes2, std::vector<Node8GPU>& nodes8, std::vector<uint32_t>& tri_slots, uint32_t& max_stack,
+                   std::vector<uint32_t>* level_start = nullptr);
+// coverage check of a wide tree on its DECODED boxes (tests, rtx_debug_validate_bvh): 0 = every triangle order[tri_slots[i]] is in
+// exactly one leaf slot and inside all boxes above it, children follow parents; otherwise a small positive code
+int validate_bvh8(const std::vector<float>& world_tris9, const std::vector<Node8GPU>& nodes, const std::vector<uint32_t>& order,
+                  const std::vector<uint32_t>& tri_slots, uint32_t* max_stack_seen);
 
 }  // namespace rtx

@@ -115,67 +115,6 @@ static int bvh_validate(const std::vector<float>& w, const std::vector<rtx::Node
     return 0;
 }
 
-// the compressed 8-wide collapse: same coverage properties, checked on the DECODED byte-grid boxes of the wide nodes
-static int bvh8_validate(const std::vector<float>& w, const std::vector<rtx::Node8GPU>& nodes, const std::vector<uint32_t>& order,
-                         const std::vector<uint32_t>& tri_slots, uint32_t* max_stack_seen) {
-    const uint32_t ntris = (uint32_t)(w.size() / 9);
-    if (tri_slots.size() != ntris) return 20;
-    struct It { uint32_t node; double mn[3], mx[3]; uint32_t pushes; };
-    std::vector<uint8_t> covered(ntris, 0), visited(nodes.size(), 0);
-    if (nodes.empty()) return ntris ? 10 : 0;
-    std::vector<It> st;
-    const double inf = INFINITY;
-    st.push_back({0u, {-inf, -inf, -inf}, {inf, inf, inf}, 0u});
-    uint32_t deepest = 0;
-    while (!st.empty()) {
-        const It it = st.back(); st.pop_back();
-        if (it.node >= nodes.size()) return 13;
-        if (visited[it.node]) return 11;
-        visited[it.node] = 1;
-        const rtx::Node8GPU& N = nodes[it.node];
-        const double p[3] = {N.px, N.py, N.pz};
-        double step[3];
-        for (int a = 0; a < 3; a++) { const int eb = (int)((N.e_imask >> (8 * a)) & 0xffu); if (eb < 1 || eb > 254) return 21; step[a] = std::ldexp(1.0, eb - 127); }
-        const uint32_t imask = N.e_imask >> 24;
-        const uint32_t nint = (uint32_t)__builtin_popcount(imask);
-        const uint32_t pushes = it.pushes + (nint > 1 ? 1u : 0u);
-        deepest = std::max(deepest, pushes);
-        uint32_t rank = 0, tri_at = N.tri_base;
-        for (int sl = 0; sl < 8; sl++) {
-            const uint32_t nib = (N.trivalid >> (4 * sl)) & 0xfu;
-            const bool internal = (imask >> sl) & 1u;
-            if (internal && nib) return 22;
-            if (!internal && !nib) continue;
-            double mn[3], mx[3];
-            for (int a = 0; a < 3; a++) {
-                const uint32_t qlo = (N.q[2 * a + (sl >> 2)] >> (8 * (sl & 3))) & 0xffu, qhi = (N.q[2 * (3 + a) + (sl >> 2)] >> (8 * (sl & 3))) & 0xffu;
-                mn[a] = std::max(p[a] + qlo * step[a], it.mn[a]); mx[a] = std::min(p[a] + qhi * step[a], it.mx[a]);
-            }
-            if (internal) {
-                const uint32_t c = N.child_base + rank++;
-                if (c <= it.node) return 12;                                     // breadth-first: children after parents
-                It nx; nx.node = c; nx.pushes = pushes;
-                for (int a = 0; a < 3; a++) { nx.mn[a] = mn[a]; nx.mx[a] = mx[a]; }
-                st.push_back(nx);
-            } else {
-                if (nib != 1 && nib != 3 && nib != 7 && nib != 15) return 23;
-                const uint32_t cnt = (uint32_t)__builtin_popcount(nib);
-                for (uint32_t k = 0; k < cnt; k++, tri_at++) {
-                    if (tri_at >= ntris || tri_slots[tri_at] >= ntris) return 14;
-                    const uint32_t g = order[tri_slots[tri_at]];
-                    if (covered[g]) return 15;
-                    covered[g] = 1;
-                    for (int vtx = 0; vtx < 3; vtx++) for (int a = 0; a < 3; a++) { const double c = w[(size_t)g * 9 + vtx * 3 + a]; if (c < mn[a] || c > mx[a]) return 16; }
-                }
-            }
-        }
-    }
-    for (uint32_t i = 0; i < ntris; i++) if (!covered[i]) return 17;
-    for (size_t i = 0; i < nodes.size(); i++) if (!visited[i]) return 18;
-    if (max_stack_seen) *max_stack_seen = deepest;
-    return 0;
-}
-
 // build + collapse; returns 0 when the wide tree covers every triangle exactly once inside its decoded boxes and the reported
 // stack bound is what the deepest root-to-leaf path can push
 int rtxh_bvh8_check(const float* wt, uint32_t ntris, uint32_t* nodes8_out, uint32_t* stack_out) {
@@ -187,7 +126,7 @@ int rtxh_bvh8_check(const float* wt, uint32_t ntris, uint32_t* nodes8_out, uint3
     if (nodes8_out) *nodes8_out = (uint32_t)n8.size();
     if (stack_out) *stack_out = stack;
     uint32_t seen = 0;
-    if (int r = bvh8_validate(w, n8, order, slots, &seen)) return r;
+    if (int r = rtx::validate_bvh8(w, n8, order, slots, &seen)) return r;
     return seen == stack ? 0 : 19;
 }
 
@@ -228,7 +167,7 @@ int rtxh_bvh_refit_check(const float* before, const float* after, uint32_t ntris
     if (int r = bvh_validate(b, nodes, order, nullptr)) return r;
     std::vector<rtx::Node8GPU> n8; std::vector<uint32_t> slots; uint32_t stack = 0;
     if (!rtx::collapse_bvh8(nodes, n8, slots, stack)) return 30;
-    return bvh8_validate(b, n8, order, slots, nullptr);
+    return rtx::validate_bvh8(b, n8, order, slots, nullptr);
 }
 
 // the tiny-scene pre-test records as rtx_commit_scene builds them (for host-side conservativeness tests)

@@ -509,14 +509,16 @@ def test_restir_garage_with_camera_motion(rt, orc, golden_dir):
     c.close()
 
 
-def test_animated_instance_refit_parity(rt, orc, golden_dir):
+@pytest.mark.parametrize("gpu_refit", [1, 0])
+def test_animated_instance_refit_parity(rt, orc, golden_dir, gpu_refit):
     """rtx_set_instance_transform + rtx_commit_scene refits the BVH (reference: TLAS refit every frame); the images of
     the bounce-loop tracer and of the ReSTIR pipeline (which reprojects through prevObjectToWorld) stay identical to the
-    oracle, which rebuilds its own BVH from scratch"""
+    oracle, which rebuilds its own BVH from scratch.  gpu_refit=1: k_refit_tris / k_refit_nodes re-derive the world triangles
+    and re-quantise the resident wide nodes; gpu_refit=0: host refit + re-collapse + upload"""
     import os
     sc = rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")
     W, H = 80, 48
-    c = rt.Context(0); c.upload(sc, W / H); c.set_camera(*sc.view_proj(W / H))
+    c = rt.Context(0); c.set_option(rt.OPT_GPU_REFIT, gpu_refit); c.upload(sc, W / H); c.set_camera(*sc.view_proj(W / H))
     o = orc.Oracle().load(sc, W / H); o.set_camera(*sc.view_proj(W / H))
     acc_o, st = np.zeros((H, W, 4), np.float32), None
     c.restir_reset(); c.clear(W, H)
@@ -525,6 +527,7 @@ def test_animated_instance_refit_parity(rt, orc, golden_dir):
         c.set_instance_transform(1, m.reshape(16)); c.commit()
         o.set_instance_transform(1, m.reshape(16))
         assert c.stats().bvh_refits == k + 1
+        assert c.validate_bvh() == 0                      # coverage of the resident (refitted) tree, checked on the host
         rays = np.concatenate([o.primary_rays(rt.Params(width=W, height=H)), random_rays(20000, 40 + k, -4, 4)])
         g, b = c.trace_closest(rays), o.trace_closest(rays, 0)
         assert np.array_equal(bits(g)[:, 3], bits(b)[:, 3])
@@ -541,6 +544,34 @@ def test_animated_instance_refit_parity(rt, orc, golden_dir):
     c.clear(W, H); c.render(pt)
     ref, _ = o.render(pt)
     assert rel_l2(c.read_accum()[..., :3], ref[..., :3]) <= REL_L2_TOL
+    c.close()
+
+
+def test_gpu_refit_large_scene_stays_conservative(rt, orc):
+    """GPU refit of a 262 k-triangle tree under a large rigid motion + non-uniform scale: the refitted tree validates on the host,
+    hit records and the image equal the oracle's (which rebuilds its own BVH), and a second refit back to identity reproduces
+    the first image"""
+    sc = rt.Scene.sponza_class(262144, 260)
+    W, H = 96, 54
+    p = rt.Params(width=W, height=H, spp=1, max_bounces=3, nee_samples=1, flags=1)
+    c = rt.Context(0); c.upload(sc, W / H)
+    o = orc.Oracle().load(sc, W / H)
+    assert c.validate_bvh() == 0
+    c.clear(W, H); c.render(p); first = c.read_accum()
+    th = 0.7
+    M = np.array([[1.3 * np.cos(th), 0, np.sin(th), 0], [0, 0.8, 0, 0], [-1.3 * np.sin(th), 0, np.cos(th), 0], [0.25, -0.1, 0.4, 1]], np.float32).reshape(16)   # column-major
+    c.set_instance_transform(0, M); c.commit(); o.set_instance_transform(0, M)
+    assert c.stats().bvh_refits == 1 and c.validate_bvh() == 0
+    rays = np.concatenate([o.primary_rays(p), random_rays(30000, 41, -1.5, 1.5)])
+    g, b = c.trace_closest(rays), o.trace_closest(rays, 1)
+    assert np.array_equal(bits(g), bits(b))
+    c.clear(W, H); c.render(p); ca, cnt = o.render(p)
+    assert np.array_equal(bits(c.read_accum()), bits(ca))
+    I = np.eye(4, dtype=np.float32).reshape(16)
+    c.set_instance_transform(0, I); c.commit()
+    assert c.stats().bvh_refits == 2 and c.validate_bvh() == 0
+    c.clear(W, H); c.render(p)
+    assert np.array_equal(bits(c.read_accum()), bits(first))
     c.close()
 
 
