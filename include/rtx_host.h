@@ -72,6 +72,13 @@ int  rtxh_renderer_read_accum(rtxh_renderer*, float* rgba32f, size_t bytes);
 int  rtxh_renderer_read_output(rtxh_renderer*, uint8_t* rgba8, size_t bytes);
 void rtxh_renderer_destroy(rtxh_renderer*);
 
+/* image writers for the headless display path (the reference presents gOutput through a swap chain, Renderer.cpp:554-735, and
+   writes no files): 8-bit RGBA PNG (stored deflate), binary PPM, and OpenEXR (uncompressed scanlines, FLOAT B/G/R =
+   accumulation xyz / max(w, 1)).  0 on success. */
+int  rtxh_write_png(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
+int  rtxh_write_ppm(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
+int  rtxh_write_exr(const char* path, const float* rgba32f_accum, uint32_t width, uint32_t height);
+
 #ifdef __cplusplus
 }
 #endif

@@ -146,6 +146,9 @@ _sig("rtxh_bvh_check", C.c_int, _vp, _u32, _u32p, _u32p, _u32p)
 _sig("rtxh_bvh_refit_check", C.c_int, _vp, _vp, _u32)
 _sig("rtxh_bvh8_check", C.c_int, _vp, _u32, _u32p, _u32p)
 _sig("rtxh_bvh8_stats", C.c_int, _vp, _u32, _vp, _u32p)
+_sig("rtxh_write_png", C.c_int, C.c_char_p, _vp, _u32, _u32)
+_sig("rtxh_write_ppm", C.c_int, C.c_char_p, _vp, _u32, _u32)
+_sig("rtxh_write_exr", C.c_int, C.c_char_p, _vp, _u32, _u32)
 _sig("rtxh_scene_small_records", C.c_int, _vp, _vp, _vp, _u32, _u32p, _fp, _fp)
 _sig("rtxh_renderer_create", _vp, _u32, _u32, C.c_char_p, C.c_int)
 _sig("rtxh_renderer_set_scene", C.c_int, _vp, _vp)
@@ -279,6 +282,19 @@ def bvh_check(world_tris):
     nodes, depth, leaf = _u32(), _u32(), _u32()
     rc = lib.rtxh_bvh_check(_ptr(w), len(w), C.byref(nodes), C.byref(depth), C.byref(leaf))
     return rc, nodes.value, depth.value, leaf.value
+
+
+def write_image(path, image):
+    """(H, W, 4) uint8 sRGB -> .png / .ppm; (H, W, 4) float32 accumulation buffer -> .exr (xyz / count)"""
+    a = np.ascontiguousarray(image)
+    h, w = a.shape[:2]
+    if path.endswith(".exr"):
+        rc = lib.rtxh_write_exr(path.encode(), _ptr(_f32(a)), w, h)
+    else:
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        rc = (lib.rtxh_write_ppm if path.endswith(".ppm") else lib.rtxh_write_png)(path.encode(), _ptr(a), w, h)
+    if rc != 0:
+        raise RtxError("could not write " + path)
 
 
 def bvh8_stats(world_tris):

@@ -9,6 +9,7 @@
 #include "../csrc/rtx_scene_host.hpp"
 #include "ObjLoader.h"
 #include "Renderer.h"
+#include "ImageIO.h"
 #include "Scenes.h"
 #include "manipulator.h"
 
@@ -203,5 +204,10 @@ int rtxh_renderer_read_output(rtxh_renderer* r, uint8_t* out, size_t bytes) {
     return guarded_rc([&] { auto v = r->r->ReadOutput(); if (bytes < v.size()) throw std::runtime_error("buffer too small"); memcpy(out, v.data(), v.size()); });
 }
 void rtxh_renderer_destroy(rtxh_renderer* r) { if (r) { delete r->r; delete r; } }
+
+// image writers of the headless display path (host/ImageIO.h)
+int rtxh_write_png(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height) { return path && WritePNG(path, rgba8, width, height) ? RTX_OK : RTX_ERR_INVALID; }
+int rtxh_write_ppm(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height) { return path && WritePPM(path, rgba8, width, height) ? RTX_OK : RTX_ERR_INVALID; }
+int rtxh_write_exr(const char* path, const float* rgba32f, uint32_t width, uint32_t height) { return path && WriteEXR(path, rgba32f, width, height) ? RTX_OK : RTX_ERR_INVALID; }
 
 }  // extern "C"

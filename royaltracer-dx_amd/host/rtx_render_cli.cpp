@@ -1,6 +1,6 @@
 // rtx_render — headless CLI over the Renderer facade (replaces the Win32 window loop, Main.cpp:18-27).
 // usage: rtx_render [--scene cornell|sponza|bistro|obj] [--obj a.obj,b.obj --mtl dir] [--w 1920 --h 1080]
-//                   [--spp 64] [--frames 1] [--bounces 8] [--nee 1] [--lambert] [--out image.ppm] [--device 0]
+//                   [--spp 64] [--frames 1] [--bounces 8] [--nee 1] [--lambert] [--out image.{png,ppm,exr}] [--device 0]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -8,6 +8,7 @@
 #include <sstream>
 #include <string>
 #include "Renderer.h"
+#include "ImageIO.h"
 
 int main(int argc, char** argv) {
     std::string scene = "cornell", out, objs, mtl = "./";
@@ -37,9 +38,11 @@ int main(int argc, char** argv) {
                    (unsigned long long)s.rays_primary, (unsigned long long)s.rays_extension, (unsigned long long)s.rays_shadow);
         }
         if (!out.empty()) {
-            std::vector<uint8_t> px = r.ReadOutput();
-            std::ofstream f(out, std::ios::binary); f << "P6\n" << w << " " << h << "\n255\n";
-            for (size_t i = 0; i < (size_t)w * h; i++) f.write((const char*)&px[i * 4], 3);
+            const bool exr = out.size() > 4 && out.substr(out.size() - 4) == ".exr", png = out.size() > 4 && out.substr(out.size() - 4) == ".png";
+            bool ok;
+            if (exr) { std::vector<float> acc = r.ReadAccumulation(); ok = WriteEXR(out, acc.data(), w, h); }
+            else { std::vector<uint8_t> px = r.ReadOutput(); ok = png ? WritePNG(out, px.data(), w, h) : WritePPM(out, px.data(), w, h); }
+            if (!ok) { fprintf(stderr, "error: could not write %s\n", out.c_str()); return 1; }
         }
         r.OnDestroy();
     } catch (const std::exception& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }

@@ -225,3 +225,60 @@ def test_bvh_refit_keeps_invariants(rt):
     b = a.copy(); b[: n // 2] = b[: n // 2] @ R.T + np.float32([0.3, -0.2, 0.1])      # half of the triangles move rigidly
     assert rt.bvh_refit_check(a.reshape(-1, 9), b.reshape(-1, 9)) == 0
     assert rt.bvh_refit_check(a.reshape(-1, 9), a.reshape(-1, 9)) == 0
+
+
+# ---- image writers (headless display path) ------------------------------------------------------
+def test_png_ppm_exr_writers_round_trip(rt, tmp_path):
+    import struct, zlib
+    rng = np.random.default_rng(3)
+    W, H = 37, 21
+    img = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+    # PNG: signature, chunk CRCs, IHDR fields, and the inflated scanlines equal the input
+    p = str(tmp_path / "a.png"); rt.write_image(p, img)
+    b = open(p, "rb").read()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    at, chunks = 8, []
+    while at < len(b):
+        n, typ = struct.unpack(">I4s", b[at:at + 8]); data = b[at + 8:at + 8 + n]; crc, = struct.unpack(">I", b[at + 8 + n:at + 12 + n])
+        assert zlib.crc32(typ + data) == crc
+        chunks.append((typ, data)); at += 12 + n
+    assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    assert struct.unpack(">IIBBBBB", chunks[0][1]) == (W, H, 8, 6, 0, 0, 0)
+    raw = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(H, 1 + W * 4)
+    assert (raw[:, 0] == 0).all() and np.array_equal(raw[:, 1:].reshape(H, W, 4), img)
+    # a frame larger than one stored deflate block (65535 bytes)
+    big = rng.integers(0, 256, (200, 300, 4), dtype=np.uint8)
+    p2 = str(tmp_path / "b.png"); rt.write_image(p2, big)
+    b2 = open(p2, "rb").read(); i = b2.index(b"IDAT"); n, = struct.unpack(">I", b2[i - 4:i])
+    assert np.array_equal(np.frombuffer(zlib.decompress(b2[i + 4:i + 4 + n]), np.uint8).reshape(200, 1 + 1200)[:, 1:].reshape(200, 300, 4), big)
+    # PPM
+    p = str(tmp_path / "a.ppm"); rt.write_image(p, img)
+    b = open(p, "rb").read(); hdr = b"P6\n%d %d\n255\n" % (W, H)
+    assert b.startswith(hdr) and np.array_equal(np.frombuffer(b[len(hdr):], np.uint8).reshape(H, W, 3), img[..., :3])
+    # EXR: header attributes, offset table, scanlines hold accum.xyz / count as B, G, R planes
+    acc = rng.uniform(0, 4, (H, W, 4)).astype(np.float32); acc[..., 3] = rng.integers(0, 5, (H, W))
+    p = str(tmp_path / "a.exr"); rt.write_image(p, acc)
+    b = open(p, "rb").read()
+    assert struct.unpack("<II", b[:8]) == (20000630, 2)
+    at, attrs = 8, {}
+    while b[at] != 0:
+        e = b.index(b"\0", at); name = b[at:e].decode(); at = e + 1
+        e = b.index(b"\0", at); typ = b[at:e].decode(); at = e + 1
+        n, = struct.unpack("<I", b[at:at + 4]); attrs[name] = (typ, b[at + 4:at + 4 + n]); at += 4 + n
+    at += 1
+    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
+    assert struct.unpack("<4i", attrs["dataWindow"][1]) == (0, 0, W - 1, H - 1) and attrs["dataWindow"] == attrs["displayWindow"]
+    ch = attrs["channels"][1]; names = []
+    k = 0
+    while ch[k] != 0:
+        e = ch.index(b"\0", k); names.append(ch[k:e].decode()); assert struct.unpack("<I", ch[e + 1:e + 5]) == (2,); k = e + 17
+    assert names == ["B", "G", "R"]
+    offs = struct.unpack("<%dQ" % H, b[at:at + 8 * H])
+    want = acc[..., :3] / np.maximum(acc[..., 3:4], 1.0)
+    for y in (0, H // 2, H - 1):
+        yy, nb = struct.unpack("<iI", b[offs[y]:offs[y] + 8]); assert (yy, nb) == (y, W * 12)
+        line = np.frombuffer(b[offs[y] + 8:offs[y] + 8 + nb], np.float32).reshape(3, W)
+        assert np.array_equal(line[0], want[y, :, 2]) and np.array_equal(line[1], want[y, :, 1]) and np.array_equal(line[2], want[y, :, 0])
+    assert len(b) == offs[-1] + 8 + W * 12
+    with pytest.raises(rt.RtxError):
+        rt.write_image(str(tmp_path / "no_such_dir" / "x.png"), img)
