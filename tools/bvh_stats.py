@@ -1,3 +1,5 @@
+"""Node steps and triangle tests per ray of the resident wide BVH (rtx_debug_trace_stats) for primary and secondary rays.
+Run on a GPU box: python tools/bvh_stats.py"""
 import sys; sys.path.insert(0,'.'); sys.path.insert(0,'tests')
 import numpy as np
 import __graft_entry__ as g

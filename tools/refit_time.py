@@ -1,3 +1,4 @@
+"""Wall time of transform-only commits: GPU refit vs host refit + re-collapse + upload.  python tools/refit_time.py"""
 import sys, time; sys.path.insert(0,'.')
 import numpy as np
 import __graft_entry__ as g
