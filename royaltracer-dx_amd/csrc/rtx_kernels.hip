@@ -448,12 +448,14 @@ __global__ __launch_bounds__(kBlock) void k_raygen_trace_small(DevScene sc, cons
 // Exit: a wave leaves when the sub-queue is exhausted and no lane holds a ray — every wave reaches that.
 // ---------------------------------------------------------------------------------------------
 int g_refill_min = 12;
-int g_trace_sched = 2;                                // 0 = while-while, 1 = voted node / triangle steps.  With the 128-B 4-wide nodes the voted schedule
-                                                      // was slower (texture-addresser bound, profiles/r01_pmc_bvh.md); with the 80-B 8-wide nodes it wins
-                                                      // (Sponza-class 59.2 vs 67.7 ms, Bistro-class 47.8 vs 56.2 ms)
+int g_trace_sched = 6;                                // 0 = while-while; 1-4 = voted node / triangle steps (vote weights); 5-7 = voted + speculative
+                                                      // (lanes with pending triangles keep walking nodes).  C3 / C5 ms per frame on the 8-wide tree:
+                                                      // while-while 67.7 / 56.2, voted (2) 55.6 / 45.3, speculative (6) 53.1 / 44.5; lanes per VALU
+                                                      // instruction 24.5 -> 40.8 -> 43.8 (profiles/r01_pmc_bvh.md).  With the 128-B 4-wide nodes the voted
+                                                      // schedule was slower: the traversal was texture-addresser bound then, not VALU bound.
 
 struct RayLane {                                       // per-lane traversal state
-    f3 o, d, idir; float tmin, tmax, bt, bu, bv; uint32_t bprim; uint32_t oct; Grp G; TriGrp T; int sp; uint32_t item; bool has, done;
+    f3 o, d, idir; float tmin, tmax, bt, bu, bv; uint32_t bprim; uint32_t oct; Grp G; TriGrp T, T2; int sp; uint32_t item; bool has, done;   // T2: second pending triangle group (speculative schedule)
 };
 __device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, float tmax, uint32_t item) {
     R.o = o; R.d = d; R.tmin = tmin; R.tmax = tmax; R.item = item;
@@ -463,11 +465,11 @@ __device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, fl
     R.idir = mk3(__builtin_amdgcn_rcpf(dxs), __builtin_amdgcn_rcpf(dys), __builtin_amdgcn_rcpf(dzs));
     R.oct = ray_octant(R.idir);
     R.bt = tmax; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.sp = 0; R.has = true; R.done = false;
-    R.G = Grp{0u, (1u << R.oct) | (1u << 8)}; R.T = TriGrp{0u, 0u, 0u};
+    R.G = Grp{0u, (1u << R.oct) | (1u << 8)}; R.T = TriGrp{0u, 0u, 0u}; R.T2 = TriGrp{0u, 0u, 0u};
 }
 __device__ __forceinline__ void ray_idle(RayLane& R) {
     R.has = false; R.done = false; R.sp = 0; R.item = 0; R.o = mk3(0, 0, 0); R.d = mk3(0, 0, 1); R.idir = mk3(0, 0, 1); R.oct = 0;
-    R.tmin = 0.0f; R.tmax = 0.0f; R.bt = 0.0f; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.G = Grp{0u, 0u}; R.T = TriGrp{0u, 0u, 0u};
+    R.tmin = 0.0f; R.tmax = 0.0f; R.bt = 0.0f; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.G = Grp{0u, 0u}; R.T = TriGrp{0u, 0u, 0u}; R.T2 = TriGrp{0u, 0u, 0u};
 }
 // after a node step or a finished triangle group: continue with the node's own internal hits, else pop, else done
 template <class STK>
@@ -523,6 +525,32 @@ __device__ __forceinline__ void voted_step(const DevScene& sc, const TraceLds& L
         if (!R.done) next_group(R, stk);
     }
 }
+// Speculative voted schedule (g_trace_sched >= 5): a lane whose triangles are still waiting for a triangle step keeps walking
+// nodes — the triangles of the next node go to a second pending group (T2) — so node steps run with most busy lanes instead of
+// only those without pending triangles, and triangle steps run when many lanes have some.  Pending triangles are always tested
+// before a ray finishes, and the order of tests does not change the result (minimum over all tested triangles / any hit); what
+// speculation costs is culling: node steps taken before the pending triangles shrink the closest distance may visit boxes that
+// would have been culled (shadow rays lose nothing: their interval is fixed).
+template <bool ANY, class STK>
+__device__ __forceinline__ void spec_step(const DevScene& sc, const TraceLds& L, RayLane& R, STK& stk, uint32_t sched) {
+    const bool busy = R.has && !R.done;
+    const bool has_tri = busy && R.T.bits != 0u;
+    const bool can_node = busy && R.T2.bits == 0u && ((R.G.bits & 0xffu) != 0u || R.sp > 0);
+    const uint32_t ni = (uint32_t)__popcll(__ballot(can_node)), nl = (uint32_t)__popcll(__ballot(has_tri));
+    const uint32_t wn = sched == 7u ? 2u : 1u, wl = sched == 5u ? 1u : sched == 6u ? 2u : 1u;
+    if (ni * wn >= nl * wl && ni) {
+        if (can_node) {
+            if (!(R.G.bits & 0xffu)) { R.sp--; R.G = stk.get(R.sp); }
+            TriGrp Tn;
+            descend8(sc, L, R.o, R.idir, R.oct, R.tmin, R.bt, R.G, Tn, stk, R.sp);
+            if (Tn.bits) { if (R.T.bits) R.T2 = Tn; else R.T = Tn; }
+        }
+    } else if (has_tri) {
+        tri_step<ANY>(sc, L, R);
+        if (!R.T.bits) { R.T = R.T2; R.T2 = TriGrp{0u, 0u, 0u}; }
+    }
+    if (R.has && !R.done && !(R.G.bits & 0xffu) && R.sp == 0 && !R.T.bits) R.done = true;
+}
 // wave-level refill: returns false when the wave may exit (queue exhausted and nothing in flight)
 template <class Fetch>
 __device__ __forceinline__ bool refill(RayLane& R, uint32_t* s_head, uint32_t n, bool& drained, uint32_t refill_min, Fetch fetch) {
@@ -572,7 +600,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
                const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
                ray_begin(R, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, pid);
            })) {
-        if (sched) voted_step<false>(sc, L, R, stk, sched);
+        if (sched >= 5u) spec_step<false>(sc, L, R, stk, sched);
+        else if (sched) voted_step<false>(sc, L, R, stk, sched);
         else { walk_internal<false>(sc, L, R, stk); process_leaf<false>(sc, L, R, stk); }
         if (R.has && R.done) { p.hit[R.item] = {R.bt, R.bu, R.bv, u2f(R.bprim)}; R.has = false; }
     }
@@ -617,7 +646,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const Smal
                const F4 so = sh_o[qb + idx], sd = sh_d[qb + idx];
                ray_begin(R, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, idx);
            })) {
-        if (sched) voted_step<true>(sc, L, R, stk, sched);
+        if (sched >= 5u) spec_step<true>(sc, L, R, stk, sched);
+        else if (sched) voted_step<true>(sc, L, R, stk, sched);
         else { walk_internal<true>(sc, L, R, stk); process_leaf<true>(sc, L, R, stk); }
         if (R.has && R.done) { finish(R.item, R.bprim != kMissPrim); R.has = false; }
     }
