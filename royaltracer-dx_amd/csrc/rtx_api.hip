@@ -221,9 +221,9 @@ int rtx_commit_scene(rtx_ctx* c) {
     budget -= (size_t)s.lds_nodes * 80;
     uint32_t want_tris = s.ntris <= 256 ? s.ntris : 0u;                    // triangles only when ALL of them fit
     s.lds_tris = (size_t)want_tris * 48 <= budget ? want_tris : 0u;
-    s.nsmall = 0;
+    s.nsmall = 0; s.nsmall_occ = 0;
     if (c->small_scene && B.small_nrec && B.small_tris.size() * 48 <= budget + (size_t)s.lds_tris * 48) {
-        s.nsmall = B.small_nrec; s.lds_tris = (uint32_t)B.small_tris.size();   // LDS holds the records' triangles instead of the leaf-ordered ones
+        s.nsmall = B.small_nrec; s.nsmall_occ = B.small_nocc; s.lds_tris = (uint32_t)B.small_tris.size();   // LDS holds the records' triangles instead of the leaf-ordered ones
     }
     if (trace_lds_bytes(s) > 64 * 1024) { c->err = "commit: BVH too deep for the LDS traversal stack"; return RTX_ERR_INVALID; }
     c->stats.bvh_refits = B.refit_count; c->stats.bvh_nodes = s.nnodes; c->stats.triangles = s.ntris; c->stats.lights = s.nlights; c->stats.materials = s.nmat;

@@ -337,10 +337,12 @@ __device__ __forceinline__ void traverse_stats(const DevScene& sc, const TraceLd
 
 template <bool ANY>
 __device__ __forceinline__ void traverse_small(const DevScene& sc, const SmallRecPair* __restrict__ sp, const TraceLds& L, f3 o, f3 d, float tmin, float tmax,
-                                               float& bt, float& bu, float& bv, uint32_t& bprim) {
+                                               float& bt, float& bu, float& bv, uint32_t& bprim, uint32_t nrec) {
+    // nrec = sc.nsmall, or sc.nsmall_occ for NEE shadow segments (both end points inside the scene's convex hull: the records
+    // after the first nsmall_occ are faces OF that hull and cannot lie between them, rtx_scene_host.cpp)
     bt = tmax; bu = 0.0f; bv = 0.0f; bprim = kMissPrim;
     uint32_t cand_lo = 0u, cand_hi = 0u;
-    const uint32_t npairs = (sc.nsmall + 1u) >> 1;
+    const uint32_t npairs = (nrec + 1u) >> 1;
     const f2v dx = splat2(d.x), dy = splat2(d.y), dz = splat2(d.z), ox = splat2(o.x), oy = splat2(o.y), oz = splat2(o.z);
     const f2v cm = splat2(sc.small_cm), c5 = splat2(1e-5f), vtmin = splat2(tmin), vtmax = splat2(tmax), dl = splat2(sc.small_delta);
 #pragma unroll 2
@@ -387,7 +389,7 @@ __device__ __forceinline__ void traverse_small(const DevScene& sc, const SmallRe
 template <bool ANY>
 __device__ __forceinline__ void trace_ray(const DevScene& sc, const SmallRecPair* __restrict__ small, const TraceLds& L, f3 o, f3 d, float tmin, float tmax,
                                           float& bt, float& bu, float& bv, uint32_t& bprim) {
-    if (sc.nsmall) traverse_small<ANY>(sc, small, L, o, d, tmin, tmax, bt, bu, bv, bprim);
+    if (sc.nsmall) traverse_small<ANY>(sc, small, L, o, d, tmin, tmax, bt, bu, bv, bprim, sc.nsmall);
     else traverse<ANY>(sc, L, o, d, tmin, tmax, bt, bu, bv, bprim);
 }
 
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen_trace_small(DevScene sc, cons
             generated++;
         }
         float t, u, v; uint32_t prim;
-        traverse_small<false>(sc, small, L, o, d, kTMinCam, valid ? kTMax : 0.0f, t, u, v, prim);
+        traverse_small<false>(sc, small, L, o, d, kTMinCam, valid ? kTMax : 0.0f, t, u, v, prim, sc.nsmall);
         const bool hit = valid && prim != kMissPrim;
         if (valid) p.rad[pid] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (hit) {
@@ -586,7 +588,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
             const uint32_t pid = myq[i];
             const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
             float t, u, v; uint32_t prim;
-            traverse_small<false>(sc, small, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, t, u, v, prim);
+            traverse_small<false>(sc, small, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, t, u, v, prim, sc.nsmall);
             p.hit[pid] = {t, u, v, u2f(prim)};
         }
         return;
@@ -633,7 +635,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const Smal
         for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
             const F4 so = sh_o[qb + i], sd = sh_d[qb + i];
             float t, u, v; uint32_t prim;
-            traverse_small<true>(sc, small, L, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, t, u, v, prim);
+            traverse_small<true>(sc, small, L, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, t, u, v, prim, sc.nsmall_occ);   // NEE segments only
             finish(i, prim != kMissPrim);
         }
         return;
@@ -904,7 +906,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
         float t = 0.0f, u = 0.0f, v = 0.0f; uint32_t prim = kMissPrim;
         if (HAVE_HIT) {                                   // bounce 0: the primary hit comes from k_raygen_trace_small
             if (active) { const F4 h = p.hit[S.pid]; t = h.x; u = h.y; v = h.z; prim = f2u(h.w); }
-        } else traverse_small<false>(sc, small, L, S.o, S.d, tmin, active ? kTMax : 0.0f, t, u, v, prim);   // inactive lanes: empty interval
+        } else traverse_small<false>(sc, small, L, S.o, S.d, tmin, active ? kTMax : 0.0f, t, u, v, prim, sc.nsmall);   // inactive lanes: empty interval
         Surf sf; sf.mat = 0; sf.normal = mk3(0, 0, 1); sf.pos = mk3(0, 0, 0);
         bool shading = false;
         if (active && prim != kMissPrim) {
@@ -925,7 +927,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
             const unsigned long long pm = __ballot(push);
             if (pm) {                                                          // wave-uniform
                 float st_, su_, sv_; uint32_t sprim;
-                traverse_small<true>(sc, small, L, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, push ? sd.w : 0.0f, st_, su_, sv_, sprim);
+                traverse_small<true>(sc, small, L, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, push ? sd.w : 0.0f, st_, su_, sv_, sprim, sc.nsmall_occ);
                 if (push && sprim == kMissPrim) {
                     if (!loaded) { radv = p.rad[S.pid]; loaded = true; }
                     radv.x = radv.x + con.x; radv.y = radv.y + con.y; radv.z = radv.z + con.z;
