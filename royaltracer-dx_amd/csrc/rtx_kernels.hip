@@ -449,12 +449,13 @@ __global__ __launch_bounds__(kBlock) void k_raygen_trace_small(DevScene sc, cons
 // until each holds a leaf (or is done)" followed by "all lanes with a leaf test its triangles" (while-while).
 // Exit: a wave leaves when the sub-queue is exhausted and no lane holds a ray — every wave reaches that.
 // ---------------------------------------------------------------------------------------------
-int g_refill_min = 12;
-int g_trace_sched = 6;                                // 0 = while-while; 1-4 = voted node / triangle steps (vote weights); 5-7 = voted + speculative
-                                                      // (lanes with pending triangles keep walking nodes).  C3 / C5 ms per frame on the 8-wide tree:
-                                                      // while-while 67.7 / 56.2, voted (2) 55.6 / 45.3, speculative (6) 53.1 / 44.5; lanes per VALU
-                                                      // instruction 24.5 -> 40.8 -> 43.8 (profiles/r01_pmc_bvh.md).  With the 128-B 4-wide nodes the voted
-                                                      // schedule was slower: the traversal was texture-addresser bound then, not VALU bound.
+// Tuning knobs of the persistent traversal (per context: DevScene::refill_min, DevScene::trace_sched).
+//   refill_min : refill when at least this many lanes are idle (default 12)
+//   trace_sched: 0 = while-while; 1-4 = voted node / triangle steps (vote weights); 5-7 = voted + speculative (lanes with pending
+//                triangles keep walking nodes; default 6).  C3 / C5 ms per frame on the 8-wide tree: while-while 67.7 / 56.2,
+//                voted (2) 55.6 / 45.3, speculative (6) 53.1 / 44.5; lanes per VALU instruction 24.5 -> 40.8 -> 43.8
+//                (profiles/r01_pmc_bvh.md).  With the 128-B 4-wide nodes the voted schedule was slower: the traversal was
+//                texture-addresser bound then, not VALU bound.
 
 struct RayLane {                                       // per-lane traversal state
     f3 o, d, idir; float tmin, tmax, bt, bu, bv; uint32_t bprim; uint32_t oct; Grp G; TriGrp T, T2; int sp; uint32_t item; bool has, done;   // T2: second pending triangle group (speculative schedule)
@@ -511,7 +512,7 @@ __device__ __forceinline__ void process_leaf(const DevScene& sc, const TraceLds&
     while (R.has && !R.done && R.T.bits) tri_step<ANY>(sc, L, R);
     if (R.has && !R.done) next_group(R, stk);
 }
-// Voted schedule (g_trace_sched = 1): instead of "walk until EVERY lane holds triangles, then test every lane's triangles"
+// Voted schedule (trace_sched 1-4): instead of "walk until EVERY lane holds triangles, then test every lane's triangles"
 // each iteration the wave votes for the step most of its busy lanes are waiting for: one node step, or one triangle test.
 template <bool ANY, class STK>
 __device__ __forceinline__ void voted_step(const DevScene& sc, const TraceLds& L, RayLane& R, STK& stk, uint32_t sched) {
@@ -527,7 +528,7 @@ __device__ __forceinline__ void voted_step(const DevScene& sc, const TraceLds& L
         if (!R.done) next_group(R, stk);
     }
 }
-// Speculative voted schedule (g_trace_sched >= 5): a lane whose triangles are still waiting for a triangle step keeps walking
+// Speculative voted schedule (trace_sched 5-7): a lane whose triangles are still waiting for a triangle step keeps walking
 // nodes — the triangles of the next node go to a second pending group (T2) — so node steps run with most busy lanes instead of
 // only those without pending triangles, and triangle steps run when many lanes have some.  Pending triangles are always tested
 // before a ray finishes, and the order of tests does not change the result (minimum over all tested triangles / any hit); what
@@ -1766,8 +1767,8 @@ void launch_raygen_trace_small(hipStream_t st, const DevScene& sc, const DevFram
 }
 void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t bounce, const uint32_t* queue, const uint32_t* qcount) {
     const float tmin = bounce == 0 ? kTMinCam : kSBias;
-    if (sc.stack_private == 1) hipLaunchKernelGGL(k_trace_closest<1>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, (uint32_t)g_refill_min, (uint32_t)g_trace_sched);
-    else hipLaunchKernelGGL(k_trace_closest<0>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, (uint32_t)g_refill_min, (uint32_t)g_trace_sched);
+    if (sc.stack_private == 1) hipLaunchKernelGGL(k_trace_closest<1>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, sc.refill_min, sc.trace_sched);
+    else hipLaunchKernelGGL(k_trace_closest<0>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, sc.refill_min, sc.trace_sched);
 }
 void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce, bool have_hit,
                          const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts) {
@@ -1777,8 +1778,8 @@ void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, 
 }
 void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t j, const uint32_t* shcount) {
     const size_t seg = (size_t)j * f.qcap * f.nblocks;
-    if (sc.stack_private == 1) hipLaunchKernelGGL(k_trace_shadow<1>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, (uint32_t)g_refill_min, (uint32_t)g_trace_sched);
-    else hipLaunchKernelGGL(k_trace_shadow<0>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, (uint32_t)g_refill_min, (uint32_t)g_trace_sched);
+    if (sc.stack_private == 1) hipLaunchKernelGGL(k_trace_shadow<1>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, sc.refill_min, sc.trace_sched);
+    else hipLaunchKernelGGL(k_trace_shadow<0>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, sc.refill_min, sc.trace_sched);
 }
 void launch_shade(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce,
                   const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts) {

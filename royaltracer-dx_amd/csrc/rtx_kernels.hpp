@@ -20,7 +20,8 @@ struct DevScene {
     float total_weight;
     uint32_t lds_nodes, lds_tris;   // how many nodes / triangles each workgroup stages in LDS
     uint32_t stack_depth;           // per-lane traversal stack entries (LDS)
-    uint32_t stack_private;         // queue kernels: 0 = stack in the LDS column, 1 = private (scratch) array, 2 = hybrid (16 LDS entries + private overflow)
+    uint32_t stack_private;         // queue kernels: 0 = stack in the LDS column, 1 = private (scratch) array
+    uint32_t refill_min, trace_sched;   // persistent traversal: idle lanes that trigger a refill; wave schedule (rtx_kernels.hip)
 };
 
 // one sample batch of one frame
@@ -49,8 +50,6 @@ struct DevPaths {
     F4* sh_c;    // contribution.xyz, pid bits
 };
 
-extern int g_refill_min;
-extern int g_trace_sched;       // tuning knob: idle lanes that trigger a refill in the persistent traversal
 extern int g_sort_materials;   // 1 = material-sorted shading in k_shade (general path)
 extern int g_bounce_variant;   // tuning knob: waves/SIMD the fused kernel is compiled for (4, 5 or 6)
 size_t trace_lds_bytes(const DevScene& sc);

@@ -7,7 +7,8 @@ namespace rtx {
 
 struct alignas(16) F4 { float x, y, z, w; };
 
-// BVH2 node with BOTH children's boxes stored in the parent (one 64-B fetch per traversal step).
+// BVH2 node with BOTH children's boxes stored in the parent: the HOST-side build / refit form (rtx_scene_host.cpp); the kernels
+// traverse the compressed 8-wide collapse below.
 //   a = (c0.min.xyz, c0.max.x)   b = (c0.max.yz, c1.min.xy)   c = (c1.min.z, c1.max.xyz)
 //   d = (child0 bits, child1 bits, -, -)
 // child >= 0: index of an internal node.  child < 0: leaf, v = ~child, first triangle slot = v >> 3,
