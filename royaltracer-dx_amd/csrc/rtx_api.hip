@@ -38,7 +38,7 @@ struct rtx_ctx {
     DevBuf d_nodes, d_tris, d_small, d_small_tris, d_shade, d_mats, d_insts, d_lights, d_cam;
     DevBuf d_objtris, d_node_aabb, d_scale;          // GPU refit: object-space vertices (uploaded on first use), per-node float boxes, max |coordinate|
     bool gpu_refit = true, device_scene_valid = false, objtris_uploaded = false;
-    uint32_t refill_min = 12, trace_sched = 6;       // persistent-traversal knobs (RTX_OPT_REFILL_MIN, RTX_OPT_TRACE_SCHED)
+    uint32_t refill_min = 12, trace_sched = 6, sort_materials = 0;       // persistent-traversal knobs (RTX_OPT_REFILL_MIN, RTX_OPT_TRACE_SCHED)
     DevScene dsc{};
     float view[16], proj[16];
     // path state
@@ -120,11 +120,11 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     switch (option) {
     case RTX_OPT_KERNEL_TIMING: c->timing = value != 0; return RTX_OK;
     case RTX_OPT_PATHS_PER_BATCH: if (value < 4096) { c->err = "paths_per_batch must be >= 4096"; return RTX_ERR_INVALID; } c->paths_per_batch = (uint64_t)value; return RTX_OK;
-    case RTX_OPT_SORT_MATERIALS: g_sort_materials = value != 0; return RTX_OK;
+    case RTX_OPT_SORT_MATERIALS: c->sort_materials = value != 0; c->dsc.sort_materials = c->sort_materials; return RTX_OK;
     case RTX_OPT_LDS_NODES: c->lds_nodes_opt = (int)value; c->committed = false; return RTX_OK;
     case RTX_OPT_SMALL_SCENE: c->small_scene = value != 0; c->committed = false; return RTX_OK;
     case RTX_OPT_FUSED_BOUNCE: c->fused = value != 0; return RTX_OK;
-    case RTX_OPT_BOUNCE_VARIANT: g_bounce_variant = (int)value; return RTX_OK;
+    case RTX_OPT_BOUNCE_VARIANT: return RTX_OK;         // retired knob (only the 4-waves/SIMD build of the fused kernel is kept): accepted, ignored
     case RTX_OPT_STACK_PRIVATE: c->stack_private = (int)value; c->committed = false; return RTX_OK;
     case RTX_OPT_GPU_REFIT: c->gpu_refit = value != 0; return RTX_OK;
     case RTX_OPT_TRACE_SCHED: if (value > 7) { c->err = "trace_sched must be in [0, 7]"; return RTX_ERR_INVALID; } c->trace_sched = (uint32_t)value; c->dsc.trace_sched = c->trace_sched; return RTX_OK;
@@ -223,7 +223,7 @@ int rtx_commit_scene(rtx_ctx* c) {
     uint32_t want_tris = s.ntris <= 256 ? s.ntris : 0u;                    // triangles only when ALL of them fit
     s.lds_tris = (size_t)want_tris * 48 <= budget ? want_tris : 0u;
     s.nsmall = 0; s.nsmall_occ = 0;
-    s.refill_min = c->refill_min; s.trace_sched = c->trace_sched;
+    s.refill_min = c->refill_min; s.trace_sched = c->trace_sched; s.sort_materials = c->sort_materials;
     if (c->small_scene && B.small_nrec && B.small_tris.size() * 48 <= budget + (size_t)s.lds_tris * 48) {
         s.nsmall = B.small_nrec; s.nsmall_occ = B.small_nocc; s.lds_tris = (uint32_t)B.small_tris.size();   // LDS holds the records' triangles instead of the leaf-ordered ones
     }

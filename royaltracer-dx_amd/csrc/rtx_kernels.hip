@@ -1638,8 +1638,6 @@ __global__ __launch_bounds__(kBlock) void k_dbg_primary(DevFrame f, const Camera
     rays[2 * i + 1] = {d.x, d.y, d.z, kTMax};
 }
 
-int g_bounce_variant = 4;
-int g_sort_materials = 0;     // measured slower (see k_shade): the permutation un-coalesces the per-path state streams
 
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
@@ -1783,7 +1781,8 @@ void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, 
 }
 void launch_shade(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce,
                   const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts) {
-    if (g_sort_materials) hipLaunchKernelGGL(k_shade<true>, dim3(f.nblocks), dim3(kBlock), 0, st, sc, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);
+    // material-sorted variant: measured slower (see k_shade), the permutation un-coalesces the per-path state streams
+    if (sc.sort_materials) hipLaunchKernelGGL(k_shade<true>, dim3(f.nblocks), dim3(kBlock), 0, st, sc, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);
     else hipLaunchKernelGGL(k_shade<false>, dim3(f.nblocks), dim3(kBlock), 0, st, sc, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);
 }
 void launch_v6_pass1(hipStream_t st, uint32_t max_blocks, const DevScene& sc, const DevFrame& f, const CameraGPU* cam, uint32_t sample_id,

@@ -21,6 +21,7 @@ struct DevScene {
     uint32_t lds_nodes, lds_tris;   // how many nodes / triangles each workgroup stages in LDS
     uint32_t stack_depth;           // per-lane traversal stack entries (LDS)
     uint32_t stack_private;         // queue kernels: 0 = stack in the LDS column, 1 = private (scratch) array
+    uint32_t sort_materials;        // 1 = material-sorted shading in k_shade (general path; tuning knob, default 0)
     uint32_t refill_min, trace_sched;   // persistent traversal: idle lanes that trigger a refill; wave schedule (rtx_kernels.hip)
 };
 
@@ -50,8 +51,6 @@ struct DevPaths {
     F4* sh_c;    // contribution.xyz, pid bits
 };
 
-extern int g_sort_materials;   // 1 = material-sorted shading in k_shade (general path)
-extern int g_bounce_variant;   // tuning knob: waves/SIMD the fused kernel is compiled for (4, 5 or 6)
 size_t trace_lds_bytes(const DevScene& sc);
 void launch_raygen(hipStream_t, const DevFrame&, const DevPaths&, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount);
 void launch_trace_closest(hipStream_t, const DevFrame&, const DevScene&, const DevPaths&, uint32_t bounce, const uint32_t* queue, const uint32_t* qcount);

@@ -583,8 +583,10 @@ def test_c4_sizes_4k_shards_and_stack_variants(rt, orc):
     base = dict(width=W, height=H, spp=1, max_bounces=3, nee_samples=1, flags=1)
     imgs = []
     # (stack, schedule): LDS column + speculative voted (default), private stack, while-while, voted, voted with other weights
-    for k, (stack, sched) in enumerate(((0, 6), (1, 6), (0, 0), (0, 2), (0, 5), (0, 7), (0, 3))):
-        c = rt.Context(0); c.set_option(rt.OPT_STACK_PRIVATE, stack); c.set_option(rt.OPT_TRACE_SCHED, sched); c.upload(sc, W / H)
+    # the last entry also turns on the material-sorted k_shade variant
+    for k, (stack, sched) in enumerate(((0, 6), (1, 6), (0, 0), (0, 2), (0, 5), (0, 7), (0, 3), (0, 6))):
+        c = rt.Context(0); c.set_option(rt.OPT_STACK_PRIVATE, stack); c.set_option(rt.OPT_TRACE_SCHED, sched)
+        c.set_option(rt.OPT_SORT_MATERIALS, 1 if k == 7 else 0); c.upload(sc, W / H)
         c.clear(W, H); c.render(rt.Params(**base)); imgs.append(c.read_accum())
         if k == 0:
             st = c.stats(); assert st.rays_primary == W * H
