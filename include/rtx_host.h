@@ -59,6 +59,9 @@ int  rtxh_bvh_refit_check(const float* before_tris9, const float* after_tris9, u
 /* the tiny-scene pre-test records rtx_commit_scene would build for this scene: per record 20 floats (plane xyz d,
    4 edge planes xyz c) and the global ids of its 1-2 triangles (-1 = none); for host-side conservativeness tests */
 int  rtxh_scene_small_records(const rtxh_scene*, float* recs20, int32_t* tri_ids2, uint32_t max_recs, uint32_t* nrec_out, float* delta_out, float* cm_out);
+/* of those records, [0, *nocc_out) can lie between two scene points; the rest are faces of the scene's convex hull, which NEE
+   shadow segments skip */
+int  rtxh_scene_small_occluders(const rtxh_scene*, uint32_t* nocc_out);
 
 /* the headless Renderer facade (Renderer.h:46-51) for FFI callers */
 typedef struct rtxh_renderer rtxh_renderer;

@@ -146,6 +146,7 @@ _sig("rtxh_bvh_check", C.c_int, _vp, _u32, _u32p, _u32p, _u32p)
 _sig("rtxh_bvh_refit_check", C.c_int, _vp, _vp, _u32)
 _sig("rtxh_bvh8_check", C.c_int, _vp, _u32, _u32p, _u32p)
 _sig("rtxh_bvh8_stats", C.c_int, _vp, _u32, _vp, _u32p)
+_sig("rtxh_scene_small_occluders", C.c_int, _vp, _u32p)
 _sig("rtxh_write_png", C.c_int, C.c_char_p, _vp, _u32, _u32)
 _sig("rtxh_write_ppm", C.c_int, C.c_char_p, _vp, _u32, _u32)
 _sig("rtxh_write_exr", C.c_int, C.c_char_p, _vp, _u32, _u32)
@@ -237,6 +238,13 @@ class Scene:
         if lib.rtxh_scene_small_records(self._h, _ptr(recs), _ptr(ids), 64, C.byref(n), C.byref(d), C.byref(cm)) != RTX_OK or n.value == 0:
             return None
         return recs[:n.value], ids[:n.value], d.value, cm.value
+
+    def small_occluders(self):
+        """number of leading tiny-scene records that are NOT faces of the scene's convex hull"""
+        n = _u32()
+        if lib.rtxh_scene_small_occluders(self._h, C.byref(n)) != RTX_OK:
+            raise RtxError("rtxh_scene_small_occluders failed")
+        return n.value
 
     def view_proj(self, aspect):
         v, p = np.zeros(16, np.float32), np.zeros(16, np.float32)

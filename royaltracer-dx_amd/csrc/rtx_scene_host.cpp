@@ -312,7 +312,7 @@ bool SceneHost::build(BuiltScene& B) {
         }
         // Faces of the scene's convex hull last: a record whose plane has ALL scene vertices on one side (within tol) cannot lie
         // strictly between two points of the scene, so NEE shadow segments (surface point + bias -> light point, shortened at both
-        // ends) only need the records before them.  In a closed room that is every wall: Cornell keeps 12 of its 17 records.
+        // ends) only need the records before them.  In a closed room that is every wall: Cornell keeps 11 of its 17 records.
         {
             std::vector<Rec> occ, hull;
             for (const Rec& R : recs) {

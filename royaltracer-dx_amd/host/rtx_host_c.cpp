@@ -172,6 +172,22 @@ int rtxh_bvh_refit_check(const float* before, const float* after, uint32_t ntris
 }
 
 // the tiny-scene pre-test records as rtx_commit_scene builds them (for host-side conservativeness tests)
+static bool build_for_inspection(const rtxh_scene* sc, rtx::BuiltScene& B);
+// records [0, *nocc_out) can lie between two scene points; the rest are faces of the scene's convex hull (skipped by NEE segments)
+int rtxh_scene_small_occluders(const rtxh_scene* sc, uint32_t* nocc_out) {
+    rtx::BuiltScene B;
+    if (!sc || !nocc_out || !build_for_inspection(sc, B)) return RTX_ERR_INVALID;
+    *nocc_out = B.small_nocc;
+    return RTX_OK;
+}
+static bool build_for_inspection(const rtxh_scene* sc, rtx::BuiltScene& B) {
+    rtx::SceneHost H;
+    const Scene& s = sc->s;
+    if (!H.set_materials(s.materials.data(), (uint32_t)s.materials.size())) return false;
+    for (const SceneModel& m : s.models) { uint32_t id; if (!H.add_mesh(m.vertices.data(), (uint32_t)m.vertices.size(), m.indices.data(), (uint32_t)m.indices.size(), m.materialIDs.data(), &id)) return false; }
+    for (const SceneInstance& in : s.instances) { uint32_t id; if (!H.add_instance(in.model, in.transform.data(), &id)) return false; }
+    return H.build(B);
+}
 int rtxh_scene_small_records(const rtxh_scene* sc, float* recs20, int32_t* tri_ids2, uint32_t max_recs, uint32_t* nrec_out, float* delta_out, float* cm_out) {
     rtx::SceneHost H; rtx::BuiltScene B;
     const Scene& s = sc->s;

@@ -155,6 +155,51 @@ def test_render_parity_cornell(rt, cornell_pair, cfg):
     assert np.array_equal(ctx.read_srgb8(), orc_srgb(o, c))
 
 
+class XformedScene:
+    """a Scene with its instance transforms replaced (same duck type as rt.Scene for Context.upload / Oracle.load)"""
+    def __init__(self, base, mats):
+        self.materials, self.meshes, self._base = base.materials, base.meshes, base
+        self.instances = [(mesh, np.asarray(m, np.float32).reshape(16)) for (mesh, _), m in zip(base.instances, mats)]
+
+    def view_proj(self, aspect):
+        return self._base.view_proj(aspect)
+
+
+@pytest.mark.parametrize("variant", ["fused_small", "separate_small", "separate_bvh"])
+@pytest.mark.parametrize("kind", ["rotated_sheared", "mirrored"])
+def test_tiny_scene_paths_on_a_skewed_room(rt, orc, cornell, variant, kind):
+    """the tiny-scene machinery (planar-quad merging, conservative pre-test, convex-hull faces skipped by NEE segments) on a room
+    that is NOT axis-aligned: the Cornell instance under a rotation + shear + non-uniform scale, and under a mirroring transform
+    (flipped winding).  Closest / any-hit records against the oracle's brute force, images bit for bit."""
+    th, ph = 0.37, -0.21
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]]) @ np.array([[1, 0, 0], [0, np.cos(ph), -np.sin(ph)], [0, np.sin(ph), np.cos(ph)]])
+    S = np.array([[1.1, 0.15, 0.0], [0.0, 0.9, 0.1], [0.05, 0.0, 1.2]])
+    A = R @ S if kind == "rotated_sheared" else np.diag([-1.0, 1.0, 1.0])
+    M = np.eye(4); M[:3, :3] = A; M[:3, 3] = (0.5, 0.5, 0.5) - A @ np.array([0.5, 0.5, 0.5]) + (0.02, -0.01, 0.03)   # about the room's centre
+    sc = XformedScene(cornell, [M.T.reshape(16)])                      # column-major storage of a column-vector matrix
+    c = rt.Context(0)
+    c.set_option(rt.OPT_SMALL_SCENE, 0 if variant == "separate_bvh" else 1); c.set_option(rt.OPT_FUSED_BOUNCE, 1 if variant == "fused_small" else 0)
+    c.upload(sc, 16 / 9)
+    o = orc.Oracle().load(sc, 16 / 9)
+    p = rt.Params(width=112, height=63, spp=3, max_bounces=8, nee_samples=2, flags=1)
+    on = o.primary_rays(p); h0 = o.trace_closest(on, 0); hit0 = bits(h0)[:, 3] != 0xFFFFFFFF
+    sec = random_rays(int(hit0.sum()), 4); sec[:, 0:3] = on[hit0, 0:3] + h0[hit0, 0:1] * on[hit0, 4:7]; sec[:, 3] = 2e-5
+    rays = np.concatenate([on, random_rays(60000, 1, -0.3, 1.3), sec])
+    g, b = c.trace_closest(rays), o.trace_closest(rays, mode=0)
+    assert np.array_equal(bits(g)[:, 3], bits(b)[:, 3])
+    hit = bits(b)[:, 3] != 0xFFFFFFFF
+    assert np.array_equal(bits(g)[hit], bits(b)[hit]) and hit.mean() > 0.3
+    sh = random_rays(60000, 2, 0.0, 1.0, tmax=0.7)
+    assert np.array_equal(c.trace_any(sh), o.trace_any(sh, mode=0))
+    c.clear(p.width, p.height); c.render(p)
+    ga = c.read_accum(); ca, cnt = o.render(p)
+    st = c.stats()
+    assert (st.rays_primary, st.rays_extension, st.rays_shadow) == cnt and st.rays_shadow > 0
+    assert np.array_equal(bits(ga), bits(ca)), f"{int((bits(ga) != bits(ca)).any(-1).sum())} pixels differ"
+    assert ga[..., :3].mean() > 0.01
+    c.close()
+
+
 def orc_srgb(o, acc):
     import __graft_entry__ as graft
     return graft.load_oracle().srgb8(acc)

@@ -282,3 +282,18 @@ def test_png_ppm_exr_writers_round_trip(rt, tmp_path):
     assert len(b) == offs[-1] + 8 + W * 12
     with pytest.raises(rt.RtxError):
         rt.write_image(str(tmp_path / "no_such_dir" / "x.png"), img)
+
+
+def test_tiny_scene_hull_faces_come_last(rt, cornell):
+    """NEE shadow segments skip the records behind small_occluders(): those must be exactly the records whose plane has every
+    scene vertex on one side (faces of the convex hull: the five walls of the Cornell Box), checked here in float64"""
+    recs, ids, delta, cm = cornell.small_records()
+    nocc = cornell.small_occluders()
+    v, idx, _ = cornell.meshes[0]
+    P = v[:, :3].astype(np.float64)
+    side = recs[:, 0:3].astype(np.float64) @ P.T - recs[:, 3:4].astype(np.float64)          # (records, vertices): signed distance to the plane
+    both = ((side > 1e-6).any(1)) & ((side < -1e-6).any(1))
+    assert nocc == 11 and len(recs) == 17                 # 6 hull records: floor, ceiling, back, green wall, and the twisted red wall as 2 single triangles
+    assert both[:nocc].all() and not both[nocc:].any()
+    # the hull faces are the floor, ceiling, back, left and right walls: together they own 10 triangles
+    assert (ids[nocc:] >= 0).sum() == 10
