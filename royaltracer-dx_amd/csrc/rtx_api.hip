@@ -35,7 +35,7 @@ struct rtx_ctx {
     int num_cus = 256;
     SceneHost host; BuiltScene built;
     bool committed = false, camera_set = false;
-    DevBuf d_nodes, d_tris, d_small, d_small_tris, d_shade, d_mats, d_insts, d_lights, d_cam;
+    DevBuf d_nodes, d_tris, d_small, d_small_tris, d_small_poly, d_shade, d_mats, d_insts, d_lights, d_cam;
     DevBuf d_objtris, d_node_aabb, d_scale;          // GPU refit: object-space vertices (uploaded on first use), per-node float boxes, max |coordinate|
     bool gpu_refit = true, device_scene_valid = false, objtris_uploaded = false;
     uint32_t refill_min = 12, trace_sched = 6, sort_materials = 0;       // persistent-traversal knobs (RTX_OPT_REFILL_MIN, RTX_OPT_TRACE_SCHED)
@@ -101,7 +101,7 @@ void rtx_destroy(rtx_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
+    DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_small_poly, &c->d_objtris, &c->d_node_aabb, &c->d_scale, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
                      &c->d_thr, &c->d_rad, &c->d_hit, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
                      &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt};
     for (DevBuf* b : all) b->release();
@@ -192,6 +192,7 @@ int rtx_commit_scene(rtx_ctx* c) {
         if ((r = upload(c, c->d_shade, B.shade))) return r;
         if ((r = upload(c, c->d_small, B.small_recs))) return r;
         if ((r = upload(c, c->d_small_tris, B.small_tris))) return r;
+        if ((r = upload(c, c->d_small_poly, B.small_poly))) return r;
         if ((r = upload(c, c->d_mats, B.mats))) return r;
         if ((r = upload(c, c->d_insts, B.insts))) return r;
         if ((r = upload(c, c->d_lights, B.lights))) return r;
@@ -202,7 +203,7 @@ int rtx_commit_scene(rtx_ctx* c) {
     s.nodes = (const Node8GPU*)c->d_nodes.p; s.nnodes = (uint32_t)B.nodes8.size();
     s.tris = (const TriGPU*)c->d_tris.p; s.ntris = (uint32_t)B.tris8.size();
     s.shade = (const TriShade*)c->d_shade.p;
-    s.small = (const SmallRecPair*)c->d_small.p; s.small_tris = (const TriGPU*)c->d_small_tris.p; s.small_cm = B.small_cm; s.small_delta = B.small_delta;
+    s.small = (const SmallRecPair*)c->d_small.p; s.small_tris = (const TriGPU*)c->d_small_tris.p; s.small_poly = (const F4*)c->d_small_poly.p; s.small_cm = B.small_cm; s.small_delta = B.small_delta;
     s.mats = (const MatGPU*)c->d_mats.p; s.nmat = (uint32_t)B.mats.size();
     s.insts = (const InstGPU*)c->d_insts.p; s.ninst = (uint32_t)B.insts.size();
     s.lights = (const LightGPU*)c->d_lights.p; s.nlights = (uint32_t)B.lights.size();

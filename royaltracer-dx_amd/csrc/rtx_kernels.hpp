@@ -12,6 +12,7 @@ struct DevScene {
     const TriShade* shade;
     const SmallRecPair* small; uint32_t nsmall;   // nsmall != 0: tiny scene: nsmall pre-test records (planar polygons), no BVH
     uint32_t nsmall_occ;                          // records [0, nsmall_occ) can occlude a segment between two scene points; the rest are faces of the scene's convex hull
+    const F4* small_poly;                         // 4 polygon corners per record (packet culling of primary rays)
     const TriGPU* small_tris;                     // 2 triangles per record (staged in LDS instead of `tris`)
     float small_cm, small_delta;                  // t-margin coefficient, distance tolerance of the edge planes
     const MatGPU*   mats;   uint32_t nmat;

@@ -251,7 +251,7 @@ bool SceneHost::build(BuiltScene& B) {
     B.tris8.resize(B.tri_slots8.size());
     for (size_t i = 0; i < B.tri_slots8.size(); i++) B.tris8[i] = B.tris[B.tri_slots8[i]];
     // ---- tiny scenes: merge triangles into planar convex quads and build the conservative pre-test records ----
-    B.small_recs.clear(); B.small_tris.clear(); B.small_nrec = 0; B.small_nocc = 0;
+    B.small_recs.clear(); B.small_tris.clear(); B.small_poly.clear(); B.small_nrec = 0; B.small_nocc = 0;
     if (!leaf_order.empty() && leaf_order.size() <= kSmallSceneMaxTris) {
         const double delta = 2e-5 * (double)scale, tol = 1e-6 * (double)scale;
         B.small_delta = (float)delta; B.small_cm = 4e-6f * scale;
@@ -264,10 +264,11 @@ bool SceneHost::build(BuiltScene& B) {
         std::vector<std::array<D3, 3>> V(n);
         for (size_t s = 0; s < n; s++) { const float* t = &wtri[(size_t)leaf_order[s] * 9]; for (int k = 0; k < 3; k++) V[s][k] = D3{t[k * 3], t[k * 3 + 1], t[k * 3 + 2]}; }
         auto same = [](D3 a, D3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; };
-        struct Rec { double pl[4]; double e[4][4]; int s0, s1; };
+        struct Rec { double pl[4]; double e[4][4]; int s0, s1; double pv[4][3]; };     // pv: polygon vertices (a triangle repeats its last one)
         std::vector<Rec> recs; std::vector<uint8_t> used(n, 0);
         auto make_rec = [&](const std::vector<D3>& poly, D3 nu, int s0, int s1) {
             Rec R; R.s0 = s0; R.s1 = s1;
+            for (int k = 0; k < 4; k++) { const D3& q = poly[std::min<size_t>((size_t)k, poly.size() - 1)]; R.pv[k][0] = q.x; R.pv[k][1] = q.y; R.pv[k][2] = q.z; }
             R.pl[0] = nu.x; R.pl[1] = nu.y; R.pl[2] = nu.z; R.pl[3] = dt(nu, poly[0]);
             for (int k = 0; k < 4; k++) { R.e[k][0] = R.e[k][1] = R.e[k][2] = 0.0; R.e[k][3] = 1e30; }     // always inside
             for (size_t k = 0; k < poly.size(); k++) {
@@ -283,7 +284,7 @@ bool SceneHost::build(BuiltScene& B) {
             D3 ni = crs(sub(V[i][1], V[i][0]), sub(V[i][2], V[i][0]));
             const double nn = sqrt(dt(ni, ni));
             if (!(nn > 0.0)) {                                       // zero-area triangle: the exact test always rejects it
-                Rec R; R.s0 = (int)i; R.s1 = -1; for (int k = 0; k < 4; k++) { R.pl[k] = 0; R.e[k][0] = R.e[k][1] = R.e[k][2] = 0; R.e[k][3] = -1e30; }
+                Rec R; R.s0 = (int)i; R.s1 = -1; for (int k = 0; k < 4; k++) { R.pl[k] = 0; R.e[k][0] = R.e[k][1] = R.e[k][2] = 0; R.e[k][3] = -1e30; R.pv[k][0] = V[i][0].x; R.pv[k][1] = V[i][0].y; R.pv[k][2] = V[i][0].z; }
                 recs.push_back(R); continue;
             }
             D3 nu = nrm(ni);
@@ -331,6 +332,9 @@ bool SceneHost::build(BuiltScene& B) {
         B.small_tris.assign(((recs.size() + 1) & ~(size_t)1) * 2, TriGPU{{0, 0, 0, u2f(kMissPrim)}, {0, 0, 0, 0}, {0, 0, 0, 0}});   // the padding record of an odd count owns two zero-area triangles
         const TriGPU none{{0, 0, 0, u2f(kMissPrim)}, {0, 0, 0, 0}, {0, 0, 0, 0}};
         for (size_t r = 0; r < recs.size(); r++) { B.small_tris[2 * r] = B.tris[recs[r].s0]; B.small_tris[2 * r + 1] = recs[r].s1 >= 0 ? B.tris[recs[r].s1] : none; }
+        // polygon corners per record: the primary-ray kernel culls records against the pyramid of each 8x8 pixel block
+        B.small_poly.assign(((recs.size() + 1) & ~(size_t)1) * 4, F4{0.0f, 0.0f, 0.0f, 0.0f});
+        for (size_t r = 0; r < recs.size(); r++) for (int k = 0; k < 4; k++) B.small_poly[r * 4 + k] = {(float)recs[r].pv[k][0], (float)recs[r].pv[k][1], (float)recs[r].pv[k][2], 0.0f};
         for (size_t r = 0; r < recs.size(); r += 2) {
             SmallRecPair P;
             for (int e = 0; e < 2; e++) {
