@@ -1,0 +1,468 @@
+// rtx_traverse.hpp — ray traversal on the device: LDS staging, the exact triangle test, the compressed 8-wide BVH (node step, simple and
+// persistent-wave traversal with the while-while / voted / speculative schedules), the tiny-scene pre-test path, packet culling
+#pragma once
+#include "rtx_dev_common.hpp"
+
+namespace rtx {
+
+// ---------------------------------------------------------------------------------------------
+// BVH traversal
+// ---------------------------------------------------------------------------------------------
+// LDS pointers carry their address space in the type: through a generic pointer hipcc emits flat_load /
+// flat_store for the staged nodes and the traversal stack instead of ds_read_b128 / ds_write_b32 (found with
+// SQ_INSTS_LDS vs SQ_INSTS_VMEM_RD in profiles/r01_pmc_v2.md).
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4f lds_v4f;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v fma2(f2v a, f2v b, f2v c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2v splat2(float x) { f2v r = {x, x}; return r; }
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v2u lds_u2;
+struct TraceLds {
+    const lds_v4f* nodes;   // LDS copy of nodes [0, lds_nodes)
+    const lds_v4f* tris;    // LDS copy of tris  [0, lds_tris)
+    lds_u2* stack;          // [depth][kBlock] sibling-group entries
+};
+
+// stage the top of the BVH and the first triangles into LDS (coalesced 16-B copies)
+__device__ __forceinline__ TraceLds stage_lds(const DevScene& sc, F4* lds_generic) {
+    TraceLds L;
+    lds_v4f* ln = (lds_v4f*)lds_generic; lds_v4f* lt = ln + (size_t)sc.lds_nodes * 5;
+    const v4f* gn = (const v4f*)sc.nodes; const v4f* gt = (const v4f*)(sc.nsmall ? sc.small_tris : sc.tris);
+    for (uint32_t i = threadIdx.x; i < sc.lds_nodes * 5u; i += kBlock) ln[i] = gn[i];
+    for (uint32_t i = threadIdx.x; i < sc.lds_tris * 3u; i += kBlock) lt[i] = gt[i];
+    L.nodes = ln; L.tris = lt;
+    L.stack = (lds_u2*)(lt + (size_t)sc.lds_tris * 3);
+    return L;
+}
+
+// Moeller-Trumbore with the fixed operation order shared with the oracle (a11).  Exclusive (tmin, tmax).
+// (A variant that checks the numerators conservatively before the IEEE division measured no faster: 32.4 vs 31.6 ms.)
+__device__ __forceinline__ bool tri_test(f3 o, f3 d, v4f v0w, v4f e1w, v4f e2w, float tmin, float tmax, float& t, float& u, float& v) {
+    const f3 v0 = mk3(v0w.x, v0w.y, v0w.z), e1 = mk3(e1w.x, e1w.y, e1w.z), e2 = mk3(e2w.x, e2w.y, e2w.z);
+    const f3 p = cross(d, e2);
+    const float det = dot(e1, p);
+    if (det == 0.0f) return false;
+    const float inv = 1.0f / det;
+    const f3 s = o - v0;
+    u = dot(s, p) * inv;
+    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    const f3 q = cross(s, e1);
+    v = dot(d, q) * inv;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
+    t = dot(e2, q) * inv;
+    return t > tmin && t < tmax;
+}
+
+// ---- compressed 8-wide node step ---------------------------------------------------------------------------------
+// One traversal step fetches a Node8GPU (five 16-B loads, or five ds_read_b128 for the staged top of the tree) and tests its
+// eight child boxes.  Planes are byte offsets on the node's power-of-two grid, so
+//     t_plane = q * (2^e * idir) + (p - o) * idir        (cvt + fma per plane; near / far rows picked by the ray's octant)
+// CONSERVATIVENESS (the closest hit must stay the minimum over ALL triangles): the builder rounds the boxes outward in exact
+// arithmetic; 2^e * idir is exact; a = fl(fl(p - o) * idir) carries a relative error <= 2^-23, so the near planes use
+// a - |a| 2^-22 and the far planes a + |a| 2^-22; what is left is relative to t and covered by kSlabLo / kSlabHi.
+// Hit children are visited in increasing (slot ^ octant) order; the rest of a node's hit children stay together in
+// ONE stack entry (base index + hit bits + internal mask), so the stack holds one entry per level.
+struct Node8R { v4f h0; v4u h1, q0, q1, q2; };
+struct Grp { uint32_t base, bits; };                 // node group: child_base, ordered internal hits (bits 0-7) | imask << 8
+struct TriGrp { uint32_t base, bits, valid; };        // triangle group: tri_base, hit triangle bits, the node's trivalid
+constexpr float kPlaneEps = 2.384185791015625e-07f;   // 2^-22
+// relative widening of the slab interval.  It must cover the error of the TRIANGLE test's t, not only the slab arithmetic: a
+// hit next to a vertex of a small triangle seen from far away has a Moeller-Trumbore t that is off by ~1e-5 relative (found by
+// test_wide_bvh_equals_brute_force_on_hostile_soups: coincident duplicates lost their lowest-id tie at 2e-6), so 5e-5.
+constexpr float kSlabLo = 0.99995f, kSlabHi = 1.00005f;
+
+__device__ __forceinline__ Node8R load_node8(const DevScene& sc, const TraceLds& L, uint32_t idx) {
+    Node8R N;
+    if (idx < sc.lds_nodes) { const lds_v4f* n = L.nodes + idx * 5u; N.h0 = n[0]; N.h1 = (v4u)n[1]; N.q0 = (v4u)n[2]; N.q1 = (v4u)n[3]; N.q2 = (v4u)n[4]; }
+    else { const v4f* n = (const v4f*)sc.nodes + (size_t)idx * 5u; N.h0 = n[0]; N.h1 = (v4u)n[1]; N.q0 = (v4u)n[2]; N.q1 = (v4u)n[3]; N.q2 = (v4u)n[4]; }
+    return N;
+}
+__device__ __forceinline__ uint32_t ray_octant(f3 idir) { return (idir.x < 0.0f ? 1u : 0u) | (idir.y < 0.0f ? 2u : 0u) | (idir.z < 0.0f ? 4u : 0u); }
+__device__ __forceinline__ float byte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyteK
+
+// tests the 8 children; G = this node's internal hits in octant order, T = the triangles of its hit leaf children
+__device__ __forceinline__ void node8_hits(const Node8R& N, f3 o, f3 idir, uint32_t oct, float tmin, float tbest, Grp& G, TriGrp& T) {
+    const uint32_t w = f2u(N.h0.w);
+    const float sx = u2f((w & 0xffu) << 23) * idir.x, sy = u2f((w & 0xff00u) << 15) * idir.y, sz = u2f((w & 0xff0000u) << 7) * idir.z;
+    const float ax = (N.h0.x - o.x) * idir.x, ay = (N.h0.y - o.y) * idir.y, az = (N.h0.z - o.z) * idir.z;
+    const float anx = __builtin_fmaf(-fabsf(ax), kPlaneEps, ax), afx = __builtin_fmaf(fabsf(ax), kPlaneEps, ax);
+    const float any_ = __builtin_fmaf(-fabsf(ay), kPlaneEps, ay), afy = __builtin_fmaf(fabsf(ay), kPlaneEps, ay);
+    const float anz = __builtin_fmaf(-fabsf(az), kPlaneEps, az), afz = __builtin_fmaf(fabsf(az), kPlaneEps, az);
+    const bool nx = (oct & 1u) != 0u, ny = (oct & 2u) != 0u, nz = (oct & 4u) != 0u;
+    // rows: q0 = (lox0, lox1, loy0, loy1)  q1 = (loz0, loz1, hix0, hix1)  q2 = (hiy0, hiy1, hiz0, hiz1)
+    const uint32_t qnx[2] = {nx ? N.q1.z : N.q0.x, nx ? N.q1.w : N.q0.y}, qfx[2] = {nx ? N.q0.x : N.q1.z, nx ? N.q0.y : N.q1.w};
+    const uint32_t qny[2] = {ny ? N.q2.x : N.q0.z, ny ? N.q2.y : N.q0.w}, qfy[2] = {ny ? N.q0.z : N.q2.x, ny ? N.q0.w : N.q2.y};
+    const uint32_t qnz[2] = {nz ? N.q2.z : N.q1.x, nz ? N.q2.w : N.q1.y}, qfz[2] = {nz ? N.q1.x : N.q2.z, nz ? N.q1.y : N.q2.w};
+    uint32_t hits = 0;
+    const f2v vsx = splat2(sx), vsy = splat2(sy), vsz = splat2(sz);
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {                     // two children per iteration on packed FP32 (v_pk_fma_f32 / v_pk_mul_f32)
+        const int h = k >> 2, b = k & 3;
+        const f2v bnx = {byte_f(qnx[h], b), byte_f(qnx[h], b + 1)}, bny = {byte_f(qny[h], b), byte_f(qny[h], b + 1)}, bnz = {byte_f(qnz[h], b), byte_f(qnz[h], b + 1)};
+        const f2v bfx = {byte_f(qfx[h], b), byte_f(qfx[h], b + 1)}, bfy = {byte_f(qfy[h], b), byte_f(qfy[h], b + 1)}, bfz = {byte_f(qfz[h], b), byte_f(qfz[h], b + 1)};
+        const f2v tnx = fma2(bnx, vsx, splat2(anx)), tny = fma2(bny, vsy, splat2(any_)), tnz = fma2(bnz, vsz, splat2(anz));
+        const f2v tfx = fma2(bfx, vsx, splat2(afx)), tfy = fma2(bfy, vsy, splat2(afy)), tfz = fma2(bfz, vsz, splat2(afz));
+        const f2v lo = {fmaxf(fmaxf(tnx.x, tny.x), fmaxf(tnz.x, tmin)), fmaxf(fmaxf(tnx.y, tny.y), fmaxf(tnz.y, tmin))};
+        const f2v hi = {fminf(fminf(tfx.x, tfy.x), fminf(tfz.x, tbest)), fminf(fminf(tfx.y, tfy.y), fminf(tfz.y, tbest))};
+        const f2v los = lo * kSlabLo, his = hi * kSlabHi;                 // lo >= tmin >= 0
+        if (los.x <= his.x) hits |= 1u << k;
+        if (los.y <= his.y) hits |= 2u << k;
+    }
+    const uint32_t imask = w >> 24;
+    // internal hits, permuted so that bit j = slot (j ^ oct): lowest set bit = first child to visit
+    uint32_t m = hits & imask;
+    if (nx) m = ((m & 0x55u) << 1) | ((m >> 1) & 0x55u);
+    if (ny) m = ((m & 0x33u) << 2) | ((m >> 2) & 0x33u);
+    if (nz) m = ((m & 0x0fu) << 4) | ((m >> 4) & 0x0fu);
+    G.base = N.h1.x; G.bits = m | (imask << 8);
+    // leaf hits: spread each bit to its nibble and keep the triangles that exist
+    uint32_t x = hits & ~imask;
+    x = (x | (x << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    T.base = N.h1.y; T.valid = N.h1.z; T.bits = (x * 15u) & N.h1.z;
+}
+
+// traversal stack of sibling groups: per-lane column in LDS (conflict-free 8-byte accesses), or a private array (scratch)
+struct StackLds { lds_u2* col; __device__ __forceinline__ void put(int i, Grp g) { v2u v = {g.base, g.bits}; col[i * kBlock] = v; }
+                  __device__ __forceinline__ Grp get(int i) const { const v2u v = col[i * kBlock]; return Grp{v.x, v.y}; } };
+constexpr int kPrivStack = 32;
+struct StackPriv { Grp a[kPrivStack]; __device__ __forceinline__ void put(int i, Grp g) { a[i] = g; } __device__ __forceinline__ Grp get(int i) const { return a[i]; } };
+
+// pick the first child of group G (which has internal hits), keep the remaining siblings on the stack, test the child's
+// eight children: G / T become the child's groups
+template <class STK>
+__device__ __forceinline__ void descend8(const DevScene& sc, const TraceLds& L, f3 o, f3 idir, uint32_t oct, float tmin, float tbest,
+                                         Grp& G, TriGrp& T, STK& stk, int& sp) {
+    const uint32_t k = (uint32_t)__builtin_ctz(G.bits);
+    const uint32_t rest = G.bits & (G.bits - 1u);
+    if (rest & 0xffu) { stk.put(sp, Grp{G.base, rest}); sp++; }
+    const uint32_t slot = k ^ oct;
+    const uint32_t idx = G.base + (uint32_t)__builtin_popcount((G.bits >> 8) & ((1u << slot) - 1u));
+    const Node8R N = load_node8(sc, L, idx);
+    node8_hits(N, o, idir, oct, tmin, tbest, G, T);
+}
+// index of the triangle behind bit `bit` of a triangle group
+__device__ __forceinline__ uint32_t tri_slot8(const TriGrp& T, uint32_t bit) { return T.base + (uint32_t)__builtin_popcount(T.valid & ((1u << bit) - 1u)); }
+
+template <bool ANY>
+__device__ __forceinline__ void traverse(const DevScene& sc, const TraceLds& L, f3 o, f3 d, float tmin, float tmax,
+                                         float& bt, float& bu, float& bv, uint32_t& bprim) {
+    // zero direction components -> huge finite reciprocal (keeps the slab test NaN-free and conservative)
+    const float dxs = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
+    const float dys = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
+    const float dzs = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
+    const f3 idir = mk3(__builtin_amdgcn_rcpf(dxs), __builtin_amdgcn_rcpf(dys), __builtin_amdgcn_rcpf(dzs));
+    const uint32_t oct = ray_octant(idir);
+    bt = tmax; bu = 0.0f; bv = 0.0f; bprim = kMissPrim;
+    StackLds stk; stk.col = L.stack + threadIdx.x;
+    int sp = 0;
+    Grp G{0u, (1u << oct) | (1u << 8)};                 // the root as slot 0 of a virtual parent
+    TriGrp T{0u, 0u, 0u};
+    while (true) {
+        if (G.bits & 0xffu) descend8(sc, L, o, idir, oct, tmin, bt, G, T, stk, sp);
+        while (T.bits) {
+            const uint32_t bit = (uint32_t)__builtin_ctz(T.bits);
+            T.bits &= T.bits - 1u;
+            const uint32_t slot = tri_slot8(T, bit);
+            v4f v0, e1, e2;
+            if (slot < sc.lds_tris) { const lds_v4f* t = L.tris + slot * 3u; v0 = t[0]; e1 = t[1]; e2 = t[2]; }
+            else { const v4f* t = (const v4f*)(sc.tris + slot); v0 = t[0]; e1 = t[1]; e2 = t[2]; }
+            float t, u, w;
+            if (tri_test(o, d, v0, e1, e2, tmin, tmax, t, u, w)) {
+                if (ANY) { bprim = 0u; return; }
+                const uint32_t gid = f2u(v0.w);
+                if (t < bt || (t == bt && gid < bprim)) { bt = t; bu = u; bv = w; bprim = gid; }
+            }
+        }
+        if (!(G.bits & 0xffu)) {
+            if (sp == 0) break;
+            sp--; G = stk.get(sp);
+        }
+    }
+}
+
+// closest-hit traversal that also counts node steps and triangle tests (rtx_debug_trace_stats: tree-quality measurements)
+__device__ __forceinline__ void traverse_stats(const DevScene& sc, const TraceLds& L, f3 o, f3 d, float tmin, float tmax,
+                                         float& bt, float& bu, float& bv, uint32_t& bprim) {
+    constexpr bool ANY = false;
+    uint32_t nsteps = 0, ntris = 0;
+    // zero direction components -> huge finite reciprocal (keeps the slab test NaN-free and conservative)
+    const float dxs = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
+    const float dys = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
+    const float dzs = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
+    const f3 idir = mk3(__builtin_amdgcn_rcpf(dxs), __builtin_amdgcn_rcpf(dys), __builtin_amdgcn_rcpf(dzs));
+    const uint32_t oct = ray_octant(idir);
+    bt = tmax; bu = 0.0f; bv = 0.0f; bprim = kMissPrim;
+    StackLds stk; stk.col = L.stack + threadIdx.x;
+    int sp = 0;
+    Grp G{0u, (1u << oct) | (1u << 8)};                 // the root as slot 0 of a virtual parent
+    TriGrp T{0u, 0u, 0u};
+    while (true) {
+        if (G.bits & 0xffu) { descend8(sc, L, o, idir, oct, tmin, bt, G, T, stk, sp); nsteps++; }
+        while (T.bits) {
+            const uint32_t bit = (uint32_t)__builtin_ctz(T.bits);
+            T.bits &= T.bits - 1u; ntris++;
+            const uint32_t slot = tri_slot8(T, bit);
+            v4f v0, e1, e2;
+            if (slot < sc.lds_tris) { const lds_v4f* t = L.tris + slot * 3u; v0 = t[0]; e1 = t[1]; e2 = t[2]; }
+            else { const v4f* t = (const v4f*)(sc.tris + slot); v0 = t[0]; e1 = t[1]; e2 = t[2]; }
+            float t, u, w;
+            if (tri_test(o, d, v0, e1, e2, tmin, tmax, t, u, w)) {
+                if (ANY) { bprim = 0u; return; }
+                const uint32_t gid = f2u(v0.w);
+                if (t < bt || (t == bt && gid < bprim)) { bt = t; bu = u; bv = w; bprim = gid; }
+            }
+        }
+        if (!(G.bits & 0xffu)) {
+            if (sp == 0) break;
+            sp--; G = stk.get(sp);
+        }
+    }
+    bu = (float)nsteps; bv = (float)ntris;
+}
+
+// Tiny-scene path (sc.nsmall != 0, all triangles staged in LDS): no BVH.  Phase 1 runs a CONSERVATIVE plane-form
+// pre-test of every triangle in a wave-uniform loop — two triangles per iteration on packed-FP32 instructions,
+// their coefficients wave-uniform (one s_load_dwordx16 pair per iteration, no LDS/VMEM traffic, no divergence) —
+// and collects a per-lane candidate bit mask.  Phase 2 runs the exact Moeller-Trumbore test on the few
+// candidates of each lane.  The result is the same minimum-over-all-triangles as the BVH path and the oracle's
+// brute force: phase 1 only removes triangles that the exact test would reject (tolerances: the edge-plane distance
+// delta and the t margin, built in rtx_scene_host.cpp).
+
+template <bool ANY>
+__device__ __forceinline__ void traverse_small(const DevScene& sc, const SmallRecPair* __restrict__ sp, const TraceLds& L, f3 o, f3 d, float tmin, float tmax,
+                                               float& bt, float& bu, float& bv, uint32_t& bprim, uint32_t nrec, unsigned long long keep = ~0ull) {
+    // keep (wave-uniform): bit r clear = no ray of this wave can touch record r (primary-ray packet culling); nrec = sc.nsmall, or sc.nsmall_occ for NEE shadow segments (both end points inside the scene's convex hull: the records
+    // after the first nsmall_occ are faces OF that hull and cannot lie between them, rtx_scene_host.cpp)
+    bt = tmax; bu = 0.0f; bv = 0.0f; bprim = kMissPrim;
+    uint32_t cand_lo = 0u, cand_hi = 0u;
+    const uint32_t npairs = (nrec + 1u) >> 1;
+    const f2v dx = splat2(d.x), dy = splat2(d.y), dz = splat2(d.z), ox = splat2(o.x), oy = splat2(o.y), oz = splat2(o.z);
+    const f2v cm = splat2(sc.small_cm), c5 = splat2(1e-5f), vtmin = splat2(tmin), vtmax = splat2(tmax), dl = splat2(sc.small_delta);
+#pragma unroll 2
+    for (uint32_t kp = 0; kp < npairs; kp++) {          // wave-uniform
+        if (!((keep >> (2u * kp)) & 3ull)) continue;
+        const f2v* __restrict__ R = (const f2v*)sp[kp].r;
+        const f2v nd = fma2(R[2], dz, fma2(R[1], dy, R[0] * dx));
+        const f2v no = R[3] - fma2(R[2], oz, fma2(R[1], oy, R[0] * ox));
+        f2v ind; ind.x = __builtin_amdgcn_rcpf(nd.x); ind.y = __builtin_amdgcn_rcpf(nd.y);
+        const f2v t = no * ind;
+        const f2v px = fma2(t, dx, ox), py = fma2(t, dy, oy), pz = fma2(t, dz, oz);
+        const f2v e0 = fma2(R[6], pz, fma2(R[5], py, fma2(R[4], px, R[7])));
+        const f2v e1 = fma2(R[10], pz, fma2(R[9], py, fma2(R[8], px, R[11])));
+        const f2v e2 = fma2(R[14], pz, fma2(R[13], py, fma2(R[12], px, R[15])));
+        const f2v e3 = fma2(R[18], pz, fma2(R[17], py, fma2(R[16], px, R[19])));
+        const f2v mt = fma2(cm, __builtin_elementwise_abs(ind), c5 * __builtin_elementwise_abs(t));
+        // all slack values must be >= 0: t in [tmin - mt, tmax + mt] and P within delta of the inside of every edge
+        const f2v a0 = (t + mt) - vtmin, a1 = (vtmax + mt) - t, b0 = e0 + dl, b1 = e1 + dl, b2 = e2 + dl, b3 = e3 + dl;
+        const float m0 = fminf(fminf(fminf(a0.x, a1.x), fminf(b0.x, b1.x)), fminf(b2.x, b3.x));
+        const float m1 = fminf(fminf(fminf(a0.y, a1.y), fminf(b0.y, b1.y)), fminf(b2.y, b3.y));
+        const bool c0 = (m0 >= 0.0f) || (fabsf(nd.x) < 1e-3f);      // grazing rays always go to the exact test
+        const bool c1 = (m1 >= 0.0f) || (fabsf(nd.y) < 1e-3f);
+        const uint32_t bit = 1u << ((2u * kp) & 31u);
+        const uint32_t add = (c0 ? bit : 0u) | (c1 ? (bit << 1) : 0u);
+        if (kp < 16u) cand_lo |= add; else cand_hi |= add;
+    }
+    unsigned long long cand = ((unsigned long long)cand_hi << 32) | cand_lo;
+    while (cand) {                                     // per-lane: exact test of the triangles of each candidate record
+        const uint32_t k = (uint32_t)__builtin_ctzll(cand);
+        cand &= cand - 1ull;
+#pragma unroll
+        for (uint32_t h = 0; h < 2u; h++) {
+            const lds_v4f* tp = L.tris + (2u * k + h) * 3u;
+            const v4f v0 = tp[0], e1 = tp[1], e2 = tp[2];
+            float t, u, w;
+            if (tri_test(o, d, v0, e1, e2, tmin, tmax, t, u, w)) {
+                if (ANY) { bprim = 0u; return; }
+                const uint32_t gid = f2u(v0.w);
+                if (t < bt || (t == bt && gid < bprim)) { bt = t; bu = u; bv = w; bprim = gid; }
+            }
+        }
+    }
+}
+
+template <bool ANY>
+__device__ __forceinline__ void trace_ray(const DevScene& sc, const SmallRecPair* __restrict__ small, const TraceLds& L, f3 o, f3 d, float tmin, float tmax,
+                                          float& bt, float& bu, float& bv, uint32_t& bprim) {
+    if (sc.nsmall) traverse_small<ANY>(sc, small, L, o, d, tmin, tmax, bt, bu, bv, bprim, sc.nsmall);
+    else traverse<ANY>(sc, L, o, d, tmin, tmax, bt, bu, bv, bprim);
+}
+
+// Tiny-scene bounce 0: generate the primary ray AND trace it; only paths that hit something are enqueued (their
+// hit record goes to p.hit), so the bounce-0 shading kernel runs without the idle lanes of the camera rays that
+// leave the scene (43 % of them on the Cornell view).  Missed paths only get their radiance slot zeroed.
+// Packet culling for camera rays.  A wave's 64 primary rays share the origin and cover one 8x8 pixel block, so they lie inside
+// the pyramid spanned by the block's four corner directions.  Lane r tests record r's polygon against the four side planes of
+// that pyramid (widened by 1e-4 of |corner - origin| in L1 norm, ~a tenth of a pixel): a polygon with all corners outside one
+// plane cannot be touched by any ray of the wave, and the wave skips its pre-test.  Conservative: only records that the exact
+// test would reject for every ray of the block are dropped (Cornell at 1080p: ~3 of 17 records survive per block).
+__device__ __forceinline__ unsigned long long packet_keep_mask(const DevScene& sc, const CameraGPU& cam, const DevFrame& f, uint32_t x0, uint32_t y0) {
+    f3 o, c[4];
+    for (int k = 0; k < 4; k++) {                                      // un-normalised corner directions (x0 + 8 (k & 1), y0 + 8 (k >> 1))
+        const float dx = ((float)(x0 + 8u * (uint32_t)(k & 1)) / (float)f.width) * 2.0f - 1.0f;
+        const float ndy = -(((float)(y0 + 8u * (uint32_t)(k >> 1)) / (float)f.height) * 2.0f - 1.0f);
+        const float* P = cam.projI;
+        const f3 tg = mk3(P[0] * dx + P[4] * ndy + P[8] + P[12], P[1] * dx + P[5] * ndy + P[9] + P[13], P[2] * dx + P[6] * ndy + P[10] + P[14]);
+        c[k] = xform_dir(cam.viewI, tg);
+    }
+    o = mk3(cam.viewI[12], cam.viewI[13], cam.viewI[14]);
+    const f3 mid = c[0] + c[3];                                        // inside direction (diagonal sum)
+    const f3 n[4] = {cross(c[0], c[1]), cross(c[1], c[3]), cross(c[3], c[2]), cross(c[2], c[0])};
+    const uint32_t r = lane_id();
+    bool culled = false;
+    if (r < sc.nsmall) {
+        f3 v[4];
+        for (int k = 0; k < 4; k++) { const F4 q = sc.small_poly[(size_t)r * 4 + k]; v[k] = mk3(q.x, q.y, q.z) - o; }
+        for (int i = 0; i < 4; i++) {
+            const float s = dot(n[i], mid) >= 0.0f ? 1.0f : -1.0f;     // orientation: the pyramid's inside has s * dot(n, .) >= 0
+            const float nl1 = fabsf(n[i].x) + fabsf(n[i].y) + fabsf(n[i].z);
+            bool all_out = true;
+            for (int k = 0; k < 4; k++) {
+                const float e = 1e-4f * nl1 * (fabsf(v[k].x) + fabsf(v[k].y) + fabsf(v[k].z));
+                all_out = all_out && (s * dot(n[i], v[k]) < -e);
+            }
+            culled = culled || all_out;
+        }
+    }
+    return __ballot(r < sc.nsmall && !culled) | (sc.nsmall & 1u ? (1ull << sc.nsmall) : 0ull);   // (the padding record of an odd count is never inside anyway)
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Persistent-wave BVH traversal with dynamic ray fetch (general scenes).  Lane utilisation of the plain
+// one-ray-per-lane loop on a 262 k-triangle scene was 8/64 (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU,
+// profiles/r01_pmc_sponza.md): traversal lengths have a heavy tail and internal / leaf phases diverge.  Here a
+// wave keeps its lanes busy: finished lanes are re-filled from the workgroup's sub-queue with a wave ballot +
+// mbcnt prefix sum and ONE LDS atomic per refill, and every outer iteration runs "all lanes walk internal nodes
+// until each holds a leaf (or is done)" followed by "all lanes with a leaf test its triangles" (while-while).
+// Exit: a wave leaves when the sub-queue is exhausted and no lane holds a ray — every wave reaches that.
+// ---------------------------------------------------------------------------------------------
+// Tuning knobs of the persistent traversal (per context: DevScene::refill_min, DevScene::trace_sched).
+//   refill_min : refill when at least this many lanes are idle (default 12)
+//   trace_sched: 0 = while-while; 1-4 = voted node / triangle steps (vote weights); 5-7 = voted + speculative (lanes with pending
+//                triangles keep walking nodes; default 6).  C3 / C5 ms per frame on the 8-wide tree: while-while 67.7 / 56.2,
+//                voted (2) 55.6 / 45.3, speculative (6) 53.1 / 44.5; lanes per VALU instruction 24.5 -> 40.8 -> 43.8
+//                (profiles/r01_pmc_bvh.md).  With the 128-B 4-wide nodes the voted schedule was slower: the traversal was
+//                texture-addresser bound then, not VALU bound.
+
+struct RayLane {                                       // per-lane traversal state
+    f3 o, d, idir; float tmin, tmax, bt, bu, bv; uint32_t bprim; uint32_t oct; Grp G; TriGrp T, T2; int sp; uint32_t item; bool has, done;   // T2: second pending triangle group (speculative schedule)
+};
+__device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, float tmax, uint32_t item) {
+    R.o = o; R.d = d; R.tmin = tmin; R.tmax = tmax; R.item = item;
+    const float dxs = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
+    const float dys = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
+    const float dzs = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
+    R.idir = mk3(__builtin_amdgcn_rcpf(dxs), __builtin_amdgcn_rcpf(dys), __builtin_amdgcn_rcpf(dzs));
+    R.oct = ray_octant(R.idir);
+    R.bt = tmax; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.sp = 0; R.has = true; R.done = false;
+    R.G = Grp{0u, (1u << R.oct) | (1u << 8)}; R.T = TriGrp{0u, 0u, 0u}; R.T2 = TriGrp{0u, 0u, 0u};
+}
+__device__ __forceinline__ void ray_idle(RayLane& R) {
+    R.has = false; R.done = false; R.sp = 0; R.item = 0; R.o = mk3(0, 0, 0); R.d = mk3(0, 0, 1); R.idir = mk3(0, 0, 1); R.oct = 0;
+    R.tmin = 0.0f; R.tmax = 0.0f; R.bt = 0.0f; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.G = Grp{0u, 0u}; R.T = TriGrp{0u, 0u, 0u}; R.T2 = TriGrp{0u, 0u, 0u};
+}
+// after a node step or a finished triangle group: continue with the node's own internal hits, else pop, else done
+template <class STK>
+__device__ __forceinline__ void next_group(RayLane& R, STK& stk) {
+    if (!(R.G.bits & 0xffu) && !R.T.bits) {
+        if (R.sp == 0) R.done = true;
+        else { R.sp--; R.G = stk.get(R.sp); }
+    }
+}
+// all lanes with a node group walk down until they hold triangles to test or are done
+template <bool ANY, class STK>
+__device__ __forceinline__ void walk_internal(const DevScene& sc, const TraceLds& L, RayLane& R, STK& stk) {
+    while (R.has && !R.done && !R.T.bits) {
+        descend8(sc, L, R.o, R.idir, R.oct, R.tmin, R.bt, R.G, R.T, stk, R.sp);
+        next_group(R, stk);
+    }
+}
+template <bool ANY>
+__device__ __forceinline__ void tri_step(const DevScene& sc, const TraceLds& L, RayLane& R) {
+    const uint32_t bit = (uint32_t)__builtin_ctz(R.T.bits);
+    R.T.bits &= R.T.bits - 1u;
+    const uint32_t slot = tri_slot8(R.T, bit);
+    v4f v0, e1, e2;
+    if (slot < sc.lds_tris) { const lds_v4f* t = L.tris + slot * 3u; v0 = t[0]; e1 = t[1]; e2 = t[2]; }
+    else { const v4f* t = (const v4f*)(sc.tris + slot); v0 = t[0]; e1 = t[1]; e2 = t[2]; }
+    float t, u, w;
+    if (tri_test(R.o, R.d, v0, e1, e2, R.tmin, R.tmax, t, u, w)) {
+        if (ANY) { R.bprim = 0u; R.done = true; R.T.bits = 0u; }
+        else {
+            const uint32_t gid = f2u(v0.w);
+            if (t < R.bt || (t == R.bt && gid < R.bprim)) { R.bt = t; R.bu = u; R.bv = w; R.bprim = gid; }
+        }
+    }
+}
+template <bool ANY, class STK>
+__device__ __forceinline__ void process_leaf(const DevScene& sc, const TraceLds& L, RayLane& R, STK& stk) {
+    while (R.has && !R.done && R.T.bits) tri_step<ANY>(sc, L, R);
+    if (R.has && !R.done) next_group(R, stk);
+}
+// Voted schedule (trace_sched 1-4): instead of "walk until EVERY lane holds triangles, then test every lane's triangles"
+// each iteration the wave votes for the step most of its busy lanes are waiting for: one node step, or one triangle test.
+template <bool ANY, class STK>
+__device__ __forceinline__ void voted_step(const DevScene& sc, const TraceLds& L, RayLane& R, STK& stk, uint32_t sched) {
+    const bool busy = R.has && !R.done;
+    const bool in_tri = busy && R.T.bits != 0u;
+    const bool in_node = busy && !in_tri;
+    const uint32_t ni = (uint32_t)__popcll(__ballot(in_node)), nl = (uint32_t)__popcll(__ballot(in_tri));
+    const uint32_t wn = sched == 3u ? 2u : 1u, wl = sched == 2u ? 2u : sched == 4u ? 3u : 1u;    // experiment: weighted vote
+    if (ni * wn >= nl * wl) {
+        if (in_node) { descend8(sc, L, R.o, R.idir, R.oct, R.tmin, R.bt, R.G, R.T, stk, R.sp); next_group(R, stk); }
+    } else if (in_tri) {
+        tri_step<ANY>(sc, L, R);
+        if (!R.done) next_group(R, stk);
+    }
+}
+// Speculative voted schedule (trace_sched 5-7): a lane whose triangles are still waiting for a triangle step keeps walking
+// nodes — the triangles of the next node go to a second pending group (T2) — so node steps run with most busy lanes instead of
+// only those without pending triangles, and triangle steps run when many lanes have some.  Pending triangles are always tested
+// before a ray finishes, and the order of tests does not change the result (minimum over all tested triangles / any hit); what
+// speculation costs is culling: node steps taken before the pending triangles shrink the closest distance may visit boxes that
+// would have been culled (shadow rays lose nothing: their interval is fixed).
+template <bool ANY, class STK>
+__device__ __forceinline__ void spec_step(const DevScene& sc, const TraceLds& L, RayLane& R, STK& stk, uint32_t sched) {
+    const bool busy = R.has && !R.done;
+    const bool has_tri = busy && R.T.bits != 0u;
+    const bool can_node = busy && R.T2.bits == 0u && ((R.G.bits & 0xffu) != 0u || R.sp > 0);
+    const uint32_t ni = (uint32_t)__popcll(__ballot(can_node)), nl = (uint32_t)__popcll(__ballot(has_tri));
+    const uint32_t wn = sched == 7u ? 2u : 1u, wl = sched == 5u ? 1u : sched == 6u ? 2u : 1u;
+    if (ni * wn >= nl * wl && ni) {
+        if (can_node) {
+            if (!(R.G.bits & 0xffu)) { R.sp--; R.G = stk.get(R.sp); }
+            TriGrp Tn;
+            descend8(sc, L, R.o, R.idir, R.oct, R.tmin, R.bt, R.G, Tn, stk, R.sp);
+            if (Tn.bits) { if (R.T.bits) R.T2 = Tn; else R.T = Tn; }
+        }
+    } else if (has_tri) {
+        tri_step<ANY>(sc, L, R);
+        if (!R.T.bits) { R.T = R.T2; R.T2 = TriGrp{0u, 0u, 0u}; }
+    }
+    if (R.has && !R.done && !(R.G.bits & 0xffu) && R.sp == 0 && !R.T.bits) R.done = true;
+}
+// wave-level refill: returns false when the wave may exit (queue exhausted and nothing in flight)
+template <class Fetch>
+__device__ __forceinline__ bool refill(RayLane& R, uint32_t* s_head, uint32_t n, bool& drained, uint32_t refill_min, Fetch fetch) {
+    const unsigned long long idle = __ballot(!R.has);
+    const uint32_t nidle = (uint32_t)__popcll(idle);
+    if (!drained && (nidle >= refill_min || nidle == 64u)) {            // wave-uniform
+        uint32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(s_head, nidle);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= n) drained = true;
+        else {
+            const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            if (!R.has && idx < n) fetch(idx);
+            if (base + nidle >= n) drained = true;
+        }
+    }
+    return __ballot(R.has) != 0ull;
+}
+
+}  // namespace rtx
