@@ -342,7 +342,7 @@ bool SceneHost::build(BuiltScene& B) {
                 for (int row = 0; row < 20; row++) {
                     double v;
                     if (!have) v = (row == 7 || row == 11 || row == 15 || row == 19) ? -1e30 : 0.0;       // padding: never inside
-                    else v = row < 4 ? recs[r + e].pl[row] : recs[r + e].e[(row - 4) / 4][(row - 4) % 4];
+                    else v = row < 4 ? recs[r + e].pl[row] : recs[r + e].e[(row - 4) / 4][(row - 4) % 4] + ((row - 4) % 4 == 3 ? delta : 0.0);   // edge constants carry the distance tolerance
                     P.r[row][e] = (float)v;
                 }
             }

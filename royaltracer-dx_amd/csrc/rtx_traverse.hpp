@@ -242,8 +242,8 @@ __device__ __forceinline__ void traverse_small(const DevScene& sc, const SmallRe
     uint32_t cand_lo = 0u, cand_hi = 0u;
     const uint32_t npairs = (nrec + 1u) >> 1;
     const f2v dx = splat2(d.x), dy = splat2(d.y), dz = splat2(d.z), ox = splat2(o.x), oy = splat2(o.y), oz = splat2(o.z);
-    const f2v cm = splat2(sc.small_cm), c5 = splat2(1e-5f), vtmin = splat2(tmin), vtmax = splat2(tmax), dl = splat2(sc.small_delta);
-#pragma unroll 2
+    const f2v cm = splat2(sc.small_cm), c5 = splat2(1e-5f), vtmin = splat2(tmin), vtmax = splat2(tmax);
+#pragma unroll 1
     for (uint32_t kp = 0; kp < npairs; kp++) {          // wave-uniform
         if (!((keep >> (2u * kp)) & 3ull)) continue;
         const f2v* __restrict__ R = (const f2v*)sp[kp].r;
@@ -257,10 +257,11 @@ __device__ __forceinline__ void traverse_small(const DevScene& sc, const SmallRe
         const f2v e2 = fma2(R[14], pz, fma2(R[13], py, fma2(R[12], px, R[15])));
         const f2v e3 = fma2(R[18], pz, fma2(R[17], py, fma2(R[16], px, R[19])));
         const f2v mt = fma2(cm, __builtin_elementwise_abs(ind), c5 * __builtin_elementwise_abs(t));
-        // all slack values must be >= 0: t in [tmin - mt, tmax + mt] and P within delta of the inside of every edge
-        const f2v a0 = (t + mt) - vtmin, a1 = (vtmax + mt) - t, b0 = e0 + dl, b1 = e1 + dl, b2 = e2 + dl, b3 = e3 + dl;
-        const float m0 = fminf(fminf(fminf(a0.x, a1.x), fminf(b0.x, b1.x)), fminf(b2.x, b3.x));
-        const float m1 = fminf(fminf(fminf(a0.y, a1.y), fminf(b0.y, b1.y)), fminf(b2.y, b3.y));
+        // all slack values must be >= 0: t in [tmin - mt, tmax + mt] and P within delta of the inside of every edge (e_k carries + delta)
+        // (the distance tolerance delta of the edge planes is folded into their constants at build time: e_k >= 0 means "within delta")
+        const f2v a0 = (t + mt) - vtmin, a1 = (vtmax + mt) - t;
+        const float m0 = fminf(fminf(fminf(a0.x, a1.x), fminf(e0.x, e1.x)), fminf(e2.x, e3.x));
+        const float m1 = fminf(fminf(fminf(a0.y, a1.y), fminf(e0.y, e1.y)), fminf(e2.y, e3.y));
         const bool c0 = (m0 >= 0.0f) || (fabsf(nd.x) < 1e-3f);      // grazing rays always go to the exact test
         const bool c1 = (m1 >= 0.0f) || (fabsf(nd.y) < 1e-3f);
         const uint32_t bit = 1u << ((2u * kp) & 31u);

@@ -196,7 +196,7 @@ int rtxh_scene_small_records(const rtxh_scene* sc, float* recs20, int32_t* tri_i
     for (const SceneInstance& in : s.instances) { uint32_t id; if (!H.add_instance(in.model, in.transform.data(), &id)) return RTX_ERR_INVALID; }
     if (!H.build(B)) return RTX_ERR_INVALID;
     if (nrec_out) *nrec_out = B.small_nrec;
-    if (delta_out) *delta_out = B.small_delta;
+    if (delta_out) *delta_out = 0.0f;                     // the tolerance is already folded into the records' edge constants (B.small_delta)
     if (cm_out) *cm_out = B.small_cm;
     for (uint32_t r = 0; r < B.small_nrec && r < max_recs; r++) {
         for (int row = 0; row < 20; row++) recs20[(size_t)r * 20 + row] = B.small_recs[r / 2].r[row][r & 1];
