@@ -269,9 +269,8 @@ __device__ __forceinline__ void traverse_small(const DevScene& sc, const SmallRe
         if (kp < 16u) cand_lo |= add; else cand_hi |= add;
     }
     unsigned long long cand = ((unsigned long long)cand_hi << 32) | cand_lo;
-    // (Testing only the triangle on the ray's side of a quad's diagonal would save one exact test per candidate, but the side
-    // computation needs ~4 more VGPRs and the fused kernel already sits at 124 of the 128 that 4 waves/SIMD allow: with 2 spilled
-    // registers it measured 28.4-28.9 ms instead of 27.6.)
+    // (Testing only the triangle on the ray's side of a quad's diagonal would save one exact test per candidate; measured slower
+    // both ways: at 4 waves/SIMD the ~4 extra VGPRs spill (28.4-28.9 ms instead of 27.6), at 3 waves/SIMD without spills 31.3 ms.)
     while (cand) {                                     // per-lane: exact test of the triangles of each candidate record
         const uint32_t k = (uint32_t)__builtin_ctzll(cand);
         cand &= cand - 1ull;
