@@ -1,0 +1,46 @@
+// Host-layer exercise for AddressSanitizer / UBSan on the CPU (GPU sanitizers are not available on the pool): scene
+// generators, OBJ loader, BVH build / collapse / refit / validators, tiny-scene records, image writers.  The device API is
+// stubbed (device_stubs.cpp); built and run by tests/test_host_layer.py::test_host_layer_under_asan_ubsan.
+#include "rtx_host.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#include <random>
+#include <string>
+int main(int argc, char** argv) {
+    // scenes
+    rtxh_scene* c = rtxh_scene_cornell();
+    rtxh_scene* s = rtxh_scene_sponza_class(262144, 260);
+    rtxh_scene* b = rtxh_scene_bistro_class(300000, 3800);
+    std::string gd = argc > 1 ? argv[1] : "tests/golden", f0 = gd + "/garage.obj", f1 = gd + "/monke.obj", md = gd + "/";
+    const char* files[2] = {f0.c_str(), f1.c_str()};
+    rtxh_scene* g = rtxh_scene_from_obj(files, 2, md.c_str());
+    if (!c || !s || !b || !g) { printf("scene creation failed\n"); return 1; }
+    std::vector<float> recs(64 * 20); std::vector<int32_t> ids(128); uint32_t n = 0, nocc = 0; float d, cm;
+    int rc = rtxh_scene_small_records(c, recs.data(), ids.data(), 64, &n, &d, &cm);
+    printf("small records rc=%d n=%u\n", rc, n);
+    rc = rtxh_scene_small_occluders(c, &nocc);
+    printf("occluders rc=%d nocc=%u\n", rc, nocc);
+    if (n != 17 || nocc != 11) return 3;
+    // BVH checks on soups
+    std::mt19937 rng(7); std::uniform_real_distribution<float> U(-1, 1); std::normal_distribution<float> N(0, 0.03f);
+    for (uint32_t nt : {0u, 1u, 2u, 3u, 7u, 65u, 1000u, 50000u}) {
+        std::vector<float> w((size_t)nt * 9);
+        for (uint32_t i = 0; i < nt; i++) { float cx = U(rng), cy = U(rng), cz = U(rng); for (int k = 0; k < 3; k++) { w[i * 9 + k * 3] = cx + N(rng); w[i * 9 + k * 3 + 1] = cy + N(rng); w[i * 9 + k * 3 + 2] = cz + N(rng); } }
+        uint32_t nodes = 0, depth = 0, leaf = 0, n8 = 0, st = 0, hist[6];
+        int r1 = rtxh_bvh_check(w.data(), nt, &nodes, &depth, &leaf), r2 = rtxh_bvh8_check(w.data(), nt, &n8, &st), r3 = rtxh_bvh8_stats(w.data(), nt, hist, &n8);
+        std::vector<float> w2 = w; for (float& x : w2) x = x * 1.3f + 0.1f;
+        int r4 = nt ? rtxh_bvh_refit_check(w.data(), w2.data(), nt) : 0;
+        printf("nt=%u bvh2 rc=%d nodes=%u depth=%u leaf=%u | bvh8 rc=%d nodes=%u stack=%u | stats rc=%d | refit rc=%d\n", nt, r1, nodes, depth, leaf, r2, n8, st, r3, r4);
+        if (r1 || r2 || r3 || r4) return 2;
+    }
+    // image writers
+    const std::string out = argc > 2 ? argv[2] : "/tmp";
+    std::vector<uint8_t> img(37 * 21 * 4, 128); std::vector<float> acc(37 * 21 * 4, 1.5f);
+    printf("png %d ppm %d exr %d\n", rtxh_write_png((out + "/a.png").c_str(), img.data(), 37, 21), rtxh_write_ppm((out + "/a.ppm").c_str(), img.data(), 37, 21), rtxh_write_exr((out + "/a.exr").c_str(), acc.data(), 37, 21));
+    float lut[16]; rtxh_generate_ess_lut(0.5f, lut); printf("lut0 %f\n", lut[0]);
+    rtxh_scene_free(c); rtxh_scene_free(s); rtxh_scene_free(b); rtxh_scene_free(g);
+    printf("done\n");
+    return 0;
+}

@@ -297,3 +297,25 @@ def test_tiny_scene_hull_faces_come_last(rt, cornell):
     assert both[:nocc].all() and not both[nocc:].any()
     # the hull faces are the floor, ceiling, back, left and right walls: together they own 10 triangles
     assert (ids[nocc:] >= 0).sum() == 10
+
+
+def test_host_layer_under_asan_ubsan(tmp_path, golden_dir):
+    """the C++ host layer (scene generators, OBJ loader, BVH build / DP collapse / refit / validators, tiny-scene records, image
+    writers) compiled with g++ -fsanitize=address,undefined and run on the CPU with the device API stubbed"""
+    import subprocess, shutil
+    if not shutil.which("g++"):
+        pytest.skip("g++ not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pk = os.path.join(root, "royaltracer-dx_amd")
+    srcs = [os.path.join(root, "tests", "sanitize", f) for f in ("host_main.cpp", "device_stubs.cpp")]
+    srcs += [os.path.join(pk, "csrc", "rtx_scene_host.cpp")] + [os.path.join(pk, "host", f) for f in
+             ("DirectXMathLite.cpp", "manipulator.cpp", "ObjLoader.cpp", "Scenes.cpp", "Renderer.cpp", "ImageIO.cpp", "rtx_host_c.cpp")]
+    exe = str(tmp_path / "san_host")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-ffp-contract=off",
+           "-I" + os.path.join(root, "include"), "-I" + os.path.join(pk, "csrc"), "-I" + os.path.join(pk, "host"), "-o", exe] + srcs
+    b = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([exe, golden_dir, str(tmp_path)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "done" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
