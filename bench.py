@@ -184,10 +184,14 @@ def main():
             scale = 1
             while est / (scale * scale) > 30.0 and scale < 8:
                 scale *= 2
-            # ... and take more of the frame's samples if it is fast: aim at ~12 s of wall time on all cores
-            cpu_spp = int(max(1, min(spp, 32, round(12.0 / max(est / (scale * scale), 1e-3)))))
-            cp = cp.copy(width=W // scale, height=H // scale, spp=cpu_spp)
+            cp = cp.copy(width=W // scale, height=H // scale, spp=1)
             tc = time.perf_counter(); _, cc = o.render(cp); tc = time.perf_counter() - tc
+            cpu_spp = 1
+            if tc < 6.0:             # fast host: take more of the frame's samples, aiming at ~12 s of wall time on all cores
+                cpu_spp = int(max(1, min(spp, 32, round(12.0 / max(tc, 1e-3)))))
+                if cpu_spp > 1:
+                    cp = cp.copy(spp=cpu_spp)
+                    tc = time.perf_counter(); _, cc = o.render(cp); tc = time.perf_counter() - tc
             cpu = {"value": round(sum(cc) / tc / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
                    "sample": f"oracle/rt_oracle.c (OpenMP), {cp.width}x{cp.height}, {cpu_spp} of {spp} spp of the same frame, {sum(cc)} rays in {tc:.2f} s"}
         out = {"metric": "Mrays/s + ms/frame at 1080p, 8-bounce Cornell Box" if kind == "cornell" else f"Mrays/s + ms/frame, {args.workload}",
