@@ -74,7 +74,7 @@ typedef struct rtx_stats {
 } rtx_stats;
 
 enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents (rtx_stats.kernel_ms) */
-       RTX_OPT_PATHS_PER_BATCH = 2,  /* max pixel-samples in flight (queue capacity) */
+       RTX_OPT_PATHS_PER_BATCH = 2,  /* max pixel-samples in flight (queue capacity), default 128 Mi (~17 GB of path state and queues) */
        RTX_OPT_SORT_MATERIALS = 3,   /* 0/1: material-sorted shading (k_shade sorts its sub-queue chunks by material in LDS; default 0: measured slower) */
        RTX_OPT_LDS_NODES = 4,        /* BVH nodes staged in LDS per workgroup (top of tree) */
        RTX_OPT_SMALL_SCENE = 5,      /* 0/1: brute-force pre-test path for scenes of <= 64 triangles (default 1) */

@@ -49,7 +49,7 @@ struct rtx_ctx {
     DevBuf d_srgb, d_res_di, d_res_gi, d_sdata, d_last_di, d_last_gi, d_last_sd, d_p1cnt; size_t p1_slots = 0, last_slots = 0;
     float prev_view[16], prev_proj[16];
     // options
-    bool timing = false; uint64_t paths_per_batch = 64u << 20; int lds_nodes_opt = -1; bool small_scene = true; bool fused = true; int stack_private = -1;
+    bool timing = false; uint64_t paths_per_batch = 128u << 20; int lds_nodes_opt = -1; bool small_scene = true; bool fused = true; int stack_private = -1;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     std::vector<TimedLaunch> timed;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;

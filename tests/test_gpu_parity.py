@@ -217,7 +217,7 @@ def test_progressive_accumulation_and_batches(rt, cornell_pair):
     assert np.array_equal(bits(one), bits(two))
     ctx.set_option(rt.OPT_PATHS_PER_BATCH, 4096)     # force many small batches
     ctx.clear(64, 36); ctx.render(rt.Params(spp=6, **base)); three = ctx.read_accum()
-    ctx.set_option(rt.OPT_PATHS_PER_BATCH, 64 << 20)
+    ctx.set_option(rt.OPT_PATHS_PER_BATCH, 128 << 20)
     assert np.array_equal(bits(one), bits(three))
     c, _ = o.render(rt.Params(spp=6, **base))
     assert rel_l2(one[..., :3], c[..., :3]) <= REL_L2_TOL
