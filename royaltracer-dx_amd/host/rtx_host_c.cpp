@@ -122,13 +122,26 @@ int rtxh_bvh8_check(const float* wt, uint32_t ntris, uint32_t* nodes8_out, uint3
     std::vector<float> w(wt, wt + (size_t)ntris * 9);
     std::vector<rtx::NodeGPU> nodes; std::vector<uint32_t> order; uint32_t depth = 0;
     rtx::build_bvh(w, 0.0f, nodes, order, depth);
-    std::vector<rtx::Node8GPU> n8; std::vector<uint32_t> slots; uint32_t stack = 0;
-    if (!rtx::collapse_bvh8(nodes, n8, slots, stack)) return 30;
+    std::vector<rtx::Node8GPU> n8; std::vector<uint32_t> slots, levels; uint32_t stack = 0;
+    if (!rtx::collapse_bvh8(nodes, n8, slots, stack, &levels)) return 30;
     if (nodes8_out) *nodes8_out = (uint32_t)n8.size();
     if (stack_out) *stack_out = stack;
     uint32_t seen = 0;
     if (int r = rtx::validate_bvh8(w, n8, order, slots, &seen)) return r;
-    return seen == stack ? 0 : 19;
+    if (seen != stack) return 19;
+    // the level table the GPU refit sweeps bottom-up: contiguous ranges, and every internal child lives exactly one level below
+    if (levels.size() < 2 || levels.front() != 0 || levels.back() != n8.size()) return 31;
+    for (size_t l = 0; l + 1 < levels.size(); l++) {
+        if (levels[l] >= levels[l + 1]) return 32;
+        for (uint32_t i = levels[l]; i < levels[l + 1]; i++) {
+            const uint32_t nint = (uint32_t)__builtin_popcount(n8[i].e_imask >> 24);
+            for (uint32_t r = 0; r < nint; r++) {
+                const uint32_t c = n8[i].child_base + r;
+                if (l + 2 >= levels.size() || c < levels[l + 1] || c >= levels[l + 2]) return 33;
+            }
+        }
+    }
+    return 0;
 }
 
 // shape of the wide tree: hist[0..4] = leaf slots holding 0 (unused slot) / 1 / 2 / 3 / 4 triangles, hist[5] = internal child slots
