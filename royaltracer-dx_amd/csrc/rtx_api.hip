@@ -42,6 +42,7 @@ struct rtx_ctx {
     DevScene dsc{};
     float view[16], proj[16];
     // path state
+    DevBuf d_hitmask;
     DevBuf d_ray_o, d_ray_d, d_thr, d_rad, d_hit, d_sh_o, d_sh_d, d_sh_c, d_queue[2], d_counters;
     uint32_t* h_counters = nullptr; size_t h_counters_words = 0;
     // accumulation
@@ -102,7 +103,7 @@ void rtx_destroy(rtx_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_small_poly, &c->d_objtris, &c->d_node_aabb, &c->d_scale, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
-                     &c->d_thr, &c->d_rad, &c->d_hit, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
+                     &c->d_thr, &c->d_rad, &c->d_hit, &c->d_hitmask, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
                      &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt};
     for (DevBuf* b : all) b->release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
@@ -353,6 +354,8 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     HIPCHK(c, c->d_sh_o.ensure(shn * 16)); HIPCHK(c, c->d_sh_d.ensure(shn * 16)); HIPCHK(c, c->d_sh_c.ensure(shn * 16));
     DevPaths P;
     P.ray_o = (F4*)c->d_ray_o.p; P.ray_d = (F4*)c->d_ray_d.p; P.thr = (F4*)c->d_thr.p; P.rad = (F4*)c->d_rad.p; P.hit = (F4*)c->d_hit.p;
+    P.hitmask = nullptr;
+    if (c->dsc.nsmall && c->fused) { HIPCHK(c, c->d_hitmask.ensure(((size_t)cap / 64 + 1) * 8)); P.hitmask = (unsigned long long*)c->d_hitmask.p; }
     P.sh_o = (F4*)c->d_sh_o.p; P.sh_d = (F4*)c->d_sh_d.p; P.sh_c = (F4*)c->d_sh_c.p;
     uint32_t* queue[2] = {(uint32_t*)c->d_queue[0].p, (uint32_t*)c->d_queue[1].p};
 

@@ -46,6 +46,8 @@ struct DevPaths {
     F4* thr;     // throughput.xyz, seed.x bits
     F4* rad;     // radiance.xyz, -           (touched only when something is added)
     F4* hit;     // t, u, v, global triangle id bits
+    unsigned long long* hitmask;   // fused tiny-scene path: bit (pid & 63) of word pid >> 6 = the primary ray hit something (rad is
+                                   // initialised only for those; k_accumulate treats the others as zero).  nullptr: rad is zeroed for all
     // shadow queues: [nee slot j][workgroup b][qcap] entries
     F4* sh_o;    // origin.xyz, tmin
     F4* sh_d;    // dir.xyz, tmax
