@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen_trace_small(DevScene sc, cons
         const unsigned long long hm = __ballot(hit);
         if (lane_id() == 0) p.hitmask[pid >> 6] = hm;
         if (hit) {
-            p.rad[pid] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (f.max_bounces == 0u) p.rad[pid] = {0.0f, 0.0f, 0.0f, 0.0f};   // otherwise the bounce-0 kernel writes every hit path's radiance slot
             p.ray_o[pid] = {o.x, o.y, o.z, u2f(s1)};
             p.ray_d[pid] = {d.x, d.y, d.z, 1.0f};
             p.thr[pid] = {1.0f, 1.0f, 1.0f, u2f(s0)};
@@ -323,13 +323,14 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
             sf = surface(sc, S.o, S.d, t, u, v, prim);
             if (sf.mat < sc.nmat) {
                 const MatGPU& m = sc.mats[sf.mat];
-                if (m.Ke_len > 0.0f) add_emissive(sc, p, S, sf, m, bounce, nee);
+                if (m.Ke_len > 0.0f) add_emissive(sc, p, S, sf, m, bounce, nee, HAVE_HIT);
                 else shading = true;
-            }
+            } else if (HAVE_HIT) p.rad[S.pid] = {0.0f, 0.0f, 0.0f, 0.0f};
         }
         const f3 outgoing = -S.d, normal = sf.normal, pos = sf.pos;
         const MatGPU* mp = sc.mats + (shading ? sf.mat : 0u);
-        bool loaded = false; F4 radv = {0, 0, 0, 0};
+        // bounce 0 (HAVE_HIT): nothing has written this path's radiance slot yet: it starts from zero here and is always stored
+        bool loaded = HAVE_HIT && shading; F4 radv = {0, 0, 0, 0};
         for (uint32_t j = 0; j < nee; j++) {
             bool push = false;
             F4 so = {0, 0, 0, 0}, sd = {0, 0, 1, 0}; f3 con = mk3(0, 0, 0);

@@ -49,9 +49,11 @@ __device__ __forceinline__ PathState load_path(const DevPaths& p, uint32_t pid) 
 }
 
 // hit on an emissive surface: Hit.hlsl:126-174 with the v6 pdf conventions (Sampler_v6.hlsl:459-465)
-__device__ __forceinline__ void add_emissive(const DevScene& sc, const DevPaths& p, const PathState& S, const Surf& sf, const MatGPU& m, uint32_t bounce, uint32_t nee) {
+// fresh: the path's radiance slot has not been written yet (bounce 0 of the fused path): start from zero instead of loading it
+__device__ __forceinline__ void add_emissive(const DevScene& sc, const DevPaths& p, const PathState& S, const Surf& sf, const MatGPU& m, uint32_t bounce, uint32_t nee, bool fresh = false) {
     const f3 Ke = mk3(m.Ke[0], m.Ke[1], m.Ke[2]);
-    F4 radv = p.rad[S.pid];
+    F4 radv = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (!fresh) radv = p.rad[S.pid];
     if (bounce == 0) { radv.x = radv.x + Ke.x; radv.y = radv.y + Ke.y; radv.z = radv.z + Ke.z; }   // Hit.hlsl:128-131
     else {
         float mi = 1.0f;
