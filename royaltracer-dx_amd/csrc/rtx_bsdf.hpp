@@ -7,13 +7,14 @@ namespace rtx {
 
 // Working copy of a material on the GPU: the fp16-rounded MaterialOptimized (Common_v6.hlsl:62-74,
 // CreateMaterialOptimized Sampler_v6.hlsl:71-83) widened back to float, plus the full-precision
-// multiscatter LUT that ESS_LUT reads from materials[mID] (GGX_v6.hlsl:17-18).  128 bytes.
+// multiscatter LUT that ESS_LUT reads from materials[mID] (GGX_v6.hlsl:17-18), plus Kd / PI.  144 bytes.
 struct MatGPU {
     float Kd[3]; float Pr;
     float Ks[3]; float Pm;
     float Ke[3]; float Ke_len;      // length(Ke) of the rounded copy
     float KeFull[3]; float KeFullLen;   // full-precision Ke and its length: `length(materials[mID].Ke) > 0` tests (pass1:104, Path_Sampler_v6.hlsl:55)
     float LUT[16];
+    float KdPi[3]; float pad;       // Kd / PI, divided once on the host (the same IEEE division the shader would do per evaluation)
 };
 
 // GGX_v6.hlsl:26-29; pow(abs(1-c),5) written as repeated multiplication
@@ -52,7 +53,7 @@ RTX_HD float ess_lut(const MatGPU& m, float NdotV) {
     return v0 + w * (v1 - v0);
 }
 // Lambertian_v6.hlsl:54-58
-RTX_HD f3 lambert_eval(const MatGPU& m) { return mk3(m.Kd[0] / kPI, m.Kd[1] / kPI, m.Kd[2] / kPI); }
+RTX_HD f3 lambert_eval(const MatGPU& m) { return mk3(m.KdPi[0], m.KdPi[1], m.KdPi[2]); }   // Kd / PI (Lambertian_v6.hlsl:44-50), precomputed in MatGPU
 // Lambertian_v6.hlsl:61-64 (L = -incoming)
 RTX_HD float lambert_pdf(f3 n, f3 L) { return maxf_(dot(n, L), kEps) / kPI; }
 // GGX_v6.hlsl:174-206 (dot products are not clamped in v6)

@@ -183,6 +183,8 @@ bool SceneHost::build(BuiltScene& B) {
         g.Pr = half_round(m[12]); g.Pm = half_round(m[13]);
         g.KeFull[0] = m[8]; g.KeFull[1] = m[9]; g.KeFull[2] = m[10]; g.KeFullLen = length(mk3(m[8], m[9], m[10]));
         g.Ke_len = length(mk3(g.Ke[0], g.Ke[1], g.Ke[2]));
+        for (int k = 0; k < 3; k++) g.KdPi[k] = g.Kd[k] / kPI;
+        g.pad = 0.0f;
         memcpy(g.LUT, m + 16, 64);
     }
     // ---- flatten instances to world-space triangles; per-triangle shade records (Hit_v6.hlsl:12-61) ----
