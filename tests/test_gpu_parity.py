@@ -644,3 +644,36 @@ def test_c4_sizes_4k_shards_and_stack_variants(rt, orc):
         assert np.array_equal(bits(imgs[0]), bits(im))
     # a 64 x 36 crop-sized oracle check is done elsewhere; here: plausibility + determinism
     assert np.isfinite(imgs[0]).all() and (imgs[0][..., 3] == 1).all() and imgs[0][..., :3].mean() > 0.01
+
+
+def test_two_contexts_from_two_threads(rt, cornell):
+    """SURVEY 8(b) threading contract: a context is not thread-safe, but different contexts may be driven from different threads.
+    Two threads render different workloads concurrently on the same GPU (different scenes, options, streams); each result must be
+    bit-identical to the same work done alone — no hidden process-wide state"""
+    import threading
+    sp = rt.Scene.sponza_class(40000, 260)
+    jobs = [dict(scene=cornell, opts={}, p=rt.Params(width=192, height=108, spp=3, max_bounces=6, nee_samples=2, flags=1)),
+            dict(scene=sp, opts={rt.OPT_TRACE_SCHED: 2, rt.OPT_REFILL_MIN: 20, rt.OPT_BLOCKS_PER_CU: 4}, p=rt.Params(width=160, height=90, spp=2, max_bounces=5, nee_samples=1, flags=0))]
+
+    def run(job, out, reps):
+        c = rt.Context(0)
+        for k, v in job["opts"].items():
+            c.set_option(k, v)
+        c.upload(job["scene"], job["p"].width / job["p"].height)
+        imgs = []
+        for _ in range(reps):
+            c.clear(job["p"].width, job["p"].height); c.render(job["p"]); imgs.append(c.read_accum())
+        c.close()
+        out.append(imgs)
+
+    alone = []
+    for j in jobs:
+        o = []; run(j, o, 1); alone.append(o[0][0])
+    outs = [[], []]
+    th = [threading.Thread(target=run, args=(jobs[k], outs[k], 6)) for k in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for k in range(2):
+        assert len(outs[k]) == 1 and len(outs[k][0]) == 6
+        for im in outs[k][0]:
+            assert np.array_equal(bits(im), bits(alone[k]))
