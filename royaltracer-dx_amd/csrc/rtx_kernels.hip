@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
     while (refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) {
                const uint32_t pid = myq[idx];
                const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
-               ray_begin(R, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, pid);
+               ray_begin(R, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, pid, true);
            })) {
         if (sched >= 5u) spec_step<false>(sc, L, R, stk, sched);
         else if (sched) voted_step<false>(sc, L, R, stk, sched);
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const Smal
     bool drained = false;
     while (refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) {
                const F4 so = sh_o[qb + idx], sd = sh_d[qb + idx];
-               ray_begin(R, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, idx);
+               ray_begin(R, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, idx, false);
            })) {
         if (sched >= 5u) spec_step<true>(sc, L, R, stk, sched);
         else if (sched) voted_step<true>(sc, L, R, stk, sched);

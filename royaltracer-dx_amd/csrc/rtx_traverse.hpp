@@ -84,6 +84,8 @@ __device__ __forceinline__ uint32_t ray_octant(f3 idir) { return (idir.x < 0.0f 
 __device__ __forceinline__ float byte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyteK
 
 // tests the 8 children; G = this node's internal hits in octant order, T = the triangles of its hit leaf children
+// ORDERED = false (any-hit rays): the visiting order does not matter, the octant permutation of the hit bits is skipped
+template <bool ORDERED>
 __device__ __forceinline__ void node8_hits(const Node8R& N, f3 o, f3 idir, uint32_t oct, float tmin, float tbest, Grp& G, TriGrp& T) {
     const uint32_t w = f2u(N.h0.w);
     const float sx = u2f((w & 0xffu) << 23) * idir.x, sy = u2f((w & 0xff00u) << 15) * idir.y, sz = u2f((w & 0xff0000u) << 7) * idir.z;
@@ -114,9 +116,11 @@ __device__ __forceinline__ void node8_hits(const Node8R& N, f3 o, f3 idir, uint3
     const uint32_t imask = w >> 24;
     // internal hits, permuted so that bit j = slot (j ^ oct): lowest set bit = first child to visit
     uint32_t m = hits & imask;
-    if (nx) m = ((m & 0x55u) << 1) | ((m >> 1) & 0x55u);
-    if (ny) m = ((m & 0x33u) << 2) | ((m >> 2) & 0x33u);
-    if (nz) m = ((m & 0x0fu) << 4) | ((m >> 4) & 0x0fu);
+    if (ORDERED) {
+        if (nx) m = ((m & 0x55u) << 1) | ((m >> 1) & 0x55u);
+        if (ny) m = ((m & 0x33u) << 2) | ((m >> 2) & 0x33u);
+        if (nz) m = ((m & 0x0fu) << 4) | ((m >> 4) & 0x0fu);
+    }
     G.base = N.h1.x; G.bits = m | (imask << 8);
     // leaf hits: spread each bit to its nibble and keep the triangles that exist
     uint32_t x = hits & ~imask;
@@ -134,16 +138,16 @@ struct StackPriv { Grp a[kPrivStack]; __device__ __forceinline__ void put(int i,
 
 // pick the first child of group G (which has internal hits), keep the remaining siblings on the stack, test the child's
 // eight children: G / T become the child's groups
-template <class STK>
+template <bool ORDERED, class STK>
 __device__ __forceinline__ void descend8(const DevScene& sc, const TraceLds& L, f3 o, f3 idir, uint32_t oct, float tmin, float tbest,
                                          Grp& G, TriGrp& T, STK& stk, int& sp) {
     const uint32_t k = (uint32_t)__builtin_ctz(G.bits);
     const uint32_t rest = G.bits & (G.bits - 1u);
     if (rest & 0xffu) { stk.put(sp, Grp{G.base, rest}); sp++; }
-    const uint32_t slot = k ^ oct;
+    const uint32_t slot = ORDERED ? (k ^ oct) : k;
     const uint32_t idx = G.base + (uint32_t)__builtin_popcount((G.bits >> 8) & ((1u << slot) - 1u));
     const Node8R N = load_node8(sc, L, idx);
-    node8_hits(N, o, idir, oct, tmin, tbest, G, T);
+    node8_hits<ORDERED>(N, o, idir, oct, tmin, tbest, G, T);
 }
 // index of the triangle behind bit `bit` of a triangle group
 __device__ __forceinline__ uint32_t tri_slot8(const TriGrp& T, uint32_t bit) { return T.base + (uint32_t)__builtin_popcount(T.valid & ((1u << bit) - 1u)); }
@@ -160,10 +164,10 @@ __device__ __forceinline__ void traverse(const DevScene& sc, const TraceLds& L, 
     bt = tmax; bu = 0.0f; bv = 0.0f; bprim = kMissPrim;
     StackLds stk; stk.col = L.stack + threadIdx.x;
     int sp = 0;
-    Grp G{0u, (1u << oct) | (1u << 8)};                 // the root as slot 0 of a virtual parent
+    Grp G{0u, (ANY ? 1u : (1u << oct)) | (1u << 8)};    // the root as slot 0 of a virtual parent (any-hit rays visit unordered)
     TriGrp T{0u, 0u, 0u};
     while (true) {
-        if (G.bits & 0xffu) descend8(sc, L, o, idir, oct, tmin, bt, G, T, stk, sp);
+        if (G.bits & 0xffu) descend8<!ANY>(sc, L, o, idir, oct, tmin, bt, G, T, stk, sp);
         while (T.bits) {
             const uint32_t bit = (uint32_t)__builtin_ctz(T.bits);
             T.bits &= T.bits - 1u;
@@ -199,10 +203,10 @@ __device__ __forceinline__ void traverse_stats(const DevScene& sc, const TraceLd
     bt = tmax; bu = 0.0f; bv = 0.0f; bprim = kMissPrim;
     StackLds stk; stk.col = L.stack + threadIdx.x;
     int sp = 0;
-    Grp G{0u, (1u << oct) | (1u << 8)};                 // the root as slot 0 of a virtual parent
+    Grp G{0u, (ANY ? 1u : (1u << oct)) | (1u << 8)};    // the root as slot 0 of a virtual parent (any-hit rays visit unordered)
     TriGrp T{0u, 0u, 0u};
     while (true) {
-        if (G.bits & 0xffu) { descend8(sc, L, o, idir, oct, tmin, bt, G, T, stk, sp); nsteps++; }
+        if (G.bits & 0xffu) { descend8<!ANY>(sc, L, o, idir, oct, tmin, bt, G, T, stk, sp); nsteps++; }
         while (T.bits) {
             const uint32_t bit = (uint32_t)__builtin_ctz(T.bits);
             T.bits &= T.bits - 1u; ntris++;
@@ -355,7 +359,7 @@ __device__ __forceinline__ unsigned long long packet_keep_mask(const DevScene& s
 struct RayLane {                                       // per-lane traversal state
     f3 o, d, idir; float tmin, tmax, bt, bu, bv; uint32_t bprim; uint32_t oct; Grp G; TriGrp T, T2; int sp; uint32_t item; bool has, done;   // T2: second pending triangle group (speculative schedule)
 };
-__device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, float tmax, uint32_t item) {
+__device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, float tmax, uint32_t item, bool ordered) {
     R.o = o; R.d = d; R.tmin = tmin; R.tmax = tmax; R.item = item;
     const float dxs = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
     const float dys = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
@@ -363,7 +367,7 @@ __device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, fl
     R.idir = mk3(__builtin_amdgcn_rcpf(dxs), __builtin_amdgcn_rcpf(dys), __builtin_amdgcn_rcpf(dzs));
     R.oct = ray_octant(R.idir);
     R.bt = tmax; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.sp = 0; R.has = true; R.done = false;
-    R.G = Grp{0u, (1u << R.oct) | (1u << 8)}; R.T = TriGrp{0u, 0u, 0u}; R.T2 = TriGrp{0u, 0u, 0u};
+    R.G = Grp{0u, (ordered ? (1u << R.oct) : 1u) | (1u << 8)}; R.T = TriGrp{0u, 0u, 0u}; R.T2 = TriGrp{0u, 0u, 0u};
 }
 __device__ __forceinline__ void ray_idle(RayLane& R) {
     R.has = false; R.done = false; R.sp = 0; R.item = 0; R.o = mk3(0, 0, 0); R.d = mk3(0, 0, 1); R.idir = mk3(0, 0, 1); R.oct = 0;
@@ -381,7 +385,7 @@ __device__ __forceinline__ void next_group(RayLane& R, STK& stk) {
 template <bool ANY, class STK>
 __device__ __forceinline__ void walk_internal(const DevScene& sc, const TraceLds& L, RayLane& R, STK& stk) {
     while (R.has && !R.done && !R.T.bits) {
-        descend8(sc, L, R.o, R.idir, R.oct, R.tmin, R.bt, R.G, R.T, stk, R.sp);
+        descend8<!ANY>(sc, L, R.o, R.idir, R.oct, R.tmin, R.bt, R.G, R.T, stk, R.sp);
         next_group(R, stk);
     }
 }
@@ -417,7 +421,7 @@ __device__ __forceinline__ void voted_step(const DevScene& sc, const TraceLds& L
     const uint32_t ni = (uint32_t)__popcll(__ballot(in_node)), nl = (uint32_t)__popcll(__ballot(in_tri));
     const uint32_t wn = sched == 3u ? 2u : 1u, wl = sched == 2u ? 2u : sched == 4u ? 3u : 1u;    // experiment: weighted vote
     if (ni * wn >= nl * wl) {
-        if (in_node) { descend8(sc, L, R.o, R.idir, R.oct, R.tmin, R.bt, R.G, R.T, stk, R.sp); next_group(R, stk); }
+        if (in_node) { descend8<!ANY>(sc, L, R.o, R.idir, R.oct, R.tmin, R.bt, R.G, R.T, stk, R.sp); next_group(R, stk); }
     } else if (in_tri) {
         tri_step<ANY>(sc, L, R);
         if (!R.done) next_group(R, stk);
@@ -440,7 +444,7 @@ __device__ __forceinline__ void spec_step(const DevScene& sc, const TraceLds& L,
         if (can_node) {
             if (!(R.G.bits & 0xffu)) { R.sp--; R.G = stk.get(R.sp); }
             TriGrp Tn;
-            descend8(sc, L, R.o, R.idir, R.oct, R.tmin, R.bt, R.G, Tn, stk, R.sp);
+            descend8<!ANY>(sc, L, R.o, R.idir, R.oct, R.tmin, R.bt, R.G, Tn, stk, R.sp);
             if (Tn.bits) { if (R.T.bits) R.T2 = Tn; else R.T = Tn; }
         }
     } else if (has_tri) {
