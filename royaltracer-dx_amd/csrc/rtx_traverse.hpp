@@ -17,6 +17,20 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2v fma2(f2v a, f2v b, f2v c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2v splat2(float x) { f2v r = {x, x}; return r; }
+// acc = (acc << 1) | c as ONE VALU instruction: acc + acc + carry-in, the carry-in being c's lane mask (the compare writes it to an SGPR pair)
+// (m is built from ballots of single compares OR-ed on the scalar unit: the ballot of an i1 expression goes through v_cndmask + v_cmp_ne)
+__device__ __forceinline__ uint32_t shift_in(uint32_t acc, unsigned long long m) {
+    uint32_t r;
+    asm("v_addc_co_u32_e64 %0, vcc, %1, %1, %2" : "=v"(r) : "v"(acc), "s"(m) : "vcc");
+    return r;
+}
+// cm |ind| + 1e-5 |t| in two instructions (|x| as a source modifier; left to the compiler it becomes four v_and + two packed ops)
+__device__ __forceinline__ float margin_t(float cm, float ind, float t) {
+    float a, r;
+    asm("v_mul_f32_e64 %0, |%1|, %2" : "=v"(a) : "v"(t), "v"(1e-5f));
+    asm("v_fma_f32 %0, |%1|, %2, %3" : "=v"(r) : "v"(ind), "s"(cm), "v"(a));
+    return r;
+}
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v2u lds_u2;
@@ -246,33 +260,47 @@ __device__ __forceinline__ void traverse_small(const DevScene& sc, const SmallRe
     uint32_t cand_lo = 0u, cand_hi = 0u;
     const uint32_t npairs = (nrec + 1u) >> 1;
     const f2v dx = splat2(d.x), dy = splat2(d.y), dz = splat2(d.z), ox = splat2(o.x), oy = splat2(o.y), oz = splat2(o.z);
-    const f2v cm = splat2(sc.small_cm), c5 = splat2(1e-5f), vtmin = splat2(tmin), vtmax = splat2(tmax);
-#pragma unroll 1
-    for (uint32_t kp = 0; kp < npairs; kp++) {          // wave-uniform
-        if (!((keep >> (2u * kp)) & 3ull)) continue;
+    const f2v vtmin = splat2(tmin), vtmax = splat2(tmax);
+    const float cm = sc.small_cm;
+    // One record pair.  Instruction budget (the loop is the hottest code of the tiny-scene kernels, ~48 VALU per pair): the edge
+    // constants are ADDED from SGPRs after the three FMAs (a VOP3P instruction takes one scalar operand, so an FMA addend from
+    // SGPRs costs two v_mov), |x| rides on source modifiers of unpacked instructions, six slacks reduce through two min3 + one
+    // min, and each record's verdict is shifted into the candidate word with ONE v_addc_co (carry-in = the compare mask).
+    auto pair = [&](uint32_t kp, uint32_t& acc) {
         const f2v* __restrict__ R = (const f2v*)sp[kp].r;
         const f2v nd = fma2(R[2], dz, fma2(R[1], dy, R[0] * dx));
         const f2v no = R[3] - fma2(R[2], oz, fma2(R[1], oy, R[0] * ox));
         f2v ind; ind.x = __builtin_amdgcn_rcpf(nd.x); ind.y = __builtin_amdgcn_rcpf(nd.y);
         const f2v t = no * ind;
         const f2v px = fma2(t, dx, ox), py = fma2(t, dy, oy), pz = fma2(t, dz, oz);
-        const f2v e0 = fma2(R[6], pz, fma2(R[5], py, fma2(R[4], px, R[7])));
-        const f2v e1 = fma2(R[10], pz, fma2(R[9], py, fma2(R[8], px, R[11])));
-        const f2v e2 = fma2(R[14], pz, fma2(R[13], py, fma2(R[12], px, R[15])));
-        const f2v e3 = fma2(R[18], pz, fma2(R[17], py, fma2(R[16], px, R[19])));
-        const f2v mt = fma2(cm, __builtin_elementwise_abs(ind), c5 * __builtin_elementwise_abs(t));
+        const f2v e0 = fma2(R[6], pz, fma2(R[5], py, R[4] * px)) + R[7];
+        const f2v e1 = fma2(R[10], pz, fma2(R[9], py, R[8] * px)) + R[11];
+        const f2v e2 = fma2(R[14], pz, fma2(R[13], py, R[12] * px)) + R[15];
+        const f2v e3 = fma2(R[18], pz, fma2(R[17], py, R[16] * px)) + R[19];
+        f2v mt; mt.x = margin_t(cm, ind.x, t.x); mt.y = margin_t(cm, ind.y, t.y);
         // all slack values must be >= 0: t in [tmin - mt, tmax + mt] and P within delta of the inside of every edge (e_k carries + delta)
         // (the distance tolerance delta of the edge planes is folded into their constants at build time: e_k >= 0 means "within delta")
         const f2v a0 = (t + mt) - vtmin, a1 = (vtmax + mt) - t;
-        const float m0 = fminf(fminf(fminf(a0.x, a1.x), fminf(e0.x, e1.x)), fminf(e2.x, e3.x));
-        const float m1 = fminf(fminf(fminf(a0.y, a1.y), fminf(e0.y, e1.y)), fminf(e2.y, e3.y));
-        const bool c0 = (m0 >= 0.0f) || (fabsf(nd.x) < 1e-3f);      // grazing rays always go to the exact test
-        const bool c1 = (m1 >= 0.0f) || (fabsf(nd.y) < 1e-3f);
-        const uint32_t bit = 1u << ((2u * kp) & 31u);
-        const uint32_t add = (c0 ? bit : 0u) | (c1 ? (bit << 1) : 0u);
-        if (kp < 16u) cand_lo |= add; else cand_hi |= add;
+        const float m0 = fminf(fminf(fminf(a0.x, a1.x), e0.x), fminf(fminf(e1.x, e2.x), e3.x));
+        const float m1 = fminf(fminf(fminf(a0.y, a1.y), e0.y), fminf(fminf(e1.y, e2.y), e3.y));
+        const unsigned long long c0 = __builtin_amdgcn_ballot_w64(m0 >= 0.0f) | __builtin_amdgcn_ballot_w64(fabsf(nd.x) < 1e-3f);   // grazing rays always go to the exact test
+        const unsigned long long c1 = __builtin_amdgcn_ballot_w64(m1 >= 0.0f) | __builtin_amdgcn_ballot_w64(fabsf(nd.y) < 1e-3f);
+        acc = shift_in(shift_in(acc, c1), c0);                        // records run downwards, so record r ends up at bit r (mod 32)
+    };
+    // records 2kp+1, 2kp for kp = npairs-1 .. 0: the first 32 records collect in cand_lo, the rest in cand_hi
+#pragma unroll 1
+    for (uint32_t kp = npairs; kp > 16u; kp--) {        // wave-uniform
+        if (!((keep >> (2u * (kp - 1u))) & 3ull)) { cand_hi <<= 2; continue; }
+        pair(kp - 1u, cand_hi);
+    }
+#pragma unroll 1
+    for (uint32_t kp = npairs < 16u ? npairs : 16u; kp > 0u; kp--) {
+        if (!((keep >> (2u * (kp - 1u))) & 3ull)) { cand_lo <<= 2; continue; }
+        pair(kp - 1u, cand_lo);
     }
     unsigned long long cand = ((unsigned long long)cand_hi << 32) | cand_lo;
+    // bits >= nrec: the padding record of an odd count (zero plane: "grazing", always forwarded) or, for NEE segments, the first hull face
+    cand &= nrec >= 64u ? ~0ull : ((1ull << nrec) - 1ull);
     // (Testing only the triangle on the ray's side of a quad's diagonal would save one exact test per candidate; measured slower
     // both ways: at 4 waves/SIMD the ~4 extra VGPRs spill (28.4-28.9 ms instead of 27.6), at 3 waves/SIMD without spills 31.3 ms.)
     while (cand) {                                     // per-lane: exact test of the triangles of each candidate record
