@@ -609,12 +609,13 @@ static inline uint32_t grid_for(uint32_t items, uint32_t max_blocks) {
     if (b < 1) b = 1;
     return b < max_blocks ? b : max_blocks;
 }
+static inline size_t small_planes_bytes(const DevScene& sc) { return sc.nsmall ? (size_t)small_planes_count(sc.nsmall) * 16 : 0; }   // stage_lds
 size_t trace_lds_bytes(const DevScene& sc) {      // the LDS column stack is always reserved: debug / pass-1 kernels use it
-    return (size_t)sc.lds_nodes * 80 + (size_t)sc.lds_tris * 48 + (size_t)sc.stack_depth * kBlock * 8;
+    return (size_t)sc.lds_nodes * 80 + (size_t)sc.lds_tris * 48 + small_planes_bytes(sc) + (size_t)sc.stack_depth * kBlock * 8;
 }
 size_t trace_lds_bytes_queue(const DevScene& sc) {   // queue kernels with a private stack need no LDS stack
     const size_t stack = sc.stack_private == 1 ? 0 : (size_t)sc.stack_depth * kBlock * 8;
-    return (size_t)sc.lds_nodes * 80 + (size_t)sc.lds_tris * 48 + stack;
+    return (size_t)sc.lds_nodes * 80 + (size_t)sc.lds_tris * 48 + small_planes_bytes(sc) + stack;
 }
 
 void launch_raygen(hipStream_t st, const DevFrame& f, const DevPaths& p, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount) {

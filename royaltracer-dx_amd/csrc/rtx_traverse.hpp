@@ -37,8 +37,10 @@ typedef __attribute__((address_space(3))) v2u lds_u2;
 struct TraceLds {
     const lds_v4f* nodes;   // LDS copy of nodes [0, lds_nodes)
     const lds_v4f* tris;    // LDS copy of tris  [0, lds_tris)
+    const lds_v4f* planes;  // tiny scenes: plane (n, n.p0) of every pre-test record
     lds_u2* stack;          // [depth][kBlock] sibling-group entries
 };
+__host__ __device__ inline uint32_t small_planes_count(uint32_t nsmall) { return (nsmall + 1u) & ~1u; }
 
 // stage the top of the BVH and the first triangles into LDS (coalesced 16-B copies)
 __device__ __forceinline__ TraceLds stage_lds(const DevScene& sc, F4* lds_generic) {
@@ -47,8 +49,15 @@ __device__ __forceinline__ TraceLds stage_lds(const DevScene& sc, F4* lds_generi
     const v4f* gn = (const v4f*)sc.nodes; const v4f* gt = (const v4f*)(sc.nsmall ? sc.small_tris : sc.tris);
     for (uint32_t i = threadIdx.x; i < sc.lds_nodes * 5u; i += kBlock) ln[i] = gn[i];
     for (uint32_t i = threadIdx.x; i < sc.lds_tris * 3u; i += kBlock) lt[i] = gt[i];
-    L.nodes = ln; L.tris = lt;
-    L.stack = (lds_u2*)(lt + (size_t)sc.lds_tris * 3);
+    lds_v4f* lp = lt + (size_t)sc.lds_tris * 3;
+    const uint32_t npl = sc.nsmall ? small_planes_count(sc.nsmall) : 0u;
+    for (uint32_t i = threadIdx.x; i < npl; i += kBlock) {                    // rows 0-3 of SmallRecPair: the record's plane
+        const float* r = &sc.small[i >> 1].r[0][i & 1u];
+        const v4f pl = {r[0], r[2], r[4], r[6]};
+        lp[i] = pl;
+    }
+    L.nodes = ln; L.tris = lt; L.planes = lp;
+    L.stack = (lds_u2*)(lp + npl);
     return L;
 }
 
@@ -266,6 +275,7 @@ __device__ __forceinline__ void traverse_small(const DevScene& sc, const SmallRe
     // constants are ADDED from SGPRs after the three FMAs (a VOP3P instruction takes one scalar operand, so an FMA addend from
     // SGPRs costs two v_mov), |x| rides on source modifiers of unpacked instructions, six slacks reduce through two min3 + one
     // min, and each record's verdict is shifted into the candidate word with ONE v_addc_co (carry-in = the compare mask).
+    uint32_t near = ~0u;
     auto pair = [&](uint32_t kp, uint32_t& acc) {
         const f2v* __restrict__ R = (const f2v*)sp[kp].r;
         const f2v nd = fma2(R[2], dz, fma2(R[1], dy, R[0] * dx));
@@ -286,6 +296,11 @@ __device__ __forceinline__ void traverse_small(const DevScene& sc, const SmallRe
         const unsigned long long c0 = __builtin_amdgcn_ballot_w64(m0 >= 0.0f) | __builtin_amdgcn_ballot_w64(fabsf(nd.x) < 1e-3f);   // grazing rays always go to the exact test
         const unsigned long long c1 = __builtin_amdgcn_ballot_w64(m1 >= 0.0f) | __builtin_amdgcn_ballot_w64(fabsf(nd.y) < 1e-3f);
         acc = shift_in(shift_in(acc, c1), c0);                        // records run downwards, so record r ends up at bit r (mod 32)
+        if (!ANY) {     // nearest candidate so far, as one sortable word: plane distance bits (positive floats order like integers) | record index
+            const uint32_t k0 = (f2u(t.x) & ~63u) | (2u * kp), k1 = (f2u(t.y) & ~63u) | (2u * kp + 1u);
+            const bool in0 = (m0 >= 0.0f) || (fabsf(nd.x) < 1e-3f), in1 = (m1 >= 0.0f) || (fabsf(nd.y) < 1e-3f);
+            near = min(near, min(in0 ? k0 : ~0u, in1 ? k1 : ~0u));
+        }
     };
     // records 2kp+1, 2kp for kp = npairs-1 .. 0: the first 32 records collect in cand_lo, the rest in cand_hi
 #pragma unroll 1
@@ -303,19 +318,51 @@ __device__ __forceinline__ void traverse_small(const DevScene& sc, const SmallRe
     cand &= nrec >= 64u ? ~0ull : ((1ull << nrec) - 1ull);
     // (Testing only the triangle on the ray's side of a quad's diagonal would save one exact test per candidate; measured slower
     // both ways: at 4 waves/SIMD the ~4 extra VGPRs spill (28.4-28.9 ms instead of 27.6), at 3 waves/SIMD without spills 31.3 ms.)
-    while (cand) {                                     // per-lane: exact test of the triangles of each candidate record
-        const uint32_t k = (uint32_t)__builtin_ctzll(cand);
-        cand &= cand - 1ull;
+    auto exact = [&](uint32_t k) -> bool {              // both triangles of record k; true = an any-hit ray is done
 #pragma unroll
         for (uint32_t h = 0; h < 2u; h++) {
             const lds_v4f* tp = L.tris + (2u * k + h) * 3u;
             const v4f v0 = tp[0], e1 = tp[1], e2 = tp[2];
             float t, u, w;
             if (tri_test(o, d, v0, e1, e2, tmin, tmax, t, u, w)) {
-                if (ANY) { bprim = 0u; return; }
+                if (ANY) { bprim = 0u; return true; }
                 const uint32_t gid = f2u(v0.w);
                 if (t < bt || (t == bt && gid < bprim)) { bt = t; bu = u; bv = w; bprim = gid; }
             }
+        }
+        return false;
+    };
+    if (ANY) {
+        while (cand) {                                 // per-lane: exact test of the triangles of each candidate record
+            const uint32_t k = (uint32_t)__builtin_ctzll(cand);
+            cand &= cand - 1ull;
+            if (exact(k)) return;
+        }
+        return;
+    }
+    // Closest hit: a wave pays for the LONGEST candidate list among its lanes, and a ray through a room crosses 1-4 record
+    // planes inside their polygons.  So each lane tests its NEAREST candidate first (phase 1 tracked it), and every further
+    // candidate must first pass the phase-1 distance test again with the current best hit as the far end: it is skipped when its
+    // plane distance minus the margin lies beyond bt (then its exact t is > bt: it can neither win nor tie).  Iterations in
+    // which no lane has a surviving candidate skip the exact tests altogether.
+    if (!cand) return;
+    uint32_t k = near & 63u;
+    if (!((cand >> k) & 1ull)) k = (uint32_t)__builtin_ctzll(cand);      // (the masked padding record can be "nearest")
+    cand &= ~(1ull << k);
+    bool go = true;
+    while (go) {
+        exact(k);
+        go = false;
+        while (cand) {
+            k = (uint32_t)__builtin_ctzll(cand);
+            cand &= cand - 1ull;
+            const v4f pl = L.planes[k];
+            const float nd = __builtin_fmaf(pl.z, d.z, __builtin_fmaf(pl.y, d.y, pl.x * d.x));
+            const float no = pl.w - __builtin_fmaf(pl.z, o.z, __builtin_fmaf(pl.y, o.y, pl.x * o.x));
+            const float ind = __builtin_amdgcn_rcpf(nd);
+            const float t = no * ind;
+            const float mt = margin_t(cm, ind, t);
+            if ((fabsf(nd) < 1e-3f) || !((t - mt) > bt)) { go = true; break; }
         }
     }
 }
