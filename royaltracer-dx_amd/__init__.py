@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtx_hip.so")
+LIB_PATH = os.environ.get("RTX_LIB_PATH") or os.path.join(_HERE, "librtx_hip.so")   # RTX_LIB_PATH: tooling builds (make PROFILE=1)
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

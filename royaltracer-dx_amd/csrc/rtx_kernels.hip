@@ -23,6 +23,16 @@
 
 namespace rtx {
 
+#ifdef RTX_PROFILE_SECTIONS
+__device__ unsigned long long g_sec[12];
+#define PF_BEGIN Prof pfv; pfv.begin(); Prof* pf = &pfv
+#define PF_MARK(i) pf->mark(i)
+#define PF_FLUSH do { if (lane_id() == 0) for (int i = 0; i < 12; i++) atomicAdd(&g_sec[i], pfv.acc[i]); } while (0)
+#else
+#define PF_BEGIN Prof* pf = nullptr; (void)pf
+#define PF_MARK(i) do { } while (0)
+#define PF_FLUSH do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // raygen: one thread per path slot of the batch
@@ -315,15 +325,18 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
     const uint32_t* myq = queue + qb;
     uint32_t* mynext = next_queue + qb;
     uint32_t par = 0;
+    PF_BEGIN;
     for (uint32_t base = 0; base < n; base += kBlock) {     // the same trip count for all four waves (barriers inside)
         const uint32_t i = base + threadIdx.x;
         const bool active = i < n;
         PathState S; S.pid = 0; S.o = mk3(0, 0, 0); S.d = mk3(0, 0, 1); S.thr = mk3(0, 0, 0); S.prev_pdf = 1.0f; S.s0 = S.s1 = 0;
         if (active) S = load_path(p, myq[i]);
         float t = 0.0f, u = 0.0f, v = 0.0f; uint32_t prim = kMissPrim;
+        PF_MARK(0);
         if (HAVE_HIT) {                                   // bounce 0: the primary hit comes from k_raygen_trace_small
             if (active) { const F4 h = p.hit[S.pid]; t = h.x; u = h.y; v = h.z; prim = f2u(h.w); }
-        } else traverse_small<false>(sc, small, L, S.o, S.d, tmin, active ? kTMax : 0.0f, t, u, v, prim, sc.nsmall);   // inactive lanes: empty interval
+        } else traverse_small<false>(sc, small, L, S.o, S.d, tmin, active ? kTMax : 0.0f, t, u, v, prim, sc.nsmall, ~0ull, pf, 1);   // inactive lanes: empty interval
+        PF_MARK(2);
         Surf sf; sf.mat = 0; sf.normal = mk3(0, 0, 1); sf.pos = mk3(0, 0, 0);
         bool shading = false;
         if (active && prim != kMissPrim) {
@@ -338,23 +351,28 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
         const MatGPU* mp = sc.mats + (shading ? sf.mat : 0u);
         // bounce 0 (HAVE_HIT): nothing has written this path's radiance slot yet: it starts from zero here and is always stored
         bool loaded = HAVE_HIT && shading; F4 radv = {0, 0, 0, 0};
+        PF_MARK(3);
         for (uint32_t j = 0; j < nee; j++) {
             bool push = false;
             F4 so = {0, 0, 0, 0}, sd = {0, 0, 1, 0}; f3 con = mk3(0, 0, 0);
             if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con);
+            PF_MARK(4);
             const uint32_t slot = block_push(push, &s_shn[par]);
             if (push) { s_sho[slot] = so; s_shd[slot] = sd; }
             __syncthreads();
+            PF_MARK(5);
             const uint32_t ns = s_shn[par];
             if ((threadIdx.x & ~63u) < ns) {                                   // wave-uniform: this wave has rays to trace
                 const bool mine = threadIdx.x < ns;
                 const F4 ro = mine ? s_sho[threadIdx.x] : F4{0, 0, 0, 0}, rd = mine ? s_shd[threadIdx.x] : F4{0, 0, 1, 0};
                 float st_, su_, sv_; uint32_t sprim;
-                traverse_small<true>(sc, small, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, mine ? rd.w : 0.0f, st_, su_, sv_, sprim, sc.nsmall_occ);
+                traverse_small<true>(sc, small, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, mine ? rd.w : 0.0f, st_, su_, sv_, sprim, sc.nsmall_occ, ~0ull, pf, 6);
                 if (mine) s_occ[threadIdx.x] = sprim != kMissPrim ? 1 : 0;
             }
+            PF_MARK(7);
             if (threadIdx.x == 0) { s_shn[par ^ 1u] = 0; s_cnt[1 + j] += ns; }
             __syncthreads();
+            PF_MARK(8);
             if (push && !s_occ[slot]) {
                 if (!loaded) { radv = p.rad[S.pid]; loaded = true; }
                 radv.x = radv.x + con.x; radv.y = radv.y + con.y; radv.z = radv.z + con.z;
@@ -368,7 +386,9 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
         if (alive) store_path(p, S, pos, smp, P);
         const uint32_t slot = block_push(alive, &s_cnt[0]);
         if (alive) mynext[slot] = S.pid;
+        PF_MARK(9);
     }
+    PF_FLUSH;
     __syncthreads();
     if (threadIdx.x == 0) next_count[blockIdx.x] = s_cnt[0];
     if (threadIdx.x >= 1 && threadIdx.x <= nee) shcounts[(size_t)(threadIdx.x - 1) * gridDim.x + blockIdx.x] = s_cnt[threadIdx.x];
@@ -698,3 +718,13 @@ void launch_dbg_primary(hipStream_t st, const DevFrame& f, const CameraGPU* cam,
 }
 
 }  // namespace rtx
+
+#ifdef RTX_PROFILE_SECTIONS
+// tooling entry point of the PROFILE=1 build only (tools/section_profile.py): read (and optionally clear) the section counters
+extern "C" int rtx_debug_sections(unsigned long long* out12, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out12 && hipMemcpyFromSymbol(out12, HIP_SYMBOL(rtx::g_sec), sizeof(unsigned long long) * 12) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[12] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rtx::g_sec), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif

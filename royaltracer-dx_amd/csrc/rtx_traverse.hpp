@@ -5,6 +5,21 @@
 
 namespace rtx {
 
+// Section profiler (tooling only: `make PROFILE=1`, tools/section_profile.py): s_memtime deltas per code section, summed per wave
+// and flushed to g_sec[] by lane 0.  With several waves per SIMD the deltas include the other waves' issue slots, so the SHARES
+// are meaningful, not the absolute cycle counts.  Compiled out of the product library.
+#ifdef RTX_PROFILE_SECTIONS
+struct Prof {
+    unsigned long long t, acc[12];
+    __device__ __forceinline__ void begin() { t = __builtin_readcyclecounter(); for (int i = 0; i < 12; i++) acc[i] = 0; }
+    __device__ __forceinline__ void mark(int i) { const unsigned long long n = __builtin_readcyclecounter(); acc[i] += n - t; t = n; }
+};
+#define RTX_PROF_MARK(pf, i) do { if (pf) (pf)->mark(i); } while (0)
+#else
+struct Prof {};
+#define RTX_PROF_MARK(pf, i) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // BVH traversal
 // ---------------------------------------------------------------------------------------------
@@ -262,7 +277,7 @@ __device__ __forceinline__ void traverse_stats(const DevScene& sc, const TraceLd
 
 template <bool ANY>
 __device__ __forceinline__ void traverse_small(const DevScene& sc, const SmallRecPair* __restrict__ sp, const TraceLds& L, f3 o, f3 d, float tmin, float tmax,
-                                               float& bt, float& bu, float& bv, uint32_t& bprim, uint32_t nrec, unsigned long long keep = ~0ull) {
+                                               float& bt, float& bu, float& bv, uint32_t& bprim, uint32_t nrec, unsigned long long keep = ~0ull, Prof* pf = nullptr, int pf_sec = 0) {
     // keep (wave-uniform): bit r clear = no ray of this wave can touch record r (primary-ray packet culling); nrec = sc.nsmall, or sc.nsmall_occ for NEE shadow segments (both end points inside the scene's convex hull: the records
     // after the first nsmall_occ are faces OF that hull and cannot lie between them, rtx_scene_host.cpp)
     bt = tmax; bu = 0.0f; bv = 0.0f; bprim = kMissPrim;
@@ -313,6 +328,7 @@ __device__ __forceinline__ void traverse_small(const DevScene& sc, const SmallRe
         if (!((keep >> (2u * (kp - 1u))) & 3ull)) { cand_lo <<= 2; continue; }
         pair(kp - 1u, cand_lo);
     }
+    RTX_PROF_MARK(pf, pf_sec);
     unsigned long long cand = ((unsigned long long)cand_hi << 32) | cand_lo;
     // bits >= nrec: the padding record of an odd count (zero plane: "grazing", always forwarded) or, for NEE segments, the first hull face
     cand &= nrec >= 64u ? ~0ull : ((1ull << nrec) - 1ull);
