@@ -9,12 +9,27 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_oracle.so")
+
+
+def _cpu_has_fma():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return " fma " in line + " "
+    except OSError:
+        pass
+    return False
+
+
+# same source, same results (fmaf is correctly rounded with or without hardware FMA): the -mfma build is only faster
+LIB_NAME = "librt_oracle_fma.so" if (_cpu_has_fma() and os.environ.get("ORC_NO_FMA_BUILD", "0") != "1") else "librt_oracle.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 
 def build(force=False):
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "rt_oracle.c")):
-        subprocess.check_call(["make", "-C", _HERE, "librt_oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "librt_oracle.so", "librt_oracle_fma.so"], stdout=subprocess.DEVNULL)
 
 
 build()

@@ -39,9 +39,13 @@ static inline v3 sub3(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); 
 static inline v3 mul3(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
 static inline v3 scale3(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
 static inline v3 neg3(v3 a) { return V3(-a.x, -a.y, -a.z); }
-static inline float dot3(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+/* DEVIATION (fused multiply-add): dot, cross and the matrix-vector products contract a*b + c into ONE rounding, fmaf, in a fixed
+   nesting.  HLSL leaves mul/add chains free to become `mad`/FMA (no `precise`), and every GPU driver compiler does so, so neither
+   form is "the" reference result; the HIP kernels issue v_fma_f32 at exactly these sites (csrc/rtx_math.hpp).  fmaf is correctly
+   rounded with or without hardware FMA, so the oracle's results do not depend on the build flags (see Makefile). */
+static inline float dot3(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 static inline v3 cross3(v3 a, v3 b) {
-    return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+    return V3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
 static inline float length3(v3 a) { return sqrtf(dot3(a, a)); }
 /* HLSL normalize(v) = v * rsqrt(dot(v,v)); restated with IEEE sqrt and divide */
@@ -159,15 +163,15 @@ void orc_mat4_inverse(const float* mf, float* out) {
 }
 /* mul(M, float4(p,1)).xyz */
 static inline v3 xform_point(const float* m, v3 p) {
-    return V3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
-              m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
-              m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
+    return V3(fmaf(m[8], p.z, fmaf(m[4], p.y, fmaf(m[0], p.x, m[12]))),
+              fmaf(m[9], p.z, fmaf(m[5], p.y, fmaf(m[1], p.x, m[13]))),
+              fmaf(m[10], p.z, fmaf(m[6], p.y, fmaf(m[2], p.x, m[14]))));
 }
 /* mul(M, float4(v,0)).xyz */
 static inline v3 xform_dir(const float* m, v3 p) {
-    return V3(m[0] * p.x + m[4] * p.y + m[8] * p.z,
-              m[1] * p.x + m[5] * p.y + m[9] * p.z,
-              m[2] * p.x + m[6] * p.y + m[10] * p.z);
+    return V3(fmaf(m[8], p.z, fmaf(m[4], p.y, m[0] * p.x)),
+              fmaf(m[9], p.z, fmaf(m[5], p.y, m[1] * p.x)),
+              fmaf(m[10], p.z, fmaf(m[6], p.y, m[2] * p.x)));
 }
 
 /* ---- scene ---- */
@@ -461,9 +465,10 @@ static inline int box_hit(const node_t* n, v3 o, v3 d, v3 inv, float tmin, float
         float lo = minf(t1, t2), hi = maxf(t1, t2);
         te = maxf(te, lo); tx = minf(tx, hi);
     }
-    /* generous: the margins must cover the error of tri_hit's t (up to ~1e-5 relative next to a vertex of a small far
-       triangle), not only the slab arithmetic; the oracle's BVH only has to be conservative, not fast */
-    te = te - fabsf(te) * 1e-4f; tx = tx + fabsf(tx) * 1e-4f;
+    /* generous: the margins must cover the error of tri_hit's t, not only the slab arithmetic: ~1e-5 relative next to a vertex of a
+       small far triangle, and 1e-3 for a ray almost parallel to the triangle (tests/test_gpu_parity.py, "duplicates" soup: a
+       coincident duplicate lost its lowest-id tie at 1e-4).  The oracle's BVH only has to be conservative, not fast. */
+    te = te - fabsf(te) * 4e-3f; tx = tx + fabsf(tx) * 4e-3f;
     return te <= tx && tx >= tmin && te <= tbest;
 }
 static hit_t closest_bvh(const orc_ctx* c, v3 o, v3 d, float tmin, float tmax) {

@@ -37,8 +37,11 @@ RTX_HD f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 RTX_HD f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 RTX_HD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 RTX_HD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
-RTX_HD float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-RTX_HD f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+// dot, cross and the matrix-vector products are FUSED (one rounding per a*b + c, fixed nesting; oracle/rt_oracle.c does the same with
+// fmaf): HLSL lets mul/add chains become mad/FMA, so this is as much "the reference result" as the unfused form, and it is what keeps
+// the VALU-bound kernels short (tri_test 41 -> 27 instructions).  Everything else stays unfused (-ffp-contract=off).
+RTX_HD float dot(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+RTX_HD f3 cross(f3 a, f3 b) { return mk3(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)), __builtin_fmaf(a.x, b.y, -(a.y * b.x))); }
 RTX_HD float length(f3 a) { return sqrtf(dot(a, a)); }
 RTX_HD f3 normalize(f3 a) { float inv = 1.0f / sqrtf(dot(a, a)); return a * inv; }
 RTX_HD float saturate(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
@@ -127,14 +130,14 @@ RTX_HD float pow_(float x, float y) {
 
 // mul(M, float4(p,1)).xyz / mul(M, float4(v,0)).xyz for the column-major 16-float layout of rtx.h
 RTX_HD f3 xform_point(const float* m, f3 p) {
-    return mk3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
-               m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
-               m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
+    return mk3(__builtin_fmaf(m[8], p.z, __builtin_fmaf(m[4], p.y, __builtin_fmaf(m[0], p.x, m[12]))),
+               __builtin_fmaf(m[9], p.z, __builtin_fmaf(m[5], p.y, __builtin_fmaf(m[1], p.x, m[13]))),
+               __builtin_fmaf(m[10], p.z, __builtin_fmaf(m[6], p.y, __builtin_fmaf(m[2], p.x, m[14]))));
 }
 RTX_HD f3 xform_dir(const float* m, f3 p) {
-    return mk3(m[0] * p.x + m[4] * p.y + m[8] * p.z,
-               m[1] * p.x + m[5] * p.y + m[9] * p.z,
-               m[2] * p.x + m[6] * p.y + m[10] * p.z);
+    return mk3(__builtin_fmaf(m[8], p.z, __builtin_fmaf(m[4], p.y, m[0] * p.x)),
+               __builtin_fmaf(m[9], p.z, __builtin_fmaf(m[5], p.y, m[1] * p.x)),
+               __builtin_fmaf(m[10], p.z, __builtin_fmaf(m[6], p.y, m[2] * p.x)));
 }
 
 }  // namespace rtx
