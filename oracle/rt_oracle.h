@@ -78,6 +78,7 @@ size_t orc_pass1_slots(uint32_t width, uint32_t height);
 void orc_tea(uint32_t seed[2], uint32_t n, float* out);
 void orc_seed_init(uint32_t x, uint32_t y, uint32_t s, uint32_t frame_seed, uint32_t out[2]);
 void orc_sincos(float x, float* s, float* c);
+void orc_rsqrt(const float* x, uint32_t n, float* out);   /* the deterministic rsqrt behind normalize() */
 float orc_pow(float x, float y);
 float orc_half_round(float x);
 void orc_mat4_inverse(const float* m16, float* out16);

@@ -68,6 +68,24 @@ def test_sincos_and_pow_accuracy(orc):
     assert np.abs(got / np.power(xs.astype(np.float64), 1.0 / 2.4) - 1.0).max() < 2e-6
 
 
+def test_rsqrt_det_is_within_one_ulp(orc):
+    """the deterministic rsqrt behind normalize() (integer seed + three Newton steps, executed identically by the kernels) against
+    float64: HLSL's rsqrt is a 1-ULP approximation, this one must be at least as good over the whole normal range"""
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([np.exp(rng.uniform(np.log(1e-30), np.log(1e30), 200000)), rng.uniform(0.25, 4.0, 200000),
+                         [1.0, 2.0, 4.0, 0.5, 3.0, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24, 2.0 - 2.0 ** -23, 1e-37, 3e38]]).astype(np.float32)
+    got = orc.rsqrt(xs).astype(np.float64)
+    ref = 1.0 / np.sqrt(xs.astype(np.float64))
+    ulp = np.spacing(ref.astype(np.float32)).astype(np.float64)
+    err = np.abs(got - ref) / ulp
+    assert err.max() < 1.0, err.max()
+    # unit vectors stay unit vectors: |normalize(v)| = 1 within 2 ulp
+    v = rng.normal(size=(100000, 3)).astype(np.float32)
+    n2 = (v.astype(np.float64) ** 2).sum(1)
+    y = orc.rsqrt((v[:, 2] * v[:, 2] + (v[:, 1] * v[:, 1] + v[:, 0] * v[:, 0])).astype(np.float32)).astype(np.float64)
+    assert np.abs(np.sqrt(n2) * y - 1.0).max() < 3e-7
+
+
 def test_mat4_inverse_vs_numpy(orc):
     rng = np.random.default_rng(1)
     for _ in range(50):
