@@ -42,7 +42,8 @@ struct rtx_ctx {
     DevScene dsc{};
     float view[16], proj[16];
     // path state
-    DevBuf d_hitmask;
+    DevBuf d_hitmask, d_order;
+    bool lpt_order = true;          // RTX_OPT_LPT_ORDER: fused kernels take their sub-queues longest first
     DevBuf d_ray_o, d_ray_d, d_thr, d_rad, d_hit, d_sh_o, d_sh_d, d_sh_c, d_queue[2], d_counters;
     uint32_t* h_counters = nullptr; size_t h_counters_words = 0;
     // accumulation
@@ -103,7 +104,7 @@ void rtx_destroy(rtx_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_small_poly, &c->d_objtris, &c->d_node_aabb, &c->d_scale, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
-                     &c->d_thr, &c->d_rad, &c->d_hit, &c->d_hitmask, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
+                     &c->d_thr, &c->d_rad, &c->d_hit, &c->d_hitmask, &c->d_order, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
                      &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt};
     for (DevBuf* b : all) b->release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
@@ -127,6 +128,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_FUSED_BOUNCE: c->fused = value != 0; return RTX_OK;
     case RTX_OPT_BOUNCE_VARIANT: return RTX_OK;         // retired knob (only the 4-waves/SIMD build of the fused kernel is kept): accepted, ignored
     case RTX_OPT_STACK_PRIVATE: c->stack_private = (int)value; c->committed = false; return RTX_OK;
+    case RTX_OPT_LPT_ORDER: c->lpt_order = value != 0; return RTX_OK;
     case RTX_OPT_BLOCKS_PER_CU: if (value < 0 || value > 64) { c->err = "blocks_per_cu must be in [0, 64]"; return RTX_ERR_INVALID; } c->blocks_per_cu = (uint32_t)value; return RTX_OK;
     case RTX_OPT_GPU_REFIT: c->gpu_refit = value != 0; return RTX_OK;
     case RTX_OPT_TRACE_SCHED: if (value > 7) { c->err = "trace_sched must be in [0, 7]"; return RTX_ERR_INVALID; } c->trace_sched = (uint32_t)value; c->dsc.trace_sched = c->trace_sched; return RTX_OK;
@@ -339,9 +341,10 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     HIPCHK(c, c->d_ray_o.ensure((size_t)cap * 16)); HIPCHK(c, c->d_ray_d.ensure((size_t)cap * 16));
     HIPCHK(c, c->d_thr.ensure((size_t)cap * 16)); HIPCHK(c, c->d_rad.ensure((size_t)cap * 16)); HIPCHK(c, c->d_hit.ensure((size_t)cap * 16));
     // work distribution: G workgroups, each with a private sub-queue (no global atomics in the loop)
-    // sub-queues per CU: shorter tails with more, but more per-workgroup overhead; measured optimum 24 for the fused tiny-scene
-    // kernels (26.2 ms vs 26.5 at 16, 27.7 at 8) and 16 for the general path (49.3 / 42.2 ms vs 53.0 / 44.2 at 8)
-    const uint32_t bpc = c->blocks_per_cu ? c->blocks_per_cu : (c->dsc.nsmall && c->fused ? 24u : 16u);
+    // sub-queues per CU: shorter tails with more, but more per-workgroup overhead; measured optimum for the fused tiny-scene kernels
+    // 40 with the longest-first dispatch order (20.7 ms; 21.3 / 20.9 / 20.8 / 20.8 at 12 / 24 / 32 / 48; it was 24 in index order) and
+    // 16 for the general path (49.3 / 42.2 ms vs 53.0 / 44.2 at 8)
+    const uint32_t bpc = c->blocks_per_cu ? c->blocks_per_cu : (c->dsc.nsmall && c->fused ? 40u : 16u);
     const uint32_t max_blocks = (uint32_t)c->num_cus * bpc;
     const uint32_t nchunks = f.chunks_per_sample * bspp;
     const uint32_t G = std::max<uint32_t>(1, std::min<uint32_t>(nchunks, max_blocks));
@@ -349,6 +352,7 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     f.nblocks = G; f.qcap = qcap;
     const size_t qtot = (size_t)G * qcap;
     HIPCHK(c, c->d_queue[0].ensure(qtot * 4)); HIPCHK(c, c->d_queue[1].ensure(qtot * 4));
+    HIPCHK(c, c->d_order.ensure((size_t)G * 4));
     const uint32_t nee1 = std::max<uint32_t>(nee, 1);
     const size_t shn = qtot * nee1;
     HIPCHK(c, c->d_sh_o.ensure(shn * 16)); HIPCHK(c, c->d_sh_d.ensure(shn * 16)); HIPCHK(c, c->d_sh_c.ensure(shn * 16));
@@ -388,10 +392,14 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
         uint32_t* gen_row = cnt + ((size_t)(mb + 1) + (size_t)mb * nee1) * G;
         if (fused) { Timed t(c, RTX_K_RAYGEN); launch_raygen_trace_small(st, c->dsc, fb, P, cam, queue[0], Q(0), gen_row); }
         else { Timed t(c, RTX_K_RAYGEN); launch_raygen(st, fb, P, cam, queue[0], Q(0)); }
+        // dispatch order of the fused bounce kernels: longest sub-queue first, from the lengths after the primary rays (the later
+        // bounces keep the ranking: survivors are a near-constant fraction)
+        const uint32_t* order = nullptr;
+        if (fused && c->lpt_order && G > 1) { launch_order_queues(st, Q(0), G, (uint32_t*)c->d_order.p); order = (const uint32_t*)c->d_order.p; }
         for (uint32_t b = 0; b < mb; b++) {
             uint32_t* q = queue[b & 1]; uint32_t* qn = queue[(b + 1) & 1];
             if (fused) {      // tiny scene: trace + shade + shadow fused into one kernel per bounce (bounce 0 was traced by raygen)
-                Timed t(c, RTX_K_BOUNCE); launch_bounce_small(st, c->dsc, fb, P, b, b == 0, q, Q(b), qn, Q(b + 1), S(b, 0));
+                Timed t(c, RTX_K_BOUNCE); launch_bounce_small(st, c->dsc, fb, P, b, b == 0, q, Q(b), qn, Q(b + 1), S(b, 0), order);
                 continue;
             }
             { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, fb, c->dsc, P, b, q, Q(b)); }

@@ -305,9 +305,11 @@ template <int WAVES, bool HAVE_HIT>
 __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, const SmallRecPair* __restrict__ small, DevFrame f, DevPaths p, uint32_t bounce,
                                                          const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount,
                                                          uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count,
-                                                         uint32_t* __restrict__ shcounts /* [nee][gridDim.x]: shadow rays traced (statistics) */) {
+                                                         uint32_t* __restrict__ shcounts /* [nee][gridDim.x]: shadow rays traced (statistics) */,
+                                                         const uint32_t* __restrict__ order /* workgroup -> sub-queue, longest first (k_order_queues); may be null */) {
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_cnt[1 + kMaxNee];
+    const uint32_t qid = order ? order[blockIdx.x] : blockIdx.x;      // the sub-queue this workgroup owns (input and output)
     // NEE shadow rays of the workgroup's 256 current items are compacted through LDS, so that the shadow traversal runs on
     // ceil(rays / 64) full waves instead of on every wave at ~2/3 occupancy (only ~65 % of the items get a shadow ray)
     __shared__ F4 s_sho[kBlock], s_shd[kBlock];
@@ -315,13 +317,13 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
     __shared__ uint8_t s_occ[kBlock];
     if (threadIdx.x <= kMaxNee) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x < 2) s_shn[threadIdx.x] = 0;
-    const uint32_t n = qcount[blockIdx.x];
+    const uint32_t n = qcount[qid];
     const uint32_t nee = sc.nlights ? f.nee_samples : 0u;
     const TraceLds L = stage_lds(sc, lds);
     __syncthreads();
     const bool last = (bounce + 1u == f.max_bounces);
     const float tmin = bounce_tmin(bounce);
-    const size_t qb = (size_t)blockIdx.x * f.qcap;
+    const size_t qb = (size_t)qid * f.qcap;
     const uint32_t* myq = queue + qb;
     uint32_t* mynext = next_queue + qb;
     uint32_t par = 0;
@@ -390,8 +392,40 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
     }
     PF_FLUSH;
     __syncthreads();
-    if (threadIdx.x == 0) next_count[blockIdx.x] = s_cnt[0];
-    if (threadIdx.x >= 1 && threadIdx.x <= nee) shcounts[(size_t)(threadIdx.x - 1) * gridDim.x + blockIdx.x] = s_cnt[threadIdx.x];
+    if (threadIdx.x == 0) next_count[qid] = s_cnt[0];
+    if (threadIdx.x >= 1 && threadIdx.x <= nee) shcounts[(size_t)(threadIdx.x - 1) * gridDim.x + qid] = s_cnt[threadIdx.x];
+}
+
+// Longest sub-queue first.  The sub-queues of a batch differ in length by ~12 % (std; each is a sample of ~84 of the image's 8100
+// 256-pixel regions, 43 % of which are background on the Cornell view) and a launch has only ~6 workgroups per resident slot, so in
+// blockIdx order the last dispatch round is ragged: 3.4 of 4 waves per SIMD resident on average.  The hardware dispatches
+// workgroups in blockIdx order, so handing the longest sub-queues out first (LPT list scheduling) lets the short ones fill the end.
+// One workgroup, counting sort by length into 1024 buckets (descending); the order inside a bucket is arbitrary (LDS atomics) and
+// never matters: every sub-queue is processed independently, results and statistics do not depend on the dispatch order.
+__global__ __launch_bounds__(1024) void k_order_queues(const uint32_t* __restrict__ qcount, uint32_t G, uint32_t* __restrict__ order) {
+    __shared__ uint32_t s_max, s_hist[1024], s_scan[1024];
+    if (threadIdx.x == 0) s_max = 0;
+    s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t m = 0;
+    for (uint32_t g = threadIdx.x; g < G; g += 1024u) m = max(m, qcount[g]);
+    atomicMax(&s_max, m);
+    __syncthreads();
+    const uint64_t mx = s_max ? s_max : 1u;
+    for (uint32_t g = threadIdx.x; g < G; g += 1024u) atomicAdd(&s_hist[1023u - (uint32_t)((uint64_t)qcount[g] * 1023u / mx)], 1u);
+    __syncthreads();
+    uint32_t v = s_hist[threadIdx.x];
+    s_scan[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {                 // inclusive scan (Hillis-Steele)
+        const uint32_t t = threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s_scan[threadIdx.x] += t;
+        __syncthreads();
+    }
+    s_hist[threadIdx.x] = s_scan[threadIdx.x] - v;            // bucket start
+    __syncthreads();
+    for (uint32_t g = threadIdx.x; g < G; g += 1024u) order[atomicAdd(&s_hist[1023u - (uint32_t)((uint64_t)qcount[g] * 1023u / mx)], 1u)] = g;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -650,10 +684,13 @@ void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc,
     else hipLaunchKernelGGL(k_trace_closest<0>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, sc.refill_min, sc.trace_sched);
 }
 void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce, bool have_hit,
-                         const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts) {
-    // 4 waves/SIMD (114 VGPRs, no spills); forcing 5 or 6 spills to scratch and measured 6 % / 16 % slower
-    if (have_hit) hipLaunchKernelGGL((k_bounce_small<4, true>), dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);
-    else hipLaunchKernelGGL((k_bounce_small<4, false>), dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);
+                         const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts, const uint32_t* order) {
+    // 4 waves/SIMD (no spills); forcing 5 or 6 spills to scratch and measured 6 % / 16 % slower
+    if (have_hit) hipLaunchKernelGGL((k_bounce_small<4, true>), dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, bounce, queue, qcount, next_queue, next_count, shcounts, order);
+    else hipLaunchKernelGGL((k_bounce_small<4, false>), dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, bounce, queue, qcount, next_queue, next_count, shcounts, order);
+}
+void launch_order_queues(hipStream_t st, const uint32_t* qcount, uint32_t G, uint32_t* order) {
+    hipLaunchKernelGGL(k_order_queues, dim3(1), dim3(1024), 0, st, qcount, G, order);
 }
 void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t j, const uint32_t* shcount) {
     const size_t seg = (size_t)j * f.qcap * f.nblocks;
