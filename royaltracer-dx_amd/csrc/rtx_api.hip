@@ -126,7 +126,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_LDS_NODES: c->lds_nodes_opt = (int)value; c->committed = false; return RTX_OK;
     case RTX_OPT_SMALL_SCENE: c->small_scene = value != 0; c->committed = false; return RTX_OK;
     case RTX_OPT_FUSED_BOUNCE: c->fused = value != 0; return RTX_OK;
-    case RTX_OPT_BOUNCE_VARIANT: return RTX_OK;         // retired knob (only the 4-waves/SIMD build of the fused kernel is kept): accepted, ignored
+    case RTX_OPT_BOUNCE_VARIANT: return RTX_OK;         // retired knob (forced waves/SIMD builds of the fused kernel measured no faster): accepted, ignored
     case RTX_OPT_STACK_PRIVATE: c->stack_private = (int)value; c->committed = false; return RTX_OK;
     case RTX_OPT_LPT_ORDER: c->lpt_order = value != 0; return RTX_OK;
     case RTX_OPT_BLOCKS_PER_CU: if (value < 0 || value > 64) { c->err = "blocks_per_cu must be in [0, 64]"; return RTX_ERR_INVALID; } c->blocks_per_cu = (uint32_t)value; return RTX_OK;
@@ -341,10 +341,10 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     HIPCHK(c, c->d_ray_o.ensure((size_t)cap * 16)); HIPCHK(c, c->d_ray_d.ensure((size_t)cap * 16));
     HIPCHK(c, c->d_thr.ensure((size_t)cap * 16)); HIPCHK(c, c->d_rad.ensure((size_t)cap * 16)); HIPCHK(c, c->d_hit.ensure((size_t)cap * 16));
     // work distribution: G workgroups, each with a private sub-queue (no global atomics in the loop)
-    // sub-queues per CU: shorter tails with more, but more per-workgroup overhead; measured optimum for the fused tiny-scene kernels
-    // 40 with the longest-first dispatch order (20.7 ms; 21.3 / 20.9 / 20.8 / 20.8 at 12 / 24 / 32 / 48; it was 24 in index order) and
-    // 16 for the general path (49.3 / 42.2 ms vs 53.0 / 44.2 at 8)
-    const uint32_t bpc = c->blocks_per_cu ? c->blocks_per_cu : (c->dsc.nsmall && c->fused ? 40u : 16u);
+    // sub-queues per CU: shorter tails with more, but more per-workgroup overhead; the fused tiny-scene kernels (5 workgroups resident per
+    // CU, longest-first dispatch) are flat from 24 to 40 (19.0-19.2 ms; 19.6 at 20, and 20.7 at 30, whose sub-queues alias with the
+    // 8100 image regions); the general path measured best at 16 (49.3 / 42.2 ms vs 53.0 / 44.2 at 8)
+    const uint32_t bpc = c->blocks_per_cu ? c->blocks_per_cu : (c->dsc.nsmall && c->fused ? 24u : 16u);
     const uint32_t max_blocks = (uint32_t)c->num_cus * bpc;
     const uint32_t nchunks = f.chunks_per_sample * bspp;
     const uint32_t G = std::max<uint32_t>(1, std::min<uint32_t>(nchunks, max_blocks));

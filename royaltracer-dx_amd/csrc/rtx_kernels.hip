@@ -301,14 +301,18 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPa
 // rays and add their contributions, sample the BSDF, compact — all in one pass over the workgroup's sub-queue.
 // Nothing but the 48-B path state and the queue index moves through HBM; hit records and shadow-ray entries
 // stay in registers.  Radiance additions happen in the oracle's order (emissive, then NEE slot 0, 1, ...).
-template <int WAVES, bool HAVE_HIT>
-__global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, const SmallRecPair* __restrict__ small, DevFrame f, DevPaths p, uint32_t bounce,
+// LAMBERT: RTX_FLAG_LAMBERT_ONLY is a launch constant, so it is a template parameter too: the Lambert-only instantiation carries no GGX code
+// (fewer live registers, fewer SGPR spills through v_writelane / v_readlane in the loop).
+template <int WAVES, bool HAVE_HIT, bool LAMBERT>
+__global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, const SmallRecPair* __restrict__ small, DevFrame f_in, DevPaths p, uint32_t bounce,
                                                          const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount,
                                                          uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count,
                                                          uint32_t* __restrict__ shcounts /* [nee][gridDim.x]: shadow rays traced (statistics) */,
                                                          const uint32_t* __restrict__ order /* workgroup -> sub-queue, longest first (k_order_queues); may be null */) {
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_cnt[1 + kMaxNee];
+    DevFrame f = f_in;
+    f.flags = LAMBERT ? (f_in.flags | 1u) : (f_in.flags & ~1u);      // bit 0 known at compile time
     const uint32_t qid = order ? order[blockIdx.x] : blockIdx.x;      // the sub-queue this workgroup owns (input and output)
     // NEE shadow rays of the workgroup's 256 current items are compacted through LDS, so that the shadow traversal runs on
     // ceil(rays / 64) full waves instead of on every wave at ~2/3 occupancy (only ~65 % of the items get a shadow ray)
@@ -685,9 +689,13 @@ void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc,
 }
 void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce, bool have_hit,
                          const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts, const uint32_t* order) {
-    // 4 waves/SIMD (no spills); forcing 5 or 6 spills to scratch and measured 6 % / 16 % slower
-    if (have_hit) hipLaunchKernelGGL((k_bounce_small<4, true>), dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, bounce, queue, qcount, next_queue, next_count, shcounts, order);
-    else hipLaunchKernelGGL((k_bounce_small<4, false>), dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, bounce, queue, qcount, next_queue, next_count, shcounts, order);
+    // general instantiation: 111 VGPRs, 4 waves/SIMD (5 or 6 spill and measured slower); Lambert-only: 83 VGPRs, 5 waves/SIMD (a build for 6 waves, 80 VGPRs
+    // with 2 spilled, measured the same: 19.13 vs 19.03 ms)
+    const bool lam = (f.flags & 1u) != 0u;
+#define RTX_LAUNCH_BOUNCE(HH, LL) hipLaunchKernelGGL((k_bounce_small<4, HH, LL>), dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, bounce, queue, qcount, next_queue, next_count, shcounts, order)
+    if (have_hit) { if (lam) RTX_LAUNCH_BOUNCE(true, true); else RTX_LAUNCH_BOUNCE(true, false); }
+    else { if (lam) RTX_LAUNCH_BOUNCE(false, true); else RTX_LAUNCH_BOUNCE(false, false); }
+#undef RTX_LAUNCH_BOUNCE
 }
 void launch_order_queues(hipStream_t st, const uint32_t* qcount, uint32_t G, uint32_t* order) {
     hipLaunchKernelGGL(k_order_queues, dim3(1), dim3(1024), 0, st, qcount, G, order);
