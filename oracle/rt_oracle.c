@@ -47,6 +47,11 @@ static inline float dot3(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x 
 static inline v3 cross3(v3 a, v3 b) {
     return V3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
+/* fused linear combinations (same DEVIATION as dot3 / cross3): a*s + b, and x*a + y*b + z*c as fma(z, c, fma(y, b, x*a)) */
+static inline v3 madd3(v3 a, float s, v3 b) { return V3(fmaf(a.x, s, b.x), fmaf(a.y, s, b.y), fmaf(a.z, s, b.z)); }
+static inline v3 lincomb3(v3 x, float a, v3 y, float b, v3 z, float c) {
+    return V3(fmaf(z.x, c, fmaf(y.x, b, x.x * a)), fmaf(z.y, c, fmaf(y.y, b, x.y * a)), fmaf(z.z, c, fmaf(y.z, b, x.z * a)));
+}
 static inline float length3(v3 a) { return sqrtf(dot3(a, a)); }
 static inline uint32_t f2u(float f);
 static inline float u2f(uint32_t u);
@@ -551,7 +556,7 @@ static surf_t surface(const orc_ctx* c, v3 o, v3 d, hit_t h) {
     uint32_t ii = c->tri_inst[h.prim], prim = c->tri_prim[h.prim];
     const inst_t* in = &c->insts[ii]; const mesh_t* m = &c->meshes[in->mesh];
     s.inst = ii;
-    s.pos = V3(o.x + h.t * d.x, o.y + h.t * d.y, o.z + h.t * d.z);            /* :15,60 */
+    s.pos = madd3(d, h.t, o);                                                 /* :15,60 */
     uint32_t vert = 3 * prim;
     uint32_t i0 = m->idx[vert], i1 = m->idx[vert + 1], i2 = m->idx[vert + 2];
     s.mat = c->matids[vert + (uint32_t)m->verts[(size_t)i0 * 7 + 6]];          /* :17 */
@@ -562,13 +567,13 @@ static surf_t surface(const orc_ctx* c, v3 o, v3 d, hit_t h) {
     s.area = fabsf(length3(cr) * 0.5f);                                        /* :31 */
     v3 flat = normalize3(cr);                                                  /* :32 */
     s.flat = flat;
-    v3 smooth = V3(0, 0, 0);
     const uint32_t vi[3] = {i0, i1, i2};
+    v3 use[3];
     for (int k = 0; k < 3; k++) {                                              /* :40-46, all(n != 0) is per component */
         v3 nk = mesh_nrm(m, vi[k]);
-        v3 use = (nk.x != 0.0f && nk.y != 0.0f && nk.z != 0.0f) ? nk : flat;
-        smooth = add3(smooth, scale3(use, bary[k]));
+        use[k] = (nk.x != 0.0f && nk.y != 0.0f && nk.z != 0.0f) ? nk : flat;
     }
+    v3 smooth = lincomb3(use[0], bary[0], use[1], bary[1], use[2], bary[2]);
     v3 n = (length3(smooth) > 0.0001f) ? normalize3(smooth) : flat;            /* :49-54 */
     s.normal = normalize3(xform_dir(in->nrm, n));                              /* :56 */
     return s;
@@ -626,7 +631,9 @@ static inline float ess_lut(const float* mat, float NdotV) {
 /* Lambertian_v6.hlsl:54-58 */
 static inline v3 lambert_eval(const matopt_t* m) { return V3(m->Kd.x / PI_REF, m->Kd.y / PI_REF, m->Kd.z / PI_REF); }
 /* Lambertian_v6.hlsl:61-64: max(dot(n, -incoming), EPS)/PI, with L = -incoming */
-static inline float lambert_pdf(v3 n, v3 L) { return maxf(dot3(n, L), EPSILON_) / PI_REF; }
+/* x / PI as x * (1 / PI), the reciprocal rounded once at compile time: what shader compilers do with a division by a constant */
+#define INV_PI_REF (1.0f / PI_REF)
+static inline float lambert_pdf(v3 n, v3 L) { return maxf(dot3(n, L), EPSILON_) * INV_PI_REF; }
 /* GGX_v6.hlsl:174-206; V = outgoing, L = -incoming (dots NOT clamped) */
 static v3 ggx_eval(const matopt_t* m, const float* mat, v3 normal, v3 Lin, v3 Vin) {
     v3 N = normalize3(normal), V = normalize3(Vin), L = normalize3(Lin);
@@ -694,7 +701,7 @@ static v3 sample_lambert(v3 normal, uint32_t seed[2]) {
     v3 up = fabsf(normal.z) < 0.999f ? V3(0, 0, 1) : V3(1, 0, 0);
     v3 right = normalize3(cross3(up, h));
     v3 fwd = cross3(h, right);
-    v3 s = V3(x * right.x + y * fwd.x + z * h.x, x * right.y + y * fwd.y + z * h.y, x * right.z + y * fwd.z + z * h.z);
+    v3 s = lincomb3(right, x, fwd, y, h, z);
     s = normalize3(s);
     if (dot3(s, normal) < 0.0f) s = neg3(s);
     return s;
@@ -840,7 +847,7 @@ static v3 trace_path(const orc_ctx* c, const orc_params* p, uint32_t x, uint32_t
             float xi1 = rnd(seed), xi2 = rnd(seed);
             if (xi1 + xi2 > 1.0f) { xi1 = 1.0f - xi1; xi2 = 1.0f - xi2; }
             float u = 1.0f - xi1 - xi2, v = xi1, w = xi2;
-            v3 sp = V3(u * xv.x + v * yv.x + w * zv.x, u * xv.y + v * yv.y + w * zv.y, u * xv.z + v * yv.z + w * zv.z);
+            v3 sp = lincomb3(xv, u, yv, v, zv, w);
             v3 Lv = sub3(sp, sf.pos);
             float dist2 = dot3(Lv, Lv);
             float dist = sqrtf(maxf(dist2, EPSILON_));
@@ -860,7 +867,7 @@ static v3 trace_path(const orc_ctx* c, const orc_params* p, uint32_t x, uint32_t
             v3 con = V3(lt[12] * (thr.x * F.x) * g, lt[13] * (thr.y * F.y) * g, lt[14] * (thr.z * F.z) * g);
             if (!finite3(con) || (con.x == 0.0f && con.y == 0.0f && con.z == 0.0f)) continue;
             /* visibility: Sampler_v6.hlsl:616-628 */
-            v3 so = add3(sf.pos, scale3(normalize3(normal), S_BIAS));
+            v3 so = madd3(normalize3(normal), S_BIAS, sf.pos);
             float smax = maxf(S_BIAS, dist - S_BIAS * 5.0f);
             cnt[2]++;
             if (!any_bvh(c, so, Ln, 0.5f * S_BIAS, smax)) rad = add3(rad, con);

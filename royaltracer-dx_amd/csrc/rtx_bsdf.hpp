@@ -55,7 +55,7 @@ RTX_HD float ess_lut(const MatGPU& m, float NdotV) {
 // Lambertian_v6.hlsl:54-58
 RTX_HD f3 lambert_eval(const MatGPU& m) { return mk3(m.KdPi[0], m.KdPi[1], m.KdPi[2]); }   // Kd / PI (Lambertian_v6.hlsl:44-50), precomputed in MatGPU
 // Lambertian_v6.hlsl:61-64 (L = -incoming)
-RTX_HD float lambert_pdf(f3 n, f3 L) { return maxf_(dot(n, L), kEps) / kPI; }
+RTX_HD float lambert_pdf(f3 n, f3 L) { return maxf_(dot(n, L), kEps) * kInvPI; }
 // GGX_v6.hlsl:174-206 (dot products are not clamped in v6)
 RTX_HD f3 ggx_eval(const MatGPU& m, f3 normal, f3 Lin, f3 Vin) {
     f3 N = normalize(normal), V = normalize(Vin), L = normalize(Lin);
@@ -120,7 +120,7 @@ RTX_HD f3 sample_lambert(f3 normal, uint32_t& s0, uint32_t& s1) {
     f3 up = fabsf(normal.z) < 0.999f ? mk3(0.0f, 0.0f, 1.0f) : mk3(1.0f, 0.0f, 0.0f);
     f3 right = normalize(cross(up, h));
     f3 fwd = cross(h, right);
-    f3 s = mk3(x * right.x + y * fwd.x + z * h.x, x * right.y + y * fwd.y + z * h.y, x * right.z + y * fwd.z + z * h.z);
+    f3 s = lincomb3(right, x, fwd, y, h, z);
     s = normalize(s);
     if (dot(s, normal) < 0.0f) s = -s;
     return s;

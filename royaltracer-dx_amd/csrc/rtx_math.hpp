@@ -22,6 +22,7 @@
 namespace rtx {
 
 constexpr float kPI      = 3.1415f;      // Common_v6.hlsl:1 (sic)
+constexpr float kInvPI   = 1.0f / kPI;   // x / PI is evaluated as x * (1 / PI), the reciprocal rounded once (rt_oracle.c: INV_PI_REF)
 constexpr float kSBias   = 0.00002f;     // Common_v6.hlsl:2
 constexpr float kEps     = 0.000001f;    // Common_v6.hlsl:3
 constexpr float kTwoPi   = 6.28318548202514648f;  // float(2.0 * 3.14159265358979323846), Lambertian_v6.hlsl:10
@@ -42,6 +43,11 @@ RTX_HD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 // the VALU-bound kernels short (tri_test 41 -> 27 instructions).  Everything else stays unfused (-ffp-contract=off).
 RTX_HD float dot(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
 RTX_HD f3 cross(f3 a, f3 b) { return mk3(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)), __builtin_fmaf(a.x, b.y, -(a.y * b.x))); }
+// fused linear combinations (same rule as dot / cross; rt_oracle.c: madd3, lincomb3)
+RTX_HD f3 madd3(f3 a, float s, f3 b) { return mk3(__builtin_fmaf(a.x, s, b.x), __builtin_fmaf(a.y, s, b.y), __builtin_fmaf(a.z, s, b.z)); }
+RTX_HD f3 lincomb3(f3 x, float a, f3 y, float b, f3 z, float c) {
+    return mk3(__builtin_fmaf(z.x, c, __builtin_fmaf(y.x, b, x.x * a)), __builtin_fmaf(z.y, c, __builtin_fmaf(y.y, b, x.y * a)), __builtin_fmaf(z.z, c, __builtin_fmaf(y.z, b, x.z * a)));
+}
 RTX_HD float length(f3 a) { return sqrtf(dot(a, a)); }
 RTX_HD uint32_t f2u(float f);
 RTX_HD float u2f(uint32_t u);

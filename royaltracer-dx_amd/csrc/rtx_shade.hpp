@@ -16,11 +16,12 @@ __device__ __forceinline__ Surf surface(const DevScene& sc, f3 o, f3 d, float t,
     const f3 flat = mk3(r0.z, r0.w, r1.x);
     const f3 n0 = mk3(r1.y, r1.z, r1.w), n1 = mk3(r2.x, r2.y, r2.z), n2 = mk3(r2.w, r3.x, r3.y);
     s.area = r3.z; s.flat = flat;
-    s.pos = mk3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);                 // :15,60
+    s.pos = madd3(d, t, o);                                                   // :15,60
     const float b0 = 1.0f - u - v;                                            // :18
-    f3 smooth = mk3(0.0f, 0.0f, 0.0f);
-    smooth = smooth + n0 * b0; smooth = smooth + n1 * u; smooth = smooth + n2 * v;   // :40-46
-    const f3 n = (length(smooth) > 0.0001f) ? normalize(smooth) : flat;       // :49-54
+    const f3 smooth = lincomb3(n0, b0, n1, u, n2, v);                         // :40-46
+    // :49-54  length(smooth) > 0.0001f, without the IEEE sqrt (19 issue slots): correctly rounded sqrt is monotonic, so the comparison is
+    // EXACTLY dot >= T*, T* = 0x322bcc78 = the smallest float whose square root rounds above 1e-4f (tests/test_oracle_golden.py)
+    const f3 n = (dot(smooth, smooth) >= u2f(0x322bcc78u)) ? normalize(smooth) : flat;
     s.normal = normalize(xform_dir(sc.insts[s.inst].nrm, n));                 // :56
     return s;
 }
@@ -84,7 +85,7 @@ __device__ __forceinline__ bool nee_sample(const DevScene& sc, const MatGPU& m, 
     float xi1 = tea_next(S.s0, S.s1), xi2 = tea_next(S.s0, S.s1);
     if (xi1 + xi2 > 1.0f) { xi1 = 1.0f - xi1; xi2 = 1.0f - xi2; }
     const float u = 1.0f - xi1 - xi2, v = xi1, w = xi2;
-    const f3 sp = mk3(u * xv.x + v * yv.x + w * zv.x, u * xv.y + v * yv.y + w * zv.y, u * xv.z + v * yv.z + w * zv.z);
+    const f3 sp = lincomb3(xv, u, yv, v, zv, w);
     const f3 Lv = sp - pos;
     const float dist2 = dot(Lv, Lv);
     const float dist = sqrtf(maxf_(dist2, kEps));
@@ -100,7 +101,7 @@ __device__ __forceinline__ bool nee_sample(const DevScene& sc, const MatGPU& m, 
     const float g = cos_x / pdf_light * mi;
     con = mk3(lt.em[0] * (S.thr.x * F.x) * g, lt.em[1] * (S.thr.y * F.y) * g, lt.em[2] * (S.thr.z * F.z) * g);
     if (!finite3(con) || is_zero3(con)) return false;
-    const f3 sorg = pos + normalize(normal) * kSBias;         // :616-621
+    const f3 sorg = madd3(normalize(normal), kSBias, pos);    // :616-621
     so = {sorg.x, sorg.y, sorg.z, 0.5f * kSBias};
     sd = {Ln.x, Ln.y, Ln.z, maxf_(kSBias, dist - kSBias * 5.0f)};
     return true;

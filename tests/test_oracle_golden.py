@@ -86,6 +86,21 @@ def test_rsqrt_det_is_within_one_ulp(orc):
     assert np.abs(np.sqrt(n2) * y - 1.0).max() < 3e-7
 
 
+def test_squared_length_threshold_is_exact():
+    """csrc/rtx_shade.hpp tests `dot(n, n) >= 0x322bcc78` where the shader (and the oracle) say `length(n) > 0.0001f`: identical for
+    every float, because correctly rounded sqrt is monotonic and 0x322bcc78 is the smallest float whose root rounds above 1e-4f"""
+    c = np.float32(1e-4)
+    T = np.array([0x322bcc78], np.uint32).view(np.float32)[0]
+    u = np.arange(0x322bcc78 - 2_000_000, 0x322bcc78 + 2_000_000, dtype=np.uint32)
+    xs = u.view(np.float32)
+    assert np.array_equal(np.sqrt(xs) > c, xs >= T)
+    ys = np.exp(np.random.default_rng(0).uniform(np.log(1e-14), np.log(1e-2), 1_000_000)).astype(np.float32)
+    assert np.array_equal(np.sqrt(ys) > c, ys >= T)
+    sp = np.array([0.0, -0.0, np.inf, np.nan, 1e-45, 3e38], np.float32)
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(np.sqrt(sp) > c, sp >= T)
+
+
 def test_mat4_inverse_vs_numpy(orc):
     rng = np.random.default_rng(1)
     for _ in range(50):
