@@ -646,6 +646,27 @@ def test_c4_sizes_4k_shards_and_stack_variants(rt, orc):
     assert np.isfinite(imgs[0]).all() and (imgs[0][..., 3] == 1).all() and imgs[0][..., :3].mean() > 0.01
 
 
+@pytest.mark.parametrize("flags", [1, 0])
+def test_fused_dispatch_order_and_subqueue_count_are_result_neutral(rt, orc, cornell, flags):
+    """the fused tiny-scene kernels take their sub-queues longest first (k_order_queues) and exist in a Lambert-only and a general
+    instantiation: image and ray counts must not depend on the dispatch order or on the number of sub-queues, and both
+    instantiations must equal the oracle"""
+    W, H = 256, 144
+    p = rt.Params(width=W, height=H, spp=4, max_bounces=6, nee_samples=1, flags=flags)
+    ref = cnt0 = None
+    for lpt, bpc in ((1, 0), (0, 0), (1, 1), (1, 7), (0, 64)):
+        c = rt.Context(0); c.set_option(rt.OPT_LPT_ORDER, lpt); c.set_option(rt.OPT_BLOCKS_PER_CU, bpc); c.upload(cornell, W / H)
+        c.clear(W, H); c.render(p); im = c.read_accum(); st = c.stats()
+        cnt = (st.rays_primary, st.rays_extension, st.rays_shadow)
+        c.close()
+        if ref is None:
+            ref, cnt0 = im, cnt
+            o = orc.Oracle().load(cornell, W / H)
+            oa, oc = o.render(p)
+            assert np.array_equal(bits(im), bits(oa)) and cnt == oc
+        assert np.array_equal(bits(im), bits(ref)) and cnt == cnt0, (lpt, bpc)
+
+
 def test_two_contexts_from_two_threads(rt, cornell):
     """SURVEY 8(b) threading contract: a context is not thread-safe, but different contexts may be driven from different threads.
     Two threads render different workloads concurrently on the same GPU (different scenes, options, streams); each result must be
