@@ -85,7 +85,7 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
        RTX_OPT_TRACE_SCHED = 10,     /* tuning: wave schedule of the BVH traversal, 0 = while-while, 1-4 = voted node / triangle steps, 5-7 = voted + speculative (default 6) */
        RTX_OPT_GPU_REFIT = 11,       /* 1 (default): a transform-only rtx_commit_scene refits the resident BVH on the GPU; 0: host refit + upload */
        RTX_OPT_LPT_ORDER = 13,       /* tuning: 1 (default) = the fused tiny-scene kernels take their sub-queues longest first (shorter launch tails), 0 = in index order */
-       RTX_OPT_BLOCKS_PER_CU = 12    /* tuning: workgroups (= private sub-queues) per compute unit; default 0 = auto (24 tiny scenes, 16 otherwise; 8 measured 4-7 % slower: tail imbalance) */ };
+       RTX_OPT_BLOCKS_PER_CU = 12    /* tuning: workgroups (= private sub-queues) per compute unit; default 0 = auto (40 tiny scenes, 16 otherwise; 8 measured 4-7 % slower: tail imbalance) */ };
 
 /* lifetime: replaces LoadPipeline/device creation (Renderer.cpp:106-254) and OnDestroy (:546-552) */
 int  rtx_create(int device_ordinal, rtx_ctx** out);

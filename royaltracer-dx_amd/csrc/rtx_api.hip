@@ -342,9 +342,10 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     HIPCHK(c, c->d_thr.ensure((size_t)cap * 16)); HIPCHK(c, c->d_rad.ensure((size_t)cap * 16)); HIPCHK(c, c->d_hit.ensure((size_t)cap * 16));
     // work distribution: G workgroups, each with a private sub-queue (no global atomics in the loop)
     // sub-queues per CU: shorter tails with more, but more per-workgroup overhead; the fused tiny-scene kernels (5 workgroups resident per
-    // CU, longest-first dispatch) are flat from 24 to 40 (19.0-19.2 ms; 19.6 at 20, and 20.7 at 30, whose sub-queues alias with the
-    // 8100 image regions); the general path measured best at 16 (49.3 / 42.2 ms vs 53.0 / 44.2 at 8)
-    const uint32_t bpc = c->blocks_per_cu ? c->blocks_per_cu : (c->dsc.nsmall && c->fused ? 24u : 16u);
+    // CU, longest-first dispatch, all bounces >= 1 in one launch) measured 18.39 / 18.15 / 18.13 / 18.30 / 18.36 ms at 24 / 32 / 40 / 48 / 64
+    // (a 1/4 shard: 5.22 / 4.96 / 4.99 / 4.92 / 4.96 ms; 30 is an outlier, its sub-queues alias with the 8100 image regions); the
+    // general path measured best at 16 (49.3 / 42.2 ms vs 53.0 / 44.2 at 8)
+    const uint32_t bpc = c->blocks_per_cu ? c->blocks_per_cu : (c->dsc.nsmall && c->fused ? 40u : 16u);
     const uint32_t max_blocks = (uint32_t)c->num_cus * bpc;
     const uint32_t nchunks = f.chunks_per_sample * bspp;
     const uint32_t G = std::max<uint32_t>(1, std::min<uint32_t>(nchunks, max_blocks));
@@ -396,12 +397,12 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
         // bounces keep the ranking: survivors are a near-constant fraction)
         const uint32_t* order = nullptr;
         if (fused && c->lpt_order && G > 1) { launch_order_queues(st, Q(0), G, (uint32_t*)c->d_order.p); order = (const uint32_t*)c->d_order.p; }
-        for (uint32_t b = 0; b < mb; b++) {
+        if (fused) {          // tiny scene: trace + shade + shadow fused; bounce 0 (traced by raygen) and then ALL later bounces in one launch each
+            { Timed t(c, RTX_K_BOUNCE); launch_bounce_small(st, c->dsc, fb, P, 0, 1, queue[0], queue[1], Q(0), S(0, 0), order); }
+            if (mb > 1) { Timed t(c, RTX_K_BOUNCE); launch_bounce_small(st, c->dsc, fb, P, 1, mb, queue[0], queue[1], Q(0), S(0, 0), order); }
+        }
+        for (uint32_t b = 0; b < mb && !fused; b++) {
             uint32_t* q = queue[b & 1]; uint32_t* qn = queue[(b + 1) & 1];
-            if (fused) {      // tiny scene: trace + shade + shadow fused into one kernel per bounce (bounce 0 was traced by raygen)
-                Timed t(c, RTX_K_BOUNCE); launch_bounce_small(st, c->dsc, fb, P, b, b == 0, q, Q(b), qn, Q(b + 1), S(b, 0), order);
-                continue;
-            }
             { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, fb, c->dsc, P, b, q, Q(b)); }
             { Timed t(c, RTX_K_SHADE); launch_shade(st, c->dsc, fb, P, b, q, Q(b), qn, Q(b + 1), S(b, 0)); }
             for (uint32_t j = 0; j < nee; j++) { Timed t(c, RTX_K_SHADOW); launch_trace_shadow(st, fb, c->dsc, P, j, S(b, j)); }

@@ -304,11 +304,17 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPa
 // LAMBERT: RTX_FLAG_LAMBERT_ONLY is a launch constant, so it is a template parameter too: the Lambert-only instantiation carries no GGX code
 // (fewer live registers, fewer SGPR spills through v_writelane / v_readlane in the loop).
 template <int WAVES, bool HAVE_HIT, bool LAMBERT>
-__global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, const SmallRecPair* __restrict__ small, DevFrame f_in, DevPaths p, uint32_t bounce,
-                                                         const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount,
-                                                         uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count,
-                                                         uint32_t* __restrict__ shcounts /* [nee][gridDim.x]: shadow rays traced (statistics) */,
+__global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, const SmallRecPair* __restrict__ small, DevFrame f_in, DevPaths p,
+                                                         uint32_t bounce_first, uint32_t bounce_end,
+                                                         uint32_t* __restrict__ queue_a, uint32_t* __restrict__ queue_b /* bounce b reads (b & 1 ? b : a), writes the other */,
+                                                         uint32_t* __restrict__ qrows /* [bounce][gridDim.x] sub-queue lengths entering each bounce */,
+                                                         uint32_t* __restrict__ srows /* [bounce][nee][gridDim.x]: shadow rays traced (statistics) */,
                                                          const uint32_t* __restrict__ order /* workgroup -> sub-queue, longest first (k_order_queues); may be null */) {
+    // BOUNCE RANGE: sub-queues are workgroup-private, so bounce b + 1 of sub-queue q depends on bounce b of the SAME sub-queue only.  One
+    // launch therefore runs the bounces [bounce_first, bounce_end) of its sub-queue back to back, with a workgroup barrier in between
+    // (workgroup-scope release / acquire: the path state and queue entries a bounce writes are read by the same workgroup).  A frame has
+    // two fused launches (bounce 0, which reads the primary hits, and bounces 1 .. max_bounces - 1) instead of eight, and no drain /
+    // ramp-up between the bounces; the sparsely populated late bounces cost a few loop trips instead of a launch each.
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_cnt[1 + kMaxNee];
     DevFrame f = f_in;
@@ -321,17 +327,20 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
     __shared__ uint8_t s_occ[kBlock];
     if (threadIdx.x <= kMaxNee) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x < 2) s_shn[threadIdx.x] = 0;
-    const uint32_t n = qcount[qid];
+    const uint32_t G = gridDim.x;
+    uint32_t n = qrows[(size_t)bounce_first * G + qid];
     const uint32_t nee = sc.nlights ? f.nee_samples : 0u;
+    const uint32_t nee1 = nee ? nee : 1u;
     const TraceLds L = stage_lds(sc, lds);
     __syncthreads();
-    const bool last = (bounce + 1u == f.max_bounces);
-    const float tmin = bounce_tmin(bounce);
     const size_t qb = (size_t)qid * f.qcap;
-    const uint32_t* myq = queue + qb;
-    uint32_t* mynext = next_queue + qb;
     uint32_t par = 0;
     PF_BEGIN;
+    for (uint32_t bounce = bounce_first; bounce < bounce_end; bounce++) {
+    const bool last = (bounce + 1u == f.max_bounces);
+    const float tmin = bounce_tmin(bounce);
+    const uint32_t* myq = ((bounce & 1u) ? queue_b : queue_a) + qb;
+    uint32_t* mynext = ((bounce & 1u) ? queue_a : queue_b) + qb;
     for (uint32_t base = 0; base < n; base += kBlock) {     // the same trip count for all four waves (barriers inside)
         const uint32_t i = base + threadIdx.x;
         const bool active = i < n;
@@ -394,10 +403,16 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
         if (alive) mynext[slot] = S.pid;
         PF_MARK(9);
     }
-    PF_FLUSH;
+    // end of this bounce of the sub-queue: publish its counters; what it wrote (path state, next queue) becomes visible to the workgroup
     __syncthreads();
-    if (threadIdx.x == 0) next_count[qid] = s_cnt[0];
-    if (threadIdx.x >= 1 && threadIdx.x <= nee) shcounts[(size_t)(threadIdx.x - 1) * gridDim.x + qid] = s_cnt[threadIdx.x];
+    n = s_cnt[0];
+    if (threadIdx.x == 0) qrows[(size_t)(bounce + 1u) * G + qid] = n;
+    if (threadIdx.x >= 1 && threadIdx.x <= nee) srows[((size_t)bounce * nee1 + (threadIdx.x - 1)) * G + qid] = s_cnt[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x <= kMaxNee) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    }
+    PF_FLUSH;
 }
 
 // Longest sub-queue first.  The sub-queues of a batch differ in length by ~12 % (std; each is a sample of ~84 of the image's 8100
@@ -687,12 +702,12 @@ void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc,
     if (sc.stack_private == 1) hipLaunchKernelGGL(k_trace_closest<1>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, sc.refill_min, sc.trace_sched);
     else hipLaunchKernelGGL(k_trace_closest<0>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, sc.refill_min, sc.trace_sched);
 }
-void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce, bool have_hit,
-                         const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts, const uint32_t* order) {
-    // general instantiation: 111 VGPRs, 4 waves/SIMD (5 or 6 spill and measured slower); Lambert-only: 83 VGPRs, 5 waves/SIMD (a build for 6 waves, 80 VGPRs
-    // with 2 spilled, measured the same: 19.13 vs 19.03 ms)
-    const bool lam = (f.flags & 1u) != 0u;
-#define RTX_LAUNCH_BOUNCE(HH, LL) hipLaunchKernelGGL((k_bounce_small<4, HH, LL>), dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, bounce, queue, qcount, next_queue, next_count, shcounts, order)
+void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce_first, uint32_t bounce_end,
+                         uint32_t* queue_a, uint32_t* queue_b, uint32_t* qrows, uint32_t* srows, const uint32_t* order) {
+    // general instantiation: 118 VGPRs, 4 waves/SIMD (5 or 6 spill and measured slower); Lambert-only: 85 VGPRs, 5 waves/SIMD (a build for 6 waves, 80 VGPRs
+    // with 2 spilled, measured the same: 19.13 vs 19.03 ms).  Bounce 0 (reads the primary hits) is its own instantiation and launch.
+    const bool lam = (f.flags & 1u) != 0u, have_hit = bounce_first == 0u;
+#define RTX_LAUNCH_BOUNCE(HH, LL) hipLaunchKernelGGL((k_bounce_small<4, HH, LL>), dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, bounce_first, bounce_end, queue_a, queue_b, qrows, srows, order)
     if (have_hit) { if (lam) RTX_LAUNCH_BOUNCE(true, true); else RTX_LAUNCH_BOUNCE(true, false); }
     else { if (lam) RTX_LAUNCH_BOUNCE(false, true); else RTX_LAUNCH_BOUNCE(false, false); }
 #undef RTX_LAUNCH_BOUNCE
