@@ -42,7 +42,7 @@ struct rtx_ctx {
     DevScene dsc{};
     float view[16], proj[16];
     // path state
-    DevBuf d_hitmask, d_order;
+    DevBuf d_hitmask, d_order, d_pmask;
     bool lpt_order = true;          // RTX_OPT_LPT_ORDER: fused kernels take their sub-queues longest first
     DevBuf d_ray_o, d_ray_d, d_thr, d_rad, d_hit, d_sh_o, d_sh_d, d_sh_c, d_queue[2], d_counters;
     uint32_t* h_counters = nullptr; size_t h_counters_words = 0;
@@ -104,7 +104,7 @@ void rtx_destroy(rtx_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_small_poly, &c->d_objtris, &c->d_node_aabb, &c->d_scale, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
-                     &c->d_thr, &c->d_rad, &c->d_hit, &c->d_hitmask, &c->d_order, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
+                     &c->d_thr, &c->d_rad, &c->d_hit, &c->d_hitmask, &c->d_order, &c->d_pmask, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
                      &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt};
     for (DevBuf* b : all) b->release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
@@ -354,6 +354,7 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     const size_t qtot = (size_t)G * qcap;
     HIPCHK(c, c->d_queue[0].ensure(qtot * 4)); HIPCHK(c, c->d_queue[1].ensure(qtot * 4));
     HIPCHK(c, c->d_order.ensure((size_t)G * 4));
+    HIPCHK(c, c->d_pmask.ensure(((size_t)f.npl / 64 + 1) * 8));
     const uint32_t nee1 = std::max<uint32_t>(nee, 1);
     const size_t shn = qtot * nee1;
     HIPCHK(c, c->d_sh_o.ensure(shn * 16)); HIPCHK(c, c->d_sh_d.ensure(shn * 16)); HIPCHK(c, c->d_sh_c.ensure(shn * 16));
@@ -385,13 +386,14 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
 
     HIPCHK(c, hipEventRecord(c->ev_begin, st));
     HIPCHK(c, hipMemsetAsync(cnt, 0, ncnt * 4, st));
+    if (c->dsc.nsmall && c->fused) launch_packet_masks(st, c->dsc, f, cam, (unsigned long long*)c->d_pmask.p);   // per 8x8 block, shared by all samples
     for (uint32_t bi = 0; bi < nbatches; bi++) {
         DevFrame fb = f;
         fb.sample_first = p->sample_base + bi * bspp;
         fb.batch_spp = std::min(bspp, p->spp - bi * bspp);
         const bool fused = c->dsc.nsmall && c->fused;
         uint32_t* gen_row = cnt + ((size_t)(mb + 1) + (size_t)mb * nee1) * G;
-        if (fused) { Timed t(c, RTX_K_RAYGEN); launch_raygen_trace_small(st, c->dsc, fb, P, cam, queue[0], Q(0), gen_row); }
+        if (fused) { Timed t(c, RTX_K_RAYGEN); launch_raygen_trace_small(st, c->dsc, fb, P, cam, queue[0], Q(0), gen_row, (const unsigned long long*)c->d_pmask.p); }
         else { Timed t(c, RTX_K_RAYGEN); launch_raygen(st, fb, P, cam, queue[0], Q(0)); }
         // dispatch order of the fused bounce kernels: longest sub-queue first, from the lengths after the primary rays (the later
         // bounces keep the ranking: survivors are a near-constant fraction)

@@ -70,8 +70,24 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DevFrame f, DevPaths p, const
     if (threadIdx.x == 0) qcount[blockIdx.x] = s_n;
 }
 
+// packet-culling masks of the primary rays, one per 8x8 pixel block of the shard (slot order): they depend on the camera and the scene, not on the
+// sample, so they are computed once per render call (one wave per block, lane = record) instead of once per block AND sample inside the raygen
+// kernel, where they were more than half of its instructions (at 17 of 64 lanes)
+__global__ __launch_bounds__(kBlock) void k_packet_masks(DevScene sc, DevFrame f, const CameraGPU* __restrict__ cam_p, unsigned long long* __restrict__ masks) {
+    __shared__ CameraGPU cam;
+    if (threadIdx.x < 64) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
+    __syncthreads();
+    const uint32_t blk = blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6);      // wave-uniform
+    if (blk >= f.npl / 64u) return;
+    uint32_t x = 0, y = 0;
+    (void)slot_to_pixel(f, blk * 64u, x, y);                                    // slot 0 of the block = its top-left pixel
+    const unsigned long long keep = packet_keep_mask(sc, cam, f, x & ~7u, y & ~7u);
+    if (lane_id() == 0) masks[blk] = keep;
+}
+
 __global__ __launch_bounds__(kBlock) void k_raygen_trace_small(DevScene sc, const SmallRecPair* __restrict__ small, DevFrame f, DevPaths p, const CameraGPU* __restrict__ cam_p,
-                                                               uint32_t* __restrict__ queue, uint32_t* __restrict__ qcount, uint32_t* __restrict__ gencount) {
+                                                               uint32_t* __restrict__ queue, uint32_t* __restrict__ qcount, uint32_t* __restrict__ gencount,
+                                                               const unsigned long long* __restrict__ masks /* k_packet_masks */) {
     extern __shared__ F4 lds[];
     __shared__ CameraGPU cam;
     __shared__ uint32_t s_n[2];
@@ -97,8 +113,9 @@ __global__ __launch_bounds__(kBlock) void k_raygen_trace_small(DevScene sc, cons
             generated++;
         }
         // pixel block of this wave: lane 0's pixel (slot_to_pixel lays 8x8 blocks out per wave)
-        const uint32_t bx0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(x & ~7u)), by0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(y & ~7u));
-        const unsigned long long keep = packet_keep_mask(sc, cam, f, bx0, by0);
+        // records that some ray of this wave's 8x8 pixel block can touch (slot_to_pixel lays one block out per wave): precomputed per block
+        const unsigned long long km = masks[pl >> 6];
+        const unsigned long long keep = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(km >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)km);
         float t, u, v; uint32_t prim;
         traverse_small<false>(sc, small, L, o, d, kTMinCam, valid ? kTMax : 0.0f, t, u, v, prim, sc.nsmall, keep);
         const bool hit = valid && prim != kMissPrim;
@@ -694,8 +711,12 @@ size_t trace_lds_bytes_queue(const DevScene& sc) {   // queue kernels with a pri
 void launch_raygen(hipStream_t st, const DevFrame& f, const DevPaths& p, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount) {
     hipLaunchKernelGGL(k_raygen, dim3(f.nblocks), dim3(kBlock), 0, st, f, p, cam, queue, qcount);
 }
-void launch_raygen_trace_small(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount, uint32_t* gencount) {
-    hipLaunchKernelGGL(k_raygen_trace_small, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, cam, queue, qcount, gencount);
+void launch_packet_masks(hipStream_t st, const DevScene& sc, const DevFrame& f, const CameraGPU* cam, unsigned long long* masks) {
+    const uint32_t nblk = f.npl / 64u;
+    hipLaunchKernelGGL(k_packet_masks, dim3((nblk + 3u) / 4u), dim3(kBlock), 0, st, sc, f, cam, masks);
+}
+void launch_raygen_trace_small(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount, uint32_t* gencount, const unsigned long long* masks) {
+    hipLaunchKernelGGL(k_raygen_trace_small, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, cam, queue, qcount, gencount, masks);
 }
 void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t bounce, const uint32_t* queue, const uint32_t* qcount) {
     const float tmin = bounce == 0 ? kTMinCam : kSBias;

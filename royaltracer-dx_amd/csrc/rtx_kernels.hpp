@@ -57,7 +57,8 @@ struct DevPaths {
 size_t trace_lds_bytes(const DevScene& sc);
 void launch_raygen(hipStream_t, const DevFrame&, const DevPaths&, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount);
 void launch_trace_closest(hipStream_t, const DevFrame&, const DevScene&, const DevPaths&, uint32_t bounce, const uint32_t* queue, const uint32_t* qcount);
-void launch_raygen_trace_small(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount, uint32_t* gencount);
+void launch_packet_masks(hipStream_t, const DevScene&, const DevFrame&, const CameraGPU* cam, unsigned long long* masks);   // one 64-bit record mask per 8x8 pixel block of the shard
+void launch_raygen_trace_small(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount, uint32_t* gencount, const unsigned long long* masks);
 void launch_bounce_small(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, uint32_t bounce_first, uint32_t bounce_end,
                          uint32_t* queue_a, uint32_t* queue_b, uint32_t* qrows, uint32_t* srows, const uint32_t* order);   // bounce 0 alone (reads the primary hits), or a range of later bounces
 void launch_order_queues(hipStream_t, const uint32_t* qcount, uint32_t G, uint32_t* order);   // longest sub-queue first (dispatch order of the fused kernels)
