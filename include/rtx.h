@@ -146,7 +146,9 @@ int  rtx_get_stats(rtx_ctx*, rtx_stats* out);
 int  rtx_get_lights(rtx_ctx*, void* out80, uint32_t max_count, uint32_t* count_out);
 
 /* multi-GPU (new; the reference is single-GPU): owned tiles of the accumulation buffer <-> compact
-   [tiles_per_shard][tile_size^2] float4 slab for one RCCL (all)gather.  Pointers are DEVICE pointers. */
+   [tiles_per_shard][tile_size^2] float4 slab for one RCCL (all)gather.  Pointers are DEVICE pointers.
+   On the context's own stream both calls are synchronous; on a caller-bound stream (rtx_set_stream) they only enqueue, so that
+   pack -> collective -> unpack runs stream-ordered without a host round trip (a 1/8-shard frame is ~2.7 ms). */
 int  rtx_shard_slab_bytes(const rtx_params*, size_t* bytes_per_shard);
 int  rtx_pack_tiles(rtx_ctx*, const rtx_params*, void* device_slab);
 int  rtx_unpack_tiles(rtx_ctx*, const rtx_params*, const void* device_slabs_all_shards);

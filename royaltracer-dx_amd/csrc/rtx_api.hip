@@ -595,7 +595,7 @@ int rtx_pack_tiles(rtx_ctx* c, const rtx_params* p, void* slab) {
     if (!slab || !c->accum_ptr() || c->acc_w != p->width || c->acc_h != p->height) { c->err = "pack_tiles: no accumulation buffer of that size"; return RTX_ERR_STATE; }
     launch_pack_tiles(c->stream, (uint32_t)c->num_cus * 8u, f, c->accum_ptr(), (F4*)slab);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream) HIPCHK(c, hipStreamSynchronize(c->stream));     // on a caller-bound stream the gather that follows is stream-ordered: no host bubble
     return RTX_OK;
 }
 int rtx_unpack_tiles(rtx_ctx* c, const rtx_params* p, const void* slabs) {
@@ -605,7 +605,7 @@ int rtx_unpack_tiles(rtx_ctx* c, const rtx_params* p, const void* slabs) {
     if ((r = ensure_accum(c, p->width, p->height, false))) return r;
     launch_unpack_tiles(c->stream, (uint32_t)c->num_cus * 8u, f, f.shard_count, (const F4*)slabs, c->accum_ptr());
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream) HIPCHK(c, hipStreamSynchronize(c->stream));
     return RTX_OK;
 }
 
