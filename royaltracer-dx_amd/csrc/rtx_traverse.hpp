@@ -111,6 +111,7 @@ constexpr float kPlaneEps = 2.384185791015625e-07f;   // 2^-22
 // hit next to a vertex of a small triangle seen from far away has a Moeller-Trumbore t that is off by ~1e-5 relative (found by
 // test_wide_bvh_equals_brute_force_on_hostile_soups: coincident duplicates lost their lowest-id tie at 2e-6), so 5e-5.
 constexpr float kSlabLo = 0.99995f, kSlabHi = 1.00005f;
+constexpr float kSlabK = 1.00010002f;                 // >= kSlabHi / kSlabLo (1.000100005...): the same widening as one factor on the far side
 
 __device__ __forceinline__ Node8R load_node8(const DevScene& sc, const TraceLds& L, uint32_t idx) {
     Node8R N;
@@ -136,7 +137,7 @@ __device__ __forceinline__ void node8_hits(const Node8R& N, f3 o, f3 idir, uint3
     const uint32_t qnx[2] = {nx ? N.q1.z : N.q0.x, nx ? N.q1.w : N.q0.y}, qfx[2] = {nx ? N.q0.x : N.q1.z, nx ? N.q0.y : N.q1.w};
     const uint32_t qny[2] = {ny ? N.q2.x : N.q0.z, ny ? N.q2.y : N.q0.w}, qfy[2] = {ny ? N.q0.z : N.q2.x, ny ? N.q0.w : N.q2.y};
     const uint32_t qnz[2] = {nz ? N.q2.z : N.q1.x, nz ? N.q2.w : N.q1.y}, qfz[2] = {nz ? N.q1.x : N.q2.z, nz ? N.q1.y : N.q2.w};
-    uint32_t hits = 0;
+    unsigned long long hm[8];                            // lane masks of the eight verdicts (SGPR pairs)
     const f2v vsx = splat2(sx), vsy = splat2(sy), vsz = splat2(sz);
 #pragma unroll
     for (int k = 0; k < 8; k += 2) {                     // two children per iteration on packed FP32 (v_pk_fma_f32 / v_pk_mul_f32)
@@ -147,10 +148,13 @@ __device__ __forceinline__ void node8_hits(const Node8R& N, f3 o, f3 idir, uint3
         const f2v tfx = fma2(bfx, vsx, splat2(afx)), tfy = fma2(bfy, vsy, splat2(afy)), tfz = fma2(bfz, vsz, splat2(afz));
         const f2v lo = {fmaxf(fmaxf(tnx.x, tny.x), fmaxf(tnz.x, tmin)), fmaxf(fmaxf(tnx.y, tny.y), fmaxf(tnz.y, tmin))};
         const f2v hi = {fminf(fminf(tfx.x, tfy.x), fminf(tfz.x, tbest)), fminf(fminf(tfx.y, tfy.y), fminf(tfz.y, tbest))};
-        const f2v los = lo * kSlabLo, his = hi * kSlabHi;                 // lo >= tmin >= 0
-        if (los.x <= his.x) hits |= 1u << k;
-        if (los.y <= his.y) hits |= 2u << k;
+        const f2v his = hi * kSlabK;                                      // lo kSlabLo <= hi kSlabHi as lo <= hi (kSlabHi / kSlabLo): one multiply; lo >= tmin >= 0
+        hm[k] = __builtin_amdgcn_ballot_w64(lo.x <= his.x);
+        hm[k + 1] = __builtin_amdgcn_ballot_w64(lo.y <= his.y);
     }
+    uint32_t hits = 0;                                   // bit k = child k: one v_addc_co per child (carry-in = its verdict mask), last child first
+#pragma unroll
+    for (int k = 7; k >= 0; k--) hits = shift_in(hits, hm[k]);
     const uint32_t imask = w >> 24;
     // internal hits, permuted so that bit j = slot (j ^ oct): lowest set bit = first child to visit
     uint32_t m = hits & imask;
