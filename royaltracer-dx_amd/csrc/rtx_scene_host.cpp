@@ -317,15 +317,26 @@ bool SceneHost::build(BuiltScene& B) {
         // strictly between two points of the scene, so NEE shadow segments (surface point + bias -> light point, shortened at both
         // ends) only need the records before them.  In a closed room that is every wall: Cornell keeps 11 of its 17 records.
         {
+            // EMISSIVE records always stay in the occluder list: an NEE segment ENDS on a light, a margin of 1e-4 short of it, and for a long
+            // grazing segment the float Moeller-Trumbore t of the light's own triangle is off by more than that, so the brute-force
+            // definition (and the oracle) reports the light as its own occluder.  Found by the analytic rectangle-light test, whose light is
+            // a hull face; the Cornell light hangs below the ceiling and was in the list anyway.
+            auto emissive = [&](int slot) {
+                if (slot < 0) return false;
+                const uint32_t g = f2u(B.tris[(size_t)slot].v0.w);
+                const uint32_t m = g < B.shade.size() ? B.shade[g].mat : 0xFFFFFFFFu;
+                return m < B.mats.size() && B.mats[m].Ke_len > 0.0f;
+            };
             std::vector<Rec> occ, hull;
             for (const Rec& R : recs) {
                 bool pos = false, neg = false;
                 const bool degenerate = R.pl[0] == 0.0 && R.pl[1] == 0.0 && R.pl[2] == 0.0;
+                const bool light = emissive(R.s0) || emissive(R.s1);
                 for (size_t s = 0; s < n && !degenerate; s++) for (int k = 0; k < 3; k++) {
                     const double dd = R.pl[0] * V[s][k].x + R.pl[1] * V[s][k].y + R.pl[2] * V[s][k].z - R.pl[3];
                     if (dd > tol) pos = true; else if (dd < -tol) neg = true;
                 }
-                ((pos && neg) ? occ : hull).push_back(R);
+                (((pos && neg) || light) ? occ : hull).push_back(R);
             }
             B.small_nocc = (uint32_t)occ.size();
             recs = occ; recs.insert(recs.end(), hull.begin(), hull.end());

@@ -646,6 +646,24 @@ def test_c4_sizes_4k_shards_and_stack_variants(rt, orc):
     assert np.isfinite(imgs[0]).all() and (imgs[0][..., 3] == 1).all() and imgs[0][..., :3].mean() > 0.01
 
 
+def test_analytic_rectangle_light_scene_gpu_equals_oracle(rt, orc):
+    """the floor-under-a-rectangular-light scene whose oracle image is pinned against the analytic irradiance
+    (test_oracle_golden.py): the GPU must reproduce the oracle's image bit for bit, so the analytic pin carries over"""
+    from test_oracle_golden import _FloorAndLight
+    sc = _FloorAndLight(); W, H = 24, 16
+    sc._v = rt.lookat((2.5, 1.6, 1.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)); sc._p = rt.perspective_fov_rh(np.radians(60.0), W / H, 0.1, 1000.0)
+    o = orc.Oracle().load(sc, W / H)
+    for flags, mb in ((1, 2), (0, 3)):
+        p = rt.Params(width=W, height=H, spp=64, max_bounces=mb, nee_samples=1, flags=flags)
+        oa, oc = o.render(p)
+        for small in (1, 0):                                  # fused tiny-scene kernels and the general BVH path
+            c = rt.Context(0); c.set_option(rt.OPT_SMALL_SCENE, small); c.upload(sc, W / H)
+            c.clear(W, H); c.render(p); st = c.stats()
+            assert np.array_equal(bits(c.read_accum()), bits(oa)), (flags, mb, small)
+            assert (st.rays_primary, st.rays_extension, st.rays_shadow) == oc
+            c.close()
+
+
 @pytest.mark.parametrize("flags", [1, 0])
 def test_fused_dispatch_order_and_subqueue_count_are_result_neutral(rt, orc, cornell, flags):
     """the fused tiny-scene kernels take their sub-queues longest first (k_order_queues) and exist in a Lambert-only and a general

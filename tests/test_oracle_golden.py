@@ -255,6 +255,76 @@ def test_ggx_mixture_is_finite_and_energy_bounded(rt, garage_oracle):
         assert np.median(w) < 1.5                                                    # throughput weights are O(1)
 
 
+class _FloorAndLight:
+    """a diffuse floor (y = 0) under a rectangular light (y = 1), nothing else: the reference's data model built by hand"""
+    KD, KE = (0.5, 0.25, 0.75), (4.0, 2.0, 1.0)                      # binary16-exact, so MaterialOptimized changes nothing
+    LX, LZ, LY = 0.5, 0.25, 1.0                                       # light half extents and height
+
+    def __init__(self):
+        m = np.zeros((3, 32), np.float32)
+        m[0, 0:4] = (1, 1, 1, 1); m[0, 12] = 1.0                      # default material (ObjLoader.h:415-417)
+        m[1, 0:4] = (*self.KD, 1); m[1, 12] = 1.0                     # floor: Kd, Ks = 0, roughness 1
+        m[2, 0:4] = (0, 0, 0, 1); m[2, 8:11] = self.KE; m[2, 12] = 1.0  # light: Ke
+        self.materials = m
+        F, lx, lz, ly = 6.0, self.LX, self.LZ, self.LY
+        quads = [((-F, 0, -F), (-F, 0, F), (F, 0, F), (F, 0, -F), 1),          # floor, normal +y
+                 ((-lx, ly, -lz), (lx, ly, -lz), (lx, ly, lz), (-lx, ly, lz), 2)]  # light
+        v, idx, mid = [], [], []
+        for a, b, c, d, mat in quads:
+            base = len(v)
+            v += [(*a, 0, 0, 0, 0), (*b, 0, 0, 0, 0), (*c, 0, 0, 0, 0), (*d, 0, 0, 0, 0)]     # normal (0,0,0) = flat, material base 0
+            idx += [base, base + 1, base + 2, base, base + 2, base + 3]; mid += [mat] * 6
+        self.meshes = [(np.array(v, np.float32), np.array(idx, np.uint32), np.array(mid, np.uint32))]
+        self.instances = [(0, np.eye(4, dtype=np.float32).reshape(16))]
+
+    def view_proj(self, aspect, rt=None):
+        return self._v, self._p
+
+
+def test_direct_light_of_a_rectangle_matches_the_analytic_irradiance(rt, orc):
+    """An ANALYTIC pin of the integrator, independent of this repository's arithmetic: a Lambert floor under a rectangular emitter
+    with nothing else in the scene has outgoing radiance (Kd / pi) E(x), E the irradiance of the rectangle (numerical quadrature
+    here).  With max_bounces = 2 the estimate is NEE at the floor (light CDF, area pdf, MIS weight) plus the BSDF-sampled ray that
+    reaches the light (emissive-hit MIS weight); a wrong pdf convention, MIS weight, cosine or throughput shows up as a bias."""
+    sc = _FloorAndLight()
+    W, H = 24, 16
+    sc._v = rt.lookat((2.5, 1.6, 1.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
+    sc._p = rt.perspective_fov_rh(np.radians(60.0), W / H, 0.1, 1000.0)
+    o = orc.Oracle().load(sc, W / H)
+    p = rt.Params(width=W, height=H, spp=600, max_bounces=2, nee_samples=1, flags=1)
+    acc, cnt = o.render(p)
+    img = acc[..., :3] / np.maximum(acc[..., 3:4], 1.0)
+    rays = o.primary_rays(rt.Params(width=W, height=H), 1)
+    hits = o.trace_closest(rays, 0)
+    prim = hits[:, 3].view(np.uint32).reshape(H, W)
+    floor = (prim == 0) | (prim == 1)
+    assert floor.sum() > 150 and ((prim == 2) | (prim == 3)).sum() > 3        # the view shows floor and light
+    X = (rays[:, 0:3] + hits[:, 0:1] * rays[:, 4:7]).reshape(H, W, 3).astype(np.float64)
+    # irradiance of the rectangle at floor points: E = Le * integral of cos_x cos_y / r^2 dA, midpoint rule 400 x 200
+    nx, nz = 400, 200
+    gx = (np.arange(nx) + 0.5) / nx * 2 * sc.LX - sc.LX
+    gz = (np.arange(nz) + 0.5) / nz * 2 * sc.LZ - sc.LZ
+    dA = (2 * sc.LX / nx) * (2 * sc.LZ / nz)
+    ff = np.zeros((H, W))
+    for yy, xx in zip(*np.nonzero(floor)):
+        dx, dz = gx[:, None] - X[yy, xx, 0], gz[None, :] - X[yy, xx, 2]
+        r2 = dx * dx + dz * dz + sc.LY ** 2
+        ff[yy, xx] = (sc.LY * sc.LY / (r2 * r2)).sum() * dA                    # cos_x = cos_y = LY / r
+    expect = ff[..., None] * (np.array(sc.KD) / np.pi)[None, None, :] * np.array(sc.KE)[None, None, :]
+    got, ref = img[floor], expect[floor]
+    # the whole floor region: 600 spp x ~250 pixels, Monte-Carlo error far below 1 %
+    assert abs(got.sum() / ref.sum() - 1.0) < 0.01, got.sum() / ref.sum()
+    for ch in range(3):
+        assert abs(got[:, ch].sum() / ref[:, ch].sum() - 1.0) < 0.012
+    # per pixel: no bias pattern (bright pixels under the light and dim ones far away alike)
+    bright = ref[:, 0] > 0.25 * ref[:, 0].max()
+    assert bright.sum() > 10 and np.abs(got[bright] / ref[bright] - 1.0).max() < 0.15
+    dim = ~bright
+    assert abs(got[dim].sum() / ref[dim].sum() - 1.0) < 0.02
+    # pixels that see the emitter itself show its radiance exactly
+    assert np.allclose(img[(prim == 2) | (prim == 3)], sc.KE)
+
+
 def test_light_list_follows_reference_rules(rt, garage_oracle, garage_scene):
     L = garage_oracle.lights()
     n = len(L)
