@@ -327,11 +327,17 @@ bool SceneHost::build(BuiltScene& B) {
                 const uint32_t m = g < B.shade.size() ? B.shade[g].mat : 0xFFFFFFFFu;
                 return m < B.mats.size() && B.mats[m].Ke_len > 0.0f;
             };
+            // The same holds for a hull face whose PLANE carries a light vertex (a lamp flush with a wall or ceiling): the segment's end point
+            // lies in that plane, so the face's triangles can pass the float test too.  Such faces stay in the list as well.
+            std::vector<D3> light_verts;
+            for (size_t s = 0; s < n; s++) if (emissive((int)s)) for (int k = 0; k < 3; k++) light_verts.push_back(V[s][k]);
+            const double near_plane = 5.0 * (double)kSBias + 2e-4 * (double)scale;      // the segment's end margin + the float test's error of t (Cornell's light hangs 9e-4 below its ceiling: not near)
             std::vector<Rec> occ, hull;
             for (const Rec& R : recs) {
                 bool pos = false, neg = false;
                 const bool degenerate = R.pl[0] == 0.0 && R.pl[1] == 0.0 && R.pl[2] == 0.0;
-                const bool light = emissive(R.s0) || emissive(R.s1);
+                bool light = emissive(R.s0) || emissive(R.s1);
+                for (const D3& q : light_verts) if (fabs(R.pl[0] * q.x + R.pl[1] * q.y + R.pl[2] * q.z - R.pl[3]) <= near_plane) light = true;
                 for (size_t s = 0; s < n && !degenerate; s++) for (int k = 0; k < 3; k++) {
                     const double dd = R.pl[0] * V[s][k].x + R.pl[1] * V[s][k].y + R.pl[2] * V[s][k].z - R.pl[3];
                     if (dd > tol) pos = true; else if (dd < -tol) neg = true;

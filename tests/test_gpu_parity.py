@@ -1,6 +1,7 @@
 """GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
 Integer / index work is compared bit-exactly; radiance within north_star's 1e-4 relative L2 (in
 practice bit-exact, which the tests also report)."""
+import os
 import numpy as np
 import pytest
 
@@ -644,6 +645,96 @@ def test_c4_sizes_4k_shards_and_stack_variants(rt, orc):
         assert np.array_equal(bits(imgs[0]), bits(im))
     # a 64 x 36 crop-sized oracle check is done elsewhere; here: plausibility + determinism
     assert np.isfinite(imgs[0]).all() and (imgs[0][..., 3] == 1).all() and imgs[0][..., :3].mean() > 0.01
+
+
+class RandomTinyScene:
+    """<= 64 random triangles in the reference's data model: loose triangles, planar quads (some flush with the scene's bounding box, i.e.
+    hull faces), boxes, one to three emissive polygons (sometimes hull faces themselves), Lambert and GGX materials"""
+    def __init__(self, rt, seed):
+        rng = np.random.default_rng(seed)
+        nm = int(rng.integers(2, 6))
+        m = np.zeros((1 + nm, 32), np.float32)
+        m[0, 0:4] = (1, 1, 1, 1); m[0, 12] = 1.0
+        for i in range(1, 1 + nm):
+            m[i, 0:3] = rng.uniform(0.05, 0.9, 3); m[i, 3] = 1.0
+            m[i, 4:7] = rng.uniform(0.0, 0.9, 3) * rng.integers(0, 2); m[i, 7] = 1.0
+            m[i, 12] = rng.choice([1.0, 0.5, 0.2, 0.03]); m[i, 13] = rng.choice([0.0, 0.0, 1.0])
+            m[i, 16:32] = np.clip(rng.uniform(0.6, 1.0, 16), 0.05, 1.0)           # any plausible Ess table
+        nl = int(rng.integers(1, 4))
+        lights = list(range(1, 1 + min(nl, nm - 1)))
+        for i in lights:
+            m[i, 0:3] = 0.0; m[i, 8:11] = rng.uniform(0.5, 12.0, 3)
+        self.materials = m
+        tris, mats = [], []
+        def quad(c, a, b, mat):
+            p = [c - a - b, c + a - b, c + a + b, c - a + b]
+            tris.extend([(p[0], p[1], p[2]), (p[0], p[2], p[3])]); mats.extend([mat, mat])
+        R = 1.0
+        nonl = [i for i in range(1, 1 + nm) if i not in lights]
+        if rng.random() < 0.7:                                  # a room-like shell: some faces of the bounding box (hull faces)
+            for ax in range(3):
+                for sgn in (-1.0, 1.0):
+                    if rng.random() < 0.6:
+                        c = np.zeros(3); c[ax] = sgn * R
+                        a = np.zeros(3); a[(ax + 1) % 3] = R
+                        b = np.zeros(3); b[(ax + 2) % 3] = R
+                        quad(c, a, b, int(rng.choice(nonl)))
+        for li in lights:                                       # emissive quads: hanging inside, or flush with a box face
+            ax = int(rng.integers(0, 3)); c = rng.uniform(-0.5, 0.5, 3); c[ax] = rng.choice([0.999 * R, R, rng.uniform(0.3, 0.9)])
+            a = np.zeros(3); a[(ax + 1) % 3] = rng.uniform(0.1, 0.4)
+            b = np.zeros(3); b[(ax + 2) % 3] = rng.uniform(0.1, 0.4)
+            quad(c, a, b, li)
+        while len(tris) < 58 and rng.random() < 0.9:
+            kind = rng.integers(0, 3)
+            c = rng.uniform(-0.8, 0.8, 3)
+            if kind == 0:                                       # loose triangle (slivers included)
+                tris.append(tuple(c + rng.normal(scale=rng.choice([0.02, 0.2, 0.5]), size=3) for _ in range(3))); mats.append(int(rng.choice(nonl)))
+            elif kind == 1:                                     # tilted quad
+                a = rng.normal(size=3); a *= rng.uniform(0.05, 0.4) / np.linalg.norm(a)
+                b = np.cross(a, rng.normal(size=3)); b *= rng.uniform(0.05, 0.4) / max(np.linalg.norm(b), 1e-9)
+                quad(c, a, b, int(rng.choice(nonl)))
+            elif len(tris) <= 46:                               # axis-aligned box
+                h = rng.uniform(0.05, 0.3, 3); mat = int(rng.choice(nonl))
+                for ax in range(3):
+                    for sgn in (-1.0, 1.0):
+                        cc = c.copy(); cc[ax] += sgn * h[ax]
+                        a = np.zeros(3); a[(ax + 1) % 3] = h[(ax + 1) % 3]
+                        b = np.zeros(3); b[(ax + 2) % 3] = h[(ax + 2) % 3]
+                        quad(cc, a, b, mat)
+        t = np.array(tris, np.float32).reshape(-1, 3, 3)[:64]
+        mats = mats[:len(t)]
+        v = np.zeros((len(t) * 3, 7), np.float32); v[:, 0:3] = t.reshape(-1, 3)
+        self.meshes = [(v, np.arange(len(t) * 3, dtype=np.uint32), np.repeat(np.array(mats, np.uint32), 3))]
+        self.instances = [(0, np.eye(4, dtype=np.float32).reshape(16))]
+        eye = rng.uniform(-0.9, 0.9, 3); eye[int(rng.integers(0, 3))] = rng.choice([-2.5, 2.5, 0.0])
+        self._v = rt.lookat(tuple(eye), tuple(rng.uniform(-0.3, 0.3, 3)), (0.0, 1.0, 0.0) if abs(eye[1]) < 2 else (0.0, 0.0, 1.0))
+        self._rt = rt
+
+    def view_proj(self, aspect):
+        return self._v, self._rt.perspective_fov_rh(np.radians(60.0), aspect, 0.1, 1000.0)
+
+
+def test_random_tiny_scenes_fused_path_equals_oracle(rt, orc):
+    """fuzz of the tiny-scene kernels (plane-form pre-test, merged quads, hull-face shortcut, nearest-first exact tests, shadow-ray
+    compaction, persistent bounce loop) against the brute-force definition on random geometry, lights and cameras"""
+    W, H = 64, 40
+    bad = []
+    for seed in range(int(os.environ.get("RTX_FUZZ_SCENES", "60"))):
+        sc = RandomTinyScene(rt, 1000 + seed)
+        flags = seed & 1
+        p = rt.Params(width=W, height=H, spp=3, max_bounces=5, nee_samples=1 + (seed % 3 == 0), flags=flags, frame_seed=seed)
+        o = orc.Oracle().load(sc, W / H)
+        oa, oc = o.render(p)
+        c = rt.Context(0); c.upload(sc, W / H)
+        assert c.stats().triangles <= 64
+        c.clear(W, H); c.render(p); st = c.stats(); im = c.read_accum()
+        rays = np.concatenate([o.primary_rays(rt.Params(width=W, height=H), 1), random_rays(4000, seed, -1.2, 1.2)])
+        ok = np.array_equal(bits(im), bits(oa)) and (st.rays_primary, st.rays_extension, st.rays_shadow) == oc \
+            and np.array_equal(bits(c.trace_closest(rays)), bits(o.trace_closest(rays, 0)))
+        c.close()
+        if not ok:
+            bad.append(seed)
+    assert not bad, f"scenes that differ from the oracle: {bad}"
 
 
 def test_analytic_rectangle_light_scene_gpu_equals_oracle(rt, orc):
