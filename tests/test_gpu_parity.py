@@ -719,21 +719,24 @@ def test_random_tiny_scenes_fused_path_equals_oracle(rt, orc):
     compaction, persistent bounce loop) against the brute-force definition on random geometry, lights and cameras"""
     W, H = 64, 40
     bad = []
+    general_too = os.environ.get("RTX_FUZZ_GENERAL", "0") == "1"
     for seed in range(int(os.environ.get("RTX_FUZZ_SCENES", "60"))):
         sc = RandomTinyScene(rt, 1000 + seed)
         flags = seed & 1
         p = rt.Params(width=W, height=H, spp=3, max_bounces=5, nee_samples=1 + (seed % 3 == 0), flags=flags, frame_seed=seed)
         o = orc.Oracle().load(sc, W / H)
         oa, oc = o.render(p)
-        c = rt.Context(0); c.upload(sc, W / H)
-        assert c.stats().triangles <= 64
-        c.clear(W, H); c.render(p); st = c.stats(); im = c.read_accum()
         rays = np.concatenate([o.primary_rays(rt.Params(width=W, height=H), 1), random_rays(4000, seed, -1.2, 1.2)])
-        ok = np.array_equal(bits(im), bits(oa)) and (st.rays_primary, st.rays_extension, st.rays_shadow) == oc \
-            and np.array_equal(bits(c.trace_closest(rays)), bits(o.trace_closest(rays, 0)))
-        c.close()
-        if not ok:
-            bad.append(seed)
+        ob = o.trace_closest(rays, 0)
+        for small in ((1, 0) if (seed % 3 == 0 or general_too) else (1,)):     # every third scene also through the general BVH kernels
+            c = rt.Context(0); c.set_option(rt.OPT_SMALL_SCENE, small); c.upload(sc, W / H)
+            assert c.stats().triangles <= 64
+            c.clear(W, H); c.render(p); st = c.stats(); im = c.read_accum()
+            ok = np.array_equal(bits(im), bits(oa)) and (st.rays_primary, st.rays_extension, st.rays_shadow) == oc \
+                and np.array_equal(bits(c.trace_closest(rays)), bits(ob))
+            c.close()
+            if not ok:
+                bad.append((seed, small))
     assert not bad, f"scenes that differ from the oracle: {bad}"
 
 
