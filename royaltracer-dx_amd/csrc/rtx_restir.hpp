@@ -208,6 +208,11 @@ __device__ f3 sample_path_simple_dev(P1Ctx& C, const DevFrame& f, Res& rs, f3 in
         acc_pdf *= pdf_bsdf;
         acc_f = mk3(acc_f.x * thr.x, acc_f.y * thr.y, acc_f.z * thr.z);
         acc_f_rec = mk3(acc_f_rec.x * thr.x, acc_f_rec.y * thr.y, acc_f_rec.z * thr.z);
+        // outgoing = -sample (Path_Sampler_v6.hlsl:263-269).  Assigned HERE, after its last use of this iteration, not with origin / mat /
+        // normal at the loop's end: placed there, hipcc (ROCm 7.2, gfx950) dropped the update on the path "light hit whose contribution is
+        // zero, fall through" and the next iteration sampled with the stale direction (found by the ReSTIR fuzz: ray counts off by one in
+        // 3 % of random scenes while every buffer stayed byte-identical, because such paths carry zero weight).
+        outgoing = -smp;
         if (mk.Ke_len > 0.0f) {
             const float dist = length(h.pos - origin), dist2 = dist * dist;
             const float cos_t = dot(h.normal, -smp);
@@ -224,7 +229,7 @@ __device__ f3 sample_path_simple_dev(P1Ctx& C, const DevFrame& f, Res& rs, f3 in
                 break;
             }
         }
-        origin = h.pos; mat = h.mat; outgoing = -smp; normal = h.normal;
+        origin = h.pos; mat = h.mat; normal = h.normal;
     }
     if (nee > 0 && length(x2s - x1s) > kEps) {
         const f3 dv = x2s - x1s;
