@@ -332,8 +332,15 @@ bool SceneHost::build(BuiltScene& B) {
             std::vector<D3> light_verts;
             for (size_t s = 0; s < n; s++) if (emissive((int)s)) for (int k = 0; k < 3; k++) light_verts.push_back(V[s][k]);
             const double near_plane = 5.0 * (double)kSBias + 2e-4 * (double)scale;      // the segment's end margin + the float test's error of t (Cornell's light hangs 9e-4 below its ceiling: not near)
+            // The shortcut also needs FLAT shading everywhere: the segment starts at pos + bias * SHADING normal and is only cast when the
+            // shading normal faces the light; with interpolated vertex normals neither keeps it on the inner side of the face it starts
+            // on (brute force then reports that face as the occluder).  Any smooth-shaded triangle turns the shortcut off for the scene.
+            bool all_flat = true;
+            for (const TriShade& ts : B.shade) for (int k = 0; k < 3; k++)
+                if (ts.n0[k] != ts.flat[k] || ts.n1[k] != ts.flat[k] || ts.n2[k] != ts.flat[k]) all_flat = false;
             std::vector<Rec> occ, hull;
             for (const Rec& R : recs) {
+                if (!all_flat) { occ.push_back(R); continue; }
                 bool pos = false, neg = false;
                 const bool degenerate = R.pl[0] == 0.0 && R.pl[1] == 0.0 && R.pl[2] == 0.0;
                 bool light = emissive(R.s0) || emissive(R.s1);

@@ -702,10 +702,33 @@ class RandomTinyScene:
                         b = np.zeros(3); b[(ax + 2) % 3] = h[(ax + 2) % 3]
                         quad(cc, a, b, mat)
         t = np.array(tris, np.float32).reshape(-1, 3, 3)[:64]
-        mats = mats[:len(t)]
-        v = np.zeros((len(t) * 3, 7), np.float32); v[:, 0:3] = t.reshape(-1, 3)
-        self.meshes = [(v, np.arange(len(t) * 3, dtype=np.uint32), np.repeat(np.array(mats, np.uint32), 3))]
-        self.instances = [(0, np.eye(4, dtype=np.float32).reshape(16))]
+        mats = np.array(mats[:len(t)], np.uint32)
+        # some scenes: smooth vertex normals, with zero components here and there (Hit_v6.hlsl:40-46 tests all(n != 0) per component)
+        nrm = np.zeros((len(t), 3, 3), np.float32)
+        if seed % 4 == 1:
+            fl = np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]); fl /= np.maximum(np.linalg.norm(fl, axis=1, keepdims=True), 1e-20)
+            nrm = fl[:, None, :] + rng.normal(scale=0.3, size=(len(t), 3, 3)).astype(np.float32)
+            nrm[rng.random((len(t), 3)) < 0.15] = 0.0                                  # whole normal missing -> flat
+            z = rng.random((len(t), 3, 3)) < 0.05; nrm[z] = 0.0                        # single zero component -> flat for that vertex too
+        # some scenes: the triangles split over two meshes / several instances with affine transforms (mirrors, non-uniform scale);
+        # the world-space geometry stays the one generated above (vertices are pulled back through the inverse transform)
+        groups = [np.arange(len(t))]
+        if seed % 5 == 2 and len(t) >= 6:
+            cut = int(rng.integers(2, len(t) - 2)); groups = [np.arange(0, cut), np.arange(cut, len(t))]
+        self.meshes, self.instances = [], []
+        matid_base = 0                                            # Vertex.normal.w = base of the model inside the global materialIDs[] (ObjLoader.h:466)
+        for gi, idx in enumerate(groups):
+            M = np.eye(4)
+            if len(groups) > 1:
+                A = rng.normal(size=(3, 3)) * 0.4 + np.diag(rng.choice([-1.0, 1.0], 3) * rng.uniform(0.5, 1.5, 3))
+                M[:3, :3] = A; M[:3, 3] = rng.uniform(-0.3, 0.3, 3)
+            Mi = np.linalg.inv(M)
+            tv = t[idx].reshape(-1, 3).astype(np.float64)
+            local = (tv @ Mi[:3, :3].T + Mi[:3, 3]).astype(np.float32)
+            v = np.zeros((len(idx) * 3, 7), np.float32); v[:, 0:3] = local; v[:, 3:6] = nrm[idx].reshape(-1, 3); v[:, 6] = matid_base
+            matid_base += len(idx) * 3
+            self.meshes.append((v, np.arange(len(idx) * 3, dtype=np.uint32), np.repeat(mats[idx], 3)))
+            self.instances.append((gi, np.ascontiguousarray(M.T, np.float32).reshape(16)))       # column-major
         eye = rng.uniform(-0.9, 0.9, 3); eye[int(rng.integers(0, 3))] = rng.choice([-2.5, 2.5, 0.0])
         self._v = rt.lookat(tuple(eye), tuple(rng.uniform(-0.3, 0.3, 3)), (0.0, 1.0, 0.0) if abs(eye[1]) < 2 else (0.0, 0.0, 1.0))
         self._rt = rt
@@ -723,7 +746,8 @@ def test_random_tiny_scenes_fused_path_equals_oracle(rt, orc):
     for seed in range(int(os.environ.get("RTX_FUZZ_SCENES", "60"))):
         sc = RandomTinyScene(rt, 1000 + seed)
         flags = seed & 1
-        p = rt.Params(width=W, height=H, spp=3, max_bounces=5, nee_samples=1 + (seed % 3 == 0), flags=flags, frame_seed=seed)
+        p = rt.Params(width=W, height=H, spp=3, max_bounces=5 + 2 * (seed % 7 == 3), nee_samples=1 + (seed % 3 == 0), flags=flags | (2 if seed % 6 == 4 else 0),
+                      frame_seed=seed, rr_start=3 if seed % 5 else 1, sample_base=1 + seed % 4)
         o = orc.Oracle().load(sc, W / H)
         oa, oc = o.render(p)
         rays = np.concatenate([o.primary_rays(rt.Params(width=W, height=H), 1), random_rays(4000, seed, -1.2, 1.2)])
