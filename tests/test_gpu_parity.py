@@ -650,7 +650,7 @@ def test_c4_sizes_4k_shards_and_stack_variants(rt, orc):
 class RandomTinyScene:
     """<= 64 random triangles in the reference's data model: loose triangles, planar quads (some flush with the scene's bounding box, i.e.
     hull faces), boxes, one to three emissive polygons (sometimes hull faces themselves), Lambert and GGX materials"""
-    def __init__(self, rt, seed):
+    def __init__(self, rt, seed, max_tris=64):
         rng = np.random.default_rng(seed)
         nm = int(rng.integers(2, 6))
         m = np.zeros((1 + nm, 32), np.float32)
@@ -684,7 +684,8 @@ class RandomTinyScene:
             a = np.zeros(3); a[(ax + 1) % 3] = rng.uniform(0.1, 0.4)
             b = np.zeros(3); b[(ax + 2) % 3] = rng.uniform(0.1, 0.4)
             quad(c, a, b, li)
-        while len(tris) < 58 and rng.random() < 0.9:
+        target = 58 if max_tris <= 64 else int(rng.integers(65, max_tris))
+        while len(tris) < target and (max_tris > 64 or rng.random() < 0.9):
             kind = rng.integers(0, 3)
             c = rng.uniform(-0.8, 0.8, 3)
             if kind == 0:                                       # loose triangle (slivers included)
@@ -693,7 +694,7 @@ class RandomTinyScene:
                 a = rng.normal(size=3); a *= rng.uniform(0.05, 0.4) / np.linalg.norm(a)
                 b = np.cross(a, rng.normal(size=3)); b *= rng.uniform(0.05, 0.4) / max(np.linalg.norm(b), 1e-9)
                 quad(c, a, b, int(rng.choice(nonl)))
-            elif len(tris) <= 46:                               # axis-aligned box
+            elif len(tris) <= target - 12:                      # axis-aligned box
                 h = rng.uniform(0.05, 0.3, 3); mat = int(rng.choice(nonl))
                 for ax in range(3):
                     for sgn in (-1.0, 1.0):
@@ -701,7 +702,7 @@ class RandomTinyScene:
                         a = np.zeros(3); a[(ax + 1) % 3] = h[(ax + 1) % 3]
                         b = np.zeros(3); b[(ax + 2) % 3] = h[(ax + 2) % 3]
                         quad(cc, a, b, mat)
-        t = np.array(tris, np.float32).reshape(-1, 3, 3)[:64]
+        t = np.array(tris, np.float32).reshape(-1, 3, 3)[:max_tris]
         mats = np.array(mats[:len(t)], np.uint32)
         # some scenes: smooth vertex normals, with zero components here and there (Hit_v6.hlsl:40-46 tests all(n != 0) per component)
         nrm = np.zeros((len(t), 3, 3), np.float32)
@@ -761,6 +762,39 @@ def test_random_tiny_scenes_fused_path_equals_oracle(rt, orc):
             c.close()
             if not ok:
                 bad.append((seed, small))
+    assert not bad, f"scenes that differ from the oracle: {bad}"
+
+
+def test_random_midsize_scenes_general_path_and_refit_equal_oracle(rt, orc):
+    """fuzz of the general BVH kernels on random scenes of 65 ... 3000 triangles: image, ray counts, closest-hit queries, then a
+    transform-only commit of one instance (mirroring, non-uniform scale) through the GPU refit and the host refit; the oracle rebuilds.
+    (600 scenes pass with RTX_FUZZ_SCENES=600.)"""
+    W, H = 48, 32
+    bad = []
+    for seed in range(int(os.environ.get("RTX_FUZZ_SCENES", "12"))):
+        sc = RandomTinyScene(rt, 9000 + seed, max_tris=[200, 800, 3000][seed % 3])
+        p = rt.Params(width=W, height=H, spp=2, max_bounces=5, nee_samples=1 + seed % 2, flags=seed & 1, frame_seed=seed)
+        o = orc.Oracle().load(sc, W / H)
+        oa, oc = o.render(p)
+        rays = np.concatenate([o.primary_rays(rt.Params(width=W, height=H), 1), random_rays(3000, seed, -1.2, 1.2)])
+        ob = o.trace_closest(rays, 1)
+        M = np.eye(4); M[:3, :3] = np.diag([1.1, 0.9, -1.05]) @ np.array([[np.cos(.3), 0, np.sin(.3)], [0, 1, 0], [-np.sin(.3), 0, np.cos(.3)]]); M[:3, 3] = (0.05, -0.02, 0.03)
+        inst = len(sc.instances) - 1
+        M2 = (M @ np.asarray(sc.instances[inst][1], np.float64).reshape(4, 4).T).T.astype(np.float32).reshape(16)
+        o2 = orc.Oracle().load(sc, W / H); o2.set_instance_transform(inst, M2)
+        oa2, oc2 = o2.render(p)
+        for refit in (1, 0):
+            c = rt.Context(0); c.set_option(rt.OPT_GPU_REFIT, refit); c.upload(sc, W / H)
+            assert c.stats().triangles > 64
+            c.clear(W, H); c.render(p); st = c.stats()
+            ok = np.array_equal(bits(c.read_accum()), bits(oa)) and (st.rays_primary, st.rays_extension, st.rays_shadow) == oc \
+                and np.array_equal(bits(c.trace_closest(rays)), bits(ob))
+            c.set_instance_transform(inst, M2); c.commit()
+            c.clear(W, H); c.render(p); st2 = c.stats()
+            ok = ok and np.array_equal(bits(c.read_accum()), bits(oa2)) and (st2.rays_primary, st2.rays_extension, st2.rays_shadow) == oc2 and c.validate_bvh() == 0
+            c.close()
+            if not ok:
+                bad.append((seed, refit))
     assert not bad, f"scenes that differ from the oracle: {bad}"
 
 
