@@ -109,6 +109,7 @@ void load_mtl(const std::string& path, std::vector<MtlRec>& mats, std::unordered
     std::ifstream f(path);
     if (!f) return;                         // tinyobj only warns when the .mtl is missing
     std::string line; MtlRec cur; bool have = false;
+    bool has_kd = false;                    // tiny_obj_loader.h:2083-2085,2173: set by any `Kd` line and (sic) never cleared at `newmtl`
     auto flush = [&]() { if (have) { map[cur.name] = (int)mats.size(); mats.push_back(cur); } };
     while (std::getline(f, line)) {
         if (!line.empty() && line.back() == '\r') line.pop_back();
@@ -116,7 +117,8 @@ void load_mtl(const std::string& path, std::vector<MtlRec>& mats, std::unordered
         if (!*p || *p == '#') continue;
         auto key = [&](const char* k) { size_t n = strlen(k); if (!strncmp(p, k, n) && (p[n] == ' ' || p[n] == '\t')) { p += n; return true; } return false; };
         if (key("newmtl")) { flush(); cur = MtlRec(); have = true; cur.name = skip_ws(p); while (!cur.name.empty() && (cur.name.back() == ' ' || cur.name.back() == '\t')) cur.name.pop_back(); }
-        else if (key("Kd")) { for (int i = 0; i < 3; i++) parse_float(p, cur.Kd[i]); }
+        else if (key("Kd")) { for (int i = 0; i < 3; i++) parse_float(p, cur.Kd[i]); has_kd = true; }
+        else if (key("map_Kd")) { if (!has_kd) cur.Kd[0] = cur.Kd[1] = cur.Kd[2] = 0.6f; }        // a diffuse texture without a Kd before it: tiny_obj_loader.h:2328-2341
         else if (key("Ks")) { for (int i = 0; i < 3; i++) parse_float(p, cur.Ks[i]); }
         else if (key("Ke")) { for (int i = 0; i < 3; i++) parse_float(p, cur.Ke[i]); }
         else if (key("d")) { parse_float(p, cur.d); cur.has_d = true; }
@@ -128,6 +130,58 @@ void load_mtl(const std::string& path, std::vector<MtlRec>& mats, std::unordered
         else if (key("Pc")) parse_float(p, cur.Pc);
     }
     flush();
+}
+
+// Polygons with more than four vertices: the ear clipping of tinyobjloader v2.0.0's default build (tiny_obj_loader.h:1741-1963, no
+// mapbox earcut), restated with its exact decisions, because the ORDER and the NUMBER of the triangles it emits are what the reference's
+// loader sees (pinned by tests/golden/objfuzz):
+//  * the polygon is projected on two coordinate axes picked from the FIRST corner (three consecutive vertices) whose cross product has a
+//    component above FLT_EPSILON: (y,z) if |c.x| is the strict maximum, (x,y) if |c.z| is, else (x,z); (y,z) if there is no such corner;
+//  * candidate ear = three consecutive vertices from `guess`; it is skipped when cross(e0, e1) * (v0.x v1.y - v0.y v1.x) / 2 < 0 (sic: the
+//    second factor is not the polygon's area) or when another remaining vertex lies inside it (the pnpoly crossing test);
+//  * a clipped ear removes its middle vertex; the search gives up after as many fruitless tries as there are vertices left, and whatever
+//    remains is emitted only if it is exactly one triangle.  All arithmetic is binary32, in the reference's operation order.
+template <class Emit>
+void ear_clip(const float* V, const std::vector<ObjIdx>& face, Emit&& tri) {
+    const size_t n0 = face.size();
+    int ax0 = 1, ax1 = 2;
+    for (size_t k = 0; k < n0; k++) {
+        const float* a = V + (size_t)face[k % n0].v * 3; const float* b = V + (size_t)face[(k + 1) % n0].v * 3; const float* c = V + (size_t)face[(k + 2) % n0].v * 3;
+        const float e0x = b[0] - a[0], e0y = b[1] - a[1], e0z = b[2] - a[2], e1x = c[0] - b[0], e1y = c[1] - b[1], e1z = c[2] - b[2];
+        const float cx = fabsf(e0y * e1z - e0z * e1y), cy = fabsf(e0z * e1x - e0x * e1z), cz = fabsf(e0x * e1y - e0y * e1x);
+        const float eps = 1.1920928955078125e-7f;                    // std::numeric_limits<float>::epsilon()
+        if (cx > eps || cy > eps || cz > eps) {
+            if (!(cx > cy && cx > cz)) { ax0 = 0; if (cz > cx && cz > cy) ax1 = 1; }
+            break;
+        }
+    }
+    std::vector<int> rem(n0);                                        // positions in `face`
+    for (size_t k = 0; k < n0; k++) rem[k] = (int)k;
+    size_t guess = 0, budget = n0, prev = n0;
+    while (rem.size() > 3 && budget > 0) {
+        const size_t m = rem.size();
+        if (guess >= m) guess -= m;
+        if (prev != m) { prev = m; budget = m; } else budget--;
+        int ind[3]; float vx[3], vy[3];
+        for (int k = 0; k < 3; k++) { ind[k] = rem[(guess + k) % m]; const float* q = V + (size_t)face[ind[k]].v * 3; vx[k] = q[ax0]; vy[k] = q[ax1]; }
+        const float e0x = vx[1] - vx[0], e0y = vy[1] - vy[0], e1x = vx[2] - vx[1], e1y = vy[2] - vy[1];
+        const float cross = e0x * e1y - e0y * e1x;
+        const float area = (vx[0] * vy[1] - vy[0] * vx[1]) * 0.5f;
+        if (cross * area < 0.0f) { guess++; continue; }
+        bool overlap = false;
+        for (size_t other = 3; other < m && !overlap; other++) {
+            const float* q = V + (size_t)face[rem[(guess + other) % m]].v * 3;
+            const float tx = q[ax0], ty = q[ax1];
+            int cflag = 0;
+            for (int i = 0, j = 2; i < 3; j = i++)
+                if (((vy[i] > ty) != (vy[j] > ty)) && (tx < (vx[j] - vx[i]) * (ty - vy[i]) / (vy[j] - vy[i]) + vx[i])) cflag = !cflag;
+            overlap = cflag != 0;
+        }
+        if (overlap) { guess++; continue; }
+        tri(ind[0], ind[1], ind[2]);
+        rem.erase(rem.begin() + (long)((guess + 1) % m));
+    }
+    if (rem.size() == 3) tri(rem[0], rem[1], rem[2]);
 }
 
 bool parse_obj(const std::string& file, const std::string& mtl_dir, ObjParsed& out, std::string& err) {
@@ -165,7 +219,7 @@ bool parse_obj(const std::string& file, const std::string& mtl_dir, ObjParsed& o
                 const float* V = out.v.data();
                 auto d2 = [&](int a, int b) { float s = 0; for (int k = 0; k < 3; k++) { float e = V[face[b].v * 3 + k] - V[face[a].v * 3 + k]; s += e * e; } return s; };
                 if (d2(0, 2) < d2(1, 3)) { tri(0, 1, 2); tri(0, 2, 3); } else { tri(0, 1, 3); tri(1, 2, 3); }
-            } else for (int k = 1; k + 1 < n; k++) tri(0, k, k + 1);
+            } else ear_clip(out.v.data(), face, tri);            // tiny_obj_loader.h:1741-1963
         }
         else if (!strncmp(p, "usemtl", 6) && (p[6] == ' ' || p[6] == '\t')) {
             std::string name = skip_ws(p + 6);

@@ -60,6 +60,32 @@ def test_obj_loader_matches_tinyobj(rt, garage, golden_dir):
     assert mesh == 1 and abs(m[0] - np.cos(1.57)) < 1e-6 and abs(m[2] + np.sin(1.57)) < 1e-6 and abs(m[8] - np.sin(1.57)) < 1e-6
 
 
+def test_obj_loader_matches_tinyobj_on_random_files(rt, golden_dir):
+    """24 random OBJ / MTL files (tests/golden/objfuzz, written by make_obj_fuzz.py together with what the reference's vendored
+    tinyobjloader v2.0.0 parses from them): index forms incl. negative indices, quads, n-gons (tinyobj's ear clipping decides the order
+    and the number of triangles), groups, CRLF / tabs / comments, unknown and missing materials, d vs Tr, the map_Kd default, PBR keys"""
+    D = os.path.join(golden_dir, "objfuzz")
+    ref = np.load(os.path.join(D, "ref.npz"))
+    ngons = 0
+    for k in range(24):
+        r = {n: ref["f%02d_%s" % (k, n)] for n in ("vertices", "normals", "vertex_index", "normal_index", "material_ids", "num_face_vertices", "materials")}
+        assert (r["num_face_vertices"] == 3).all()
+        sc = rt.Scene.from_obj([os.path.join(D, "fz%02d.obj" % k)], D + "/")
+        ev, ei, em = expected_load(r, 0, 0)
+        gv, gi, gm = sc.meshes[0]
+        assert gv.shape == ev.shape and np.array_equal(bits(gv), bits(ev)), k
+        assert np.array_equal(gi, ei) and np.array_equal(gm, em), k
+        assert len(sc.materials) == 1 + len(r["materials"]), k
+        for j, m in enumerate(r["materials"]):
+            g = sc.materials[1 + j]
+            assert np.array_equal(bits(g[0:3]), bits(m[0:3])) and g[3] == m[9], (k, j)            # Kd (0.6 after a bare map_Kd), dissolve (d wins over Tr)
+            assert np.array_equal(bits(g[4:7]), bits(m[3:6])) and np.array_equal(bits(g[8:11]), bits(m[6:9])), (k, j)   # Ks, Ke
+            assert np.array_equal(bits(g[12:16]), bits(m[10:14])), (k, j)                          # Pr Pm Ps Pc
+        with open(os.path.join(D, "fz%02d.obj" % k)) as f:
+            ngons += sum(1 for line in f if line.startswith("f") and len(line.split()) > 5)
+    assert ngons >= 10                                    # the set does exercise the ear clipping
+
+
 def test_lookat_matches_glm(rt, golden_dir):
     for case in json.load(open(os.path.join(golden_dir, "ref_glm_lookat.json"))):
         a = case["args"]
