@@ -27,6 +27,11 @@ PROBE = os.path.join(ROOT, "oracle", "_ref", "ref_probe")
 LOOKATS = [(-1.5, 1.5, 3.5, 0, 1, 0, 0, 1, 0),                                   # Renderer.cpp:46-48
            (278 / 555, 273 / 555, -475 / 555, 278 / 555, 273 / 555, 0, 0, 1, 0),  # Cornell camera
            (3.25, -2.5, 7.125, -1.0, 0.5, 0.25, 0.1, 0.9, 0.2)]
+_rng = np.random.default_rng(31)
+for _ in range(29):                                                                  # random eye / centre / up (not normalised, some nearly along the view)
+    e, c = _rng.normal(size=3) * 10.0 ** _rng.integers(-1, 3), _rng.normal(size=3)
+    u = _rng.normal(size=3) if _rng.random() < 0.7 else (c - e) * 0.98 + _rng.normal(size=3) * 0.2
+    LOOKATS.append(tuple(float(x) for x in np.concatenate([e, c, u])))
 
 
 def ref_fixtures():
