@@ -256,7 +256,7 @@ bool SceneHost::build(BuiltScene& B) {
     B.small_recs.clear(); B.small_tris.clear(); B.small_poly.clear(); B.small_nrec = 0; B.small_nocc = 0;
     if (!leaf_order.empty() && leaf_order.size() <= kSmallSceneMaxTris) {
         const double delta = 2e-5 * (double)scale, tol = 1e-6 * (double)scale;
-        B.small_delta = (float)delta; B.small_cm = 4e-6f * scale;
+        B.small_delta = (float)delta; B.small_cm = 4e-6f * scale; B.small_hull_margin = 1e-5f * scale;
         struct D3 { double x, y, z; };
         auto sub = [](D3 a, D3 b) { return D3{a.x - b.x, a.y - b.y, a.z - b.z}; };
         auto crs = [](D3 a, D3 b) { return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; };
@@ -335,7 +335,9 @@ bool SceneHost::build(BuiltScene& B) {
             // The shortcut also needs FLAT shading everywhere: the segment starts at pos + bias * SHADING normal and is only cast when the
             // shading normal faces the light; with interpolated vertex normals neither keeps it on the inner side of the face it starts
             // on (brute force then reports that face as the occluder).  Any smooth-shaded triangle turns the shortcut off for the scene.
-            bool all_flat = true;
+            // ... and it needs room for the per-ray guard (traverse_small): the origin sits s_bias inside its OWN face, which must stay
+            // outside the guard's margin, or every ray would fall back anyway.
+            bool all_flat = B.small_hull_margin < 0.9f * kSBias;
             for (const TriShade& ts : B.shade) for (int k = 0; k < 3; k++)
                 if (ts.n0[k] != ts.flat[k] || ts.n1[k] != ts.flat[k] || ts.n2[k] != ts.flat[k]) all_flat = false;
             std::vector<Rec> occ, hull;
