@@ -435,18 +435,19 @@ __device__ __forceinline__ unsigned long long packet_keep_mask(const DevScene& s
     if (r < sc.nsmall) {
         f3 v[4];
         for (int k = 0; k < 4; k++) { const F4 q = sc.small_poly[(size_t)r * 4 + k]; v[k] = mk3(q.x, q.y, q.z) - o; }
-        // a polygon seen (nearly) edge-on is never culled: for rays a few milliradians off its plane the exact test accepts hits up to
-        // ~eps scale / |n.d| outside the polygon, which from the camera is more than the tenth of a pixel this test allows
+        // a polygon seen (nearly) edge-on gets a wider margin: for rays a few milliradians off its plane the exact test accepts hits up to
+        // ~eps scale / |n.d| outside the polygon, which from the camera is more than the tenth of a pixel allowed below; the margin grows
+        // with 1 / |n.d| from |n.d| = 0.02 on (the error reaches 1e-4 rad at ~0.01), up to 100-fold = 0.01 rad for a polygon exactly edge-on
         const f3 pn = cross(v[1] - v[0], v[2] - v[0]);
         float gmin = 1.0f;
         for (int k = 0; k < 4; k++) gmin = minf_(gmin, fabsf(dot(pn, c[k])) * rsqrt_det(maxf_(dot(pn, pn) * dot(c[k], c[k]), 1e-30f)));
-        const bool edge_on = !(gmin > 0.02f);                              // |cos(angle between normal and corner ray)| (the error reaches the cull's 1e-4 rad at ~0.01); NaN -> keep
-        for (int i = 0; i < 4 && !edge_on; i++) {
+        const float widen = gmin > 0.02f ? 1.0f : minf_(100.0f, 0.02f / maxf_(gmin, 1e-9f));      // |cos(angle between normal and corner ray)|
+        for (int i = 0; i < 4; i++) {
             const float s = dot(n[i], mid) >= 0.0f ? 1.0f : -1.0f;     // orientation: the pyramid's inside has s * dot(n, .) >= 0
             const float nl1 = fabsf(n[i].x) + fabsf(n[i].y) + fabsf(n[i].z);
             bool all_out = true;
             for (int k = 0; k < 4; k++) {
-                const float e = 1e-4f * nl1 * (fabsf(v[k].x) + fabsf(v[k].y) + fabsf(v[k].z));
+                const float e = widen * 1e-4f * nl1 * (fabsf(v[k].x) + fabsf(v[k].y) + fabsf(v[k].z));
                 all_out = all_out && (s * dot(n[i], v[k]) < -e);
             }
             culled = culled || all_out;
