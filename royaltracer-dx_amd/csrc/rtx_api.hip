@@ -207,7 +207,7 @@ int rtx_commit_scene(rtx_ctx* c) {
     s.nodes = (const Node8GPU*)c->d_nodes.p; s.nnodes = (uint32_t)B.nodes8.size();
     s.tris = (const TriGPU*)c->d_tris.p; s.ntris = (uint32_t)B.tris8.size();
     s.shade = (const TriShade*)c->d_shade.p;
-    s.small = (const SmallRecPair*)c->d_small.p; s.small_tris = (const TriGPU*)c->d_small_tris.p; s.small_poly = (const F4*)c->d_small_poly.p; s.small_cm = B.small_cm; s.small_delta = B.small_delta; s.small_hull_margin = B.small_hull_margin;
+    s.small = (const SmallRecPair*)c->d_small.p; s.small_tris = (const TriGPU*)c->d_small_tris.p; s.small_poly = (const F4*)c->d_small_poly.p; s.small_cm = B.small_cm; s.small_delta = B.small_delta;
     s.mats = (const MatGPU*)c->d_mats.p; s.nmat = (uint32_t)B.mats.size();
     s.insts = (const InstGPU*)c->d_insts.p; s.ninst = (uint32_t)B.insts.size();
     s.lights = (const LightGPU*)c->d_lights.p; s.nlights = (uint32_t)B.lights.size();

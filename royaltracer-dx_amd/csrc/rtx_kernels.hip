@@ -200,7 +200,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const Smal
         for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
             const F4 so = sh_o[qb + i], sd = sh_d[qb + i];
             float t, u, v; uint32_t prim;
-            traverse_small<true>(sc, small, L, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, t, u, v, prim, sc.nsmall_occ);   // NEE segments only
+            const uint32_t nrec_sh = __builtin_amdgcn_ballot_w64(so.w < 0.0f) != 0ull ? sc.nsmall : sc.nsmall_occ;                        // hull guard, as in k_bounce_small
+            traverse_small<true>(sc, small, L, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), fabsf(so.w), sd.w, t, u, v, prim, nrec_sh);   // NEE segments only
             finish(i, prim != kMissPrim);
         }
         return;
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPa
             for (uint32_t j = 0; j < nee; j++) {                                  // NEE: visibility deferred to k_trace_shadow
                 bool push = false;
                 F4 so = {0, 0, 0, 0}, sd = {0, 0, 0, 0}; f3 con = mk3(0, 0, 0);
-                if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con);
+                if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con, sc.nsmall != 0u && sf.near_hull);
                 const size_t seg = (size_t)j * f.qcap * gridDim.x + qb;           // NEE slot j, this workgroup's sub-queue
                 const uint32_t slot = block_push(push, &s_cnt[1 + j]);
                 if (push) { p.sh_o[seg + slot] = so; p.sh_d[seg + slot] = sd; p.sh_c[seg + slot] = {con.x, con.y, con.z, u2f(S.pid)}; }
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
         for (uint32_t j = 0; j < nee; j++) {
             bool push = false;
             F4 so = {0, 0, 0, 0}, sd = {0, 0, 1, 0}; f3 con = mk3(0, 0, 0);
-            if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con);
+            if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con, sf.near_hull);
             PF_MARK(4);
             const uint32_t slot = block_push(push, &s_shn[par]);
             if (push) { s_sho[slot] = so; s_shd[slot] = sd; }
@@ -398,7 +399,9 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
                 const bool mine = threadIdx.x < ns;
                 const F4 ro = mine ? s_sho[threadIdx.x] : F4{0, 0, 0, 0}, rd = mine ? s_shd[threadIdx.x] : F4{0, 0, 1, 0};
                 float st_, su_, sv_; uint32_t sprim;
-                traverse_small<true>(sc, small, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, mine ? rd.w : 0.0f, st_, su_, sv_, sprim, sc.nsmall_occ, ~0ull, pf, 6);
+                // hull-face shortcut only if no ray of this wave starts near a hull plane (flag in the sign of tmin, TriShade::guard_tau)
+                const uint32_t nrec_sh = __builtin_amdgcn_ballot_w64(mine && ro.w < 0.0f) != 0ull ? sc.nsmall : sc.nsmall_occ;
+                traverse_small<true>(sc, small, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), fabsf(ro.w), mine ? rd.w : 0.0f, st_, su_, sv_, sprim, nrec_sh, ~0ull, pf, 6);
                 if (mine) s_occ[threadIdx.x] = sprim != kMissPrim ? 1 : 0;
             }
             PF_MARK(7);

@@ -15,7 +15,6 @@ struct DevScene {
     const F4* small_poly;                         // 4 polygon corners per record (packet culling of primary rays)
     const TriGPU* small_tris;                     // 2 triangles per record (staged in LDS instead of `tris`)
     float small_cm, small_delta;                  // t-margin coefficient, distance tolerance of the edge planes
-    float small_hull_margin;                      // NEE segments whose origin is closer than this to a hull-face plane test all records
     const MatGPU*   mats;   uint32_t nmat;
     const InstGPU*  insts;  uint32_t ninst;
     const LightGPU* lights; uint32_t nlights;

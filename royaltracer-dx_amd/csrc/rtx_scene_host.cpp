@@ -224,7 +224,7 @@ bool SceneHost::build(BuiltScene& B) {
                 f3 use = (nk.x != 0.0f && nk.y != 0.0f && nk.z != 0.0f) ? nk : flat;
                 dst[k][0] = use.x; dst[k][1] = use.y; dst[k][2] = use.z;
             }
-            s.pad = 0.0f;
+            s.guard_tau = 0.0f;
         }
     }
     build_lights(B);
@@ -256,7 +256,7 @@ bool SceneHost::build(BuiltScene& B) {
     B.small_recs.clear(); B.small_tris.clear(); B.small_poly.clear(); B.small_nrec = 0; B.small_nocc = 0;
     if (!leaf_order.empty() && leaf_order.size() <= kSmallSceneMaxTris) {
         const double delta = 2e-5 * (double)scale, tol = 1e-6 * (double)scale;
-        B.small_delta = (float)delta; B.small_cm = 4e-6f * scale; B.small_hull_margin = 1e-5f * scale;
+        B.small_delta = (float)delta; B.small_cm = 4e-6f * scale; B.small_hull_margin = 2e-6f * scale;     // how far inside every hull plane an NEE origin must lie (20 x the float error of a hit position)
         struct D3 { double x, y, z; };
         auto sub = [](D3 a, D3 b) { return D3{a.x - b.x, a.y - b.y, a.z - b.z}; };
         auto crs = [](D3 a, D3 b) { return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; };
@@ -354,6 +354,38 @@ bool SceneHost::build(BuiltScene& B) {
                 (((pos && neg) || light) ? occ : hull).push_back(R);
             }
             B.small_nocc = (uint32_t)occ.size();
+            // Per-ray guard of the shortcut.  An NEE segment may skip the hull faces only if its ORIGIN lies clearly inside every hull
+            // plane: a shading point in a room corner can sit within rounding distance of the neighbouring wall's plane, whose triangles the
+            // float test then accepts for a segment grazing that wall (expected about once per 1080p x 64 spp Cornell frame).
+            //   origin = pos + s_bias n_T (n_T: the shading normal the kernels compute, flat shading here), so for triangle T and hull plane B
+            //   dist(origin, B) = dist(pos, B) + s_bias (n_T . n_B), n_B the plane's inward normal;  required >= safety (20 x the float
+            //   error of pos), i.e.  dist(pos, B) >= s_TB := safety - s_bias (n_T . n_B).  Planes with s_TB <= 0 never matter (T's own plane,
+            //   the other half of a slightly twisted wall: the origin is s_bias inside them wherever it is on T).
+            //   dist(pos, B) is the barycentric blend of T's vertex distances d_i(B) >= 0, hence >= min(b) max_i d_i(B):
+            //   tau_T = max over the planes that matter of s_TB / max_i d_i(B), and "min barycentric >= tau_T" proves the origin safe.
+            // Three instructions per hit (TriShade::guard_tau); a wave with a ray that fails runs its shadow rays against all records.
+            const double safety = (double)B.small_hull_margin;
+            for (size_t si = 0; si < n && !hull.empty(); si++) {
+                const uint32_t g = f2u(B.tris[si].v0.w);
+                if (g >= B.shade.size()) continue;
+                const TriShade& ts = B.shade[g];
+                const f3 nw = normalize(xform_dir(B.insts[ts.inst].nrm, mk3(ts.flat[0], ts.flat[1], ts.flat[2])));      // = Surf::normal of a flat-shaded hit (rtx_shade.hpp)
+                double tau = 0.0;
+                for (const Rec& Hf : hull) {
+                    double dmax = 0.0, side = 0.0;
+                    for (size_t s2 = 0; s2 < n; s2++) for (int k = 0; k < 3; k++) {                                     // the scene's side of the plane
+                        const double dd = Hf.pl[0] * V[s2][k].x + Hf.pl[1] * V[s2][k].y + Hf.pl[2] * V[s2][k].z - Hf.pl[3];
+                        if (fabs(dd) > fabs(side)) side = dd;
+                    }
+                    const double sgn = side >= 0.0 ? 1.0 : -1.0;
+                    for (int k = 0; k < 3; k++) dmax = std::max(dmax, fabs(Hf.pl[0] * V[si][k].x + Hf.pl[1] * V[si][k].y + Hf.pl[2] * V[si][k].z - Hf.pl[3]));
+                    const double ndot = sgn * (Hf.pl[0] * (double)nw.x + Hf.pl[1] * (double)nw.y + Hf.pl[2] * (double)nw.z);
+                    const double need = safety - (double)kSBias * ndot + 1e-7 * (double)kSBias;                            // (+ rounding of n_T)
+                    if (!(need > 0.0)) continue;
+                    tau = dmax > 0.0 ? std::max(tau, need / dmax) : 2.0;
+                }
+                B.shade[g].guard_tau = (float)std::min(2.0, tau * 1.000001);
+            }
             recs = occ; recs.insert(recs.end(), hull.begin(), hull.end());
         }
         B.small_nrec = (uint32_t)recs.size();

@@ -32,7 +32,7 @@ struct BuiltScene {
     std::vector<F4> small_poly;       // 4 corners per record (world space; a triangle repeats its last corner)
     uint32_t small_nocc = 0;          // records [0, small_nocc) can lie between two scene points; [small_nocc, small_nrec) are faces of the scene's convex hull
     float small_cm = 0.0f, small_delta = 0.0f;   // margin coefficient for t, distance tolerance of the edge planes
-    float small_hull_margin = 0.0f;              // see DevScene
+    float small_hull_margin = 0.0f;              // NEE origins must lie this far inside every hull-face plane to use the hull-face shortcut (TriShade::guard_tau)
     std::vector<TriShade> shade;      // global triangle id order
     std::vector<InstGPU>  insts;
     std::vector<LightGPU> lights;

@@ -7,7 +7,7 @@ namespace rtx {
 // ---------------------------------------------------------------------------------------------
 // surface reconstruction: ClosestHit, Hit_v6.hlsl:12-61, from the pre-gathered TriShade record
 // ---------------------------------------------------------------------------------------------
-struct Surf { f3 pos; f3 normal; uint32_t mat; uint32_t inst; float area; f3 flat; };
+struct Surf { f3 pos; f3 normal; uint32_t mat; uint32_t inst; float area; f3 flat; bool near_hull; };   // near_hull: tiny scenes, see TriShade::guard_tau
 __device__ __forceinline__ Surf surface(const DevScene& sc, f3 o, f3 d, float t, float u, float v, uint32_t gid) {
     Surf s;
     const F4* rec = (const F4*)(sc.shade + gid);
@@ -16,6 +16,7 @@ __device__ __forceinline__ Surf surface(const DevScene& sc, f3 o, f3 d, float t,
     const f3 flat = mk3(r0.z, r0.w, r1.x);
     const f3 n0 = mk3(r1.y, r1.z, r1.w), n1 = mk3(r2.x, r2.y, r2.z), n2 = mk3(r2.w, r3.x, r3.y);
     s.area = r3.z; s.flat = flat;
+    s.near_hull = minf_(1.0f - u - v, minf_(u, v)) < r3.w;
     s.pos = madd3(d, t, o);                                                   // :15,60
     const float b0 = 1.0f - u - v;                                            // :18
     const f3 smooth = lincomb3(n0, b0, n1, u, n2, v);                         // :40-46
@@ -73,7 +74,7 @@ __device__ __forceinline__ void add_emissive(const DevScene& sc, const DevPaths&
 
 // one NEE sample: SampleLightNEE_GI, Sampler_v6.hlsl:508-647.  Returns true when a shadow ray is needed.
 __device__ __forceinline__ bool nee_sample(const DevScene& sc, const MatGPU& m, uint32_t flags, uint32_t nee, PathState& S, f3 pos, f3 normal, f3 outgoing,
-                                           F4& so, F4& sd, f3& con) {
+                                           F4& so, F4& sd, f3& con, bool near_hull = false) {
     const float rv = tea_next(S.s0, S.s1);
     int left = 0, right = (int)sc.nlights - 1, sel = 0;
     while (left <= right) {                                   // :523-537
@@ -102,7 +103,7 @@ __device__ __forceinline__ bool nee_sample(const DevScene& sc, const MatGPU& m, 
     con = mk3(lt.em[0] * (S.thr.x * F.x) * g, lt.em[1] * (S.thr.y * F.y) * g, lt.em[2] * (S.thr.z * F.z) * g);
     if (!finite3(con) || is_zero3(con)) return false;
     const f3 sorg = madd3(normalize(normal), kSBias, pos);    // :616-621
-    so = {sorg.x, sorg.y, sorg.z, 0.5f * kSBias};
+    so = {sorg.x, sorg.y, sorg.z, near_hull ? -0.5f * kSBias : 0.5f * kSBias};     // tmin; its sign carries the hull-guard flag of the tiny-scene path
     sd = {Ln.x, Ln.y, Ln.z, maxf_(kSBias, dist - kSBias * 5.0f)};
     return true;
 }

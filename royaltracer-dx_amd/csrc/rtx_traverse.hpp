@@ -285,19 +285,6 @@ __device__ __forceinline__ void traverse_small(const DevScene& sc, const SmallRe
     // keep (wave-uniform): bit r clear = no ray of this wave can touch record r (primary-ray packet culling); nrec = sc.nsmall, or sc.nsmall_occ for NEE shadow segments (both end points inside the scene's convex hull: the records
     // after the first nsmall_occ are faces OF that hull and cannot lie between them, rtx_scene_host.cpp)
     bt = tmax; bu = 0.0f; bv = 0.0f; bprim = kMissPrim;
-    if (ANY && nrec < sc.nsmall) {
-        // Hull-face shortcut of the NEE segments: only for origins that lie clearly inside EVERY hull plane.  A shading point in a room
-        // corner can sit within rounding distance of the neighbouring wall's plane (even 1e-7 outside it), and the brute-force float
-        // test then reports that wall as the occluder of a segment grazing it (expected about once per 1080p x 64 spp Cornell frame).
-        // Wave-uniform: if any ray of the wave starts within the margin of a hull plane, the wave tests all records.  2.6 % of the frame;
-        // the same test on packed plane pairs from SGPRs measured slower (scalar-load waits, 19.7 vs 18.5 ms).
-        float near = 1e30f;
-        for (uint32_t r = nrec; r < sc.nsmall; r++) {               // wave-uniform, a handful of planes (LDS broadcast reads)
-            const v4f pl = L.planes[r];
-            near = fminf(near, fabsf(__builtin_fmaf(pl.z, o.z, __builtin_fmaf(pl.y, o.y, __builtin_fmaf(pl.x, o.x, -pl.w)))));
-        }
-        if (__builtin_amdgcn_ballot_w64(near < sc.small_hull_margin && tmax > 0.0f) != 0ull) nrec = sc.nsmall;
-    }
     uint32_t cand_lo = 0u, cand_hi = 0u;
     const uint32_t npairs = (nrec + 1u) >> 1;
     const f2v dx = splat2(d.x), dy = splat2(d.y), dz = splat2(d.z), ox = splat2(o.x), oy = splat2(o.y), oz = splat2(o.z);

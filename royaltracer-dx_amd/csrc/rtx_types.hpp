@@ -53,7 +53,7 @@ struct alignas(16) TriShade {
     float flat[3];
     float n0[3], n1[3], n2[3];
     float area;
-    float pad;
+    float guard_tau;   // tiny scenes: a hit whose smallest barycentric is below this may lie within the guard margin of a hull plane (rtx_scene_host.cpp); 0 = never
 };
 static_assert(sizeof(TriShade) == 64, "TriShade must be 64 bytes");
 
