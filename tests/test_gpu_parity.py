@@ -824,6 +824,23 @@ def test_random_tiny_scenes_restir_frames_equal_oracle(rt, orc):
     assert not bad, f"scenes that differ from the oracle: {bad}"
 
 
+def test_full_size_headline_frame_is_bit_identical(rt, orc, cornell):
+    """BASELINE.json configs[1] at its FULL size — Cornell Box, 1920 x 1080, 64 spp, 8 bounces: 132.7 M paths, 552 M rays — rendered by
+    the fused tiny-scene kernels and compared with the oracle's frame bit for bit, ray counts included (the oracle needs ~10 s on 16
+    threads).  Rare-event coverage the small images cannot give: ~2e8 NEE segments, every room corner, every grazing angle."""
+    W, H = 1920, 1080
+    p = rt.Params(width=W, height=H, spp=64, max_bounces=8, nee_samples=1, rr_start=3, flags=1, frame_seed=5)
+    o = orc.Oracle().load(cornell, W / H); o.set_threads(min(16, os.cpu_count() or 1))
+    oa, oc = o.render(p)
+    c = rt.Context(0); c.upload(cornell, W / H)
+    c.clear(W, H); c.render(p); st = c.stats(); im = c.read_accum()
+    c.close()
+    assert (st.rays_primary, st.rays_extension, st.rays_shadow) == oc
+    assert oc[0] == W * H * 64 and sum(oc) > 5.4e8
+    d = (bits(im) != bits(oa)).any(-1)
+    assert not d.any(), f"{int(d.sum())} of {W * H} pixels differ, first at {np.argwhere(d)[0].tolist()}"
+
+
 def test_analytic_rectangle_light_scene_gpu_equals_oracle(rt, orc):
     """the floor-under-a-rectangular-light scene whose oracle image is pinned against the analytic irradiance
     (test_oracle_golden.py): the GPU must reproduce the oracle's image bit for bit, so the analytic pin carries over"""
