@@ -647,6 +647,9 @@ def test_c4_sizes_4k_shards_and_stack_variants(rt, orc):
     assert np.isfinite(imgs[0]).all() and (imgs[0][..., 3] == 1).all() and imgs[0][..., :3].mean() > 0.01
 
 
+FUZZ_SEED = int(os.environ.get("RTX_FUZZ_SEED", "0"))       # offset of the random scenes' seeds: RTX_FUZZ_SEED=100000 RTX_FUZZ_SCENES=5000 explores new ones
+
+
 class RandomTinyScene:
     """<= 64 random triangles in the reference's data model: loose triangles, planar quads (some flush with the scene's bounding box, i.e.
     hull faces), boxes, one to three emissive polygons (sometimes hull faces themselves), Lambert and GGX materials"""
@@ -745,7 +748,7 @@ def test_random_tiny_scenes_fused_path_equals_oracle(rt, orc):
     bad = []
     general_too = os.environ.get("RTX_FUZZ_GENERAL", "0") == "1"
     for seed in range(int(os.environ.get("RTX_FUZZ_SCENES", "60"))):
-        sc = RandomTinyScene(rt, 1000 + seed)
+        sc = RandomTinyScene(rt, 1000 + FUZZ_SEED + seed)
         flags = seed & 1
         p = rt.Params(width=W, height=H, spp=3, max_bounces=5 + 2 * (seed % 7 == 3), nee_samples=1 + (seed % 3 == 0), flags=flags | (2 if seed % 6 == 4 else 0),
                       frame_seed=seed, rr_start=3 if seed % 5 else 1, sample_base=1 + seed % 4)
@@ -772,7 +775,7 @@ def test_random_midsize_scenes_general_path_and_refit_equal_oracle(rt, orc):
     W, H = 48, 32
     bad = []
     for seed in range(int(os.environ.get("RTX_FUZZ_SCENES", "12"))):
-        sc = RandomTinyScene(rt, 9000 + seed, max_tris=[200, 800, 3000][seed % 3])
+        sc = RandomTinyScene(rt, 9000 + FUZZ_SEED + seed, max_tris=[200, 800, 3000][seed % 3])
         p = rt.Params(width=W, height=H, spp=2, max_bounces=5, nee_samples=1 + seed % 2, flags=seed & 1, frame_seed=seed)
         o = orc.Oracle().load(sc, W / H)
         oa, oc = o.render(p)
@@ -805,7 +808,7 @@ def test_random_tiny_scenes_restir_frames_equal_oracle(rt, orc):
     W, H = 48, 32
     bad = []
     for seed in range(int(os.environ.get("RTX_FUZZ_SCENES", "30"))):
-        sc = RandomTinyScene(rt, 5000 + seed)
+        sc = RandomTinyScene(rt, 5000 + FUZZ_SEED + seed)
         o = orc.Oracle().load(sc, W / H)
         vp = sc.view_proj(W / H)
         p = rt.Params(width=W, height=H, spp=2, max_bounces=3, nee_samples=2 + seed % 3, flags=seed & 1, frame_seed=seed)
