@@ -827,6 +827,62 @@ def test_random_tiny_scenes_restir_frames_equal_oracle(rt, orc):
     assert not bad, f"scenes that differ from the oracle: {bad}"
 
 
+class _RawScene:
+    """hand-built scene in the reference's data model: tris (n,3,3) world space, one material id per triangle"""
+    def __init__(self, rt, tris, mat_of_tri, materials, eye=(0.2, 0.3, 2.5)):
+        tris = np.asarray(tris, np.float32).reshape(-1, 3, 3)
+        self.materials = np.asarray(materials, np.float32).reshape(-1, 32)
+        if len(tris):
+            v = np.zeros((len(tris) * 3, 7), np.float32); v[:, 0:3] = tris.reshape(-1, 3)
+            self.meshes = [(v, np.arange(len(tris) * 3, dtype=np.uint32), np.repeat(np.asarray(mat_of_tri, np.uint32), 3))]
+            self.instances = [(0, np.eye(4, dtype=np.float32).reshape(16))]
+        else:
+            self.meshes, self.instances = [], []
+        self._v = rt.lookat(eye, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)); self._rt = rt
+
+    def view_proj(self, aspect):
+        return self._v, self._rt.perspective_fov_rh(np.radians(60.0), aspect, 0.1, 1000.0)
+
+
+def test_degenerate_scenes_gpu_equals_oracle(rt, orc):
+    """the edge cases of the scene model through the C-ABI: no geometry at all, geometry without lights, a lone emissive triangle, only
+    zero-area triangles, a zero-area light — image and ray counts as the oracle's, on both kernel paths; a material id beyond the table is refused"""
+    def mat(kd=(0.6, 0.5, 0.4), ke=(0, 0, 0)):
+        m = np.zeros(32, np.float32); m[0:3] = kd; m[3] = 1; m[8:11] = ke; m[12] = 1; m[16:32] = 0.9
+        return m
+    quad = lambda y, s: [[(-s, y, -s), (-s, y, s), (s, y, s)], [(-s, y, -s), (s, y, s), (s, y, -s)]]
+    floor, lamp = quad(-0.5, 1.5), quad(0.9, 0.3)
+    point = [[(0.1, 0.2, 0.3)] * 3]                                    # zero-area triangle
+    line = [[(0, 0, 0), (1, 1, 1), (2, 2, 2)]]                         # collinear vertices
+    M = [mat(), mat(), mat(kd=(0, 0, 0), ke=(6, 5, 4))]
+    scenes = {
+        "empty": _RawScene(rt, [], [], M),
+        "no lights": _RawScene(rt, floor, [1, 1], M),
+        "lone light": _RawScene(rt, lamp[:1], [2], M),
+        "only degenerate": _RawScene(rt, point + line + point, [1, 1, 2], M),
+        "degenerate among real": _RawScene(rt, floor + lamp + point + line, [1, 1, 2, 2, 2, 1], M),          # incl. a zero-area LIGHT
+    }
+    # a material id beyond the table: the reference reads out of bounds (zeros); the C-ABI refuses the scene at commit instead
+    bad = _RawScene(rt, floor + lamp, [1, 7, 2, 2], M)
+    c = rt.Context(0)
+    with pytest.raises(rt.RtxError, match="material id out of range"):
+        c.upload(bad, 1.5)
+    c.close()
+    W, H = 48, 32
+    for name, sc in scenes.items():
+        o = orc.Oracle().load(sc, W / H)
+        for flags in (1, 0):
+            p = rt.Params(width=W, height=H, spp=3, max_bounces=4, nee_samples=2, flags=flags, frame_seed=9)
+            oa, oc = o.render(p)
+            for small in (1, 0):
+                c = rt.Context(0); c.set_option(rt.OPT_SMALL_SCENE, small); c.upload(sc, W / H)
+                c.clear(W, H); c.render(p); st = c.stats()
+                assert np.array_equal(bits(c.read_accum()), bits(oa)), (name, flags, small)
+                assert (st.rays_primary, st.rays_extension, st.rays_shadow) == oc, (name, flags, small)
+                c.close()
+        assert oc[0] == W * H * 3
+
+
 def test_full_size_headline_frame_is_bit_identical(rt, orc, cornell):
     """BASELINE.json configs[1] at its FULL size — Cornell Box, 1920 x 1080, 64 spp, 8 bounces: 132.7 M paths, 552 M rays — rendered by
     the fused tiny-scene kernels and compared with the oracle's frame bit for bit, ray counts included (the oracle needs ~10 s on 16
