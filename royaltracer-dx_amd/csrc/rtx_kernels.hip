@@ -321,9 +321,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPa
 // stay in registers.  Radiance additions happen in the oracle's order (emissive, then NEE slot 0, 1, ...).
 // LAMBERT: RTX_FLAG_LAMBERT_ONLY is a launch constant, so it is a template parameter too: the Lambert-only instantiation carries no GGX code
 // (fewer live registers, fewer SGPR spills through v_writelane / v_readlane in the loop).
-__device__ DevScene g_dsc_exp;
 template <int WAVES, bool HAVE_HIT, bool LAMBERT>
-__global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(const DevScene* __restrict__ scp, const SmallRecPair* __restrict__ small, DevFrame f_in, DevPaths p,
+__global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, const SmallRecPair* __restrict__ small, DevFrame f_in, DevPaths p,
                                                          uint32_t bounce_first, uint32_t bounce_end,
                                                          uint32_t* __restrict__ queue_a, uint32_t* __restrict__ queue_b /* bounce b reads (b & 1 ? b : a), writes the other */,
                                                          uint32_t* __restrict__ qrows /* [bounce][gridDim.x] sub-queue lengths entering each bounce */,
@@ -336,7 +335,6 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(const DevScene* 
     // ramp-up between the bounces; the sparsely populated late bounces cost a few loop trips instead of a launch each.
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_cnt[1 + kMaxNee];
-    const DevScene& sc = *scp;
     DevFrame f = f_in;
     f.flags = LAMBERT ? (f_in.flags | 1u) : (f_in.flags & ~1u);      // bit 0 known at compile time
     const uint32_t qid = order ? order[blockIdx.x] : blockIdx.x;      // the sub-queue this workgroup owns (input and output)
@@ -733,9 +731,7 @@ void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, 
     // general instantiation: 118 VGPRs, 4 waves/SIMD (5 or 6 spill and measured slower); Lambert-only: 85 VGPRs, 5 waves/SIMD (a build for 6 waves, 80 VGPRs
     // with 2 spilled, measured the same: 19.13 vs 19.03 ms).  Bounce 0 (reads the primary hits) is its own instantiation and launch.
     const bool lam = (f.flags & 1u) != 0u, have_hit = bounce_first == 0u;
-    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_dsc_exp), &sc, sizeof(DevScene), 0, hipMemcpyHostToDevice, st);
-    DevScene* scp = nullptr; (void)hipGetSymbolAddress((void**)&scp, HIP_SYMBOL(g_dsc_exp));
-#define RTX_LAUNCH_BOUNCE(HH, LL) hipLaunchKernelGGL((k_bounce_small<4, HH, LL>), dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, (const DevScene*)scp, sc.small, f, p, bounce_first, bounce_end, queue_a, queue_b, qrows, srows, order)
+#define RTX_LAUNCH_BOUNCE(HH, LL) hipLaunchKernelGGL((k_bounce_small<4, HH, LL>), dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, bounce_first, bounce_end, queue_a, queue_b, qrows, srows, order)
     if (have_hit) { if (lam) RTX_LAUNCH_BOUNCE(true, true); else RTX_LAUNCH_BOUNCE(true, false); }
     else { if (lam) RTX_LAUNCH_BOUNCE(false, true); else RTX_LAUNCH_BOUNCE(false, false); }
 #undef RTX_LAUNCH_BOUNCE
