@@ -938,6 +938,29 @@ def test_fused_dispatch_order_and_subqueue_count_are_result_neutral(rt, orc, cor
         assert np.array_equal(bits(im), bits(ref)) and cnt == cnt0, (lpt, bpc)
 
 
+def test_bench_two_ranks_assemble_the_single_rank_frame():
+    """bench.py's N > 1 flow end to end on ONE GPU: two processes (torch.distributed.run), each renders its pixel tiles on device 0, packs
+    its slab, one gather (gloo, staged through the host: two ranks cannot share a GPU under RCCL), unpack; rank 0's JSON line must carry
+    the same frame checksum and ray counts as the single-rank run.  The 8-GPU RCCL run differs only in the collective's backend."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    common = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--checksum"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1])
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29617",
+                          os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device", "0"] + common,
+                         capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert two.returncode == 0, two.stderr[-3000:]
+    b = json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert b["n_gpus"] == 2 and b["config"]["parallelism"] == "pixel-tiles/2" and b["scaling"] == "strong"
+    assert a["accum_sha1"] == b["accum_sha1"]
+    assert a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
+    for k in ("metric", "value", "unit", "ms_per_step", "roofline"):
+        assert k in b and b[k] is not None
+
+
 def test_two_contexts_from_two_threads(rt, cornell):
     """SURVEY 8(b) threading contract: a context is not thread-safe, but different contexts may be driven from different threads.
     Two threads render different workloads concurrently on the same GPU (different scenes, options, streams); each result must be
