@@ -749,8 +749,9 @@ def test_random_tiny_scenes_fused_path_equals_oracle(rt, orc):
     for seed in range(int(os.environ.get("RTX_FUZZ_SCENES", "60"))):
         sc = RandomTinyScene(rt, 1000 + FUZZ_SEED + seed)
         flags = seed & 1
-        p = rt.Params(width=W, height=H, spp=3, max_bounces=5 + 2 * (seed % 7 == 3), nee_samples=1 + (seed % 3 == 0), flags=flags | (2 if seed % 6 == 4 else 0),
-                      frame_seed=seed, rr_start=3 if seed % 5 else 1, sample_base=1 + seed % 4)
+        nsh = 1 + (seed % 11) % 3                                   # every scene renders ONE shard of a 1 / 2 / 3-way tiling with 64 / 32 / 16-pixel tiles
+        p = rt.Params(width=W, height=H, spp=3, max_bounces=5 + 2 * (seed % 7 == 3), nee_samples=[1, 1, 2, 4][seed % 4] if seed % 3 == 0 else 1, flags=flags | (2 if seed % 6 == 4 else 0),
+                      frame_seed=seed, rr_start=3 if seed % 5 else 1, sample_base=1 + seed % 4, tile_size=[64, 32, 16][seed % 3], shard_rank=seed % nsh, shard_count=nsh)
         o = orc.Oracle().load(sc, W / H)
         oa, oc = o.render(p)
         rays = np.concatenate([o.primary_rays(rt.Params(width=W, height=H), 1), random_rays(4000, seed, -1.2, 1.2)])
