@@ -3,30 +3,45 @@
 Cornell Box, 1920x1080, 64 spp, 8 bounces, diffuse + emissive (configs[1]), on N MI355X.
 
 A "step" is one whole frame (all spp) of the hot path over synthetic, in-repo generated input that is
-already resident in HBM when the timed region starts.  For N > 1 the driver launches one process per GPU
+already resident in HBM when the timed region starts.  For N > 1 there is one process per GPU
 (torch.distributed, backend nccl == RCCL); 64x64 pixel tiles are dealt round-robin to the ranks (no
 data-path collective inside the frame) and the frame ends with ONE all_gather of the tile slabs over xGMI.
 `value` = rays traced by all ranks / max-over-ranks wall time.  Rank 0 prints one JSON line.
+
+Launching: either under a launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`, which sets
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), or plainly as `python bench.py --gpus N`: then this process — before it imports
+torch or touches the GPU — starts N children of itself with those variables set, relays rank 0's JSON line and exits with the
+worst child exit code.  Nothing is ever exec'ed from a process that has initialised the GPU.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import __graft_entry__ as graft  # noqa: E402
+import __graft_entry__ as graft  # noqa: E402   (does not import torch)
 
-# algorithmic bytes per work item of each kernel (DESIGN.md "Bytes model"; SURVEY.md §8d:
-# 224 B per extension ray = 48 (trace) + 176 (shade); 96 B per shadow ray = 48 written by shade + 48 read
-# by trace_shadow; 32 B per pixel-sample accumulation)
-ALG_BYTES = {"trace_closest": 48, "shade": 176, "trace_shadow": 48, "accumulate": 32, "raygen": 64,
-             "bounce_fused": 224}   # fused trace+shade+shadow kernel: 224 B per extension ray + 96 B per shadow ray it traces
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-TRAFFIC_PROFILE = "r01_cornell_c2_latest.json"   # written by tools/rocprof_summary.py from separate --pmc passes
+# ALGORITHMIC bytes (SURVEY.md §8d, DESIGN.md §4): 224 B per extension ray (ray 32 W + 32 R, path state 64 R + 64 W, hit 16 W + 16 R),
+# 96 B per shadow ray (48 B entry W + R), 32 B per pixel-sample (accumulation R + W).  The separate kernels of the general path split
+# them: trace_closest 48 (ray R + hit W) and shade 176 per extension ray; trace_shadow 48 of the 96 per shadow ray, the other 48 are
+# shade's write.  Primary rays are priced like extension rays (their ray + state are written by raygen: 64 B of the 224).
+B_EXT, B_SHADOW, B_PIX = 224.0, 96.0, 32.0
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# VALU issue roofline: 256 CUs x 4 SIMDs; a CDNA4 SIMD is 32 lanes wide, so a wave64 VALU instruction occupies it for 2 cycles
+# (MI355X_MICROARCH.md "v_fma_f32 (wave64): 2 cyc (SIMD-32); one wave alone: 4"; measured with tools/valu_peak.hip, profiles/r02_valu_peak.md)
+VALU_INST_PER_CYCLE_PER_SIMD = 0.5
+CLOCK_GHZ = 2.4
+PMC_PROFILE = {"cornell_1080p_64spp_8b": "r02_pmc_cornell.json", "sponza_1080p_16spp_8b": "r02_pmc_sponza.json",
+               "bistro_1080p_16spp_8b": "r02_pmc_bistro.json"}     # tools/pmc_run.sh + tools/pmc_summary.py of this same command
+KERNEL_SYMBOL = {"bounce_fused": ("k_bounce_small", "k_bounce_bvh"), "trace_closest": ("k_trace_closest",), "shade": ("k_shade",),
+                 "trace_shadow": ("k_trace_shadow",), "accumulate": ("k_accumulate",), "raygen": ("k_raygen", "k_raygen_trace_small")}
 
 WORKLOADS = {
     # name: (scene ctor, width, height, spp, bounces, nee, flags)
@@ -36,6 +51,7 @@ WORKLOADS = {
     "sponza_4k_64spp_8b": ("sponza", 3840, 2160, 64, 8, 1, 1),
     "bistro_1080p_16spp_8b": ("bistro", 1920, 1080, 16, 8, 1, 0),
 }
+EXTRA_WORKLOADS = ("sponza_1080p_16spp_8b", "bistro_1080p_16spp_8b")    # the general BVH path, timed beside the headline (GPU only)
 
 
 def make_scene(rt, kind):
@@ -48,6 +64,160 @@ def make_scene(rt, kind):
     raise ValueError(kind)
 
 
+def scene_name(kind):
+    return {"cornell": "Cornell Box (32 triangles, 2 emissive)", "sponza": "Sponza-class procedural atrium",
+            "bistro": "Bistro-class procedural street"}[kind]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# plain `python bench.py --gpus N`: start the ranks (this process never touches the GPU)
+# ------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+
+    def relay():
+        for line in procs[0].stdout:
+            sys.stdout.write(line); sys.stdout.flush()
+    t = threading.Thread(target=relay, daemon=True); t.start()
+    worst = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            alive.discard(r)
+            if rc != 0:
+                worst = worst or rc
+                for q in alive:               # one rank failed: the others would wait in the collective forever
+                    procs[q].terminate()      # (exactly the children started above, by handle)
+        time.sleep(0.05)
+    t.join(timeout=5)
+    return worst
+
+
+def load_pmc(workload):
+    """rows of tools/pmc_summary.py (list of per-kernel dicts) from the tracked profile of this workload, or None"""
+    f = PMC_PROFILE.get(workload)
+    if not f:
+        return None, None
+    path = os.path.join(ROOT, "profiles", f)
+    try:
+        return json.load(open(path)), "profiles/" + f
+    except Exception:
+        return None, None
+
+
+def pmc_for(rows, cls):
+    """sum the template instantiations of one kernel class: -> dict(valu_inst_per_launch, lanes_per_valu, hbm_bytes_per_launch) or None"""
+    if not rows:
+        return None
+    sel = [r for r in rows if r["kernel"].split("<")[0] in KERNEL_SYMBOL.get(cls, ())]
+    if not sel:
+        return None
+    launches = sum(r["launches"] for r in sel)
+    valu = sum(r["valu_inst"] for r in sel)
+    lanes = sum((r.get("lanes_per_valu") or 0.0) * r["valu_inst"] for r in sel) / valu if valu else None
+    return {"launches": launches, "valu_inst_per_launch": valu / launches, "lanes_per_valu": lanes,
+            "hbm_bytes_per_launch": sum(r["hbm_bytes"] for r in sel) / launches}
+
+
+def roofline_record(rt, workload, kms, kitems, klaunch, rays, n_pixel_samples, steps):
+    """roofline of the kernel class with the largest HIP-event time inside the timed region (events are recorded on the context's stream)"""
+    if kms.sum() <= 0:
+        return None
+    k = int(np.argmax(kms))
+    name = rt.KERNEL_NAMES[k]
+    launches = max(klaunch[k], 1)
+    n_prim, n_ext, n_sh = rays
+    # algorithmic bytes of all launches of this class over the timed region, per SURVEY 8(d)
+    if name == "bounce_fused":       # fused trace + shade + shadow + sample: every extension ray and every shadow ray of the frame
+        alg = B_EXT * n_ext + B_SHADOW * n_sh
+    elif name == "trace_closest":
+        alg = 48.0 * (n_prim + n_ext)
+    elif name == "shade":
+        alg = 176.0 * (n_prim + n_ext) + 48.0 * n_sh
+    elif name == "trace_shadow":
+        alg = 48.0 * n_sh
+    elif name == "raygen":
+        alg = 64.0 * n_prim
+    else:
+        alg = B_PIX * n_pixel_samples
+    avg_ms = kms[k] / launches
+    bytes_per_launch = alg / launches
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    rows, src = load_pmc(workload)
+    pm = pmc_for(rows, name)
+    traffic = round(pm["hbm_bytes_per_launch"]) if pm else None
+    roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "traffic_source": (src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2*FETCH+WRITE KiB; not measured in this run)") if pm else None,
+            "alg_bytes_per_launch": round(bytes_per_launch), "alg_bytes_model": "224*N_ext + 96*N_shadow (+ 32*N_px*spp for the frame)",
+            "avg_launch_ms": round(avg_ms, 5), "launches": int(klaunch[k]),
+            "kernel_ms_by_class": {rt.KERNEL_NAMES[i]: round(float(kms[i]), 3) for i in rt.KERNEL_NAMES if klaunch[i] > 0}}
+    # whole frame, all kernels: the figure BASELINE.md quotes
+    frame_ms = float(kms.sum()) / max(steps, 1)
+    frame_alg = (B_EXT * (n_ext + n_prim) + B_SHADOW * n_sh + B_PIX * n_pixel_samples) / max(steps, 1)
+    roof["frame"] = {"alg_bytes": round(frame_alg), "kernel_ms": round(frame_ms, 4),
+                     "frac": round(frame_alg / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if frame_ms > 0 else None}
+    if pm and traffic:
+        roof["traffic_frac"] = round(pm["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)   # measured HBM bytes / live launch time
+    if pm and pm["valu_inst_per_launch"]:
+        peak_inst = 256 * 4 * VALU_INST_PER_CYCLE_PER_SIMD * CLOCK_GHZ       # G wave-instructions / s
+        ach = pm["valu_inst_per_launch"] / (avg_ms * 1e-3) / 1e9
+        roof["compute"] = {"valu_inst_per_launch": round(pm["valu_inst_per_launch"]), "lanes_per_inst": round(pm["lanes_per_valu"], 2) if pm["lanes_per_valu"] else None,
+                           "achieved_ginst_s": round(ach, 2), "peak_ginst_s": round(peak_inst, 1),
+                           "peak_model": f"256 CUs x 4 SIMDs x {VALU_INST_PER_CYCLE_PER_SIMD} wave64 VALU inst/cycle x {CLOCK_GHZ} GHz",
+                           "frac_valu": round(ach / peak_inst, 5),
+                           "frac_valu_lanes": round(ach / peak_inst * (pm["lanes_per_valu"] or 64.0) / 64.0, 5),
+                           "source": src + " (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU; counters of a separate run, time of this run)"}
+        if roof["compute"]["frac_valu"] > max(roof["frac"], roof.get("traffic_frac", 0.0)):
+            roof["bound"] = "valu"
+    return roof
+
+
+def time_extra(rt, dev_index, workload, steps=2):
+    """one BVH workload, GPU only: warm-up + `steps` timed frames on a context of its own -> small record for the JSON line"""
+    import torch
+    kind, W, H, spp, bounces, nee, flags = WORKLOADS[workload]
+    scene = make_scene(rt, kind)
+    ctx = rt.Context(dev_index)
+    try:
+        ctx.upload(scene, W / H)
+        ctx.clear(W, H)
+        params = rt.Params(width=W, height=H, spp=spp, sample_base=1, max_bounces=bounces, nee_samples=nee, rr_start=3, frame_seed=1, flags=flags)
+        ctx.render(params)                                        # warm-up (allocations)
+        ctx.set_option(rt.OPT_KERNEL_TIMING, 1)
+        kms = np.zeros(rt.K_COUNT); kl = np.zeros(rt.K_COUNT); rays = np.zeros(3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            params.frame_seed = 2 + i
+            ctx.render(params)
+            st = ctx.stats()
+            kms += np.array(st.kernel_ms[:]); kl += np.array(st.kernel_launches[:], dtype=np.float64)
+            rays += np.array([st.rays_primary, st.rays_extension, st.rays_shadow], dtype=np.float64)
+        dt = time.perf_counter() - t0
+        roof = roofline_record(rt, workload, kms, None, kl, rays, float(W) * H * spp * steps, steps)
+        rec = {"ms_per_frame": round(dt * 1e3 / steps, 3), "Mrays_s": round(float(rays.sum()) / dt / 1e6, 1), "triangles": int(scene.num_triangles),
+               "rays_per_frame": int(rays.sum() / steps), "dominant_kernel": roof["kernel"] if roof else None,
+               "frac": roof["frac"] if roof else None, "bound": roof["bound"] if roof else None,
+               "frac_valu": roof.get("compute", {}).get("frac_valu") if roof else None,
+               "kernel_ms_per_frame": {k: round(v / steps, 3) for k, v in roof["kernel_ms_by_class"].items()} if roof else None}
+        return rec
+    finally:
+        ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,28 +226,35 @@ def main():
     ap.add_argument("--workload", default="cornell_1080p_64spp_8b", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the BVH workloads timed beside the headline (N = 1, default workload only)")
     ap.add_argument("--paths-per-batch", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo: host-staged gather, for testing the N>1 flow on one GPU")
     ap.add_argument("--device", type=int, default=-1, help="force this CUDA device on every rank (testing only)")
     ap.add_argument("--checksum", action="store_true", help="add a checksum of the final accumulation buffer to the JSON line")
     ap.add_argument("--opt", action="append", default=[], help="tuning: rtx option id=value (repeatable)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
-    import torch
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:          # no launcher: be the launcher (before torch / the GPU are touched)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world} set by the launcher")
+
+    import torch
     dev_index = args.device if args.device >= 0 else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     rt = graft.load_package()
     from royaltracer_dx_amd import sharding
     dist = None
+    ranks_seen = 1
     if world > 1:
         dist, rank, world = sharding.init_process_group(args.dist_backend, dev)     # backend "nccl" is RCCL on ROCm
+        ranks_seen = dist.get_world_size()
     kind, W, H, spp, bounces, nee, flags = WORKLOADS[args.workload]
     scene = make_scene(rt, kind)
     ctx = rt.Context(dev_index)
@@ -122,51 +299,47 @@ def main():
         frame(i)
     ctx.set_option(rt.OPT_KERNEL_TIMING, 0 if args.no_kernel_timing else 1)
     kms = np.zeros(rt.K_COUNT); kitems = np.zeros(rt.K_COUNT); klaunch = np.zeros(rt.K_COUNT)
-    rays = np.zeros(3); phits = 0.0
+    rays = np.zeros(3)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         st = frame(args.warmup + i)
         kms += np.array(st.kernel_ms[:]); kitems += np.array(st.kernel_items[:], dtype=np.float64); klaunch += np.array(st.kernel_launches[:], dtype=np.float64)
-        rays += np.array([st.rays_primary, st.rays_extension, st.rays_shadow], dtype=np.float64); phits += st.primary_hits
+        rays += np.array([st.rays_primary, st.rays_extension, st.rays_shadow], dtype=np.float64)
     barrier()
     dt = time.perf_counter() - t0
-    dt_max, rays_all = dt, rays
+    dt_max, rays_all, dt_ranks = dt, rays, [dt]
     if world > 1:
         cdev = dev if args.dist_backend == "nccl" else None
         dt_max = sharding.max_over_ranks(dist, dt, cdev)
         rays_all = sharding.sum_over_ranks(dist, rays, cdev)
-        # (phits stays rank-local: it only prices rank 0's own kernel launches below)
+        per = np.zeros(world); per[rank] = dt
+        dt_ranks = list(sharding.sum_over_ranks(dist, per, cdev))
     ms_per_step = dt_max * 1e3 / max(args.steps, 1)
     value = float(rays_all.sum()) / dt_max / 1e6 if dt_max > 0 else 0.0
 
-    out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel (HIP-event time per class, measured in the timed region) ----
+        sha = None
+        if args.checksum:
+            import hashlib
+            sha = hashlib.sha1(accum.cpu().numpy().tobytes()).hexdigest()
+        # ---- roofline of the dominant kernel (HIP-event time per class, measured in the timed region, on the context's stream) ----
         roof = None
-        if not args.no_kernel_timing and kms.sum() > 0:
-            k = int(np.argmax(kms))
-            name = rt.KERNEL_NAMES[k]
-            bytes_per_launch = ALG_BYTES[name] * kitems[k] / max(klaunch[k], 1)
-            if name == "bounce_fused":      # bounce 0 items were traced by raygen (their 48 B belong to it); + 96 B per shadow ray
-                bytes_per_launch += (96.0 * rays[2] - 48.0 * phits) / max(klaunch[k], 1)
-            avg_ms = kms[k] / max(klaunch[k], 1)
-            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            traffic = None
-            try:    # HBM bytes per launch from the rocprofv3 PMC passes of this same command (tools/rocprof_summary.py)
-                prof = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)))
-                if args.workload == "cornell_1080p_64spp_8b" and world == 1:
-                    sym = {"bounce_fused": "k_bounce_small"}.get(name, "k_" + name)
-                    rows = [v for k, v in prof["kernels"].items() if k.split("<")[0] == sym]      # template instantiations of one kernel
-                    traffic = round(sum(v["hbm_bytes_per_launch"] * v["calls"] for v in rows) / sum(v["calls"] for v in rows))
-            except Exception:
-                traffic = None
-            roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "alg_bytes_per_launch": round(bytes_per_launch),
-                    "alg_bytes_per_item": ALG_BYTES[name], "items_per_launch": round(kitems[k] / max(klaunch[k], 1), 1),
-                    "avg_launch_ms": round(avg_ms, 5), "launches": int(klaunch[k]),
-                    "kernel_ms_by_class": {rt.KERNEL_NAMES[i]: round(float(kms[i]), 3) for i in rt.KERNEL_NAMES if klaunch[i] > 0}}
+        if not args.no_kernel_timing:
+            local_px = float(W) * H * spp * args.steps / world
+            roof = roofline_record(rt, args.workload if world == 1 else "", kms, kitems, klaunch, rays, local_px, args.steps)
+        # ---- the general BVH path beside the headline: driver-timed numbers for C3 / C5 (GPU only, ~2 s each + scene build) ----
+        extra = None
+        if world == 1 and not args.no_extra and args.workload == "cornell_1080p_64spp_8b":
+            ctx.close(); ctx = None
+            del accum
+            torch.cuda.empty_cache()
+            extra = {}
+            for wl in EXTRA_WORKLOADS:
+                try:
+                    extra[wl] = time_extra(rt, dev_index, wl)
+                except Exception as e:                       # the headline line must survive a failing extra
+                    extra[wl] = {"error": str(e)[:200]}
         # ---- CPU baseline: the oracle (a port of the reference's shader math) on this host's cores ----
         cpu = None
         if not args.no_cpu_baseline and world == 1:
@@ -174,7 +347,6 @@ def main():
             o = orc.Oracle().load(scene, W / H)
             cores = os.cpu_count() or 1
             o.set_threads(cores)
-            cw, ch = W, H
             cp = params.copy(spp=1, shard_rank=0, shard_count=1, frame_seed=1)
             # bounded sample: 1 spp of the same frame; shrink the image if this host is slow
             probe = cp.copy(width=W // 8, height=H // 8)
@@ -195,8 +367,9 @@ def main():
             cpu = {"value": round(sum(cc) / tc / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
                    "sample": f"oracle/rt_oracle.c (OpenMP), {cp.width}x{cp.height}, {cpu_spp} of {spp} spp of the same frame, {sum(cc)} rays in {tc:.2f} s"}
         out = {"metric": "Mrays/s + ms/frame at 1080p, 8-bounce Cornell Box" if kind == "cornell" else f"Mrays/s + ms/frame, {args.workload}",
-               "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms_per_step, 3), "ms_per_step_by_rank": [round(t * 1e3 / max(args.steps, 1), 3) for t in dt_ranks],
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": args.workload, "scene": scene_name(kind), "width": W, "height": H, "spp": spp,
                           "max_bounces": bounces, "nee_samples": nee, "rr_start": 3, "flags": flags,
@@ -204,19 +377,16 @@ def main():
                           "rays_per_frame": {"primary": int(rays_all[0] / max(args.steps, 1)), "extension": int(rays_all[1] / max(args.steps, 1)),
                                              "shadow": int(rays_all[2] / max(args.steps, 1))}},
                "roofline": roof, "cpu_baseline": cpu}
-        if args.checksum:
-            import hashlib
-            out["accum_sha1"] = hashlib.sha1(accum.cpu().numpy().tobytes()).hexdigest()
+        if extra is not None:
+            out["extra"] = extra
+        if sha:
+            out["accum_sha1"] = sha
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
-
-
-def scene_name(kind):
-    return {"cornell": "Cornell Box (32 triangles, 2 emissive)", "sponza": "Sponza-class procedural atrium",
-            "bistro": "Bistro-class procedural street"}[kind]
+    if ctx is not None:
+        ctx.close()
 
 
 if __name__ == "__main__":

@@ -49,7 +49,7 @@ typedef struct rtx_params {
     uint32_t rr_start;        /* Russian roulette when bounce index > rr_start (`rr_threshold`, RayGen.hlsl:69,118) */
     uint32_t frame_seed;      /* stands in for uint(time) (RayGen_v6_pass1.hlsl:76-77; Renderer.cpp:1754-1760) */
     uint32_t flags;           /* RTX_FLAG_* */
-    uint32_t tile_size;       /* shard tile edge in pixels, multiple of 8 (0 => 64) */
+    uint32_t tile_size;       /* shard tile edge in pixels: a power of two in [16, 1024] (0 => 64); anything else is RTX_ERR_INVALID everywhere */
     uint32_t shard_rank;      /* this context renders tiles t (row-major tile index) with t % shard_count == shard_rank */
     uint32_t shard_count;     /* 0 or 1 => whole image */
 } rtx_params;
@@ -94,7 +94,7 @@ const char* rtx_last_error(rtx_ctx*);          /* ctx may be NULL: last create e
 int  rtx_set_option(rtx_ctx*, int option, int64_t value);
 /* run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream.
    replaces the single m_commandQueue (Renderer.cpp:192-199) */
-int  rtx_set_stream(rtx_ctx*, void* hip_stream);
+int  rtx_set_stream(rtx_ctx*, void* hip_stream);   /* a caller-owned stream must outlive the work enqueued on it; rtx_destroy does not touch it */
 
 /* t5 `materials` StructuredBuffer<Material>, 128 B stride (Renderer.cpp:373-389, 1287-1296) */
 int  rtx_set_materials(rtx_ctx*, const void* mats128, uint32_t count);

@@ -24,12 +24,14 @@ def _cpu_has_fma():
 
 # same source, same results (fmaf is correctly rounded with or without hardware FMA): the -mfma build is only faster
 LIB_NAME = "librt_oracle_fma.so" if (_cpu_has_fma() and os.environ.get("ORC_NO_FMA_BUILD", "0") != "1") else "librt_oracle.so"
+# ORC_LIB_NAME=librt_oracle_literal.so: the literal-arithmetic variant (oracle/Makefile), loaded only by tests/test_ggx_pins.py in a child process
+LIB_NAME = os.environ.get("ORC_LIB_NAME") or LIB_NAME
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 
 def build(force=False):
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "rt_oracle.c")):
-        subprocess.check_call(["make", "-C", _HERE, "librt_oracle.so", "librt_oracle_fma.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "librt_oracle.so", "librt_oracle_fma.so", "librt_oracle_literal.so"], stdout=subprocess.DEVNULL)
 
 
 build()

@@ -39,18 +39,31 @@ static inline v3 sub3(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); 
 static inline v3 mul3(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
 static inline v3 scale3(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
 static inline v3 neg3(v3 a) { return V3(-a.x, -a.y, -a.z); }
+/* ORC_LITERAL (make librt_oracle_literal.so; tests/test_ggx_pins.py): the three speed-motivated arithmetic DEVIATIONs switched OFF — mul / add chains
+   unfused (two roundings), normalize(v) = v / sqrt(dot(v,v)) with IEEE sqrt and divide, x / PI as a division.  Not what the GPU is compared
+   with; it exists to show that the default build's images agree with the literal reading of the HLSL within Monte-Carlo noise. */
+#ifdef ORC_LITERAL
+#define ORC_LIT_FMA
+#define ORC_LIT_NORM
+#define ORC_LIT_PI
+#endif
+#ifdef ORC_LIT_FMA
+#define FMAF(a, b, c) ((a) * (b) + (c))
+#else
+#define FMAF(a, b, c) fmaf((a), (b), (c))
+#endif
 /* DEVIATION (fused multiply-add): dot, cross and the matrix-vector products contract a*b + c into ONE rounding, fmaf, in a fixed
    nesting.  HLSL leaves mul/add chains free to become `mad`/FMA (no `precise`), and every GPU driver compiler does so, so neither
    form is "the" reference result; the HIP kernels issue v_fma_f32 at exactly these sites (csrc/rtx_math.hpp).  fmaf is correctly
    rounded with or without hardware FMA, so the oracle's results do not depend on the build flags (see Makefile). */
-static inline float dot3(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline float dot3(v3 a, v3 b) { return FMAF(a.z, b.z, FMAF(a.y, b.y, a.x * b.x)); }
 static inline v3 cross3(v3 a, v3 b) {
-    return V3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+    return V3(FMAF(a.y, b.z, -(a.z * b.y)), FMAF(a.z, b.x, -(a.x * b.z)), FMAF(a.x, b.y, -(a.y * b.x)));
 }
 /* fused linear combinations (same DEVIATION as dot3 / cross3): a*s + b, and x*a + y*b + z*c as fma(z, c, fma(y, b, x*a)) */
-static inline v3 madd3(v3 a, float s, v3 b) { return V3(fmaf(a.x, s, b.x), fmaf(a.y, s, b.y), fmaf(a.z, s, b.z)); }
+static inline v3 madd3(v3 a, float s, v3 b) { return V3(FMAF(a.x, s, b.x), FMAF(a.y, s, b.y), FMAF(a.z, s, b.z)); }
 static inline v3 lincomb3(v3 x, float a, v3 y, float b, v3 z, float c) {
-    return V3(fmaf(z.x, c, fmaf(y.x, b, x.x * a)), fmaf(z.y, c, fmaf(y.y, b, x.y * a)), fmaf(z.z, c, fmaf(y.z, b, x.z * a)));
+    return V3(FMAF(z.x, c, FMAF(y.x, b, x.x * a)), FMAF(z.y, c, FMAF(y.y, b, x.y * a)), FMAF(z.z, c, FMAF(y.z, b, x.z * a)));
 }
 static inline float length3(v3 a) { return sqrtf(dot3(a, a)); }
 static inline uint32_t f2u(float f);
@@ -68,7 +81,11 @@ static inline float rsqrt_det(float x) {
     return fmaf(0.5f * y, fmaf(-x, y * y, 1.0f), y);
 }
 /* HLSL normalize(v) = v * rsqrt(dot(v,v)) */
+#ifdef ORC_LIT_NORM
+static inline v3 normalize3(v3 a) { const float l = sqrtf(dot3(a, a)); return V3(a.x / l, a.y / l, a.z / l); }
+#else
 static inline v3 normalize3(v3 a) { return scale3(a, rsqrt_det(dot3(a, a))); }
+#endif
 static inline float saturatef(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
 static inline float maxf(float a, float b) { return a > b ? a : b; }
 static inline float minf(float a, float b) { return a < b ? a : b; }
@@ -183,15 +200,15 @@ void orc_mat4_inverse(const float* mf, float* out) {
 }
 /* mul(M, float4(p,1)).xyz */
 static inline v3 xform_point(const float* m, v3 p) {
-    return V3(fmaf(m[8], p.z, fmaf(m[4], p.y, fmaf(m[0], p.x, m[12]))),
-              fmaf(m[9], p.z, fmaf(m[5], p.y, fmaf(m[1], p.x, m[13]))),
-              fmaf(m[10], p.z, fmaf(m[6], p.y, fmaf(m[2], p.x, m[14]))));
+    return V3(FMAF(m[8], p.z, FMAF(m[4], p.y, FMAF(m[0], p.x, m[12]))),
+              FMAF(m[9], p.z, FMAF(m[5], p.y, FMAF(m[1], p.x, m[13]))),
+              FMAF(m[10], p.z, FMAF(m[6], p.y, FMAF(m[2], p.x, m[14]))));
 }
 /* mul(M, float4(v,0)).xyz */
 static inline v3 xform_dir(const float* m, v3 p) {
-    return V3(fmaf(m[8], p.z, fmaf(m[4], p.y, m[0] * p.x)),
-              fmaf(m[9], p.z, fmaf(m[5], p.y, m[1] * p.x)),
-              fmaf(m[10], p.z, fmaf(m[6], p.y, m[2] * p.x)));
+    return V3(FMAF(m[8], p.z, FMAF(m[4], p.y, m[0] * p.x)),
+              FMAF(m[9], p.z, FMAF(m[5], p.y, m[1] * p.x)),
+              FMAF(m[10], p.z, FMAF(m[6], p.y, m[2] * p.x)));
 }
 
 /* ---- scene ---- */
@@ -633,7 +650,11 @@ static inline v3 lambert_eval(const matopt_t* m) { return V3(m->Kd.x / PI_REF, m
 /* Lambertian_v6.hlsl:61-64: max(dot(n, -incoming), EPS)/PI, with L = -incoming */
 /* x / PI as x * (1 / PI), the reciprocal rounded once at compile time: what shader compilers do with a division by a constant */
 #define INV_PI_REF (1.0f / PI_REF)
+#ifdef ORC_LIT_PI
+static inline float lambert_pdf(v3 n, v3 L) { return maxf(dot3(n, L), EPSILON_) / PI_REF; }
+#else
 static inline float lambert_pdf(v3 n, v3 L) { return maxf(dot3(n, L), EPSILON_) * INV_PI_REF; }
+#endif
 /* GGX_v6.hlsl:174-206; V = outgoing, L = -incoming (dots NOT clamped) */
 static v3 ggx_eval(const matopt_t* m, const float* mat, v3 normal, v3 Lin, v3 Vin) {
     v3 N = normalize3(normal), V = normalize3(Vin), L = normalize3(Lin);

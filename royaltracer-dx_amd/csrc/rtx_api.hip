@@ -48,7 +48,7 @@ struct rtx_ctx {
     uint32_t* h_counters = nullptr; size_t h_counters_words = 0;
     // accumulation
     DevBuf d_accum; void* ext_accum = nullptr; size_t ext_accum_bytes = 0; uint32_t acc_w = 0, acc_h = 0;
-    DevBuf d_srgb, d_res_di, d_res_gi, d_sdata, d_last_di, d_last_gi, d_last_sd, d_p1cnt; size_t p1_slots = 0, last_slots = 0;
+    DevBuf d_srgb, d_res_di, d_res_gi, d_sdata, d_last_di, d_last_gi, d_last_sd, d_p1cnt, d_p1scratch; size_t p1_slots = 0, last_slots = 0;
     float prev_view[16], prev_proj[16];
     // options
     bool timing = false; uint64_t paths_per_batch = 128u << 20; int lds_nodes_opt = -1; bool small_scene = true; bool fused = true; int stack_private = -1;
@@ -102,10 +102,13 @@ int rtx_create(int device_ordinal, rtx_ctx** out) {
 void rtx_destroy(rtx_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    // a caller-owned stream (rtx_set_stream) may already be gone (torch destroys its streams first): every entry point that enqueues on it
+    // synchronises before it returns or documents that it only enqueues, so only the context's own stream is drained here
+    if (c->own_stream && c->stream) (void)hipStreamSynchronize(c->stream);
+    else (void)hipDeviceSynchronize();
     DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_small_poly, &c->d_objtris, &c->d_node_aabb, &c->d_scale, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
                      &c->d_thr, &c->d_rad, &c->d_hit, &c->d_hitmask, &c->d_order, &c->d_pmask, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
-                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt};
+                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch};
     for (DevBuf* b : all) b->release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
@@ -139,7 +142,8 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
 
 int rtx_set_stream(rtx_ctx* c, void* s) {
     BIND(c);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
+    else HIPCHK(c, hipDeviceSynchronize());                // the old caller-owned stream may no longer exist: drain the device instead of touching it
     if (c->own_stream && c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; c->own_stream = false; }
     if (s) { c->stream = (hipStream_t)s; c->own_stream = false; }
     else { HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
@@ -178,7 +182,9 @@ int rtx_commit_scene(rtx_ctx* c) {
     // only re-derives the instance matrices and the light list.  Anything else: host build (or host refit) + upload.
     const bool gpu_path = c->gpu_refit && c->device_scene_valid && !c->host.topo_dirty && B.small_nrec == 0 && !B.nodes8.empty() && B.level_start8.size() >= 2;
     if (gpu_path) {
+        const bool mats_changed = c->host.mats_dirty;
         if (!c->host.refresh_transforms(B)) { c->err = c->host.err; return RTX_ERR_INVALID; }
+        if (mats_changed && (r = upload(c, c->d_mats, B.mats))) return r;      // rtx_set_materials on a resident scene: new table beside the new light list
         if ((r = upload(c, c->d_insts, B.insts))) return r;
         if ((r = upload(c, c->d_lights, B.lights))) return r;
         if (!c->objtris_uploaded) { if ((r = upload(c, c->d_objtris, B.objtris))) return r; c->objtris_uploaded = true; }
@@ -284,22 +290,29 @@ int rtx_clear_accum(rtx_ctx* c, uint32_t w, uint32_t h) {
     return RTX_OK;
 }
 
+// the ONE rule for the shard tiling, shared by every entry point that takes rtx_params (render, pack / unpack, rtx_shard_slab_bytes):
+// tile_size a power of two in [16, 1024] (0 => 64), shard_rank < shard_count, the local slot count fits 31 bits.  All in 64-bit arithmetic.
+static const char* validate_tiling(const rtx_params* p, uint32_t& ts, uint32_t& cnt, uint64_t& npl) {
+    if (!p || !p->width || !p->height) return "params: width/height must be non-zero";
+    ts = p->tile_size ? p->tile_size : 64;
+    if (ts < 16 || ts > 1024 || (ts & (ts - 1))) return "params: tile_size must be a power of two in [16, 1024] (0 = 64)";
+    cnt = p->shard_count ? p->shard_count : 1;
+    if (p->shard_rank >= cnt) return "params: shard_rank >= shard_count";
+    const uint64_t total = (uint64_t)((p->width + (uint64_t)ts - 1) / ts) * ((p->height + (uint64_t)ts - 1) / ts);
+    npl = ((total + cnt - 1) / cnt) * ts * ts;
+    if (npl > 0x7FFFFFFFull) return "params: image too large";
+    return nullptr;
+}
+
 static int make_frame(rtx_ctx* c, const rtx_params* p, DevFrame& f) {
-    if (!p || !p->width || !p->height) { c->err = "params: width/height must be non-zero"; return RTX_ERR_INVALID; }
-    const uint32_t ts = p->tile_size ? p->tile_size : 64;
-    if (ts < 16 || ts > 1024 || (ts & (ts - 1))) { c->err = "params: tile_size must be a power of two in [16, 1024]"; return RTX_ERR_INVALID; }
-    const uint32_t cnt = p->shard_count ? p->shard_count : 1;
-    if (p->shard_rank >= cnt) { c->err = "params: shard_rank >= shard_count"; return RTX_ERR_INVALID; }
+    uint32_t ts = 0, cnt = 0; uint64_t npl64 = 0;
+    if (const char* e = validate_tiling(p, ts, cnt, npl64)) { c->err = e; return RTX_ERR_INVALID; }
     f.width = p->width; f.height = p->height; f.tile_size = ts;
     f.tile_shift = 0; while ((1u << f.tile_shift) < ts) f.tile_shift++;
     f.nblocks = 1; f.qcap = 0; f.chunks_per_sample = 0;
     f.tiles_x = (p->width + ts - 1) / ts; f.tiles_y = (p->height + ts - 1) / ts;
     f.shard_rank = p->shard_rank; f.shard_count = cnt;
-    const uint32_t total = f.tiles_x * f.tiles_y;
-    const uint32_t per = (total + cnt - 1) / cnt;
-    const uint64_t npl = (uint64_t)per * ts * ts;
-    if (npl > 0x7FFFFFFFull) { c->err = "params: image too large"; return RTX_ERR_INVALID; }
-    f.npl = (uint32_t)npl;
+    f.npl = (uint32_t)npl64;
     f.chunks_per_sample = f.npl / 256;          // tile_size >= 16 makes npl a multiple of 256
     f.batch_spp = 1; f.sample_first = p->sample_base;
     f.max_bounces = p->max_bounces; f.nee_samples = p->nee_samples; f.rr_start = p->rr_start;
@@ -505,7 +518,7 @@ int rtx_render_restir(rtx_ctx* c, const rtx_params* p) {
         c->last_slots = slots;
     }
     // pass 1 writes its debug estimate into a scratch image (the displayed image is pass 3's)
-    DevBuf scratch; HIPCHK(c, scratch.ensure((size_t)p->width * p->height * 16));
+    DevBuf& scratch = c->d_p1scratch; HIPCHK(c, scratch.ensure((size_t)p->width * p->height * 16));     // context-owned: no per-call hipMalloc / hipFree, nothing to leak on an early return
     HIPCHK(c, hipMemsetAsync(c->d_p1cnt.p, 0, 24, c->stream));
     uint32_t* bufs[6] = {(uint32_t*)c->d_res_di.p, (uint32_t*)c->d_res_gi.p, (uint32_t*)c->d_sdata.p, (uint32_t*)c->d_last_di.p, (uint32_t*)c->d_last_gi.p, (uint32_t*)c->d_last_sd.p};
     const uint32_t mbk = (uint32_t)c->num_cus * 8u;
@@ -523,7 +536,6 @@ int rtx_render_restir(rtx_ctx* c, const rtx_params* p) {
     unsigned long long cnt[3] = {0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(cnt, c->d_p1cnt.p, 24, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    scratch.release();
     memset(c->stats.kernel_ms, 0, sizeof(c->stats.kernel_ms)); memset(c->stats.kernel_launches, 0, sizeof(c->stats.kernel_launches)); memset(c->stats.kernel_items, 0, sizeof(c->stats.kernel_items));
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) c->stats.render_ms = ms;
@@ -583,10 +595,10 @@ int rtx_get_lights(rtx_ctx* c, void* out80, uint32_t max_count, uint32_t* count_
 }
 
 int rtx_shard_slab_bytes(const rtx_params* p, size_t* bytes) {
-    if (!p || !bytes || !p->width || !p->height) return RTX_ERR_INVALID;
-    const uint32_t ts = p->tile_size ? p->tile_size : 64, cnt = p->shard_count ? p->shard_count : 1;
-    const uint32_t total = ((p->width + ts - 1) / ts) * ((p->height + ts - 1) / ts);
-    *bytes = (size_t)((total + cnt - 1) / cnt) * ts * ts * 16;
+    if (!bytes) return RTX_ERR_INVALID;
+    uint32_t ts = 0, cnt = 0; uint64_t npl = 0;
+    if (const char* e = validate_tiling(p, ts, cnt, npl)) { g_create_err = e; return RTX_ERR_INVALID; }   // no context here: message via rtx_last_error(NULL)
+    *bytes = (size_t)npl * 16;
     return RTX_OK;
 }
 int rtx_pack_tiles(rtx_ctx* c, const rtx_params* p, void* slab) {

@@ -63,6 +63,7 @@ void normal_matrix(const float* o2w, float* out) {
 bool SceneHost::set_materials(const void* mats, uint32_t count) {
     if (!mats && count) { err = "materials pointer is null"; return false; }
     mats128.assign((const float*)mats, (const float*)mats + (size_t)count * 32);
+    mats_dirty = true;
     return true;
 }
 
@@ -163,6 +164,7 @@ void SceneHost::build_lights(BuiltScene& B) const {
 // transform-only commit on the GPU-refit path: the kernels re-derive triangles and boxes; the host re-derives what is small
 bool SceneHost::refresh_transforms(BuiltScene& B) {
     if (topo_dirty || B.insts.size() != insts.size()) { err = "refresh_transforms: topology changed"; return false; }
+    if (mats_dirty) build_materials(B);          // rtx_set_materials since the last commit: new table (the light list below reads the new Ke)
     for (size_t ii = 0; ii < insts.size(); ii++) {
         const InstHost& in = insts[ii];
         memcpy(B.insts[ii].o2w, in.o2w, 64); memcpy(B.insts[ii].nrm, in.nrm, 64); memcpy(B.insts[ii].o2w_inv, in.o2w_inv, 64); memcpy(B.insts[ii].prev_o2w, in.prev_o2w, 64);
@@ -172,9 +174,10 @@ bool SceneHost::refresh_transforms(BuiltScene& B) {
     return true;
 }
 
-bool SceneHost::build(BuiltScene& B) {
+// materials: MaterialOptimized rounding (Common_v6.hlsl:62-74).  Shared by the full build and by a commit that only changed materials
+// (rtx_set_materials after the scene is resident: the BVH stays, the material table and the light list are re-derived).
+void SceneHost::build_materials(BuiltScene& B) {
     const uint32_t nmat = (uint32_t)(mats128.size() / 32);
-    // ---- materials: MaterialOptimized rounding (Common_v6.hlsl:62-74) ----
     B.mats.resize(nmat);
     for (uint32_t i = 0; i < nmat; i++) {
         const float* m = &mats128[(size_t)i * 32];   // Kd[4] Ks[3] Ni Ke[3] pad Pr_Pm_Ps_Pc[4] LUT[16]
@@ -187,6 +190,11 @@ bool SceneHost::build(BuiltScene& B) {
         g.pad = 0.0f;
         memcpy(g.LUT, m + 16, 64);
     }
+    mats_dirty = false;
+}
+
+bool SceneHost::build(BuiltScene& B) {
+    build_materials(B);
     // ---- flatten instances to world-space triangles; per-triangle shade records (Hit_v6.hlsl:12-61) ----
     uint32_t nt = 0;
     for (auto& in : insts) { in.tri_base = nt; nt += (uint32_t)(meshes[in.mesh].idx.size() / 3); }

@@ -50,12 +50,14 @@ struct SceneHost {
     std::vector<InstHost> insts;
     std::string err;
     bool topo_dirty = true;                     // meshes / instances added since the last build (a transform change alone refits)
+    bool mats_dirty = true;                     // rtx_set_materials since the material table was last derived
 
     bool set_materials(const void* mats, uint32_t count);
     bool add_mesh(const void* verts28, uint32_t nverts, const uint32_t* idx, uint32_t nidx, const uint32_t* matids, uint32_t* out);
     bool add_instance(uint32_t mesh, const float* o2w, uint32_t* out);
     bool set_instance_transform(uint32_t inst, const float* o2w);
     bool build(BuiltScene& out);
+    void build_materials(BuiltScene& out);      // mats128 -> MatGPU table (clears mats_dirty)
     // transform-only update of the records the GPU refit does not derive itself: instance matrices and the light list
     bool refresh_transforms(BuiltScene& out);
     void build_lights(BuiltScene& out) const;

@@ -12,6 +12,8 @@ import numpy as np
 
 def layout(width, height, tile_size=64, world=1):
     ts = tile_size or 64
+    if ts < 16 or ts > 1024 or ts & (ts - 1):          # the same rule as validate_tiling() behind rtx_render / rtx_pack_tiles / rtx_shard_slab_bytes
+        raise ValueError("tile_size must be a power of two in [16, 1024] (0 = 64)")
     tiles_x, tiles_y = (width + ts - 1) // ts, (height + ts - 1) // ts
     total = tiles_x * tiles_y
     per = (total + world - 1) // world

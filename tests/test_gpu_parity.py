@@ -595,6 +595,66 @@ def test_animated_instance_refit_parity(rt, orc, golden_dir, gpu_refit):
     c.close()
 
 
+class _EditedScene:
+    """a Scene with another material table (what rtx_set_materials + rtx_commit_scene on a resident scene must equal)"""
+    def __init__(self, base, materials):
+        self.materials, self.meshes, self.instances, self._b = materials, base.meshes, base.instances, base
+
+    def view_proj(self, aspect):
+        return self._b.view_proj(aspect)
+
+
+@pytest.mark.parametrize("gpu_refit", [1, 0])
+@pytest.mark.parametrize("tris", [40000, 28])
+def test_material_edit_after_commit(rt, orc, cornell, gpu_refit, tris):
+    """rtx_set_materials on a scene that is already resident, then rtx_commit_scene: the material table, its count and the emissive
+    list must all follow, on the GPU-refit commit path (non-tiny scene, RTX_OPT_GPU_REFIT=1), the host-refit path (=0) and the tiny-scene
+    path alike — compared with an oracle loaded from scratch with the edited table (image bits, ray counts, light records)."""
+    sc = rt.Scene.sponza_class(tris, 260) if tris > 64 else cornell
+    W, H = 96, 54
+    p = rt.Params(width=W, height=H, spp=2, max_bounces=4, nee_samples=1, flags=0, frame_seed=9)
+    c = rt.Context(0); c.set_option(rt.OPT_GPU_REFIT, gpu_refit); c.upload(sc, W / H)
+    c.clear(W, H); c.render(p); before = c.read_accum(); n0 = c.stats().materials; l0 = c.stats().lights
+    mats = np.array(sc.materials, dtype=np.float32, copy=True)
+    used = np.unique(np.concatenate([m for _, _, m in sc.meshes]))
+    dark = [int(i) for i in used if mats[i, 8:11].sum() == 0.0]
+    assert len(dark) >= 2
+    mats[dark[0], 0:3] = (0.9, 0.1, 0.2)                       # a new Kd
+    mats[dark[1], 8:11] = (3.0, 2.0, 1.0)                      # a surface material becomes a light: the CDF grows, its hits now end paths
+    mats = np.concatenate([mats, mats[:1]])                    # and the table grows by one (unused) entry
+    c.set_materials(mats); c.commit()
+    st = c.stats()
+    assert st.materials == n0 + 1 and st.lights > l0
+    c.clear(W, H); c.render(p); after = c.read_accum(); st = c.stats()
+    o = orc.Oracle().load(_EditedScene(sc, mats), W / H)
+    oa, oc = o.render(p)
+    assert np.array_equal(bits(c.lights()), bits(o.lights()))
+    assert (st.rays_primary, st.rays_extension, st.rays_shadow) == oc
+    assert np.array_equal(bits(after), bits(oa)) and not np.array_equal(bits(after), bits(before))
+    c.close()
+
+
+def test_tile_size_contract_is_one_rule(rt, cornell):
+    """tile_size: a power of two in [16, 1024] (0 = 64) — the same verdict from rtx_shard_slab_bytes, rtx_render, rtx_pack_tiles and the
+    host-side layout; slab sizes are computed in 64 bits"""
+    from royaltracer_dx_amd import sharding
+    c = rt.Context(0); c.upload(cornell, 1.0)
+    for ts in (8, 24, 48, 2048, 1000):
+        p = rt.Params(width=64, height=64, spp=1, tile_size=ts)
+        with pytest.raises(rt.RtxError):
+            c.slab_bytes(p)
+        with pytest.raises(rt.RtxError):
+            c.render(p)
+        with pytest.raises(ValueError):
+            sharding.layout(64, 64, ts, 1)
+    for ts in (0, 16, 64, 1024):
+        p = rt.Params(width=200, height=120, spp=1, tile_size=ts, shard_rank=1, shard_count=3)
+        assert c.slab_bytes(p) == sharding.layout(200, 120, ts, 3)["npl"] * 16
+    with pytest.raises(rt.RtxError):
+        c.slab_bytes(rt.Params(width=0xFFFFFFFF, height=0xFFFFFFFF, tile_size=16))      # 7.2e16 tile pixels: refused, not wrapped
+    c.close()
+
+
 def test_gpu_refit_large_scene_stays_conservative(rt, orc):
     """GPU refit of a 262 k-triangle tree under a large rigid motion + non-uniform scale: the refitted tree validates on the host,
     hit records and the image equal the oracle's (which rebuilds its own BVH), and a second refit back to identity reproduces
@@ -900,6 +960,44 @@ def test_full_size_headline_frame_is_bit_identical(rt, orc, cornell):
     assert not d.any(), f"{int(d.sum())} of {W * H} pixels differ, first at {np.argwhere(d)[0].tolist()}"
 
 
+def _host_threads():
+    """threads for the oracle: the CPUs this process may run on (a GPU box hands a share of its cores to each GPU)"""
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
+@pytest.mark.parametrize("name,kind,W,H,spp,flags,shard", [
+    ("C3", "sponza", 1920, 1080, 16, 1, (0, 1)),      # BASELINE.json configs[2]: Sponza-class 262 144 triangles, 1080p, 16 spp, 8 bounces
+    ("C5", "bistro", 1920, 1080, 16, 0, (0, 1)),      # configs[4]: Bistro-class 3.8 M triangles, 1080p, 16 spp, GGX microfacet + NEE (full strategy selection)
+    ("C4-shard-5-of-8", "sponza", 3840, 2160, 64, 1, (5, 8)),   # configs[3]: Sponza-class, 4K, 64 spp, 8 bounces: the tiles ONE of the 8 ranks renders
+])
+def test_full_size_baseline_configs_are_bit_identical(rt, orc, name, kind, W, H, spp, flags, shard):
+    """BASELINE.json configs[2..4] at their FULL sizes through the general BVH path, against the oracle on all host cores: every pixel of
+    the float accumulation buffer bit for bit, and the primary / extension / shadow ray counts.  C4 is the share of one rank (tile t ->
+    rank t mod 8): seeds depend on (x, y, sample, frame_seed) only, so the 8 shards are independent and any one of them is as good a
+    witness as the whole frame (the gather itself: test_pack_unpack_kernels_match_host_layout, test_bench_two_ranks_*)."""
+    import time
+    sc = rt.Scene.sponza_class() if kind == "sponza" else rt.Scene.bistro_class()
+    assert abs(sc.num_triangles - (262144 if kind == "sponza" else 3800000)) <= 0.01 * sc.num_triangles
+    p = rt.Params(width=W, height=H, spp=spp, max_bounces=8, nee_samples=1, rr_start=3, flags=flags, frame_seed=5,
+                  tile_size=64, shard_rank=shard[0], shard_count=shard[1])
+    c = rt.Context(0); c.upload(sc, W / H)
+    c.clear(W, H); c.render(p); st = c.stats(); im = c.read_accum()
+    c.close()
+    o = orc.Oracle().load(sc, W / H); o.set_threads(_host_threads())
+    t0 = time.time(); oa, oc = o.render(p); dt = time.time() - t0
+    print(f"{name}: {st.triangles} triangles, rays {oc} = {sum(oc) / 1e6:.1f} M, GPU {st.render_ms:.1f} ms, oracle {dt:.1f} s on {_host_threads()} threads")
+    assert (st.rays_primary, st.rays_extension, st.rays_shadow) == oc
+    from royaltracer_dx_amd import sharding
+    own = sharding.owner_map(W, H, 64, shard[1]) == shard[0]
+    assert oc[0] == int(own.sum()) * spp
+    d = (bits(im) != bits(oa)).any(-1)
+    assert not d.any(), f"{name}: {int(d.sum())} of {W * H} pixels differ, first at {np.argwhere(d)[0].tolist()}"
+    assert not im[~own].any() and (im[own][:, 3] == spp).all()          # only this rank's tiles were touched, every sample landed
+
+
 def test_analytic_rectangle_light_scene_gpu_equals_oracle(rt, orc):
     """the floor-under-a-rectangular-light scene whose oracle image is pinned against the analytic irradiance
     (test_oracle_golden.py): the GPU must reproduce the oracle's image bit for bit, so the analytic pin carries over"""
@@ -946,7 +1044,7 @@ def test_bench_two_ranks_assemble_the_single_rank_frame():
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    common = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--checksum"]
+    common = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extra", "--checksum"]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert one.returncode == 0, one.stderr[-2000:]
     a = json.loads(one.stdout.strip().splitlines()[-1])
@@ -960,6 +1058,18 @@ def test_bench_two_ranks_assemble_the_single_rank_frame():
     assert a["config"]["rays_per_frame"] == b["config"]["rays_per_frame"]
     for k in ("metric", "value", "unit", "ms_per_step", "roofline"):
         assert k in b and b[k] is not None
+    # the driver's plain form, no launcher: `python bench.py --gpus 2` starts its own ranks (before it touches the GPU) and relays rank 0's line
+    env2 = {k: v for k, v in env.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    self_launched = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device", "0"] + common,
+                                   capture_output=True, text=True, timeout=900, env=env2, cwd=root)
+    assert self_launched.returncode == 0, self_launched.stderr[-3000:]
+    c = json.loads([ln for ln in self_launched.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert c["n_gpus"] == 2 and c["ranks_seen"] == 2 and len(c["ms_per_step_by_rank"]) == 2
+    assert c["accum_sha1"] == a["accum_sha1"] and c["config"]["rays_per_frame"] == a["config"]["rays_per_frame"]
+    # a launcher / --gpus mismatch is an error, not a silently different run
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=120,
+                         env=dict(env2, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=root)
+    assert bad.returncode != 0 and "does not match WORLD_SIZE" in bad.stderr
 
 
 def test_two_contexts_from_two_threads(rt, cornell):

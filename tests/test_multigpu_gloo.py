@@ -73,3 +73,23 @@ def test_two_rank_gloo_frame_assembly(tmp_path):
         outs.append(out)
     assert all(pr.returncode == 0 for pr in procs), "\n".join(outs)
     assert "GLOO_OK 2" in outs[0], outs[0]
+
+
+def test_bench_self_launch_plumbing_without_a_gpu():
+    """`python bench.py --gpus N` with no launcher must start its own ranks BEFORE importing torch / touching the GPU, relay rank 0 and
+    exit with the worst child code.  Without a GPU the children fail (rtx has no CPU fallback): the parent must reap them, not hang, and
+    fail too; a launcher / --gpus mismatch is refused up front."""
+    chk = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import bench; assert 'torch' not in sys.modules; print('NO_TORCH')" % ROOT],
+                         capture_output=True, text=True, timeout=120)
+    assert chk.returncode == 0 and "NO_TORCH" in chk.stdout, chk.stderr[-2000:]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=120,
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode != 0 and "does not match WORLD_SIZE" in bad.stderr
+    import torch
+    if torch.cuda.is_available():
+        return        # on a GPU box the full flow is tests/test_gpu_parity.py::test_bench_two_ranks_assemble_the_single_rank_frame
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--dist-backend", "gloo", "--device", "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert run.returncode != 0                     # children could not open a GPU
+    assert "SystemExit: launch with" not in run.stderr

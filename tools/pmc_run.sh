@@ -14,6 +14,6 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD S
            "FETCH_SIZE WRITE_SIZE"; do
   i=$((i+1))
   if [ -n "$PMC_GROUPS" ] && [[ " $PMC_GROUPS " != *" $i "* ]]; then continue; fi
-  timeout 600 rocprofv3 --pmc $grp -d "$out/g$i" -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > "$out/g$i.log" 2>&1
+  timeout 600 rocprofv3 --pmc $grp -d "$out/g$i" -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra "$@" > "$out/g$i.log" 2>&1
   echo "group $i rc=$?"
 done

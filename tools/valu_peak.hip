@@ -1,0 +1,181 @@
+// valu_peak.hip — what is the wave64 VALU issue peak of one gfx950 SIMD?  (tooling only; not part of the product library)
+//
+// MI355X_MICROARCH.md says the CDNA4 SIMD is 32 lanes wide: a wave64 v_fma_f32 occupies it for 2 cycles, while ONE wave's own stream
+// issues every 4.  Round 1 priced the VALU roofline at one instruction per 4 cycles per SIMD.  This microbenchmark measures the rate
+// directly: W waves per SIMD (W = 1, 2, 3, 4, 5, 8) each run a long stream of independent VALU instructions; reported are
+// wave-instructions per cycle per SIMD from s_memtime inside the kernel (median over waves) and from the hipEvent wall time at the
+// clock GRBM would report (we print the in-kernel clock as well: s_memtime / s_memrealtime).
+//   build + run on the GPU box:  hipcc --offload-arch=gfx950 -O2 tools/valu_peak.hip -o gpurun_out/valu_peak && gpurun_out/valu_peak
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+// KIND: 0 = v_fma_f32 independent (16 accumulators), 1 = v_pk_fma_f32 independent, 2 = v_fma_f32 one dependent chain,
+//       3 = v_rcp_f32 independent, 4 = mix typical of the traversal (cvt_f32_ubyte + fma + max3 + cmp), 5 = v_add_u32 (integer, TEA-like)
+template <int KIND>
+__global__ __launch_bounds__(256) void k_valu(float* out, unsigned long long* cyc, unsigned long long* rt, int iters) {
+    float a[16];
+    for (int i = 0; i < 16; i++) a[i] = (float)(threadIdx.x + i) * 1e-3f;
+    float b = 1.0000001f, c = 1e-9f;
+    unsigned u = threadIdx.x * 2654435761u;
+    f2v p[8]; for (int i = 0; i < 8; i++) { p[i].x = a[2 * i]; p[i].y = a[2 * i + 1]; }
+    f2v pb = {b, b}, pc = {c, c};
+    __syncthreads();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+        if (KIND == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+        } else if (KIND == 1) {
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pb), "v"(pc));
+        } else if (KIND == 2) {
+#pragma unroll
+            for (int k = 0; k < 64; k++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[0]) : "v"(b), "v"(c));
+        } else if (KIND == 3) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+        } else if (KIND == 4) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                asm volatile("v_cvt_f32_ubyte0 %0, %1" : "=v"(a[k & 15]) : "v"(u));
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[(k + 1) & 15]) : "v"(b), "v"(c));
+                asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[(k + 2) & 15]) : "v"(b), "v"(c));
+                asm volatile("v_cmp_le_f32 vcc, %0, %1" :: "v"(a[(k + 3) & 15]), "v"(b) : "vcc");
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 64; k++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u) : "v"(threadIdx.x));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.0f;
+    for (int i = 0; i < 16; i++) s += a[i];
+    for (int i = 0; i < 8; i++) s += p[i].x + p[i].y;
+    out[blockIdx.x * 256 + threadIdx.x] = s + (float)u;
+    if ((threadIdx.x & 63) == 0) { cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0; rt[blockIdx.x * 4 + (threadIdx.x >> 6)] = r1 - r0; }
+}
+
+// per-instruction issue cost: 16 independent destination registers x 4, one opcode per kernel
+#define OPK(ID, ASM) template <> __global__ __launch_bounds__(256) void k_op<ID>(float* out, unsigned long long* cyc, unsigned long long* rt, int iters) { \
+    float a[16]; for (int i = 0; i < 16; i++) a[i] = 1.0f + (float)(threadIdx.x + i) * 1e-3f; \
+    float b = 1.0000001f, c = 1.5f; unsigned u = threadIdx.x * 2654435761u + 12345u; (void)u; \
+    __syncthreads(); \
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime(); \
+    for (int it = 0; it < iters; it++) { \
+        _Pragma("unroll") for (int k = 0; k < 4; k++) _Pragma("unroll") for (int i = 0; i < 16; i++) asm volatile(ASM : "+v"(a[i]) : "v"(b), "v"(c), "v"(u) : "vcc"); } \
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime(); \
+    float s = 0.0f; for (int i = 0; i < 16; i++) s += a[i]; out[blockIdx.x * 256 + threadIdx.x] = s; \
+    if ((threadIdx.x & 63) == 0) { cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0; rt[blockIdx.x * 4 + (threadIdx.x >> 6)] = r1 - r0; } }
+template <int ID> __global__ void k_op(float* out, unsigned long long* cyc, unsigned long long* rt, int iters);
+OPK(0, "v_mul_f32 %0, %0, %1")
+OPK(1, "v_add_f32 %0, %0, %2")
+OPK(2, "v_max3_f32 %0, %0, %1, %2")
+OPK(3, "v_min_f32 %0, %0, %1")
+OPK(4, "v_cvt_f32_ubyte0 %0, %3")
+OPK(5, "v_cmp_le_f32 vcc, %0, %1")
+OPK(6, "v_cndmask_b32 %0, %0, %1, vcc")
+OPK(7, "v_sqrt_f32 %0, %0")
+OPK(8, "v_rsq_f32 %0, %0")
+OPK(9, "v_mul_lo_u32 %0, %0, %3")
+OPK(10, "v_lshl_add_u32 %0, %0, 4, %3")
+OPK(11, "v_xor_b32 %0, %0, %3")
+OPK(22, "v_add3_u32 %0, %0, %3, %3")
+OPK(23, "v_xad_u32 %0, %0, %3, %3")
+OPK(12, "v_add_u32 %0, %0, %3")
+OPK(13, "v_div_scale_f32 %0, vcc, %0, %1, %0")
+OPK(14, "v_div_fmas_f32 %0, %0, %1, %2")
+OPK(15, "v_div_fixup_f32 %0, %0, %1, %2")
+OPK(16, "v_fma_f32 %0, %0, %1, %2")
+OPK(17, "v_mov_b32 %0, %1")
+OPK(18, "v_and_b32 %0, %0, %3")
+OPK(19, "v_lshrrev_b32 %0, 5, %0")
+OPK(20, "v_cvt_f32_u32 %0, %0")
+OPK(21, "v_mad_u32_u24 %0, %0, %3, %3")
+
+template <int ID>
+static int run_op(const char* name, int ncu, float* d_out, unsigned long long* d_cyc, unsigned long long* d_rt) {
+    const int iters = 10000;
+    for (int W : {1, 4, 8}) {
+        const int blocks = ncu * W;
+        hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_op<ID>, dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, d_rt, 200);
+        CHK(hipDeviceSynchronize());
+        CHK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_op<ID>, dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, d_rt, iters);
+        CHK(hipEventRecord(e1, 0));
+        CHK(hipDeviceSynchronize());
+        float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<unsigned long long> c(blocks * 4), r(blocks * 4);
+        CHK(hipMemcpy(c.data(), d_cyc, c.size() * 8, hipMemcpyDeviceToHost));
+        CHK(hipMemcpy(r.data(), d_rt, r.size() * 8, hipMemcpyDeviceToHost));
+        std::sort(c.begin(), c.end()); std::sort(r.begin(), r.end());
+        const double cyc = (double)c[c.size() / 2], rtk = (double)r[r.size() / 2], inst = (double)iters * 64, ghz = cyc / (rtk * 10.0);
+        const double rate = (double)blocks * 4 * inst / (ms * 1e-3);                    // wave-instructions per second, whole chip
+        printf("op %-36s W=%d  one-wave cycles/inst=%.2f  clock=%.3f GHz  chip rate=%.1f Ginst/s  => SIMD cycles/inst=%.2f\n", name, W, cyc / inst, ghz, rate / 1e9,
+               (ncu * 4.0) * ghz * 1e9 / rate);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    return 0;
+}
+
+template <int KIND>
+static int run(const char* name, int ncu, int inst_per_iter, float* d_out, unsigned long long* d_cyc, unsigned long long* d_rt) {
+    const int iters = 20000;
+    const int Ws[] = {1, 2, 3, 4, 5, 8};
+    for (int W : Ws) {
+        const int blocks = ncu * W;                 // 256-thread workgroups: one wave per SIMD each, W workgroups per CU
+        hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_valu<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, d_rt, 200);   // warm-up
+        CHK(hipDeviceSynchronize());
+        CHK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_valu<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, d_rt, iters);
+        CHK(hipEventRecord(e1, 0));
+        CHK(hipDeviceSynchronize());
+        float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<unsigned long long> c(blocks * 4), r(blocks * 4);
+        CHK(hipMemcpy(c.data(), d_cyc, c.size() * 8, hipMemcpyDeviceToHost));
+        CHK(hipMemcpy(r.data(), d_rt, r.size() * 8, hipMemcpyDeviceToHost));
+        std::sort(c.begin(), c.end()); std::sort(r.begin(), r.end());
+        const double cyc = (double)c[c.size() / 2], rtk = (double)r[r.size() / 2];
+        const double inst = (double)iters * inst_per_iter;
+        const double ghz = cyc / (rtk * 10.0);                       // s_memrealtime ticks at 100 MHz
+        printf("%-28s W=%d  cycles/inst/wave=%.3f  wave-inst/cycle/SIMD=%.3f  in-kernel clock=%.3f GHz  wall=%.3f ms  wall-rate=%.1f Ginst/s/chip\n",
+               name, W, cyc / inst, W * inst / cyc, ghz, ms, (double)blocks * 4 * inst / (ms * 1e-3) / 1e9);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    return 0;
+}
+
+int main() {
+    hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
+    const int ncu = prop.multiProcessorCount;
+    printf("device %s, %d CUs, clock %d kHz\n", prop.name, ncu, prop.clockRate);
+    float* d_out; unsigned long long *d_cyc, *d_rt;
+    CHK(hipMalloc(&d_out, (size_t)ncu * 8 * 256 * 4)); CHK(hipMalloc(&d_cyc, (size_t)ncu * 8 * 4 * 8)); CHK(hipMalloc(&d_rt, (size_t)ncu * 8 * 4 * 8));
+    if (run<0>("v_fma_f32 independent", ncu, 64, d_out, d_cyc, d_rt)) return 1;
+    if (run<1>("v_pk_fma_f32 independent", ncu, 64, d_out, d_cyc, d_rt)) return 1;
+    if (run<2>("v_fma_f32 dependent chain", ncu, 64, d_out, d_cyc, d_rt)) return 1;
+    if (run<3>("v_rcp_f32 independent", ncu, 64, d_out, d_cyc, d_rt)) return 1;
+    if (run<4>("cvt/fma/max3/cmp mix", ncu, 64, d_out, d_cyc, d_rt)) return 1;
+    if (run<5>("v_add_u32 dependent chain", ncu, 64, d_out, d_cyc, d_rt)) return 1;
+#define RUNOP(ID, NAME) if (run_op<ID>(NAME, ncu, d_out, d_cyc, d_rt)) return 1;
+    RUNOP(16, "v_fma_f32") RUNOP(0, "v_mul_f32") RUNOP(1, "v_add_f32") RUNOP(2, "v_max3_f32") RUNOP(3, "v_min_f32") RUNOP(4, "v_cvt_f32_ubyte0")
+    RUNOP(5, "v_cmp_le_f32 vcc") RUNOP(6, "v_cndmask_b32") RUNOP(7, "v_sqrt_f32") RUNOP(8, "v_rsq_f32") RUNOP(9, "v_mul_lo_u32") RUNOP(10, "v_lshl_add_u32")
+    RUNOP(11, "v_xor_b32") RUNOP(22, "v_add3_u32") RUNOP(23, "v_xad_u32") RUNOP(12, "v_add_u32") RUNOP(13, "v_div_scale_f32") RUNOP(14, "v_div_fmas_f32") RUNOP(15, "v_div_fixup_f32") RUNOP(17, "v_mov_b32")
+    RUNOP(18, "v_and_b32") RUNOP(19, "v_lshrrev_b32") RUNOP(20, "v_cvt_f32_u32") RUNOP(21, "v_mad_u32_u24")
+    return 0;
+}
