@@ -34,10 +34,11 @@ import __graft_entry__ as graft  # noqa: E402   (does not import torch)
 # shade's write.  Primary rays are priced like extension rays (their ray + state are written by raygen: 64 B of the 224).
 B_EXT, B_SHADOW, B_PIX = 224.0, 96.0, 32.0
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-# VALU issue roofline: 256 CUs x 4 SIMDs; a CDNA4 SIMD is 32 lanes wide, so a wave64 VALU instruction occupies it for 2 cycles
-# (MI355X_MICROARCH.md "v_fma_f32 (wave64): 2 cyc (SIMD-32); one wave alone: 4"; measured with tools/valu_peak.hip, profiles/r02_valu_peak.md)
-VALU_INST_PER_CYCLE_PER_SIMD = 0.5
-CLOCK_GHZ = 2.4
+# VALU roofline: what fraction of the SIMD-cycles of the launch had a VALU instruction in flight (4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs x
+# GRBM_GUI_ACTIVE / 8), tools/pmc_summary.py: "valu_pipe_util").  There is no single instruction-count peak on gfx950 — measured with
+# tools/valu_peak.hip (profiles/r02_valu_peak.md): a wave64 VOP3 fma / mul / add occupies its SIMD for 2.3 cycles, a VOP2-encoded mul / add /
+# logic op for 3.0-3.1, everything else (min / max / cvt / cmp / cndmask / bfe / packed f16) for 4.2, v_pk_fma_f32 for 4.0, rcp / rsq / sqrt for
+# 8.1 — so the busy fraction is the roofline figure, and lanes / 64 says how much of that work is useful.
 PMC_PROFILE = {"cornell_1080p_64spp_8b": "r02_pmc_cornell.json", "sponza_1080p_16spp_8b": "r02_pmc_sponza.json",
                "bistro_1080p_16spp_8b": "r02_pmc_bistro.json"}     # tools/pmc_run.sh + tools/pmc_summary.py of this same command
 KERNEL_SYMBOL = {"bounce_fused": ("k_bounce_small", "k_bounce_bvh"), "trace_closest": ("k_trace_closest",), "shade": ("k_shade",),
@@ -127,7 +128,9 @@ def pmc_for(rows, cls):
     launches = sum(r["launches"] for r in sel)
     valu = sum(r["valu_inst"] for r in sel)
     lanes = sum((r.get("lanes_per_valu") or 0.0) * r["valu_inst"] for r in sel) / valu if valu else None
-    return {"launches": launches, "valu_inst_per_launch": valu / launches, "lanes_per_valu": lanes,
+    cyc = sum(r.get("gpu_cycles") or 0.0 for r in sel)
+    busy = sum((r.get("valu_pipe_util") or 0.0) * (r.get("gpu_cycles") or 0.0) for r in sel) / cyc if cyc else None
+    return {"launches": launches, "valu_inst_per_launch": valu / launches, "lanes_per_valu": lanes, "valu_busy": busy,
             "hbm_bytes_per_launch": sum(r["hbm_bytes"] for r in sel) / launches}
 
 
@@ -172,15 +175,15 @@ def roofline_record(rt, workload, kms, kitems, klaunch, rays, n_pixel_samples, s
     if pm and traffic:
         roof["traffic_frac"] = round(pm["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)   # measured HBM bytes / live launch time
     if pm and pm["valu_inst_per_launch"]:
-        peak_inst = 256 * 4 * VALU_INST_PER_CYCLE_PER_SIMD * CLOCK_GHZ       # G wave-instructions / s
         ach = pm["valu_inst_per_launch"] / (avg_ms * 1e-3) / 1e9
-        roof["compute"] = {"valu_inst_per_launch": round(pm["valu_inst_per_launch"]), "lanes_per_inst": round(pm["lanes_per_valu"], 2) if pm["lanes_per_valu"] else None,
-                           "achieved_ginst_s": round(ach, 2), "peak_ginst_s": round(peak_inst, 1),
-                           "peak_model": f"256 CUs x 4 SIMDs x {VALU_INST_PER_CYCLE_PER_SIMD} wave64 VALU inst/cycle x {CLOCK_GHZ} GHz",
-                           "frac_valu": round(ach / peak_inst, 5),
-                           "frac_valu_lanes": round(ach / peak_inst * (pm["lanes_per_valu"] or 64.0) / 64.0, 5),
-                           "source": src + " (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU; counters of a separate run, time of this run)"}
-        if roof["compute"]["frac_valu"] > max(roof["frac"], roof.get("traffic_frac", 0.0)):
+        roof["compute"] = {"valu_busy_frac": round(pm["valu_busy"], 4) if pm["valu_busy"] is not None else None,
+                           "lanes_per_inst": round(pm["lanes_per_valu"], 2) if pm["lanes_per_valu"] else None,
+                           "frac_valu_lanes": round(pm["valu_busy"] * (pm["lanes_per_valu"] or 64.0) / 64.0, 4) if pm["valu_busy"] is not None else None,
+                           "valu_inst_per_launch": round(pm["valu_inst_per_launch"]), "achieved_ginst_s": round(ach, 2),
+                           "model": "valu_busy_frac = 4*SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE/8): SIMD-cycles with a VALU instruction in flight; "
+                                    "frac_valu_lanes = that x active lanes / 64",
+                           "source": src + " (counters of a separate rocprofv3 --pmc run of this command; instruction rate uses this run's launch time)"}
+        if (pm["valu_busy"] or 0.0) > max(roof["frac"], roof.get("traffic_frac", 0.0)):
             roof["bound"] = "valu"
     return roof
 
@@ -211,7 +214,8 @@ def time_extra(rt, dev_index, workload, steps=2):
         rec = {"ms_per_frame": round(dt * 1e3 / steps, 3), "Mrays_s": round(float(rays.sum()) / dt / 1e6, 1), "triangles": int(scene.num_triangles),
                "rays_per_frame": int(rays.sum() / steps), "dominant_kernel": roof["kernel"] if roof else None,
                "frac": roof["frac"] if roof else None, "bound": roof["bound"] if roof else None,
-               "frac_valu": roof.get("compute", {}).get("frac_valu") if roof else None,
+               "valu_busy_frac": roof.get("compute", {}).get("valu_busy_frac") if roof else None,
+               "lanes_per_inst": roof.get("compute", {}).get("lanes_per_inst") if roof else None,
                "kernel_ms_per_frame": {k: round(v / steps, 3) for k, v in roof["kernel_ms_by_class"].items()} if roof else None}
         return rec
     finally:

@@ -111,6 +111,14 @@ int  rtx_set_instance_transform(rtx_ctx*, uint32_t inst, const float o2w[16]);
 /* CreateAccelerationStructures (Renderer.cpp:893-946) + CollectEmissiveTriangles (:2123-2213) +
    CreateEmissiveTrianglesBuffer (:2237-2280): BVH build, emissive CDF, upload */
 int  rtx_commit_scene(rtx_ctx*);
+/* SURVEY 8(f3) binary scene cache.  rtx_save_scene_cache writes the committed scene — what the calls above handed over AND what
+   rtx_commit_scene derived for the device (MaterialOptimized table + Ess LUTs, compressed 8-wide BVH, leaf-ordered triangles, shading
+   records, emissive CDF, tiny-scene records) — to one versioned, checksummed file.  rtx_load_scene_cache REPLACES the context's scene
+   by the file's and uploads it (no BVH build: 3.8 M triangles in a fraction of the 2.2 s a commit takes); it returns RTX_ERR_INVALID and
+   leaves the current scene untouched for a missing / truncated / corrupt file, another version or another record layout.  The
+   reference has no such file (it rebuilds its BLAS / TLAS at start-up, Renderer.cpp:893-946). */
+int  rtx_save_scene_cache(rtx_ctx*, const char* path);
+int  rtx_load_scene_cache(rtx_ctx*, const char* path);
 /* b0 `CameraParams` (UpdateCameraBuffer, Renderer.cpp:1722-1768): view + projection; inverses computed inside */
 int  rtx_set_camera(rtx_ctx*, const float view[16], const float proj[16]);
 

@@ -20,11 +20,27 @@ rtxh_scene* rtxh_scene_bistro_class(uint32_t target_tris, uint32_t seed);  /* C5
 /* files: nfiles OBJ paths, each loaded through ObjLoader::loadObjFile (ObjLoader.h:393-495) as the reference's
    Renderer does (Renderer.cpp:363-407); returns NULL on parse error (message via rtxh_last_error) */
 rtxh_scene* rtxh_scene_from_obj(const char* const* files, uint32_t nfiles, const char* mtl_dir);
+/* SURVEY 8(f3) binary scene cache at the host level: the scene (materials, meshes, instances, camera) AND everything rtx_commit_scene
+   derives from it (BVH, shading records, LUTs, light CDF); versioned + checksummed (csrc/rtx_scene_cache.cpp).  Saving needs no GPU.
+   A loaded scene answers the accessors below like any other and rtxh_scene_upload hands the file's prebuilt arrays to the context
+   (rtx_load_scene_cache) instead of rebuilding.  NULL / RTX_ERR_INVALID + rtxh_last_error on a missing, corrupt or foreign file. */
+int         rtxh_scene_save(const rtxh_scene*, const char* path);
+rtxh_scene* rtxh_scene_load(const char* path);
 void        rtxh_scene_free(rtxh_scene*);
 const char* rtxh_last_error(void);
 
 uint32_t    rtxh_scene_num_materials(const rtxh_scene*);
 const void* rtxh_scene_materials(const rtxh_scene*);                       /* 128-byte Material records */
+/* SURVEY 8(f3) "full MTL PBR extension coverage": what tinyobj's material_t holds beyond the 128-byte Material (ObjLoader.h:428-435 copies
+   Kd, d, Ks, Ke, Pr, Pm, Ps, Pc only; Vertex.h:21 "ADD MAP IDs LATER"): Ni, Ns, illum, Ka, Tf / Kt, Pcr, aniso, anisor and one texture id per map
+   statement (-1 = none; ids index rtxh_scene_texture).  Only scenes loaded from OBJ / MTL files carry it (index-aligned with the
+   material table, default materials included); no kernel reads it — the reference's shaders sample no textures. */
+#define RTXH_NUM_MAP_SLOTS 13
+enum { RTXH_MAP_KA = 0, RTXH_MAP_KD, RTXH_MAP_KS, RTXH_MAP_KE, RTXH_MAP_NS, RTXH_MAP_BUMP, RTXH_MAP_D, RTXH_MAP_DISP, RTXH_MAP_REFL, RTXH_MAP_PR, RTXH_MAP_PM, RTXH_MAP_PS, RTXH_MAP_NORM };
+typedef struct rtxh_material_ext { float Ni, Ns, Pcr, aniso, anisor; int32_t illum; float Ka[3], Tf[3]; int32_t map[RTXH_NUM_MAP_SLOTS]; } rtxh_material_ext;
+int         rtxh_scene_material_ext(const rtxh_scene*, uint32_t material, rtxh_material_ext* out);   /* RTX_ERR_INVALID: no such record */
+uint32_t    rtxh_scene_num_textures(const rtxh_scene*);
+const char* rtxh_scene_texture(const rtxh_scene*, uint32_t i);                                      /* file name as written in the .mtl */
 uint32_t    rtxh_scene_num_meshes(const rtxh_scene*);
 int         rtxh_scene_mesh(const rtxh_scene*, uint32_t i, const void** verts28, uint32_t* nverts,
                             const uint32_t** indices, uint32_t* nidx, const uint32_t** material_ids);

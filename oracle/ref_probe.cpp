@@ -33,6 +33,14 @@ int main(int argc, char** argv) {
             const auto& m = mt[i];
             printf("%s{\"name\":\"%s\",", i ? "," : "", m.name.c_str());
             arr("diffuse", m.diffuse, 3); arr("specular", m.specular, 3); arr("emission", m.emission, 3);
+            arr("ambient", m.ambient, 3); arr("transmittance", m.transmittance, 3);
+            // texture names in the order of royaltracer-dx_amd/host/ObjLoader.h MapSlot (Ka Kd Ks Ke Ns bump d disp refl Pr Pm Ps norm)
+            const std::string* tex[13] = {&m.ambient_texname, &m.diffuse_texname, &m.specular_texname, &m.emissive_texname, &m.specular_highlight_texname, &m.bump_texname,
+                                          &m.alpha_texname, &m.displacement_texname, &m.reflection_texname, &m.roughness_texname, &m.metallic_texname, &m.sheen_texname, &m.normal_texname};
+            printf("\"tex\":[");
+            for (int k = 0; k < 13; k++) printf("%s\"%s\"", k ? "," : "", tex[k]->c_str());
+            printf("],\"shininess\":%.9g,\"illum\":%d,\"clearcoat_roughness\":%.9g,\"anisotropy\":%.9g,\"anisotropy_rotation\":%.9g,", m.shininess, m.illum, m.clearcoat_roughness,
+                   m.anisotropy, m.anisotropy_rotation);
             printf("\"dissolve\":%.9g,\"roughness\":%.9g,\"metallic\":%.9g,\"sheen\":%.9g,\"clearcoat_thickness\":%.9g,\"ior\":%.9g}",
                    m.dissolve, m.roughness, m.metallic, m.sheen, m.clearcoat_thickness, m.ior);
         }

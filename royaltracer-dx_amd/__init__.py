@@ -95,6 +95,8 @@ _sig("rtx_add_instance", C.c_int, _vp, _u32, _fp, _u32p)
 _sig("rtx_set_instance_transform", C.c_int, _vp, _u32, _fp)
 _sig("rtx_commit_scene", C.c_int, _vp)
 _sig("rtx_set_camera", C.c_int, _vp, _fp, _fp)
+_sig("rtx_save_scene_cache", C.c_int, _vp, C.c_char_p)
+_sig("rtx_load_scene_cache", C.c_int, _vp, C.c_char_p)
 _sig("rtx_bind_accum", C.c_int, _vp, _vp, C.c_size_t)
 _sig("rtx_clear_accum", C.c_int, _vp, _u32, _u32)
 _sig("rtx_render", C.c_int, _vp, C.POINTER(Params))
@@ -126,9 +128,21 @@ _sig("rtxh_scene_sponza_class", _vp, _u32, _u32)
 _sig("rtxh_scene_bistro_class", _vp, _u32, _u32)
 _sig("rtxh_scene_from_obj", _vp, C.POINTER(C.c_char_p), _u32, C.c_char_p)
 _sig("rtxh_scene_free", None, _vp)
+_sig("rtxh_scene_save", C.c_int, _vp, C.c_char_p)
+_sig("rtxh_scene_load", _vp, C.c_char_p)
 _sig("rtxh_last_error", C.c_char_p)
 _sig("rtxh_scene_num_materials", _u32, _vp)
 _sig("rtxh_scene_materials", _vp, _vp)
+class MaterialExt(C.Structure):
+    """rtxh_material_ext (include/rtx_host.h)"""
+    _fields_ = [("Ni", C.c_float), ("Ns", C.c_float), ("Pcr", C.c_float), ("aniso", C.c_float), ("anisor", C.c_float), ("illum", C.c_int32),
+                ("Ka", C.c_float * 3), ("Tf", C.c_float * 3), ("map", C.c_int32 * 13)]
+
+
+MAP_SLOTS = ("Ka", "Kd", "Ks", "Ke", "Ns", "bump", "d", "disp", "refl", "Pr", "Pm", "Ps", "norm")
+_sig("rtxh_scene_material_ext", C.c_int, _vp, _u32, C.POINTER(MaterialExt))
+_sig("rtxh_scene_num_textures", _u32, _vp)
+_sig("rtxh_scene_texture", C.c_char_p, _vp, _u32)
 _sig("rtxh_scene_num_meshes", _u32, _vp)
 _sig("rtxh_scene_mesh", C.c_int, _vp, _u32, C.POINTER(_vp), _u32p, C.POINTER(_vp), _u32p, C.POINTER(_vp))
 _sig("rtxh_scene_num_instances", _u32, _vp)
@@ -188,6 +202,14 @@ class Scene:
         n = lib.rtxh_scene_num_materials(handle)
         buf = (C.c_float * (n * 32)).from_address(lib.rtxh_scene_materials(handle)) if n else []
         self.materials = np.array(buf, dtype=np.float32).reshape(n, 32)
+        self.textures = [lib.rtxh_scene_texture(handle, i).decode() for i in range(lib.rtxh_scene_num_textures(handle))]
+        self.material_ext = []                       # per material (OBJ / MTL scenes only): the MTL fields and map ids beside the 128-byte record
+        for i in range(n):
+            x = MaterialExt()
+            if lib.rtxh_scene_material_ext(handle, i, C.byref(x)) != RTX_OK:
+                break
+            self.material_ext.append(dict(Ni=x.Ni, Ns=x.Ns, Pcr=x.Pcr, aniso=x.aniso, anisor=x.anisor, illum=x.illum, Ka=list(x.Ka), Tf=list(x.Tf),
+                                          maps={MAP_SLOTS[k]: self.textures[x.map[k]] for k in range(13) if x.map[k] >= 0}))
         self.meshes = []
         for i in range(lib.rtxh_scene_num_meshes(handle)):
             v, idx, mid = _vp(), _vp(), _vp()
@@ -230,6 +252,18 @@ class Scene:
     def from_obj(cls, files, mtl_dir):
         arr = (C.c_char_p * len(files))(*[f.encode() for f in files])
         return cls(lib.rtxh_scene_from_obj(arr, len(files), mtl_dir.encode()))
+
+    def save(self, path):
+        """write the binary scene cache: this scene + its BVH / shading records / LUTs (built on the host, no GPU needed)"""
+        if lib.rtxh_scene_save(self._h, str(path).encode()) != RTX_OK:
+            raise RtxError("rtxh_scene_save failed: " + lib.rtxh_last_error().decode())
+
+    @classmethod
+    def load(cls, path):
+        """a scene from a binary cache file; Context.upload(scene) then hands the prebuilt arrays to the GPU without rebuilding"""
+        s = cls(lib.rtxh_scene_load(str(path).encode()))
+        s.cache_path = str(path)
+        return s
 
     def small_records(self):
         """-> (records (n,20) f32, triangle ids (n,2) i32, delta, cm) of the tiny-scene pre-test, or None"""
@@ -381,8 +415,19 @@ class Context:
         v, p = _f32(view).reshape(16), _f32(proj).reshape(16)
         self._ck(lib.rtx_set_camera(self._h, _fptr(v), _fptr(p)), "rtx_set_camera")
 
+    def save_scene_cache(self, path):
+        self._ck(lib.rtx_save_scene_cache(self._h, str(path).encode()), "rtx_save_scene_cache")
+
+    def load_scene_cache(self, path):
+        self._ck(lib.rtx_load_scene_cache(self._h, str(path).encode()), "rtx_load_scene_cache")
+
     def upload(self, scene, aspect):
-        """rtx_set_materials / add_mesh / add_instance / commit / set_camera from a Scene (array path)."""
+        """rtx_set_materials / add_mesh / add_instance / commit / set_camera from a Scene (array path); a Scene.load()-ed scene
+        goes through rtx_load_scene_cache instead (prebuilt BVH)."""
+        if getattr(scene, "cache_path", None):
+            self.load_scene_cache(scene.cache_path)
+            self.set_camera(*scene.view_proj(aspect))
+            return
         self.set_materials(scene.materials)
         for v, i, m in scene.meshes:
             self.add_mesh(v, i, m)

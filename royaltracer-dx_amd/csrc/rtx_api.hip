@@ -171,6 +171,21 @@ int rtx_set_instance_transform(rtx_ctx* c, uint32_t inst, const float o2w[16]) {
     c->committed = false; return RTX_OK;
 }
 
+static int upload_built(rtx_ctx* c) {          // every device array of a freshly built (or freshly loaded) scene
+    BuiltScene& B = c->built;
+    int r;
+    if ((r = upload(c, c->d_nodes, B.nodes8))) return r;
+    if ((r = upload(c, c->d_tris, B.tris8))) return r;
+    if ((r = upload(c, c->d_shade, B.shade))) return r;
+    if ((r = upload(c, c->d_small, B.small_recs))) return r;
+    if ((r = upload(c, c->d_small_tris, B.small_tris))) return r;
+    if ((r = upload(c, c->d_small_poly, B.small_poly))) return r;
+    if ((r = upload(c, c->d_mats, B.mats))) return r;
+    if ((r = upload(c, c->d_insts, B.insts))) return r;
+    return upload(c, c->d_lights, B.lights);
+}
+static int finalise_scene(rtx_ctx* c);
+
 int rtx_commit_scene(rtx_ctx* c) {
     BIND(c);
     for (size_t i = 0; i < c->host.matids.size(); i++)
@@ -187,7 +202,10 @@ int rtx_commit_scene(rtx_ctx* c) {
         if (mats_changed && (r = upload(c, c->d_mats, B.mats))) return r;      // rtx_set_materials on a resident scene: new table beside the new light list
         if ((r = upload(c, c->d_insts, B.insts))) return r;
         if ((r = upload(c, c->d_lights, B.lights))) return r;
-        if (!c->objtris_uploaded) { if ((r = upload(c, c->d_objtris, B.objtris))) return r; c->objtris_uploaded = true; }
+        if (!c->objtris_uploaded) {
+            if (B.objtris.empty()) c->host.fill_objtris(B);             // scene came from a cache file: derive them from the meshes now
+            if ((r = upload(c, c->d_objtris, B.objtris))) return r; c->objtris_uploaded = true;
+        }
         HIPCHK(c, c->d_node_aabb.ensure(B.nodes8.size() * 32));
         const std::vector<uint32_t> one(1, 0x3f800000u);      // scale starts at 1.0 like the host's max(1, |coordinates|)
         if ((r = upload(c, c->d_scale, one))) return r;
@@ -197,16 +215,30 @@ int rtx_commit_scene(rtx_ctx* c) {
     } else {
         c->device_scene_valid = false; c->objtris_uploaded = false;
         if (!c->host.build(B)) { c->err = c->host.err; return RTX_ERR_INVALID; }
-        if ((r = upload(c, c->d_nodes, B.nodes8))) return r;
-        if ((r = upload(c, c->d_tris, B.tris8))) return r;
-        if ((r = upload(c, c->d_shade, B.shade))) return r;
-        if ((r = upload(c, c->d_small, B.small_recs))) return r;
-        if ((r = upload(c, c->d_small_tris, B.small_tris))) return r;
-        if ((r = upload(c, c->d_small_poly, B.small_poly))) return r;
-        if ((r = upload(c, c->d_mats, B.mats))) return r;
-        if ((r = upload(c, c->d_insts, B.insts))) return r;
-        if ((r = upload(c, c->d_lights, B.lights))) return r;
+        if ((r = upload_built(c))) return r;
     }
+    return finalise_scene(c);
+}
+
+// the binary scene cache.  Save = the committed scene (inputs + everything rtx_commit_scene derived); load = replace the
+// context's scene by the file's and upload it, instead of rtx_set_materials / rtx_add_mesh / rtx_add_instance / rtx_commit_scene.
+int rtx_save_scene_cache(rtx_ctx* c, const char* path) {
+    if (!c) return RTX_ERR_INVALID;
+    if (!c->committed) { c->err = "save_scene_cache: scene not committed"; return RTX_ERR_STATE; }
+    if (!save_scene_cache(c->host, c->built, path, c->err)) return RTX_ERR_INVALID;
+    return RTX_OK;
+}
+int rtx_load_scene_cache(rtx_ctx* c, const char* path) {
+    BIND(c);
+    if (!load_scene_cache(path, c->host, c->built, c->err)) return RTX_ERR_INVALID;     // on failure the previous scene is untouched
+    c->committed = false; c->device_scene_valid = false; c->objtris_uploaded = false;
+    int r = upload_built(c);
+    if (r) return r;
+    return finalise_scene(c);
+}
+
+static int finalise_scene(rtx_ctx* c) {
+    BuiltScene& B = c->built;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->device_scene_valid = true;
     DevScene& s = c->dsc;
@@ -299,8 +331,9 @@ static const char* validate_tiling(const rtx_params* p, uint32_t& ts, uint32_t& 
     cnt = p->shard_count ? p->shard_count : 1;
     if (p->shard_rank >= cnt) return "params: shard_rank >= shard_count";
     const uint64_t total = (uint64_t)((p->width + (uint64_t)ts - 1) / ts) * ((p->height + (uint64_t)ts - 1) / ts);
-    npl = ((total + cnt - 1) / cnt) * ts * ts;
-    if (npl > 0x7FFFFFFFull) return "params: image too large";
+    const uint64_t per = (total + cnt - 1) / cnt;
+    if (per > 0x7FFFFFFFull / ((uint64_t)ts * ts)) return "params: image too large";      // (checked before the multiplication: 2^56 tiles of 16 x 16 would wrap)
+    npl = per * ts * ts;
     return nullptr;
 }
 

@@ -61,7 +61,13 @@ struct SceneHost {
     // transform-only update of the records the GPU refit does not derive itself: instance matrices and the light list
     bool refresh_transforms(BuiltScene& out);
     void build_lights(BuiltScene& out) const;
+    void fill_objtris(BuiltScene& out) const;   // object-space triangles for the GPU refit (rtx_scene_cache.cpp: not stored in a cache file)
 };
+
+// binary scene cache (rtx_scene_cache.cpp): the host scene + everything build() derived that the device needs; versioned, checksummed
+// cam12 (optional): eye, center, up, fovY degrees, znear, zfar of the host layer's scene (rtxh_scene_save / rtxh_scene_load)
+bool save_scene_cache(const SceneHost& H, const BuiltScene& B, const char* path, std::string& err, const float* cam12 = nullptr);
+bool load_scene_cache(const char* path, SceneHost& H, BuiltScene& B, std::string& err, float* cam12 = nullptr);
 
 // binned-SAH BVH2 over world-space triangles (9 floats each); fills nodes (breadth-first, children boxes in
 // parent) and the leaf-ordered triangle permutation.

@@ -1,4 +1,5 @@
 #include "ObjLoader.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -98,12 +99,34 @@ void GenerateEssLUT(Material& mat) {
 // minimal OBJ / MTL reader
 // ------------------------------------------------------------------------------------------------
 namespace {
-struct MtlRec { std::string name; float Kd[3] = {0, 0, 0}, Ks[3] = {0, 0, 0}, Ke[3] = {0, 0, 0}; float d = 1.0f, Pr = 0, Pm = 0, Ps = 0, Pc = 0, Ni = 1.0f; bool has_d = false; };
+inline const char* skip_ws(const char* p) { while (*p == ' ' || *p == '\t') p++; return p; }
+inline bool parse_float(const char*& p, float& out) { p = skip_ws(p); char* e; double d = strtod(p, &e); if (e == p) return false; out = (float)d; p = e; return true; }
+// tinyobj::material_t's defaults (InitMaterial, tiny_obj_loader.h): everything zero except dissolve = 1, ior = 1, shininess = 1
+struct MtlRec { std::string name; float Kd[3] = {0, 0, 0}, Ks[3] = {0, 0, 0}, Ke[3] = {0, 0, 0}; float d = 1.0f, Pr = 0, Pm = 0, Ps = 0, Pc = 0, Ni = 1.0f; bool has_d = false;
+                float Ka[3] = {0, 0, 0}, Tf[3] = {0, 0, 0}; float Ns = 1.0f, Pcr = 0, aniso = 0, anisor = 0; int illum = 0;
+                std::string tex[kNumMapSlots]; };
+// `map_* [options] file name until the end of the line` (ParseTextureNameAndOption, tiny_obj_loader.h): options first, each with its own
+// argument count, then the rest of the line is the name (it may contain blanks)
+std::string parse_texname(const char* p) {
+    auto word = [&](const char* k) { size_t n = strlen(k); if (!strncmp(p, k, n) && (p[n] == ' ' || p[n] == '\t')) { p += n + 1; return true; } return false; };
+    auto skip_tok = [&]() { p = skip_ws(p); while (*p && *p != ' ' && *p != '\t') p++; };
+    auto skip_reals = [&](int n) { for (int i = 0; i < n; i++) { p = skip_ws(p); char* e; (void)strtod(p, &e); if (e == p) break; p = e; } };
+    std::string name;
+    while (true) {
+        p = skip_ws(p);
+        if (!*p) break;
+        if (word("-blendu") || word("-blendv") || word("-clamp") || word("-imfchan") || word("-colorspace") || word("-type") || word("-texres")) skip_tok();
+        else if (word("-boost") || word("-bm")) skip_reals(1);
+        else if (word("-mm")) skip_reals(2);
+        else if (word("-o") || word("-s") || word("-t")) skip_reals(3);
+        else { name = p; break; }
+    }
+    while (!name.empty() && (name.back() == ' ' || name.back() == '\t')) name.pop_back();
+    return name;
+}
 struct ObjIdx { int v, vn; };
 struct ObjParsed { std::vector<float> v, vn; std::vector<ObjIdx> idx; std::vector<int> face_mat; std::vector<MtlRec> mats; };
 
-inline const char* skip_ws(const char* p) { while (*p == ' ' || *p == '\t') p++; return p; }
-inline bool parse_float(const char*& p, float& out) { p = skip_ws(p); char* e; double d = strtod(p, &e); if (e == p) return false; out = (float)d; p = e; return true; }
 
 void load_mtl(const std::string& path, std::vector<MtlRec>& mats, std::unordered_map<std::string, int>& map) {
     std::ifstream f(path);
@@ -118,7 +141,7 @@ void load_mtl(const std::string& path, std::vector<MtlRec>& mats, std::unordered
         auto key = [&](const char* k) { size_t n = strlen(k); if (!strncmp(p, k, n) && (p[n] == ' ' || p[n] == '\t')) { p += n; return true; } return false; };
         if (key("newmtl")) { flush(); cur = MtlRec(); have = true; cur.name = skip_ws(p); while (!cur.name.empty() && (cur.name.back() == ' ' || cur.name.back() == '\t')) cur.name.pop_back(); }
         else if (key("Kd")) { for (int i = 0; i < 3; i++) parse_float(p, cur.Kd[i]); has_kd = true; }
-        else if (key("map_Kd")) { if (!has_kd) cur.Kd[0] = cur.Kd[1] = cur.Kd[2] = 0.6f; }        // a diffuse texture without a Kd before it: tiny_obj_loader.h:2328-2341
+        else if (key("map_Kd")) { if (!has_kd) cur.Kd[0] = cur.Kd[1] = cur.Kd[2] = 0.6f; cur.tex[MAP_KD] = parse_texname(p); }   // a diffuse texture without a Kd before it: tiny_obj_loader.h:2328-2341
         else if (key("Ks")) { for (int i = 0; i < 3; i++) parse_float(p, cur.Ks[i]); }
         else if (key("Ke")) { for (int i = 0; i < 3; i++) parse_float(p, cur.Ke[i]); }
         else if (key("d")) { parse_float(p, cur.d); cur.has_d = true; }
@@ -128,6 +151,26 @@ void load_mtl(const std::string& path, std::vector<MtlRec>& mats, std::unordered
         else if (key("Pm")) parse_float(p, cur.Pm);
         else if (key("Ps")) parse_float(p, cur.Ps);
         else if (key("Pc")) parse_float(p, cur.Pc);
+        // the rest of tinyobj's material_t: parsed and carried beside the 128-byte record (Vertex.h:21 "ADD MAP IDs LATER"), not consumed by any shader
+        else if (key("Pcr")) parse_float(p, cur.Pcr);
+        else if (key("aniso")) parse_float(p, cur.aniso);
+        else if (key("anisor")) parse_float(p, cur.anisor);
+        else if (key("Ns")) parse_float(p, cur.Ns);
+        else if (key("Ka")) { for (int i = 0; i < 3; i++) parse_float(p, cur.Ka[i]); }
+        else if (key("Kt") || key("Tf")) { for (int i = 0; i < 3; i++) parse_float(p, cur.Tf[i]); }
+        else if (key("illum")) { float v = 0; if (parse_float(p, v)) cur.illum = (int)v; }
+        else if (key("map_Ka")) cur.tex[MAP_KA] = parse_texname(p);
+        else if (key("map_Ks")) cur.tex[MAP_KS] = parse_texname(p);
+        else if (key("map_Ke")) cur.tex[MAP_KE] = parse_texname(p);
+        else if (key("map_Ns")) cur.tex[MAP_NS] = parse_texname(p);
+        else if (key("map_bump") || key("map_Bump") || key("bump")) cur.tex[MAP_BUMP] = parse_texname(p);
+        else if (key("map_d")) cur.tex[MAP_D] = parse_texname(p);
+        else if (key("disp")) cur.tex[MAP_DISP] = parse_texname(p);
+        else if (key("refl")) cur.tex[MAP_REFL] = parse_texname(p);
+        else if (key("map_Pr")) cur.tex[MAP_PR] = parse_texname(p);
+        else if (key("map_Pm")) cur.tex[MAP_PM] = parse_texname(p);
+        else if (key("map_Ps")) cur.tex[MAP_PS] = parse_texname(p);
+        else if (key("norm")) cur.tex[MAP_NORM] = parse_texname(p);
     }
     flush();
 }
@@ -245,17 +288,38 @@ bool parse_obj(const std::string& file, const std::string& mtl_dir, ObjParsed& o
 void ObjLoader::loadObjFile(const std::string& inputfile, std::vector<Vertex>* vertices, std::vector<UINT>* indices,
                             std::vector<Material>* mats, std::vector<UINT>* materialIDs, UINT* materialOffset,
                             UINT* materialVertexOffset, const std::string& material_search_path) {
+    loadObjFileEx(inputfile, vertices, indices, mats, materialIDs, materialOffset, materialVertexOffset, nullptr, nullptr, material_search_path);
+}
+
+void ObjLoader::loadObjFileEx(const std::string& inputfile, std::vector<Vertex>* vertices, std::vector<UINT>* indices,
+                              std::vector<Material>* mats, std::vector<UINT>* materialIDs, UINT* materialOffset,
+                              UINT* materialVertexOffset, std::vector<MaterialExt>* ext, std::vector<std::string>* textures,
+                              const std::string& material_search_path) {
     ObjParsed P; std::string err;
     if (!parse_obj(inputfile, material_search_path, P, err)) throw std::runtime_error("ObjLoader: " + err);   // ObjLoader.h:399-404
     // default material for faces without one (ObjLoader.h:415-417)
     Material defaultMaterial(XMFLOAT4(1.0f, 1.0f, 1.0f, 1.0f), XMFLOAT4(1.0f, 0.0f, 0.0f, 0.0f));
     mats->push_back(defaultMaterial);
+    if (ext) ext->push_back(MaterialExt());
     (*materialOffset)++;
     for (const MtlRec& m : P.mats) {                                                                        // :420-444
         Material t(XMFLOAT4(m.Kd[0], m.Kd[1], m.Kd[2], m.d), XMFLOAT4(m.Pr, m.Pm, m.Ps, m.Pc));
         t.Ke = XMFLOAT3(m.Ke); t.Ks = XMFLOAT3(m.Ks);
         GenerateEssLUT(t);
         mats->push_back(t);
+        if (ext) {                         // everything else tinyobj parsed: beside the record, map ids index *textures (one entry per distinct file name)
+            MaterialExt x;
+            x.Ni = m.Ni; x.Ns = m.Ns; x.Pcr = m.Pcr; x.aniso = m.aniso; x.anisor = m.anisor; x.illum = m.illum;
+            for (int k = 0; k < 3; k++) { x.Ka[k] = m.Ka[k]; x.Tf[k] = m.Tf[k]; }
+            for (int k = 0; k < kNumMapSlots; k++) {
+                x.map[k] = -1;
+                if (m.tex[k].empty() || !textures) continue;
+                auto it = std::find(textures->begin(), textures->end(), m.tex[k]);
+                if (it == textures->end()) { textures->push_back(m.tex[k]); it = textures->end() - 1; }
+                x.map[k] = (int)(it - textures->begin());
+            }
+            ext->push_back(x);
+        }
     }
     std::unordered_map<Vertex, uint32_t> unique;
     const size_t nfaces = P.idx.size() / 3;

@@ -319,7 +319,7 @@ Scene LoadObjScene(const std::vector<std::string>& files, const std::string& mtl
     size_t total_ids = 0;
     for (size_t i = 0; i < files.size(); i++) {
         SceneModel m;
-        ObjLoader::loadObjFile(files[i], &m.vertices, &m.indices, &s.materials, &m.materialIDs, &materialIDOffset, &materialVertexOffset, mtl_dir);
+        ObjLoader::loadObjFileEx(files[i], &m.vertices, &m.indices, &s.materials, &m.materialIDs, &materialIDOffset, &materialVertexOffset, &s.materialExt, &s.textures, mtl_dir);
         total_ids += m.materialIDs.size();
         materialVertexOffset = (UINT)total_ids;                // Renderer.cpp:1997
         s.models.push_back(std::move(m));

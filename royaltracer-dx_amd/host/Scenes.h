@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include "Vertex.h"
+#include "ObjLoader.h"
 #include "../../include/rtx.h"
 
 struct SceneModel { std::vector<Vertex> vertices; std::vector<UINT> indices; std::vector<UINT> materialIDs; };
@@ -13,6 +14,8 @@ struct SceneInstance { UINT model; XMMATRIX transform; };
 struct Scene {
     std::string name;
     std::vector<Material> materials;         // [default_0, mats of model 0..., default_1, ...]  (ObjLoader.h:415-417,494)
+    std::vector<MaterialExt> materialExt;    // index-aligned with `materials` when the scene came from OBJ / MTL files (empty otherwise): the MTL fields and
+    std::vector<std::string> textures;       // texture map ids the 128-byte record has no room for (Vertex.h:21 "ADD MAP IDs LATER"), and the distinct map file names
     std::vector<SceneModel> models;
     std::vector<SceneInstance> instances;
     XMFLOAT3 eye{0, 0, 1}, center{0, 0, 0}, up{0, 1, 0};

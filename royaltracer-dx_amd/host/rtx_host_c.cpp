@@ -13,7 +13,7 @@
 #include "Scenes.h"
 #include "manipulator.h"
 
-struct rtxh_scene { Scene s; };
+struct rtxh_scene { Scene s; std::string cache_path; };     // cache_path: the scene came from rtxh_scene_load; rtxh_scene_upload hands the FILE to the context (no rebuild)
 struct rtxh_renderer { Renderer* r; };
 static thread_local std::string g_err;
 
@@ -40,6 +40,17 @@ const char* rtxh_last_error(void) { return g_err.c_str(); }
 
 uint32_t rtxh_scene_num_materials(const rtxh_scene* s) { return (uint32_t)s->s.materials.size(); }
 const void* rtxh_scene_materials(const rtxh_scene* s) { return s->s.materials.data(); }
+uint32_t rtxh_scene_num_textures(const rtxh_scene* s) { return (uint32_t)s->s.textures.size(); }
+const char* rtxh_scene_texture(const rtxh_scene* s, uint32_t i) { return i < s->s.textures.size() ? s->s.textures[i].c_str() : nullptr; }
+int rtxh_scene_material_ext(const rtxh_scene* s, uint32_t i, rtxh_material_ext* out) {
+    if (!out || i >= s->s.materialExt.size()) return RTX_ERR_INVALID;
+    const MaterialExt& x = s->s.materialExt[i];
+    static_assert(RTXH_NUM_MAP_SLOTS == kNumMapSlots, "map slot count");
+    out->Ni = x.Ni; out->Ns = x.Ns; out->Pcr = x.Pcr; out->aniso = x.aniso; out->anisor = x.anisor; out->illum = x.illum;
+    for (int k = 0; k < 3; k++) { out->Ka[k] = x.Ka[k]; out->Tf[k] = x.Tf[k]; }
+    for (int k = 0; k < kNumMapSlots; k++) out->map[k] = x.map[k];
+    return RTX_OK;
+}
 uint32_t rtxh_scene_num_meshes(const rtxh_scene* s) { return (uint32_t)s->s.models.size(); }
 int rtxh_scene_mesh(const rtxh_scene* s, uint32_t i, const void** v, uint32_t* nv, const uint32_t** idx, uint32_t* nidx, const uint32_t** mids) {
     if (i >= s->s.models.size()) return RTX_ERR_INVALID;
@@ -62,7 +73,53 @@ int rtxh_scene_camera(const rtxh_scene* s, float eye[3], float center[3], float 
     return RTX_OK;
 }
 int rtxh_scene_view_proj(const rtxh_scene* s, float aspect, float view[16], float proj[16]) { SceneViewProj(s->s, aspect, view, proj); return RTX_OK; }
-int rtxh_scene_upload(const rtxh_scene* s, rtx_ctx* c, float aspect) { return UploadScene(s->s, c, aspect); }
+int rtxh_scene_upload(const rtxh_scene* s, rtx_ctx* c, float aspect) {
+    if (s->cache_path.empty()) return UploadScene(s->s, c, aspect);
+    int r = rtx_load_scene_cache(c, s->cache_path.c_str());               // prebuilt BVH / shading records / LUTs straight from the file
+    if (r) return r;
+    float view[16], proj[16];
+    SceneViewProj(s->s, aspect, view, proj);
+    return rtx_set_camera(c, view, proj);
+}
+
+// the host scene with everything rtx_commit_scene would derive from it, in one file (format: csrc/rtx_scene_cache.cpp).
+// Saving builds on the host only (no GPU needed); a loaded scene reads like any other (materials, meshes, instances, camera) and uploads
+// without a BVH build.
+int rtxh_scene_save(const rtxh_scene* s, const char* path) {
+    rtx::SceneHost H; rtx::BuiltScene B;
+    const Scene& sc = s->s;
+    bool ok = H.set_materials(sc.materials.data(), (uint32_t)sc.materials.size());
+    for (const SceneModel& m : sc.models) { uint32_t id; ok = ok && H.add_mesh(m.vertices.data(), (uint32_t)m.vertices.size(), m.indices.data(), (uint32_t)m.indices.size(), m.materialIDs.data(), &id); }
+    for (const SceneInstance& in : sc.instances) { uint32_t id; ok = ok && H.add_instance(in.model, in.transform.data(), &id); }
+    if (!ok || !H.build(B)) { g_err = H.err; return RTX_ERR_INVALID; }
+    const float cam[12] = {sc.eye.x, sc.eye.y, sc.eye.z, sc.center.x, sc.center.y, sc.center.z, sc.up.x, sc.up.y, sc.up.z, sc.fovY_deg, sc.zn, sc.zf};
+    std::string err;
+    if (!rtx::save_scene_cache(H, B, path, err, cam)) { g_err = err; return RTX_ERR_INVALID; }
+    return RTX_OK;
+}
+rtxh_scene* rtxh_scene_load(const char* path) {
+    rtx::SceneHost H; rtx::BuiltScene B; float cam[12]; std::string err;
+    if (!rtx::load_scene_cache(path, H, B, err, cam)) { g_err = err; return nullptr; }
+    rtxh_scene* h = new rtxh_scene();
+    Scene& sc = h->s;
+    sc.name = path; h->cache_path = path;
+    const size_t nmat = H.mats128.size() / 32;
+    sc.materials.assign(nmat, Material(XMFLOAT4(1, 1, 1, 1), XMFLOAT4(0, 0, 0, 0)));
+    static_assert(sizeof(Material) == 128 && sizeof(Vertex) == 28, "reference record sizes");
+    if (nmat) memcpy((void*)sc.materials.data(), H.mats128.data(), nmat * 128);
+    sc.models.resize(H.meshes.size());
+    for (size_t i = 0; i < H.meshes.size(); i++) {
+        const rtx::MeshHost& m = H.meshes[i]; SceneModel& o = sc.models[i];
+        o.vertices.assign(m.verts.size() / 7, Vertex(XMFLOAT3(0, 0, 0), XMFLOAT4(0, 0, 0, 0)));
+        if (!m.verts.empty()) memcpy((void*)o.vertices.data(), m.verts.data(), m.verts.size() * 4);
+        o.indices = m.idx;
+        o.materialIDs.assign(H.matids.begin() + m.matid_base, H.matids.begin() + m.matid_base + (long)m.idx.size());
+    }
+    for (const rtx::InstHost& in : H.insts) { SceneInstance si; si.model = in.mesh; memcpy((void*)si.transform.data(), in.o2w, 64); sc.instances.push_back(si); }
+    sc.eye = XMFLOAT3(cam[0], cam[1], cam[2]); sc.center = XMFLOAT3(cam[3], cam[4], cam[5]); sc.up = XMFLOAT3(cam[6], cam[7], cam[8]);
+    sc.fovY_deg = cam[9]; sc.zn = cam[10]; sc.zf = cam[11];
+    return h;
+}
 
 void rtxh_lookat(const float e[3], const float c[3], const float u[3], float view[16]) {
     nv_helpers_dx12::Manipulator m;

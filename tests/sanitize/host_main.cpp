@@ -40,6 +40,26 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> img(37 * 21 * 4, 128); std::vector<float> acc(37 * 21 * 4, 1.5f);
     printf("png %d ppm %d exr %d\n", rtxh_write_png((out + "/a.png").c_str(), img.data(), 37, 21), rtxh_write_ppm((out + "/a.ppm").c_str(), img.data(), 37, 21), rtxh_write_exr((out + "/a.exr").c_str(), acc.data(), 37, 21));
     float lut[16]; rtxh_generate_ess_lut(0.5f, lut); printf("lut0 %f\n", lut[0]);
+    // binary scene cache: save (host build), load, and every way a file can be damaged (must be refused without touching freed / foreign memory)
+    for (rtxh_scene* sc : {c, g, b}) {
+        const std::string path = out + "/cache.rtxscn";
+        if (rtxh_scene_save(sc, path.c_str()) != 0) { printf("cache save failed: %s\n", rtxh_last_error()); return 4; }
+        rtxh_scene* back = rtxh_scene_load(path.c_str());
+        if (!back || rtxh_scene_num_triangles(back) != rtxh_scene_num_triangles(sc) || rtxh_scene_num_materials(back) != rtxh_scene_num_materials(sc)) { printf("cache load failed\n"); return 4; }
+        rtxh_scene_free(back);
+        FILE* f = fopen(path.c_str(), "rb"); fseek(f, 0, SEEK_END); long len = ftell(f); fseek(f, 0, SEEK_SET);
+        std::vector<uint8_t> blob((size_t)len); if (fread(blob.data(), 1, blob.size(), f) != blob.size()) return 4; fclose(f);
+        auto refused = [&](const std::vector<uint8_t>& d) { const std::string bp = out + "/bad.rtxscn"; FILE* w = fopen(bp.c_str(), "wb"); if (!d.empty()) fwrite(d.data(), 1, d.size(), w); fclose(w);
+                                                             rtxh_scene* x = rtxh_scene_load(bp.c_str()); if (x) { rtxh_scene_free(x); return false; } return true; };
+        std::vector<uint8_t> t(blob.begin(), blob.begin() + (long)(blob.size() / 3)), fl = blob, ver = blob, tiny(blob.begin(), blob.begin() + 40);
+        fl[fl.size() - 100] ^= 0x40; ver[8] ^= 3;
+        if (!refused(t) || !refused(fl) || !refused(ver) || !refused(tiny) || !refused({})) { printf("a damaged cache file was accepted\n"); return 4; }
+    }
+    printf("scene cache ok\n");
+    // MTL extension records of an OBJ scene
+    rtxh_material_ext mx; uint32_t nx = 0; while (rtxh_scene_material_ext(g, nx, &mx) == 0) nx++;
+    printf("material ext records %u textures %u\n", nx, rtxh_scene_num_textures(g));
+    if (nx != rtxh_scene_num_materials(g)) return 5;
     rtxh_scene_free(c); rtxh_scene_free(s); rtxh_scene_free(b); rtxh_scene_free(g);
     printf("done\n");
     return 0;

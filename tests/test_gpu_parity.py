@@ -634,6 +634,70 @@ def test_material_edit_after_commit(rt, orc, cornell, gpu_refit, tris):
     c.close()
 
 
+@pytest.mark.parametrize("kind", ["cornell", "garage", "atrium"])
+def test_scene_cache_renders_bit_identically(rt, orc, cornell, golden_dir, tmp_path, kind):
+    """a scene loaded from the binary cache (prebuilt BVH, shading records, LUTs, light CDF: no build at commit) renders the
+    same bits and traces the same rays as the scene committed from scratch — through the context-level pair rtx_save_scene_cache /
+    rtx_load_scene_cache and through the host-level rtxh_scene_save / rtxh_scene_load; the loaded scene can still be edited (a
+    transform-only commit refits on the GPU from object-space triangles re-derived at that point, a material edit re-derives the table)."""
+    sc = {"cornell": lambda: cornell, "atrium": lambda: rt.Scene.sponza_class(60000, 260),
+          "garage": lambda: rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")}[kind]()
+    W, H = 128, 72
+    p = rt.Params(width=W, height=H, spp=2, max_bounces=5, nee_samples=1, flags=0, frame_seed=3)
+    a = rt.Context(0); a.upload(sc, W / H); a.clear(W, H); a.render(p); ref = a.read_accum(); sa = a.stats()
+    a.save_scene_cache(tmp_path / "ctx.rtxscn")
+    sc.save(tmp_path / "host.rtxscn")
+    for how in ("ctx", "host"):
+        b = rt.Context(0)
+        if how == "ctx":
+            b.load_scene_cache(tmp_path / "ctx.rtxscn"); b.set_camera(*sc.view_proj(W / H))
+        else:
+            b.upload(rt.Scene.load(tmp_path / "host.rtxscn"), W / H)
+        b.clear(W, H); b.render(p); sb = b.stats()
+        assert np.array_equal(bits(b.read_accum()), bits(ref)), (kind, how)
+        assert (sb.rays_primary, sb.rays_extension, sb.rays_shadow, sb.triangles, sb.bvh_nodes, sb.lights, sb.materials) == \
+               (sa.rays_primary, sa.rays_extension, sa.rays_shadow, sa.triangles, sa.bvh_nodes, sa.lights, sa.materials)
+        assert np.array_equal(bits(b.lights()), bits(a.lights()))
+        if kind != "cornell":
+            assert b.validate_bvh() == 0
+        # the loaded scene stays editable: move an instance in both contexts, commit, compare again
+        M = np.eye(4, dtype=np.float32); M[3, 0] = 0.05; M[0, 0] = 1.1
+        for c in (a, b):
+            c.set_instance_transform(0, M.reshape(16)); c.commit(); c.clear(W, H); c.render(p)
+        assert np.array_equal(bits(a.read_accum()), bits(b.read_accum())), (kind, how, "after a transform edit")
+        I = np.eye(4, dtype=np.float32).reshape(16)
+        a.set_instance_transform(0, I); a.commit()
+        b.close()
+    bad = tmp_path / "bad.rtxscn"; blob = bytearray(open(tmp_path / "ctx.rtxscn", "rb").read()); blob[len(blob) // 3] ^= 1; bad.write_bytes(bytes(blob))
+    a.clear(W, H); a.render(p); again = a.read_accum()
+    with pytest.raises(rt.RtxError):
+        a.load_scene_cache(bad)                                 # refused ...
+    a.clear(W, H); a.render(p)
+    assert np.array_equal(bits(a.read_accum()), bits(again))   # ... and the resident scene is untouched
+    a.close()
+
+
+def test_scene_cache_loads_a_bistro_class_scene_faster_than_it_builds(rt, tmp_path):
+    """3.8 M triangles: commit from the cache (read + checksum + upload) against the commit that builds the BVH, and the same image"""
+    import time
+    sc = rt.Scene.bistro_class()
+    W, H = 160, 90
+    p = rt.Params(width=W, height=H, spp=1, max_bounces=4, nee_samples=1, flags=0)
+    a = rt.Context(0)
+    t0 = time.perf_counter(); a.upload(sc, W / H); t_build = time.perf_counter() - t0
+    a.clear(W, H); a.render(p); ref = a.read_accum()
+    path = tmp_path / "bistro.rtxscn"
+    t0 = time.perf_counter(); a.save_scene_cache(path); t_save = time.perf_counter() - t0
+    a.close()
+    b = rt.Context(0)
+    t0 = time.perf_counter(); b.load_scene_cache(path); t_load = time.perf_counter() - t0
+    b.set_camera(*sc.view_proj(W / H)); b.clear(W, H); b.render(p)
+    print(f"bistro-class {sc.num_triangles} triangles: upload + commit with build {t_build:.2f} s, cache save {t_save:.2f} s ({os.path.getsize(path) / 1e6:.0f} MB), cache load + upload {t_load:.2f} s")
+    assert np.array_equal(bits(b.read_accum()), bits(ref))
+    assert t_load < 0.5 * t_build
+    b.close()
+
+
 def test_tile_size_contract_is_one_rule(rt, cornell):
     """tile_size: a power of two in [16, 1024] (0 = 64) — the same verdict from rtx_shard_slab_bytes, rtx_render, rtx_pack_tiles and the
     host-side layout; slab sizes are computed in 64 bits"""

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_valu(float* out, unsigned long long* cy
     __syncthreads(); \
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime(); \
     for (int it = 0; it < iters; it++) { \
-        _Pragma("unroll") for (int k = 0; k < 4; k++) _Pragma("unroll") for (int i = 0; i < 16; i++) asm volatile(ASM : "+v"(a[i]) : "v"(b), "v"(c), "v"(u) : "vcc"); } \
+        _Pragma("unroll") for (int k = 0; k < 4; k++) _Pragma("unroll") for (int i = 0; i < 16; i++) asm volatile(ASM : "+v"(a[i]) : "v"(b), "v"(c), "v"(u) : "vcc", "s20", "s21", "s22", "s23"); } \
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime(); \
     float s = 0.0f; for (int i = 0; i < 16; i++) s += a[i]; out[blockIdx.x * 256 + threadIdx.x] = s; \
     if ((threadIdx.x & 63) == 0) { cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0; rt[blockIdx.x * 4 + (threadIdx.x >> 6)] = r1 - r0; } }
@@ -105,6 +105,29 @@ OPK(18, "v_and_b32 %0, %0, %3")
 OPK(19, "v_lshrrev_b32 %0, 5, %0")
 OPK(20, "v_cvt_f32_u32 %0, %0")
 OPK(21, "v_mad_u32_u24 %0, %0, %3, %3")
+OPK(24, "v_mul_f32_e64 %0, %0, %1")
+OPK(25, "v_add_f32_e64 %0, %0, %2")
+OPK(26, "v_fmac_f32 %0, %1, %2")
+OPK(27, "v_fma_f32 %0, %0, %1, 0")
+OPK(28, "v_fma_f32 %0, %0, 1.0, %2")
+OPK(29, "v_cndmask_b32_e64 %0, %0, %1, s[20:21]")
+OPK(30, "v_max_f32 %0, %0, %1")
+OPK(31, "v_med3_f32 %0, %0, %1, %2")
+OPK(32, "v_perm_b32 %0, %0, %3, %3")
+OPK(33, "v_pk_fma_f16 %0, %0, %1, %2")
+OPK(34, "v_pk_max_f16 %0, %0, %1")
+OPK(35, "v_pk_add_f16 %0, %0, %1")
+OPK(36, "v_cvt_pkrtz_f16_f32 %0, %0, %1")
+OPK(37, "v_bfe_u32 %0, %0, 3, 8")
+OPK(38, "v_sub_f32 %0, %0, %1")
+OPK(39, "v_and_or_b32 %0, %0, %3, %3")
+OPK(40, "v_or_b32 %0, %0, %3")
+OPK(41, "v_cvt_f32_ubyte1 %0, %3")
+OPK(42, "v_cmp_le_f32_e64 s[22:23], %0, %1")
+OPK(43, "v_lshlrev_b32 %0, 3, %0")
+OPK(44, "v_mul_legacy_f32 %0, %0, %1")
+OPK(45, "v_ldexp_f32 %0, %0, %3")
+OPK(46, "v_dot2c_f32_f16 %0, %1, %2")
 
 template <int ID>
 static int run_op(const char* name, int ncu, float* d_out, unsigned long long* d_cyc, unsigned long long* d_rt) {
@@ -177,5 +200,9 @@ int main() {
     RUNOP(5, "v_cmp_le_f32 vcc") RUNOP(6, "v_cndmask_b32") RUNOP(7, "v_sqrt_f32") RUNOP(8, "v_rsq_f32") RUNOP(9, "v_mul_lo_u32") RUNOP(10, "v_lshl_add_u32")
     RUNOP(11, "v_xor_b32") RUNOP(22, "v_add3_u32") RUNOP(23, "v_xad_u32") RUNOP(12, "v_add_u32") RUNOP(13, "v_div_scale_f32") RUNOP(14, "v_div_fmas_f32") RUNOP(15, "v_div_fixup_f32") RUNOP(17, "v_mov_b32")
     RUNOP(18, "v_and_b32") RUNOP(19, "v_lshrrev_b32") RUNOP(20, "v_cvt_f32_u32") RUNOP(21, "v_mad_u32_u24")
+    RUNOP(24, "v_mul_f32_e64") RUNOP(25, "v_add_f32_e64") RUNOP(26, "v_fmac_f32") RUNOP(27, "v_fma_f32 a,b,0") RUNOP(28, "v_fma_f32 a,1.0,c") RUNOP(29, "v_cndmask_b32_e64 sgpr-cond")
+    RUNOP(30, "v_max_f32") RUNOP(31, "v_med3_f32") RUNOP(32, "v_perm_b32") RUNOP(33, "v_pk_fma_f16") RUNOP(34, "v_pk_max_f16") RUNOP(35, "v_pk_add_f16") RUNOP(36, "v_cvt_pkrtz_f16_f32")
+    RUNOP(37, "v_bfe_u32") RUNOP(38, "v_sub_f32") RUNOP(39, "v_and_or_b32") RUNOP(40, "v_or_b32") RUNOP(41, "v_cvt_f32_ubyte1") RUNOP(42, "v_cmp_le_f32_e64 sgpr") RUNOP(43, "v_lshlrev_b32")
+    RUNOP(44, "v_mul_legacy_f32") RUNOP(45, "v_ldexp_f32") RUNOP(46, "v_dot2c_f32_f16")
     return 0;
 }
