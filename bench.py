@@ -50,7 +50,7 @@ WORKLOADS = {
     "cornell_1080p_1spp_4b": ("cornell", 1920, 1080, 1, 4, 1, 1),
     "sponza_1080p_16spp_8b": ("sponza", 1920, 1080, 16, 8, 1, 1),
     "sponza_4k_64spp_8b": ("sponza", 3840, 2160, 64, 8, 1, 1),
-    "bistro_1080p_16spp_8b": ("bistro", 1920, 1080, 16, 8, 1, 0),
+    "bistro_1080p_16spp_8b": ("bistro", 1920, 1080, 16, 8, 1, 4),     # flags 4 = RTX_FLAG_TRANSMISSION: GGX microfacet + dielectric panes (strategy 3) + NEE
 }
 EXTRA_WORKLOADS = ("sponza_1080p_16spp_8b", "bistro_1080p_16spp_8b")    # the general BVH path, timed beside the headline (GPU only)
 

@@ -56,6 +56,9 @@ typedef struct rtx_params {
 
 #define RTX_FLAG_LAMBERT_ONLY 1u  /* strategy 0 only, p_d = 1 (BRDF_v6.hlsl:7-70 bypassed) */
 #define RTX_FLAG_JITTER       2u  /* legacy sub-pixel jitter (RayGen.hlsl:84-87); v6 shoots pixel corners (pass1:80-82) */
+#define RTX_FLAG_TRANSMISSION 4u  /* EXTENSION: strategy 3 (rough dielectric transmission) for materials with dissolve Kd.w < 1 and Ni != 1; the reference
+                                     has the strategy as a stub only (BRDF_v6.hlsl:5,28-29,44-47,85-87).  rtx_render only; ignored with LAMBERT_ONLY
+                                     and by the literal pass-1 / ReSTIR modes.  Off: every result is the reference-faithful one */
 
 /* kernel classes for rtx_stats */
 enum { RTX_K_RAYGEN = 0, RTX_K_TRACE = 1, RTX_K_SHADE = 2, RTX_K_SHADOW = 3, RTX_K_ACCUM = 4, RTX_K_SORT = 5,

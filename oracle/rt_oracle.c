@@ -215,6 +215,7 @@ static inline v3 xform_dir(const float* m, v3 p) {
 typedef struct {            /* fp16-rounded working copy: MaterialOptimized, Common_v6.hlsl:62-74 */
     v3 Kd; float alpha;
     float Pr, Pm, Ps, Pc;
+    float Ni;               /* full-precision Material.Ni (strategy-3 EXTENSION only; MaterialOptimized has no such member) */
     v3 Ks; v3 Ke;
     float Ke_len;           /* length(Ke) of the rounded copy */
 } matopt_t;
@@ -259,7 +260,7 @@ int orc_set_materials(orc_ctx* c, const void* mats128, uint32_t count) {
     for (uint32_t i = 0; i < count; i++) {
         const float* m = c->mats + i * 32;  /* Kd[4] Ks[3] Ni Ke[3] pad Pr_Pm_Ps_Pc[4] LUT[16]: Vertex.h:14-23 */
         matopt_t* o = &c->mopt[i];
-        o->Kd = V3(orc_half_round(m[0]), orc_half_round(m[1]), orc_half_round(m[2])); o->alpha = orc_half_round(m[3]);
+        o->Kd = V3(orc_half_round(m[0]), orc_half_round(m[1]), orc_half_round(m[2])); o->alpha = orc_half_round(m[3]); o->Ni = m[7];
         o->Ks = V3(orc_half_round(m[4]), orc_half_round(m[5]), orc_half_round(m[6]));
         o->Ke = V3(orc_half_round(m[8]), orc_half_round(m[9]), orc_half_round(m[10]));
         o->Pr = orc_half_round(m[12]); o->Pm = orc_half_round(m[13]); o->Ps = orc_half_round(m[14]); o->Pc = orc_half_round(m[15]);
@@ -679,36 +680,85 @@ static float ggx_pdf(const matopt_t* m, v3 normal, v3 Lin, v3 Vin) {
     float alpha = m->Pr * m->Pr;
     return g1_smith(NdotV, alpha) * d_ggx(NdotH, m->Pr) / (NdotV * 4.0f);
 }
-/* BRDF_v6.hlsl:50-70 -> (p_d, p_s) */
-static inline void strategy_probs(const matopt_t* m, v3 outgoing, v3 normal, uint32_t flags, float* pd, float* ps) {
+/* ---- EXTENSION: strategy 3, rough dielectric transmission (ORC_FLAG_TRANSMISSION).  The reference has it as a stub only ("3 - Refraction",
+   `//p_d *= alpha;`, `// Refraction, currently replaced by diffuse (later 3)`, `//SampleBTDF_GGX` ...: BRDF_v6.hlsl:5,28-29,44-47,85-87,102-104,
+   120-122); there is nothing to restate, so this part of the oracle is UNPINNED BY DEFINITION and pinned by its own properties
+   (tests/test_dielectric.py).  Same operation order as royaltracer-dx_amd/csrc/rtx_bsdf.hpp, which documents the model. */
+static inline float transmission_eta(const matopt_t* m, uint32_t flags, v3 outgoing, v3* normal) {
+    if (!(flags & ORC_FLAG_TRANSMISSION) || (flags & ORC_FLAG_LAMBERT_ONLY) || !(m->alpha < 1.0f) || fabsf(m->Ni - 1.0f) < 0.01f) return 0.0f;
+    if (dot3(*normal, outgoing) < 0.0f) *normal = neg3(*normal);     /* thin-pane model: every crossing is air -> Ni, from either side (rtx_bsdf.hpp) */
+    return m->Ni;
+}
+static v3 btdf_eval(const matopt_t* m, v3 normal, v3 Lin, v3 Vin, float eta_p, float* pdf) {
+    *pdf = 0.0f;
+    const v3 zero = V3(0, 0, 0);
+    v3 N = normalize3(normal), V = normalize3(Vin), L = normalize3(Lin);
+    float NdotV = dot3(N, V), NdotL = dot3(N, L);
+    if (!(NdotV > 0.0f) || !(NdotL < 0.0f)) return zero;
+    v3 H = normalize3(madd3(L, eta_p, V));
+    if (dot3(N, H) < 0.0f) H = neg3(H);
+    float VdotH = dot3(V, H), LdotH = dot3(L, H);
+    if (!(VdotH > 0.0f) || !(LdotH < 0.0f)) return zero;
+    float sq = VdotH + eta_p * LdotH;
+    float den = sq * sq;
+    if (den < EPSILON_) return zero;
+    float alpha = m->Pr * m->Pr;
+    float D = d_ggx(dot3(N, H), m->Pr);
+    float G = g2_smith(NdotV, -NdotL, alpha);
+    float e2 = eta_p * eta_p;
+    float c = D * G * e2 * (-LdotH) * VdotH / (NdotV * (-NdotL) * den);
+    v3 Fr = schlick(m->Ks, VdotH);
+    float q = g1_smith(NdotV, alpha) * VdotH * D / NdotV * (e2 * (-LdotH) / den);
+    v3 f = V3((1.0f - Fr.x) * c, (1.0f - Fr.y) * c, (1.0f - Fr.z) * c);
+    if (!finite3(f) || is_nan(q) || is_inf(q)) return zero;
+    *pdf = q;
+    return f;
+}
+/* BRDF_v6.hlsl:50-70 -> (p_d, p_s); pt: the transmitted share of the diffuse part (extension; 0 when eta_p = 0) */
+static inline void strategy_probs3(const matopt_t* m, v3 outgoing, v3 normal, uint32_t flags, float* pd, float* ps, float eta_p, float* pt) {
+    *pt = 0.0f;
     if (flags & ORC_FLAG_LAMBERT_ONLY) { *pd = 1.0f; *ps = 0.0f; return; }
     v3 fr = schlick(m->Ks, dot3(normal, outgoing));
     float p_s = minf(1.0f, (fr.x + fr.y + fr.z) / 3.0f + m->Pm);
     *ps = p_s; *pd = 1.0f - p_s;
+    if (eta_p != 0.0f) { *pt = *pd * (1.0f - m->alpha); *pd = *pd * m->alpha; }      /* BRDF_v6.hlsl:28-29 `p_d *= alpha` */
 }
+static inline void strategy_probs(const matopt_t* m, v3 outgoing, v3 normal, uint32_t flags, float* pd, float* ps) { float pt; strategy_probs3(m, outgoing, normal, flags, pd, ps, 0.0f, &pt); }
 /* BRDF_v6.hlsl:7-48; LAMBERT_ONLY consumes no random number */
-static inline uint32_t select_strategy(const matopt_t* m, v3 outgoing, v3 normal, uint32_t flags, uint32_t seed[2]) {
+static inline uint32_t select_strategy3(const matopt_t* m, v3 outgoing, v3 normal, uint32_t flags, uint32_t seed[2], float eta_p) {
     if (flags & ORC_FLAG_LAMBERT_ONLY) return 0;
     float r = rnd(seed);
     v3 fr = schlick(m->Ks, dot3(normal, outgoing));
     float p_s = minf(1.0f, (fr.x + fr.y + fr.z) / 3.0f + m->Pm);
     if (r <= p_s) return m->Pr < 0.04f ? 0u : 1u;
+    if (eta_p != 0.0f) {                                                         /* :41-47 with `p_d *= alpha` un-commented */
+        float p_d = (1.0f - p_s) * m->alpha;
+        return r <= p_s + p_d ? 0u : 3u;
+    }
     return 0;
 }
-/* mixture F = p_d f_lambert + p_s f_ggx and P likewise: Sampler_v6.hlsl:443-457, Path_Sampler_v6.hlsl:66-80 */
-static inline void bsdf_mixture(const orc_ctx* c, uint32_t mid, uint32_t flags, v3 normal, v3 L, v3 outgoing, v3* F, float* P, float* pd_o, float* ps_o) {
+static inline uint32_t select_strategy(const matopt_t* m, v3 outgoing, v3 normal, uint32_t flags, uint32_t seed[2]) { return select_strategy3(m, outgoing, normal, flags, seed, 0.0f); }
+/* mixture F = p_d f_lambert + p_s f_ggx and P likewise: Sampler_v6.hlsl:443-457, Path_Sampler_v6.hlsl:66-80; with eta_p != 0 a direction on the far
+   side of the interface gets p_t f_t, p_t pdf_t alone */
+static inline void bsdf_mixture3(const orc_ctx* c, uint32_t mid, uint32_t flags, v3 normal, v3 L, v3 outgoing, v3* F, float* P, float* pd_o, float* ps_o, float eta_p) {
     const matopt_t* m = &c->mopt[mid];
-    float pd, ps; strategy_probs(m, outgoing, normal, flags, &pd, &ps);
+    float pd, ps, pt; strategy_probs3(m, outgoing, normal, flags, &pd, &ps, eta_p, &pt);
     v3 f0 = lambert_eval(m); float q0 = lambert_pdf(normal, L);
-    if (flags & ORC_FLAG_LAMBERT_ONLY) { *F = safe_mul3(pd, f0); *P = safe_mul1(pd, q0); }
-    else {
-        v3 f1 = ggx_eval(m, c->mats + (size_t)mid * 32, normal, L, outgoing);
-        float q1 = ggx_pdf(m, normal, L, outgoing);
-        *F = add3(safe_mul3(pd, f0), safe_mul3(ps, f1));
-        *P = safe_mul1(pd, q0) + safe_mul1(ps, q1);
-    }
     if (pd_o) *pd_o = pd;
     if (ps_o) *ps_o = ps;
+    if (flags & ORC_FLAG_LAMBERT_ONLY) { *F = safe_mul3(pd, f0); *P = safe_mul1(pd, q0); return; }
+    if (eta_p != 0.0f && dot3(normal, L) < 0.0f) {
+        float q3; v3 f3 = btdf_eval(m, normal, L, outgoing, eta_p, &q3);
+        *F = safe_mul3(pt, f3); *P = safe_mul1(pt, q3);
+        return;
+    }
+    v3 f1 = ggx_eval(m, c->mats + (size_t)mid * 32, normal, L, outgoing);
+    float q1 = ggx_pdf(m, normal, L, outgoing);
+    *F = add3(safe_mul3(pd, f0), safe_mul3(ps, f1));
+    *P = safe_mul1(pd, q0) + safe_mul1(ps, q1);
+}
+static inline void bsdf_mixture(const orc_ctx* c, uint32_t mid, uint32_t flags, v3 normal, v3 L, v3 outgoing, v3* F, float* P, float* pd_o, float* ps_o) {
+    bsdf_mixture3(c, mid, flags, normal, L, outgoing, F, P, pd_o, ps_o, 0.0f);
 }
 /* Lambertian_v6.hlsl:2-38 */
 static v3 sample_lambert(v3 normal, uint32_t seed[2]) {
@@ -733,10 +783,11 @@ static inline void coord_system(v3 N, v3* T, v3* B) {
     else *T = normalize3(cross3(V3(1, 0, 0), N));
     *B = cross3(N, *T);
 }
-/* GGX_v6.hlsl:93-169 */
-static v3 sample_ggx(const matopt_t* m, v3 outgoing, v3 normal, uint32_t seed[2]) {
+/* GGX_v6.hlsl:93-169: the visible half vector H (:104-157) ... */
+static v3 sample_ggx_h(const matopt_t* m, v3 outgoing, v3 normal, uint32_t seed[2], v3* Vout) {
     float alpha = m->Pr * m->Pr;
     v3 N = normalize3(normal), V = normalize3(outgoing), T1, T2;
+    *Vout = V;
     coord_system(N, &T1, &T2);
     float vx = dot3(T1, V), vy = dot3(T2, V), vz = dot3(N, V);
     v3 Ve = normalize3(V3(alpha * vx, alpha * vy, vz));
@@ -755,24 +806,42 @@ static v3 sample_ggx(const matopt_t* m, v3 outgoing, v3 normal, uint32_t seed[2]
     float w = sqrtf(saturatef(1.0f - t1 * t1 - t2 * t2));
     v3 Nh = V3(t1 * T1h.x + t2 * T2h.x + w * Ve.x, t1 * T1h.y + t2 * T2h.y + w * Ve.y, t1 * T1h.z + t2 * T2h.z + w * Ve.z);
     v3 Ne = normalize3(V3(alpha * Nh.x, alpha * Nh.y, maxf(0.0f, Nh.z)));
-    v3 H = V3(Ne.x * T1.x + Ne.y * T2.x + Ne.z * N.x, Ne.x * T1.y + Ne.y * T2.y + Ne.z * N.y, Ne.x * T1.z + Ne.y * T2.z + Ne.z * N.z);
+    return V3(Ne.x * T1.x + Ne.y * T2.x + Ne.z * N.x, Ne.x * T1.y + Ne.y * T2.y + Ne.z * N.y, Ne.x * T1.z + Ne.y * T2.z + Ne.z * N.z);
+}
+/* ... and the direction reflected about it (:159-165) */
+static v3 sample_ggx(const matopt_t* m, v3 outgoing, v3 normal, uint32_t seed[2]) {
+    v3 V; v3 H = sample_ggx_h(m, outgoing, normal, seed, &V);
     v3 I = neg3(V);                                   /* reflect(-V, H) = I - 2 dot(H,I) H */
     float k = 2.0f * dot3(H, I);
     v3 smp = V3(I.x - k * H.x, I.y - k * H.y, I.z - k * H.z);
     if (dot3(smp, normal) < 0.0f) smp = neg3(smp);    /* :164-165 flipped, not rejected */
     return smp;
 }
-static inline v3 sample_bsdf(const orc_ctx* c, uint32_t mid, uint32_t strategy, v3 outgoing, v3 normal, uint32_t seed[2]) {
+/* EXTENSION, strategy 3: refract about the same visible half vector; total internal reflection ends the path (zero vector) */
+static v3 sample_btdf(const matopt_t* m, v3 outgoing, v3 normal, float eta_p, uint32_t seed[2]) {
+    v3 V; v3 H = sample_ggx_h(m, outgoing, normal, seed, &V);
+    float eta = 1.0f / eta_p;
+    float c = dot3(V, H);
+    float s2 = eta * eta * (1.0f - c * c);
+    if (!(s2 < 1.0f)) return V3(0, 0, 0);
+    float k = eta * c - sqrtf(1.0f - s2);
+    return normalize3(V3(k * H.x - eta * V.x, k * H.y - eta * V.y, k * H.z - eta * V.z));
+}
+static inline v3 sample_bsdf3(const orc_ctx* c, uint32_t mid, uint32_t strategy, v3 outgoing, v3 normal, uint32_t seed[2], float eta_p) {
+    if (strategy == 3) return sample_btdf(&c->mopt[mid], outgoing, normal, eta_p, seed);
     return strategy == 1 ? sample_ggx(&c->mopt[mid], outgoing, normal, seed) : sample_lambert(normal, seed);   /* BRDF_v6.hlsl:74-88 */
 }
+static inline v3 sample_bsdf(const orc_ctx* c, uint32_t mid, uint32_t strategy, v3 outgoing, v3 normal, uint32_t seed[2]) { return sample_bsdf3(c, mid, strategy, outgoing, normal, seed, 0.0f); }
 
 int orc_bsdf_eval(orc_ctx* c, uint32_t mid, uint32_t flags, const float* in9, uint32_t n, float* out8) {
     if (mid >= c->nmat) return -1;
     for (uint32_t i = 0; i < n; i++) {
         const float* q = in9 + (size_t)i * 9; float* o = out8 + (size_t)i * 8;
         v3 F; float P, pd, ps;
-        bsdf_mixture(c, mid, flags, V3(q[0], q[1], q[2]), V3(q[6], q[7], q[8]), V3(q[3], q[4], q[5]), &F, &P, &pd, &ps);
-        o[0] = F.x; o[1] = F.y; o[2] = F.z; o[3] = P; o[4] = pd; o[5] = ps; o[6] = o[7] = 0.0f;
+        v3 nrm = V3(q[0], q[1], q[2]), wo = V3(q[3], q[4], q[5]);
+        float eta_p = transmission_eta(&c->mopt[mid], flags, wo, &nrm);
+        bsdf_mixture3(c, mid, flags, nrm, V3(q[6], q[7], q[8]), wo, &F, &P, &pd, &ps, eta_p);
+        o[0] = F.x; o[1] = F.y; o[2] = F.z; o[3] = P; o[4] = pd; o[5] = ps; o[6] = eta_p; o[7] = 0.0f;
     }
     return 0;
 }
@@ -782,8 +851,9 @@ int orc_bsdf_sample(orc_ctx* c, uint32_t mid, uint32_t flags, const float* in8, 
         const float* q = in8 + (size_t)i * 8; float* o = out8 + (size_t)i * 8;
         uint32_t seed[2]; memcpy(seed, &q[6], 8);
         v3 nrm = V3(q[0], q[1], q[2]), wo = V3(q[3], q[4], q[5]);
-        uint32_t st = select_strategy(&c->mopt[mid], wo, nrm, flags, seed);
-        v3 wi = sample_bsdf(c, mid, st, wo, nrm, seed);
+        float eta_p = transmission_eta(&c->mopt[mid], flags, wo, &nrm);
+        uint32_t st = select_strategy3(&c->mopt[mid], wo, nrm, flags, seed, eta_p);
+        v3 wi = sample_bsdf3(c, mid, st, wo, nrm, seed, eta_p);
         o[0] = wi.x; o[1] = wi.y; o[2] = wi.z; memcpy(&o[3], &st, 4); memcpy(&o[4], seed, 8); o[6] = o[7] = 0.0f;
     }
     return 0;
@@ -845,6 +915,7 @@ static v3 trace_path(const orc_ctx* c, const orc_params* p, uint32_t x, uint32_t
                     float cos_t = fabsf(dot3(sf.normal, neg3(dir)));           /* DEVIATION: abs (two-sided lights, as NEE does) */
                     float pdf_light = (((m->Ke.x + m->Ke.y + m->Ke.z) / 3.0f) / c->total_weight) * dist2 / maxf(cos_t, EPSILON_);
                     mi = prev_pdf / ((float)nee * pdf_light + prev_pdf);
+                    if (prev_pdf < 0.0f) mi = 1.0f;                            /* (extension) the ray came through a transmission lobe: NEE never samples through an interface */
                 }
                 v3 e = V3(m->Ke.x * thr.x * mi, m->Ke.y * thr.y * mi, m->Ke.z * thr.z * mi);   /* Hit.hlsl:173 */
                 if (finite3(e)) rad = add3(rad, e);
@@ -853,6 +924,7 @@ static v3 trace_path(const orc_ctx* c, const orc_params* p, uint32_t x, uint32_t
         }
         v3 outgoing = neg3(dir);
         v3 normal = sf.normal;
+        const float eta_p = transmission_eta(m, flags, outgoing, &normal);    /* (extension) hits from behind a dielectric flip the shading normal */
         /* ---- NEE: SampleLightNEE_GI, Sampler_v6.hlsl:508-647, with its visibility ray enabled ---- */
         for (uint32_t j = 0; j < nee; j++) {
             float rv = rnd(seed);
@@ -882,7 +954,7 @@ static v3 trace_path(const orc_ctx* c, const orc_params* p, uint32_t x, uint32_t
             float cos_y = fabsf(dot3(nl, neg3(Ln)));
             if (cos_x < EPSILON_ || cos_y < EPSILON_) continue;                /* :580-585; no shadow ray is traced */
             float pdf_light = maxf(EPSILON_, pdf_l) * dist2 / cos_y;           /* :629-630 */
-            v3 F; float P; bsdf_mixture(c, sf.mat, flags, normal, Ln, outgoing, &F, &P, NULL, NULL);
+            v3 F; float P; bsdf_mixture3(c, sf.mat, flags, normal, Ln, outgoing, &F, &P, NULL, NULL, eta_p);
             float mi = pdf_light / ((float)nee * pdf_light + P);               /* Path_Sampler_v6.hlsl:164 */
             float g = cos_x / pdf_light * mi;
             v3 con = V3(lt[12] * (thr.x * F.x) * g, lt[13] * (thr.y * F.y) * g, lt[14] * (thr.z * F.z) * g);
@@ -895,15 +967,17 @@ static v3 trace_path(const orc_ctx* c, const orc_params* p, uint32_t x, uint32_t
         }
         if (b + 1 == p->max_bounces) break;
         /* ---- BSDF sampling: Path_Sampler_v6.hlsl:205-229, Sampler_v6.hlsl:423-457,482-497 ---- */
-        uint32_t st = select_strategy(m, outgoing, normal, flags, seed);
-        v3 smp = sample_bsdf(c, sf.mat, st, outgoing, normal, seed);
-        v3 F; float P; bsdf_mixture(c, sf.mat, flags, normal, smp, outgoing, &F, &P, NULL, NULL);
+        uint32_t st = select_strategy3(m, outgoing, normal, flags, seed, eta_p);
+        v3 smp = sample_bsdf3(c, sf.mat, st, outgoing, normal, seed, eta_p);
+        if (st == 3 && smp.x == 0.0f && smp.y == 0.0f && smp.z == 0.0f) break;    /* (extension) total internal reflection ends the path */
+        v3 F; float P; bsdf_mixture3(c, sf.mat, flags, normal, smp, outgoing, &F, &P, NULL, NULL, eta_p);
         float NdotL = dot3(normal, smp);                                       /* unclamped: Sampler_v6.hlsl:455 */
+        if (st == 3) NdotL = fabsf(NdotL);                                     /* (extension) the transmitted direction lies on the far side */
         if (!(P > 0.0f)) break;
         float wgt = NdotL / P;                                                 /* Hit.hlsl:366 */
         thr = V3(thr.x * (F.x * wgt), thr.y * (F.y * wgt), thr.z * (F.z * wgt));
         if (!finite3(thr) || (thr.x == 0.0f && thr.y == 0.0f && thr.z == 0.0f)) break;
-        prev_pdf = P;                                                          /* Hit.hlsl:369 */
+        prev_pdf = st == 3 ? -P : P;                                           /* Hit.hlsl:369; the sign carries "transmitted" to the next emissive hit */
         if (b > p->rr_start) {                                                 /* RayGen.hlsl:118-130 */
             float mx = maxf(thr.x, maxf(thr.y, thr.z));
             float q = minf(maxf(mx, 0.05f), 1.0f);

@@ -47,6 +47,7 @@ typedef struct orc_params {
 
 #define ORC_FLAG_LAMBERT_ONLY 1u   /* force strategy 0, p_d = 1 */
 #define ORC_FLAG_JITTER       2u   /* legacy sub-pixel jitter (RayGen.hlsl:84-87) */
+#define ORC_FLAG_TRANSMISSION 4u   /* EXTENSION: strategy 3, rough dielectric transmission (the reference has a stub only: BRDF_v6.hlsl:44-47,85-87) */
 
 orc_ctx* orc_create(void);
 void     orc_destroy(orc_ctx*);

@@ -291,19 +291,21 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPa
                     }
                 }
             }
-            const f3 outgoing = -S.d, normal = sf.normal, pos = sf.pos;
+            const f3 outgoing = -S.d, pos = sf.pos;
             const MatGPU* mp = sc.mats + (shading ? sf.mat : 0u);
+            f3 normal = sf.normal;
+            const float eta_p = transmission_eta(*mp, f.flags, outgoing, normal);          // (extension) hits from behind a dielectric flip the shading normal
             for (uint32_t j = 0; j < nee; j++) {                                  // NEE: visibility deferred to k_trace_shadow
                 bool push = false;
                 F4 so = {0, 0, 0, 0}, sd = {0, 0, 0, 0}; f3 con = mk3(0, 0, 0);
-                if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con, sc.nsmall != 0u && sf.near_hull);
+                if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con, sc.nsmall != 0u && sf.near_hull, eta_p);
                 const size_t seg = (size_t)j * f.qcap * gridDim.x + qb;           // NEE slot j, this workgroup's sub-queue
                 const uint32_t slot = block_push(push, &s_cnt[1 + j]);
                 if (push) { p.sh_o[seg + slot] = so; p.sh_d[seg + slot] = sd; p.sh_c[seg + slot] = {con.x, con.y, con.z, u2f(S.pid)}; }
             }
             bool alive = false;
             f3 smp = mk3(0, 0, 1); float P = 0.0f;
-            if (shading && !last) alive = bsdf_continue(*mp, f, bounce, S, normal, outgoing, smp, P);
+            if (shading && !last) alive = bsdf_continue(*mp, f, bounce, S, normal, outgoing, smp, P, eta_p);
             if (alive) store_path(p, S, pos, smp, P);
             const uint32_t slot = block_push(alive, &s_cnt[0]);
             if (alive) mynext[slot] = S.pid;
@@ -380,15 +382,17 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
                 else shading = true;
             } else if (HAVE_HIT) p.rad[S.pid] = {0.0f, 0.0f, 0.0f, 0.0f};
         }
-        const f3 outgoing = -S.d, normal = sf.normal, pos = sf.pos;
+        const f3 outgoing = -S.d, pos = sf.pos;
         const MatGPU* mp = sc.mats + (shading ? sf.mat : 0u);
+        f3 normal = sf.normal;
+        const float eta_p = LAMBERT ? 0.0f : transmission_eta(*mp, f.flags, outgoing, normal);
         // bounce 0 (HAVE_HIT): nothing has written this path's radiance slot yet: it starts from zero here and is always stored
         bool loaded = HAVE_HIT && shading; F4 radv = {0, 0, 0, 0};
         PF_MARK(3);
         for (uint32_t j = 0; j < nee; j++) {
             bool push = false;
             F4 so = {0, 0, 0, 0}, sd = {0, 0, 1, 0}; f3 con = mk3(0, 0, 0);
-            if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con, sf.near_hull);
+            if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con, sf.near_hull, eta_p);
             PF_MARK(4);
             const uint32_t slot = block_push(push, &s_shn[par]);
             if (push) { s_sho[slot] = so; s_shd[slot] = sd; }
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
         if (loaded) p.rad[S.pid] = radv;
         bool alive = false;
         f3 smp = mk3(0, 0, 1); float P = 0.0f;
-        if (shading && !last) alive = bsdf_continue(*mp, f, bounce, S, normal, outgoing, smp, P);
+        if (shading && !last) alive = bsdf_continue(*mp, f, bounce, S, normal, outgoing, smp, P, eta_p);
         if (alive) store_path(p, S, pos, smp, P);
         const uint32_t slot = block_push(alive, &s_cnt[0]);
         if (alive) mynext[slot] = S.pid;
@@ -561,17 +565,20 @@ __global__ __launch_bounds__(kBlock) void k_dbg_bsdf_eval(DevScene sc, uint32_t 
     if (i >= n) return;
     const float* q = in9 + (size_t)i * 9; float* o = out8 + (size_t)i * 8;
     f3 F; float P, pd, ps;
-    bsdf_mixture(sc.mats[mat], flags, mk3(q[0], q[1], q[2]), mk3(q[6], q[7], q[8]), mk3(q[3], q[4], q[5]), F, P, pd, ps);
-    o[0] = F.x; o[1] = F.y; o[2] = F.z; o[3] = P; o[4] = pd; o[5] = ps; o[6] = 0.0f; o[7] = 0.0f;
+    f3 nrm = mk3(q[0], q[1], q[2]); const f3 wo = mk3(q[3], q[4], q[5]);
+    const float eta_p = transmission_eta(sc.mats[mat], flags, wo, nrm);
+    bsdf_mixture(sc.mats[mat], flags, nrm, mk3(q[6], q[7], q[8]), wo, F, P, pd, ps, eta_p);
+    o[0] = F.x; o[1] = F.y; o[2] = F.z; o[3] = P; o[4] = pd; o[5] = ps; o[6] = eta_p; o[7] = 0.0f;
 }
 __global__ __launch_bounds__(kBlock) void k_dbg_bsdf_sample(DevScene sc, uint32_t mat, uint32_t flags, const float* __restrict__ in8, uint32_t n, float* __restrict__ out8) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float* q = in8 + (size_t)i * 8; float* o = out8 + (size_t)i * 8;
     uint32_t s0 = f2u(q[6]), s1 = f2u(q[7]);
-    const f3 nrm = mk3(q[0], q[1], q[2]), wo = mk3(q[3], q[4], q[5]);
-    const uint32_t st = select_strategy(sc.mats[mat], wo, nrm, flags, s0, s1);
-    const f3 wi = sample_bsdf(sc.mats[mat], st, wo, nrm, s0, s1);
+    f3 nrm = mk3(q[0], q[1], q[2]); const f3 wo = mk3(q[3], q[4], q[5]);
+    const float eta_p = transmission_eta(sc.mats[mat], flags, wo, nrm);
+    const uint32_t st = select_strategy(sc.mats[mat], wo, nrm, flags, s0, s1, eta_p);
+    const f3 wi = sample_bsdf(sc.mats[mat], st, wo, nrm, s0, s1, eta_p);
     o[0] = wi.x; o[1] = wi.y; o[2] = wi.z; o[3] = u2f(st); o[4] = u2f(s0); o[5] = u2f(s1); o[6] = 0.0f; o[7] = 0.0f;
 }
 __global__ void k_dbg_tea(uint32_t s0, uint32_t s1, uint32_t n, float* __restrict__ out, uint32_t* __restrict__ seed_out) {

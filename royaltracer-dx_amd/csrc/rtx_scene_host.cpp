@@ -188,6 +188,7 @@ void SceneHost::build_materials(BuiltScene& B) {
         g.Ke_len = length(mk3(g.Ke[0], g.Ke[1], g.Ke[2]));
         for (int k = 0; k < 3; k++) g.KdPi[k] = g.Kd[k] / kPI;
         g.pad = 0.0f;
+        g.alpha = half_round(m[3]); g.Ni = m[7]; g.pad1 = g.pad2 = 0.0f;      // MaterialOptimized.Kd.w (fp16) and the full-precision Material.Ni (strategy-3 extension)
         memcpy(g.LUT, m + 16, 64);
     }
     mats_dirty = false;

@@ -292,7 +292,11 @@ Scene MakeBistroClass(uint32_t target, uint32_t seed) {
     for (int i = 1; i <= 39; i++) {
         const float r = 0.25f + 0.6f * hash01(i, 1, seed), g = 0.25f + 0.6f * hash01(i, 2, seed), b = 0.25f + 0.6f * hash01(i, 3, seed);
         if (i == 39) s.materials.push_back(make_mat(0, 0, 0, 0, 1, 0, 40.0f, 34.0f, 22.0f));                 // lamps
-        else if (i >= 28 && i <= 31) s.materials.push_back(make_mat(0.05f, 0.05f, 0.05f, 0.9f, 0.10f + 0.02f * (i - 28), 0.0f));   // panes: smooth GGX (dielectric BTDF is a stub in the reference, BRDF_v6.hlsl:44-47)
+        else if (i >= 28 && i <= 31) {     // panes: dielectric (F0 0.04, Ni 1.5, dissolve 0.1, smooth GGX interface): they TRANSMIT under RTX_FLAG_TRANSMISSION (strategy 3 is a
+            Material m = make_mat(0.05f, 0.05f, 0.05f, 0.04f, 0.10f + 0.02f * (i - 28), 0.0f);   // stub in the reference, BRDF_v6.hlsl:44-47; see csrc/rtx_bsdf.hpp) and are dark, slightly glossy plates without it
+            m.Kd.w = 0.1f; m.Ni = 1.5f;
+            s.materials.push_back(m);
+        }
         else if (i >= 20 && i <= 27) s.materials.push_back(make_mat(r, g, b, 0.6f + 0.3f * hash01(i, 4, seed), 0.1f + 0.5f * hash01(i, 5, seed), (float)(i & 1)));   // GGX, roughness U[0.1,0.6], metallic {0,1}
         else s.materials.push_back(make_mat(r, g, b, 0.04f, 1.0f, 0.0f));
     }

@@ -230,3 +230,42 @@ def directional_albedo_single_scatter(roughness, cosv, nt=1500, nphi=192):
     up = L[:, 2] > 0.0
     f = ggx_eval(m, N, L[up], V)[:, 0]
     return float((f * L[up, 2] * 4.0 * VH[ok][up] * w[ok][up]).sum())
+
+
+# ---- strategy 3 (EXTENSION; the reference has a stub only): rough dielectric transmission, Walter et al., "Microfacet Models for Refraction
+# through Rough Surfaces" (EGSR 2007), eqs. 16, 17, 21 — restated from the paper, with this renderer's conventions: GGX D and Smith G of
+# GGX_v6.hlsl, Schlick Fresnel with F0 = Ks, visible-normal sampling (pdf of h = G1(wo) |wo.h| D(h) / |wo.n|), no 1/eta^2 radiance scaling.
+#   n on wo's side, eta_p = n_t / n_i
+def btdf_eval(m, n, L, V, eta_p):
+    """-> (f rgb, pdf) for wo = V (incident side) and wi = L (far side)"""
+    N, V, L = normalize(n), normalize(V), normalize(L)
+    NdotV, NdotL = float(dot(N, V)), float(dot(N, L))
+    if not (NdotV > 0.0 and NdotL < 0.0):
+        return np.zeros(3), 0.0
+    ht = -(V + eta_p * L)                                  # eq. 16: h_t = -(eta_i i + eta_o o), here divided by eta_i
+    ht = ht / np.sqrt(float(dot(ht, ht)))
+    if float(dot(ht, N)) < 0.0:
+        ht = -ht
+    VH, LH = float(dot(V, ht)), float(dot(L, ht))
+    if not (VH > 0.0 and LH < 0.0):
+        return np.zeros(3), 0.0
+    den = (VH + eta_p * LH) ** 2                           # (eta_i (i.h) + eta_o (o.h))^2 / eta_i^2
+    alpha = m.Pr * m.Pr
+    D = d_ggx(float(dot(N, ht)), m.Pr)
+    G = g2_smith(NdotV, -NdotL, alpha)
+    F = schlick(m.Ks, VH)
+    # eq. 21: |i.h||o.h| / (|i.n||o.n|) * eta_o^2 (1 - F) G D / (eta_i (i.h) + eta_o (o.h))^2, with eta_o / eta_i = eta_p
+    f = (1.0 - F) * (abs(VH) * abs(LH) / (abs(NdotV) * abs(NdotL)) * eta_p ** 2 * G * D / den)
+    jac = eta_p ** 2 * abs(LH) / den                       # eq. 17: |dh / do|
+    pdf = g1_smith(NdotV, alpha) * abs(VH) * D / abs(NdotV) * jac
+    return f, pdf
+
+
+def refract(V, H, eta_p):
+    """Snell about the microfacet normal H (V.H > 0): the transmitted unit direction, or None on total internal reflection"""
+    eta = 1.0 / eta_p
+    c = float(dot(V, H))
+    s2 = eta * eta * (1.0 - c * c)
+    if s2 >= 1.0:
+        return None
+    return normalize((eta * c - np.sqrt(1.0 - s2)) * np.asarray(H) - eta * np.asarray(V))

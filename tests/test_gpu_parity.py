@@ -447,6 +447,7 @@ def test_wide_bvh_equals_brute_force_on_hostile_soups(rt, orc, kind):
 @pytest.mark.parametrize("kind,tris,cfg", [
     ("sponza", 262144, dict(width=160, height=90, spp=2, max_bounces=8, nee_samples=1, flags=1)),          # C3 settings, small image
     ("bistro", 300000, dict(width=128, height=72, spp=2, max_bounces=8, nee_samples=1, flags=0)),          # C5 materials (GGX + NEE), reduced triangle count
+    ("bistro", 300000, dict(width=128, height=72, spp=4, max_bounces=8, nee_samples=1, flags=4)),          # ... with the dielectric panes transmitting (strategy-3 extension)
 ])
 def test_large_scene_parity(rt, orc, kind, tris, cfg):
     """deep-BVH scenes through the general traversal path: hit records equal the oracle's, images within 1e-4"""
@@ -1034,7 +1035,7 @@ def _host_threads():
 
 @pytest.mark.parametrize("name,kind,W,H,spp,flags,shard", [
     ("C3", "sponza", 1920, 1080, 16, 1, (0, 1)),      # BASELINE.json configs[2]: Sponza-class 262 144 triangles, 1080p, 16 spp, 8 bounces
-    ("C5", "bistro", 1920, 1080, 16, 0, (0, 1)),      # configs[4]: Bistro-class 3.8 M triangles, 1080p, 16 spp, GGX microfacet + NEE (full strategy selection)
+    ("C5", "bistro", 1920, 1080, 16, 4, (0, 1)),      # configs[4]: Bistro-class 3.8 M triangles, 1080p, 16 spp, dielectric (strategy 3, RTX_FLAG_TRANSMISSION) + GGX microfacet + NEE
     ("C4-shard-5-of-8", "sponza", 3840, 2160, 64, 1, (5, 8)),   # configs[3]: Sponza-class, 4K, 64 spp, 8 bounces: the tiles ONE of the 8 ranks renders
 ])
 def test_full_size_baseline_configs_are_bit_identical(rt, orc, name, kind, W, H, spp, flags, shard):

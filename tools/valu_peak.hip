@@ -128,6 +128,14 @@ OPK(43, "v_lshlrev_b32 %0, 3, %0")
 OPK(44, "v_mul_legacy_f32 %0, %0, %1")
 OPK(45, "v_ldexp_f32 %0, %0, %3")
 OPK(46, "v_dot2c_f32_f16 %0, %1, %2")
+OPK(47, "v_add_u32_e64 %0, %0, %3")
+OPK(48, "v_xor_b32_e64 %0, %0, %3")
+OPK(49, "v_and_b32_e64 %0, %0, %3")
+OPK(50, "v_lshrrev_b32_e64 %0, 5, %0")
+OPK(51, "v_max_f32_e64 %0, %0, %1")
+OPK(52, "v_sub_f32_e64 %0, %0, %1")
+OPK(53, "v_mov_b32_e64 %0, %1")
+OPK(54, "v_or_b32_e64 %0, %0, %3")
 
 template <int ID>
 static int run_op(const char* name, int ncu, float* d_out, unsigned long long* d_cyc, unsigned long long* d_rt) {
@@ -204,5 +212,7 @@ int main() {
     RUNOP(30, "v_max_f32") RUNOP(31, "v_med3_f32") RUNOP(32, "v_perm_b32") RUNOP(33, "v_pk_fma_f16") RUNOP(34, "v_pk_max_f16") RUNOP(35, "v_pk_add_f16") RUNOP(36, "v_cvt_pkrtz_f16_f32")
     RUNOP(37, "v_bfe_u32") RUNOP(38, "v_sub_f32") RUNOP(39, "v_and_or_b32") RUNOP(40, "v_or_b32") RUNOP(41, "v_cvt_f32_ubyte1") RUNOP(42, "v_cmp_le_f32_e64 sgpr") RUNOP(43, "v_lshlrev_b32")
     RUNOP(44, "v_mul_legacy_f32") RUNOP(45, "v_ldexp_f32") RUNOP(46, "v_dot2c_f32_f16")
+    RUNOP(47, "v_add_u32_e64") RUNOP(48, "v_xor_b32_e64") RUNOP(49, "v_and_b32_e64") RUNOP(50, "v_lshrrev_b32_e64") RUNOP(51, "v_max_f32_e64") RUNOP(52, "v_sub_f32_e64") RUNOP(53, "v_mov_b32_e64")
+    RUNOP(54, "v_or_b32_e64")
     return 0;
 }
