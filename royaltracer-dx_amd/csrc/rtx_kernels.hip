@@ -24,13 +24,15 @@
 namespace rtx {
 
 #ifdef RTX_PROFILE_SECTIONS
-__device__ unsigned long long g_sec[12];
+__device__ unsigned long long g_sec[36];          // [0,12) cycles, [12,24) active lanes summed, [24,36) calls
 #define PF_BEGIN Prof pfv; pfv.begin(); Prof* pf = &pfv
 #define PF_MARK(i) pf->mark(i)
-#define PF_FLUSH do { if (lane_id() == 0) for (int i = 0; i < 12; i++) atomicAdd(&g_sec[i], pfv.acc[i]); } while (0)
+#define PF_COUNT(i) pf->count(i)
+#define PF_FLUSH do { if (lane_id() == 0) for (int i = 0; i < 12; i++) { atomicAdd(&g_sec[i], pfv.acc[i]); atomicAdd(&g_sec[12 + i], pfv.lanes[i]); atomicAdd(&g_sec[24 + i], pfv.calls[i]); } } while (0)
 #else
 #define PF_BEGIN Prof* pf = nullptr; (void)pf
 #define PF_MARK(i) do { } while (0)
+#define PF_COUNT(i) do { } while (0)
 #define PF_FLUSH do { } while (0)
 #endif
 
@@ -355,26 +357,66 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
     __syncthreads();
     const size_t qb = (size_t)qid * f.qcap;
     uint32_t par = 0;
+    // HIT RING (bounces >= 1).  20-25 % of the extension rays of a bounce leave the open front of the box or end on the light, and their lanes used to idle
+    // through surface reconstruction, NEE and BSDF sampling — over half of the kernel's instructions (46-47 of 64 lanes active per VALU instruction,
+    // profiles/r02_pmc_cornell.md).  Tracing and shading are therefore decoupled inside the workgroup: the trace phase takes 256 queue entries at a time
+    // and pushes only the HITS (path slot + hit record, 20 B) into an LDS ring (ballot + one LDS atomic per wave); whenever the ring holds a full 256 (or
+    // the input is exhausted) the shading phase runs on ring entries, i.e. on full waves.  A miss costs nothing beyond its trace.  The price: the path state
+    // is read twice (origin / direction for the trace, all 48 B for the shading), which a VALU-bound kernel at 2.4 of 8 TB/s does not notice.
+    // All four waves walk through the same phases (every decision is read from LDS after a barrier), so there is no producer / consumer protocol.
+    constexpr uint32_t kRing = 512u;                       // < 256 waiting + <= 256 pushed by one trace pass
+    __shared__ uint32_t s_rpid[HAVE_HIT ? 1 : kRing];
+    __shared__ F4 s_rhit[HAVE_HIT ? 1 : kRing];
+    __shared__ uint32_t s_ring[2];                         // consumed, produced (monotonic; index = count & (kRing - 1))
     PF_BEGIN;
     for (uint32_t bounce = bounce_first; bounce < bounce_end; bounce++) {
     const bool last = (bounce + 1u == f.max_bounces);
     const float tmin = bounce_tmin(bounce);
     const uint32_t* myq = ((bounce & 1u) ? queue_b : queue_a) + qb;
     uint32_t* mynext = ((bounce & 1u) ? queue_a : queue_b) + qb;
-    for (uint32_t base = 0; base < n; base += kBlock) {     // the same trip count for all four waves (barriers inside)
-        const uint32_t i = base + threadIdx.x;
-        const bool active = i < n;
+    if (!HAVE_HIT) { if (threadIdx.x < 2) s_ring[threadIdx.x] = 0; __syncthreads(); }
+    uint32_t next_in = 0;                                   // trace phase: next input entry (uniform)
+    for (uint32_t base = 0; HAVE_HIT ? base < n : true; base += kBlock) {     // HAVE_HIT: one trip per 256 queue entries; otherwise until input and ring are empty
         PathState S; S.pid = 0; S.o = mk3(0, 0, 0); S.d = mk3(0, 0, 1); S.thr = mk3(0, 0, 0); S.prev_pdf = 1.0f; S.s0 = S.s1 = 0;
-        if (active) S = load_path(p, myq[i]);
         float t = 0.0f, u = 0.0f, v = 0.0f; uint32_t prim = kMissPrim;
+        bool active;
         PF_MARK(0);
-        if (HAVE_HIT) {                                   // bounce 0: the primary hit comes from k_raygen_trace_small
-            if (active) { const F4 h = p.hit[S.pid]; t = h.x; u = h.y; v = h.z; prim = f2u(h.w); }
-        } else traverse_small<false>(sc, small, L, S.o, S.d, tmin, active ? kTMax : 0.0f, t, u, v, prim, sc.nsmall, ~0ull, pf, 1);   // inactive lanes: empty interval
+        if (HAVE_HIT) {                                   // bounce 0: the primary hit comes from k_raygen_trace_small; every queue entry is a hit
+            const uint32_t i = base + threadIdx.x;
+            active = i < n;
+            if (active) { S = load_path(p, myq[i]); const F4 h = p.hit[S.pid]; t = h.x; u = h.y; v = h.z; prim = f2u(h.w); }
+        } else {
+            // ---- trace phase: fill the ring until it holds a full workgroup of hits (or the input runs out) ----
+            while (next_in < n && s_ring[1] - s_ring[0] < kBlock) {           // uniform: both counters were published before the last barrier
+                const uint32_t i = next_in + threadIdx.x;
+                const bool act = i < n;
+                uint32_t pid = 0; f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
+                if (act) { pid = myq[i]; const F4 a = p.ray_o[pid], b = p.ray_d[pid]; ro = mk3(a.x, a.y, a.z); rd = mk3(b.x, b.y, b.z); }
+                float ht, hu, hv; uint32_t hp;
+                traverse_small<false>(sc, small, L, ro, rd, tmin, act ? kTMax : 0.0f, ht, hu, hv, hp, sc.nsmall, ~0ull, pf, 1);   // inactive lanes: empty interval
+                const bool hit = act && hp != kMissPrim;
+                const uint32_t slot = block_push(hit, &s_ring[1]);
+                if (hit) { s_rpid[slot & (kRing - 1u)] = pid; s_rhit[slot & (kRing - 1u)] = {ht, hu, hv, u2f(hp)}; }
+                next_in += kBlock;
+                __syncthreads();
+            }
+            const uint32_t head = s_ring[0], avail = s_ring[1] - head;
+            if (avail == 0u) break;                                             // input exhausted and ring drained: this bounce is done (uniform)
+            const uint32_t take = avail < (uint32_t)kBlock ? avail : (uint32_t)kBlock;
+            active = threadIdx.x < take;
+            if (active) {
+                const uint32_t e = (head + threadIdx.x) & (kRing - 1u);
+                S = load_path(p, s_rpid[e]);
+                const F4 h = s_rhit[e]; t = h.x; u = h.y; v = h.z; prim = f2u(h.w);
+            }
+            __syncthreads();                                                    // every lane has read its entry before the slots are released
+            if (threadIdx.x == 0) s_ring[0] = head + take;
+        }
         PF_MARK(2);
         Surf sf; sf.mat = 0; sf.normal = mk3(0, 0, 1); sf.pos = mk3(0, 0, 0);
         bool shading = false;
         if (active && prim != kMissPrim) {
+            PF_COUNT(3);
             sf = surface(sc, S.o, S.d, t, u, v, prim);
             if (sf.mat < sc.nmat) {
                 const MatGPU& m = sc.mats[sf.mat];
@@ -392,7 +434,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
         for (uint32_t j = 0; j < nee; j++) {
             bool push = false;
             F4 so = {0, 0, 0, 0}, sd = {0, 0, 1, 0}; f3 con = mk3(0, 0, 0);
-            if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con, sf.near_hull, eta_p);
+            if (shading) { PF_COUNT(4); push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con, sf.near_hull, eta_p); }
             PF_MARK(4);
             const uint32_t slot = block_push(push, &s_shn[par]);
             if (push) { s_sho[slot] = so; s_shd[slot] = sd; }
@@ -421,11 +463,12 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
         if (loaded) p.rad[S.pid] = radv;
         bool alive = false;
         f3 smp = mk3(0, 0, 1); float P = 0.0f;
-        if (shading && !last) alive = bsdf_continue(*mp, f, bounce, S, normal, outgoing, smp, P, eta_p);
-        if (alive) store_path(p, S, pos, smp, P);
+        if (shading && !last) { PF_COUNT(9); alive = bsdf_continue(*mp, f, bounce, S, normal, outgoing, smp, P, eta_p); }
+        if (alive) { PF_COUNT(10); store_path(p, S, pos, smp, P); }
         const uint32_t slot = block_push(alive, &s_cnt[0]);
         if (alive) mynext[slot] = S.pid;
         PF_MARK(9);
+        if (!HAVE_HIT) __syncthreads();                     // the released ring slots (s_ring[0]) are visible to the next trip's trace phase
     }
     // end of this bounce of the sub-queue: publish its counters; what it wrote (path state, next queue) becomes visible to the workgroup
     __syncthreads();
@@ -812,10 +855,10 @@ void launch_dbg_primary(hipStream_t st, const DevFrame& f, const CameraGPU* cam,
 
 #ifdef RTX_PROFILE_SECTIONS
 // tooling entry point of the PROFILE=1 build only (tools/section_profile.py): read (and optionally clear) the section counters
-extern "C" int rtx_debug_sections(unsigned long long* out12, int reset) {
+extern "C" int rtx_debug_sections(unsigned long long* out36, int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (out12 && hipMemcpyFromSymbol(out12, HIP_SYMBOL(rtx::g_sec), sizeof(unsigned long long) * 12) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[12] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rtx::g_sec), z, sizeof(z)) != hipSuccess) return -1; }
+    if (out36 && hipMemcpyFromSymbol(out36, HIP_SYMBOL(rtx::g_sec), sizeof(unsigned long long) * 36) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[36] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rtx::g_sec), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #endif

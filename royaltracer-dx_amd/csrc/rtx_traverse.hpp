@@ -10,14 +10,18 @@ namespace rtx {
 // are meaningful, not the absolute cycle counts.  Compiled out of the product library.
 #ifdef RTX_PROFILE_SECTIONS
 struct Prof {
-    unsigned long long t, acc[12];
-    __device__ __forceinline__ void begin() { t = __builtin_readcyclecounter(); for (int i = 0; i < 12; i++) acc[i] = 0; }
+    unsigned long long t, acc[12], lanes[12], calls[12];
+    __device__ __forceinline__ void begin() { t = __builtin_readcyclecounter(); for (int i = 0; i < 12; i++) { acc[i] = 0; lanes[i] = 0; calls[i] = 0; } }
     __device__ __forceinline__ void mark(int i) { const unsigned long long n = __builtin_readcyclecounter(); acc[i] += n - t; t = n; }
+    // how many lanes are executing at this point (EXEC), once per call: lanes[i] / calls[i] = average active lanes of the code that follows
+    __device__ __forceinline__ void count(int i) { lanes[i] += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_read_exec()); calls[i] += 1; }
 };
 #define RTX_PROF_MARK(pf, i) do { if (pf) (pf)->mark(i); } while (0)
+#define RTX_PROF_COUNT(pf, i) do { if (pf) (pf)->count(i); } while (0)
 #else
 struct Prof {};
 #define RTX_PROF_MARK(pf, i) do { } while (0)
+#define RTX_PROF_COUNT(pf, i) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -342,6 +346,7 @@ __device__ __forceinline__ void traverse_small(const DevScene& sc, const SmallRe
     // (Testing only the triangle on the ray's side of a quad's diagonal would save one exact test per candidate; measured slower
     // both ways: at 4 waves/SIMD the ~4 extra VGPRs spill (28.4-28.9 ms instead of 27.6), at 3 waves/SIMD without spills 31.3 ms.)
     auto exact = [&](uint32_t k) -> bool {              // both triangles of record k; true = an any-hit ray is done
+        RTX_PROF_COUNT(pf, pf_sec + 1);
 #pragma unroll
         for (uint32_t h = 0; h < 2u; h++) {
             const lds_v4f* tp = L.tris + (2u * k + h) * 3u;

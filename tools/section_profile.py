@@ -33,18 +33,22 @@ def main():
     p = rt.Params(width=W, height=H, spp=64, sample_base=1, max_bounces=8, nee_samples=1, rr_start=3, frame_seed=1, flags=1,
                   tile_size=64, shard_rank=0, shard_count=1)
     ctx.render(p)                                   # warm-up
-    out = (C.c_ulonglong * 12)()
+    out = (C.c_ulonglong * 36)()
     rt.lib.rtx_debug_sections.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
     assert rt.lib.rtx_debug_sections(out, 1) == 0
     for i in range(frames):
         p.frame_seed = 2 + i
         ctx.render(p)
     assert rt.lib.rtx_debug_sections(out, 0) == 0
-    tot = float(sum(out))
-    print(f"k_bounce_small, {frames} frame(s) of Cornell 1080p 64 spp 8 bounces: share of wave time by section")
-    for n, v in zip(NAMES, out):
+    tot = float(sum(out[:12]))
+    print(f"k_bounce_small, {frames} frame(s) of Cornell 1080p 64 spp 8 bounces: share of wave time by section; active lanes where counted")
+    LANES = {2: "per exact-test round (closest)", 3: "surface reconstruction", 4: "NEE sample", 7: "per exact-test round (shadow)", 9: "BSDF sample", 10: "store path"}
+    for i, (n, v) in enumerate(zip(NAMES, out[:12])):
         if v:
             print(f"  {n:34s} {100.0 * v / tot:5.1f} %")
+    for i, what in LANES.items():
+        if out[24 + i]:
+            print(f"  lanes {what:34s} {out[12 + i] / out[24 + i]:5.1f} of 64   ({out[24 + i] / 1e6:.1f} M wave-level calls)")
     ctx.close()
 
 
