@@ -62,7 +62,7 @@ typedef struct rtx_params {
 
 /* kernel classes for rtx_stats */
 enum { RTX_K_RAYGEN = 0, RTX_K_TRACE = 1, RTX_K_SHADE = 2, RTX_K_SHADOW = 3, RTX_K_ACCUM = 4, RTX_K_SORT = 5,
-       RTX_K_BOUNCE = 6 /* fused trace+shade+shadow kernel of the tiny-scene path */, RTX_K_COUNT = 8 };
+       RTX_K_BOUNCE = 6 /* fused trace+shade+shadow kernels: k_bounce_small (tiny scenes), k_bounce_bvh (general path) */, RTX_K_COUNT = 8 };
 
 typedef struct rtx_stats {
     uint64_t rays_primary, rays_extension, rays_shadow;  /* BVH queries issued by the last rtx_render */
@@ -87,6 +87,10 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
        RTX_OPT_STACK_PRIVATE = 9,    /* tuning: traversal stack 0 = LDS column, 1 = private (scratch) memory, (2 is accepted and means 0) */
        RTX_OPT_TRACE_SCHED = 10,     /* tuning: wave schedule of the BVH traversal, 0 = while-while, 1-4 = voted node / triangle steps, 5-7 = voted + speculative (default 6) */
        RTX_OPT_GPU_REFIT = 11,       /* 1 (default): a transform-only rtx_commit_scene refits the resident BVH on the GPU; 0: host refit + upload */
+       RTX_OPT_FUSED_BVH = 14,       /* 1: general (BVH) scenes run trace -> shade -> shadow of all bounces in ONE launch per batch (k_bounce_bvh, phases separated by workgroup
+                                        barriers).  Bit-identical, but MEASURED SLOWER than one launch per phase and bounce (C3 51.3 vs 47.7 ms, C5 46.2 vs 44.4 ms: a wave that has
+                                        finished its phase keeps its SIMD slot while it waits for the slowest wave of its workgroup, and the kernel needs 86 VGPRs where the
+                                        traversal kernels need 75), so the default is 0.  Needs RTX_OPT_TRACE_SCHED 5-7 */
        RTX_OPT_LPT_ORDER = 13,       /* tuning: 1 (default) = the fused tiny-scene kernels take their sub-queues longest first (shorter launch tails), 0 = in index order */
        RTX_OPT_BLOCKS_PER_CU = 12    /* tuning: workgroups (= private sub-queues) per compute unit; default 0 = auto (40 tiny scenes, 16 otherwise; 8 measured 4-7 % slower: tail imbalance) */ };
 

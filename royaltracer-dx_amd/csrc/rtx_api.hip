@@ -44,6 +44,8 @@ struct rtx_ctx {
     // path state
     DevBuf d_hitmask, d_order, d_pmask;
     bool lpt_order = true;          // RTX_OPT_LPT_ORDER: fused kernels take their sub-queues longest first
+    bool fused_bvh = false;         // RTX_OPT_FUSED_BVH: general path = one k_bounce_bvh launch per batch (trace -> shade -> shadow per sub-queue and bounce); measured SLOWER, default off
+    DevBuf d_hitq;
     DevBuf d_ray_o, d_ray_d, d_thr, d_rad, d_hit, d_sh_o, d_sh_d, d_sh_c, d_queue[2], d_counters;
     uint32_t* h_counters = nullptr; size_t h_counters_words = 0;
     // accumulation
@@ -108,7 +110,7 @@ void rtx_destroy(rtx_ctx* c) {
     else (void)hipDeviceSynchronize();
     DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_small_poly, &c->d_objtris, &c->d_node_aabb, &c->d_scale, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
                      &c->d_thr, &c->d_rad, &c->d_hit, &c->d_hitmask, &c->d_order, &c->d_pmask, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
-                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch};
+                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq};
     for (DevBuf* b : all) b->release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
@@ -132,6 +134,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_BOUNCE_VARIANT: return RTX_OK;         // retired knob (forced waves/SIMD builds of the fused kernel measured no faster): accepted, ignored
     case RTX_OPT_STACK_PRIVATE: c->stack_private = (int)value; c->committed = false; return RTX_OK;
     case RTX_OPT_LPT_ORDER: c->lpt_order = value != 0; return RTX_OK;
+    case RTX_OPT_FUSED_BVH: c->fused_bvh = value != 0; return RTX_OK;
     case RTX_OPT_BLOCKS_PER_CU: if (value < 0 || value > 64) { c->err = "blocks_per_cu must be in [0, 64]"; return RTX_ERR_INVALID; } c->blocks_per_cu = (uint32_t)value; return RTX_OK;
     case RTX_OPT_GPU_REFIT: c->gpu_refit = value != 0; return RTX_OK;
     case RTX_OPT_TRACE_SCHED: if (value > 7) { c->err = "trace_sched must be in [0, 7]"; return RTX_ERR_INVALID; } c->trace_sched = (uint32_t)value; c->dsc.trace_sched = c->trace_sched; return RTX_OK;
@@ -391,7 +394,8 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     // CU, longest-first dispatch, all bounces >= 1 in one launch) measured 18.39 / 18.15 / 18.13 / 18.30 / 18.36 ms at 24 / 32 / 40 / 48 / 64
     // (a 1/4 shard: 5.22 / 4.96 / 4.99 / 4.92 / 4.96 ms; 30 is an outlier, its sub-queues alias with the 8100 image regions); the
     // general path measured best at 16 (49.3 / 42.2 ms vs 53.0 / 44.2 at 8)
-    const uint32_t bpc = c->blocks_per_cu ? c->blocks_per_cu : (c->dsc.nsmall && c->fused ? 40u : 16u);
+    const bool fused_bvh = !c->dsc.nsmall && c->fused_bvh && c->trace_sched >= 5u;      // (the other wave schedules are experiment knobs of the separate kernels)
+    const uint32_t bpc = c->blocks_per_cu ? c->blocks_per_cu : (c->dsc.nsmall && c->fused ? 40u : fused_bvh ? 32u : 16u);
     const uint32_t max_blocks = (uint32_t)c->num_cus * bpc;
     const uint32_t nchunks = f.chunks_per_sample * bspp;
     const uint32_t G = std::max<uint32_t>(1, std::min<uint32_t>(nchunks, max_blocks));
@@ -400,6 +404,7 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     const size_t qtot = (size_t)G * qcap;
     HIPCHK(c, c->d_queue[0].ensure(qtot * 4)); HIPCHK(c, c->d_queue[1].ensure(qtot * 4));
     HIPCHK(c, c->d_order.ensure((size_t)G * 4));
+    if (fused_bvh) HIPCHK(c, c->d_hitq.ensure(qtot * 4));
     HIPCHK(c, c->d_pmask.ensure(((size_t)f.npl / 64 + 1) * 8));
     const uint32_t nee1 = std::max<uint32_t>(nee, 1);
     const size_t shn = qtot * nee1;
@@ -449,7 +454,13 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
             { Timed t(c, RTX_K_BOUNCE); launch_bounce_small(st, c->dsc, fb, P, 0, 1, queue[0], queue[1], Q(0), S(0, 0), order); }
             if (mb > 1) { Timed t(c, RTX_K_BOUNCE); launch_bounce_small(st, c->dsc, fb, P, 1, mb, queue[0], queue[1], Q(0), S(0, 0), order); }
         }
-        for (uint32_t b = 0; b < mb && !fused; b++) {
+        if (fused_bvh) {      // general scenes: all bounces of every sub-queue in one launch (k_bounce_bvh), sub-queues longest first
+            const uint32_t* ord = nullptr;
+            if (c->lpt_order && G > 1) { launch_order_queues(st, Q(0), G, (uint32_t*)c->d_order.p); ord = (const uint32_t*)c->d_order.p; }
+            Timed t(c, RTX_K_BOUNCE);
+            launch_bounce_bvh(st, c->dsc, fb, P, 0, mb, queue[0], queue[1], (uint32_t*)c->d_hitq.p, Q(0), S(0, 0), ord);
+        }
+        for (uint32_t b = 0; b < mb && !fused && !fused_bvh; b++) {
             uint32_t* q = queue[b & 1]; uint32_t* qn = queue[(b + 1) & 1];
             { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, fb, c->dsc, P, b, q, Q(b)); }
             { Timed t(c, RTX_K_SHADE); launch_shade(st, c->dsc, fb, P, b, q, Q(b), qn, Q(b + 1), S(b, 0)); }
@@ -476,10 +487,10 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     }
     c->stats.kernel_items[RTX_K_RAYGEN] = c->stats.paths;
     const bool fused = c->dsc.nsmall && c->fused;
-    c->stats.kernel_items[RTX_K_BOUNCE] = fused ? c->stats.primary_hits + c->stats.rays_extension : 0;   // bounce 0 shades the primary hits only
-    c->stats.kernel_items[RTX_K_TRACE] = fused ? 0 : c->stats.rays_primary + c->stats.rays_extension;
-    c->stats.kernel_items[RTX_K_SHADE] = fused ? 0 : c->stats.rays_primary + c->stats.rays_extension;
-    c->stats.kernel_items[RTX_K_SHADOW] = fused ? 0 : c->stats.rays_shadow;
+    c->stats.kernel_items[RTX_K_BOUNCE] = fused ? c->stats.primary_hits + c->stats.rays_extension : fused_bvh ? c->stats.rays_primary + c->stats.rays_extension : 0;   // tiny scenes: bounce 0 shades the primary hits only
+    c->stats.kernel_items[RTX_K_TRACE] = (fused || fused_bvh) ? 0 : c->stats.rays_primary + c->stats.rays_extension;
+    c->stats.kernel_items[RTX_K_SHADE] = (fused || fused_bvh) ? 0 : c->stats.rays_primary + c->stats.rays_extension;
+    c->stats.kernel_items[RTX_K_SHADOW] = (fused || fused_bvh) ? 0 : c->stats.rays_shadow;
     c->stats.kernel_items[RTX_K_ACCUM] = c->stats.paths;
     return RTX_OK;
 }

@@ -482,6 +482,142 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
     PF_FLUSH;
 }
 
+// Fused bounce kernel of the GENERAL (BVH) path: for its private sub-queue a workgroup runs, bounce after bounce in ONE launch,
+//   phase 1  closest-hit traversal (persistent waves with refill, as k_trace_closest) — hits go to p.hit and, compacted, to a hit list
+//   phase 2  shading of the hit list (as k_shade: surface, emissive MIS, NEE sample -> shadow entries, BSDF sample, RR, compaction)
+//   phase 3  any-hit traversal of the shadow entries, radiance added per NEE slot in order (as k_trace_shadow)
+// with workgroup barriers in between (sub-queues are workgroup-private: bounce b + 1 of a sub-queue depends on bounce b of the same sub-queue
+// only, exactly as in k_bounce_small).  The idea: the traversal phases are VALU-bound (VALU busy 1.00 / 0.80, profiles/r02_pmc_sponza.md) and the
+// shading phase is HBM-bound (3.6-4 TB/s at VALU busy 0.46), so with the workgroups of a launch in different phases at any moment the two resources
+// would be used at the same time; shading iterates over HITS only; 1 launch per frame instead of 24-25.
+// MEASURED (MI355X, round 2): bit-identical to the separate kernels (every general-path test runs both), and SLOWER — C3 51.3 vs 47.7 ms, C5 46.2 vs
+// 44.4 ms per frame (58.5 / 53.0 before the kernel was built for 5 waves per SIMD and reduced to one wave schedule).  Why (rocprofv3 --pmc): the
+// same VALU work (+7 % instructions from SGPR spill traffic in the loops) runs at 79 % VALU-busy instead of 100 %: waves are parked 56 % of the
+// time, because a wave that has finished its share of a phase keeps its SIMD slot while it waits at the barrier for the slowest wave of its
+// workgroup (in the separate kernels it retires and the next workgroup's wave takes the slot), and 86 VGPRs (75 for the traversal kernels) leave
+// fewer waves to cover that.  Hence RTX_OPT_FUSED_BVH defaults to 0; the kernel stays as the measured alternative.
+// Arithmetic and the order of radiance additions per path are those of the separate kernels.
+template <int STK>
+__global__ __launch_bounds__(kBlock, 5) void k_bounce_bvh(DevScene sc, DevFrame f, DevPaths p, uint32_t bounce_first, uint32_t bounce_end,
+                                                        uint32_t* __restrict__ queue_a, uint32_t* __restrict__ queue_b, uint32_t* __restrict__ hitq,
+                                                        uint32_t* __restrict__ qrows, uint32_t* __restrict__ srows, const uint32_t* __restrict__ order) {
+    extern __shared__ F4 lds[];
+    __shared__ uint32_t s_head, s_nh;
+    __shared__ uint32_t s_cnt[1 + kMaxNee];
+    const uint32_t G = gridDim.x;
+    const uint32_t qid = order ? order[blockIdx.x] : blockIdx.x;
+    const uint32_t nee = sc.nlights ? f.nee_samples : 0u;
+    const uint32_t nee1 = nee ? nee : 1u;
+    const TraceLds L = stage_lds(sc, lds);
+    if (threadIdx.x <= kMaxNee) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_head = 0; s_nh = 0; }
+    __syncthreads();
+    const size_t qb = (size_t)qid * f.qcap;
+    uint32_t* myhits = hitq + qb;
+    uint32_t n = qrows[(size_t)bounce_first * G + qid];
+    typename std::conditional<STK == 1, StackPriv, StackLds>::type stk;
+    if constexpr (STK != 1) stk.col = L.stack + threadIdx.x;
+    for (uint32_t bounce = bounce_first; bounce < bounce_end; bounce++) {
+        const bool last = (bounce + 1u == f.max_bounces);
+        const float tmin = bounce_tmin(bounce);
+        const uint32_t* myq = ((bounce & 1u) ? queue_b : queue_a) + qb;
+        uint32_t* mynext = ((bounce & 1u) ? queue_a : queue_b) + qb;
+        // ---- phase 1: closest hit for every entry of the sub-queue ----
+        if (n) {
+            RayLane R; ray_idle(R);
+            bool drained = false;
+            while (refill(R, &s_head, n, drained, sc.refill_min, [&](uint32_t idx) {
+                       const uint32_t pid = myq[idx];
+                       const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
+                       ray_begin(R, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, pid, true);
+                   })) {
+                spec_step<false>(sc, L, R, stk, sc.trace_sched);               // (the fused kernel carries the speculative voted schedule only: RTX_OPT_TRACE_SCHED 5-7)
+                const bool fin = R.has && R.done;
+                const bool hit = fin && R.bprim != kMissPrim;
+                if (__ballot(fin) != 0ull) {                                   // wave-uniform
+                    const uint32_t slot = block_push(hit, &s_nh);              // only hits reach the shading phase (a miss ends the path: Miss.hlsl:3-11)
+                    if (hit) { p.hit[R.item] = {R.bt, R.bu, R.bv, u2f(R.bprim)}; myhits[slot] = R.item; }
+                    if (fin) R.has = false;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t nh = s_nh;
+        // ---- phase 2: shade the hits ----
+        for (uint32_t base = threadIdx.x & ~63u; base < nh; base += kBlock) {
+            const uint32_t i = base + (threadIdx.x & 63u);
+            PathState S; S.pid = 0; S.o = mk3(0, 0, 0); S.d = mk3(0, 0, 1); S.thr = mk3(0, 0, 0); S.prev_pdf = 1.0f; S.s0 = S.s1 = 0;
+            Surf sf; sf.mat = 0; sf.normal = mk3(0, 0, 1); sf.pos = mk3(0, 0, 0);
+            bool shading = false;
+            if (i < nh) {
+                const uint32_t pid = myhits[i];
+                const F4 h = p.hit[pid];
+                S = load_path(p, pid);
+                sf = surface(sc, S.o, S.d, h.x, h.y, h.z, f2u(h.w));
+                if (sf.mat < sc.nmat) {
+                    const MatGPU& m = sc.mats[sf.mat];
+                    if (m.Ke_len > 0.0f) add_emissive(sc, p, S, sf, m, bounce, nee);
+                    else shading = true;
+                }
+            }
+            const f3 outgoing = -S.d, pos = sf.pos;
+            const MatGPU* mp = sc.mats + (shading ? sf.mat : 0u);
+            f3 normal = sf.normal;
+            const float eta_p = transmission_eta(*mp, f.flags, outgoing, normal);
+            for (uint32_t j = 0; j < nee; j++) {
+                bool push = false;
+                F4 so = {0, 0, 0, 0}, sd = {0, 0, 0, 0}; f3 con = mk3(0, 0, 0);
+                if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con, false, eta_p);
+                const size_t seg = (size_t)j * f.qcap * G + qb;
+                const uint32_t slot = block_push(push, &s_cnt[1 + j]);
+                if (push) { p.sh_o[seg + slot] = so; p.sh_d[seg + slot] = sd; p.sh_c[seg + slot] = {con.x, con.y, con.z, u2f(S.pid)}; }
+            }
+            bool alive = false;
+            f3 smp = mk3(0, 0, 1); float P = 0.0f;
+            if (shading && !last) alive = bsdf_continue(*mp, f, bounce, S, normal, outgoing, smp, P, eta_p);
+            if (alive) store_path(p, S, pos, smp, P);
+            const uint32_t slot = block_push(alive, &s_cnt[0]);
+            if (alive) mynext[slot] = S.pid;
+        }
+        __syncthreads();
+        // ---- phase 3: NEE visibility, slot by slot (a path appears at most once per slot: plain read-modify-write, fixed order of additions) ----
+        for (uint32_t j = 0; j < nee; j++) {
+            const uint32_t ns = s_cnt[1 + j];
+            if (threadIdx.x == 0) s_head = 0;
+            __syncthreads();
+            if (ns) {
+                const size_t sb = (size_t)j * f.qcap * G + qb;
+                RayLane R; ray_idle(R);
+                bool drained = false;
+                while (refill(R, &s_head, ns, drained, sc.refill_min, [&](uint32_t idx) {
+                           const F4 so = p.sh_o[sb + idx], sd = p.sh_d[sb + idx];
+                           ray_begin(R, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), fabsf(so.w), sd.w, idx, false);
+                       })) {
+                    spec_step<true>(sc, L, R, stk, sc.trace_sched);
+                    if (R.has && R.done) {
+                        if (R.bprim == kMissPrim) {                            // visible
+                            const F4 c = p.sh_c[sb + R.item];
+                            const uint32_t pid = f2u(c.w);
+                            F4 r = p.rad[pid];
+                            r.x = r.x + c.x; r.y = r.y + c.y; r.z = r.z + c.z;
+                            p.rad[pid] = r;
+                        }
+                        R.has = false;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // ---- end of this bounce: publish the counters, reset for the next one ----
+        n = s_cnt[0];
+        if (threadIdx.x == 0) { qrows[(size_t)(bounce + 1u) * G + qid] = n; s_head = 0; s_nh = 0; }
+        if (threadIdx.x >= 1 && threadIdx.x <= nee) srows[((size_t)bounce * nee1 + (threadIdx.x - 1)) * G + qid] = s_cnt[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x <= kMaxNee) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+    }
+}
+
 // Longest sub-queue first.  The sub-queues of a batch differ in length by ~12 % (std; each is a sample of ~84 of the image's 8100
 // 256-pixel regions, 43 % of which are background on the Cornell view) and a launch has only ~6 workgroups per resident slot, so in
 // blockIdx order the last dispatch round is ragged: 3.4 of 4 waves per SIMD resident on average.  The hardware dispatches
@@ -785,6 +921,11 @@ void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, 
     if (have_hit) { if (lam) RTX_LAUNCH_BOUNCE(true, true); else RTX_LAUNCH_BOUNCE(true, false); }
     else { if (lam) RTX_LAUNCH_BOUNCE(false, true); else RTX_LAUNCH_BOUNCE(false, false); }
 #undef RTX_LAUNCH_BOUNCE
+}
+void launch_bounce_bvh(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce_first, uint32_t bounce_end,
+                       uint32_t* queue_a, uint32_t* queue_b, uint32_t* hitq, uint32_t* qrows, uint32_t* srows, const uint32_t* order) {
+    if (sc.stack_private == 1) hipLaunchKernelGGL(k_bounce_bvh<1>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, f, p, bounce_first, bounce_end, queue_a, queue_b, hitq, qrows, srows, order);
+    else hipLaunchKernelGGL(k_bounce_bvh<0>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, f, p, bounce_first, bounce_end, queue_a, queue_b, hitq, qrows, srows, order);
 }
 void launch_order_queues(hipStream_t st, const uint32_t* qcount, uint32_t G, uint32_t* order) {
     hipLaunchKernelGGL(k_order_queues, dim3(1), dim3(1024), 0, st, qcount, G, order);

@@ -61,6 +61,9 @@ void launch_packet_masks(hipStream_t, const DevScene&, const DevFrame&, const Ca
 void launch_raygen_trace_small(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount, uint32_t* gencount, const unsigned long long* masks);
 void launch_bounce_small(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, uint32_t bounce_first, uint32_t bounce_end,
                          uint32_t* queue_a, uint32_t* queue_b, uint32_t* qrows, uint32_t* srows, const uint32_t* order);   // bounce 0 alone (reads the primary hits), or a range of later bounces
+// general (BVH) path: trace -> shade -> shadow of a bounce range for every workgroup-private sub-queue in one launch (hitq: G * qcap indices of scratch)
+void launch_bounce_bvh(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, uint32_t bounce_first, uint32_t bounce_end,
+                       uint32_t* queue_a, uint32_t* queue_b, uint32_t* hitq, uint32_t* qrows, uint32_t* srows, const uint32_t* order);
 void launch_order_queues(hipStream_t, const uint32_t* qcount, uint32_t G, uint32_t* order);   // longest sub-queue first (dispatch order of the fused kernels)
 void launch_trace_shadow(hipStream_t, const DevFrame&, const DevScene&, const DevPaths&, uint32_t j, const uint32_t* shcount);
 void launch_shade(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, uint32_t bounce,

@@ -27,12 +27,14 @@ def ctx(rt):
     c.close()
 
 
-@pytest.fixture(scope="module", params=["fused_small", "separate_small", "separate_bvh"])
+@pytest.fixture(scope="module", params=["fused_small", "separate_small", "separate_bvh", "fused_bvh"])
 def cornell_pair(request, rt, orc, cornell):
     """Cornell through every kernel path: fused bounce kernel (default for tiny scenes), separate
-    trace / shade / shadow kernels with the tiny-scene traversal, and the general BVH traversal"""
+    trace / shade / shadow kernels with the tiny-scene traversal, and the general BVH traversal with separate kernels
+    and with the fused k_bounce_bvh (the default for general scenes)"""
     c = rt.Context(0)
-    c.set_option(rt.OPT_SMALL_SCENE, 0 if request.param == "separate_bvh" else 1)
+    c.set_option(rt.OPT_SMALL_SCENE, 0 if request.param.endswith("_bvh") else 1)
+    c.set_option(rt.OPT_FUSED_BVH, 1 if request.param == "fused_bvh" else 0)
     c.set_option(rt.OPT_FUSED_BOUNCE, 1 if request.param == "fused_small" else 0)
     c.upload(cornell, 16 / 9)
     yield c, orc.Oracle().load(cornell, 16 / 9)
@@ -168,7 +170,7 @@ class XformedScene:
         return self._base.view_proj(aspect)
 
 
-@pytest.mark.parametrize("variant", ["fused_small", "separate_small", "separate_bvh"])
+@pytest.mark.parametrize("variant", ["fused_small", "separate_small", "separate_bvh", "fused_bvh"])
 @pytest.mark.parametrize("kind", ["rotated_sheared", "mirrored"])
 def test_tiny_scene_paths_on_a_skewed_room(rt, orc, cornell, variant, kind):
     """the tiny-scene machinery (planar-quad merging, conservative pre-test, convex-hull faces skipped by NEE segments) on a room
@@ -181,7 +183,7 @@ def test_tiny_scene_paths_on_a_skewed_room(rt, orc, cornell, variant, kind):
     M = np.eye(4); M[:3, :3] = A; M[:3, 3] = (0.5, 0.5, 0.5) - A @ np.array([0.5, 0.5, 0.5]) + (0.02, -0.01, 0.03)   # about the room's centre
     sc = XformedScene(cornell, [M.T.reshape(16)])                      # column-major storage of a column-vector matrix
     c = rt.Context(0)
-    c.set_option(rt.OPT_SMALL_SCENE, 0 if variant == "separate_bvh" else 1); c.set_option(rt.OPT_FUSED_BOUNCE, 1 if variant == "fused_small" else 0)
+    c.set_option(rt.OPT_SMALL_SCENE, 0 if variant.endswith("_bvh") else 1); c.set_option(rt.OPT_FUSED_BVH, 1 if variant == "fused_bvh" else 0); c.set_option(rt.OPT_FUSED_BOUNCE, 1 if variant == "fused_small" else 0)
     c.upload(sc, 16 / 9)
     o = orc.Oracle().load(sc, 16 / 9)
     p = rt.Params(width=112, height=63, spp=3, max_bounces=8, nee_samples=2, flags=1)
@@ -757,9 +759,11 @@ def test_c4_sizes_4k_shards_and_stack_variants(rt, orc):
     imgs = []
     # (stack, schedule): LDS column + speculative voted (default), private stack, while-while, voted, voted with other weights
     # the last entry also turns on the material-sorted k_shade variant
-    for k, (stack, sched) in enumerate(((0, 6), (1, 6), (0, 0), (0, 2), (0, 5), (0, 7), (0, 3), (0, 6))):
+    # entries 8-10 run the separate trace / shade / shadow kernels (RTX_OPT_FUSED_BVH = 0), the last one with material-sorted shading
+    for k, (stack, sched) in enumerate(((0, 6), (1, 6), (0, 0), (0, 2), (0, 5), (0, 7), (0, 3), (0, 6), (0, 6), (1, 2), (0, 6))):
         c = rt.Context(0); c.set_option(rt.OPT_STACK_PRIVATE, stack); c.set_option(rt.OPT_TRACE_SCHED, sched)
-        c.set_option(rt.OPT_SORT_MATERIALS, 1 if k == 7 else 0); c.upload(sc, W / H)
+        c.set_option(rt.OPT_FUSED_BVH, 0 if k >= 8 else 1)
+        c.set_option(rt.OPT_SORT_MATERIALS, 1 if k in (7, 10) else 0); c.upload(sc, W / H)
         c.clear(W, H); c.render(rt.Params(**base)); imgs.append(c.read_accum())
         if k == 0:
             st = c.stats(); assert st.rays_primary == W * H
