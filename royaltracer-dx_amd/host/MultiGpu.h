@@ -1,0 +1,37 @@
+// MultiGpu.h — the native N-GPU frame of the C++ host layer (SURVEY 8(e), §5 last row): ONE process, one rtx_ctx per GPU, pixel tiles dealt round-robin
+// (tile t -> rank t mod N), every rank renders its tiles, packs them into a slab (rtx_pack_tiles) and the frame ends with ONE all-gather of the slabs
+// over xGMI followed by rtx_unpack_tiles.  Nothing is exchanged inside the frame.  The reference is single-GPU (one device, one command queue:
+// Renderer.cpp:106-254); where its Renderer::PopulateCommandList issues the frame (Renderer.cpp:646-673) a maintainer calls MultiGpuFrame::Render.
+//
+// The collective is RCCL in a single process: ncclCommInitAll over the device list, ncclAllGather on every rank's own stream inside
+// ncclGroupStart / ncclGroupEnd (/opt/rocm/include/rccl/rccl.h:236,678,923).  RCCL is linked into the rtx_render executable only, never into
+// librtx_hip.so.  For tests on ONE GPU (two ranks cannot share a device under RCCL) the gather can be replaced by plain device-to-device copies
+// (Gather::COPY): the same slab layout, the same pack / unpack kernels, the same result.
+#pragma once
+#include <string>
+#include <vector>
+#include "Scenes.h"
+
+class MultiGpuFrame {
+public:
+    enum class Gather { RCCL, COPY };
+    MultiGpuFrame(const std::vector<int>& devices, Gather g);
+    ~MultiGpuFrame();
+    void SetScene(const Scene& s, float aspect);          // replicated on every GPU (Bistro-class: 0.4 GB << 288 GB)
+    // one frame: p.shard_rank / shard_count are filled per rank; the assembled accumulation buffer ends up on EVERY rank (all-gather)
+    void Render(const rtx_params& p);
+    void Clear(uint32_t width, uint32_t height);          // zero every rank's accumulation buffer (view-change reset)
+    std::vector<float> ReadAccumulation(int rank = 0);
+    std::vector<uint8_t> ReadOutput(int rank = 0);
+    rtx_stats Stats(int rank) const { return m_stats[rank]; }
+    double LastFrameMs() const { return m_lastMs; }       // wall time of Render: max over ranks, gather included
+    int Ranks() const { return (int)m_devices.size(); }
+private:
+    struct Impl;
+    Impl* m;
+    std::vector<int> m_devices;
+    std::vector<rtx_stats> m_stats;
+    Gather m_gather;
+    double m_lastMs = 0.0;
+    uint32_t m_w = 0, m_h = 0;
+};

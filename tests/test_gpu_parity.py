@@ -1141,6 +1141,29 @@ def test_bench_two_ranks_assemble_the_single_rank_frame():
     assert bad.returncode != 0 and "does not match WORLD_SIZE" in bad.stderr
 
 
+def test_native_multi_gpu_frame_of_the_cli(tmp_path):
+    """SURVEY 8(e) in the C++ host layer: `rtx_render --gpus N` = ONE process, N contexts on N threads, tiles round-robin, pack -> all-gather -> unpack.
+    On one GPU the ranks share device 0 and the collective is replaced by device copies (`--gather copy`: two ranks cannot share a device under
+    RCCL); the slab layout, the pack / unpack kernels and the threading are the real ones.  1, 2 and 3 ranks must write byte-identical images."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "royaltracer-dx_amd", "rtx_render")
+    blobs = []
+    for n, scene in ((1, "cornell"), (2, "cornell"), (3, "cornell"), (1, "sponza"), (2, "sponza")):
+        out = tmp_path / f"{scene}_{n}.exr"
+        r = subprocess.run([exe, "--scene", scene, "--w", "320", "--h", "200", "--spp", "3", "--bounces", "5", "--gpus", str(n), "--devices", ",".join(["0"] * n),
+                            "--gather", "copy", "--out", str(out)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert f"on {n} GPUs" in r.stdout
+        blobs.append((scene, n, out.read_bytes()))
+    for scene, n, b in blobs:
+        ref = [x for s, k, x in blobs if s == scene and k == 1][0]
+        assert b == ref, (scene, n)
+    ldd = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    lib = subprocess.run(["ldd", os.path.join(root, "royaltracer-dx_amd", "librtx_hip.so")], capture_output=True, text=True).stdout
+    assert "librccl" in ldd and "librccl" not in lib            # the collective library is linked into the executable only
+
+
 def test_two_contexts_from_two_threads(rt, cornell):
     """SURVEY 8(b) threading contract: a context is not thread-safe, but different contexts may be driven from different threads.
     Two threads render different workloads concurrently on the same GPU (different scenes, options, streams); each result must be
