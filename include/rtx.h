@@ -156,6 +156,11 @@ int  rtx_read_restir_last(rtx_ctx*, void* reservoirs_di40, void* reservoirs_gi40
 int  rtx_read_accum(rtx_ctx*, float* rgba32f, size_t bytes);       /* copy of u1 to the host */
 /* u0 `gOutput` layer 0, RGBA8 UNORM after sRGB OETF (RayGen_v6_pass3.hlsl:405,428-441; Common_v6.hlsl:353-376) */
 int  rtx_read_srgb8(rtx_ctx*, uint8_t* rgba8, size_t bytes);
+/* u0 `gOutput` is a 30-layer RGBA8 array and 'C' cycles the displayed layer through m_displayLevels = {0, 10..17, 20..28} (Renderer.h:298-299,
+   Renderer.cpp:690-698, 748-754).  The reference's live shaders only write layer 0.  Here: 0 = the image, 10-17 = first-hit debug attributes of the
+   pixel-corner primary ray (10 normal, 11 depth, 12 material id, 13 Kd, 14 instance id, 15 barycentrics, 16 Ke, 17 roughness / metallic / dissolve;
+   defined in csrc/rtx_kernels.hip: k_debug_layer), every other layer < 30 opaque black. */
+int  rtx_read_layer(rtx_ctx*, uint32_t layer, uint32_t width, uint32_t height, uint8_t* rgba8, size_t bytes);
 int  rtx_get_stats(rtx_ctx*, rtx_stats* out);
 /* t6 `g_EmissiveTriangles` as built by rtx_commit_scene (80 B records, Renderer.h:113-124) */
 int  rtx_get_lights(rtx_ctx*, void* out80, uint32_t max_count, uint32_t* count_out);

@@ -89,6 +89,8 @@ int  rtxh_renderer_on_update(rtxh_renderer*);
 int  rtxh_renderer_on_render(rtxh_renderer*);
 int  rtxh_renderer_read_accum(rtxh_renderer*, float* rgba32f, size_t bytes);
 int  rtxh_renderer_read_output(rtxh_renderer*, uint8_t* rgba8, size_t bytes);
+int  rtxh_renderer_on_key_up(rtxh_renderer*, uint8_t key);          /* 'C': next entry of m_displayLevels (Renderer.cpp:748-754); read_output returns that layer */
+uint32_t rtxh_renderer_display_layer(const rtxh_renderer*);
 void rtxh_renderer_destroy(rtxh_renderer*);
 
 /* image writers for the headless display path (the reference presents gOutput through a swap chain, Renderer.cpp:554-735, and

@@ -110,6 +110,7 @@ _sig("rtx_pass1_slots", C.c_size_t, _u32, _u32)
 _sig("rtx_read_pass1_buffers", C.c_int, _vp, _vp, _vp, _vp, C.c_size_t)
 _sig("rtx_read_srgb8", C.c_int, _vp, _vp, C.c_size_t)
 _sig("rtx_get_stats", C.c_int, _vp, C.POINTER(Stats))
+_sig("rtx_read_layer", C.c_int, _vp, _u32, _u32, _u32, _vp, C.c_size_t)
 _sig("rtx_get_lights", C.c_int, _vp, _vp, _u32, _u32p)
 _sig("rtx_shard_slab_bytes", C.c_int, C.POINTER(Params), C.POINTER(C.c_size_t))
 _sig("rtx_pack_tiles", C.c_int, _vp, C.POINTER(Params), _vp)
@@ -174,6 +175,8 @@ _sig("rtxh_renderer_on_update", C.c_int, _vp)
 _sig("rtxh_renderer_on_render", C.c_int, _vp)
 _sig("rtxh_renderer_read_accum", C.c_int, _vp, _vp, C.c_size_t)
 _sig("rtxh_renderer_read_output", C.c_int, _vp, _vp, C.c_size_t)
+_sig("rtxh_renderer_on_key_up", C.c_int, _vp, C.c_uint8)
+_sig("rtxh_renderer_display_layer", _u32, _vp)
 _sig("rtxh_renderer_destroy", None, _vp)
 
 
@@ -483,6 +486,13 @@ class Context:
         self._ck(lib.rtx_read_srgb8(self._h, _ptr(out), out.nbytes), "rtx_read_srgb8")
         return out
 
+    def read_layer(self, layer, width=None, height=None):
+        """gOutput layer `layer`: 0 = the image, 10-17 = first-hit debug attributes, others black (rtx_read_layer)"""
+        w, h = width or self.width, height or self.height
+        out = np.zeros((h, w, 4), np.uint8)
+        self._ck(lib.rtx_read_layer(self._h, layer, w, h, _ptr(out), out.nbytes), "rtx_read_layer")
+        return out
+
     def stats(self):
         s = Stats()
         self._ck(lib.rtx_get_stats(self._h, C.byref(s)), "rtx_get_stats")
@@ -598,6 +608,13 @@ class Renderer:
         out = np.zeros((self.height, self.width, 4), np.uint8)
         self._ck(lib.rtxh_renderer_read_output(self._h, _ptr(out), out.nbytes), "read_output")
         return out
+
+    def on_key_up(self, key):
+        self._ck(lib.rtxh_renderer_on_key_up(self._h, ord(key) if isinstance(key, str) else key), "OnKeyUp")
+
+    @property
+    def display_layer(self):
+        return lib.rtxh_renderer_display_layer(self._h)
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None

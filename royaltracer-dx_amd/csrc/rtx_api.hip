@@ -627,6 +627,24 @@ int rtx_read_srgb8(rtx_ctx* c, uint8_t* out, size_t bytes) {
     return RTX_OK;
 }
 
+// gOutput layer `layer` of the reference's 30-layer output array (Renderer.h:298-299): 0 = the image (== rtx_read_srgb8); 10-17 = first-hit debug
+// attributes (k_debug_layer); every other layer below 30 reads black, as in the reference whose shaders never write them
+int rtx_read_layer(rtx_ctx* c, uint32_t layer, uint32_t width, uint32_t height, uint8_t* out, size_t bytes) {
+    BIND(c);
+    if (layer >= 30u) { c->err = "read_layer: the output array has 30 layers"; return RTX_ERR_INVALID; }
+    if (layer == 0u) { if (width != c->acc_w || height != c->acc_h) { c->err = "read_layer: layer 0 has the size of the accumulation buffer"; return RTX_ERR_INVALID; } return rtx_read_srgb8(c, out, bytes); }
+    const size_t npix = (size_t)width * height;
+    if (!out || !npix || npix > 0x7FFFFFFFull || bytes < npix * 4) { c->err = "read_layer: bad size"; return RTX_ERR_INVALID; }
+    if (layer < 10u || layer > 17u) { memset(out, 0, npix * 4); for (size_t i = 0; i < npix; i++) out[i * 4 + 3] = 255; return RTX_OK; }
+    if (!c->committed || !c->camera_set) { c->err = "read_layer: scene not committed or camera not set"; return RTX_ERR_STATE; }
+    HIPCHK(c, c->d_srgb.ensure(npix * 4));
+    launch_debug_layer(c->stream, (uint32_t)c->num_cus * 8u, c->dsc, width, height, (const CameraGPU*)c->d_cam.p, layer, (uint32_t*)c->d_srgb.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->d_srgb.p, npix * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RTX_OK;
+}
+
 int rtx_get_stats(rtx_ctx* c, rtx_stats* out) { if (!c || !out) return RTX_ERR_INVALID; *out = c->stats; return RTX_OK; }
 
 int rtx_get_lights(rtx_ctx* c, void* out80, uint32_t max_count, uint32_t* count_out) {

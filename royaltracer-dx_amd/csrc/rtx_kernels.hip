@@ -689,6 +689,52 @@ __global__ __launch_bounds__(kBlock) void k_srgb8(const F4* __restrict__ accum, 
     out[i] = px;
 }
 
+// Debug output layers (the reference's gOutput is a 30-layer texture array and 'C' cycles m_displayLevels = {0, 10..17, 20..28}: Renderer.h:298-299,
+// Renderer.cpp:690-698, 748-754; its live shaders only ever write layer 0, the others show whatever was left there).  Here layers 10-17 are
+// DEFINED: first-hit attributes of the pixel-corner primary ray (jitter-free, RayGen_v6_pass1.hlsl:80-95), one thread per pixel:
+//   10 shading normal n/2 + 1/2   11 depth t / (1 + t)   12 material id (hashed colour)   13 Kd (fp16-rounded, as shaded)
+//   14 instance id (hashed colour)   15 barycentrics (1-u-v, u, v)   16 Ke / (1 + Ke)   17 (roughness, metallic, dissolve)
+// a miss is black; layers 20-28 stay black (never written by the reference either).  Linear values, quantised like layer 0's alpha: v * 255 + 0.5.
+__device__ __forceinline__ uint32_t hash_colour(uint32_t id) {
+    uint32_t h = id * 2654435761u + 0x9E3779B9u; h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13;
+    return 0xFF000000u | (0x404040u + (h & 0x00BFBFBFu));
+}
+__device__ __forceinline__ uint32_t pack_rgb8(float r, float g, float b) {
+    const float c[3] = {saturate(r), saturate(g), saturate(b)};
+    uint32_t px = 0xFF000000u;
+    for (int k = 0; k < 3; k++) px |= ((uint32_t)(int)(c[k] * 255.0f + 0.5f)) << (8 * k);
+    return px;
+}
+__global__ __launch_bounds__(kBlock) void k_debug_layer(DevScene sc, const SmallRecPair* __restrict__ small, uint32_t width, uint32_t height, const CameraGPU* __restrict__ cam, uint32_t layer, uint32_t* __restrict__ out) {
+    extern __shared__ F4 lds[];
+    const TraceLds L = stage_lds(sc, lds);
+    __syncthreads();
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < width * height; i += stride) {
+        const uint32_t x = i % width, y = i / width;
+        f3 o, d; primary_ray(*cam, width, height, x, y, 0.0f, 0.0f, o, d);
+        float t, u, v; uint32_t prim;
+        trace_ray<false>(sc, small, L, o, d, kTMinCam, kTMax, t, u, v, prim);
+        uint32_t px = 0xFF000000u;
+        if (prim != kMissPrim && layer >= 10u && layer <= 17u) {
+            const Surf sf = surface(sc, o, d, t, u, v, prim);
+            const bool hm = sf.mat < sc.nmat;
+            const MatGPU& m = sc.mats[hm ? sf.mat : 0u];
+            switch (layer) {
+            case 10u: px = pack_rgb8(sf.normal.x * 0.5f + 0.5f, sf.normal.y * 0.5f + 0.5f, sf.normal.z * 0.5f + 0.5f); break;
+            case 11u: { const float z = t / (1.0f + t); px = pack_rgb8(z, z, z); break; }
+            case 12u: px = hash_colour(sf.mat); break;
+            case 13u: px = hm ? pack_rgb8(m.Kd[0], m.Kd[1], m.Kd[2]) : px; break;
+            case 14u: px = hash_colour(sf.inst + 0x51ED27u); break;
+            case 15u: px = pack_rgb8(1.0f - u - v, u, v); break;
+            case 16u: px = hm ? pack_rgb8(m.Ke[0] / (1.0f + m.Ke[0]), m.Ke[1] / (1.0f + m.Ke[1]), m.Ke[2] / (1.0f + m.Ke[2])) : px; break;
+            default: px = hm ? pack_rgb8(m.Pr, m.Pm, m.alpha) : px; break;
+            }
+        }
+        out[i] = px;
+    }
+}
+
 // tile slabs for the multi-GPU gather
 __global__ __launch_bounds__(kBlock) void k_pack_tiles(DevFrame f, const F4* __restrict__ accum, F4* __restrict__ slab) {
     const uint32_t stride = gridDim.x * kBlock;
@@ -958,6 +1004,9 @@ void launch_accumulate(hipStream_t st, uint32_t max_blocks, const DevFrame& f, c
 }
 void launch_srgb8(hipStream_t st, const F4* accum, uint32_t npix, uint32_t* out) {
     hipLaunchKernelGGL(k_srgb8, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, st, accum, npix, out);
+}
+void launch_debug_layer(hipStream_t st, uint32_t max_blocks, const DevScene& sc, uint32_t width, uint32_t height, const CameraGPU* cam, uint32_t layer, uint32_t* out) {
+    hipLaunchKernelGGL(k_debug_layer, dim3(grid_for(width * height, max_blocks)), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, width, height, cam, layer, out);
 }
 void launch_pack_tiles(hipStream_t st, uint32_t max_blocks, const DevFrame& f, const F4* accum, F4* slab) {
     hipLaunchKernelGGL(k_pack_tiles, dim3(grid_for(f.npl, max_blocks)), dim3(kBlock), 0, st, f, accum, slab);

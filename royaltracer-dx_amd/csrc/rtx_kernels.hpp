@@ -74,6 +74,7 @@ void launch_restir_pass2(hipStream_t, uint32_t max_blocks, const DevScene&, cons
 void launch_restir_pass3(hipStream_t, uint32_t max_blocks, const DevScene&, const DevFrame&, const CameraGPU* cam, uint32_t* const bufs[6], F4* accum, unsigned long long* counters);
 void launch_accumulate(hipStream_t, uint32_t max_blocks, const DevFrame&, const DevPaths&, F4* accum);
 void launch_srgb8(hipStream_t, const F4* accum, uint32_t npix, uint32_t* out);
+void launch_debug_layer(hipStream_t, uint32_t max_blocks, const DevScene&, uint32_t width, uint32_t height, const CameraGPU* cam, uint32_t layer, uint32_t* out);
 void launch_pack_tiles(hipStream_t, uint32_t max_blocks, const DevFrame&, const F4* accum, F4* slab);
 void launch_unpack_tiles(hipStream_t, uint32_t max_blocks, const DevFrame&, uint32_t nshards, const F4* slabs, F4* accum);
 // transform-only commit: re-derive world triangles and re-quantise the wide nodes on the GPU (level_start: host array, nlevels + 1 entries)

@@ -69,7 +69,10 @@ std::vector<float> Renderer::ReadAccumulation() {
 }
 std::vector<uint8_t> Renderer::ReadOutput() {
     std::vector<uint8_t> v((size_t)m_width * m_height * 4);
-    Check(rtx_read_srgb8(m_ctx, v.data(), v.size()), "rtx_read_srgb8");
+    Check(rtx_read_layer(m_ctx, m_displayLevels[m_currentDisplayLevel], m_width, m_height, v.data(), v.size()), "rtx_read_layer");   // selectedLayer, Renderer.cpp:690
     return v;
+}
+void Renderer::OnKeyUp(uint8_t key) {
+    if (key == 'C') m_currentDisplayLevel = (m_currentDisplayLevel + 1) % (UINT)m_displayLevels.size();                             // Renderer.cpp:750-753
 }
 rtx_stats Renderer::Stats() { rtx_stats s{}; Check(rtx_get_stats(m_ctx, &s), "rtx_get_stats"); return s; }

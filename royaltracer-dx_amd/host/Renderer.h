@@ -27,7 +27,9 @@ public:
     const std::string& GetTitle() const { return m_title; }
     uint32_t FrameIndex() const { return m_time; }
     std::vector<float> ReadAccumulation();          // gPermanentData (RGBA32F)
-    std::vector<uint8_t> ReadOutput();              // gOutput layer 0 (RGBA8, sRGB)
+    std::vector<uint8_t> ReadOutput();              // the DISPLAYED layer of gOutput (RGBA8): what the reference copies to the back buffer (Renderer.cpp:690-698)
+    void OnKeyUp(uint8_t key);                      // 'C' cycles m_displayLevels (Renderer.cpp:748-754); other keys do nothing here (VK_SPACE toggles a raster path that does not exist)
+    UINT CurrentDisplayLayer() const { return m_displayLevels[m_currentDisplayLevel]; }
     rtx_stats Stats();
     rtx_ctx* Context() { return m_ctx; }
 private:
@@ -40,5 +42,7 @@ private:
     rtx_ctx* m_ctx = nullptr;
     rtx_params m_params{};
     uint32_t m_time = 0;                             // Renderer.h: m_time
+    UINT m_currentDisplayLevel = 0;                  // Renderer.h:298
+    std::vector<UINT> m_displayLevels = {0, 10, 11, 12, 13, 14, 15, 16, 17, 20, 21, 22, 23, 24, 25, 26, 27, 28};   // Renderer.h:299
     float m_prevView[16]; bool m_havePrev = false;   // m_prevViewMatrix
 };

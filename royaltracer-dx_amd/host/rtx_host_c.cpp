@@ -289,6 +289,8 @@ int rtxh_renderer_read_accum(rtxh_renderer* r, float* out, size_t bytes) {
 int rtxh_renderer_read_output(rtxh_renderer* r, uint8_t* out, size_t bytes) {
     return guarded_rc([&] { auto v = r->r->ReadOutput(); if (bytes < v.size()) throw std::runtime_error("buffer too small"); memcpy(out, v.data(), v.size()); });
 }
+int rtxh_renderer_on_key_up(rtxh_renderer* h, uint8_t key) { return guarded_rc([&] { h->r->OnKeyUp(key); }); }
+uint32_t rtxh_renderer_display_layer(const rtxh_renderer* h) { return h->r->CurrentDisplayLayer(); }
 void rtxh_renderer_destroy(rtxh_renderer* r) { if (r) { delete r->r; delete r; } }
 
 // image writers of the headless display path (host/ImageIO.h)

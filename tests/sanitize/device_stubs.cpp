@@ -18,4 +18,5 @@ int rtx_read_accum(rtx_ctx*, float*, size_t) { return RTX_ERR_NO_DEVICE; }
 int rtx_read_srgb8(rtx_ctx*, uint8_t*, size_t) { return RTX_ERR_NO_DEVICE; }
 int rtx_get_stats(rtx_ctx*, rtx_stats*) { return RTX_ERR_NO_DEVICE; }
 int rtx_load_scene_cache(rtx_ctx*, const char*) { return RTX_ERR_NO_DEVICE; }
+int rtx_read_layer(rtx_ctx*, uint32_t, uint32_t, uint32_t, uint8_t*, size_t) { return RTX_ERR_NO_DEVICE; }
 }

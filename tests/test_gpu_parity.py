@@ -340,6 +340,53 @@ def test_renderer_facade_lifecycle(rt, cornell):
     r.close()
 
 
+def test_debug_output_layers(rt, orc, cornell, golden_dir):
+    """the reference's 30-layer gOutput and its 'C' key (Renderer.h:298-299, Renderer.cpp:690-698, 748-754): layer 0 is the image, layers 10-17 are
+    first-hit attributes (recomputed here from the oracle's primary rays / closest hits / ClosestHit surfaces, in float32 like the kernel), the rest is black"""
+    garage = rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")
+    f32 = np.float32
+
+    def rgb8(v):
+        v = np.clip(np.asarray(v, np.float32), f32(0), f32(1))
+        return (v * f32(255.0) + f32(0.5)).astype(np.int32).astype(np.uint8)
+    for sc, small in ((cornell, 1), (cornell, 0), (garage, 0)):
+        W, H = 96, 54
+        c = rt.Context(0); c.set_option(rt.OPT_SMALL_SCENE, small); c.upload(sc, W / H)
+        o = orc.Oracle().load(sc, W / H)
+        p = rt.Params(width=W, height=H, spp=1, flags=1)
+        c.clear(W, H); c.render(p)
+        assert np.array_equal(c.read_layer(0), c.read_srgb8())
+        rays = o.primary_rays(p); hits = o.trace_closest(rays, 1); sf = o.surface(rays, hits)
+        hit = bits(hits)[:, 3] != 0xFFFFFFFF
+        mat = bits(sf)[:, 3]; kd = np.array([[rt.half_round(float(x)) for x in sc.materials[m][0:3]] if h else [0, 0, 0] for m, h in zip(mat, hit)], np.float32)
+        t, u, v = hits[:, 0], hits[:, 1], hits[:, 2]
+        expect = {10: rgb8(sf[:, 4:7] * f32(0.5) + f32(0.5)), 11: rgb8(np.repeat((t / (f32(1.0) + t))[:, None], 3, 1)), 13: rgb8(kd),
+                  15: rgb8(np.stack([f32(1.0) - u - v, u, v], 1))}
+        for layer, rgb in expect.items():
+            got = c.read_layer(layer).reshape(-1, 4)
+            assert (got[:, 3] == 255).all() and (got[~hit, :3] == 0).all(), layer
+            assert np.array_equal(got[hit, :3], rgb[hit]), (layer, small)
+        ids = c.read_layer(12).reshape(-1, 4)
+        for m in np.unique(mat[hit]):                                  # one colour per material id, different ids differ
+            assert len(np.unique(ids[hit & (mat == m)][:, :3], axis=0)) == 1
+        assert len(np.unique(ids[hit][:, :3], axis=0)) == len(np.unique(mat[hit]))
+        for layer in (1, 9, 20, 28, 29):
+            g = c.read_layer(layer); assert (g[..., :3] == 0).all() and (g[..., 3] == 255).all()
+        with pytest.raises(rt.RtxError):
+            c.read_layer(30)
+        c.close()
+    r = rt.Renderer(64, 36, "layers"); r.set_scene(cornell); r.params.flags = 1; r.on_init(); r.on_update(); r.on_render()
+    seen = [r.display_layer]
+    img0 = r.read_output()
+    for _ in range(18):
+        r.on_key_up("C"); seen.append(r.display_layer)
+    assert seen == [0, 10, 11, 12, 13, 14, 15, 16, 17, 20, 21, 22, 23, 24, 25, 26, 27, 28, 0]      # m_displayLevels, wrapping around
+    assert np.array_equal(r.read_output(), img0)
+    r.on_key_up("C"); n10 = r.read_output()
+    assert r.display_layer == 10 and not np.array_equal(n10, img0) and (n10[..., 3] == 255).all()
+    r.close()
+
+
 def test_error_paths(rt, cornell):
     c = rt.Context(0)
     with pytest.raises(rt.RtxError):
