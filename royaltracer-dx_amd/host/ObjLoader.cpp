@@ -110,7 +110,9 @@ struct MtlRec { std::string name; float Kd[3] = {0, 0, 0}, Ks[3] = {0, 0, 0}, Ke
 std::string parse_texname(const char* p) {
     auto word = [&](const char* k) { size_t n = strlen(k); if (!strncmp(p, k, n) && (p[n] == ' ' || p[n] == '\t')) { p += n + 1; return true; } return false; };
     auto skip_tok = [&]() { p = skip_ws(p); while (*p && *p != ' ' && *p != '\t') p++; };
-    auto skip_reals = [&](int n) { for (int i = 0; i < n; i++) { p = skip_ws(p); char* e; (void)strtod(p, &e); if (e == p) break; p = e; } };
+    // tinyobj's parseReal advances past one blank-separated word whether or not it is a number, and parseReal3 always takes three: `-o 0.5 a b.png`
+    // eats `a` and `b.png` as the missing y and z (tiny_obj_loader.h: parseReal / parseReal3) — restated, since the reference's loader sees exactly that
+    auto skip_reals = [&](int n) { for (int i = 0; i < n; i++) skip_tok(); };
     std::string name;
     while (true) {
         p = skip_ws(p);
@@ -134,6 +136,7 @@ void load_mtl(const std::string& path, std::vector<MtlRec>& mats, std::unordered
     std::string line; MtlRec cur; bool have = false;
     bool has_kd = false;                    // tiny_obj_loader.h:2083-2085,2173: set by any `Kd` line and (sic) never cleared at `newmtl`
     auto flush = [&]() { if (have) { map[cur.name] = (int)mats.size(); mats.push_back(cur); } };
+    auto set_tex = [&](int slot, const char* q) { std::string n = parse_texname(q); if (!n.empty()) cur.tex[slot] = n; };   // a statement without a name (its options ate it) leaves the slot as it was, as tinyobj does
     while (std::getline(f, line)) {
         if (!line.empty() && line.back() == '\r') line.pop_back();
         const char* p = skip_ws(line.c_str());
@@ -141,7 +144,7 @@ void load_mtl(const std::string& path, std::vector<MtlRec>& mats, std::unordered
         auto key = [&](const char* k) { size_t n = strlen(k); if (!strncmp(p, k, n) && (p[n] == ' ' || p[n] == '\t')) { p += n; return true; } return false; };
         if (key("newmtl")) { flush(); cur = MtlRec(); have = true; cur.name = skip_ws(p); while (!cur.name.empty() && (cur.name.back() == ' ' || cur.name.back() == '\t')) cur.name.pop_back(); }
         else if (key("Kd")) { for (int i = 0; i < 3; i++) parse_float(p, cur.Kd[i]); has_kd = true; }
-        else if (key("map_Kd")) { if (!has_kd) cur.Kd[0] = cur.Kd[1] = cur.Kd[2] = 0.6f; cur.tex[MAP_KD] = parse_texname(p); }   // a diffuse texture without a Kd before it: tiny_obj_loader.h:2328-2341
+        else if (key("map_Kd")) { if (!has_kd) cur.Kd[0] = cur.Kd[1] = cur.Kd[2] = 0.6f; set_tex(MAP_KD, p); }   // a diffuse texture without a Kd before it: tiny_obj_loader.h:2328-2341
         else if (key("Ks")) { for (int i = 0; i < 3; i++) parse_float(p, cur.Ks[i]); }
         else if (key("Ke")) { for (int i = 0; i < 3; i++) parse_float(p, cur.Ke[i]); }
         else if (key("d")) { parse_float(p, cur.d); cur.has_d = true; }
@@ -159,18 +162,18 @@ void load_mtl(const std::string& path, std::vector<MtlRec>& mats, std::unordered
         else if (key("Ka")) { for (int i = 0; i < 3; i++) parse_float(p, cur.Ka[i]); }
         else if (key("Kt") || key("Tf")) { for (int i = 0; i < 3; i++) parse_float(p, cur.Tf[i]); }
         else if (key("illum")) { float v = 0; if (parse_float(p, v)) cur.illum = (int)v; }
-        else if (key("map_Ka")) cur.tex[MAP_KA] = parse_texname(p);
-        else if (key("map_Ks")) cur.tex[MAP_KS] = parse_texname(p);
-        else if (key("map_Ke")) cur.tex[MAP_KE] = parse_texname(p);
-        else if (key("map_Ns")) cur.tex[MAP_NS] = parse_texname(p);
-        else if (key("map_bump") || key("map_Bump") || key("bump")) cur.tex[MAP_BUMP] = parse_texname(p);
-        else if (key("map_d")) cur.tex[MAP_D] = parse_texname(p);
-        else if (key("disp")) cur.tex[MAP_DISP] = parse_texname(p);
-        else if (key("refl")) cur.tex[MAP_REFL] = parse_texname(p);
-        else if (key("map_Pr")) cur.tex[MAP_PR] = parse_texname(p);
-        else if (key("map_Pm")) cur.tex[MAP_PM] = parse_texname(p);
-        else if (key("map_Ps")) cur.tex[MAP_PS] = parse_texname(p);
-        else if (key("norm")) cur.tex[MAP_NORM] = parse_texname(p);
+        else if (key("map_Ka")) set_tex(MAP_KA, p);
+        else if (key("map_Ks")) set_tex(MAP_KS, p);
+        else if (key("map_Ke")) set_tex(MAP_KE, p);
+        else if (key("map_Ns")) set_tex(MAP_NS, p);
+        else if (key("map_bump") || key("map_Bump") || key("bump")) set_tex(MAP_BUMP, p);
+        else if (key("map_d")) set_tex(MAP_D, p);
+        else if (key("disp")) set_tex(MAP_DISP, p);
+        else if (key("refl")) set_tex(MAP_REFL, p);
+        else if (key("map_Pr")) set_tex(MAP_PR, p);
+        else if (key("map_Pm")) set_tex(MAP_PM, p);
+        else if (key("map_Ps")) set_tex(MAP_PS, p);
+        else if (key("norm")) set_tex(MAP_NORM, p);
     }
     flush();
 }
