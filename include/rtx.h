@@ -149,8 +149,14 @@ int  rtx_read_pass1_buffers(rtx_ctx*, void* reservoirs_di40, void* reservoirs_gi
    with the pairwise MIS of MIS_v6.hlsl / MIS_GI_v6.hlsl.  `spp` = number of consecutive frames (frame_seed, frame_seed+1, ...)
    rendered with the current camera; each adds ReconnectDI*W + f_gi*W_gi to u1.  u3/u5/u7 (`g_*_last`) persist in the context
    between calls; rtx_set_camera keeps the previous view/projection for the reprojection; rtx_restir_reset zeroes the history.
-   Needs the whole image in one context (shard_count = 1): pass 3 reads neighbours within 20 px. */
+   ON SHARDS (shard_count > 1; one frame per call: spp = 1): passes 1 and 2 run on the shard's tiles dilated by the 20-px radius of the spatial pass (the
+   halo is recomputed, seeds depend on the pixel only), pass 3 and the accumulation on the shard's own tiles; between frames the shards exchange the history of
+   their own tiles — rtx_restir_pack_state -> ONE all-gather (140 B per pixel) -> rtx_restir_unpack_state — because the temporal pass reprojects to arbitrary
+   pixels.  Images and histories are bit-identical to the unsharded run. */
 int  rtx_render_restir(rtx_ctx*, const rtx_params*);
+int  rtx_restir_state_slab_bytes(const rtx_params*, size_t* bytes_per_shard);
+int  rtx_restir_pack_state(rtx_ctx*, const rtx_params*, void* device_slab);                       /* u3 / u5 / u7 of my tiles -> slab */
+int  rtx_restir_unpack_state(rtx_ctx*, const rtx_params*, const void* device_slabs_all_shards);   /* all shards' slabs -> my u3 / u5 / u7 */
 int  rtx_restir_reset(rtx_ctx*);
 int  rtx_read_restir_last(rtx_ctx*, void* reservoirs_di40, void* reservoirs_gi40, void* samples60, size_t slots);   /* u3 / u5 / u7 */
 int  rtx_read_accum(rtx_ctx*, float* rgba32f, size_t bytes);       /* copy of u1 to the host */

@@ -105,6 +105,9 @@ _sig("rtx_read_accum", C.c_int, _vp, _vp, C.c_size_t)
 _sig("rtx_render_v6_pass1", C.c_int, _vp, C.POINTER(Params))
 _sig("rtx_render_restir", C.c_int, _vp, C.POINTER(Params))
 _sig("rtx_restir_reset", C.c_int, _vp)
+_sig("rtx_restir_state_slab_bytes", C.c_int, C.POINTER(Params), C.POINTER(C.c_size_t))
+_sig("rtx_restir_pack_state", C.c_int, _vp, C.POINTER(Params), _vp)
+_sig("rtx_restir_unpack_state", C.c_int, _vp, C.POINTER(Params), _vp)
 _sig("rtx_read_restir_last", C.c_int, _vp, _vp, _vp, _vp, C.c_size_t)
 _sig("rtx_pass1_slots", C.c_size_t, _u32, _u32)
 _sig("rtx_read_pass1_buffers", C.c_int, _vp, _vp, _vp, _vp, C.c_size_t)
@@ -465,6 +468,17 @@ class Context:
         """`params.spp` consecutive ReSTIR frames (pass 1 + temporal + spatial) with the current camera"""
         self.width, self.height = params.width, params.height
         self._ck(lib.rtx_render_restir(self._h, C.byref(params)), "rtx_render_restir")
+
+    def restir_state_slab_bytes(self, params):
+        b = C.c_size_t()
+        self._ck(lib.rtx_restir_state_slab_bytes(C.byref(params), C.byref(b)), "rtx_restir_state_slab_bytes")
+        return b.value
+
+    def restir_pack_state(self, params, device_ptr):
+        self._ck(lib.rtx_restir_pack_state(self._h, C.byref(params), _vp(device_ptr)), "rtx_restir_pack_state")
+
+    def restir_unpack_state(self, params, device_ptr):
+        self._ck(lib.rtx_restir_unpack_state(self._h, C.byref(params), _vp(device_ptr)), "rtx_restir_unpack_state")
 
     def restir_reset(self):
         self._ck(lib.rtx_restir_reset(self._h), "rtx_restir_reset")

@@ -44,6 +44,7 @@ struct rtx_ctx {
     // path state
     DevBuf d_hitmask, d_order, d_pmask;
     bool lpt_order = true;          // RTX_OPT_LPT_ORDER: fused kernels take their sub-queues longest first
+    DevBuf d_halo; uint32_t halo_count = 0; uint32_t halo_key[5] = {0, 0, 0, 0, 0};     // ReSTIR on shards: the shard's tiles dilated by 20 px, as a pixel list (width, height, tile, rank, count)
     bool fused_bvh = false;         // RTX_OPT_FUSED_BVH: general path = one k_bounce_bvh launch per batch (trace -> shade -> shadow per sub-queue and bounce); measured SLOWER, default off
     DevBuf d_hitq;
     DevBuf d_ray_o, d_ray_d, d_thr, d_rad, d_hit, d_sh_o, d_sh_d, d_sh_c, d_queue[2], d_counters;
@@ -110,7 +111,7 @@ void rtx_destroy(rtx_ctx* c) {
     else (void)hipDeviceSynchronize();
     DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_small_poly, &c->d_objtris, &c->d_node_aabb, &c->d_scale, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
                      &c->d_thr, &c->d_rad, &c->d_hit, &c->d_hitmask, &c->d_order, &c->d_pmask, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
-                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq};
+                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq, &c->d_halo};
     for (DevBuf* b : all) b->release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
@@ -551,8 +552,37 @@ int rtx_render_restir(rtx_ctx* c, const rtx_params* p) {
     int r = make_frame(c, p, f);
     if (r) return r;
     if (p->max_bounces > 64 || p->nee_samples > 16) { c->err = "params: max_bounces <= 64, nee_samples <= 16"; return RTX_ERR_INVALID; }
-    if (p->shard_count > 1) { c->err = "render_restir: the spatial pass reads neighbouring pixels; shard_count must be 1"; return RTX_ERR_INVALID; }
+    // ReSTIR ON SHARDS (shard_count > 1).  The spatial pass of a pixel reads this frame's pass-1 / pass-2 records of neighbours within 20 px
+    // (RayGen_v6_pass3.hlsl:46-372) and the temporal pass reads last frame's history at an arbitrary reprojected pixel (RayGen_v6_pass2.hlsl:46-204).  So a shard
+    //   * runs passes 1 and 2 on its tiles DILATED by 20 px (the halo is recomputed: seeds depend on the pixel only, results are what the owner computes),
+    //   * runs pass 3 (and the accumulation) on its own tiles,
+    //   * and after the frame the shards exchange the history of their own tiles: rtx_restir_pack_state -> one all-gather -> rtx_restir_unpack_state,
+    // which the caller does between frames — hence one frame per call.  Images and histories are bit-identical to the unsharded run.
+    const bool sharded = p->shard_count > 1;
+    if (sharded && p->spp != 1) { c->err = "render_restir: on shards the history has to be exchanged after every frame (rtx_restir_pack_state / unpack_state): spp must be 1"; return RTX_ERR_INVALID; }
+    if (sharded && (p->width > 65535u || p->height > 65535u)) { c->err = "render_restir: sharded images are limited to 65535 x 65535"; return RTX_ERR_INVALID; }
     if ((r = ensure_accum(c, p->width, p->height, false))) return r;
+    const uint32_t* halo = nullptr; uint32_t nhalo = 0;
+    if (sharded) {
+        const uint32_t key[5] = {p->width, p->height, f.tile_size, p->shard_rank, p->shard_count};
+        if (memcmp(key, c->halo_key, sizeof(key)) != 0 || !c->d_halo.p) {
+            const uint32_t W = p->width, H = p->height, ts = f.tile_size, R = 20u;           // spatial radius: RayGen_v6_pass3.hlsl (random pixel within 20)
+            std::vector<uint8_t> mask((size_t)W * H, 0);
+            for (uint32_t t = p->shard_rank; t < f.tiles_x * f.tiles_y; t += p->shard_count) {
+                const uint32_t tx = t % f.tiles_x, ty = t / f.tiles_x;
+                const uint32_t x0 = tx * ts > R ? tx * ts - R : 0u, y0 = ty * ts > R ? ty * ts - R : 0u;
+                const uint32_t x1 = std::min(W, (tx + 1) * ts + R), y1 = std::min(H, (ty + 1) * ts + R);
+                for (uint32_t y = y0; y < y1; y++) memset(&mask[(size_t)y * W + x0], 1, x1 - x0);
+            }
+            std::vector<uint32_t> list;
+            for (uint32_t by = 0; by < H; by += 8) for (uint32_t bx = 0; bx < W; bx += 8)         // 8 x 8 blocks, so a wave covers a compact screen region
+                for (uint32_t y = by; y < std::min(H, by + 8); y++) for (uint32_t x = bx; x < std::min(W, bx + 8); x++)
+                    if (mask[(size_t)y * W + x]) list.push_back(x | (y << 16));
+            if ((r = upload(c, c->d_halo, list))) return r;
+            c->halo_count = (uint32_t)list.size(); memcpy(c->halo_key, key, sizeof(key));
+        }
+        halo = (const uint32_t*)c->d_halo.p; nhalo = c->halo_count;
+    }
     const size_t slots = rtx_pass1_slots(p->width, p->height);
     if ((r = p1_alloc(c, slots))) return r;
     HIPCHK(c, c->d_last_di.ensure(slots * 40)); HIPCHK(c, c->d_last_gi.ensure(slots * 40)); HIPCHK(c, c->d_last_sd.ensure(slots * 60));
@@ -571,8 +601,8 @@ int rtx_render_restir(rtx_ctx* c, const rtx_params* p) {
     for (uint32_t fr = 0; fr < p->spp; fr++) {                       // spp = number of consecutive frames with this camera
         DevFrame ff = f; ff.frame_seed = p->frame_seed + fr;
         HIPCHK(c, hipMemsetAsync(scratch.p, 0, (size_t)p->width * p->height * 16, c->stream));
-        launch_v6_pass1(c->stream, mbk, c->dsc, ff, cam, 1u, (F4*)scratch.p, bufs[0], bufs[1], bufs[2], (unsigned long long*)c->d_p1cnt.p);   // Renderer.cpp:651-654
-        launch_restir_pass2(c->stream, mbk, c->dsc, ff, cam, bufs, (unsigned long long*)c->d_p1cnt.p);                                       // :662-664
+        launch_v6_pass1(c->stream, mbk, c->dsc, ff, cam, 1u, (F4*)scratch.p, bufs[0], bufs[1], bufs[2], (unsigned long long*)c->d_p1cnt.p, halo, nhalo);   // Renderer.cpp:651-654
+        launch_restir_pass2(c->stream, mbk, c->dsc, ff, cam, bufs, (unsigned long long*)c->d_p1cnt.p, halo, nhalo);                                       // :662-664
         launch_restir_pass3(c->stream, mbk, c->dsc, ff, cam, bufs, c->accum_ptr(), (unsigned long long*)c->d_p1cnt.p);                       // :671-673
     }
     HIPCHK(c, hipEventRecord(c->ev_end, c->stream));
@@ -584,6 +614,43 @@ int rtx_render_restir(rtx_ctx* c, const rtx_params* p) {
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) c->stats.render_ms = ms;
     c->stats.rays_primary = cnt[0]; c->stats.rays_extension = cnt[1]; c->stats.rays_shadow = cnt[2]; c->stats.paths = cnt[0]; c->stats.primary_hits = 0;
+    return RTX_OK;
+}
+
+// ---- ReSTIR on shards: exchange of the history (u3 / u5 / u7) of the shard's own tiles, see rtx_render_restir ----
+int rtx_restir_state_slab_bytes(const rtx_params* p, size_t* bytes) {
+    if (!bytes) return RTX_ERR_INVALID;
+    uint32_t ts = 0, cnt = 0; uint64_t npl = 0;
+    if (const char* e = validate_tiling(p, ts, cnt, npl)) { g_create_err = e; return RTX_ERR_INVALID; }
+    *bytes = (size_t)npl * 140;             // 40 + 40 + 60 bytes per local pixel slot
+    return RTX_OK;
+}
+static int restir_state_bufs(rtx_ctx* c, const rtx_params* p, DevFrame& f, uint32_t* bufs[6]) {
+    int r = make_frame(c, p, f); if (r) return r;
+    const size_t slots = rtx_pass1_slots(p->width, p->height);
+    if (!c->last_slots || c->last_slots != slots) { c->err = "restir state: no ReSTIR history of that image size (render a frame first)"; return RTX_ERR_STATE; }
+    bufs[0] = (uint32_t*)c->d_res_di.p; bufs[1] = (uint32_t*)c->d_res_gi.p; bufs[2] = (uint32_t*)c->d_sdata.p;
+    bufs[3] = (uint32_t*)c->d_last_di.p; bufs[4] = (uint32_t*)c->d_last_gi.p; bufs[5] = (uint32_t*)c->d_last_sd.p;
+    return RTX_OK;
+}
+int rtx_restir_pack_state(rtx_ctx* c, const rtx_params* p, void* slab) {
+    BIND(c);
+    DevFrame f; uint32_t* bufs[6];
+    int r = restir_state_bufs(c, p, f, bufs); if (r) return r;
+    if (!slab) return RTX_ERR_INVALID;
+    launch_restir_pack_state(c->stream, (uint32_t)c->num_cus * 8u, f, bufs, (uint32_t*)slab);
+    HIPCHK(c, hipGetLastError());
+    if (c->own_stream) HIPCHK(c, hipStreamSynchronize(c->stream));      // on a caller-bound stream the gather that follows is stream-ordered
+    return RTX_OK;
+}
+int rtx_restir_unpack_state(rtx_ctx* c, const rtx_params* p, const void* slabs) {
+    BIND(c);
+    DevFrame f; uint32_t* bufs[6];
+    int r = restir_state_bufs(c, p, f, bufs); if (r) return r;
+    if (!slabs) return RTX_ERR_INVALID;
+    launch_restir_unpack_state(c->stream, (uint32_t)c->num_cus * 8u, f, f.shard_count, (const uint32_t*)slabs, bufs);
+    HIPCHK(c, hipGetLastError());
+    if (c->own_stream) HIPCHK(c, hipStreamSynchronize(c->stream));
     return RTX_OK;
 }
 

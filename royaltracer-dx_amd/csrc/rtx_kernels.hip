@@ -988,12 +988,21 @@ void launch_shade(hipStream_t st, const DevScene& sc, const DevFrame& f, const D
     else hipLaunchKernelGGL(k_shade<false>, dim3(f.nblocks), dim3(kBlock), 0, st, sc, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);
 }
 void launch_v6_pass1(hipStream_t st, uint32_t max_blocks, const DevScene& sc, const DevFrame& f, const CameraGPU* cam, uint32_t sample_id,
-                     F4* accum, uint32_t* res_di, uint32_t* res_gi, uint32_t* sdata, unsigned long long* counters) {
-    hipLaunchKernelGGL(k_v6_pass1, dim3(grid_for(f.npl, max_blocks)), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, cam, sample_id, accum, res_di, res_gi, sdata, counters);
+                     F4* accum, uint32_t* res_di, uint32_t* res_gi, uint32_t* sdata, unsigned long long* counters, const uint32_t* pixels, uint32_t npixels) {
+    hipLaunchKernelGGL(k_v6_pass1, dim3(grid_for(pixels ? npixels : f.npl, max_blocks)), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, cam, sample_id, accum, res_di, res_gi, sdata, counters, pixels, npixels);
 }
-void launch_restir_pass2(hipStream_t st, uint32_t max_blocks, const DevScene& sc, const DevFrame& f, const CameraGPU* cam, uint32_t* const bufs[6], unsigned long long* counters) {
+void launch_restir_pass2(hipStream_t st, uint32_t max_blocks, const DevScene& sc, const DevFrame& f, const CameraGPU* cam, uint32_t* const bufs[6], unsigned long long* counters,
+                         const uint32_t* pixels, uint32_t npixels) {
     RestirBufs B = {bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], bufs[5]};
-    hipLaunchKernelGGL(k_restir_pass2, dim3(grid_for(f.npl, max_blocks)), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, cam, B, counters);
+    hipLaunchKernelGGL(k_restir_pass2, dim3(grid_for(pixels ? npixels : f.npl, max_blocks)), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, cam, B, counters, pixels, npixels);
+}
+void launch_restir_pack_state(hipStream_t st, uint32_t max_blocks, const DevFrame& f, uint32_t* const bufs[6], uint32_t* slab) {
+    RestirBufs B = {bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], bufs[5]};
+    hipLaunchKernelGGL(k_restir_pack_state, dim3(grid_for(f.npl, max_blocks)), dim3(kBlock), 0, st, f, B, slab);
+}
+void launch_restir_unpack_state(hipStream_t st, uint32_t max_blocks, const DevFrame& f, uint32_t nshards, const uint32_t* slabs, uint32_t* const bufs[6]) {
+    RestirBufs B = {bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], bufs[5]};
+    hipLaunchKernelGGL(k_restir_unpack_state, dim3(grid_for(f.npl * nshards, max_blocks)), dim3(kBlock), 0, st, f, nshards, slabs, B);
 }
 void launch_restir_pass3(hipStream_t st, uint32_t max_blocks, const DevScene& sc, const DevFrame& f, const CameraGPU* cam, uint32_t* const bufs[6], F4* accum, unsigned long long* counters) {
     RestirBufs B = {bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], bufs[5]};

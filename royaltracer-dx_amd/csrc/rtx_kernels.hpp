@@ -68,9 +68,14 @@ void launch_order_queues(hipStream_t, const uint32_t* qcount, uint32_t G, uint32
 void launch_trace_shadow(hipStream_t, const DevFrame&, const DevScene&, const DevPaths&, uint32_t j, const uint32_t* shcount);
 void launch_shade(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, uint32_t bounce,
                   const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts);
+// pixels / npixels (optional): an explicit work list (x | y << 16) instead of the shard's own tiles — ReSTIR on shards runs passes 1 and 2 on the tiles dilated by 20 px
 void launch_v6_pass1(hipStream_t, uint32_t max_blocks, const DevScene&, const DevFrame&, const CameraGPU* cam, uint32_t sample_id,
-                     F4* accum, uint32_t* res_di, uint32_t* res_gi, uint32_t* sdata, unsigned long long* counters);
-void launch_restir_pass2(hipStream_t, uint32_t max_blocks, const DevScene&, const DevFrame&, const CameraGPU* cam, uint32_t* const bufs[6], unsigned long long* counters);
+                     F4* accum, uint32_t* res_di, uint32_t* res_gi, uint32_t* sdata, unsigned long long* counters, const uint32_t* pixels = nullptr, uint32_t npixels = 0);
+void launch_restir_pass2(hipStream_t, uint32_t max_blocks, const DevScene&, const DevFrame&, const CameraGPU* cam, uint32_t* const bufs[6], unsigned long long* counters,
+                         const uint32_t* pixels = nullptr, uint32_t npixels = 0);
+// the ReSTIR history (u3 / u5 / u7) of the shard's own tiles <-> [local slot][35 dwords] slab, for the per-frame all-gather of sharded ReSTIR
+void launch_restir_pack_state(hipStream_t, uint32_t max_blocks, const DevFrame&, uint32_t* const bufs[6], uint32_t* slab);
+void launch_restir_unpack_state(hipStream_t, uint32_t max_blocks, const DevFrame&, uint32_t nshards, const uint32_t* slabs, uint32_t* const bufs[6]);
 void launch_restir_pass3(hipStream_t, uint32_t max_blocks, const DevScene&, const DevFrame&, const CameraGPU* cam, uint32_t* const bufs[6], F4* accum, unsigned long long* counters);
 void launch_accumulate(hipStream_t, uint32_t max_blocks, const DevFrame&, const DevPaths&, F4* accum);
 void launch_srgb8(hipStream_t, const F4* accum, uint32_t npix, uint32_t* out);

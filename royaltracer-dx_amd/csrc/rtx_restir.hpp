@@ -249,9 +249,18 @@ __device__ __forceinline__ void store_res(uint32_t* dst, const Res& r) {        
     dst[8] = half_bits_dev(r.L2.x) | (half_bits_dev(r.L2.y) << 16); dst[9] = half_bits_dev(r.L2.z) | ((r.M & 0xFFFFu) << 16);
 }
 
+// Work items of the thread-per-pixel passes: the shard's own tiles (slot_to_pixel), or — ReSTIR on shards, passes 1 and 2 — an explicit pixel list
+// (x | y << 16): the shard's tiles DILATED by the 20-pixel radius of the spatial pass, whose neighbour reads (RayGen_v6_pass3.hlsl:46-372) must find
+// this frame's pass-1 / pass-2 records of pixels that other shards own.  The halo is recomputed, not exchanged (seeds depend on the pixel only).
+__device__ __forceinline__ bool pass_pixel(const DevFrame& f, const uint32_t* __restrict__ pixels, uint32_t i, uint32_t& x, uint32_t& y) {
+    if (pixels) { const uint32_t v = pixels[i]; x = v & 0xFFFFu; y = v >> 16; return true; }
+    return slot_to_pixel(f, i, x, y);
+}
+
 __global__ __launch_bounds__(kBlock) void k_v6_pass1(DevScene sc, const SmallRecPair* __restrict__ small, DevFrame f, const CameraGPU* __restrict__ cam_p, uint32_t sample_id,
                                                      F4* __restrict__ accum, uint32_t* __restrict__ res_di, uint32_t* __restrict__ res_gi, uint32_t* __restrict__ sdata,
-                                                     unsigned long long* __restrict__ counters /* primary, extension, shadow */) {
+                                                     unsigned long long* __restrict__ counters /* primary, extension, shadow */,
+                                                     const uint32_t* __restrict__ pixels = nullptr, uint32_t npixels = 0) {
     extern __shared__ F4 lds[];
     __shared__ CameraGPU cam;
     if (threadIdx.x < 64) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
@@ -259,9 +268,10 @@ __global__ __launch_bounds__(kBlock) void k_v6_pass1(DevScene sc, const SmallRec
     __syncthreads();
     uint32_t n_prim = 0, n_ext = 0, n_sh = 0;
     const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < f.npl; pl += stride) {
+    const uint32_t nitems = pixels ? npixels : f.npl;
+    for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < nitems; pl += stride) {
         uint32_t x, y;
-        if (!slot_to_pixel(f, pl, x, y)) continue;
+        if (!pass_pixel(f, pixels, pl, x, y)) continue;
         uint32_t s0, s1; seed_init(x, y, sample_id, f.frame_seed, s0, s1);
         f3 origin, dir; primary_ray(cam, f.width, f.height, x, y, 0.0f, 0.0f, origin, dir);      // jitter = 0, pass1:80-82
         Res rdi; rdi.x2 = mk3(0, 0, 0); rdi.w_sum = 0.0f; rdi.n2 = mk3(0, 0, 0); rdi.W = 0.0f; rdi.L2 = mk3(0, 0, 0); rdi.M = 0;
@@ -397,7 +407,7 @@ __device__ __forceinline__ void random_pixel_dev(uint32_t radius, uint32_t w, ui
 struct RestirBufs { uint32_t *cur_di, *cur_gi, *cur_sd, *last_di, *last_gi, *last_sd; };
 
 __global__ __launch_bounds__(kBlock) void k_restir_pass2(DevScene sc, const SmallRecPair* __restrict__ small, DevFrame f, const CameraGPU* __restrict__ cam_p, RestirBufs B,
-                                                         unsigned long long* __restrict__ counters) {
+                                                         unsigned long long* __restrict__ counters, const uint32_t* __restrict__ pixels = nullptr, uint32_t npixels = 0) {
     extern __shared__ F4 lds[];
     __shared__ CameraGPU cam;
     if (threadIdx.x < 64) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
@@ -405,9 +415,10 @@ __global__ __launch_bounds__(kBlock) void k_restir_pass2(DevScene sc, const Smal
     __syncthreads();
     uint32_t n_sh = 0;
     const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < f.npl; pl += stride) {
+    const uint32_t nitems = pixels ? npixels : f.npl;
+    for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < nitems; pl += stride) {
         uint32_t x, y;
-        if (!slot_to_pixel(f, pl, x, y)) continue;
+        if (!pass_pixel(f, pixels, pl, x, y)) continue;
         const size_t slot = map_pixel_id(f.width, x, y);
         Res rc = load_res_dev(B.cur_di + slot * 10), gc = load_res_dev(B.cur_gi + slot * 10);
         const SData sd = load_sd_dev(B.cur_sd + slot * 15);
@@ -575,6 +586,35 @@ __global__ __launch_bounds__(kBlock) void k_restir_pass3(DevScene sc, const Smal
         if (finite3(out)) { F4 a = accum[(size_t)y * W + x]; a.x = a.x + out.x; a.y = a.y + out.y; a.z = a.z + out.z; a.w = a.w + 1.0f; accum[(size_t)y * W + x] = a; }
     }
     atomicAdd(&counters[2], (unsigned long long)n_sh);
+}
+
+// ReSTIR on shards: the history a frame leaves behind (u3 / u5 / u7 = g_Reservoirs_last, g_Reservoirs_last_gi, g_sample_last: 40 + 40 + 60 B per pixel) is written by the
+// spatial pass for the shard's own pixels only, but the next frame's temporal pass reprojects to ARBITRARY pixels (RayGen_v6_pass2.hlsl:46-204).  So after every frame the
+// shards exchange their own tiles' records: pack -> ONE all-gather -> unpack, exactly like the framebuffer tiles (slab: [local slot][35 dwords]).
+constexpr uint32_t kStateDwords = 35;       // 10 + 10 + 15
+__global__ __launch_bounds__(kBlock) void k_restir_pack_state(DevFrame f, RestirBufs B, uint32_t* __restrict__ slab) {
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < f.npl; pl += stride) {
+        uint32_t x, y;
+        uint32_t* o = slab + (size_t)pl * kStateDwords;
+        if (!slot_to_pixel(f, pl, x, y)) { for (uint32_t k = 0; k < kStateDwords; k++) o[k] = 0u; continue; }
+        const size_t slot = map_pixel_id(f.width, x, y);
+        for (int k = 0; k < 10; k++) { o[k] = B.last_di[slot * 10 + k]; o[10 + k] = B.last_gi[slot * 10 + k]; }
+        for (int k = 0; k < 15; k++) o[20 + k] = B.last_sd[slot * 15 + k];
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_restir_unpack_state(DevFrame f, uint32_t nshards, const uint32_t* __restrict__ slabs, RestirBufs B) {
+    const uint32_t stride = gridDim.x * kBlock;
+    const uint32_t total = f.npl * nshards;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
+        DevFrame g = f; g.shard_rank = i / f.npl; g.shard_count = nshards;
+        uint32_t x, y;
+        if (!slot_to_pixel(g, i - g.shard_rank * f.npl, x, y)) continue;
+        const size_t slot = map_pixel_id(f.width, x, y);
+        const uint32_t* in = slabs + (size_t)i * kStateDwords;
+        for (int k = 0; k < 10; k++) { B.last_di[slot * 10 + k] = in[k]; B.last_gi[slot * 10 + k] = in[10 + k]; }
+        for (int k = 0; k < 15; k++) B.last_sd[slot * 15 + k] = in[20 + k];
+    }
 }
 
 }  // namespace rtx

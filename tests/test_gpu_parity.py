@@ -607,6 +607,50 @@ def test_restir_garage_with_camera_motion(rt, orc, golden_dir):
     c.close()
 
 
+@pytest.mark.parametrize("nshards", [2, 3])
+def test_restir_on_shards_equals_the_unsharded_frames(rt, orc, golden_dir, nshards):
+    """SURVEY 8(f1) on pixel-tile shards: every shard runs passes 1 + 2 on its tiles dilated by the 20-px radius of the spatial pass, pass 3 on its own tiles, and
+    after each frame the shards exchange the history (u3 / u5 / u7) of their own tiles (pack -> gather -> unpack; the gather is a torch.cat here, the
+    shards being contexts on one GPU).  Three frames with a moving camera on garage.obj + monke.obj (GGX + Lambert, two instances): every shard's tiles of the
+    accumulation buffer and the complete history equal the unsharded run's (which equals the oracle's: test_restir_garage_with_camera_motion)."""
+    import torch
+    from royaltracer_dx_amd import sharding
+    sc = rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")
+    W, H, TS = 160, 96, 32
+    cams = [rt.lookat((-1.5 + 0.05 * k, 1.5, 3.5 - 0.04 * k), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0)) for k in range(3)]
+    proj = rt.perspective_fov_rh(np.radians(60.0), W / H, 0.1, 1000.0)
+    base = dict(width=W, height=H, spp=1, max_bounces=3, nee_samples=4, flags=0, tile_size=TS)
+    ref = rt.Context(0); ref.upload(sc, W / H); ref.restir_reset(); ref.clear(W, H)
+    for k, v in enumerate(cams):
+        ref.set_camera(v, proj); ref.render_restir(rt.Params(frame_seed=70 + k, **base))
+    ref_img, ref_last = ref.read_accum(), ref.read_restir_last()
+    ranks = []
+    for r in range(nshards):
+        c = rt.Context(0); c.upload(sc, W / H); c.restir_reset(); c.clear(W, H); ranks.append(c)
+    for k, v in enumerate(cams):
+        slabs = []
+        for r, c in enumerate(ranks):
+            p = rt.Params(frame_seed=70 + k, shard_rank=r, shard_count=nshards, **base)
+            c.set_camera(v, proj); c.render_restir(p)
+            slab = torch.empty(c.restir_state_slab_bytes(p) // 4, dtype=torch.float32, device="cuda:0")
+            c.restir_pack_state(p, slab.data_ptr()); slabs.append(slab)
+        torch.cuda.synchronize()
+        gathered = torch.cat(slabs)                                      # what ONE all_gather_into_tensor leaves on every rank
+        for r, c in enumerate(ranks):
+            c.restir_unpack_state(rt.Params(frame_seed=70 + k, shard_rank=r, shard_count=nshards, **base), gathered.data_ptr())
+    own = sharding.owner_map(W, H, TS, nshards)
+    for r, c in enumerate(ranks):
+        img = c.read_accum()
+        assert np.array_equal(bits(img[own == r]), bits(ref_img[own == r])), r
+        assert not img[own != r].any()
+        for a, b in zip(c.read_restir_last(), ref_last):
+            assert np.array_equal(a, b), r
+        with pytest.raises(rt.RtxError):
+            c.render_restir(rt.Params(frame_seed=1, shard_rank=r, shard_count=nshards, **dict(base, spp=2)))    # the history must be exchanged after every frame
+        c.close()
+    ref.close()
+
+
 @pytest.mark.parametrize("gpu_refit", [1, 0])
 def test_animated_instance_refit_parity(rt, orc, golden_dir, gpu_refit):
     """rtx_set_instance_transform + rtx_commit_scene refits the BVH (reference: TLAS refit every frame); the images of
