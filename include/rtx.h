@@ -82,7 +82,8 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
        RTX_OPT_LDS_NODES = 4,        /* BVH nodes staged in LDS per workgroup (top of tree) */
        RTX_OPT_SMALL_SCENE = 5,      /* 0/1: brute-force pre-test path for scenes of <= 64 triangles (default 1) */
        RTX_OPT_FUSED_BOUNCE = 6,     /* 0/1: with SMALL_SCENE, fuse trace+shade+shadow into one kernel per bounce (default 1) */
-       RTX_OPT_BOUNCE_VARIANT = 7,   /* retired (5 and 6 waves/SIMD spilled and measured slower): accepted and ignored */
+       RTX_OPT_BOUNCE_VARIANT = 7,   /* fused tiny-scene kernel, bounces >= 1: 0 (default) = trace phase pushes HITS into an LDS ring, shading runs on ring entries (full waves);
+                                        1 = trace and shade the same 256 queue entries (the round-1 form) */
        RTX_OPT_REFILL_MIN = 8,       /* tuning: idle lanes that trigger a refill in the persistent BVH traversal (default 12) */
        RTX_OPT_STACK_PRIVATE = 9,    /* tuning: traversal stack 0 = LDS column, 1 = private (scratch) memory, (2 is accepted and means 0) */
        RTX_OPT_TRACE_SCHED = 10,     /* tuning: wave schedule of the BVH traversal, 0 = while-while, 1-4 = voted node / triangle steps, 5-7 = voted + speculative (default 6) */

@@ -45,6 +45,7 @@ struct rtx_ctx {
     DevBuf d_hitmask, d_order, d_pmask;
     bool lpt_order = true;          // RTX_OPT_LPT_ORDER: fused kernels take their sub-queues longest first
     DevBuf d_halo; uint32_t halo_count = 0; uint32_t halo_key[5] = {0, 0, 0, 0, 0};     // ReSTIR on shards: the shard's tiles dilated by 20 px, as a pixel list (width, height, tile, rank, count)
+    bool bounce_ring = true;        // RTX_OPT_BOUNCE_VARIANT
     bool fused_bvh = false;         // RTX_OPT_FUSED_BVH: general path = one k_bounce_bvh launch per batch (trace -> shade -> shadow per sub-queue and bounce); measured SLOWER, default off
     DevBuf d_hitq;
     DevBuf d_ray_o, d_ray_d, d_thr, d_rad, d_hit, d_sh_o, d_sh_d, d_sh_c, d_queue[2], d_counters;
@@ -132,7 +133,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_LDS_NODES: c->lds_nodes_opt = (int)value; c->committed = false; return RTX_OK;
     case RTX_OPT_SMALL_SCENE: c->small_scene = value != 0; c->committed = false; return RTX_OK;
     case RTX_OPT_FUSED_BOUNCE: c->fused = value != 0; return RTX_OK;
-    case RTX_OPT_BOUNCE_VARIANT: return RTX_OK;         // retired knob (forced waves/SIMD builds of the fused kernel measured no faster): accepted, ignored
+    case RTX_OPT_BOUNCE_VARIANT: c->bounce_ring = value == 0; return RTX_OK;     // 0 (default): LDS hit ring between trace and shading; 1: trace and shade the same 256 entries
     case RTX_OPT_STACK_PRIVATE: c->stack_private = (int)value; c->committed = false; return RTX_OK;
     case RTX_OPT_LPT_ORDER: c->lpt_order = value != 0; return RTX_OK;
     case RTX_OPT_FUSED_BVH: c->fused_bvh = value != 0; return RTX_OK;
@@ -453,7 +454,7 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
         if (fused && c->lpt_order && G > 1) { launch_order_queues(st, Q(0), G, (uint32_t*)c->d_order.p); order = (const uint32_t*)c->d_order.p; }
         if (fused) {          // tiny scene: trace + shade + shadow fused; bounce 0 (traced by raygen) and then ALL later bounces in one launch each
             { Timed t(c, RTX_K_BOUNCE); launch_bounce_small(st, c->dsc, fb, P, 0, 1, queue[0], queue[1], Q(0), S(0, 0), order); }
-            if (mb > 1) { Timed t(c, RTX_K_BOUNCE); launch_bounce_small(st, c->dsc, fb, P, 1, mb, queue[0], queue[1], Q(0), S(0, 0), order); }
+            if (mb > 1) { Timed t(c, RTX_K_BOUNCE); launch_bounce_small(st, c->dsc, fb, P, 1, mb, queue[0], queue[1], Q(0), S(0, 0), order, c->bounce_ring); }
         }
         if (fused_bvh) {      // general scenes: all bounces of every sub-queue in one launch (k_bounce_bvh), sub-queues longest first
             const uint32_t* ord = nullptr;

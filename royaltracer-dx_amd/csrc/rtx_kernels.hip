@@ -325,7 +325,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPa
 // stay in registers.  Radiance additions happen in the oracle's order (emissive, then NEE slot 0, 1, ...).
 // LAMBERT: RTX_FLAG_LAMBERT_ONLY is a launch constant, so it is a template parameter too: the Lambert-only instantiation carries no GGX code
 // (fewer live registers, fewer SGPR spills through v_writelane / v_readlane in the loop).
-template <int WAVES, bool HAVE_HIT, bool LAMBERT>
+template <int WAVES, bool HAVE_HIT, bool LAMBERT, bool RING>
 __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, const SmallRecPair* __restrict__ small, DevFrame f_in, DevPaths p,
                                                          uint32_t bounce_first, uint32_t bounce_end,
                                                          uint32_t* __restrict__ queue_a, uint32_t* __restrict__ queue_b /* bounce b reads (b & 1 ? b : a), writes the other */,
@@ -365,8 +365,8 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
     // is read twice (origin / direction for the trace, all 48 B for the shading), which a VALU-bound kernel at 2.4 of 8 TB/s does not notice.
     // All four waves walk through the same phases (every decision is read from LDS after a barrier), so there is no producer / consumer protocol.
     constexpr uint32_t kRing = 512u;                       // < 256 waiting + <= 256 pushed by one trace pass
-    __shared__ uint32_t s_rpid[HAVE_HIT ? 1 : kRing];
-    __shared__ F4 s_rhit[HAVE_HIT ? 1 : kRing];
+    __shared__ uint32_t s_rpid[(HAVE_HIT || !RING) ? 1 : kRing];
+    __shared__ F4 s_rhit[(HAVE_HIT || !RING) ? 1 : kRing];
     __shared__ uint32_t s_ring[2];                         // consumed, produced (monotonic; index = count & (kRing - 1))
     PF_BEGIN;
     for (uint32_t bounce = bounce_first; bounce < bounce_end; bounce++) {
@@ -374,9 +374,9 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
     const float tmin = bounce_tmin(bounce);
     const uint32_t* myq = ((bounce & 1u) ? queue_b : queue_a) + qb;
     uint32_t* mynext = ((bounce & 1u) ? queue_a : queue_b) + qb;
-    if (!HAVE_HIT) { if (threadIdx.x < 2) s_ring[threadIdx.x] = 0; __syncthreads(); }
+    if (!HAVE_HIT && RING) { if (threadIdx.x < 2) s_ring[threadIdx.x] = 0; __syncthreads(); }
     uint32_t next_in = 0;                                   // trace phase: next input entry (uniform)
-    for (uint32_t base = 0; HAVE_HIT ? base < n : true; base += kBlock) {     // HAVE_HIT: one trip per 256 queue entries; otherwise until input and ring are empty
+    for (uint32_t base = 0; (HAVE_HIT || !RING) ? base < n : true; base += kBlock) {     // one trip per 256 queue entries; with the ring: until input and ring are empty
         PathState S; S.pid = 0; S.o = mk3(0, 0, 0); S.d = mk3(0, 0, 1); S.thr = mk3(0, 0, 0); S.prev_pdf = 1.0f; S.s0 = S.s1 = 0;
         float t = 0.0f, u = 0.0f, v = 0.0f; uint32_t prim = kMissPrim;
         bool active;
@@ -385,6 +385,11 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
             const uint32_t i = base + threadIdx.x;
             active = i < n;
             if (active) { S = load_path(p, myq[i]); const F4 h = p.hit[S.pid]; t = h.x; u = h.y; v = h.z; prim = f2u(h.w); }
+        } else if (!RING) {                               // RTX_OPT_BOUNCE_VARIANT = 1: trace and shade the same 256 entries (lanes whose ray missed idle through the shading)
+            const uint32_t i = base + threadIdx.x;
+            active = i < n;
+            if (active) S = load_path(p, myq[i]);
+            traverse_small<false>(sc, small, L, S.o, S.d, tmin, active ? kTMax : 0.0f, t, u, v, prim, sc.nsmall, ~0ull, pf, 1);   // inactive lanes: empty interval
         } else {
             // ---- trace phase: fill the ring until it holds a full workgroup of hits (or the input runs out) ----
             while (next_in < n && s_ring[1] - s_ring[0] < kBlock) {           // uniform: both counters were published before the last barrier
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
         const uint32_t slot = block_push(alive, &s_cnt[0]);
         if (alive) mynext[slot] = S.pid;
         PF_MARK(9);
-        if (!HAVE_HIT) __syncthreads();                     // the released ring slots (s_ring[0]) are visible to the next trip's trace phase
+        if (!HAVE_HIT && RING) __syncthreads();             // the released ring slots (s_ring[0]) are visible to the next trip's trace phase
     }
     // end of this bounce of the sub-queue: publish its counters; what it wrote (path state, next queue) becomes visible to the workgroup
     __syncthreads();
@@ -959,13 +964,14 @@ void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc,
     else hipLaunchKernelGGL(k_trace_closest<0>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, sc.refill_min, sc.trace_sched);
 }
 void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce_first, uint32_t bounce_end,
-                         uint32_t* queue_a, uint32_t* queue_b, uint32_t* qrows, uint32_t* srows, const uint32_t* order) {
+                         uint32_t* queue_a, uint32_t* queue_b, uint32_t* qrows, uint32_t* srows, const uint32_t* order, bool ring) {
     // general instantiation: 118 VGPRs, 4 waves/SIMD (5 or 6 spill and measured slower); Lambert-only: 85 VGPRs, 5 waves/SIMD (a build for 6 waves, 80 VGPRs
     // with 2 spilled, measured the same: 19.13 vs 19.03 ms).  Bounce 0 (reads the primary hits) is its own instantiation and launch.
     const bool lam = (f.flags & 1u) != 0u, have_hit = bounce_first == 0u;
-#define RTX_LAUNCH_BOUNCE(HH, LL) hipLaunchKernelGGL((k_bounce_small<4, HH, LL>), dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, bounce_first, bounce_end, queue_a, queue_b, qrows, srows, order)
-    if (have_hit) { if (lam) RTX_LAUNCH_BOUNCE(true, true); else RTX_LAUNCH_BOUNCE(true, false); }
-    else { if (lam) RTX_LAUNCH_BOUNCE(false, true); else RTX_LAUNCH_BOUNCE(false, false); }
+#define RTX_LAUNCH_BOUNCE(HH, LL, RR) hipLaunchKernelGGL((k_bounce_small<4, HH, LL, RR>), dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, bounce_first, bounce_end, queue_a, queue_b, qrows, srows, order)
+    if (have_hit) { if (lam) RTX_LAUNCH_BOUNCE(true, true, false); else RTX_LAUNCH_BOUNCE(true, false, false); }
+    else if (ring) { if (lam) RTX_LAUNCH_BOUNCE(false, true, true); else RTX_LAUNCH_BOUNCE(false, false, true); }
+    else { if (lam) RTX_LAUNCH_BOUNCE(false, true, false); else RTX_LAUNCH_BOUNCE(false, false, false); }
 #undef RTX_LAUNCH_BOUNCE
 }
 void launch_bounce_bvh(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce_first, uint32_t bounce_end,

@@ -60,7 +60,7 @@ void launch_trace_closest(hipStream_t, const DevFrame&, const DevScene&, const D
 void launch_packet_masks(hipStream_t, const DevScene&, const DevFrame&, const CameraGPU* cam, unsigned long long* masks);   // one 64-bit record mask per 8x8 pixel block of the shard
 void launch_raygen_trace_small(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount, uint32_t* gencount, const unsigned long long* masks);
 void launch_bounce_small(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, uint32_t bounce_first, uint32_t bounce_end,
-                         uint32_t* queue_a, uint32_t* queue_b, uint32_t* qrows, uint32_t* srows, const uint32_t* order);   // bounce 0 alone (reads the primary hits), or a range of later bounces
+                         uint32_t* queue_a, uint32_t* queue_b, uint32_t* qrows, uint32_t* srows, const uint32_t* order, bool ring = true);   // bounce 0 alone (reads the primary hits), or a range of later bounces; ring: hits go through the LDS ring
 // general (BVH) path: trace -> shade -> shadow of a bounce range for every workgroup-private sub-queue in one launch (hitq: G * qcap indices of scratch)
 void launch_bounce_bvh(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, uint32_t bounce_first, uint32_t bounce_end,
                        uint32_t* queue_a, uint32_t* queue_b, uint32_t* hitq, uint32_t* qrows, uint32_t* srows, const uint32_t* order);
