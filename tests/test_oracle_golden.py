@@ -404,3 +404,25 @@ def test_restir_agrees_with_the_path_tracer_in_the_mean(rt, orc, cornell):
     assert np.allclose(a, b, rtol=0.08), (a, b)
     M = st[3].view(np.uint16).reshape(len(st[3]), 20)[:, 19]
     assert M.max() > 16                                  # history accumulates beyond one frame's cap
+
+
+def test_c1_cpu_reference_path_at_full_size(rt, orc, cornell):
+    """BASELINE.json configs[0]: Cornell Box, 1920 x 1080, 1 spp, 4 bounces, Lambertian only, on the CPU reference path (the oracle; plumbing, no GPU).
+    The whole frame in a few seconds; invariants that need no second implementation: one primary ray per pixel, every pixel gets one sample, the ray
+    budget (<= 3 extension rays and <= 4 shadow rays per path), a black background outside the box opening and the light seen at its own radiance,
+    determinism across thread counts, and the 128 x 72 crop of the same settings that the committed golden fixture holds."""
+    W, H = 1920, 1080
+    p = rt.Params(width=W, height=H, spp=1, max_bounces=4, nee_samples=1, rr_start=3, flags=rt.FLAG_LAMBERT_ONLY, frame_seed=1)
+    o = orc.Oracle().load(cornell, W / H)
+    o.set_threads(max(1, len(os.sched_getaffinity(0))))
+    img, cnt = o.render(p)
+    assert cnt[0] == W * H and 0 < cnt[1] <= 3 * W * H and 0 < cnt[2] <= 4 * W * H
+    assert (img[..., 3] == 1.0).all() and np.isfinite(img).all() and (img[..., :3] >= 0.0).all()
+    assert not img[:, :200, :3].any() and not img[:, -200:, :3].any()           # left and right of the box opening: the camera sees nothing (Miss -> black)
+    light = img[:, :, :3].reshape(-1, 3).max(0)
+    assert np.allclose(light, [17.0, 12.0, 4.0])                                  # the light seen directly carries Ke (fp16-exact values), Hit.hlsl:128-131
+    o.set_threads(1)
+    again, cnt1 = o.render(rt.Params(width=W // 8, height=H // 8, spp=1, max_bounces=4, nee_samples=1, rr_start=3, flags=1, frame_seed=1))
+    o.set_threads(3)
+    again3, cnt3 = o.render(rt.Params(width=W // 8, height=H // 8, spp=1, max_bounces=4, nee_samples=1, rr_start=3, flags=1, frame_seed=1))
+    assert cnt1 == cnt3 and np.array_equal(again.view(np.uint32), again3.view(np.uint32))
