@@ -48,6 +48,8 @@ struct rtx_ctx {
     bool bounce_ring = true;        // RTX_OPT_BOUNCE_VARIANT
     bool fused_bvh = false;         // RTX_OPT_FUSED_BVH: general path = one k_bounce_bvh launch per batch (trace -> shade -> shadow per sub-queue and bounce); measured SLOWER, default off
     DevBuf d_hitq;
+    bool work_stealing = false;     // RTX_OPT_WORK_STEALING: trace kernels of general scenes continue with other sub-queues instead of draining (refill_steal); measured SLOWER, default off
+    DevBuf d_heads;                 // per trace launch of a batch: G fetch cursors + the retired count
     DevBuf d_ray_o, d_ray_d, d_thr, d_rad, d_hit, d_sh_o, d_sh_d, d_sh_c, d_queue[2], d_counters;
     uint32_t* h_counters = nullptr; size_t h_counters_words = 0;
     // accumulation
@@ -112,7 +114,7 @@ void rtx_destroy(rtx_ctx* c) {
     else (void)hipDeviceSynchronize();
     DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_small_poly, &c->d_objtris, &c->d_node_aabb, &c->d_scale, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
                      &c->d_thr, &c->d_rad, &c->d_hit, &c->d_hitmask, &c->d_order, &c->d_pmask, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
-                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq, &c->d_halo};
+                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq, &c->d_halo, &c->d_heads};
     for (DevBuf* b : all) b->release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
@@ -137,6 +139,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_STACK_PRIVATE: c->stack_private = (int)value; c->committed = false; return RTX_OK;
     case RTX_OPT_LPT_ORDER: c->lpt_order = value != 0; return RTX_OK;
     case RTX_OPT_FUSED_BVH: c->fused_bvh = value != 0; return RTX_OK;
+    case RTX_OPT_WORK_STEALING: c->work_stealing = value != 0; return RTX_OK;
     case RTX_OPT_BLOCKS_PER_CU: if (value < 0 || value > 64) { c->err = "blocks_per_cu must be in [0, 64]"; return RTX_ERR_INVALID; } c->blocks_per_cu = (uint32_t)value; return RTX_OK;
     case RTX_OPT_GPU_REFIT: c->gpu_refit = value != 0; return RTX_OK;
     case RTX_OPT_TRACE_SCHED: if (value > 7) { c->err = "trace_sched must be in [0, 7]"; return RTX_ERR_INVALID; } c->trace_sched = (uint32_t)value; c->dsc.trace_sched = c->trace_sched; return RTX_OK;
@@ -407,6 +410,10 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     HIPCHK(c, c->d_queue[0].ensure(qtot * 4)); HIPCHK(c, c->d_queue[1].ensure(qtot * 4));
     HIPCHK(c, c->d_order.ensure((size_t)G * 4));
     if (fused_bvh) HIPCHK(c, c->d_hitq.ensure(qtot * 4));
+    const bool stealing = !c->dsc.nsmall && !fused_bvh && c->work_stealing && p->max_bounces > 0;
+    const size_t hstride = (size_t)G + (G + 31) / 32;                      // per trace launch: G fetch cursors + the exhausted bitmap
+    const size_t nheads = stealing ? (size_t)p->max_bounces * (1 + std::max<uint32_t>(nee, 1)) * hstride : 0;
+    if (stealing) HIPCHK(c, c->d_heads.ensure(nheads * 4));
     HIPCHK(c, c->d_pmask.ensure(((size_t)f.npl / 64 + 1) * 8));
     const uint32_t nee1 = std::max<uint32_t>(nee, 1);
     const size_t shn = qtot * nee1;
@@ -462,11 +469,13 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
             Timed t(c, RTX_K_BOUNCE);
             launch_bounce_bvh(st, c->dsc, fb, P, 0, mb, queue[0], queue[1], (uint32_t*)c->d_hitq.p, Q(0), S(0, 0), ord);
         }
+        if (stealing) HIPCHK(c, hipMemsetAsync(c->d_heads.p, 0, nheads * 4, st));          // one cursor block per trace launch of the batch
+        auto Hd = [&](uint32_t b, uint32_t k) { return stealing ? (uint32_t*)c->d_heads.p + ((size_t)b * (1 + nee1) + k) * hstride : nullptr; };
         for (uint32_t b = 0; b < mb && !fused && !fused_bvh; b++) {
             uint32_t* q = queue[b & 1]; uint32_t* qn = queue[(b + 1) & 1];
-            { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, fb, c->dsc, P, b, q, Q(b)); }
+            { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, fb, c->dsc, P, b, q, Q(b), Hd(b, 0)); }
             { Timed t(c, RTX_K_SHADE); launch_shade(st, c->dsc, fb, P, b, q, Q(b), qn, Q(b + 1), S(b, 0)); }
-            for (uint32_t j = 0; j < nee; j++) { Timed t(c, RTX_K_SHADOW); launch_trace_shadow(st, fb, c->dsc, P, j, S(b, j)); }
+            for (uint32_t j = 0; j < nee; j++) { Timed t(c, RTX_K_SHADOW); launch_trace_shadow(st, fb, c->dsc, P, j, S(b, j), Hd(b, 1 + j)); }
         }
         { Timed t(c, RTX_K_ACCUM); launch_accumulate(st, max_blocks, fb, P, c->accum_ptr()); }
         HIPCHK(c, hipMemcpyAsync(c->h_counters + (size_t)bi * ncnt, cnt, ncnt * 4, hipMemcpyDeviceToHost, st));

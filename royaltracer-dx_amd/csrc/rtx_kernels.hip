@@ -140,12 +140,12 @@ __global__ __launch_bounds__(kBlock) void k_raygen_trace_small(DevScene sc, cons
 }
 
 // closest hit for every path in this workgroup's sub-queue: reads ray_o/ray_d, writes hit
-template <int STK>   // traversal stack: 0 = LDS column, 1 = private (scratch)
-__global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin, uint32_t refill_min, uint32_t sched) {
+template <int STK, bool STEAL>   // traversal stack: 0 = LDS column, 1 = private (scratch); STEAL: work stealing between sub-queues (refill_steal)
+__global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin, uint32_t refill_min, uint32_t sched, uint32_t* heads) {
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_head;
     const uint32_t n = qcount[blockIdx.x];
-    if (n == 0) return;
+    if (STEAL ? all_exhausted(heads, gridDim.x) : n == 0) return;      // (work stealing: nothing left in the whole launch)
     if (threadIdx.x == 0) s_head = 0;
     const TraceLds L = stage_lds(sc, lds);
     __syncthreads();
@@ -164,11 +164,14 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
     if constexpr (STK != 1) stk.col = L.stack + threadIdx.x;
     RayLane R; ray_idle(R);
     bool drained = false;
-    while (refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) {
-               const uint32_t pid = myq[idx];
-               const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
-               ray_begin(R, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, pid, true);
-           })) {
+    RaySource W{heads, qcount, gridDim.x, blockIdx.x, n, 0u, 0u};
+    uint32_t rng = steal_seed();
+    auto fetch = [&](uint32_t q, uint32_t idx) {
+        const uint32_t pid = queue[(size_t)q * qcap + idx];
+        const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
+        ray_begin(R, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, pid, true);
+    };
+    while (STEAL ? refill_steal(R, W, drained, refill_min, rng, fetch) : refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) { fetch(blockIdx.x, idx); })) {
         if (sched >= 5u) spec_step<false>(sc, L, R, stk, sched);
         else if (sched) voted_step<false>(sc, L, R, stk, sched);
         else { walk_internal<false>(sc, L, R, stk); process_leaf<false>(sc, L, R, stk); }
@@ -178,20 +181,20 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
 
 // any-hit for NEE slot j: visible contributions are added to the path's radiance (a path appears at most once
 // per slot, so the read-modify-write needs no atomic and the order of additions per path is fixed)
-template <int STK>
+template <int STK, bool STEAL>
 __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const F4* __restrict__ sh_o, const F4* __restrict__ sh_d,
-                                                         const F4* __restrict__ sh_c, const uint32_t* __restrict__ shcount, uint32_t qcap, uint32_t refill_min, uint32_t sched) {
+                                                         const F4* __restrict__ sh_c, const uint32_t* __restrict__ shcount, uint32_t qcap, uint32_t refill_min, uint32_t sched, uint32_t* heads) {
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_head;
     const uint32_t n = shcount[blockIdx.x];
-    if (n == 0) return;
+    if (STEAL ? all_exhausted(heads, gridDim.x) : n == 0) return;
     if (threadIdx.x == 0) s_head = 0;
     const TraceLds L = stage_lds(sc, lds);
     __syncthreads();
     const size_t qb = (size_t)blockIdx.x * qcap;
-    auto finish = [&](uint32_t i, bool occluded) {
+    auto finish = [&](size_t gi, bool occluded) {         // gi: index into the launch's shadow-ray arrays (sub-queue * qcap + entry)
         if (!occluded) {
-            const F4 c = sh_c[qb + i];
+            const F4 c = sh_c[gi];
             const uint32_t pid = f2u(c.w);
             F4 r = p.rad[pid];
             r.x = r.x + c.x; r.y = r.y + c.y; r.z = r.z + c.z;
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const Smal
             float t, u, v; uint32_t prim;
             const uint32_t nrec_sh = __builtin_amdgcn_ballot_w64(so.w < 0.0f) != 0ull ? sc.nsmall : sc.nsmall_occ;                        // hull guard, as in k_bounce_small
             traverse_small<true>(sc, small, L, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), fabsf(so.w), sd.w, t, u, v, prim, nrec_sh);   // NEE segments only
-            finish(i, prim != kMissPrim);
+            finish(qb + i, prim != kMissPrim);
         }
         return;
     }
@@ -212,10 +215,14 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const Smal
     if constexpr (STK != 1) stk.col = L.stack + threadIdx.x;
     RayLane R; ray_idle(R);
     bool drained = false;
-    while (refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) {
-               const F4 so = sh_o[qb + idx], sd = sh_d[qb + idx];
-               ray_begin(R, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, idx, false);
-           })) {
+    RaySource W{heads, shcount, gridDim.x, blockIdx.x, n, 0u, 0u};
+    uint32_t rng = steal_seed();
+    auto fetch = [&](uint32_t q, uint32_t idx) {
+        const uint32_t gi = q * qcap + idx;                               // (< 2^32: the batch cap)
+        const F4 so = sh_o[gi], sd = sh_d[gi];
+        ray_begin(R, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, gi, false);
+    };
+    while (STEAL ? refill_steal(R, W, drained, refill_min, rng, fetch) : refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) { fetch(blockIdx.x, idx); })) {
         if (sched >= 5u) spec_step<true>(sc, L, R, stk, sched);
         else if (sched) voted_step<true>(sc, L, R, stk, sched);
         else { walk_internal<true>(sc, L, R, stk); process_leaf<true>(sc, L, R, stk); }
@@ -958,10 +965,13 @@ void launch_packet_masks(hipStream_t st, const DevScene& sc, const DevFrame& f, 
 void launch_raygen_trace_small(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount, uint32_t* gencount, const unsigned long long* masks) {
     hipLaunchKernelGGL(k_raygen_trace_small, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, cam, queue, qcount, gencount, masks);
 }
-void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t bounce, const uint32_t* queue, const uint32_t* qcount) {
+void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t bounce, const uint32_t* queue, const uint32_t* qcount, uint32_t* heads) {
     const float tmin = bounce == 0 ? kTMinCam : kSBias;
-    if (sc.stack_private == 1) hipLaunchKernelGGL(k_trace_closest<1>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, sc.refill_min, sc.trace_sched);
-    else hipLaunchKernelGGL(k_trace_closest<0>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, queue, qcount, f.qcap, tmin, sc.refill_min, sc.trace_sched);
+    if (sc.nsmall) heads = nullptr;                     // (the un-fused tiny-scene test path has no persistent waves)
+#define RTX_LAUNCH_TC(SS, TT, LDSB) hipLaunchKernelGGL((k_trace_closest<SS, TT>), dim3(f.nblocks), dim3(kBlock), LDSB, st, sc, sc.small, p, queue, qcount, f.qcap, tmin, sc.refill_min, sc.trace_sched, heads)
+    if (sc.stack_private == 1) { if (heads) RTX_LAUNCH_TC(1, true, trace_lds_bytes_queue(sc)); else RTX_LAUNCH_TC(1, false, trace_lds_bytes_queue(sc)); }
+    else { if (heads) RTX_LAUNCH_TC(0, true, trace_lds_bytes(sc)); else RTX_LAUNCH_TC(0, false, trace_lds_bytes(sc)); }
+#undef RTX_LAUNCH_TC
 }
 void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce_first, uint32_t bounce_end,
                          uint32_t* queue_a, uint32_t* queue_b, uint32_t* qrows, uint32_t* srows, const uint32_t* order, bool ring) {
@@ -982,10 +992,13 @@ void launch_bounce_bvh(hipStream_t st, const DevScene& sc, const DevFrame& f, co
 void launch_order_queues(hipStream_t st, const uint32_t* qcount, uint32_t G, uint32_t* order) {
     hipLaunchKernelGGL(k_order_queues, dim3(1), dim3(1024), 0, st, qcount, G, order);
 }
-void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t j, const uint32_t* shcount) {
+void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t j, const uint32_t* shcount, uint32_t* heads) {
     const size_t seg = (size_t)j * f.qcap * f.nblocks;
-    if (sc.stack_private == 1) hipLaunchKernelGGL(k_trace_shadow<1>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, sc.refill_min, sc.trace_sched);
-    else hipLaunchKernelGGL(k_trace_shadow<0>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, sc.refill_min, sc.trace_sched);
+    if (sc.nsmall) heads = nullptr;
+#define RTX_LAUNCH_TS(SS, TT, LDSB) hipLaunchKernelGGL((k_trace_shadow<SS, TT>), dim3(f.nblocks), dim3(kBlock), LDSB, st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, sc.refill_min, sc.trace_sched, heads)
+    if (sc.stack_private == 1) { if (heads) RTX_LAUNCH_TS(1, true, trace_lds_bytes_queue(sc)); else RTX_LAUNCH_TS(1, false, trace_lds_bytes_queue(sc)); }
+    else { if (heads) RTX_LAUNCH_TS(0, true, trace_lds_bytes(sc)); else RTX_LAUNCH_TS(0, false, trace_lds_bytes(sc)); }
+#undef RTX_LAUNCH_TS
 }
 void launch_shade(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce,
                   const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts) {
@@ -1060,6 +1073,12 @@ void launch_dbg_primary(hipStream_t st, const DevFrame& f, const CameraGPU* cam,
 
 #ifdef RTX_PROFILE_SECTIONS
 // tooling entry point of the PROFILE=1 build only (tools/section_profile.py): read (and optionally clear) the section counters
+extern "C" int rtx_debug_traversal(unsigned long long* out8, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(rtx::g_trv), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rtx::g_trv), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
 extern "C" int rtx_debug_sections(unsigned long long* out36, int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (out36 && hipMemcpyFromSymbol(out36, HIP_SYMBOL(rtx::g_sec), sizeof(unsigned long long) * 36) != hipSuccess) return -1;

@@ -468,9 +468,18 @@ __device__ __forceinline__ unsigned long long packet_keep_mask(const DevScene& s
 //                (profiles/r01_pmc_bvh.md).  With the 128-B 4-wide nodes the voted schedule was slower: the traversal was
 //                texture-addresser bound then, not VALU bound.
 
+#ifndef RTX_PEND
+#define RTX_PEND 2                                     // triangle groups a lane may hold (current + pending), speculative schedule
+#endif
+constexpr int kPend = RTX_PEND;
+static_assert(kPend >= 2 && kPend <= 4, "RTX_PEND");
 struct RayLane {                                       // per-lane traversal state
-    f3 o, d, idir; float tmin, tmax, bt, bu, bv; uint32_t bprim; uint32_t oct; Grp G; TriGrp T, T2; int sp; uint32_t item; bool has, done;   // T2: second pending triangle group (speculative schedule)
+    f3 o, d, idir; float tmin, tmax, bt, bu, bv; uint32_t bprim; uint32_t oct; Grp G; TriGrp T, P[kPend - 1]; int sp; uint32_t item; bool has, done;   // P: pending triangle groups behind T (speculative schedule)
 };
+__device__ __forceinline__ void pend_clear(RayLane& R) {
+#pragma unroll
+    for (int i = 0; i < kPend - 1; i++) R.P[i] = TriGrp{0u, 0u, 0u};
+}
 __device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, float tmax, uint32_t item, bool ordered) {
     R.o = o; R.d = d; R.tmin = tmin; R.tmax = tmax; R.item = item;
     const float dxs = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
@@ -479,11 +488,11 @@ __device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, fl
     R.idir = mk3(__builtin_amdgcn_rcpf(dxs), __builtin_amdgcn_rcpf(dys), __builtin_amdgcn_rcpf(dzs));
     R.oct = ray_octant(R.idir);
     R.bt = tmax; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.sp = 0; R.has = true; R.done = false;
-    R.G = Grp{0u, (ordered ? (1u << R.oct) : 1u) | (1u << 8)}; R.T = TriGrp{0u, 0u, 0u}; R.T2 = TriGrp{0u, 0u, 0u};
+    R.G = Grp{0u, (ordered ? (1u << R.oct) : 1u) | (1u << 8)}; R.T = TriGrp{0u, 0u, 0u}; pend_clear(R);
 }
 __device__ __forceinline__ void ray_idle(RayLane& R) {
     R.has = false; R.done = false; R.sp = 0; R.item = 0; R.o = mk3(0, 0, 0); R.d = mk3(0, 0, 1); R.idir = mk3(0, 0, 1); R.oct = 0;
-    R.tmin = 0.0f; R.tmax = 0.0f; R.bt = 0.0f; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.G = Grp{0u, 0u}; R.T = TriGrp{0u, 0u, 0u}; R.T2 = TriGrp{0u, 0u, 0u};
+    R.tmin = 0.0f; R.tmax = 0.0f; R.bt = 0.0f; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.G = Grp{0u, 0u}; R.T = TriGrp{0u, 0u, 0u}; pend_clear(R);
 }
 // after a node step or a finished triangle group: continue with the node's own internal hits, else pop, else done
 template <class STK>
@@ -545,23 +554,48 @@ __device__ __forceinline__ void voted_step(const DevScene& sc, const TraceLds& L
 // before a ray finishes, and the order of tests does not change the result (minimum over all tested triangles / any hit); what
 // speculation costs is culling: node steps taken before the pending triangles shrink the closest distance may visit boxes that
 // would have been culled (shadow rays lose nothing: their interval is fixed).
+#ifdef RTX_PROFILE_SECTIONS
+__device__ unsigned long long g_trv[8];      // tooling (PROFILE build): node iterations, lanes in them, triangle iterations, lanes in them, busy lanes summed over iterations, iterations
+#endif
 template <bool ANY, class STK>
 __device__ __forceinline__ void spec_step(const DevScene& sc, const TraceLds& L, RayLane& R, STK& stk, uint32_t sched) {
     const bool busy = R.has && !R.done;
     const bool has_tri = busy && R.T.bits != 0u;
-    const bool can_node = busy && R.T2.bits == 0u && ((R.G.bits & 0xffu) != 0u || R.sp > 0);
+    const bool can_node = busy && R.P[kPend - 2].bits == 0u && ((R.G.bits & 0xffu) != 0u || R.sp > 0);
     const uint32_t ni = (uint32_t)__popcll(__ballot(can_node)), nl = (uint32_t)__popcll(__ballot(has_tri));
+#ifdef RTX_PROFILE_SECTIONS
+    if (!ANY) {
+        const uint32_t nbusy = (uint32_t)__popcll(__ballot(busy)), nboth = (uint32_t)__popcll(__ballot(can_node && has_tri));
+        if (lane_id() == 0) {
+            const uint32_t wn_ = sched == 7u ? 2u : 1u, wl_ = sched == 5u ? 1u : sched == 6u ? 2u : 1u;
+            const bool node_it = ni * wn_ >= nl * wl_ && ni;
+            atomicAdd(&g_trv[node_it ? 0 : 2], 1ull); atomicAdd(&g_trv[node_it ? 1 : 3], (unsigned long long)(node_it ? ni : nl));
+            atomicAdd(&g_trv[4], (unsigned long long)nbusy); atomicAdd(&g_trv[5], 1ull);
+            atomicAdd(&g_trv[6], (unsigned long long)nboth);     // lanes that could do either
+        }
+    }
+#endif
     const uint32_t wn = sched == 7u ? 2u : 1u, wl = sched == 5u ? 1u : sched == 6u ? 2u : 1u;
     if (ni * wn >= nl * wl && ni) {
         if (can_node) {
             if (!(R.G.bits & 0xffu)) { R.sp--; R.G = stk.get(R.sp); }
             TriGrp Tn;
             descend8<!ANY>(sc, L, R.o, R.idir, R.oct, R.tmin, R.bt, R.G, Tn, stk, R.sp);
-            if (Tn.bits) { if (R.T.bits) R.T2 = Tn; else R.T = Tn; }
+            if (Tn.bits) {                                                        // first free slot: T, then P[0], P[1], ...
+                bool placed = false;
+                if (!R.T.bits) { R.T = Tn; placed = true; }
+#pragma unroll
+                for (int i = 0; i < kPend - 1; i++) if (!placed && !R.P[i].bits) { R.P[i] = Tn; placed = true; }
+            }
         }
     } else if (has_tri) {
         tri_step<ANY>(sc, L, R);
-        if (!R.T.bits) { R.T = R.T2; R.T2 = TriGrp{0u, 0u, 0u}; }
+        if (!R.T.bits) {
+            R.T = R.P[0];
+#pragma unroll
+            for (int i = 0; i + 1 < kPend - 1; i++) R.P[i] = R.P[i + 1];
+            R.P[kPend - 2] = TriGrp{0u, 0u, 0u};
+        }
     }
     if (R.has && !R.done && !(R.G.bits & 0xffu) && R.sp == 0 && !R.T.bits) R.done = true;
 }
@@ -579,6 +613,85 @@ __device__ __forceinline__ bool refill(RayLane& R, uint32_t* s_head, uint32_t n,
             const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             if (!R.has && idx < n) fetch(idx);
             if (base + nidle >= n) drained = true;
+        }
+    }
+    return __ballot(R.has) != 0ull;
+}
+
+// Refill with work stealing (the separate trace kernels of general scenes).  Every sub-queue has a fetch cursor in GLOBAL memory
+// (heads[q], zeroed before the launch) from which a WAVE takes chunks of kStealChunk entries into a wave-private range (no atomic
+// per refill), and a bitmap (heads[G ...]) marks the sub-queues found exhausted.  A wave whose sub-queue is exhausted does not
+// drain: it loads the bitmap, picks the first sub-queue not yet exhausted behind a pseudo-random position (thieves must spread over
+// the victims: versions that sent all waves, or herds of them, to the same victim ran 5-80x slower — every wave of the herd pays an
+// atomic and a bitmap load per victim), and fetches chunks from it like its owner
+// would.  Lanes stay filled until EVERY sub-queue of the launch is empty, so the low-occupancy tail that each workgroup had at the
+// end of its own sub-queue happens once per launch (busy lanes per iteration 50.3 -> 55.3 of 64, profiles/r02_traversal.md).
+// A workgroup dispatched after its sub-queue was taken joins the stealing, or exits at once when all are exhausted.
+// Results do not depend on which wave traces a ray (per-path state only).
+// MEASURED (MI355X, same box, tools/steal_probe.py): wave iterations -8 %, but C3 56.6 vs 47.4 ms and C5 51.0 vs 44.7 ms per frame —
+// the iterations it removes are the latency-bound ones of nearly empty waves, which cost few issue slots next to the full waves of
+// the other workgroups on the SIMD, and with stealing all waves of a launch reach that tail together (+0.3-0.6 ms per launch).
+// Hence RTX_OPT_WORK_STEALING defaults to 0.
+constexpr uint32_t kStealChunk = 256;
+struct RaySource { uint32_t* heads; const uint32_t* counts; uint32_t G, cur, n, lo, hi; };      // wave-uniform; heads[0..G) cursors, heads[G ...] exhausted bitmap
+__device__ __forceinline__ uint32_t steal_words(uint32_t G) { return (G + 31u) / 32u; }
+__device__ __forceinline__ bool all_exhausted(const uint32_t* heads, uint32_t G) {              // whole wave
+    const uint32_t nw = steal_words(G);
+    bool open = false;
+    for (uint32_t k = lane_id(); k < nw; k += 64u) {
+        const uint32_t valid = (G - k * 32u >= 32u) ? ~0u : ((1u << (G - k * 32u)) - 1u);
+        open = open || (~__hip_atomic_load(heads + G + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & valid) != 0u;
+    }
+    return __ballot(open) == 0ull;
+}
+// first sub-queue not marked exhausted at or after bit `start` of the bitmap (cyclic); G = none left.  Whole wave.
+__device__ __forceinline__ uint32_t pick_victim(const uint32_t* heads, uint32_t G, uint32_t start) {
+    const uint32_t nw = steal_words(G), sw = (start >> 5) % nw, sb = start & 31u;
+    for (uint32_t r = 0; r < nw + 1u; r += 64u) {                       // nw + 1 words: the start word is looked at twice (bits >= sb first, bits < sb last)
+        const uint32_t k = r + lane_id();
+        uint32_t w = 0, wi = 0;
+        if (k <= nw) {
+            wi = sw + k; while (wi >= nw) wi -= nw;
+            uint32_t valid = (G - wi * 32u >= 32u) ? ~0u : ((1u << (G - wi * 32u)) - 1u);
+            if (k == 0u) valid &= ~0u << sb;
+            if (k == nw) valid &= ~(~0u << sb);
+            w = ~__hip_atomic_load(heads + G + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & valid;
+        }
+        const unsigned long long m = __ballot(w != 0u);
+        if (m) {
+            const int src = __builtin_ctzll(m);
+            const uint32_t ww = (uint32_t)__builtin_amdgcn_readlane((int)w, src), wwi = (uint32_t)__builtin_amdgcn_readlane((int)wi, src);
+            return wwi * 32u + (uint32_t)__builtin_ctz(ww);
+        }
+    }
+    return G;
+}
+// a wave's pseudo-random sequence of start positions, seeded from workgroup and wave number
+__device__ __forceinline__ uint32_t steal_seed() { return (blockIdx.x * 4u + (threadIdx.x >> 6)) * 2654435761u + 0x9e3779b9u; }
+template <class Fetch>
+__device__ __forceinline__ bool refill_steal(RayLane& R, RaySource& W, bool& drained, uint32_t refill_min, uint32_t& rng, Fetch fetch) {
+    unsigned long long idle = __ballot(!R.has);
+    uint32_t nidle = (uint32_t)__popcll(idle);
+    if (!drained && (nidle >= refill_min || nidle == 64u)) {            // wave-uniform
+        for (;;) {
+            if (W.lo < W.hi) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                const uint32_t take = nidle < W.hi - W.lo ? nidle : W.hi - W.lo;
+                if (!R.has && rank < take) fetch(W.cur, W.lo + rank);
+                W.lo += take;
+                if (take == nidle) break;
+                idle = __ballot(!R.has); nidle -= take;
+                if (nidle < refill_min) break;
+            }
+            uint32_t base = 0;                                          // next chunk of the current sub-queue
+            if (lane_id() == 0) base = atomicAdd(W.heads + W.cur, kStealChunk);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (base < W.n) { W.lo = base; W.hi = base + kStealChunk < W.n ? base + kStealChunk : W.n; continue; }
+            if (lane_id() == 0) atomicOr(W.heads + W.G + (W.cur >> 5), 1u << (W.cur & 31u));      // exhausted: mark it and take another
+            rng = rng * 1664525u + 1013904223u;
+            const uint32_t v = pick_victim(W.heads, W.G, (rng >> 8) % W.G);
+            if (v >= W.G) { drained = true; break; }
+            W.cur = v; W.n = W.counts[v];
         }
     }
     return __ballot(R.has) != 0ull;
