@@ -50,6 +50,8 @@ struct rtx_ctx {
     DevBuf d_hitq;
     bool work_stealing = false;     // RTX_OPT_WORK_STEALING: trace kernels of general scenes continue with other sub-queues instead of draining (refill_steal); measured SLOWER, default off
     DevBuf d_heads;                 // per trace launch of a batch: G fetch cursors + the retired count
+    bool compact_state = true;      // RTX_OPT_COMPACT_STATE: separate-kernel path keeps ray / throughput / hit records by queue position, ping-pong (DevPaths::out_*)
+    DevBuf d_alt_o, d_alt_d, d_alt_thr;
     DevBuf d_ray_o, d_ray_d, d_thr, d_rad, d_hit, d_sh_o, d_sh_d, d_sh_c, d_queue[2], d_counters;
     uint32_t* h_counters = nullptr; size_t h_counters_words = 0;
     // accumulation
@@ -114,7 +116,7 @@ void rtx_destroy(rtx_ctx* c) {
     else (void)hipDeviceSynchronize();
     DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_small_poly, &c->d_objtris, &c->d_node_aabb, &c->d_scale, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
                      &c->d_thr, &c->d_rad, &c->d_hit, &c->d_hitmask, &c->d_order, &c->d_pmask, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
-                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq, &c->d_halo, &c->d_heads};
+                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq, &c->d_halo, &c->d_heads, &c->d_alt_o, &c->d_alt_d, &c->d_alt_thr};
     for (DevBuf* b : all) b->release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
@@ -140,6 +142,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_LPT_ORDER: c->lpt_order = value != 0; return RTX_OK;
     case RTX_OPT_FUSED_BVH: c->fused_bvh = value != 0; return RTX_OK;
     case RTX_OPT_WORK_STEALING: c->work_stealing = value != 0; return RTX_OK;
+    case RTX_OPT_COMPACT_STATE: c->compact_state = value != 0; return RTX_OK;
     case RTX_OPT_BLOCKS_PER_CU: if (value < 0 || value > 64) { c->err = "blocks_per_cu must be in [0, 64]"; return RTX_ERR_INVALID; } c->blocks_per_cu = (uint32_t)value; return RTX_OK;
     case RTX_OPT_GPU_REFIT: c->gpu_refit = value != 0; return RTX_OK;
     case RTX_OPT_TRACE_SCHED: if (value > 7) { c->err = "trace_sched must be in [0, 7]"; return RTX_ERR_INVALID; } c->trace_sched = (uint32_t)value; c->dsc.trace_sched = c->trace_sched; return RTX_OK;
@@ -392,8 +395,7 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     const uint64_t cap64 = (uint64_t)f.npl * bspp;
     if (cap64 > 0x7FFFFFFFull) { c->err = "render: batch too large"; return RTX_ERR_INVALID; }
     const uint32_t cap = (uint32_t)cap64;
-    HIPCHK(c, c->d_ray_o.ensure((size_t)cap * 16)); HIPCHK(c, c->d_ray_d.ensure((size_t)cap * 16));
-    HIPCHK(c, c->d_thr.ensure((size_t)cap * 16)); HIPCHK(c, c->d_rad.ensure((size_t)cap * 16)); HIPCHK(c, c->d_hit.ensure((size_t)cap * 16));
+    HIPCHK(c, c->d_rad.ensure((size_t)cap * 16));
     // work distribution: G workgroups, each with a private sub-queue (no global atomics in the loop)
     // sub-queues per CU: shorter tails with more, but more per-workgroup overhead; the fused tiny-scene kernels (5 workgroups resident per
     // CU, longest-first dispatch, all bounces >= 1 in one launch) measured 18.39 / 18.15 / 18.13 / 18.30 / 18.36 ms at 24 / 32 / 40 / 48 / 64
@@ -407,6 +409,12 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     const uint32_t qcap = ((nchunks + G - 1) / G) * 256u;
     f.nblocks = G; f.qcap = qcap;
     const size_t qtot = (size_t)G * qcap;
+    // path state: by path id (cap entries), or — separate kernels of the default configuration — by queue position (qtot >= cap entries) in two sets
+    const bool compact = c->compact_state && !(c->dsc.nsmall && c->fused) && !fused_bvh && !c->sort_materials;
+    const size_t nstate = compact ? qtot : (size_t)cap;
+    if (nstate > 0xFFFFFFFFull) { c->err = "render: batch too large"; return RTX_ERR_INVALID; }
+    HIPCHK(c, c->d_ray_o.ensure(nstate * 16)); HIPCHK(c, c->d_ray_d.ensure(nstate * 16)); HIPCHK(c, c->d_thr.ensure(nstate * 16)); HIPCHK(c, c->d_hit.ensure(nstate * 16));
+    if (compact) { HIPCHK(c, c->d_alt_o.ensure(nstate * 16)); HIPCHK(c, c->d_alt_d.ensure(nstate * 16)); HIPCHK(c, c->d_alt_thr.ensure(nstate * 16)); }
     HIPCHK(c, c->d_queue[0].ensure(qtot * 4)); HIPCHK(c, c->d_queue[1].ensure(qtot * 4));
     HIPCHK(c, c->d_order.ensure((size_t)G * 4));
     if (fused_bvh) HIPCHK(c, c->d_hitq.ensure(qtot * 4));
@@ -421,6 +429,7 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     DevPaths P;
     P.ray_o = (F4*)c->d_ray_o.p; P.ray_d = (F4*)c->d_ray_d.p; P.thr = (F4*)c->d_thr.p; P.rad = (F4*)c->d_rad.p; P.hit = (F4*)c->d_hit.p;
     P.hitmask = nullptr;
+    P.out_o = P.out_d = P.out_thr = nullptr;
     if (c->dsc.nsmall && c->fused) { HIPCHK(c, c->d_hitmask.ensure(((size_t)cap / 64 + 1) * 8)); P.hitmask = (unsigned long long*)c->d_hitmask.p; }
     P.sh_o = (F4*)c->d_sh_o.p; P.sh_d = (F4*)c->d_sh_d.p; P.sh_c = (F4*)c->d_sh_c.p;
     uint32_t* queue[2] = {(uint32_t*)c->d_queue[0].p, (uint32_t*)c->d_queue[1].p};
@@ -454,7 +463,7 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
         const bool fused = c->dsc.nsmall && c->fused;
         uint32_t* gen_row = cnt + ((size_t)(mb + 1) + (size_t)mb * nee1) * G;
         if (fused) { Timed t(c, RTX_K_RAYGEN); launch_raygen_trace_small(st, c->dsc, fb, P, cam, queue[0], Q(0), gen_row, (const unsigned long long*)c->d_pmask.p); }
-        else { Timed t(c, RTX_K_RAYGEN); launch_raygen(st, fb, P, cam, queue[0], Q(0)); }
+        else { Timed t(c, RTX_K_RAYGEN); launch_raygen(st, fb, P, cam, queue[0], Q(0), compact); }
         // dispatch order of the fused bounce kernels: longest sub-queue first, from the lengths after the primary rays (the later
         // bounces keep the ranking: survivors are a near-constant fraction)
         const uint32_t* order = nullptr;
@@ -473,9 +482,15 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
         auto Hd = [&](uint32_t b, uint32_t k) { return stealing ? (uint32_t*)c->d_heads.p + ((size_t)b * (1 + nee1) + k) * hstride : nullptr; };
         for (uint32_t b = 0; b < mb && !fused && !fused_bvh; b++) {
             uint32_t* q = queue[b & 1]; uint32_t* qn = queue[(b + 1) & 1];
-            { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, fb, c->dsc, P, b, q, Q(b), Hd(b, 0)); }
-            { Timed t(c, RTX_K_SHADE); launch_shade(st, c->dsc, fb, P, b, q, Q(b), qn, Q(b + 1), S(b, 0)); }
-            for (uint32_t j = 0; j < nee; j++) { Timed t(c, RTX_K_SHADOW); launch_trace_shadow(st, fb, c->dsc, P, j, S(b, j), Hd(b, 1 + j)); }
+            DevPaths Pb = P;                                  // compact state: bounce b reads set (b & 1) and writes the survivors into the other one
+            if (compact) {
+                F4* set[2][3] = {{(F4*)c->d_ray_o.p, (F4*)c->d_ray_d.p, (F4*)c->d_thr.p}, {(F4*)c->d_alt_o.p, (F4*)c->d_alt_d.p, (F4*)c->d_alt_thr.p}};
+                Pb.ray_o = set[b & 1][0]; Pb.ray_d = set[b & 1][1]; Pb.thr = set[b & 1][2];
+                Pb.out_o = set[(b + 1) & 1][0]; Pb.out_d = set[(b + 1) & 1][1]; Pb.out_thr = set[(b + 1) & 1][2];
+            }
+            { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, fb, c->dsc, Pb, b, q, Q(b), Hd(b, 0)); }
+            { Timed t(c, RTX_K_SHADE); launch_shade(st, c->dsc, fb, Pb, b, q, Q(b), qn, Q(b + 1), S(b, 0)); }
+            for (uint32_t j = 0; j < nee; j++) { Timed t(c, RTX_K_SHADOW); launch_trace_shadow(st, fb, c->dsc, Pb, j, S(b, j), Hd(b, 1 + j)); }
         }
         { Timed t(c, RTX_K_ACCUM); launch_accumulate(st, max_blocks, fb, P, c->accum_ptr()); }
         HIPCHK(c, hipMemcpyAsync(c->h_counters + (size_t)bi * ncnt, cnt, ncnt * 4, hipMemcpyDeviceToHost, st));

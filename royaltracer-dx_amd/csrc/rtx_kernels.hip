@@ -39,7 +39,7 @@ __device__ unsigned long long g_sec[36];          // [0,12) cycles, [12,24) acti
 // ---------------------------------------------------------------------------------------------
 // raygen: one thread per path slot of the batch
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_raygen(DevFrame f, DevPaths p, const CameraGPU* __restrict__ cam_p, uint32_t* __restrict__ queue, uint32_t* __restrict__ qcount) {
+__global__ __launch_bounds__(kBlock) void k_raygen(DevFrame f, DevPaths p, const CameraGPU* __restrict__ cam_p, uint32_t* __restrict__ queue, uint32_t* __restrict__ qcount, uint32_t compact) {
     __shared__ CameraGPU cam;
     __shared__ uint32_t s_n;
     if (threadIdx.x < 64) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
@@ -55,18 +55,19 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DevFrame f, DevPaths p, const
         const uint32_t pid = sl * f.npl + pl;
         uint32_t x = 0, y = 0;
         const bool valid = slot_to_pixel(f, pl, x, y);
+        const uint32_t slot = block_push(valid, &s_n);
         if (valid) {
             uint32_t s0, s1; seed_init(x, y, f.sample_first + sl, f.frame_seed, s0, s1);
             float jx = 0.0f, jy = 0.0f;
             if (f.flags & 2u) { jx = tea_next(s0, s1); jy = tea_next(s0, s1); }   // RayGen.hlsl:84-85
             f3 o, d; primary_ray(cam, f.width, f.height, x, y, jx, jy, o, d);
-            p.ray_o[pid] = {o.x, o.y, o.z, u2f(s1)};
-            p.ray_d[pid] = {d.x, d.y, d.z, 1.0f};
-            p.thr[pid] = {1.0f, 1.0f, 1.0f, u2f(s0)};
+            const uint32_t dst = compact ? blockIdx.x * f.qcap + slot : pid;      // compact state: indexed by the queue position
+            p.ray_o[dst] = {o.x, o.y, o.z, u2f(s1)};
+            p.ray_d[dst] = {d.x, d.y, d.z, 1.0f};
+            p.thr[dst] = {1.0f, 1.0f, 1.0f, u2f(s0)};
             p.rad[pid] = {0.0f, 0.0f, 0.0f, 0.0f};
+            myq[slot] = pid;
         }
-        const uint32_t slot = block_push(valid, &s_n);
-        if (valid) myq[slot] = pid;
     }
     __syncthreads();
     if (threadIdx.x == 0) qcount[blockIdx.x] = s_n;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
     const uint32_t* myq = queue + (size_t)blockIdx.x * qcap;
     if (sc.nsmall) {                                       // tiny scene, un-fused kernels (test path)
         for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
-            const uint32_t pid = myq[i];
+            const uint32_t pid = p.out_o ? blockIdx.x * qcap + i : myq[i];       // compact state: the queue position is the index
             const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
             float t, u, v; uint32_t prim;
             traverse_small<false>(sc, small, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, t, u, v, prim, sc.nsmall);
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
     RaySource W{heads, qcount, gridDim.x, blockIdx.x, n, 0u, 0u};
     uint32_t rng = steal_seed();
     auto fetch = [&](uint32_t q, uint32_t idx) {
-        const uint32_t pid = queue[(size_t)q * qcap + idx];
+        const uint32_t pid = p.out_o ? q * qcap + idx : queue[(size_t)q * qcap + idx];
         const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
         ray_begin(R, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, pid, true);
     };
@@ -240,8 +241,12 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const Smal
 // coalesced per-path state streams into gathers; k_trace_shadow gains 4-8 % from the more coherent shadow rays, the
 // frame loses 1-10 %.  Hence RTX_OPT_SORT_MATERIALS defaults to 0.
 constexpr uint32_t kSortChunk = 2048, kSortKeys = 64;
+#ifndef RTX_SHADE_WAVES
+#define RTX_SHADE_WAVES 6          // waves per SIMD k_shade is compiled for: 6 = 80 VGPRs, no spills (uncapped: 94 VGPRs, 5 waves; 8: 64 VGPRs, 8 spilled).  k_shade
+                                   // per frame, C3 / C5: 7.42 / 8.77 ms uncapped, 6.93 / 8.54 at 6, 7.50 / 8.83 at 8
+#endif
 template <bool SORT>
-__global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPaths p, uint32_t bounce,
+__global__ __launch_bounds__(kBlock, RTX_SHADE_WAVES) void k_shade(DevScene sc, DevFrame f, DevPaths p, uint32_t bounce,
                                                   const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount,
                                                   uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count,
                                                   uint32_t* __restrict__ shcounts /* [nee][gridDim.x] */) {
@@ -288,10 +293,11 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPa
             bool shading = false;
             if (i < cn) {
                 const uint32_t pid = SORT ? s_sorted[i] : myq[cb + i];
-                const F4 h = p.hit[pid];
+                const uint32_t src = (!SORT && p.out_o) ? (uint32_t)qb + cb + i : pid;     // compact state: hit and path state live at the queue position
+                const F4 h = p.hit[src];
                 const uint32_t prim = f2u(h.w);
                 if (prim != kMissPrim) {                                          // miss: Miss.hlsl:3-11 -> black, terminate
-                    S = load_path(p, pid);
+                    S = load_path(p, src); S.pid = pid;
                     sf = surface(sc, S.o, S.d, h.x, h.y, h.z, prim);
                     if (sf.mat < sc.nmat) {
                         const MatGPU& m = sc.mats[sf.mat];
@@ -315,9 +321,12 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevFrame f, DevPa
             bool alive = false;
             f3 smp = mk3(0, 0, 1); float P = 0.0f;
             if (shading && !last) alive = bsdf_continue(*mp, f, bounce, S, normal, outgoing, smp, P, eta_p);
-            if (alive) store_path(p, S, pos, smp, P);
             const uint32_t slot = block_push(alive, &s_cnt[0]);
-            if (alive) mynext[slot] = S.pid;
+            if (alive) {
+                if (!SORT && p.out_o) store_path_at(p.out_o, p.out_d, p.out_thr, (uint32_t)qb + slot, S, pos, smp, P);     // densely, at its place in the next queue
+                else store_path(p, S, pos, smp, P);
+                mynext[slot] = S.pid;
+            }
         }
         if (SORT) __syncthreads();                              // the next chunk overwrites the LDS buffers
     }
@@ -955,8 +964,8 @@ size_t trace_lds_bytes_queue(const DevScene& sc) {   // queue kernels with a pri
     return (size_t)sc.lds_nodes * 80 + (size_t)sc.lds_tris * 48 + small_planes_bytes(sc) + stack;
 }
 
-void launch_raygen(hipStream_t st, const DevFrame& f, const DevPaths& p, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount) {
-    hipLaunchKernelGGL(k_raygen, dim3(f.nblocks), dim3(kBlock), 0, st, f, p, cam, queue, qcount);
+void launch_raygen(hipStream_t st, const DevFrame& f, const DevPaths& p, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount, bool compact) {
+    hipLaunchKernelGGL(k_raygen, dim3(f.nblocks), dim3(kBlock), 0, st, f, p, cam, queue, qcount, compact ? 1u : 0u);
 }
 void launch_packet_masks(hipStream_t st, const DevScene& sc, const DevFrame& f, const CameraGPU* cam, unsigned long long* masks) {
     const uint32_t nblk = f.npl / 64u;

@@ -611,7 +611,10 @@ bool collapse_bvh8(const std::vector<NodeGPU>& n2, std::vector<Node8GPU>& n8, st
     //      parent: as ONE slot (a leaf slot holding all its <= 4 triangles, or an internal slot = a wide node of its own with 8
     //      slots to distribute), or split between its two children.  Greedy "open the largest child" filled 4.1 of 8 slots. ----
     const size_t nn = n2.size();
-    constexpr double kNodeCost = 1.0, kTriCost = 0.45;     // a triangle test costs ~0.45 node steps (VALU counts 95 : 207)
+    // a triangle test is 95 VALU instructions against ~200 of a node step, but triangle steps run with half the lanes of node steps
+    // (profiles/r02_traversal.md), so per ray it costs more than the 0.45 the instruction counts say: measured k_trace_closest
+    // 23.80 / 21.31 ms (C3 / C5) at 0.45, 23.39 / 20.93 at 0.7, 23.49 / 21.00 at 1.0, 23.53 / 20.95 at 1.5, 24.30 / 21.82 at 0.3
+    constexpr double kNodeCost = 1.0, kTriCost = 0.7;
     struct Sub { double area; uint32_t prims, first; };
     std::vector<Sub> sub(nn);
     std::vector<std::array<double, 8>> cost(nn);           // index 1..7

@@ -134,10 +134,11 @@ __device__ __forceinline__ bool bsdf_continue(const MatGPU& m, const DevFrame& f
     return true;
 }
 
-__device__ __forceinline__ void store_path(const DevPaths& p, const PathState& S, f3 pos, f3 smp, float P) {
-    p.ray_o[S.pid] = {pos.x, pos.y, pos.z, u2f(S.s1)};       // un-offset origin, Sampler_v6.hlsl:224-227
-    p.ray_d[S.pid] = {smp.x, smp.y, smp.z, P};                // pdf for the MIS at the next emissive hit, Hit.hlsl:369
-    p.thr[S.pid] = {S.thr.x, S.thr.y, S.thr.z, u2f(S.s0)};
+__device__ __forceinline__ void store_path_at(F4* ray_o, F4* ray_d, F4* thr, uint32_t idx, const PathState& S, f3 pos, f3 smp, float P) {
+    ray_o[idx] = {pos.x, pos.y, pos.z, u2f(S.s1)};            // un-offset origin, Sampler_v6.hlsl:224-227
+    ray_d[idx] = {smp.x, smp.y, smp.z, P};                    // pdf for the MIS at the next emissive hit, Hit.hlsl:369
+    thr[idx] = {S.thr.x, S.thr.y, S.thr.z, u2f(S.s0)};
 }
+__device__ __forceinline__ void store_path(const DevPaths& p, const PathState& S, f3 pos, f3 smp, float P) { store_path_at(p.ray_o, p.ray_d, p.thr, S.pid, S, pos, smp, P); }
 
 }  // namespace rtx

@@ -27,7 +27,7 @@ def ctx(rt):
     c.close()
 
 
-@pytest.fixture(scope="module", params=["fused_small", "separate_small", "separate_bvh", "fused_bvh", "steal_bvh"])
+@pytest.fixture(scope="module", params=["fused_small", "separate_small", "separate_bvh", "fused_bvh", "steal_bvh", "inplace_bvh"])
 def cornell_pair(request, rt, orc, cornell):
     """Cornell through every kernel path: fused bounce kernel (default for tiny scenes), separate
     trace / shade / shadow kernels with the tiny-scene traversal, and the general BVH traversal with separate kernels
@@ -35,6 +35,7 @@ def cornell_pair(request, rt, orc, cornell):
     c = rt.Context(0)
     c.set_option(rt.OPT_SMALL_SCENE, 0 if request.param.endswith("_bvh") else 1)
     c.set_option(rt.OPT_WORK_STEALING, 1 if request.param == "steal_bvh" else 0)
+    c.set_option(rt.OPT_COMPACT_STATE, 0 if request.param == "inplace_bvh" else 1)      # path state by path id, in place (the default keeps it by queue position)
     c.set_option(rt.OPT_FUSED_BVH, 1 if request.param == "fused_bvh" else 0)
     c.set_option(rt.OPT_FUSED_BOUNCE, 1 if request.param == "fused_small" else 0)
     c.upload(cornell, 16 / 9)
@@ -853,9 +854,10 @@ def test_c4_sizes_4k_shards_and_stack_variants(rt, orc):
     # the last entry also turns on the material-sorted k_shade variant
     # entries 8-12 run the separate trace / shade / shadow kernels (RTX_OPT_FUSED_BVH = 0), entry 10 with material-sorted shading,
     # entries 11-12 with work stealing between the sub-queues (RTX_OPT_WORK_STEALING)
-    for k, (stack, sched) in enumerate(((0, 6), (1, 6), (0, 0), (0, 2), (0, 5), (0, 7), (0, 3), (0, 6), (0, 6), (1, 2), (0, 6), (0, 6), (1, 2))):
+    # entries 12-13: path state by path id, in place (RTX_OPT_COMPACT_STATE = 0; the others keep it by queue position, the default)
+    for k, (stack, sched) in enumerate(((0, 6), (1, 6), (0, 0), (0, 2), (0, 5), (0, 7), (0, 3), (0, 6), (0, 6), (1, 2), (0, 6), (0, 6), (1, 2), (0, 6))):
         c = rt.Context(0); c.set_option(rt.OPT_STACK_PRIVATE, stack); c.set_option(rt.OPT_TRACE_SCHED, sched)
-        c.set_option(rt.OPT_FUSED_BVH, 0 if k >= 8 else 1); c.set_option(rt.OPT_WORK_STEALING, 1 if k >= 11 else 0)
+        c.set_option(rt.OPT_FUSED_BVH, 0 if k >= 8 else 1); c.set_option(rt.OPT_WORK_STEALING, 1 if k in (11, 12) else 0); c.set_option(rt.OPT_COMPACT_STATE, 0 if k >= 12 else 1)
         c.set_option(rt.OPT_SORT_MATERIALS, 1 if k in (7, 10) else 0); c.upload(sc, W / H)
         c.clear(W, H); c.render(rt.Params(**base)); imgs.append(c.read_accum())
         if k == 0:

@@ -13,9 +13,10 @@ W, H = 1920, 1080
 c = rt.Context(0); c.upload(sc, W / H)
 c.set_option(rt.OPT_KERNEL_TIMING, 1)
 p = rt.Params(width=W, height=H, spp=16, max_bounces=mb, nee_samples=1, flags=1 if kind == "sponza" else 4)
+OPT = int(os.environ.get("PROBE_OPT", rt.OPT_WORK_STEALING))
 for steal in (0, 1, 0, 1):
-    c.set_option(rt.OPT_WORK_STEALING, steal)
+    c.set_option(OPT, steal)
     c.clear(W, H); c.render(p); c.clear(W, H); c.render(p)
     st = c.stats()
-    print(f"{kind} mb={mb} stealing={steal}: frame {st.render_ms:.2f} ms; " + ", ".join(f"{rt.KERNEL_NAMES[i]} {st.kernel_ms[i]:.2f}" for i in rt.KERNEL_NAMES if st.kernel_launches[i] > 0))
+    print(f"{kind} mb={mb} opt {OPT}={steal}: frame {st.render_ms:.2f} ms; " + ", ".join(f"{rt.KERNEL_NAMES[i]} {st.kernel_ms[i]:.2f}" for i in rt.KERNEL_NAMES if st.kernel_launches[i] > 0))
 c.close()

@@ -136,6 +136,12 @@ OPK(51, "v_max_f32_e64 %0, %0, %1")
 OPK(52, "v_sub_f32_e64 %0, %0, %1")
 OPK(53, "v_mov_b32_e64 %0, %1")
 OPK(54, "v_or_b32_e64 %0, %0, %3")
+OPK(55, "v_fma_mix_f32 %0, %3, %1, %0 op_sel_hi:[1,0,0]")
+OPK(56, "v_fma_mix_f32 %0, %3, %1, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]")
+OPK(57, "v_cvt_f32_f16 %0, %3")
+OPK(60, "v_fma_mix_f32 %0, %0, %1, %2")
+OPK(61, "v_cvt_f32_ubyte3 %0, %3")
+OPK(62, "v_mul_f32_sdwa %0, %3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD")
 
 template <int ID>
 static int run_op(const char* name, int ncu, float* d_out, unsigned long long* d_cyc, unsigned long long* d_rt) {
@@ -191,7 +197,8 @@ static int run(const char* name, int ncu, int inst_per_iter, float* d_out, unsig
     return 0;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const int first_op = argc > 1 ? atoi(argv[1]) : 0;          // run only the per-opcode kernels with id >= first_op
     hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
     const int ncu = prop.multiProcessorCount;
     printf("device %s, %d CUs, clock %d kHz\n", prop.name, ncu, prop.clockRate);
@@ -203,7 +210,7 @@ int main() {
     if (run<3>("v_rcp_f32 independent", ncu, 64, d_out, d_cyc, d_rt)) return 1;
     if (run<4>("cvt/fma/max3/cmp mix", ncu, 64, d_out, d_cyc, d_rt)) return 1;
     if (run<5>("v_add_u32 dependent chain", ncu, 64, d_out, d_cyc, d_rt)) return 1;
-#define RUNOP(ID, NAME) if (run_op<ID>(NAME, ncu, d_out, d_cyc, d_rt)) return 1;
+#define RUNOP(ID, NAME) if (ID >= first_op && run_op<ID>(NAME, ncu, d_out, d_cyc, d_rt)) return 1;
     RUNOP(16, "v_fma_f32") RUNOP(0, "v_mul_f32") RUNOP(1, "v_add_f32") RUNOP(2, "v_max3_f32") RUNOP(3, "v_min_f32") RUNOP(4, "v_cvt_f32_ubyte0")
     RUNOP(5, "v_cmp_le_f32 vcc") RUNOP(6, "v_cndmask_b32") RUNOP(7, "v_sqrt_f32") RUNOP(8, "v_rsq_f32") RUNOP(9, "v_mul_lo_u32") RUNOP(10, "v_lshl_add_u32")
     RUNOP(11, "v_xor_b32") RUNOP(22, "v_add3_u32") RUNOP(23, "v_xad_u32") RUNOP(12, "v_add_u32") RUNOP(13, "v_div_scale_f32") RUNOP(14, "v_div_fmas_f32") RUNOP(15, "v_div_fixup_f32") RUNOP(17, "v_mov_b32")
@@ -214,5 +221,6 @@ int main() {
     RUNOP(44, "v_mul_legacy_f32") RUNOP(45, "v_ldexp_f32") RUNOP(46, "v_dot2c_f32_f16")
     RUNOP(47, "v_add_u32_e64") RUNOP(48, "v_xor_b32_e64") RUNOP(49, "v_and_b32_e64") RUNOP(50, "v_lshrrev_b32_e64") RUNOP(51, "v_max_f32_e64") RUNOP(52, "v_sub_f32_e64") RUNOP(53, "v_mov_b32_e64")
     RUNOP(54, "v_or_b32_e64")
+    RUNOP(55, "v_fma_mix_f32 f16lo,f32,f32") RUNOP(56, "v_fma_mix_f32 f16hi,f32,f32") RUNOP(57, "v_cvt_f32_f16") RUNOP(60, "v_fma_mix_f32 all f32") RUNOP(61, "v_cvt_f32_ubyte3") RUNOP(62, "v_mul_f32_sdwa byte1")
     return 0;
 }
