@@ -54,8 +54,9 @@ struct DevPaths {
     F4* sh_c;    // contribution.xyz, pid bits
     // COMPACT path state (separate trace / shade kernels, RTX_OPT_COMPACT_STATE): ray_o / ray_d / thr / hit are indexed by the QUEUE POSITION
     // (sub-queue * qcap + entry) instead of the path id, and k_shade writes the state of a surviving path at its position in the NEXT queue
-    // into the other buffer set (out_*).  The survivors of a bounce then lie densely in memory: by path id only ~17 % of the slots are alive
-    // after bounce 0 on the BVH workloads, and every 16-B access dragged a 128-B line through the fabric.  rad stays indexed by path id.
+    // into the other buffer set (out_*).  A wave's state accesses stay one contiguous run however many paths died before (by path id the
+    // bounces after Russian roulette touched one 16-B record per 128-B line), and the trace kernels need no queue read before they can
+    // fetch a ray.  rad stays indexed by path id.
     F4* out_o; F4* out_d; F4* out_thr;        // nullptr: state indexed by path id, updated in place
 };
 
