@@ -410,7 +410,7 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     f.nblocks = G; f.qcap = qcap;
     const size_t qtot = (size_t)G * qcap;
     // path state: by path id (cap entries), or — separate kernels of the default configuration — by queue position (qtot >= cap entries) in two sets
-    const bool compact = c->compact_state && !(c->dsc.nsmall && c->fused) && !fused_bvh && !c->sort_materials;
+    const bool compact = c->compact_state && !(c->dsc.nsmall && c->fused) && !fused_bvh;
     const size_t nstate = compact ? qtot : (size_t)cap;
     if (nstate > 0xFFFFFFFFull) { c->err = "render: batch too large"; return RTX_ERR_INVALID; }
     HIPCHK(c, c->d_ray_o.ensure(nstate * 16)); HIPCHK(c, c->d_ray_d.ensure(nstate * 16)); HIPCHK(c, c->d_thr.ensure(nstate * 16)); HIPCHK(c, c->d_hit.ensure(nstate * 16));

@@ -141,7 +141,8 @@ __global__ __launch_bounds__(kBlock) void k_raygen_trace_small(DevScene sc, cons
 }
 
 // closest hit for every path in this workgroup's sub-queue: reads ray_o/ray_d, writes hit
-template <int STK, bool STEAL>   // traversal stack: 0 = LDS column, 1 = private (scratch); STEAL: work stealing between sub-queues (refill_steal)
+template <int STK, bool STEAL, int SCHED>   // traversal stack: 0 = LDS column, 1 = private (scratch); STEAL: work stealing between sub-queues (refill_steal);
+                                            // SCHED: the wave schedule as a compile-time constant (the default, 6), or -1 = the run-time parameter (experiment knobs)
 __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin, uint32_t refill_min, uint32_t sched, uint32_t* heads) {
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_head;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
     const TraceLds L = stage_lds(sc, lds);
     __syncthreads();
     const uint32_t* myq = queue + (size_t)blockIdx.x * qcap;
-    if (sc.nsmall) {                                       // tiny scene, un-fused kernels (test path)
+    if (SCHED < 0 && sc.nsmall) {                          // tiny scene, un-fused kernels (test path)
         for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
             const uint32_t pid = p.out_o ? blockIdx.x * qcap + i : myq[i];       // compact state: the queue position is the index
             const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
@@ -173,7 +174,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
         ray_begin(R, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, pid, true);
     };
     while (STEAL ? refill_steal(R, W, drained, refill_min, rng, fetch) : refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) { fetch(blockIdx.x, idx); })) {
-        if (sched >= 5u) spec_step<false>(sc, L, R, stk, sched);
+        if (SCHED >= 5) spec_step<false>(sc, L, R, stk, (uint32_t)SCHED);
+        else if (sched >= 5u) spec_step<false>(sc, L, R, stk, sched);
         else if (sched) voted_step<false>(sc, L, R, stk, sched);
         else { walk_internal<false>(sc, L, R, stk); process_leaf<false>(sc, L, R, stk); }
         if (R.has && R.done) { p.hit[R.item] = {R.bt, R.bu, R.bv, u2f(R.bprim)}; R.has = false; }
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
 
 // any-hit for NEE slot j: visible contributions are added to the path's radiance (a path appears at most once
 // per slot, so the read-modify-write needs no atomic and the order of additions per path is fixed)
-template <int STK, bool STEAL>
+template <int STK, bool STEAL, int SCHED>
 __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const F4* __restrict__ sh_o, const F4* __restrict__ sh_d,
                                                          const F4* __restrict__ sh_c, const uint32_t* __restrict__ shcount, uint32_t qcap, uint32_t refill_min, uint32_t sched, uint32_t* heads) {
     extern __shared__ F4 lds[];
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const Smal
             p.rad[pid] = r;
         }
     };
-    if (sc.nsmall) {
+    if (SCHED < 0 && sc.nsmall) {
         for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
             const F4 so = sh_o[qb + i], sd = sh_d[qb + i];
             float t, u, v; uint32_t prim;
@@ -224,7 +226,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const Smal
         ray_begin(R, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, gi, false);
     };
     while (STEAL ? refill_steal(R, W, drained, refill_min, rng, fetch) : refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) { fetch(blockIdx.x, idx); })) {
-        if (sched >= 5u) spec_step<true>(sc, L, R, stk, sched);
+        if (SCHED >= 5) spec_step<true>(sc, L, R, stk, (uint32_t)SCHED);
+        else if (sched >= 5u) spec_step<true>(sc, L, R, stk, sched);
         else if (sched) voted_step<true>(sc, L, R, stk, sched);
         else { walk_internal<true>(sc, L, R, stk); process_leaf<true>(sc, L, R, stk); }
         if (R.has && R.done) { finish(R.item, R.bprim != kMissPrim); R.has = false; }
@@ -239,7 +242,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const Smal
 // MEASURED (MI355X, 1080p 16 spp 8 bounces, ms per 2 frames in k_shade): Bistro-class (30 % GGX) 18.1 unsorted vs 23.3
 // sorted, Sponza-class 16.1 vs 32.1 — k_shade is HBM-bound, not divergence-bound, and the permutation turns its
 // coalesced per-path state streams into gathers; k_trace_shadow gains 4-8 % from the more coherent shadow rays, the
-// frame loses 1-10 %.  Hence RTX_OPT_SORT_MATERIALS defaults to 0.
+// frame loses 1-10 %.  Round 2, with the path state kept by queue position (the permutation then stays inside a 2048-entry window of
+// each stream): still slower, k_shade per frame 7.4 -> 10.6 ms (Sponza-class), 8.6 -> 9.8 ms (Bistro-class, where k_shade is VALU-bound at
+// 33 of 64 lanes).  Hence RTX_OPT_SORT_MATERIALS defaults to 0.
 constexpr uint32_t kSortChunk = 2048, kSortKeys = 64;
 #ifndef RTX_SHADE_WAVES
 #define RTX_SHADE_WAVES 6          // waves per SIMD k_shade is compiled for: 6 = 80 VGPRs, no spills (uncapped: 94 VGPRs, 5 waves; 8: 64 VGPRs, 8 spilled).  k_shade
@@ -268,10 +273,9 @@ __global__ __launch_bounds__(kBlock, RTX_SHADE_WAVES) void k_shade(DevScene sc, 
             if (threadIdx.x < kSortKeys) s_hist[threadIdx.x] = 0;
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < cn; i += kBlock) {
-                const uint32_t pid = myq[cb + i];
-                const uint32_t prim = f2u(p.hit[pid].w);
+                const uint32_t prim = f2u(p.hit[p.out_o ? (uint32_t)qb + cb + i : myq[cb + i]].w);
                 const uint32_t key = prim == kMissPrim ? kSortKeys - 1u : (sc.shade[prim].mat % (kSortKeys - 1u));
-                s_pid[i] = pid; s_key[i] = (uint8_t)key;
+                s_pid[i] = i; s_key[i] = (uint8_t)key;                 // (the entry's place in the chunk: the queue position is needed too)
                 atomicAdd(&s_hist[key], 1u);
             }
             __syncthreads();
@@ -292,8 +296,9 @@ __global__ __launch_bounds__(kBlock, RTX_SHADE_WAVES) void k_shade(DevScene sc, 
             Surf sf; sf.mat = 0; sf.normal = mk3(0, 0, 1); sf.pos = mk3(0, 0, 0);
             bool shading = false;
             if (i < cn) {
-                const uint32_t pid = SORT ? s_sorted[i] : myq[cb + i];
-                const uint32_t src = (!SORT && p.out_o) ? (uint32_t)qb + cb + i : pid;     // compact state: hit and path state live at the queue position
+                const uint32_t qi = cb + (SORT ? s_sorted[i] : i);                // entry of the sub-queue
+                const uint32_t pid = myq[qi];
+                const uint32_t src = p.out_o ? (uint32_t)qb + qi : pid;               // compact state: hit and path state live at the queue position
                 const F4 h = p.hit[src];
                 const uint32_t prim = f2u(h.w);
                 if (prim != kMissPrim) {                                          // miss: Miss.hlsl:3-11 -> black, terminate
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(kBlock, RTX_SHADE_WAVES) void k_shade(DevScene sc, 
             if (shading && !last) alive = bsdf_continue(*mp, f, bounce, S, normal, outgoing, smp, P, eta_p);
             const uint32_t slot = block_push(alive, &s_cnt[0]);
             if (alive) {
-                if (!SORT && p.out_o) store_path_at(p.out_o, p.out_d, p.out_thr, (uint32_t)qb + slot, S, pos, smp, P);     // densely, at its place in the next queue
+                if (p.out_o) store_path_at(p.out_o, p.out_d, p.out_thr, (uint32_t)qb + slot, S, pos, smp, P);     // densely, at its place in the next queue
                 else store_path(p, S, pos, smp, P);
                 mynext[slot] = S.pid;
             }
@@ -977,9 +982,13 @@ void launch_raygen_trace_small(hipStream_t st, const DevScene& sc, const DevFram
 void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t bounce, const uint32_t* queue, const uint32_t* qcount, uint32_t* heads) {
     const float tmin = bounce == 0 ? kTMinCam : kSBias;
     if (sc.nsmall) heads = nullptr;                     // (the un-fused tiny-scene test path has no persistent waves)
-#define RTX_LAUNCH_TC(SS, TT, LDSB) hipLaunchKernelGGL((k_trace_closest<SS, TT>), dim3(f.nblocks), dim3(kBlock), LDSB, st, sc, sc.small, p, queue, qcount, f.qcap, tmin, sc.refill_min, sc.trace_sched, heads)
-    if (sc.stack_private == 1) { if (heads) RTX_LAUNCH_TC(1, true, trace_lds_bytes_queue(sc)); else RTX_LAUNCH_TC(1, false, trace_lds_bytes_queue(sc)); }
-    else { if (heads) RTX_LAUNCH_TC(0, true, trace_lds_bytes(sc)); else RTX_LAUNCH_TC(0, false, trace_lds_bytes(sc)); }
+#define RTX_LAUNCH_TC(SS, TT, CC, LDSB) hipLaunchKernelGGL((k_trace_closest<SS, TT, CC>), dim3(f.nblocks), dim3(kBlock), LDSB, st, sc, sc.small, p, queue, qcount, f.qcap, tmin, sc.refill_min, sc.trace_sched, heads)
+    if (sc.stack_private == 1) { if (heads) RTX_LAUNCH_TC(1, true, -1, trace_lds_bytes_queue(sc)); else RTX_LAUNCH_TC(1, false, -1, trace_lds_bytes_queue(sc)); }
+    else if (heads) RTX_LAUNCH_TC(0, true, -1, trace_lds_bytes(sc));
+#ifndef RTX_NO_SCHED_SPECIAL
+    else if (sc.trace_sched == 6u && !sc.nsmall) RTX_LAUNCH_TC(0, false, 6, trace_lds_bytes(sc));      // the default configuration: schedule compiled in
+#endif
+    else RTX_LAUNCH_TC(0, false, -1, trace_lds_bytes(sc));
 #undef RTX_LAUNCH_TC
 }
 void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce_first, uint32_t bounce_end,
@@ -1004,9 +1013,13 @@ void launch_order_queues(hipStream_t st, const uint32_t* qcount, uint32_t G, uin
 void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t j, const uint32_t* shcount, uint32_t* heads) {
     const size_t seg = (size_t)j * f.qcap * f.nblocks;
     if (sc.nsmall) heads = nullptr;
-#define RTX_LAUNCH_TS(SS, TT, LDSB) hipLaunchKernelGGL((k_trace_shadow<SS, TT>), dim3(f.nblocks), dim3(kBlock), LDSB, st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, sc.refill_min, sc.trace_sched, heads)
-    if (sc.stack_private == 1) { if (heads) RTX_LAUNCH_TS(1, true, trace_lds_bytes_queue(sc)); else RTX_LAUNCH_TS(1, false, trace_lds_bytes_queue(sc)); }
-    else { if (heads) RTX_LAUNCH_TS(0, true, trace_lds_bytes(sc)); else RTX_LAUNCH_TS(0, false, trace_lds_bytes(sc)); }
+#define RTX_LAUNCH_TS(SS, TT, CC, LDSB) hipLaunchKernelGGL((k_trace_shadow<SS, TT, CC>), dim3(f.nblocks), dim3(kBlock), LDSB, st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, sc.refill_min, sc.trace_sched, heads)
+    if (sc.stack_private == 1) { if (heads) RTX_LAUNCH_TS(1, true, -1, trace_lds_bytes_queue(sc)); else RTX_LAUNCH_TS(1, false, -1, trace_lds_bytes_queue(sc)); }
+    else if (heads) RTX_LAUNCH_TS(0, true, -1, trace_lds_bytes(sc));
+#ifndef RTX_NO_SCHED_SPECIAL
+    else if (sc.trace_sched == 6u && !sc.nsmall) RTX_LAUNCH_TS(0, false, 6, trace_lds_bytes(sc));
+#endif
+    else RTX_LAUNCH_TS(0, false, -1, trace_lds_bytes(sc));
 #undef RTX_LAUNCH_TS
 }
 void launch_shade(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce,

@@ -98,6 +98,22 @@ __device__ __forceinline__ bool tri_test(f3 o, f3 d, v4f v0w, v4f e1w, v4f e2w, 
     return t > tmin && t < tmax;
 }
 
+// The same test without early exits (same operations in the same order, so t, u, v are the same bits whenever it accepts): for the wave
+// schedules, where a step tests ONE triangle per lane and the exits only nest the control flow — the compiler kept the lane's best hit in a
+// second register set across the nest and copied it on every exit edge (5 x 4 v_mov per triangle step).
+__device__ __forceinline__ bool tri_test_flat(f3 o, f3 d, v4f v0w, v4f e1w, v4f e2w, float tmin, float tmax, float& t, float& u, float& v) {
+    const f3 v0 = mk3(v0w.x, v0w.y, v0w.z), e1 = mk3(e1w.x, e1w.y, e1w.z), e2 = mk3(e2w.x, e2w.y, e2w.z);
+    const f3 p = cross(d, e2);
+    const float det = dot(e1, p);
+    const float inv = 1.0f / det;
+    const f3 s = o - v0;
+    u = dot(s, p) * inv;
+    const f3 q = cross(s, e1);
+    v = dot(d, q) * inv;
+    t = dot(e2, q) * inv;
+    return (det != 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > tmin) & (t < tmax);
+}
+
 // ---- compressed 8-wide node step ---------------------------------------------------------------------------------
 // One traversal step fetches a Node8GPU (five 16-B loads, or five ds_read_b128 for the staged top of the tree) and tests its
 // eight child boxes.  Planes are byte offsets on the node's power-of-two grid, so
@@ -527,6 +543,23 @@ __device__ __forceinline__ void tri_step(const DevScene& sc, const TraceLds& L, 
         }
     }
 }
+// Triangle step of the speculative schedule: tests the next pending triangle and only REPORTS what it found (closest hit: a record that
+// beats the lane's best; any hit: a hit) — the caller applies it after the wave-uniform node / triangle branch has merged.  Updating the
+// lane's best record inside the branch made the compiler keep it in a second register set there and copy it on every edge of the
+// (nested) control flow: 12-24 v_mov per iteration, ~10 % of the loop's VALU instructions.
+template <bool ANY>
+__device__ __forceinline__ bool tri_candidate(const DevScene& sc, const TraceLds& L, RayLane& R, float& t, float& u, float& w, uint32_t& gid) {
+    const uint32_t bit = (uint32_t)__builtin_ctz(R.T.bits);
+    R.T.bits &= R.T.bits - 1u;
+    const uint32_t slot = tri_slot8(R.T, bit);
+    v4f v0, e1, e2;
+    if (slot < sc.lds_tris) { const lds_v4f* tp = L.tris + slot * 3u; v0 = tp[0]; e1 = tp[1]; e2 = tp[2]; }
+    else { const v4f* tp = (const v4f*)(sc.tris + slot); v0 = tp[0]; e1 = tp[1]; e2 = tp[2]; }
+    const bool hit = tri_test_flat(R.o, R.d, v0, e1, e2, R.tmin, R.tmax, t, u, w);
+    gid = f2u(v0.w);
+    if (ANY) return hit;
+    return hit & ((t < R.bt) | ((t == R.bt) & (gid < R.bprim)));
+}
 template <bool ANY, class STK>
 __device__ __forceinline__ void process_leaf(const DevScene& sc, const TraceLds& L, RayLane& R, STK& stk) {
     while (R.has && !R.done && R.T.bits) tri_step<ANY>(sc, L, R);
@@ -576,6 +609,26 @@ __device__ __forceinline__ void spec_step(const DevScene& sc, const TraceLds& L,
     }
 #endif
     const uint32_t wn = sched == 7u ? 2u : 1u, wl = sched == 5u ? 1u : sched == 6u ? 2u : 1u;
+#if RTX_PEND == 2
+    // Two slots: a node step writes its triangles into P (empty, or the lane could not take the step), a triangle step works on T, and ONE
+    // place after both moves P up when T is empty.  (Placing the new group into "T if empty, else P" inside the node branch and shifting inside
+    // the triangle branch is the same state machine, but the compiler then kept two register copies of both groups and paid 12-20 v_mov per
+    // iteration to shuttle between them.)
+    bool upd = false; float ct, cu, cw; uint32_t cg;                        // (set by the triangle branch only)
+    if (ni * wn >= nl * wl && ni) {
+        if (can_node) {
+            if (!(R.G.bits & 0xffu)) { R.sp--; R.G = stk.get(R.sp); }
+            descend8<!ANY>(sc, L, R.o, R.idir, R.oct, R.tmin, R.bt, R.G, R.P[0], stk, R.sp);
+        }
+    } else if (has_tri) upd = tri_candidate<ANY>(sc, L, R, ct, cu, cw, cg);
+    uint32_t updv = upd ? 1u : 0u;
+    asm volatile("" : "+v"(updv));                                          // opaque: keeps the update below OUT of the branch above (the optimiser would thread it back in)
+    if (updv) {
+        if (ANY) { R.bprim = 0u; R.done = true; R.T.bits = 0u; }
+        else { R.bt = ct; R.bu = cu; R.bv = cw; R.bprim = cg; }
+    }
+    if (!R.T.bits) { R.T = R.P[0]; R.P[0].bits = 0u; }
+#else
     if (ni * wn >= nl * wl && ni) {
         if (can_node) {
             if (!(R.G.bits & 0xffu)) { R.sp--; R.G = stk.get(R.sp); }
@@ -597,6 +650,7 @@ __device__ __forceinline__ void spec_step(const DevScene& sc, const TraceLds& L,
             R.P[kPend - 2] = TriGrp{0u, 0u, 0u};
         }
     }
+#endif
     if (R.has && !R.done && !(R.G.bits & 0xffu) && R.sp == 0 && !R.T.bits) R.done = true;
 }
 // wave-level refill: returns false when the wave may exit (queue exhausted and nothing in flight)
