@@ -250,11 +250,13 @@ constexpr uint32_t kSortChunk = 2048, kSortKeys = 64;
 #define RTX_SHADE_WAVES 6          // waves per SIMD k_shade is compiled for: 6 = 80 VGPRs, no spills (uncapped: 94 VGPRs, 5 waves; 8: 64 VGPRs, 8 spilled).  k_shade
                                    // per frame, C3 / C5: 7.42 / 8.77 ms uncapped, 6.93 / 8.54 at 6, 7.50 / 8.83 at 8
 #endif
-template <bool SORT>
-__global__ __launch_bounds__(kBlock, RTX_SHADE_WAVES) void k_shade(DevScene sc, DevFrame f, DevPaths p, uint32_t bounce,
+template <bool SORT, bool LAMBERT>     // LAMBERT: RTX_FLAG_LAMBERT_ONLY as a compile-time constant (no GGX / transmission code in that instantiation)
+__global__ __launch_bounds__(kBlock, RTX_SHADE_WAVES) void k_shade(DevScene sc, DevFrame f_in, DevPaths p, uint32_t bounce,
                                                   const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount,
                                                   uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count,
                                                   uint32_t* __restrict__ shcounts /* [nee][gridDim.x] */) {
+    DevFrame f = f_in;
+    f.flags = LAMBERT ? (f_in.flags | 1u) : (f_in.flags & ~1u);
     __shared__ uint32_t s_cnt[1 + kMaxNee];                 // [0] next-queue length, [1 + j] shadow queue j length
     __shared__ uint32_t s_pid[SORT ? kSortChunk : 1], s_sorted[SORT ? kSortChunk : 1], s_hist[SORT ? kSortKeys : 1];
     __shared__ uint8_t s_key[SORT ? kSortChunk : 1];
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(kBlock, RTX_SHADE_WAVES) void k_shade(DevScene sc, 
             const f3 outgoing = -S.d, pos = sf.pos;
             const MatGPU* mp = sc.mats + (shading ? sf.mat : 0u);
             f3 normal = sf.normal;
-            const float eta_p = transmission_eta(*mp, f.flags, outgoing, normal);          // (extension) hits from behind a dielectric flip the shading normal
+            const float eta_p = LAMBERT ? 0.0f : transmission_eta(*mp, f.flags, outgoing, normal);          // (extension) hits from behind a dielectric flip the shading normal
             for (uint32_t j = 0; j < nee; j++) {                                  // NEE: visibility deferred to k_trace_shadow
                 bool push = false;
                 F4 so = {0, 0, 0, 0}, sd = {0, 0, 0, 0}; f3 con = mk3(0, 0, 0);
@@ -1025,8 +1027,11 @@ void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, 
 void launch_shade(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce,
                   const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts) {
     // material-sorted variant: measured slower (see k_shade), the permutation un-coalesces the per-path state streams
-    if (sc.sort_materials) hipLaunchKernelGGL(k_shade<true>, dim3(f.nblocks), dim3(kBlock), 0, st, sc, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(f.nblocks), dim3(kBlock), 0, st, sc, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);
+#define RTX_LAUNCH_SHADE(SS, LL) hipLaunchKernelGGL((k_shade<SS, LL>), dim3(f.nblocks), dim3(kBlock), 0, st, sc, f, p, bounce, queue, qcount, next_queue, next_count, shcounts)
+    const bool lam = (f.flags & 1u) != 0u;
+    if (sc.sort_materials) { if (lam) RTX_LAUNCH_SHADE(true, true); else RTX_LAUNCH_SHADE(true, false); }
+    else { if (lam) RTX_LAUNCH_SHADE(false, true); else RTX_LAUNCH_SHADE(false, false); }
+#undef RTX_LAUNCH_SHADE
 }
 void launch_v6_pass1(hipStream_t st, uint32_t max_blocks, const DevScene& sc, const DevFrame& f, const CameraGPU* cam, uint32_t sample_id,
                      F4* accum, uint32_t* res_di, uint32_t* res_gi, uint32_t* sdata, unsigned long long* counters, const uint32_t* pixels, uint32_t npixels) {
