@@ -182,64 +182,6 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
     }
 }
 
-// The two trace kernels with the queued schedule (RTX_OPT_TRACE_SCHED 8, experiment: triangle tests shared by the whole wave, rtx_traverse.hpp)
-__global__ __launch_bounds__(kBlock) void k_trace_closest_q(DevScene sc, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin, uint32_t refill_min, uint32_t wq_off) {
-    extern __shared__ F4 lds[];
-    __shared__ uint32_t s_head;
-    const uint32_t n = qcount[blockIdx.x];
-    if (n == 0) return;
-    if (threadIdx.x == 0) s_head = 0;
-    const TraceLds L = stage_lds(sc, lds);
-    WaveQueue Q = wave_queue((lds_u32*)((lds_v4f*)lds + wq_off / 16u));
-    __syncthreads();
-    StackLds stk; stk.col = L.stack + threadIdx.x;
-    RayLaneQ R; rayq_idle(R);
-    bool drained = false;
-    while (refill_q(R, &s_head, n, drained, refill_min, [&](uint32_t idx) {
-               const uint32_t pid = p.out_o ? blockIdx.x * qcap + idx : queue[(size_t)blockIdx.x * qcap + idx];
-               const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
-               rayq_begin<false>(R, Q, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, pid, true);
-           })) {
-        queue_step<false>(sc, L, R, stk, Q, kWqNodeMin);
-        if (R.has && R.done) {
-            const unsigned long long key = Q.best[lane_id()]; const f2v uv = Q.uv[lane_id()];
-            p.hit[R.item] = {u2f((uint32_t)(key >> 32)), uv.x, uv.y, u2f((uint32_t)key)};
-            R.has = false;
-        }
-    }
-}
-__global__ __launch_bounds__(kBlock) void k_trace_shadow_q(DevScene sc, DevPaths p, const F4* __restrict__ sh_o, const F4* __restrict__ sh_d, const F4* __restrict__ sh_c,
-                                                           const uint32_t* __restrict__ shcount, uint32_t qcap, uint32_t refill_min, uint32_t wq_off) {
-    extern __shared__ F4 lds[];
-    __shared__ uint32_t s_head;
-    const uint32_t n = shcount[blockIdx.x];
-    if (n == 0) return;
-    if (threadIdx.x == 0) s_head = 0;
-    const TraceLds L = stage_lds(sc, lds);
-    WaveQueue Q = wave_queue((lds_u32*)((lds_v4f*)lds + wq_off / 16u));
-    __syncthreads();
-    const size_t qb = (size_t)blockIdx.x * qcap;
-    StackLds stk; stk.col = L.stack + threadIdx.x;
-    RayLaneQ R; rayq_idle(R);
-    bool drained = false;
-    while (refill_q(R, &s_head, n, drained, refill_min, [&](uint32_t idx) {
-               const F4 so = sh_o[qb + idx], sd = sh_d[qb + idx];
-               rayq_begin<true>(R, Q, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, idx, false);
-           })) {
-        queue_step<true>(sc, L, R, stk, Q, kWqNodeMin);
-        if (R.has && R.done) {
-            if (((lds_u32*)(Q.best + lane_id()))[0] != 0u) {          // not occluded
-                const F4 c = sh_c[qb + R.item];
-                const uint32_t pid = f2u(c.w);
-                F4 r = p.rad[pid];
-                r.x = r.x + c.x; r.y = r.y + c.y; r.z = r.z + c.z;
-                p.rad[pid] = r;
-            }
-            R.has = false;
-        }
-    }
-}
-
 // any-hit for NEE slot j: visible contributions are added to the path's radiance (a path appears at most once
 // per slot, so the read-modify-write needs no atomic and the order of additions per path is fixed)
 template <int STK, bool STEAL, int SCHED>
@@ -1043,11 +985,6 @@ void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc,
     const float tmin = bounce == 0 ? kTMinCam : kSBias;
     if (sc.nsmall) heads = nullptr;                     // (the un-fused tiny-scene test path has no persistent waves)
 #define RTX_LAUNCH_TC(SS, TT, CC, LDSB) hipLaunchKernelGGL((k_trace_closest<SS, TT, CC>), dim3(f.nblocks), dim3(kBlock), LDSB, st, sc, sc.small, p, queue, qcount, f.qcap, tmin, sc.refill_min, sc.trace_sched, heads)
-    if (sc.trace_sched == 8u && !sc.nsmall) {          // queued schedule (experiment): LDS column stack, no stealing
-        const uint32_t off = (uint32_t)((trace_lds_bytes(sc) + 15) & ~(size_t)15);
-        hipLaunchKernelGGL(k_trace_closest_q, dim3(f.nblocks), dim3(kBlock), off + (kBlock / 64) * kWqBytes, st, sc, p, queue, qcount, f.qcap, tmin, sc.refill_min, off);
-        return;
-    }
     if (sc.stack_private == 1) { if (heads) RTX_LAUNCH_TC(1, true, -1, trace_lds_bytes_queue(sc)); else RTX_LAUNCH_TC(1, false, -1, trace_lds_bytes_queue(sc)); }
     else if (heads) RTX_LAUNCH_TC(0, true, -1, trace_lds_bytes(sc));
 #ifndef RTX_NO_SCHED_SPECIAL
@@ -1079,11 +1016,6 @@ void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, 
     const size_t seg = (size_t)j * f.qcap * f.nblocks;
     if (sc.nsmall) heads = nullptr;
 #define RTX_LAUNCH_TS(SS, TT, CC, LDSB) hipLaunchKernelGGL((k_trace_shadow<SS, TT, CC>), dim3(f.nblocks), dim3(kBlock), LDSB, st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, sc.refill_min, sc.trace_sched, heads)
-    if (sc.trace_sched == 8u && !sc.nsmall) {
-        const uint32_t off = (uint32_t)((trace_lds_bytes(sc) + 15) & ~(size_t)15);
-        hipLaunchKernelGGL(k_trace_shadow_q, dim3(f.nblocks), dim3(kBlock), off + (kBlock / 64) * kWqBytes, st, sc, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, sc.refill_min, off);
-        return;
-    }
     if (sc.stack_private == 1) { if (heads) RTX_LAUNCH_TS(1, true, -1, trace_lds_bytes_queue(sc)); else RTX_LAUNCH_TS(1, false, -1, trace_lds_bytes_queue(sc)); }
     else if (heads) RTX_LAUNCH_TS(0, true, -1, trace_lds_bytes(sc));
 #ifndef RTX_NO_SCHED_SPECIAL

@@ -672,133 +672,6 @@ __device__ __forceinline__ bool refill(RayLane& R, uint32_t* s_head, uint32_t n,
     return __ballot(R.has) != 0ull;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Queued schedule (RTX_OPT_TRACE_SCHED 8, experiment): triangle tests shared by the whole wave.
-// In the voted schedules a triangle step runs with the ~24 lanes that have a triangle pending.  Here a node step PUSHES the triangles of
-// the leaf slots it hit as (owner lane, triangle) entries into a per-wave queue in LDS, and a triangle phase runs when 64 entries have
-// collected: lane i tests entry i for its owner — the owner's ray comes over ds_bpermute, the result goes into the owner's best-hit
-// record in LDS with ONE 64-bit atomic minimum on (t bits << 32 | triangle id): t > 0, so the float order is the integer order and the
-// key order is exactly "smaller t, ties to the smaller id" — and the lane that holds the minimum afterwards stores its u, v.  The final
-// record is the same minimum over the same set of tested triangles (every triangle a ray pushed is tested before the ray may finish).
-// Per wave: 128 queue entries + 64 keys + 64 (u, v) = 1.5 KB of LDS.
-// ---------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) unsigned long long lds_u64;
-typedef __attribute__((address_space(3))) f2v lds_f2;
-#ifndef RTX_WQ_FLUSH
-#define RTX_WQ_FLUSH 64
-#endif
-constexpr uint32_t kWqFlush = RTX_WQ_FLUSH;            // a triangle phase runs when this many entries have collected
-constexpr uint32_t kWqEntries = 128, kWqBytes = kWqEntries * 4 + 64 * 8 + 64 * 8;       // per wave
-struct WaveQueue { lds_u32* q; lds_u64* best; lds_f2* uv; uint32_t head, tail; };         // head / tail: wave-uniform, monotonic
-struct RayLaneQ {                                       // per-lane state of the queued schedule
-    f3 o, d, idir; float tmin, tmax; uint32_t oct; Grp G; TriGrp T /* triangles not pushed yet */; int sp; uint32_t item, last_pos; bool has, done;
-};
-__device__ __forceinline__ WaveQueue wave_queue(lds_u32* base /* workgroup region */) {
-    lds_u32* w = base + (threadIdx.x >> 6) * (kWqBytes / 4u);
-    return WaveQueue{w, (lds_u64*)(w + kWqEntries), (lds_f2*)(w + kWqEntries + 128u), 0u, 0u};
-}
-__device__ __forceinline__ void rayq_idle(RayLaneQ& R) {
-    R.has = false; R.done = false; R.sp = 0; R.item = 0; R.last_pos = 0; R.o = mk3(0, 0, 0); R.d = mk3(0, 0, 1); R.idir = mk3(0, 0, 1); R.oct = 0;
-    R.tmin = 0.0f; R.tmax = 0.0f; R.G = Grp{0u, 0u}; R.T = TriGrp{0u, 0u, 0u};
-}
-template <bool ANY>
-__device__ __forceinline__ void rayq_begin(RayLaneQ& R, WaveQueue& Q, f3 o, f3 d, float tmin, float tmax, uint32_t item, bool ordered) {
-    R.o = o; R.d = d; R.tmin = tmin; R.tmax = tmax; R.item = item;
-    const float dxs = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
-    const float dys = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
-    const float dzs = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
-    R.idir = mk3(__builtin_amdgcn_rcpf(dxs), __builtin_amdgcn_rcpf(dys), __builtin_amdgcn_rcpf(dzs));
-    R.oct = ray_octant(R.idir);
-    R.sp = 0; R.has = true; R.done = false; R.last_pos = Q.head;
-    R.G = Grp{0u, (ordered ? (1u << R.oct) : 1u) | (1u << 8)}; R.T = TriGrp{0u, 0u, 0u};
-    Q.best[lane_id()] = ((unsigned long long)f2u(tmax) << 32) | (unsigned long long)kMissPrim;     // any-hit: the low word turns 0 on a hit
-    if (!ANY) { const f2v z = {0.0f, 0.0f}; Q.uv[lane_id()] = z; }
-}
-__device__ __forceinline__ float bperm_f(uint32_t src_lane, float v) { return u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)f2u(v))); }
-// one triangle phase: up to 64 queue entries, one per lane.  Runs with ALL lanes (ds_bpermute reads nothing from disabled lanes).
-template <bool ANY>
-__device__ __forceinline__ void queue_tri_phase(const DevScene& sc, const TraceLds& L, const RayLaneQ& R, WaveQueue& Q) {
-    const uint32_t count = Q.tail - Q.head, n = count < 64u ? count : 64u;
-    const bool mine = lane_id() < n;
-    const uint32_t e = Q.q[(Q.head + lane_id()) & (kWqEntries - 1u)];
-    const uint32_t owner = mine ? (e >> 26) : lane_id(), slot = mine ? (e & 0x3ffffffu) : 0u;
-    const f3 o = mk3(bperm_f(owner, R.o.x), bperm_f(owner, R.o.y), bperm_f(owner, R.o.z));
-    const f3 d = mk3(bperm_f(owner, R.d.x), bperm_f(owner, R.d.y), bperm_f(owner, R.d.z));
-    const float tmin = bperm_f(owner, R.tmin), tmax = bperm_f(owner, R.tmax);
-    v4f v0, e1, e2;
-    if (slot < sc.lds_tris) { const lds_v4f* tp = L.tris + slot * 3u; v0 = tp[0]; e1 = tp[1]; e2 = tp[2]; }
-    else { const v4f* tp = (const v4f*)(sc.tris + slot); v0 = tp[0]; e1 = tp[1]; e2 = tp[2]; }
-    float t, u, w;
-    const bool hit = mine & tri_test_flat(o, d, v0, e1, e2, tmin, tmax, t, u, w);
-    if (ANY) { if (hit) ((lds_u32*)(Q.best + owner))[0] = 0u; }
-    else {
-        const unsigned long long key = ((unsigned long long)f2u(t) << 32) | (unsigned long long)f2u(v0.w);
-        if (hit) __hip_atomic_fetch_min(Q.best + owner, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        __builtin_amdgcn_wave_barrier();
-        if (hit && Q.best[owner] == key) { const f2v uvv = {u, w}; Q.uv[owner] = uvv; }
-    }
-    __builtin_amdgcn_wave_barrier();
-    Q.head += n;
-}
-// one iteration of the queued schedule
-template <bool ANY, class STK>
-__device__ __forceinline__ void queue_step(const DevScene& sc, const TraceLds& L, RayLaneQ& R, STK& stk, WaveQueue& Q, uint32_t node_min) {
-    // an any-hit ray that was hit drops the rest of its traversal; it still waits for its queued entries (they name its LANE, which must not
-    // hold another ray when they are tested)
-    if (ANY) { if (R.has && !R.done && ((lds_u32*)(Q.best + lane_id()))[0] == 0u) { R.G.bits &= ~0xffu; R.sp = 0; R.T.bits = 0u; } }
-    const bool live = R.has && !R.done;
-    const bool can_node = live && R.T.bits == 0u && ((R.G.bits & 0xffu) != 0u || R.sp > 0);
-    const uint32_t count = Q.tail - Q.head;
-    const uint32_t ni = (uint32_t)__popcll(__ballot(can_node));
-    const bool any_left = __ballot(live && R.T.bits != 0u) != 0ull;
-    if (count >= kWqFlush || (count != 0u && ni < node_min && !any_left)) { queue_tri_phase<ANY>(sc, L, R, Q); }
-    else {
-        if (can_node) {
-            if (!(R.G.bits & 0xffu)) { R.sp--; R.G = stk.get(R.sp); }
-            const float bt = ANY ? R.tmax : u2f(((lds_u32*)(Q.best + lane_id()))[1]);
-            descend8<!ANY>(sc, L, R.o, R.idir, R.oct, R.tmin, bt, R.G, R.T, stk, R.sp);
-        }
-        // push rounds: one triangle per lane and round, while a whole round fits
-        for (;;) {
-            const unsigned long long m = __ballot(live && R.T.bits != 0u);
-            if (!m || kWqEntries - (Q.tail - Q.head) < 64u) break;
-            if (live && R.T.bits != 0u) {
-                const uint32_t bit = (uint32_t)__builtin_ctz(R.T.bits);
-                R.T.bits &= R.T.bits - 1u;
-                const uint32_t pos = Q.tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                Q.q[pos & (kWqEntries - 1u)] = (lane_id() << 26) | tri_slot8(R.T, bit);
-                R.last_pos = pos + 1u;
-            }
-            Q.tail += (uint32_t)__popcll(m);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    // a ray is finished when it has no node left, has pushed everything and all its entries were tested ((int) difference: the counters wrap)
-    if (R.has && !R.done && !(R.G.bits & 0xffu) && R.sp == 0 && !R.T.bits && (int)(Q.head - R.last_pos) >= 0) R.done = true;
-}
-
-#ifndef RTX_WQ_NODE_MIN
-#define RTX_WQ_NODE_MIN 32
-#endif
-constexpr uint32_t kWqNodeMin = RTX_WQ_NODE_MIN;      // a partly filled queue is flushed when fewer lanes than this can take a node step
-template <class Fetch>
-__device__ __forceinline__ bool refill_q(RayLaneQ& R, uint32_t* s_head, uint32_t n, bool& drained, uint32_t refill_min, Fetch fetch) {
-    const unsigned long long idle = __ballot(!R.has);
-    const uint32_t nidle = (uint32_t)__popcll(idle);
-    if (!drained && (nidle >= refill_min || nidle == 64u)) {            // wave-uniform
-        uint32_t base = 0;
-        if (lane_id() == 0) base = atomicAdd(s_head, nidle);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (base >= n) drained = true;
-        else {
-            const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-            if (!R.has && idx < n) fetch(idx);
-            if (base + nidle >= n) drained = true;
-        }
-    }
-    return __ballot(R.has) != 0ull;
-}
-
 // Refill with work stealing (the separate trace kernels of general scenes).  Every sub-queue has a fetch cursor in GLOBAL memory
 // (heads[q], zeroed before the launch) from which a WAVE takes chunks of kStealChunk entries into a wave-private range (no atomic
 // per refill), and a bitmap (heads[G ...]) marks the sub-queues found exhausted.  A wave whose sub-queue is exhausted does not
