@@ -262,16 +262,26 @@ static int finalise_scene(rtx_ctx* c) {
     s.lights = (const LightGPU*)c->d_lights.p; s.nlights = (uint32_t)B.lights.size();
     s.total_weight = B.total_weight;
     // LDS budget per workgroup: stack + top of tree + first triangles, kept <= 64 KiB
-    s.stack_depth = B.stack8 + 2;                         // exact bound of the 8-wide tree (one sibling group per level) + slack
+    // exact bound of the 8-wide tree, no slack: a level adds ONE entry (the rest of its hit siblings) and only where a node has >= 2 internal
+    // children (collapse_bvh8: need[]); a pop precedes every descent from an exhausted group.  Each entry costs 2 KB of LDS per workgroup, and
+    // LDS decides how many workgroups live on a CU: two entries of slack cost C3 2.3 % (5 instead of 6 workgroups) and C5 1.3 %.
+    s.stack_depth = B.stack8;
     s.stack_private = c->stack_private == 1 ? 1u : 0u;    // 1 (private / scratch) is a tuning knob; it measured slower than the LDS column
-    if (s.stack_depth > 30) { c->err = "commit: BVH too deep for the traversal stack (more than 28 levels of 8-wide nodes)"; return RTX_ERR_INVALID; }
+    if (s.stack_depth > 30) { c->err = "commit: BVH too deep for the traversal stack (more than 30 levels of 8-wide nodes with two or more internal children)"; return RTX_ERR_INVALID; }
     // LDS per workgroup = traversal stack (8 B per entry and lane) + top of the tree (+ all triangles of a small scene), <= 64 KiB.
     const size_t stack_bytes = (size_t)s.stack_depth * 256 * 8;
     const size_t hard = 64 * 1024;
     size_t budget = hard > stack_bytes ? hard - stack_bytes : 0;
     uint32_t want_nodes;
     if (c->lds_nodes_opt >= 0) want_nodes = (uint32_t)c->lds_nodes_opt;
-    else want_nodes = 73;                                  // root + 8 + 64: the first three levels of the wide tree
+    else {
+        // root + 8 + 64 nodes (the first three levels of the wide tree), unless staging only root + 8 lets one more workgroup live on a CU: the
+        // traversal kernels are limited by LDS (160 KB per CU; ~70 VGPRs would allow 7 waves per SIMD), and on a deep tree the 5 KB decide between
+        // 4 and 5 workgroups.  Measured: Bistro-class (3.8 M triangles) 40.4 -> 39.2 ms per frame with 9 nodes, Sponza-class (5 workgroups either
+        // way) 42.3-42.7 with 73 vs 42.7-43.0 with 9.
+        auto groups = [&](uint32_t nodes) { return (160u * 1024u) / (uint32_t)(stack_bytes + (size_t)nodes * 80 + 512); };
+        want_nodes = groups(9) > groups(73) ? 9u : 73u;
+    }
     s.lds_nodes = std::min<uint32_t>(std::min<uint32_t>(want_nodes, s.nnodes), (uint32_t)(budget / 80));
     budget -= (size_t)s.lds_nodes * 80;
     uint32_t want_tris = s.ntris <= 256 ? s.ntris : 0u;                    // triangles only when ALL of them fit

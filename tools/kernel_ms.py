@@ -10,10 +10,11 @@ rt = graft.load_package()
 kind = sys.argv[1] if len(sys.argv) > 1 else "sponza"
 sc = rt.Scene.sponza_class() if kind == "sponza" else rt.Scene.bistro_class()
 W, H = 1920, 1080
-c = rt.Context(0); c.upload(sc, W / H)
+c = rt.Context(0)
 c.set_option(rt.OPT_KERNEL_TIMING, 1)
 for a in sys.argv[2:]:
     k, v = a.split("="); c.set_option(int(k), int(v))
+c.upload(sc, W / H)
 p = rt.Params(width=W, height=H, spp=16, max_bounces=8, nee_samples=1, flags=1 if kind == "sponza" else 4)
 for rep in range(3):
     c.clear(W, H); c.render(p)
