@@ -606,6 +606,7 @@ __device__ __forceinline__ void spec_step(const DevScene& sc, const TraceLds& L,
             atomicAdd(&g_trv[4], (unsigned long long)nbusy); atomicAdd(&g_trv[5], 1ull);
             atomicAdd(&g_trv[6], (unsigned long long)nboth);     // lanes that could do either
         }
+        if (busy && R.sp > 0) atomicMax(&g_trv[7], (unsigned long long)R.sp);       // deepest stack seen (the LDS column holds exactly sc.stack_depth entries)
     }
 #endif
     const uint32_t wn = sched == 7u ? 2u : 1u, wl = sched == 5u ? 1u : sched == 6u ? 2u : 1u;

@@ -21,10 +21,12 @@ assert rt.lib.rtx_debug_traversal(out, 1) == 0
 c.render(p)
 assert rt.lib.rtx_debug_traversal(out, 0) == 0
 ni, nl, ti, tl, busy, it, both = [float(x) for x in out[:7]]
+max_sp = int(out[7])
 st = c.stats(); rays = st.rays_primary + st.rays_extension
 print(f"{os.path.basename(os.environ['RTX_LIB_PATH'])} sched {sys.argv[2] if len(sys.argv) > 2 else 'default'}")
 print(f"{kind}: closest-hit traversal, {rays / 1e6:.1f} M rays, {it / 1e6:.1f} M wave iterations")
 print(f"  node iterations {ni / it:.2%} of all, lanes taking part {nl / ni:.1f} of 64;  triangle iterations {ti / it:.2%}, lanes {tl / ti:.1f} of 64")
 print(f"  busy lanes (holding an unfinished ray) {busy / it:.1f} of 64; lanes that could do either step {both / it:.1f}")
 print(f"  per ray: {nl / rays:.2f} node steps, {tl / rays:.2f} triangle tests")
+print(f"  deepest traversal stack seen: {max_sp} entries")
 c.close()
