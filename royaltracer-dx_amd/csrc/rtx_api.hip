@@ -275,12 +275,7 @@ static int finalise_scene(rtx_ctx* c) {
     uint32_t want_nodes;
     if (c->lds_nodes_opt >= 0) want_nodes = (uint32_t)c->lds_nodes_opt;
     else {
-        // root + 8 + 64 nodes (the first three levels of the wide tree), unless staging only root + 8 lets one more workgroup live on a CU: the
-        // traversal kernels are limited by LDS (160 KB per CU; ~70 VGPRs would allow 7 waves per SIMD), and on a deep tree the 5 KB decide between
-        // 4 and 5 workgroups.  Measured: Bistro-class (3.8 M triangles) 40.4 -> 39.2 ms per frame with 9 nodes, Sponza-class (5 workgroups either
-        // way) 42.3-42.7 with 73 vs 42.7-43.0 with 9.
-        auto groups = [&](uint32_t nodes) { return (160u * 1024u) / (uint32_t)(stack_bytes + (size_t)nodes * 80 + 512); };
-        want_nodes = groups(9) > groups(73) ? 9u : 73u;
+        want_nodes = 73;                                   // root + 8 + 64: the first three levels of the wide tree; trimmed below for occupancy
     }
     s.lds_nodes = std::min<uint32_t>(std::min<uint32_t>(want_nodes, s.nnodes), (uint32_t)(budget / 80));
     budget -= (size_t)s.lds_nodes * 80;
@@ -292,6 +287,20 @@ static int finalise_scene(rtx_ctx* c) {
         s.nsmall = B.small_nrec; s.nsmall_occ = B.small_nocc; s.lds_tris = (uint32_t)B.small_tris.size();   // LDS holds the records' triangles instead of the leaf-ordered ones
     }
     if (trace_lds_bytes(s) > 64 * 1024) { c->err = "commit: BVH too deep for the LDS traversal stack"; return RTX_ERR_INVALID; }
+    // Staged nodes vs workgroups per CU.  The persistent traversal kernels are limited by LDS (160 KB per CU), and they gain from every workgroup
+    // (`k_trace_shadow` C3: 12.8 -> 12.0 ms for one more) more than from nodes in LDS.  So: the workgroup count that root + 8 nodes alone would reach,
+    // and then as many nodes as fit beside it.  Measured per frame: C3 41.5 ms with 9 nodes, 40.9 with 50 (eight workgroups either way,
+    // `k_trace_closest` 21.9 -> 21.4 ms), 41.3 with 57-73 (seven); C5 40.4 ms with 73 nodes, 38.6 with 9, 38.3 with 31.  RTX_DEBUG_LDS=1 prints the choice.
+    // (LDS is granted in 512-B granules, which the runtime's occupancy query does not count: 33 nodes on C5 "fit" seven workgroups by its answer and
+    // ran like six.  Hence the model below, with the query only as the upper bound the registers set.)
+    if (c->lds_nodes_opt < 0 && !s.nsmall && s.lds_nodes > 9u) {
+        auto fit = [&](uint32_t nodes) { DevScene t = s; t.lds_nodes = nodes; return (160u * 1024u) / (uint32_t)((trace_lds_bytes(t) + 64 + 511) & ~(size_t)511); };
+        DevScene t9 = s; t9.lds_nodes = 9;
+        const int by_regs = trace_workgroups_per_cu(t9);
+        const uint32_t target = std::min<uint32_t>(fit(9), by_regs > 0 ? (uint32_t)by_regs : 8u);
+        while (s.lds_nodes > 9u && fit(s.lds_nodes) < target) s.lds_nodes--;
+        if (getenv("RTX_DEBUG_LDS")) fprintf(stderr, "[rtx] stack_depth %u workgroups per CU %u, %u nodes staged, %zu B of LDS\n", s.stack_depth, target, s.lds_nodes, trace_lds_bytes(s));
+    }
     c->stats.bvh_refits = B.refit_count; c->stats.bvh_nodes = s.nnodes; c->stats.triangles = s.ntris; c->stats.lights = s.nlights; c->stats.materials = s.nmat;
     c->committed = true;
     return RTX_OK;

@@ -971,6 +971,13 @@ size_t trace_lds_bytes_queue(const DevScene& sc) {   // queue kernels with a pri
     return (size_t)sc.lds_nodes * 80 + (size_t)sc.lds_tris * 48 + small_planes_bytes(sc) + stack;
 }
 
+// workgroups of the two persistent traversal kernels (default instantiations) that fit on a CU with this scene's LDS layout; 0 = query failed
+int trace_workgroups_per_cu(const DevScene& sc) {
+    int a = 0, b = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_closest<0, false, 6>, (int)kBlock, trace_lds_bytes(sc)) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<0, false, 6>, (int)kBlock, trace_lds_bytes(sc)) != hipSuccess) return 0;
+    return a < b ? a : b;
+}
 void launch_raygen(hipStream_t st, const DevFrame& f, const DevPaths& p, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount, bool compact) {
     hipLaunchKernelGGL(k_raygen, dim3(f.nblocks), dim3(kBlock), 0, st, f, p, cam, queue, qcount, compact ? 1u : 0u);
 }

@@ -61,6 +61,7 @@ struct DevPaths {
 };
 
 size_t trace_lds_bytes(const DevScene& sc);
+int trace_workgroups_per_cu(const DevScene& sc);   // occupancy of the persistent traversal kernels for this LDS layout (hipOccupancyMaxActiveBlocksPerMultiprocessor)
 void launch_raygen(hipStream_t, const DevFrame&, const DevPaths&, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount, bool compact);
 void launch_trace_closest(hipStream_t, const DevFrame&, const DevScene&, const DevPaths&, uint32_t bounce, const uint32_t* queue, const uint32_t* qcount, uint32_t* heads);
 void launch_packet_masks(hipStream_t, const DevScene&, const DevFrame&, const CameraGPU* cam, unsigned long long* masks);   // one 64-bit record mask per 8x8 pixel block of the shard
