@@ -140,10 +140,13 @@ __global__ __launch_bounds__(kBlock) void k_raygen_trace_small(DevScene sc, cons
     if (threadIdx.x == 0) { qcount[blockIdx.x] = s_n[0]; gencount[blockIdx.x] = s_n[1]; }
 }
 
+#ifndef RTX_TRACE_WAVES
+#define RTX_TRACE_WAVES 1          // waves per SIMD the persistent traversal kernels are compiled for (1 = no register cap: ~70 VGPRs)
+#endif
 // closest hit for every path in this workgroup's sub-queue: reads ray_o/ray_d, writes hit
 template <int STK, bool STEAL, int SCHED>   // traversal stack: 0 = LDS column, 1 = private (scratch); STEAL: work stealing between sub-queues (refill_steal);
                                             // SCHED: the wave schedule as a compile-time constant (the default, 6), or -1 = the run-time parameter (experiment knobs)
-__global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin, uint32_t refill_min, uint32_t sched, uint32_t* heads) {
+__global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin, uint32_t refill_min, uint32_t sched, uint32_t* heads) {
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_head;
     const uint32_t n = qcount[blockIdx.x];
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene sc, const Sma
 // any-hit for NEE slot j: visible contributions are added to the path's radiance (a path appears at most once
 // per slot, so the read-modify-write needs no atomic and the order of additions per path is fixed)
 template <int STK, bool STEAL, int SCHED>
-__global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const F4* __restrict__ sh_o, const F4* __restrict__ sh_d,
+__global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_shadow(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const F4* __restrict__ sh_o, const F4* __restrict__ sh_d,
                                                          const F4* __restrict__ sh_c, const uint32_t* __restrict__ shcount, uint32_t qcap, uint32_t refill_min, uint32_t sched, uint32_t* heads) {
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_head;
