@@ -88,6 +88,9 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
        RTX_OPT_STACK_PRIVATE = 9,    /* tuning: traversal stack 0 = LDS column, 1 = private (scratch) memory, (2 is accepted and means 0) */
        RTX_OPT_TRACE_SCHED = 10,     /* tuning: wave schedule of the BVH traversal, 0 = while-while, 1-4 = voted node / triangle steps, 5-7 = voted + speculative (default 6) */
        RTX_OPT_GPU_REFIT = 11,       /* 1 (default): a transform-only rtx_commit_scene refits the resident BVH on the GPU; 0: host refit + upload */
+       RTX_OPT_OVERLAP_SHADOW = 18,  /* 1 (default): general scenes run the shadow-ray kernel of bounce b on a second (internal) stream beside the closest-hit kernel of
+                                        bounce b + 1; everything is joined into the context's stream before rtx_render returns.  Off while RTX_OPT_KERNEL_TIMING is on
+                                        (overlapping launches have no per-kernel time).  Results identical */
        RTX_OPT_COMPACT_STATE = 16,   /* 1 (default): the separate trace / shade kernels keep ray, throughput and hit records by QUEUE POSITION in two buffer sets (a bounce
                                         writes its survivors densely at their place in the next queue) instead of by path id in place.  Results identical */
        RTX_OPT_WORK_STEALING = 15,   /* 1: a wave of the general-scene trace kernels whose sub-queue is exhausted continues with other sub-queues (global chunk cursors + an

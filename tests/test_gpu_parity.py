@@ -858,6 +858,7 @@ def test_c4_sizes_4k_shards_and_stack_variants(rt, orc):
     for k, (stack, sched) in enumerate(((0, 6), (1, 6), (0, 0), (0, 2), (0, 5), (0, 7), (0, 3), (0, 6), (0, 6), (1, 2), (0, 6), (0, 6), (1, 2), (0, 6))):
         c = rt.Context(0); c.set_option(rt.OPT_STACK_PRIVATE, stack); c.set_option(rt.OPT_TRACE_SCHED, sched)
         c.set_option(rt.OPT_FUSED_BVH, 0 if k >= 8 else 1); c.set_option(rt.OPT_WORK_STEALING, 1 if k in (11, 12) else 0); c.set_option(rt.OPT_COMPACT_STATE, 0 if k >= 12 else 1)
+        c.set_option(rt.OPT_OVERLAP_SHADOW, 0 if k in (8, 13) else 1)        # (default 1: shadow rays of bounce b beside the closest-hit rays of bounce b + 1)
         c.set_option(rt.OPT_SORT_MATERIALS, 1 if k in (7, 10) else 0); c.upload(sc, W / H)
         c.clear(W, H); c.render(rt.Params(**base)); imgs.append(c.read_accum())
         if k == 0:
