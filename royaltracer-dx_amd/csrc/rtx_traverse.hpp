@@ -362,7 +362,10 @@ __device__ __forceinline__ void traverse_small(const DevScene& sc, const SmallRe
     // bits >= nrec: the padding record of an odd count (zero plane: "grazing", always forwarded) or, for NEE segments, the first hull face
     cand &= nrec >= 64u ? ~0ull : ((1ull << nrec) - 1ull);
     // (Testing only the triangle on the ray's side of a quad's diagonal would save one exact test per candidate; measured slower
-    // both ways: at 4 waves/SIMD the ~4 extra VGPRs spill (28.4-28.9 ms instead of 27.6), at 3 waves/SIMD without spills 31.3 ms.)
+    // both ways: at 4 waves/SIMD the ~4 extra VGPRs spill (28.4-28.9 ms instead of 27.6), at 3 waves/SIMD without spills 31.3 ms.
+    // Round 2, second attempt with the diagonal's line per record in LDS, the side decided per lane from the plane point with the
+    // pre-test's tolerance, one triangle per lane and round: 92 VGPRs, no spills, bit-identical, 17.75 vs 17.59 ms — recomputing the
+    // plane point and the bookkeeping cost what the shorter rounds save.)
     auto exact = [&](uint32_t k) -> bool {              // both triangles of record k; true = an any-hit ray is done
         RTX_PROF_COUNT(pf, pf_sec + 1);
 #pragma unroll
