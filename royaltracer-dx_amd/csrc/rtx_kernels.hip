@@ -272,6 +272,7 @@ __global__ __launch_bounds__(kBlock, RTX_SHADE_WAVES) void k_shade(DevScene sc, 
     const uint32_t* myq = queue + qb;
     uint32_t* mynext = next_queue + qb;
     const uint32_t chunk = SORT ? kSortChunk : n;
+    PF_BEGIN;                                               // (PROFILE build: sections 0 load, 1 surface, 2 emissive / setup, 3 NEE sample, 4 shadow push, 5 BSDF sample, 6 store)
     for (uint32_t cb = 0; cb < n; cb += chunk) {
         const uint32_t cn = (n - cb < chunk) ? n - cb : chunk;
         if (SORT) {
@@ -308,7 +309,9 @@ __global__ __launch_bounds__(kBlock, RTX_SHADE_WAVES) void k_shade(DevScene sc, 
                 const uint32_t prim = f2u(h.w);
                 if (prim != kMissPrim) {                                          // miss: Miss.hlsl:3-11 -> black, terminate
                     S = load_path(p, src); S.pid = pid;
+                    PF_MARK(0); PF_COUNT(1);
                     sf = surface(sc, S.o, S.d, h.x, h.y, h.z, prim);
+                    PF_MARK(1);
                     if (sf.mat < sc.nmat) {
                         const MatGPU& m = sc.mats[sf.mat];
                         if (m.Ke_len > 0.0f) add_emissive(sc, p, S, sf, m, bounce, nee);   // Hit.hlsl:126, Sampler_v6.hlsl:457
@@ -320,17 +323,25 @@ __global__ __launch_bounds__(kBlock, RTX_SHADE_WAVES) void k_shade(DevScene sc, 
             const MatGPU* mp = sc.mats + (shading ? sf.mat : 0u);
             f3 normal = sf.normal;
             const float eta_p = LAMBERT ? 0.0f : transmission_eta(*mp, f.flags, outgoing, normal);          // (extension) hits from behind a dielectric flip the shading normal
+            PF_MARK(2);
             for (uint32_t j = 0; j < nee; j++) {                                  // NEE: visibility deferred to k_trace_shadow
                 bool push = false;
                 F4 so = {0, 0, 0, 0}, sd = {0, 0, 0, 0}; f3 con = mk3(0, 0, 0);
+                if (shading) { PF_COUNT(3); }
                 if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con, sc.nsmall != 0u && sf.near_hull, eta_p);
+                PF_MARK(3);
+                if (push) { PF_COUNT(4); }
                 const size_t seg = (size_t)j * f.qcap * gridDim.x + qb;           // NEE slot j, this workgroup's sub-queue
                 const uint32_t slot = block_push(push, &s_cnt[1 + j]);
                 if (push) { p.sh_o[seg + slot] = so; p.sh_d[seg + slot] = sd; p.sh_c[seg + slot] = {con.x, con.y, con.z, u2f(S.pid)}; }
             }
+            PF_MARK(4);
             bool alive = false;
             f3 smp = mk3(0, 0, 1); float P = 0.0f;
+            if (shading && !last) { PF_COUNT(5); }
             if (shading && !last) alive = bsdf_continue(*mp, f, bounce, S, normal, outgoing, smp, P, eta_p);
+            PF_MARK(5);
+            if (alive) { PF_COUNT(6); }
             const uint32_t slot = block_push(alive, &s_cnt[0]);
             if (alive) {
                 if (p.out_o) store_path_at(p.out_o, p.out_d, p.out_thr, (uint32_t)qb + slot, S, pos, smp, P);     // densely, at its place in the next queue
@@ -340,6 +351,8 @@ __global__ __launch_bounds__(kBlock, RTX_SHADE_WAVES) void k_shade(DevScene sc, 
         }
         if (SORT) __syncthreads();                              // the next chunk overwrites the LDS buffers
     }
+    PF_MARK(6);
+    PF_FLUSH;
     __syncthreads();
     if (threadIdx.x == 0) next_count[blockIdx.x] = s_cnt[0];
     if (threadIdx.x >= 1 && threadIdx.x <= nee) shcounts[(size_t)(threadIdx.x - 1) * gridDim.x + blockIdx.x] = s_cnt[threadIdx.x];
