@@ -423,9 +423,10 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     // sub-queues per CU: shorter tails with more, but more per-workgroup overhead; the fused tiny-scene kernels (5 workgroups resident per
     // CU, longest-first dispatch, all bounces >= 1 in one launch) measured 18.39 / 18.15 / 18.13 / 18.30 / 18.36 ms at 24 / 32 / 40 / 48 / 64
     // (a 1/4 shard: 5.22 / 4.96 / 4.99 / 4.92 / 4.96 ms; 30 is an outlier, its sub-queues alias with the 8100 image regions); the
-    // general path measured best at 16 (49.3 / 42.2 ms vs 53.0 / 44.2 at 8)
+    // general path: 16 was best in round 1 (49.3 / 42.2 ms vs 53.0 / 44.2 at 8) with 4-6 workgroups resident per CU; with the 7-8 of the end of round 2
+    // (LDS trimmed) it is 32: C3 39.8 vs 40.7 ms, C5 37.8 vs 38.2 (48: 40.4 / 39.0)
     const bool fused_bvh = !c->dsc.nsmall && c->fused_bvh && c->trace_sched >= 5u;      // (the other wave schedules are experiment knobs of the separate kernels)
-    const uint32_t bpc = c->blocks_per_cu ? c->blocks_per_cu : (c->dsc.nsmall && c->fused ? 40u : fused_bvh ? 32u : 16u);
+    const uint32_t bpc = c->blocks_per_cu ? c->blocks_per_cu : (c->dsc.nsmall && c->fused ? 40u : 32u);
     const uint32_t max_blocks = (uint32_t)c->num_cus * bpc;
     const uint32_t nchunks = f.chunks_per_sample * bspp;
     const uint32_t G = std::max<uint32_t>(1, std::min<uint32_t>(nchunks, max_blocks));
