@@ -103,7 +103,7 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
                                         finished its phase keeps its SIMD slot while it waits for the slowest wave of its workgroup, and the kernel needs 86 VGPRs where the
                                         traversal kernels need 75), so the default is 0.  Needs RTX_OPT_TRACE_SCHED 5-7 */
        RTX_OPT_LPT_ORDER = 13,       /* tuning: 1 (default) = the fused tiny-scene kernels take their sub-queues longest first (shorter launch tails), 0 = in index order */
-       RTX_OPT_BLOCKS_PER_CU = 12    /* tuning: workgroups (= private sub-queues) per compute unit; default 0 = auto (40 tiny scenes, 16 otherwise; 8 measured 4-7 % slower: tail imbalance) */ };
+       RTX_OPT_BLOCKS_PER_CU = 12    /* tuning: workgroups (= private sub-queues) per compute unit; default 0 = auto (40 tiny scenes, 32 otherwise; 8 measured 4-7 % slower: tail imbalance) */ };
 
 /* lifetime: replaces LoadPipeline/device creation (Renderer.cpp:106-254) and OnDestroy (:546-552) */
 int  rtx_create(int device_ordinal, rtx_ctx** out);
