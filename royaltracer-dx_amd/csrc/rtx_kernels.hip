@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen_trace_small(DevScene sc, cons
 }
 
 #ifndef RTX_TRACE_WAVES
-#define RTX_TRACE_WAVES 1          // waves per SIMD the persistent traversal kernels are compiled for (1 = no register cap: ~70 VGPRs)
+#define RTX_TRACE_WAVES 1          // waves per SIMD the persistent traversal kernels are compiled for (1 = no cap: the default-schedule instantiations take 64 / 63 VGPRs, 8 waves per SIMD)
 #endif
 // closest hit for every path in this workgroup's sub-queue: reads ray_o/ray_d, writes hit
 template <int STK, bool STEAL, int SCHED>   // traversal stack: 0 = LDS column, 1 = private (scratch); STEAL: work stealing between sub-queues (refill_steal);
