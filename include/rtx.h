@@ -108,7 +108,7 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
 /* lifetime: replaces LoadPipeline/device creation (Renderer.cpp:106-254) and OnDestroy (:546-552) */
 int  rtx_create(int device_ordinal, rtx_ctx** out);
 void rtx_destroy(rtx_ctx*);
-const char* rtx_last_error(rtx_ctx*);          /* ctx may be NULL: last create error */
+const char* rtx_last_error(rtx_ctx*);          /* ctx may be NULL: the CALLING THREAD's last error of a context-free call (rtx_create, rtx_shard_slab_bytes, rtx_restir_state_slab_bytes) */
 int  rtx_set_option(rtx_ctx*, int option, int64_t value);
 /* run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream.
    replaces the single m_commandQueue (Renderer.cpp:192-199) */

@@ -12,7 +12,9 @@
 
 using namespace rtx;
 
-static std::string g_create_err;
+// message of the calls that have no context to hold one (rtx_create failing, rtx_shard_slab_bytes, rtx_restir_state_slab_bytes): PER THREAD, so the N threads of
+// the native multi-GPU frame (host/MultiGpu.cpp) that ask for their slab sizes at once never write the same string; rtx_last_error(NULL) reads the caller's own
+static thread_local std::string g_create_err;
 
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
@@ -477,6 +479,9 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     auto Q = [&](uint32_t b) { return cnt + (size_t)b * G; };
     auto S = [&](uint32_t b, uint32_t j) { return cnt + ((size_t)(mb + 1) + (size_t)b * nee1 + j) * G; };
 
+    // every early return below (HIPCHK) must not leave shadow-ray launches of the internal `aux` stream running behind the caller's back: they read the
+    // shadow entries and update `rad`, which the next call re-uses
+    struct AuxJoin { rtx_ctx* c; bool armed = true; ~AuxJoin() { if (armed && c->aux) (void)hipStreamSynchronize(c->aux); } } aux_join{c};
     HIPCHK(c, hipEventRecord(c->ev_begin, st));
     HIPCHK(c, hipMemsetAsync(cnt, 0, ncnt * 4, st));
     if (c->dsc.nsmall && c->fused) launch_packet_masks(st, c->dsc, f, cam, (unsigned long long*)c->d_pmask.p);   // per 8x8 block, shared by all samples
@@ -539,6 +544,7 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     HIPCHK(c, hipEventRecord(c->ev_end, st));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));
+    aux_join.armed = false;                    // the main stream waited for the last shadow launch (ev_shadow_done) before the accumulation
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) c->stats.render_ms = ms;
     for (const TimedLaunch& t : c->timed) { float m = 0.0f; if (hipEventElapsedTime(&m, t.a, t.b) == hipSuccess) c->stats.kernel_ms[t.cls] += m; }

@@ -406,15 +406,21 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
     constexpr uint32_t kRing = 512u;                       // < 256 waiting + <= 256 pushed by one trace pass
     __shared__ uint32_t s_rpid[(HAVE_HIT || !RING) ? 1 : kRing];
     __shared__ F4 s_rhit[(HAVE_HIT || !RING) ? 1 : kRing];
-    __shared__ uint32_t s_ring[2];                         // consumed, produced (monotonic; index = count & (kRing - 1))
+    // Ring counters.  s_ring[0] = entries consumed (written by thread 0 between two barriers).  Entries PRODUCED are counted per trace pass in one of three
+    // rotating LDS words (pass k pushes into s_rc[k % 3]) and summed in a register (`prod`) after the barrier that ends the pass: the loop condition below then
+    // depends on registers and on s_ring[0] only, never on a word another wave may be pushing into.  (With ONE produced-counter read in the condition, a wave
+    // that evaluated it late could see a push of the current pass, leave the loop and strand the others at the barrier — a formal race)  A word is
+    // cleared by thread 0 after the barrier of pass k + 1 and next pushed into in pass k + 3; it was last read before that barrier.
+    __shared__ uint32_t s_ring[1], s_rc[3];
     PF_BEGIN;
     for (uint32_t bounce = bounce_first; bounce < bounce_end; bounce++) {
     const bool last = (bounce + 1u == f.max_bounces);
     const float tmin = bounce_tmin(bounce);
     const uint32_t* myq = ((bounce & 1u) ? queue_b : queue_a) + qb;
     uint32_t* mynext = ((bounce & 1u) ? queue_a : queue_b) + qb;
-    if (!HAVE_HIT && RING) { if (threadIdx.x < 2) s_ring[threadIdx.x] = 0; __syncthreads(); }
+    if (!HAVE_HIT && RING) { if (threadIdx.x < 3) s_rc[threadIdx.x] = 0; if (threadIdx.x == 3) s_ring[0] = 0; __syncthreads(); }
     uint32_t next_in = 0;                                   // trace phase: next input entry (uniform)
+    uint32_t prod = 0, rk = 0;                              // hits pushed by the completed trace passes of this bounce; pass number mod 3 (both uniform)
     for (uint32_t base = 0; (HAVE_HIT || !RING) ? base < n : true; base += kBlock) {     // one trip per 256 queue entries; with the ring: until input and ring are empty
         PathState S; S.pid = 0; S.o = mk3(0, 0, 0); S.d = mk3(0, 0, 1); S.thr = mk3(0, 0, 0); S.prev_pdf = 1.0f; S.s0 = S.s1 = 0;
         float t = 0.0f, u = 0.0f, v = 0.0f; uint32_t prim = kMissPrim;
@@ -431,7 +437,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
             traverse_small<false>(sc, small, L, S.o, S.d, tmin, active ? kTMax : 0.0f, t, u, v, prim, sc.nsmall, ~0ull, pf, 1);   // inactive lanes: empty interval
         } else {
             // ---- trace phase: fill the ring until it holds a full workgroup of hits (or the input runs out) ----
-            while (next_in < n && s_ring[1] - s_ring[0] < kBlock) {           // uniform: both counters were published before the last barrier
+            while (next_in < n && prod - s_ring[0] < kBlock) {                // uniform: `prod` is a register, s_ring[0] was written before the last barrier
                 const uint32_t i = next_in + threadIdx.x;
                 const bool act = i < n;
                 uint32_t pid = 0; f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
@@ -439,12 +445,15 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
                 float ht, hu, hv; uint32_t hp;
                 traverse_small<false>(sc, small, L, ro, rd, tmin, act ? kTMax : 0.0f, ht, hu, hv, hp, sc.nsmall, ~0ull, pf, 1);   // inactive lanes: empty interval
                 const bool hit = act && hp != kMissPrim;
-                const uint32_t slot = block_push(hit, &s_ring[1]);
+                const uint32_t slot = prod + block_push(hit, &s_rc[rk]);
                 if (hit) { s_rpid[slot & (kRing - 1u)] = pid; s_rhit[slot & (kRing - 1u)] = {ht, hu, hv, u2f(hp)}; }
                 next_in += kBlock;
                 __syncthreads();
+                prod += s_rc[rk];                                               // this pass's pushes are complete; the word stays untouched for two more passes
+                if (threadIdx.x == 0) s_rc[rk == 0u ? 2u : rk - 1u] = 0;        // the word of the PREVIOUS pass: every wave read it before the barrier above; next used two passes from now
+                rk = rk == 2u ? 0u : rk + 1u;
             }
-            const uint32_t head = s_ring[0], avail = s_ring[1] - head;
+            const uint32_t head = s_ring[0], avail = prod - head;
             if (avail == 0u) break;                                             // input exhausted and ring drained: this bounce is done (uniform)
             const uint32_t take = avail < (uint32_t)kBlock ? avail : (uint32_t)kBlock;
             active = threadIdx.x < take;

@@ -19,6 +19,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <thread>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -30,7 +32,7 @@ namespace rtx {
 namespace {
 
 constexpr char kMagic[8] = {'R', 'T', 'X', 'S', 'C', 'N', '0', '1'};
-constexpr uint32_t kVersion = 1;
+constexpr uint32_t kVersion = 2;              // 2: + the host layer's MaterialExt records and texture names (two sections at the end)
 struct Header { char magic[8]; uint32_t version, endian; uint32_t layout[8]; uint64_t payload, checksum, nsections; };
 struct SecHead { uint32_t tag, elem; uint64_t count; };
 static_assert(sizeof(Header) == 72 && sizeof(SecHead) == 16, "cache header layout");
@@ -116,11 +118,11 @@ struct Reader {
 };
 
 enum : uint32_t { T_SCAL = 1, T_MATS128, T_MATIDS, T_INSTH, T_MESHV, T_MESHI, T_MESHB, T_BMATS, T_NODES8, T_SLOTS8, T_TRIS8, T_LEVELS, T_SMALLR, T_SMALLT, T_SMALLP,
-                T_SHADE, T_BINST, T_LIGHTS, T_LIGHTS80 };
+                T_SHADE, T_BINST, T_LIGHTS, T_LIGHTS80, T_AUXREC, T_AUXTXT };
 
 }  // namespace
 
-bool save_scene_cache(const SceneHost& H, const BuiltScene& B, const char* path, std::string& err, const float* cam12) {
+bool save_scene_cache(const SceneHost& H, const BuiltScene& B, const char* path, std::string& err, const float* cam12, const CacheAux* aux) {
     if (!path || !*path) { err = "scene cache: empty path"; return false; }
     if (H.topo_dirty || H.mats_dirty || B.shade.size() != B.tris8.size() || (!B.tris8.empty() && B.nodes8.empty())) { err = "scene cache: scene not built"; return false; }
     Writer w;
@@ -133,6 +135,9 @@ bool save_scene_cache(const SceneHost& H, const BuiltScene& B, const char* path,
     w.vec(T_BMATS, B.mats); w.vec(T_NODES8, B.nodes8); w.vec(T_SLOTS8, B.tri_slots8); w.vec(T_TRIS8, B.tris8); w.vec(T_LEVELS, B.level_start8);
     w.vec(T_SMALLR, B.small_recs); w.vec(T_SMALLT, B.small_tris); w.vec(T_SMALLP, B.small_poly);
     w.vec(T_SHADE, B.shade); w.vec(T_BINST, B.insts); w.vec(T_LIGHTS, B.lights); w.vec(T_LIGHTS80, B.lights80);
+    const CacheAux none;                                                       // what rides beside the material table in the host layer (MaterialExt, texture names); empty for a context-level save
+    const CacheAux& ax = aux ? *aux : none;
+    w.raw(T_AUXREC, ax.rec_bytes ? ax.rec_bytes : 1u, ax.rec_bytes ? ax.records.size() / ax.rec_bytes : 0u, ax.records.data()); w.vec(T_AUXTXT, ax.text);
     Header h{}; memcpy(h.magic, kMagic, 8); h.version = kVersion; h.endian = 0x01020304u; fill_layout(h.layout);
     h.payload = w.buf.size(); h.checksum = hash_payload(w.buf.data(), w.buf.size()); h.nsections = w.nsec;
     uint8_t hb[kHeaderBytes] = {0}; memcpy(hb, &h, sizeof(h));
@@ -145,7 +150,7 @@ bool save_scene_cache(const SceneHost& H, const BuiltScene& B, const char* path,
     return true;
 }
 
-bool load_scene_cache(const char* path, SceneHost& H, BuiltScene& B, std::string& err, float* cam12) {
+static bool load_scene_cache_impl(const char* path, SceneHost& H, BuiltScene& B, std::string& err, float* cam12, CacheAux* aux) {
     const int fd = path ? open(path, O_RDONLY) : -1;
     if (fd < 0) { err = std::string("scene cache: cannot open ") + (path ? path : "(null)"); return false; }
     struct stat st;
@@ -162,6 +167,7 @@ bool load_scene_cache(const char* path, SceneHost& H, BuiltScene& B, std::string
     if (h.version != kVersion) { err = "scene cache: version " + std::to_string(h.version) + ", this library reads version " + std::to_string(kVersion); return false; }
     if (h.endian != 0x01020304u || memcmp(h.layout, lay, sizeof(lay)) != 0) { err = "scene cache: written with another record layout"; return false; }
     if (h.payload != total - kHeaderBytes) { err = "scene cache: length does not match the header"; return false; }
+    // (the checksum is a word hash: it catches accidental damage, not a crafted file — hence every index below is checked against its array)
     if (hash_payload(base + kHeaderBytes, h.payload) != h.checksum) { err = "scene cache: checksum mismatch (corrupt file)"; return false; }
     // everything is read into temporaries first: a malformed section table must not leave a half-loaded scene behind
     SceneHost Hn; BuiltScene Bn;
@@ -170,6 +176,8 @@ bool load_scene_cache(const char* path, SceneHost& H, BuiltScene& B, std::string
     if (!r.head(T_SCAL, sizeof(Scalars), s) || s.count != 1) { if (err.empty()) err = "scene cache: bad scalar block"; return false; }
     memcpy(&sc, r.p + r.at, sizeof(sc)); r.at += sizeof(sc);
     if (!r.vec(T_MATS128, Hn.mats128) || !r.vec(T_MATIDS, Hn.matids) || !r.vec(T_INSTH, Hn.insts)) return false;
+    // a mesh is three sections (vertices, indices, material-id base): at least 3 section heads + 16 bytes of what is left, and never more than the header's count
+    if ((uint64_t)sc.nmesh * (3 * sizeof(SecHead) + 16) > h.payload - r.at || (uint64_t)sc.nmesh * 3 > h.nsections) { err = "scene cache: mesh count does not fit the file"; return false; }
     Hn.meshes.resize(sc.nmesh);
     for (MeshHost& m : Hn.meshes) {
         if (!r.vec(T_MESHV, m.verts) || !r.vec(T_MESHI, m.idx)) return false;
@@ -179,14 +187,38 @@ bool load_scene_cache(const char* path, SceneHost& H, BuiltScene& B, std::string
     if (!r.vec(T_BMATS, Bn.mats) || !r.vec(T_NODES8, Bn.nodes8) || !r.vec(T_SLOTS8, Bn.tri_slots8) || !r.vec(T_TRIS8, Bn.tris8) || !r.vec(T_LEVELS, Bn.level_start8) ||
         !r.vec(T_SMALLR, Bn.small_recs) || !r.vec(T_SMALLT, Bn.small_tris) || !r.vec(T_SMALLP, Bn.small_poly) || !r.vec(T_SHADE, Bn.shade) || !r.vec(T_BINST, Bn.insts) ||
         !r.vec(T_LIGHTS, Bn.lights) || !r.vec(T_LIGHTS80, Bn.lights80)) return false;
+    CacheAux ax;
+    {   // opaque to this layer: fixed-size records + a text blob (the host layer checks their shape against its own structs)
+        if (r.at + sizeof(SecHead) > r.n) { err = "scene cache: truncated section table"; return false; }
+        SecHead a; memcpy(&a, r.p + r.at, sizeof(a));
+        if (a.tag != T_AUXREC || !a.elem || a.elem > 4096u || !r.head(T_AUXREC, a.elem, a)) { if (err.empty()) err = "scene cache: bad auxiliary section"; return false; }
+        ax.rec_bytes = a.elem; ax.records.assign(r.p + r.at, r.p + r.at + (size_t)a.elem * a.count);
+        r.at += ((size_t)a.elem * a.count + 15) & ~(size_t)15;
+        if (!r.vec(T_AUXTXT, ax.text)) return false;
+    }
     if (r.at != h.payload) { err = "scene cache: trailing bytes"; return false; }
-    // consistency of what was read (indices stay inside their arrays: the kernels trust these)
+    // consistency of what was read (indices stay inside their arrays: the kernels and the refit trust these)
     const size_t nt = Bn.shade.size(), nmat = Hn.mats128.size() / 32;
+    const size_t nrec_pad = ((size_t)sc.small_nrec + 1) & ~(size_t)1;      // records are stored in pairs (rtx_scene_host.cpp)
     bool ok = Bn.tris8.size() == nt && Bn.tri_slots8.size() == nt && Bn.mats.size() == nmat && Bn.insts.size() == Hn.insts.size() && Bn.lights80.size() == Bn.lights.size() * 20 &&
-              Hn.mats128.size() % 32 == 0 && (Bn.nodes8.empty() || Bn.level_start8.size() >= 2) && Bn.small_recs.size() * 2 >= sc.small_nrec && sc.small_nocc <= sc.small_nrec;
-    for (const MeshHost& m : Hn.meshes) ok = ok && m.verts.size() % 7 == 0 && m.idx.size() % 3 == 0 && (size_t)m.matid_base + m.idx.size() <= Hn.matids.size();
-    for (const InstHost& in : Hn.insts) ok = ok && in.mesh < Hn.meshes.size();
-    for (size_t i = 0; ok && i < nt; i++) ok = Bn.shade[i].inst < Bn.insts.size() && f2u(Bn.tris8[i].v0.w) < nt;
+              Hn.mats128.size() % 32 == 0 && (Bn.nodes8.empty() || Bn.level_start8.size() >= 2) && sc.small_nocc <= sc.small_nrec && sc.small_nrec <= kSmallSceneMaxTris &&
+              Bn.small_recs.size() * 2 >= nrec_pad && (sc.small_nrec == 0 || (Bn.small_tris.size() >= nrec_pad * 2 && Bn.small_poly.size() >= nrec_pad * 4)) &&
+              nt < (1u << 31);
+    for (uint32_t id : Hn.matids) ok = ok && id < nmat;                       // (what rtx_commit_scene checks before a build)
+    for (const MeshHost& m : Hn.meshes) {
+        ok = ok && m.verts.size() % 7 == 0 && m.idx.size() % 3 == 0 && (size_t)m.matid_base + m.idx.size() <= Hn.matids.size();
+        const size_t nv = m.verts.size() / 7;
+        for (size_t i = 0; ok && i < m.idx.size(); i++) ok = m.idx[i] < nv;   // fill_objtris / a later host build gather vertices through these
+    }
+    size_t tri_at = 0;                                                        // instances own consecutive global triangle ranges (SceneHost::build)
+    for (const InstHost& in : Hn.insts) {
+        ok = ok && in.mesh < Hn.meshes.size() && in.tri_base == tri_at;
+        if (ok) tri_at += Hn.meshes[in.mesh].idx.size() / 3;
+    }
+    ok = ok && tri_at == nt;
+    for (size_t i = 0; ok && i < nt; i++) ok = Bn.shade[i].inst < Bn.insts.size() && f2u(Bn.tris8[i].v0.w) < nt && Bn.tri_slots8[i] < nt;
+    for (size_t i = 0; ok && i < Bn.small_tris.size(); i++) { const uint32_t g = f2u(Bn.small_tris[i].v0.w); ok = g < nt || g == kMissPrim; }
+    for (size_t i = 0; ok && i < Bn.lights.size(); i++) ok = f2u(Bn.lights80[i * 20 + 7]) < Bn.insts.size();     // LightTriangle::instanceID (Renderer.h:113-124)
     for (size_t i = 0; ok && i < Bn.nodes8.size(); i++) {
         const Node8GPU& N = Bn.nodes8[i];
         const uint32_t ninternal = (uint32_t)__builtin_popcount(N.e_imask >> 24);
@@ -194,12 +226,46 @@ bool load_scene_cache(const char* path, SceneHost& H, BuiltScene& B, std::string
         ok = (ninternal == 0 || ((size_t)N.child_base + ninternal <= Bn.nodes8.size() && N.child_base > i)) && (size_t)N.tri_base + ntri <= nt;
     }
     if (!ok) { err = "scene cache: inconsistent contents"; return false; }
+    // The traversal stack depth and the breadth-first levels are RE-DERIVED from the nodes (collapse_bvh8's two sweeps; children have larger indices, checked
+    // above), never taken from the file: the per-lane LDS stack column has exactly stack8 entries, and the GPU refit sweeps the levels bottom-up.
+    {
+        const size_t nn = Bn.nodes8.size();
+        std::vector<uint32_t> need(nn, 0), level(nn, 0);
+        for (size_t i = nn; i-- > 0;) {
+            const uint32_t nint = (uint32_t)__builtin_popcount(Bn.nodes8[i].e_imask >> 24);
+            uint32_t deep = 0;
+            for (uint32_t k = 0; k < nint; k++) deep = std::max(deep, need[(size_t)Bn.nodes8[i].child_base + k]);
+            need[i] = (nint > 1 ? 1u : 0u) + deep;
+        }
+        const uint32_t stack8 = nn ? need[0] : 0u;
+        std::vector<uint32_t> levels;
+        for (size_t i = 0; i < nn; i++) {
+            const uint32_t nint = (uint32_t)__builtin_popcount(Bn.nodes8[i].e_imask >> 24);
+            for (uint32_t k = 0; k < nint; k++) level[(size_t)Bn.nodes8[i].child_base + k] = level[i] + 1;
+        }
+        for (size_t i = 0; i < nn; i++) {
+            if (i && level[i] < level[i - 1]) { err = "scene cache: nodes are not in breadth-first order"; return false; }
+            if (i == 0 || level[i] != level[i - 1]) levels.push_back((uint32_t)i);
+        }
+        if (nn) levels.push_back((uint32_t)nn);
+        if (stack8 != sc.stack8 || (nn && levels != Bn.level_start8)) { err = "scene cache: stack depth / level table do not match the nodes"; return false; }
+    }
     Bn.stack8 = sc.stack8; Bn.small_nrec = sc.small_nrec; Bn.small_nocc = sc.small_nocc; Bn.max_depth = sc.max_depth; Bn.bvh_pad = sc.bvh_pad;
     Bn.small_cm = sc.small_cm; Bn.small_delta = sc.small_delta; Bn.small_hull_margin = sc.small_hull_margin; Bn.total_weight = sc.total_weight; Bn.refit_count = 0;
     Hn.topo_dirty = false; Hn.mats_dirty = false;
     if (cam12) { if (!sc.has_cam) { err = "scene cache: the file holds no camera (written by rtx_save_scene_cache, not rtxh_scene_save)"; return false; } memcpy(cam12, sc.cam, sizeof(sc.cam)); }
     H = std::move(Hn); B = std::move(Bn);
+    if (aux) *aux = std::move(ax);
     return true;
+}
+
+// nothing may throw across the extern "C" entry points that call this (rtx_load_scene_cache, rtxh_scene_load): a section count that passes the bounds but
+// exhausts memory ends as an error string, not as std::terminate
+bool load_scene_cache(const char* path, SceneHost& H, BuiltScene& B, std::string& err, float* cam12, CacheAux* aux) {
+    try { return load_scene_cache_impl(path, H, B, err, cam12, aux); }
+    catch (const std::bad_alloc&) { err = "scene cache: out of memory while reading"; }
+    catch (const std::exception& e) { err = std::string("scene cache: ") + e.what(); }
+    return false;
 }
 
 // object-space triangles of the GPU refit, re-derived from the meshes (what build() fills; a loaded cache does not carry them)

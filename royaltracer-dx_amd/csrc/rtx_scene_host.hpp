@@ -66,8 +66,11 @@ struct SceneHost {
 
 // binary scene cache (rtx_scene_cache.cpp): the host scene + everything build() derived that the device needs; versioned, checksummed
 // cam12 (optional): eye, center, up, fovY degrees, znear, zfar of the host layer's scene (rtxh_scene_save / rtxh_scene_load)
-bool save_scene_cache(const SceneHost& H, const BuiltScene& B, const char* path, std::string& err, const float* cam12 = nullptr);
-bool load_scene_cache(const char* path, SceneHost& H, BuiltScene& B, std::string& err, float* cam12 = nullptr);
+// aux (optional): data the host layer keeps beside the scene and this layer only carries — fixed-size records (MaterialExt, index-aligned with the material
+// table) and a text blob (the texture file names, each NUL-terminated); both empty for a context-level save
+struct CacheAux { uint32_t rec_bytes = 0; std::vector<uint8_t> records; std::vector<char> text; };
+bool save_scene_cache(const SceneHost& H, const BuiltScene& B, const char* path, std::string& err, const float* cam12 = nullptr, const CacheAux* aux = nullptr);
+bool load_scene_cache(const char* path, SceneHost& H, BuiltScene& B, std::string& err, float* cam12 = nullptr, CacheAux* aux = nullptr);
 
 // binned-SAH BVH2 over world-space triangles (9 floats each); fills nodes (breadth-first, children boxes in
 // parent) and the leaf-ordered triangle permutation.

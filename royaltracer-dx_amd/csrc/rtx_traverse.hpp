@@ -29,7 +29,7 @@ struct Prof {};
 // ---------------------------------------------------------------------------------------------
 // LDS pointers carry their address space in the type: through a generic pointer hipcc emits flat_load /
 // flat_store for the staged nodes and the traversal stack instead of ds_read_b128 / ds_write_b32 (found with
-// SQ_INSTS_LDS vs SQ_INSTS_VMEM_RD in profiles/r01_pmc_v2.md).
+// SQ_INSTS_LDS vs SQ_INSTS_VMEM_RD in a round-1 counter run).
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4f lds_v4f;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -473,7 +473,7 @@ __device__ __forceinline__ unsigned long long packet_keep_mask(const DevScene& s
 // ---------------------------------------------------------------------------------------------
 // Persistent-wave BVH traversal with dynamic ray fetch (general scenes).  Lane utilisation of the plain
 // one-ray-per-lane loop on a 262 k-triangle scene was 8/64 (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU,
-// profiles/r01_pmc_sponza.md): traversal lengths have a heavy tail and internal / leaf phases diverge.  Here a
+// round-1 counters, see profiles/r01_pmc_bvh.md): traversal lengths have a heavy tail and internal / leaf phases diverge.  Here a
 // wave keeps its lanes busy: finished lanes are re-filled from the workgroup's sub-queue with a wave ballot +
 // mbcnt prefix sum and ONE LDS atomic per refill, and every outer iteration runs "all lanes walk internal nodes
 // until each holds a leaf (or is done)" followed by "all lanes with a leaf test its triangles" (while-while).

@@ -15,37 +15,76 @@ struct MultiGpuFrame::Impl {
     std::vector<rtx_ctx*> ctx;
     std::vector<hipStream_t> stream;
     std::vector<void*> slab, gathered;          // per rank: its own slab, the slabs of all ranks
+    std::vector<void*> state_slab, state_gathered;      // ReSTIR frames: the history records (u3 / u5 / u7) of the rank's own tiles, 140 B per pixel
     std::vector<ncclComm_t> comm;
-    size_t slab_bytes = 0;
+    size_t slab_bytes = 0, state_bytes = 0;
 };
 
 MultiGpuFrame::MultiGpuFrame(const std::vector<int>& devices, Gather g) : m(new Impl), m_devices(devices), m_stats(devices.size()), m_gather(g) {
-    if (devices.empty()) throw std::runtime_error("MultiGpuFrame: no devices");
-    const int n = (int)devices.size();
-    m->ctx.assign(n, nullptr); m->stream.assign(n, nullptr); m->slab.assign(n, nullptr); m->gathered.assign(n, nullptr);
-    for (int r = 0; r < n; r++) {
-        if (rtx_create(devices[r], &m->ctx[r]) != RTX_OK) throw std::runtime_error(std::string("rtx_create: ") + rtx_last_error(nullptr));
-        hipck(hipSetDevice(devices[r]), "hipSetDevice");
-        hipck(hipStreamCreateWithFlags(&m->stream[r], hipStreamNonBlocking), "hipStreamCreate");
-        if (rtx_set_stream(m->ctx[r], m->stream[r]) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));   // pack -> gather -> unpack run stream-ordered
-    }
-    if (g == Gather::RCCL && n > 1) {
-        m->comm.assign(n, nullptr);
-        ncclck(ncclCommInitAll(m->comm.data(), n, devices.data()), "ncclCommInitAll");      // single process, one communicator per device
-    }
+    // a constructor that throws runs no destructor: whatever was created before the failure (contexts, streams, communicators, Impl itself) is torn down here
+    try {
+        if (devices.empty()) throw std::runtime_error("MultiGpuFrame: no devices");
+        const int n = (int)devices.size();
+        m->ctx.assign(n, nullptr); m->stream.assign(n, nullptr); m->slab.assign(n, nullptr); m->gathered.assign(n, nullptr);
+        m->state_slab.assign(n, nullptr); m->state_gathered.assign(n, nullptr);
+        for (int r = 0; r < n; r++) {
+            if (rtx_create(devices[r], &m->ctx[r]) != RTX_OK) throw std::runtime_error(std::string("rtx_create: ") + rtx_last_error(nullptr));
+            hipck(hipSetDevice(devices[r]), "hipSetDevice");
+            hipck(hipStreamCreateWithFlags(&m->stream[r], hipStreamNonBlocking), "hipStreamCreate");
+            if (rtx_set_stream(m->ctx[r], m->stream[r]) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));   // pack -> gather -> unpack run stream-ordered
+        }
+        if (g == Gather::RCCL && n > 1) {
+            m->comm.assign(n, nullptr);
+            ncclck(ncclCommInitAll(m->comm.data(), n, devices.data()), "ncclCommInitAll");      // single process, one communicator per device
+        }
+    } catch (...) { Teardown(); throw; }
 }
 
-MultiGpuFrame::~MultiGpuFrame() {
+void MultiGpuFrame::Teardown() {
+    if (!m) return;
     for (size_t r = 0; r < m->ctx.size(); r++) {
         (void)hipSetDevice(m_devices[r]);
         if (m->stream[r]) (void)hipStreamSynchronize(m->stream[r]);
         if (r < m->comm.size() && m->comm[r]) (void)ncclCommDestroy(m->comm[r]);
         if (m->ctx[r]) rtx_destroy(m->ctx[r]);
-        if (m->slab[r]) (void)hipFree(m->slab[r]);
-        if (m->gathered[r]) (void)hipFree(m->gathered[r]);
+        for (std::vector<void*>* v : {&m->slab, &m->gathered, &m->state_slab, &m->state_gathered}) if (r < v->size() && (*v)[r]) (void)hipFree((*v)[r]);
         if (m->stream[r]) (void)hipStreamDestroy(m->stream[r]);
     }
-    delete m;
+    delete m; m = nullptr;
+}
+MultiGpuFrame::~MultiGpuFrame() { Teardown(); }
+
+// (re)allocate one slab + one gathered buffer per rank; on a failure part-way the sizes read 0 and every pointer is either valid or null
+void MultiGpuFrame::EnsureSlabs(std::vector<void*>& slab, std::vector<void*>& gathered, size_t& have, size_t bytes) {
+    if (bytes == have) return;
+    const int n = (int)m->ctx.size();
+    have = 0;
+    for (int r = 0; r < n; r++) {
+        hipck(hipSetDevice(m_devices[r]), "hipSetDevice");
+        if (slab[r]) { (void)hipFree(slab[r]); slab[r] = nullptr; }
+        if (gathered[r]) { (void)hipFree(gathered[r]); gathered[r] = nullptr; }
+        hipck(hipMalloc(&slab[r], bytes), "hipMalloc slab");
+        hipck(hipMalloc(&gathered[r], bytes * (size_t)n), "hipMalloc gathered");
+    }
+    have = bytes;
+}
+
+// ONE collective per call for all ranks of this process, each on its rank's stream (behind whatever that rank enqueued before: its pack kernel)
+void MultiGpuFrame::AllGather(std::vector<void*>& slab, std::vector<void*>& gathered, size_t bytes) {
+    const int n = (int)m->ctx.size();
+    if (m_gather == Gather::RCCL) {
+        ncclck(ncclGroupStart(), "ncclGroupStart");
+        for (int r = 0; r < n; r++)
+            ncclck(ncclAllGather(slab[r], gathered[r], bytes / sizeof(float), ncclFloat, m->comm[r], m->stream[r]), "ncclAllGather");
+        ncclck(ncclGroupEnd(), "ncclGroupEnd");
+    } else {                                                                        // testing stand-in (one GPU, several ranks): plain device copies
+        for (int r = 0; r < n; r++) { hipck(hipSetDevice(m_devices[r]), "hipSetDevice"); hipck(hipStreamSynchronize(m->stream[r]), "sync pack"); }
+        for (int r = 0; r < n; r++) {
+            hipck(hipSetDevice(m_devices[r]), "hipSetDevice");
+            for (int q = 0; q < n; q++)
+                hipck(hipMemcpyAsync((char*)gathered[r] + (size_t)q * bytes, slab[q], bytes, hipMemcpyDeviceToDevice, m->stream[r]), "copy slab");
+        }
+    }
 }
 
 void MultiGpuFrame::SetScene(const Scene& s, float aspect) {
@@ -61,16 +100,7 @@ void MultiGpuFrame::Render(const rtx_params& p0) {
     rtx_params probe = p0; probe.shard_rank = 0; probe.shard_count = (uint32_t)n;
     size_t bytes = 0;
     if (rtx_shard_slab_bytes(&probe, &bytes) != RTX_OK) throw std::runtime_error(std::string("rtx_shard_slab_bytes: ") + rtx_last_error(nullptr));
-    if (bytes != m->slab_bytes) {
-        for (int r = 0; r < n; r++) {
-            hipck(hipSetDevice(m_devices[r]), "hipSetDevice");
-            if (m->slab[r]) (void)hipFree(m->slab[r]);
-            if (m->gathered[r]) (void)hipFree(m->gathered[r]);
-            hipck(hipMalloc(&m->slab[r], bytes), "hipMalloc slab");
-            hipck(hipMalloc(&m->gathered[r], bytes * (size_t)n), "hipMalloc gathered");
-        }
-        m->slab_bytes = bytes;
-    }
+    EnsureSlabs(m->slab, m->gathered, m->slab_bytes, bytes);
     m_w = p0.width; m_h = p0.height;
     std::vector<std::string> err(n);
     const auto t0 = std::chrono::steady_clock::now();
@@ -88,20 +118,7 @@ void MultiGpuFrame::Render(const rtx_params& p0) {
     for (auto& t : th) t.join();
     for (auto& e : err) if (!e.empty()) throw std::runtime_error("MultiGpuFrame::Render: " + e);
     if (n > 1) {
-        // phase 2: ONE collective per frame, issued for all ranks of this process in one group, each on its rank's stream (behind that rank's pack)
-        if (m_gather == Gather::RCCL) {
-            ncclck(ncclGroupStart(), "ncclGroupStart");
-            for (int r = 0; r < n; r++)
-                ncclck(ncclAllGather(m->slab[r], m->gathered[r], bytes / sizeof(float), ncclFloat, m->comm[r], m->stream[r]), "ncclAllGather");
-            ncclck(ncclGroupEnd(), "ncclGroupEnd");
-        } else {                                                                        // testing stand-in (one GPU, several ranks): plain device copies
-            for (int r = 0; r < n; r++) { hipck(hipSetDevice(m_devices[r]), "hipSetDevice"); hipck(hipStreamSynchronize(m->stream[r]), "sync pack"); }
-            for (int r = 0; r < n; r++) {
-                hipck(hipSetDevice(m_devices[r]), "hipSetDevice");
-                for (int q = 0; q < n; q++)
-                    hipck(hipMemcpyAsync((char*)m->gathered[r] + (size_t)q * bytes, m->slab[q], bytes, hipMemcpyDeviceToDevice, m->stream[r]), "copy slab");
-            }
-        }
+        AllGather(m->slab, m->gathered, bytes);                                         // phase 2: ONE collective per frame
         // phase 3: every rank scatters all slabs into its accumulation buffer (enqueued behind the gather on the same stream)
         for (int r = 0; r < n; r++) {
             rtx_params p = p0; p.shard_rank = (uint32_t)r; p.shard_count = (uint32_t)n;

@@ -29,6 +29,9 @@ public:
 private:
     struct Impl;
     Impl* m;
+    void Teardown();
+    void EnsureSlabs(std::vector<void*>& slab, std::vector<void*>& gathered, size_t& have, size_t bytes);
+    void AllGather(std::vector<void*>& slab, std::vector<void*>& gathered, size_t bytes);
     std::vector<int> m_devices;
     std::vector<rtx_stats> m_stats;
     Gather m_gather;

@@ -1,6 +1,7 @@
 // rtx_host_c.cpp — C entry points of include/rtx_host.h over the C++ host layer.
 #include "../../include/rtx_host.h"
 #include <cstring>
+#include <type_traits>
 #include <exception>
 #include <stdexcept>
 #include <algorithm>
@@ -94,14 +95,28 @@ int rtxh_scene_save(const rtxh_scene* s, const char* path) {
     if (!ok || !H.build(B)) { g_err = H.err; return RTX_ERR_INVALID; }
     const float cam[12] = {sc.eye.x, sc.eye.y, sc.eye.z, sc.center.x, sc.center.y, sc.center.z, sc.up.x, sc.up.y, sc.up.z, sc.fovY_deg, sc.zn, sc.zf};
     std::string err;
-    if (!rtx::save_scene_cache(H, B, path, err, cam)) { g_err = err; return RTX_ERR_INVALID; }
+    rtx::CacheAux aux;                                                // MaterialExt + texture names ride along (an OBJ / MTL scene answers the accessors after a load, too)
+    static_assert(std::is_trivially_copyable<MaterialExt>::value, "MaterialExt is stored as raw records");
+    aux.rec_bytes = (uint32_t)sizeof(MaterialExt);
+    aux.records.resize(sc.materialExt.size() * sizeof(MaterialExt));
+    if (!sc.materialExt.empty()) memcpy(aux.records.data(), sc.materialExt.data(), aux.records.size());
+    for (const std::string& t : sc.textures) { aux.text.insert(aux.text.end(), t.begin(), t.end()); aux.text.push_back('\0'); }
+    if (!rtx::save_scene_cache(H, B, path, err, cam, &aux)) { g_err = err; return RTX_ERR_INVALID; }
     return RTX_OK;
 }
 rtxh_scene* rtxh_scene_load(const char* path) {
-    rtx::SceneHost H; rtx::BuiltScene B; float cam[12]; std::string err;
-    if (!rtx::load_scene_cache(path, H, B, err, cam)) { g_err = err; return nullptr; }
+    rtx::SceneHost H; rtx::BuiltScene B; float cam[12]; std::string err; rtx::CacheAux aux;
+    if (!rtx::load_scene_cache(path, H, B, err, cam, &aux)) { g_err = err; return nullptr; }
+    const size_t next = aux.rec_bytes == sizeof(MaterialExt) ? aux.records.size() / sizeof(MaterialExt) : 0;
+    if ((!aux.records.empty() && (aux.rec_bytes != sizeof(MaterialExt) || next != H.mats128.size() / 32)) || (!aux.text.empty() && aux.text.back() != '\0')) {
+        g_err = "scene cache: material extension records do not match this library"; return nullptr;
+    }
     rtxh_scene* h = new rtxh_scene();
     Scene& sc = h->s;
+    sc.materialExt.resize(next);
+    if (next) memcpy((void*)sc.materialExt.data(), aux.records.data(), next * sizeof(MaterialExt));
+    for (size_t at = 0; at < aux.text.size();) { const std::string t(&aux.text[at]); at += t.size() + 1; sc.textures.push_back(t); }
+    for (MaterialExt& e : sc.materialExt) for (int& m : e.map) if (m < -1 || m >= (int)sc.textures.size()) m = -1;      // ids stay inside the name list
     sc.name = path; h->cache_path = path;
     const size_t nmat = H.mats128.size() / 32;
     sc.materials.assign(nmat, Material(XMFLOAT4(1, 1, 1, 1), XMFLOAT4(0, 0, 0, 0)));

@@ -378,10 +378,86 @@ def test_scene_cache_round_trip_and_rejects_damaged_files(rt, cornell, tmp_path,
     flipped = bytearray(blob); flipped[len(blob) // 2] ^= 0x10
     refused(flipped, "checksum")
     refused(b"P6\n" + bytes(200), "not a scene cache")
-    newer = bytearray(blob); newer[8] = 2
+    newer = bytearray(blob); newer[8] = 9
     refused(newer, "version")
     with pytest.raises(rt.RtxError):
         rt.Scene.load(tmp_path / "missing.rtxscn")
+
+    # CRAFTED files: the checksum is a word hash, not a signature, so a file that carries a valid one must still be refused when a field the kernels
+    # or the refit trust is out of range (mesh count, traversal stack depth, vertex indices, instance triangle ranges).  The hash of
+    # csrc/rtx_scene_cache.cpp restated here (4 lanes over 64-bit words per 4 MiB chunk, chunks folded in order).
+    M64 = (1 << 64) - 1
+
+    def mix(h, w):
+        h = ((h ^ w) * 0x9E3779B97F4A7C15) & M64
+        return h ^ (h >> 29)
+
+    def hash_chunk(b):
+        h = [0x243F6A8885A308D3, 0x13198A2E03707344, 0xA4093822299F31D0, 0x082EFA98EC4E6C89]
+        n = len(b); full = n - n % 32
+        w = np.frombuffer(bytes(b[:full]), dtype="<u8").tolist()
+        for i in range(0, len(w), 4):
+            for k in range(4):
+                h[k] = mix(h[k], w[i + k])
+        tail = np.frombuffer(bytes(b[full:]) + bytes(32 - (n - full)), dtype="<u8").tolist()
+        for k in range(4):
+            h[k] = mix(h[k], tail[k])
+        return mix(mix(mix(mix(n, h[0]), h[1]), h[2]), h[3])
+
+    def resign(data):
+        pay = data[80:]
+        h = 0x452821E638D01377 ^ len(pay)
+        for c in range(0, len(pay), 4 << 20):
+            h = mix(h, hash_chunk(pay[c:c + (4 << 20)]))
+        data[56:64] = int(h).to_bytes(8, "little")            # Header: magic 8, version 4, endian 4, layout 32, payload 8, checksum 8, sections 8
+        return data
+
+    small = tmp_path / "cornell.rtxscn"
+    blob = bytearray(open(small, "rb").read())
+    assert bytes(resign(bytearray(blob))) == bytes(blob)                            # the restated hash reproduces the file's own checksum
+    rt.Scene.load(small)
+    # the scalar block follows the first section head: payload offset 16; Scalars = {stack8, small_nrec, small_nocc, max_depth, nmesh, ...}
+    sc0 = 80 + 16
+    def patched(off, value):
+        d = bytearray(blob); d[off:off + 4] = int(value).to_bytes(4, "little"); return resign(d)
+    refused(patched(sc0 + 16, 0x7FFFFFFF), "mesh count")                           # nmesh: used to size a vector
+    refused(patched(sc0 + 16, 3), "unexpected section")                            # nmesh: more meshes than sections
+    refused(patched(sc0 + 0, 7), "stack depth")                                    # stack8: sizes the per-lane LDS stack column
+    refused(patched(sc0 + 4, 65), "inconsistent")                                  # small_nrec beyond the tiny-scene limit / the stored records
+    # a vertex index beyond the mesh's vertices: find the first T_MESHI section (tag 6, element size 4) and poison its first entry
+    at, tag_meshi = 80, 6
+    while at < len(blob):
+        tag, elem = int.from_bytes(blob[at:at + 4], "little"), int.from_bytes(blob[at + 4:at + 8], "little")
+        cnt = int.from_bytes(blob[at + 8:at + 16], "little")
+        if tag == tag_meshi:
+            break
+        at += 16 + ((elem * cnt + 15) & ~15)
+    assert tag == tag_meshi and elem == 4 and cnt >= 3
+    refused(patched(at + 16, 0x00FFFFFF), "inconsistent")
+    # InstHost::tri_base (the last dword of the 264-byte record; section tag 4)
+    at = 80
+    while True:
+        tag, elem = int.from_bytes(blob[at:at + 4], "little"), int.from_bytes(blob[at + 4:at + 8], "little")
+        cnt = int.from_bytes(blob[at + 8:at + 16], "little")
+        if tag == 4:
+            break
+        at += 16 + ((elem * cnt + 15) & ~15)
+    assert elem == 264 and cnt >= 1
+    refused(patched(at + 16 + 260, 5), "inconsistent")
+
+
+def test_scene_cache_keeps_material_extension_records_and_texture_names(rt, golden_dir, tmp_path):
+    """an OBJ / MTL scene that goes through Scene.save() / Scene.load() answers the MaterialExt / texture accessors as before
+    (the cache carries both beside the material table: format version 2)."""
+    D = os.path.join(golden_dir, "mtlext")
+    sc = rt.Scene.from_obj([os.path.join(D, "mx03.obj")], D + "/")
+    assert sc.material_ext and sc.textures
+    path = tmp_path / "mx03.rtxscn"
+    sc.save(path)
+    back = rt.Scene.load(path)
+    assert back.textures == sc.textures and back.material_ext == sc.material_ext
+    cb = rt.Scene.cornell(); cb.save(tmp_path / "c.rtxscn")
+    assert rt.Scene.load(tmp_path / "c.rtxscn").material_ext == []
 
 
 def test_mtl_extension_keys_and_map_ids_match_tinyobj(rt, golden_dir):
