@@ -50,7 +50,7 @@ typedef struct rtx_params {
     uint32_t frame_seed;      /* stands in for uint(time) (RayGen_v6_pass1.hlsl:76-77; Renderer.cpp:1754-1760) */
     uint32_t flags;           /* RTX_FLAG_* */
     uint32_t tile_size;       /* shard tile edge in pixels: a power of two in [16, 1024] (0 => 64); anything else is RTX_ERR_INVALID everywhere */
-    uint32_t shard_rank;      /* this context renders tiles t (row-major tile index) with t % shard_count == shard_rank */
+    uint32_t shard_rank;      /* this context renders tiles t (row-major tile index) with t % shard_count == shard_rank (RTX_FLAG_BLOCK_TILES: one rectangle of tiles instead) */
     uint32_t shard_count;     /* 0 or 1 => whole image */
 } rtx_params;
 
@@ -59,6 +59,11 @@ typedef struct rtx_params {
 #define RTX_FLAG_TRANSMISSION 4u  /* EXTENSION: strategy 3 (rough dielectric transmission) for materials with dissolve Kd.w < 1 and Ni != 1; the reference
                                      has the strategy as a stub only (BRDF_v6.hlsl:5,28-29,44-47,85-87).  rtx_render only; ignored with LAMBERT_ONLY
                                      and by the literal pass-1 / ReSTIR modes.  Off: every result is the reference-faithful one */
+
+#define RTX_FLAG_BLOCK_TILES  8u  /* sharding: the tiles of a shard form ONE rectangle (the shard_count ranks as a gx x gy grid of blocks, gx * gy = shard_count chosen
+                                     for the smallest block perimeter) instead of tile t -> rank t mod shard_count.  Same pixels, same image; what changes is who owns
+                                     which tile: round-robin balances a path-traced frame, blocks keep the 20-px halo of a ReSTIR frame small (rtx_render_restir).
+                                     Every call that takes rtx_params (render, pack / unpack, slab sizes) follows the flag */
 
 /* kernel classes for rtx_stats */
 enum { RTX_K_RAYGEN = 0, RTX_K_TRACE = 1, RTX_K_SHADE = 2, RTX_K_SHADOW = 3, RTX_K_ACCUM = 4, RTX_K_SORT = 5,
@@ -88,6 +93,10 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
        RTX_OPT_STACK_PRIVATE = 9,    /* tuning: traversal stack 0 = LDS column, 1 = private (scratch) memory, (2 is accepted and means 0) */
        RTX_OPT_TRACE_SCHED = 10,     /* tuning: wave schedule of the BVH traversal, 0 = while-while, 1-4 = voted node / triangle steps, 5-7 = voted + speculative (default 6) */
        RTX_OPT_GPU_REFIT = 11,       /* 1 (default): a transform-only rtx_commit_scene refits the resident BVH on the GPU; 0: host refit + upload */
+       RTX_OPT_RESTIR_WAVEFRONT = 19,/* 1 (default): rtx_render_v6_pass1 / rtx_render_restir run as wavefront stages (csrc/rtx_restir_wave.hpp: stage kernels of <= 128 VGPRs, every
+                                        ray traversed by the persistent kernels of the path tracer); 0: the literal form, one thread per pixel and pass like the reference's raygen
+                                        shaders (csrc/rtx_restir.hpp).  Byte-identical buffers and images either way */
+       RTX_OPT_RESTIR_CHUNKS = 20,   /* tuning: 256-pixel chunks per workgroup (= private sub-queue) of the ReSTIR stages, default 4 */
        RTX_OPT_OVERLAP_SHADOW = 18,  /* 1 (default): general scenes run the shadow-ray kernel of bounce b on a second (internal) stream beside the closest-hit kernel of
                                         bounce b + 1; everything is joined into the context's stream before rtx_render returns.  Off while RTX_OPT_KERNEL_TIMING is on
                                         (overlapping launches have no per-kernel time).  Results identical */

@@ -46,7 +46,7 @@ struct rtx_ctx {
     // path state
     DevBuf d_hitmask, d_order, d_pmask;
     bool lpt_order = true;          // RTX_OPT_LPT_ORDER: fused kernels take their sub-queues longest first
-    DevBuf d_halo; uint32_t halo_count = 0; uint32_t halo_key[5] = {0, 0, 0, 0, 0};     // ReSTIR on shards: the shard's tiles dilated by 20 px, as a pixel list (width, height, tile, rank, count)
+    DevBuf d_halo; uint32_t halo_count = 0; uint32_t halo_key[6] = {0, 0, 0, 0, 0, 0};     // ReSTIR on shards: the shard's tiles dilated by 20 px, as a pixel list (width, height, tile, rank, count)
     bool bounce_ring = true;        // RTX_OPT_BOUNCE_VARIANT
     bool fused_bvh = false;         // RTX_OPT_FUSED_BVH: general path = one k_bounce_bvh launch per batch (trace -> shade -> shadow per sub-queue and bounce); measured SLOWER, default off
     DevBuf d_hitq;
@@ -61,6 +61,10 @@ struct rtx_ctx {
     DevBuf d_accum; void* ext_accum = nullptr; size_t ext_accum_bytes = 0; uint32_t acc_w = 0, acc_h = 0;
     DevBuf d_srgb, d_res_di, d_res_gi, d_sdata, d_last_di, d_last_gi, d_last_sd, d_p1cnt, d_p1scratch; size_t p1_slots = 0, last_slots = 0;
     float prev_view[16], prev_proj[16];
+    // wavefront ReSTIR (rtx_restir_wave.hpp): path state by queue position (two sets), hit records, per-item records, the any-hit ray queue, queue lengths
+    bool restir_wave = true;        // RTX_OPT_RESTIR_WAVEFRONT
+    uint32_t restir_chunks = 4;     // RTX_OPT_RESTIR_CHUNKS: 256-item chunks per sub-queue (= workgroup) of the ReSTIR stages
+    DevBuf d_rs_state, d_rs_hit, d_rs_cls, d_rs_fin, d_rs_cold, d_rs_occ, d_rs_cand, d_rs_sho, d_rs_shd, d_rs_pay, d_rs_cnt;
     // options
     bool timing = false; uint64_t paths_per_batch = 128u << 20; int lds_nodes_opt = -1; bool small_scene = true; bool fused = true; int stack_private = -1;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
@@ -119,7 +123,8 @@ void rtx_destroy(rtx_ctx* c) {
     else (void)hipDeviceSynchronize();
     DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_small_poly, &c->d_objtris, &c->d_node_aabb, &c->d_scale, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
                      &c->d_thr, &c->d_rad, &c->d_hit, &c->d_hitmask, &c->d_order, &c->d_pmask, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
-                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq, &c->d_halo, &c->d_heads, &c->d_alt_o, &c->d_alt_d, &c->d_alt_thr};
+                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq, &c->d_halo, &c->d_heads, &c->d_alt_o, &c->d_alt_d, &c->d_alt_thr,
+                     &c->d_rs_state, &c->d_rs_hit, &c->d_rs_cls, &c->d_rs_fin, &c->d_rs_cold, &c->d_rs_occ, &c->d_rs_cand, &c->d_rs_sho, &c->d_rs_shd, &c->d_rs_pay, &c->d_rs_cnt};
     for (DevBuf* b : all) b->release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
@@ -150,6 +155,8 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_OVERLAP_SHADOW: c->overlap_shadow = value != 0; return RTX_OK;
     case RTX_OPT_BLOCKS_PER_CU: if (value < 0 || value > 64) { c->err = "blocks_per_cu must be in [0, 64]"; return RTX_ERR_INVALID; } c->blocks_per_cu = (uint32_t)value; return RTX_OK;
     case RTX_OPT_GPU_REFIT: c->gpu_refit = value != 0; return RTX_OK;
+    case RTX_OPT_RESTIR_WAVEFRONT: c->restir_wave = value != 0; return RTX_OK;
+    case RTX_OPT_RESTIR_CHUNKS: if (value < 1 || value > 64) { c->err = "restir_chunks must be in [1, 64]"; return RTX_ERR_INVALID; } c->restir_chunks = (uint32_t)value; return RTX_OK;
     case RTX_OPT_TRACE_SCHED: if (value > 7) { c->err = "trace_sched must be in [0, 7]"; return RTX_ERR_INVALID; } c->trace_sched = (uint32_t)value; c->dsc.trace_sched = c->trace_sched; return RTX_OK;
     case RTX_OPT_REFILL_MIN: if (value < 1 || value > 64) { c->err = "refill_min must be in [1, 64]"; return RTX_ERR_INVALID; } c->refill_min = (uint32_t)value; c->dsc.refill_min = c->refill_min; return RTX_OK;
     default: c->err = "unknown option"; return RTX_ERR_INVALID;
@@ -359,14 +366,28 @@ int rtx_clear_accum(rtx_ctx* c, uint32_t w, uint32_t h) {
 
 // the ONE rule for the shard tiling, shared by every entry point that takes rtx_params (render, pack / unpack, rtx_shard_slab_bytes):
 // tile_size a power of two in [16, 1024] (0 => 64), shard_rank < shard_count, the local slot count fits 31 bits.  All in 64-bit arithmetic.
-static const char* validate_tiling(const rtx_params* p, uint32_t& ts, uint32_t& cnt, uint64_t& npl) {
+// RTX_FLAG_BLOCK_TILES: the ranks form a gx x gy grid of tile rectangles, gx gy = shard_count with the smallest rectangle perimeter (ties: the wider grid).
+static void block_grid(uint64_t TX, uint64_t TY, uint32_t N, uint32_t& gx, uint32_t& gy) {
+    double best = 1e300; gx = N; gy = 1;
+    for (uint32_t a = 1; a <= N; a++) {
+        if (N % a) continue;
+        const uint32_t b = N / a;
+        const double cost = (double)((TX + a - 1) / a) + (double)((TY + b - 1) / b);
+        if (cost < best) { best = cost; gx = a; gy = b; }
+    }
+}
+static const char* validate_tiling(const rtx_params* p, uint32_t& ts, uint32_t& cnt, uint64_t& npl, uint32_t* gx_out = nullptr, uint32_t* gy_out = nullptr) {
     if (!p || !p->width || !p->height) return "params: width/height must be non-zero";
     ts = p->tile_size ? p->tile_size : 64;
     if (ts < 16 || ts > 1024 || (ts & (ts - 1))) return "params: tile_size must be a power of two in [16, 1024] (0 = 64)";
     cnt = p->shard_count ? p->shard_count : 1;
     if (p->shard_rank >= cnt) return "params: shard_rank >= shard_count";
-    const uint64_t total = (uint64_t)((p->width + (uint64_t)ts - 1) / ts) * ((p->height + (uint64_t)ts - 1) / ts);
-    const uint64_t per = (total + cnt - 1) / cnt;
+    const uint64_t TX = (p->width + (uint64_t)ts - 1) / ts, TY = (p->height + (uint64_t)ts - 1) / ts;
+    uint64_t per = (TX * TY + cnt - 1) / cnt;
+    uint32_t gx = 0, gy = 0;
+    if ((p->flags & RTX_FLAG_BLOCK_TILES) && cnt > 1) { block_grid(TX, TY, cnt, gx, gy); per = ((TX + gx - 1) / gx) * ((TY + gy - 1) / gy); }
+    if (gx_out) *gx_out = gx;
+    if (gy_out) *gy_out = gy;
     if (per > 0x7FFFFFFFull / ((uint64_t)ts * ts)) return "params: image too large";      // (checked before the multiplication: 2^56 tiles of 16 x 16 would wrap)
     npl = per * ts * ts;
     return nullptr;
@@ -374,7 +395,7 @@ static const char* validate_tiling(const rtx_params* p, uint32_t& ts, uint32_t& 
 
 static int make_frame(rtx_ctx* c, const rtx_params* p, DevFrame& f) {
     uint32_t ts = 0, cnt = 0; uint64_t npl64 = 0;
-    if (const char* e = validate_tiling(p, ts, cnt, npl64)) { c->err = e; return RTX_ERR_INVALID; }
+    if (const char* e = validate_tiling(p, ts, cnt, npl64, &f.blk_gx, &f.blk_gy)) { c->err = e; return RTX_ERR_INVALID; }
     f.width = p->width; f.height = p->height; f.tile_size = ts;
     f.tile_shift = 0; while ((1u << f.tile_shift) < ts) f.tile_shift++;
     f.nblocks = 1; f.qcap = 0; f.chunks_per_sample = 0;
@@ -571,6 +592,96 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
 size_t rtx_pass1_slots(uint32_t w, uint32_t h) { return (size_t)((w + 3) / 4) * ((h + 3) / 4) * 16; }
 static int p1_alloc(rtx_ctx* c, size_t slots);
 
+// ---- the ReSTIR passes as wavefront stages (csrc/rtx_restir_wave.hpp) ----------------------------------------------------------------------------------
+// One pass at a time owns the work area.  `nitems` work items (pixels of the shard's own tiles, or — passes 1 and 2 on shards — of the dilated tiles) are cut
+// into 256-item chunks and dealt round-robin to G workgroups, each with a private sub-queue: stage kernels and the persistent traversal kernels of a pass all run
+// with G workgroups, workgroup b owning sub-queue b.  G: `restir_chunks` chunks per workgroup (more = fuller persistent waves, fewer = shorter launch tails).
+struct RsPlan { RsQ q; uint32_t* cnt; uint32_t G; DevFrame fq; DevPaths P[2]; };
+static int rs_plan(rtx_ctx* c, const DevFrame& f, uint32_t nitems, const uint32_t* pixels, uint32_t rows, RsPlan& R) {
+    const uint32_t nchunks = std::max<uint32_t>(1u, (nitems + 255u) / 256u);
+    const uint32_t G = std::max<uint32_t>(1u, std::min<uint32_t>((nchunks + c->restir_chunks - 1) / c->restir_chunks, (uint32_t)c->num_cus * 64u));
+    const uint32_t qcap = ((nchunks + G - 1) / G) * 256u, rcap = qcap * 9u;              // a pixel casts at most 9 visibility rays in one stage (pass 3, select)
+    const size_t qtot = (size_t)G * qcap, rtot = (size_t)G * rcap;
+    if (rtot > 0xFFFFFFFFull) { c->err = "render_restir: image too large"; return RTX_ERR_INVALID; }
+    HIPCHK(c, c->d_rs_state.ensure(qtot * 16 * 2 * kRsStreams)); HIPCHK(c, c->d_rs_hit.ensure(qtot * 16));
+    HIPCHK(c, c->d_rs_cls.ensure((size_t)nitems * 4)); HIPCHK(c, c->d_rs_fin.ensure((size_t)nitems * 16)); HIPCHK(c, c->d_rs_cold.ensure((size_t)nitems * 16 * 5));
+    HIPCHK(c, c->d_rs_occ.ensure((size_t)nitems * kRsOcc)); HIPCHK(c, c->d_rs_cand.ensure((size_t)nitems * 4 * kRsCand));
+    HIPCHK(c, c->d_rs_sho.ensure(rtot * 16)); HIPCHK(c, c->d_rs_shd.ensure(rtot * 16)); HIPCHK(c, c->d_rs_pay.ensure(rtot * 4));
+    HIPCHK(c, c->d_rs_cnt.ensure((size_t)rows * G * 4));
+    RsQ& q = R.q;
+    q.nitems = nitems; q.pixels = pixels; q.G = G; q.qcap = qcap; q.rcap = rcap;
+    for (uint32_t set = 0; set < 2; set++) for (uint32_t k = 0; k < kRsStreams; k++) q.st[set][k] = (F4*)c->d_rs_state.p + ((size_t)set * kRsStreams + k) * qtot;
+    q.hit = (F4*)c->d_rs_hit.p; q.cls = (uint32_t*)c->d_rs_cls.p; q.fin = (F4*)c->d_rs_fin.p; q.cold = (F4*)c->d_rs_cold.p;
+    q.occ = (uint8_t*)c->d_rs_occ.p; q.cand = (uint32_t*)c->d_rs_cand.p;
+    q.sh_o = (F4*)c->d_rs_sho.p; q.sh_d = (F4*)c->d_rs_shd.p; q.sh_pay = (uint32_t*)c->d_rs_pay.p;
+    q.rays = (unsigned long long*)c->d_p1cnt.p;
+    R.cnt = (uint32_t*)c->d_rs_cnt.p; R.G = G;
+    R.fq = f; R.fq.nblocks = G; R.fq.qcap = qcap;
+    for (uint32_t set = 0; set < 2; set++) {          // what k_trace_closest sees of a set: rays and hit records by queue position ("compact state": out_o != nullptr is the flag)
+        DevPaths P{}; P.ray_o = q.st[set][0]; P.ray_d = q.st[set][1]; P.hit = q.hit; P.out_o = q.st[set ^ 1u][0];
+        R.P[set] = P;
+    }
+    return RTX_OK;
+}
+// pass 1 of one sample (RayGen_v6_pass1.hlsl:48-190): raygen | trace | ris | trace | ris_finish | trace x 2 | first | (trace | loop) x bounces | emit_final | trace | finish
+static int rs_pass1(rtx_ctx* c, const DevFrame& f, uint32_t sample_id, F4* accum, const uint32_t* pixels, uint32_t npixels) {
+    const uint32_t mb = f.max_bounces, rows = 4u + mb + 2u;
+    RsPlan R; int r = rs_plan(c, f, pixels ? npixels : f.npl, pixels, rows, R); if (r) return r;
+    hipStream_t st = c->stream;
+    const DevScene& sc = c->dsc; const RsQ& q = R.q;
+    auto row = [&](uint32_t k) { return R.cnt + (size_t)k * R.G; };
+    uint32_t* res_di = (uint32_t*)c->d_res_di.p; uint32_t* res_gi = (uint32_t*)c->d_res_gi.p; uint32_t* sdata = (uint32_t*)c->d_sdata.p;
+    { Timed t(c, RTX_K_RAYGEN); launch_rs_raygen(st, R.fq, q, (const CameraGPU*)c->d_cam.p, sample_id, row(0)); }
+    { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, R.fq, sc, R.P[0], 0, nullptr, row(0), nullptr); }                    // camera rays (tmin 1e-4)
+    { Timed t(c, RTX_K_SHADE); launch_rs_p1_ris(st, sc, R.fq, q, row(0), row(1), accum, res_di, res_gi, sdata); }
+    { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, R.fq, sc, R.P[1], 1, nullptr, row(1), nullptr); }                    // the BSDF candidates of SampleRIS
+    { Timed t(c, RTX_K_SHADE); launch_rs_p1_ris_finish(st, sc, R.fq, q, row(1), row(2), row(4 + mb), res_di, sdata); }
+    { Timed t(c, RTX_K_SHADOW); launch_trace_occ(st, sc, q, row(4 + mb)); }                                                  // DI visibility
+    { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, R.fq, sc, R.P[0], 1, nullptr, row(2), nullptr); }                    // first path vertex
+    { Timed t(c, RTX_K_SHADE); launch_rs_p1_first(st, sc, R.fq, q, row(2), row(3)); }
+    for (uint32_t i = 0; i < mb; i++) {
+        const uint32_t set = (i + 1u) & 1u;                 // k_rs_p1_first wrote set 1
+        { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, R.fq, sc, R.P[set], 1, nullptr, row(3 + i), nullptr); }
+        { Timed t(c, RTX_K_SHADE); launch_rs_p1_loop(st, sc, R.fq, q, set, i, row(3 + i), row(4 + i)); }
+    }
+    { Timed t(c, RTX_K_SHADE); launch_rs_p1_emit_final(st, sc, R.fq, q, row(5 + mb)); }
+    { Timed t(c, RTX_K_SHADOW); launch_trace_occ(st, sc, q, row(5 + mb)); }                                                  // the selected reconnection
+    { Timed t(c, RTX_K_SHADE); launch_rs_p1_finish(st, sc, R.fq, q, accum, res_di, res_gi, sdata); }
+    HIPCHK(c, hipGetLastError());
+    return RTX_OK;
+}
+static int rs_pass2(rtx_ctx* c, const DevFrame& f, uint32_t* const bufs[6], const uint32_t* pixels, uint32_t npixels) {
+    RsPlan R; int r = rs_plan(c, f, pixels ? npixels : f.npl, pixels, 1, R); if (r) return r;
+    const CameraGPU* cam = (const CameraGPU*)c->d_cam.p;
+    { Timed t(c, RTX_K_SHADE); launch_rs_p2_emit(c->stream, c->dsc, R.fq, R.q, cam, bufs, R.cnt); }
+    { Timed t(c, RTX_K_SHADOW); launch_trace_occ(c->stream, c->dsc, R.q, R.cnt); }
+    { Timed t(c, RTX_K_SHADE); launch_rs_p2_merge(c->stream, c->dsc, R.fq, R.q, cam, bufs); }
+    HIPCHK(c, hipGetLastError());
+    return RTX_OK;
+}
+static int rs_pass3(rtx_ctx* c, const DevFrame& f, uint32_t* const bufs[6], F4* accum) {
+    RsPlan R; int r = rs_plan(c, f, f.npl, nullptr, 2, R); if (r) return r;
+    const CameraGPU* cam = (const CameraGPU*)c->d_cam.p;
+    { Timed t(c, RTX_K_SHADE); launch_rs_p3_select(c->stream, c->dsc, R.fq, R.q, cam, bufs, R.cnt); }
+    { Timed t(c, RTX_K_SHADOW); launch_trace_occ(c->stream, c->dsc, R.q, R.cnt); }
+    { Timed t(c, RTX_K_SHADE); launch_rs_p3_merge(c->stream, c->dsc, R.fq, R.q, bufs, R.cnt + R.G); }
+    { Timed t(c, RTX_K_SHADOW); launch_trace_occ(c->stream, c->dsc, R.q, R.cnt + R.G); }
+    { Timed t(c, RTX_K_SHADE); launch_rs_p3_shade(c->stream, c->dsc, R.fq, R.q, bufs, accum); }
+    HIPCHK(c, hipGetLastError());
+    return RTX_OK;
+}
+static void stats_begin(rtx_ctx* c) {
+    memset(c->stats.kernel_ms, 0, sizeof(c->stats.kernel_ms)); memset(c->stats.kernel_launches, 0, sizeof(c->stats.kernel_launches)); memset(c->stats.kernel_items, 0, sizeof(c->stats.kernel_items));
+    c->ev_used = 0; c->timed.clear();
+}
+static void stats_end_restir(rtx_ctx* c, const unsigned long long cnt[3]) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) c->stats.render_ms = ms;
+    for (const TimedLaunch& t : c->timed) { float m = 0.0f; if (hipEventElapsedTime(&m, t.a, t.b) == hipSuccess) c->stats.kernel_ms[t.cls] += m; }
+    c->stats.rays_primary = cnt[0]; c->stats.rays_extension = cnt[1]; c->stats.rays_shadow = cnt[2]; c->stats.paths = cnt[0]; c->stats.primary_hits = 0;
+    c->stats.kernel_items[RTX_K_RAYGEN] = cnt[0]; c->stats.kernel_items[RTX_K_TRACE] = cnt[0] + cnt[1]; c->stats.kernel_items[RTX_K_SHADOW] = cnt[2];
+}
+
 int rtx_render_v6_pass1(rtx_ctx* c, const rtx_params* p) {
     BIND(c);
     if (!c->committed) { c->err = "render: scene not committed"; return RTX_ERR_STATE; }
@@ -582,20 +693,21 @@ int rtx_render_v6_pass1(rtx_ctx* c, const rtx_params* p) {
     if ((r = ensure_accum(c, p->width, p->height, false))) return r;
     const size_t slots = rtx_pass1_slots(p->width, p->height);
     if ((r = p1_alloc(c, slots))) return r;
+    stats_begin(c);
     HIPCHK(c, hipMemsetAsync(c->d_p1cnt.p, 0, 24, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_begin, c->stream));
-    for (uint32_t s = 0; s < p->spp; s++)
-        launch_v6_pass1(c->stream, (uint32_t)c->num_cus * 8u, c->dsc, f, (const CameraGPU*)c->d_cam.p, p->sample_base + s, c->accum_ptr(),
-                        (uint32_t*)c->d_res_di.p, (uint32_t*)c->d_res_gi.p, (uint32_t*)c->d_sdata.p, (unsigned long long*)c->d_p1cnt.p);
+    for (uint32_t s = 0; s < p->spp; s++) {
+        if (c->restir_wave) { if ((r = rs_pass1(c, f, p->sample_base + s, c->accum_ptr(), nullptr, 0))) return r; }
+        else { Timed t(c, RTX_K_BOUNCE);
+               launch_v6_pass1(c->stream, (uint32_t)c->num_cus * 8u, c->dsc, f, (const CameraGPU*)c->d_cam.p, p->sample_base + s, c->accum_ptr(),
+                               (uint32_t*)c->d_res_di.p, (uint32_t*)c->d_res_gi.p, (uint32_t*)c->d_sdata.p, (unsigned long long*)c->d_p1cnt.p); }
+    }
     HIPCHK(c, hipEventRecord(c->ev_end, c->stream));
     HIPCHK(c, hipGetLastError());
     unsigned long long cnt[3] = {0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(cnt, c->d_p1cnt.p, 24, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    memset(c->stats.kernel_ms, 0, sizeof(c->stats.kernel_ms)); memset(c->stats.kernel_launches, 0, sizeof(c->stats.kernel_launches)); memset(c->stats.kernel_items, 0, sizeof(c->stats.kernel_items));
-    float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) c->stats.render_ms = ms;
-    c->stats.rays_primary = cnt[0]; c->stats.rays_extension = cnt[1]; c->stats.rays_shadow = cnt[2]; c->stats.paths = cnt[0]; c->stats.primary_hits = 0;
+    stats_end_restir(c, cnt);
     return RTX_OK;
 }
 
@@ -630,18 +742,21 @@ int rtx_render_restir(rtx_ctx* c, const rtx_params* p) {
     //   * runs pass 3 (and the accumulation) on its own tiles,
     //   * and after the frame the shards exchange the history of their own tiles: rtx_restir_pack_state -> one all-gather -> rtx_restir_unpack_state,
     // which the caller does between frames — hence one frame per call.  Images and histories are bit-identical to the unsharded run.
+    // With RTX_FLAG_BLOCK_TILES the tiles of a shard form ONE rectangle, so the dilation adds a 20-px rim (8 shards at 1080p: 1.16 x the own pixels) instead of a rim
+    // around every 64-px tile (2.6 x with the round-robin deal).
     const bool sharded = p->shard_count > 1;
     if (sharded && p->spp != 1) { c->err = "render_restir: on shards the history has to be exchanged after every frame (rtx_restir_pack_state / unpack_state): spp must be 1"; return RTX_ERR_INVALID; }
     if (sharded && (p->width > 65535u || p->height > 65535u)) { c->err = "render_restir: sharded images are limited to 65535 x 65535"; return RTX_ERR_INVALID; }
     if ((r = ensure_accum(c, p->width, p->height, false))) return r;
     const uint32_t* halo = nullptr; uint32_t nhalo = 0;
     if (sharded) {
-        const uint32_t key[5] = {p->width, p->height, f.tile_size, p->shard_rank, p->shard_count};
+        const uint32_t key[6] = {p->width, p->height, f.tile_size, p->shard_rank, p->shard_count, p->flags & RTX_FLAG_BLOCK_TILES};
         if (memcmp(key, c->halo_key, sizeof(key)) != 0 || !c->d_halo.p) {
             const uint32_t W = p->width, H = p->height, ts = f.tile_size, R = 20u;           // spatial radius: RayGen_v6_pass3.hlsl (random pixel within 20)
             std::vector<uint8_t> mask((size_t)W * H, 0);
-            for (uint32_t t = p->shard_rank; t < f.tiles_x * f.tiles_y; t += p->shard_count) {
-                const uint32_t tx = t % f.tiles_x, ty = t / f.tiles_x;
+            for (uint32_t k = 0; k < f.npl >> (2u * f.tile_shift); k++) {                     // the shard's tiles, by the one rule of slot_to_pixel
+                uint32_t tx, ty;
+                if (!shard_tile(f, k, tx, ty)) continue;
                 const uint32_t x0 = tx * ts > R ? tx * ts - R : 0u, y0 = ty * ts > R ? ty * ts - R : 0u;
                 const uint32_t x1 = std::min(W, (tx + 1) * ts + R), y1 = std::min(H, (ty + 1) * ts + R);
                 for (uint32_t y = y0; y < y1; y++) memset(&mask[(size_t)y * W + x0], 1, x1 - x0);
@@ -665,6 +780,7 @@ int rtx_render_restir(rtx_ctx* c, const rtx_params* p) {
     }
     // pass 1 writes its debug estimate into a scratch image (the displayed image is pass 3's)
     DevBuf& scratch = c->d_p1scratch; HIPCHK(c, scratch.ensure((size_t)p->width * p->height * 16));     // context-owned: no per-call hipMalloc / hipFree, nothing to leak on an early return
+    stats_begin(c);
     HIPCHK(c, hipMemsetAsync(c->d_p1cnt.p, 0, 24, c->stream));
     uint32_t* bufs[6] = {(uint32_t*)c->d_res_di.p, (uint32_t*)c->d_res_gi.p, (uint32_t*)c->d_sdata.p, (uint32_t*)c->d_last_di.p, (uint32_t*)c->d_last_gi.p, (uint32_t*)c->d_last_sd.p};
     const uint32_t mbk = (uint32_t)c->num_cus * 8u;
@@ -673,19 +789,22 @@ int rtx_render_restir(rtx_ctx* c, const rtx_params* p) {
     for (uint32_t fr = 0; fr < p->spp; fr++) {                       // spp = number of consecutive frames with this camera
         DevFrame ff = f; ff.frame_seed = p->frame_seed + fr;
         HIPCHK(c, hipMemsetAsync(scratch.p, 0, (size_t)p->width * p->height * 16, c->stream));
-        launch_v6_pass1(c->stream, mbk, c->dsc, ff, cam, 1u, (F4*)scratch.p, bufs[0], bufs[1], bufs[2], (unsigned long long*)c->d_p1cnt.p, halo, nhalo);   // Renderer.cpp:651-654
-        launch_restir_pass2(c->stream, mbk, c->dsc, ff, cam, bufs, (unsigned long long*)c->d_p1cnt.p, halo, nhalo);                                       // :662-664
-        launch_restir_pass3(c->stream, mbk, c->dsc, ff, cam, bufs, c->accum_ptr(), (unsigned long long*)c->d_p1cnt.p);                       // :671-673
+        if (c->restir_wave) {                                                                                                               // the three DispatchRays of Renderer.cpp:646-673 as wavefront stages
+            if ((r = rs_pass1(c, ff, 1u, (F4*)scratch.p, halo, nhalo))) return r;
+            if ((r = rs_pass2(c, ff, bufs, halo, nhalo))) return r;
+            if ((r = rs_pass3(c, ff, bufs, c->accum_ptr()))) return r;
+        } else {                                                                                                                            // ... or literally, a thread per pixel
+            { Timed t(c, RTX_K_BOUNCE); launch_v6_pass1(c->stream, mbk, c->dsc, ff, cam, 1u, (F4*)scratch.p, bufs[0], bufs[1], bufs[2], (unsigned long long*)c->d_p1cnt.p, halo, nhalo); }   // Renderer.cpp:651-654
+            { Timed t(c, RTX_K_BOUNCE); launch_restir_pass2(c->stream, mbk, c->dsc, ff, cam, bufs, (unsigned long long*)c->d_p1cnt.p, halo, nhalo); }                                       // :662-664
+            { Timed t(c, RTX_K_BOUNCE); launch_restir_pass3(c->stream, mbk, c->dsc, ff, cam, bufs, c->accum_ptr(), (unsigned long long*)c->d_p1cnt.p); }                                    // :671-673
+        }
     }
     HIPCHK(c, hipEventRecord(c->ev_end, c->stream));
     HIPCHK(c, hipGetLastError());
     unsigned long long cnt[3] = {0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(cnt, c->d_p1cnt.p, 24, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    memset(c->stats.kernel_ms, 0, sizeof(c->stats.kernel_ms)); memset(c->stats.kernel_launches, 0, sizeof(c->stats.kernel_launches)); memset(c->stats.kernel_items, 0, sizeof(c->stats.kernel_items));
-    float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) c->stats.render_ms = ms;
-    c->stats.rays_primary = cnt[0]; c->stats.rays_extension = cnt[1]; c->stats.rays_shadow = cnt[2]; c->stats.paths = cnt[0]; c->stats.primary_hits = 0;
+    stats_end_restir(c, cnt);
     return RTX_OK;
 }
 

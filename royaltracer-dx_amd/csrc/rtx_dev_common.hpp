@@ -35,9 +35,8 @@ __device__ __forceinline__ uint32_t block_push(bool pred, uint32_t* lds_counter)
 __device__ __forceinline__ bool slot_to_pixel(const DevFrame& f, uint32_t pl, uint32_t& x, uint32_t& y) {
     const uint32_t ts2 = 2u * f.tile_shift;                  // tile_size is a power of two
     const uint32_t k = pl >> ts2, r = pl & ((1u << ts2) - 1u);
-    const uint32_t t = f.shard_rank + k * f.shard_count;
-    if (t >= f.tiles_x * f.tiles_y) return false;
-    const uint32_t ty = t / f.tiles_x, tx = t - ty * f.tiles_x;
+    uint32_t tx, ty;
+    if (!shard_tile(f, k, tx, ty)) return false;
     const uint32_t bshift = f.tile_shift - 3u;               // 8x8 pixel blocks per tile row = 2^bshift
     const uint32_t blk = r >> 6, ln = r & 63u;
     const uint32_t bx = blk & ((1u << bshift) - 1u), by = blk >> bshift;

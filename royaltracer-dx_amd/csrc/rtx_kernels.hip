@@ -19,7 +19,8 @@
 #include "rtx_dev_common.hpp"   // wave helpers, compaction, slot -> pixel, primary ray
 #include "rtx_traverse.hpp"     // triangle test, 8-wide BVH traversal (simple + persistent), tiny-scene pre-test
 #include "rtx_shade.hpp"        // surface reconstruction, NEE, BSDF continuation
-#include "rtx_restir.hpp"       // k_v6_pass1, k_restir_pass2 / 3
+#include "rtx_restir.hpp"       // k_v6_pass1, k_restir_pass2 / 3 (thread per pixel) + the shared per-pixel math
+#include "rtx_restir_wave.hpp"  // the same three passes as wavefront stages
 
 namespace rtx {
 
@@ -187,9 +188,12 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevSc
 
 // any-hit for NEE slot j: visible contributions are added to the path's radiance (a path appears at most once
 // per slot, so the read-modify-write needs no atomic and the order of additions per path is fixed)
-template <int STK, bool STEAL, int SCHED>
+// SINK 0: the path tracer's NEE rays (visible contributions are added to the path's radiance).  SINK 1: visibility rays of the ReSTIR stages (rtx_restir_wave.hpp):
+// the answer goes to occ[pay[entry]] as a byte, 1 = occluded; end points may be anywhere (last frame's samples), so the tiny-scene path tests every record.
+template <int STK, bool STEAL, int SCHED, int SINK = 0>
 __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_shadow(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const F4* __restrict__ sh_o, const F4* __restrict__ sh_d,
-                                                         const F4* __restrict__ sh_c, const uint32_t* __restrict__ shcount, uint32_t qcap, uint32_t refill_min, uint32_t sched, uint32_t* heads) {
+                                                         const F4* __restrict__ sh_c, const uint32_t* __restrict__ shcount, uint32_t qcap, uint32_t refill_min, uint32_t sched, uint32_t* heads,
+                                                         const uint32_t* __restrict__ pay = nullptr, uint8_t* __restrict__ occ = nullptr) {
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_head;
     const uint32_t n = shcount[blockIdx.x];
@@ -199,6 +203,7 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_shadow(DevSce
     __syncthreads();
     const size_t qb = (size_t)blockIdx.x * qcap;
     auto finish = [&](size_t gi, bool occluded) {         // gi: index into the launch's shadow-ray arrays (sub-queue * qcap + entry)
+        if (SINK) { occ[pay[gi]] = occluded ? 1 : 0; return; }
         if (!occluded) {
             const F4 c = sh_c[gi];
             const uint32_t pid = f2u(c.w);
@@ -211,8 +216,8 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_shadow(DevSce
         for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
             const F4 so = sh_o[qb + i], sd = sh_d[qb + i];
             float t, u, v; uint32_t prim;
-            const uint32_t nrec_sh = __builtin_amdgcn_ballot_w64(so.w < 0.0f) != 0ull ? sc.nsmall : sc.nsmall_occ;                        // hull guard, as in k_bounce_small
-            traverse_small<true>(sc, small, L, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), fabsf(so.w), sd.w, t, u, v, prim, nrec_sh);   // NEE segments only
+            const uint32_t nrec_sh = (SINK || __builtin_amdgcn_ballot_w64(so.w < 0.0f) != 0ull) ? sc.nsmall : sc.nsmall_occ;                        // hull guard, as in k_bounce_small
+            traverse_small<true>(sc, small, L, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), SINK ? so.w : fabsf(so.w), sd.w, t, u, v, prim, nrec_sh);   // the short list: NEE segments only
             finish(qb + i, prim != kMissPrim);
         }
         return;
@@ -1085,6 +1090,50 @@ void launch_restir_unpack_state(hipStream_t st, uint32_t max_blocks, const DevFr
 void launch_restir_pass3(hipStream_t st, uint32_t max_blocks, const DevScene& sc, const DevFrame& f, const CameraGPU* cam, uint32_t* const bufs[6], F4* accum, unsigned long long* counters) {
     RestirBufs B = {bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], bufs[5]};
     hipLaunchKernelGGL(k_restir_pass3, dim3(grid_for(f.npl, max_blocks)), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, cam, B, accum, counters);
+}
+// ---- wavefront ReSTIR stages ----
+void launch_trace_occ(hipStream_t st, const DevScene& sc, const RsQ& q, const uint32_t* shcnt) {
+    DevPaths none{};
+#define RTX_LAUNCH_TO(CC) hipLaunchKernelGGL((k_trace_shadow<0, false, CC, 1>), dim3(q.G), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, none, q.sh_o, q.sh_d, (const F4*)nullptr, shcnt, q.rcap, sc.refill_min, sc.trace_sched, (uint32_t*)nullptr, q.sh_pay, q.occ)
+    if (sc.trace_sched == 6u && !sc.nsmall) RTX_LAUNCH_TO(6); else RTX_LAUNCH_TO(-1);
+#undef RTX_LAUNCH_TO
+}
+static inline RestirBufs rs_bufs(uint32_t* const b[6]) { return RestirBufs{b[0], b[1], b[2], b[3], b[4], b[5]}; }
+void launch_rs_raygen(hipStream_t st, const DevFrame& f, const RsQ& q, const CameraGPU* cam, uint32_t sample_id, uint32_t* cnt_out) {
+    hipLaunchKernelGGL(k_rs_raygen, dim3(q.G), dim3(kBlock), 0, st, f, q, cam, sample_id, cnt_out);
+}
+void launch_rs_p1_ris(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, const uint32_t* cnt_in, uint32_t* cnt_out, F4* accum, uint32_t* res_di, uint32_t* res_gi, uint32_t* sdata) {
+    hipLaunchKernelGGL(k_rs_p1_ris, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, cnt_in, cnt_out, accum, res_di, res_gi, sdata);
+}
+void launch_rs_p1_ris_finish(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, const uint32_t* cnt_in, uint32_t* cnt_out, uint32_t* shcnt, uint32_t* res_di, uint32_t* sdata) {
+    hipLaunchKernelGGL(k_rs_p1_ris_finish, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, cnt_in, cnt_out, shcnt, res_di, sdata);
+}
+void launch_rs_p1_first(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, const uint32_t* cnt_in, uint32_t* cnt_out) {
+    hipLaunchKernelGGL(k_rs_p1_first, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, cnt_in, cnt_out);
+}
+void launch_rs_p1_loop(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, uint32_t set, uint32_t iter, const uint32_t* cnt_in, uint32_t* cnt_out) {
+    hipLaunchKernelGGL(k_rs_p1_loop, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, set, iter, cnt_in, cnt_out);
+}
+void launch_rs_p1_emit_final(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, uint32_t* shcnt) {
+    hipLaunchKernelGGL(k_rs_p1_emit_final, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, shcnt);
+}
+void launch_rs_p1_finish(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, F4* accum, uint32_t* res_di, uint32_t* res_gi, uint32_t* sdata) {
+    hipLaunchKernelGGL(k_rs_p1_finish, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, accum, res_di, res_gi, sdata);
+}
+void launch_rs_p2_emit(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, const CameraGPU* cam, uint32_t* const bufs[6], uint32_t* shcnt) {
+    hipLaunchKernelGGL(k_rs_p2_emit, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, cam, rs_bufs(bufs), shcnt);
+}
+void launch_rs_p2_merge(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, const CameraGPU* cam, uint32_t* const bufs[6]) {
+    hipLaunchKernelGGL(k_rs_p2_merge, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, cam, rs_bufs(bufs));
+}
+void launch_rs_p3_select(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, const CameraGPU* cam, uint32_t* const bufs[6], uint32_t* shcnt) {
+    hipLaunchKernelGGL(k_rs_p3_select, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, cam, rs_bufs(bufs), shcnt);
+}
+void launch_rs_p3_merge(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, uint32_t* const bufs[6], uint32_t* shcnt) {
+    hipLaunchKernelGGL(k_rs_p3_merge, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, rs_bufs(bufs), shcnt);
+}
+void launch_rs_p3_shade(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, uint32_t* const bufs[6], F4* accum) {
+    hipLaunchKernelGGL(k_rs_p3_shade, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, rs_bufs(bufs), accum);
 }
 void launch_accumulate(hipStream_t st, uint32_t max_blocks, const DevFrame& f, const DevPaths& p, F4* accum) {
     hipLaunchKernelGGL(k_accumulate, dim3(grid_for(f.npl, max_blocks)), dim3(kBlock), 0, st, f, p, accum);

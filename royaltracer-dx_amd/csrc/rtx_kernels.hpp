@@ -31,6 +31,7 @@ struct DevFrame {
     uint32_t width, height;
     uint32_t tile_size, tile_shift, tiles_x, tiles_y;   // tile_size = 1 << tile_shift
     uint32_t shard_rank, shard_count;
+    uint32_t blk_gx, blk_gy; // RTX_FLAG_BLOCK_TILES: the ranks as a blk_gx x blk_gy grid of tile rectangles (0: tile t -> rank t mod shard_count)
     uint32_t npl;            // local pixel slots = tiles_per_shard * tile_size^2
     uint32_t batch_spp;      // samples in this batch
     uint32_t sample_first;   // sample id of the first one
@@ -38,6 +39,27 @@ struct DevFrame {
     // work distribution: `nblocks` workgroups, each owning a private sub-queue of `qcap` entries
     uint32_t nblocks, qcap, chunks_per_sample;   // chunks_per_sample = npl / 256
 };
+
+// THE rule "k-th tile of a shard -> tile coordinates" (slot_to_pixel on the device, the halo list and the slab sizes on the host).  false: the shard has no such tile
+// (its slot range is padded to the same length for every rank, so that the all-gather of the slabs has equal counts).
+#if defined(__HIPCC__)
+#define RTX_TILE_HD __host__ __device__ __forceinline__
+#else
+#define RTX_TILE_HD inline
+#endif
+RTX_TILE_HD bool shard_tile(const DevFrame& f, uint32_t k, uint32_t& tx, uint32_t& ty) {
+    if (f.blk_gx) {                                                   // rectangle (bx, by) of the block grid: tile columns [bx TX / gx, (bx + 1) TX / gx), rows alike
+        const uint32_t bx = f.shard_rank % f.blk_gx, by = f.shard_rank / f.blk_gx;
+        const uint32_t tx0 = bx * f.tiles_x / f.blk_gx, tx1 = (bx + 1u) * f.tiles_x / f.blk_gx, ty0 = by * f.tiles_y / f.blk_gy, ty1 = (by + 1u) * f.tiles_y / f.blk_gy;
+        const uint32_t bw = (f.tiles_x + f.blk_gx - 1u) / f.blk_gx;   // widest rectangle: the row length of the local tile index
+        tx = tx0 + k % bw; ty = ty0 + k / bw;
+        return tx < tx1 && ty < ty1;
+    }
+    const uint32_t t = f.shard_rank + k * f.shard_count;
+    if (t >= f.tiles_x * f.tiles_y) return false;
+    ty = t / f.tiles_x; tx = t - ty * f.tiles_x;
+    return true;
+}
 
 // per-path state, SoA float4 streams indexed by path slot (pid = s_local * npl + pl)
 struct DevPaths {
@@ -58,6 +80,24 @@ struct DevPaths {
     // bounces after Russian roulette touched one 16-B record per 128-B line), and the trace kernels need no queue read before they can
     // fetch a ray.  rad stays indexed by path id.
     F4* out_o; F4* out_d; F4* out_thr;        // nullptr: state indexed by path id, updated in place
+};
+
+// work area of the wavefront ReSTIR stages (rtx_restir_wave.hpp), device pointers; one pass at a time
+constexpr uint32_t kRsStreams = 7;      // ray_o (origin, seed.y) | ray_d (direction, seed.x) | a0 (normal, material) | a1 (outgoing, item) | a2 | a3 | a4
+constexpr uint32_t kRsOcc = 16;         // occlusion bytes per item (pass 3 uses 10)
+constexpr uint32_t kRsCand = 10;        // pass 3: candidate record, dwords per item
+struct RsQ {
+    uint32_t nitems; const uint32_t* pixels;        // work list of this pass (nullptr: the shard's own slots, slot_to_pixel)
+    uint32_t G, qcap, rcap;                         // workgroups = private sub-queues; path entries / ray entries per sub-queue
+    F4* st[2][kRsStreams];                          // path state by queue position, two sets
+    F4* hit;                                        // closest hit of the entry at that position (current set)
+    uint32_t* cls;                                  // per item: 0 = pass 1 sampled nothing here (miss / light seen directly), else material id + 1
+    F4* fin;                                        // per item: (acc_L, w_sum) when its path ended
+    F4* cold;                                       // per item, 5 streams of nitems: xn | nn | x1s | x2s | (L2, selected)
+    uint8_t* occ;                                   // per item kRsOcc bytes: ray k of the pass was occluded
+    uint32_t* cand;                                 // per item kRsCand dwords (pass 3)
+    F4* sh_o; F4* sh_d; uint32_t* sh_pay;           // any-hit ray queue [G][rcap]: (origin, tmin) (direction, tmax) index of the occlusion byte
+    unsigned long long* rays;                       // primary, extension, shadow (rtx_stats)
 };
 
 size_t trace_lds_bytes(const DevScene& sc);
@@ -84,6 +124,20 @@ void launch_restir_pass2(hipStream_t, uint32_t max_blocks, const DevScene&, cons
 void launch_restir_pack_state(hipStream_t, uint32_t max_blocks, const DevFrame&, uint32_t* const bufs[6], uint32_t* slab);
 void launch_restir_unpack_state(hipStream_t, uint32_t max_blocks, const DevFrame&, uint32_t nshards, const uint32_t* slabs, uint32_t* const bufs[6]);
 void launch_restir_pass3(hipStream_t, uint32_t max_blocks, const DevScene&, const DevFrame&, const CameraGPU* cam, uint32_t* const bufs[6], F4* accum, unsigned long long* counters);
+// ---- the ReSTIR frame as wavefront stages (rtx_restir_wave.hpp); every launch has q.G workgroups unless noted; cnt_* / shcnt: one entry per workgroup ----
+void launch_trace_occ(hipStream_t, const DevScene&, const RsQ&, const uint32_t* shcnt);                  // any-hit rays of the ray queue -> q.occ bytes
+void launch_rs_raygen(hipStream_t, const DevFrame&, const RsQ&, const CameraGPU* cam, uint32_t sample_id, uint32_t* cnt_out);
+void launch_rs_p1_ris(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, const uint32_t* cnt_in, uint32_t* cnt_out, F4* accum, uint32_t* res_di, uint32_t* res_gi, uint32_t* sdata);
+void launch_rs_p1_ris_finish(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, const uint32_t* cnt_in, uint32_t* cnt_out, uint32_t* shcnt, uint32_t* res_di, uint32_t* sdata);
+void launch_rs_p1_first(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, const uint32_t* cnt_in, uint32_t* cnt_out);
+void launch_rs_p1_loop(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, uint32_t set, uint32_t iter, const uint32_t* cnt_in, uint32_t* cnt_out);
+void launch_rs_p1_emit_final(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, uint32_t* shcnt);
+void launch_rs_p1_finish(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, F4* accum, uint32_t* res_di, uint32_t* res_gi, uint32_t* sdata);
+void launch_rs_p2_emit(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, const CameraGPU* cam, uint32_t* const bufs[6], uint32_t* shcnt);
+void launch_rs_p2_merge(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, const CameraGPU* cam, uint32_t* const bufs[6]);
+void launch_rs_p3_select(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, const CameraGPU* cam, uint32_t* const bufs[6], uint32_t* shcnt);
+void launch_rs_p3_merge(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, uint32_t* const bufs[6], uint32_t* shcnt);
+void launch_rs_p3_shade(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, uint32_t* const bufs[6], F4* accum);
 void launch_accumulate(hipStream_t, uint32_t max_blocks, const DevFrame&, const DevPaths&, F4* accum);
 void launch_srgb8(hipStream_t, const F4* accum, uint32_t npix, uint32_t* out);
 void launch_debug_layer(hipStream_t, uint32_t max_blocks, const DevScene&, uint32_t width, uint32_t height, const CameraGPU* cam, uint32_t layer, uint32_t* out);

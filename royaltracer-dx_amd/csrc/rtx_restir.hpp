@@ -95,11 +95,13 @@ __device__ __forceinline__ bool p1_hit(P1Ctx& C, f3 o, f3 d, float tmin, Surf& s
     return sf.mat < C.sc->nmat;
 }
 
-__device__ void sample_ris_dev(P1Ctx& C, uint32_t M1, uint32_t M2, f3 outgoing, Res& rs, const Surf& pay, uint32_t& s0, uint32_t& s1) {
-    const DevScene& sc = *C.sc; const uint32_t flags = C.flags;
-    const MatGPU& m = sc.mats[pay.mat];
-    const uint32_t strategy = select_strategy(m, outgoing, pay.normal, flags, s0, s1);
-    const f3 origin = pay.pos, normal = pay.normal;
+// ---- SampleRIS (Sampler_v6.hlsl:653-736), cut at its ONE ray (the BSDF candidate): ris_front = strategy draw + M1 light candidates + the candidate's direction,
+// ris_back = the candidate's evaluation once its hit is known.  The thread-per-pixel kernel traces in between; the wavefront stages (rtx_restir_wave.hpp)
+// write the ray to a queue and run ris_back in the next stage.  M2 = bsdf_samples_DI = 1 (Common_v6.hlsl:10).
+constexpr uint32_t kRisM2 = 1u;
+__device__ __forceinline__ f3 ris_front(const DevScene& sc, uint32_t flags, uint32_t M1, f3 outgoing, Res& rs, f3 origin, f3 normal, uint32_t mat, uint32_t& s0, uint32_t& s1) {
+    const MatGPU& m = sc.mats[mat];
+    const uint32_t strategy = select_strategy(m, outgoing, normal, flags, s0, s1);
     for (uint32_t i = 0; i < M1 && sc.nlights; i++) {
         const LSample ls = light_point_dev(sc, origin, s0, s1);
         const float cos_x = dot(normal, ls.Ln), cos_y = dot(ls.nl, -ls.Ln);
@@ -110,133 +112,205 @@ __device__ void sample_ris_dev(P1Ctx& C, uint32_t M1, uint32_t M2, f3 outgoing, 
         const float P = safe_mul(pd, q0 * cos_y / ls.dist2) + safe_mul(ps, q1 * cos_y / ls.dist2);
         const float p_hat = length(mk3(ls.em.x * F.x * G * 1.0f, ls.em.y * F.y * G * 1.0f, ls.em.z * F.z * G * 1.0f));
         const float pdf_light = maxf_(kEps, ls.pdf_l);
-        const float mi = pdf_light / ((float)M1 * pdf_light + (float)M2 * P);
+        const float mi = pdf_light / ((float)M1 * pdf_light + (float)kRisM2 * P);
         const float wi = mi * p_hat / pdf_light;
         if (p_hat > 0.0f) res_update_dev(rs, wi, ls.sp, ls.nl, ls.em, s0, s1);
     }
-    for (uint32_t j = 0; j < M2; j++) {
-        float pdf_light = 0.0f, pdf_bsdf = 0.0f, p_hat = 0.0f;
-        f3 em = mk3(0, 0, 0), x2 = mk3(0, 0, 0), n2 = mk3(0, 0, 0);
-        const f3 smp = sample_bsdf(m, strategy, outgoing, normal, s0, s1);
-        Surf h2;
-        C.cnt_ext++;
-        if (p1_hit(C, origin, smp, kSBias, h2)) {
-            const MatGPU& mk = sc.mats[h2.mat];
-            const float Ke = mk.KeFull[0] + mk.KeFull[1] + mk.KeFull[2];
-            em = mk3(mk.KeFull[0], mk.KeFull[1], mk.KeFull[2]); x2 = h2.pos; n2 = h2.normal;
-            if (Ke > kEps && sc.nlights) {
-                const float dist = length(h2.pos - origin), dist2 = dist * dist;
-                const float cos_t = dot(h2.normal, -smp);
-                pdf_light = (Ke / 3.0f) / sc.total_weight;
-                f3 f0, f1; float q0, q1, pd, ps;
-                lobes_dev(m, flags, normal, smp, normalize(outgoing), outgoing, f0, f1, q0, q1, pd, ps);
-                const f3 F = safe_mul(pd, f0) + safe_mul(ps, f1);
-                pdf_bsdf = safe_mul(pd, q0 * cos_t / dist2) + safe_mul(ps, q1 * cos_t / dist2);
-                const float ndot = dot(normal, smp);
-                p_hat = length(mk3(F.x * em.x * ndot * cos_t / dist2, F.y * em.y * ndot * cos_t / dist2, F.z * em.z * ndot * cos_t / dist2));
-            }
+    return sample_bsdf(m, strategy, outgoing, normal, s0, s1);
+}
+// hit: the candidate ray found a surface with a valid material (p1_hit); h2 = that surface
+__device__ __forceinline__ void ris_back(const DevScene& sc, uint32_t flags, uint32_t M1, f3 outgoing, Res& rs, f3 origin, f3 normal, uint32_t mat, f3 smp, bool hit, const Surf& h2,
+                                         uint32_t& s0, uint32_t& s1) {
+    const MatGPU& m = sc.mats[mat];
+    float pdf_light = 0.0f, pdf_bsdf = 0.0f, p_hat = 0.0f;
+    f3 em = mk3(0, 0, 0), x2 = mk3(0, 0, 0), n2 = mk3(0, 0, 0);
+    if (hit) {
+        const MatGPU& mk = sc.mats[h2.mat];
+        const float Ke = mk.KeFull[0] + mk.KeFull[1] + mk.KeFull[2];
+        em = mk3(mk.KeFull[0], mk.KeFull[1], mk.KeFull[2]); x2 = h2.pos; n2 = h2.normal;
+        if (Ke > kEps && sc.nlights) {
+            const float dist = length(h2.pos - origin), dist2 = dist * dist;
+            const float cos_t = dot(h2.normal, -smp);
+            pdf_light = (Ke / 3.0f) / sc.total_weight;
+            f3 f0, f1; float q0, q1, pd, ps;
+            lobes_dev(m, flags, normal, smp, normalize(outgoing), outgoing, f0, f1, q0, q1, pd, ps);
+            const f3 F = safe_mul(pd, f0) + safe_mul(ps, f1);
+            pdf_bsdf = safe_mul(pd, q0 * cos_t / dist2) + safe_mul(ps, q1 * cos_t / dist2);
+            const float ndot = dot(normal, smp);
+            p_hat = length(mk3(F.x * em.x * ndot * cos_t / dist2, F.y * em.y * ndot * cos_t / dist2, F.z * em.z * ndot * cos_t / dist2));
         }
-        const float mi = pdf_bsdf / ((float)M1 * pdf_light + (float)M2 * pdf_bsdf);
-        const float wi = mi * p_hat / pdf_bsdf;
-        if (p_hat > 0.0f) res_update_dev(rs, wi, x2, n2, em, s0, s1);
     }
+    const float mi = pdf_bsdf / ((float)M1 * pdf_light + (float)kRisM2 * pdf_bsdf);
+    const float wi = mi * p_hat / pdf_bsdf;
+    if (p_hat > 0.0f) res_update_dev(rs, wi, x2, n2, em, s0, s1);
     rs.M = 1;
+}
+
+// ---- SamplePathSimple (Path_Sampler_v6.hlsl:3-286), cut at its closest-hit rays.  GiHot = what a path carries from one ray to the next; what a reservoir
+// update SELECTS (the reconnection radiance L2 and, for a light sample, the end points x1s / x2s of the final shadow ray) goes to a caller-supplied sink:
+// local variables in the thread-per-pixel kernel, per-pixel records in HBM in the wavefront stages (selections are rare; the hot state stays small).
+//   gi_first_sample -> ray -> gi_first_hit -> [ gi_front -> ray -> gi_back ] x `bounces` -> final shadow ray (callers)
+struct GiHot { f3 origin, normal, outgoing; uint32_t mat; f3 acc_f, acc_f_rec, acc_L; float acc_pdf, w_sum; };
+__device__ __forceinline__ void gi_begin(GiHot& H, f3 init_point, f3 init_normal, f3 init_outgoing, uint32_t init_mat) {
+    H.acc_f = mk3(1, 1, 1); H.acc_f_rec = mk3(1, 1, 1); H.acc_L = mk3(0, 0, 0); H.acc_pdf = 1.0f; H.w_sum = 0.0f;
+    H.origin = init_point; H.normal = init_normal; H.outgoing = normalize(init_outgoing); H.mat = init_mat;
+}
+__device__ __forceinline__ f3 gi_first_sample(const DevScene& sc, uint32_t flags, const GiHot& H, uint32_t& s0, uint32_t& s1) {      // :37-52
+    const uint32_t st = select_strategy(sc.mats[H.mat], H.outgoing, H.normal, flags, s0, s1);
+    return sample_bsdf(sc.mats[H.mat], st, H.outgoing, H.normal, s0, s1);
+}
+// false: the estimator returns zero here (miss, or the first bounce ends on a light: :53-57)
+__device__ __forceinline__ bool gi_first_hit(const DevScene& sc, uint32_t flags, GiHot& H, f3 smp, bool hit, const Surf& h) {
+    if (!hit) return false;
+    if (sc.mats[h.mat].KeFullLen > 0.0f) return false;
+    const f3 incoming = normalize(-smp);
+    f3 f0, f1; float q0, q1, pd, ps;
+    lobes_dev(sc.mats[H.mat], flags, H.normal, -incoming, H.outgoing, H.outgoing, f0, f1, q0, q1, pd, ps);
+    const f3 F = safe_mul(pd, f0) + safe_mul(ps, f1);
+    const float P = safe_mul(pd, q0) + safe_mul(ps, q1);
+    const float NdotL = dot(H.normal, smp);
+    H.acc_pdf *= P;
+    H.acc_f = mk3(H.acc_f.x * (F.x * NdotL), H.acc_f.y * (F.y * NdotL), H.acc_f.z * (F.z * NdotL));
+    H.outgoing = incoming; H.mat = h.mat; H.normal = h.normal; H.origin = h.pos;
+    return true;
+}
+// the reservoir update of the GI path (UpdateReservoir_GI): the stored point is always (xn, nn) — the first path vertex — so only w_sum and the selection matter
+__device__ __forceinline__ bool gi_update(GiHot& H, float wi, uint32_t& s0, uint32_t& s1) {
+    H.w_sum += wi;
+    return tea_next(s0, s1) < wi / H.w_sum;
+}
+// loop body up to its ray (:111-216): the unused strategy draw, `nee` unshadowed light samples, the BSDF sample.  sel(L2, true, x1s, x2s) on a selected light sample
+template <class Sel>
+__device__ __forceinline__ f3 gi_front(const DevScene& sc, uint32_t flags, uint32_t nee, GiHot& H, uint32_t& s0, uint32_t& s1, Sel&& sel) {
+    (void)select_strategy(sc.mats[H.mat], H.outgoing, H.normal, flags, s0, s1);
+    for (uint32_t j = 0; j < nee; j++) {
+        const LSample ls = light_point_dev(sc, H.origin, s0, s1);
+        float cos_x = fabsf(dot(H.normal, ls.Ln)); if (cos_x < kEps) cos_x = 0.0f;
+        float cos_y = fabsf(dot(ls.nl, -ls.Ln)); if (cos_y < kEps) cos_y = 0.0f;
+        f3 f0, f1; float q0, q1, pd, ps;
+        lobes_dev(sc.mats[H.mat], flags, H.normal, ls.Ln, normalize(H.outgoing), normalize(H.outgoing), f0, f1, q0, q1, pd, ps);
+        const f3 F = safe_mul(pd, f0) + safe_mul(ps, f1);
+        const float pdf_bsdf = safe_mul(pd, q0) + safe_mul(ps, q1);
+        float pdf_light = 1.0f;
+        if (cos_y > 0.0f) pdf_light = maxf_(kEps, ls.pdf_l) * ls.dist2 / cos_y;
+        const float a_pdf = H.acc_pdf * pdf_light;
+        const f3 thr = mk3(F.x * cos_x * 1.0f, F.y * cos_x * 1.0f, F.z * cos_x * 1.0f);
+        const f3 a_l = mk3(H.acc_f.x * thr.x, H.acc_f.y * thr.y, H.acc_f.z * thr.z);
+        const f3 contribution = a_pdf > 0.0f ? mk3(ls.em.x * a_l.x / a_pdf, ls.em.y * a_l.y / a_pdf, ls.em.z * a_l.z / a_pdf) : mk3(0, 0, 0);
+        const float mi = pdf_light / ((float)nee * pdf_light + pdf_bsdf);
+        const f3 E_rec = mk3(H.acc_f_rec.x * mi * ls.em.x * thr.x, H.acc_f_rec.y * mi * ls.em.y * thr.y, H.acc_f_rec.z * mi * ls.em.z * thr.z);
+        const f3 E_path = contribution * mi;
+        float wi = length(E_path);
+        H.acc_L = H.acc_L + E_path;
+        if (is_nan(wi) || is_inf(wi)) wi = 0.0f;
+        if (gi_update(H, wi, s0, s1)) sel(half3_dev(E_rec), true, H.origin + normalize(H.normal) * kSBias, ls.sp);
+    }
+    const uint32_t st = select_strategy(sc.mats[H.mat], H.outgoing, H.normal, flags, s0, s1);
+    return sample_bsdf(sc.mats[H.mat], st, H.outgoing, H.normal, s0, s1);
+}
+// loop body after its ray (:217-269).  false: the path ends here (miss, or a light was reached).  sel(L2, false, -, -) when the light hit is selected
+template <class Sel>
+__device__ __forceinline__ bool gi_back(const DevScene& sc, uint32_t flags, uint32_t nee, GiHot& H, f3 smp, bool hit, const Surf& h, uint32_t& s0, uint32_t& s1, Sel&& sel) {
+    if (!hit) return false;
+    f3 f0, f1; float q0, q1, pd, ps;
+    lobes_dev(sc.mats[H.mat], flags, H.normal, smp, normalize(H.outgoing), H.outgoing, f0, f1, q0, q1, pd, ps);
+    const f3 F = safe_mul(pd, f0) + safe_mul(ps, f1);
+    const float pdf_bsdf = safe_mul(pd, q0) + safe_mul(ps, q1);
+    const float NdotL = dot(H.normal, smp);
+    const MatGPU& mk = sc.mats[h.mat];
+    const f3 thr = mk3(F.x * NdotL, F.y * NdotL, F.z * NdotL);
+    H.acc_pdf *= pdf_bsdf;
+    H.acc_f = mk3(H.acc_f.x * thr.x, H.acc_f.y * thr.y, H.acc_f.z * thr.z);
+    H.acc_f_rec = mk3(H.acc_f_rec.x * thr.x, H.acc_f_rec.y * thr.y, H.acc_f_rec.z * thr.z);
+    // outgoing = -sample (Path_Sampler_v6.hlsl:263-269).  Assigned HERE, after its last use of this iteration, not with origin / mat / normal at the end: in the
+    // one-function form of round 1, placed there, hipcc (ROCm 7.2, gfx950) dropped the update on the path "light hit whose contribution is zero, fall through" and
+    // the next iteration sampled with the stale direction (found by the ReSTIR fuzz: ray counts off by one in 3 % of random scenes while every buffer stayed
+    // byte-identical, because such paths carry zero weight).
+    H.outgoing = -smp;
+    if (mk.Ke_len > 0.0f) {
+        const float dist = length(h.pos - H.origin), dist2 = dist * dist;
+        const float cos_t = dot(h.normal, -smp);
+        const float pdf_light = sc.nlights ? (((mk.Ke[0] + mk.Ke[1] + mk.Ke[2]) / 3.0f) / sc.total_weight) * dist2 / cos_t : 0.0f;
+        const f3 contribution = mk3(mk.Ke[0] * H.acc_f.x / H.acc_pdf, mk.Ke[1] * H.acc_f.y / H.acc_pdf, mk.Ke[2] * H.acc_f.z / H.acc_pdf);
+        if (length(contribution) > 0.0f) {
+            const float mi = pdf_bsdf / ((float)nee * pdf_light + pdf_bsdf);
+            const f3 E_rec = mk3(H.acc_f_rec.x * mi * mk.Ke[0], H.acc_f_rec.y * mi * mk.Ke[1], H.acc_f_rec.z * mi * mk.Ke[2]);
+            const f3 E_path = contribution * mi;
+            float wi = length(E_path);
+            H.acc_L = H.acc_L + E_path;
+            if (is_nan(wi) || is_inf(wi)) wi = 0.0f;
+            if (gi_update(H, wi, s0, s1)) sel(half3_dev(E_rec), false, mk3(0, 0, 0), mk3(0, 0, 0));
+            return false;
+        }
+    }
+    H.origin = h.pos; H.mat = h.mat; H.normal = h.normal;
+    return true;
+}
+// the final shadow ray of the selected reconnection (:271-283): cast iff nee > 0 and the end points differ
+__device__ __forceinline__ bool gi_final_ray(uint32_t nee, f3 x1s, f3 x2s, F4& so, F4& sd) {
+    if (!(nee > 0 && length(x2s - x1s) > kEps)) return false;
+    const f3 dv = x2s - x1s, dn = normalize(dv);
+    so = {x1s.x, x1s.y, x1s.z, 0.5f * kSBias};
+    sd = {dn.x, dn.y, dn.z, maxf_(kSBias, length(dv) - kSBias * 5.0f)};
+    return true;
+}
+// pass1:150-186 after the path sampler: the GI reservoir's W at the primary hit; rgi = (x2, n2, L2, w_sum) on entry
+__device__ __forceinline__ void gi_finish(const MatGPU& m, uint32_t flags, f3 x1, f3 n1, f3 ov, Res& rgi) {
+    const f3 dg = rgi.x2 - x1;
+    const float cos1 = fabsf(dot(n1, normalize(dg)));
+    f3 f0, f1; float q0, q1, pd, ps;
+    lobes_dev(m, flags, n1, normalize(dg), normalize(ov), normalize(ov), f0, f1, q0, q1, pd, ps);
+    const f3 Fx = safe_mul(pd, f0) + safe_mul(ps, f1);
+    f3 fr = mk3(Fx.x * cos1 * rgi.L2.x, Fx.y * cos1 * rgi.L2.y, Fx.z * cos1 * rgi.L2.z);
+    if (!finite3(fr)) fr = mk3(0, 0, 0);
+    const float fc = length(fr);
+    rgi.W = fc > kEps ? rgi.w_sum / fc : 0.0f;
+    rgi.M = 1;
+}
+// the visibility ray of GetP_Hat / VisibilityCheck (Sampler_v6.hlsl:86-104): from x1 (lifted by s_bias along n1) towards x2
+__device__ __forceinline__ void vis_ray(f3 x1, f3 n1, f3 x2, F4& so, F4& sd) {
+    const f3 dv = x2 - x1, o = x1 + normalize(n1) * kSBias, dn = normalize(dv);
+    so = {o.x, o.y, o.z, 0.0f};
+    sd = {dn.x, dn.y, dn.z, maxf_(length(dv) - 10.0f * kSBias, 2.0f * kSBias)};
+}
+
+__device__ void sample_ris_dev(P1Ctx& C, uint32_t M1, f3 outgoing, Res& rs, const Surf& pay, uint32_t& s0, uint32_t& s1) {
+    const f3 smp = ris_front(*C.sc, C.flags, M1, outgoing, rs, pay.pos, pay.normal, pay.mat, s0, s1);
+    Surf h2;
+    C.cnt_ext++;
+    const bool hit = p1_hit(C, pay.pos, smp, kSBias, h2);
+    ris_back(*C.sc, C.flags, M1, outgoing, rs, pay.pos, pay.normal, pay.mat, smp, hit, h2, s0, s1);
 }
 
 __device__ f3 sample_path_simple_dev(P1Ctx& C, const DevFrame& f, Res& rs, f3 init_point, f3 init_normal, f3 init_outgoing, uint32_t init_mat, uint32_t& s0, uint32_t& s1) {
     const DevScene& sc = *C.sc; const uint32_t flags = C.flags;
     const uint32_t nee = sc.nlights ? f.nee_samples : 0u;
-    f3 acc_f = mk3(1, 1, 1), acc_f_rec = mk3(1, 1, 1), acc_L = mk3(0, 0, 0);
-    float acc_pdf = 1.0f;
+    GiHot H; gi_begin(H, init_point, init_normal, init_outgoing, init_mat);
+    H.w_sum = rs.w_sum;
     f3 x1s = mk3(0, 0, 0), x2s = mk3(0, 0, 0);
-    f3 origin = init_point, normal = init_normal, outgoing = normalize(init_outgoing);
-    uint32_t mat = init_mat;
     {
-        const uint32_t st = select_strategy(sc.mats[mat], outgoing, normal, flags, s0, s1);
-        const f3 smp = sample_bsdf(sc.mats[mat], st, outgoing, normal, s0, s1);
+        const f3 smp = gi_first_sample(sc, flags, H, s0, s1);
         Surf h;
         C.cnt_ext++;
-        if (!p1_hit(C, origin, smp, kSBias, h)) return mk3(0, 0, 0);
-        if (sc.mats[h.mat].KeFullLen > 0.0f) return mk3(0, 0, 0);
-        const f3 incoming = normalize(-smp);
-        f3 f0, f1; float q0, q1, pd, ps;
-        lobes_dev(sc.mats[mat], flags, normal, -incoming, outgoing, outgoing, f0, f1, q0, q1, pd, ps);
-        const f3 F = safe_mul(pd, f0) + safe_mul(ps, f1);
-        const float P = safe_mul(pd, q0) + safe_mul(ps, q1);
-        const float NdotL = dot(normal, smp);
-        acc_pdf *= P;
-        acc_f = mk3(acc_f.x * (F.x * NdotL), acc_f.y * (F.y * NdotL), acc_f.z * (F.z * NdotL));
-        outgoing = incoming; mat = h.mat; normal = h.normal; origin = h.pos;
+        const bool hit = p1_hit(C, H.origin, smp, kSBias, h);
+        if (!gi_first_hit(sc, flags, H, smp, hit, h)) return mk3(0, 0, 0);
     }
-    const f3 xn = origin, nn = normalize(normal);
+    const f3 xn = H.origin, nn = normalize(H.normal);
+    auto sel = [&](f3 L2h, bool light, f3 a, f3 b) { rs.x2 = xn; rs.n2 = normalize(nn); rs.L2 = L2h; if (light) { x1s = a; x2s = b; } };
     for (uint32_t i = 0; i < f.max_bounces; i++) {
-        (void)select_strategy(sc.mats[mat], outgoing, normal, flags, s0, s1);
-        for (uint32_t j = 0; j < nee; j++) {
-            const LSample ls = light_point_dev(sc, origin, s0, s1);
-            float cos_x = fabsf(dot(normal, ls.Ln)); if (cos_x < kEps) cos_x = 0.0f;
-            float cos_y = fabsf(dot(ls.nl, -ls.Ln)); if (cos_y < kEps) cos_y = 0.0f;
-            f3 f0, f1; float q0, q1, pd, ps;
-            lobes_dev(sc.mats[mat], flags, normal, ls.Ln, normalize(outgoing), normalize(outgoing), f0, f1, q0, q1, pd, ps);
-            const f3 F = safe_mul(pd, f0) + safe_mul(ps, f1);
-            const float pdf_bsdf = safe_mul(pd, q0) + safe_mul(ps, q1);
-            float pdf_light = 1.0f;
-            if (cos_y > 0.0f) pdf_light = maxf_(kEps, ls.pdf_l) * ls.dist2 / cos_y;
-            const float a_pdf = acc_pdf * pdf_light;
-            const f3 thr = mk3(F.x * cos_x * 1.0f, F.y * cos_x * 1.0f, F.z * cos_x * 1.0f);
-            const f3 a_l = mk3(acc_f.x * thr.x, acc_f.y * thr.y, acc_f.z * thr.z);
-            const f3 contribution = a_pdf > 0.0f ? mk3(ls.em.x * a_l.x / a_pdf, ls.em.y * a_l.y / a_pdf, ls.em.z * a_l.z / a_pdf) : mk3(0, 0, 0);
-            const float mi = pdf_light / ((float)nee * pdf_light + pdf_bsdf);
-            const f3 E_rec = mk3(acc_f_rec.x * mi * ls.em.x * thr.x, acc_f_rec.y * mi * ls.em.y * thr.y, acc_f_rec.z * mi * ls.em.z * thr.z);
-            const f3 E_path = contribution * mi;
-            float wi = length(E_path);
-            acc_L = acc_L + E_path;
-            if (is_nan(wi) || is_inf(wi)) wi = 0.0f;
-            if (res_update_dev(rs, wi, xn, normalize(nn), E_rec, s0, s1)) { x1s = origin + normalize(normal) * kSBias; x2s = ls.sp; }
-        }
-        const uint32_t st = select_strategy(sc.mats[mat], outgoing, normal, flags, s0, s1);
-        const f3 smp = sample_bsdf(sc.mats[mat], st, outgoing, normal, s0, s1);
+        const f3 smp = gi_front(sc, flags, nee, H, s0, s1, sel);
         Surf h;
         C.cnt_ext++;
-        if (!p1_hit(C, origin, smp, kSBias, h)) break;
-        f3 f0, f1; float q0, q1, pd, ps;
-        lobes_dev(sc.mats[mat], flags, normal, smp, normalize(outgoing), outgoing, f0, f1, q0, q1, pd, ps);
-        const f3 F = safe_mul(pd, f0) + safe_mul(ps, f1);
-        const float pdf_bsdf = safe_mul(pd, q0) + safe_mul(ps, q1);
-        const float NdotL = dot(normal, smp);
-        const MatGPU& mk = sc.mats[h.mat];
-        const f3 thr = mk3(F.x * NdotL, F.y * NdotL, F.z * NdotL);
-        acc_pdf *= pdf_bsdf;
-        acc_f = mk3(acc_f.x * thr.x, acc_f.y * thr.y, acc_f.z * thr.z);
-        acc_f_rec = mk3(acc_f_rec.x * thr.x, acc_f_rec.y * thr.y, acc_f_rec.z * thr.z);
-        // outgoing = -sample (Path_Sampler_v6.hlsl:263-269).  Assigned HERE, after its last use of this iteration, not with origin / mat /
-        // normal at the loop's end: placed there, hipcc (ROCm 7.2, gfx950) dropped the update on the path "light hit whose contribution is
-        // zero, fall through" and the next iteration sampled with the stale direction (found by the ReSTIR fuzz: ray counts off by one in
-        // 3 % of random scenes while every buffer stayed byte-identical, because such paths carry zero weight).
-        outgoing = -smp;
-        if (mk.Ke_len > 0.0f) {
-            const float dist = length(h.pos - origin), dist2 = dist * dist;
-            const float cos_t = dot(h.normal, -smp);
-            const float pdf_light = sc.nlights ? (((mk.Ke[0] + mk.Ke[1] + mk.Ke[2]) / 3.0f) / sc.total_weight) * dist2 / cos_t : 0.0f;
-            const f3 contribution = mk3(mk.Ke[0] * acc_f.x / acc_pdf, mk.Ke[1] * acc_f.y / acc_pdf, mk.Ke[2] * acc_f.z / acc_pdf);
-            if (length(contribution) > 0.0f) {
-                const float mi = pdf_bsdf / ((float)nee * pdf_light + pdf_bsdf);
-                const f3 E_rec = mk3(acc_f_rec.x * mi * mk.Ke[0], acc_f_rec.y * mi * mk.Ke[1], acc_f_rec.z * mi * mk.Ke[2]);
-                const f3 E_path = contribution * mi;
-                float wi = length(E_path);
-                acc_L = acc_L + E_path;
-                if (is_nan(wi) || is_inf(wi)) wi = 0.0f;
-                res_update_dev(rs, wi, xn, normalize(nn), E_rec, s0, s1);
-                break;
-            }
-        }
-        origin = h.pos; mat = h.mat; normal = h.normal;
+        const bool hit = p1_hit(C, H.origin, smp, kSBias, h);
+        if (!gi_back(sc, flags, nee, H, smp, hit, h, s0, s1, sel)) break;
     }
-    if (nee > 0 && length(x2s - x1s) > kEps) {
-        const f3 dv = x2s - x1s;
-        if (p1_any(C, x1s, normalize(dv), 0.5f * kSBias, maxf_(kSBias, length(dv) - kSBias * 5.0f))) rs.w_sum *= 0.0f;
+    rs.w_sum = H.w_sum;
+    F4 so, sd;
+    if (gi_final_ray(nee, x1s, x2s, so, sd)) {
+        if (p1_any(C, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w)) rs.w_sum *= 0.0f;
         else rs.w_sum *= 1.0f;
     }
-    return acc_L;
+    return H.acc_L;
 }
 
 __device__ __forceinline__ uint32_t map_pixel_id(uint32_t w, uint32_t x, uint32_t y) {    // Common_v6.hlsl:173-198
@@ -287,7 +361,7 @@ __global__ __launch_bounds__(kBlock) void k_v6_pass1(DevScene sc, const SmallRec
             L1 = mk3(m.Ke[0], m.Ke[1], m.Ke[2]);
             if (!(m.KeFullLen > 0.0f)) {                                                         // performSampling, pass1:102-106
                 const f3 outgoing = -dir;
-                sample_ris_dev(C, sc.nlights ? f.nee_samples : 0u, 1u, outgoing, rdi, pay, s0, s1);
+                sample_ris_dev(C, sc.nlights ? f.nee_samples : 0u, outgoing, rdi, pay, s0, s1);
                 x1 = pay.pos; n1 = normalize(pay.normal); ov = outgoing;
                 const float f_g = length(reconnect_di_dev(m, f.flags, x1, n1, rdi.x2, rdi.n2, rdi.L2, ov));
                 const f3 dv = rdi.x2 - x1;
@@ -297,18 +371,7 @@ __global__ __launch_bounds__(kBlock) void k_v6_pass1(DevScene sc, const SmallRec
                 debug = sample_path_simple_dev(C, f, rgi, pay.pos, pay.normal, outgoing, mID, s0, s1);
                 const f3 rc = reconnect_di_dev(m, f.flags, x1, n1, rdi.x2, rdi.n2, rdi.L2, ov);
                 debug = debug + rc * rdi.W;
-                {
-                    const f3 dg = rgi.x2 - x1;
-                    const float cos1 = fabsf(dot(n1, normalize(dg)));
-                    f3 f0, f1; float q0, q1, pd, ps;
-                    lobes_dev(m, f.flags, n1, normalize(dg), normalize(ov), normalize(ov), f0, f1, q0, q1, pd, ps);
-                    const f3 Fx = safe_mul(pd, f0) + safe_mul(ps, f1);
-                    f3 fr = mk3(Fx.x * cos1 * rgi.L2.x, Fx.y * cos1 * rgi.L2.y, Fx.z * cos1 * rgi.L2.z);
-                    if (!finite3(fr)) fr = mk3(0, 0, 0);
-                    const float fc = length(fr);
-                    rgi.W = fc > kEps ? rgi.w_sum / fc : 0.0f;
-                    rgi.M = 1;
-                }
+                gi_finish(m, f.flags, x1, n1, ov, rgi);
                 out = debug;
             } else out = L1;
         }
@@ -355,24 +418,36 @@ __device__ __forceinline__ SData load_sd_dev(const uint32_t* d) {
 __device__ __forceinline__ SData zero_sd() { SData s; s.x1 = mk3(0, 0, 0); s.mID = 0; s.L1 = mk3(0, 0, 0); s.n1 = mk3(0, 0, 0); s.o = mk3(0, 0, 0); s.objID = 0; return s; }
 __device__ __forceinline__ float minf_u(float cap, uint32_t m) { return (float)(m < (uint32_t)cap ? m : (uint32_t)cap); }
 
-__device__ __forceinline__ float get_p_hat_dev(P1Ctx& C, const MatGPU& m, f3 x1, f3 n1, f3 x2, f3 n2, f3 L2, f3 o, bool vis) {
-    const float f_g = length(reconnect_di_dev(m, C.flags, x1, n1, x2, n2, L2, o));
+// GetP_Hat / GetP_Hat_GI (Sampler_v6.hlsl:163-171, MIS_GI_v6.hlsl) with the visibility term behind a functor: vis(k, x1, n1, x2) -> 1.0f (visible) or 0.0f, k = the
+// number of this ray among the pixel's rays of the pass (k < 0: no visibility term).  The thread-per-pixel kernels trace inside the functor (VisTrace); the
+// wavefront stages trace all rays of a pass in one persistent launch beforehand and look the answer up (rtx_restir_wave.hpp: VisLookup).
+template <class V>
+__device__ __forceinline__ float p_hat_di(uint32_t flags, const MatGPU& m, f3 x1, f3 n1, f3 x2, f3 n2, f3 L2, f3 o, int k, V&& vis) {
+    const float f_g = length(reconnect_di_dev(m, flags, x1, n1, x2, n2, L2, o));
     float v = 1.0f;
-    if (vis) { const f3 dv = x2 - x1; v = p1_any(C, x1 + normalize(n1) * kSBias, normalize(dv), 0.0f, maxf_(length(dv) - 10.0f * kSBias, 2.0f * kSBias)) ? 0.0f : 1.0f; }
+    if (k >= 0) v = vis(k, x1, n1, x2);
     return f_g * v;
 }
-__device__ __forceinline__ f3 get_p_hat_gi_dev(P1Ctx& C, const MatGPU& m, f3 x1, f3 n1, f3 x2, f3 L, f3 o, bool vis) {
+template <class V>
+__device__ __forceinline__ f3 p_hat_gi(uint32_t flags, const MatGPU& m, f3 x1, f3 n1, f3 x2, f3 L, f3 o, int k, V&& vis) {
     const f3 dir = x2 - x1;
     const float cos1 = fabsf(dot(n1, normalize(dir)));
     f3 f0, f1; float q0, q1, pd, ps;
-    lobes_dev(m, C.flags, n1, normalize(dir), normalize(o), normalize(o), f0, f1, q0, q1, pd, ps);
+    lobes_dev(m, flags, n1, normalize(dir), normalize(o), normalize(o), f0, f1, q0, q1, pd, ps);
     const f3 Fx = safe_mul(pd, f0) + safe_mul(ps, f1);
     f3 fr = mk3(Fx.x * cos1 * L.x, Fx.y * cos1 * L.y, Fx.z * cos1 * L.z);
     if (!finite3(fr)) fr = mk3(0, 0, 0);
     float v = 1.0f;
-    if (vis) v = p1_any(C, x1 + normalize(n1) * kSBias, normalize(dir), 0.0f, maxf_(length(dir) - 10.0f * kSBias, 2.0f * kSBias)) ? 0.0f : 1.0f;
+    if (k >= 0) v = vis(k, x1, n1, x2);
     return fr * v;
 }
+struct VisTrace {            // the literal form: one any-hit traversal per call, inside the pixel's thread
+    P1Ctx& C;
+    __device__ __forceinline__ float operator()(int, f3 x1, f3 n1, f3 x2) const {
+        F4 so, sd; vis_ray(x1, n1, x2, so, sd);
+        return p1_any(C, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w) ? 0.0f : 1.0f;
+    }
+};
 __device__ __forceinline__ float get_w_dev(float w_sum, float p_hat) { return p_hat > kEps ? w_sum / p_hat : 0.0f; }
 __device__ __forceinline__ float jacobian_dev(const SData& r, const SData& q, f3 x2q, f3 n2q) {
     const f3 vq = x2q - q.x1, vr = x2q - r.x1;
@@ -406,6 +481,73 @@ __device__ __forceinline__ void random_pixel_dev(uint32_t radius, uint32_t w, ui
 
 struct RestirBufs { uint32_t *cur_di, *cur_gi, *cur_sd, *last_di, *last_gi, *last_sd; };
 
+// ---- pass 2 (RayGen_v6_pass2.hlsl:46-204) in two parts: what the pixel reads and whether it merges at all (p2_gather), then the two pairwise-MIS merges (p2_merge).
+// Its visibility rays: k = 0 DI (x1 -> last frame's x2), k = 1 GI (x1 -> last frame's GI x2); each is cast iff the merge it belongs to runs.
+struct P2Pix { size_t slot; Res rc, gc, rl, gl; SData sd; bool acc_di, acc_gi; };
+__device__ __forceinline__ bool p2_gather(const DevScene& sc, const DevFrame& f, const CameraGPU& cam, const RestirBufs& B, uint32_t x, uint32_t y, P2Pix& I) {
+    I.slot = map_pixel_id(f.width, x, y);
+    I.sd = load_sd_dev(B.cur_sd + I.slot * 15);
+    const SData& sd = I.sd;
+    if (!(sd.L1.x == 0.0f && sd.L1.y == 0.0f && sd.L1.z == 0.0f) || sd.mID == 0xFFFEu || sd.mID >= sc.nmat) return false;
+    I.rc = load_res_dev(B.cur_di + I.slot * 10); I.gc = load_res_dev(B.cur_gi + I.slot * 10);
+    const f3 camo = mk3(cam.viewI[12], cam.viewI[13], cam.viewI[14]);
+    int px, py;
+    {   // GetBestReprojectedPixel_d, Sampler_v6.hlsl:738-785
+        float w0, w1, w2, w3;
+        const InstGPU& in = sc.insts[sd.objID < sc.ninst ? sd.objID : 0u];
+        const f3 lp = mul44_dev(in.o2w_inv, sd.x1, 1.0f, w0);
+        const f3 pw = mul44_dev(in.prev_o2w, lp, w0, w1);
+        const f3 vp = mul44_dev(cam.prev_view, pw, w1, w2);
+        const f3 cp = mul44_dev(cam.prev_proj, vp, w2, w3);
+        if (w3 <= 0.0f) { px = -1; py = -1; }
+        else { const float ux = (cp.x / w3) * 0.5f + 0.5f; float uy = (cp.y / w3) * 0.5f + 0.5f; uy = 1.0f - uy; px = (int)rintf(ux * (float)f.width); py = (int)rintf(uy * (float)f.height); }
+    }
+    const bool inside = px >= 0 && py >= 0 && px < (int)f.width && py < (int)f.height;
+    const size_t ts = inside ? map_pixel_id(f.width, (uint32_t)px, (uint32_t)py) : 0;
+    I.rl = inside ? load_res_dev(B.last_di + ts * 10) : zero_res(); I.gl = inside ? load_res_dev(B.last_gi + ts * 10) : zero_res();
+    const SData sl = inside ? load_sd_dev(B.last_sd + ts * 15) : zero_sd();
+    const bool base_ok = (px != -1 && py != -1) && length(sl.L1) == 0.0f && !reject_distance_dev(sd.x1, sl.x1, camo, 0.1f) && sl.mID == sd.mID;
+    I.acc_di = base_ok && valid_res_dev(I.rl) && (I.rl.x2.x != 0.0f && I.rl.x2.y != 0.0f && I.rl.x2.z != 0.0f);
+    I.acc_gi = base_ok && !(I.gl.w_sum > 5.0f) && valid_res_gi_dev(I.gl);
+    return true;
+}
+template <class V>
+__device__ __forceinline__ void p2_merge(const DevScene& sc, const DevFrame& f, const RestirBufs& B, uint32_t x, uint32_t y, P2Pix& I, V&& vis) {
+    Res &rc = I.rc, &gc = I.gc; const Res &rl = I.rl, &gl = I.gl; const SData& sd = I.sd;
+    const uint32_t flags = f.flags;
+    uint32_t s0, s1; seed_init(x, y, 2u, f.frame_seed, s0, s1);
+    const MatGPU& m = sc.mats[sd.mID];
+    if (I.acc_di) {
+        const float mc = minf_u(16.0f, rc.M), ml = minf_u(16.0f, rl.M), M_sum = mc + ml;
+        float mi_c = mc / M_sum;
+        { const float m_num = mc, m_den = m_num + (M_sum - mc); if (m_den > 0.0f) mi_c += (ml / M_sum) * (m_num / m_den); }
+        float mi_t;
+        { const float m_num = M_sum - mc, m_den = m_num + mc; mi_t = m_den > 0.0f ? (ml / M_sum) * m_num / m_den : 0.0f; }
+        if (length(rl.n2) == 0.0f) { mi_c = 1.0f; mi_t = 0.0f; }
+        const float w_c = mi_c * p_hat_di(flags, m, sd.x1, sd.n1, rc.x2, rc.n2, rc.L2, sd.o, -1, vis) * rc.W;
+        const float w_t = mi_t * p_hat_di(flags, m, sd.x1, sd.n1, rl.x2, rl.n2, rl.L2, sd.o, 0, vis) * rl.W;
+        rc.M = (uint32_t)mc; rc.w_sum = w_c;
+        rc.w_sum += w_t; rc.M = (rc.M + (uint32_t)ml) & 0xFFFFu;
+        if (tea_next(s0, s1) < w_t / rc.w_sum) { rc.x2 = rl.x2; rc.n2 = rl.n2; rc.L2 = rl.L2; }
+        const float p_hat = p_hat_di(flags, m, sd.x1, sd.n1, rc.x2, rc.n2, rc.L2, sd.o, -1, vis);
+        rc.W = get_w_dev(rc.w_sum, p_hat);
+    }
+    if (I.acc_gi) {
+        const float mc = minf_u(16.0f, gc.M), ml = minf_u(16.0f, gl.M), M_sum = mc + ml;
+        float mi_c = mc / M_sum;
+        { const float m_num = mc, m_den = m_num + (M_sum - mc); if (m_den > 0.0f) mi_c += (ml / M_sum) * (m_num / m_den); }
+        float mi_t;
+        { const float m_num = M_sum - mc, m_den = m_num + mc; mi_t = m_den > 0.0f ? (ml / M_sum) * m_num / m_den : 0.0f; }
+        const float w_c = mi_c * length(p_hat_gi(flags, m, sd.x1, sd.n1, gc.x2, gc.L2, sd.o, -1, vis)) * gc.W;
+        const float w_t = mi_t * length(p_hat_gi(flags, m, sd.x1, sd.n1, gl.x2, gl.L2, sd.o, 1, vis)) * gl.W;
+        gc.M = (uint32_t)mc; gc.w_sum = w_c;
+        gc.w_sum += w_t; gc.M = (gc.M + (uint32_t)ml) & 0xFFFFu;
+        if (tea_next(s0, s1) < w_t / gc.w_sum) { gc.x2 = gl.x2; gc.n2 = gl.n2; gc.L2 = gl.L2; }
+        gc.W = get_w_dev(gc.w_sum, length(p_hat_gi(flags, m, sd.x1, sd.n1, gc.x2, gc.L2, sd.o, -1, vis)));
+    }
+    store_res(B.cur_di + I.slot * 10, rc); store_res(B.cur_gi + I.slot * 10, gc);
+}
+
 __global__ __launch_bounds__(kBlock) void k_restir_pass2(DevScene sc, const SmallRecPair* __restrict__ small, DevFrame f, const CameraGPU* __restrict__ cam_p, RestirBufs B,
                                                          unsigned long long* __restrict__ counters, const uint32_t* __restrict__ pixels = nullptr, uint32_t npixels = 0) {
     extern __shared__ F4 lds[];
@@ -419,64 +561,112 @@ __global__ __launch_bounds__(kBlock) void k_restir_pass2(DevScene sc, const Smal
     for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < nitems; pl += stride) {
         uint32_t x, y;
         if (!pass_pixel(f, pixels, pl, x, y)) continue;
-        const size_t slot = map_pixel_id(f.width, x, y);
-        Res rc = load_res_dev(B.cur_di + slot * 10), gc = load_res_dev(B.cur_gi + slot * 10);
-        const SData sd = load_sd_dev(B.cur_sd + slot * 15);
-        if (!(sd.L1.x == 0.0f && sd.L1.y == 0.0f && sd.L1.z == 0.0f) || sd.mID == 0xFFFEu || sd.mID >= sc.nmat) continue;
+        P2Pix I;
+        if (!p2_gather(sc, f, cam, B, x, y, I)) continue;
         P1Ctx C; C.sc = &sc; C.small = small; C.L = &L; C.flags = f.flags; C.cnt_ext = 0; C.cnt_sh = 0;
-        const f3 camo = mk3(cam.viewI[12], cam.viewI[13], cam.viewI[14]);
-        uint32_t s0, s1; seed_init(x, y, 2u, f.frame_seed, s0, s1);
-        int px, py;
-        {   // GetBestReprojectedPixel_d, Sampler_v6.hlsl:738-785
-            float w0, w1, w2, w3;
-            const InstGPU& in = sc.insts[sd.objID < sc.ninst ? sd.objID : 0u];
-            const f3 lp = mul44_dev(in.o2w_inv, sd.x1, 1.0f, w0);
-            const f3 pw = mul44_dev(in.prev_o2w, lp, w0, w1);
-            const f3 vp = mul44_dev(cam.prev_view, pw, w1, w2);
-            const f3 cp = mul44_dev(cam.prev_proj, vp, w2, w3);
-            if (w3 <= 0.0f) { px = -1; py = -1; }
-            else { const float ux = (cp.x / w3) * 0.5f + 0.5f; float uy = (cp.y / w3) * 0.5f + 0.5f; uy = 1.0f - uy; px = (int)rintf(ux * (float)f.width); py = (int)rintf(uy * (float)f.height); }
-        }
-        const bool inside = px >= 0 && py >= 0 && px < (int)f.width && py < (int)f.height;
-        const size_t ts = inside ? map_pixel_id(f.width, (uint32_t)px, (uint32_t)py) : 0;
-        const Res rl = inside ? load_res_dev(B.last_di + ts * 10) : zero_res(), gl = inside ? load_res_dev(B.last_gi + ts * 10) : zero_res();
-        const SData sl = inside ? load_sd_dev(B.last_sd + ts * 15) : zero_sd();
-        const bool base_ok = (px != -1 && py != -1) && length(sl.L1) == 0.0f && !reject_distance_dev(sd.x1, sl.x1, camo, 0.1f) && sl.mID == sd.mID;
-        const bool acc_di = base_ok && valid_res_dev(rl) && (rl.x2.x != 0.0f && rl.x2.y != 0.0f && rl.x2.z != 0.0f);
-        const bool acc_gi = base_ok && !(gl.w_sum > 5.0f) && valid_res_gi_dev(gl);
-        const MatGPU& m = sc.mats[sd.mID];
-        if (acc_di) {
-            const float mc = minf_u(16.0f, rc.M), ml = minf_u(16.0f, rl.M), M_sum = mc + ml;
-            float mi_c = mc / M_sum;
-            { const float m_num = mc, m_den = m_num + (M_sum - mc); if (m_den > 0.0f) mi_c += (ml / M_sum) * (m_num / m_den); }
-            float mi_t;
-            { const float m_num = M_sum - mc, m_den = m_num + mc; mi_t = m_den > 0.0f ? (ml / M_sum) * m_num / m_den : 0.0f; }
-            if (length(rl.n2) == 0.0f) { mi_c = 1.0f; mi_t = 0.0f; }
-            const float w_c = mi_c * get_p_hat_dev(C, m, sd.x1, sd.n1, rc.x2, rc.n2, rc.L2, sd.o, false) * rc.W;
-            const float w_t = mi_t * get_p_hat_dev(C, m, sd.x1, sd.n1, rl.x2, rl.n2, rl.L2, sd.o, true) * rl.W;
-            rc.M = (uint32_t)mc; rc.w_sum = w_c;
-            rc.w_sum += w_t; rc.M = (rc.M + (uint32_t)ml) & 0xFFFFu;
-            if (tea_next(s0, s1) < w_t / rc.w_sum) { rc.x2 = rl.x2; rc.n2 = rl.n2; rc.L2 = rl.L2; }
-            const float p_hat = get_p_hat_dev(C, m, sd.x1, sd.n1, rc.x2, rc.n2, rc.L2, sd.o, false);
-            rc.W = get_w_dev(rc.w_sum, p_hat);
-        }
-        if (acc_gi) {
-            const float mc = minf_u(16.0f, gc.M), ml = minf_u(16.0f, gl.M), M_sum = mc + ml;
-            float mi_c = mc / M_sum;
-            { const float m_num = mc, m_den = m_num + (M_sum - mc); if (m_den > 0.0f) mi_c += (ml / M_sum) * (m_num / m_den); }
-            float mi_t;
-            { const float m_num = M_sum - mc, m_den = m_num + mc; mi_t = m_den > 0.0f ? (ml / M_sum) * m_num / m_den : 0.0f; }
-            const float w_c = mi_c * length(get_p_hat_gi_dev(C, m, sd.x1, sd.n1, gc.x2, gc.L2, sd.o, false)) * gc.W;
-            const float w_t = mi_t * length(get_p_hat_gi_dev(C, m, sd.x1, sd.n1, gl.x2, gl.L2, sd.o, true)) * gl.W;
-            gc.M = (uint32_t)mc; gc.w_sum = w_c;
-            gc.w_sum += w_t; gc.M = (gc.M + (uint32_t)ml) & 0xFFFFu;
-            if (tea_next(s0, s1) < w_t / gc.w_sum) { gc.x2 = gl.x2; gc.n2 = gl.n2; gc.L2 = gl.L2; }
-            gc.W = get_w_dev(gc.w_sum, length(get_p_hat_gi_dev(C, m, sd.x1, sd.n1, gc.x2, gc.L2, sd.o, false)));
-        }
-        store_res(B.cur_di + slot * 10, rc); store_res(B.cur_gi + slot * 10, gc);
+        p2_merge(sc, f, B, x, y, I, VisTrace{C});
         n_sh += C.cnt_sh;
     }
     atomicAdd(&counters[2], (unsigned long long)n_sh);
+}
+
+// ---- pass 3 (RayGen_v6_pass3.hlsl:46-441) in three parts: the neighbour search (p3_select: all the random numbers but the merges' own), the two generalized
+// pairwise-MIS merges (p3_merge) and the final shade (p3_shade).  Visibility rays of a pixel, in the order the reference casts them:
+//   k = 0..2  DI, canonical sample seen from neighbour j      (neighbour's x1 -> my x2)         k = 3..5  the same for GI
+//   k = 6..8  GI, neighbour v's sample seen from this pixel   (my x1 -> neighbour's GI x2)      k = 9     the selected DI sample (my x1 -> its x2)
+struct P3Cand { uint32_t di[3], gi[3]; int n_di, n_gi; float M_sum_DI, M_sum_GI; };
+__device__ __forceinline__ void p3_select(const DevScene& sc, const DevFrame& f, const RestirBufs& B, f3 camo, uint32_t x, uint32_t y, const SData& sd, const MatGPU& m,
+                                          const Res& rcur, const Res& gcur, uint32_t& s0, uint32_t& s1, P3Cand& K) {
+    const uint32_t W = f.width, H = f.height;
+    K.n_di = 0; K.n_gi = 0;
+    K.M_sum_DI = minf_u(128.0f, rcur.M); K.M_sum_GI = minf_u(128.0f, gcur.M);
+    for (int a = 0; a < 9 && K.n_di < 3; a++) {
+        int nx, ny; random_pixel_dev(20u, W, H, x, y, s0, s1, nx, ny);
+        const size_t pr = map_pixel_id(W, (uint32_t)nx, (uint32_t)ny);
+        const SData sn = load_sd_dev(B.cur_sd + pr * 15); const Res rn = load_res_dev(B.cur_di + pr * 10);
+        const bool ok = !(dot(sd.n1, sn.n1) < 0.9f) && !reject_distance_dev(sd.x1, sn.x1, camo, 0.1f) && valid_res_dev(rn) && length(sn.L1) == 0.0f && sn.mID == sd.mID;
+        if (ok) { K.di[K.n_di++] = (uint32_t)pr; K.M_sum_DI += minf_u(128.0f, rn.M); }
+    }
+    for (int a = 0; a < 9 && K.n_gi < 3; a++) {
+        int nx, ny; random_pixel_dev(20u, W, H, x, y, s0, s1, nx, ny);
+        const size_t pr = map_pixel_id(W, (uint32_t)nx, (uint32_t)ny);
+        const SData sn = load_sd_dev(B.cur_sd + pr * 15); const Res gn = load_res_dev(B.cur_gi + pr * 10);
+        const bool ok = m.Pr > 0.3f && !reject_distance_dev(sd.x1, sn.x1, camo, 0.1f) && !(dot(normalize(gn.x2 - sd.x1), sd.n1) < 0.0f) &&
+                        !(gn.w_sum > 5.0f) && valid_res_gi_dev(gn) && !reject_jacobian_dev(jacobian_dev(sn, sd, gn.x2, gn.n2), 5.0f) &&
+                        length(sn.L1) == 0.0f && sn.mID == sd.mID;
+        if (ok) { K.gi[K.n_gi++] = (uint32_t)pr; K.M_sum_GI += minf_u(128.0f, gn.M); }
+    }
+}
+// rcur / gcur: in = this pixel's reservoirs after pass 2, out = merged (w_sum, M, selected sample; W still to be set by p3_shade)
+template <class V>
+__device__ __forceinline__ void p3_merge(const DevScene& sc, const DevFrame& f, const RestirBufs& B, const SData& sd, const MatGPU& m, const P3Cand& K,
+                                         Res& rcur, Res& gcur, uint32_t& s0, uint32_t& s1, V&& vis) {
+    const uint32_t flags = f.flags;
+    const float M_sum_DI = K.M_sum_DI, M_sum_GI = K.M_sum_GI;
+    const int n_di = K.n_di, n_gi = K.n_gi;
+    const Res can = rcur, can_gi = gcur;
+    const float cMmin = minf_u(128.0f, can.M), cMmax = M_sum_DI - cMmin;
+    const float p_c = p_hat_di(flags, m, sd.x1, sd.n1, can.x2, can.n2, can.L2, sd.o, -1, vis);
+    const float c_m_num = cMmin * p_c; float mi_c = cMmin / M_sum_DI;
+    for (int j = 0; j < n_di; j++) {
+        const SData sn = load_sd_dev(B.cur_sd + (size_t)K.di[j] * 15); const Res rn = load_res_dev(B.cur_di + (size_t)K.di[j] * 10);
+        const float nM = minf_u(128.0f, rn.M);
+        const float p_from = p_hat_di(flags, m, sn.x1, sn.n1, can.x2, can.n2, can.L2, sn.o, j, vis);
+        const float m_den = c_m_num + (cMmax * p_from);
+        if (m_den > 0.0f) mi_c += (nM / M_sum_DI) * (c_m_num / m_den);
+    }
+    const float w_c = mi_c * p_hat_di(flags, m, sd.x1, sd.n1, can.x2, can.n2, can.L2, sd.o, -1, vis) * can.W;
+    const float gMmin = minf_u(128.0f, can_gi.M), gMmax = M_sum_GI - gMmin;
+    const float pg_c = length(p_hat_gi(flags, m, sd.x1, sd.n1, can_gi.x2, can_gi.L2, sd.o, -1, vis));
+    const float g_m_num = gMmin * pg_c; float mi_c_gi = gMmin / M_sum_GI;
+    for (int j = 0; j < n_gi; j++) {
+        const SData sn = load_sd_dev(B.cur_sd + (size_t)K.gi[j] * 15); const Res gn = load_res_dev(B.cur_gi + (size_t)K.gi[j] * 10);
+        const float nM = minf_u(128.0f, gn.M);
+        const float j_gi = jacobian_dev(sd, sn, can_gi.x2, can_gi.n2);
+        const float p_from = length(p_hat_gi(flags, m, sn.x1, sn.n1, can_gi.x2, can_gi.L2, sn.o, 3 + j, vis)) * j_gi;
+        const float m_den = g_m_num + (gMmax * p_from);
+        if (m_den > 0.0f) mi_c_gi += (nM / M_sum_GI) * (g_m_num / m_den);
+    }
+    mi_c_gi = minf_(maxf_(mi_c_gi, 0.0f), 1.0f);
+    const float w_c_gi = mi_c_gi * length(p_hat_gi(flags, m, sd.x1, sd.n1, can_gi.x2, can_gi.L2, sd.o, -1, vis)) * can_gi.W;
+    rcur.M = (uint32_t)cMmin; rcur.w_sum = w_c;
+    gcur.M = (uint32_t)gMmin; gcur.w_sum = w_c_gi;
+    for (int v = 0; v < n_di; v++) {
+        const SData sn = load_sd_dev(B.cur_sd + (size_t)K.di[v] * 15); const Res rn = load_res_dev(B.cur_di + (size_t)K.di[v] * 10);
+        const float pc2 = p_hat_di(flags, m, sd.x1, sd.n1, can.x2, can.n2, can.L2, sd.o, -1, vis);
+        const float p_from = p_hat_di(flags, m, sn.x1, sn.n1, can.x2, can.n2, can.L2, sn.o, -1, vis);
+        const float m_num = (M_sum_DI - cMmin) * p_from, m_den = m_num + (cMmin * pc2);
+        const float mi_s = m_den > 0.0f ? (minf_u(128.0f, rn.M) / M_sum_DI) * (m_num / m_den) : 0.0f;
+        const float w_s = mi_s * p_hat_di(flags, m, sd.x1, sd.n1, rn.x2, rn.n2, rn.L2, sd.o, -1, vis) * rn.W;
+        rcur.w_sum += w_s; rcur.M = (rcur.M + (uint32_t)minf_u(128.0f, rn.M)) & 0xFFFFu;
+        if (tea_next(s0, s1) < w_s / rcur.w_sum) { rcur.x2 = rn.x2; rcur.n2 = rn.n2; rcur.L2 = rn.L2; }
+    }
+    for (int v = 0; v < n_gi; v++) {
+        const SData sn = load_sd_dev(B.cur_sd + (size_t)K.gi[v] * 15); const Res gn = load_res_dev(B.cur_gi + (size_t)K.gi[v] * 10);
+        const float pc2 = length(p_hat_gi(flags, m, sd.x1, sd.n1, can_gi.x2, can_gi.L2, sd.o, -1, vis));
+        const float jj = jacobian_dev(sd, sn, can_gi.x2, can_gi.n2);
+        const float p_from = length(p_hat_gi(flags, m, sn.x1, sn.n1, can_gi.x2, can_gi.L2, sn.o, -1, vis)) * jj;
+        const float m_num = (M_sum_GI - gMmin) * p_from, m_den = m_num + (gMmin * pc2);
+        const float mi_s = m_den > 0.0f ? minf_(maxf_((minf_u(128.0f, gn.M) / M_sum_GI) * (m_num / m_den), 0.0f), 1.0f) : 0.0f;
+        const float j_gi = jacobian_dev(sn, sd, gn.x2, gn.n2);
+        const f3 f_gi = p_hat_gi(flags, m, sd.x1, sd.n1, gn.x2, gn.L2, sd.o, 6 + v, vis);
+        const float w_s = mi_s * length(f_gi) * gn.W * j_gi;
+        if (j_gi != 0.0f) {
+            gcur.w_sum += w_s; gcur.M = (gcur.M + (uint32_t)minf_u(128.0f, gn.M)) & 0xFFFFu;
+            if (tea_next(s0, s1) < w_s / gcur.w_sum) { gcur.x2 = gn.x2; gcur.n2 = gn.n2; gcur.L2 = gn.L2; }
+        }
+    }
+}
+// final W of both reservoirs and the pixel's radiance ReconnectDI * W + f_gi * W_gi (pass3:353-372)
+template <class V>
+__device__ __forceinline__ f3 p3_shade(const DevFrame& f, const SData& sd, const MatGPU& m, Res& rcur, Res& gcur, V&& vis) {
+    const float p_hat = p_hat_di(f.flags, m, sd.x1, sd.n1, rcur.x2, rcur.n2, rcur.L2, sd.o, 9, vis);
+    rcur.W = get_w_dev(rcur.w_sum, p_hat);
+    f3 acc = reconnect_di_dev(m, f.flags, sd.x1, sd.n1, rcur.x2, rcur.n2, rcur.L2, sd.o) * rcur.W;
+    const f3 f_fin = p_hat_gi(f.flags, m, sd.x1, sd.n1, gcur.x2, gcur.L2, sd.o, -1, vis);
+    gcur.W = get_w_dev(gcur.w_sum, length(f_fin));
+    acc = acc + f_fin * gcur.W;
+    return acc;
 }
 
 __global__ __launch_bounds__(kBlock) void k_restir_pass3(DevScene sc, const SmallRecPair* __restrict__ small, DevFrame f, const CameraGPU* __restrict__ cam_p, RestirBufs B,
@@ -488,7 +678,7 @@ __global__ __launch_bounds__(kBlock) void k_restir_pass3(DevScene sc, const Smal
     __syncthreads();
     uint32_t n_sh = 0;
     const uint32_t stride = gridDim.x * kBlock;
-    const uint32_t W = f.width, H = f.height;
+    const uint32_t W = f.width;
     for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < f.npl; pl += stride) {
         uint32_t x, y;
         if (!slot_to_pixel(f, pl, x, y)) continue;
@@ -502,85 +692,12 @@ __global__ __launch_bounds__(kBlock) void k_restir_pass3(DevScene sc, const Smal
             uint32_t s0, s1; seed_init(x, y, 3u, f.frame_seed, s0, s1);
             const MatGPU& m = sc.mats[sd.mID];
             Res rcur = load_res_dev(B.cur_di + slot * 10), gcur = load_res_dev(B.cur_gi + slot * 10);
-            size_t cand_di[3], cand_gi[3]; int n_di = 0, n_gi = 0;
-            float M_sum_DI = minf_u(128.0f, rcur.M), M_sum_GI = minf_u(128.0f, gcur.M);
-            for (int a = 0; a < 9 && n_di < 3; a++) {
-                int nx, ny; random_pixel_dev(20u, W, H, x, y, s0, s1, nx, ny);
-                const size_t pr = map_pixel_id(W, (uint32_t)nx, (uint32_t)ny);
-                const SData sn = load_sd_dev(B.cur_sd + pr * 15); const Res rn = load_res_dev(B.cur_di + pr * 10);
-                const bool ok = !(dot(sd.n1, sn.n1) < 0.9f) && !reject_distance_dev(sd.x1, sn.x1, camo, 0.1f) && valid_res_dev(rn) && length(sn.L1) == 0.0f && sn.mID == sd.mID;
-                if (ok) { cand_di[n_di++] = pr; M_sum_DI += minf_u(128.0f, rn.M); }
-            }
-            for (int a = 0; a < 9 && n_gi < 3; a++) {
-                int nx, ny; random_pixel_dev(20u, W, H, x, y, s0, s1, nx, ny);
-                const size_t pr = map_pixel_id(W, (uint32_t)nx, (uint32_t)ny);
-                const SData sn = load_sd_dev(B.cur_sd + pr * 15); const Res gn = load_res_dev(B.cur_gi + pr * 10);
-                const bool ok = m.Pr > 0.3f && !reject_distance_dev(sd.x1, sn.x1, camo, 0.1f) && !(dot(normalize(gn.x2 - sd.x1), sd.n1) < 0.0f) &&
-                                !(gn.w_sum > 5.0f) && valid_res_gi_dev(gn) && !reject_jacobian_dev(jacobian_dev(sn, sd, gn.x2, gn.n2), 5.0f) &&
-                                length(sn.L1) == 0.0f && sn.mID == sd.mID;
-                if (ok) { cand_gi[n_gi++] = pr; M_sum_GI += minf_u(128.0f, gn.M); }
-            }
-            const Res can = rcur, can_gi = gcur;
-            const float cMmin = minf_u(128.0f, can.M), cMmax = M_sum_DI - cMmin;
-            const float p_c = get_p_hat_dev(C, m, sd.x1, sd.n1, can.x2, can.n2, can.L2, sd.o, false);
-            const float c_m_num = cMmin * p_c; float mi_c = cMmin / M_sum_DI;
-            for (int j = 0; j < n_di; j++) {
-                const SData sn = load_sd_dev(B.cur_sd + cand_di[j] * 15); const Res rn = load_res_dev(B.cur_di + cand_di[j] * 10);
-                const float nM = minf_u(128.0f, rn.M);
-                const float p_from = get_p_hat_dev(C, m, sn.x1, sn.n1, can.x2, can.n2, can.L2, sn.o, true);
-                const float m_den = c_m_num + (cMmax * p_from);
-                if (m_den > 0.0f) mi_c += (nM / M_sum_DI) * (c_m_num / m_den);
-            }
-            const float w_c = mi_c * get_p_hat_dev(C, m, sd.x1, sd.n1, can.x2, can.n2, can.L2, sd.o, false) * can.W;
-            const float gMmin = minf_u(128.0f, can_gi.M), gMmax = M_sum_GI - gMmin;
-            const float pg_c = length(get_p_hat_gi_dev(C, m, sd.x1, sd.n1, can_gi.x2, can_gi.L2, sd.o, false));
-            const float g_m_num = gMmin * pg_c; float mi_c_gi = gMmin / M_sum_GI;
-            for (int j = 0; j < n_gi; j++) {
-                const SData sn = load_sd_dev(B.cur_sd + cand_gi[j] * 15); const Res gn = load_res_dev(B.cur_gi + cand_gi[j] * 10);
-                const float nM = minf_u(128.0f, gn.M);
-                const float j_gi = jacobian_dev(sd, sn, can_gi.x2, can_gi.n2);
-                const float p_from = length(get_p_hat_gi_dev(C, m, sn.x1, sn.n1, can_gi.x2, can_gi.L2, sn.o, true)) * j_gi;
-                const float m_den = g_m_num + (gMmax * p_from);
-                if (m_den > 0.0f) mi_c_gi += (nM / M_sum_GI) * (g_m_num / m_den);
-            }
-            mi_c_gi = minf_(maxf_(mi_c_gi, 0.0f), 1.0f);
-            const float w_c_gi = mi_c_gi * length(get_p_hat_gi_dev(C, m, sd.x1, sd.n1, can_gi.x2, can_gi.L2, sd.o, false)) * can_gi.W;
-            rcur.M = (uint32_t)cMmin; rcur.w_sum = w_c;
-            gcur.M = (uint32_t)gMmin; gcur.w_sum = w_c_gi;
-            for (int v = 0; v < n_di; v++) {
-                const SData sn = load_sd_dev(B.cur_sd + cand_di[v] * 15); const Res rn = load_res_dev(B.cur_di + cand_di[v] * 10);
-                const float pc2 = get_p_hat_dev(C, m, sd.x1, sd.n1, can.x2, can.n2, can.L2, sd.o, false);
-                const float p_from = get_p_hat_dev(C, m, sn.x1, sn.n1, can.x2, can.n2, can.L2, sn.o, false);
-                const float m_num = (M_sum_DI - cMmin) * p_from, m_den = m_num + (cMmin * pc2);
-                const float mi_s = m_den > 0.0f ? (minf_u(128.0f, rn.M) / M_sum_DI) * (m_num / m_den) : 0.0f;
-                const float w_s = mi_s * get_p_hat_dev(C, m, sd.x1, sd.n1, rn.x2, rn.n2, rn.L2, sd.o, false) * rn.W;
-                rcur.w_sum += w_s; rcur.M = (rcur.M + (uint32_t)minf_u(128.0f, rn.M)) & 0xFFFFu;
-                if (tea_next(s0, s1) < w_s / rcur.w_sum) { rcur.x2 = rn.x2; rcur.n2 = rn.n2; rcur.L2 = rn.L2; }
-            }
-            for (int v = 0; v < n_gi; v++) {
-                const SData sn = load_sd_dev(B.cur_sd + cand_gi[v] * 15); const Res gn = load_res_dev(B.cur_gi + cand_gi[v] * 10);
-                const float pc2 = length(get_p_hat_gi_dev(C, m, sd.x1, sd.n1, can_gi.x2, can_gi.L2, sd.o, false));
-                const float jj = jacobian_dev(sd, sn, can_gi.x2, can_gi.n2);
-                const float p_from = length(get_p_hat_gi_dev(C, m, sn.x1, sn.n1, can_gi.x2, can_gi.L2, sn.o, false)) * jj;
-                const float m_num = (M_sum_GI - gMmin) * p_from, m_den = m_num + (gMmin * pc2);
-                const float mi_s = m_den > 0.0f ? minf_(maxf_((minf_u(128.0f, gn.M) / M_sum_GI) * (m_num / m_den), 0.0f), 1.0f) : 0.0f;
-                const float j_gi = jacobian_dev(sn, sd, gn.x2, gn.n2);
-                const f3 f_gi = get_p_hat_gi_dev(C, m, sd.x1, sd.n1, gn.x2, gn.L2, sd.o, true);
-                const float w_s = mi_s * length(f_gi) * gn.W * j_gi;
-                if (j_gi != 0.0f) {
-                    gcur.w_sum += w_s; gcur.M = (gcur.M + (uint32_t)minf_u(128.0f, gn.M)) & 0xFFFFu;
-                    if (tea_next(s0, s1) < w_s / gcur.w_sum) { gcur.x2 = gn.x2; gcur.n2 = gn.n2; gcur.L2 = gn.L2; }
-                }
-            }
-            const float p_hat = get_p_hat_dev(C, m, sd.x1, sd.n1, rcur.x2, rcur.n2, rcur.L2, sd.o, true);
-            rcur.W = get_w_dev(rcur.w_sum, p_hat);
-            f3 acc = reconnect_di_dev(m, f.flags, sd.x1, sd.n1, rcur.x2, rcur.n2, rcur.L2, sd.o) * rcur.W;
-            const f3 f_fin = get_p_hat_gi_dev(C, m, sd.x1, sd.n1, gcur.x2, gcur.L2, sd.o, false);
-            gcur.W = get_w_dev(gcur.w_sum, length(f_fin));
-            acc = acc + f_fin * gcur.W;
+            P3Cand K;
+            p3_select(sc, f, B, camo, x, y, sd, m, rcur, gcur, s0, s1, K);
+            p3_merge(sc, f, B, sd, m, K, rcur, gcur, s0, s1, VisTrace{C});
+            out = p3_shade(f, sd, m, rcur, gcur, VisTrace{C});
             store_res(B.last_di + slot * 10, rcur); store_res(B.last_gi + slot * 10, gcur);
             for (int k = 0; k < 15; k++) B.last_sd[slot * 15 + k] = B.cur_sd[slot * 15 + k];
-            out = acc;
             n_sh += C.cnt_sh;
         }
         if (finite3(out)) { F4 a = accum[(size_t)y * W + x]; a.x = a.x + out.x; a.y = a.y + out.y; a.z = a.z + out.z; a.w = a.w + 1.0f; accum[(size_t)y * W + x] = a; }

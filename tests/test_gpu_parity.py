@@ -527,15 +527,21 @@ def test_large_scene_parity(rt, orc, kind, tris, cfg):
     c.close()
 
 
-@pytest.mark.parametrize("flags,nee,bounces", [(1, 4, 3), (0, 4, 3), (0, 1, 2), (1, 0, 3)])
-def test_v6_pass1_estimator_parity(rt, cornell_pair, flags, nee, bounces):
+RESTIR_FORMS = [pytest.param(1, id="wavefront"), pytest.param(0, id="literal")]     # RTX_OPT_RESTIR_WAVEFRONT: stage kernels + persistent traversal | one thread per pixel and pass
+
+
+@pytest.mark.parametrize("wave", RESTIR_FORMS)
+@pytest.mark.parametrize("flags,nee,bounces", [(1, 4, 3), (0, 4, 3), (0, 1, 2), (1, 0, 3), (0, 2, 0)])
+def test_v6_pass1_estimator_parity(rt, cornell_pair, flags, nee, bounces, wave):
     """the reference's own pass 1 (SampleRIS + SamplePathSimple, RayGen_v6_pass1.hlsl:48-190): reservoirs,
-    sample data (reference byte layouts, MapPixelID order) and radiance, bit for bit against the oracle"""
+    sample data (reference byte layouts, MapPixelID order) and radiance, bit for bit against the oracle — as wavefront stages (the default) and literally"""
     ctx, o = cornell_pair
+    ctx.set_option(rt.OPT_RESTIR_WAVEFRONT, wave)
     W, H = 100, 58                                        # not a multiple of the 4x4 MapPixelID tile
     p = rt.Params(width=W, height=H, spp=2, max_bounces=bounces, nee_samples=nee, flags=flags, frame_seed=5)
     ctx.set_camera(*rt.Scene.cornell().view_proj(W / H)); o.set_camera(*rt.Scene.cornell().view_proj(W / H))
     ctx.clear(W, H); ctx.render_v6_pass1(p)
+    ctx.set_option(rt.OPT_RESTIR_WAVEFRONT, 1)
     g = ctx.read_accum(); gd, gg, gs = ctx.read_pass1_buffers()
     c, (cd, cg, cs), cnt = o.render_v6_pass1(p)
     st = ctx.stats()
@@ -547,10 +553,11 @@ def test_v6_pass1_estimator_parity(rt, cornell_pair, flags, nee, bounces):
     assert g[..., :3].sum() > 0 and (g[..., 3] == 2).all()
 
 
-def test_v6_pass1_garage(rt, orc, golden_dir):
+@pytest.mark.parametrize("wave", RESTIR_FORMS)
+def test_v6_pass1_garage(rt, orc, golden_dir, wave):
     import os
     sc = rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")
-    c = rt.Context(0); c.upload(sc, 96 / 54)
+    c = rt.Context(0); c.set_option(rt.OPT_RESTIR_WAVEFRONT, wave); c.upload(sc, 96 / 54)
     o = orc.Oracle().load(sc, 96 / 54)
     p = rt.Params(width=96, height=54, spp=1, max_bounces=3, nee_samples=4, flags=0)     # the reference's defines (Common_v6.hlsl:8-12)
     c.clear(96, 54); c.render_v6_pass1(p)
@@ -563,16 +570,19 @@ def test_v6_pass1_garage(rt, orc, golden_dir):
     c.close()
 
 
+@pytest.mark.parametrize("wave", RESTIR_FORMS)
 @pytest.mark.parametrize("flags", [1, 0])
-def test_restir_frames_parity(rt, cornell_pair, flags):
+def test_restir_frames_parity(rt, cornell_pair, flags, wave):
     """the reference's shipping pipeline: pass 1 + temporal reuse (pass 2) + spatial reuse and shade (pass 3), three
     consecutive frames so that the temporal history is exercised; all six reservoir / sample buffers and the image"""
     ctx, o = cornell_pair
+    ctx.set_option(rt.OPT_RESTIR_WAVEFRONT, wave)
     W, H = 96, 56
     vp = rt.Scene.cornell().view_proj(W / H)
     ctx.set_camera(*vp); ctx.set_camera(*vp); o.set_camera(*vp); o.set_camera(*vp)      # previous view = current view
     p = rt.Params(width=W, height=H, spp=3, max_bounces=3, nee_samples=4, flags=flags, frame_seed=11)
     ctx.restir_reset(); ctx.clear(W, H); ctx.render_restir(p)
+    ctx.set_option(rt.OPT_RESTIR_WAVEFRONT, 1)
     g = ctx.read_accum(); gd, gg, gs = ctx.read_pass1_buffers(); ld, lg, ls = ctx.read_restir_last()
     c, st, cnt = o.restir_frames(p)
     s = ctx.stats()
@@ -585,12 +595,13 @@ def test_restir_frames_parity(rt, cornell_pair, flags):
     assert g[..., :3].sum() > 0
 
 
-def test_restir_garage_with_camera_motion(rt, orc, golden_dir):
+@pytest.mark.parametrize("wave", RESTIR_FORMS)
+def test_restir_garage_with_camera_motion(rt, orc, golden_dir, wave):
     """GGX scene with two instances; the camera moves between frames so the reprojection path is taken"""
     import os
     sc = rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")
     W, H = 80, 48
-    c = rt.Context(0); c.upload(sc, W / H)
+    c = rt.Context(0); c.set_option(rt.OPT_RESTIR_WAVEFRONT, wave); c.upload(sc, W / H)
     o = orc.Oracle().load(sc, W / H)
     acc_o, st = np.zeros((H, W, 4), np.float32), None
     c.restir_reset(); c.clear(W, H)
@@ -609,26 +620,27 @@ def test_restir_garage_with_camera_motion(rt, orc, golden_dir):
     c.close()
 
 
-@pytest.mark.parametrize("nshards", [2, 3])
-def test_restir_on_shards_equals_the_unsharded_frames(rt, orc, golden_dir, nshards):
+@pytest.mark.parametrize("nshards,wave,blocks", [(2, 1, 0), (3, 1, 0), (2, 0, 0), (2, 1, 1), (3, 1, 1), (4, 1, 1), (4, 0, 1)])
+def test_restir_on_shards_equals_the_unsharded_frames(rt, orc, golden_dir, nshards, wave, blocks):
     """SURVEY 8(f1) on pixel-tile shards: every shard runs passes 1 + 2 on its tiles dilated by the 20-px radius of the spatial pass, pass 3 on its own tiles, and
     after each frame the shards exchange the history (u3 / u5 / u7) of their own tiles (pack -> gather -> unpack; the gather is a torch.cat here, the
     shards being contexts on one GPU).  Three frames with a moving camera on garage.obj + monke.obj (GGX + Lambert, two instances): every shard's tiles of the
-    accumulation buffer and the complete history equal the unsharded run's (which equals the oracle's: test_restir_garage_with_camera_motion)."""
+    accumulation buffer and the complete history equal the unsharded run's (which equals the oracle's: test_restir_garage_with_camera_motion).
+    blocks = RTX_FLAG_BLOCK_TILES: every shard owns ONE rectangle of tiles (a 20-px rim of recomputed pixels instead of a rim around every tile)."""
     import torch
     from royaltracer_dx_amd import sharding
     sc = rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")
     W, H, TS = 160, 96, 32
     cams = [rt.lookat((-1.5 + 0.05 * k, 1.5, 3.5 - 0.04 * k), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0)) for k in range(3)]
     proj = rt.perspective_fov_rh(np.radians(60.0), W / H, 0.1, 1000.0)
-    base = dict(width=W, height=H, spp=1, max_bounces=3, nee_samples=4, flags=0, tile_size=TS)
+    base = dict(width=W, height=H, spp=1, max_bounces=3, nee_samples=4, flags=rt.FLAG_BLOCK_TILES if blocks else 0, tile_size=TS)
     ref = rt.Context(0); ref.upload(sc, W / H); ref.restir_reset(); ref.clear(W, H)
     for k, v in enumerate(cams):
         ref.set_camera(v, proj); ref.render_restir(rt.Params(frame_seed=70 + k, **base))
     ref_img, ref_last = ref.read_accum(), ref.read_restir_last()
     ranks = []
     for r in range(nshards):
-        c = rt.Context(0); c.upload(sc, W / H); c.restir_reset(); c.clear(W, H); ranks.append(c)
+        c = rt.Context(0); c.set_option(rt.OPT_RESTIR_WAVEFRONT, wave); c.upload(sc, W / H); c.restir_reset(); c.clear(W, H); ranks.append(c)
     for k, v in enumerate(cams):
         slabs = []
         for r, c in enumerate(ranks):
@@ -640,7 +652,7 @@ def test_restir_on_shards_equals_the_unsharded_frames(rt, orc, golden_dir, nshar
         gathered = torch.cat(slabs)                                      # what ONE all_gather_into_tensor leaves on every rank
         for r, c in enumerate(ranks):
             c.restir_unpack_state(rt.Params(frame_seed=70 + k, shard_rank=r, shard_count=nshards, **base), gathered.data_ptr())
-    own = sharding.owner_map(W, H, TS, nshards)
+    own = sharding.owner_map(W, H, TS, nshards, bool(blocks))
     for r, c in enumerate(ranks):
         img = c.read_accum()
         assert np.array_equal(bits(img[own == r]), bits(ref_img[own == r])), r
@@ -651,6 +663,40 @@ def test_restir_on_shards_equals_the_unsharded_frames(rt, orc, golden_dir, nshar
             c.render_restir(rt.Params(frame_seed=1, shard_rank=r, shard_count=nshards, **dict(base, spp=2)))    # the history must be exchanged after every frame
         c.close()
     ref.close()
+
+
+def test_restir_wavefront_equals_literal_on_a_bvh_scene_at_scale(rt, orc):
+    """The wavefront stages at a size where their machinery is exercised — many workgroups with several 256-pixel chunks per sub-queue, persistent traversal
+    kernels that refill their lanes, a ray queue of several rays per pixel — on a 20 k-triangle atrium (compressed wide BVH): three frames with a moving camera,
+    all six buffers, the image and the ray counts equal the literal thread-per-pixel form's AND the oracle's; RTX_OPT_RESTIR_CHUNKS 1 / 4 / 16 (sub-queue
+    lengths) give the same bytes."""
+    sc = rt.Scene.sponza_class(20000, 260)
+    W, H = 384, 216
+    proj = rt.perspective_fov_rh(np.radians(60.0), W / H, 0.1, 1000.0)
+    v0 = sc.view_proj(W / H)[0]
+    cams = []
+    for k in range(3):
+        v = v0.copy(); v[12] += 0.02 * k; v[13] -= 0.01 * k; cams.append(v)       # small translations of the view
+    o = orc.Oracle().load(sc, W / H)
+    acc_o, st, total = np.zeros((H, W, 4), np.float32), None, np.zeros(3, np.uint64)
+    for k, v in enumerate(cams):
+        o.set_camera(v, proj)
+        acc_o, st, cnt = o.restir_frames(rt.Params(width=W, height=H, spp=1, max_bounces=3, nee_samples=4, flags=0, frame_seed=30 + k), acc_o, st)
+        total += np.array(cnt, np.uint64)
+    for wave, chunks in ((1, 4), (1, 1), (1, 16), (0, 4)):
+        c = rt.Context(0); c.set_option(rt.OPT_RESTIR_WAVEFRONT, wave); c.set_option(rt.OPT_RESTIR_CHUNKS, chunks); c.upload(sc, W / H)
+        c.restir_reset(); c.clear(W, H)
+        rays = np.zeros(3, np.uint64)
+        for k, v in enumerate(cams):
+            c.set_camera(v, proj)
+            c.render_restir(rt.Params(width=W, height=H, spp=1, max_bounces=3, nee_samples=4, flags=0, frame_seed=30 + k))
+            s = c.stats(); rays += np.array([s.rays_primary, s.rays_extension, s.rays_shadow], np.uint64)
+        assert np.array_equal(rays, total), (wave, chunks, rays, total)
+        for name, a, b in zip(("cur_di", "cur_gi", "cur_sd", "last_di", "last_gi", "last_sd"), c.read_pass1_buffers() + c.read_restir_last(), st):
+            assert np.array_equal(a, b), (wave, chunks, name, int((a != b).any(1).sum()))
+        assert np.array_equal(bits(c.read_accum()), bits(acc_o)), (wave, chunks)
+        c.close()
+    assert total[2] > 4 * W * H and total[1] > 2 * W * H
 
 
 @pytest.mark.parametrize("gpu_refit", [1, 0])
@@ -1039,8 +1085,8 @@ def test_random_tiny_scenes_restir_frames_equal_oracle(rt, orc):
         p = rt.Params(width=W, height=H, spp=2, max_bounces=3, nee_samples=2 + seed % 3, flags=seed & 1, frame_seed=seed)
         o.set_camera(*vp); o.set_camera(*vp)
         oimg, st, cnt = o.restir_frames(p)
-        for small in (1, 0):
-            c = rt.Context(0); c.set_option(rt.OPT_SMALL_SCENE, small); c.upload(sc, W / H)
+        for small, wave in ((1, 1), (0, 1), (1, 0), (0, 0)):                   # tiny-scene / BVH traversal x wavefront stages / one thread per pixel
+            c = rt.Context(0); c.set_option(rt.OPT_SMALL_SCENE, small); c.set_option(rt.OPT_RESTIR_WAVEFRONT, wave); c.upload(sc, W / H)
             c.set_camera(*vp); c.set_camera(*vp)
             c.restir_reset(); c.clear(W, H); c.render_restir(p)
             gimg = c.read_accum(); ld, lg, ls = c.read_restir_last(); s = c.stats()
@@ -1048,7 +1094,7 @@ def test_random_tiny_scenes_restir_frames_equal_oracle(rt, orc):
                 and np.array_equal(ls, st[5]) and np.array_equal(bits(gimg), bits(oimg))
             c.close()
             if not ok:
-                bad.append((seed, small))
+                bad.append((seed, small, wave))
     assert not bad, f"scenes that differ from the oracle: {bad}"
 
 
