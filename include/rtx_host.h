@@ -84,6 +84,11 @@ typedef struct rtxh_renderer rtxh_renderer;
 rtxh_renderer* rtxh_renderer_create(uint32_t width, uint32_t height, const char* name, int device);
 int  rtxh_renderer_set_scene(rtxh_renderer*, const rtxh_scene*);
 rtx_params* rtxh_renderer_params(rtxh_renderer*);
+/* what OnRender issues: 0 (default) = rtx_render with params(), 1 = the reference's shipping frame — its three DispatchRays (Renderer.cpp:646-673), rtx_render_restir with
+   restir_params() (one frame per OnRender; nee_samples 4, max_bounces 3 as in Common_v6.hlsl:8-12) */
+int  rtxh_renderer_set_mode(rtxh_renderer*, int mode);
+rtx_params* rtxh_renderer_restir_params(rtxh_renderer*);
+rtx_ctx* rtxh_renderer_context(rtxh_renderer*);                           /* the context behind the facade (options, statistics); NULL before on_init */
 int  rtxh_renderer_on_init(rtxh_renderer*);
 int  rtxh_renderer_on_update(rtxh_renderer*);
 int  rtxh_renderer_on_render(rtxh_renderer*);

@@ -175,6 +175,9 @@ _sig("rtxh_scene_small_records", C.c_int, _vp, _vp, _vp, _u32, _u32p, _fp, _fp)
 _sig("rtxh_renderer_create", _vp, _u32, _u32, C.c_char_p, C.c_int)
 _sig("rtxh_renderer_set_scene", C.c_int, _vp, _vp)
 _sig("rtxh_renderer_params", C.POINTER(Params), _vp)
+_sig("rtxh_renderer_restir_params", C.POINTER(Params), _vp)
+_sig("rtxh_renderer_set_mode", C.c_int, _vp, C.c_int)
+_sig("rtxh_renderer_context", _vp, _vp)
 _sig("rtxh_renderer_on_init", C.c_int, _vp)
 _sig("rtxh_renderer_on_update", C.c_int, _vp)
 _sig("rtxh_renderer_on_render", C.c_int, _vp)
@@ -605,6 +608,19 @@ class Renderer:
     @property
     def params(self):
         return lib.rtxh_renderer_params(self._h).contents
+
+    @property
+    def restir_params(self):
+        return lib.rtxh_renderer_restir_params(self._h).contents
+
+    def set_mode(self, mode):
+        """0 = path tracer (rtx_render), 1 = the reference's ReSTIR frame (rtx_render_restir), one frame per on_render"""
+        self._ck(lib.rtxh_renderer_set_mode(self._h, int(mode)), "set_mode")
+
+    def set_option(self, opt, value):
+        h = lib.rtxh_renderer_context(self._h)
+        if not h or lib.rtx_set_option(h, int(opt), int(value)) != RTX_OK:
+            raise RtxError("set_option: " + (lib.rtx_last_error(h).decode() if h else "renderer not initialised"))
 
     def on_init(self):
         self._ck(lib.rtxh_renderer_on_init(self._h), "OnInit")

@@ -623,20 +623,22 @@ static int rs_plan(rtx_ctx* c, const DevFrame& f, uint32_t nitems, const uint32_
     }
     return RTX_OK;
 }
-// pass 1 of one sample (RayGen_v6_pass1.hlsl:48-190): raygen | trace | ris | trace | ris_finish | trace x 2 | first | (trace | loop) x bounces | emit_final | trace | finish
-static int rs_pass1(rtx_ctx* c, const DevFrame& f, uint32_t sample_id, F4* accum, const uint32_t* pixels, uint32_t npixels) {
-    const uint32_t mb = f.max_bounces, rows = 4u + mb + 2u;
+// pass 1 of one sample (RayGen_v6_pass1.hlsl:48-190): raygen | trace | ris | trace | ris_finish | trace | first | (trace | loop) x bounces | emit_final | trace | finish.
+// bufs != nullptr (a ReSTIR frame): pass 2 (RayGen_v6_pass2.hlsl:46-204) rides on the last two stages
+static int rs_pass1(rtx_ctx* c, const DevFrame& f, uint32_t sample_id, F4* accum, const uint32_t* pixels, uint32_t npixels, uint32_t* const* bufs) {
+    const uint32_t mb = f.max_bounces, rows = 4u + mb + 1u;
     RsPlan R; int r = rs_plan(c, f, pixels ? npixels : f.npl, pixels, rows, R); if (r) return r;
     hipStream_t st = c->stream;
     const DevScene& sc = c->dsc; const RsQ& q = R.q;
+    const CameraGPU* cam = (const CameraGPU*)c->d_cam.p;
     auto row = [&](uint32_t k) { return R.cnt + (size_t)k * R.G; };
     uint32_t* res_di = (uint32_t*)c->d_res_di.p; uint32_t* res_gi = (uint32_t*)c->d_res_gi.p; uint32_t* sdata = (uint32_t*)c->d_sdata.p;
-    { Timed t(c, RTX_K_RAYGEN); launch_rs_raygen(st, R.fq, q, (const CameraGPU*)c->d_cam.p, sample_id, row(0)); }
+    uint32_t* shrow = row(4 + mb);                          // lengths of the ray sub-queues: DI visibility (stage 2) + reconnection + temporal rays (stage 5)
+    { Timed t(c, RTX_K_RAYGEN); launch_rs_raygen(st, R.fq, q, cam, sample_id, row(0)); }
     { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, R.fq, sc, R.P[0], 0, nullptr, row(0), nullptr); }                    // camera rays (tmin 1e-4)
     { Timed t(c, RTX_K_SHADE); launch_rs_p1_ris(st, sc, R.fq, q, row(0), row(1), accum, res_di, res_gi, sdata); }
     { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, R.fq, sc, R.P[1], 1, nullptr, row(1), nullptr); }                    // the BSDF candidates of SampleRIS
-    { Timed t(c, RTX_K_SHADE); launch_rs_p1_ris_finish(st, sc, R.fq, q, row(1), row(2), row(4 + mb), res_di, sdata); }
-    { Timed t(c, RTX_K_SHADOW); launch_trace_occ(st, sc, q, row(4 + mb)); }                                                  // DI visibility
+    { Timed t(c, RTX_K_SHADE); launch_rs_p1_ris_finish(st, sc, R.fq, q, row(1), row(2), shrow, res_di, sdata); }
     { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, R.fq, sc, R.P[0], 1, nullptr, row(2), nullptr); }                    // first path vertex
     { Timed t(c, RTX_K_SHADE); launch_rs_p1_first(st, sc, R.fq, q, row(2), row(3)); }
     for (uint32_t i = 0; i < mb; i++) {
@@ -644,18 +646,9 @@ static int rs_pass1(rtx_ctx* c, const DevFrame& f, uint32_t sample_id, F4* accum
         { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, R.fq, sc, R.P[set], 1, nullptr, row(3 + i), nullptr); }
         { Timed t(c, RTX_K_SHADE); launch_rs_p1_loop(st, sc, R.fq, q, set, i, row(3 + i), row(4 + i)); }
     }
-    { Timed t(c, RTX_K_SHADE); launch_rs_p1_emit_final(st, sc, R.fq, q, row(5 + mb)); }
-    { Timed t(c, RTX_K_SHADOW); launch_trace_occ(st, sc, q, row(5 + mb)); }                                                  // the selected reconnection
-    { Timed t(c, RTX_K_SHADE); launch_rs_p1_finish(st, sc, R.fq, q, accum, res_di, res_gi, sdata); }
-    HIPCHK(c, hipGetLastError());
-    return RTX_OK;
-}
-static int rs_pass2(rtx_ctx* c, const DevFrame& f, uint32_t* const bufs[6], const uint32_t* pixels, uint32_t npixels) {
-    RsPlan R; int r = rs_plan(c, f, pixels ? npixels : f.npl, pixels, 1, R); if (r) return r;
-    const CameraGPU* cam = (const CameraGPU*)c->d_cam.p;
-    { Timed t(c, RTX_K_SHADE); launch_rs_p2_emit(c->stream, c->dsc, R.fq, R.q, cam, bufs, R.cnt); }
-    { Timed t(c, RTX_K_SHADOW); launch_trace_occ(c->stream, c->dsc, R.q, R.cnt); }
-    { Timed t(c, RTX_K_SHADE); launch_rs_p2_merge(c->stream, c->dsc, R.fq, R.q, cam, bufs); }
+    { Timed t(c, RTX_K_SHADE); launch_rs_p1_emit_final(st, sc, R.fq, q, cam, bufs, shrow); }
+    { Timed t(c, RTX_K_SHADOW); launch_trace_occ(st, sc, q, shrow); }                                                        // DI visibility, the selected reconnection, the temporal pass's two rays
+    { Timed t(c, RTX_K_SHADE); launch_rs_p1_finish(st, sc, R.fq, q, accum, res_di, res_gi, sdata, cam, bufs); }
     HIPCHK(c, hipGetLastError());
     return RTX_OK;
 }
@@ -697,7 +690,7 @@ int rtx_render_v6_pass1(rtx_ctx* c, const rtx_params* p) {
     HIPCHK(c, hipMemsetAsync(c->d_p1cnt.p, 0, 24, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_begin, c->stream));
     for (uint32_t s = 0; s < p->spp; s++) {
-        if (c->restir_wave) { if ((r = rs_pass1(c, f, p->sample_base + s, c->accum_ptr(), nullptr, 0))) return r; }
+        if (c->restir_wave) { if ((r = rs_pass1(c, f, p->sample_base + s, c->accum_ptr(), nullptr, 0, nullptr))) return r; }
         else { Timed t(c, RTX_K_BOUNCE);
                launch_v6_pass1(c->stream, (uint32_t)c->num_cus * 8u, c->dsc, f, (const CameraGPU*)c->d_cam.p, p->sample_base + s, c->accum_ptr(),
                                (uint32_t*)c->d_res_di.p, (uint32_t*)c->d_res_gi.p, (uint32_t*)c->d_sdata.p, (unsigned long long*)c->d_p1cnt.p); }
@@ -790,8 +783,7 @@ int rtx_render_restir(rtx_ctx* c, const rtx_params* p) {
         DevFrame ff = f; ff.frame_seed = p->frame_seed + fr;
         HIPCHK(c, hipMemsetAsync(scratch.p, 0, (size_t)p->width * p->height * 16, c->stream));
         if (c->restir_wave) {                                                                                                               // the three DispatchRays of Renderer.cpp:646-673 as wavefront stages
-            if ((r = rs_pass1(c, ff, 1u, (F4*)scratch.p, halo, nhalo))) return r;
-            if ((r = rs_pass2(c, ff, bufs, halo, nhalo))) return r;
+            if ((r = rs_pass1(c, ff, 1u, (F4*)scratch.p, halo, nhalo, bufs))) return r;              // passes 1 + 2
             if ((r = rs_pass3(c, ff, bufs, c->accum_ptr()))) return r;
         } else {                                                                                                                            // ... or literally, a thread per pixel
             { Timed t(c, RTX_K_BOUNCE); launch_v6_pass1(c->stream, mbk, c->dsc, ff, cam, 1u, (F4*)scratch.p, bufs[0], bufs[1], bufs[2], (unsigned long long*)c->d_p1cnt.p, halo, nhalo); }   // Renderer.cpp:651-654

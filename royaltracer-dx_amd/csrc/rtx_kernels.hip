@@ -1098,7 +1098,7 @@ void launch_trace_occ(hipStream_t st, const DevScene& sc, const RsQ& q, const ui
     if (sc.trace_sched == 6u && !sc.nsmall) RTX_LAUNCH_TO(6); else RTX_LAUNCH_TO(-1);
 #undef RTX_LAUNCH_TO
 }
-static inline RestirBufs rs_bufs(uint32_t* const b[6]) { return RestirBufs{b[0], b[1], b[2], b[3], b[4], b[5]}; }
+static inline RestirBufs rs_bufs(uint32_t* const* b) { return RestirBufs{b[0], b[1], b[2], b[3], b[4], b[5]}; }
 void launch_rs_raygen(hipStream_t st, const DevFrame& f, const RsQ& q, const CameraGPU* cam, uint32_t sample_id, uint32_t* cnt_out) {
     hipLaunchKernelGGL(k_rs_raygen, dim3(q.G), dim3(kBlock), 0, st, f, q, cam, sample_id, cnt_out);
 }
@@ -1114,17 +1114,11 @@ void launch_rs_p1_first(hipStream_t st, const DevScene& sc, const DevFrame& f, c
 void launch_rs_p1_loop(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, uint32_t set, uint32_t iter, const uint32_t* cnt_in, uint32_t* cnt_out) {
     hipLaunchKernelGGL(k_rs_p1_loop, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, set, iter, cnt_in, cnt_out);
 }
-void launch_rs_p1_emit_final(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, uint32_t* shcnt) {
-    hipLaunchKernelGGL(k_rs_p1_emit_final, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, shcnt);
+void launch_rs_p1_emit_final(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, const CameraGPU* cam, uint32_t* const* bufs, uint32_t* shcnt) {
+    hipLaunchKernelGGL(k_rs_p1_emit_final, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, cam, bufs ? rs_bufs(bufs) : RestirBufs{}, bufs ? 1u : 0u, shcnt);
 }
-void launch_rs_p1_finish(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, F4* accum, uint32_t* res_di, uint32_t* res_gi, uint32_t* sdata) {
-    hipLaunchKernelGGL(k_rs_p1_finish, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, accum, res_di, res_gi, sdata);
-}
-void launch_rs_p2_emit(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, const CameraGPU* cam, uint32_t* const bufs[6], uint32_t* shcnt) {
-    hipLaunchKernelGGL(k_rs_p2_emit, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, cam, rs_bufs(bufs), shcnt);
-}
-void launch_rs_p2_merge(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, const CameraGPU* cam, uint32_t* const bufs[6]) {
-    hipLaunchKernelGGL(k_rs_p2_merge, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, cam, rs_bufs(bufs));
+void launch_rs_p1_finish(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, F4* accum, uint32_t* res_di, uint32_t* res_gi, uint32_t* sdata, const CameraGPU* cam, uint32_t* const* bufs) {
+    hipLaunchKernelGGL(k_rs_p1_finish, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, accum, res_di, res_gi, sdata, cam, bufs ? rs_bufs(bufs) : RestirBufs{}, bufs ? 1u : 0u);
 }
 void launch_rs_p3_select(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, const CameraGPU* cam, uint32_t* const bufs[6], uint32_t* shcnt) {
     hipLaunchKernelGGL(k_rs_p3_select, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, cam, rs_bufs(bufs), shcnt);

@@ -131,10 +131,9 @@ void launch_rs_p1_ris(hipStream_t, const DevScene&, const DevFrame&, const RsQ&,
 void launch_rs_p1_ris_finish(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, const uint32_t* cnt_in, uint32_t* cnt_out, uint32_t* shcnt, uint32_t* res_di, uint32_t* sdata);
 void launch_rs_p1_first(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, const uint32_t* cnt_in, uint32_t* cnt_out);
 void launch_rs_p1_loop(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, uint32_t set, uint32_t iter, const uint32_t* cnt_in, uint32_t* cnt_out);
-void launch_rs_p1_emit_final(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, uint32_t* shcnt);
-void launch_rs_p1_finish(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, F4* accum, uint32_t* res_di, uint32_t* res_gi, uint32_t* sdata);
-void launch_rs_p2_emit(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, const CameraGPU* cam, uint32_t* const bufs[6], uint32_t* shcnt);
-void launch_rs_p2_merge(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, const CameraGPU* cam, uint32_t* const bufs[6]);
+// bufs != nullptr: a ReSTIR frame — the temporal pass (pass 2) of a pixel rides on these two stages (its rays join pass 1's shadow rays, its merge follows the pixel's finish)
+void launch_rs_p1_emit_final(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, const CameraGPU* cam, uint32_t* const* bufs, uint32_t* shcnt);
+void launch_rs_p1_finish(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, F4* accum, uint32_t* res_di, uint32_t* res_gi, uint32_t* sdata, const CameraGPU* cam, uint32_t* const* bufs);
 void launch_rs_p3_select(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, const CameraGPU* cam, uint32_t* const bufs[6], uint32_t* shcnt);
 void launch_rs_p3_merge(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, uint32_t* const bufs[6], uint32_t* shcnt);
 void launch_rs_p3_shade(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, uint32_t* const bufs[6], F4* accum);

@@ -484,12 +484,13 @@ struct RestirBufs { uint32_t *cur_di, *cur_gi, *cur_sd, *last_di, *last_gi, *las
 // ---- pass 2 (RayGen_v6_pass2.hlsl:46-204) in two parts: what the pixel reads and whether it merges at all (p2_gather), then the two pairwise-MIS merges (p2_merge).
 // Its visibility rays: k = 0 DI (x1 -> last frame's x2), k = 1 GI (x1 -> last frame's GI x2); each is cast iff the merge it belongs to runs.
 struct P2Pix { size_t slot; Res rc, gc, rl, gl; SData sd; bool acc_di, acc_gi; };
-__device__ __forceinline__ bool p2_gather(const DevScene& sc, const DevFrame& f, const CameraGPU& cam, const RestirBufs& B, uint32_t x, uint32_t y, P2Pix& I) {
+// with_cur = false: only what decides the rays is read (the wavefront emit stage runs before this frame's reservoirs of the pixel are complete)
+__device__ __forceinline__ bool p2_gather(const DevScene& sc, const DevFrame& f, const CameraGPU& cam, const RestirBufs& B, uint32_t x, uint32_t y, P2Pix& I, bool with_cur = true) {
     I.slot = map_pixel_id(f.width, x, y);
     I.sd = load_sd_dev(B.cur_sd + I.slot * 15);
     const SData& sd = I.sd;
     if (!(sd.L1.x == 0.0f && sd.L1.y == 0.0f && sd.L1.z == 0.0f) || sd.mID == 0xFFFEu || sd.mID >= sc.nmat) return false;
-    I.rc = load_res_dev(B.cur_di + I.slot * 10); I.gc = load_res_dev(B.cur_gi + I.slot * 10);
+    if (with_cur) { I.rc = load_res_dev(B.cur_di + I.slot * 10); I.gc = load_res_dev(B.cur_gi + I.slot * 10); }
     const f3 camo = mk3(cam.viewI[12], cam.viewI[13], cam.viewI[14]);
     int px, py;
     {   // GetBestReprojectedPixel_d, Sampler_v6.hlsl:738-785

@@ -10,7 +10,8 @@
 //     rare events (a reservoir selection) go straight to per-pixel records.
 // Pass 1 is a chain (its random-number stream runs through all of its rays): raygen | ris | ris_finish | first | loop x bounces | emit_final | finish.
 // Passes 2 and 3 need no carried state: a visibility ray there depends on buffer contents only, so an EMIT stage writes all rays of the pass, one launch traces
-// them into a byte per ray, and the merge stage — the same code as the literal kernel, p2_merge / p3_merge / p3_shade — looks the answers up.  Pass 3 has one
+// them into a byte per ray, and the merge stage — the same code as the literal kernel, p2_merge / p3_merge / p3_shade — looks the answers up.  Pass 2 rides on
+// pass 1's last two stages (its rays join pass 1's shadow rays in one traversal launch, its merge follows the pixel's finish in the same thread); pass 3 has one
 // dependent ray (the selected DI sample), hence select | merge | shade.
 // Per-pixel statement order, random-number order and arithmetic are those of rtx_restir.hpp (shared functions), so the six buffers and the image stay byte-equal
 // to the oracle's (tests/test_gpu_parity.py: every ReSTIR test runs both forms).
@@ -40,12 +41,12 @@ __device__ __forceinline__ void store_sdata_head(uint32_t* d, f3 x1, uint32_t mI
     d[5] = f2u(n1.x); d[6] = f2u(n1.y); d[7] = f2u(n1.z); d[8] = f2u(ov.x); d[9] = f2u(ov.y); d[10] = f2u(ov.z);
     d[11] = objID;
 }
-// end of a stage kernel: publish the sub-queue length(s) and the ray statistics (one atomic per workgroup and class)
-__device__ __forceinline__ void rs_publish(uint32_t* cnt_out, const uint32_t* s_n, uint32_t* shcnt, const uint32_t* s_rn, const RsQ& q, int ray_class) {
+// end of a stage kernel: publish the sub-queue length(s) and the ray statistics (one atomic per workgroup and class); ray_base: entries the ray sub-queue held before this launch
+__device__ __forceinline__ void rs_publish(uint32_t* cnt_out, const uint32_t* s_n, uint32_t* shcnt, const uint32_t* s_rn, const RsQ& q, int ray_class, uint32_t ray_base = 0u) {
     __syncthreads();
     if (threadIdx.x == 0) {
         if (cnt_out) { cnt_out[blockIdx.x] = *s_n; if (*s_n) atomicAdd(&q.rays[ray_class], (unsigned long long)*s_n); }
-        if (shcnt) { shcnt[blockIdx.x] = *s_rn; if (*s_rn) atomicAdd(&q.rays[2], (unsigned long long)*s_rn); }
+        if (shcnt) { shcnt[blockIdx.x] = *s_rn; if (*s_rn > ray_base) atomicAdd(&q.rays[2], (unsigned long long)(*s_rn - ray_base)); }
     }
 }
 
@@ -133,7 +134,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_ris(DevScene sc, DevFrame f
 }
 
 // stage 2: the BSDF candidate's hit closes SampleRIS: the DI reservoir and the pixel's sample record are written, the DI visibility ray goes to the ray queue
-// (it only decides whether W becomes 0: applied by k_rs_p1_finish), and the path sampler's first BSDF ray starts (set 1 -> set 0)
+// (it only decides whether W becomes 0, which k_rs_p1_finish applies: it is traced later, together with the rays of k_rs_p1_emit_final), and the path sampler's first
+// BSDF ray starts (set 1 -> set 0)
 __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_ris_finish(DevScene sc, DevFrame f, RsQ q, const uint32_t* __restrict__ cnt_in, uint32_t* __restrict__ cnt_out, uint32_t* __restrict__ shcnt,
                                                                 uint32_t* __restrict__ res_di, uint32_t* __restrict__ sdata) {
     __shared__ uint32_t s_n, s_rn;
@@ -277,29 +279,54 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_loop(DevScene sc, DevFrame 
     rs_publish(cnt_out, &s_n, nullptr, nullptr, q, 1);
 }
 
-// stage 5: the shadow ray of the selected reconnection (Path_Sampler_v6.hlsl:271-283), for every pixel that sampled
-__global__ __launch_bounds__(kBlock) void k_rs_p1_emit_final(DevScene sc, DevFrame f, RsQ q, uint32_t* __restrict__ shcnt) {
+// stage 5: the shadow ray of the selected reconnection (Path_Sampler_v6.hlsl:271-283), for every pixel that sampled — appended to the DI visibility rays of stage 2
+// (the ray sub-queues are workgroup-private and a pixel stays with its workgroup, so the counter simply continues).  In a ReSTIR frame (with_p2) the two visibility
+// rays of the TEMPORAL pass join them: they depend on this frame's primary hit (written by stages 1 / 2) and on last frame's records only, so all four rays of a
+// pixel are traversed by ONE persistent launch.  Occlusion bytes of a pixel: 0 DI, 1 GI reconnection, 2 / 3 temporal DI / GI.
+__global__ __launch_bounds__(kBlock, 4) void k_rs_p1_emit_final(DevScene sc, DevFrame f, RsQ q, const CameraGPU* __restrict__ cam_p, RestirBufs B, uint32_t with_p2, uint32_t* __restrict__ shcnt) {
+    __shared__ CameraGPU cam;
     __shared__ uint32_t s_rn;
-    if (threadIdx.x == 0) s_rn = 0;
+    if (threadIdx.x < 64) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
+    const uint32_t ray_base = shcnt[blockIdx.x];
+    if (threadIdx.x == 0) s_rn = ray_base;
     __syncthreads();
     const uint32_t nee = sc.nlights ? f.nee_samples : 0u;
     const uint32_t nchunks = (q.nitems + kBlock - 1) / kBlock;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const uint32_t it = c * kBlock + threadIdx.x;
-        bool cast = false; F4 so = {0, 0, 0, 0}, sd = {0, 0, 1, 0};
+        bool cast = false, r0 = false, r1 = false;
+        F4 so = {0, 0, 0, 0}, sd = {0, 0, 1, 0}, so0 = so, sd0 = sd, so1 = so, sd1 = sd;
         uint32_t x, y;
-        if (it < q.nitems && rs_item_pixel(f, q, it, x, y) && q.cls[it]) {
-            const F4 a = q.cold[(size_t)2 * q.nitems + it], b = q.cold[(size_t)3 * q.nitems + it];
-            cast = gi_final_ray(nee, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), so, sd);
+        if (it < q.nitems && rs_item_pixel(f, q, it, x, y)) {
+            if (q.cls[it]) {
+                const F4 a = q.cold[(size_t)2 * q.nitems + it], b = q.cold[(size_t)3 * q.nitems + it];
+                cast = gi_final_ray(nee, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), so, sd);
+            }
+            if (with_p2) {
+                P2Pix I;
+                if (p2_gather(sc, f, cam, B, x, y, I, false)) {
+                    r0 = I.acc_di; r1 = I.acc_gi;
+                    if (r0) vis_ray(I.sd.x1, I.sd.n1, I.rl.x2, so0, sd0);
+                    if (r1) vis_ray(I.sd.x1, I.sd.n1, I.gl.x2, so1, sd1);
+                }
+            }
         }
         rs_push_ray(q, &s_rn, cast, so, sd, it * kRsOcc + 1u);
+        if (with_p2) {                                                  // (uniform)
+            rs_push_ray(q, &s_rn, r0, so0, sd0, it * kRsOcc + 2u);
+            rs_push_ray(q, &s_rn, r1, so1, sd1, it * kRsOcc + 3u);
+        }
     }
-    rs_publish(nullptr, nullptr, shcnt, &s_rn, q, 1);
+    rs_publish(nullptr, nullptr, shcnt, &s_rn, q, 1, ray_base);
 }
 
-// stage 6: both visibility answers are in: W of the DI reservoir, w_sum / W of the GI reservoir, the pixel's estimate (pass1:140-190)
+// stage 6: the visibility answers are in: W of the DI reservoir, w_sum / W of the GI reservoir, the pixel's estimate (pass1:140-190) — and, in a ReSTIR frame
+// (with_p2), the pixel's TEMPORAL pass right behind it (RayGen_v6_pass2.hlsl:46-204: it reads this pixel's own pass-1 records and last frame's buffers only)
 __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_finish(DevScene sc, DevFrame f, RsQ q, F4* __restrict__ accum, uint32_t* __restrict__ res_di, uint32_t* __restrict__ res_gi,
-                                                            uint32_t* __restrict__ sdata) {
+                                                            uint32_t* __restrict__ sdata, const CameraGPU* __restrict__ cam_p, RestirBufs B, uint32_t with_p2) {
+    __shared__ CameraGPU cam;
+    if (threadIdx.x < 64) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
+    __syncthreads();
     const uint32_t nee = sc.nlights ? f.nee_samples : 0u;
     const uint32_t nchunks = (q.nitems + kBlock - 1) / kBlock;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
@@ -307,74 +334,36 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_finish(DevScene sc, DevFram
         uint32_t x, y;
         if (!(it < q.nitems) || !rs_item_pixel(f, q, it, x, y)) continue;
         const uint32_t cl = q.cls[it];
-        if (!cl) continue;
-        const MatGPU& m = sc.mats[cl - 1u];
-        const size_t slot = map_pixel_id(f.width, x, y);
-        const uint32_t* sp = sdata + slot * 15;
-        const f3 x1 = mk3(u2f(sp[0]), u2f(sp[1]), u2f(sp[2])), n1 = mk3(u2f(sp[5]), u2f(sp[6]), u2f(sp[7])), ov = mk3(u2f(sp[8]), u2f(sp[9]), u2f(sp[10]));
-        Res rdi = load_res_dev(res_di + slot * 10);
         const uint8_t* oc = q.occ + (size_t)it * kRsOcc;
-        if (oc[0]) { rdi.W = 0.0f; res_di[slot * 10 + 7] = 0u; }
-        const F4 fv = q.fin[it], c0 = q.cold[it], c1 = q.cold[(size_t)q.nitems + it], c2 = q.cold[(size_t)2 * q.nitems + it], c3 = q.cold[(size_t)3 * q.nitems + it], c4 = q.cold[(size_t)4 * q.nitems + it];
-        Res rgi = zero_res();
-        rgi.w_sum = fv.w; rgi.L2 = mk3(c4.x, c4.y, c4.z);
-        if (c4.w != 0.0f) { rgi.x2 = mk3(c0.x, c0.y, c0.z); rgi.n2 = normalize(mk3(c1.x, c1.y, c1.z)); }
-        F4 so, sd;
-        if (gi_final_ray(nee, mk3(c2.x, c2.y, c2.z), mk3(c3.x, c3.y, c3.z), so, sd)) {
-            if (oc[1]) rgi.w_sum *= 0.0f;
-            else rgi.w_sum *= 1.0f;
-        }
-        f3 debug = mk3(fv.x, fv.y, fv.z);
-        const f3 rc = reconnect_di_dev(m, f.flags, x1, n1, rdi.x2, rdi.n2, rdi.L2, ov);
-        debug = debug + rc * rdi.W;
-        gi_finish(m, f.flags, x1, n1, ov, rgi);
-        store_res(res_gi + slot * 10, rgi);
-        uint32_t* d = sdata + slot * 15;
-        d[12] = f2u(debug.x); d[13] = f2u(debug.y); d[14] = f2u(debug.z);
-        rs_accumulate(accum, f.width, x, y, debug);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------------------------
-// PASS 2 (RayGen_v6_pass2.hlsl:46-204): emit | trace | merge
-// ---------------------------------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock, 4) void k_rs_p2_emit(DevScene sc, DevFrame f, RsQ q, const CameraGPU* __restrict__ cam_p, RestirBufs B, uint32_t* __restrict__ shcnt) {
-    __shared__ CameraGPU cam;
-    __shared__ uint32_t s_rn;
-    if (threadIdx.x < 64) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
-    if (threadIdx.x == 0) s_rn = 0;
-    __syncthreads();
-    const uint32_t nchunks = (q.nitems + kBlock - 1) / kBlock;
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        const uint32_t it = c * kBlock + threadIdx.x;
-        bool r0 = false, r1 = false;
-        F4 so0 = {0, 0, 0, 0}, sd0 = {0, 0, 1, 0}, so1 = so0, sd1 = sd0;
-        uint32_t x, y;
-        if (it < q.nitems && rs_item_pixel(f, q, it, x, y)) {
-            P2Pix I;
-            if (p2_gather(sc, f, cam, B, x, y, I)) {
-                r0 = I.acc_di; r1 = I.acc_gi;
-                if (r0) vis_ray(I.sd.x1, I.sd.n1, I.rl.x2, so0, sd0);
-                if (r1) vis_ray(I.sd.x1, I.sd.n1, I.gl.x2, so1, sd1);
+        if (cl) {
+            const MatGPU& m = sc.mats[cl - 1u];
+            const size_t slot = map_pixel_id(f.width, x, y);
+            const uint32_t* sp = sdata + slot * 15;
+            const f3 x1 = mk3(u2f(sp[0]), u2f(sp[1]), u2f(sp[2])), n1 = mk3(u2f(sp[5]), u2f(sp[6]), u2f(sp[7])), ov = mk3(u2f(sp[8]), u2f(sp[9]), u2f(sp[10]));
+            Res rdi = load_res_dev(res_di + slot * 10);
+            if (oc[0]) { rdi.W = 0.0f; res_di[slot * 10 + 7] = 0u; }
+            const F4 fv = q.fin[it], c0 = q.cold[it], c1 = q.cold[(size_t)q.nitems + it], c2 = q.cold[(size_t)2 * q.nitems + it], c3 = q.cold[(size_t)3 * q.nitems + it], c4 = q.cold[(size_t)4 * q.nitems + it];
+            Res rgi = zero_res();
+            rgi.w_sum = fv.w; rgi.L2 = mk3(c4.x, c4.y, c4.z);
+            if (c4.w != 0.0f) { rgi.x2 = mk3(c0.x, c0.y, c0.z); rgi.n2 = normalize(mk3(c1.x, c1.y, c1.z)); }
+            F4 so, sd;
+            if (gi_final_ray(nee, mk3(c2.x, c2.y, c2.z), mk3(c3.x, c3.y, c3.z), so, sd)) {
+                if (oc[1]) rgi.w_sum *= 0.0f;
+                else rgi.w_sum *= 1.0f;
             }
+            f3 debug = mk3(fv.x, fv.y, fv.z);
+            const f3 rc = reconnect_di_dev(m, f.flags, x1, n1, rdi.x2, rdi.n2, rdi.L2, ov);
+            debug = debug + rc * rdi.W;
+            gi_finish(m, f.flags, x1, n1, ov, rgi);
+            store_res(res_gi + slot * 10, rgi);
+            uint32_t* d = sdata + slot * 15;
+            d[12] = f2u(debug.x); d[13] = f2u(debug.y); d[14] = f2u(debug.z);
+            rs_accumulate(accum, f.width, x, y, debug);
         }
-        rs_push_ray(q, &s_rn, r0, so0, sd0, it * kRsOcc + 0u);
-        rs_push_ray(q, &s_rn, r1, so1, sd1, it * kRsOcc + 1u);
-    }
-    rs_publish(nullptr, nullptr, shcnt, &s_rn, q, 1);
-}
-__global__ __launch_bounds__(kBlock, 4) void k_rs_p2_merge(DevScene sc, DevFrame f, RsQ q, const CameraGPU* __restrict__ cam_p, RestirBufs B) {
-    __shared__ CameraGPU cam;
-    if (threadIdx.x < 64) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
-    __syncthreads();
-    const uint32_t nchunks = (q.nitems + kBlock - 1) / kBlock;
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        const uint32_t it = c * kBlock + threadIdx.x;
-        uint32_t x, y;
-        if (!(it < q.nitems) || !rs_item_pixel(f, q, it, x, y)) continue;
-        P2Pix I;
-        if (!p2_gather(sc, f, cam, B, x, y, I)) continue;
-        p2_merge(sc, f, B, x, y, I, VisLookup{q.occ + (size_t)it * kRsOcc});
+        if (with_p2) {                                                  // every pixel, as the literal pass does (a pixel that sampled nothing leaves at p2_gather's first test)
+            P2Pix I;
+            if (p2_gather(sc, f, cam, B, x, y, I, true)) p2_merge(sc, f, B, x, y, I, VisLookup{oc + 2});
+        }
     }
 }
 

@@ -130,6 +130,55 @@ void MultiGpuFrame::Render(const rtx_params& p0) {
     m_lastMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
+void MultiGpuFrame::RenderRestir(const rtx_params& p0) {
+    const int n = (int)m->ctx.size();
+    rtx_params probe = p0; probe.shard_rank = 0; probe.shard_count = (uint32_t)n;
+    size_t bytes = 0, sbytes = 0;
+    if (rtx_shard_slab_bytes(&probe, &bytes) != RTX_OK || rtx_restir_state_slab_bytes(&probe, &sbytes) != RTX_OK) throw std::runtime_error(std::string("slab bytes: ") + rtx_last_error(nullptr));
+    if (n > 1) { EnsureSlabs(m->slab, m->gathered, m->slab_bytes, bytes); EnsureSlabs(m->state_slab, m->state_gathered, m->state_bytes, sbytes); }
+    m_w = p0.width; m_h = p0.height;
+    std::vector<std::string> err(n);
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int r = 0; r < n; r++) th.emplace_back([&, r] {            // phase 1: the three passes on my tiles, then both packs enqueued behind them
+        try {
+            hipck(hipSetDevice(m_devices[r]), "hipSetDevice");
+            rtx_params p = p0; p.shard_rank = (uint32_t)r; p.shard_count = (uint32_t)n;
+            if (rtx_render_restir(m->ctx[r], &p) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));
+            (void)rtx_get_stats(m->ctx[r], &m_stats[r]);
+            if (n > 1 && (rtx_restir_pack_state(m->ctx[r], &p, m->state_slab[r]) != RTX_OK || rtx_pack_tiles(m->ctx[r], &p, m->slab[r]) != RTX_OK)) throw std::runtime_error(rtx_last_error(m->ctx[r]));
+        } catch (const std::exception& e) { err[r] = e.what(); }
+    });
+    for (auto& t : th) t.join();
+    for (auto& e : err) if (!e.empty()) throw std::runtime_error("MultiGpuFrame::RenderRestir: " + e);
+    if (n > 1) {
+        if (m_gather == Gather::RCCL) {                                 // phase 2: the frame's ONE exchange: history + framebuffer tiles in one group
+            ncclck(ncclGroupStart(), "ncclGroupStart");
+            for (int r = 0; r < n; r++) {
+                ncclck(ncclAllGather(m->state_slab[r], m->state_gathered[r], sbytes / sizeof(float), ncclFloat, m->comm[r], m->stream[r]), "ncclAllGather state");
+                ncclck(ncclAllGather(m->slab[r], m->gathered[r], bytes / sizeof(float), ncclFloat, m->comm[r], m->stream[r]), "ncclAllGather tiles");
+            }
+            ncclck(ncclGroupEnd(), "ncclGroupEnd");
+        } else { AllGather(m->state_slab, m->state_gathered, sbytes); AllGather(m->slab, m->gathered, bytes); }
+        for (int r = 0; r < n; r++) {                                   // phase 3: scatter both, stream-ordered behind the gathers
+            rtx_params p = p0; p.shard_rank = (uint32_t)r; p.shard_count = (uint32_t)n;
+            hipck(hipSetDevice(m_devices[r]), "hipSetDevice");
+            if (rtx_restir_unpack_state(m->ctx[r], &p, m->state_gathered[r]) != RTX_OK || rtx_unpack_tiles(m->ctx[r], &p, m->gathered[r]) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));
+        }
+        for (int r = 0; r < n; r++) { hipck(hipSetDevice(m_devices[r]), "hipSetDevice"); hipck(hipStreamSynchronize(m->stream[r]), "sync frame"); }
+    }
+    m_lastMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+void MultiGpuFrame::SetCamera(const float view[16], const float proj[16]) {
+    for (size_t r = 0; r < m->ctx.size(); r++) { hipck(hipSetDevice(m_devices[r]), "hipSetDevice"); if (rtx_set_camera(m->ctx[r], view, proj) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r])); }
+}
+void MultiGpuFrame::ResetRestir() {
+    for (size_t r = 0; r < m->ctx.size(); r++) { hipck(hipSetDevice(m_devices[r]), "hipSetDevice"); if (rtx_restir_reset(m->ctx[r]) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r])); }
+}
+void MultiGpuFrame::SetOption(int option, int64_t value) {
+    for (size_t r = 0; r < m->ctx.size(); r++) if (rtx_set_option(m->ctx[r], option, value) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));
+}
+
 void MultiGpuFrame::Clear(uint32_t w, uint32_t h) {
     for (size_t r = 0; r < m->ctx.size(); r++) { hipck(hipSetDevice(m_devices[r]), "hipSetDevice"); if (rtx_clear_accum(m->ctx[r], w, h) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r])); }
     m_w = w; m_h = h;

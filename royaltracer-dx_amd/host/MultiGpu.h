@@ -1,5 +1,5 @@
 // MultiGpu.h — the native N-GPU frame of the C++ host layer (SURVEY 8(e), §5 last row): ONE process, one rtx_ctx per GPU, pixel tiles dealt round-robin
-// (tile t -> rank t mod N), every rank renders its tiles, packs them into a slab (rtx_pack_tiles) and the frame ends with ONE all-gather of the slabs
+// (tile t -> rank t mod N; with RTX_FLAG_BLOCK_TILES in the params one rectangle of tiles per rank), every rank renders its tiles, packs them into a slab (rtx_pack_tiles) and the frame ends with ONE all-gather of the slabs
 // over xGMI followed by rtx_unpack_tiles.  Nothing is exchanged inside the frame.  The reference is single-GPU (one device, one command queue:
 // Renderer.cpp:106-254); where its Renderer::PopulateCommandList issues the frame (Renderer.cpp:646-673) a maintainer calls MultiGpuFrame::Render.
 //
@@ -20,6 +20,13 @@ public:
     void SetScene(const Scene& s, float aspect);          // replicated on every GPU (Bistro-class: 0.4 GB << 288 GB)
     // one frame: p.shard_rank / shard_count are filled per rank; the assembled accumulation buffer ends up on EVERY rank (all-gather)
     void Render(const rtx_params& p);
+    // one frame of the reference's ReSTIR pipeline on N shards: every rank runs rtx_render_restir on its tiles (passes 1 + 2 on the tiles dilated by
+    // the 20-px spatial radius, pass 3 on its own), then ONE group of collectives ends the frame: the all-gather of the history records of the own tiles (u3 / u5 / u7,
+    // 140 B per pixel: the next frame's temporal pass reprojects to arbitrary pixels) and the all-gather of the framebuffer tiles.  p.spp must be 1.
+    void RenderRestir(const rtx_params& p);
+    void SetCamera(const float view[16], const float proj[16]);   // every rank (rtx_set_camera keeps the previous matrices for the reprojection)
+    void ResetRestir();                                   // forget the ReSTIR history on every rank
+    void SetOption(int option, int64_t value);            // rtx_set_option on every rank
     void Clear(uint32_t width, uint32_t height);          // zero every rank's accumulation buffer (view-change reset)
     std::vector<float> ReadAccumulation(int rank = 0);
     std::vector<uint8_t> ReadOutput(int rank = 0);

@@ -10,6 +10,9 @@ Renderer::Renderer(UINT width, UINT height, std::string name) : m_width(width), 
     m_params.spp = 1; m_params.sample_base = 1;
     m_params.max_bounces = 8; m_params.nee_samples = 1; m_params.rr_start = 3;     // rr_threshold = 3, RayGen.hlsl:69
     m_params.frame_seed = 0; m_params.flags = 0; m_params.tile_size = 64; m_params.shard_rank = 0; m_params.shard_count = 1;
+    m_restir = m_params;
+    m_restir.spp = 1;                                                               // one frame per OnRender
+    m_restir.nee_samples = 4; m_restir.max_bounces = 3;                             // nee_samples / nee_samples_DI = 4, bounces = 3 (Common_v6.hlsl:8-12)
 }
 Renderer::~Renderer() { OnDestroy(); }
 
@@ -56,6 +59,12 @@ void Renderer::OnUpdate() {
 }
 
 void Renderer::OnRender() {
+    if (m_mode == Mode::ReSTIR) {                                                   // PopulateCommandList: DispatchRays x 3 (Renderer.cpp:646-673)
+        m_restir.width = m_width; m_restir.height = m_height;
+        m_restir.frame_seed = m_time;
+        Check(rtx_render_restir(m_ctx, &m_restir), "rtx_render_restir");
+        return;
+    }
     m_params.frame_seed = m_time;                                                   // stands in for uint(time), Renderer.cpp:1754-1760
     Check(rtx_render(m_ctx, &m_params), "rtx_render");
 }

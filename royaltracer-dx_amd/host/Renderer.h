@@ -16,6 +16,13 @@ public:
     void SetScene(const Scene& s) { m_scene = s; m_haveScene = true; }
     void SetDevice(int ordinal) { m_device = ordinal; }
     rtx_params& Params() { return m_params; }
+    // What OnRender issues.  ReSTIR = the reference's shipping frame, its three DispatchRays (Renderer.cpp:646-673: RayGen = pass 1, RayGen2 = temporal reuse,
+    // RayGen3 = spatial reuse + shade) with its shader defines nee_samples 4 / bounces 3 (Common_v6.hlsl:8-12) unless RestirParams() is changed; one frame per
+    // OnRender, history carried in the context.  PathTracer (the default of this headless build) = Params().spp samples of the bounce-loop estimator.
+    enum class Mode { PathTracer, ReSTIR };
+    void SetMode(Mode m) { m_mode = m; }
+    Mode GetMode() const { return m_mode; }
+    rtx_params& RestirParams() { return m_restir; }
 
     void OnInit();      // Renderer.cpp:44-103: camera lookat, load models, build acceleration structures, upload
     void OnUpdate();    // Renderer.cpp:431-452: camera buffer, instance 1 rotation, instance properties
@@ -40,7 +47,8 @@ private:
     Scene m_scene; bool m_haveScene = false;
     int m_device = 0;
     rtx_ctx* m_ctx = nullptr;
-    rtx_params m_params{};
+    rtx_params m_params{}, m_restir{};
+    Mode m_mode = Mode::PathTracer;
     uint32_t m_time = 0;                             // Renderer.h: m_time
     UINT m_currentDisplayLevel = 0;                  // Renderer.h:298
     std::vector<UINT> m_displayLevels = {0, 10, 11, 12, 13, 14, 15, 16, 17, 20, 21, 22, 23, 24, 25, 26, 27, 28};   // Renderer.h:299

@@ -295,6 +295,12 @@ rtxh_renderer* rtxh_renderer_create(uint32_t w, uint32_t h, const char* name, in
 }
 int rtxh_renderer_set_scene(rtxh_renderer* r, const rtxh_scene* s) { r->r->SetScene(s->s); return RTX_OK; }
 rtx_params* rtxh_renderer_params(rtxh_renderer* r) { return &r->r->Params(); }
+int rtxh_renderer_set_mode(rtxh_renderer* r, int mode) {
+    if (mode != 0 && mode != 1) { g_err = "renderer mode must be 0 (path tracer) or 1 (ReSTIR frame)"; return RTX_ERR_INVALID; }
+    r->r->SetMode(mode ? Renderer::Mode::ReSTIR : Renderer::Mode::PathTracer); return RTX_OK;
+}
+rtx_params* rtxh_renderer_restir_params(rtxh_renderer* r) { return &r->r->RestirParams(); }
+rtx_ctx* rtxh_renderer_context(rtxh_renderer* r) { return r->r->Context(); }
 int rtxh_renderer_on_init(rtxh_renderer* r) { return guarded_rc([&] { r->r->OnInit(); }); }
 int rtxh_renderer_on_update(rtxh_renderer* r) { return guarded_rc([&] { r->r->OnUpdate(); }); }
 int rtxh_renderer_on_render(rtxh_renderer* r) { return guarded_rc([&] { r->r->OnRender(); }); }

@@ -1,13 +1,19 @@
 // rtx_render — headless CLI over the Renderer facade (replaces the Win32 window loop, Main.cpp:18-27).
 // usage: rtx_render [--scene cornell|sponza|bistro|obj] [--obj a.obj,b.obj --mtl dir] [--w 1920 --h 1080]
 //                   [--spp 64] [--frames 1] [--bounces 8] [--nee 1] [--lambert] [--out image.{png,ppm,exr}] [--device 0]
+//                   [--mode pt|restir]   restir = the reference's shipping frame (3 DispatchRays, Renderer.cpp:646-673: pass 1 + temporal + spatial reuse), one per --frames,
+//                   nee 4 / bounces 3 as in Common_v6.hlsl:8-12 unless --nee / --bounces are given; with --gpus N the shards own one tile rectangle each (RTX_FLAG_BLOCK_TILES,
+//                   32-px tiles) and exchange history + framebuffer tiles once per frame; [--literal] = the thread-per-pixel kernels instead of the wavefront stages;
+//                   [--orbit deg] moves the camera about the look-at point between frames (exercises the reprojection)
 //                   [--gpus N [--devices 0,1,..] [--gather rccl|copy]]   the native N-GPU frame (MultiGpu.h): one process, N contexts, pixel tiles
 //                   round-robin, ONE RCCL all-gather per frame; `--gather copy` replaces the collective by device copies (several ranks on one GPU: tests)
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <stdexcept>
 #include <string>
 #include "Renderer.h"
 #include "ImageIO.h"
@@ -16,16 +22,26 @@
 int main(int argc, char** argv) {
     std::string scene = "cornell", out, objs, mtl = "./";
     UINT w = 1920, h = 1080, spp = 1, frames = 1, bounces = 8, nee = 1; int device = 0; bool lambert = false;
-    int gpus = 1; std::string devlist, gather = "rccl";
+    int gpus = 1; std::string devlist, gather = "rccl", mode = "pt"; bool literal = false, nee_set = false, bounces_set = false; float orbit = 0.0f;
     for (int i = 1; i < argc; i++) {
         auto arg = [&](const char* k) { return !strcmp(argv[i], k) && i + 1 < argc; };
         if (arg("--scene")) scene = argv[++i]; else if (arg("--obj")) { objs = argv[++i]; scene = "obj"; } else if (arg("--mtl")) mtl = argv[++i];
         else if (arg("--w")) w = atoi(argv[++i]); else if (arg("--h")) h = atoi(argv[++i]); else if (arg("--spp")) spp = atoi(argv[++i]);
-        else if (arg("--frames")) frames = atoi(argv[++i]); else if (arg("--bounces")) bounces = atoi(argv[++i]); else if (arg("--nee")) nee = atoi(argv[++i]);
+        else if (arg("--frames")) frames = atoi(argv[++i]); else if (arg("--bounces")) { bounces = atoi(argv[++i]); bounces_set = true; } else if (arg("--nee")) { nee = atoi(argv[++i]); nee_set = true; }
+        else if (arg("--mode")) mode = argv[++i]; else if (arg("--orbit")) orbit = (float)atof(argv[++i]); else if (!strcmp(argv[i], "--literal")) literal = true;
         else if (arg("--gpus")) gpus = atoi(argv[++i]); else if (arg("--devices")) devlist = argv[++i]; else if (arg("--gather")) gather = argv[++i];
         else if (arg("--out")) out = argv[++i]; else if (arg("--device")) device = atoi(argv[++i]); else if (!strcmp(argv[i], "--lambert")) lambert = true;
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
+    if (mode != "pt" && mode != "restir") { fprintf(stderr, "--mode must be pt or restir\n"); return 2; }
+    const bool restir = mode == "restir";
+    if (restir) { if (!nee_set) nee = 4; if (!bounces_set) bounces = 3; }
+    // camera of frame f: the scene's eye rotated by f * orbit degrees about the vertical axis through the look-at point
+    auto orbit_eye = [&](const Scene& sc, UINT f) {
+        const float a = orbit * 3.14159265f / 180.0f * (float)f, cs = cosf(a), sn = sinf(a);
+        const float dx = sc.eye.x - sc.center.x, dz = sc.eye.z - sc.center.z;
+        return XMFLOAT3(sc.center.x + cs * dx + sn * dz, sc.eye.y, sc.center.z - sn * dx + cs * dz);
+    };
     auto write_image = [&](const std::vector<float>& acc, const std::vector<uint8_t>& px) {
         const bool exr = out.size() > 4 && out.substr(out.size() - 4) == ".exr", png = out.size() > 4 && out.substr(out.size() - 4) == ".png";
         return exr ? WriteEXR(out, acc.data(), w, h) : png ? WritePNG(out, px.data(), w, h) : WritePPM(out, px.data(), w, h);
@@ -44,9 +60,21 @@ int main(int argc, char** argv) {
             mg.Clear(w, h);
             rtx_params p{}; p.width = w; p.height = h; p.spp = spp; p.max_bounces = bounces; p.nee_samples = nee; p.rr_start = 3; p.tile_size = 64;
             p.flags = lambert ? RTX_FLAG_LAMBERT_ONLY : (scene == "bistro" ? RTX_FLAG_TRANSMISSION : 0);
+            if (restir) { p.spp = 1; p.flags = (lambert ? RTX_FLAG_LAMBERT_ONLY : 0u) | RTX_FLAG_BLOCK_TILES; p.tile_size = 32; mg.SetOption(RTX_OPT_RESTIR_WAVEFRONT, literal ? 0 : 1); mg.ResetRestir(); }
+            float prev_view[16] = {0};
             for (UINT f = 0; f < frames; f++) {
                 p.sample_base = 1 + f * spp; p.frame_seed = f + 1;
-                mg.Render(p);
+                if (restir) {
+                    nv_helpers_dx12::Manipulator cam; cam.setLookat(orbit_eye(sc, f), sc.center, sc.up);
+                    XMMATRIX proj = XMMatrixPerspectiveFovRH(sc.fovY_deg * XM_PI / 180.0f, (float)w / (float)h, sc.zn, sc.zf);
+                    mg.SetCamera(cam.getMatrix(), proj.data());
+                    if (f == 0) mg.SetCamera(cam.getMatrix(), proj.data());            // previous view = current view for the first frame
+                    bool moved = false;                                                // the reference's accumulation reset (RayGen_v6_pass3.hlsl:407-423), as Renderer::UpdateCameraBuffer applies it
+                    for (int k = 0; k < 16 && f > 0; k++) moved = moved || fabsf(cam.getMatrix()[k] - prev_view[k]) > 0.00002f;
+                    if (moved) mg.Clear(w, h);
+                    memcpy(prev_view, cam.getMatrix(), 64);
+                    mg.RenderRestir(p);
+                } else mg.Render(p);
                 double rays = 0; for (int r = 0; r < gpus; r++) { rtx_stats s = mg.Stats(r); rays += (double)(s.rays_primary + s.rays_extension + s.rays_shadow); }
                 printf("frame %u on %d GPUs: %.3f ms (gather included), %.1f Mrays/s\n", f, gpus, mg.LastFrameMs(), rays / (mg.LastFrameMs() * 1e3));
             }
@@ -62,8 +90,15 @@ int main(int argc, char** argv) {
         else if (scene == "bistro") r.SetScene(MakeBistroClass());
         else { std::vector<std::string> f; std::stringstream ss(objs); std::string t; while (std::getline(ss, t, ',')) f.push_back(t); r.SetModels(f, mtl); }
         r.Params().spp = spp; r.Params().max_bounces = bounces; r.Params().nee_samples = nee; r.Params().flags = lambert ? RTX_FLAG_LAMBERT_ONLY : (scene == "bistro" ? RTX_FLAG_TRANSMISSION : 0);
+        if (restir) {
+            r.SetMode(Renderer::Mode::ReSTIR);
+            r.RestirParams().nee_samples = nee; r.RestirParams().max_bounces = bounces; r.RestirParams().flags = lambert ? RTX_FLAG_LAMBERT_ONLY : 0u;
+        }
         r.OnInit();
+        if (restir && rtx_set_option(r.Context(), RTX_OPT_RESTIR_WAVEFRONT, literal ? 0 : 1) != RTX_OK) throw std::runtime_error(rtx_last_error(r.Context()));
+        XMFLOAT3 eye0, ctr0, up0; nv_helpers_dx12::CameraManip.getLookat(eye0, ctr0, up0);
         for (UINT f = 0; f < frames; f++) {
+            if (orbit != 0.0f) { Scene tmp; tmp.eye = eye0; tmp.center = ctr0; tmp.up = up0; nv_helpers_dx12::CameraManip.setLookat(orbit_eye(tmp, f), ctr0, up0); }
             r.OnUpdate(); r.Params().sample_base = 1 + f * spp; r.OnRender();
             rtx_stats s = r.Stats();
             double rays = (double)(s.rays_primary + s.rays_extension + s.rays_shadow);

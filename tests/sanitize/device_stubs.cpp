@@ -14,6 +14,7 @@ int rtx_commit_scene(rtx_ctx*) { return RTX_ERR_NO_DEVICE; }
 int rtx_set_camera(rtx_ctx*, const float*, const float*) { return RTX_ERR_NO_DEVICE; }
 int rtx_clear_accum(rtx_ctx*, uint32_t, uint32_t) { return RTX_ERR_NO_DEVICE; }
 int rtx_render(rtx_ctx*, const rtx_params*) { return RTX_ERR_NO_DEVICE; }
+int rtx_render_restir(rtx_ctx*, const rtx_params*) { return RTX_ERR_NO_DEVICE; }
 int rtx_read_accum(rtx_ctx*, float*, size_t) { return RTX_ERR_NO_DEVICE; }
 int rtx_read_srgb8(rtx_ctx*, uint8_t*, size_t) { return RTX_ERR_NO_DEVICE; }
 int rtx_get_stats(rtx_ctx*, rtx_stats*) { return RTX_ERR_NO_DEVICE; }
