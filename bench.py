@@ -34,13 +34,13 @@ import __graft_entry__ as graft  # noqa: E402   (does not import torch)
 # shade's write.  Primary rays are priced like extension rays (their ray + state are written by raygen: 64 B of the 224).
 B_EXT, B_SHADOW, B_PIX = 224.0, 96.0, 32.0
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-# VALU roofline: what fraction of the SIMD-cycles of the launch had a VALU instruction in flight (4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs x
-# GRBM_GUI_ACTIVE / 8), tools/pmc_summary.py: "valu_pipe_util").  There is no single instruction-count peak on gfx950 — measured with
-# tools/valu_peak.hip (profiles/r02_valu_peak.md): a wave64 VOP3 fma / mul / add occupies its SIMD for 2.3 cycles, a VOP2-encoded mul / add /
-# logic op for 3.0-3.1, everything else (min / max / cvt / cmp / cndmask / bfe / packed f16) for 4.2, v_pk_fma_f32 for 4.0, rcp / rsq / sqrt for
-# 8.1 — so the busy fraction is the roofline figure, and lanes / 64 says how much of that work is useful.
-PMC_PROFILE = {"cornell_1080p_64spp_8b": "r02_pmc_cornell.json", "sponza_1080p_16spp_8b": "r02_pmc_sponza.json",
-               "bistro_1080p_16spp_8b": "r02_pmc_bistro.json"}     # tools/pmc_run.sh + tools/pmc_summary.py of this same command
+# COMPUTE roofline (the fused tiny-scene kernels and the BVH traversal are VALU-bound, not HBM-bound): VALU instructions per SIMD-cycle of the kernel divided by what a
+# SATURATED REPLAY LOOP of the kernel's own instruction-class mix reaches on this chip (tools/gen_mix.py + tools/valu_peak.hip, 8 waves / SIMD) — a fraction that cannot
+# exceed 1 by construction.  (Round 2 reported 4 * SQ_ACTIVE_INST_VALU / SIMD-cycles, which read 1.05-1.10: that counter charges every VALU instruction 4 cycles, while
+# v_fma_f32 / VOP2 integer ops take 2.3 / 3.0; and per-opcode costs do not add up either — profiles/r03_valu_calib.md — so the peak of a mix has to be measured.)
+# The counters come from tracked profiles/r03_roof_<workload>.json (tools/roofline_run.sh: separate rocprofv3 --pmc passes of this command); each file carries the hash
+# of the kernel sources it was recorded with, and a profile that no longer matches the loaded kernels is reported as stale instead of being priced.
+ROOF_PROFILE = {"cornell_1080p_64spp_8b": "r03_roof_cornell.json", "sponza_1080p_16spp_8b": "r03_roof_sponza.json", "bistro_1080p_16spp_8b": "r03_roof_bistro.json"}
 KERNEL_SYMBOL = {"bounce_fused": ("k_bounce_small", "k_bounce_bvh"), "trace_closest": ("k_trace_closest",), "shade": ("k_shade",),
                  "trace_shadow": ("k_trace_shadow",), "accumulate": ("k_accumulate",), "raygen": ("k_raygen", "k_raygen_trace_small")}
 
@@ -55,19 +55,32 @@ WORKLOADS = {
 EXTRA_WORKLOADS = ("sponza_1080p_16spp_8b", "bistro_1080p_16spp_8b")    # the general BVH path, timed beside the headline (GPU only)
 
 
+ASSETS = {"sponza": "sponza.obj", "bistro": "bistro.obj"}       # SURVEY 8(d) / BASELINE.md: the real asset if it lies under assets/, else the procedural stand-in of its class
+
+
+def asset_path(kind):
+    f = ASSETS.get(kind)
+    for d in (os.environ.get("RTX_ASSETS", ""), os.path.join(ROOT, "assets")):
+        if f and d and os.path.isfile(os.path.join(d, f)):
+            return os.path.join(d, f)
+    return None
+
+
 def make_scene(rt, kind):
+    """-> (scene, source description).  Sponza / Bistro: assets/<name>.obj through the OBJ / MTL reader (ObjLoader::loadObjFile, as the reference loads its models:
+    Renderer.cpp:363-370), looked at from the asset's own bounding box; without the file, the deterministic procedural scene of that class."""
     if kind == "cornell":
-        return rt.Scene.cornell()
+        return rt.Scene.cornell(), "generated: Cornell Box (32 triangles, 2 emissive)"
+    a = asset_path(kind)
+    if a:
+        sc = rt.Scene.from_obj([a], os.path.dirname(a) + "/")
+        sc.frame_bounds()                                     # camera inside / in front of the model's bounding box (an OBJ file carries no camera)
+        return sc, f"asset: {os.path.relpath(a, ROOT)} ({sc.num_triangles} triangles)"
     if kind == "sponza":
-        return rt.Scene.sponza_class()
+        return rt.Scene.sponza_class(), "generated: Sponza-class procedural atrium (no assets/sponza.obj)"
     if kind == "bistro":
-        return rt.Scene.bistro_class()
+        return rt.Scene.bistro_class(), "generated: Bistro-class procedural street (no assets/bistro.obj)"
     raise ValueError(kind)
-
-
-def scene_name(kind):
-    return {"cornell": "Cornell Box (32 triangles, 2 emissive)", "sponza": "Sponza-class procedural atrium",
-            "bistro": "Bistro-class procedural street"}[kind]
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -106,20 +119,31 @@ def spawn_ranks(n, argv):
     return worst
 
 
+def kernel_source_hash():
+    """hash of the kernel sources (tools/valu_calib.py writes the same into a profile): tells whether a tracked counter profile still describes the loaded kernels"""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "royaltracer-dx_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_pmc(workload):
-    """rows of tools/pmc_summary.py (list of per-kernel dicts) from the tracked profile of this workload, or None"""
-    f = PMC_PROFILE.get(workload)
+    """-> (kernel rows, source string, stale flag) from the tracked counter profile of this workload, or (None, None, None)"""
+    f = ROOF_PROFILE.get(workload)
     if not f:
-        return None, None
-    path = os.path.join(ROOT, "profiles", f)
+        return None, None, None
     try:
-        return json.load(open(path)), "profiles/" + f
+        d = json.load(open(os.path.join(ROOT, "profiles", f)))
     except Exception:
-        return None, None
+        return None, None, None
+    return d["kernels"], "profiles/" + f, d.get("kernel_source_sha") != kernel_source_hash()
 
 
 def pmc_for(rows, cls):
-    """sum the template instantiations of one kernel class: -> dict(valu_inst_per_launch, lanes_per_valu, hbm_bytes_per_launch) or None"""
+    """sum the template instantiations of one kernel class"""
     if not rows:
         return None
     sel = [r for r in rows if r["kernel"].split("<")[0] in KERNEL_SYMBOL.get(cls, ())]
@@ -128,9 +152,13 @@ def pmc_for(rows, cls):
     launches = sum(r["launches"] for r in sel)
     valu = sum(r["valu_inst"] for r in sel)
     lanes = sum((r.get("lanes_per_valu") or 0.0) * r["valu_inst"] for r in sel) / valu if valu else None
-    cyc = sum(r.get("gpu_cycles") or 0.0 for r in sel)
-    busy = sum((r.get("valu_pipe_util") or 0.0) * (r.get("gpu_cycles") or 0.0) for r in sel) / cyc if cyc else None
-    return {"launches": launches, "valu_inst_per_launch": valu / launches, "lanes_per_valu": lanes, "valu_busy": busy,
+    # compute fraction of the class = instruction-weighted mean over the instantiations that have a replay peak
+    wf = [(r["compute_frac"], r["valu_inst"], r["inst_per_simd_cycle"], r["compute_peak_inst_per_simd_cycle"]) for r in sel if r.get("compute_frac") is not None]
+    wsum = sum(w for _, w, _, _ in wf)
+    return {"launches": launches, "valu_inst_per_launch": valu / launches, "lanes_per_valu": lanes,
+            "compute_frac": sum(f * w for f, w, _, _ in wf) / wsum if wsum else None,
+            "inst_per_simd_cycle": sum(a * w for _, w, a, _ in wf) / wsum if wsum else None,
+            "peak_inst_per_simd_cycle": sum(pk * w for _, w, _, pk in wf) / wsum if wsum else None,
             "hbm_bytes_per_launch": sum(r["hbm_bytes"] for r in sel) / launches}
 
 
@@ -158,32 +186,33 @@ def roofline_record(rt, workload, kms, kitems, klaunch, rays, n_pixel_samples, s
     avg_ms = kms[k] / launches
     bytes_per_launch = alg / launches
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    rows, src = load_pmc(workload)
-    pm = pmc_for(rows, name)
+    rows, src, stale = load_pmc(workload)
+    pm = pmc_for(rows, name) if not stale else None
     traffic = round(pm["hbm_bytes_per_launch"]) if pm else None
     roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-            "traffic_source": (src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2*FETCH+WRITE KiB; not measured in this run)") if pm else None,
+            "traffic_source": ((src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2*FETCH+WRITE KiB; not measured in this run)") if pm else
+                               (src + ": STALE (recorded with other kernel sources) - not used" if stale else None)),
             "alg_bytes_per_launch": round(bytes_per_launch), "alg_bytes_model": "224*N_ext + 96*N_shadow (+ 32*N_px*spp for the frame)",
             "avg_launch_ms": round(avg_ms, 5), "launches": int(klaunch[k]),
             "kernel_ms_by_class": {rt.KERNEL_NAMES[i]: round(float(kms[i]), 3) for i in rt.KERNEL_NAMES if klaunch[i] > 0}}
-    # whole frame, all kernels: the figure BASELINE.md quotes
+    # whole frame, all kernels, SURVEY 8(d): bytes_alg = 224*N_ext + 96*N_shadow + 32*N_px*spp (primary rays are not priced: their state is part of the first extension ray's 224 B)
     frame_ms = float(kms.sum()) / max(steps, 1)
-    frame_alg = (B_EXT * (n_ext + n_prim) + B_SHADOW * n_sh + B_PIX * n_pixel_samples) / max(steps, 1)
+    frame_alg = (B_EXT * n_ext + B_SHADOW * n_sh + B_PIX * n_pixel_samples) / max(steps, 1)
     roof["frame"] = {"alg_bytes": round(frame_alg), "kernel_ms": round(frame_ms, 4),
                      "frac": round(frame_alg / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if frame_ms > 0 else None}
     if pm and traffic:
         roof["traffic_frac"] = round(pm["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)   # measured HBM bytes / live launch time
-    if pm and pm["valu_inst_per_launch"]:
-        ach = pm["valu_inst_per_launch"] / (avg_ms * 1e-3) / 1e9
-        roof["compute"] = {"valu_busy_frac": round(pm["valu_busy"], 4) if pm["valu_busy"] is not None else None,
+    if pm and pm["compute_frac"] is not None:
+        roof["compute"] = {"frac": round(pm["compute_frac"], 4), "unit": "VALU instructions per SIMD-cycle",
+                           "achieved": round(pm["inst_per_simd_cycle"], 4), "peak": round(pm["peak_inst_per_simd_cycle"], 4),
                            "lanes_per_inst": round(pm["lanes_per_valu"], 2) if pm["lanes_per_valu"] else None,
-                           "frac_valu_lanes": round(pm["valu_busy"] * (pm["lanes_per_valu"] or 64.0) / 64.0, 4) if pm["valu_busy"] is not None else None,
-                           "valu_inst_per_launch": round(pm["valu_inst_per_launch"]), "achieved_ginst_s": round(ach, 2),
-                           "model": "valu_busy_frac = 4*SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE/8): SIMD-cycles with a VALU instruction in flight; "
-                                    "frac_valu_lanes = that x active lanes / 64",
-                           "source": src + " (counters of a separate rocprofv3 --pmc run of this command; instruction rate uses this run's launch time)"}
-        if (pm["valu_busy"] or 0.0) > max(roof["frac"], roof.get("traffic_frac", 0.0)):
+                           "frac_x_lanes": round(pm["compute_frac"] * (pm["lanes_per_valu"] or 64.0) / 64.0, 4),
+                           "valu_inst_per_launch": round(pm["valu_inst_per_launch"]),
+                           "model": "peak = what a saturated replay loop of this kernel's own instruction-class mix issues on this chip (tools/gen_mix.py, tools/valu_peak.hip); "
+                                    "achieved = SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of the kernel; frac_x_lanes = frac x active lanes / 64",
+                           "source": src + " (counters of separate rocprofv3 --pmc runs of this command, same kernel sources as loaded)"}
+        if pm["compute_frac"] > max(roof["frac"], roof.get("traffic_frac", 0.0)):
             roof["bound"] = "valu"
     return roof
 
@@ -192,7 +221,7 @@ def time_extra(rt, dev_index, workload, steps=2):
     """one BVH workload, GPU only: warm-up + `steps` timed frames on a context of its own -> small record for the JSON line"""
     import torch
     kind, W, H, spp, bounces, nee, flags = WORKLOADS[workload]
-    scene = make_scene(rt, kind)
+    scene, source = make_scene(rt, kind)
     ctx = rt.Context(dev_index)
     try:
         ctx.upload(scene, W / H)
@@ -218,15 +247,63 @@ def time_extra(rt, dev_index, workload, steps=2):
             rays += np.array([st.rays_primary, st.rays_extension, st.rays_shadow], dtype=np.float64)
         dt_timed = time.perf_counter() - t1
         roof = roofline_record(rt, workload, kms, None, kl, rays, float(W) * H * spp * steps, steps)
-        rec = {"ms_per_frame": round(dt * 1e3 / steps, 3), "Mrays_s": round(float(rays.sum()) / dt / 1e6, 1), "triangles": int(scene.num_triangles),
+        rec = {"ms_per_frame": round(dt * 1e3 / steps, 3), "Mrays_s": round(float(rays.sum()) / dt / 1e6, 1), "triangles": int(scene.num_triangles), "scene": source,
                "rays_per_frame": int(rays.sum() / steps), "dominant_kernel": roof["kernel"] if roof else None,
                "frac": roof["frac"] if roof else None, "bound": roof["bound"] if roof else None,
-               "valu_busy_frac": roof.get("compute", {}).get("valu_busy_frac") if roof else None,
+               "compute_frac": roof.get("compute", {}).get("frac") if roof else None,
                "lanes_per_inst": roof.get("compute", {}).get("lanes_per_inst") if roof else None,
                "kernel_ms_per_frame": {k: round(v / steps, 3) for k, v in roof["kernel_ms_by_class"].items()} if roof else None,
                "ms_per_frame_kernels_timed": round(dt_timed * 1e3 / steps, 3),
                "note": "ms_per_frame / Mrays_s: kernel timing off (shadow rays of bounce b overlap the closest-hit rays of bounce b + 1); kernel_ms_per_frame, frac: a second pass with per-kernel HIP events, which runs the launches one after the other"}
         return rec
+    finally:
+        ctx.close()
+
+
+RESTIR_EXTRAS = {"restir_garage_1080p": "garage", "restir_atrium_1080p": "sponza"}     # the reference's shipping frame (3 DispatchRays: pass 1 + temporal + spatial reuse)
+
+
+def time_restir(rt, dev_index, kind, frames=6):
+    """The reference's own frame — rtx_render_restir: pass 1 + temporal + spatial reuse with its defines nee 4 / bounces 3 (Common_v6.hlsl:8-12) — at 1920x1080 on the
+    reference's start-up scene (garage.obj + monke.obj, Renderer.cpp:363) or the Sponza-class atrium: ms per frame once the history is warm, rays by type, and the
+    per-class kernel times of the wavefront stages (raygen / trace_closest = persistent closest-hit launches / shade = the stage kernels / trace_shadow = persistent
+    any-hit launches).  `frac` prices the dominant class like the path tracer's separate kernels: 48 B per ray of a traversal launch."""
+    import torch
+    W, H = 1920, 1080
+    gd = os.path.join(ROOT, "tests", "golden")
+    if kind == "garage":
+        scene, source = rt.Scene.from_obj([os.path.join(gd, "garage.obj"), os.path.join(gd, "monke.obj")], gd + "/"), "tests/golden/garage.obj + monke.obj (the reference's start-up scene)"
+    else:
+        scene, source = make_scene(rt, kind)
+    ctx = rt.Context(dev_index)
+    try:
+        ctx.upload(scene, W / H)
+        vp = scene.view_proj(W / H)
+        ctx.set_camera(*vp); ctx.set_camera(*vp)
+        ctx.restir_reset(); ctx.clear(W, H)
+        p = rt.Params(width=W, height=H, spp=1, max_bounces=3, nee_samples=4, flags=0)
+        for f in range(2):
+            ctx.render_restir(p.copy(frame_seed=1 + f))          # allocations + a history for the temporal pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for f in range(frames):
+            ctx.render_restir(p.copy(frame_seed=3 + f))
+        dt = time.perf_counter() - t0
+        ctx.set_option(rt.OPT_KERNEL_TIMING, 1)
+        kms = np.zeros(rt.K_COUNT); rays = np.zeros(3)
+        for f in range(frames):
+            ctx.render_restir(p.copy(frame_seed=3 + frames + f))
+            st = ctx.stats()
+            kms += np.array(st.kernel_ms[:]); rays += np.array([st.rays_primary, st.rays_extension, st.rays_shadow], dtype=np.float64)
+        by = {rt.KERNEL_NAMES[i]: float(kms[i]) / frames for i in rt.KERNEL_NAMES if kms[i] > 0}
+        dom = max(by, key=by.get) if by else None
+        nray = {"trace_closest": rays[0] + rays[1], "trace_shadow": rays[2]}.get(dom)
+        frac = (48.0 * nray / frames) / (by[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS if nray else None
+        return {"ms_per_frame": round(dt * 1e3 / frames, 3), "Mrays_s": round(float(rays.sum()) / frames / (dt / frames) / 1e6, 1), "triangles": int(scene.num_triangles), "scene": source,
+                "rays_per_frame": {"primary": int(rays[0] / frames), "extension": int(rays[1] / frames), "shadow": int(rays[2] / frames)},
+                "kernel_ms_per_frame": {k: round(v, 3) for k, v in by.items()}, "dominant_kernel": dom, "frac": round(frac, 5) if frac else None,
+                "form": "wavefront stages (csrc/rtx_restir_wave.hpp); RTX_OPT_RESTIR_WAVEFRONT=0 is the thread-per-pixel form",
+                "params": "1920x1080, nee_samples 4, bounces 3, 1 frame per step, history warm"}
     finally:
         ctx.close()
 
@@ -269,7 +346,7 @@ def main():
         dist, rank, world = sharding.init_process_group(args.dist_backend, dev)     # backend "nccl" is RCCL on ROCm
         ranks_seen = dist.get_world_size()
     kind, W, H, spp, bounces, nee, flags = WORKLOADS[args.workload]
-    scene = make_scene(rt, kind)
+    scene, scene_source = make_scene(rt, kind)
     ctx = rt.Context(dev_index)
     for kv in args.opt:                      # tuning knobs must be set before the scene is committed
         k, v = kv.split("=")
@@ -353,6 +430,11 @@ def main():
                     extra[wl] = time_extra(rt, dev_index, wl)
                 except Exception as e:                       # the headline line must survive a failing extra
                     extra[wl] = {"error": str(e)[:200]}
+            for name, k in RESTIR_EXTRAS.items():            # the reference's shipping frame (ReSTIR DI + GI), ~1 s each
+                try:
+                    extra[name] = time_restir(rt, dev_index, k)
+                except Exception as e:
+                    extra[name] = {"error": str(e)[:200]}
         # ---- CPU baseline: the oracle (a port of the reference's shader math) on this host's cores ----
         cpu = None
         if not args.no_cpu_baseline and world == 1:
@@ -384,7 +466,7 @@ def main():
                "ms_per_step": round(ms_per_step, 3), "ms_per_step_by_rank": [round(t * 1e3 / max(args.steps, 1), 3) for t in dt_ranks],
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
-               "config": {"workload": args.workload, "scene": scene_name(kind), "width": W, "height": H, "spp": spp,
+               "config": {"workload": args.workload, "scene": scene_source, "width": W, "height": H, "spp": spp,
                           "max_bounces": bounces, "nee_samples": nee, "rr_start": 3, "flags": flags,
                           "triangles": int(scene.num_triangles), "parallelism": f"pixel-tiles/{world}", "tile_size": 64,
                           "rays_per_frame": {"primary": int(rays_all[0] / max(args.steps, 1)), "extension": int(rays_all[1] / max(args.steps, 1)),

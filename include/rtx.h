@@ -96,6 +96,10 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
        RTX_OPT_RESTIR_WAVEFRONT = 19,/* 1 (default): rtx_render_v6_pass1 / rtx_render_restir run as wavefront stages (csrc/rtx_restir_wave.hpp: stage kernels of <= 128 VGPRs, every
                                         ray traversed by the persistent kernels of the path tracer); 0: the literal form, one thread per pixel and pass like the reference's raygen
                                         shaders (csrc/rtx_restir.hpp).  Byte-identical buffers and images either way */
+       RTX_OPT_OCCLUDER_CACHE = 21,  /* 1: in the persistent any-hit traversal a lane first tests the triangle that occluded its previous ray (neighbouring queue entries are neighbouring
+                                        pixels aiming at the same light / sample).  Any-hit is existence, so results are identical — and it is MEASURED SLOWER (same box, alternating:
+                                        k_trace_shadow 11.63 -> 12.23 ms on C3, 10.21 -> 10.48 on C5, ReSTIR frames +1 %): the extra triangle step per ray costs more than
+                                        the early exits save.  Default 0 */
        RTX_OPT_RESTIR_CHUNKS = 20,   /* tuning: 256-pixel chunks per workgroup (= private sub-queue) of the ReSTIR stages, default 4 */
        RTX_OPT_OVERLAP_SHADOW = 18,  /* 1 (default): general scenes run the shadow-ray kernel of bounce b on a second (internal) stream beside the closest-hit kernel of
                                         bounce b + 1; everything is joined into the context's stream before rtx_render returns.  Off while RTX_OPT_KERNEL_TIMING is on

@@ -49,6 +49,7 @@ int         rtxh_scene_instance(const rtxh_scene*, uint32_t i, uint32_t* mesh, f
 uint64_t    rtxh_scene_num_triangles(const rtxh_scene*);
 /* eye[3], center[3], up[3], fovY in degrees, znear, zfar (Renderer.cpp:46-48, 1730-1731) */
 int         rtxh_scene_camera(const rtxh_scene*, float eye[3], float center[3], float up[3], float* fovy_deg, float* zn, float* zf);
+int         rtxh_scene_set_camera(rtxh_scene*, const float eye[3], const float center[3], const float up[3]);   /* CameraManip.setLookat of the scene (Renderer.cpp:46-48); an OBJ file carries no camera */
 /* view (Manipulator::setLookat -> getMatrix) and projection (XMMatrixPerspectiveFovRH) for an aspect ratio */
 int         rtxh_scene_view_proj(const rtxh_scene*, float aspect, float view[16], float proj[16]);
 /* rtx_set_materials / rtx_add_mesh / rtx_add_instance / rtx_commit_scene / rtx_set_camera */

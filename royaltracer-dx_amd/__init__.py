@@ -39,7 +39,7 @@ K_RAYGEN, K_TRACE, K_SHADE, K_SHADOW, K_ACCUM, K_SORT, K_BOUNCE, K_COUNT = 0, 1,
 KERNEL_NAMES = {K_RAYGEN: "raygen", K_TRACE: "trace_closest", K_SHADE: "shade", K_SHADOW: "trace_shadow", K_ACCUM: "accumulate", K_SORT: "sort", K_BOUNCE: "bounce_fused"}
 OPT_KERNEL_TIMING, OPT_PATHS_PER_BATCH, OPT_SORT_MATERIALS, OPT_LDS_NODES, OPT_SMALL_SCENE, OPT_FUSED_BOUNCE, OPT_BOUNCE_VARIANT = 1, 2, 3, 4, 5, 6, 7
 OPT_REFILL_MIN, OPT_STACK_PRIVATE, OPT_TRACE_SCHED, OPT_GPU_REFIT, OPT_BLOCKS_PER_CU, OPT_LPT_ORDER, OPT_FUSED_BVH, OPT_WORK_STEALING, OPT_COMPACT_STATE, OPT_OVERLAP_SHADOW = 8, 9, 10, 11, 12, 13, 14, 15, 16, 18
-OPT_RESTIR_WAVEFRONT, OPT_RESTIR_CHUNKS = 19, 20
+OPT_RESTIR_WAVEFRONT, OPT_RESTIR_CHUNKS, OPT_OCCLUDER_CACHE = 19, 20, 21
 
 
 class RtxError(RuntimeError):
@@ -172,6 +172,7 @@ _sig("rtxh_write_png", C.c_int, C.c_char_p, _vp, _u32, _u32)
 _sig("rtxh_write_ppm", C.c_int, C.c_char_p, _vp, _u32, _u32)
 _sig("rtxh_write_exr", C.c_int, C.c_char_p, _vp, _u32, _u32)
 _sig("rtxh_scene_small_records", C.c_int, _vp, _vp, _vp, _u32, _u32p, _fp, _fp)
+_sig("rtxh_scene_set_camera", C.c_int, _vp, _fp, _fp, _fp)
 _sig("rtxh_renderer_create", _vp, _u32, _u32, C.c_char_p, C.c_int)
 _sig("rtxh_renderer_set_scene", C.c_int, _vp, _vp)
 _sig("rtxh_renderer_params", C.POINTER(Params), _vp)
@@ -264,6 +265,33 @@ class Scene:
     def from_obj(cls, files, mtl_dir):
         arr = (C.c_char_p * len(files))(*[f.encode() for f in files])
         return cls(lib.rtxh_scene_from_obj(arr, len(files), mtl_dir.encode()))
+
+    def set_camera(self, eye, center, up=(0.0, 1.0, 0.0)):
+        e, c, u = (np.asarray(v, np.float32) for v in (eye, center, up))
+        lib.rtxh_scene_set_camera(self._h, _fptr(e), _fptr(c), _fptr(u))
+        self.eye, self.center, self.up = e, c, u
+
+    def bounds(self):
+        """world-space bounding box of all instances -> (lo, hi)"""
+        lo, hi = np.full(3, np.inf, np.float32), np.full(3, -np.inf, np.float32)
+        for mesh, m in self.instances:
+            v = self.meshes[mesh][0][:, :3]
+            if len(v):
+                M = np.asarray(m, np.float32).reshape(4, 4)              # column-major 16 floats: element (r, c) at m[c * 4 + r]
+                w = v @ M[:3, :3] + M[3, :3]
+                lo, hi = np.minimum(lo, w.min(0)), np.maximum(hi, w.max(0))
+        return lo, hi
+
+    def frame_bounds(self):
+        """camera for a model that brings none (an OBJ asset): inside the bounding box at 40 % of its height, 35 % of the way in from one end of its longer horizontal
+        axis, looking along that axis (Sponza: down the nave)"""
+        lo, hi = self.bounds()
+        c, ext = (lo + hi) * 0.5, hi - lo
+        ax = 0 if ext[0] >= ext[2] else 2
+        eye, ctr = c.copy(), c.copy()
+        eye[1] = ctr[1] = lo[1] + 0.4 * ext[1]
+        eye[ax] = c[ax] - 0.35 * ext[ax]
+        self.set_camera(eye, ctr)
 
     def save(self, path):
         """write the binary scene cache: this scene + its BVH / shading records / LUTs (built on the host, no GPU needed)"""

@@ -40,7 +40,7 @@ struct rtx_ctx {
     DevBuf d_nodes, d_tris, d_small, d_small_tris, d_small_poly, d_shade, d_mats, d_insts, d_lights, d_cam;
     DevBuf d_objtris, d_node_aabb, d_scale;          // GPU refit: object-space vertices (uploaded on first use), per-node float boxes, max |coordinate|
     bool gpu_refit = true, device_scene_valid = false, objtris_uploaded = false;
-    uint32_t refill_min = 12, trace_sched = 6, sort_materials = 0, blocks_per_cu = 0 /* 0 = auto */;       // persistent-traversal knobs (RTX_OPT_REFILL_MIN, RTX_OPT_TRACE_SCHED)
+    uint32_t refill_min = 12, trace_sched = 6, sort_materials = 0, blocks_per_cu = 0 /* 0 = auto */, occluder_cache = 0;       // persistent-traversal knobs (RTX_OPT_REFILL_MIN, RTX_OPT_TRACE_SCHED)
     DevScene dsc{};
     float view[16], proj[16];
     // path state
@@ -155,6 +155,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_OVERLAP_SHADOW: c->overlap_shadow = value != 0; return RTX_OK;
     case RTX_OPT_BLOCKS_PER_CU: if (value < 0 || value > 64) { c->err = "blocks_per_cu must be in [0, 64]"; return RTX_ERR_INVALID; } c->blocks_per_cu = (uint32_t)value; return RTX_OK;
     case RTX_OPT_GPU_REFIT: c->gpu_refit = value != 0; return RTX_OK;
+    case RTX_OPT_OCCLUDER_CACHE: c->occluder_cache = value != 0; c->dsc.occluder_cache = c->occluder_cache; return RTX_OK;
     case RTX_OPT_RESTIR_WAVEFRONT: c->restir_wave = value != 0; return RTX_OK;
     case RTX_OPT_RESTIR_CHUNKS: if (value < 1 || value > 64) { c->err = "restir_chunks must be in [1, 64]"; return RTX_ERR_INVALID; } c->restir_chunks = (uint32_t)value; return RTX_OK;
     case RTX_OPT_TRACE_SCHED: if (value > 7) { c->err = "trace_sched must be in [0, 7]"; return RTX_ERR_INVALID; } c->trace_sched = (uint32_t)value; c->dsc.trace_sched = c->trace_sched; return RTX_OK;
@@ -294,7 +295,7 @@ static int finalise_scene(rtx_ctx* c) {
     uint32_t want_tris = s.ntris <= 256 ? s.ntris : 0u;                    // triangles only when ALL of them fit
     s.lds_tris = (size_t)want_tris * 48 <= budget ? want_tris : 0u;
     s.nsmall = 0; s.nsmall_occ = 0;
-    s.refill_min = c->refill_min; s.trace_sched = c->trace_sched; s.sort_materials = c->sort_materials;
+    s.refill_min = c->refill_min; s.trace_sched = c->trace_sched; s.sort_materials = c->sort_materials; s.occluder_cache = c->occluder_cache;
     if (c->small_scene && B.small_nrec && B.small_tris.size() * 48 <= budget + (size_t)s.lds_tris * 48) {
         s.nsmall = B.small_nrec; s.nsmall_occ = B.small_nocc; s.lds_tris = (uint32_t)B.small_tris.size();   // LDS holds the records' triangles instead of the leaf-ordered ones
     }

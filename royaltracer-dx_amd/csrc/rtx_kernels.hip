@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_shadow(DevSce
     auto fetch = [&](uint32_t q, uint32_t idx) {
         const uint32_t gi = q * qcap + idx;                               // (< 2^32: the batch cap)
         const F4 so = sh_o[gi], sd = sh_d[gi];
-        ray_begin(R, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, gi, false);
+        ray_begin(R, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, gi, false, sc.occluder_cache != 0u);
     };
     while (STEAL ? refill_steal(R, W, drained, refill_min, rng, fetch) : refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) { fetch(blockIdx.x, idx); })) {
         if (SCHED >= 5) spec_step<true>(sc, L, R, stk, (uint32_t)SCHED);

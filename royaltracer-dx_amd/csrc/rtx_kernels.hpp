@@ -24,6 +24,7 @@ struct DevScene {
     uint32_t stack_private;         // queue kernels: 0 = stack in the LDS column, 1 = private (scratch) array
     uint32_t sort_materials;        // 1 = material-sorted shading in k_shade (general path; tuning knob, default 0)
     uint32_t refill_min, trace_sched;   // persistent traversal: idle lanes that trigger a refill; wave schedule (rtx_kernels.hip)
+    uint32_t occluder_cache;            // any-hit rays: a lane tests the triangle that occluded its previous ray first (rtx_traverse.hpp: ray_begin)
 };
 
 // one sample batch of one frame

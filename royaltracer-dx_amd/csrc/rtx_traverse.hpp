@@ -494,12 +494,14 @@ constexpr int kPend = RTX_PEND;
 static_assert(kPend >= 2 && kPend <= 4, "RTX_PEND");
 struct RayLane {                                       // per-lane traversal state
     f3 o, d, idir; float tmin, tmax, bt, bu, bv; uint32_t bprim; uint32_t oct; Grp G; TriGrp T, P[kPend - 1]; int sp; uint32_t item; bool has, done;   // P: pending triangle groups behind T (speculative schedule)
+    uint32_t occluder;       // any-hit rays: slot of the triangle that occluded this lane's previous occluded ray (kNoOccluder: none yet), see ray_begin
 };
+constexpr uint32_t kNoOccluder = 0xFFFFFFFFu;
 __device__ __forceinline__ void pend_clear(RayLane& R) {
 #pragma unroll
     for (int i = 0; i < kPend - 1; i++) R.P[i] = TriGrp{0u, 0u, 0u};
 }
-__device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, float tmax, uint32_t item, bool ordered) {
+__device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, float tmax, uint32_t item, bool ordered, bool occluder_cache = false) {
     R.o = o; R.d = d; R.tmin = tmin; R.tmax = tmax; R.item = item;
     const float dxs = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
     const float dys = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
@@ -508,10 +510,19 @@ __device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, fl
     R.oct = ray_octant(R.idir);
     R.bt = tmax; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.sp = 0; R.has = true; R.done = false;
     R.G = Grp{0u, (ordered ? (1u << R.oct) : 1u) | (1u << 8)}; R.T = TriGrp{0u, 0u, 0u}; pend_clear(R);
+    // OCCLUDER CACHE (any-hit rays).  A lane's consecutive rays come from neighbouring queue entries — shadow rays of neighbouring pixels towards the same light, or
+    // visibility rays between neighbouring ReSTIR samples — and what blocked the last one often blocks the next.  So the lane's last occluder is handed to the new
+    // ray as its first triangle group: it is tested by the first triangle step the wave takes, and a hit ends the ray before (most of) its traversal.  Any-hit is
+    // existence, so the answer cannot change; a miss costs one triangle test.  (The slot persists in R.occluder across rays; spec_step records it on a hit.)
+    // MEASURED (round 3, same box, alternating, RTX_OPT_OCCLUDER_CACHE 0 / 1): slower everywhere — k_trace_shadow 11.63 -> 12.23 ms per frame on C3, 10.21 -> 10.48 on C5,
+    // the ReSTIR frames (27 M visibility rays at 1080p) 9.69 -> 9.79 ms on the atrium: too few rays are blocked by the SAME triangle as their queue neighbour, and the
+    // extra triangle step every ray now starts with runs at the triangle steps' low lane count.  Off by default; the knob stays as the measured alternative.
+    if (occluder_cache && R.occluder != kNoOccluder) R.T = TriGrp{R.occluder, 1u, 1u};
 }
 __device__ __forceinline__ void ray_idle(RayLane& R) {
     R.has = false; R.done = false; R.sp = 0; R.item = 0; R.o = mk3(0, 0, 0); R.d = mk3(0, 0, 1); R.idir = mk3(0, 0, 1); R.oct = 0;
     R.tmin = 0.0f; R.tmax = 0.0f; R.bt = 0.0f; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.G = Grp{0u, 0u}; R.T = TriGrp{0u, 0u, 0u}; pend_clear(R);
+    R.occluder = kNoOccluder;
 }
 // after a node step or a finished triangle group: continue with the node's own internal hits, else pop, else done
 template <class STK>
@@ -559,7 +570,7 @@ __device__ __forceinline__ bool tri_candidate(const DevScene& sc, const TraceLds
     if (slot < sc.lds_tris) { const lds_v4f* tp = L.tris + slot * 3u; v0 = tp[0]; e1 = tp[1]; e2 = tp[2]; }
     else { const v4f* tp = (const v4f*)(sc.tris + slot); v0 = tp[0]; e1 = tp[1]; e2 = tp[2]; }
     const bool hit = tri_test_flat(R.o, R.d, v0, e1, e2, R.tmin, R.tmax, t, u, w);
-    gid = f2u(v0.w);
+    gid = ANY ? slot : f2u(v0.w);                      // any-hit: the occluder's slot (occluder cache); closest hit: the global triangle id
     if (ANY) return hit;
     return hit & ((t < R.bt) | ((t == R.bt) & (gid < R.bprim)));
 }
@@ -628,7 +639,7 @@ __device__ __forceinline__ void spec_step(const DevScene& sc, const TraceLds& L,
     uint32_t updv = upd ? 1u : 0u;
     asm volatile("" : "+v"(updv));                                          // opaque: keeps the update below OUT of the branch above (the optimiser would thread it back in)
     if (updv) {
-        if (ANY) { R.bprim = 0u; R.done = true; R.T.bits = 0u; }
+        if (ANY) { R.bprim = 0u; R.done = true; R.T.bits = 0u; R.occluder = cg; }
         else { R.bt = ct; R.bu = cu; R.bv = cw; R.bprim = cg; }
     }
     if (!R.T.bits) { R.T = R.P[0]; R.P[0].bits = 0u; }

@@ -73,6 +73,10 @@ int rtxh_scene_camera(const rtxh_scene* s, float eye[3], float center[3], float 
     *fov = s->s.fovY_deg; *zn = s->s.zn; *zf = s->s.zf;
     return RTX_OK;
 }
+int rtxh_scene_set_camera(rtxh_scene* s, const float eye[3], const float center[3], const float up[3]) {
+    s->s.eye = XMFLOAT3(eye[0], eye[1], eye[2]); s->s.center = XMFLOAT3(center[0], center[1], center[2]); s->s.up = XMFLOAT3(up[0], up[1], up[2]);
+    return RTX_OK;
+}
 int rtxh_scene_view_proj(const rtxh_scene* s, float aspect, float view[16], float proj[16]) { SceneViewProj(s->s, aspect, view, proj); return RTX_OK; }
 int rtxh_scene_upload(const rtxh_scene* s, rtx_ctx* c, float aspect) {
     if (s->cache_path.empty()) return UploadScene(s->s, c, aspect);

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -55,9 +56,26 @@ __global__ __launch_bounds__(256) void k_valu(float* out, unsigned long long* cy
                 asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[(k + 2) & 15]) : "v"(b), "v"(c));
                 asm volatile("v_cmp_le_f32 vcc, %0, %1" :: "v"(a[(k + 3) & 15]), "v"(b) : "vcc");
             }
-        } else {
+        } else if (KIND == 5) {
 #pragma unroll
             for (int k = 0; k < 64; k++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u) : "v"(threadIdx.x));
+        } else {
+            // 1:1 mixes of two opcodes on independent registers (calibration of the compute roofline: do the costs of two instruction classes ADD, or do they
+            // overlap in separate pipes?): 6 fma + min, 7 fma + add_u32, 8 min + cvt_ubyte, 9 fma + rcp, 10 add_u32 + min, 11 fma + mul (VOP2), 12 fma + mov, 13 add_u32 + cvt
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    float& x = a[i]; float& y = a[8 + i];
+                    if (KIND == 6) { asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c)); asm volatile("v_min_f32 %0, %0, %1" : "+v"(y) : "v"(b)); }
+                    if (KIND == 7) { asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c)); asm volatile("v_add_u32 %0, %0, %1" : "+v"(y) : "v"(u)); }
+                    if (KIND == 8) { asm volatile("v_min_f32 %0, %0, %1" : "+v"(x) : "v"(b)); asm volatile("v_cvt_f32_ubyte0 %0, %1" : "=v"(y) : "v"(u)); }
+                    if (KIND == 9) { asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c)); asm volatile("v_rcp_f32 %0, %0" : "+v"(y)); }
+                    if (KIND == 10) { asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(u)); asm volatile("v_min_f32 %0, %0, %1" : "+v"(y) : "v"(b)); }
+                    if (KIND == 11) { asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(y) : "v"(b)); }
+                    if (KIND == 12) { asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c)); asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "v"(b)); }
+                    if (KIND == 13) { asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(u)); asm volatile("v_cvt_f32_ubyte0 %0, %1" : "=v"(y) : "v"(u)); }
+                }
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -197,13 +215,87 @@ static int run(const char* name, int ncu, int inst_per_iter, float* d_out, unsig
     return 0;
 }
 
+// Instruction-mix replay (tools/gen_mix.py writes mix_kernels.inc from a kernel's measured class counts): 128 instructions per block, independent registers
+template <int ID> __device__ __forceinline__ void mix_block(float* a, f2v* p, unsigned* w, float b, float c, f2v pb, f2v pc, unsigned u);
+#ifdef RTX_HAVE_MIX
+#include "mix_kernels.inc"
+#endif
+template <int ID>
+__global__ __launch_bounds__(256) void k_mix(float* out, unsigned long long* cyc, unsigned long long* rt, int iters) {
+    float a[16]; for (int i = 0; i < 16; i++) a[i] = 1.0f + (float)(threadIdx.x + i) * 1e-3f;
+    f2v p[8]; for (int i = 0; i < 8; i++) { p[i].x = a[2 * i]; p[i].y = a[2 * i + 1]; }
+    unsigned w[8]; for (int i = 0; i < 8; i++) w[i] = threadIdx.x * 2654435761u + i;
+    float b = 1.0000001f, c = 1e-9f; f2v pb = {b, b}, pc = {c, c}; unsigned u = threadIdx.x * 40503u + 7u;
+    __syncthreads();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) mix_block<ID>(a, p, w, b, c, pb, pc, u);
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.0f; for (int i = 0; i < 16; i++) s += a[i]; for (int i = 0; i < 8; i++) s += p[i].x + p[i].y + (float)w[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) { cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0; rt[blockIdx.x * 4 + (threadIdx.x >> 6)] = r1 - r0; }
+}
+
+// CALIBRATION of the compute roofline (`valu_peak calib`, tools/valu_calib.sh): ONE launch per kernel, 8 waves per SIMD, so that a `rocprofv3 --pmc` pass of this
+// program has exactly one dispatch row per kernel name.  Each line prints what the kernel measured about itself (SIMD cycles per instruction from the in-kernel
+// clock); the counter passes then tell how the SQ_INSTS_VALU_* counters classify the opcode and what  sum(n_class x cycles_class) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)
+// reads for a loop that is known to saturate the pipe — it must be 1.00 +- 0.03 for the formula to be usable as a roofline fraction.
+template <class K>
+static int calib_one(const char* name, K kernel, int ncu, int iters, int inst_per_iter, float* d_out, unsigned long long* d_cyc, unsigned long long* d_rt) {
+    const int W = 8, blocks = ncu * W;
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    CHK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, d_rt, iters);
+    CHK(hipEventRecord(e1, 0));
+    CHK(hipDeviceSynchronize());
+    float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> c(blocks * 4), r(blocks * 4);
+    CHK(hipMemcpy(c.data(), d_cyc, c.size() * 8, hipMemcpyDeviceToHost));
+    CHK(hipMemcpy(r.data(), d_rt, r.size() * 8, hipMemcpyDeviceToHost));
+    std::sort(c.begin(), c.end()); std::sort(r.begin(), r.end());
+    const double cyc = (double)c[c.size() / 2], rtk = (double)r[r.size() / 2], inst = (double)iters * inst_per_iter, ghz = cyc / (rtk * 10.0);
+    printf("calib %-28s wave-inst=%.0f  wave-cycles=%.0f  clock=%.3f GHz  wall=%.3f ms  SIMD-cycles/inst=%.3f\n", name, (double)blocks * 4 * inst, cyc, ghz, ms, (ncu * 4.0) * ghz * 1e6 * ms / ((double)blocks * 4 * inst));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
+}
+
 int main(int argc, char** argv) {
-    const int first_op = argc > 1 ? atoi(argv[1]) : 0;          // run only the per-opcode kernels with id >= first_op
+    const bool calib = argc > 1 && !strcmp(argv[1], "calib");
+    const int first_op = (argc > 1 && !calib) ? atoi(argv[1]) : 0;          // run only the per-opcode kernels with id >= first_op
     hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
     const int ncu = prop.multiProcessorCount;
     printf("device %s, %d CUs, clock %d kHz\n", prop.name, ncu, prop.clockRate);
     float* d_out; unsigned long long *d_cyc, *d_rt;
     CHK(hipMalloc(&d_out, (size_t)ncu * 8 * 256 * 4)); CHK(hipMalloc(&d_cyc, (size_t)ncu * 8 * 4 * 8)); CHK(hipMalloc(&d_rt, (size_t)ncu * 8 * 4 * 8));
+    if (calib) {
+        const int it = 20000;
+        if (calib_one("k_valu<0> v_fma_f32", k_valu<0>, ncu, it, 64, d_out, d_cyc, d_rt)) return 1;
+        if (calib_one("k_valu<1> v_pk_fma_f32", k_valu<1>, ncu, it, 64, d_out, d_cyc, d_rt)) return 1;
+        if (calib_one("k_valu<3> v_rcp_f32", k_valu<3>, ncu, it / 2, 64, d_out, d_cyc, d_rt)) return 1;
+        if (calib_one("k_valu<4> cvt/fma/max3/cmp", k_valu<4>, ncu, it, 64, d_out, d_cyc, d_rt)) return 1;
+        if (calib_one("k_valu<6> fma+min", k_valu<6>, ncu, it, 64, d_out, d_cyc, d_rt)) return 1;
+        if (calib_one("k_valu<7> fma+add_u32", k_valu<7>, ncu, it, 64, d_out, d_cyc, d_rt)) return 1;
+        if (calib_one("k_valu<8> min+cvt", k_valu<8>, ncu, it, 64, d_out, d_cyc, d_rt)) return 1;
+        if (calib_one("k_valu<9> fma+rcp", k_valu<9>, ncu, it / 2, 64, d_out, d_cyc, d_rt)) return 1;
+        if (calib_one("k_valu<10> add_u32+min", k_valu<10>, ncu, it, 64, d_out, d_cyc, d_rt)) return 1;
+        if (calib_one("k_valu<11> fma+mul", k_valu<11>, ncu, it, 64, d_out, d_cyc, d_rt)) return 1;
+        if (calib_one("k_valu<12> fma+mov", k_valu<12>, ncu, it, 64, d_out, d_cyc, d_rt)) return 1;
+        if (calib_one("k_valu<13> add_u32+cvt", k_valu<13>, ncu, it, 64, d_out, d_cyc, d_rt)) return 1;
+        if (calib_one("k_op<0> v_mul_f32", k_op<0>, ncu, it, 64, d_out, d_cyc, d_rt)) return 1;
+        if (calib_one("k_op<1> v_add_f32", k_op<1>, ncu, it, 64, d_out, d_cyc, d_rt)) return 1;
+        if (calib_one("k_op<3> v_min_f32", k_op<3>, ncu, it, 64, d_out, d_cyc, d_rt)) return 1;
+        if (calib_one("k_op<4> v_cvt_f32_ubyte0", k_op<4>, ncu, it, 64, d_out, d_cyc, d_rt)) return 1;
+        if (calib_one("k_op<12> v_add_u32", k_op<12>, ncu, it, 64, d_out, d_cyc, d_rt)) return 1;
+        if (calib_one("k_op<29> v_cndmask_b32", k_op<29>, ncu, it, 64, d_out, d_cyc, d_rt)) return 1;
+        if (calib_one("k_op<9> v_mul_lo_u32", k_op<9>, ncu, it, 64, d_out, d_cyc, d_rt)) return 1;
+        if (calib_one("k_op<37> v_bfe_u32", k_op<37>, ncu, it, 64, d_out, d_cyc, d_rt)) return 1;
+        if (calib_one("k_op<17> v_mov_b32", k_op<17>, ncu, it, 64, d_out, d_cyc, d_rt)) return 1;
+#ifdef RTX_HAVE_MIX
+#define MIX(ID, NAME) if (calib_one("k_mix<" #ID "> " NAME, k_mix<ID>, ncu, it / 2, 128, d_out, d_cyc, d_rt)) return 1;
+        RTX_MIX_LIST
+#undef MIX
+#endif
+        return 0;
+    }
     if (run<0>("v_fma_f32 independent", ncu, 64, d_out, d_cyc, d_rt)) return 1;
     if (run<1>("v_pk_fma_f32 independent", ncu, 64, d_out, d_cyc, d_rt)) return 1;
     if (run<2>("v_fma_f32 dependent chain", ncu, 64, d_out, d_cyc, d_rt)) return 1;
