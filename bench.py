@@ -354,12 +354,15 @@ def main():
     ctx.upload(scene, W / H)
     if args.paths_per_batch:
         ctx.set_option(rt.OPT_PATHS_PER_BATCH, args.paths_per_batch)
+    # tile edge of the round-robin deal: 64 on one GPU (the order of the path slots the headline was tuned with); 32 when the frame is sharded — four times as many tiles
+    # per rank even out which ranks get the empty background (max / mean over 8 ranks 1.15 -> 1.04, slowest rank 3.16 -> 2.95 ms: tools/shard_time.py, profiles/r03_shard_time.md)
+    TILE = 64 if world == 1 else 32
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     ctx.bind_accum(accum.data_ptr(), accum.numel() * 4)
     params = rt.Params(width=W, height=H, spp=spp, sample_base=1, max_bounces=bounces, nee_samples=nee, rr_start=3,
-                       frame_seed=1, flags=flags, tile_size=64, shard_rank=rank, shard_count=world)
+                       frame_seed=1, flags=flags, tile_size=TILE, shard_rank=rank, shard_count=world)
     slab = gathered = None
     if world > 1:
         nfl = ctx.slab_bytes(params) // 4
@@ -468,7 +471,7 @@ def main():
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": args.workload, "scene": scene_source, "width": W, "height": H, "spp": spp,
                           "max_bounces": bounces, "nee_samples": nee, "rr_start": 3, "flags": flags,
-                          "triangles": int(scene.num_triangles), "parallelism": f"pixel-tiles/{world}", "tile_size": 64,
+                          "triangles": int(scene.num_triangles), "parallelism": f"pixel-tiles/{world}", "tile_size": TILE,
                           "rays_per_frame": {"primary": int(rays_all[0] / max(args.steps, 1)), "extension": int(rays_all[1] / max(args.steps, 1)),
                                              "shadow": int(rays_all[2] / max(args.steps, 1))}},
                "roofline": roof, "cpu_baseline": cpu}

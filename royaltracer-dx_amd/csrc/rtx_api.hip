@@ -600,7 +600,10 @@ static int p1_alloc(rtx_ctx* c, size_t slots);
 struct RsPlan { RsQ q; uint32_t* cnt; uint32_t G; DevFrame fq; DevPaths P[2]; };
 static int rs_plan(rtx_ctx* c, const DevFrame& f, uint32_t nitems, const uint32_t* pixels, uint32_t rows, RsPlan& R) {
     const uint32_t nchunks = std::max<uint32_t>(1u, (nitems + 255u) / 256u);
-    const uint32_t G = std::max<uint32_t>(1u, std::min<uint32_t>((nchunks + c->restir_chunks - 1) / c->restir_chunks, (uint32_t)c->num_cus * 64u));
+    // `restir_chunks` chunks per workgroup at full frame size, but never fewer than ~8 workgroups per CU while there are that many chunks: a 1/8 shard (1 180 chunks with its
+    // halo) ran 3.63 ms per frame with 295 workgroups of 4 chunks and 2.22 ms with 1 180 of one (tools/shard_time.py sponza restir 8 blocks=1 tile=32)
+    const uint32_t want = std::max<uint32_t>((nchunks + c->restir_chunks - 1) / c->restir_chunks, (uint32_t)c->num_cus * 8u);
+    const uint32_t G = std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>(want, nchunks), (uint32_t)c->num_cus * 64u));
     const uint32_t qcap = ((nchunks + G - 1) / G) * 256u, rcap = qcap * 9u;              // a pixel casts at most 9 visibility rays in one stage (pass 3, select)
     const size_t qtot = (size_t)G * qcap, rtot = (size_t)G * rcap;
     if (rtot > 0xFFFFFFFFull) { c->err = "render_restir: image too large"; return RTX_ERR_INVALID; }

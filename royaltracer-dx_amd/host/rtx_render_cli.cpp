@@ -58,7 +58,8 @@ int main(int argc, char** argv) {
             MultiGpuFrame mg(devs, gather == "copy" ? MultiGpuFrame::Gather::COPY : MultiGpuFrame::Gather::RCCL);
             mg.SetScene(sc, (float)w / (float)h);
             mg.Clear(w, h);
-            rtx_params p{}; p.width = w; p.height = h; p.spp = spp; p.max_bounces = bounces; p.nee_samples = nee; p.rr_start = 3; p.tile_size = 64;
+            rtx_params p{}; p.width = w; p.height = h; p.spp = spp; p.max_bounces = bounces; p.nee_samples = nee; p.rr_start = 3;
+            p.tile_size = gpus > 1 ? 32 : 64;      // round-robin deal: 32-px tiles even out the background across 8 ranks (max / mean 1.04 instead of 1.15, tools/shard_time.py)
             p.flags = lambert ? RTX_FLAG_LAMBERT_ONLY : (scene == "bistro" ? RTX_FLAG_TRANSMISSION : 0);
             if (restir) { p.spp = 1; p.flags = (lambert ? RTX_FLAG_LAMBERT_ONLY : 0u) | RTX_FLAG_BLOCK_TILES; p.tile_size = 32; mg.SetOption(RTX_OPT_RESTIR_WAVEFRONT, literal ? 0 : 1); mg.ResetRestir(); }
             float prev_view[16] = {0};

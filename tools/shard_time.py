@@ -1,24 +1,32 @@
 #!/usr/bin/env python3
-"""Per-rank frame time of the headline workload when the image is sharded N ways (one GPU renders shard 0 of N, no gather):
-what strong scaling can reach at best, and how much of a small shard's frame is fixed per-launch cost.
-usage: python tools/shard_time.py [N ...] [option_id=value ...]"""
+"""Per-rank frame times when the image is sharded N ways, measured on ONE GPU by rendering every shard r of N one after the other (no gather): what the slowest rank
+of an N-GPU frame costs (max over ranks decides the frame), how uneven the tile deal is (max / mean) and how large the slab of the frame's one all-gather is.
+usage: python tools/shard_time.py [cornell|sponza|bistro|sponza4k] [pt|restir] [N ...] [blocks=0|1] [tile=64] [frames=4] [option_id=value ...]
+   pt      BASELINE's path-traced frame of that scene (cornell: 1080p 64 spp 8 bounces; sponza / bistro: 1080p 16 spp; sponza4k: C4, 3840x2160 64 spp)
+   restir  the reference's ReSTIR frame (nee 4, bounces 3), 1080p; blocks=1 (RTX_FLAG_BLOCK_TILES, one tile rectangle per rank) is the deal meant for it"""
 import os
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import __graft_entry__ as graft  # noqa: E402
 
 
 def main():
-    ns = [int(a) for a in sys.argv[1:] if "=" not in a] or [1, 2, 4, 8]
-    opts = [a.split("=") for a in sys.argv[1:] if "=" in a]            # rtx option id=value
+    args = sys.argv[1:]
+    kind = next((a for a in args if a in ("cornell", "sponza", "bistro", "sponza4k")), "cornell")
+    mode = next((a for a in args if a in ("pt", "restir")), "pt")
+    ns = [int(a) for a in args if a.isdigit()] or [1, 2, 4, 8]
+    named = {a.split("=")[0]: int(a.split("=")[1]) for a in args if "=" in a and not a.split("=")[0].isdigit()}
+    opts = [a.split("=") for a in args if "=" in a and a.split("=")[0].isdigit()]            # rtx option id=value
+    blocks, tile, frames = named.get("blocks", 0), named.get("tile", 64), named.get("frames", 4)
     rt = graft.load_package()
     dev = torch.device("cuda", 0)
-    scene = rt.Scene.cornell()
-    W, H = 1920, 1080
+    scene = {"cornell": rt.Scene.cornell, "sponza": rt.Scene.sponza_class, "sponza4k": rt.Scene.sponza_class, "bistro": rt.Scene.bistro_class}[kind]()
+    W, H = (3840, 2160) if kind == "sponza4k" else (1920, 1080)
     ctx = rt.Context(0)
     for k, v in opts:
         ctx.set_option(int(k), int(v))
@@ -26,20 +34,37 @@ def main():
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     ctx.bind_accum(accum.data_ptr(), accum.numel() * 4)
+    flags = (rt.FLAG_BLOCK_TILES if blocks else 0)
+    if mode == "restir":
+        base = dict(width=W, height=H, spp=1, max_bounces=3, nee_samples=4, flags=flags, tile_size=tile)
+    else:
+        spp = 64 if kind in ("cornell", "sponza4k") else 16
+        base = dict(width=W, height=H, spp=spp, sample_base=1, max_bounces=8, nee_samples=1, rr_start=3,
+                    flags=flags | (1 if kind in ("cornell", "sponza", "sponza4k") else 4), tile_size=tile)
+    render = ctx.render_restir if mode == "restir" else ctx.render
     t1 = None
+    print(f"# {kind} {mode} {W}x{H} tile {tile} {'block' if blocks else 'round-robin'} deal; ms per frame of each rank's shard, rendered alone on one MI355X")
+    print("| N | max over ranks ms | mean ms | max / mean | ideal t1 / N ms | compute-only efficiency t1 / (N max) | slab MB / rank | per rank ms |\n|---|---|---|---|---|---|---|---|")
     for n in ns:
-        p = rt.Params(width=W, height=H, spp=64, sample_base=1, max_bounces=8, nee_samples=1, rr_start=3, frame_seed=1, flags=1,
-                      tile_size=64, shard_rank=0, shard_count=n)
-        ctx.render(p)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for i in range(5):
-            p.frame_seed = 2 + i
-            ctx.render(p)
-        torch.cuda.synchronize(dev)
-        ms = (time.perf_counter() - t0) * 1e3 / 5
-        t1 = t1 or ms
-        print(f"shard 0 of {n}: {ms:7.3f} ms/frame   ideal {t1 / n:7.3f}   compute-only efficiency {t1 / (n * ms):.3f}")
+        per = []
+        for r in range(n):
+            p = rt.Params(frame_seed=1, shard_rank=r, shard_count=n, **base)
+            if mode == "restir":
+                ctx.restir_reset()
+            render(p)                                              # warm-up of this shard (allocations, halo list)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(frames):
+                p.frame_seed = 2 + i
+                render(p)
+            torch.cuda.synchronize(dev)
+            per.append((time.perf_counter() - t0) * 1e3 / frames)
+        mx, mean = max(per), float(np.mean(per))
+        t1 = t1 or mx
+        slab = ctx.slab_bytes(rt.Params(shard_rank=0, shard_count=n, **base)) / 1e6
+        if mode == "restir":
+            slab += ctx.restir_state_slab_bytes(rt.Params(shard_rank=0, shard_count=n, **base)) / 1e6
+        print(f"| {n} | {mx:.3f} | {mean:.3f} | {mx / mean:.3f} | {t1 / n:.3f} | {t1 / (n * mx):.3f} | {slab:.2f} | " + " ".join(f"{t:.2f}" for t in per) + " |", flush=True)
     ctx.close()
 
 
