@@ -1,6 +1,7 @@
 """CPU suite, part 1: the oracle against (a) independent re-derivations written here in numpy / pure
 Python, (b) the committed golden vectors, (c) physical properties of the math it restates."""
 import os
+import sys
 import numpy as np
 import pytest
 
@@ -323,6 +324,65 @@ def test_direct_light_of_a_rectangle_matches_the_analytic_irradiance(rt, orc):
     assert abs(got[dim].sum() / ref[dim].sum() - 1.0) < 0.02
     # pixels that see the emitter itself show its radiance exactly
     assert np.allclose(img[(prim == 2) | (prim == 3)], sc.KE)
+
+
+@pytest.mark.parametrize("rough", [0.3, 0.7])
+def test_ggx_floor_under_a_rectangle_light_matches_float64_quadrature(rt, orc, rough):
+    """the GGX + NEE + MIS integrator pinned against an independent float64 quadrature (the Lambert-only rectangle test above cannot see a wrong
+    microfacet pdf measure or MIS weight).  Floor material Kd 0.25, Ks 0.5, roughness 0.3 / 0.7, its Ess LUT from the host generator; the BSDF is the reference's mixture
+    F = p_d f_lambert + p_s f_ggx (Sampler_v6.hlsl:443-457) restated in tests/ggx_ref64.py from the HLSL text.  Per floor pixel, with V = the camera direction:
+      * FULL:      L_o = integral over the light of F(L, V) Le cos_x cos_y / r^2 dA       <-> max_bounces = 2: NEE at the floor + the BSDF-sampled ray that reaches the light.
+                   Any pair of MIS weights that sums to one gives this; a pdf in the wrong measure (area vs solid angle) on either side breaks the sum and shows as a bias.
+      * NEE HALF:  the same integrand times w = p_l / (p_l + P), p_l = r^2 / (A cos_y) the light's pdf per solid angle, P the mixture pdf (Path_Sampler_v6.hlsl:164)
+                   <-> max_bounces = 1 (the path ends after its first vertex: only NEE contributes).  Pins the weight itself, restated in float64.
+    Agreement within 3 sigma of the Monte-Carlo error (8 independent batches give sigma) plus 0.3 % for the midpoint rule."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import ggx_ref64 as R
+    sc = _FloorAndLight()
+    kd, ks = (0.25, 0.25, 0.25), (0.5, 0.5, 0.5)
+    lut = rt.generate_ess_lut(rough)
+    sc.materials[1, 0:4] = (*kd, 1); sc.materials[1, 4:7] = ks; sc.materials[1, 12] = rough; sc.materials[1, 13] = 0.0; sc.materials[1, 16:32] = lut
+    W, H = 24, 16
+    sc._v = rt.lookat((2.5, 1.6, 1.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
+    sc._p = rt.perspective_fov_rh(np.radians(60.0), W / H, 0.1, 1000.0)
+    o = orc.Oracle().load(sc, W / H)
+    rays = o.primary_rays(rt.Params(width=W, height=H), 1)
+    hits = o.trace_closest(rays, 0)
+    prim = hits[:, 3].view(np.uint32).reshape(H, W)
+    floor = (prim == 0) | (prim == 1)
+    assert floor.sum() > 150
+    X = (rays[:, 0:3] + hits[:, 0:1] * rays[:, 4:7]).reshape(H, W, 3).astype(np.float64)
+    V = -rays[:, 4:7].reshape(H, W, 3).astype(np.float64)
+    m = R.Mat(kd, ks, rough, 0.0, lut)
+    N = np.array([0.0, 1.0, 0.0])
+    nx, nz = 240, 120
+    gx = (np.arange(nx) + 0.5) / nx * 2 * sc.LX - sc.LX
+    gz = (np.arange(nz) + 0.5) / nz * 2 * sc.LZ - sc.LZ
+    dA = (2 * sc.LX / nx) * (2 * sc.LZ / nz); A = 4 * sc.LX * sc.LZ
+    P_l = np.stack(np.broadcast_arrays(gx[:, None], np.full((1, 1), sc.LY), gz[None, :]), -1).reshape(-1, 3)       # light points
+    full, half = np.zeros((H, W, 3)), np.zeros((H, W, 3))
+    Ke = np.array(sc.KE, np.float64)
+    for yy, xx in zip(*np.nonzero(floor)):
+        d = P_l - X[yy, xx]; r2 = (d * d).sum(-1); L = d / np.sqrt(r2)[:, None]
+        cos_x, cos_y = L[:, 1], L[:, 1]                                                                        # floor normal +y, light normal -y: both cosines are L.y
+        F, Pm, _, _ = R.mixture(m, N, L, V[yy, xx])
+        g = cos_x * cos_y / r2 * dA
+        p_l = r2 / (A * cos_y)
+        full[yy, xx] = (F * (g[:, None])).sum(0) * Ke
+        half[yy, xx] = (F * (g * p_l / (p_l + Pm))[:, None]).sum(0) * Ke
+    base = dict(width=W, height=H, spp=150, nee_samples=1, flags=0)
+    for bounces, expect in ((2, full), (1, half)):
+        sums = []
+        for b in range(8):
+            acc, _ = o.render(rt.Params(max_bounces=bounces, sample_base=1 + 150 * b, **base))
+            sums.append((acc[..., :3] / np.maximum(acc[..., 3:4], 1.0))[floor].sum(0))
+        sums = np.array(sums)
+        mean, sem = sums.mean(0), sums.std(0, ddof=1) / np.sqrt(len(sums))
+        ref = expect[floor].sum(0)
+        z = np.abs(mean - ref) / (3.0 * sem + 0.003 * ref)
+        assert (z < 1.0).all(), (rough, bounces, mean / ref, sem / ref)
+        assert (sem / ref < 0.02).all()                                                                       # the test has the power to see a 3-5 % error
+    assert (half[floor].sum(0) < 0.98 * full[floor].sum(0)).all()                                             # the BSDF-sampled half is not negligible: the weight is really exercised
 
 
 def test_light_list_follows_reference_rules(rt, garage_oracle, garage_scene):
