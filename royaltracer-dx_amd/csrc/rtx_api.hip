@@ -46,7 +46,9 @@ struct rtx_ctx {
     // path state
     DevBuf d_hitmask, d_order, d_pmask;
     bool lpt_order = true;          // RTX_OPT_LPT_ORDER: fused kernels take their sub-queues longest first
-    DevBuf d_halo; uint32_t halo_count = 0; uint32_t halo_key[6] = {0, 0, 0, 0, 0, 0};     // ReSTIR on shards: the shard's tiles dilated by 20 px, as a pixel list (width, height, tile, rank, count)
+    // ReSTIR work lists (x | y << 16 per pixel, 8 x 8 pixel blocks in MORTON order so that consecutive chunks are compact screen regions): the shard's own pixels
+    // (pass 3) and — on shards — its tiles dilated by the 20-px radius of the spatial pass (passes 1 and 2); key = (width, height, tile, rank, count, deal)
+    DevBuf d_halo, d_own; uint32_t halo_count = 0, own_count = 0; uint32_t halo_key[6] = {0, 0, 0, 0, 0, 0};
     bool bounce_ring = true;        // RTX_OPT_BOUNCE_VARIANT
     bool fused_bvh = false;         // RTX_OPT_FUSED_BVH: general path = one k_bounce_bvh launch per batch (trace -> shade -> shadow per sub-queue and bounce); measured SLOWER, default off
     DevBuf d_hitq;
@@ -123,7 +125,7 @@ void rtx_destroy(rtx_ctx* c) {
     else (void)hipDeviceSynchronize();
     DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_small_poly, &c->d_objtris, &c->d_node_aabb, &c->d_scale, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
                      &c->d_thr, &c->d_rad, &c->d_hit, &c->d_hitmask, &c->d_order, &c->d_pmask, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
-                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq, &c->d_halo, &c->d_heads, &c->d_alt_o, &c->d_alt_d, &c->d_alt_thr,
+                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq, &c->d_halo, &c->d_own, &c->d_heads, &c->d_alt_o, &c->d_alt_d, &c->d_alt_thr,
                      &c->d_rs_state, &c->d_rs_hit, &c->d_rs_cls, &c->d_rs_fin, &c->d_rs_cold, &c->d_rs_occ, &c->d_rs_cand, &c->d_rs_sho, &c->d_rs_shd, &c->d_rs_pay, &c->d_rs_cnt};
     for (DevBuf* b : all) b->release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
@@ -603,7 +605,7 @@ static int rs_plan(rtx_ctx* c, const DevFrame& f, uint32_t nitems, const uint32_
     // `restir_chunks` chunks per workgroup at full frame size, but never fewer than ~8 workgroups per CU while there are that many chunks: a 1/8 shard (1 180 chunks with its
     // halo) ran 3.63 ms per frame with 295 workgroups of 4 chunks and 2.22 ms with 1 180 of one (tools/shard_time.py sponza restir 8 blocks=1 tile=32)
     const uint32_t want = std::max<uint32_t>((nchunks + c->restir_chunks - 1) / c->restir_chunks, (uint32_t)c->num_cus * 8u);
-    const uint32_t G = std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>(want, nchunks), (uint32_t)c->num_cus * 64u));
+    const uint32_t G = (std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>(want, nchunks), (uint32_t)c->num_cus * 64u)) + 7u) & ~7u;   // a multiple of 8: rs_wg() maps workgroups to XCD-contiguous ranges
     const uint32_t qcap = ((nchunks + G - 1) / G) * 256u, rcap = qcap * 9u;              // a pixel casts at most 9 visibility rays in one stage (pass 3, select)
     const size_t qtot = (size_t)G * qcap, rtot = (size_t)G * rcap;
     if (rtot > 0xFFFFFFFFull) { c->err = "render_restir: image too large"; return RTX_ERR_INVALID; }
@@ -656,8 +658,8 @@ static int rs_pass1(rtx_ctx* c, const DevFrame& f, uint32_t sample_id, F4* accum
     HIPCHK(c, hipGetLastError());
     return RTX_OK;
 }
-static int rs_pass3(rtx_ctx* c, const DevFrame& f, uint32_t* const bufs[6], F4* accum) {
-    RsPlan R; int r = rs_plan(c, f, f.npl, nullptr, 2, R); if (r) return r;
+static int rs_pass3(rtx_ctx* c, const DevFrame& f, uint32_t* const bufs[6], F4* accum, const uint32_t* pixels, uint32_t npixels) {
+    RsPlan R; int r = rs_plan(c, f, pixels ? npixels : f.npl, pixels, 2, R); if (r) return r;
     const CameraGPU* cam = (const CameraGPU*)c->d_cam.p;
     { Timed t(c, RTX_K_SHADE); launch_rs_p3_select(c->stream, c->dsc, R.fq, R.q, cam, bufs, R.cnt); }
     { Timed t(c, RTX_K_SHADOW); launch_trace_occ(c->stream, c->dsc, R.q, R.cnt); }
@@ -743,29 +745,50 @@ int rtx_render_restir(rtx_ctx* c, const rtx_params* p) {
     // around every 64-px tile (2.6 x with the round-robin deal).
     const bool sharded = p->shard_count > 1;
     if (sharded && p->spp != 1) { c->err = "render_restir: on shards the history has to be exchanged after every frame (rtx_restir_pack_state / unpack_state): spp must be 1"; return RTX_ERR_INVALID; }
-    if (sharded && (p->width > 65535u || p->height > 65535u)) { c->err = "render_restir: sharded images are limited to 65535 x 65535"; return RTX_ERR_INVALID; }
     if ((r = ensure_accum(c, p->width, p->height, false))) return r;
-    const uint32_t* halo = nullptr; uint32_t nhalo = 0;
-    if (sharded) {
-        const uint32_t key[6] = {p->width, p->height, f.tile_size, p->shard_rank, p->shard_count, p->flags & RTX_FLAG_BLOCK_TILES};
-        if (memcmp(key, c->halo_key, sizeof(key)) != 0 || !c->d_halo.p) {
+    const uint32_t* halo = nullptr; const uint32_t* own = nullptr; uint32_t nhalo = 0, nown = 0;
+    // (tiny scenes keep the slot order when unsharded: the Cornell frame measured 3.19 ms that way and 3.69 ms through the Morton list; the BVH scenes gain ~1 %)
+    if (sharded || (c->restir_wave && !c->dsc.nsmall)) {
+        const uint32_t key[6] = {p->width, p->height, f.tile_size, p->shard_rank, f.shard_count, p->flags & RTX_FLAG_BLOCK_TILES};
+        if (memcmp(key, c->halo_key, sizeof(key)) != 0 || !c->d_own.p) {
             const uint32_t W = p->width, H = p->height, ts = f.tile_size, R = 20u;           // spatial radius: RayGen_v6_pass3.hlsl (random pixel within 20)
-            std::vector<uint8_t> mask((size_t)W * H, 0);
+            if (W > 65535u || H > 65535u) { c->err = "render_restir: images are limited to 65535 x 65535"; return RTX_ERR_INVALID; }
+            std::vector<uint8_t> mask((size_t)W * H, 0);                                      // bit 0: own pixel, bit 1: own or within the halo
             for (uint32_t k = 0; k < f.npl >> (2u * f.tile_shift); k++) {                     // the shard's tiles, by the one rule of slot_to_pixel
                 uint32_t tx, ty;
                 if (!shard_tile(f, k, tx, ty)) continue;
                 const uint32_t x0 = tx * ts > R ? tx * ts - R : 0u, y0 = ty * ts > R ? ty * ts - R : 0u;
                 const uint32_t x1 = std::min(W, (tx + 1) * ts + R), y1 = std::min(H, (ty + 1) * ts + R);
-                for (uint32_t y = y0; y < y1; y++) memset(&mask[(size_t)y * W + x0], 1, x1 - x0);
+                for (uint32_t y = y0; y < y1; y++) memset(&mask[(size_t)y * W + x0], 2, x1 - x0);
             }
-            std::vector<uint32_t> list;
-            for (uint32_t by = 0; by < H; by += 8) for (uint32_t bx = 0; bx < W; bx += 8)         // 8 x 8 blocks, so a wave covers a compact screen region
-                for (uint32_t y = by; y < std::min(H, by + 8); y++) for (uint32_t x = bx; x < std::min(W, bx + 8); x++)
-                    if (mask[(size_t)y * W + x]) list.push_back(x | (y << 16));
-            if ((r = upload(c, c->d_halo, list))) return r;
-            c->halo_count = (uint32_t)list.size(); memcpy(c->halo_key, key, sizeof(key));
+            for (uint32_t k = 0; k < f.npl >> (2u * f.tile_shift); k++) {
+                uint32_t tx, ty;
+                if (!shard_tile(f, k, tx, ty)) continue;
+                for (uint32_t y = ty * ts; y < std::min(H, (ty + 1) * ts); y++) memset(&mask[(size_t)y * W + tx * ts], 3, std::min(W, (tx + 1) * ts) - tx * ts);
+            }
+            // 8 x 8 pixel blocks (one wave each) in Morton order: a 256-pixel chunk is a 16 x 16 px square, the 256 consecutive chunks a range of workgroups on one
+            // XCD takes (rs_wg) a 256 x 256 px square — the neighbour gathers of the spatial pass stay in that XCD's L2
+            const uint32_t BX = (W + 7) / 8, BY = (H + 7) / 8;
+            uint32_t side = 1; while (side < std::max(BX, BY)) side <<= 1;
+            std::vector<uint32_t> lown, lhalo;
+            auto spread = [](uint32_t v) { v &= 0xFFFFu; v = (v | (v << 8)) & 0x00FF00FFu; v = (v | (v << 4)) & 0x0F0F0F0Fu; v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u; return v; };
+            std::vector<std::pair<uint32_t, uint32_t>> order; order.reserve((size_t)BX * BY);
+            for (uint32_t by = 0; by < BY; by++) for (uint32_t bx = 0; bx < BX; bx++) order.push_back({spread(bx) | (spread(by) << 1), bx | (by << 16)});
+            std::sort(order.begin(), order.end());
+            for (const auto& e : order) {
+                const uint32_t bx = (e.second & 0xFFFFu) * 8u, by = (e.second >> 16) * 8u;
+                for (uint32_t y = by; y < std::min(H, by + 8); y++) for (uint32_t x = bx; x < std::min(W, bx + 8); x++) {
+                    const uint8_t mk = mask[(size_t)y * W + x];
+                    if (mk & 1) lown.push_back(x | (y << 16));
+                    if (mk & 2) lhalo.push_back(x | (y << 16));
+                }
+            }
+            if ((r = upload(c, c->d_own, lown))) return r;
+            if (sharded) { if ((r = upload(c, c->d_halo, lhalo))) return r; }
+            c->own_count = (uint32_t)lown.size(); c->halo_count = sharded ? (uint32_t)lhalo.size() : 0u; memcpy(c->halo_key, key, sizeof(key));
         }
-        halo = (const uint32_t*)c->d_halo.p; nhalo = c->halo_count;
+        own = (const uint32_t*)c->d_own.p; nown = c->own_count;
+        if (sharded) { halo = (const uint32_t*)c->d_halo.p; nhalo = c->halo_count; } else { halo = own; nhalo = nown; }
     }
     const size_t slots = rtx_pass1_slots(p->width, p->height);
     if ((r = p1_alloc(c, slots))) return r;
@@ -788,10 +811,10 @@ int rtx_render_restir(rtx_ctx* c, const rtx_params* p) {
         HIPCHK(c, hipMemsetAsync(scratch.p, 0, (size_t)p->width * p->height * 16, c->stream));
         if (c->restir_wave) {                                                                                                               // the three DispatchRays of Renderer.cpp:646-673 as wavefront stages
             if ((r = rs_pass1(c, ff, 1u, (F4*)scratch.p, halo, nhalo, bufs))) return r;              // passes 1 + 2
-            if ((r = rs_pass3(c, ff, bufs, c->accum_ptr()))) return r;
+            if ((r = rs_pass3(c, ff, bufs, c->accum_ptr(), own, nown))) return r;
         } else {                                                                                                                            // ... or literally, a thread per pixel
-            { Timed t(c, RTX_K_BOUNCE); launch_v6_pass1(c->stream, mbk, c->dsc, ff, cam, 1u, (F4*)scratch.p, bufs[0], bufs[1], bufs[2], (unsigned long long*)c->d_p1cnt.p, halo, nhalo); }   // Renderer.cpp:651-654
-            { Timed t(c, RTX_K_BOUNCE); launch_restir_pass2(c->stream, mbk, c->dsc, ff, cam, bufs, (unsigned long long*)c->d_p1cnt.p, halo, nhalo); }                                       // :662-664
+            { Timed t(c, RTX_K_BOUNCE); launch_v6_pass1(c->stream, mbk, c->dsc, ff, cam, 1u, (F4*)scratch.p, bufs[0], bufs[1], bufs[2], (unsigned long long*)c->d_p1cnt.p, sharded ? halo : nullptr, sharded ? nhalo : 0u); }   // Renderer.cpp:651-654
+            { Timed t(c, RTX_K_BOUNCE); launch_restir_pass2(c->stream, mbk, c->dsc, ff, cam, bufs, (unsigned long long*)c->d_p1cnt.p, sharded ? halo : nullptr, sharded ? nhalo : 0u); }                                       // :662-664
             { Timed t(c, RTX_K_BOUNCE); launch_restir_pass3(c->stream, mbk, c->dsc, ff, cam, bufs, c->accum_ptr(), (unsigned long long*)c->d_p1cnt.p); }                                    // :671-673
         }
     }

@@ -22,11 +22,16 @@ namespace rtx {
 
 // (the work area RsQ and its constants are declared in rtx_kernels.hpp: the host fills it)
 
+// LOGICAL workgroup (= sub-queue) index of this workgroup.  The hardware deals workgroups to the 8 XCDs round-robin (blockIdx.x % 8), each XCD with its own L2; chunks of 256
+// pixels are dealt to LOGICAL workgroups in order (chunk c -> workgroup c mod G), and consecutive chunks are neighbouring screen regions.  Mapping the workgroups of one XCD
+// to a contiguous range of logical indices (G is a multiple of 8) gives every XCD contiguous strips of the image instead of every eighth chunk — what the neighbour gathers
+// of the spatial pass need: records within 20 px are then mostly in the same L2 (k_rs_p3_select fetched 8.4 GB per frame at an L2 hit rate of 0.41 before, profiles/r03_pmc_restir.md).
+__device__ __forceinline__ uint32_t rs_wg(const RsQ& q) { return (blockIdx.x & 7u) * (q.G >> 3) + (blockIdx.x >> 3); }
 __device__ __forceinline__ bool rs_item_pixel(const DevFrame& f, const RsQ& q, uint32_t it, uint32_t& x, uint32_t& y) { return pass_pixel(f, q.pixels, it, x, y); }
 // push one any-hit ray into the workgroup's ray sub-queue (every lane of the wave calls this)
 __device__ __forceinline__ void rs_push_ray(const RsQ& q, uint32_t* s_rn, bool pred, const F4& so, const F4& sd, uint32_t pay) {
     const uint32_t slot = block_push(pred, s_rn);
-    if (pred) { const size_t gi = (size_t)blockIdx.x * q.rcap + slot; q.sh_o[gi] = so; q.sh_d[gi] = sd; q.sh_pay[gi] = pay; }
+    if (pred) { const size_t gi = (size_t)rs_wg(q) * q.rcap + slot; q.sh_o[gi] = so; q.sh_d[gi] = sd; q.sh_pay[gi] = pay; }
 }
 struct VisLookup {           // the answer of ray k, traced before this stage
     const uint8_t* occ;
@@ -45,8 +50,8 @@ __device__ __forceinline__ void store_sdata_head(uint32_t* d, f3 x1, uint32_t mI
 __device__ __forceinline__ void rs_publish(uint32_t* cnt_out, const uint32_t* s_n, uint32_t* shcnt, const uint32_t* s_rn, const RsQ& q, int ray_class, uint32_t ray_base = 0u) {
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (cnt_out) { cnt_out[blockIdx.x] = *s_n; if (*s_n) atomicAdd(&q.rays[ray_class], (unsigned long long)*s_n); }
-        if (shcnt) { shcnt[blockIdx.x] = *s_rn; if (*s_rn > ray_base) atomicAdd(&q.rays[2], (unsigned long long)(*s_rn - ray_base)); }
+        if (cnt_out) { cnt_out[rs_wg(q)] = *s_n; if (*s_n) atomicAdd(&q.rays[ray_class], (unsigned long long)*s_n); }
+        if (shcnt) { shcnt[rs_wg(q)] = *s_rn; if (*s_rn > ray_base) atomicAdd(&q.rays[2], (unsigned long long)(*s_rn - ray_base)); }
     }
 }
 
@@ -60,9 +65,9 @@ __global__ __launch_bounds__(kBlock) void k_rs_raygen(DevFrame f, RsQ q, const C
     if (threadIdx.x < 64) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    const size_t qb = (size_t)blockIdx.x * q.qcap;
+    const size_t qb = (size_t)rs_wg(q) * q.qcap;
     const uint32_t nchunks = (q.nitems + kBlock - 1) / kBlock;
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (uint32_t c = rs_wg(q); c < nchunks; c += gridDim.x) {
         const uint32_t it = c * kBlock + threadIdx.x;
         uint32_t x = 0, y = 0;
         const bool valid = it < q.nitems && rs_item_pixel(f, q, it, x, y);
@@ -84,8 +89,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_ris(DevScene sc, DevFrame f
     __shared__ uint32_t s_n;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    const uint32_t n = cnt_in[blockIdx.x];
-    const size_t qb = (size_t)blockIdx.x * q.qcap;
+    const uint32_t n = cnt_in[rs_wg(q)];
+    const size_t qb = (size_t)rs_wg(q) * q.qcap;
     const uint32_t M1 = sc.nlights ? f.nee_samples : 0u;
     for (uint32_t base = 0; base < n; base += kBlock) {
         const uint32_t i = base + threadIdx.x;
@@ -141,8 +146,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_ris_finish(DevScene sc, Dev
     __shared__ uint32_t s_n, s_rn;
     if (threadIdx.x == 0) { s_n = 0; s_rn = 0; }
     __syncthreads();
-    const uint32_t n = cnt_in[blockIdx.x];
-    const size_t qb = (size_t)blockIdx.x * q.qcap;
+    const uint32_t n = cnt_in[rs_wg(q)];
+    const size_t qb = (size_t)rs_wg(q) * q.qcap;
     const uint32_t M1 = sc.nlights ? f.nee_samples : 0u;
     for (uint32_t base = 0; base < n; base += kBlock) {
         const uint32_t i = base + threadIdx.x;
@@ -213,8 +218,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_first(DevScene sc, DevFrame
     __shared__ uint32_t s_n;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    const uint32_t n = cnt_in[blockIdx.x];
-    const size_t qb = (size_t)blockIdx.x * q.qcap;
+    const uint32_t n = cnt_in[rs_wg(q)];
+    const size_t qb = (size_t)rs_wg(q) * q.qcap;
     const uint32_t nee = sc.nlights ? f.nee_samples : 0u;
     for (uint32_t base = 0; base < n; base += kBlock) {
         const uint32_t i = base + threadIdx.x;
@@ -250,8 +255,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_loop(DevScene sc, DevFrame 
     __shared__ uint32_t s_n;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    const uint32_t n = cnt_in[blockIdx.x];
-    const size_t qb = (size_t)blockIdx.x * q.qcap;
+    const uint32_t n = cnt_in[rs_wg(q)];
+    const size_t qb = (size_t)rs_wg(q) * q.qcap;
     const uint32_t nee = sc.nlights ? f.nee_samples : 0u;
     for (uint32_t base = 0; base < n; base += kBlock) {
         const uint32_t i = base + threadIdx.x;
@@ -287,12 +292,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_emit_final(DevScene sc, Dev
     __shared__ CameraGPU cam;
     __shared__ uint32_t s_rn;
     if (threadIdx.x < 64) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
-    const uint32_t ray_base = shcnt[blockIdx.x];
+    const uint32_t ray_base = shcnt[rs_wg(q)];
     if (threadIdx.x == 0) s_rn = ray_base;
     __syncthreads();
     const uint32_t nee = sc.nlights ? f.nee_samples : 0u;
     const uint32_t nchunks = (q.nitems + kBlock - 1) / kBlock;
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (uint32_t c = rs_wg(q); c < nchunks; c += gridDim.x) {
         const uint32_t it = c * kBlock + threadIdx.x;
         bool cast = false, r0 = false, r1 = false;
         F4 so = {0, 0, 0, 0}, sd = {0, 0, 1, 0}, so0 = so, sd0 = sd, so1 = so, sd1 = sd;
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_finish(DevScene sc, DevFram
     __syncthreads();
     const uint32_t nee = sc.nlights ? f.nee_samples : 0u;
     const uint32_t nchunks = (q.nitems + kBlock - 1) / kBlock;
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (uint32_t c = rs_wg(q); c < nchunks; c += gridDim.x) {
         const uint32_t it = c * kBlock + threadIdx.x;
         uint32_t x, y;
         if (!(it < q.nitems) || !rs_item_pixel(f, q, it, x, y)) continue;
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p3_select(DevScene sc, DevFram
     __syncthreads();
     const f3 camo = mk3(cam_p->viewI[12], cam_p->viewI[13], cam_p->viewI[14]);
     const uint32_t nchunks = (q.nitems + kBlock - 1) / kBlock;
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (uint32_t c = rs_wg(q); c < nchunks; c += gridDim.x) {
         const uint32_t it = c * kBlock + threadIdx.x;
         uint32_t x = 0, y = 0;
         bool run = it < q.nitems && rs_item_pixel(f, q, it, x, y);
@@ -419,7 +424,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p3_merge(DevScene sc, DevFrame
     if (threadIdx.x == 0) s_rn = 0;
     __syncthreads();
     const uint32_t nchunks = (q.nitems + kBlock - 1) / kBlock;
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (uint32_t c = rs_wg(q); c < nchunks; c += gridDim.x) {
         const uint32_t it = c * kBlock + threadIdx.x;
         uint32_t x = 0, y = 0;
         bool run = it < q.nitems && rs_item_pixel(f, q, it, x, y);
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p3_merge(DevScene sc, DevFrame
 }
 __global__ __launch_bounds__(kBlock, 4) void k_rs_p3_shade(DevScene sc, DevFrame f, RsQ q, RestirBufs B, F4* __restrict__ accum) {
     const uint32_t nchunks = (q.nitems + kBlock - 1) / kBlock;
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (uint32_t c = rs_wg(q); c < nchunks; c += gridDim.x) {
         const uint32_t it = c * kBlock + threadIdx.x;
         uint32_t x, y;
         if (!(it < q.nitems) || !rs_item_pixel(f, q, it, x, y)) continue;
