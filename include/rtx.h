@@ -100,6 +100,9 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
                                         pixels aiming at the same light / sample).  Any-hit is existence, so results are identical — and it is MEASURED SLOWER (same box, alternating:
                                         k_trace_shadow 11.63 -> 12.23 ms on C3, 10.21 -> 10.48 on C5, ReSTIR frames +1 %): the extra triangle step per ray costs more than
                                         the early exits save.  Default 0 */
+       RTX_OPT_RESTIR_LANES = 22,    /* 2 (default): the pixels of a ReSTIR frame are processed as two independent halves on two streams (passes 1 + 2, then pass 3), so that the
+                                        many short dependent launches of one half fill the launch tails of the other; 1: one chain.  Off while RTX_OPT_KERNEL_TIMING is on.
+                                        Results identical */
        RTX_OPT_RESTIR_CHUNKS = 20,   /* tuning: 256-pixel chunks per workgroup (= private sub-queue) of the ReSTIR stages, default 4 */
        RTX_OPT_OVERLAP_SHADOW = 18,  /* 1 (default): general scenes run the shadow-ray kernel of bounce b on a second (internal) stream beside the closest-hit kernel of
                                         bounce b + 1; everything is joined into the context's stream before rtx_render returns.  Off while RTX_OPT_KERNEL_TIMING is on

@@ -66,7 +66,9 @@ struct rtx_ctx {
     // wavefront ReSTIR (rtx_restir_wave.hpp): path state by queue position (two sets), hit records, per-item records, the any-hit ray queue, queue lengths
     bool restir_wave = true;        // RTX_OPT_RESTIR_WAVEFRONT
     uint32_t restir_chunks = 4;     // RTX_OPT_RESTIR_CHUNKS: 256-item chunks per sub-queue (= workgroup) of the ReSTIR stages
-    DevBuf d_rs_state, d_rs_hit, d_rs_cls, d_rs_fin, d_rs_cold, d_rs_occ, d_rs_cand, d_rs_sho, d_rs_shd, d_rs_pay, d_rs_cnt;
+    struct RsArea { DevBuf state, hit, cls, fin, cold, occ, cand, sho, shd, pay, cnt; } rs_area[4];      // one per pipeline lane (RTX_OPT_RESTIR_LANES)
+    hipStream_t lane_stream[3] = {nullptr, nullptr, nullptr};      // lanes 1 .. 3 (lane 0 runs on the context's stream)
+    uint32_t restir_lanes = 2;      // RTX_OPT_RESTIR_LANES: the work list of a ReSTIR frame as 1 .. 4 independent parts on as many streams (the tails of one part's many short launches fill with the others' work)
     // options
     bool timing = false; uint64_t paths_per_batch = 128u << 20; int lds_nodes_opt = -1; bool small_scene = true; bool fused = true; int stack_private = -1;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
@@ -125,8 +127,9 @@ void rtx_destroy(rtx_ctx* c) {
     else (void)hipDeviceSynchronize();
     DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_small_poly, &c->d_objtris, &c->d_node_aabb, &c->d_scale, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
                      &c->d_thr, &c->d_rad, &c->d_hit, &c->d_hitmask, &c->d_order, &c->d_pmask, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
-                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq, &c->d_halo, &c->d_own, &c->d_heads, &c->d_alt_o, &c->d_alt_d, &c->d_alt_thr,
-                     &c->d_rs_state, &c->d_rs_hit, &c->d_rs_cls, &c->d_rs_fin, &c->d_rs_cold, &c->d_rs_occ, &c->d_rs_cand, &c->d_rs_sho, &c->d_rs_shd, &c->d_rs_pay, &c->d_rs_cnt};
+                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq, &c->d_halo, &c->d_own, &c->d_heads, &c->d_alt_o, &c->d_alt_d, &c->d_alt_thr};
+    for (auto& A : c->rs_area) for (DevBuf* b : {&A.state, &A.hit, &A.cls, &A.fin, &A.cold, &A.occ, &A.cand, &A.sho, &A.shd, &A.pay, &A.cnt}) b->release();
+    for (hipStream_t& ls : c->lane_stream) if (ls) { (void)hipStreamDestroy(ls); ls = nullptr; }
     for (DevBuf* b : all) b->release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
@@ -159,6 +162,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_GPU_REFIT: c->gpu_refit = value != 0; return RTX_OK;
     case RTX_OPT_OCCLUDER_CACHE: c->occluder_cache = value != 0; c->dsc.occluder_cache = c->occluder_cache; return RTX_OK;
     case RTX_OPT_RESTIR_WAVEFRONT: c->restir_wave = value != 0; return RTX_OK;
+    case RTX_OPT_RESTIR_LANES: if (value < 1 || value > 4) { c->err = "restir_lanes must be in [1, 4]"; return RTX_ERR_INVALID; } c->restir_lanes = (uint32_t)value; return RTX_OK;
     case RTX_OPT_RESTIR_CHUNKS: if (value < 1 || value > 64) { c->err = "restir_chunks must be in [1, 64]"; return RTX_ERR_INVALID; } c->restir_chunks = (uint32_t)value; return RTX_OK;
     case RTX_OPT_TRACE_SCHED: if (value > 7) { c->err = "trace_sched must be in [0, 7]"; return RTX_ERR_INVALID; } c->trace_sched = (uint32_t)value; c->dsc.trace_sched = c->trace_sched; return RTX_OK;
     case RTX_OPT_REFILL_MIN: if (value < 1 || value > 64) { c->err = "refill_min must be in [1, 64]"; return RTX_ERR_INVALID; } c->refill_min = (uint32_t)value; c->dsc.refill_min = c->refill_min; return RTX_OK;
@@ -600,7 +604,8 @@ static int p1_alloc(rtx_ctx* c, size_t slots);
 // into 256-item chunks and dealt round-robin to G workgroups, each with a private sub-queue: stage kernels and the persistent traversal kernels of a pass all run
 // with G workgroups, workgroup b owning sub-queue b.  G: `restir_chunks` chunks per workgroup (more = fuller persistent waves, fewer = shorter launch tails).
 struct RsPlan { RsQ q; uint32_t* cnt; uint32_t G; DevFrame fq; DevPaths P[2]; };
-static int rs_plan(rtx_ctx* c, const DevFrame& f, uint32_t nitems, const uint32_t* pixels, uint32_t rows, RsPlan& R) {
+static int rs_plan(rtx_ctx* c, const DevFrame& f, uint32_t nitems, const uint32_t* pixels, uint32_t rows, RsPlan& R, uint32_t lane) {
+    rtx_ctx::RsArea& A = c->rs_area[lane];
     const uint32_t nchunks = std::max<uint32_t>(1u, (nitems + 255u) / 256u);
     // `restir_chunks` chunks per workgroup at full frame size, but never fewer than ~8 workgroups per CU while there are that many chunks: a 1/8 shard (1 180 chunks with its
     // halo) ran 3.63 ms per frame with 295 workgroups of 4 chunks and 2.22 ms with 1 180 of one (tools/shard_time.py sponza restir 8 blocks=1 tile=32)
@@ -609,19 +614,19 @@ static int rs_plan(rtx_ctx* c, const DevFrame& f, uint32_t nitems, const uint32_
     const uint32_t qcap = ((nchunks + G - 1) / G) * 256u, rcap = qcap * 9u;              // a pixel casts at most 9 visibility rays in one stage (pass 3, select)
     const size_t qtot = (size_t)G * qcap, rtot = (size_t)G * rcap;
     if (rtot > 0xFFFFFFFFull) { c->err = "render_restir: image too large"; return RTX_ERR_INVALID; }
-    HIPCHK(c, c->d_rs_state.ensure(qtot * 16 * 2 * kRsStreams)); HIPCHK(c, c->d_rs_hit.ensure(qtot * 16));
-    HIPCHK(c, c->d_rs_cls.ensure((size_t)nitems * 4)); HIPCHK(c, c->d_rs_fin.ensure((size_t)nitems * 16)); HIPCHK(c, c->d_rs_cold.ensure((size_t)nitems * 16 * 5));
-    HIPCHK(c, c->d_rs_occ.ensure((size_t)nitems * kRsOcc)); HIPCHK(c, c->d_rs_cand.ensure((size_t)nitems * 4 * kRsCand));
-    HIPCHK(c, c->d_rs_sho.ensure(rtot * 16)); HIPCHK(c, c->d_rs_shd.ensure(rtot * 16)); HIPCHK(c, c->d_rs_pay.ensure(rtot * 4));
-    HIPCHK(c, c->d_rs_cnt.ensure((size_t)rows * G * 4));
+    HIPCHK(c, A.state.ensure(qtot * 16 * 2 * kRsStreams)); HIPCHK(c, A.hit.ensure(qtot * 16));
+    HIPCHK(c, A.cls.ensure((size_t)nitems * 4)); HIPCHK(c, A.fin.ensure((size_t)nitems * 16)); HIPCHK(c, A.cold.ensure((size_t)nitems * 16 * 5));
+    HIPCHK(c, A.occ.ensure((size_t)nitems * kRsOcc)); HIPCHK(c, A.cand.ensure((size_t)nitems * 4 * kRsCand));
+    HIPCHK(c, A.sho.ensure(rtot * 16)); HIPCHK(c, A.shd.ensure(rtot * 16)); HIPCHK(c, A.pay.ensure(rtot * 4));
+    HIPCHK(c, A.cnt.ensure((size_t)rows * G * 4));
     RsQ& q = R.q;
     q.nitems = nitems; q.pixels = pixels; q.G = G; q.qcap = qcap; q.rcap = rcap;
-    for (uint32_t set = 0; set < 2; set++) for (uint32_t k = 0; k < kRsStreams; k++) q.st[set][k] = (F4*)c->d_rs_state.p + ((size_t)set * kRsStreams + k) * qtot;
-    q.hit = (F4*)c->d_rs_hit.p; q.cls = (uint32_t*)c->d_rs_cls.p; q.fin = (F4*)c->d_rs_fin.p; q.cold = (F4*)c->d_rs_cold.p;
-    q.occ = (uint8_t*)c->d_rs_occ.p; q.cand = (uint32_t*)c->d_rs_cand.p;
-    q.sh_o = (F4*)c->d_rs_sho.p; q.sh_d = (F4*)c->d_rs_shd.p; q.sh_pay = (uint32_t*)c->d_rs_pay.p;
+    for (uint32_t set = 0; set < 2; set++) for (uint32_t k = 0; k < kRsStreams; k++) q.st[set][k] = (F4*)A.state.p + ((size_t)set * kRsStreams + k) * qtot;
+    q.hit = (F4*)A.hit.p; q.cls = (uint32_t*)A.cls.p; q.fin = (F4*)A.fin.p; q.cold = (F4*)A.cold.p;
+    q.occ = (uint8_t*)A.occ.p; q.cand = (uint32_t*)A.cand.p;
+    q.sh_o = (F4*)A.sho.p; q.sh_d = (F4*)A.shd.p; q.sh_pay = (uint32_t*)A.pay.p;
     q.rays = (unsigned long long*)c->d_p1cnt.p;
-    R.cnt = (uint32_t*)c->d_rs_cnt.p; R.G = G;
+    R.cnt = (uint32_t*)A.cnt.p; R.G = G;
     R.fq = f; R.fq.nblocks = G; R.fq.qcap = qcap;
     for (uint32_t set = 0; set < 2; set++) {          // what k_trace_closest sees of a set: rays and hit records by queue position ("compact state": out_o != nullptr is the flag)
         DevPaths P{}; P.ray_o = q.st[set][0]; P.ray_d = q.st[set][1]; P.hit = q.hit; P.out_o = q.st[set ^ 1u][0];
@@ -630,45 +635,71 @@ static int rs_plan(rtx_ctx* c, const DevFrame& f, uint32_t nitems, const uint32_
     return RTX_OK;
 }
 // pass 1 of one sample (RayGen_v6_pass1.hlsl:48-190): raygen | trace | ris | trace | ris_finish | trace | first | (trace | loop) x bounces | emit_final | trace | finish.
-// bufs != nullptr (a ReSTIR frame): pass 2 (RayGen_v6_pass2.hlsl:46-204) rides on the last two stages
-static int rs_pass1(rtx_ctx* c, const DevFrame& f, uint32_t sample_id, F4* accum, const uint32_t* pixels, uint32_t npixels, uint32_t* const* bufs) {
+// bufs != nullptr (a ReSTIR frame): pass 2 (RayGen_v6_pass2.hlsl:46-204) rides on the last two stages.  Everything is enqueued on `st` with the work area of `lane`.
+static int rs_pass1(rtx_ctx* c, const DevFrame& f, uint32_t sample_id, F4* accum, const uint32_t* pixels, uint32_t npixels, uint32_t* const* bufs, uint32_t lane, hipStream_t st) {
     const uint32_t mb = f.max_bounces, rows = 4u + mb + 1u;
-    RsPlan R; int r = rs_plan(c, f, pixels ? npixels : f.npl, pixels, rows, R); if (r) return r;
-    hipStream_t st = c->stream;
+    RsPlan R; int r = rs_plan(c, f, pixels ? npixels : f.npl, pixels, rows, R, lane); if (r) return r;
     const DevScene& sc = c->dsc; const RsQ& q = R.q;
     const CameraGPU* cam = (const CameraGPU*)c->d_cam.p;
     auto row = [&](uint32_t k) { return R.cnt + (size_t)k * R.G; };
     uint32_t* res_di = (uint32_t*)c->d_res_di.p; uint32_t* res_gi = (uint32_t*)c->d_res_gi.p; uint32_t* sdata = (uint32_t*)c->d_sdata.p;
     uint32_t* shrow = row(4 + mb);                          // lengths of the ray sub-queues: DI visibility (stage 2) + reconnection + temporal rays (stage 5)
-    { Timed t(c, RTX_K_RAYGEN); launch_rs_raygen(st, R.fq, q, cam, sample_id, row(0)); }
-    { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, R.fq, sc, R.P[0], 0, nullptr, row(0), nullptr); }                    // camera rays (tmin 1e-4)
-    { Timed t(c, RTX_K_SHADE); launch_rs_p1_ris(st, sc, R.fq, q, row(0), row(1), accum, res_di, res_gi, sdata); }
-    { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, R.fq, sc, R.P[1], 1, nullptr, row(1), nullptr); }                    // the BSDF candidates of SampleRIS
-    { Timed t(c, RTX_K_SHADE); launch_rs_p1_ris_finish(st, sc, R.fq, q, row(1), row(2), shrow, res_di, sdata); }
-    { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, R.fq, sc, R.P[0], 1, nullptr, row(2), nullptr); }                    // first path vertex
-    { Timed t(c, RTX_K_SHADE); launch_rs_p1_first(st, sc, R.fq, q, row(2), row(3)); }
+    { Timed t(c, RTX_K_RAYGEN, st); launch_rs_raygen(st, R.fq, q, cam, sample_id, row(0)); }
+    { Timed t(c, RTX_K_TRACE, st); launch_trace_closest(st, R.fq, sc, R.P[0], 0, nullptr, row(0), nullptr); }                    // camera rays (tmin 1e-4)
+    { Timed t(c, RTX_K_SHADE, st); launch_rs_p1_ris(st, sc, R.fq, q, row(0), row(1), accum, res_di, res_gi, sdata); }
+    { Timed t(c, RTX_K_TRACE, st); launch_trace_closest(st, R.fq, sc, R.P[1], 1, nullptr, row(1), nullptr); }                    // the BSDF candidates of SampleRIS
+    { Timed t(c, RTX_K_SHADE, st); launch_rs_p1_ris_finish(st, sc, R.fq, q, row(1), row(2), shrow, res_di, sdata); }
+    { Timed t(c, RTX_K_TRACE, st); launch_trace_closest(st, R.fq, sc, R.P[0], 1, nullptr, row(2), nullptr); }                    // first path vertex
+    { Timed t(c, RTX_K_SHADE, st); launch_rs_p1_first(st, sc, R.fq, q, row(2), row(3)); }
     for (uint32_t i = 0; i < mb; i++) {
         const uint32_t set = (i + 1u) & 1u;                 // k_rs_p1_first wrote set 1
-        { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, R.fq, sc, R.P[set], 1, nullptr, row(3 + i), nullptr); }
-        { Timed t(c, RTX_K_SHADE); launch_rs_p1_loop(st, sc, R.fq, q, set, i, row(3 + i), row(4 + i)); }
+        { Timed t(c, RTX_K_TRACE, st); launch_trace_closest(st, R.fq, sc, R.P[set], 1, nullptr, row(3 + i), nullptr); }
+        { Timed t(c, RTX_K_SHADE, st); launch_rs_p1_loop(st, sc, R.fq, q, set, i, row(3 + i), row(4 + i)); }
     }
-    { Timed t(c, RTX_K_SHADE); launch_rs_p1_emit_final(st, sc, R.fq, q, cam, bufs, shrow); }
-    { Timed t(c, RTX_K_SHADOW); launch_trace_occ(st, sc, q, shrow); }                                                        // DI visibility, the selected reconnection, the temporal pass's two rays
-    { Timed t(c, RTX_K_SHADE); launch_rs_p1_finish(st, sc, R.fq, q, accum, res_di, res_gi, sdata, cam, bufs); }
+    { Timed t(c, RTX_K_SHADE, st); launch_rs_p1_emit_final(st, sc, R.fq, q, cam, bufs, shrow); }
+    { Timed t(c, RTX_K_SHADOW, st); launch_trace_occ(st, sc, q, shrow); }                                                        // DI visibility, the selected reconnection, the temporal pass's two rays
+    { Timed t(c, RTX_K_SHADE, st); launch_rs_p1_finish(st, sc, R.fq, q, accum, res_di, res_gi, sdata, cam, bufs); }
     HIPCHK(c, hipGetLastError());
     return RTX_OK;
 }
-static int rs_pass3(rtx_ctx* c, const DevFrame& f, uint32_t* const bufs[6], F4* accum, const uint32_t* pixels, uint32_t npixels) {
-    RsPlan R; int r = rs_plan(c, f, pixels ? npixels : f.npl, pixels, 2, R); if (r) return r;
+static int rs_pass3(rtx_ctx* c, const DevFrame& f, uint32_t* const bufs[6], F4* accum, const uint32_t* pixels, uint32_t npixels, uint32_t lane, hipStream_t st) {
+    RsPlan R; int r = rs_plan(c, f, pixels ? npixels : f.npl, pixels, 2, R, lane); if (r) return r;
     const CameraGPU* cam = (const CameraGPU*)c->d_cam.p;
-    { Timed t(c, RTX_K_SHADE); launch_rs_p3_select(c->stream, c->dsc, R.fq, R.q, cam, bufs, R.cnt); }
-    { Timed t(c, RTX_K_SHADOW); launch_trace_occ(c->stream, c->dsc, R.q, R.cnt); }
-    { Timed t(c, RTX_K_SHADE); launch_rs_p3_merge(c->stream, c->dsc, R.fq, R.q, bufs, R.cnt + R.G); }
-    { Timed t(c, RTX_K_SHADOW); launch_trace_occ(c->stream, c->dsc, R.q, R.cnt + R.G); }
-    { Timed t(c, RTX_K_SHADE); launch_rs_p3_shade(c->stream, c->dsc, R.fq, R.q, bufs, accum); }
+    { Timed t(c, RTX_K_SHADE, st); launch_rs_p3_select(st, c->dsc, R.fq, R.q, cam, bufs, R.cnt); }
+    { Timed t(c, RTX_K_SHADOW, st); launch_trace_occ(st, c->dsc, R.q, R.cnt); }
+    { Timed t(c, RTX_K_SHADE, st); launch_rs_p3_merge(st, c->dsc, R.fq, R.q, bufs, R.cnt + R.G); }
+    { Timed t(c, RTX_K_SHADOW, st); launch_trace_occ(st, c->dsc, R.q, R.cnt + R.G); }
+    { Timed t(c, RTX_K_SHADE, st); launch_rs_p3_shade(st, c->dsc, R.fq, R.q, bufs, accum); }
     HIPCHK(c, hipGetLastError());
     return RTX_OK;
 }
+// One pass over a work list as `lanes` independent parts: part 0 on the context's stream, part 1 on the internal stream, joined at the end.  A ReSTIR frame is ~20 short,
+// dependent launches; run as ONE chain every launch drains before the next ramps up (k_trace_* at 4.8-5.0 of 8 waves per SIMD, VALU pipes 0.82 busy: profiles/r03_pmc_restir.md).
+// Pixels are independent inside passes 1 + 2 and inside pass 3, so two chains over the two halves of the list fill each other's tails.  Not while kernels are timed.
+extern "C++" {
+template <class F>
+static int rs_lanes(rtx_ctx* c, const uint32_t* pixels, uint32_t npixels, F&& pass) {
+    const uint32_t L = (pixels && !c->timing && npixels >= 1u << 16) ? c->restir_lanes : 1u;
+    if (L <= 1u) return pass(pixels, npixels, 0u, c->stream);
+    hipEvent_t e0 = take_event(c);
+    if (!e0) { c->err = "render_restir: out of events"; return RTX_ERR_HIP; }
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    const uint32_t part = (((npixels + L - 1u) / L) + 255u) & ~255u;          // whole chunks
+    for (uint32_t l = 0; l < L; l++) {
+        const uint32_t lo = std::min(npixels, l * part), hi = std::min(npixels, (l + 1u) * part);
+        if (lo == hi) continue;
+        hipStream_t st = c->stream;
+        if (l) {
+            if (!c->lane_stream[l - 1]) HIPCHK(c, hipStreamCreateWithFlags(&c->lane_stream[l - 1], hipStreamNonBlocking));
+            st = c->lane_stream[l - 1];
+            HIPCHK(c, hipStreamWaitEvent(st, e0, 0));
+        }
+        int r = pass(pixels + lo, hi - lo, l, st); if (r) return r;
+        if (l) { hipEvent_t e = take_event(c); if (!e) { c->err = "render_restir: out of events"; return RTX_ERR_HIP; } HIPCHK(c, hipEventRecord(e, st)); HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0)); }
+    }
+    return RTX_OK;
+}
+}  // extern "C++"
 static void stats_begin(rtx_ctx* c) {
     memset(c->stats.kernel_ms, 0, sizeof(c->stats.kernel_ms)); memset(c->stats.kernel_launches, 0, sizeof(c->stats.kernel_launches)); memset(c->stats.kernel_items, 0, sizeof(c->stats.kernel_items));
     c->ev_used = 0; c->timed.clear();
@@ -696,7 +727,7 @@ int rtx_render_v6_pass1(rtx_ctx* c, const rtx_params* p) {
     HIPCHK(c, hipMemsetAsync(c->d_p1cnt.p, 0, 24, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_begin, c->stream));
     for (uint32_t s = 0; s < p->spp; s++) {
-        if (c->restir_wave) { if ((r = rs_pass1(c, f, p->sample_base + s, c->accum_ptr(), nullptr, 0, nullptr))) return r; }
+        if (c->restir_wave) { if ((r = rs_pass1(c, f, p->sample_base + s, c->accum_ptr(), nullptr, 0, nullptr, 0u, c->stream))) return r; }
         else { Timed t(c, RTX_K_BOUNCE);
                launch_v6_pass1(c->stream, (uint32_t)c->num_cus * 8u, c->dsc, f, (const CameraGPU*)c->d_cam.p, p->sample_base + s, c->accum_ptr(),
                                (uint32_t*)c->d_res_di.p, (uint32_t*)c->d_res_gi.p, (uint32_t*)c->d_sdata.p, (unsigned long long*)c->d_p1cnt.p); }
@@ -801,6 +832,7 @@ int rtx_render_restir(rtx_ctx* c, const rtx_params* p) {
     // pass 1 writes its debug estimate into a scratch image (the displayed image is pass 3's)
     DevBuf& scratch = c->d_p1scratch; HIPCHK(c, scratch.ensure((size_t)p->width * p->height * 16));     // context-owned: no per-call hipMalloc / hipFree, nothing to leak on an early return
     stats_begin(c);
+    struct LaneJoin { rtx_ctx* c; ~LaneJoin() { for (hipStream_t ls : c->lane_stream) if (ls) (void)hipStreamSynchronize(ls); } } lane_join{c};      // no early return leaves another lane running
     HIPCHK(c, hipMemsetAsync(c->d_p1cnt.p, 0, 24, c->stream));
     uint32_t* bufs[6] = {(uint32_t*)c->d_res_di.p, (uint32_t*)c->d_res_gi.p, (uint32_t*)c->d_sdata.p, (uint32_t*)c->d_last_di.p, (uint32_t*)c->d_last_gi.p, (uint32_t*)c->d_last_sd.p};
     const uint32_t mbk = (uint32_t)c->num_cus * 8u;
@@ -810,8 +842,8 @@ int rtx_render_restir(rtx_ctx* c, const rtx_params* p) {
         DevFrame ff = f; ff.frame_seed = p->frame_seed + fr;
         HIPCHK(c, hipMemsetAsync(scratch.p, 0, (size_t)p->width * p->height * 16, c->stream));
         if (c->restir_wave) {                                                                                                               // the three DispatchRays of Renderer.cpp:646-673 as wavefront stages
-            if ((r = rs_pass1(c, ff, 1u, (F4*)scratch.p, halo, nhalo, bufs))) return r;              // passes 1 + 2
-            if ((r = rs_pass3(c, ff, bufs, c->accum_ptr(), own, nown))) return r;
+            if ((r = rs_lanes(c, halo, nhalo, [&](const uint32_t* px, uint32_t n, uint32_t lane, hipStream_t st) { return rs_pass1(c, ff, 1u, (F4*)scratch.p, px, n, bufs, lane, st); }))) return r;   // passes 1 + 2
+            if ((r = rs_lanes(c, own, nown, [&](const uint32_t* px, uint32_t n, uint32_t lane, hipStream_t st) { return rs_pass3(c, ff, bufs, c->accum_ptr(), px, n, lane, st); }))) return r;
         } else {                                                                                                                            // ... or literally, a thread per pixel
             { Timed t(c, RTX_K_BOUNCE); launch_v6_pass1(c->stream, mbk, c->dsc, ff, cam, 1u, (F4*)scratch.p, bufs[0], bufs[1], bufs[2], (unsigned long long*)c->d_p1cnt.p, sharded ? halo : nullptr, sharded ? nhalo : 0u); }   // Renderer.cpp:651-654
             { Timed t(c, RTX_K_BOUNCE); launch_restir_pass2(c->stream, mbk, c->dsc, ff, cam, bufs, (unsigned long long*)c->d_p1cnt.p, sharded ? halo : nullptr, sharded ? nhalo : 0u); }                                       // :662-664

@@ -1124,7 +1124,8 @@ void launch_rs_p3_select(hipStream_t st, const DevScene& sc, const DevFrame& f, 
     hipLaunchKernelGGL(k_rs_p3_select, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, cam, rs_bufs(bufs), shcnt);
 }
 void launch_rs_p3_merge(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, uint32_t* const bufs[6], uint32_t* shcnt) {
-    hipLaunchKernelGGL(k_rs_p3_merge, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, rs_bufs(bufs), shcnt);
+    hipLaunchKernelGGL(k_rs_p3_merge<false>, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, rs_bufs(bufs), shcnt);
+    hipLaunchKernelGGL(k_rs_p3_merge<true>, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, rs_bufs(bufs), shcnt);
 }
 void launch_rs_p3_shade(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, uint32_t* const bufs[6], F4* accum) {
     hipLaunchKernelGGL(k_rs_p3_shade, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, rs_bufs(bufs), accum);

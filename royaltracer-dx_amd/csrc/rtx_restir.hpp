@@ -598,14 +598,15 @@ __device__ __forceinline__ void p3_select(const DevScene& sc, const DevFrame& f,
         if (ok) { K.gi[K.n_gi++] = (uint32_t)pr; K.M_sum_GI += minf_u(128.0f, gn.M); }
     }
 }
-// rcur / gcur: in = this pixel's reservoirs after pass 2, out = merged (w_sum, M, selected sample; W still to be set by p3_shade)
+// The two merges are independent but for the random-number stream: the DI merge draws one number per DI candidate, then the GI merge one per GI candidate that takes part.
+// rcur / gcur: in = this pixel's reservoir after pass 2, out = merged (w_sum, M, selected sample; W still to be set by p3_shade)
 template <class V>
-__device__ __forceinline__ void p3_merge(const DevScene& sc, const DevFrame& f, const RestirBufs& B, const SData& sd, const MatGPU& m, const P3Cand& K,
-                                         Res& rcur, Res& gcur, uint32_t& s0, uint32_t& s1, V&& vis) {
+__device__ __forceinline__ void p3_merge_di(const DevScene& sc, const DevFrame& f, const RestirBufs& B, const SData& sd, const MatGPU& m, const P3Cand& K,
+                                            Res& rcur, uint32_t& s0, uint32_t& s1, V&& vis) {
     const uint32_t flags = f.flags;
-    const float M_sum_DI = K.M_sum_DI, M_sum_GI = K.M_sum_GI;
-    const int n_di = K.n_di, n_gi = K.n_gi;
-    const Res can = rcur, can_gi = gcur;
+    const float M_sum_DI = K.M_sum_DI;
+    const int n_di = K.n_di;
+    const Res can = rcur;
     const float cMmin = minf_u(128.0f, can.M), cMmax = M_sum_DI - cMmin;
     const float p_c = p_hat_di(flags, m, sd.x1, sd.n1, can.x2, can.n2, can.L2, sd.o, -1, vis);
     const float c_m_num = cMmin * p_c; float mi_c = cMmin / M_sum_DI;
@@ -617,6 +618,25 @@ __device__ __forceinline__ void p3_merge(const DevScene& sc, const DevFrame& f, 
         if (m_den > 0.0f) mi_c += (nM / M_sum_DI) * (c_m_num / m_den);
     }
     const float w_c = mi_c * p_hat_di(flags, m, sd.x1, sd.n1, can.x2, can.n2, can.L2, sd.o, -1, vis) * can.W;
+    rcur.M = (uint32_t)cMmin; rcur.w_sum = w_c;
+    for (int v = 0; v < n_di; v++) {
+        const SData sn = load_sd_dev(B.cur_sd + (size_t)K.di[v] * 15); const Res rn = load_res_dev(B.cur_di + (size_t)K.di[v] * 10);
+        const float pc2 = p_hat_di(flags, m, sd.x1, sd.n1, can.x2, can.n2, can.L2, sd.o, -1, vis);
+        const float p_from = p_hat_di(flags, m, sn.x1, sn.n1, can.x2, can.n2, can.L2, sn.o, -1, vis);
+        const float m_num = (M_sum_DI - cMmin) * p_from, m_den = m_num + (cMmin * pc2);
+        const float mi_s = m_den > 0.0f ? (minf_u(128.0f, rn.M) / M_sum_DI) * (m_num / m_den) : 0.0f;
+        const float w_s = mi_s * p_hat_di(flags, m, sd.x1, sd.n1, rn.x2, rn.n2, rn.L2, sd.o, -1, vis) * rn.W;
+        rcur.w_sum += w_s; rcur.M = (rcur.M + (uint32_t)minf_u(128.0f, rn.M)) & 0xFFFFu;
+        if (tea_next(s0, s1) < w_s / rcur.w_sum) { rcur.x2 = rn.x2; rcur.n2 = rn.n2; rcur.L2 = rn.L2; }
+    }
+}
+template <class V>
+__device__ __forceinline__ void p3_merge_gi(const DevScene& sc, const DevFrame& f, const RestirBufs& B, const SData& sd, const MatGPU& m, const P3Cand& K,
+                                            Res& gcur, uint32_t& s0, uint32_t& s1, V&& vis) {
+    const uint32_t flags = f.flags;
+    const float M_sum_GI = K.M_sum_GI;
+    const int n_gi = K.n_gi;
+    const Res can_gi = gcur;
     const float gMmin = minf_u(128.0f, can_gi.M), gMmax = M_sum_GI - gMmin;
     const float pg_c = length(p_hat_gi(flags, m, sd.x1, sd.n1, can_gi.x2, can_gi.L2, sd.o, -1, vis));
     const float g_m_num = gMmin * pg_c; float mi_c_gi = gMmin / M_sum_GI;
@@ -630,18 +650,7 @@ __device__ __forceinline__ void p3_merge(const DevScene& sc, const DevFrame& f, 
     }
     mi_c_gi = minf_(maxf_(mi_c_gi, 0.0f), 1.0f);
     const float w_c_gi = mi_c_gi * length(p_hat_gi(flags, m, sd.x1, sd.n1, can_gi.x2, can_gi.L2, sd.o, -1, vis)) * can_gi.W;
-    rcur.M = (uint32_t)cMmin; rcur.w_sum = w_c;
     gcur.M = (uint32_t)gMmin; gcur.w_sum = w_c_gi;
-    for (int v = 0; v < n_di; v++) {
-        const SData sn = load_sd_dev(B.cur_sd + (size_t)K.di[v] * 15); const Res rn = load_res_dev(B.cur_di + (size_t)K.di[v] * 10);
-        const float pc2 = p_hat_di(flags, m, sd.x1, sd.n1, can.x2, can.n2, can.L2, sd.o, -1, vis);
-        const float p_from = p_hat_di(flags, m, sn.x1, sn.n1, can.x2, can.n2, can.L2, sn.o, -1, vis);
-        const float m_num = (M_sum_DI - cMmin) * p_from, m_den = m_num + (cMmin * pc2);
-        const float mi_s = m_den > 0.0f ? (minf_u(128.0f, rn.M) / M_sum_DI) * (m_num / m_den) : 0.0f;
-        const float w_s = mi_s * p_hat_di(flags, m, sd.x1, sd.n1, rn.x2, rn.n2, rn.L2, sd.o, -1, vis) * rn.W;
-        rcur.w_sum += w_s; rcur.M = (rcur.M + (uint32_t)minf_u(128.0f, rn.M)) & 0xFFFFu;
-        if (tea_next(s0, s1) < w_s / rcur.w_sum) { rcur.x2 = rn.x2; rcur.n2 = rn.n2; rcur.L2 = rn.L2; }
-    }
     for (int v = 0; v < n_gi; v++) {
         const SData sn = load_sd_dev(B.cur_sd + (size_t)K.gi[v] * 15); const Res gn = load_res_dev(B.cur_gi + (size_t)K.gi[v] * 10);
         const float pc2 = length(p_hat_gi(flags, m, sd.x1, sd.n1, can_gi.x2, can_gi.L2, sd.o, -1, vis));
@@ -657,6 +666,12 @@ __device__ __forceinline__ void p3_merge(const DevScene& sc, const DevFrame& f, 
             if (tea_next(s0, s1) < w_s / gcur.w_sum) { gcur.x2 = gn.x2; gcur.n2 = gn.n2; gcur.L2 = gn.L2; }
         }
     }
+}
+template <class V>
+__device__ __forceinline__ void p3_merge(const DevScene& sc, const DevFrame& f, const RestirBufs& B, const SData& sd, const MatGPU& m, const P3Cand& K,
+                                         Res& rcur, Res& gcur, uint32_t& s0, uint32_t& s1, V&& vis) {
+    p3_merge_di(sc, f, B, sd, m, K, rcur, s0, s1, vis);
+    p3_merge_gi(sc, f, B, sd, m, K, gcur, s0, s1, vis);
 }
 // final W of both reservoirs and the pixel's radiance ReconnectDI * W + f_gi * W_gi (pass3:353-372)
 template <class V>

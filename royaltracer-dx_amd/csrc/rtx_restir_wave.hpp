@@ -373,7 +373,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_finish(DevScene sc, DevFram
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
-// PASS 3 (RayGen_v6_pass3.hlsl:46-441): select (+ emit rays 0-8) | trace | merge (+ emit ray 9) | trace | shade
+// PASS 3 (RayGen_v6_pass3.hlsl:46-441): select (+ emit rays 0-8) | trace | merge DI (+ emit ray 9) | merge GI | trace | shade
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool p3_samples(const DevScene& sc, const SData& sd) {      // the pixel runs the spatial pass (not a light seen directly, not a miss)
     return (sd.L1.x == 0.0f && sd.L1.y == 0.0f && sd.L1.z == 0.0f) && !(sd.mID == 0xFFFEu || sd.mID >= sc.nmat);
@@ -419,6 +419,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p3_select(DevScene sc, DevFram
     }
     rs_publish(nullptr, nullptr, shcnt, &s_rn, q, 1);
 }
+// GI = false: the DI merge (+ the ray of the selected DI sample); GI = true: the GI merge, whose random numbers continue behind the n_di the DI merge drew.  Two launches
+// of half the register pressure each: as one kernel the merge needed 128 VGPRs with 51 of them spilled (148 B of scratch per lane).
+template <bool GI>
 __global__ __launch_bounds__(kBlock, 4) void k_rs_p3_merge(DevScene sc, DevFrame f, RsQ q, RestirBufs B, uint32_t* __restrict__ shcnt) {
     __shared__ uint32_t s_rn;
     if (threadIdx.x == 0) s_rn = 0;
@@ -438,15 +441,22 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p3_merge(DevScene sc, DevFrame
                 P3Cand K; K.n_di = 0; K.n_gi = 0;
                 for (int k = 0; k < 3; k++) { K.di[k] = rec[k]; K.gi[k] = rec[3 + k]; if (rec[k] != 0xFFFFFFFFu) K.n_di = k + 1; if (rec[3 + k] != 0xFFFFFFFFu) K.n_gi = k + 1; }
                 uint32_t s0 = rec[6], s1 = rec[7]; K.M_sum_DI = u2f(rec[8]); K.M_sum_GI = u2f(rec[9]);
-                Res rcur = load_res_dev(B.cur_di + slot * 10), gcur = load_res_dev(B.cur_gi + slot * 10);
-                p3_merge(sc, f, B, sd, sc.mats[sd.mID], K, rcur, gcur, s0, s1, VisLookup{q.occ + (size_t)it * kRsOcc});
-                store_res(B.last_di + slot * 10, rcur); store_res(B.last_gi + slot * 10, gcur);          // W still to come (k_rs_p3_shade)
-                vis_ray(sd.x1, sd.n1, rcur.x2, so, sdv);
+                if (!GI) {
+                    Res rcur = load_res_dev(B.cur_di + slot * 10);
+                    p3_merge_di(sc, f, B, sd, sc.mats[sd.mID], K, rcur, s0, s1, VisLookup{q.occ + (size_t)it * kRsOcc});
+                    store_res(B.last_di + slot * 10, rcur);                                                  // W still to come (k_rs_p3_shade)
+                    vis_ray(sd.x1, sd.n1, rcur.x2, so, sdv);
+                } else {
+                    for (int k = 0; k < K.n_di; k++) (void)tea_next(s0, s1);                                 // the DI merge's draws
+                    Res gcur = load_res_dev(B.cur_gi + slot * 10);
+                    p3_merge_gi(sc, f, B, sd, sc.mats[sd.mID], K, gcur, s0, s1, VisLookup{q.occ + (size_t)it * kRsOcc});
+                    store_res(B.last_gi + slot * 10, gcur);
+                }
             }
         }
-        rs_push_ray(q, &s_rn, run, so, sdv, it * kRsOcc + 9u);
+        if (!GI) rs_push_ray(q, &s_rn, run, so, sdv, it * kRsOcc + 9u);
     }
-    rs_publish(nullptr, nullptr, shcnt, &s_rn, q, 1);
+    if (!GI) rs_publish(nullptr, nullptr, shcnt, &s_rn, q, 1);
 }
 __global__ __launch_bounds__(kBlock, 4) void k_rs_p3_shade(DevScene sc, DevFrame f, RsQ q, RestirBufs B, F4* __restrict__ accum) {
     const uint32_t nchunks = (q.nitems + kBlock - 1) / kBlock;
