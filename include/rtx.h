@@ -100,6 +100,10 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
                                         pixels aiming at the same light / sample).  Any-hit is existence, so results are identical — and it is MEASURED SLOWER (same box, alternating:
                                         k_trace_shadow 11.63 -> 12.23 ms on C3, 10.21 -> 10.48 on C5, ReSTIR frames +1 %): the extra triangle step per ray costs more than
                                         the early exits save.  Default 0 */
+       RTX_OPT_SHADE_DENSE = 23,     /* general path: 1 = k_shade compacts the HITS of its sub-queue through an LDS ring and shades full waves of them (k_shade_dense), 0 (default) = shades
+                                        the queue entries in place (lanes whose ray missed idle).  Results identical.  MEASURED, same box alternating: no gain where it was meant to help
+                                        (C5, 14-56 % of a bounce's rays miss: k_shade 8.20 vs 8.22 ms — the lanes are lost inside the NEE / BSDF sections, not at their entry) and
+                                        slower where nearly every ray hits (C3: 6.51 -> 7.89 ms: two barriers and a second read of the hit record per 256 entries) */
        RTX_OPT_RESTIR_LANES = 22,    /* 2 (default): the pixels of a ReSTIR frame are processed as two independent halves on two streams (passes 1 + 2, then pass 3), so that the
                                         many short dependent launches of one half fill the launch tails of the other; 1: one chain.  Off while RTX_OPT_KERNEL_TIMING is on.
                                         Results identical */

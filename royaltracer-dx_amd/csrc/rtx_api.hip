@@ -37,10 +37,10 @@ struct rtx_ctx {
     int num_cus = 256;
     SceneHost host; BuiltScene built;
     bool committed = false, camera_set = false;
-    DevBuf d_nodes, d_tris, d_small, d_small_tris, d_small_poly, d_shade, d_mats, d_insts, d_lights, d_cam;
+    DevBuf d_nodes, d_tris, d_small, d_small_tris, d_small_poly, d_shade, d_mats, d_insts, d_lights, d_cdf, d_cam;
     DevBuf d_objtris, d_node_aabb, d_scale;          // GPU refit: object-space vertices (uploaded on first use), per-node float boxes, max |coordinate|
     bool gpu_refit = true, device_scene_valid = false, objtris_uploaded = false;
-    uint32_t refill_min = 12, trace_sched = 6, sort_materials = 0, blocks_per_cu = 0 /* 0 = auto */, occluder_cache = 0;       // persistent-traversal knobs (RTX_OPT_REFILL_MIN, RTX_OPT_TRACE_SCHED)
+    uint32_t refill_min = 12, trace_sched = 6, sort_materials = 0, blocks_per_cu = 0 /* 0 = auto */, occluder_cache = 0; int shade_dense = 0;       // persistent-traversal knobs (RTX_OPT_REFILL_MIN, RTX_OPT_TRACE_SCHED)
     DevScene dsc{};
     float view[16], proj[16];
     // path state
@@ -125,7 +125,7 @@ void rtx_destroy(rtx_ctx* c) {
     // synchronises before it returns or documents that it only enqueues, so only the context's own stream is drained here
     if (c->own_stream && c->stream) (void)hipStreamSynchronize(c->stream);
     else (void)hipDeviceSynchronize();
-    DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_small_poly, &c->d_objtris, &c->d_node_aabb, &c->d_scale, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
+    DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_small_poly, &c->d_objtris, &c->d_node_aabb, &c->d_scale, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cdf, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
                      &c->d_thr, &c->d_rad, &c->d_hit, &c->d_hitmask, &c->d_order, &c->d_pmask, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
                      &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq, &c->d_halo, &c->d_own, &c->d_heads, &c->d_alt_o, &c->d_alt_d, &c->d_alt_thr};
     for (auto& A : c->rs_area) for (DevBuf* b : {&A.state, &A.hit, &A.cls, &A.fin, &A.cold, &A.occ, &A.cand, &A.sho, &A.shd, &A.pay, &A.cnt}) b->release();
@@ -160,6 +160,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_OVERLAP_SHADOW: c->overlap_shadow = value != 0; return RTX_OK;
     case RTX_OPT_BLOCKS_PER_CU: if (value < 0 || value > 64) { c->err = "blocks_per_cu must be in [0, 64]"; return RTX_ERR_INVALID; } c->blocks_per_cu = (uint32_t)value; return RTX_OK;
     case RTX_OPT_GPU_REFIT: c->gpu_refit = value != 0; return RTX_OK;
+    case RTX_OPT_SHADE_DENSE: c->shade_dense = (int)value; c->dsc.shade_dense = value > 0 ? 1u : 0u; return RTX_OK;
     case RTX_OPT_OCCLUDER_CACHE: c->occluder_cache = value != 0; c->dsc.occluder_cache = c->occluder_cache; return RTX_OK;
     case RTX_OPT_RESTIR_WAVEFRONT: c->restir_wave = value != 0; return RTX_OK;
     case RTX_OPT_RESTIR_LANES: if (value < 1 || value > 4) { c->err = "restir_lanes must be in [1, 4]"; return RTX_ERR_INVALID; } c->restir_lanes = (uint32_t)value; return RTX_OK;
@@ -201,6 +202,14 @@ int rtx_set_instance_transform(rtx_ctx* c, uint32_t inst, const float o2w[16]) {
     c->committed = false; return RTX_OK;
 }
 
+static int upload_lights(rtx_ctx* c) {         // the light records and their CDF as a dense float array (DevScene::cdf)
+    const BuiltScene& B = c->built;
+    std::vector<float> cdf(B.lights.size());
+    for (size_t i = 0; i < cdf.size(); i++) cdf[i] = B.lights[i].cdf;
+    int r = upload(c, c->d_lights, B.lights);
+    if (r) return r;
+    return upload(c, c->d_cdf, cdf);
+}
 static int upload_built(rtx_ctx* c) {          // every device array of a freshly built (or freshly loaded) scene
     BuiltScene& B = c->built;
     int r;
@@ -212,7 +221,7 @@ static int upload_built(rtx_ctx* c) {          // every device array of a freshl
     if ((r = upload(c, c->d_small_poly, B.small_poly))) return r;
     if ((r = upload(c, c->d_mats, B.mats))) return r;
     if ((r = upload(c, c->d_insts, B.insts))) return r;
-    return upload(c, c->d_lights, B.lights);
+    return upload_lights(c);
 }
 static int finalise_scene(rtx_ctx* c);
 
@@ -231,7 +240,7 @@ int rtx_commit_scene(rtx_ctx* c) {
         if (!c->host.refresh_transforms(B)) { c->err = c->host.err; return RTX_ERR_INVALID; }
         if (mats_changed && (r = upload(c, c->d_mats, B.mats))) return r;      // rtx_set_materials on a resident scene: new table beside the new light list
         if ((r = upload(c, c->d_insts, B.insts))) return r;
-        if ((r = upload(c, c->d_lights, B.lights))) return r;
+        if ((r = upload_lights(c))) return r;
         if (!c->objtris_uploaded) {
             if (B.objtris.empty()) c->host.fill_objtris(B);             // scene came from a cache file: derive them from the meshes now
             if ((r = upload(c, c->d_objtris, B.objtris))) return r; c->objtris_uploaded = true;
@@ -278,7 +287,7 @@ static int finalise_scene(rtx_ctx* c) {
     s.small = (const SmallRecPair*)c->d_small.p; s.small_tris = (const TriGPU*)c->d_small_tris.p; s.small_poly = (const F4*)c->d_small_poly.p; s.small_cm = B.small_cm; s.small_delta = B.small_delta;
     s.mats = (const MatGPU*)c->d_mats.p; s.nmat = (uint32_t)B.mats.size();
     s.insts = (const InstGPU*)c->d_insts.p; s.ninst = (uint32_t)B.insts.size();
-    s.lights = (const LightGPU*)c->d_lights.p; s.nlights = (uint32_t)B.lights.size();
+    s.lights = (const LightGPU*)c->d_lights.p; s.nlights = (uint32_t)B.lights.size(); s.cdf = (const float*)c->d_cdf.p;
     s.total_weight = B.total_weight;
     // LDS budget per workgroup: stack + top of tree + first triangles, kept <= 64 KiB
     // exact bound of the 8-wide tree, no slack: a level adds ONE entry (the rest of its hit siblings) and only where a node has >= 2 internal
@@ -301,7 +310,7 @@ static int finalise_scene(rtx_ctx* c) {
     uint32_t want_tris = s.ntris <= 256 ? s.ntris : 0u;                    // triangles only when ALL of them fit
     s.lds_tris = (size_t)want_tris * 48 <= budget ? want_tris : 0u;
     s.nsmall = 0; s.nsmall_occ = 0;
-    s.refill_min = c->refill_min; s.trace_sched = c->trace_sched; s.sort_materials = c->sort_materials; s.occluder_cache = c->occluder_cache;
+    s.refill_min = c->refill_min; s.trace_sched = c->trace_sched; s.sort_materials = c->sort_materials; s.occluder_cache = c->occluder_cache; s.shade_dense = c->shade_dense > 0 ? 1u : 0u;
     if (c->small_scene && B.small_nrec && B.small_tris.size() * 48 <= budget + (size_t)s.lds_tris * 48) {
         s.nsmall = B.small_nrec; s.nsmall_occ = B.small_nocc; s.lds_tris = (uint32_t)B.small_tris.size();   // LDS holds the records' triangles instead of the leaf-ordered ones
     }

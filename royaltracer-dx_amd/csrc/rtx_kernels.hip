@@ -253,6 +253,61 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_shadow(DevSce
 // frame loses 1-10 %.  Round 2, with the path state kept by queue position (the permutation then stays inside a 2048-entry window of
 // each stream): still slower, k_shade per frame 7.4 -> 10.6 ms (Sponza-class), 8.6 -> 9.8 ms (Bistro-class, where k_shade is VALU-bound at
 // 33 of 64 lanes).  Hence RTX_OPT_SORT_MATERIALS defaults to 0.
+// One item of k_shade / k_shade_dense: entry `qi` of the workgroup's sub-queue (valid = the lane has one).  Every lane of the wave goes through the compactions.
+template <bool LAMBERT>
+__device__ __forceinline__ void shade_item(const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce, uint32_t nee, bool last, size_t qb,
+                                           const uint32_t* __restrict__ myq, uint32_t* __restrict__ mynext, uint32_t* s_cnt, bool valid, uint32_t qi, Prof* pf) {
+    PathState S; S.pid = 0; S.o = mk3(0, 0, 0); S.d = mk3(0, 0, 1); S.thr = mk3(0, 0, 0); S.prev_pdf = 1.0f; S.s0 = S.s1 = 0;
+    Surf sf; sf.mat = 0; sf.normal = mk3(0, 0, 1); sf.pos = mk3(0, 0, 0);
+    bool shading = false;
+    if (valid) {
+        const uint32_t pid = myq[qi];
+        const uint32_t src = p.out_o ? (uint32_t)qb + qi : pid;               // compact state: hit and path state live at the queue position
+        const F4 h = p.hit[src];
+        const uint32_t prim = f2u(h.w);
+        if (prim != kMissPrim) {                                          // miss: Miss.hlsl:3-11 -> black, terminate
+            S = load_path(p, src); S.pid = pid;
+            PF_MARK(0); PF_COUNT(1);
+            sf = surface(sc, S.o, S.d, h.x, h.y, h.z, prim);
+            PF_MARK(1);
+            if (sf.mat < sc.nmat) {
+                const MatGPU& m = sc.mats[sf.mat];
+                if (m.Ke_len > 0.0f) add_emissive(sc, p, S, sf, m, bounce, nee);   // Hit.hlsl:126, Sampler_v6.hlsl:457
+                else shading = true;
+            }
+        }
+    }
+    const f3 outgoing = -S.d, pos = sf.pos;
+    const MatGPU* mp = sc.mats + (shading ? sf.mat : 0u);
+    f3 normal = sf.normal;
+    const float eta_p = LAMBERT ? 0.0f : transmission_eta(*mp, f.flags, outgoing, normal);          // (extension) hits from behind a dielectric flip the shading normal
+    PF_MARK(2);
+    for (uint32_t j = 0; j < nee; j++) {                                  // NEE: visibility deferred to k_trace_shadow
+        bool push = false;
+        F4 so = {0, 0, 0, 0}, sd = {0, 0, 0, 0}; f3 con = mk3(0, 0, 0);
+        if (shading) { PF_COUNT(3); }
+        if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con, sc.nsmall != 0u && sf.near_hull, eta_p);
+        PF_MARK(3);
+        if (push) { PF_COUNT(4); }
+        const size_t seg = (size_t)j * f.qcap * gridDim.x + qb;           // NEE slot j, this workgroup's sub-queue
+        const uint32_t slot = block_push(push, &s_cnt[1 + j]);
+        if (push) { p.sh_o[seg + slot] = so; p.sh_d[seg + slot] = sd; p.sh_c[seg + slot] = {con.x, con.y, con.z, u2f(S.pid)}; }
+    }
+    PF_MARK(4);
+    bool alive = false;
+    f3 smp = mk3(0, 0, 1); float P = 0.0f;
+    if (shading && !last) { PF_COUNT(5); }
+    if (shading && !last) alive = bsdf_continue(*mp, f, bounce, S, normal, outgoing, smp, P, eta_p);
+    PF_MARK(5);
+    if (alive) { PF_COUNT(6); }
+    const uint32_t slot = block_push(alive, &s_cnt[0]);
+    if (alive) {
+        if (p.out_o) store_path_at(p.out_o, p.out_d, p.out_thr, (uint32_t)qb + slot, S, pos, smp, P);     // densely, at its place in the next queue
+        else store_path(p, S, pos, smp, P);
+        mynext[slot] = S.pid;
+    }
+}
+
 constexpr uint32_t kSortChunk = 2048, kSortKeys = 64;
 #ifndef RTX_SHADE_WAVES
 #define RTX_SHADE_WAVES 6          // waves per SIMD k_shade is compiled for: 6 = 80 VGPRs, no spills (uncapped: 94 VGPRs, 5 waves; 8: 64 VGPRs, 8 spilled).  k_shade
@@ -303,61 +358,63 @@ __global__ __launch_bounds__(kBlock, RTX_SHADE_WAVES) void k_shade(DevScene sc, 
         }
         for (uint32_t base = threadIdx.x & ~63u; base < cn; base += kBlock) {
             const uint32_t i = base + (threadIdx.x & 63u);
-            PathState S; S.pid = 0; S.o = mk3(0, 0, 0); S.d = mk3(0, 0, 1); S.thr = mk3(0, 0, 0); S.prev_pdf = 1.0f; S.s0 = S.s1 = 0;
-            Surf sf; sf.mat = 0; sf.normal = mk3(0, 0, 1); sf.pos = mk3(0, 0, 0);
-            bool shading = false;
-            if (i < cn) {
-                const uint32_t qi = cb + (SORT ? s_sorted[i] : i);                // entry of the sub-queue
-                const uint32_t pid = myq[qi];
-                const uint32_t src = p.out_o ? (uint32_t)qb + qi : pid;               // compact state: hit and path state live at the queue position
-                const F4 h = p.hit[src];
-                const uint32_t prim = f2u(h.w);
-                if (prim != kMissPrim) {                                          // miss: Miss.hlsl:3-11 -> black, terminate
-                    S = load_path(p, src); S.pid = pid;
-                    PF_MARK(0); PF_COUNT(1);
-                    sf = surface(sc, S.o, S.d, h.x, h.y, h.z, prim);
-                    PF_MARK(1);
-                    if (sf.mat < sc.nmat) {
-                        const MatGPU& m = sc.mats[sf.mat];
-                        if (m.Ke_len > 0.0f) add_emissive(sc, p, S, sf, m, bounce, nee);   // Hit.hlsl:126, Sampler_v6.hlsl:457
-                        else shading = true;
-                    }
-                }
-            }
-            const f3 outgoing = -S.d, pos = sf.pos;
-            const MatGPU* mp = sc.mats + (shading ? sf.mat : 0u);
-            f3 normal = sf.normal;
-            const float eta_p = LAMBERT ? 0.0f : transmission_eta(*mp, f.flags, outgoing, normal);          // (extension) hits from behind a dielectric flip the shading normal
-            PF_MARK(2);
-            for (uint32_t j = 0; j < nee; j++) {                                  // NEE: visibility deferred to k_trace_shadow
-                bool push = false;
-                F4 so = {0, 0, 0, 0}, sd = {0, 0, 0, 0}; f3 con = mk3(0, 0, 0);
-                if (shading) { PF_COUNT(3); }
-                if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con, sc.nsmall != 0u && sf.near_hull, eta_p);
-                PF_MARK(3);
-                if (push) { PF_COUNT(4); }
-                const size_t seg = (size_t)j * f.qcap * gridDim.x + qb;           // NEE slot j, this workgroup's sub-queue
-                const uint32_t slot = block_push(push, &s_cnt[1 + j]);
-                if (push) { p.sh_o[seg + slot] = so; p.sh_d[seg + slot] = sd; p.sh_c[seg + slot] = {con.x, con.y, con.z, u2f(S.pid)}; }
-            }
-            PF_MARK(4);
-            bool alive = false;
-            f3 smp = mk3(0, 0, 1); float P = 0.0f;
-            if (shading && !last) { PF_COUNT(5); }
-            if (shading && !last) alive = bsdf_continue(*mp, f, bounce, S, normal, outgoing, smp, P, eta_p);
-            PF_MARK(5);
-            if (alive) { PF_COUNT(6); }
-            const uint32_t slot = block_push(alive, &s_cnt[0]);
-            if (alive) {
-                if (p.out_o) store_path_at(p.out_o, p.out_d, p.out_thr, (uint32_t)qb + slot, S, pos, smp, P);     // densely, at its place in the next queue
-                else store_path(p, S, pos, smp, P);
-                mynext[slot] = S.pid;
-            }
+            shade_item<LAMBERT>(sc, f, p, bounce, nee, last, qb, myq, mynext, s_cnt, i < cn, cb + (SORT ? s_sorted[i] : i), pf);
         }
         if (SORT) __syncthreads();                              // the next chunk overwrites the LDS buffers
     }
     PF_MARK(6);
     PF_FLUSH;
+    __syncthreads();
+    if (threadIdx.x == 0) next_count[blockIdx.x] = s_cnt[0];
+    if (threadIdx.x >= 1 && threadIdx.x <= nee) shcounts[(size_t)(threadIdx.x - 1) * gridDim.x + blockIdx.x] = s_cnt[threadIdx.x];
+}
+
+// k_shade with the HITS of the sub-queue compacted before they are shaded (RTX_OPT_SHADE_DENSE).  In an open scene a large part of a bounce's rays leaves the scene
+// (the Bistro-class street keeps 86 / 66 / 53 / 44 % of its paths through bounces 1-4) and in k_shade their lanes idle through surface reconstruction, NEE and BSDF
+// sampling, which on that scene is VALU-bound work at 33 of 64 lanes (profiles/r02_pmc_bvh.md).  Here the workgroup reads the hit records of 256 entries at a time, pushes
+// the entries that hit something into an LDS ring (ballot + one LDS atomic per wave), and shades ring entries 256 at a time — full waves of hits, as the hit ring of the
+// fused tiny-scene kernel does.  The permutation stays inside the workgroup's sub-queue, so the state streams stay coalesced (monotone gathers within a 2-KB window; this is
+// not the global material sort that was rightly rejected).  Same arithmetic per item; only the order of the entries in the next queue changes, which no result depends on.
+// Ring bookkeeping as in k_bounce_small: hits of pass k are counted in s_blk[k % 3] and summed in a register after the pass's barrier, a word is cleared one pass later.
+template <bool LAMBERT>
+__global__ __launch_bounds__(kBlock, RTX_SHADE_WAVES) void k_shade_dense(DevScene sc, DevFrame f_in, DevPaths p, uint32_t bounce,
+                                                        const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount,
+                                                        uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count, uint32_t* __restrict__ shcounts) {
+    DevFrame f = f_in;
+    f.flags = LAMBERT ? (f_in.flags | 1u) : (f_in.flags & ~1u);
+    constexpr uint32_t kRing = 512u;
+    __shared__ uint32_t s_cnt[1 + kMaxNee], s_list[kRing], s_blk[3];
+    if (threadIdx.x <= kMaxNee) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < 3) s_blk[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t n = qcount[blockIdx.x];
+    const uint32_t nee = sc.nlights ? f.nee_samples : 0u;
+    const bool last = (bounce + 1u == f.max_bounces);
+    const size_t qb = (size_t)blockIdx.x * f.qcap;
+    const uint32_t* myq = queue + qb;
+    uint32_t* mynext = next_queue + qb;
+    Prof* pf = nullptr;
+    uint32_t prod = 0, head = 0, rk = 0;                    // hits pushed / shaded so far, pass number mod 3 (all uniform, in registers)
+    for (uint32_t base = 0; base < n; base += kBlock) {
+        const uint32_t i = base + threadIdx.x;
+        bool is_hit = false;
+        if (i < n) is_hit = f2u(p.hit[p.out_o ? (uint32_t)qb + i : myq[i]].w) != kMissPrim;        // miss: Miss.hlsl:3-11 -> black, the path ends: nothing to do
+        const uint32_t slot = prod + block_push(is_hit, &s_blk[rk]);
+        if (is_hit) s_list[slot & (kRing - 1u)] = i;
+        __syncthreads();
+        prod += s_blk[rk];
+        if (threadIdx.x == 0) s_blk[rk == 0u ? 2u : rk - 1u] = 0;
+        rk = rk == 2u ? 0u : rk + 1u;
+        const bool flush = base + kBlock >= n;
+        while (prod - head >= (uint32_t)kBlock || (flush && prod != head)) {                      // uniform
+            const uint32_t take = prod - head < (uint32_t)kBlock ? prod - head : (uint32_t)kBlock;
+            const bool valid = threadIdx.x < take;
+            const uint32_t qi = valid ? s_list[(head + threadIdx.x) & (kRing - 1u)] : 0u;
+            shade_item<LAMBERT>(sc, f, p, bounce, nee, last, qb, myq, mynext, s_cnt, valid, qi, pf);
+            head += take;
+            __syncthreads();                                // every lane has read its ring slot before the next pass overwrites it
+        }
+    }
     __syncthreads();
     if (threadIdx.x == 0) next_count[blockIdx.x] = s_cnt[0];
     if (threadIdx.x >= 1 && threadIdx.x <= nee) shcounts[(size_t)(threadIdx.x - 1) * gridDim.x + blockIdx.x] = s_cnt[threadIdx.x];
@@ -1066,7 +1123,11 @@ void launch_shade(hipStream_t st, const DevScene& sc, const DevFrame& f, const D
     // material-sorted variant: measured slower (see k_shade), the permutation un-coalesces the per-path state streams
 #define RTX_LAUNCH_SHADE(SS, LL) hipLaunchKernelGGL((k_shade<SS, LL>), dim3(f.nblocks), dim3(kBlock), 0, st, sc, f, p, bounce, queue, qcount, next_queue, next_count, shcounts)
     const bool lam = (f.flags & 1u) != 0u;
-    if (sc.sort_materials) { if (lam) RTX_LAUNCH_SHADE(true, true); else RTX_LAUNCH_SHADE(true, false); }
+    if (sc.shade_dense && !sc.sort_materials) {
+        if (lam) hipLaunchKernelGGL((k_shade_dense<true>), dim3(f.nblocks), dim3(kBlock), 0, st, sc, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);
+        else hipLaunchKernelGGL((k_shade_dense<false>), dim3(f.nblocks), dim3(kBlock), 0, st, sc, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);
+    }
+    else if (sc.sort_materials) { if (lam) RTX_LAUNCH_SHADE(true, true); else RTX_LAUNCH_SHADE(true, false); }
     else { if (lam) RTX_LAUNCH_SHADE(false, true); else RTX_LAUNCH_SHADE(false, false); }
 #undef RTX_LAUNCH_SHADE
 }

@@ -18,12 +18,14 @@ struct DevScene {
     const MatGPU*   mats;   uint32_t nmat;
     const InstGPU*  insts;  uint32_t ninst;
     const LightGPU* lights; uint32_t nlights;
+    const float* cdf;               // lights[i].cdf as a dense array: the binary search of the light selection probes 4-byte entries side by side instead of one 80-byte record per probe
     float total_weight;
     uint32_t lds_nodes, lds_tris;   // how many nodes / triangles each workgroup stages in LDS
     uint32_t stack_depth;           // per-lane traversal stack entries (LDS)
     uint32_t stack_private;         // queue kernels: 0 = stack in the LDS column, 1 = private (scratch) array
     uint32_t sort_materials;        // 1 = material-sorted shading in k_shade (general path; tuning knob, default 0)
     uint32_t refill_min, trace_sched;   // persistent traversal: idle lanes that trigger a refill; wave schedule (rtx_kernels.hip)
+    uint32_t shade_dense;               // general path: k_shade compacts the hits of its sub-queue through an LDS ring before shading them (k_shade_dense)
     uint32_t occluder_cache;            // any-hit rays: a lane tests the triangle that occluded its previous ray first (rtx_traverse.hpp: ray_begin)
 };
 

@@ -80,7 +80,7 @@ __device__ __forceinline__ bool nee_sample(const DevScene& sc, const MatGPU& m, 
     int left = 0, right = (int)sc.nlights - 1, sel = 0;
     while (left <= right) {                                   // :523-537
         const int mid = left + (right - left) / 2;
-        if (rv < sc.lights[mid].cdf) { sel = mid; right = mid - 1; } else left = mid + 1;
+        if (rv < sc.cdf[mid]) { sel = mid; right = mid - 1; } else left = mid + 1;
     }
     const LightGPU& lt = sc.lights[sel];
     const f3 xv = mk3(lt.xv[0], lt.xv[1], lt.xv[2]), yv = mk3(lt.yv[0], lt.yv[1], lt.yv[2]), zv = mk3(lt.zv[0], lt.zv[1], lt.zv[2]);
