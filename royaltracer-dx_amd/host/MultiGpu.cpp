@@ -20,7 +20,7 @@ struct MultiGpuFrame::Impl {
     size_t slab_bytes = 0, state_bytes = 0;
 };
 
-MultiGpuFrame::MultiGpuFrame(const std::vector<int>& devices, Gather g) : m(new Impl), m_devices(devices), m_stats(devices.size()), m_gather(g) {
+MultiGpuFrame::MultiGpuFrame(const std::vector<int>& devices, Gather g, bool always_gather) : m(new Impl), m_devices(devices), m_stats(devices.size()), m_gather(g), m_always(always_gather) {
     // a constructor that throws runs no destructor: whatever was created before the failure (contexts, streams, communicators, Impl itself) is torn down here
     try {
         if (devices.empty()) throw std::runtime_error("MultiGpuFrame: no devices");
@@ -33,7 +33,7 @@ MultiGpuFrame::MultiGpuFrame(const std::vector<int>& devices, Gather g) : m(new 
             hipck(hipStreamCreateWithFlags(&m->stream[r], hipStreamNonBlocking), "hipStreamCreate");
             if (rtx_set_stream(m->ctx[r], m->stream[r]) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));   // pack -> gather -> unpack run stream-ordered
         }
-        if (g == Gather::RCCL && n > 1) {
+        if (g == Gather::RCCL && (n > 1 || always_gather)) {
             m->comm.assign(n, nullptr);
             ncclck(ncclCommInitAll(m->comm.data(), n, devices.data()), "ncclCommInitAll");      // single process, one communicator per device
         }
@@ -112,12 +112,12 @@ void MultiGpuFrame::Render(const rtx_params& p0) {
             rtx_params p = p0; p.shard_rank = (uint32_t)r; p.shard_count = (uint32_t)n;
             if (rtx_render(m->ctx[r], &p) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));
             (void)rtx_get_stats(m->ctx[r], &m_stats[r]);
-            if (n > 1 && rtx_pack_tiles(m->ctx[r], &p, m->slab[r]) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));
+            if ((n > 1 || m_always) && rtx_pack_tiles(m->ctx[r], &p, m->slab[r]) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));
         } catch (const std::exception& e) { err[r] = e.what(); }
     });
     for (auto& t : th) t.join();
     for (auto& e : err) if (!e.empty()) throw std::runtime_error("MultiGpuFrame::Render: " + e);
-    if (n > 1) {
+    if (n > 1 || m_always) {
         AllGather(m->slab, m->gathered, bytes);                                         // phase 2: ONE collective per frame
         // phase 3: every rank scatters all slabs into its accumulation buffer (enqueued behind the gather on the same stream)
         for (int r = 0; r < n; r++) {
@@ -135,7 +135,8 @@ void MultiGpuFrame::RenderRestir(const rtx_params& p0) {
     rtx_params probe = p0; probe.shard_rank = 0; probe.shard_count = (uint32_t)n;
     size_t bytes = 0, sbytes = 0;
     if (rtx_shard_slab_bytes(&probe, &bytes) != RTX_OK || rtx_restir_state_slab_bytes(&probe, &sbytes) != RTX_OK) throw std::runtime_error(std::string("slab bytes: ") + rtx_last_error(nullptr));
-    if (n > 1) { EnsureSlabs(m->slab, m->gathered, m->slab_bytes, bytes); EnsureSlabs(m->state_slab, m->state_gathered, m->state_bytes, sbytes); }
+    const bool gather = n > 1 || m_always;
+    if (gather) { EnsureSlabs(m->slab, m->gathered, m->slab_bytes, bytes); EnsureSlabs(m->state_slab, m->state_gathered, m->state_bytes, sbytes); }
     m_w = p0.width; m_h = p0.height;
     std::vector<std::string> err(n);
     const auto t0 = std::chrono::steady_clock::now();
@@ -146,12 +147,12 @@ void MultiGpuFrame::RenderRestir(const rtx_params& p0) {
             rtx_params p = p0; p.shard_rank = (uint32_t)r; p.shard_count = (uint32_t)n;
             if (rtx_render_restir(m->ctx[r], &p) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));
             (void)rtx_get_stats(m->ctx[r], &m_stats[r]);
-            if (n > 1 && (rtx_restir_pack_state(m->ctx[r], &p, m->state_slab[r]) != RTX_OK || rtx_pack_tiles(m->ctx[r], &p, m->slab[r]) != RTX_OK)) throw std::runtime_error(rtx_last_error(m->ctx[r]));
+            if (gather && (rtx_restir_pack_state(m->ctx[r], &p, m->state_slab[r]) != RTX_OK || rtx_pack_tiles(m->ctx[r], &p, m->slab[r]) != RTX_OK)) throw std::runtime_error(rtx_last_error(m->ctx[r]));
         } catch (const std::exception& e) { err[r] = e.what(); }
     });
     for (auto& t : th) t.join();
     for (auto& e : err) if (!e.empty()) throw std::runtime_error("MultiGpuFrame::RenderRestir: " + e);
-    if (n > 1) {
+    if (gather) {
         if (m_gather == Gather::RCCL) {                                 // phase 2: the frame's ONE exchange: history + framebuffer tiles in one group
             ncclck(ncclGroupStart(), "ncclGroupStart");
             for (int r = 0; r < n; r++) {

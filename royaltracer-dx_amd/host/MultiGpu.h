@@ -15,7 +15,9 @@
 class MultiGpuFrame {
 public:
     enum class Gather { RCCL, COPY };
-    MultiGpuFrame(const std::vector<int>& devices, Gather g);
+    // always_gather: run pack -> collective -> unpack even with ONE rank (a one-rank communicator): exercises the RCCL path of the frame — communicator setup,
+    // ncclGroupStart / ncclAllGather / ncclGroupEnd on the rank's stream, the slab round trip — on a machine with a single GPU
+    MultiGpuFrame(const std::vector<int>& devices, Gather g, bool always_gather = false);
     ~MultiGpuFrame();
     void SetScene(const Scene& s, float aspect);          // replicated on every GPU (Bistro-class: 0.4 GB << 288 GB)
     // one frame: p.shard_rank / shard_count are filled per rank; the assembled accumulation buffer ends up on EVERY rank (all-gather)
@@ -42,6 +44,7 @@ private:
     std::vector<int> m_devices;
     std::vector<rtx_stats> m_stats;
     Gather m_gather;
+    bool m_always = false;
     double m_lastMs = 0.0;
     uint32_t m_w = 0, m_h = 0;
 };

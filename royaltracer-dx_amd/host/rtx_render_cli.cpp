@@ -4,6 +4,7 @@
 //                   [--mode pt|restir]   restir = the reference's shipping frame (3 DispatchRays, Renderer.cpp:646-673: pass 1 + temporal + spatial reuse), one per --frames,
 //                   nee 4 / bounces 3 as in Common_v6.hlsl:8-12 unless --nee / --bounces are given; with --gpus N the shards own one tile rectangle each (RTX_FLAG_BLOCK_TILES,
 //                   32-px tiles) and exchange history + framebuffer tiles once per frame; [--literal] = the thread-per-pixel kernels instead of the wavefront stages;
+//                   [--force-gather] with --gpus 1: pack -> RCCL all-gather of a one-rank communicator -> unpack all the same (exercises the collective path on one GPU);
 //                   [--orbit deg] moves the camera about the look-at point between frames (exercises the reprojection)
 //                   [--gpus N [--devices 0,1,..] [--gather rccl|copy]]   the native N-GPU frame (MultiGpu.h): one process, N contexts, pixel tiles
 //                   round-robin, ONE RCCL all-gather per frame; `--gather copy` replaces the collective by device copies (several ranks on one GPU: tests)
@@ -22,13 +23,13 @@
 int main(int argc, char** argv) {
     std::string scene = "cornell", out, objs, mtl = "./";
     UINT w = 1920, h = 1080, spp = 1, frames = 1, bounces = 8, nee = 1; int device = 0; bool lambert = false;
-    int gpus = 1; std::string devlist, gather = "rccl", mode = "pt"; bool literal = false, nee_set = false, bounces_set = false; float orbit = 0.0f;
+    int gpus = 1; std::string devlist, gather = "rccl", mode = "pt"; bool literal = false, nee_set = false, bounces_set = false, force_gather = false; float orbit = 0.0f;
     for (int i = 1; i < argc; i++) {
         auto arg = [&](const char* k) { return !strcmp(argv[i], k) && i + 1 < argc; };
         if (arg("--scene")) scene = argv[++i]; else if (arg("--obj")) { objs = argv[++i]; scene = "obj"; } else if (arg("--mtl")) mtl = argv[++i];
         else if (arg("--w")) w = atoi(argv[++i]); else if (arg("--h")) h = atoi(argv[++i]); else if (arg("--spp")) spp = atoi(argv[++i]);
         else if (arg("--frames")) frames = atoi(argv[++i]); else if (arg("--bounces")) { bounces = atoi(argv[++i]); bounces_set = true; } else if (arg("--nee")) { nee = atoi(argv[++i]); nee_set = true; }
-        else if (arg("--mode")) mode = argv[++i]; else if (arg("--orbit")) orbit = (float)atof(argv[++i]); else if (!strcmp(argv[i], "--literal")) literal = true;
+        else if (arg("--mode")) mode = argv[++i]; else if (arg("--orbit")) orbit = (float)atof(argv[++i]); else if (!strcmp(argv[i], "--literal")) literal = true; else if (!strcmp(argv[i], "--force-gather")) force_gather = true;
         else if (arg("--gpus")) gpus = atoi(argv[++i]); else if (arg("--devices")) devlist = argv[++i]; else if (arg("--gather")) gather = argv[++i];
         else if (arg("--out")) out = argv[++i]; else if (arg("--device")) device = atoi(argv[++i]); else if (!strcmp(argv[i], "--lambert")) lambert = true;
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
@@ -55,7 +56,7 @@ int main(int argc, char** argv) {
             Scene sc = scene == "cornell" ? MakeCornellBox() : scene == "sponza" ? MakeSponzaClass() : scene == "bistro" ? MakeBistroClass() : Scene();
             if (scene == "obj") { std::vector<std::string> f; std::stringstream ss(objs); std::string t; while (std::getline(ss, t, ',')) f.push_back(t); sc = LoadObjScene(f, mtl); }
             if (scene == "cornell") lambert = true;
-            MultiGpuFrame mg(devs, gather == "copy" ? MultiGpuFrame::Gather::COPY : MultiGpuFrame::Gather::RCCL);
+            MultiGpuFrame mg(devs, gather == "copy" ? MultiGpuFrame::Gather::COPY : MultiGpuFrame::Gather::RCCL, force_gather);      // --force-gather: the collective also with one rank
             mg.SetScene(sc, (float)w / (float)h);
             mg.Clear(w, h);
             rtx_params p{}; p.width = w; p.height = h; p.spp = spp; p.max_bounces = bounces; p.nee_samples = nee; p.rr_start = 3;

@@ -1391,6 +1391,42 @@ def test_native_multi_gpu_restir_frames_of_the_cli(tmp_path):
             assert b == blobs["facade"], (name, tag)
 
 
+def test_rccl_collective_path_with_one_rank(tmp_path):
+    """What one GPU allows of SURVEY 8(e)'s collective: the frame's RCCL path with a ONE-rank communicator.  (a) native: `rtx_render --gpus 1 --gather rccl --force-gather` =
+    ncclCommInitAll over one device, pack -> ncclGroupStart / ncclAllGather / ncclGroupEnd on the context's stream -> unpack; the image must be byte-identical to the run
+    without a collective, for the path tracer and for the ReSTIR frame (history + tiles).  (b) torch.distributed, backend nccl (= RCCL), world size 1: the all_gather_into_tensor of
+    sharding.gather_slabs on a device slab returns the slab.  N > 1 ranks need N GPUs (two ranks cannot share a device under RCCL): the 8-rank gather itself stays unexecuted here."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "royaltracer-dx_amd", "rtx_render")
+    for mode in (["--spp", "2", "--bounces", "4"], ["--mode", "restir", "--frames", "2", "--orbit", "1"]):
+        blobs = []
+        for extra in ([], ["--gather", "rccl", "--force-gather"]):
+            out = tmp_path / f"o{len(blobs)}.exr"
+            r = subprocess.run([exe, "--scene", "sponza", "--w", "192", "--h", "108", "--gpus", "1", "--devices", "0", "--out", str(out)] + mode + extra,
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            blobs.append(out.read_bytes())
+        assert blobs[0] == blobs[1], mode
+    code = (
+        "import os, sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as g\n"
+        "g.load_package()\n"
+        "from royaltracer_dx_amd import sharding\n"
+        "os.environ.update(RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29641')\n"
+        "dev = torch.device('cuda', 0); torch.cuda.set_device(0)\n"
+        "dist, rank, world = sharding.init_process_group('nccl', dev)\n"
+        "slab = torch.arange(1 << 20, dtype=torch.float32, device=dev)\n"
+        "out = sharding.gather_slabs(dist, slab)\n"
+        "torch.cuda.synchronize()\n"
+        "assert world == 1 and torch.equal(out, slab)\n"
+        "print('backend', dist.get_backend(), 'ok')\n"
+        "dist.destroy_process_group()\n") % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "backend nccl ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_two_contexts_from_two_threads(rt, cornell):
     """SURVEY 8(b) threading contract: a context is not thread-safe, but different contexts may be driven from different threads.
     Two threads render different workloads concurrently on the same GPU (different scenes, options, streams); each result must be
