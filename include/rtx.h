@@ -123,7 +123,11 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
                                         finished its phase keeps its SIMD slot while it waits for the slowest wave of its workgroup, and the kernel needs 86 VGPRs where the
                                         traversal kernels need 75), so the default is 0.  Needs RTX_OPT_TRACE_SCHED 5-7 */
        RTX_OPT_LPT_ORDER = 13,       /* tuning: 1 (default) = the fused tiny-scene kernels take their sub-queues longest first (shorter launch tails), 0 = in index order */
-       RTX_OPT_BLOCKS_PER_CU = 12    /* tuning: workgroups (= private sub-queues) per compute unit; default 0 = auto (40 tiny scenes, 32 otherwise; 8 measured 4-7 % slower: tail imbalance) */ };
+       RTX_OPT_MERGE_RAYS = 24,      /* tuning, general scenes: a launch of the persistent traversal kernels that is predicted (from the previous rtx_render's counters) to hold fewer than
+                                        this many rays per sub-queue gives each workgroup 2 / 4 / 8 consecutive sub-queues, down to one round of resident workgroups (the late bounces of
+                                        a frame, after Russian roulette).  Default 1024; 0 = one sub-queue per workgroup always.  Never changes a result */
+       RTX_OPT_BLOCKS_PER_CU = 12    /* tuning: workgroups (= private sub-queues) per compute unit; default 0 = auto: 40 (tiny scenes) / 32 at full frame size (8 measured 4-7 % slower there: tail imbalance), fewer — down to 8 — when a batch is so
+                                        small (a shard) that a sub-queue would start with fewer than ~16 / ~8 chunks of 256 paths */ };
 
 /* lifetime: replaces LoadPipeline/device creation (Renderer.cpp:106-254) and OnDestroy (:546-552) */
 int  rtx_create(int device_ordinal, rtx_ctx** out);

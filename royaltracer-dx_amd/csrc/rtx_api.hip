@@ -56,6 +56,10 @@ struct rtx_ctx {
     DevBuf d_heads;                 // per trace launch of a batch: G fetch cursors + the retired count
     bool compact_state = true;      // RTX_OPT_COMPACT_STATE: separate-kernel path keeps ray / throughput / hit records by queue position, ping-pong (DevPaths::out_*)
     DevBuf d_alt_o, d_alt_d, d_alt_thr;
+    // RTX_OPT_MERGE_RAYS: thin launches of the traversal kernels take several sub-queues per workgroup (MergedQ).  The host cannot see a launch's ray count (it is on the
+    // device), so it predicts it from the counters of the previous rtx_render of this context: per path entering the batch, how many were still alive at bounce b and how many
+    // shadow rays slot j of bounce b cast.  A wrong prediction costs time only.
+    uint32_t merge_rays = 1024; uint64_t pred_paths = 0; std::vector<uint64_t> pred_q, pred_s; uint32_t pred_nee1 = 0;
     bool overlap_shadow = true; hipStream_t aux = nullptr;       // RTX_OPT_OVERLAP_SHADOW: k_trace_shadow of bounce b on a second stream, beside k_trace_closest of bounce b + 1 (not while kernels are timed)
     DevBuf d_ray_o, d_ray_d, d_thr, d_rad, d_hit, d_sh_o, d_sh_d, d_sh_c, d_queue[2], d_counters;
     uint32_t* h_counters = nullptr; size_t h_counters_words = 0;
@@ -159,6 +163,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_COMPACT_STATE: c->compact_state = value != 0; return RTX_OK;
     case RTX_OPT_OVERLAP_SHADOW: c->overlap_shadow = value != 0; return RTX_OK;
     case RTX_OPT_BLOCKS_PER_CU: if (value < 0 || value > 64) { c->err = "blocks_per_cu must be in [0, 64]"; return RTX_ERR_INVALID; } c->blocks_per_cu = (uint32_t)value; return RTX_OK;
+    case RTX_OPT_MERGE_RAYS: if (value < 0 || value > (1 << 20)) { c->err = "merge_rays must be in [0, 2^20]"; return RTX_ERR_INVALID; } c->merge_rays = (uint32_t)value; return RTX_OK;
     case RTX_OPT_GPU_REFIT: c->gpu_refit = value != 0; return RTX_OK;
     case RTX_OPT_SHADE_DENSE: c->shade_dense = (int)value; c->dsc.shade_dense = value > 0 ? 1u : 0u; return RTX_OK;
     case RTX_OPT_OCCLUDER_CACHE: c->occluder_cache = value != 0; c->dsc.occluder_cache = c->occluder_cache; return RTX_OK;
@@ -465,9 +470,15 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     // general path: 16 was best in round 1 (49.3 / 42.2 ms vs 53.0 / 44.2 at 8) with 4-6 workgroups resident per CU; with the 7-8 of the end of round 2
     // (LDS trimmed) it is 32: C3 39.8 vs 40.7 ms, C5 37.8 vs 38.2 (48: 40.4 / 39.0)
     const bool fused_bvh = !c->dsc.nsmall && c->fused_bvh && c->trace_sched >= 5u;      // (the other wave schedules are experiment knobs of the separate kernels)
-    const uint32_t bpc = c->blocks_per_cu ? c->blocks_per_cu : (c->dsc.nsmall && c->fused ? 40u : 32u);
-    const uint32_t max_blocks = (uint32_t)c->num_cus * bpc;
+    // (round 3) ... and never so many that a sub-queue starts with fewer than ~8 (tiny scenes: ~16) chunks of 256 paths while there are 8 workgroups per CU: a 1/8 shard of the
+    // 1080p frame (16 200 chunks at 16 spp) ran 7.29 / 6.71 / 6.30 / 6.09 / 6.08 ms with 32 / 24 / 16 / 12 / 8 sub-queues per CU (C3), Cornell at 64 spp 2.54 / 2.41 ms with 40 / 16
+    // (tools/shard_kernels.py): short sub-queues leave the persistent waves of a workgroup half empty, and every round of workgroups costs one ray latency
+    const bool tiny_fused = c->dsc.nsmall && c->fused;
     const uint32_t nchunks = f.chunks_per_sample * bspp;
+    const uint32_t bpc_hi = tiny_fused ? 40u : 32u, per_wg = tiny_fused ? 16u : 8u;
+    const uint32_t bpc = c->blocks_per_cu ? c->blocks_per_cu
+                                          : std::max<uint32_t>(8u, std::min<uint32_t>(bpc_hi, (nchunks / per_wg + (uint32_t)c->num_cus - 1u) / (uint32_t)c->num_cus));
+    const uint32_t max_blocks = (uint32_t)c->num_cus * bpc;
     const uint32_t G = std::max<uint32_t>(1, std::min<uint32_t>(nchunks, max_blocks));
     const uint32_t qcap = ((nchunks + G - 1) / G) * 256u;
     f.nblocks = G; f.qcap = qcap;
@@ -553,6 +564,16 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
         if (ovl && !c->aux) HIPCHK(c, hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
         hipEvent_t ev_shadow_done = nullptr;
         auto Hd = [&](uint32_t b, uint32_t k) { return stealing ? (uint32_t*)c->d_heads.p + ((size_t)b * (1 + nee1) + k) * hstride : nullptr; };
+        // sub-queues per workgroup of a traversal launch predicted to hold `rays` rays: double while a workgroup would start with fewer than merge_rays and at least one full
+        // round of resident workgroups (8 per CU) remains.  Measured in ONE context, option switched between rounds (tools/ab_frame.py same=1): C3 39.45 -> 38.67 / 38.57 /
+        // 38.51 ms per frame at 512 / 1024 / 2048, C5 36.77 -> 35.90 / 35.78 / 36.02; going below one round (4 workgroups per CU) changes nothing
+        auto merge_for = [&](uint64_t pred_num, bool have) -> uint32_t {
+            if (!have || !c->merge_rays || !c->pred_paths || stealing) return 1u;
+            const double rays = (double)pred_num * (double)((uint64_t)fb.npl * fb.batch_spp) / (double)c->pred_paths;
+            uint32_t k = 1u;
+            while (k < kMaxMerge && G / (2u * k) >= (uint32_t)c->num_cus * 8u && rays * k / G < (double)c->merge_rays) k *= 2u;
+            return k;
+        };
         for (uint32_t b = 0; b < mb && !fused && !fused_bvh; b++) {
             uint32_t* q = queue[b & 1]; uint32_t* qn = queue[(b + 1) & 1];
             DevPaths Pb = P;                                  // compact state: bounce b reads set (b & 1) and writes the survivors into the other one
@@ -561,7 +582,7 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
                 Pb.ray_o = set[b & 1][0]; Pb.ray_d = set[b & 1][1]; Pb.thr = set[b & 1][2];
                 Pb.out_o = set[(b + 1) & 1][0]; Pb.out_d = set[(b + 1) & 1][1]; Pb.out_thr = set[(b + 1) & 1][2];
             }
-            { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, fb, c->dsc, Pb, b, q, Q(b), Hd(b, 0)); }
+            { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, fb, c->dsc, Pb, b, q, Q(b), Hd(b, 0), merge_for(b < c->pred_q.size() ? c->pred_q[b] : 0, b < c->pred_q.size())); }
             if (ovl && ev_shadow_done) HIPCHK(c, hipStreamWaitEvent(st, ev_shadow_done, 0));      // shade(b) overwrites the shadow entries and touches rad: after shadow(b - 1)
             { Timed t(c, RTX_K_SHADE); launch_shade(st, c->dsc, fb, Pb, b, q, Q(b), qn, Q(b + 1), S(b, 0)); }
             hipStream_t ss = st;
@@ -571,7 +592,7 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
                 HIPCHK(c, hipEventRecord(e, st)); HIPCHK(c, hipStreamWaitEvent(c->aux, e, 0));
                 ss = c->aux;
             }
-            for (uint32_t j = 0; j < nee; j++) { Timed t(c, RTX_K_SHADOW, ss); launch_trace_shadow(ss, fb, c->dsc, Pb, j, S(b, j), Hd(b, 1 + j)); }
+            for (uint32_t j = 0; j < nee; j++) { const size_t ps = (size_t)b * nee1 + j; Timed t(c, RTX_K_SHADOW, ss); launch_trace_shadow(ss, fb, c->dsc, Pb, j, S(b, j), Hd(b, 1 + j), merge_for(ps < c->pred_s.size() ? c->pred_s[ps] : 0, ps < c->pred_s.size() && c->pred_nee1 == nee1)); }
             if (ovl && nee) HIPCHK(c, hipEventRecord(ev_shadow_done, c->aux));
         }
         if (ovl && ev_shadow_done) { HIPCHK(c, hipStreamWaitEvent(st, ev_shadow_done, 0)); ev_shadow_done = nullptr; }
@@ -585,9 +606,14 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) c->stats.render_ms = ms;
     for (const TimedLaunch& t : c->timed) { float m = 0.0f; if (hipEventElapsedTime(&m, t.a, t.b) == hipSuccess) c->stats.kernel_ms[t.cls] += m; }
+    if (!(c->dsc.nsmall && c->fused) && !fused_bvh) { c->pred_paths = 0; c->pred_q.assign(mb, 0); c->pred_s.assign((size_t)mb * nee1, 0); c->pred_nee1 = nee1; }
     for (uint32_t bi = 0; bi < nbatches; bi++) {
         const uint32_t* h = c->h_counters + (size_t)bi * ncnt;
         auto sumG = [&](size_t row) { uint64_t s = 0; for (uint32_t g = 0; g < G; g++) s += h[row * G + g]; return s; };
+        if (!(c->dsc.nsmall && c->fused) && !fused_bvh) {                 // what the next call's launches are sized by (merge_for)
+            c->pred_paths += sumG(0);
+            for (uint32_t b = 0; b < mb; b++) { c->pred_q[b] += sumG(b); for (uint32_t j = 0; j < nee1; j++) c->pred_s[(size_t)b * nee1 + j] += sumG((size_t)(mb + 1) + (size_t)b * nee1 + j); }
+        }
         const bool fusedb = c->dsc.nsmall && c->fused;
         const uint64_t prim = fusedb ? sumG((size_t)(mb + 1) + (size_t)mb * nee1) : sumG(0);
         c->stats.rays_primary += prim; c->stats.paths += prim;

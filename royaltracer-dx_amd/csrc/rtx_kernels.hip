@@ -147,10 +147,12 @@ __global__ __launch_bounds__(kBlock) void k_raygen_trace_small(DevScene sc, cons
 // closest hit for every path in this workgroup's sub-queue: reads ray_o/ray_d, writes hit
 template <int STK, bool STEAL, int SCHED>   // traversal stack: 0 = LDS column, 1 = private (scratch); STEAL: work stealing between sub-queues (refill_steal);
                                             // SCHED: the wave schedule as a compile-time constant (the default, 6), or -1 = the run-time parameter (experiment knobs)
-__global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin, uint32_t refill_min, uint32_t sched, uint32_t* heads) {
+__global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin, uint32_t refill_min, uint32_t sched, uint32_t* heads,
+                                                                       uint32_t nq, uint32_t merge) {           // nq sub-queues in the launch, `merge` of them per workgroup (MergedQ; 1 with STEAL and on the tiny-scene test path)
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_head;
-    const uint32_t n = qcount[blockIdx.x];
+    MergedQ M; M.init(qcount, nq, merge);
+    const uint32_t n = M.n;
     if (STEAL ? all_exhausted(heads, gridDim.x) : n == 0) return;      // (work stealing: nothing left in the whole launch)
     if (threadIdx.x == 0) s_head = 0;
     const TraceLds L = stage_lds(sc, lds);
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevSc
         const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
         ray_begin(R, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, pid, true);
     };
-    while (STEAL ? refill_steal(R, W, drained, refill_min, rng, fetch) : refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) { fetch(blockIdx.x, idx); })) {
+    while (STEAL ? refill_steal(R, W, drained, refill_min, rng, fetch) : refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) { uint32_t q, off; M.locate(idx, q, off); fetch(q, off); })) {
         if (SCHED >= 5) spec_step<false>(sc, L, R, stk, (uint32_t)SCHED);
         else if (sched >= 5u) spec_step<false>(sc, L, R, stk, sched);
         else if (sched) voted_step<false>(sc, L, R, stk, sched);
@@ -193,10 +195,11 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevSc
 template <int STK, bool STEAL, int SCHED, int SINK = 0>
 __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_shadow(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const F4* __restrict__ sh_o, const F4* __restrict__ sh_d,
                                                          const F4* __restrict__ sh_c, const uint32_t* __restrict__ shcount, uint32_t qcap, uint32_t refill_min, uint32_t sched, uint32_t* heads,
-                                                         const uint32_t* __restrict__ pay = nullptr, uint8_t* __restrict__ occ = nullptr) {
+                                                         uint32_t nq, uint32_t merge, const uint32_t* __restrict__ pay = nullptr, uint8_t* __restrict__ occ = nullptr) {
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_head;
-    const uint32_t n = shcount[blockIdx.x];
+    MergedQ M; M.init(shcount, nq, merge);
+    const uint32_t n = M.n;
     if (STEAL ? all_exhausted(heads, gridDim.x) : n == 0) return;
     if (threadIdx.x == 0) s_head = 0;
     const TraceLds L = stage_lds(sc, lds);
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_shadow(DevSce
         const F4 so = sh_o[gi], sd = sh_d[gi];
         ray_begin(R, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, gi, false, sc.occluder_cache != 0u);
     };
-    while (STEAL ? refill_steal(R, W, drained, refill_min, rng, fetch) : refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) { fetch(blockIdx.x, idx); })) {
+    while (STEAL ? refill_steal(R, W, drained, refill_min, rng, fetch) : refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) { uint32_t q, off; M.locate(idx, q, off); fetch(q, off); })) {
         if (SCHED >= 5) spec_step<true>(sc, L, R, stk, (uint32_t)SCHED);
         else if (sched >= 5u) spec_step<true>(sc, L, R, stk, sched);
         else if (sched) voted_step<true>(sc, L, R, stk, sched);
@@ -1075,10 +1078,13 @@ void launch_packet_masks(hipStream_t st, const DevScene& sc, const DevFrame& f, 
 void launch_raygen_trace_small(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount, uint32_t* gencount, const unsigned long long* masks) {
     hipLaunchKernelGGL(k_raygen_trace_small, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, p, cam, queue, qcount, gencount, masks);
 }
-void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t bounce, const uint32_t* queue, const uint32_t* qcount, uint32_t* heads) {
+void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t bounce, const uint32_t* queue, const uint32_t* qcount, uint32_t* heads, uint32_t merge) {
     const float tmin = bounce == 0 ? kTMinCam : kSBias;
     if (sc.nsmall) heads = nullptr;                     // (the un-fused tiny-scene test path has no persistent waves)
-#define RTX_LAUNCH_TC(SS, TT, CC, LDSB) hipLaunchKernelGGL((k_trace_closest<SS, TT, CC>), dim3(f.nblocks), dim3(kBlock), LDSB, st, sc, sc.small, p, queue, qcount, f.qcap, tmin, sc.refill_min, sc.trace_sched, heads)
+    if (heads || sc.nsmall || merge < 1u) merge = 1u;
+    if (merge > kMaxMerge) merge = kMaxMerge;
+    const uint32_t grid = (f.nblocks + merge - 1u) / merge;
+#define RTX_LAUNCH_TC(SS, TT, CC, LDSB) hipLaunchKernelGGL((k_trace_closest<SS, TT, CC>), dim3(grid), dim3(kBlock), LDSB, st, sc, sc.small, p, queue, qcount, f.qcap, tmin, sc.refill_min, sc.trace_sched, heads, f.nblocks, merge)
     if (sc.stack_private == 1) { if (heads) RTX_LAUNCH_TC(1, true, -1, trace_lds_bytes_queue(sc)); else RTX_LAUNCH_TC(1, false, -1, trace_lds_bytes_queue(sc)); }
     else if (heads) RTX_LAUNCH_TC(0, true, -1, trace_lds_bytes(sc));
 #ifndef RTX_NO_SCHED_SPECIAL
@@ -1106,10 +1112,13 @@ void launch_bounce_bvh(hipStream_t st, const DevScene& sc, const DevFrame& f, co
 void launch_order_queues(hipStream_t st, const uint32_t* qcount, uint32_t G, uint32_t* order) {
     hipLaunchKernelGGL(k_order_queues, dim3(1), dim3(1024), 0, st, qcount, G, order);
 }
-void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t j, const uint32_t* shcount, uint32_t* heads) {
+void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, const DevPaths& p, uint32_t j, const uint32_t* shcount, uint32_t* heads, uint32_t merge) {
     const size_t seg = (size_t)j * f.qcap * f.nblocks;
     if (sc.nsmall) heads = nullptr;
-#define RTX_LAUNCH_TS(SS, TT, CC, LDSB) hipLaunchKernelGGL((k_trace_shadow<SS, TT, CC>), dim3(f.nblocks), dim3(kBlock), LDSB, st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, sc.refill_min, sc.trace_sched, heads)
+    if (heads || sc.nsmall || merge < 1u) merge = 1u;
+    if (merge > kMaxMerge) merge = kMaxMerge;
+    const uint32_t grid = (f.nblocks + merge - 1u) / merge;
+#define RTX_LAUNCH_TS(SS, TT, CC, LDSB) hipLaunchKernelGGL((k_trace_shadow<SS, TT, CC>), dim3(grid), dim3(kBlock), LDSB, st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, sc.refill_min, sc.trace_sched, heads, f.nblocks, merge)
     if (sc.stack_private == 1) { if (heads) RTX_LAUNCH_TS(1, true, -1, trace_lds_bytes_queue(sc)); else RTX_LAUNCH_TS(1, false, -1, trace_lds_bytes_queue(sc)); }
     else if (heads) RTX_LAUNCH_TS(0, true, -1, trace_lds_bytes(sc));
 #ifndef RTX_NO_SCHED_SPECIAL
@@ -1155,7 +1164,7 @@ void launch_restir_pass3(hipStream_t st, uint32_t max_blocks, const DevScene& sc
 // ---- wavefront ReSTIR stages ----
 void launch_trace_occ(hipStream_t st, const DevScene& sc, const RsQ& q, const uint32_t* shcnt) {
     DevPaths none{};
-#define RTX_LAUNCH_TO(CC) hipLaunchKernelGGL((k_trace_shadow<0, false, CC, 1>), dim3(q.G), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, none, q.sh_o, q.sh_d, (const F4*)nullptr, shcnt, q.rcap, sc.refill_min, sc.trace_sched, (uint32_t*)nullptr, q.sh_pay, q.occ)
+#define RTX_LAUNCH_TO(CC) hipLaunchKernelGGL((k_trace_shadow<0, false, CC, 1>), dim3(q.G), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, none, q.sh_o, q.sh_d, (const F4*)nullptr, shcnt, q.rcap, sc.refill_min, sc.trace_sched, (uint32_t*)nullptr, q.G, 1u, q.sh_pay, q.occ)
     if (sc.trace_sched == 6u && !sc.nsmall) RTX_LAUNCH_TO(6); else RTX_LAUNCH_TO(-1);
 #undef RTX_LAUNCH_TO
 }

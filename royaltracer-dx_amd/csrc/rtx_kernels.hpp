@@ -86,6 +86,7 @@ struct DevPaths {
 };
 
 // work area of the wavefront ReSTIR stages (rtx_restir_wave.hpp), device pointers; one pass at a time
+constexpr uint32_t kMaxMerge = 8;       // most sub-queues one workgroup of a traversal launch takes (MergedQ, rtx_traverse.hpp)
 constexpr uint32_t kRsStreams = 7;      // ray_o (origin, seed.y) | ray_d (direction, seed.x) | a0 (normal, material) | a1 (outgoing, item) | a2 | a3 | a4
 constexpr uint32_t kRsOcc = 16;         // occlusion bytes per item (pass 3 uses 10)
 constexpr uint32_t kRsCand = 10;        // pass 3: candidate record, dwords per item
@@ -106,7 +107,7 @@ struct RsQ {
 size_t trace_lds_bytes(const DevScene& sc);
 int trace_workgroups_per_cu(const DevScene& sc);   // occupancy of the persistent traversal kernels for this LDS layout (hipOccupancyMaxActiveBlocksPerMultiprocessor)
 void launch_raygen(hipStream_t, const DevFrame&, const DevPaths&, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount, bool compact);
-void launch_trace_closest(hipStream_t, const DevFrame&, const DevScene&, const DevPaths&, uint32_t bounce, const uint32_t* queue, const uint32_t* qcount, uint32_t* heads);
+void launch_trace_closest(hipStream_t, const DevFrame&, const DevScene&, const DevPaths&, uint32_t bounce, const uint32_t* queue, const uint32_t* qcount, uint32_t* heads, uint32_t merge = 1);   // merge: consecutive sub-queues per workgroup (MergedQ)
 void launch_packet_masks(hipStream_t, const DevScene&, const DevFrame&, const CameraGPU* cam, unsigned long long* masks);   // one 64-bit record mask per 8x8 pixel block of the shard
 void launch_raygen_trace_small(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, const CameraGPU* cam, uint32_t* queue, uint32_t* qcount, uint32_t* gencount, const unsigned long long* masks);
 void launch_bounce_small(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, uint32_t bounce_first, uint32_t bounce_end,
@@ -115,7 +116,7 @@ void launch_bounce_small(hipStream_t, const DevScene&, const DevFrame&, const De
 void launch_bounce_bvh(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, uint32_t bounce_first, uint32_t bounce_end,
                        uint32_t* queue_a, uint32_t* queue_b, uint32_t* hitq, uint32_t* qrows, uint32_t* srows, const uint32_t* order);
 void launch_order_queues(hipStream_t, const uint32_t* qcount, uint32_t G, uint32_t* order);   // longest sub-queue first (dispatch order of the fused kernels)
-void launch_trace_shadow(hipStream_t, const DevFrame&, const DevScene&, const DevPaths&, uint32_t j, const uint32_t* shcount, uint32_t* heads);
+void launch_trace_shadow(hipStream_t, const DevFrame&, const DevScene&, const DevPaths&, uint32_t j, const uint32_t* shcount, uint32_t* heads, uint32_t merge = 1);
 void launch_shade(hipStream_t, const DevScene&, const DevFrame&, const DevPaths&, uint32_t bounce,
                   const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts);
 // pixels / npixels (optional): an explicit work list (x | y << 16) instead of the shard's own tiles — ReSTIR on shards runs passes 1 and 2 on the tiles dilated by 20 px

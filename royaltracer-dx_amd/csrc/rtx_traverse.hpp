@@ -668,6 +668,25 @@ __device__ __forceinline__ void spec_step(const DevScene& sc, const TraceLds& L,
 #endif
     if (R.has && !R.done && !(R.G.bits & 0xffu) && R.sp == 0 && !R.T.bits) R.done = true;
 }
+// A workgroup of the persistent traversal kernels may own `merge` CONSECUTIVE sub-queues (thin launches: the late bounces of a frame, where Russian roulette has left a few
+// dozen rays per sub-queue — one round of workgroups then costs a ray's latency whatever it holds, so fewer, fuller workgroups win; the host picks `merge` per launch from the
+// previous frame's counts, rtx_render).  The sub-queues appear to refill() as one queue of n entries; locate() maps an entry back to (sub-queue, offset).  Everything is
+// wave-uniform but idx.  Results do not depend on merge: every entry of every sub-queue is fetched exactly once either way.
+struct MergedQ {
+    uint32_t q0, n, pre[kMaxMerge];                 // first sub-queue, total entries, pre[t] = entries in the sub-queues before q0 + t
+    __device__ __forceinline__ void init(const uint32_t* __restrict__ cnt, uint32_t nq, uint32_t merge) {
+        q0 = blockIdx.x * merge; n = 0;
+#pragma unroll
+        for (uint32_t t = 0; t < kMaxMerge; t++) { pre[t] = n; if (t < merge && q0 + t < nq) n += cnt[q0 + t]; }
+    }
+    __device__ __forceinline__ void locate(uint32_t idx, uint32_t& q, uint32_t& off) const {
+        uint32_t j = 0, b = 0;
+#pragma unroll
+        for (uint32_t t = 1; t < kMaxMerge; t++) if (idx >= pre[t]) { j = t; b = pre[t]; }      // the LAST t with pre[t] <= idx: skips empty sub-queues
+        q = q0 + j; off = idx - b;
+    }
+};
+
 // wave-level refill: returns false when the wave may exit (queue exhausted and nothing in flight)
 template <class Fetch>
 __device__ __forceinline__ bool refill(RayLane& R, uint32_t* s_head, uint32_t n, bool& drained, uint32_t refill_min, Fetch fetch) {

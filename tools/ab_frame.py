@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same-box, same-process alternating A/B of rtx options on one workload: the scene is built once, the option values alternate round by round.
-usage: python tools/ab_frame.py <sponza|bistro|garage|cornell> <pt|restir> <opt>=<a>,<b>[,...] [rounds=3] [frames=3] [timing=1] [fixed <opt>=<v> ...]
+usage: python tools/ab_frame.py <sponza|bistro|garage|cornell> <pt|restir> <opt>=<a>,<b>[,...] [rounds=3] [frames=3] [timing=1] [same=1] [fixed <opt>=<v> ...]
 prints per setting: ms per frame (wall, all rounds), per-kernel-class ms (last round, with timing=1: launches serialised) and the image checksum"""
 import hashlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,8 +20,12 @@ fixed = [(int(a.split("=")[0]), int(a.split("=")[1])) for a in kv[1:] if a.split
 rounds, frames, timing = named.get("rounds", 3), named.get("frames", 3), named.get("timing", 0)
 W, H = 1920, 1080
 sc = ctors[kind]()
+same = named.get("same", 0)                     # same=1: ONE context, the option is switched between rounds (run-time options only; removes context-to-context placement effects, +-1.5 %)
 ctxs = {}
 for v in vals:                                   # one context per setting (options that change the commit need their own scene upload)
+    if same and ctxs:
+        ctxs[v] = next(iter(ctxs.values()))
+        continue
     c = rt.Context(0)
     for k, x in fixed:
         c.set_option(k, x)
@@ -48,12 +52,18 @@ def run(c, seed0):
 
 res = {v: [] for v in vals}
 for v in vals:
+    ctxs[v].set_option(opt, v)
     run(ctxs[v], 1)                              # warm-up (allocations)
 for r in range(rounds):
     for v in vals:
+        if same:
+            ctxs[v].set_option(opt, v)
+            run(ctxs[v], 1)                      # one untimed pass after a switch (launch sizes are predicted from the previous call)
         res[v].append(run(ctxs[v], 1))
 for v in vals:
     c = ctxs[v]
+    if same:
+        c.set_option(opt, v); run(c, 1)
     sha = hashlib.sha1(c.read_accum().tobytes()).hexdigest()[:12]
     km = ""
     if timing:
@@ -61,4 +71,5 @@ for v in vals:
         km = "  " + ", ".join(f"{rt.KERNEL_NAMES[i]} {st.kernel_ms[i]:.2f}" for i in rt.KERNEL_NAMES if st.kernel_launches[i] > 0)
     st = c.stats()
     print(f"{kind} {mode} opt {opt}={v}: " + " ".join(f"{t:.3f}" for t in res[v]) + f" ms/frame  (min {min(res[v]):.3f})  rays {st.rays_primary + st.rays_extension + st.rays_shadow}  sha {sha}{km}", flush=True)
-    c.close()
+    if not same:
+        c.close()
