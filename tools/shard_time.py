@@ -64,7 +64,8 @@ def main():
         slab = ctx.slab_bytes(rt.Params(shard_rank=0, shard_count=n, **base)) / 1e6
         if mode == "restir":
             slab += ctx.restir_state_slab_bytes(rt.Params(shard_rank=0, shard_count=n, **base)) / 1e6
-        print(f"| {n} | {mx:.3f} | {mean:.3f} | {mx / mean:.3f} | {t1 / n:.3f} | {t1 / (n * mx):.3f} | {slab:.2f} | " + " ".join(f"{t:.2f}" for t in per) + " |", flush=True)
+        ideal, eff = (f"{t1 / n:.3f}", f"{t1 / (n * mx):.3f}") if ns[0] == 1 else ("-", "-")          # (needs the N = 1 frame of the same run)
+        print(f"| {n} | {mx:.3f} | {mean:.3f} | {mx / mean:.3f} | {ideal} | {eff} | {slab:.2f} | " + " ".join(f"{t:.2f}" for t in per) + " |", flush=True)
     ctx.close()
 
 
