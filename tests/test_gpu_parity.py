@@ -1220,6 +1220,14 @@ def test_full_size_baseline_configs_are_bit_identical(rt, orc, name, kind, W, H,
                   tile_size=64, shard_rank=shard[0], shard_count=shard[1])
     c = rt.Context(0); c.upload(sc, W / H)
     c.clear(W, H); c.render(p); st = c.stats(); im = c.read_accum()
+    # the same frame again: now the launch sizes are PREDICTED from the first call's counters, and the thin launches (after Russian roulette) take 2 / 4 sub-queues per
+    # workgroup (RTX_OPT_MERGE_RAYS); then with every launch merged as far as one round of workgroups allows: same image, same counts
+    for merge_rays in (None, 1 << 20):
+        if merge_rays is not None:
+            c.set_option(rt.OPT_MERGE_RAYS, merge_rays)
+        c.clear(W, H); c.render(p); s2 = c.stats()
+        assert (s2.rays_primary, s2.rays_extension, s2.rays_shadow) == (st.rays_primary, st.rays_extension, st.rays_shadow), merge_rays
+        assert np.array_equal(bits(c.read_accum()), bits(im)), merge_rays
     c.close()
     o = orc.Oracle().load(sc, W / H); o.set_threads(_host_threads())
     t0 = time.time(); oa, oc = o.render(p); dt = time.time() - t0
@@ -1249,6 +1257,27 @@ def test_analytic_rectangle_light_scene_gpu_equals_oracle(rt, orc):
             assert np.array_equal(bits(c.read_accum()), bits(oa)), (flags, mb, small)
             assert (st.rays_primary, st.rays_extension, st.rays_shadow) == oc
             c.close()
+
+
+def test_merged_subqueues_of_thin_launches_are_result_neutral(rt, orc, golden_dir):
+    """RTX_OPT_MERGE_RAYS: a workgroup of the persistent traversal kernels takes several consecutive sub-queues when the previous call's counters predict a thin launch.
+    garage.obj + monke.obj at 640 x 360 x 8 spp with 64 sub-queues per CU (7 200 sub-queues: two per workgroup is the most one round of resident workgroups allows):
+    frames rendered with the option off, at its default and at 2^20 (every launch merged) must equal the oracle's image bit for bit, ray counts included"""
+    sc = rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")
+    W, H = 640, 360
+    p = rt.Params(width=W, height=H, spp=8, max_bounces=8, nee_samples=2, rr_start=2, flags=0, frame_seed=11)
+    o = orc.Oracle().load(sc, W / H); o.set_threads(_host_threads())
+    oa, oc = o.render(p)
+    c = rt.Context(0); c.set_option(rt.OPT_BLOCKS_PER_CU, 64); c.upload(sc, W / H)
+    for merge_rays in (0, 1024, 1 << 20, 1 << 20):              # (the first call of a context has no prediction: one sub-queue per workgroup whatever the option says)
+        c.set_option(rt.OPT_MERGE_RAYS, merge_rays)
+        c.clear(W, H); c.render(p); st = c.stats()
+        assert (st.rays_primary, st.rays_extension, st.rays_shadow) == oc, merge_rays
+        assert np.array_equal(bits(c.read_accum()), bits(oa)), merge_rays
+    for bad in (-1, (1 << 20) + 1):
+        with pytest.raises(rt.RtxError):
+            c.set_option(rt.OPT_MERGE_RAYS, bad)
+    c.close()
 
 
 @pytest.mark.parametrize("flags", [1, 0])
