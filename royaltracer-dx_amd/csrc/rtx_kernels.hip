@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevSc
         const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
         ray_begin(R, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, pid, true);
     };
-    while (STEAL ? refill_steal(R, W, drained, refill_min, rng, fetch) : refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) { uint32_t q, off; M.locate(idx, q, off); fetch(q, off); })) {
+    while (STEAL ? refill_steal<true>(R, W, drained, refill_min, rng, fetch) : refill<true>(R, &s_head, n, drained, refill_min, [&](uint32_t idx) { uint32_t q, off; M.locate(idx, q, off); fetch(q, off); })) {
         if (SCHED >= 5) spec_step<false>(sc, L, R, stk, (uint32_t)SCHED);
         else if (sched >= 5u) spec_step<false>(sc, L, R, stk, sched);
         else if (sched) voted_step<false>(sc, L, R, stk, sched);
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_shadow(DevSce
         const F4 so = sh_o[gi], sd = sh_d[gi];
         ray_begin(R, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, gi, false, sc.occluder_cache != 0u);
     };
-    while (STEAL ? refill_steal(R, W, drained, refill_min, rng, fetch) : refill(R, &s_head, n, drained, refill_min, [&](uint32_t idx) { uint32_t q, off; M.locate(idx, q, off); fetch(q, off); })) {
+    while (STEAL ? refill_steal<false>(R, W, drained, refill_min, rng, fetch) : refill<false>(R, &s_head, n, drained, refill_min, [&](uint32_t idx) { uint32_t q, off; M.locate(idx, q, off); fetch(q, off); })) {
         if (SCHED >= 5) spec_step<true>(sc, L, R, stk, (uint32_t)SCHED);
         else if (sched >= 5u) spec_step<true>(sc, L, R, stk, sched);
         else if (sched) voted_step<true>(sc, L, R, stk, sched);
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_bounce_bvh(DevScene sc, DevFrame 
         if (n) {
             RayLane R; ray_idle(R);
             bool drained = false;
-            while (refill(R, &s_head, n, drained, sc.refill_min, [&](uint32_t idx) {
+            while (refill<true>(R, &s_head, n, drained, sc.refill_min, [&](uint32_t idx) {
                        const uint32_t pid = myq[idx];
                        const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
                        ray_begin(R, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, pid, true);
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_bounce_bvh(DevScene sc, DevFrame 
                 const size_t sb = (size_t)j * f.qcap * G + qb;
                 RayLane R; ray_idle(R);
                 bool drained = false;
-                while (refill(R, &s_head, ns, drained, sc.refill_min, [&](uint32_t idx) {
+                while (refill<false>(R, &s_head, ns, drained, sc.refill_min, [&](uint32_t idx) {
                            const F4 so = p.sh_o[sb + idx], sd = p.sh_d[sb + idx];
                            ray_begin(R, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), fabsf(so.w), sd.w, idx, false);
                        })) {

@@ -144,15 +144,16 @@ __device__ __forceinline__ float byte_f(uint32_t w, int k) { return (float)((w >
 
 // tests the 8 children; G = this node's internal hits in octant order, T = the triangles of its hit leaf children
 // ORDERED = false (any-hit rays): the visiting order does not matter, the octant permutation of the hit bits is skipped
+// nx / ny / nz: the ray's direction is negative on that axis (bits 0-2 of its octant).  The persistent schedules hand them in as lanes of three WAVE MASKS kept in SGPR pairs
+// (OctMasks below) — derived from the octant inside the step they cost 3 v_and + 3 v_cmp per node step, 3 % of its instructions, for values that only change on a refill.
 template <bool ORDERED>
-__device__ __forceinline__ void node8_hits(const Node8R& N, f3 o, f3 idir, uint32_t oct, float tmin, float tbest, Grp& G, TriGrp& T) {
+__device__ __forceinline__ void node8_hits(const Node8R& N, f3 o, f3 idir, bool nx, bool ny, bool nz, float tmin, float tbest, Grp& G, TriGrp& T) {
     const uint32_t w = f2u(N.h0.w);
     const float sx = u2f((w & 0xffu) << 23) * idir.x, sy = u2f((w & 0xff00u) << 15) * idir.y, sz = u2f((w & 0xff0000u) << 7) * idir.z;
     const float ax = (N.h0.x - o.x) * idir.x, ay = (N.h0.y - o.y) * idir.y, az = (N.h0.z - o.z) * idir.z;
     const float anx = __builtin_fmaf(-fabsf(ax), kPlaneEps, ax), afx = __builtin_fmaf(fabsf(ax), kPlaneEps, ax);
     const float any_ = __builtin_fmaf(-fabsf(ay), kPlaneEps, ay), afy = __builtin_fmaf(fabsf(ay), kPlaneEps, ay);
     const float anz = __builtin_fmaf(-fabsf(az), kPlaneEps, az), afz = __builtin_fmaf(fabsf(az), kPlaneEps, az);
-    const bool nx = (oct & 1u) != 0u, ny = (oct & 2u) != 0u, nz = (oct & 4u) != 0u;
     // rows: q0 = (lox0, lox1, loy0, loy1)  q1 = (loz0, loz1, hix0, hix1)  q2 = (hiy0, hiy1, hiz0, hiz1)
     const uint32_t qnx[2] = {nx ? N.q1.z : N.q0.x, nx ? N.q1.w : N.q0.y}, qfx[2] = {nx ? N.q0.x : N.q1.z, nx ? N.q0.y : N.q1.w};
     const uint32_t qny[2] = {ny ? N.q2.x : N.q0.z, ny ? N.q2.y : N.q0.w}, qfy[2] = {ny ? N.q0.z : N.q2.x, ny ? N.q0.w : N.q2.y};
@@ -202,16 +203,22 @@ struct StackPriv { Grp a[kPrivStack]; __device__ __forceinline__ void put(int i,
 
 // pick the first child of group G (which has internal hits), keep the remaining siblings on the stack, test the child's
 // eight children: G / T become the child's groups
+// the rays' octant bits as three wave masks (lane l of x = ray l points towards -x ...): wave-uniform, refreshed by refill() whenever it has fetched new rays
+struct OctMasks { unsigned long long x, y, z; };
 template <bool ORDERED, class STK>
 __device__ __forceinline__ void descend8(const DevScene& sc, const TraceLds& L, f3 o, f3 idir, uint32_t oct, float tmin, float tbest,
-                                         Grp& G, TriGrp& T, STK& stk, int& sp) {
+                                         Grp& G, TriGrp& T, STK& stk, int& sp, const OctMasks* om = nullptr) {
     const uint32_t k = (uint32_t)__builtin_ctz(G.bits);
     const uint32_t rest = G.bits & (G.bits - 1u);
     if (rest & 0xffu) { stk.put(sp, Grp{G.base, rest}); sp++; }
     const uint32_t slot = ORDERED ? (k ^ oct) : k;
     const uint32_t idx = G.base + (uint32_t)__builtin_popcount((G.bits >> 8) & ((1u << slot) - 1u));
     const Node8R N = load_node8(sc, L, idx);
-    node8_hits<ORDERED>(N, o, idir, oct, tmin, tbest, G, T);
+#ifdef RTX_NO_OCT_MASKS          // (A/B build: the conditions derived from the octant inside the step, as before round 3)
+    om = nullptr;
+#endif
+    if (om) node8_hits<ORDERED>(N, o, idir, __builtin_amdgcn_inverse_ballot_w64(om->x), __builtin_amdgcn_inverse_ballot_w64(om->y), __builtin_amdgcn_inverse_ballot_w64(om->z), tmin, tbest, G, T);
+    else node8_hits<ORDERED>(N, o, idir, (oct & 1u) != 0u, (oct & 2u) != 0u, (oct & 4u) != 0u, tmin, tbest, G, T);
 }
 // index of the triangle behind bit `bit` of a triangle group
 __device__ __forceinline__ uint32_t tri_slot8(const TriGrp& T, uint32_t bit) { return T.base + (uint32_t)__builtin_popcount(T.valid & ((1u << bit) - 1u)); }
@@ -495,7 +502,9 @@ static_assert(kPend >= 2 && kPend <= 4, "RTX_PEND");
 struct RayLane {                                       // per-lane traversal state
     f3 o, d, idir; float tmin, tmax, bt, bu, bv; uint32_t bprim; uint32_t oct; Grp G; TriGrp T, P[kPend - 1]; int sp; uint32_t item; bool has, done;   // P: pending triangle groups behind T (speculative schedule)
     uint32_t occluder;       // any-hit rays: slot of the triangle that occluded this lane's previous occluded ray (kNoOccluder: none yet), see ray_begin
+    OctMasks om;             // WAVE-UNIFORM: ballots of the lanes' octant bits, kept current by refill() / refill_steal() (the only places where a lane gets a new ray)
 };
+__device__ __forceinline__ void oct_masks_update(RayLane& R) { R.om.x = __ballot((R.oct & 1u) != 0u); R.om.y = __ballot((R.oct & 2u) != 0u); R.om.z = __ballot((R.oct & 4u) != 0u); }
 constexpr uint32_t kNoOccluder = 0xFFFFFFFFu;
 __device__ __forceinline__ void pend_clear(RayLane& R) {
 #pragma unroll
@@ -522,7 +531,7 @@ __device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, fl
 __device__ __forceinline__ void ray_idle(RayLane& R) {
     R.has = false; R.done = false; R.sp = 0; R.item = 0; R.o = mk3(0, 0, 0); R.d = mk3(0, 0, 1); R.idir = mk3(0, 0, 1); R.oct = 0;
     R.tmin = 0.0f; R.tmax = 0.0f; R.bt = 0.0f; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.G = Grp{0u, 0u}; R.T = TriGrp{0u, 0u, 0u}; pend_clear(R);
-    R.occluder = kNoOccluder;
+    R.occluder = kNoOccluder; R.om = OctMasks{0ull, 0ull, 0ull};
 }
 // after a node step or a finished triangle group: continue with the node's own internal hits, else pop, else done
 template <class STK>
@@ -633,7 +642,7 @@ __device__ __forceinline__ void spec_step(const DevScene& sc, const TraceLds& L,
     if (ni * wn >= nl * wl && ni) {
         if (can_node) {
             if (!(R.G.bits & 0xffu)) { R.sp--; R.G = stk.get(R.sp); }
-            descend8<!ANY>(sc, L, R.o, R.idir, R.oct, R.tmin, R.bt, R.G, R.P[0], stk, R.sp);
+            descend8<!ANY>(sc, L, R.o, R.idir, R.oct, R.tmin, R.bt, R.G, R.P[0], stk, R.sp, ANY ? nullptr : &R.om);
         }
     } else if (has_tri) upd = tri_candidate<ANY>(sc, L, R, ct, cu, cw, cg);
     uint32_t updv = upd ? 1u : 0u;
@@ -648,7 +657,7 @@ __device__ __forceinline__ void spec_step(const DevScene& sc, const TraceLds& L,
         if (can_node) {
             if (!(R.G.bits & 0xffu)) { R.sp--; R.G = stk.get(R.sp); }
             TriGrp Tn;
-            descend8<!ANY>(sc, L, R.o, R.idir, R.oct, R.tmin, R.bt, R.G, Tn, stk, R.sp);
+            descend8<!ANY>(sc, L, R.o, R.idir, R.oct, R.tmin, R.bt, R.G, Tn, stk, R.sp, ANY ? nullptr : &R.om);
             if (Tn.bits) {                                                        // first free slot: T, then P[0], P[1], ...
                 bool placed = false;
                 if (!R.T.bits) { R.T = Tn; placed = true; }
@@ -688,7 +697,7 @@ struct MergedQ {
 };
 
 // wave-level refill: returns false when the wave may exit (queue exhausted and nothing in flight)
-template <class Fetch>
+template <bool MASKS, class Fetch>      // MASKS: keep R.om current (closest-hit kernels; the any-hit kernel measured 5 % SLOWER with the masks on C3 and derives the conditions from the octant)
 __device__ __forceinline__ bool refill(RayLane& R, uint32_t* s_head, uint32_t n, bool& drained, uint32_t refill_min, Fetch fetch) {
     const unsigned long long idle = __ballot(!R.has);
     const uint32_t nidle = (uint32_t)__popcll(idle);
@@ -701,6 +710,7 @@ __device__ __forceinline__ bool refill(RayLane& R, uint32_t* s_head, uint32_t n,
             const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             if (!R.has && idx < n) fetch(idx);
             if (base + nidle >= n) drained = true;
+            if (MASKS) oct_masks_update(R);
         }
     }
     return __ballot(R.has) != 0ull;
@@ -756,7 +766,7 @@ __device__ __forceinline__ uint32_t pick_victim(const uint32_t* heads, uint32_t 
 }
 // a wave's pseudo-random sequence of start positions, seeded from workgroup and wave number
 __device__ __forceinline__ uint32_t steal_seed() { return (blockIdx.x * 4u + (threadIdx.x >> 6)) * 2654435761u + 0x9e3779b9u; }
-template <class Fetch>
+template <bool MASKS, class Fetch>
 __device__ __forceinline__ bool refill_steal(RayLane& R, RaySource& W, bool& drained, uint32_t refill_min, uint32_t& rng, Fetch fetch) {
     unsigned long long idle = __ballot(!R.has);
     uint32_t nidle = (uint32_t)__popcll(idle);
@@ -781,6 +791,7 @@ __device__ __forceinline__ bool refill_steal(RayLane& R, RaySource& W, bool& dra
             if (v >= W.G) { drained = true; break; }
             W.cur = v; W.n = W.counts[v];
         }
+        if (MASKS) oct_masks_update(R);
     }
     return __ballot(R.has) != 0ull;
 }
