@@ -267,7 +267,8 @@ def time_restir(rt, dev_index, kind, frames=6):
     """The reference's own frame — rtx_render_restir: pass 1 + temporal + spatial reuse with its defines nee 4 / bounces 3 (Common_v6.hlsl:8-12) — at 1920x1080 on the
     reference's start-up scene (garage.obj + monke.obj, Renderer.cpp:363) or the Sponza-class atrium: ms per frame once the history is warm, rays by type, and the
     per-class kernel times of the wavefront stages (raygen / trace_closest = persistent closest-hit launches / shade = the stage kernels / trace_shadow = persistent
-    any-hit launches).  `frac` prices the dominant class like the path tracer's separate kernels: 48 B per ray of a traversal launch."""
+    any-hit launches).  `frac` prices the dominant class by its algorithmic bytes (rays: 48 B each as for the path tracer's separate kernels; stage kernels: the
+    reference's per-pixel records), `frame_frac` the whole frame."""
     import torch
     W, H = 1920, 1080
     gd = os.path.join(ROOT, "tests", "golden")
@@ -297,11 +298,18 @@ def time_restir(rt, dev_index, kind, frames=6):
             kms += np.array(st.kernel_ms[:]); rays += np.array([st.rays_primary, st.rays_extension, st.rays_shadow], dtype=np.float64)
         by = {rt.KERNEL_NAMES[i]: float(kms[i]) / frames for i in rt.KERNEL_NAMES if kms[i] > 0}
         dom = max(by, key=by.get) if by else None
-        nray = {"trace_closest": rays[0] + rays[1], "trace_shadow": rays[2]}.get(dom)
-        frac = (48.0 * nray / frames) / (by[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS if nray else None
+        # algorithmic bytes: 48 B per ray of a traversal launch; the stage kernels ("shade") move the reference's per-pixel records — pass 1 writes Reservoir_DI 40 +
+        # Reservoir_GI 40 + SampleData 60 B; pass 2 reads them and the reprojected pixel's 140 B and writes the two reservoirs; pass 3 reads the pixel's 140 B and 3 + 3 neighbours'
+        # reservoir + sample data (100 B each), writes both reservoirs and the sample data to the history and adds to the accumulation buffer (16 B read + 16 B written)
+        px_bytes = 140 + (140 + 140 + 80) + (140 + 6 * 100 + 80 + 60 + 32)
+        alg = {"trace_closest": 48.0 * (rays[0] + rays[1]) / frames, "trace_shadow": 48.0 * rays[2] / frames, "shade": float(px_bytes) * W * H}
+        frac = alg[dom] / (by[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS if dom in alg else None
+        frame_alg = (224.0 * rays[1] + 96.0 * rays[2]) / frames + float(px_bytes) * W * H            # the path tracer's per-ray prices + the records
         return {"ms_per_frame": round(dt * 1e3 / frames, 3), "Mrays_s": round(float(rays.sum()) / frames / (dt / frames) / 1e6, 1), "triangles": int(scene.num_triangles), "scene": source,
                 "rays_per_frame": {"primary": int(rays[0] / frames), "extension": int(rays[1] / frames), "shadow": int(rays[2] / frames)},
                 "kernel_ms_per_frame": {k: round(v, 3) for k, v in by.items()}, "dominant_kernel": dom, "frac": round(frac, 5) if frac else None,
+                "frame_frac": round(frame_alg / (dt / frames) / 1e9 / HBM_PEAK_GBS, 5),
+                "alg_bytes_model": f"dominant class: 48 B per ray of a traversal launch, {px_bytes} B of reservoir / sample records per pixel for the stage kernels; frame: 224*N_ext + 96*N_shadow + {px_bytes}*N_px",
                 "form": "wavefront stages (csrc/rtx_restir_wave.hpp); RTX_OPT_RESTIR_WAVEFRONT=0 is the thread-per-pixel form",
                 "params": "1920x1080, nee_samples 4, bounces 3, 1 frame per step, history warm"}
     finally:

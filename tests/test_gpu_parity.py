@@ -1336,6 +1336,20 @@ def test_bench_runs_a_real_asset_and_reports_bounded_rooflines(golden_dir, tmp_p
         assert roof["traffic"] is None and (roof["traffic_source"] is None or "STALE" in roof["traffic_source"])
 
 
+def test_bench_restir_extra_prices_its_dominant_class(rt):
+    """bench.py's `extra.restir_*` entries (the reference's own frame at 1080p on its start-up scene): every kernel class is timed, the dominant one and the frame carry a
+    fraction of the HBM roofline in (0, 1] with the byte model spelled out, and the ray counts are those of pass 1-3 (<= 8 + 2 + 10 rays per pixel)"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py")); bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    r = bench.time_restir(rt, 0, "garage", frames=2)
+    assert set(r["kernel_ms_per_frame"]) >= {"raygen", "trace_closest", "shade", "trace_shadow"} and r["dominant_kernel"] in r["kernel_ms_per_frame"]
+    assert 0.0 < r["frac"] <= 1.0 and 0.0 < r["frame_frac"] <= 1.0 and "per pixel" in r["alg_bytes_model"]
+    px = 1920 * 1080
+    assert r["rays_per_frame"]["primary"] == px and 0 < r["rays_per_frame"]["extension"] <= 7 * px and 0 < r["rays_per_frame"]["shadow"] <= 20 * px
+    assert 0.5 < r["ms_per_frame"] < 100.0
+
+
 def test_bench_two_ranks_assemble_the_single_rank_frame():
     """bench.py's N > 1 flow end to end on ONE GPU: two processes (torch.distributed.run), each renders its pixel tiles on device 0, packs
     its slab, one gather (gloo, staged through the host: two ranks cannot share a GPU under RCCL), unpack; rank 0's JSON line must carry
