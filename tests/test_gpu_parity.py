@@ -1259,6 +1259,41 @@ def test_analytic_rectangle_light_scene_gpu_equals_oracle(rt, orc):
             c.close()
 
 
+@pytest.mark.parametrize("knob", ["shade_dense", "occluder_cache", "both"])
+def test_measured_and_rejected_knob_kernels_stay_bit_identical(rt, orc, golden_dir, cornell, knob):
+    """RTX_OPT_SHADE_DENSE (k_shade_dense: hits compacted through an LDS ring before shading) and RTX_OPT_OCCLUDER_CACHE (any-hit rays first test the triangle that occluded
+    the lane's previous ray) are kept as knobs after they measured slower: they must keep producing the oracle's image bit for bit and its ray counts —
+    Cornell through the general BVH path (Lambert-only and GGX instantiations) and the reference's garage scene, plus one ReSTIR frame pair for the occluder cache"""
+    garage = rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")
+    for sc, W, H, flags in ((cornell, 160, 90, 1), (cornell, 160, 90, 0), (garage, 192, 108, 0)):
+        p = rt.Params(width=W, height=H, spp=3, max_bounces=6, nee_samples=2, rr_start=2, flags=flags, frame_seed=4)
+        oa, oc = orc.Oracle().load(sc, W / H).render(p)
+        c = rt.Context(0); c.set_option(rt.OPT_SMALL_SCENE, 0)
+        c.set_option(rt.OPT_SHADE_DENSE, 1 if knob in ("shade_dense", "both") else 0)
+        c.set_option(rt.OPT_OCCLUDER_CACHE, 1 if knob in ("occluder_cache", "both") else 0)
+        c.upload(sc, W / H)
+        for _ in range(2):                                                  # (the second frame: launch sizes predicted, lanes carry occluders over from the first)
+            c.clear(W, H); c.render(p); st = c.stats()
+            assert (st.rays_primary, st.rays_extension, st.rays_shadow) == oc, (knob, flags)
+            assert np.array_equal(bits(c.read_accum()), bits(oa)), (knob, flags)
+        c.close()
+    if knob != "shade_dense":
+        W, H = 96, 54
+        o = orc.Oracle().load(garage, W / H)
+        vp = garage.view_proj(W / H); o.set_camera(*vp); o.set_camera(*vp)
+        c = rt.Context(0); c.set_option(rt.OPT_OCCLUDER_CACHE, 1); c.upload(garage, W / H)
+        c.set_camera(*vp); c.set_camera(*vp)
+        c.restir_reset(); c.clear(W, H)
+        acc_o, st = np.zeros((H, W, 4), np.float32), None
+        for f in range(2):
+            p = rt.Params(width=W, height=H, spp=1, max_bounces=3, nee_samples=4, flags=0, frame_seed=20 + f)
+            c.render_restir(p); s = c.stats()
+            acc_o, st, cnt = o.restir_frames(p, acc_o, st)
+            assert (s.rays_primary, s.rays_extension, s.rays_shadow) == cnt, f
+            assert np.array_equal(bits(c.read_accum()), bits(acc_o)), f
+        c.close()
+
+
 def test_merged_subqueues_of_thin_launches_are_result_neutral(rt, orc, golden_dir):
     """RTX_OPT_MERGE_RAYS: a workgroup of the persistent traversal kernels takes several consecutive sub-queues when the previous call's counters predict a thin launch.
     garage.obj + monke.obj at 640 x 360 x 8 spp with 64 sub-queues per CU (7 200 sub-queues: two per workgroup is the most one round of resident workgroups allows):
