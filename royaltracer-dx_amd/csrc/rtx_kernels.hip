@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevSc
     uint32_t rng = steal_seed();
     auto fetch = [&](uint32_t q, uint32_t idx) {
         const uint32_t pid = p.out_o ? q * qcap + idx : queue[(size_t)q * qcap + idx];
-        const F4 ro = p.ray_o[pid], rd = p.ray_d[pid];
+        const F4 ro = ld_stream(p.ray_o + pid), rd = ld_stream(p.ray_d + pid);
         ray_begin(R, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, pid, true);
     };
     while (STEAL ? refill_steal<true>(R, W, drained, refill_min, rng, fetch) : refill<true>(R, &s_head, n, drained, refill_min, [&](uint32_t idx) { uint32_t q, off; M.locate(idx, q, off); fetch(q, off); })) {
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevSc
         else if (sched >= 5u) spec_step<false>(sc, L, R, stk, sched);
         else if (sched) voted_step<false>(sc, L, R, stk, sched);
         else { walk_internal<false>(sc, L, R, stk); process_leaf<false>(sc, L, R, stk); }
-        if (R.has && R.done) { p.hit[R.item] = {R.bt, R.bu, R.bv, u2f(R.bprim)}; R.has = false; }
+        if (R.has && R.done) { st_stream(p.hit + R.item, F4{R.bt, R.bu, R.bv, u2f(R.bprim)}); R.has = false; }
     }
 }
 
@@ -266,10 +266,10 @@ __device__ __forceinline__ void shade_item(const DevScene& sc, const DevFrame& f
     if (valid) {
         const uint32_t pid = myq[qi];
         const uint32_t src = p.out_o ? (uint32_t)qb + qi : pid;               // compact state: hit and path state live at the queue position
-        const F4 h = p.hit[src];
+        const F4 h = ld_stream(p.hit + src);
         const uint32_t prim = f2u(h.w);
         if (prim != kMissPrim) {                                          // miss: Miss.hlsl:3-11 -> black, terminate
-            S = load_path(p, src); S.pid = pid;
+            S = load_path_stream(p, src); S.pid = pid;
             PF_MARK(0); PF_COUNT(1);
             sf = surface(sc, S.o, S.d, h.x, h.y, h.z, prim);
             PF_MARK(1);
@@ -294,7 +294,7 @@ __device__ __forceinline__ void shade_item(const DevScene& sc, const DevFrame& f
         if (push) { PF_COUNT(4); }
         const size_t seg = (size_t)j * f.qcap * gridDim.x + qb;           // NEE slot j, this workgroup's sub-queue
         const uint32_t slot = block_push(push, &s_cnt[1 + j]);
-        if (push) { p.sh_o[seg + slot] = so; p.sh_d[seg + slot] = sd; p.sh_c[seg + slot] = {con.x, con.y, con.z, u2f(S.pid)}; }
+        if (push) { st_stream(p.sh_o + seg + slot, so); st_stream(p.sh_d + seg + slot, sd); st_stream(p.sh_c + seg + slot, F4{con.x, con.y, con.z, u2f(S.pid)}); }
     }
     PF_MARK(4);
     bool alive = false;
@@ -305,7 +305,7 @@ __device__ __forceinline__ void shade_item(const DevScene& sc, const DevFrame& f
     if (alive) { PF_COUNT(6); }
     const uint32_t slot = block_push(alive, &s_cnt[0]);
     if (alive) {
-        if (p.out_o) store_path_at(p.out_o, p.out_d, p.out_thr, (uint32_t)qb + slot, S, pos, smp, P);     // densely, at its place in the next queue
+        if (p.out_o) store_path_at_stream(p.out_o, p.out_d, p.out_thr, (uint32_t)qb + slot, S, pos, smp, P);     // densely, at its place in the next queue
         else store_path(p, S, pos, smp, P);
         mynext[slot] = S.pid;
     }

@@ -41,6 +41,33 @@ struct PathState { uint32_t pid; f3 o, d; float prev_pdf; f3 thr; uint32_t s0, s
 
 __device__ __forceinline__ float bounce_tmin(uint32_t bounce) { return bounce == 0 ? kTMinCam : kSBias; }
 
+// STREAMING ACCESSES of the general path.  Path state, hit records, the next bounce's state and the shadow entries are written once and read once per bounce, gigabytes of them
+// (33 M paths x 48 B); marked non-temporal they do not displace what IS re-used from L2 — the randomly fetched TriShade / material lines of k_shade (L2 hit 0.44) and the BVH of
+// k_trace_closest (C5: 0.62).  Same box, three alternating rounds (make VARIANT=x VARFLAGS=-DRTX_NO_NT_STREAMS, tools/lib_ab.sh): k_shade 6.60 -> 6.23 ms (C3), 7.91 -> 7.79
+// (C5); the ray loads / hit stores of k_trace_closest: 19.09 -> 18.86 ms on C5, nothing on C3; frames -0.9 % both.  NOT in k_trace_shadow: its entries marked the same way
+// cost 2.6 % there (11.35 -> 11.65 ms, C3).
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+#ifdef RTX_NO_NT_STREAMS
+constexpr bool kNtStreams = false;
+#else
+constexpr bool kNtStreams = true;
+#endif
+__device__ __forceinline__ F4 ld_stream(const F4* p) {
+    if (kNtStreams) { const nt_f4 v = __builtin_nontemporal_load((const nt_f4*)p); return F4{v.x, v.y, v.z, v.w}; }
+    return *p;
+}
+__device__ __forceinline__ void st_stream(F4* p, F4 v) {
+    if (kNtStreams) { nt_f4 w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, (nt_f4*)p); }
+    else *p = v;
+}
+__device__ __forceinline__ PathState load_path_stream(const DevPaths& p, uint32_t pid) {
+    PathState S; S.pid = pid;
+    const F4 ro = ld_stream(p.ray_o + pid), rd = ld_stream(p.ray_d + pid), tv = ld_stream(p.thr + pid);
+    S.o = mk3(ro.x, ro.y, ro.z); S.s1 = f2u(ro.w);
+    S.d = mk3(rd.x, rd.y, rd.z); S.prev_pdf = rd.w;
+    S.thr = mk3(tv.x, tv.y, tv.z); S.s0 = f2u(tv.w);
+    return S;
+}
 __device__ __forceinline__ PathState load_path(const DevPaths& p, uint32_t pid) {
     PathState S; S.pid = pid;
     const F4 ro = p.ray_o[pid], rd = p.ray_d[pid], tv = p.thr[pid];
@@ -138,6 +165,11 @@ __device__ __forceinline__ void store_path_at(F4* ray_o, F4* ray_d, F4* thr, uin
     ray_o[idx] = {pos.x, pos.y, pos.z, u2f(S.s1)};            // un-offset origin, Sampler_v6.hlsl:224-227
     ray_d[idx] = {smp.x, smp.y, smp.z, P};                    // pdf for the MIS at the next emissive hit, Hit.hlsl:369
     thr[idx] = {S.thr.x, S.thr.y, S.thr.z, u2f(S.s0)};
+}
+__device__ __forceinline__ void store_path_at_stream(F4* ray_o, F4* ray_d, F4* thr, uint32_t idx, const PathState& S, f3 pos, f3 smp, float P) {
+    st_stream(ray_o + idx, F4{pos.x, pos.y, pos.z, u2f(S.s1)});
+    st_stream(ray_d + idx, F4{smp.x, smp.y, smp.z, P});
+    st_stream(thr + idx, F4{S.thr.x, S.thr.y, S.thr.z, u2f(S.s0)});
 }
 __device__ __forceinline__ void store_path(const DevPaths& p, const PathState& S, f3 pos, f3 smp, float P) { store_path_at(p.ray_o, p.ray_d, p.thr, S.pid, S, pos, smp, P); }
 

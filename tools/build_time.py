@@ -1,0 +1,10 @@
+import sys, time, os
+sys.path.insert(0, '/root/repo')
+os.chdir(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+import __graft_entry__ as g
+rt = g.load_package()
+for kind in ('sponza', 'bistro'):
+    t0 = time.time(); sc = rt.Scene.sponza_class() if kind == 'sponza' else rt.Scene.bistro_class(); t1 = time.time()
+    c = rt.Context(0); t2 = time.time(); c.upload(sc, 16 / 9); t3 = time.time()
+    print(f"{kind}: generate {t1 - t0:.2f} s, upload+commit (BVH build) {t3 - t2:.2f} s, triangles {sc.num_triangles}")
+    c.close()
