@@ -59,6 +59,7 @@ struct rtx_ctx {
     // RTX_OPT_MERGE_RAYS: thin launches of the traversal kernels take several sub-queues per workgroup (MergedQ).  The host cannot see a launch's ray count (it is on the
     // device), so it predicts it from the counters of the previous rtx_render of this context: per path entering the batch, how many were still alive at bounce b and how many
     // shadow rays slot j of bounce b cast.  A wrong prediction costs time only.
+    bool taper = true; uint32_t taper_levels = 4;             // RTX_OPT_TAPER
     uint32_t merge_rays = 1024; uint64_t pred_paths = 0; std::vector<uint64_t> pred_q, pred_s; uint32_t pred_nee1 = 0;
     bool overlap_shadow = true; hipStream_t aux = nullptr;       // RTX_OPT_OVERLAP_SHADOW: k_trace_shadow of bounce b on a second stream, beside k_trace_closest of bounce b + 1 (not while kernels are timed)
     DevBuf d_ray_o, d_ray_d, d_thr, d_rad, d_hit, d_sh_o, d_sh_d, d_sh_c, d_queue[2], d_counters;
@@ -163,6 +164,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_COMPACT_STATE: c->compact_state = value != 0; return RTX_OK;
     case RTX_OPT_OVERLAP_SHADOW: c->overlap_shadow = value != 0; return RTX_OK;
     case RTX_OPT_BLOCKS_PER_CU: if (value < 0 || value > 64) { c->err = "blocks_per_cu must be in [0, 64]"; return RTX_ERR_INVALID; } c->blocks_per_cu = (uint32_t)value; return RTX_OK;
+    case RTX_OPT_TAPER: if (value < 0 || value > 8) { c->err = "taper must be in [0, 8]"; return RTX_ERR_INVALID; } c->taper = value != 0; c->taper_levels = value == 1 ? 4u : (uint32_t)std::max<long long>(value, 1); return RTX_OK;
     case RTX_OPT_MERGE_RAYS: if (value < 0 || value > (1 << 20)) { c->err = "merge_rays must be in [0, 2^20]"; return RTX_ERR_INVALID; } c->merge_rays = (uint32_t)value; return RTX_OK;
     case RTX_OPT_GPU_REFIT: c->gpu_refit = value != 0; return RTX_OK;
     case RTX_OPT_SHADE_DENSE: c->shade_dense = (int)value; c->dsc.shade_dense = value > 0 ? 1u : 0u; return RTX_OK;
@@ -419,7 +421,7 @@ static int make_frame(rtx_ctx* c, const rtx_params* p, DevFrame& f) {
     if (const char* e = validate_tiling(p, ts, cnt, npl64, &f.blk_gx, &f.blk_gy)) { c->err = e; return RTX_ERR_INVALID; }
     f.width = p->width; f.height = p->height; f.tile_size = ts;
     f.tile_shift = 0; while ((1u << f.tile_shift) < ts) f.tile_shift++;
-    f.nblocks = 1; f.qcap = 0; f.chunks_per_sample = 0;
+    f.nblocks = 1; f.qcap = 0; f.chunks_per_sample = 0; f.taper_levels = 0;
     f.tiles_x = (p->width + ts - 1) / ts; f.tiles_y = (p->height + ts - 1) / ts;
     f.shard_rank = p->shard_rank; f.shard_count = cnt;
     f.npl = (uint32_t)npl64;
@@ -480,8 +482,15 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
                                           : std::max<uint32_t>(8u, std::min<uint32_t>(bpc_hi, (nchunks / per_wg + (uint32_t)c->num_cus - 1u) / (uint32_t)c->num_cus));
     const uint32_t max_blocks = (uint32_t)c->num_cus * bpc;
     const uint32_t G = std::max<uint32_t>(1, std::min<uint32_t>(nchunks, max_blocks));
-    const uint32_t qcap = ((nchunks + G - 1) / G) * 256u;
-    f.nblocks = G; f.qcap = qcap;
+    // tapered sub-queue sizes (taper_row_width, rtx_kernels.hpp): general path with separate kernels only; needs a few chunks in the shortest sub-queue to mean anything
+    uint32_t taper_levels = 0, qchunks = (nchunks + G - 1) / G;
+    if (c->taper && !tiny_fused && !fused_bvh && G >= 64u && nchunks >= 4u * G) {
+        taper_levels = c->taper_levels;
+        qchunks = 0;                                                                   // sub-queue 0 takes part in every row
+        for (uint32_t k = 0, row0 = 0; row0 < nchunks; k++) { row0 += taper_row_width(k, G, taper_levels); qchunks++; }
+    }
+    const uint32_t qcap = qchunks * 256u;
+    f.nblocks = G; f.qcap = qcap; f.taper_levels = taper_levels;
     const size_t qtot = (size_t)G * qcap;
     // path state: by path id (cap entries), or — separate kernels of the default configuration — by queue position (qtot >= cap entries) in two sets
     const bool compact = c->compact_state && !(c->dsc.nsmall && c->fused) && !fused_bvh;

@@ -50,7 +50,14 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DevFrame f, DevPaths p, const
     // chunk c = 256 consecutive path slots of ONE sample; chunks are dealt round-robin to workgroups so that
     // every workgroup's sub-queue holds a representative sample of the image (load balance across bounces)
     const uint32_t nchunks = f.chunks_per_sample * f.batch_spp;
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    // even deal: chunks b, b + G, b + 2 G, ...; tapered deal (f.taper_levels > 0): row k hands chunks row0 .. row0 + n_k - 1 to the sub-queues 0 .. n_k - 1 (taper_row_width)
+    for (uint32_t k = 0, row0 = 0; row0 < nchunks; k++) {
+        const uint32_t nk = f.taper_levels ? taper_row_width(k, gridDim.x, f.taper_levels) : gridDim.x;
+        uint32_t pos = blockIdx.x;
+        if (f.taper_levels && blockIdx.x < nk) { pos += (k * 2654435761u) % nk; if (pos >= nk) pos -= nk; }      // rotate the row: every sub-queue sees every part of the image over its rows
+        const uint32_t c = row0 + pos;
+        row0 += nk;
+        if (blockIdx.x >= nk || c >= nchunks) continue;                                   // wave-uniform
         const uint32_t sl = c / f.chunks_per_sample, cl = c - sl * f.chunks_per_sample;   // wave-uniform (SALU)
         const uint32_t pl = cl * kBlock + threadIdx.x;
         const uint32_t pid = sl * f.npl + pl;
@@ -151,6 +158,11 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevSc
                                                                        uint32_t nq, uint32_t merge) {           // nq sub-queues in the launch, `merge` of them per workgroup (MergedQ; 1 with STEAL and on the tiny-scene test path)
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_head;
+#ifdef RTX_WAVE_CLOCK
+    struct WaveClock { bool on; unsigned long long t0; uint32_t w;
+        __device__ ~WaveClock() { if (on && lane_id() == 0 && w < 65536u) { g_wgt[2u * w] = t0; g_wgt[2u * w + 1u] = __builtin_amdgcn_s_memrealtime(); } } };
+    WaveClock wclk{tmin != kTMinCam, __builtin_amdgcn_s_memrealtime(), blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6)};
+#endif
     MergedQ M; M.init(qcount, nq, merge);
     const uint32_t n = M.n;
     if (STEAL ? all_exhausted(heads, gridDim.x) : n == 0) return;      // (work stealing: nothing left in the whole launch)
@@ -1256,6 +1268,15 @@ extern "C" int rtx_debug_sections(unsigned long long* out36, int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (out36 && hipMemcpyFromSymbol(out36, HIP_SYMBOL(rtx::g_sec), sizeof(unsigned long long) * 36) != hipSuccess) return -1;
     if (reset) { unsigned long long z[36] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rtx::g_sec), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+
+#ifdef RTX_WAVE_CLOCK
+extern "C" int rtx_debug_wave_times(unsigned long long* out, unsigned nwaves, int reset) {      // nwaves <= 65536 (start, end) pairs
+    if (hipDeviceSynchronize() != hipSuccess || nwaves > 65536u) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rtx::g_wgt), sizeof(unsigned long long) * 2 * nwaves) != hipSuccess) return -1;
+    if (reset) { void* d = nullptr; if (hipGetSymbolAddress(&d, HIP_SYMBOL(rtx::g_wgt)) != hipSuccess || hipMemset(d, 0, sizeof(unsigned long long) * 2 * 65536) != hipSuccess) return -1; }
     return 0;
 }
 #endif

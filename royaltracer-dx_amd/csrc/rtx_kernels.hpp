@@ -41,8 +41,28 @@ struct DevFrame {
     uint32_t max_bounces, nee_samples, rr_start, frame_seed, flags;
     // work distribution: `nblocks` workgroups, each owning a private sub-queue of `qcap` entries
     uint32_t nblocks, qcap, chunks_per_sample;   // chunks_per_sample = npl / 256
+    uint32_t taper_levels;   // k_raygen: 0 = chunks dealt evenly (chunk c -> sub-queue c mod nblocks); L > 0 = tapered deal with L weight classes (taper_row_width below)
 };
 
+// TAPERED sub-queue sizes (RTX_OPT_TAPER).  Workgroups are dispatched in index order and every launch of a bounce ends when its LAST workgroup does; with equal sub-queues
+// the last round of workgroups drains over one workgroup lifetime (~1 ms of a 4.8-ms launch at 32 sub-queues per CU: tools/wave_timeline.py shows 96 % of the peak number of
+// waves until 83 % of the launch, then a ramp down: 12 % of the launch's wave slots idle).  So the sub-queues get SHORTER towards the end of the dispatch order: with L levels the
+// index ranges [0, G/2) | [G/2, 3G/4) | ... (each half of what is left, the last level the rest) carry the weights 2^(L-1) | 2^(L-2) | ... | 1 — the long ones start first,
+// the short ones fill the end.  The sizes persist through the bounces (survivors are a near-constant fraction), so every launch of the frame is tapered.
+// The deal keeps what the even deal (chunk c -> sub-queue c mod G) has: chunks go out in ROWS of consecutive chunks, one per sub-queue in index order, so that neighbouring
+// sub-queues — which run at the same time — hold neighbouring pixels of the same sample and walk the same part of the tree together (a scattered deal of the same sizes measured
+// 2.5-4.6 % SLOWER than the even deal).  A sub-queue of weight w takes part in the rows k with (k mod 2^(L-1)) < w; the sub-queues taking part in a row are a prefix [0, n_k).
+#if defined(__HIPCC__)
+#define RTX_TAPER_HD __host__ __device__ __forceinline__
+#else
+#define RTX_TAPER_HD inline
+#endif
+RTX_TAPER_HD uint32_t taper_row_width(uint32_t k, uint32_t G, uint32_t levels) {      // n_k: sub-queues [0, n_k) get one chunk each in row k
+    const uint32_t m = k & ((1u << (levels - 1u)) - 1u);
+    if (m == 0u) return G;
+    uint32_t lg = 0; while ((m >> (lg + 1u)) != 0u) lg++;                              // floor(log2 m)
+    return G - (G >> (levels - 1u - lg));                                              // first index of the first class whose weight is <= m
+}
 // THE rule "k-th tile of a shard -> tile coordinates" (slot_to_pixel on the device, the halo list and the slab sizes on the host).  false: the shard has no such tile
 // (its slot range is padded to the same length for every rank, so that the all-gather of the slabs has equal counts).
 #if defined(__HIPCC__)

@@ -610,6 +610,9 @@ __device__ __forceinline__ void voted_step(const DevScene& sc, const TraceLds& L
 // before a ray finishes, and the order of tests does not change the result (minimum over all tested triangles / any hit); what
 // speculation costs is culling: node steps taken before the pending triangles shrink the closest distance may visit boxes that
 // would have been culled (shadow rays lose nothing: their interval is fixed).
+#ifdef RTX_WAVE_CLOCK      // tooling build (make VARIANT=wclk VARFLAGS=-DRTX_WAVE_CLOCK): start / end (s_memrealtime, 100 MHz) of every WAVE of the closest-hit launches after the camera rays' (tools/wave_timeline.py renders two bounces, so there is one)
+__device__ unsigned long long g_wgt[2 * 65536];
+#endif
 #ifdef RTX_PROFILE_SECTIONS
 __device__ unsigned long long g_trv[8];      // tooling (PROFILE build): node iterations, lanes in them, triangle iterations, lanes in them, busy lanes summed over iterations, iterations
 #endif

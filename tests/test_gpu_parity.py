@@ -1228,6 +1228,13 @@ def test_full_size_baseline_configs_are_bit_identical(rt, orc, name, kind, W, H,
         c.clear(W, H); c.render(p); s2 = c.stats()
         assert (s2.rays_primary, s2.rays_extension, s2.rays_shadow) == (st.rays_primary, st.rays_extension, st.rays_shadow), merge_rays
         assert np.array_equal(bits(c.read_accum()), bits(im)), merge_rays
+    # RTX_OPT_TAPER: the first frame above ran with the default (sub-queue sizes tapered 8 | 4 | 2 | 1 over the dispatch order); equal sub-queues and a steeper taper must
+    # give the same image and counts
+    for taper in (0, 6):
+        c.set_option(rt.OPT_TAPER, taper)
+        c.clear(W, H); c.render(p); s2 = c.stats()
+        assert (s2.rays_primary, s2.rays_extension, s2.rays_shadow) == (st.rays_primary, st.rays_extension, st.rays_shadow), ("taper", taper)
+        assert np.array_equal(bits(c.read_accum()), bits(im)), ("taper", taper)
     c.close()
     o = orc.Oracle().load(sc, W / H); o.set_threads(_host_threads())
     t0 = time.time(); oa, oc = o.render(p); dt = time.time() - t0

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""How full the machine is over ONE launch of the persistent closest-hit kernel (tooling build: make -C royaltracer-dx_amd VARIANT=wclk VARFLAGS=-DRTX_WAVE_CLOCK): every wave records its start and end
+(s_memrealtime); the tool renders 1080p 16 spp with TWO bounces, so the recorded launch is bounce 1 (31 M incoherent rays), and prints the number of live waves over time.
+usage: python tools/wave_timeline.py [sponza|bistro] [option_id=value ...]"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["RTX_LIB_PATH"] = os.environ.get("RTX_LIB_PATH") or os.path.join(ROOT, "royaltracer-dx_amd", "librtx_hip_wclk.so")
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch  # noqa
+import __graft_entry__ as graft
+rt = graft.load_package()
+kind = next((a for a in sys.argv[1:] if a in ("sponza", "bistro")), "sponza")
+sc = rt.Scene.sponza_class() if kind == "sponza" else rt.Scene.bistro_class()
+W, H = 1920, 1080
+c = rt.Context(0)
+for a in sys.argv[1:]:
+    if "=" in a:
+        c.set_option(int(a.split("=")[0]), int(a.split("=")[1]))
+c.upload(sc, W / H); c.clear(W, H)
+p = rt.Params(width=W, height=H, spp=16, max_bounces=2, nee_samples=1, flags=1 if kind == "sponza" else 4)
+rt.lib.rtx_debug_wave_times.argtypes = [C.POINTER(C.c_ulonglong), C.c_uint, C.c_int]
+c.render(p)
+assert rt.lib.rtx_debug_wave_times(None, 0, 1) == 0
+c.render(p)
+N = 65536
+out = (C.c_ulonglong * (2 * N))()
+assert rt.lib.rtx_debug_wave_times(out, N, 0) == 0
+a = np.frombuffer(out, dtype=np.uint64).reshape(N, 2).astype(np.int64)
+a = a[a[:, 1] > 0]
+t0, t1 = a[:, 0].min(), a[:, 1].max()
+span = (t1 - t0) / 100.0                                    # microseconds (100 MHz)
+life = (a[:, 1] - a[:, 0]) / 100.0
+ev = np.concatenate([np.stack([a[:, 0], np.ones(len(a), np.int64)], 1), np.stack([a[:, 1], -np.ones(len(a), np.int64)], 1)])
+ev = ev[np.argsort(ev[:, 0], kind="stable")]
+live = np.cumsum(ev[:, 1]); tt = (ev[:, 0] - t0) / 100.0
+peak = live.max()
+area = float(np.sum(live[:-1] * np.diff(tt)))
+print(f"{kind}: {len(a)} waves, launch span {span:.0f} us, wave lifetime median {np.median(life):.0f} us (p5 {np.percentile(life, 5):.0f}, p95 {np.percentile(life, 95):.0f}), peak live waves {peak}")
+print(f"  wave-time / (span x peak) = {area / (span * peak):.3f}   (1 = the machine holds its peak number of waves from the first to the last microsecond)")
+grid = np.linspace(0, span, 21)
+idx = np.searchsorted(tt, grid, side="right") - 1
+print("  live waves at 0 %, 5 %, ... 100 % of the span: " + " ".join(str(int(live[max(i, 0)])) for i in idx))
+below = tt[np.where(live < 0.9 * peak)[0]]
+tail = below[below > 0.5 * span]
+print(f"  first time after mid-launch with fewer than 90 % of the peak: {tail.min():.0f} us ({tail.min() / span:.1%} of the span)" if len(tail) else "  never below 90 % after mid-launch")
+c.close()
