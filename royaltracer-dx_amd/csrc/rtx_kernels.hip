@@ -159,9 +159,8 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevSc
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_head;
 #ifdef RTX_WAVE_CLOCK
-    struct WaveClock { bool on; unsigned long long t0; uint32_t w;
-        __device__ ~WaveClock() { if (on && lane_id() == 0 && w < 65536u) { g_wgt[2u * w] = t0; g_wgt[2u * w + 1u] = __builtin_amdgcn_s_memrealtime(); } } };
-    WaveClock wclk{tmin != kTMinCam, __builtin_amdgcn_s_memrealtime(), blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6)};
+    #define RTX_WAVE_STAMP(K) do { const uint32_t w_ = blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6); if (tmin != kTMinCam && lane_id() == 0 && w_ < 65536u) g_wgt[2u * w_ + (K)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    RTX_WAVE_STAMP(0u);
 #endif
     MergedQ M; M.init(qcount, nq, merge);
     const uint32_t n = M.n;
@@ -198,6 +197,9 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevSc
         else { walk_internal<false>(sc, L, R, stk); process_leaf<false>(sc, L, R, stk); }
         if (R.has && R.done) { st_stream(p.hit + R.item, F4{R.bt, R.bu, R.bv, u2f(R.bprim)}); R.has = false; }
     }
+#ifdef RTX_WAVE_CLOCK
+    RTX_WAVE_STAMP(1u);
+#endif
 }
 
 // any-hit for NEE slot j: visible contributions are added to the path's radiance (a path appears at most once

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""How full the machine is over ONE launch of the persistent closest-hit kernel (tooling build: make -C royaltracer-dx_amd VARIANT=wclk VARFLAGS=-DRTX_WAVE_CLOCK): every wave records its start and end
+"""How full the machine is over ONE launch of the persistent closest-hit kernel (tooling build: make -C royaltracer-dx_amd VARIANT=wclk VARFLAGS="-DRTX_WAVE_CLOCK -DRTX_TRACE_WAVES=8" (the cap keeps the stamped kernel at the 64 VGPRs / 8 waves per SIMD of the product build)): every wave records its start and end
 (s_memrealtime); the tool renders 1080p 16 spp with TWO bounces, so the recorded launch is bounce 1 (31 M incoherent rays), and prints the number of live waves over time.
 usage: python tools/wave_timeline.py [sponza|bistro] [option_id=value ...]"""
 import ctypes as C, os, sys
