@@ -123,8 +123,9 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
                                         finished its phase keeps its SIMD slot while it waits for the slowest wave of its workgroup, and the kernel needs 86 VGPRs where the
                                         traversal kernels need 75), so the default is 0.  Needs RTX_OPT_TRACE_SCHED 5-7 */
        RTX_OPT_LPT_ORDER = 13,       /* tuning: 1 (default) = the fused tiny-scene kernels take their sub-queues longest first (shorter launch tails), 0 = in index order */
-       RTX_OPT_TAPER = 25,           /* general scenes: 1 (default) = the sub-queues of a batch get shorter towards the end of the dispatch order (weights 8 | 4 | 2 | 1 over the
-                                        index ranges G/2 | G/4 | G/8 | G/8), so that the last workgroups of every launch are short ones; 0 = equal sub-queues.  Never changes a result */
+       RTX_OPT_TAPER = 25,           /* 1 (default) = the sub-queues of a batch get shorter towards the end of the dispatch order (weights 8 | 4 | 2 | 1 over the
+                                        index ranges G/2 | G/4 | G/8 | G/8), so that the last workgroups of every launch are short ones; 0 = equal sub-queues; 2-8 = that many weight classes.
+                                        Never changes a result */
        RTX_OPT_MERGE_RAYS = 24,      /* tuning, general scenes: a launch of the persistent traversal kernels that is predicted (from the previous rtx_render's counters) to hold fewer than
                                         this many rays per sub-queue gives each workgroup 2 / 4 / 8 consecutive sub-queues, down to one round of resident workgroups (the late bounces of
                                         a frame, after Russian roulette).  Default 1024; 0 = one sub-queue per workgroup always.  Never changes a result */

@@ -109,7 +109,13 @@ __global__ __launch_bounds__(kBlock) void k_raygen_trace_small(DevScene sc, cons
     uint32_t* myq = queue + (size_t)blockIdx.x * f.qcap;
     const uint32_t nchunks = f.chunks_per_sample * f.batch_spp;
     uint32_t generated = 0;
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (uint32_t k = 0, row0 = 0; row0 < nchunks; k++) {                                  // the deal of k_raygen: even, or tapered rows (taper_row_width)
+        const uint32_t nk = f.taper_levels ? taper_row_width(k, gridDim.x, f.taper_levels) : gridDim.x;
+        uint32_t pos = blockIdx.x;
+        if (f.taper_levels && blockIdx.x < nk) { pos += (k * 2654435761u) % nk; if (pos >= nk) pos -= nk; }
+        const uint32_t c = row0 + pos;
+        row0 += nk;
+        if (blockIdx.x >= nk || c >= nchunks) continue;                                   // wave-uniform
         const uint32_t sl = c / f.chunks_per_sample, cl = c - sl * f.chunks_per_sample;
         const uint32_t pl = cl * kBlock + threadIdx.x;
         const uint32_t pid = sl * f.npl + pl;

@@ -1188,6 +1188,10 @@ def test_full_size_headline_frame_is_bit_identical(rt, orc, cornell):
     oa, oc = o.render(p)
     c = rt.Context(0); c.upload(cornell, W / H)
     c.clear(W, H); c.render(p); st = c.stats(); im = c.read_accum()
+    for taper in (0, 6):                                    # the default deal is tapered (RTX_OPT_TAPER): equal sub-queues and a steeper taper give the same frame
+        c.set_option(rt.OPT_TAPER, taper); c.clear(W, H); c.render(p); s2 = c.stats()
+        assert (s2.rays_primary, s2.rays_extension, s2.rays_shadow) == oc, taper
+        assert np.array_equal(bits(c.read_accum()), bits(im)), taper
     c.close()
     assert (st.rays_primary, st.rays_extension, st.rays_shadow) == oc
     assert oc[0] == W * H * 64 and sum(oc) > 5.4e8
