@@ -466,6 +466,10 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
     DevFrame f = f_in;
     f.flags = LAMBERT ? (f_in.flags | 1u) : (f_in.flags & ~1u);      // bit 0 known at compile time
     const uint32_t qid = order ? order[blockIdx.x] : blockIdx.x;      // the sub-queue this workgroup owns (input and output)
+#ifdef RTX_WAVE_CLOCK        // tooling build: wave start / end stamps of the launch of bounces >= 1 (tools/wave_timeline.py cornell)
+    #define RTX_WAVE_STAMP_B(K) do { const uint32_t w_ = blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6); if (!HAVE_HIT && lane_id() == 0 && w_ < 65536u) g_wgt[2u * w_ + (K)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    RTX_WAVE_STAMP_B(0u);
+#endif
     // NEE shadow rays of the workgroup's 256 current items are compacted through LDS, so that the shadow traversal runs on
     // ceil(rays / 64) full waves instead of on every wave at ~2/3 occupancy (only ~65 % of the items get a shadow ray)
     __shared__ F4 s_sho[kBlock], s_shd[kBlock];
@@ -618,6 +622,9 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_bounce_small(DevScene sc, con
     __syncthreads();
     }
     PF_FLUSH;
+#ifdef RTX_WAVE_CLOCK
+    RTX_WAVE_STAMP_B(1u);
+#endif
 }
 
 // Fused bounce kernel of the GENERAL (BVH) path: for its private sub-queue a workgroup runs, bounce after bounce in ONE launch,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How full the machine is over ONE launch of the persistent closest-hit kernel (tooling build: make -C royaltracer-dx_amd VARIANT=wclk VARFLAGS="-DRTX_WAVE_CLOCK -DRTX_TRACE_WAVES=8" (the cap keeps the stamped kernel at the 64 VGPRs / 8 waves per SIMD of the product build)): every wave records its start and end
 (s_memrealtime); the tool renders 1080p 16 spp with TWO bounces, so the recorded launch is bounce 1 (31 M incoherent rays), and prints the number of live waves over time.
-usage: python tools/wave_timeline.py [sponza|bistro] [option_id=value ...]"""
+usage: python tools/wave_timeline.py [sponza|bistro|cornell] [option_id=value ...]     (cornell: the fused tiny-scene kernel of bounces 1-7 of the headline frame)"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["RTX_LIB_PATH"] = os.environ.get("RTX_LIB_PATH") or os.path.join(ROOT, "royaltracer-dx_amd", "librtx_hip_wclk.so")
@@ -10,8 +10,8 @@ import numpy as np
 import torch  # noqa
 import __graft_entry__ as graft
 rt = graft.load_package()
-kind = next((a for a in sys.argv[1:] if a in ("sponza", "bistro")), "sponza")
-sc = rt.Scene.sponza_class() if kind == "sponza" else rt.Scene.bistro_class()
+kind = next((a for a in sys.argv[1:] if a in ("sponza", "bistro", "cornell")), "sponza")
+sc = {"sponza": rt.Scene.sponza_class, "bistro": rt.Scene.bistro_class, "cornell": rt.Scene.cornell}[kind]()
 W, H = 1920, 1080
 c = rt.Context(0)
 for a in sys.argv[1:]:
@@ -19,6 +19,8 @@ for a in sys.argv[1:]:
         c.set_option(int(a.split("=")[0]), int(a.split("=")[1]))
 c.upload(sc, W / H); c.clear(W, H)
 p = rt.Params(width=W, height=H, spp=16, max_bounces=2, nee_samples=1, flags=1 if kind == "sponza" else 4)
+if kind == "cornell":            # the headline frame: the stamped launch is the fused kernel of bounces 1-7 (up to 10 240 workgroups = 40 960 waves)
+    p = rt.Params(width=W, height=H, spp=64, max_bounces=8, nee_samples=1, rr_start=3, flags=1)
 rt.lib.rtx_debug_wave_times.argtypes = [C.POINTER(C.c_ulonglong), C.c_uint, C.c_int]
 c.render(p)
 assert rt.lib.rtx_debug_wave_times(None, 0, 1) == 0
