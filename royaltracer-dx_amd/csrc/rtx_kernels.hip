@@ -218,6 +218,10 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_shadow(DevSce
                                                          uint32_t nq, uint32_t merge, const uint32_t* __restrict__ pay = nullptr, uint8_t* __restrict__ occ = nullptr) {
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_head;
+#ifdef RTX_WAVE_CLOCK        // tooling build: the FIRST any-hit launch after a reset (bounce 0's shadow rays, which overlap the stamped closest-hit launch of bounce 1), waves 32768 ...
+    #define RTX_WAVE_STAMP_S(K) do { const uint32_t w_ = 32768u + blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6); if (!SINK && lane_id() == 0 && w_ < 65536u && g_wgt[2u * w_ + (K)] == 0ull) g_wgt[2u * w_ + (K)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    RTX_WAVE_STAMP_S(0u);
+#endif
     MergedQ M; M.init(shcount, nq, merge);
     const uint32_t n = M.n;
     if (STEAL ? all_exhausted(heads, gridDim.x) : n == 0) return;
@@ -263,6 +267,9 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_shadow(DevSce
         else { walk_internal<true>(sc, L, R, stk); process_leaf<true>(sc, L, R, stk); }
         if (R.has && R.done) { finish(R.item, R.bprim != kMissPrim); R.has = false; }
     }
+#ifdef RTX_WAVE_CLOCK
+    RTX_WAVE_STAMP_S(1u);
+#endif
 }
 
 // shade: one thread per queued path (general path: hits come from k_trace_closest, shadow rays go to queues).

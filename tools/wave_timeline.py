@@ -29,6 +29,8 @@ N = 65536
 out = (C.c_ulonglong * (2 * N))()
 assert rt.lib.rtx_debug_wave_times(out, N, 0) == 0
 a = np.frombuffer(out, dtype=np.uint64).reshape(N, 2).astype(np.int64)
+sh = a[32768:][(a[32768:, 1] > 0) & (a[32768:, 0] > 0)] if kind != "cornell" else a[:0]      # general path: the any-hit launch of bounce 0 (overlaps the stamped closest-hit launch)
+a = a[:32768] if kind != "cornell" else a
 a = a[a[:, 1] > 0]
 t0, t1 = a[:, 0].min(), a[:, 1].max()
 span = (t1 - t0) / 100.0                                    # microseconds (100 MHz)
@@ -46,4 +48,14 @@ print("  live waves at 0 %, 5 %, ... 100 % of the span: " + " ".join(str(int(liv
 below = tt[np.where(live < 0.9 * peak)[0]]
 tail = below[below > 0.5 * span]
 print(f"  first time after mid-launch with fewer than 90 % of the peak: {tail.min():.0f} us ({tail.min() / span:.1%} of the span)" if len(tail) else "  never below 90 % after mid-launch")
+if len(sh):
+    s0, s1 = sh[:, 0].min(), sh[:, 1].max()
+    both = np.concatenate([a, sh])
+    ev2 = np.concatenate([np.stack([both[:, 0], np.ones(len(both), np.int64)], 1), np.stack([both[:, 1], -np.ones(len(both), np.int64)], 1)])
+    ev2 = ev2[np.argsort(ev2[:, 0], kind="stable")]
+    live2 = np.cumsum(ev2[:, 1]); b0, b1 = both[:, 0].min(), both[:, 1].max(); tt2 = (ev2[:, 0] - b0) / 100.0
+    sp2 = (b1 - b0) / 100.0
+    idx2 = np.searchsorted(tt2, np.linspace(0, sp2, 21), side="right") - 1
+    print(f"  any-hit launch of bounce 0: {len(sh)} waves, from {(s0 - t0) / 100.0:.0f} to {(s1 - t0) / 100.0:.0f} us on the closest-hit launch's clock")
+    print(f"  BOTH launches: span {sp2:.0f} us, wave-time / (span x {live2.max()}) = {float(np.sum(live2[:-1] * np.diff(tt2))) / (sp2 * live2.max()):.3f}; live waves at 0 %, 5 %, ...: " + " ".join(str(int(live2[max(i, 0)])) for i in idx2))
 c.close()
