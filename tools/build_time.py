@@ -1,3 +1,4 @@
+"""Scene generation and commit (BVH build) times of the two large procedural scenes on the GPU box: python tools/build_time.py"""
 import sys, time, os
 sys.path.insert(0, '/root/repo')
 os.chdir(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
