@@ -1305,6 +1305,29 @@ def test_measured_and_rejected_knob_kernels_stay_bit_identical(rt, orc, golden_d
         c.close()
 
 
+def test_tapered_subqueues_are_result_neutral(rt, orc, golden_dir, cornell):
+    """RTX_OPT_TAPER at a size the oracle renders in seconds: 640 x 360 x 4 spp with ONE sub-queue per CU (256 sub-queues of 14 chunks on average, so that the tapered deal is
+    active: it needs >= 4 chunks per sub-queue), in one batch and in two (RTX_OPT_PATHS_PER_BATCH), on the reference's garage scene (general path) and on Cornell (fused
+    tiny-scene kernels, which take the sub-queues longest first): equal sub-queues, the default taper and the steepest one give the oracle's image bit for bit"""
+    garage = rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")
+    W, H = 640, 360
+    for sc, flags in ((garage, 0), (cornell, 1)):
+        p = rt.Params(width=W, height=H, spp=4, max_bounces=6, nee_samples=1, rr_start=2, flags=flags, frame_seed=9)
+        o = orc.Oracle().load(sc, W / H); o.set_threads(_host_threads())
+        oa, oc = o.render(p)
+        for batch_paths in (0, W * H * 2):
+            c = rt.Context(0); c.set_option(rt.OPT_BLOCKS_PER_CU, 1)
+            if batch_paths:
+                c.set_option(rt.OPT_PATHS_PER_BATCH, batch_paths)
+            c.upload(sc, W / H)
+            for taper in (0, 1, 8):
+                c.set_option(rt.OPT_TAPER, taper)
+                c.clear(W, H); c.render(p); st = c.stats()
+                assert (st.rays_primary, st.rays_extension, st.rays_shadow) == oc, (flags, batch_paths, taper)
+                assert np.array_equal(bits(c.read_accum()), bits(oa)), (flags, batch_paths, taper)
+            c.close()
+
+
 def test_merged_subqueues_of_thin_launches_are_result_neutral(rt, orc, golden_dir):
     """RTX_OPT_MERGE_RAYS: a workgroup of the persistent traversal kernels takes several consecutive sub-queues when the previous call's counters predict a thin launch.
     garage.obj + monke.obj at 640 x 360 x 8 spp with 64 sub-queues per CU (7 200 sub-queues: two per workgroup is the most one round of resident workgroups allows):
