@@ -129,6 +129,13 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
        RTX_OPT_MERGE_RAYS = 24,      /* tuning, general scenes: a launch of the persistent traversal kernels that is predicted (from the previous rtx_render's counters) to hold fewer than
                                         this many rays per sub-queue gives each workgroup 2 / 4 / 8 consecutive sub-queues, down to one round of resident workgroups (the late bounces of
                                         a frame, after Russian roulette).  Default 1024; 0 = one sub-queue per workgroup always.  Never changes a result */
+       RTX_OPT_BVH_REINSERT = 26,    /* BVH builder: passes of the insertion-based topology optimisation after the top-down SAH build (Bittner et al. 2013; default see DESIGN.md section 6c).
+                                        Changes the tree, never a result; the next rtx_commit_scene rebuilds */
+       RTX_OPT_BVH_SPLIT = 27,       /* BVH builder: spatial splits (Stich et al. 2009) where an object split leaves its two sides overlapping by more than value * 1e-9 of the scene's surface
+                                        area; 0 (default) = never.  A split triangle is referenced from several leaves; closest hit = minimum over all triangles and any hit = existence,
+                                        so no result changes.  The next rtx_commit_scene rebuilds */
+       RTX_OPT_ANYHIT_ORDER = 28,    /* any-hit (shadow / visibility) rays visit the hit children of a node in 0 = slot order, 1 = nearest octant first, 2 = farthest octant first;
+                                        -1 (default) = what a commit-time probe of 2 048 NEE-like segments on the host found cheapest for this scene and its lights.  Never changes a result */
        RTX_OPT_BLOCKS_PER_CU = 12    /* tuning: workgroups (= private sub-queues) per compute unit; default 0 = auto: 40 (tiny scenes) / 32 at full frame size (8 measured 4-7 % slower there: tail imbalance), fewer — down to 8 — when a batch is so
                                         small (a shard) that a sub-queue would start with fewer than ~16 / ~8 chunks of 256 paths */ };
 

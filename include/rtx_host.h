@@ -70,6 +70,10 @@ int  rtxh_bvh_check(const float* world_tris9, uint32_t ntris, uint32_t* nodes_ou
 int  rtxh_bvh8_check(const float* world_tris9, uint32_t ntris, uint32_t* nodes8_out, uint32_t* stack_out);
 /* shape of that tree: hist[0..4] = leaf slots with 0 (unused) / 1 / 2 / 3 / 4 triangles, hist[5] = internal child slots */
 int  rtxh_bvh8_stats(const float* world_tris9, uint32_t ntris, uint32_t hist[6], uint32_t* nodes8_out);
+/* builder knobs of the checks above and of every context created afterwards (process-wide defaults; csrc/rtx_scene_host.hpp BvhBuildOptions): "bins", "sweep",
+   "leaf_stop", "split" (spatial splits, overlap threshold as a fraction of the scene's surface area), "split_budget", "reinsert" (passes), "reinsert_frac", "slot_assign",
+   "tri_cost".  Returns 0, or RTX_ERR_INVALID for an unknown key */
+int  rtxh_bvh_option(const char* key, double value);
 /* same invariants after building on `before` and REFITTING (topology kept) to `after` (TLAS refit, Renderer.cpp:594) */
 int  rtxh_bvh_refit_check(const float* before_tris9, const float* after_tris9, uint32_t ntris);
 

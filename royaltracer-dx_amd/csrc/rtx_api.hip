@@ -45,6 +45,7 @@ struct rtx_ctx {
     float view[16], proj[16];
     // path state
     DevBuf d_hitmask, d_order, d_pmask;
+    int any_order_opt = -1;         // RTX_OPT_ANYHIT_ORDER: -1 = what the commit-time probe chose (BuiltScene::any_order)
     bool lpt_order = true;          // RTX_OPT_LPT_ORDER: fused kernels take their sub-queues longest first
     // ReSTIR work lists (x | y << 16 per pixel, 8 x 8 pixel blocks in MORTON order so that consecutive chunks are compact screen regions): the shard's own pixels
     // (pass 3) and — on shards — its tiles dilated by the 20-px radius of the spatial pass (passes 1 and 2); key = (width, height, tile, rank, count, deal)
@@ -151,6 +152,9 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     if (!c) return RTX_ERR_INVALID;
     switch (option) {
     case RTX_OPT_KERNEL_TIMING: c->timing = value != 0; return RTX_OK;
+    case RTX_OPT_BVH_REINSERT: if (value < 0 || value > 16) { c->err = "bvh_reinsert must be in [0, 16]"; return RTX_ERR_INVALID; } c->host.bvh.reinsert_passes = (int)value; c->host.topo_dirty = true; c->committed = false; return RTX_OK;
+    case RTX_OPT_BVH_SPLIT: if (value < 0 || value > 1000000000) { c->err = "bvh_split must be in [0, 1e9] (parts per billion of the scene's surface area)"; return RTX_ERR_INVALID; } c->host.bvh.split_alpha = (double)value * 1e-9; c->host.topo_dirty = true; c->committed = false; return RTX_OK;
+    case RTX_OPT_ANYHIT_ORDER: if (value < -1 || value > 2) { c->err = "anyhit_order must be -1 (probe), 0, 1 or 2"; return RTX_ERR_INVALID; } c->any_order_opt = (int)value; if (c->committed) c->dsc.any_order = value < 0 ? c->built.any_order : (uint32_t)value; return RTX_OK;
     case RTX_OPT_PATHS_PER_BATCH: if (value < 4096) { c->err = "paths_per_batch must be >= 4096"; return RTX_ERR_INVALID; } c->paths_per_batch = (uint64_t)value; return RTX_OK;
     case RTX_OPT_SORT_MATERIALS: c->sort_materials = value != 0; c->dsc.sort_materials = c->sort_materials; return RTX_OK;
     case RTX_OPT_LDS_NODES: c->lds_nodes_opt = (int)value; c->committed = false; return RTX_OK;
@@ -317,6 +321,7 @@ static int finalise_scene(rtx_ctx* c) {
     uint32_t want_tris = s.ntris <= 256 ? s.ntris : 0u;                    // triangles only when ALL of them fit
     s.lds_tris = (size_t)want_tris * 48 <= budget ? want_tris : 0u;
     s.nsmall = 0; s.nsmall_occ = 0;
+    s.any_order = c->any_order_opt < 0 ? B.any_order : (uint32_t)c->any_order_opt;
     s.refill_min = c->refill_min; s.trace_sched = c->trace_sched; s.sort_materials = c->sort_materials; s.occluder_cache = c->occluder_cache; s.shade_dense = c->shade_dense > 0 ? 1u : 0u;
     if (c->small_scene && B.small_nrec && B.small_tris.size() * 48 <= budget + (size_t)s.lds_tris * 48) {
         s.nsmall = B.small_nrec; s.nsmall_occ = B.small_nocc; s.lds_tris = (uint32_t)B.small_tris.size();   // LDS holds the records' triangles instead of the leaf-ordered ones
@@ -1076,12 +1081,15 @@ int rtx_debug_validate_bvh(rtx_ctx* c) {
     if (!nodes.empty()) HIPCHK(c, hipMemcpyAsync(nodes.data(), c->d_nodes.p, nodes.size() * sizeof(Node8GPU), hipMemcpyDeviceToHost, c->stream));
     if (!tris.empty()) HIPCHK(c, hipMemcpyAsync(tris.data(), c->d_tris.p, tris.size() * sizeof(TriGPU), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::vector<float> w(tris.size() * 9); std::vector<uint32_t> ident(tris.size());
-    for (size_t i = 0; i < tris.size(); i++) {                 // the triangle the kernels intersect: (v0, v0 + e1, v0 + e2)
-        const TriGPU& T = tris[i]; float* o = &w[i * 9]; ident[i] = (uint32_t)i;
+    // the triangle the kernels intersect: (v0, v0 + e1, v0 + e2), filed under its global id (v0.w): a spatial split references a triangle from several leaf entries
+    uint32_t ng = 0;
+    for (const TriGPU& T : tris) ng = std::max(ng, f2u(T.v0.w) + 1u);
+    std::vector<float> w((size_t)ng * 9, 0.0f); std::vector<uint32_t> ident(tris.size()), gid(tris.size());
+    for (size_t i = 0; i < tris.size(); i++) {
+        const TriGPU& T = tris[i]; ident[i] = (uint32_t)i; gid[i] = f2u(T.v0.w); float* o = &w[(size_t)gid[i] * 9];
         o[0] = T.v0.x; o[1] = T.v0.y; o[2] = T.v0.z; o[3] = T.v0.x + T.e1.x; o[4] = T.v0.y + T.e1.y; o[5] = T.v0.z + T.e1.z; o[6] = T.v0.x + T.e2.x; o[7] = T.v0.y + T.e2.y; o[8] = T.v0.z + T.e2.z;
     }
-    return validate_bvh8(w, nodes, ident, ident, nullptr);
+    return validate_bvh8(w, nodes, gid, ident, nullptr);
 }
 int rtx_debug_trace_stats(rtx_ctx* c, const float* rays8, uint32_t n, float* stats4) { return dbg_trace(c, rays8, n, 2, stats4, nullptr); }
 

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_shadow(DevSce
     auto fetch = [&](uint32_t q, uint32_t idx) {
         const uint32_t gi = q * qcap + idx;                               // (< 2^32: the batch cap)
         const F4 so = sh_o[gi], sd = sh_d[gi];
-        ray_begin(R, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, gi, false, sc.occluder_cache != 0u);
+        ray_begin(R, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, sd.w, gi, false, sc.occluder_cache != 0u, sc.any_order);
     };
     while (STEAL ? refill_steal<false>(R, W, drained, refill_min, rng, fetch) : refill<false>(R, &s_head, n, drained, refill_min, [&](uint32_t idx) { uint32_t q, off; M.locate(idx, q, off); fetch(q, off); })) {
         if (SCHED >= 5) spec_step<true>(sc, L, R, stk, (uint32_t)SCHED);
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_bounce_bvh(DevScene sc, DevFrame 
                 bool drained = false;
                 while (refill<false>(R, &s_head, ns, drained, sc.refill_min, [&](uint32_t idx) {
                            const F4 so = p.sh_o[sb + idx], sd = p.sh_d[sb + idx];
-                           ray_begin(R, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), fabsf(so.w), sd.w, idx, false);
+                           ray_begin(R, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), fabsf(so.w), sd.w, idx, false, false, sc.any_order);
                        })) {
                     spec_step<true>(sc, L, R, stk, sc.trace_sched);
                     if (R.has && R.done) {

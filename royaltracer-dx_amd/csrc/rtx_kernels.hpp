@@ -26,6 +26,7 @@ struct DevScene {
     uint32_t sort_materials;        // 1 = material-sorted shading in k_shade (general path; tuning knob, default 0)
     uint32_t refill_min, trace_sched;   // persistent traversal: idle lanes that trigger a refill; wave schedule (rtx_kernels.hip)
     uint32_t shade_dense;               // general path: k_shade compacts the hits of its sub-queue through an LDS ring before shading them (k_shade_dense)
+    uint32_t any_order;                 // any-hit rays: visiting order of a node's hit children, 0 slot order / 1 nearest octant first / 2 farthest first (rtx_traverse.hpp: node8_hits)
     uint32_t occluder_cache;            // any-hit rays: a lane tests the triangle that occluded its previous ray first (rtx_traverse.hpp: ray_begin)
 };
 

@@ -200,10 +200,11 @@ static bool load_scene_cache_impl(const char* path, SceneHost& H, BuiltScene& B,
     // consistency of what was read (indices stay inside their arrays: the kernels and the refit trust these)
     const size_t nt = Bn.shade.size(), nmat = Hn.mats128.size() / 32;
     const size_t nrec_pad = ((size_t)sc.small_nrec + 1) & ~(size_t)1;      // records are stored in pairs (rtx_scene_host.cpp)
-    bool ok = Bn.tris8.size() == nt && Bn.tri_slots8.size() == nt && Bn.mats.size() == nmat && Bn.insts.size() == Hn.insts.size() && Bn.lights80.size() == Bn.lights.size() * 20 &&
+    const size_t nrefs = Bn.tris8.size();                                      // leaf entries: the triangle count, plus the references spatial splits added
+    bool ok = nrefs >= nt && Bn.tri_slots8.size() == nrefs && Bn.mats.size() == nmat && Bn.insts.size() == Hn.insts.size() && Bn.lights80.size() == Bn.lights.size() * 20 &&
               Hn.mats128.size() % 32 == 0 && (Bn.nodes8.empty() || Bn.level_start8.size() >= 2) && sc.small_nocc <= sc.small_nrec && sc.small_nrec <= kSmallSceneMaxTris &&
               Bn.small_recs.size() * 2 >= nrec_pad && (sc.small_nrec == 0 || (Bn.small_tris.size() >= nrec_pad * 2 && Bn.small_poly.size() >= nrec_pad * 4)) &&
-              nt < (1u << 31);
+              nrefs < (1u << 31);
     for (uint32_t id : Hn.matids) ok = ok && id < nmat;                       // (what rtx_commit_scene checks before a build)
     for (const MeshHost& m : Hn.meshes) {
         ok = ok && m.verts.size() % 7 == 0 && m.idx.size() % 3 == 0 && (size_t)m.matid_base + m.idx.size() <= Hn.matids.size();
@@ -216,14 +217,15 @@ static bool load_scene_cache_impl(const char* path, SceneHost& H, BuiltScene& B,
         if (ok) tri_at += Hn.meshes[in.mesh].idx.size() / 3;
     }
     ok = ok && tri_at == nt;
-    for (size_t i = 0; ok && i < nt; i++) ok = Bn.shade[i].inst < Bn.insts.size() && f2u(Bn.tris8[i].v0.w) < nt && Bn.tri_slots8[i] < nt;
+    for (size_t i = 0; ok && i < nt; i++) ok = Bn.shade[i].inst < Bn.insts.size();
+    for (size_t i = 0; ok && i < nrefs; i++) ok = f2u(Bn.tris8[i].v0.w) < nt && Bn.tri_slots8[i] < nrefs;
     for (size_t i = 0; ok && i < Bn.small_tris.size(); i++) { const uint32_t g = f2u(Bn.small_tris[i].v0.w); ok = g < nt || g == kMissPrim; }
     for (size_t i = 0; ok && i < Bn.lights.size(); i++) ok = f2u(Bn.lights80[i * 20 + 7]) < Bn.insts.size();     // LightTriangle::instanceID (Renderer.h:113-124)
     for (size_t i = 0; ok && i < Bn.nodes8.size(); i++) {
         const Node8GPU& N = Bn.nodes8[i];
         const uint32_t ninternal = (uint32_t)__builtin_popcount(N.e_imask >> 24);
         uint32_t ntri = 0; for (int sl = 0; sl < 8; sl++) ntri += (uint32_t)__builtin_popcount((N.trivalid >> (4 * sl)) & 0xfu);
-        ok = (ninternal == 0 || ((size_t)N.child_base + ninternal <= Bn.nodes8.size() && N.child_base > i)) && (size_t)N.tri_base + ntri <= nt;
+        ok = (ninternal == 0 || ((size_t)N.child_base + ninternal <= Bn.nodes8.size() && N.child_base > i)) && (size_t)N.tri_base + ntri <= nrefs;
     }
     if (!ok) { err = "scene cache: inconsistent contents"; return false; }
     // The traversal stack depth and the breadth-first levels are RE-DERIVED from the nodes (collapse_bvh8's two sweeps; children have larger indices, checked
@@ -252,6 +254,7 @@ static bool load_scene_cache_impl(const char* path, SceneHost& H, BuiltScene& B,
     }
     Bn.stack8 = sc.stack8; Bn.small_nrec = sc.small_nrec; Bn.small_nocc = sc.small_nocc; Bn.max_depth = sc.max_depth; Bn.bvh_pad = sc.bvh_pad;
     Bn.small_cm = sc.small_cm; Bn.small_delta = sc.small_delta; Bn.small_hull_margin = sc.small_hull_margin; Bn.total_weight = sc.total_weight; Bn.refit_count = 0;
+    Bn.any_order = probe_anyhit_order(Bn);                                   // derived, like the stack depth: not taken from the file
     Hn.topo_dirty = false; Hn.mats_dirty = false;
     if (cam12) { if (!sc.has_cam) { err = "scene cache: the file holds no camera (written by rtx_save_scene_cache, not rtxh_scene_save)"; return false; } memcpy(cam12, sc.cam, sizeof(sc.cam)); }
     H = std::move(Hn); B = std::move(Bn);

@@ -6,6 +6,8 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <cstdio>
+#include <cstdlib>
 
 namespace rtx {
 
@@ -240,10 +242,10 @@ bool SceneHost::build(BuiltScene& B) {
     // ---- BVH: full binned-SAH build, or a REFIT when only instance transforms changed since the last build
     //      (the reference refits its TLAS every frame: Renderer.cpp:594, TopLevelASGenerator.cpp:149-250) ----
     std::vector<uint32_t>& leaf_order = B.leaf_order;
-    const bool refit = !topo_dirty && B.leaf_order.size() == (size_t)nt && !B.nodes.empty();
+    const bool refit = !topo_dirty && B.built_tris == nt && !B.leaf_order.empty() && !B.nodes.empty();
     const float bvh_pad = 2e-6f * scale; B.bvh_pad = bvh_pad;                  // absolute box padding (1e-5 measured 3 % slower; the relative margins kSlabLo / kSlabHi carry the triangle-test error)
     if (refit) refit_bvh(wtri, bvh_pad, B.nodes, leaf_order);
-    else build_bvh(wtri, bvh_pad, B.nodes, leaf_order, B.max_depth);
+    else { build_bvh(wtri, bvh_pad, B.nodes, leaf_order, B.max_depth, bvh); B.built_tris = nt; }
     B.refit_count = refit ? B.refit_count + 1 : 0;
     topo_dirty = false;
     B.tris.resize(leaf_order.size());
@@ -258,7 +260,7 @@ bool SceneHost::build(BuiltScene& B) {
         T.e2 = {e2.x, e2.y, e2.z, 0.0f};
     }
     // device traversal form: derived data, redone after a refit too (O(nodes))
-    if (!collapse_bvh8(B.nodes, B.nodes8, B.tri_slots8, B.stack8, &B.level_start8)) { err = "build: BVH collapse failed"; return false; }
+    if (!collapse_bvh8(B.nodes, B.nodes8, B.tri_slots8, B.stack8, &B.level_start8, bvh)) { err = "build: BVH collapse failed"; return false; }
     B.tris8.resize(B.tri_slots8.size());
     for (size_t i = 0; i < B.tri_slots8.size(); i++) B.tris8[i] = B.tris[B.tri_slots8[i]];
     // ---- tiny scenes: merge triangles into planar convex quads and build the conservative pre-test records ----
@@ -418,12 +420,46 @@ bool SceneHost::build(BuiltScene& B) {
             B.small_recs.push_back(P);
         }
     }
+    B.any_order = probe_anyhit_order(B);
     return true;
 }
 
 // ------------------------------------------------------------------------------------------------
 // binned SAH BVH2 (16 bins, leaves of <= 4 triangles unless a split is impossible, hard cap 8)
 // ------------------------------------------------------------------------------------------------
+BvhBuildOptions& bvh_build_options() {
+    static BvhBuildOptions o;
+    static bool env_read = false;
+    if (!env_read) {                                       // tooling: RTX_BVH="reinsert=2,split=1e-5" (A/B runs of one binary)
+        env_read = true;
+        if (const char* e = getenv("RTX_BVH")) {
+            std::string s = e; size_t at = 0;
+            while (at < s.size()) {
+                size_t end = s.find(',', at); if (end == std::string::npos) end = s.size();
+                const std::string kv = s.substr(at, end - at); const size_t eq = kv.find('=');
+                if (eq != std::string::npos && !bvh_build_option(o, kv.substr(0, eq).c_str(), atof(kv.c_str() + eq + 1))) fprintf(stderr, "[rtx] RTX_BVH: unknown key in '%s'\n", kv.c_str());
+                at = end + 1;
+            }
+        }
+    }
+    return o;
+}
+bool bvh_build_option(const char* key, double v) { return bvh_build_option(bvh_build_options(), key, v); }
+bool bvh_build_option(BvhBuildOptions& o, const char* key, double v) {
+    const std::string k = key ? key : "";
+    if (k == "bins") o.bins = (int)v;
+    else if (k == "sweep") o.sweep_below = (uint32_t)v;
+    else if (k == "tri_cost") o.tri_cost = v;
+    else if (k == "leaf_stop") o.leaf_stop = (uint32_t)v;
+    else if (k == "split") o.split_alpha = v;
+    else if (k == "slot_assign") o.slot_assign = (int)v;
+    else if (k == "split_budget") o.split_budget = v;
+    else if (k == "reinsert") o.reinsert_passes = (int)v;
+    else if (k == "reinsert_frac") o.reinsert_frac = v;
+    else return false;
+    return true;
+}
+
 namespace {
 struct Box { float mn[3], mx[3]; };
 inline Box empty_box() { Box b; for (int a = 0; a < 3; a++) { b.mn[a] = INFINITY; b.mx[a] = -INFINITY; } return b; }
@@ -465,85 +501,307 @@ void refit_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGP
     }
 }
 
-void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGPU>& nodes, std::vector<uint32_t>& order, uint32_t& max_depth) {
+// ---- the top-down builder works on REFERENCES (box, triangle): a spatial split (Stich, Friedrich, Dietrich, "Spatial Splits in Bounding Volume
+//      Hierarchies", HPG 2009) may hand a triangle to both sides of a plane, each side keeping the box of ITS part.  The closest hit is defined as
+//      the minimum over all triangles (ties: lowest id) and any hit as existence, so a triangle referenced from two leaves changes no result; what
+//      has to hold is COVERAGE: every point of a triangle lies in the box of one of its references and in every box above it.  Parts are clipped
+//      in double and their boxes rounded outward, so the pieces' boxes cover the triangle like the whole box did. ----
+namespace {
+struct Ref { Box box; uint32_t tri; };
+inline float f_below(float x) { return std::nextafterf(x, -INFINITY); }
+inline float f_above(float x) { return std::nextafterf(x, INFINITY); }
+inline Box intersect(const Box& a, const Box& b) { Box r; for (int k = 0; k < 3; k++) { r.mn[k] = std::max(a.mn[k], b.mn[k]); r.mx[k] = std::min(a.mx[k], b.mx[k]); } return r; }
+// parts of triangle t9 inside `in` on either side of the plane x[axis] = pos
+inline void split_ref(const float* t9, const Box& in, int axis, float pos, Box& L, Box& R) {
+    L = empty_box(); R = empty_box();
+    auto add = [](Box& b, const double* p, bool exact) {
+        for (int k = 0; k < 3; k++) {
+            const float f = (float)p[k];
+            const float lo = exact ? f : ((double)f > p[k] ? f_below(f) : f), hi = exact ? f : ((double)f < p[k] ? f_above(f) : f);
+            b.mn[k] = std::min(b.mn[k], exact ? f : f_below(lo)); b.mx[k] = std::max(b.mx[k], exact ? f : f_above(hi));
+        }
+    };
+    for (int e = 0; e < 3; e++) {
+        const float* a = t9 + 3 * e; const float* b = t9 + 3 * ((e + 1) % 3);
+        const double pa[3] = {a[0], a[1], a[2]};
+        if (a[axis] <= pos) add(L, pa, true);
+        if (a[axis] >= pos) add(R, pa, true);
+        if ((a[axis] < pos && b[axis] > pos) || (a[axis] > pos && b[axis] < pos)) {
+            const double t = std::min(1.0, std::max(0.0, ((double)pos - (double)a[axis]) / ((double)b[axis] - (double)a[axis])));
+            double p[3]; for (int k = 0; k < 3; k++) p[k] = (double)a[k] + t * ((double)b[k] - (double)a[k]);
+            p[axis] = pos;
+            add(L, p, false); add(R, p, false);
+        }
+    }
+    L.mx[axis] = std::min(L.mx[axis], pos); R.mn[axis] = std::max(R.mn[axis], pos);
+    L = intersect(L, in); R = intersect(R, in);
+    L.mx[axis] = std::max(L.mx[axis], L.mn[axis]); R.mx[axis] = std::max(R.mx[axis], R.mn[axis]);    // (a sliver part keeps a valid, zero-width box)
+}
+inline bool valid_box(const Box& b) { return b.mn[0] <= b.mx[0] && b.mn[1] <= b.mx[1] && b.mn[2] <= b.mx[2]; }
+
+// Insertion-based optimisation of the binary tree (Bittner, Hapala, Havran, "Fast Insertion-Based Optimization of Bounding Volume Hierarchies", CGF 2013; the
+// per-node search of Meister & Bittner, "Parallel Reinsertion for Bounding Volume Hierarchy Optimization", EG 2018): a subtree is cut out and put back where it
+// enlarges the fewest / smallest boxes (branch-and-bound over the induced surface-area cost).  Topology only: leaves and their references stay as they are.
+void reinsert_pass(std::vector<TmpNode>& tn, std::vector<int32_t>& parent, double frac) {
+    const size_t n = tn.size();
+    std::vector<uint32_t> cand; cand.reserve(n);
+    for (size_t i = 1; i < n; i++) if (parent[i] > 0) cand.push_back((uint32_t)i);                    // not the root, not a child of the root (the root stays node 0)
+    std::stable_sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) { return half_area(tn[a].box) > half_area(tn[b].box); });
+    cand.resize((size_t)((double)cand.size() * frac));
+    auto refit_up = [&](int32_t a) {
+        for (; a >= 0; a = parent[a]) {
+            Box b = tn[tn[a].left].box; grow(b, tn[tn[a].right].box);
+            if (!memcmp(&b, &tn[a].box, sizeof(Box))) break;
+            tn[a].box = b;
+        }
+    };
+    struct It { float bound; float induced; int32_t node; };
+    auto cmp = [](const It& a, const It& b) { return a.bound > b.bound; };
+    std::vector<It> pq;
+    for (uint32_t x : cand) {
+        const int32_t p = parent[x];
+        if (p <= 0) continue;                                   // (moves may have lifted x to the root's children)
+        const int32_t g = parent[p], s = tn[p].left == (int32_t)x ? tn[p].right : tn[p].left;
+        // cut x (and its parent node p) out
+        (tn[g].left == p ? tn[g].left : tn[g].right) = s; parent[s] = g;
+        refit_up(g);
+        const Box xb = tn[x].box; const float xa = half_area(xb);
+        float best = INFINITY; int32_t best_node = s;
+        pq.clear();
+        pq.push_back({0.0f, 0.0f, tn[0].left}); pq.push_back({0.0f, 0.0f, tn[0].right});
+        {   // the root's own enlargement is paid by every position alike: leave it out
+        }
+        std::make_heap(pq.begin(), pq.end(), cmp);
+        while (!pq.empty()) {
+            std::pop_heap(pq.begin(), pq.end(), cmp); const It it = pq.back(); pq.pop_back();
+            if (it.bound + xa >= best) break;
+            Box u = tn[it.node].box; grow(u, xb);
+            const float direct = half_area(u), total = it.induced + direct;
+            if (total < best) { best = total; best_node = it.node; }
+            if (!tn[it.node].count) {
+                const float ind = it.induced + direct - half_area(tn[it.node].box);
+                if (ind + xa < best) {
+                    pq.push_back({ind, ind, tn[it.node].left}); std::push_heap(pq.begin(), pq.end(), cmp);
+                    pq.push_back({ind, ind, tn[it.node].right}); std::push_heap(pq.begin(), pq.end(), cmp);
+                }
+            }
+        }
+        // put it back: p becomes the parent of (best_node, x) where best_node was
+        const int32_t gb = parent[best_node];
+        (tn[gb].left == best_node ? tn[gb].left : tn[gb].right) = p; parent[p] = gb;
+        tn[p].left = best_node; tn[p].right = (int32_t)x; parent[best_node] = p; parent[x] = p;
+        tn[p].box = tn[best_node].box; grow(tn[p].box, xb);
+        refit_up(gb);
+    }
+}
+}  // namespace
+
+void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGPU>& nodes, std::vector<uint32_t>& order, uint32_t& max_depth, const BvhBuildOptions& opt) {
     const uint32_t nt = (uint32_t)(wtri.size() / 9);
-    std::vector<Box> tb(nt); std::vector<float> cen((size_t)nt * 3);
+    std::vector<Ref> refs(nt);
+    Box scene = empty_box();
     for (uint32_t i = 0; i < nt; i++) {
         const float* t = &wtri[(size_t)i * 9];
         for (int a = 0; a < 3; a++) {
-            tb[i].mn[a] = std::min(t[a], std::min(t[3 + a], t[6 + a]));
-            tb[i].mx[a] = std::max(t[a], std::max(t[3 + a], t[6 + a]));
-            cen[(size_t)i * 3 + a] = 0.5f * (tb[i].mn[a] + tb[i].mx[a]);
+            refs[i].box.mn[a] = std::min(t[a], std::min(t[3 + a], t[6 + a]));
+            refs[i].box.mx[a] = std::max(t[a], std::max(t[3 + a], t[6 + a]));
         }
+        refs[i].tri = i;
+        grow(scene, refs[i].box);
     }
-    order.resize(nt);
-    std::iota(order.begin(), order.end(), 0u);
+    order.clear(); order.reserve(nt);
     std::vector<TmpNode> tn; tn.reserve((size_t)2 * nt + 2);
     max_depth = 0;
-    struct Job { int32_t node; uint32_t first, count, depth; };
+    // spatial splits only for scenes that take the BVH path (the tiny-scene records are built from the leaf order as a permutation of the triangles)
+    const bool spatial = opt.split_alpha > 0.0 && nt > kSmallSceneMaxTris;
+    const float spatial_min = (float)(opt.split_alpha * (double)half_area(scene));
+    const size_t ref_budget = (size_t)((double)nt * (1.0 + opt.split_budget)) + 8;
+    size_t refs_total = nt;                                                       // references handed out so far (leaves made + still on the stack)
+    struct Job { int32_t node; uint32_t count, depth; };
     std::vector<Job> st;
     tn.emplace_back();
-    st.push_back({0, 0u, nt, 0u});
-    constexpr int NB = 16;
+    st.push_back({0, nt, 0u});
+    constexpr int NB = 16, NS = 16;
+    std::vector<uint32_t> sweep_ids; std::vector<float> sweep_ra; std::vector<Ref> tmp;
+    auto cen = [](const Ref& r, int a) { return 0.5f * (r.box.mn[a] + r.box.mx[a]); };
     while (!st.empty()) {
-        Job j = st.back(); st.pop_back();
+        const Job j = st.back(); st.pop_back();
         max_depth = std::max(max_depth, j.depth);
+        Ref* R = refs.data() + (refs.size() - j.count);                              // this node's references: the top of the reference stack
         Box nb = empty_box(), cb = empty_box();
         for (uint32_t i = 0; i < j.count; i++) {
-            uint32_t g = order[j.first + i];
-            grow(nb, tb[g]);
-            for (int a = 0; a < 3; a++) { cb.mn[a] = std::min(cb.mn[a], cen[(size_t)g * 3 + a]); cb.mx[a] = std::max(cb.mx[a], cen[(size_t)g * 3 + a]); }
+            grow(nb, R[i].box);
+            for (int a = 0; a < 3; a++) { const float c = cen(R[i], a); cb.mn[a] = std::min(cb.mn[a], c); cb.mx[a] = std::max(cb.mx[a], c); }
         }
         tn[j.node].box = nb;
-        auto make_leaf = [&]() { tn[j.node].first = j.first; tn[j.node].count = j.count; };
-        if (j.count <= 2) { make_leaf(); continue; }
-        // best binned split over 3 axes
-        float best_cost = INFINITY; int best_axis = -1, best_bin = -1;
-        for (int a = 0; a < 3; a++) {
-            float lo = cb.mn[a], ext = cb.mx[a] - cb.mn[a];
-            if (!(ext > 0.0f)) continue;
-            Box bb[NB]; uint32_t bc[NB];
-            for (int b = 0; b < NB; b++) { bb[b] = empty_box(); bc[b] = 0; }
-            float k = (float)NB / ext;
-            for (uint32_t i = 0; i < j.count; i++) {
-                uint32_t g = order[j.first + i];
-                int b = (int)((cen[(size_t)g * 3 + a] - lo) * k); if (b >= NB) b = NB - 1; if (b < 0) b = 0;
-                grow(bb[b], tb[g]); bc[b]++;
+        auto make_leaf = [&]() {
+            tn[j.node].first = (uint32_t)order.size(); tn[j.node].count = j.count;
+            for (uint32_t i = 0; i < j.count; i++) order.push_back(R[i].tri);
+            refs.resize(refs.size() - j.count);
+        };
+        if (j.count <= opt.leaf_stop || j.depth >= 96u) {
+            if (j.count <= 4) { make_leaf(); continue; }
+        }
+        // ---- best object split over 3 axes: full sweep over the sorted centroids for small nodes, bins above ----
+        float best_cost = INFINITY, sweep_split = 0.0f; int best_axis = -1, best_bin = -1;
+        Box best_lb = empty_box(), best_rb = empty_box();
+        const bool sweep = j.count <= opt.sweep_below;
+        if (sweep) {
+            sweep_ids.resize(j.count); sweep_ra.resize(j.count);
+            for (int a = 0; a < 3; a++) {
+                if (!(cb.mx[a] - cb.mn[a] > 0.0f)) continue;
+                for (uint32_t i = 0; i < j.count; i++) sweep_ids[i] = i;
+                std::stable_sort(sweep_ids.begin(), sweep_ids.end(), [&](uint32_t x, uint32_t y) { return cen(R[x], a) < cen(R[y], a); });
+                Box acc = empty_box();
+                for (uint32_t i = j.count; i-- > 1;) { grow(acc, R[sweep_ids[i]].box); sweep_ra[i] = half_area(acc); }
+                acc = empty_box();
+                for (uint32_t i = 0; i + 1 < j.count; i++) {
+                    grow(acc, R[sweep_ids[i]].box);
+                    const float c0 = cen(R[sweep_ids[i]], a), c1 = cen(R[sweep_ids[i + 1]], a);
+                    if (c0 == c1) continue;                                          // equal centroids stay together (the partition is by value)
+                    const float cost = half_area(acc) * (float)(i + 1) + sweep_ra[i + 1] * (float)(j.count - i - 1);
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = (int)i; sweep_split = 0.5f * (c0 + c1); if (!(sweep_split > c0)) sweep_split = c1; }
+                }
             }
-            float ra[NB]; uint32_t rc[NB]; Box acc = empty_box(); uint32_t c = 0;
-            for (int b = NB - 1; b > 0; b--) { grow(acc, bb[b]); c += bc[b]; ra[b] = half_area(acc); rc[b] = c; }
-            acc = empty_box(); c = 0;
-            for (int b = 0; b < NB - 1; b++) {
-                grow(acc, bb[b]); c += bc[b];
-                if (!c || !rc[b + 1]) continue;
-                float cost = half_area(acc) * (float)c + ra[b + 1] * (float)rc[b + 1];
-                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+        } else {
+            for (int a = 0; a < 3; a++) {
+                const float lo = cb.mn[a], ext = cb.mx[a] - cb.mn[a];
+                if (!(ext > 0.0f)) continue;
+                Box bb[NB]; uint32_t bc[NB];
+                for (int b = 0; b < NB; b++) { bb[b] = empty_box(); bc[b] = 0; }
+                const float k = (float)NB / ext;
+                for (uint32_t i = 0; i < j.count; i++) {
+                    int b = (int)((cen(R[i], a) - lo) * k); if (b >= NB) b = NB - 1; if (b < 0) b = 0;
+                    grow(bb[b], R[i].box); bc[b]++;
+                }
+                float ra[NB]; uint32_t rc[NB]; Box rbx[NB]; Box acc = empty_box(); uint32_t c = 0;
+                for (int b = NB - 1; b > 0; b--) { grow(acc, bb[b]); c += bc[b]; ra[b] = half_area(acc); rc[b] = c; rbx[b] = acc; }
+                acc = empty_box(); c = 0;
+                for (int b = 0; b < NB - 1; b++) {
+                    grow(acc, bb[b]); c += bc[b];
+                    if (!c || !rc[b + 1]) continue;
+                    const float cost = half_area(acc) * (float)c + ra[b + 1] * (float)rc[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; best_lb = acc; best_rb = rbx[b + 1]; }
+                }
             }
         }
-        uint32_t mid = 0;
-        bool split = false;
-        if (best_axis >= 0) {
-            float leaf_cost = half_area(nb) * (float)j.count;
-            if (j.count > 4 || best_cost + half_area(nb) * 1.0f < leaf_cost) {
-                float lo = cb.mn[best_axis], k = (float)NB / (cb.mx[best_axis] - cb.mn[best_axis]);
-                auto it = std::partition(order.begin() + j.first, order.begin() + j.first + j.count, [&](uint32_t g) {
-                    int b = (int)((cen[(size_t)g * 3 + best_axis] - lo) * k); if (b >= NB) b = NB - 1; if (b < 0) b = 0;
-                    return b <= best_bin;
-                });
-                mid = (uint32_t)(it - (order.begin() + j.first));
-                split = mid > 0 && mid < j.count;
+        const float leaf_cost = half_area(nb) * (float)j.count;
+        // ---- spatial split candidate: only where the object split leaves the two sides overlapping (Stich et al., section 4.5) ----
+        float sp_cost = INFINITY, sp_pos = 0.0f; int sp_axis = -1;
+        if (spatial && j.count > 2 && refs_total < ref_budget) {
+            bool try_it = best_axis < 0;
+            if (!try_it) {
+                if (sweep) {                                                         // (the sweep kept no boxes: rebuild the two sides of its best split)
+                    best_lb = empty_box(); best_rb = empty_box();
+                    for (uint32_t i = 0; i < j.count; i++) grow(cen(R[i], best_axis) < sweep_split ? best_lb : best_rb, R[i].box);
+                }
+                const Box ov = intersect(best_lb, best_rb);
+                try_it = valid_box(ov) && half_area(ov) > spatial_min;
             }
+            if (try_it) {
+                for (int a = 0; a < 3; a++) {
+                    const float lo = nb.mn[a], ext = nb.mx[a] - nb.mn[a];
+                    if (!(ext > 0.0f)) continue;
+                    Box bb[NS]; uint32_t enter[NS], leave[NS];
+                    for (int b = 0; b < NS; b++) { bb[b] = empty_box(); enter[b] = leave[b] = 0; }
+                    const float k = (float)NS / ext;
+                    auto plane = [&](int b) { return lo + ext * ((float)b / (float)NS); };
+                    for (uint32_t i = 0; i < j.count; i++) {
+                        int b0 = (int)((R[i].box.mn[a] - lo) * k), b1 = (int)((R[i].box.mx[a] - lo) * k);
+                        b0 = std::min(NS - 1, std::max(0, b0)); b1 = std::min(NS - 1, std::max(b0, b1));
+                        while (b0 < b1 && plane(b0 + 1) <= R[i].box.mn[a]) b0++;               // (float binning vs. the plane positions used for chopping)
+                        while (b1 > b0 && plane(b1) >= R[i].box.mx[a]) b1--;
+                        enter[b0]++; leave[b1]++;
+                        Box cur = R[i].box;
+                        for (int b = b0; b < b1; b++) {
+                            Box l, r; split_ref(&wtri[(size_t)R[i].tri * 9], cur, a, plane(b + 1), l, r);
+                            if (valid_box(l)) grow(bb[b], l);
+                            cur = r;
+                            if (!valid_box(cur)) break;
+                        }
+                        if (valid_box(cur)) grow(bb[b1], cur);
+                    }
+                    float ra[NS]; uint32_t rc[NS]; Box acc = empty_box(); uint32_t c = 0;
+                    for (int b = NS - 1; b > 0; b--) { grow(acc, bb[b]); c += leave[b]; ra[b] = half_area(acc); rc[b] = c; }
+                    acc = empty_box(); c = 0;
+                    for (int b = 0; b < NS - 1; b++) {
+                        grow(acc, bb[b]); c += enter[b];
+                        if (!c || !rc[b + 1] || c >= j.count || rc[b + 1] >= j.count) continue;       // a split that sends every reference to one side makes no progress
+                        const float cost = half_area(acc) * (float)c + ra[b + 1] * (float)rc[b + 1];
+                        if (cost < sp_cost) { sp_cost = cost; sp_axis = a; sp_pos = plane(b + 1); }
+                    }
+                }
+            }
+        }
+        uint32_t nl = 0, nr = 0;                                                     // sizes of the two sides, laid out as [.. | left | right] on the reference stack
+        bool split = false;
+        if (sp_axis >= 0 && sp_cost < best_cost && (j.count > 4 || sp_cost + half_area(nb) < leaf_cost)) {
+            // ---- spatial split with reference unsplitting (section 4.4): a straddling reference goes to both sides, or whole to one if that is cheaper ----
+            tmp.clear();
+            Box lb = empty_box(), rb = empty_box();
+            std::vector<Ref> left, right, both;
+            for (uint32_t i = 0; i < j.count; i++) {
+                if (R[i].box.mx[sp_axis] <= sp_pos) { left.push_back(R[i]); grow(lb, R[i].box); }
+                else if (R[i].box.mn[sp_axis] >= sp_pos) { right.push_back(R[i]); grow(rb, R[i].box); }
+                else both.push_back(R[i]);
+            }
+            uint32_t cl = (uint32_t)(left.size() + both.size()), cr = (uint32_t)(right.size() + both.size());
+            for (const Ref& r : both) {
+                Box l, rr; split_ref(&wtri[(size_t)r.tri * 9], r.box, sp_axis, sp_pos, l, rr);
+                const bool lv = valid_box(l), rv = valid_box(rr);
+                Box lbs = lb, rbs = rb, lbw = lb, rbw = rb;
+                if (lv) grow(lbs, l); if (rv) grow(rbs, rr); grow(lbw, r.box); grow(rbw, r.box);
+                const float c_split = half_area(lbs) * (float)cl + half_area(rbs) * (float)cr;
+                const float c_left = half_area(lbw) * (float)cl + half_area(rb) * (float)(cr - 1);
+                const float c_right = half_area(lb) * (float)(cl - 1) + half_area(rbw) * (float)cr;
+                if (lv && rv && c_split <= c_left && c_split <= c_right && refs_total < ref_budget) {
+                    left.push_back({l, r.tri}); right.push_back({rr, r.tri}); lb = lbs; rb = rbs; refs_total++;
+                } else if ((c_left <= c_right && cr > 1) || !rv || cl <= 1) { left.push_back(r); lb = lbw; cr--; }
+                else { right.push_back(r); rb = rbw; cl--; }
+            }
+            nl = (uint32_t)left.size(); nr = (uint32_t)right.size();
+            if (nl && nr && nl < j.count + both.size() && nr < j.count + both.size() && !(nl >= j.count && nr >= j.count)) {
+                refs.resize(refs.size() - j.count);
+                refs.insert(refs.end(), left.begin(), left.end()); refs.insert(refs.end(), right.begin(), right.end());
+                split = true;
+            } else { refs_total -= (nl + nr > j.count) ? (nl + nr - j.count) : 0; nl = nr = 0; }
+        }
+        if (!split && best_axis >= 0 && (j.count > 4 || best_cost + half_area(nb) * 1.0f < leaf_cost)) {
+            const float lo = cb.mn[best_axis], k = (float)NB / (cb.mx[best_axis] - cb.mn[best_axis]);
+            Ref* mid = sweep ? std::stable_partition(R, R + j.count, [&](const Ref& r) { return cen(r, best_axis) < sweep_split; })
+                             : std::stable_partition(R, R + j.count, [&](const Ref& r) { int b = (int)((cen(r, best_axis) - lo) * k); if (b >= NB) b = NB - 1; if (b < 0) b = 0; return b <= best_bin; });
+            nl = (uint32_t)(mid - R); nr = j.count - nl;
+            split = nl > 0 && nr > 0;
         }
         if (!split) {
             if (j.count <= 4) { make_leaf(); continue; }            // leaves hold at most 4 triangles (the wide node's 4-bit slots)
-            // degenerate (all centroids equal) or forced: median split by index
-            mid = j.count / 2;
+            nl = j.count / 2; nr = j.count - nl;                    // degenerate (all centroids equal) or forced: median split by index
         }
-        int32_t l = (int32_t)tn.size(); tn.emplace_back();
-        int32_t r = (int32_t)tn.size(); tn.emplace_back();
+        const int32_t l = (int32_t)tn.size(); tn.emplace_back();
+        const int32_t r = (int32_t)tn.size(); tn.emplace_back();
         tn[j.node].left = l; tn[j.node].right = r;
-        st.push_back({r, j.first + mid, j.count - mid, j.depth + 1});
-        st.push_back({l, j.first, mid, j.depth + 1});
+        st.push_back({l, nl, j.depth + 1});
+        st.push_back({r, nr, j.depth + 1});                          // the right side lies on top of the reference stack: it is processed first
+    }
+    // ---- insertion-based optimisation of the topology ----
+    if (opt.reinsert_passes > 0 && tn.size() > 7) {
+        std::vector<int32_t> parent(tn.size(), -1);
+        for (size_t i = 0; i < tn.size(); i++) if (!tn[i].count) { parent[tn[i].left] = (int32_t)i; parent[tn[i].right] = (int32_t)i; }
+        for (int pass = 0; pass < opt.reinsert_passes; pass++) reinsert_pass(tn, parent, opt.reinsert_frac);
+        std::vector<std::pair<int32_t, uint32_t>> dst; dst.push_back({0, 0u}); max_depth = 0;
+        while (!dst.empty()) { const auto it = dst.back(); dst.pop_back(); max_depth = std::max(max_depth, it.second); if (!tn[it.first].count) { dst.push_back({tn[it.first].left, it.second + 1}); dst.push_back({tn[it.first].right, it.second + 1}); } }
+    }
+    // ---- leaf order: depth-first, left to right, so that every subtree owns ONE contiguous range of references (collapse_bvh8 merges small subtrees into a
+    //      leaf slot by range; the build emits the right side first and the re-insertion moves subtrees) ----
+    {
+        std::vector<uint32_t> emitted; emitted.reserve(order.size());
+        std::vector<int32_t> dfs; dfs.push_back(0);
+        while (!dfs.empty() && !tn.empty()) {
+            const int32_t i = dfs.back(); dfs.pop_back();
+            if (tn[i].count) { const uint32_t f = tn[i].first; tn[i].first = (uint32_t)emitted.size(); for (uint32_t k = 0; k < tn[i].count; k++) emitted.push_back(order[f + k]); }
+            else if (tn[i].left >= 0) { dfs.push_back(tn[i].right); dfs.push_back(tn[i].left); }
+        }
+        if (emitted.size() == order.size()) order.swap(emitted);
     }
     // ---- breadth-first relayout with children boxes stored in the parent ----
     nodes.clear();
@@ -594,7 +852,7 @@ void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGP
 // are the binary tree's padded boxes rounded OUTWARD onto the node's byte grid (checked in exact double arithmetic), so the
 // wide tree is conservative whenever the binary one is.
 bool collapse_bvh8(const std::vector<NodeGPU>& n2, std::vector<Node8GPU>& n8, std::vector<uint32_t>& tri_slots, uint32_t& max_stack,
-                   std::vector<uint32_t>* level_start) {
+                   std::vector<uint32_t>* level_start, const BvhBuildOptions& opt) {
     struct Ch { float mn[3], mx[3]; int32_t c; };
     auto get = [](const NodeGPU& N, int which) {
         Ch r;
@@ -614,7 +872,7 @@ bool collapse_bvh8(const std::vector<NodeGPU>& n2, std::vector<Node8GPU>& n8, st
     // a triangle test is 95 VALU instructions against ~200 of a node step, but triangle steps run with half the lanes of node steps
     // (profiles/r02_traversal.md), so per ray it costs more than the 0.45 the instruction counts say: measured k_trace_closest
     // 23.80 / 21.31 ms (C3 / C5) at 0.45, 23.39 / 20.93 at 0.7, 23.49 / 21.00 at 1.0, 23.53 / 20.95 at 1.5, 24.30 / 21.82 at 0.3
-    constexpr double kNodeCost = 1.0, kTriCost = 0.7;
+    const double kNodeCost = 1.0, kTriCost = opt.tri_cost;
     struct Sub { double area; uint32_t prims, first; };
     std::vector<Sub> sub(nn);
     std::vector<std::array<double, 8>> cost(nn);           // index 1..7
@@ -701,11 +959,30 @@ bool collapse_bvh8(const std::vector<NodeGPU>& n2, std::vector<Node8GPU>& n8, st
                 }
                 cost[k][sl] = c;
             }
+            if (opt.slot_assign == 0) {
             bool done[8] = {false, false, false, false, false, false, false, false};
             for (int it = 0; it < m; it++) {
                 int bk = -1, bs = -1; double bc = 0.0;
                 for (int k = 0; k < m; k++) if (!done[k]) for (int sl = 0; sl < 8; sl++) if (!slot_used[sl]) if (bk < 0 || cost[k][sl] > bc) { bc = cost[k][sl]; bk = k; bs = sl; }
                 done[bk] = true; slot_used[bs] = true; slot_of[bk] = bs;
+            }
+            } else {
+                // the assignment that maximises the summed projections (Ylitie et al. solve it by auction; with eight slots a subset table is exact): best[k][S] = children
+                // k.. placed into the free slots of S
+                double best[9][256]; int8_t pick[9][256];
+                for (int S = 0; S < 256; S++) best[m][S] = 0.0;
+                for (int k = m - 1; k >= 0; k--) for (int S = 0; S < 256; S++) {
+                    best[k][S] = -1e300; pick[k][S] = -1;
+                    if (__builtin_popcount(S) != k) continue;                       // S = slots taken by children 0..k-1
+                    for (int sl = 0; sl < 8; sl++) if (!(S & (1 << sl))) {
+                        const double nxt = best[k + 1][S | (1 << sl)];
+                        if (nxt <= -1e299 && k + 1 < m) continue;
+                        const double c = cost[k][sl] + (k + 1 < m ? nxt : 0.0);
+                        if (c > best[k][S]) { best[k][S] = c; pick[k][S] = (int8_t)sl; }
+                    }
+                }
+                int S = 0;
+                for (int k = 0; k < m; k++) { const int sl = pick[k][S]; slot_of[k] = sl; slot_used[sl] = true; S |= 1 << sl; }
             }
         }
         int child_at[8]; for (int sl = 0; sl < 8; sl++) child_at[sl] = -1;
@@ -779,14 +1056,171 @@ bool collapse_bvh8(const std::vector<NodeGPU>& n2, std::vector<Node8GPU>& n8, st
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Host-side REPLAY of the device traversal (csrc/rtx_traverse.hpp: node8_hits / descend8 / traverse, one ray at a time, non-speculative order) on the
+// wide tree of a BuiltScene, counting node steps and triangle tests.  Two users: tools/bvh_lab.cpp (builder work judged by work per ray, no GPU) and the
+// commit-time probe below.  Scalar float code with the kernels' formulas; not bit-pinned to them (the counts, not the hits, are what it is for).
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct RGrp { uint32_t base, bits; };
+struct RTri { uint32_t base, bits, valid; };
+constexpr float kRPlaneEps = 2.384185791015625e-07f, kRSlabK = 1.00010002f;
+inline void replay_node(const Node8GPU& N, const float o[3], const float idir[3], uint32_t oct, bool ordered, uint32_t oct_order, float tmin, float tbest, RGrp& G, RTri& T) {
+    const uint32_t w = N.e_imask;
+    const float s[3] = {u2f((w & 0xffu) << 23) * idir[0], u2f((w & 0xff00u) << 15) * idir[1], u2f((w & 0xff0000u) << 7) * idir[2]};
+    const float a3[3] = {(N.px - o[0]) * idir[0], (N.py - o[1]) * idir[1], (N.pz - o[2]) * idir[2]};
+    uint32_t hits = 0;
+    for (int k = 0; k < 8; k++) {
+        float lo = tmin, hi = tbest;
+        for (int a = 0; a < 3; a++) {
+            const uint32_t qlo = (N.q[2 * a + (k >> 2)] >> (8 * (k & 3))) & 0xffu, qhi = (N.q[2 * (3 + a) + (k >> 2)] >> (8 * (k & 3))) & 0xffu;
+            const bool neg = (oct >> a) & 1u;
+            const float an = fmaf(-fabsf(a3[a]), kRPlaneEps, a3[a]), af = fmaf(fabsf(a3[a]), kRPlaneEps, a3[a]);
+            lo = fmaxf(lo, fmaf((float)(neg ? qhi : qlo), s[a], an)); hi = fminf(hi, fmaf((float)(neg ? qlo : qhi), s[a], af));
+        }
+        if (!(f2u(fmaf(hi, kRSlabK, -lo)) >> 31)) hits |= 1u << k;
+    }
+    const uint32_t imask = w >> 24;
+    uint32_t m = hits & imask;
+    if (ordered) { uint32_t pm = 0; for (int j = 0; j < 8; j++) if (m & (1u << (j ^ oct_order))) pm |= 1u << j; m = pm; }
+    G.base = N.child_base; G.bits = m | (imask << 8);
+    uint32_t x = hits & ~imask, sp = 0;
+    for (int k = 0; k < 8; k++) if (x & (1u << k)) sp |= 0xfu << (4 * k);
+    T.base = N.tri_base; T.valid = N.trivalid; T.bits = sp & N.trivalid;
+}
+inline bool replay_tri(const float o[3], const float d[3], const TriGPU& Tg, float tmin, float tmax, float& t) {
+    const f3 v0 = mk3(Tg.v0.x, Tg.v0.y, Tg.v0.z), e1 = mk3(Tg.e1.x, Tg.e1.y, Tg.e1.z), e2 = mk3(Tg.e2.x, Tg.e2.y, Tg.e2.z), dd = mk3(d[0], d[1], d[2]);
+    const f3 pv = cross(dd, e2);
+    const float det = dot(e1, pv);
+    if (det == 0.0f) return false;
+    const float inv = 1.0f / det;
+    const f3 sv = mk3(o[0], o[1], o[2]) - v0;
+    const float u = dot(sv, pv) * inv;
+    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    const f3 q = cross(sv, e1);
+    const float v = dot(dd, q) * inv;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
+    t = dot(e2, q) * inv;
+    return t > tmin && t < tmax;
+}
+}  // namespace
+
+ReplayHit replay_trace(const BuiltScene& B, const float o[3], const float d[3], float tmin, float tmax, bool any, uint32_t any_order, float t_known) {
+    float idir[3]; uint32_t oct = 0;
+    for (int a = 0; a < 3; a++) { const float ds = fabsf(d[a]) < 1e-30f ? copysignf(1e-30f, d[a]) : d[a]; idir[a] = 1.0f / ds; if (idir[a] < 0.0f) oct |= 1u << a; }
+    const bool ordered = !any || any_order != 0;
+    const uint32_t oct_order = (any && any_order == 2) ? (oct ^ 7u) : oct;
+    ReplayHit H{t_known > 0.0f ? t_known * 1.0000005f : tmax, 0xffffffffu, 0xffffffffu, 0u, 0u};
+    if (B.nodes8.empty()) return H;
+    RGrp stk[64]; int sp = 0;
+    RGrp G{0u, (ordered ? (1u << oct_order) : 1u) | (1u << 8)};
+    RTri T{0u, 0u, 0u};
+    while (true) {
+        if (G.bits & 0xffu) {
+            const uint32_t k = (uint32_t)__builtin_ctz(G.bits), rest = G.bits & (G.bits - 1u);
+            if ((rest & 0xffu) && sp < 64) stk[sp++] = RGrp{G.base, rest};
+            const uint32_t slot = ordered ? (k ^ oct_order) : k;
+            const uint32_t idx = G.base + (uint32_t)__builtin_popcount((G.bits >> 8) & ((1u << slot) - 1u));
+            replay_node(B.nodes8[idx], o, idir, oct, ordered, oct_order, tmin, H.t, G, T);
+            H.steps++;
+        }
+        while (T.bits) {
+            const uint32_t bit = (uint32_t)__builtin_ctz(T.bits);
+            T.bits &= T.bits - 1u; H.tris++;
+            const uint32_t slot = T.base + (uint32_t)__builtin_popcount(T.valid & ((1u << bit) - 1u));
+            float t;
+            if (replay_tri(o, d, B.tris8[slot], tmin, tmax, t)) {
+                const uint32_t gid = f2u(B.tris8[slot].v0.w);
+                if (any) { H.prim = gid; H.slot = slot; H.t = t; return H; }
+                if (t < H.t || (t == H.t && gid < H.prim)) { H.t = t; H.prim = gid; H.slot = slot; }
+            }
+        }
+        if (!(G.bits & 0xffu)) { if (sp == 0) break; G = stk[--sp]; }
+    }
+    return H;
+}
+
+// In which order should an any-hit ray visit the hit children of a node?  Any-hit is existence, so the order changes no result, only how soon an occluder is found:
+// slot order (0), nearest octant first (1) or FARTHEST first (2: from the light's end — where a lamp's own housing, or the far faces of a closed emissive mesh, block
+// the ray).  Which one wins is a property of the scene and its lights (Bistro-class street: far first -17 % node steps per occluded ray; the atrium under its sky
+// quad: slot order), so it is probed once per commit: 2 048 NEE-like segments (a point on a random triangle to a CDF-sampled point on a light) replayed in the three
+// orders; the cheapest by the traversal kernels' own cost model wins (node step 205 VALU at 47 of 64 lanes, triangle test 70 at 24), with 2 % hysteresis for order 0.
+uint32_t probe_anyhit_order(const BuiltScene& B) {
+    if (B.lights.empty() || B.tris8.empty() || B.nodes8.empty() || B.small_nrec) return 0u;
+    auto h32 = [](uint32_t a, uint32_t b) { uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u; h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15; return h; };
+    auto r01 = [&](uint32_t a, uint32_t b) { return (float)(h32(a, b) >> 8) * (1.0f / 16777216.0f); };
+    double cost[3] = {0.0, 0.0, 0.0};
+    for (uint32_t i = 0; i < 2048u; i++) {
+        const TriGPU& Tg = B.tris8[h32(i, 1u) % (uint32_t)B.tris8.size()];
+        float u = r01(i, 2u), v = r01(i, 3u); if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+        const f3 p = mk3(Tg.v0.x + u * Tg.e1.x + v * Tg.e2.x, Tg.v0.y + u * Tg.e1.y + v * Tg.e2.y, Tg.v0.z + u * Tg.e1.z + v * Tg.e2.z);
+        f3 n = normalize(cross(mk3(Tg.e1.x, Tg.e1.y, Tg.e1.z), mk3(Tg.e2.x, Tg.e2.y, Tg.e2.z)));
+        const float xi = r01(i, 4u);
+        size_t li = 0; while (li + 1 < B.lights.size() && B.lights[li].cdf < xi) li++;
+        const LightGPU& Lg = B.lights[li];
+        float a = r01(i, 5u), b = r01(i, 6u); if (a + b > 1.0f) { a = 1.0f - a; b = 1.0f - b; }
+        const f3 lp = mk3(Lg.xv[0] + a * (Lg.yv[0] - Lg.xv[0]) + b * (Lg.zv[0] - Lg.xv[0]), Lg.xv[1] + a * (Lg.yv[1] - Lg.xv[1]) + b * (Lg.zv[1] - Lg.xv[1]), Lg.xv[2] + a * (Lg.yv[2] - Lg.xv[2]) + b * (Lg.zv[2] - Lg.xv[2]));
+        f3 dir = lp - p;
+        if (dot(n, dir) < 0.0f) n = mk3(-n.x, -n.y, -n.z);                      // surfaces are lit from either side
+        const f3 org = mk3(p.x + kSBias * n.x, p.y + kSBias * n.y, p.z + kSBias * n.z);
+        dir = lp - org;
+        const float dist = length(dir);
+        if (!(dist > 10.0f * kSBias)) continue;
+        const float od[3] = {org.x, org.y, org.z}, dd[3] = {dir.x / dist, dir.y / dist, dir.z / dist};
+        for (uint32_t ord = 0; ord < 3u; ord++) {
+            const ReplayHit H = replay_trace(B, od, dd, 0.5f * kSBias, dist - 5.0f * kSBias, true, ord);
+            cost[ord] += (double)H.steps * (205.0 * 64.0 / 47.0) + (double)H.tris * (70.0 * 64.0 / 24.0);
+        }
+    }
+    uint32_t best = 0;
+    for (uint32_t ord = 1; ord < 3u; ord++) if (cost[ord] < 0.98 * cost[0] && cost[ord] < cost[best]) best = ord;
+    return best;
+}
+
+// Coverage bookkeeping shared by the validators of the binary and of the wide tree.  A triangle referenced ONCE must lie inside every box above its
+// reference (all three corners).  A triangle that spatial splits handed to several leaves is checked on 28 points (corners, edge thirds, an interior lattice):
+// each must lie inside all boxes above ONE of the references — the property the traversal needs (a hit point is found through whichever reference's boxes
+// contain it).  Points are evaluated in double; the tolerance covers that evaluation only (boxes of split parts are rounded outward by a float spacing).
+CoverCheck::CoverCheck(const std::vector<float>& world_tris9) : w(world_tris9), refs((uint32_t)(world_tris9.size() / 9), 0u) {}
+void CoverCheck::count(uint32_t g) { refs[g]++; }
+int CoverCheck::add(uint32_t g, const double mn[3], const double mx[3]) {
+    if (refs[g] == 1) {
+        for (int vtx = 0; vtx < 3; vtx++) for (int a = 0; a < 3; a++) { const double c = w[(size_t)g * 9 + vtx * 3 + a]; if (c < mn[a] || c > mx[a]) return 16; }
+        return 0;
+    }
+    boxes.push_back({g, {mn[0], mn[1], mn[2], mx[0], mx[1], mx[2]}});
+    return 0;
+}
+int CoverCheck::finish() {
+    for (uint32_t r : refs) if (!r) return 17;
+    std::stable_sort(boxes.begin(), boxes.end(), [](const Part& a, const Part& b) { return a.tri < b.tri; });
+    for (size_t i = 0; i < boxes.size();) {
+        size_t j = i; while (j < boxes.size() && boxes[j].tri == boxes[i].tri) j++;
+        const float* t = &w[(size_t)boxes[i].tri * 9];
+        double scale = 1.0; for (int k = 0; k < 9; k++) scale = std::max(scale, std::fabs((double)t[k]));
+        const double tol = 1e-12 * scale;
+        for (int a = 0; a <= 6; a++) for (int b = 0; a + b <= 6; b++) {
+            const double u = a / 6.0, v = b / 6.0, q = 1.0 - u - v;
+            const double pt[3] = {q * t[0] + u * t[3] + v * t[6], q * t[1] + u * t[4] + v * t[7], q * t[2] + u * t[5] + v * t[8]};
+            bool in = false;
+            for (size_t k = i; k < j && !in; k++) { const double* bx = boxes[k].b; in = pt[0] >= bx[0] - tol && pt[1] >= bx[1] - tol && pt[2] >= bx[2] - tol && pt[0] <= bx[3] + tol && pt[1] <= bx[4] + tol && pt[2] <= bx[5] + tol; }
+            if (!in) return 24;
+        }
+        i = j;
+    }
+    return 0;
+}
+
 // the compressed 8-wide collapse: same coverage properties, checked on the DECODED byte-grid boxes of the wide nodes
 int validate_bvh8(const std::vector<float>& w, const std::vector<Node8GPU>& nodes, const std::vector<uint32_t>& order,
                   const std::vector<uint32_t>& tri_slots, uint32_t* max_stack_seen) {
-    const uint32_t ntris = (uint32_t)(w.size() / 9);
-    if (tri_slots.size() != ntris) return 20;
+    const uint32_t ntris = (uint32_t)(w.size() / 9), nrefs = (uint32_t)tri_slots.size();
+    if (order.size() != nrefs || nrefs < ntris) return 20;
     struct It { uint32_t node; double mn[3], mx[3]; uint32_t pushes; };
-    std::vector<uint8_t> covered(ntris, 0), visited(nodes.size(), 0);
+    std::vector<uint8_t> used(nrefs, 0), visited(nodes.size(), 0);
     if (nodes.empty()) return ntris ? 10 : 0;
+    CoverCheck cover(w);
+    for (uint32_t s = 0; s < nrefs; s++) { if (tri_slots[s] >= nrefs || order[tri_slots[s]] >= ntris) return 14; cover.count(order[tri_slots[s]]); }
     std::vector<It> st;
     const double inf = INFINITY;
     st.push_back({0u, {-inf, -inf, -inf}, {inf, inf, inf}, 0u});
@@ -825,20 +1259,19 @@ int validate_bvh8(const std::vector<float>& w, const std::vector<Node8GPU>& node
                 if (nib != 1 && nib != 3 && nib != 7 && nib != 15) return 23;
                 const uint32_t cnt = (uint32_t)__builtin_popcount(nib);
                 for (uint32_t k = 0; k < cnt; k++, tri_at++) {
-                    if (tri_at >= ntris || tri_slots[tri_at] >= ntris) return 14;
-                    const uint32_t g = order[tri_slots[tri_at]];
-                    if (covered[g]) return 15;
-                    covered[g] = 1;
-                    for (int vtx = 0; vtx < 3; vtx++) for (int a = 0; a < 3; a++) { const double c = w[(size_t)g * 9 + vtx * 3 + a]; if (c < mn[a] || c > mx[a]) return 16; }
+                    if (tri_at >= nrefs) return 14;
+                    if (used[tri_at]) return 15;                                 // every leaf entry belongs to one leaf slot
+                    used[tri_at] = 1;
+                    if (int r = cover.add(order[tri_slots[tri_at]], mn, mx)) return r;
                 }
             }
         }
     }
-    for (uint32_t i = 0; i < ntris; i++) if (!covered[i]) return 17;
+    for (uint32_t i = 0; i < nrefs; i++) if (!used[i]) return 17;
     for (size_t i = 0; i < nodes.size(); i++) if (!visited[i]) return 18;
+    if (int r = cover.finish()) return r;
     if (max_stack_seen) *max_stack_seen = deepest;
     return 0;
 }
-
 
 }  // namespace rtx

@@ -13,6 +13,22 @@ float half_round(float x);                               // binary16 round trip 
 void  mat4_inverse(const float* m16, float* out16);      // XMMatrixInverse stand-in
 void  normal_matrix(const float* o2w16, float* out16);   // Renderer.cpp:2104-2116
 
+// Knobs of the BVH builder (defaults = what the product builds; tools/bvh_lab.cpp and the A/B tools change them by key).
+struct BvhBuildOptions {
+    int      bins = 16;           // binned SAH: bins per axis for nodes above `sweep_below`
+    uint32_t sweep_below = 0;     // nodes with at most this many references use the full-sweep SAH (every centroid position) instead of bins
+    uint32_t leaf_stop = 2;       // nodes with at most this many references are not split further (the wide collapse merges small subtrees into leaf slots anyway)
+    double   split_alpha = 0.0;   // spatial splits where the object split's two sides overlap by more than this fraction of the scene's surface area (0 = never)
+    double   split_budget = 0.3;  // ... and at most this many extra references, as a fraction of the triangle count
+    int      reinsert_passes = 0; // passes of the insertion-based topology optimisation
+    double   reinsert_frac = 1.0; // share of the nodes (largest boxes first) a pass tries to re-insert
+    int      slot_assign = 0;     // collapse_bvh8: children to octant slots greedily (0) or by the exact maximum of the summed diagonal projections (1)
+    double   tri_cost = 0.7;      // collapse_bvh8: cost of a triangle test relative to a node step
+};
+BvhBuildOptions& bvh_build_options();                      // process-wide defaults: what a new SceneHost starts with (RTX_BVH="key=value,..." in the environment edits them once)
+bool bvh_build_option(const char* key, double value);      // edits the defaults; false: unknown key
+bool bvh_build_option(BvhBuildOptions& o, const char* key, double value);
+
 struct MeshHost { std::vector<float> verts; std::vector<uint32_t> idx; uint32_t matid_base = 0; };
 struct InstHost { uint32_t mesh; float o2w[16]; float nrm[16]; float o2w_inv[16]; float prev_o2w[16]; uint32_t tri_base; };
 
@@ -37,7 +53,9 @@ struct BuiltScene {
     std::vector<InstGPU>  insts;
     std::vector<LightGPU> lights;
     std::vector<float>    lights80;   // reference-layout LightTriangle records (20 floats each)
-    std::vector<uint32_t> leaf_order;   // BVH leaf order (kept for refits)
+    std::vector<uint32_t> leaf_order;   // BVH leaf order (kept for refits): the triangle behind every leaf REFERENCE — a permutation unless spatial splits duplicated some
+    uint32_t any_order = 0;             // visiting order of any-hit rays chosen by probe_anyhit_order (0 slot order, 1 nearest octant first, 2 farthest first)
+    uint32_t built_tris = 0;            // triangle count the topology was built for
     float total_weight = 0.0f;
     uint32_t max_depth = 0;
     uint32_t refit_count = 0;           // commits since the last full build that only refitted the boxes
@@ -51,6 +69,7 @@ struct SceneHost {
     std::string err;
     bool topo_dirty = true;                     // meshes / instances added since the last build (a transform change alone refits)
     bool mats_dirty = true;                     // rtx_set_materials since the material table was last derived
+    BvhBuildOptions bvh = bvh_build_options();  // builder knobs of this scene (rtx_set_option RTX_OPT_BVH_*)
 
     bool set_materials(const void* mats, uint32_t count);
     bool add_mesh(const void* verts28, uint32_t nverts, const uint32_t* idx, uint32_t nidx, const uint32_t* matids, uint32_t* out);
@@ -76,14 +95,28 @@ bool load_scene_cache(const char* path, SceneHost& H, BuiltScene& B, std::string
 // parent) and the leaf-ordered triangle permutation.
 void refit_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGPU>& nodes, const std::vector<uint32_t>& leaf_order);
 void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGPU>& nodes,
-               std::vector<uint32_t>& leaf_order, uint32_t& max_depth);
+               std::vector<uint32_t>& leaf_order, uint32_t& max_depth, const BvhBuildOptions& opt = bvh_build_options());
 // collapse the binary tree into the compressed 8-wide device form (largest-area internal child opened first, octant-ordered
 // slots, outward-rounded byte quantisation); tri_slots = leaf-order slots in the wide tree's triangle order; max_stack =
 // bound on the sibling-group entries a traversal can hold (one per level).  Returns false on a malformed input tree.
 bool collapse_bvh8(const std::vector<NodeGPU>& nodes2, std::vector<Node8GPU>& nodes8, std::vector<uint32_t>& tri_slots, uint32_t& max_stack,
-                   std::vector<uint32_t>* level_start = nullptr);
-// coverage check of a wide tree on its DECODED boxes (tests, rtx_debug_validate_bvh): 0 = every triangle order[tri_slots[i]] is in
-// exactly one leaf slot and inside all boxes above it, children follow parents; otherwise a small positive code
+                   std::vector<uint32_t>* level_start = nullptr, const BvhBuildOptions& opt = bvh_build_options());
+// coverage check of a wide tree on its DECODED boxes (tests, rtx_debug_validate_bvh): 0 = children follow parents, every leaf slot entry order[tri_slots[i]] is a
+// triangle, and every triangle is COVERED: referenced once and inside all boxes above that reference, or — a triangle a spatial split handed to several leaves —
+// each of a fixed set of 28 points on it (corners, edge thirds, interior lattice) lies inside all boxes above one of its references; otherwise a small positive code
+// host-side replay of the device traversal on B.nodes8 / B.tris8 (counts for tools/bvh_lab.cpp and the any-hit probe; rtx_scene_host.cpp)
+struct ReplayHit { float t; uint32_t slot, prim; uint32_t steps, tris; };     // prim = global triangle id or 0xffffffff; steps = node steps, tris = triangle tests
+ReplayHit replay_trace(const BuiltScene& B, const float o[3], const float d[3], float tmin, float tmax, bool any, uint32_t any_order = 0, float t_known = -1.0f);
+uint32_t probe_anyhit_order(const BuiltScene& B);
+
+struct CoverCheck {                                         // coverage bookkeeping of the tree validators (rtx_scene_host.cpp)
+    struct Part { uint32_t tri; double b[6]; };
+    const std::vector<float>& w; std::vector<uint32_t> refs; std::vector<Part> boxes;
+    explicit CoverCheck(const std::vector<float>& world_tris9);
+    void count(uint32_t tri);                                // first pass: one call per reference
+    int add(uint32_t tri, const double mn[3], const double mx[3]);   // second pass: the box chain above a reference (intersection of all boxes above it)
+    int finish();
+};
 int validate_bvh8(const std::vector<float>& world_tris9, const std::vector<Node8GPU>& nodes, const std::vector<uint32_t>& order,
                   const std::vector<uint32_t>& tri_slots, uint32_t* max_stack_seen);
 

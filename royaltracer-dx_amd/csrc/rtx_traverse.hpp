@@ -146,8 +146,10 @@ __device__ __forceinline__ float byte_f(uint32_t w, int k) { return (float)((w >
 // ORDERED = false (any-hit rays): the visiting order does not matter, the octant permutation of the hit bits is skipped
 // nx / ny / nz: the ray's direction is negative on that axis (bits 0-2 of its octant).  The persistent schedules hand them in as lanes of three WAVE MASKS kept in SGPR pairs
 // (OctMasks below) — derived from the octant inside the step they cost 3 v_and + 3 v_cmp per node step, 3 % of its instructions, for values that only change on a refill.
+// aord (any-hit rays, wave-uniform; DevScene::any_order): 0 = slot order, 1 = nearest octant first, 2 = FARTHEST first (the octant permutation of the mirrored direction) — the
+// order of an any-hit ray changes no answer, only how soon an occluder turns up; which one pays is a property of the scene and is probed at commit (probe_anyhit_order)
 template <bool ORDERED>
-__device__ __forceinline__ void node8_hits(const Node8R& N, f3 o, f3 idir, bool nx, bool ny, bool nz, float tmin, float tbest, Grp& G, TriGrp& T) {
+__device__ __forceinline__ void node8_hits(const Node8R& N, f3 o, f3 idir, bool nx, bool ny, bool nz, float tmin, float tbest, Grp& G, TriGrp& T, uint32_t aord = 0u) {
     const uint32_t w = f2u(N.h0.w);
     const float sx = u2f((w & 0xffu) << 23) * idir.x, sy = u2f((w & 0xff00u) << 15) * idir.y, sz = u2f((w & 0xff0000u) << 7) * idir.z;
     const float ax = (N.h0.x - o.x) * idir.x, ay = (N.h0.y - o.y) * idir.y, az = (N.h0.z - o.z) * idir.z;
@@ -185,6 +187,11 @@ __device__ __forceinline__ void node8_hits(const Node8R& N, f3 o, f3 idir, bool 
         if (nx) m = ((m & 0x55u) << 1) | ((m >> 1) & 0x55u);
         if (ny) m = ((m & 0x33u) << 2) | ((m >> 2) & 0x33u);
         if (nz) m = ((m & 0x0fu) << 4) | ((m >> 4) & 0x0fu);
+    } else if (aord) {
+        const bool far = aord == 2u;
+        if (nx != far) m = ((m & 0x55u) << 1) | ((m >> 1) & 0x55u);
+        if (ny != far) m = ((m & 0x33u) << 2) | ((m >> 2) & 0x33u);
+        if (nz != far) m = ((m & 0x0fu) << 4) | ((m >> 4) & 0x0fu);
     }
     G.base = N.h1.x; G.bits = m | (imask << 8);
     // leaf hits: spread each bit to its nibble and keep the triangles that exist
@@ -211,14 +218,15 @@ __device__ __forceinline__ void descend8(const DevScene& sc, const TraceLds& L, 
     const uint32_t k = (uint32_t)__builtin_ctz(G.bits);
     const uint32_t rest = G.bits & (G.bits - 1u);
     if (rest & 0xffu) { stk.put(sp, Grp{G.base, rest}); sp++; }
-    const uint32_t slot = ORDERED ? (k ^ oct) : k;
+    const uint32_t aord = ORDERED ? 0u : sc.any_order;
+    const uint32_t slot = ORDERED ? (k ^ oct) : (aord ? (k ^ oct ^ (aord == 2u ? 7u : 0u)) : k);
     const uint32_t idx = G.base + (uint32_t)__builtin_popcount((G.bits >> 8) & ((1u << slot) - 1u));
     const Node8R N = load_node8(sc, L, idx);
 #ifdef RTX_NO_OCT_MASKS          // (A/B build: the conditions derived from the octant inside the step, as before round 3)
     om = nullptr;
 #endif
     if (om) node8_hits<ORDERED>(N, o, idir, __builtin_amdgcn_inverse_ballot_w64(om->x), __builtin_amdgcn_inverse_ballot_w64(om->y), __builtin_amdgcn_inverse_ballot_w64(om->z), tmin, tbest, G, T);
-    else node8_hits<ORDERED>(N, o, idir, (oct & 1u) != 0u, (oct & 2u) != 0u, (oct & 4u) != 0u, tmin, tbest, G, T);
+    else node8_hits<ORDERED>(N, o, idir, (oct & 1u) != 0u, (oct & 2u) != 0u, (oct & 4u) != 0u, tmin, tbest, G, T, aord);
 }
 // index of the triangle behind bit `bit` of a triangle group
 __device__ __forceinline__ uint32_t tri_slot8(const TriGrp& T, uint32_t bit) { return T.base + (uint32_t)__builtin_popcount(T.valid & ((1u << bit) - 1u)); }
@@ -235,7 +243,7 @@ __device__ __forceinline__ void traverse(const DevScene& sc, const TraceLds& L, 
     bt = tmax; bu = 0.0f; bv = 0.0f; bprim = kMissPrim;
     StackLds stk; stk.col = L.stack + threadIdx.x;
     int sp = 0;
-    Grp G{0u, (ANY ? 1u : (1u << oct)) | (1u << 8)};    // the root as slot 0 of a virtual parent (any-hit rays visit unordered)
+    Grp G{0u, (ANY ? (sc.any_order ? 1u << (oct ^ (sc.any_order == 2u ? 7u : 0u)) : 1u) : (1u << oct)) | (1u << 8)};    // the root as slot 0 of a virtual parent (any-hit rays: DevScene::any_order)
     TriGrp T{0u, 0u, 0u};
     while (true) {
         if (G.bits & 0xffu) descend8<!ANY>(sc, L, o, idir, oct, tmin, bt, G, T, stk, sp);
@@ -510,7 +518,7 @@ __device__ __forceinline__ void pend_clear(RayLane& R) {
 #pragma unroll
     for (int i = 0; i < kPend - 1; i++) R.P[i] = TriGrp{0u, 0u, 0u};
 }
-__device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, float tmax, uint32_t item, bool ordered, bool occluder_cache = false) {
+__device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, float tmax, uint32_t item, bool ordered, bool occluder_cache = false, uint32_t aord = 0u) {
     R.o = o; R.d = d; R.tmin = tmin; R.tmax = tmax; R.item = item;
     const float dxs = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
     const float dys = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
@@ -518,7 +526,7 @@ __device__ __forceinline__ void ray_begin(RayLane& R, f3 o, f3 d, float tmin, fl
     R.idir = mk3(__builtin_amdgcn_rcpf(dxs), __builtin_amdgcn_rcpf(dys), __builtin_amdgcn_rcpf(dzs));
     R.oct = ray_octant(R.idir);
     R.bt = tmax; R.bu = 0.0f; R.bv = 0.0f; R.bprim = kMissPrim; R.sp = 0; R.has = true; R.done = false;
-    R.G = Grp{0u, (ordered ? (1u << R.oct) : 1u) | (1u << 8)}; R.T = TriGrp{0u, 0u, 0u}; pend_clear(R);
+    R.G = Grp{0u, (ordered ? (1u << R.oct) : (aord ? 1u << (R.oct ^ (aord == 2u ? 7u : 0u)) : 1u)) | (1u << 8)}; R.T = TriGrp{0u, 0u, 0u}; pend_clear(R);      // the root as slot 0 of a virtual parent
     // OCCLUDER CACHE (any-hit rays).  A lane's consecutive rays come from neighbouring queue entries — shadow rays of neighbouring pixels towards the same light, or
     // visibility rays between neighbouring ReSTIR samples — and what blocked the last one often blocks the next.  So the lane's last occluder is handed to the new
     // ray as its first triangle group: it is tested by the first triangle step the wave takes, and a hit ends the ray before (most of) its traversal.  Any-hit is

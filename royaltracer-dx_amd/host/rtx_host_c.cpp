@@ -157,11 +157,11 @@ float rtxh_half_round(float x) { return rtx::half_round(x); }
 // every triangle in exactly one leaf, every child box contains its subtree
 static int bvh_validate(const std::vector<float>& w, const std::vector<rtx::NodeGPU>& nodes, const std::vector<uint32_t>& order, uint32_t* max_leaf_out) {
     const uint32_t ntris = (uint32_t)(w.size() / 9);
-    if (order.size() != ntris) return 1;
-    std::vector<uint8_t> seen(ntris, 0);
-    for (uint32_t g : order) { if (g >= ntris || seen[g]) return 2; seen[g] = 1; }
+    if (order.size() < ntris) return 1;
+    rtx::CoverCheck cover(w);
+    for (uint32_t g : order) { if (g >= ntris) return 2; cover.count(g); }
     struct It { int32_t child; float mn[3], mx[3]; };
-    std::vector<uint8_t> covered(ntris, 0);
+    std::vector<uint8_t> used(order.size(), 0);
     uint32_t max_leaf = 0;
     std::vector<It> st;
     auto push_children = [&](const rtx::NodeGPU& N, const float* pmn, const float* pmx) {
@@ -180,14 +180,15 @@ static int bvh_validate(const std::vector<float>& w, const std::vector<rtx::Node
         uint32_t v = ~(uint32_t)it.child, first = v >> 3, cnt = (v & 7u) + 1u;
         max_leaf = std::max(max_leaf, cnt);
         for (uint32_t k = 0; k < cnt; k++) {
-            if (first + k >= ntris) return 4;
-            uint32_t g = order[first + k];
-            if (covered[g]) return 5;
-            covered[g] = 1;
-            for (int vtx = 0; vtx < 3; vtx++) for (int a = 0; a < 3; a++) { float c = w[(size_t)g * 9 + vtx * 3 + a]; if (c < it.mn[a] || c > it.mx[a]) return 6; }
+            if (first + k >= order.size()) return 4;
+            if (used[first + k]) return 5;                         // a leaf entry belongs to one leaf
+            used[first + k] = 1;
+            const double mn[3] = {it.mn[0], it.mn[1], it.mn[2]}, mx[3] = {it.mx[0], it.mx[1], it.mx[2]};
+            if (cover.add(order[first + k], mn, mx)) return 6;
         }
     }
-    for (uint32_t i = 0; i < ntris; i++) if (!covered[i]) return 7;
+    for (uint8_t u : used) if (!u) return 7;
+    if (int r = cover.finish()) return r == 17 ? 7 : 8;
     if (max_leaf_out) *max_leaf_out = max_leaf;
     return 0;
 }
@@ -219,6 +220,8 @@ int rtxh_bvh8_check(const float* wt, uint32_t ntris, uint32_t* nodes8_out, uint3
     }
     return 0;
 }
+
+int rtxh_bvh_option(const char* key, double value) { return rtx::bvh_build_option(key, value) ? RTX_OK : RTX_ERR_INVALID; }
 
 // shape of the wide tree: hist[0..4] = leaf slots holding 0 (unused slot) / 1 / 2 / 3 / 4 triangles, hist[5] = internal child slots
 int rtxh_bvh8_stats(const float* wt, uint32_t ntris, uint32_t hist[6], uint32_t* nodes8_out) {

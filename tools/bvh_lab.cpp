@@ -1,0 +1,265 @@
+// bvh_lab.cpp — CPU laboratory for the BVH builder (tooling; no GPU, no HIP).  Builds a scene's wide BVH with the product's own
+// builder code (csrc/rtx_scene_host.cpp compiled into this executable) and replays the device traversal of csrc/rtx_traverse.hpp
+// (node8_hits / descend8 / traverse, non-speculative order) in scalar C++ on path-like rays (camera rays + cosine-sampled bounces),
+// counting node steps and triangle tests per ray.  The point: judge a builder change by WORK PER RAY here, in seconds, before
+// spending GPU minutes on frame times.
+//   make -C tools bvh_lab && tools/bvh_lab sponza|bistro|garage [key=value ...]
+// Keys are handed to rtx::bvh_build_options() (see csrc/rtx_scene_host.hpp) — e.g. sweep=4096 reinsert=2 split=1e-5
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../royaltracer-dx_amd/csrc/rtx_scene_host.hpp"
+#include "../royaltracer-dx_amd/host/Scenes.h"
+
+using namespace rtx;
+
+// host/Scenes.cpp's UploadScene refers to the C-ABI; this tool never uploads anything
+extern "C" {
+int rtx_set_materials(rtx_ctx*, const void*, uint32_t) { return -1; }
+int rtx_add_mesh(rtx_ctx*, const void*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, uint32_t*) { return -1; }
+int rtx_add_instance(rtx_ctx*, uint32_t, const float*, uint32_t*) { return -1; }
+int rtx_commit_scene(rtx_ctx*) { return -1; }
+int rtx_set_camera(rtx_ctx*, const float*, const float*) { return -1; }
+}
+
+namespace {
+struct V3 { float x, y, z; };
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline V3 crs(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float dt(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 nrm(V3 a) { float l = sqrtf(dt(a, a)); return l > 0 ? a * (1.0f / l) : a; }
+
+inline float u2f_(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+inline uint32_t f2u_(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+constexpr float kPlaneEps = 2.384185791015625e-07f, kSlabK = 1.00010002f;
+
+
+inline bool tri_test(V3 o, V3 d, const TriGPU& Tg, float tmin, float tmax, float& t, float& u, float& v) {
+    const V3 v0{Tg.v0.x, Tg.v0.y, Tg.v0.z}, e1{Tg.e1.x, Tg.e1.y, Tg.e1.z}, e2{Tg.e2.x, Tg.e2.y, Tg.e2.z};
+    const V3 p = crs(d, e2);
+    const float det = dt(e1, p);
+    if (det == 0.0f) return false;
+    const float inv = 1.0f / det;
+    const V3 s = o - v0;
+    u = dt(s, p) * inv;
+    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    const V3 q = crs(s, e1);
+    v = dt(d, q) * inv;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
+    t = dt(e2, q) * inv;
+    return t > tmin && t < tmax;
+}
+
+struct Hit { float t; uint32_t slot, prim; uint32_t steps, tris; };
+
+int g_any_order = 0;      // any-hit visiting order: 0 = slot order, 1 = near first (octant order), 2 = far first
+// the product's own host-side replay of the device traversal (csrc/rtx_scene_host.cpp: replay_trace)
+template <bool ANY>
+Hit traverse(const BuiltScene& B, V3 o, V3 d, float tmin, float tmax, float tknown = -1.0f) {
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+    const ReplayHit R = replay_trace(B, oo, dd, tmin, tmax, ANY, ANY ? (uint32_t)g_any_order : 0u, tknown);
+    Hit H{R.t, R.slot, ANY ? (R.prim == 0xffffffffu ? 0xffffffffu : 0u) : R.prim, R.steps, R.tris};
+    return H;
+}
+
+// What-if traversal (closest hit): mode 1 = octant order, a child whose entry distance lies beyond the best hit WHEN IT IS POPPED is skipped without a node step
+// (needs per-child distances on the stack); mode 2 = children visited by entry distance + the same skip.  Counts only.
+struct WhatIf { const BuiltScene& B; V3 o, d, idir; uint32_t oct; float tmin; float bt; uint32_t bprim; uint32_t steps, tris; int mode; double* lev = nullptr; double* zero = nullptr;
+    void node(uint32_t idx, int depth = 0) {
+        const Node8GPU& N = B.nodes8[idx]; steps++; if (lev && depth < 16) lev[depth] += 1;
+        const uint32_t w = N.e_imask;
+        const float s[3] = {u2f_((w & 0xffu) << 23) * idir.x, u2f_((w & 0xff00u) << 15) * idir.y, u2f_((w & 0xff0000u) << 7) * idir.z};
+        const float a3[3] = {(N.px - o.x) * idir.x, (N.py - o.y) * idir.y, (N.pz - o.z) * idir.z};
+        float lo8[8]; uint32_t hits = 0;
+        for (int k = 0; k < 8; k++) {
+            float lo = tmin, hi = bt;
+            for (int a = 0; a < 3; a++) {
+                const uint32_t qlo = (N.q[2 * a + (k >> 2)] >> (8 * (k & 3))) & 0xffu, qhi = (N.q[2 * (3 + a) + (k >> 2)] >> (8 * (k & 3))) & 0xffu;
+                const bool neg = (oct >> a) & 1u;
+                const float an = fmaf(-fabsf(a3[a]), kPlaneEps, a3[a]), af = fmaf(fabsf(a3[a]), kPlaneEps, a3[a]);
+                lo = fmaxf(lo, fmaf((float)(neg ? qhi : qlo), s[a], an)); hi = fminf(hi, fmaf((float)(neg ? qlo : qhi), s[a], af));
+            }
+            lo8[k] = lo;
+            if (!(f2u_(fmaf(hi, kSlabK, -lo)) >> 31)) hits |= 1u << k;
+        }
+        const uint32_t imask = w >> 24;
+        if (zero && !hits && depth < 16) zero[depth] += 1;
+        // leaves first (as the device does: the triangles of a node are tested before its internal children are entered)
+        uint32_t x = hits & ~imask;
+        for (int k = 0; k < 8; k++) if (x & (1u << k)) {
+            const uint32_t nib = (N.trivalid >> (4 * k)) & 0xfu;
+            for (int b = 0; b < 4; b++) if (nib & (1u << b)) {
+                const uint32_t slot = N.tri_base + (uint32_t)__builtin_popcount(N.trivalid & ((1u << (4 * k + b)) - 1u));
+                float t, u, v; tris++;
+                if (tri_test(o, d, B.tris8[slot], tmin, 1e30f, t, u, v)) { const uint32_t g = f2u_(B.tris8[slot].v0.w); if (t < bt || (t == bt && g < bprim)) { bt = t; bprim = g; } }
+            }
+        }
+        int ord[8], m = 0;
+        for (int j = 0; j < 8; j++) { const int k = j ^ (int)oct; if ((hits & imask) & (1u << k)) ord[m++] = k; }
+        if (mode == 2 || mode == 4) std::stable_sort(ord, ord + m, [&](int a, int b) { return lo8[a] < lo8[b]; });
+        for (int i = 0; i < m; i++) {
+            const int k = ord[i];
+            if ((mode == 1 || mode == 2) && lo8[k] > bt * kSlabK) continue;
+            node(N.child_base + (uint32_t)__builtin_popcount(imask & ((1u << k) - 1u)), depth + 1);
+        }
+    }
+};
+
+inline uint32_t hash32(uint32_t a, uint32_t b) { uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u; h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15; return h; }
+inline float rnd(uint32_t a, uint32_t b) { return (float)(hash32(a, b) >> 8) * (1.0f / 16777216.0f); }
+
+// SAH cost of the wide tree in units of (node step, triangle test) weighted by the probability of a random ray hitting the box, relative to the root
+void wide_sah(const BuiltScene& B, double& node_cost, double& tri_cost, double& fill, uint32_t hist[5]) {
+    node_cost = tri_cost = 0; fill = 0; for (int i = 0; i < 5; i++) hist[i] = 0;
+    if (B.nodes8.empty()) return;
+    struct It { uint32_t n; double area; };
+    std::vector<It> st; st.push_back({0, -1.0});
+    double root_area = 0;
+    size_t slots = 0;
+    while (!st.empty()) {
+        It it = st.back(); st.pop_back();
+        const Node8GPU& N = B.nodes8[it.n];
+        double step[3]; for (int a = 0; a < 3; a++) step[a] = std::ldexp(1.0, (int)((N.e_imask >> (8 * a)) & 0xff) - 127);
+        double umn[3] = {1e300, 1e300, 1e300}, umx[3] = {-1e300, -1e300, -1e300};
+        const uint32_t imask = N.e_imask >> 24; uint32_t rank = 0;
+        struct C { double area; bool internal; uint32_t cnt; } ch[8]; int m = 0;
+        for (int sl = 0; sl < 8; sl++) {
+            const uint32_t nib = (N.trivalid >> (4 * sl)) & 0xf; const bool internal = (imask >> sl) & 1;
+            if (!internal && !nib) continue;
+            double e[3];
+            for (int a = 0; a < 3; a++) {
+                const double qlo = (N.q[2 * a + (sl >> 2)] >> (8 * (sl & 3))) & 0xff, qhi = (N.q[2 * (3 + a) + (sl >> 2)] >> (8 * (sl & 3))) & 0xff;
+                e[a] = (qhi - qlo) * step[a]; umn[a] = std::min(umn[a], qlo * step[a]); umx[a] = std::max(umx[a], qhi * step[a]);
+            }
+            ch[m++] = {e[0] * e[1] + e[1] * e[2] + e[2] * e[0], internal, (uint32_t)__builtin_popcount(nib)};
+            slots++;
+        }
+        double my_area = it.area;
+        if (my_area < 0) { const double e0 = umx[0] - umn[0], e1 = umx[1] - umn[1], e2 = umx[2] - umn[2]; my_area = root_area = e0 * e1 + e1 * e2 + e2 * e0; }
+        node_cost += my_area;
+        for (int k = 0; k < m; k++) {
+            if (ch[k].internal) st.push_back({N.child_base + rank++, ch[k].area});
+            else { tri_cost += ch[k].area * ch[k].cnt; hist[ch[k].cnt]++; }
+        }
+    }
+    node_cost /= root_area; tri_cost /= root_area; fill = (double)slots / (double)B.nodes8.size();
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+    const std::string which = argc > 1 ? argv[1] : "sponza";
+    int W = 480, Hh = 270, bounces = 4; bool check = false, lower = false; int whatif = 0;
+    for (int i = 2; i < argc; i++) {
+        std::string kv = argv[i]; const size_t eq = kv.find('=');
+        if (eq == std::string::npos) continue;
+        const std::string k = kv.substr(0, eq); const double v = atof(kv.c_str() + eq + 1);
+        if (k == "w") W = (int)v; else if (k == "h") Hh = (int)v; else if (k == "bounces") bounces = (int)v; else if (k == "check") check = v != 0; else if (k == "lower") lower = v != 0; else if (k == "whatif") whatif = (int)v; else if (k == "any_order") g_any_order = (int)v;
+        else if (!bvh_build_option(k.c_str(), v)) { fprintf(stderr, "unknown key %s\n", k.c_str()); return 2; }
+    }
+    Scene s;
+    if (which == "sponza") s = MakeSponzaClass();
+    else if (which == "bistro") s = MakeBistroClass();
+    else if (which == "garage") s = LoadObjScene({"tests/golden/garage.obj", "tests/golden/monke.obj"}, "tests/golden/");
+    else if (which == "cornell") s = MakeCornellBox();
+    else { fprintf(stderr, "scene?\n"); return 2; }
+    SceneHost Hs;
+    Hs.set_materials(s.materials.data(), (uint32_t)s.materials.size());
+    for (auto& m : s.models) { uint32_t id; if (!Hs.add_mesh(m.vertices.data(), (uint32_t)m.vertices.size(), m.indices.data(), (uint32_t)m.indices.size(), m.materialIDs.data(), &id)) { fprintf(stderr, "%s\n", Hs.err.c_str()); return 1; } }
+    for (auto& in : s.instances) { uint32_t id; Hs.add_instance(in.model, in.transform.data(), &id); }
+    BuiltScene B;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!Hs.build(B)) { fprintf(stderr, "build: %s\n", Hs.err.c_str()); return 1; }
+    const double build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    double nc, tc, fill; uint32_t hist[5];
+    wide_sah(B, nc, tc, fill, hist);
+    printf("any-hit order chosen by the commit-time probe: %u\n", B.any_order);
+    printf("%s: tris %zu refs %zu nodes2 %zu nodes8 %zu stack %u build %.2fs | wide SAH node %.2f tri %.2f | slots/node %.2f leaf hist 1:%u 2:%u 3:%u 4:%u\n", which.c_str(), B.shade.size(), B.tris8.size(),
+           B.nodes.size(), B.nodes8.size(), B.stack8, build_s, nc, tc, fill, hist[1], hist[2], hist[3], hist[4]);
+    // camera
+    float view[16], proj[16];
+    SceneViewProj(s, (float)W / Hh, view, proj);
+    float vI[16], pI[16]; mat4_inverse(view, vI); mat4_inverse(proj, pI);
+    auto mulp = [](const float* m, float x, float y, float z, float w, float* o) { for (int c = 0; c < 4; c++) o[c] = x * m[c] + y * m[4 + c] + z * m[8 + c] + w * m[12 + c]; };   // row-vector convention (DirectXMath)
+    const int npx = W * Hh;
+    std::vector<double> st_steps(bounces + 1, 0), st_tris(bounces + 1, 0), sh_steps(bounces + 1, 0), sh_tris(bounces + 1, 0); std::vector<size_t> cnt(bounces + 1, 0), shc(bounces + 1, 0), hitc(bounces + 1, 0);
+    // a point on the first light for shadow rays
+    V3 lightp{0, 0, 0}; bool have_light = !B.lights.empty();
+    const auto t1 = std::chrono::steady_clock::now();
+    size_t mism = 0; double low_steps = 0, low_tris = 0; double lev_all[16] = {0}, zero_all[16] = {0}; double g_occ[4] = {0, 0, 0, 0};
+#pragma omp parallel
+    {
+        std::vector<double> a(bounces + 1, 0), b(bounces + 1, 0), sa(bounces + 1, 0), sb(bounces + 1, 0); std::vector<size_t> c(bounces + 1, 0), sc(bounces + 1, 0), hc(bounces + 1, 0); size_t mm = 0; double la = 0, lb = 0; double levl[16] = {0}, zerol[16] = {0}; double occ_n = 0, occ_steps = 0, vis_n = 0, vis_steps = 0;
+#pragma omp for schedule(dynamic, 64)
+        for (int px = 0; px < npx; px++) {
+            const int x = px % W, y = px / W;
+            const float dx = ((x + 0.5f) / W) * 2.0f - 1.0f, dy = 1.0f - ((y + 0.5f) / Hh) * 2.0f;
+            float org[4], tgt[4], dir4[4];
+            mulp(vI, 0, 0, 0, 1, org); mulp(pI, dx, dy, 1, 1, tgt);
+            V3 tg = nrm(V3{tgt[0], tgt[1], tgt[2]}); mulp(vI, tg.x, tg.y, tg.z, 0, dir4);
+            V3 o{org[0], org[1], org[2]}, d = nrm(V3{dir4[0], dir4[1], dir4[2]});
+            float tmin = 1e-4f;
+            for (int bnc = 0; bnc <= bounces; bnc++) {
+                const Hit H = traverse<false>(B, o, d, tmin, 1e30f);
+                a[bnc] += H.steps; b[bnc] += H.tris; c[bnc]++;
+                if (whatif) { const float dxs = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x, dys = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y, dzs = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
+                    const V3 idir{1.0f / dxs, 1.0f / dys, 1.0f / dzs};
+                    WhatIf Wf{B, o, d, idir, (idir.x < 0 ? 1u : 0u) | (idir.y < 0 ? 2u : 0u) | (idir.z < 0 ? 4u : 0u), tmin, 1e30f, 0xffffffffu, 0, 0, whatif == 3 ? 0 : whatif, levl, zerol};      // 3: the device's order and culling (depth statistics), 4: visit by entry distance, no skip
+                    Wf.node(0); la += Wf.steps; lb += Wf.tris; if (Wf.bprim != H.prim) mm++; }
+                if (lower) { const Hit H2 = traverse<false>(B, o, d, tmin, 1e30f, H.prim == 0xffffffffu ? 1e30f : H.t); la += H2.steps; lb += H2.tris; }
+                if (H.prim == 0xffffffffu) break;
+                hc[bnc]++;
+                if (check) {      // brute force over all references
+                    float bt = 1e30f; uint32_t bp = 0xffffffffu;
+                    for (size_t i = 0; i < B.tris8.size(); i++) { float t, u, v; if (tri_test(o, d, B.tris8[i], tmin, 1e30f, t, u, v)) { const uint32_t g = f2u_(B.tris8[i].v0.w); if (t < bt || (t == bt && g < bp)) { bt = t; bp = g; } } }
+                    if (bp != H.prim || bt != H.t) mm++;
+                }
+                const TriGPU& Tg = B.tris8[H.slot];
+                V3 n = nrm(crs(V3{Tg.e1.x, Tg.e1.y, Tg.e1.z}, V3{Tg.e2.x, Tg.e2.y, Tg.e2.z}));
+                if (dt(n, d) > 0) n = n * -1.0f;
+                const V3 pos = o + d * H.t;
+                o = pos + n * 2e-5f;
+                // shadow ray towards a point on a light (any-hit), like NEE
+                if (have_light) {
+                    const uint32_t li = hash32((uint32_t)px, 77u + bnc) % (uint32_t)B.lights.size(); const LightGPU& Lg = B.lights[li];
+                    float r1 = rnd((uint32_t)px, 100u + bnc), r2 = rnd((uint32_t)px, 200u + bnc); if (r1 + r2 > 1) { r1 = 1 - r1; r2 = 1 - r2; }
+                    const V3 lp{Lg.xv[0] + r1 * (Lg.yv[0] - Lg.xv[0]) + r2 * (Lg.zv[0] - Lg.xv[0]), Lg.xv[1] + r1 * (Lg.yv[1] - Lg.xv[1]) + r2 * (Lg.zv[1] - Lg.xv[1]), Lg.xv[2] + r1 * (Lg.yv[2] - Lg.xv[2]) + r2 * (Lg.zv[2] - Lg.xv[2])};
+                    V3 sd = lp - o; const float dist = sqrtf(dt(sd, sd)); sd = sd * (1.0f / dist);
+                    if (dt(sd, n) > 0) { const Hit S = traverse<true>(B, o, sd, 2e-5f, dist - 1e-4f); sa[bnc] += S.steps; sb[bnc] += S.tris; sc[bnc]++; if (S.prim == 0) { occ_n++; occ_steps += S.steps; } else { vis_n++; vis_steps += S.steps; } }
+                }
+                // cosine-sampled bounce
+                const float u1 = rnd((uint32_t)px, 300u + bnc), u2 = rnd((uint32_t)px, 400u + bnc);
+                const float r = sqrtf(u1), ph = 6.2831853f * u2;
+                const V3 tx = nrm(fabsf(n.x) > 0.5f ? crs(n, V3{0, 1, 0}) : crs(n, V3{1, 0, 0})), ty = crs(n, tx);
+                d = nrm(tx * (r * cosf(ph)) + ty * (r * sinf(ph)) + n * sqrtf(std::max(0.0f, 1.0f - u1)));
+                tmin = 2e-5f;
+            }
+        }
+#pragma omp critical
+        { for (int i = 0; i <= bounces; i++) { st_steps[i] += a[i]; st_tris[i] += b[i]; cnt[i] += c[i]; sh_steps[i] += sa[i]; sh_tris[i] += sb[i]; shc[i] += sc[i]; hitc[i] += hc[i]; } mism += mm; low_steps += la; low_tris += lb; g_occ[0] += occ_n; g_occ[1] += occ_steps; g_occ[2] += vis_n; g_occ[3] += vis_steps; for (int i = 0; i < 16; i++) { lev_all[i] += levl[i]; zero_all[i] += zerol[i]; } }
+    }
+    const double sim_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+    double ts = 0, tt = 0, ss = 0, stt = 0; size_t tc_ = 0, sc_ = 0;
+    for (int i = 0; i <= bounces; i++) {
+        printf("  bounce %d: rays %zu hit %.3f steps/ray %.2f tris/ray %.2f | shadow rays %zu steps/ray %.2f tris/ray %.2f\n", i, cnt[i], cnt[i] ? (double)hitc[i] / cnt[i] : 0.0, cnt[i] ? st_steps[i] / cnt[i] : 0.0, cnt[i] ? st_tris[i] / cnt[i] : 0.0,
+               shc[i], shc[i] ? sh_steps[i] / shc[i] : 0.0, shc[i] ? sh_tris[i] / shc[i] : 0.0);
+        ts += st_steps[i]; tt += st_tris[i]; tc_ += cnt[i]; ss += sh_steps[i]; stt += sh_tris[i]; sc_ += shc[i];
+    }
+    // cost proxy in VALU lane-slots per ray: node step 205 at 47/64 lanes, triangle test 70 at 24/64 lanes (profiles/r02_traversal.md)
+    const double cs = ts / tc_, ct = tt / tc_, hs = sc_ ? ss / sc_ : 0, ht = sc_ ? stt / sc_ : 0;
+    printf("  ALL closest: steps/ray %.3f tris/ray %.3f cost %.0f | shadow: steps/ray %.3f tris/ray %.3f cost %.0f | sim %.1fs%s\n", cs, ct, cs * 205 * 64 / 47 + ct * 70 * 64 / 24, hs, ht, hs * 205 * 64 / 47 + ht * 70 * 64 / 24, sim_s,
+           check ? (mism ? "  BRUTE-FORCE MISMATCH" : "  brute force: equal") : "");
+    printf("  shadow rays: occluded %.3f (steps/ray %.2f), visible steps/ray %.2f\n", g_occ[0] / std::max(1.0, g_occ[0] + g_occ[2]), g_occ[1] / std::max(1.0, g_occ[0]), g_occ[3] / std::max(1.0, g_occ[2]));
+    if (whatif) printf("  what-if %d (1: skip popped children beyond the best hit; 2: + visit by entry distance): steps/ray %.3f tris/ray %.3f mismatches %zu\n", whatif, low_steps / tc_, low_tris / tc_, mism);
+    if (whatif) { printf("  steps per ray by depth (zero-hit share):"); for (int i = 0; i < 16 && lev_all[i] > 0; i++) printf(" %d: %.2f (%.0f%%)", i, lev_all[i] / tc_, 100.0 * zero_all[i] / lev_all[i]); printf("\n"); }
+    if (lower) printf("  with the closest distance known in advance (bound for any visiting order): steps/ray %.3f tris/ray %.3f\n", low_steps / tc_, low_tris / tc_);
+    if (check && mism) { printf("  mismatches: %zu\n", mism); return 1; }
+    return 0;
+}
