@@ -78,7 +78,8 @@ typedef struct rtx_stats {
     double   render_ms;                                   /* hipEvent time of the whole rtx_render on its stream */
     uint32_t bvh_nodes, triangles, lights, materials;
     uint64_t primary_hits;                                /* camera rays that hit the scene (items of the bounce-0 shading launch) */
-    uint32_t bvh_refits, reserved;                        /* commits since the last full BVH build that only refitted boxes */
+    uint32_t bvh_refits, bvh_refs;                        /* commits since the last full BVH build that only refitted boxes; leaf entries of the tree (= triangles unless
+                                                             spatial splits, RTX_OPT_BVH_SPLIT, reference some from several leaves) */
 } rtx_stats;
 
 enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents (rtx_stats.kernel_ms) */

@@ -74,6 +74,10 @@ int  rtxh_bvh8_stats(const float* world_tris9, uint32_t ntris, uint32_t hist[6],
    "leaf_stop", "split" (spatial splits, overlap threshold as a fraction of the scene's surface area), "split_budget", "reinsert" (passes), "reinsert_frac", "slot_assign",
    "tri_cost".  Returns 0, or RTX_ERR_INVALID for an unknown key */
 int  rtxh_bvh_option(const char* key, double value);
+/* the device traversal REPLAYED on the host over the wide tree the current options build for these triangles (node steps and triangle tests per ray: tools/bvh_lab.cpp
+   judges builder changes by them; tests compare its hits with brute force): out4 = (t, node steps, triangle tests, global triangle id bits / 0xffffffff) per ray
+   (origin, tmin, direction, tmax); any != 0: first hit found in visiting order any_order (RTX_OPT_ANYHIT_ORDER).  *refs_out = leaf entries (> ntris after spatial splits) */
+int  rtxh_bvh_replay(const float* world_tris9, uint32_t ntris, const float* rays8, uint32_t nrays, int any, uint32_t any_order, float* out4, uint32_t* refs_out);
 /* same invariants after building on `before` and REFITTING (topology kept) to `after` (TLAS refit, Renderer.cpp:594) */
 int  rtxh_bvh_refit_check(const float* before_tris9, const float* after_tris9, uint32_t ntris);
 

@@ -69,7 +69,7 @@ class Stats(C.Structure):
                 ("paths", C.c_uint64), ("kernel_ms", C.c_double * K_COUNT), ("kernel_launches", C.c_uint64 * K_COUNT),
                 ("kernel_items", C.c_uint64 * K_COUNT), ("render_ms", C.c_double),
                 ("bvh_nodes", C.c_uint32), ("triangles", C.c_uint32), ("lights", C.c_uint32), ("materials", C.c_uint32),
-                ("primary_hits", C.c_uint64), ("bvh_refits", C.c_uint32), ("reserved", C.c_uint32)]
+                ("primary_hits", C.c_uint64), ("bvh_refits", C.c_uint32), ("bvh_refs", C.c_uint32)]
 
     @property
     def rays(self):
@@ -169,6 +169,7 @@ _sig("rtxh_bvh_refit_check", C.c_int, _vp, _vp, _u32)
 _sig("rtxh_bvh8_check", C.c_int, _vp, _u32, _u32p, _u32p)
 _sig("rtxh_bvh8_stats", C.c_int, _vp, _u32, _vp, _u32p)
 _sig("rtxh_bvh_option", C.c_int, C.c_char_p, C.c_double)
+_sig("rtxh_bvh_replay", C.c_int, _vp, _u32, _vp, _u32, C.c_int, _u32, _vp, _u32p)
 _sig("rtxh_scene_small_occluders", C.c_int, _vp, _u32p)
 _sig("rtxh_write_png", C.c_int, C.c_char_p, _vp, _u32, _u32)
 _sig("rtxh_write_ppm", C.c_int, C.c_char_p, _vp, _u32, _u32)
@@ -387,6 +388,22 @@ def bvh8_stats(world_tris):
     hist = np.zeros(6, np.uint32); nodes = _u32()
     rc = lib.rtxh_bvh8_stats(_ptr(w), len(w), _ptr(hist), C.byref(nodes))
     return rc, hist, nodes.value
+
+
+def bvh_option(key, value):
+    """process-wide builder default (csrc/rtx_scene_host.hpp BvhBuildOptions); contexts created afterwards start with it"""
+    if lib.rtxh_bvh_option(key.encode(), float(value)) != 0:
+        raise RtxError("unknown BVH builder option " + key)
+
+
+def bvh_replay(world_tris, rays8, any_hit=False, any_order=0):
+    """host replay of the device traversal on the tree the current builder options give: (hits (n, 4): t, node steps, triangle tests, id bits; leaf entries)"""
+    w = _f32(world_tris).reshape(-1, 9); r = _f32(rays8).reshape(-1, 8)
+    out = np.zeros((len(r), 4), np.float32); refs = _u32()
+    rc = lib.rtxh_bvh_replay(_ptr(w), len(w), _ptr(r), len(r), int(any_hit), any_order, _ptr(out), C.byref(refs))
+    if rc != 0:
+        raise RtxError("rtxh_bvh_replay failed: %d" % rc)
+    return out, refs.value
 
 
 def bvh8_check(world_tris):

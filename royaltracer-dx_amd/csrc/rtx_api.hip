@@ -341,7 +341,7 @@ static int finalise_scene(rtx_ctx* c) {
         while (s.lds_nodes > 9u && fit(s.lds_nodes) < target) s.lds_nodes--;
         if (getenv("RTX_DEBUG_LDS")) fprintf(stderr, "[rtx] stack_depth %u workgroups per CU %u, %u nodes staged, %zu B of LDS\n", s.stack_depth, target, s.lds_nodes, trace_lds_bytes(s));
     }
-    c->stats.bvh_refits = B.refit_count; c->stats.bvh_nodes = s.nnodes; c->stats.triangles = s.ntris; c->stats.lights = s.nlights; c->stats.materials = s.nmat;
+    c->stats.bvh_refits = B.refit_count; c->stats.bvh_nodes = s.nnodes; c->stats.triangles = (uint32_t)B.shade.size(); c->stats.bvh_refs = s.ntris; c->stats.lights = s.nlights; c->stats.materials = s.nmat;
     c->committed = true;
     return RTX_OK;
 }

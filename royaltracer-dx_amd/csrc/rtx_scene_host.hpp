@@ -20,8 +20,9 @@ struct BvhBuildOptions {
     uint32_t leaf_stop = 2;       // nodes with at most this many references are not split further (the wide collapse merges small subtrees into leaf slots anyway)
     double   split_alpha = 0.0;   // spatial splits where the object split's two sides overlap by more than this fraction of the scene's surface area (0 = never)
     double   split_budget = 0.3;  // ... and at most this many extra references, as a fraction of the triangle count
-    int      reinsert_passes = 0; // passes of the insertion-based topology optimisation
-    double   reinsert_frac = 1.0; // share of the nodes (largest boxes first) a pass tries to re-insert
+    int      reinsert_passes = 2; // passes of the insertion-based topology optimisation
+    double   reinsert_frac = 1.0; // share of the nodes (largest boxes first) a pass tries to re-insert ...
+    uint32_t reinsert_cap = 200000; // ... and at most this many of them
     int      slot_assign = 0;     // collapse_bvh8: children to octant slots greedily (0) or by the exact maximum of the summed diagonal projections (1)
     double   tri_cost = 0.7;      // collapse_bvh8: cost of a triangle test relative to a node step
 };

@@ -221,6 +221,28 @@ int rtxh_bvh8_check(const float* wt, uint32_t ntris, uint32_t* nodes8_out, uint3
     return 0;
 }
 
+// the device traversal replayed on the host (csrc/rtx_scene_host.cpp: replay_trace) over the wide tree the CURRENT builder options give for these triangles, leaf
+// boxes padded as rtx_commit_scene pads them: out4 = (t, node steps, triangle tests, global id bits or 0xffffffff) per ray (o.xyz, tmin, d.xyz, tmax)
+int rtxh_bvh_replay(const float* wt, uint32_t ntris, const float* rays8, uint32_t nrays, int any, uint32_t any_order, float* out4, uint32_t* refs_out) {
+    std::vector<float> w(wt, wt + (size_t)ntris * 9);
+    float scale = 1.0f; for (float x : w) scale = std::max(scale, std::fabs(x));
+    rtx::BuiltScene B; uint32_t depth = 0;
+    rtx::build_bvh(w, 2e-6f * scale, B.nodes, B.leaf_order, depth);
+    if (!rtx::collapse_bvh8(B.nodes, B.nodes8, B.tri_slots8, B.stack8)) return 30;
+    B.tris8.resize(B.tri_slots8.size());
+    for (size_t i = 0; i < B.tri_slots8.size(); i++) {
+        const uint32_t g = B.leaf_order[B.tri_slots8[i]]; const float* t = &w[(size_t)g * 9];
+        B.tris8[i].v0 = {t[0], t[1], t[2], rtx::u2f(g)}; B.tris8[i].e1 = {t[3] - t[0], t[4] - t[1], t[5] - t[2], 0.0f}; B.tris8[i].e2 = {t[6] - t[0], t[7] - t[1], t[8] - t[2], 0.0f};
+    }
+    if (refs_out) *refs_out = (uint32_t)B.tris8.size();
+    for (uint32_t i = 0; i < nrays; i++) {
+        const float* r = rays8 + (size_t)i * 8;
+        const rtx::ReplayHit H = rtx::replay_trace(B, r, r + 4, r[3], r[7], any != 0, any_order);
+        out4[(size_t)i * 4] = H.t; out4[(size_t)i * 4 + 1] = (float)H.steps; out4[(size_t)i * 4 + 2] = (float)H.tris; out4[(size_t)i * 4 + 3] = rtx::u2f(H.prim);
+    }
+    return 0;
+}
+
 int rtxh_bvh_option(const char* key, double value) { return rtx::bvh_build_option(key, value) ? RTX_OK : RTX_ERR_INVALID; }
 
 // shape of the wide tree: hist[0..4] = leaf slots holding 0 (unused slot) / 1 / 2 / 3 / 4 triangles, hist[5] = internal child slots

@@ -466,17 +466,24 @@ def soup(kind, n, rng):
     return t.astype(np.float32)
 
 
+@pytest.mark.parametrize("builder", ["default", "split"])
 @pytest.mark.parametrize("kind", ["random", "coplanar", "far_offset", "needles", "duplicates", "mixed_scale"])
-def test_wide_bvh_equals_brute_force_on_hostile_soups(rt, orc, kind):
+def test_wide_bvh_equals_brute_force_on_hostile_soups(rt, orc, kind, builder):
     """the compressed 8-wide BVH (byte-quantised child boxes, octant-ordered traversal) must return exactly the brute-force
-    minimum over all triangles, ties to the lowest id, on geometry chosen to stress the quantisation and its margins"""
+    minimum over all triangles, ties to the lowest id, on geometry chosen to stress the quantisation and its margins —
+    with the default builder and with spatial splits on (a triangle referenced from several leaves, each with the box of its part)"""
     rng = np.random.default_rng(sum(map(ord, kind)) + 7 + FUZZ_SEED)
     n = 6000
     t = soup(kind, n, rng)
     sc = SoupScene(t)
-    c = rt.Context(0); c.upload(sc, 1.0)
+    c = rt.Context(0)
+    if builder == "split":
+        c.set_option(rt.OPT_BVH_SPLIT, 1000); c.set_option(rt.OPT_BVH_REINSERT, 3)      # overlap threshold 1e-6 of the scene's area, three re-insertion passes
+    c.upload(sc, 1.0)
     o = orc.Oracle().load(sc, 1.0)
-    assert c.stats().triangles == len(t)
+    assert c.stats().triangles == len(t) and c.stats().bvh_refs >= len(t)                # leaf entries: spatial splits add references
+    assert (c.stats().bvh_refs == len(t)) if builder == "default" else (c.stats().bvh_refs > len(t) or kind != "needles")
+    assert c.validate_bvh() == 0
     lo, hi = t.reshape(-1, 3).min(0), t.reshape(-1, 3).max(0)
     ext = float((hi - lo).max())
     m = 60000
@@ -516,6 +523,9 @@ def test_wide_bvh_equals_brute_force_on_hostile_soups(rt, orc, kind):
     sh = rays.copy(); sh[:, 7] = rng.uniform(0.05, 1.0, m).astype(np.float32) * ext
     ga, ba = c.trace_any(sh), o.trace_any(sh, mode=0)
     assert int((ga != ba).sum()) <= 5 and np.array_equal(ga, o.trace_any(sh, mode=1))
+    for order in (0, 1, 2):                                               # any-hit is existence: the visiting order of a node's children changes no answer
+        c.set_option(rt.OPT_ANYHIT_ORDER, order)
+        assert np.array_equal(c.trace_any(sh), ga), f"any-hit order {order}"
     c.close()
 
 
@@ -723,16 +733,19 @@ def test_restir_wavefront_equals_literal_on_a_bvh_scene_at_scale(rt, orc):
     assert total[2] > 4 * W * H and total[1] > 2 * W * H
 
 
+@pytest.mark.parametrize("split", [0, 10000], ids=["object_splits", "spatial_splits"])
 @pytest.mark.parametrize("gpu_refit", [1, 0])
-def test_animated_instance_refit_parity(rt, orc, golden_dir, gpu_refit):
+def test_animated_instance_refit_parity(rt, orc, golden_dir, gpu_refit, split):
     """rtx_set_instance_transform + rtx_commit_scene refits the BVH (reference: TLAS refit every frame); the images of
     the bounce-loop tracer and of the ReSTIR pipeline (which reprojects through prevObjectToWorld) stay identical to the
     oracle, which rebuilds its own BVH from scratch.  gpu_refit=1: k_refit_tris / k_refit_nodes re-derive the world triangles
-    and re-quantise the resident wide nodes; gpu_refit=0: host refit + re-collapse + upload"""
+    and re-quantise the resident wide nodes; gpu_refit=0: host refit + re-collapse + upload.  spatial_splits: the tree was built with RTX_OPT_BVH_SPLIT, so
+    triangles are referenced from several leaves; a refit gives every reference the bounds of its whole (moved) triangle"""
     import os
     sc = rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")
     W, H = 80, 48
-    c = rt.Context(0); c.set_option(rt.OPT_GPU_REFIT, gpu_refit); c.upload(sc, W / H); c.set_camera(*sc.view_proj(W / H))
+    c = rt.Context(0); c.set_option(rt.OPT_GPU_REFIT, gpu_refit); c.set_option(rt.OPT_BVH_SPLIT, split); c.upload(sc, W / H); c.set_camera(*sc.view_proj(W / H))
+    assert c.stats().triangles == sc.num_triangles and (c.stats().bvh_refs > sc.num_triangles) == (split > 0)
     o = orc.Oracle().load(sc, W / H); o.set_camera(*sc.view_proj(W / H))
     acc_o, st = np.zeros((H, W, 4), np.float32), None
     c.restir_reset(); c.clear(W, H)

@@ -167,6 +167,87 @@ def test_bvh_builder_invariants(rt, cornell):
     assert rt.bvh8_check(np.zeros((0, 9), np.float32))[0] == 0
 
 
+BUILDER_DEFAULTS = {"bins": 16, "sweep": 0, "leaf_stop": 2, "split": 0.0, "split_budget": 0.3, "reinsert": 2, "reinsert_frac": 1.0, "reinsert_cap": 200000, "slot_assign": 0, "tri_cost": 0.7}
+
+
+@pytest.fixture
+def builder_options(rt):
+    """set BVH builder knobs for one test; the process-wide defaults are restored afterwards"""
+    def apply(**kw):
+        for k, v in kw.items():
+            rt.bvh_option(k, v)
+    yield apply
+    for k, v in BUILDER_DEFAULTS.items():
+        rt.bvh_option(k, v)
+
+
+def _lab_soup(kind, n, rng):
+    c = rng.uniform(-1, 1, (n, 1, 3))
+    if kind == "needles":                # long thin triangles: the case spatial splits exist for
+        a = rng.uniform(-1, 1, (n, 3)); d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        return np.stack([a, a + 1.5 * d, a + 1.5 * d + rng.normal(scale=0.002, size=(n, 3))], axis=1).astype(np.float32)
+    if kind == "mixed":                  # a few room-sized triangles over a carpet of small ones
+        small = c[: n - 12] * np.array([1.0, 0.02, 1.0]) + rng.normal(scale=0.02, size=(n - 12, 3, 3))
+        big = rng.uniform(-1.2, 1.2, (12, 3, 3))
+        return np.concatenate([small, big]).astype(np.float32)
+    return (c + rng.normal(scale=0.03, size=(n, 3, 3))).astype(np.float32)
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(reinsert=0), dict(split=1e-5, sweep=64), dict(split=1e-7, split_budget=2.0, reinsert=3), dict(bins=8, leaf_stop=1, slot_assign=1)],
+                         ids=["default", "no_reinsert", "split_sweep", "split_heavy", "misc"])
+@pytest.mark.parametrize("kind", ["random", "needles", "mixed"])
+def test_builder_variants_keep_the_tree_valid_and_the_replayed_traversal_exact(rt, orc, builder_options, kind, opts):
+    """Every builder knob (spatial splits, re-insertion, sweep SAH, slot assignment) changes the tree and never an answer: the validators accept the tree, and the
+    device traversal replayed on the host returns the brute-force closest hit (minimum over all triangles, ties to the lowest id) of the oracle — also where a
+    triangle is referenced from several leaves."""
+    rng = np.random.default_rng(sum(map(ord, kind)) + len(opts))
+    t = _lab_soup(kind, 3000, rng)
+    builder_options(**opts)
+    rc, nodes, depth, leaf = rt.bvh_check(t.reshape(-1, 9))
+    assert rc == 0 and leaf <= 4, (rc, leaf)
+    rc8, nodes8, stack8 = rt.bvh8_check(t.reshape(-1, 9))
+    assert rc8 == 0 and stack8 <= 30, (rc8, stack8)
+    m = 6000
+    lo, hi = t.reshape(-1, 3).min(0), t.reshape(-1, 3).max(0)
+    org = rng.uniform(lo - 0.1, hi + 0.1, (m, 3)); d = rng.normal(size=(m, 3))
+    pick = rng.integers(0, len(t), m // 2); w = rng.dirichlet((1, 1, 1), m // 2); w[: m // 8] = np.eye(3)[rng.integers(0, 3, m // 8)]
+    d[: m // 2] = (t[pick] * w[:, :, None]).sum(1) - org[: m // 2]
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)
+    rays = np.zeros((m, 8), np.float32); rays[:, 0:3], rays[:, 3], rays[:, 4:7], rays[:, 7] = org, 1e-5, d, 1e30
+
+    class Soup:
+        materials = np.zeros((2, 32), np.float32)
+        def __init__(self, tris):
+            n = len(tris); v = np.zeros((3 * n, 7), np.float32); v[:, 0:3] = tris.reshape(-1, 3)
+            self.meshes = [(v, np.arange(3 * n, dtype=np.uint32), np.ones(3 * n, np.uint32))]
+            self.instances = [(0, np.eye(4, dtype=np.float32).reshape(16))]
+        def view_proj(self, aspect):
+            e = np.eye(4, dtype=np.float32).reshape(16); return e, e
+
+    ref = orc.Oracle().load(Soup(t), 1.0).trace_closest(rays, mode=0)                 # brute force over all triangles
+    got, refs = rt.bvh_replay(t, rays)
+    if opts.get("split"):
+        assert refs > len(t) or kind == "random", "spatial splits added no reference"
+    else:
+        assert refs == len(t)
+    hit = bits(ref)[:, 3] != 0xFFFFFFFF
+    assert hit.mean() > 0.3
+    # float Moeller-Trumbore can accept a point nowhere near a sliver (DESIGN.md section 2): brute force reports it, every BVH culls it; excluded like in the GPU test
+    P = rays[hit, 0:3].astype(np.float64) + ref[hit, 0:1].astype(np.float64) * rays[hit, 4:7].astype(np.float64)
+    tv = t[bits(ref)[hit, 3].astype(np.int64)].astype(np.float64)
+    Q = tv[:, 0] + ref[hit, 1:2] * (tv[:, 1] - tv[:, 0]) + ref[hit, 2:3] * (tv[:, 2] - tv[:, 0])
+    bogus = np.zeros(m, bool); bogus[np.nonzero(hit)[0]] = np.abs(P - Q).max(1) > 0.02 * float((hi - lo).max())
+    assert bogus.sum() <= 3
+    ok = ~bogus
+    assert np.array_equal(bits(got)[ok, 3], bits(ref)[ok, 3]), "closest-hit triangle ids differ from brute force"
+    assert np.array_equal(bits(got)[hit & ok, 0], bits(ref)[hit & ok, 0]), "closest-hit distances differ from brute force"
+    # any-hit: the same answer in every visiting order
+    sh = rays.copy(); sh[:, 7] = rng.uniform(0.05, 2.0, m).astype(np.float32)
+    occ = [bits(rt.bvh_replay(t, sh, any_hit=True, any_order=k)[0])[:, 3] != 0xFFFFFFFF for k in (0, 1, 2)]
+    assert np.array_equal(occ[0], occ[1]) and np.array_equal(occ[0], occ[2])
+    assert occ[0].mean() > 0.02
+
+
 # ---- the C-ABI library -------------------------------------------------------------------------
 def declared_functions(header):
     src = re.sub(r"/\*.*?\*/", "", open(header).read(), flags=re.S)
