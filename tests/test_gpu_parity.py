@@ -263,7 +263,7 @@ def test_pack_unpack_kernels_match_host_layout(rt, cornell_pair):
         got = t.cpu().numpy().reshape(-1, 4)
         assert np.array_equal(bits(got), bits(sharding.pack(whole, TS, r, world)))
         slabs.append(t)
-    allslabs = torch.cat(slabs)
+    allslabs = torch.cat(slabs); torch.cuda.synchronize()               # (torch's stream vs the context's own stream)
     ctx.clear(W, H)
     ctx.unpack_tiles(rt.Params(shard_rank=0, shard_count=world, **base), allslabs.data_ptr())
     assert np.array_equal(bits(ctx.read_accum()), bits(whole))
@@ -684,6 +684,7 @@ def test_restir_on_shards_equals_the_unsharded_frames(rt, orc, golden_dir, nshar
             c.restir_pack_state(p, slab.data_ptr()); slabs.append(slab)
         torch.cuda.synchronize()
         gathered = torch.cat(slabs)                                      # what ONE all_gather_into_tensor leaves on every rank
+        torch.cuda.synchronize()                                         # the cat runs on torch's stream, the unpack on each context's own (non-blocking) stream: order them
         for r, c in enumerate(ranks):
             c.restir_unpack_state(rt.Params(frame_seed=70 + k, shard_rank=r, shard_count=nshards, **base), gathered.data_ptr())
     own = sharding.owner_map(W, H, TS, nshards, bool(blocks))
