@@ -476,7 +476,7 @@ def main():
                "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "ms_per_step_by_rank": [round(t * 1e3 / max(args.steps, 1), 3) for t in dt_ranks],
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": "f32", "data": "asset (assets/*.obj loaded through the OBJ / MTL reader)" if scene_source.startswith("asset:") else "synthetic",
                "config": {"workload": args.workload, "scene": scene_source, "width": W, "height": H, "spp": spp,
                           "max_bounces": bounces, "nee_samples": nee, "rr_start": 3, "flags": flags,
                           "triangles": int(scene.num_triangles), "parallelism": f"pixel-tiles/{world}", "tile_size": TILE,

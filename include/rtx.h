@@ -61,7 +61,7 @@ typedef struct rtx_params {
                                      and by the literal pass-1 / ReSTIR modes.  Off: every result is the reference-faithful one */
 
 #define RTX_FLAG_BLOCK_TILES  8u  /* sharding: the tiles of a shard form ONE rectangle (the shard_count ranks as a gx x gy grid of blocks, gx * gy = shard_count chosen
-                                     for the smallest block perimeter) instead of tile t -> rank t mod shard_count.  Same pixels, same image; what changes is who owns
+                                     for the smallest block perimeter; of two grids with the same perimeter the one with fewer columns) instead of tile t -> rank t mod shard_count.  Same pixels, same image; what changes is who owns
                                      which tile: round-robin balances a path-traced frame, blocks keep the 20-px halo of a ReSTIR frame small (rtx_render_restir).
                                      Every call that takes rtx_params (render, pack / unpack, slab sizes) follows the flag */
 
@@ -108,6 +108,8 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
        RTX_OPT_RESTIR_LANES = 22,    /* 2 (default): the pixels of a ReSTIR frame are processed as two independent halves on two streams (passes 1 + 2, then pass 3), so that the
                                         many short dependent launches of one half fill the launch tails of the other; 1: one chain.  Off while RTX_OPT_KERNEL_TIMING is on.
                                         Results identical */
+       RTX_OPT_RESTIR_LANE_MIN = 29, /* pixel lists shorter than this many entries run as ONE chain whatever RTX_OPT_RESTIR_LANES says (default 65 536: below that the second stream has
+                                        nothing to hide); tests lower it to exercise the cross-stream ordering on small frames */
        RTX_OPT_RESTIR_CHUNKS = 20,   /* tuning: 256-pixel chunks per workgroup (= private sub-queue) of the ReSTIR stages, default 4 */
        RTX_OPT_OVERLAP_SHADOW = 18,  /* 1 (default): general scenes run the shadow-ray kernel of bounce b on a second (internal) stream beside the closest-hit kernel of
                                         bounce b + 1; everything is joined into the context's stream before rtx_render returns.  Off while RTX_OPT_KERNEL_TIMING is on

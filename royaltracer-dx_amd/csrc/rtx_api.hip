@@ -74,6 +74,7 @@ struct rtx_ctx {
     uint32_t restir_chunks = 4;     // RTX_OPT_RESTIR_CHUNKS: 256-item chunks per sub-queue (= workgroup) of the ReSTIR stages
     struct RsArea { DevBuf state, hit, cls, fin, cold, occ, cand, sho, shd, pay, cnt; } rs_area[4];      // one per pipeline lane (RTX_OPT_RESTIR_LANES)
     hipStream_t lane_stream[3] = {nullptr, nullptr, nullptr};      // lanes 1 .. 3 (lane 0 runs on the context's stream)
+    uint32_t restir_lane_min = 1u << 16;   // RTX_OPT_RESTIR_LANE_MIN: pixel lists shorter than this run as one chain
     uint32_t restir_lanes = 2;      // RTX_OPT_RESTIR_LANES: the work list of a ReSTIR frame as 1 .. 4 independent parts on as many streams (the tails of one part's many short launches fill with the others' work)
     // options
     bool timing = false; uint64_t paths_per_batch = 128u << 20; int lds_nodes_opt = -1; bool small_scene = true; bool fused = true; int stack_private = -1;
@@ -174,6 +175,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_SHADE_DENSE: c->shade_dense = (int)value; c->dsc.shade_dense = value > 0 ? 1u : 0u; return RTX_OK;
     case RTX_OPT_OCCLUDER_CACHE: c->occluder_cache = value != 0; c->dsc.occluder_cache = c->occluder_cache; return RTX_OK;
     case RTX_OPT_RESTIR_WAVEFRONT: c->restir_wave = value != 0; return RTX_OK;
+    case RTX_OPT_RESTIR_LANE_MIN: if (value < 256 || value > (1ll << 31)) { c->err = "restir_lane_min must be in [256, 2^31]"; return RTX_ERR_INVALID; } c->restir_lane_min = (uint32_t)value; return RTX_OK;
     case RTX_OPT_RESTIR_LANES: if (value < 1 || value > 4) { c->err = "restir_lanes must be in [1, 4]"; return RTX_ERR_INVALID; } c->restir_lanes = (uint32_t)value; return RTX_OK;
     case RTX_OPT_RESTIR_CHUNKS: if (value < 1 || value > 64) { c->err = "restir_chunks must be in [1, 64]"; return RTX_ERR_INVALID; } c->restir_chunks = (uint32_t)value; return RTX_OK;
     case RTX_OPT_TRACE_SCHED: if (value > 7) { c->err = "trace_sched must be in [0, 7]"; return RTX_ERR_INVALID; } c->trace_sched = (uint32_t)value; c->dsc.trace_sched = c->trace_sched; return RTX_OK;
@@ -394,7 +396,9 @@ int rtx_clear_accum(rtx_ctx* c, uint32_t w, uint32_t h) {
 
 // the ONE rule for the shard tiling, shared by every entry point that takes rtx_params (render, pack / unpack, rtx_shard_slab_bytes):
 // tile_size a power of two in [16, 1024] (0 => 64), shard_rank < shard_count, the local slot count fits 31 bits.  All in 64-bit arithmetic.
-// RTX_FLAG_BLOCK_TILES: the ranks form a gx x gy grid of tile rectangles, gx gy = shard_count with the smallest rectangle perimeter (ties: the wider grid).
+// RTX_FLAG_BLOCK_TILES: the ranks form a gx x gy grid of tile rectangles, gx gy = shard_count with the smallest rectangle perimeter; on a TIE the
+// first factorisation in ascending gx wins, i.e. the grid with FEWER columns (taller).  royaltracer-dx_amd/sharding.py block_grid mirrors this loop line for line — pack / unpack and the slab
+// sizes of all ranks depend on both sides agreeing, so change them together (tests/test_multigpu_gloo.py::test_block_grid_tie_goes_to_the_grid_with_fewer_columns pins the choice).
 static void block_grid(uint64_t TX, uint64_t TY, uint32_t N, uint32_t& gx, uint32_t& gy) {
     double best = 1e300; gx = N; gy = 1;
     for (uint32_t a = 1; a <= N; a++) {
@@ -466,10 +470,6 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
 
     const uint32_t nee = c->dsc.nlights ? p->nee_samples : 0;
     uint32_t bspp = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->spp, c->paths_per_batch / f.npl));
-    const uint64_t cap64 = (uint64_t)f.npl * bspp;
-    if (cap64 > 0x7FFFFFFFull) { c->err = "render: batch too large"; return RTX_ERR_INVALID; }
-    const uint32_t cap = (uint32_t)cap64;
-    HIPCHK(c, c->d_rad.ensure((size_t)cap * 16));
     // work distribution: G workgroups, each with a private sub-queue (no global atomics in the loop)
     // sub-queues per CU: shorter tails with more, but more per-workgroup overhead; the fused tiny-scene kernels (5 workgroups resident per
     // CU, longest-first dispatch, all bounces >= 1 in one launch) measured 18.39 / 18.15 / 18.13 / 18.30 / 18.36 ms at 24 / 32 / 40 / 48 / 64
@@ -481,25 +481,43 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     // 1080p frame (16 200 chunks at 16 spp) ran 7.29 / 6.71 / 6.30 / 6.09 / 6.08 ms with 32 / 24 / 16 / 12 / 8 sub-queues per CU (C3), Cornell at 64 spp 2.54 / 2.41 ms with 40 / 16
     // (tools/shard_kernels.py): short sub-queues leave the persistent waves of a workgroup half empty, and every round of workgroups costs one ray latency
     const bool tiny_fused = c->dsc.nsmall && c->fused;
-    const uint32_t nchunks = f.chunks_per_sample * bspp;
-    const uint32_t bpc_hi = tiny_fused ? 40u : 32u, per_wg = tiny_fused ? 16u : 8u;
-    const uint32_t bpc = c->blocks_per_cu ? c->blocks_per_cu
-                                          : std::max<uint32_t>(8u, std::min<uint32_t>(bpc_hi, (nchunks / per_wg + (uint32_t)c->num_cus - 1u) / (uint32_t)c->num_cus));
-    const uint32_t max_blocks = (uint32_t)c->num_cus * bpc;
-    const uint32_t G = std::max<uint32_t>(1, std::min<uint32_t>(nchunks, max_blocks));
-    // tapered sub-queue sizes (taper_row_width, rtx_kernels.hpp); needs a few chunks in the shortest sub-queue to mean anything.  The fused tiny-scene kernels take their
-    // sub-queues longest first anyway (k_order_queues): tapered, that order has something to work with — headline frame 17.18 -> 17.00 ms (same context, option switched)
-    uint32_t taper_levels = 0, qchunks = (nchunks + G - 1) / G;
-    if (c->taper && !fused_bvh && G >= 64u && nchunks >= 4u * G) {
-        taper_levels = c->taper_levels;
-        qchunks = 0;                                                                   // sub-queue 0 takes part in every row
-        for (uint32_t k = 0, row0 = 0; row0 < nchunks; k++) { row0 += taper_row_width(k, G, taper_levels); qchunks++; }
+    uint32_t nchunks = 0, G = 1, taper_levels = 0, qchunks = 1;
+    auto plan = [&](uint32_t spp_batch) {
+        nchunks = f.chunks_per_sample * spp_batch;
+        const uint32_t bpc_hi = tiny_fused ? 40u : 32u, per_wg = tiny_fused ? 16u : 8u;
+        const uint32_t bpc = c->blocks_per_cu ? c->blocks_per_cu
+                                              : std::max<uint32_t>(8u, std::min<uint32_t>(bpc_hi, (nchunks / per_wg + (uint32_t)c->num_cus - 1u) / (uint32_t)c->num_cus));
+        const uint32_t max_blocks = (uint32_t)c->num_cus * bpc;
+        G = std::max<uint32_t>(1, std::min<uint32_t>(nchunks, max_blocks));
+        // tapered sub-queue sizes (taper_row_width, rtx_kernels.hpp); needs a few chunks in the shortest sub-queue to mean anything.  The fused tiny-scene kernels take their
+        // sub-queues longest first anyway (k_order_queues): tapered, that order has something to work with — headline frame 17.18 -> 17.00 ms (same context, option switched)
+        taper_levels = 0; qchunks = (nchunks + G - 1) / G;
+        if (c->taper && !fused_bvh && G >= 64u && nchunks >= 4u * G) {
+            taper_levels = c->taper_levels;
+            qchunks = 0;                                                                   // sub-queue 0 takes part in every row
+            for (uint32_t k = 0, row0 = 0; row0 < nchunks; k++) { row0 += taper_row_width(k, G, taper_levels); qchunks++; }
+        }
+    };
+    plan(bspp);
+    // MEMORY of the taper: every per-queue-position buffer has the uniform stride G * qcap with qcap = the LONGEST sub-queue, so the weights 8 | 4 | 2 | 1 cost
+    // 8 / 5.375 = 1.49 x the entries of the even deal (both compact path-state sets, hit records, both queues, nee x 3 shadow streams: ~ +10 GB at the 128 Mi-path cap).
+    // Where the path state lives by queue position (the general path: 176 B + 48 B per NEE slot and entry) RTX_OPT_PATHS_PER_BATCH therefore caps the ENTRIES: the batch shrinks
+    // until the tapered layout fits it, so a frame that fitted before the taper fits now.  The fused tiny-scene kernels keep their state by path id and only
+    // the two 4-byte queues grow (1.06 -> 1.58 GB at the cap): their batch stays whole — the headline frame is one batch of 132.7 M paths.
+    const bool compact = c->compact_state && !(c->dsc.nsmall && c->fused) && !fused_bvh;
+    while (taper_levels && compact && bspp > 1u && (uint64_t)G * qchunks * 256u > c->paths_per_batch) {
+        const uint32_t next = (uint32_t)std::max<uint64_t>(1, (uint64_t)bspp * c->paths_per_batch / ((uint64_t)G * qchunks * 256u));
+        bspp = next < bspp ? next : bspp - 1u;
+        plan(bspp);
     }
+    const uint64_t cap64 = (uint64_t)f.npl * bspp;
+    if (cap64 > 0x7FFFFFFFull) { c->err = "render: batch too large"; return RTX_ERR_INVALID; }
+    const uint32_t cap = (uint32_t)cap64;
+    HIPCHK(c, c->d_rad.ensure((size_t)cap * 16));
     const uint32_t qcap = qchunks * 256u;
     f.nblocks = G; f.qcap = qcap; f.taper_levels = taper_levels;
     const size_t qtot = (size_t)G * qcap;
     // path state: by path id (cap entries), or — separate kernels of the default configuration — by queue position (qtot >= cap entries) in two sets
-    const bool compact = c->compact_state && !(c->dsc.nsmall && c->fused) && !fused_bvh;
     const size_t nstate = compact ? qtot : (size_t)cap;
     if (nstate > 0xFFFFFFFFull) { c->err = "render: batch too large"; return RTX_ERR_INVALID; }
     HIPCHK(c, c->d_ray_o.ensure(nstate * 16)); HIPCHK(c, c->d_ray_d.ensure(nstate * 16)); HIPCHK(c, c->d_thr.ensure(nstate * 16)); HIPCHK(c, c->d_hit.ensure(nstate * 16));
@@ -663,7 +681,11 @@ static int rs_plan(rtx_ctx* c, const DevFrame& f, uint32_t nitems, const uint32_
     const uint32_t G = (std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>(want, nchunks), (uint32_t)c->num_cus * 64u)) + 7u) & ~7u;   // a multiple of 8: rs_wg() maps workgroups to XCD-contiguous ranges
     const uint32_t qcap = ((nchunks + G - 1) / G) * 256u, rcap = qcap * 9u;              // a pixel casts at most 9 visibility rays in one stage (pass 3, select)
     const size_t qtot = (size_t)G * qcap, rtot = (size_t)G * rcap;
-    if (rtot > 0xFFFFFFFFull) { c->err = "render_restir: image too large"; return RTX_ERR_INVALID; }
+    // 32-bit indices everywhere: queue positions (rtot), the per-item candidate / cold records, and the ray payload `item * kRsOcc + k` that addresses the occlusion bytes
+    // (rs_push_ray: a wrapped payload would write the verdict of ANOTHER pixel's ray, silently)
+    if (rtot > 0xFFFFFFFFull || (uint64_t)nitems * kRsOcc > 0xFFFFFFFFull || (uint64_t)nitems * kRsCand > 0xFFFFFFFFull || (uint64_t)nitems * 5u > 0xFFFFFFFFull) {
+        c->err = "render_restir: image too large (32-bit ray payloads and record indices)"; return RTX_ERR_INVALID;
+    }
     HIPCHK(c, A.state.ensure(qtot * 16 * 2 * kRsStreams)); HIPCHK(c, A.hit.ensure(qtot * 16));
     HIPCHK(c, A.cls.ensure((size_t)nitems * 4)); HIPCHK(c, A.fin.ensure((size_t)nitems * 16)); HIPCHK(c, A.cold.ensure((size_t)nitems * 16 * 5));
     HIPCHK(c, A.occ.ensure((size_t)nitems * kRsOcc)); HIPCHK(c, A.cand.ensure((size_t)nitems * 4 * kRsCand));
@@ -729,7 +751,7 @@ static int rs_pass3(rtx_ctx* c, const DevFrame& f, uint32_t* const bufs[6], F4* 
 extern "C++" {
 template <class F>
 static int rs_lanes(rtx_ctx* c, const uint32_t* pixels, uint32_t npixels, F&& pass) {
-    const uint32_t L = (pixels && !c->timing && npixels >= 1u << 16) ? c->restir_lanes : 1u;
+    const uint32_t L = (pixels && !c->timing && npixels >= c->restir_lane_min) ? c->restir_lanes : 1u;
     if (L <= 1u) return pass(pixels, npixels, 0u, c->stream);
     hipEvent_t e0 = take_event(c);
     if (!e0) { c->err = "render_restir: out of events"; return RTX_ERR_HIP; }

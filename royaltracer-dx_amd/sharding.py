@@ -11,7 +11,8 @@ import numpy as np
 
 
 def block_grid(tiles_x, tiles_y, world):
-    """RTX_FLAG_BLOCK_TILES: the ranks as a gx x gy grid of tile rectangles, gx * gy = world with the smallest rectangle perimeter (block_grid() in csrc/rtx_api.hip)"""
+    """RTX_FLAG_BLOCK_TILES: the ranks as a gx x gy grid of tile rectangles, gx * gy = world with the smallest rectangle perimeter; ties go to the
+    first factorisation in ascending gx, i.e. FEWER columns (block_grid() in csrc/rtx_api.hip is the same loop: the two must agree, or the ranks' slabs do not line up)"""
     best, g = None, (world, 1)
     for a in range(1, world + 1):
         if world % a:

@@ -734,6 +734,59 @@ def test_restir_wavefront_equals_literal_on_a_bvh_scene_at_scale(rt, orc):
     assert total[2] > 4 * W * H and total[1] > 2 * W * H
 
 
+@pytest.mark.parametrize("lanes", [1, 2, 3, 4])
+def test_restir_pipeline_lanes_equal_the_literal_form(rt, orc, golden_dir, lanes):
+    """RTX_OPT_RESTIR_LANES: the pixel list of a ReSTIR frame as 1 .. 4 independent parts on as many streams (passes 1 + 2, join, pass 3).  The lanes only engage for lists
+    of >= 65 536 pixels, so RTX_OPT_RESTIR_LANE_MIN is lowered here: three frames with a moving camera on garage.obj + monke.obj (a BVH scene: Morton-ordered list),
+    unsharded and on two BLOCK_TILES shards with their halo lists — image, the three history buffers and the ray counts equal the LITERAL form's (one thread per pixel
+    and pass, no lists, no streams), which equals the oracle's (test_restir_garage_with_camera_motion)."""
+    import torch
+    from royaltracer_dx_amd import sharding
+    sc = rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")
+    W, H, TS = 160, 96, 32
+    cams = [rt.lookat((-1.5 + 0.05 * k, 1.5, 3.5 - 0.04 * k), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0)) for k in range(3)]
+    proj = rt.perspective_fov_rh(np.radians(60.0), W / H, 0.1, 1000.0)
+    base = dict(width=W, height=H, spp=1, max_bounces=3, nee_samples=4, tile_size=TS)
+    ref = rt.Context(0); ref.set_option(rt.OPT_RESTIR_WAVEFRONT, 0); ref.upload(sc, W / H); ref.restir_reset(); ref.clear(W, H)
+    ref_counts = []
+    for k, v in enumerate(cams):
+        ref.set_camera(v, proj); ref.render_restir(rt.Params(frame_seed=70 + k, flags=0, **base))
+        s = ref.stats(); ref_counts.append((s.rays_primary, s.rays_extension, s.rays_shadow))
+    ref_img, ref_last = ref.read_accum(), ref.read_restir_last()
+    ref.close()
+
+    def ctx():
+        c = rt.Context(0); c.set_option(rt.OPT_RESTIR_LANES, lanes); c.set_option(rt.OPT_RESTIR_LANE_MIN, 256)
+        c.upload(sc, W / H); c.restir_reset(); c.clear(W, H)
+        return c
+    c = ctx()
+    for k, v in enumerate(cams):
+        c.set_camera(v, proj); c.render_restir(rt.Params(frame_seed=70 + k, flags=0, **base))
+        s = c.stats(); assert (s.rays_primary, s.rays_extension, s.rays_shadow) == ref_counts[k], k
+    assert np.array_equal(bits(c.read_accum()), bits(ref_img))
+    for a, b in zip(c.read_restir_last(), ref_last):
+        assert np.array_equal(a, b)
+    c.close()
+    ranks = [ctx(), ctx()]
+    for k, v in enumerate(cams):
+        slabs = []
+        for r, cr in enumerate(ranks):
+            p = rt.Params(frame_seed=70 + k, flags=rt.FLAG_BLOCK_TILES, shard_rank=r, shard_count=2, **base)
+            cr.set_camera(v, proj); cr.render_restir(p)
+            slab = torch.empty(cr.restir_state_slab_bytes(p) // 4, dtype=torch.float32, device="cuda:0")
+            cr.restir_pack_state(p, slab.data_ptr()); slabs.append(slab)
+        torch.cuda.synchronize()
+        gathered = torch.cat(slabs); torch.cuda.synchronize()
+        for r, cr in enumerate(ranks):
+            cr.restir_unpack_state(rt.Params(frame_seed=70 + k, flags=rt.FLAG_BLOCK_TILES, shard_rank=r, shard_count=2, **base), gathered.data_ptr())
+    own = sharding.owner_map(W, H, TS, 2, True)
+    for r, cr in enumerate(ranks):
+        assert np.array_equal(bits(cr.read_accum()[own == r]), bits(ref_img[own == r])), r
+        for a, b in zip(cr.read_restir_last(), ref_last):
+            assert np.array_equal(a, b), r
+        cr.close()
+
+
 @pytest.mark.parametrize("split", [0, 10000], ids=["object_splits", "spatial_splits"])
 @pytest.mark.parametrize("gpu_refit", [1, 0])
 def test_animated_instance_refit_parity(rt, orc, golden_dir, gpu_refit, split):
@@ -1211,6 +1264,46 @@ def test_full_size_headline_frame_is_bit_identical(rt, orc, cornell):
     assert oc[0] == W * H * 64 and sum(oc) > 5.4e8
     d = (bits(im) != bits(oa)).any(-1)
     assert not d.any(), f"{int(d.sum())} of {W * H} pixels differ, first at {np.argwhere(d)[0].tolist()}"
+
+
+@pytest.mark.parametrize("kind", ["garage", "atrium"])
+def test_full_size_restir_frames_are_byte_identical(rt, orc, golden_dir, kind):
+    """What bench.py's extra.restir_garage_1080p / restir_atrium_1080p time, checked at THEIR size: the reference's shipping frame (pass 1 + temporal + spatial reuse,
+    nee 4, bounces 3: Common_v6.hlsl:8-12, Renderer.cpp:646-673) at the reference's hard-wired 1920 x 1080 (Main.cpp:25) on its start-up scene with its camera
+    (garage.obj + monke.obj, Renderer.cpp:46-48,363) and on the Sponza-class atrium; three frames with a moving camera, so the temporal pass reprojects.  With the default
+    options (wavefront stages, two pipeline lanes, the Morton-ordered pixel list, full-size chunking) and with ONE lane: the image, the three history buffers
+    (u3 / u5 / u7) and the three ray counts equal the oracle's byte for byte."""
+    import time
+    W, H = 1920, 1080
+    if kind == "garage":
+        sc = rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")
+        eyes, center = [(-1.5, 1.5, 3.5), (-1.46, 1.5, 3.5), (-1.42, 1.52, 3.47)], (0.0, 1.0, 0.0)                     # Renderer.cpp:46-48, then moving
+    else:
+        sc = rt.Scene.sponza_class()
+        eyes, center = [(-1.8, 0.45, 0.0), (-1.77, 0.45, 0.01), (-1.74, 0.46, 0.02)], (0.5, 0.55, 0.0)
+    proj = rt.perspective_fov_rh(np.radians(60.0), W / H, 0.1, 1000.0)
+    views = [rt.lookat(e, center, (0.0, 1.0, 0.0)) for e in eyes]
+    o = orc.Oracle().load(sc, W / H); o.set_threads(_host_threads())
+    acc_o, st, counts = np.zeros((H, W, 4), np.float32), None, []
+    t0 = time.time()
+    for k, v in enumerate(views):
+        o.set_camera(v, proj)
+        acc_o, st, cnt = o.restir_frames(rt.Params(width=W, height=H, spp=1, max_bounces=3, nee_samples=4, flags=0, frame_seed=300 + k), acc_o, st)
+        counts.append(cnt)
+    print(f"{kind}: oracle {time.time() - t0:.1f} s for 3 frames on {_host_threads()} threads, rays per frame {counts[-1]}")
+    for lanes in (2, 1):
+        c = rt.Context(0); c.set_option(rt.OPT_RESTIR_LANES, lanes); c.upload(sc, W / H)
+        c.restir_reset(); c.clear(W, H)
+        for k, v in enumerate(views):
+            c.set_camera(v, proj)
+            c.render_restir(rt.Params(width=W, height=H, spp=1, max_bounces=3, nee_samples=4, flags=0, frame_seed=300 + k))
+            s = c.stats()
+            assert (s.rays_primary, s.rays_extension, s.rays_shadow) == counts[k], (lanes, k)
+        ld, lg, ls = c.read_restir_last()
+        assert np.array_equal(ld, st[3]) and np.array_equal(lg, st[4]) and np.array_equal(ls, st[5]), lanes
+        d = (bits(c.read_accum()) != bits(acc_o)).any(-1)
+        assert not d.any(), f"lanes {lanes}: {int(d.sum())} of {W * H} pixels differ, first at {np.argwhere(d)[0].tolist()}"
+        c.close()
 
 
 def _host_threads():

@@ -27,6 +27,18 @@ def test_slab_layout_is_a_partition(rt):
     assert sharding.layout(1920, 1080, 64, 8)["npl"] * 16 == 64 * 4096 * 16   # 510 tiles -> 64 per rank, 4.2 MB slab at 1080p
 
 
+def test_block_grid_tie_goes_to_the_grid_with_fewer_columns(rt):
+    """RTX_FLAG_BLOCK_TILES: of two rank grids with the same block perimeter the first factorisation in ascending gx wins — the loop of block_grid() in csrc/rtx_api.hip,
+    mirrored by sharding.block_grid; the GPU tests compare the two sides tile by tile (test_restir_on_shards_*, blocks = 1), this pins the choice itself"""
+    from royaltracer_dx_amd import sharding
+    assert sharding.block_grid(8, 8, 2) == (1, 2)            # 8 + 4 either way: fewer columns
+    assert sharding.block_grid(8, 8, 4) == (2, 2)            # the square grid has the smaller perimeter (4 + 4 < 8 + 2)
+    assert sharding.block_grid(60, 34, 8) == (4, 2)          # 1080p in 32-px tiles on 8 ranks: 15 + 17 (DESIGN section 5: 480 x 544 px blocks)
+    assert sharding.block_grid(5, 3, 4) == (2, 2)
+    own = sharding.owner_map(256, 256, 32, 2, True)
+    assert (own[:128] == 0).all() and (own[128:] == 1).all()  # two ranks on a square image: the split runs across rows (gx = 1, gy = 2)
+
+
 WORKER = r'''
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, sys.argv[1])

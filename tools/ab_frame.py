@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-box, same-process alternating A/B of rtx options on one workload: the scene is built once, the option values alternate round by round.
-usage: python tools/ab_frame.py <sponza|bistro|garage|cornell> <pt|restir> <opt>=<a>,<b>[,...] [rounds=3] [frames=3] [timing=1] [same=1] [fixed <opt>=<v> ...]
-prints per setting: ms per frame (wall, all rounds), per-kernel-class ms (last round, with timing=1: launches serialised) and the image checksum"""
+usage: python tools/ab_frame.py <sponza|bistro|garage|cornell> <pt|restir> <opt>=<a>,<b>[,...] [rounds=3] [frames=3] [timing=0] [same=0] [fixed <opt>=<v> ...]
+prints per setting: ms per frame (wall, all rounds), per-kernel-class ms (last round, only with timing=1: launches serialised; the default timing=0 leaves the frame as a caller gets it) and the image checksum"""
 import hashlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

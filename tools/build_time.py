@@ -1,7 +1,8 @@
 """Scene generation and commit (BVH build) times of the two large procedural scenes on the GPU box: python tools/build_time.py"""
 import sys, time, os
-sys.path.insert(0, '/root/repo')
-os.chdir(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.chdir(ROOT)
 import __graft_entry__ as g
 rt = g.load_package()
 for kind in ('sponza', 'bistro'):
