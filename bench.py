@@ -194,7 +194,7 @@ def roofline_record(rt, workload, kms, kitems, klaunch, rays, n_pixel_samples, s
             "traffic_source": ((src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2*FETCH+WRITE KiB; not measured in this run)") if pm else
                                (src + ": STALE (recorded with other kernel sources) - not used" if stale else None)),
             "alg_bytes_per_launch": round(bytes_per_launch), "alg_bytes_model": "224*N_ext + 96*N_shadow (+ 32*N_px*spp for the frame)",
-            "avg_launch_ms": round(avg_ms, 5), "launches": int(klaunch[k]),
+            "avg_launch_ms": round(avg_ms, 5), "launches": int(klaunch[k]), "frames": int(max(steps, 1)),
             "kernel_ms_by_class": {rt.KERNEL_NAMES[i]: round(float(kms[i]), 3) for i in rt.KERNEL_NAMES if klaunch[i] > 0}}
     # whole frame, all kernels, SURVEY 8(d): bytes_alg = 224*N_ext + 96*N_shadow + 32*N_px*spp (primary rays are not priced: their state is part of the first extension ray's 224 B)
     frame_ms = float(kms.sum()) / max(steps, 1)
@@ -215,6 +215,31 @@ def roofline_record(rt, workload, kms, kitems, klaunch, rays, n_pixel_samples, s
         if pm["compute_frac"] > max(roof["frac"], roof.get("traffic_frac", 0.0)):
             roof["bound"] = "valu"
     return roof
+
+
+def trace_work(rt, ctx, params, roof):
+    """WORK per ray of the BVH traversal, the number a tree-quality or visiting-order change moves: one more frame with RTX_OPT_TRACE_COUNTERS — the generic
+    instantiations of the persistent kernels tally every lane's node steps and triangle tests — divided by the rays of that frame; and, where the tracked counter profile of
+    this workload is current, the VALU lane-instructions per ray of the dominant kernel class (SQ_INSTS_VALU x active lanes / rays)."""
+    ctx.set_option(rt.OPT_KERNEL_TIMING, 0); ctx.set_option(rt.OPT_TRACE_COUNTERS, 1)
+    try:
+        ctx.trace_counters()                                   # reset
+        ctx.render(params)
+        st = ctx.stats(); cn, ct, an, at = ctx.trace_counters()
+    finally:
+        ctx.set_option(rt.OPT_TRACE_COUNTERS, 0)
+    n_closest, n_any = st.rays_primary + st.rays_extension, st.rays_shadow
+    out = {"closest_hit": {"rays": int(n_closest), "node_steps_per_ray": round(cn / max(n_closest, 1), 3), "tri_tests_per_ray": round(ct / max(n_closest, 1), 3)},
+           "any_hit": {"rays": int(n_any), "node_steps_per_ray": round(an / max(n_any, 1), 3), "tri_tests_per_ray": round(at / max(n_any, 1), 3)},
+           "source": "RTX_OPT_TRACE_COUNTERS on one more frame (generic instantiation of k_trace_closest / k_trace_shadow, speculative schedule as timed)"}
+    comp = (roof or {}).get("compute")
+    if comp and comp.get("valu_inst_per_launch") and comp.get("lanes_per_inst") and roof.get("launches"):
+        n_dom = {"trace_closest": n_closest, "trace_shadow": n_any}.get(roof["kernel"])
+        if n_dom:       # the profile's launches are those of the timed frames: per frame = per launch x launches per frame
+            per_frame_launches = roof["launches"] / max(roof.get("frames", 1), 1)
+            out["valu_lane_inst_per_ray"] = round(comp["valu_inst_per_launch"] * per_frame_launches * comp["lanes_per_inst"] / n_dom, 1)
+            out["valu_lane_inst_source"] = comp["source"]
+    return out
 
 
 def time_extra(rt, dev_index, workload, steps=2):
@@ -247,12 +272,14 @@ def time_extra(rt, dev_index, workload, steps=2):
             rays += np.array([st.rays_primary, st.rays_extension, st.rays_shadow], dtype=np.float64)
         dt_timed = time.perf_counter() - t1
         roof = roofline_record(rt, workload, kms, None, kl, rays, float(W) * H * spp * steps, steps)
+        work = trace_work(rt, ctx, params, roof)
         rec = {"ms_per_frame": round(dt * 1e3 / steps, 3), "Mrays_s": round(float(rays.sum()) / dt / 1e6, 1), "triangles": int(scene.num_triangles), "scene": source,
                "rays_per_frame": int(rays.sum() / steps), "dominant_kernel": roof["kernel"] if roof else None,
                "frac": roof["frac"] if roof else None, "bound": roof["bound"] if roof else None,
                "compute_frac": roof.get("compute", {}).get("frac") if roof else None,
                "lanes_per_inst": roof.get("compute", {}).get("lanes_per_inst") if roof else None,
                "kernel_ms_per_frame": {k: round(v / steps, 3) for k, v in roof["kernel_ms_by_class"].items()} if roof else None,
+               "work_per_ray": work,
                "ms_per_frame_kernels_timed": round(dt_timed * 1e3 / steps, 3),
                "note": "ms_per_frame / Mrays_s: kernel timing off (shadow rays of bounce b overlap the closest-hit rays of bounce b + 1); kernel_ms_per_frame, frac: a second pass with per-kernel HIP events, which runs the launches one after the other"}
         return rec
@@ -396,9 +423,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # the warm-up frames run in the timed frames' mode (with per-kernel events the shadow-ray kernel of bounce b does not overlap the closest-hit kernel of bounce b + 1): a
+    # rocprofv3 trace of this command then holds frames of ONE kind, and its per-kernel averages reproduce the event times of the line
+    ctx.set_option(rt.OPT_KERNEL_TIMING, 0 if args.no_kernel_timing else 1)
     for i in range(args.warmup):
         frame(i)
-    ctx.set_option(rt.OPT_KERNEL_TIMING, 0 if args.no_kernel_timing else 1)
     kms = np.zeros(rt.K_COUNT); kitems = np.zeros(rt.K_COUNT); klaunch = np.zeros(rt.K_COUNT)
     rays = np.zeros(3)
     barrier()
@@ -429,6 +458,14 @@ def main():
         if not args.no_kernel_timing:
             local_px = float(W) * H * spp * args.steps / world
             roof = roofline_record(rt, args.workload if world == 1 else "", kms, kitems, klaunch, rays, local_px, args.steps)
+            comp = (roof or {}).get("compute")
+            if comp and comp.get("valu_inst_per_launch") and comp.get("lanes_per_inst"):
+                # WORK metric beside the self-referential compute fraction: VALU lane-instructions the dominant class issues per ray it handles
+                n_dom = {"bounce_fused": rays[1] + rays[2], "trace_closest": rays[0] + rays[1], "trace_shadow": rays[2]}.get(roof["kernel"])
+                if n_dom:
+                    comp["valu_lane_inst_per_ray"] = round(comp["valu_inst_per_launch"] * roof["launches"] * comp["lanes_per_inst"] / float(n_dom), 1)
+                    comp["work_model"] = ("valu_lane_inst_per_ray = SQ_INSTS_VALU per launch x launches of the timed region x active lanes per instruction / rays the class handled "
+                                          "(bounce_fused: extension + shadow rays; the tiny-scene path has no tree: node steps / triangle tests per ray are reported for C3 / C5 under extra.*.work_per_ray)")
         # ---- the general BVH path beside the headline: driver-timed numbers for C3 / C5 (GPU only, ~2 s each + scene build) ----
         extra = None
         if world == 1 and not args.no_extra and args.workload == "cornell_1080p_64spp_8b":

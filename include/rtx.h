@@ -132,6 +132,8 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
        RTX_OPT_MERGE_RAYS = 24,      /* tuning, general scenes: a launch of the persistent traversal kernels that is predicted (from the previous rtx_render's counters) to hold fewer than
                                         this many rays per sub-queue gives each workgroup 2 / 4 / 8 consecutive sub-queues, down to one round of resident workgroups (the late bounces of
                                         a frame, after Russian roulette).  Default 1024; 0 = one sub-queue per workgroup always.  Never changes a result */
+       RTX_OPT_TRACE_COUNTERS = 30,  /* 1: the persistent traversal kernels count node steps and triangle tests (their generic instantiations; a few per cent slower), read with
+                                        rtx_debug_trace_counters: work per ray for the bench record.  Default 0.  Never changes a result */
        RTX_OPT_BVH_REINSERT = 26,    /* BVH builder: passes of the insertion-based topology optimisation after the top-down SAH build (Bittner et al. 2013; default see DESIGN.md section 6c).
                                         Changes the tree, never a result; the next rtx_commit_scene rebuilds */
        RTX_OPT_BVH_SPLIT = 27,       /* BVH builder: spatial splits (Stich et al. 2009) where an object split leaves its two sides overlapping by more than value * 1e-9 of the scene's surface
@@ -236,6 +238,8 @@ int  rtx_debug_trace_any(rtx_ctx*, const float* rays8, uint32_t n, uint8_t* occl
 /* closest-hit traversal of the BVH (never the tiny-scene path) that reports its work: stats4 = n * (t, node steps, triangle tests,
    prim bits) — tree-quality measurements for DESIGN.md, not part of the reference boundary */
 int  rtx_debug_trace_stats(rtx_ctx*, const float* rays8, uint32_t n, float* stats4);
+/* RTX_OPT_TRACE_COUNTERS: node steps / triangle tests of the closest-hit rays and of the any-hit rays traced by the persistent kernels since the last call (which resets them) */
+int  rtx_debug_trace_counters(rtx_ctx*, uint64_t out4[4]);
 /* downloads the resident wide BVH and checks it on the host: 0 = every triangle is in exactly one leaf slot and inside all the
    decoded boxes above it (what the GPU refit must preserve); > 0 = validator code; < 0 = RTX_ERR_* */
 int  rtx_debug_validate_bvh(rtx_ctx*);

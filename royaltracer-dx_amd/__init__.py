@@ -40,7 +40,7 @@ KERNEL_NAMES = {K_RAYGEN: "raygen", K_TRACE: "trace_closest", K_SHADE: "shade", 
 OPT_KERNEL_TIMING, OPT_PATHS_PER_BATCH, OPT_SORT_MATERIALS, OPT_LDS_NODES, OPT_SMALL_SCENE, OPT_FUSED_BOUNCE, OPT_BOUNCE_VARIANT = 1, 2, 3, 4, 5, 6, 7
 OPT_REFILL_MIN, OPT_STACK_PRIVATE, OPT_TRACE_SCHED, OPT_GPU_REFIT, OPT_BLOCKS_PER_CU, OPT_LPT_ORDER, OPT_FUSED_BVH, OPT_WORK_STEALING, OPT_COMPACT_STATE, OPT_OVERLAP_SHADOW = 8, 9, 10, 11, 12, 13, 14, 15, 16, 18
 OPT_RESTIR_WAVEFRONT, OPT_RESTIR_CHUNKS, OPT_OCCLUDER_CACHE, OPT_RESTIR_LANES, OPT_SHADE_DENSE, OPT_MERGE_RAYS, OPT_TAPER = 19, 20, 21, 22, 23, 24, 25
-OPT_BVH_REINSERT, OPT_BVH_SPLIT, OPT_ANYHIT_ORDER, OPT_RESTIR_LANE_MIN = 26, 27, 28, 29
+OPT_BVH_REINSERT, OPT_BVH_SPLIT, OPT_ANYHIT_ORDER, OPT_RESTIR_LANE_MIN, OPT_TRACE_COUNTERS = 26, 27, 28, 29, 30
 
 
 class RtxError(RuntimeError):
@@ -126,6 +126,7 @@ _sig("rtx_debug_trace_closest", C.c_int, _vp, _vp, _u32, _vp)
 _sig("rtx_debug_trace_any", C.c_int, _vp, _vp, _u32, _vp)
 _sig("rtx_debug_trace_stats", C.c_int, _vp, _vp, _u32, _vp)
 _sig("rtx_debug_validate_bvh", C.c_int, _vp)
+_sig("rtx_debug_trace_counters", C.c_int, _vp, C.POINTER(C.c_uint64))
 _sig("rtx_debug_surface", C.c_int, _vp, _vp, _vp, _u32, _vp)
 _sig("rtx_debug_bsdf_eval", C.c_int, _vp, _u32, _u32, _vp, _u32, _vp)
 _sig("rtx_debug_bsdf_sample", C.c_int, _vp, _u32, _u32, _vp, _u32, _vp)
@@ -601,6 +602,12 @@ class Context:
         out = np.zeros(len(r), np.uint8)
         self._ck(lib.rtx_debug_trace_any(self._h, _ptr(r), len(r), _ptr(out)), "rtx_debug_trace_any")
         return out
+
+    def trace_counters(self):
+        """(node steps, triangle tests) of the closest-hit rays and of the any-hit rays since the last call (OPT_TRACE_COUNTERS 1)"""
+        out = (C.c_uint64 * 4)()
+        self._ck(lib.rtx_debug_trace_counters(self._h, out), "rtx_debug_trace_counters")
+        return tuple(int(v) for v in out)
 
     def validate_bvh(self):
         """0 when the resident wide BVH (as built, or as refitted on the GPU) covers every triangle inside its decoded boxes"""

@@ -45,6 +45,7 @@ struct rtx_ctx {
     float view[16], proj[16];
     // path state
     DevBuf d_hitmask, d_order, d_pmask;
+    bool trace_counters = false; DevBuf d_trace_cnt;      // RTX_OPT_TRACE_COUNTERS
     int any_order_opt = -1;         // RTX_OPT_ANYHIT_ORDER: -1 = what the commit-time probe chose (BuiltScene::any_order)
     bool lpt_order = true;          // RTX_OPT_LPT_ORDER: fused kernels take their sub-queues longest first
     // ReSTIR work lists (x | y << 16 per pixel, 8 x 8 pixel blocks in MORTON order so that consecutive chunks are compact screen regions): the shard's own pixels
@@ -153,6 +154,11 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     if (!c) return RTX_ERR_INVALID;
     switch (option) {
     case RTX_OPT_KERNEL_TIMING: c->timing = value != 0; return RTX_OK;
+    case RTX_OPT_TRACE_COUNTERS:
+        c->trace_counters = value != 0;
+        if (c->trace_counters) { HIPCHK(c, c->d_trace_cnt.ensure(4 * sizeof(unsigned long long))); HIPCHK(c, hipMemsetAsync(c->d_trace_cnt.p, 0, 32, c->stream)); }
+        c->dsc.trace_cnt = c->trace_counters ? (unsigned long long*)c->d_trace_cnt.p : nullptr;
+        return RTX_OK;
     case RTX_OPT_BVH_REINSERT: if (value < 0 || value > 16) { c->err = "bvh_reinsert must be in [0, 16]"; return RTX_ERR_INVALID; } c->host.bvh.reinsert_passes = (int)value; c->host.topo_dirty = true; c->committed = false; return RTX_OK;
     case RTX_OPT_BVH_SPLIT: if (value < 0 || value > 1000000000) { c->err = "bvh_split must be in [0, 1e9] (parts per billion of the scene's surface area)"; return RTX_ERR_INVALID; } c->host.bvh.split_alpha = (double)value * 1e-9; c->host.topo_dirty = true; c->committed = false; return RTX_OK;
     case RTX_OPT_ANYHIT_ORDER: if (value < -1 || value > 2) { c->err = "anyhit_order must be -1 (probe), 0, 1 or 2"; return RTX_ERR_INVALID; } c->any_order_opt = (int)value; if (c->committed) c->dsc.any_order = value < 0 ? c->built.any_order : (uint32_t)value; return RTX_OK;
@@ -324,6 +330,7 @@ static int finalise_scene(rtx_ctx* c) {
     s.lds_tris = (size_t)want_tris * 48 <= budget ? want_tris : 0u;
     s.nsmall = 0; s.nsmall_occ = 0;
     s.any_order = c->any_order_opt < 0 ? B.any_order : (uint32_t)c->any_order_opt;
+    s.trace_cnt = c->trace_counters ? (unsigned long long*)c->d_trace_cnt.p : nullptr;
     s.refill_min = c->refill_min; s.trace_sched = c->trace_sched; s.sort_materials = c->sort_materials; s.occluder_cache = c->occluder_cache; s.shade_dense = c->shade_dense > 0 ? 1u : 0u;
     if (c->small_scene && B.small_nrec && B.small_tris.size() * 48 <= budget + (size_t)s.lds_tris * 48) {
         s.nsmall = B.small_nrec; s.nsmall_occ = B.small_nocc; s.lds_tris = (uint32_t)B.small_tris.size();   // LDS holds the records' triangles instead of the leaf-ordered ones
@@ -481,13 +488,13 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     // 1080p frame (16 200 chunks at 16 spp) ran 7.29 / 6.71 / 6.30 / 6.09 / 6.08 ms with 32 / 24 / 16 / 12 / 8 sub-queues per CU (C3), Cornell at 64 spp 2.54 / 2.41 ms with 40 / 16
     // (tools/shard_kernels.py): short sub-queues leave the persistent waves of a workgroup half empty, and every round of workgroups costs one ray latency
     const bool tiny_fused = c->dsc.nsmall && c->fused;
-    uint32_t nchunks = 0, G = 1, taper_levels = 0, qchunks = 1;
+    uint32_t nchunks = 0, G = 1, taper_levels = 0, qchunks = 1, max_blocks = 1;
     auto plan = [&](uint32_t spp_batch) {
         nchunks = f.chunks_per_sample * spp_batch;
         const uint32_t bpc_hi = tiny_fused ? 40u : 32u, per_wg = tiny_fused ? 16u : 8u;
         const uint32_t bpc = c->blocks_per_cu ? c->blocks_per_cu
                                               : std::max<uint32_t>(8u, std::min<uint32_t>(bpc_hi, (nchunks / per_wg + (uint32_t)c->num_cus - 1u) / (uint32_t)c->num_cus));
-        const uint32_t max_blocks = (uint32_t)c->num_cus * bpc;
+        max_blocks = (uint32_t)c->num_cus * bpc;
         G = std::max<uint32_t>(1, std::min<uint32_t>(nchunks, max_blocks));
         // tapered sub-queue sizes (taper_row_width, rtx_kernels.hpp); needs a few chunks in the shortest sub-queue to mean anything.  The fused tiny-scene kernels take their
         // sub-queues longest first anyway (k_order_queues): tapered, that order has something to work with — headline frame 17.18 -> 17.00 ms (same context, option switched)
@@ -1112,6 +1119,19 @@ int rtx_debug_validate_bvh(rtx_ctx* c) {
         o[0] = T.v0.x; o[1] = T.v0.y; o[2] = T.v0.z; o[3] = T.v0.x + T.e1.x; o[4] = T.v0.y + T.e1.y; o[5] = T.v0.z + T.e1.z; o[6] = T.v0.x + T.e2.x; o[7] = T.v0.y + T.e2.y; o[8] = T.v0.z + T.e2.z;
     }
     return validate_bvh8(w, nodes, gid, ident, nullptr);
+}
+// work counters of the persistent traversal kernels since they were last read (RTX_OPT_TRACE_COUNTERS 1): out4 = node steps and triangle tests of closest-hit rays, node steps and
+// triangle tests of any-hit rays; reading resets them.  Rays per class: rtx_stats (rays_primary + rays_extension, rays_shadow)
+int rtx_debug_trace_counters(rtx_ctx* c, uint64_t out4[4]) {
+    BIND(c);
+    if (!c->trace_counters || !c->d_trace_cnt.p) { c->err = "trace counters are off (RTX_OPT_TRACE_COUNTERS)"; return RTX_ERR_STATE; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->aux) HIPCHK(c, hipStreamSynchronize(c->aux));
+    unsigned long long h[4];
+    HIPCHK(c, hipMemcpy(h, c->d_trace_cnt.p, 32, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemset(c->d_trace_cnt.p, 0, 32));
+    for (int i = 0; i < 4; i++) out4[i] = h[i];
+    return RTX_OK;
 }
 int rtx_debug_trace_stats(rtx_ctx* c, const float* rays8, uint32_t n, float* stats4) { return dbg_trace(c, rays8, n, 2, stats4, nullptr); }
 

@@ -154,6 +154,13 @@ __global__ __launch_bounds__(kBlock) void k_raygen_trace_small(DevScene sc, cons
     if (threadIdx.x == 0) { qcount[blockIdx.x] = s_n[0]; gencount[blockIdx.x] = s_n[1]; }
 }
 
+// RTX_OPT_TRACE_COUNTERS: a wave adds its lanes' tallies of node steps and triangle tests to two 64-bit counters (one atomic pair per wave, at its exit)
+__device__ __forceinline__ void trace_count_flush(unsigned long long* cnt, uint32_t nodes, uint32_t tris) {
+    unsigned long long a = nodes, b = tris;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+    if (lane_id() == 0) { atomicAdd(cnt, a); atomicAdd(cnt + 1, b); }
+}
 #ifndef RTX_TRACE_WAVES
 #define RTX_TRACE_WAVES 1          // waves per SIMD the persistent traversal kernels are compiled for (1 = no cap: the default-schedule instantiations take 64 / 63 VGPRs, 8 waves per SIMD)
 #endif
@@ -191,6 +198,7 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevSc
     bool drained = false;
     RaySource W{heads, qcount, gridDim.x, blockIdx.x, n, 0u, 0u};
     uint32_t rng = steal_seed();
+    uint32_t cnt_nodes = 0, cnt_tris = 0;
     auto fetch = [&](uint32_t q, uint32_t idx) {
         const uint32_t pid = p.out_o ? q * qcap + idx : queue[(size_t)q * qcap + idx];
         const F4 ro = ld_stream(p.ray_o + pid), rd = ld_stream(p.ray_d + pid);
@@ -198,11 +206,12 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevSc
     };
     while (STEAL ? refill_steal<true>(R, W, drained, refill_min, rng, fetch) : refill<true>(R, &s_head, n, drained, refill_min, [&](uint32_t idx) { uint32_t q, off; M.locate(idx, q, off); fetch(q, off); })) {
         if (SCHED >= 5) spec_step<false>(sc, L, R, stk, (uint32_t)SCHED);
-        else if (sched >= 5u) spec_step<false>(sc, L, R, stk, sched);
+        else if (sched >= 5u) spec_step<false, decltype(stk), true>(sc, L, R, stk, sched, &cnt_nodes, &cnt_tris);
         else if (sched) voted_step<false>(sc, L, R, stk, sched);
         else { walk_internal<false>(sc, L, R, stk); process_leaf<false>(sc, L, R, stk); }
         if (R.has && R.done) { st_stream(p.hit + R.item, F4{R.bt, R.bu, R.bv, u2f(R.bprim)}); R.has = false; }
     }
+    if (SCHED < 0 && sc.trace_cnt) trace_count_flush(sc.trace_cnt, cnt_nodes, cnt_tris);      // RTX_OPT_TRACE_COUNTERS (generic instantiation only)
 #ifdef RTX_WAVE_CLOCK
     RTX_WAVE_STAMP(1u);
 #endif
@@ -255,6 +264,7 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_shadow(DevSce
     bool drained = false;
     RaySource W{heads, shcount, gridDim.x, blockIdx.x, n, 0u, 0u};
     uint32_t rng = steal_seed();
+    uint32_t cnt_nodes = 0, cnt_tris = 0;
     auto fetch = [&](uint32_t q, uint32_t idx) {
         const uint32_t gi = q * qcap + idx;                               // (< 2^32: the batch cap)
         const F4 so = sh_o[gi], sd = sh_d[gi];
@@ -262,11 +272,12 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_shadow(DevSce
     };
     while (STEAL ? refill_steal<false>(R, W, drained, refill_min, rng, fetch) : refill<false>(R, &s_head, n, drained, refill_min, [&](uint32_t idx) { uint32_t q, off; M.locate(idx, q, off); fetch(q, off); })) {
         if (SCHED >= 5) spec_step<true>(sc, L, R, stk, (uint32_t)SCHED);
-        else if (sched >= 5u) spec_step<true>(sc, L, R, stk, sched);
+        else if (sched >= 5u) spec_step<true, decltype(stk), true>(sc, L, R, stk, sched, &cnt_nodes, &cnt_tris);
         else if (sched) voted_step<true>(sc, L, R, stk, sched);
         else { walk_internal<true>(sc, L, R, stk); process_leaf<true>(sc, L, R, stk); }
         if (R.has && R.done) { finish(R.item, R.bprim != kMissPrim); R.has = false; }
     }
+    if (SCHED < 0 && sc.trace_cnt) trace_count_flush(sc.trace_cnt + 2, cnt_nodes, cnt_tris);
 #ifdef RTX_WAVE_CLOCK
     RTX_WAVE_STAMP_S(1u);
 #endif
@@ -1122,7 +1133,7 @@ void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc,
     if (sc.stack_private == 1) { if (heads) RTX_LAUNCH_TC(1, true, -1, trace_lds_bytes_queue(sc)); else RTX_LAUNCH_TC(1, false, -1, trace_lds_bytes_queue(sc)); }
     else if (heads) RTX_LAUNCH_TC(0, true, -1, trace_lds_bytes(sc));
 #ifndef RTX_NO_SCHED_SPECIAL
-    else if (sc.trace_sched == 6u && !sc.nsmall) RTX_LAUNCH_TC(0, false, 6, trace_lds_bytes(sc));      // the default configuration: schedule compiled in
+    else if (sc.trace_sched == 6u && !sc.nsmall && !sc.trace_cnt) RTX_LAUNCH_TC(0, false, 6, trace_lds_bytes(sc));      // the default configuration: schedule compiled in (the work counters live in the generic one)
 #endif
     else RTX_LAUNCH_TC(0, false, -1, trace_lds_bytes(sc));
 #undef RTX_LAUNCH_TC
@@ -1156,7 +1167,7 @@ void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, 
     if (sc.stack_private == 1) { if (heads) RTX_LAUNCH_TS(1, true, -1, trace_lds_bytes_queue(sc)); else RTX_LAUNCH_TS(1, false, -1, trace_lds_bytes_queue(sc)); }
     else if (heads) RTX_LAUNCH_TS(0, true, -1, trace_lds_bytes(sc));
 #ifndef RTX_NO_SCHED_SPECIAL
-    else if (sc.trace_sched == 6u && !sc.nsmall) RTX_LAUNCH_TS(0, false, 6, trace_lds_bytes(sc));
+    else if (sc.trace_sched == 6u && !sc.nsmall && !sc.trace_cnt) RTX_LAUNCH_TS(0, false, 6, trace_lds_bytes(sc));
 #endif
     else RTX_LAUNCH_TS(0, false, -1, trace_lds_bytes(sc));
 #undef RTX_LAUNCH_TS
@@ -1199,7 +1210,7 @@ void launch_restir_pass3(hipStream_t st, uint32_t max_blocks, const DevScene& sc
 void launch_trace_occ(hipStream_t st, const DevScene& sc, const RsQ& q, const uint32_t* shcnt) {
     DevPaths none{};
 #define RTX_LAUNCH_TO(CC) hipLaunchKernelGGL((k_trace_shadow<0, false, CC, 1>), dim3(q.G), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, none, q.sh_o, q.sh_d, (const F4*)nullptr, shcnt, q.rcap, sc.refill_min, sc.trace_sched, (uint32_t*)nullptr, q.G, 1u, q.sh_pay, q.occ)
-    if (sc.trace_sched == 6u && !sc.nsmall) RTX_LAUNCH_TO(6); else RTX_LAUNCH_TO(-1);
+    if (sc.trace_sched == 6u && !sc.nsmall && !sc.trace_cnt) RTX_LAUNCH_TO(6); else RTX_LAUNCH_TO(-1);
 #undef RTX_LAUNCH_TO
 }
 static inline RestirBufs rs_bufs(uint32_t* const* b) { return RestirBufs{b[0], b[1], b[2], b[3], b[4], b[5]}; }

@@ -624,8 +624,9 @@ __device__ unsigned long long g_wgt[2 * 65536];
 #ifdef RTX_PROFILE_SECTIONS
 __device__ unsigned long long g_trv[8];      // tooling (PROFILE build): node iterations, lanes in them, triangle iterations, lanes in them, busy lanes summed over iterations, iterations
 #endif
-template <bool ANY, class STK>
-__device__ __forceinline__ void spec_step(const DevScene& sc, const TraceLds& L, RayLane& R, STK& stk, uint32_t sched) {
+// COUNT (the generic instantiations with RTX_OPT_TRACE_COUNTERS): the lane's node steps and triangle tests are tallied in cnt_nodes / cnt_tris (work per ray for the bench record)
+template <bool ANY, class STK, bool COUNT = false>
+__device__ __forceinline__ void spec_step(const DevScene& sc, const TraceLds& L, RayLane& R, STK& stk, uint32_t sched, uint32_t* cnt_nodes = nullptr, uint32_t* cnt_tris = nullptr) {
     const bool busy = R.has && !R.done;
     const bool has_tri = busy && R.T.bits != 0u;
     const bool can_node = busy && R.P[kPend - 2].bits == 0u && ((R.G.bits & 0xffu) != 0u || R.sp > 0);
@@ -654,8 +655,9 @@ __device__ __forceinline__ void spec_step(const DevScene& sc, const TraceLds& L,
         if (can_node) {
             if (!(R.G.bits & 0xffu)) { R.sp--; R.G = stk.get(R.sp); }
             descend8<!ANY>(sc, L, R.o, R.idir, R.oct, R.tmin, R.bt, R.G, R.P[0], stk, R.sp, ANY ? nullptr : &R.om);
+            if (COUNT) *cnt_nodes += 1u;
         }
-    } else if (has_tri) upd = tri_candidate<ANY>(sc, L, R, ct, cu, cw, cg);
+    } else if (has_tri) { upd = tri_candidate<ANY>(sc, L, R, ct, cu, cw, cg); if (COUNT) *cnt_tris += 1u; }
     uint32_t updv = upd ? 1u : 0u;
     asm volatile("" : "+v"(updv));                                          // opaque: keeps the update below OUT of the branch above (the optimiser would thread it back in)
     if (updv) {

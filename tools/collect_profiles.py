@@ -38,10 +38,24 @@ for wl, name in (("cornell", "c2"), ("sponza", "c3"), ("bistro", "c5")):
         line = [l for l in open(os.path.join(kt, "bench.log")) if l.startswith("{")]
         with open(os.path.join(P, f"{tag}_{name}.md"), "w") as f:
             f.write(f"# rocprofv3 --kernel-trace --stats of `python3 bench.py --workload <{wl}> --steps 2 --warmup 1 --no-cpu-baseline --no-extra` ({tag})\n\n"
-                    f"Three frames are in the trace (one warm-up + two timed); per frame = totals / 3.  Sum of kernel time per frame: {tot:.2f} ms.  Registers / occupancy: profiles/{tag}_kernel_resources.md.\n\n" + tab + "\n")
+                    f"Three frames are in the trace (one warm-up + two timed), all three with per-kernel events, i.e. the launches one after the other (bench.py warms up in the timed frames' mode since round 4); "
+                    f"per frame = totals / 3.  Sum of kernel time per frame: {tot:.2f} ms.  Registers / occupancy: profiles/{tag}_kernel_resources.md.\n\n" + tab + "\n")
             if line:
                 d = json.loads(line[-1])
-                f.write(f"\nbench line of the same run: {d['value']} {d['unit']}, {d['ms_per_step']} ms per frame; roofline " + json.dumps(d.get("roofline"))[:1500] + "\n")
+                f.write(f"\nbench line of the same run: {d['value']} {d['unit']}, {d['ms_per_step']} ms per frame; roofline " + json.dumps(d.get("roofline"))[:1800] + "\n")
+                # does the trace reproduce the line?  average duration of the dominant class's launches: trace vs HIP events of the same run; frac recomputed from the trace
+                roof = d.get("roofline") or {}
+                cls = {"trace_closest": "k_trace_closest", "trace_shadow": "k_trace_shadow", "shade": "k_shade", "bounce_fused": "k_bounce_small", "raygen": "k_raygen"}.get(roof.get("kernel"), "")
+                calls = tms = 0.0
+                for fcsv in glob.glob(os.path.join(kt, "**", "*kernel_stats.csv"), recursive=True):
+                    for r in csv.DictReader(open(fcsv)):
+                        if cls and cls in r["Name"]:
+                            calls += int(r["Calls"]); tms += float(r["TotalDurationNs"]) / 1e6
+                if calls and roof.get("avg_launch_ms"):
+                    avg_tr = tms / calls
+                    frac_tr = roof["alg_bytes_per_launch"] / (avg_tr * 1e-3) / 1e9 / roof["peak"]
+                    f.write(f"\nCross-check (VERDICT r03 item 2): `{cls}` averages {avg_tr:.4f} ms per launch in this trace ({int(calls)} launches) against {roof['avg_launch_ms']:.4f} ms by the HIP events of the same run "
+                            f"(ratio {avg_tr / roof['avg_launch_ms']:.3f}); `frac` recomputed from the trace {frac_tr:.4f}, the line says {roof['frac']:.4f}.\n")
 for sc in ("garage", "sponza", "bistro"):
     kt = os.path.join(G, f"{tag}_kt_restir_{sc}")
     if os.path.isdir(kt):
