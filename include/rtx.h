@@ -132,6 +132,9 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
        RTX_OPT_MERGE_RAYS = 24,      /* tuning, general scenes: a launch of the persistent traversal kernels that is predicted (from the previous rtx_render's counters) to hold fewer than
                                         this many rays per sub-queue gives each workgroup 2 / 4 / 8 consecutive sub-queues, down to one round of resident workgroups (the late bounces of
                                         a frame, after Russian roulette).  Default 1024; 0 = one sub-queue per workgroup always.  Never changes a result */
+       RTX_OPT_ASYNC = 31,           /* 1: on a caller-bound stream (rtx_set_stream) rtx_render returns once the frame is ENQUEUED; rtx_pack_tiles / rtx_unpack_tiles (and the caller's collective)
+                                        follow it in stream order with no host join in between.  Statistics (rtx_get_stats) and every other entry point join the frame first.  Default 0:
+                                        rtx_render returns with the frame finished.  On the context's own stream the option is ignored */
        RTX_OPT_TRACE_COUNTERS = 30,  /* 1: the persistent traversal kernels count node steps and triangle tests (their generic instantiations; a few per cent slower), read with
                                         rtx_debug_trace_counters: work per ray for the bench record.  Default 0.  Never changes a result */
        RTX_OPT_BVH_REINSERT = 26,    /* BVH builder: passes of the insertion-based topology optimisation after the top-down SAH build (Bittner et al. 2013; default see DESIGN.md section 6c).
@@ -183,7 +186,7 @@ int  rtx_set_camera(rtx_ctx*, const float view[16], const float proj[16]);
    rtx_bind_accum lets the caller own the device buffer (W*H*16 bytes, e.g. a torch tensor); NULL = internal. */
 int  rtx_bind_accum(rtx_ctx*, void* device_rgba32f, size_t bytes);
 int  rtx_clear_accum(rtx_ctx*, uint32_t width, uint32_t height);   /* view-change reset (RayGen_v6_pass3.hlsl:407-423) */
-/* 3x DispatchRays (PopulateCommandList, Renderer.cpp:646-673) -> here: the wavefront loop; synchronous on return */
+/* 3x DispatchRays (PopulateCommandList, Renderer.cpp:646-673) -> here: the wavefront loop; returns with the frame finished (RTX_OPT_ASYNC on a caller-bound stream: enqueued) */
 int  rtx_render(rtx_ctx*, const rtx_params*);
 /* The reference's OWN first pass, literally: RayGen of RayGen_v6_pass1.hlsl:48-190 (first DispatchRays,
    Renderer.cpp:651-654): primary hit, SampleRIS (Sampler_v6.hlsl:653-736), visibility, SamplePathSimple

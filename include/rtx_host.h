@@ -100,6 +100,9 @@ rtx_params* rtxh_renderer_restir_params(rtxh_renderer*);
 rtx_ctx* rtxh_renderer_context(rtxh_renderer*);                           /* the context behind the facade (options, statistics); NULL before on_init */
 int  rtxh_renderer_on_init(rtxh_renderer*);
 int  rtxh_renderer_on_update(rtxh_renderer*);
+/* Renderer::SetInstanceTransform: m_instances[i].second of the reference's OnUpdate (Renderer.cpp:444-449); the next on_update hands the matrix to the context and refits the
+   resident tree on the GPU (transform-only rtx_commit_scene; the reference refits its TLAS every frame, Renderer.cpp:594) */
+int  rtxh_renderer_set_instance_transform(rtxh_renderer*, uint32_t instance, const float o2w[16]);
 int  rtxh_renderer_on_render(rtxh_renderer*);
 int  rtxh_renderer_read_accum(rtxh_renderer*, float* rgba32f, size_t bytes);
 int  rtxh_renderer_read_output(rtxh_renderer*, uint8_t* rgba8, size_t bytes);

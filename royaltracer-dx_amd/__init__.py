@@ -40,7 +40,7 @@ KERNEL_NAMES = {K_RAYGEN: "raygen", K_TRACE: "trace_closest", K_SHADE: "shade", 
 OPT_KERNEL_TIMING, OPT_PATHS_PER_BATCH, OPT_SORT_MATERIALS, OPT_LDS_NODES, OPT_SMALL_SCENE, OPT_FUSED_BOUNCE, OPT_BOUNCE_VARIANT = 1, 2, 3, 4, 5, 6, 7
 OPT_REFILL_MIN, OPT_STACK_PRIVATE, OPT_TRACE_SCHED, OPT_GPU_REFIT, OPT_BLOCKS_PER_CU, OPT_LPT_ORDER, OPT_FUSED_BVH, OPT_WORK_STEALING, OPT_COMPACT_STATE, OPT_OVERLAP_SHADOW = 8, 9, 10, 11, 12, 13, 14, 15, 16, 18
 OPT_RESTIR_WAVEFRONT, OPT_RESTIR_CHUNKS, OPT_OCCLUDER_CACHE, OPT_RESTIR_LANES, OPT_SHADE_DENSE, OPT_MERGE_RAYS, OPT_TAPER = 19, 20, 21, 22, 23, 24, 25
-OPT_BVH_REINSERT, OPT_BVH_SPLIT, OPT_ANYHIT_ORDER, OPT_RESTIR_LANE_MIN, OPT_TRACE_COUNTERS = 26, 27, 28, 29, 30
+OPT_BVH_REINSERT, OPT_BVH_SPLIT, OPT_ANYHIT_ORDER, OPT_RESTIR_LANE_MIN, OPT_TRACE_COUNTERS, OPT_ASYNC = 26, 27, 28, 29, 30, 31
 
 
 class RtxError(RuntimeError):
@@ -185,6 +185,7 @@ _sig("rtxh_renderer_set_mode", C.c_int, _vp, C.c_int)
 _sig("rtxh_renderer_context", _vp, _vp)
 _sig("rtxh_renderer_on_init", C.c_int, _vp)
 _sig("rtxh_renderer_on_update", C.c_int, _vp)
+_sig("rtxh_renderer_set_instance_transform", C.c_int, _vp, _u32, _vp)
 _sig("rtxh_renderer_on_render", C.c_int, _vp)
 _sig("rtxh_renderer_read_accum", C.c_int, _vp, _vp, C.c_size_t)
 _sig("rtxh_renderer_read_output", C.c_int, _vp, _vp, C.c_size_t)
@@ -681,6 +682,11 @@ class Renderer:
 
     def on_update(self):
         self._ck(lib.rtxh_renderer_on_update(self._h), "OnUpdate")
+
+    def set_instance_transform(self, instance, o2w16):
+        """Renderer::SetInstanceTransform: takes effect in the next on_update (transform-only commit = GPU refit)"""
+        m = _f32(o2w16).reshape(16)
+        self._ck(lib.rtxh_renderer_set_instance_transform(self._h, int(instance), _ptr(m)), "SetInstanceTransform")
 
     def on_render(self):
         self._ck(lib.rtxh_renderer_on_render(self._h), "OnRender")

@@ -45,6 +45,9 @@ struct rtx_ctx {
     float view[16], proj[16];
     // path state
     DevBuf d_hitmask, d_order, d_pmask;
+    // RTX_OPT_ASYNC: what finish_render needs of the frame that rtx_render enqueued
+    struct Pending { bool active = false; size_t ncnt = 0; uint32_t nbatches = 0, G = 0, mb = 0, nee = 0, nee1 = 1; bool fused = false, fused_bvh = false; } pending;
+    bool async = false;
     bool trace_counters = false; DevBuf d_trace_cnt;      // RTX_OPT_TRACE_COUNTERS
     int any_order_opt = -1;         // RTX_OPT_ANYHIT_ORDER: -1 = what the commit-time probe chose (BuiltScene::any_order)
     bool lpt_order = true;          // RTX_OPT_LPT_ORDER: fused kernels take their sub-queues longest first
@@ -91,7 +94,11 @@ struct rtx_ctx {
     do { hipError_t e_ = (call);                                                                 \
          if (e_ != hipSuccess) { (c)->err = std::string(#call) + ": " + hipGetErrorString(e_);  \
                                  return e_ == hipErrorOutOfMemory ? RTX_ERR_OOM : RTX_ERR_HIP; } } while (0)
-#define BIND(c) do { if (!(c)) return RTX_ERR_INVALID; HIPCHK(c, hipSetDevice((c)->device)); } while (0)
+// RTX_OPT_ASYNC: an rtx_render that only ENQUEUED its frame leaves statistics to be collected (finish_render: stream sync + counter read-back).  Every entry point joins
+// first (BIND) — except the calls a frame's epilogue is made of, which must stay stream-ordered behind the render without a host join (BIND_NOWAIT: pack / unpack)
+static int finish_render(rtx_ctx* c);
+#define BIND_NOWAIT(c) do { if (!(c)) return RTX_ERR_INVALID; HIPCHK(c, hipSetDevice((c)->device)); } while (0)
+#define BIND(c) do { BIND_NOWAIT(c); if ((c)->pending.active) { const int r_ = finish_render(c); if (r_ != RTX_OK) return r_; } } while (0)
 
 template <class T> static int upload(rtx_ctx* c, DevBuf& b, const std::vector<T>& v) {
     HIPCHK(c, b.ensure(v.size() * sizeof(T)));
@@ -154,6 +161,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     if (!c) return RTX_ERR_INVALID;
     switch (option) {
     case RTX_OPT_KERNEL_TIMING: c->timing = value != 0; return RTX_OK;
+    case RTX_OPT_ASYNC: c->async = value != 0; return RTX_OK;
     case RTX_OPT_TRACE_COUNTERS:
         c->trace_counters = value != 0;
         if (c->trace_counters) { HIPCHK(c, c->d_trace_cnt.ensure(4 * sizeof(unsigned long long))); HIPCHK(c, hipMemsetAsync(c->d_trace_cnt.p, 0, 32, c->stream)); }
@@ -641,28 +649,39 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     }
     HIPCHK(c, hipEventRecord(c->ev_end, st));
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(st));
-    aux_join.armed = false;                    // the main stream waited for the last shadow launch (ev_shadow_done) before the accumulation
+    aux_join.armed = false;                    // the main stream waited for the last shadow launch (ev_shadow_done) before the accumulation: stream order covers the aux stream
+    c->pending.active = true; c->pending.ncnt = ncnt; c->pending.nbatches = nbatches; c->pending.G = G; c->pending.mb = mb; c->pending.nee = nee; c->pending.nee1 = nee1;
+    c->pending.fused = c->dsc.nsmall && c->fused; c->pending.fused_bvh = fused_bvh;
+    // RTX_OPT_ASYNC on a caller-bound stream: the frame is enqueued, the caller goes on enqueueing its epilogue (rtx_pack_tiles -> collective -> rtx_unpack_tiles) behind it
+    // with no host join in between; statistics and the launch-size predictions of the next frame are collected at the next call that needs them (BIND)
+    if (c->async && !c->own_stream) return RTX_OK;
+    return finish_render(c);
+}
+
+static int finish_render(rtx_ctx* c) {
+    if (!c->pending.active) return RTX_OK;
+    c->pending.active = false;
+    const size_t ncnt = c->pending.ncnt; const uint32_t nbatches = c->pending.nbatches, G = c->pending.G, mb = c->pending.mb, nee = c->pending.nee, nee1 = c->pending.nee1;
+    const bool fused = c->pending.fused, fused_bvh = c->pending.fused_bvh;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) c->stats.render_ms = ms;
     for (const TimedLaunch& t : c->timed) { float m = 0.0f; if (hipEventElapsedTime(&m, t.a, t.b) == hipSuccess) c->stats.kernel_ms[t.cls] += m; }
-    if (!(c->dsc.nsmall && c->fused) && !fused_bvh) { c->pred_paths = 0; c->pred_q.assign(mb, 0); c->pred_s.assign((size_t)mb * nee1, 0); c->pred_nee1 = nee1; }
+    if (!fused && !fused_bvh) { c->pred_paths = 0; c->pred_q.assign(mb, 0); c->pred_s.assign((size_t)mb * nee1, 0); c->pred_nee1 = nee1; }
     for (uint32_t bi = 0; bi < nbatches; bi++) {
         const uint32_t* h = c->h_counters + (size_t)bi * ncnt;
         auto sumG = [&](size_t row) { uint64_t s = 0; for (uint32_t g = 0; g < G; g++) s += h[row * G + g]; return s; };
-        if (!(c->dsc.nsmall && c->fused) && !fused_bvh) {                 // what the next call's launches are sized by (merge_for)
+        if (!fused && !fused_bvh) {                 // what the next call's launches are sized by (merge_for)
             c->pred_paths += sumG(0);
             for (uint32_t b = 0; b < mb; b++) { c->pred_q[b] += sumG(b); for (uint32_t j = 0; j < nee1; j++) c->pred_s[(size_t)b * nee1 + j] += sumG((size_t)(mb + 1) + (size_t)b * nee1 + j); }
         }
-        const bool fusedb = c->dsc.nsmall && c->fused;
-        const uint64_t prim = fusedb ? sumG((size_t)(mb + 1) + (size_t)mb * nee1) : sumG(0);
+        const uint64_t prim = fused ? sumG((size_t)(mb + 1) + (size_t)mb * nee1) : sumG(0);
         c->stats.rays_primary += prim; c->stats.paths += prim;
-        c->stats.primary_hits += fusedb ? sumG(0) : 0;
+        c->stats.primary_hits += fused ? sumG(0) : 0;
         for (uint32_t b = 1; b < mb; b++) c->stats.rays_extension += sumG(b);
         for (uint32_t b = 0; b < mb; b++) for (uint32_t j = 0; j < nee; j++) c->stats.rays_shadow += sumG((size_t)(mb + 1) + (size_t)b * nee1 + j);
     }
     c->stats.kernel_items[RTX_K_RAYGEN] = c->stats.paths;
-    const bool fused = c->dsc.nsmall && c->fused;
     c->stats.kernel_items[RTX_K_BOUNCE] = fused ? c->stats.primary_hits + c->stats.rays_extension : fused_bvh ? c->stats.rays_primary + c->stats.rays_extension : 0;   // tiny scenes: bounce 0 shades the primary hits only
     c->stats.kernel_items[RTX_K_TRACE] = (fused || fused_bvh) ? 0 : c->stats.rays_primary + c->stats.rays_extension;
     c->stats.kernel_items[RTX_K_SHADE] = (fused || fused_bvh) ? 0 : c->stats.rays_primary + c->stats.rays_extension;
@@ -1033,7 +1052,7 @@ int rtx_read_layer(rtx_ctx* c, uint32_t layer, uint32_t width, uint32_t height, 
     return RTX_OK;
 }
 
-int rtx_get_stats(rtx_ctx* c, rtx_stats* out) { if (!c || !out) return RTX_ERR_INVALID; *out = c->stats; return RTX_OK; }
+int rtx_get_stats(rtx_ctx* c, rtx_stats* out) { if (!out) return RTX_ERR_INVALID; BIND(c); *out = c->stats; return RTX_OK; }     // (joins a frame that RTX_OPT_ASYNC left in flight)
 
 int rtx_get_lights(rtx_ctx* c, void* out80, uint32_t max_count, uint32_t* count_out) {
     if (!c) return RTX_ERR_INVALID;
@@ -1052,7 +1071,7 @@ int rtx_shard_slab_bytes(const rtx_params* p, size_t* bytes) {
     return RTX_OK;
 }
 int rtx_pack_tiles(rtx_ctx* c, const rtx_params* p, void* slab) {
-    BIND(c);
+    BIND_NOWAIT(c);                       // stream-ordered behind an enqueued rtx_render (RTX_OPT_ASYNC): no host join
     DevFrame f; int r = make_frame(c, p, f); if (r) return r;
     if (!slab || !c->accum_ptr() || c->acc_w != p->width || c->acc_h != p->height) { c->err = "pack_tiles: no accumulation buffer of that size"; return RTX_ERR_STATE; }
     launch_pack_tiles(c->stream, (uint32_t)c->num_cus * 8u, f, c->accum_ptr(), (F4*)slab);
@@ -1061,7 +1080,7 @@ int rtx_pack_tiles(rtx_ctx* c, const rtx_params* p, void* slab) {
     return RTX_OK;
 }
 int rtx_unpack_tiles(rtx_ctx* c, const rtx_params* p, const void* slabs) {
-    BIND(c);
+    BIND_NOWAIT(c);                       // stream-ordered behind an enqueued rtx_render (RTX_OPT_ASYNC): no host join
     DevFrame f; int r = make_frame(c, p, f); if (r) return r;
     if (!slabs) return RTX_ERR_INVALID;
     if ((r = ensure_accum(c, p->width, p->height, false))) return r;

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <stdexcept>
 #include <thread>
 
@@ -18,20 +20,44 @@ struct MultiGpuFrame::Impl {
     std::vector<void*> state_slab, state_gathered;      // ReSTIR frames: the history records (u3 / u5 / u7) of the rank's own tiles, 140 B per pixel
     std::vector<ncclComm_t> comm;
     size_t slab_bytes = 0, state_bytes = 0;
+    // persistent per-rank worker threads (round 4: a frame used to create and join N std::threads): a worker sleeps on `cv` until `gen` moves, runs `job(rank)`, counts itself done
+    std::vector<std::thread> worker;
+    std::mutex mu; std::condition_variable cv, cv_done;
+    const std::function<void(int)>* job = nullptr;
+    unsigned long long gen = 0; int done = 0, nactive = 0; bool quit = false;
+    std::vector<std::string> err;
 };
 
-MultiGpuFrame::MultiGpuFrame(const std::vector<int>& devices, Gather g, bool always_gather) : m(new Impl), m_devices(devices), m_stats(devices.size()), m_gather(g), m_always(always_gather) {
+MultiGpuFrame::MultiGpuFrame(const std::vector<int>& devices, Gather g, bool always_gather, int only_rank) : m(new Impl), m_devices(devices), m_stats(devices.size()), m_gather(g), m_always(always_gather), m_only(only_rank) {
     // a constructor that throws runs no destructor: whatever was created before the failure (contexts, streams, communicators, Impl itself) is torn down here
     try {
         if (devices.empty()) throw std::runtime_error("MultiGpuFrame: no devices");
         const int n = (int)devices.size();
+        if (only_rank >= n || (only_rank >= 0 && g != Gather::COPY)) throw std::runtime_error("MultiGpuFrame: only_rank needs a rank of the list and Gather::COPY");
         m->ctx.assign(n, nullptr); m->stream.assign(n, nullptr); m->slab.assign(n, nullptr); m->gathered.assign(n, nullptr);
         m->state_slab.assign(n, nullptr); m->state_gathered.assign(n, nullptr);
         for (int r = 0; r < n; r++) {
+            if (only_rank >= 0 && r != only_rank) continue;
             if (rtx_create(devices[r], &m->ctx[r]) != RTX_OK) throw std::runtime_error(std::string("rtx_create: ") + rtx_last_error(nullptr));
             hipck(hipSetDevice(devices[r]), "hipSetDevice");
             hipck(hipStreamCreateWithFlags(&m->stream[r], hipStreamNonBlocking), "hipStreamCreate");
-            if (rtx_set_stream(m->ctx[r], m->stream[r]) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));   // pack -> gather -> unpack run stream-ordered
+            if (rtx_set_stream(m->ctx[r], m->stream[r]) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));   // render -> pack -> gather -> unpack run stream-ordered
+            if (rtx_set_option(m->ctx[r], RTX_OPT_ASYNC, 1) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));   // rtx_render only enqueues: no host join before the pack
+        }
+        m->err.assign(n, std::string());
+        for (int r = 0; r < n; r++) {
+            if (!m->ctx[r]) continue;
+            m->nactive++;
+            m->worker.emplace_back([this, r] {
+                unsigned long long seen = 0;
+                for (;;) {
+                    const std::function<void(int)>* job;
+                    { std::unique_lock<std::mutex> lk(m->mu); m->cv.wait(lk, [&] { return m->quit || m->gen != seen; }); if (m->quit) return; seen = m->gen; job = m->job; }
+                    try { (void)hipSetDevice(m_devices[r]); (*job)(r); } catch (const std::exception& e) { m->err[r] = e.what(); }
+                    { std::lock_guard<std::mutex> lk(m->mu); m->done++; }
+                    m->cv_done.notify_one();
+                }
+            });
         }
         if (g == Gather::RCCL && (n > 1 || always_gather)) {
             m->comm.assign(n, nullptr);
@@ -40,9 +66,21 @@ MultiGpuFrame::MultiGpuFrame(const std::vector<int>& devices, Gather g, bool alw
     } catch (...) { Teardown(); throw; }
 }
 
+void MultiGpuFrame::RunOnRanks(const std::function<void(int)>& job) {
+    for (auto& e : m->err) e.clear();
+    { std::lock_guard<std::mutex> lk(m->mu); m->job = &job; m->done = 0; m->gen++; }
+    m->cv.notify_all();
+    { std::unique_lock<std::mutex> lk(m->mu); m->cv_done.wait(lk, [&] { return m->done == m->nactive; }); m->job = nullptr; }
+    for (auto& e : m->err) if (!e.empty()) throw std::runtime_error(e);
+}
+
 void MultiGpuFrame::Teardown() {
     if (!m) return;
+    { std::lock_guard<std::mutex> lk(m->mu); m->quit = true; }
+    m->cv.notify_all();
+    for (auto& t : m->worker) if (t.joinable()) t.join();
     for (size_t r = 0; r < m->ctx.size(); r++) {
+        if (!m->ctx[r] && !m->stream[r]) continue;
         (void)hipSetDevice(m_devices[r]);
         if (m->stream[r]) (void)hipStreamSynchronize(m->stream[r]);
         if (r < m->comm.size() && m->comm[r]) (void)ncclCommDestroy(m->comm[r]);
@@ -60,6 +98,7 @@ void MultiGpuFrame::EnsureSlabs(std::vector<void*>& slab, std::vector<void*>& ga
     const int n = (int)m->ctx.size();
     have = 0;
     for (int r = 0; r < n; r++) {
+        if (!m->ctx[r]) continue;
         hipck(hipSetDevice(m_devices[r]), "hipSetDevice");
         if (slab[r]) { (void)hipFree(slab[r]); slab[r] = nullptr; }
         if (gathered[r]) { (void)hipFree(gathered[r]); gathered[r] = nullptr; }
@@ -77,6 +116,9 @@ void MultiGpuFrame::AllGather(std::vector<void*>& slab, std::vector<void*>& gath
         for (int r = 0; r < n; r++)
             ncclck(ncclAllGather(slab[r], gathered[r], bytes / sizeof(float), ncclFloat, m->comm[r], m->stream[r]), "ncclAllGather");
         ncclck(ncclGroupEnd(), "ncclGroupEnd");
+    } else if (m_only >= 0) {                                                       // one rank of N measured alone: its own slab into its slot, stream-ordered (what the collective hands back to it)
+        hipck(hipSetDevice(m_devices[m_only]), "hipSetDevice");
+        hipck(hipMemcpyAsync((char*)gathered[m_only] + (size_t)m_only * bytes, slab[m_only], bytes, hipMemcpyDeviceToDevice, m->stream[m_only]), "copy slab");
     } else {                                                                        // testing stand-in (one GPU, several ranks): plain device copies
         for (int r = 0; r < n; r++) { hipck(hipSetDevice(m_devices[r]), "hipSetDevice"); hipck(hipStreamSynchronize(m->stream[r]), "sync pack"); }
         for (int r = 0; r < n; r++) {
@@ -88,11 +130,8 @@ void MultiGpuFrame::AllGather(std::vector<void*>& slab, std::vector<void*>& gath
 }
 
 void MultiGpuFrame::SetScene(const Scene& s, float aspect) {
-    std::vector<std::thread> th; std::vector<std::string> err(m->ctx.size());
-    for (size_t r = 0; r < m->ctx.size(); r++)        // uploads + BVH builds run in parallel, one thread per context (SURVEY 8(b) threading contract)
-        th.emplace_back([&, r] { if (UploadScene(s, m->ctx[r], aspect) != RTX_OK) err[r] = rtx_last_error(m->ctx[r]); });
-    for (auto& t : th) t.join();
-    for (auto& e : err) if (!e.empty()) throw std::runtime_error("MultiGpuFrame::SetScene: " + e);
+    // uploads + BVH builds run in parallel, one (persistent) thread per context (SURVEY 8(b) threading contract)
+    RunOnRanks([&](int r) { if (UploadScene(s, m->ctx[r], aspect) != RTX_OK) throw std::runtime_error(std::string("MultiGpuFrame::SetScene: ") + rtx_last_error(m->ctx[r])); });
 }
 
 void MultiGpuFrame::Render(const rtx_params& p0) {
@@ -102,32 +141,37 @@ void MultiGpuFrame::Render(const rtx_params& p0) {
     if (rtx_shard_slab_bytes(&probe, &bytes) != RTX_OK) throw std::runtime_error(std::string("rtx_shard_slab_bytes: ") + rtx_last_error(nullptr));
     EnsureSlabs(m->slab, m->gathered, m->slab_bytes, bytes);
     m_w = p0.width; m_h = p0.height;
-    std::vector<std::string> err(n);
     const auto t0 = std::chrono::steady_clock::now();
-    // phase 1, one thread per rank (rtx_render is synchronous; different contexts may be driven from different threads): render my tiles, enqueue the pack
-    std::vector<std::thread> th;
-    for (int r = 0; r < n; r++) th.emplace_back([&, r] {
-        try {
-            hipck(hipSetDevice(m_devices[r]), "hipSetDevice");
-            rtx_params p = p0; p.shard_rank = (uint32_t)r; p.shard_count = (uint32_t)n;
-            if (rtx_render(m->ctx[r], &p) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));
-            (void)rtx_get_stats(m->ctx[r], &m_stats[r]);
-            if ((n > 1 || m_always) && rtx_pack_tiles(m->ctx[r], &p, m->slab[r]) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));
-        } catch (const std::exception& e) { err[r] = e.what(); }
+    // phase 1, on every rank's worker thread (different contexts may be driven from different threads): ENQUEUE my tiles' frame (RTX_OPT_ASYNC) and the pack behind it
+    RunOnRanks([&](int r) {
+        rtx_params p = p0; p.shard_rank = (uint32_t)r; p.shard_count = (uint32_t)n;
+        if (rtx_render(m->ctx[r], &p) != RTX_OK) throw std::runtime_error(std::string("MultiGpuFrame::Render: ") + rtx_last_error(m->ctx[r]));
+        if ((n > 1 || m_always) && rtx_pack_tiles(m->ctx[r], &p, m->slab[r]) != RTX_OK) throw std::runtime_error(std::string("MultiGpuFrame::Render: ") + rtx_last_error(m->ctx[r]));
     });
-    for (auto& t : th) t.join();
-    for (auto& e : err) if (!e.empty()) throw std::runtime_error("MultiGpuFrame::Render: " + e);
     if (n > 1 || m_always) {
         AllGather(m->slab, m->gathered, bytes);                                         // phase 2: ONE collective per frame
         // phase 3: every rank scatters all slabs into its accumulation buffer (enqueued behind the gather on the same stream)
         for (int r = 0; r < n; r++) {
+            if (!m->ctx[r]) continue;
             rtx_params p = p0; p.shard_rank = (uint32_t)r; p.shard_count = (uint32_t)n;
             hipck(hipSetDevice(m_devices[r]), "hipSetDevice");
             if (rtx_unpack_tiles(m->ctx[r], &p, m->gathered[r]) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));
         }
-        for (int r = 0; r < n; r++) { hipck(hipSetDevice(m_devices[r]), "hipSetDevice"); hipck(hipStreamSynchronize(m->stream[r]), "sync frame"); }
     }
+    // the ONE host wait of the frame: every rank's stream (render -> pack -> gather -> unpack)
+    for (int r = 0; r < n; r++) { if (!m->ctx[r]) continue; hipck(hipSetDevice(m_devices[r]), "hipSetDevice"); hipck(hipStreamSynchronize(m->stream[r]), "sync frame"); }
     m_lastMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (int r = 0; r < n; r++) if (m->ctx[r]) (void)rtx_get_stats(m->ctx[r], &m_stats[r]);          // (collects the counters of the finished frame)
+}
+
+void MultiGpuFrame::SetInstanceTransform(uint32_t instance, const float o2w[16]) {
+    const auto t0 = std::chrono::steady_clock::now();
+    RunOnRanks([&](int r) {
+        if (rtx_set_instance_transform(m->ctx[r], instance, o2w) != RTX_OK || rtx_commit_scene(m->ctx[r]) != RTX_OK)
+            throw std::runtime_error(std::string("MultiGpuFrame::SetInstanceTransform: ") + rtx_last_error(m->ctx[r]));
+    });
+    for (size_t r = 0; r < m->ctx.size(); r++) { if (!m->ctx[r]) continue; hipck(hipSetDevice(m_devices[r]), "hipSetDevice"); hipck(hipStreamSynchronize(m->stream[r]), "sync refit"); }
+    m_refitMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
 void MultiGpuFrame::RenderRestir(const rtx_params& p0) {
@@ -138,20 +182,13 @@ void MultiGpuFrame::RenderRestir(const rtx_params& p0) {
     const bool gather = n > 1 || m_always;
     if (gather) { EnsureSlabs(m->slab, m->gathered, m->slab_bytes, bytes); EnsureSlabs(m->state_slab, m->state_gathered, m->state_bytes, sbytes); }
     m_w = p0.width; m_h = p0.height;
-    std::vector<std::string> err(n);
     const auto t0 = std::chrono::steady_clock::now();
-    std::vector<std::thread> th;
-    for (int r = 0; r < n; r++) th.emplace_back([&, r] {            // phase 1: the three passes on my tiles, then both packs enqueued behind them
-        try {
-            hipck(hipSetDevice(m_devices[r]), "hipSetDevice");
-            rtx_params p = p0; p.shard_rank = (uint32_t)r; p.shard_count = (uint32_t)n;
-            if (rtx_render_restir(m->ctx[r], &p) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));
-            (void)rtx_get_stats(m->ctx[r], &m_stats[r]);
-            if (gather && (rtx_restir_pack_state(m->ctx[r], &p, m->state_slab[r]) != RTX_OK || rtx_pack_tiles(m->ctx[r], &p, m->slab[r]) != RTX_OK)) throw std::runtime_error(rtx_last_error(m->ctx[r]));
-        } catch (const std::exception& e) { err[r] = e.what(); }
+    RunOnRanks([&](int r) {                                             // phase 1: the three passes on my tiles, then both packs enqueued behind them
+        rtx_params p = p0; p.shard_rank = (uint32_t)r; p.shard_count = (uint32_t)n;
+        if (rtx_render_restir(m->ctx[r], &p) != RTX_OK) throw std::runtime_error(std::string("MultiGpuFrame::RenderRestir: ") + rtx_last_error(m->ctx[r]));
+        (void)rtx_get_stats(m->ctx[r], &m_stats[r]);
+        if (gather && (rtx_restir_pack_state(m->ctx[r], &p, m->state_slab[r]) != RTX_OK || rtx_pack_tiles(m->ctx[r], &p, m->slab[r]) != RTX_OK)) throw std::runtime_error(std::string("MultiGpuFrame::RenderRestir: ") + rtx_last_error(m->ctx[r]));
     });
-    for (auto& t : th) t.join();
-    for (auto& e : err) if (!e.empty()) throw std::runtime_error("MultiGpuFrame::RenderRestir: " + e);
     if (gather) {
         if (m_gather == Gather::RCCL) {                                 // phase 2: the frame's ONE exchange: history + framebuffer tiles in one group
             ncclck(ncclGroupStart(), "ncclGroupStart");
@@ -162,26 +199,27 @@ void MultiGpuFrame::RenderRestir(const rtx_params& p0) {
             ncclck(ncclGroupEnd(), "ncclGroupEnd");
         } else { AllGather(m->state_slab, m->state_gathered, sbytes); AllGather(m->slab, m->gathered, bytes); }
         for (int r = 0; r < n; r++) {                                   // phase 3: scatter both, stream-ordered behind the gathers
+            if (!m->ctx[r]) continue;
             rtx_params p = p0; p.shard_rank = (uint32_t)r; p.shard_count = (uint32_t)n;
             hipck(hipSetDevice(m_devices[r]), "hipSetDevice");
             if (rtx_restir_unpack_state(m->ctx[r], &p, m->state_gathered[r]) != RTX_OK || rtx_unpack_tiles(m->ctx[r], &p, m->gathered[r]) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));
         }
-        for (int r = 0; r < n; r++) { hipck(hipSetDevice(m_devices[r]), "hipSetDevice"); hipck(hipStreamSynchronize(m->stream[r]), "sync frame"); }
+        for (int r = 0; r < n; r++) { if (!m->ctx[r]) continue; hipck(hipSetDevice(m_devices[r]), "hipSetDevice"); hipck(hipStreamSynchronize(m->stream[r]), "sync frame"); }
     }
     m_lastMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 void MultiGpuFrame::SetCamera(const float view[16], const float proj[16]) {
-    for (size_t r = 0; r < m->ctx.size(); r++) { hipck(hipSetDevice(m_devices[r]), "hipSetDevice"); if (rtx_set_camera(m->ctx[r], view, proj) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r])); }
+    for (size_t r = 0; r < m->ctx.size(); r++) { if (!m->ctx[r]) continue; hipck(hipSetDevice(m_devices[r]), "hipSetDevice"); if (rtx_set_camera(m->ctx[r], view, proj) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r])); }
 }
 void MultiGpuFrame::ResetRestir() {
-    for (size_t r = 0; r < m->ctx.size(); r++) { hipck(hipSetDevice(m_devices[r]), "hipSetDevice"); if (rtx_restir_reset(m->ctx[r]) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r])); }
+    for (size_t r = 0; r < m->ctx.size(); r++) { if (!m->ctx[r]) continue; hipck(hipSetDevice(m_devices[r]), "hipSetDevice"); if (rtx_restir_reset(m->ctx[r]) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r])); }
 }
 void MultiGpuFrame::SetOption(int option, int64_t value) {
-    for (size_t r = 0; r < m->ctx.size(); r++) if (rtx_set_option(m->ctx[r], option, value) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));
+    for (size_t r = 0; r < m->ctx.size(); r++) if (m->ctx[r] && rtx_set_option(m->ctx[r], option, value) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));
 }
 
 void MultiGpuFrame::Clear(uint32_t w, uint32_t h) {
-    for (size_t r = 0; r < m->ctx.size(); r++) { hipck(hipSetDevice(m_devices[r]), "hipSetDevice"); if (rtx_clear_accum(m->ctx[r], w, h) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r])); }
+    for (size_t r = 0; r < m->ctx.size(); r++) { if (!m->ctx[r]) continue; hipck(hipSetDevice(m_devices[r]), "hipSetDevice"); if (rtx_clear_accum(m->ctx[r], w, h) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r])); }
     m_w = w; m_h = h;
 }
 std::vector<float> MultiGpuFrame::ReadAccumulation(int rank) {

@@ -8,6 +8,7 @@
 // librtx_hip.so.  For tests on ONE GPU (two ranks cannot share a device under RCCL) the gather can be replaced by plain device-to-device copies
 // (Gather::COPY): the same slab layout, the same pack / unpack kernels, the same result.
 #pragma once
+#include <functional>
 #include <string>
 #include <vector>
 #include "Scenes.h"
@@ -17,7 +18,9 @@ public:
     enum class Gather { RCCL, COPY };
     // always_gather: run pack -> collective -> unpack even with ONE rank (a one-rank communicator): exercises the RCCL path of the frame — communicator setup,
     // ncclGroupStart / ncclAllGather / ncclGroupEnd on the rank's stream, the slab round trip — on a machine with a single GPU
-    MultiGpuFrame(const std::vector<int>& devices, Gather g, bool always_gather = false);
+    // only_rank >= 0 (measurement on ONE GPU): the frame of an N-rank run as rank `only_rank` alone sees it — its worker thread, its enqueue-only render, its pack, the gather
+    // (its own slab copied into its slot of the gathered buffer; Gather::COPY only), its unpack, one sync — so that per-rank times include the host path (tools/shard_time.py native=1)
+    MultiGpuFrame(const std::vector<int>& devices, Gather g, bool always_gather = false, int only_rank = -1);
     ~MultiGpuFrame();
     void SetScene(const Scene& s, float aspect);          // replicated on every GPU (Bistro-class: 0.4 GB << 288 GB)
     // one frame: p.shard_rank / shard_count are filled per rank; the assembled accumulation buffer ends up on EVERY rank (all-gather)
@@ -26,6 +29,10 @@ public:
     // the 20-px spatial radius, pass 3 on its own), then ONE group of collectives ends the frame: the all-gather of the history records of the own tiles (u3 / u5 / u7,
     // 140 B per pixel: the next frame's temporal pass reprojects to arbitrary pixels) and the all-gather of the framebuffer tiles.  p.spp must be 1.
     void RenderRestir(const rtx_params& p);
+    // a moving instance (the reference re-sets instance 1 and refits its TLAS every frame: Renderer.cpp:444-452, 594): rtx_set_instance_transform + a transform-only
+    // rtx_commit_scene on EVERY rank — the scene is replicated, so every rank refits its own copy of the tree on its GPU (k_refit_tris / k_refit_nodes)
+    void SetInstanceTransform(uint32_t instance, const float o2w[16]);
+    double LastRefitMs() const { return m_refitMs; }        // wall time of the last SetInstanceTransform: max over ranks
     void SetCamera(const float view[16], const float proj[16]);   // every rank (rtx_set_camera keeps the previous matrices for the reprojection)
     void ResetRestir();                                   // forget the ReSTIR history on every rank
     void SetOption(int option, int64_t value);            // rtx_set_option on every rank
@@ -39,12 +46,14 @@ private:
     struct Impl;
     Impl* m;
     void Teardown();
+    void RunOnRanks(const std::function<void(int)>& job);      // every active rank's persistent worker thread runs job(rank); returns when all have finished; rethrows the first error
     void EnsureSlabs(std::vector<void*>& slab, std::vector<void*>& gathered, size_t& have, size_t bytes);
     void AllGather(std::vector<void*>& slab, std::vector<void*>& gathered, size_t bytes);
     std::vector<int> m_devices;
     std::vector<rtx_stats> m_stats;
     Gather m_gather;
     bool m_always = false;
-    double m_lastMs = 0.0;
+    double m_lastMs = 0.0, m_refitMs = 0.0;
+    int m_only = -1;
     uint32_t m_w = 0, m_h = 0;
 };

@@ -1,4 +1,5 @@
 #include "Renderer.h"
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
@@ -51,11 +52,26 @@ void Renderer::UpdateCameraBuffer() {
     memcpy(m_prevView, view, 64); m_havePrev = true;                                // :1766-1767
 }
 
+void Renderer::SetInstanceTransform(UINT instance, const XMMATRIX& objectToWorld) {
+    if (instance >= m_scene.instances.size()) throw std::out_of_range("Renderer::SetInstanceTransform: no such instance");
+    m_scene.instances[instance].transform = objectToWorld;
+    for (UINT i : m_movedInstances) if (i == instance) return;
+    m_movedInstances.push_back(instance);
+}
+
 void Renderer::OnUpdate() {
     UpdateCameraBuffer();
     m_time++;                                                                       // Renderer.cpp:438
-    // the reference re-sets instance 1 every frame to the same matrix (Renderer.cpp:444-449) and refits the TLAS
-    // (:594); the matrix is already in the scene, nothing changes between frames, so no re-commit is needed.
+    // The reference re-sets instance 1 every frame (Renderer.cpp:444-449), rebuilds InstanceProperties (:451, 2091-2121) and refits the TLAS (:594).  Here an instance
+    // moves when SetInstanceTransform was called since the last update: its matrix goes to the context (which keeps the old one as prevObjectToWorld for the temporal
+    // pass) and ONE transform-only commit refits the resident tree (k_refit_tris / k_refit_nodes).  Nothing moved: nothing to do.
+    if (!m_movedInstances.empty()) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (UINT i : m_movedInstances) Check(rtx_set_instance_transform(m_ctx, i, m_scene.instances[i].transform.data()), "rtx_set_instance_transform");
+        Check(rtx_commit_scene(m_ctx), "rtx_commit_scene");
+        m_movedInstances.clear();
+        m_refitMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
 }
 
 void Renderer::OnRender() {

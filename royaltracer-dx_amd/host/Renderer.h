@@ -23,6 +23,10 @@ public:
     void SetMode(Mode m) { m_mode = m; }
     Mode GetMode() const { return m_mode; }
     rtx_params& RestirParams() { return m_restir; }
+    // m_instances[i].second = ... of the reference's OnUpdate (Renderer.cpp:444-449): the matrix takes effect in the next OnUpdate, which hands it to the context and
+    // re-commits — a transform-only commit, i.e. a REFIT of the resident tree on the GPU (the reference refits its TLAS every frame, Renderer.cpp:594, 2091-2121)
+    void SetInstanceTransform(UINT instance, const XMMATRIX& objectToWorld);
+    double LastRefitMs() const { return m_refitMs; }
 
     void OnInit();      // Renderer.cpp:44-103: camera lookat, load models, build acceleration structures, upload
     void OnUpdate();    // Renderer.cpp:431-452: camera buffer, instance 1 rotation, instance properties
@@ -53,4 +57,5 @@ private:
     UINT m_currentDisplayLevel = 0;                  // Renderer.h:298
     std::vector<UINT> m_displayLevels = {0, 10, 11, 12, 13, 14, 15, 16, 17, 20, 21, 22, 23, 24, 25, 26, 27, 28};   // Renderer.h:299
     float m_prevView[16]; bool m_havePrev = false;   // m_prevViewMatrix
+    std::vector<UINT> m_movedInstances; double m_refitMs = 0.0;
 };

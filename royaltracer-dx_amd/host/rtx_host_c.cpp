@@ -332,6 +332,7 @@ rtx_params* rtxh_renderer_restir_params(rtxh_renderer* r) { return &r->r->Restir
 rtx_ctx* rtxh_renderer_context(rtxh_renderer* r) { return r->r->Context(); }
 int rtxh_renderer_on_init(rtxh_renderer* r) { return guarded_rc([&] { r->r->OnInit(); }); }
 int rtxh_renderer_on_update(rtxh_renderer* r) { return guarded_rc([&] { r->r->OnUpdate(); }); }
+int rtxh_renderer_set_instance_transform(rtxh_renderer* r, uint32_t instance, const float o2w[16]) { return guarded_rc([&] { XMMATRIX m; memcpy(m.data(), o2w, 64); r->r->SetInstanceTransform(instance, m); }); }
 int rtxh_renderer_on_render(rtxh_renderer* r) { return guarded_rc([&] { r->r->OnRender(); }); }
 int rtxh_renderer_read_accum(rtxh_renderer* r, float* out, size_t bytes) {
     return guarded_rc([&] { auto v = r->r->ReadAccumulation(); if (bytes < v.size() * 4) throw std::runtime_error("buffer too small"); memcpy(out, v.data(), v.size() * 4); });

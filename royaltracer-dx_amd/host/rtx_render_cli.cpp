@@ -6,6 +6,9 @@
 //                   32-px tiles) and exchange history + framebuffer tiles once per frame; [--literal] = the thread-per-pixel kernels instead of the wavefront stages;
 //                   [--force-gather] with --gpus 1: pack -> RCCL all-gather of a one-rank communicator -> unpack all the same (exercises the collective path on one GPU);
 //                   [--orbit deg] moves the camera about the look-at point between frames (exercises the reprojection)
+//                   [--spin deg] turns instance 1 (the reference's moving instance, Renderer.cpp:444-449) by `deg` about the vertical axis before every frame after the first: a
+//                   transform-only commit = a refit of the resident tree on the GPU, on every rank with --gpus N (the reference refits its TLAS every frame, Renderer.cpp:594)
+//                   [--only-rank r] with --gpus N --gather copy: rank r of N alone, through the same host path (measurement on one GPU: tools/shard_time.py native=1)
 //                   [--gpus N [--devices 0,1,..] [--gather rccl|copy]]   the native N-GPU frame (MultiGpu.h): one process, N contexts, pixel tiles
 //                   round-robin, ONE RCCL all-gather per frame; `--gather copy` replaces the collective by device copies (several ranks on one GPU: tests)
 #include <cstdio>
@@ -23,13 +26,13 @@
 int main(int argc, char** argv) {
     std::string scene = "cornell", out, objs, mtl = "./";
     UINT w = 1920, h = 1080, spp = 1, frames = 1, bounces = 8, nee = 1; int device = 0; bool lambert = false;
-    int gpus = 1; std::string devlist, gather = "rccl", mode = "pt"; bool literal = false, nee_set = false, bounces_set = false, force_gather = false; float orbit = 0.0f;
+    int gpus = 1; std::string devlist, gather = "rccl", mode = "pt"; bool literal = false, nee_set = false, bounces_set = false, force_gather = false; float orbit = 0.0f, spin = 0.0f; int only_rank = -1;
     for (int i = 1; i < argc; i++) {
         auto arg = [&](const char* k) { return !strcmp(argv[i], k) && i + 1 < argc; };
         if (arg("--scene")) scene = argv[++i]; else if (arg("--obj")) { objs = argv[++i]; scene = "obj"; } else if (arg("--mtl")) mtl = argv[++i];
         else if (arg("--w")) w = atoi(argv[++i]); else if (arg("--h")) h = atoi(argv[++i]); else if (arg("--spp")) spp = atoi(argv[++i]);
         else if (arg("--frames")) frames = atoi(argv[++i]); else if (arg("--bounces")) { bounces = atoi(argv[++i]); bounces_set = true; } else if (arg("--nee")) { nee = atoi(argv[++i]); nee_set = true; }
-        else if (arg("--mode")) mode = argv[++i]; else if (arg("--orbit")) orbit = (float)atof(argv[++i]); else if (!strcmp(argv[i], "--literal")) literal = true; else if (!strcmp(argv[i], "--force-gather")) force_gather = true;
+        else if (arg("--mode")) mode = argv[++i]; else if (arg("--orbit")) orbit = (float)atof(argv[++i]); else if (arg("--spin")) spin = (float)atof(argv[++i]); else if (arg("--only-rank")) only_rank = atoi(argv[++i]); else if (!strcmp(argv[i], "--literal")) literal = true; else if (!strcmp(argv[i], "--force-gather")) force_gather = true;
         else if (arg("--gpus")) gpus = atoi(argv[++i]); else if (arg("--devices")) devlist = argv[++i]; else if (arg("--gather")) gather = argv[++i];
         else if (arg("--out")) out = argv[++i]; else if (arg("--device")) device = atoi(argv[++i]); else if (!strcmp(argv[i], "--lambert")) lambert = true;
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
@@ -43,6 +46,8 @@ int main(int argc, char** argv) {
         const float dx = sc.eye.x - sc.center.x, dz = sc.eye.z - sc.center.z;
         return XMFLOAT3(sc.center.x + cs * dx + sn * dz, sc.eye.y, sc.center.z - sn * dx + cs * dz);
     };
+    // instance 1 at frame f: its start-up matrix turned by f * spin degrees about the vertical axis (row-vector convention: M * R)
+    auto spun = [&](const Scene& sc, UINT f) { return sc.instances[1].transform * XMMatrixRotationAxis({0.f, 1.f, 0.f}, spin * 3.14159265f / 180.0f * (float)f); };
     auto write_image = [&](const std::vector<float>& acc, const std::vector<uint8_t>& px) {
         const bool exr = out.size() > 4 && out.substr(out.size() - 4) == ".exr", png = out.size() > 4 && out.substr(out.size() - 4) == ".png";
         return exr ? WriteEXR(out, acc.data(), w, h) : png ? WritePNG(out, px.data(), w, h) : WritePPM(out, px.data(), w, h);
@@ -56,7 +61,7 @@ int main(int argc, char** argv) {
             Scene sc = scene == "cornell" ? MakeCornellBox() : scene == "sponza" ? MakeSponzaClass() : scene == "bistro" ? MakeBistroClass() : Scene();
             if (scene == "obj") { std::vector<std::string> f; std::stringstream ss(objs); std::string t; while (std::getline(ss, t, ',')) f.push_back(t); sc = LoadObjScene(f, mtl); }
             if (scene == "cornell") lambert = true;
-            MultiGpuFrame mg(devs, gather == "copy" ? MultiGpuFrame::Gather::COPY : MultiGpuFrame::Gather::RCCL, force_gather);      // --force-gather: the collective also with one rank
+            MultiGpuFrame mg(devs, gather == "copy" ? MultiGpuFrame::Gather::COPY : MultiGpuFrame::Gather::RCCL, force_gather, only_rank);      // --force-gather: the collective also with one rank
             mg.SetScene(sc, (float)w / (float)h);
             mg.Clear(w, h);
             rtx_params p{}; p.width = w; p.height = h; p.spp = spp; p.max_bounces = bounces; p.nee_samples = nee; p.rr_start = 3;
@@ -64,8 +69,10 @@ int main(int argc, char** argv) {
             p.flags = lambert ? RTX_FLAG_LAMBERT_ONLY : (scene == "bistro" ? RTX_FLAG_TRANSMISSION : 0);
             if (restir) { p.spp = 1; p.flags = (lambert ? RTX_FLAG_LAMBERT_ONLY : 0u) | RTX_FLAG_BLOCK_TILES; p.tile_size = 32; mg.SetOption(RTX_OPT_RESTIR_WAVEFRONT, literal ? 0 : 1); mg.ResetRestir(); }
             float prev_view[16] = {0};
+            if (spin != 0.0f && sc.instances.size() < 2) { fprintf(stderr, "--spin needs a scene with an instance 1\n"); return 2; }
             for (UINT f = 0; f < frames; f++) {
                 p.sample_base = 1 + f * spp; p.frame_seed = f + 1;
+                if (spin != 0.0f && f > 0) { mg.SetInstanceTransform(1, spun(sc, f).data()); if (!restir) mg.Clear(w, h); printf("refit on %d ranks: %.3f ms\n", gpus, mg.LastRefitMs()); }
                 if (restir) {
                     nv_helpers_dx12::Manipulator cam; cam.setLookat(orbit_eye(sc, f), sc.center, sc.up);
                     XMMATRIX proj = XMMatrixPerspectiveFovRH(sc.fovY_deg * XM_PI / 180.0f, (float)w / (float)h, sc.zn, sc.zf);
@@ -77,10 +84,11 @@ int main(int argc, char** argv) {
                     memcpy(prev_view, cam.getMatrix(), 64);
                     mg.RenderRestir(p);
                 } else mg.Render(p);
-                double rays = 0; for (int r = 0; r < gpus; r++) { rtx_stats s = mg.Stats(r); rays += (double)(s.rays_primary + s.rays_extension + s.rays_shadow); }
+                double rays = 0; for (int r = 0; r < gpus; r++) { if (only_rank >= 0 && r != only_rank) continue; rtx_stats s = mg.Stats(r); rays += (double)(s.rays_primary + s.rays_extension + s.rays_shadow); }
                 printf("frame %u on %d GPUs: %.3f ms (gather included), %.1f Mrays/s\n", f, gpus, mg.LastFrameMs(), rays / (mg.LastFrameMs() * 1e3));
             }
-            if (!out.empty() && !write_image(mg.ReadAccumulation(0), mg.ReadOutput(0))) { fprintf(stderr, "error: could not write %s\n", out.c_str()); return 1; }
+            const int rr = only_rank >= 0 ? only_rank : 0;
+            if (!out.empty() && !write_image(mg.ReadAccumulation(rr), mg.ReadOutput(rr))) { fprintf(stderr, "error: could not write %s\n", out.c_str()); return 1; }
         } catch (const std::exception& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
         return 0;
     }
@@ -99,7 +107,14 @@ int main(int argc, char** argv) {
         r.OnInit();
         if (restir && rtx_set_option(r.Context(), RTX_OPT_RESTIR_WAVEFRONT, literal ? 0 : 1) != RTX_OK) throw std::runtime_error(rtx_last_error(r.Context()));
         XMFLOAT3 eye0, ctr0, up0; nv_helpers_dx12::CameraManip.getLookat(eye0, ctr0, up0);
+        Scene inst0; bool have_inst0 = false;
         for (UINT f = 0; f < frames; f++) {
+            if (spin != 0.0f && f > 0) {
+                if (!have_inst0) { inst0 = scene == "cornell" ? MakeCornellBox() : scene == "sponza" ? MakeSponzaClass() : scene == "bistro" ? MakeBistroClass() : Scene(); if (scene == "obj") { std::vector<std::string> fl; std::stringstream ss(objs); std::string t; while (std::getline(ss, t, ',')) fl.push_back(t); inst0 = LoadObjScene(fl, mtl); } have_inst0 = true; }
+                if (inst0.instances.size() < 2) { fprintf(stderr, "--spin needs a scene with an instance 1\n"); return 2; }
+                r.SetInstanceTransform(1, spun(inst0, f));
+                if (!restir) rtx_clear_accum(r.Context(), w, h);               // a moved scene restarts the progressive accumulation (the ReSTIR frame reprojects instead)
+            }
             if (orbit != 0.0f) { Scene tmp; tmp.eye = eye0; tmp.center = ctr0; tmp.up = up0; nv_helpers_dx12::CameraManip.setLookat(orbit_eye(tmp, f), ctr0, up0); }
             r.OnUpdate(); r.Params().sample_base = 1 + f * spp; r.OnRender();
             rtx_stats s = r.Stats();

@@ -734,6 +734,30 @@ def test_restir_wavefront_equals_literal_on_a_bvh_scene_at_scale(rt, orc):
     assert total[2] > 4 * W * H and total[1] > 2 * W * H
 
 
+def test_trace_counters_report_work_per_ray_and_change_nothing(rt):
+    """RTX_OPT_TRACE_COUNTERS (bench.py: extra.*.work_per_ray): the persistent traversal kernels tally node steps and triangle tests; same image and ray counts with the
+    counters on, and per closest-hit ray the tally lies within a few per cent of the one-ray-per-thread statistics kernel's (rtx_debug_trace_stats on the frame's own primary
+    rays: the speculative schedule takes a few node steps more, because pending triangles have not yet shortened the ray)"""
+    sc = rt.Scene.sponza_class(40000, 260)
+    W, H = 160, 90
+    c = rt.Context(0); c.upload(sc, W / H)
+    p = rt.Params(width=W, height=H, spp=2, max_bounces=1, nee_samples=1, flags=1)
+    c.clear(W, H); c.render(p); ref, s0 = c.read_accum(), c.stats()
+    c.set_option(rt.OPT_TRACE_COUNTERS, 1)
+    c.clear(W, H); c.render(p); s1 = c.stats()
+    cn, ct, an, at = c.trace_counters()
+    assert np.array_equal(bits(c.read_accum()), bits(ref))
+    assert (s1.rays_primary, s1.rays_extension, s1.rays_shadow) == (s0.rays_primary, s0.rays_extension, s0.rays_shadow)
+    assert s1.rays_extension == 0 and s1.rays_primary == W * H * 2                 # max_bounces 1: the closest-hit rays ARE the camera rays (two samples, no jitter: the same rays twice)
+    st = c.trace_stats(c.primary_rays(p))
+    steps_ref, tris_ref = float(st[:, 1].sum()) * 2, float(st[:, 2].sum()) * 2
+    assert steps_ref * 0.999 <= cn <= steps_ref * 1.15, (cn, steps_ref)
+    assert tris_ref * 0.999 <= ct <= tris_ref * 1.15, (ct, tris_ref)
+    assert s1.rays_shadow > 0 and 2.0 < an / s1.rays_shadow < 40.0 and at > 0
+    assert c.trace_counters() == (0, 0, 0, 0)                                      # reading resets
+    c.close()
+
+
 @pytest.mark.parametrize("lanes", [1, 2, 3, 4])
 def test_restir_pipeline_lanes_equal_the_literal_form(rt, orc, golden_dir, lanes):
     """RTX_OPT_RESTIR_LANES: the pixel list of a ReSTIR frame as 1 .. 4 independent parts on as many streams (passes 1 + 2, join, pass 3).  The lanes only engage for lists
@@ -1621,6 +1645,49 @@ def test_native_multi_gpu_restir_frames_of_the_cli(tmp_path):
             blobs[tag] = out.read_bytes()
         for tag, b in blobs.items():
             assert b == blobs["facade"], (name, tag)
+
+
+def test_spinning_instance_from_the_cpp_host(rt, orc, golden_dir, tmp_path):
+    """a moving instance reachable from the C++ host, as the reference moves instance 1 and refits its TLAS every frame (Renderer.cpp:431-452, 594,
+    2091-2121).  (a) Renderer::SetInstanceTransform + OnUpdate (a transform-only commit: the resident tree refits on the GPU) through the facade's C entry points: three
+    ReSTIR frames on garage.obj + monke.obj with the monkey turning equal the oracle's frames bit for bit — the oracle rebuilds its tree from scratch, and the temporal pass
+    reprojects through prevObjectToWorld.  (b) `rtx_render --spin`: the facade, one native rank and two native ranks (MultiGpuFrame::SetInstanceTransform: EVERY rank refits
+    its replica) write byte-identical images, path tracer and ReSTIR frame."""
+    import subprocess
+    sc = rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")
+    W, H = 96, 56
+    mats = []
+    for k in range(3):
+        ang = np.float32(1.57 + 0.2 * k)
+        m = np.eye(4, dtype=np.float32); m[0, 0] = np.cos(ang); m[0, 2] = -np.sin(ang); m[2, 0] = np.sin(ang); m[2, 2] = np.cos(ang); m[3, 1] = np.float32(0.03 * k)
+        mats.append(m.reshape(16))
+    o = orc.Oracle().load(sc, W / H)
+    acc_o, st = np.zeros((H, W, 4), np.float32), None
+    for k in range(3):
+        o.set_camera(*sc.view_proj(W / H))
+        o.set_instance_transform(1, mats[k])
+        acc_o, st, _ = o.restir_frames(rt.Params(width=W, height=H, spp=1, max_bounces=3, nee_samples=4, flags=0, frame_seed=k + 1), acc_o, st)
+    r = rt.Renderer(W, H, "spin", 0)
+    r.set_scene(sc); r.set_mode(1); r.on_init()
+    for k in range(3):
+        r.set_instance_transform(1, mats[k])
+        r.on_update(); r.on_render()
+    acc = r.read_accum()
+    assert np.array_equal(bits(acc), bits(acc_o))
+    r.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "royaltracer-dx_amd", "rtx_render")
+    sargs = ["--obj", os.path.join(golden_dir, "garage.obj") + "," + os.path.join(golden_dir, "monke.obj"), "--mtl", golden_dir + "/"]
+    for mode, margs in (("restir", ["--mode", "restir"]), ("pt", ["--spp", "2", "--bounces", "4"])):
+        blobs = {}
+        for tag, extra in (("facade", []), ("n1", ["--gpus", "1", "--devices", "0"]), ("n2", ["--gpus", "2", "--devices", "0,0"])):
+            out = tmp_path / f"spin_{mode}_{tag}.exr"
+            cmd = [exe] + sargs + margs + ["--w", "192", "--h", "108", "--frames", "3", "--spin", "9", "--gather", "copy", "--out", str(out)] + extra
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            assert p.returncode == 0, (cmd, p.stderr[-2000:])
+            assert p.stdout.count("frame ") == 3 and (tag == "facade" or p.stdout.count("refit on") == 2)
+            blobs[tag] = out.read_bytes()
+        assert blobs["n1"] == blobs["facade"] and blobs["n2"] == blobs["facade"], mode
 
 
 def test_rccl_collective_path_with_one_rank(tmp_path):

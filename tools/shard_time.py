@@ -3,7 +3,9 @@
 of an N-GPU frame costs (max over ranks decides the frame), how uneven the tile deal is (max / mean) and how large the slab of the frame's one all-gather is.
 usage: python tools/shard_time.py [cornell|sponza|bistro|sponza4k] [pt|restir] [N ...] [blocks=0|1] [tile=64] [frames=4] [option_id=value ...]
    pt      BASELINE's path-traced frame of that scene (cornell: 1080p 64 spp 8 bounces; sponza / bistro: 1080p 16 spp; sponza4k: C4, 3840x2160 64 spp)
-   restir  the reference's ReSTIR frame (nee 4, bounces 3), 1080p; blocks=1 (RTX_FLAG_BLOCK_TILES, one tile rectangle per rank) is the deal meant for it"""
+   restir  the reference's ReSTIR frame (nee 4, bounces 3), 1080p; blocks=1 (RTX_FLAG_BLOCK_TILES, one tile rectangle per rank) is the deal meant for it
+   native=1  (pt, cornell | sponza | bistro) every rank THROUGH THE HOST PATH of the native N-GPU frame: `rtx_render --gpus N --only-rank r --gather copy` = MultiGpuFrame with
+             its persistent worker thread, the enqueue-only render (RTX_OPT_ASYNC), pack, the rank's own slab copied into the gathered buffer, unpack, ONE host wait per frame"""
 import os
 import sys
 import time
@@ -15,6 +17,29 @@ import torch  # noqa: E402
 import __graft_entry__ as graft  # noqa: E402
 
 
+def native(kind, ns, frames):
+    import re, subprocess
+    exe = os.path.join(ROOT, "royaltracer-dx_amd", "rtx_render")
+    spp = 64 if kind == "cornell" else 16
+    print(f"# {kind} pt 1920x1080 through the native host path (MultiGpuFrame: worker thread, enqueue-only render, pack, own slab -> gathered, unpack, one wait); 32-px tiles for N > 1; ms per frame of each rank alone on one MI355X")
+    print("| N | max over ranks ms | mean ms | max / mean | compute + host-path efficiency t1 / (N max) | per rank ms |\n|---|---|---|---|---|---|")
+    t1 = None
+    for n in ns:
+        per = []
+        for r in range(n):
+            cmd = [exe, "--scene", kind, "--w", "1920", "--h", "1080", "--spp", str(spp), "--bounces", "8", "--nee", "1", "--frames", str(frames + 1), "--gpus", str(n),
+                   "--devices", ",".join(["0"] * n), "--only-rank", str(r), "--gather", "copy"] + (["--force-gather"] if n == 1 else [])
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            ms = [float(m) for m in re.findall(r"frame \d+ on \d+ GPUs: ([0-9.]+) ms", out.stdout)]
+            if out.returncode != 0 or len(ms) != frames + 1:
+                raise SystemExit(f"{cmd}: rc {out.returncode}\n{out.stderr[-2000:]}")
+            per.append(float(np.mean(ms[1:])))                       # the first frame allocates
+        mx, mean = max(per), float(np.mean(per))
+        t1 = t1 or mx
+        eff = f"{t1 / (n * mx):.3f}" if ns[0] == 1 else "-"
+        print(f"| {n} | {mx:.3f} | {mean:.3f} | {mx / mean:.3f} | {eff} | " + " ".join(f"{t:.2f}" for t in per) + " |", flush=True)
+
+
 def main():
     args = sys.argv[1:]
     kind = next((a for a in args if a in ("cornell", "sponza", "bistro", "sponza4k")), "cornell")
@@ -23,6 +48,8 @@ def main():
     named = {a.split("=")[0]: int(a.split("=")[1]) for a in args if "=" in a and not a.split("=")[0].isdigit()}
     opts = [a.split("=") for a in args if "=" in a and a.split("=")[0].isdigit()]            # rtx option id=value
     blocks, tile, frames = named.get("blocks", 0), named.get("tile", 64), named.get("frames", 4)
+    if named.get("native"):
+        return native(kind, ns, frames)
     rt = graft.load_package()
     dev = torch.device("cuda", 0)
     scene = {"cornell": rt.Scene.cornell, "sponza": rt.Scene.sponza_class, "sponza4k": rt.Scene.sponza_class, "bistro": rt.Scene.bistro_class}[kind]()
