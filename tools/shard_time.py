@@ -27,13 +27,14 @@ def native(kind, ns, frames):
     for n in ns:
         per = []
         for r in range(n):
-            cmd = [exe, "--scene", kind, "--w", "1920", "--h", "1080", "--spp", str(spp), "--bounces", "8", "--nee", "1", "--frames", str(frames + 1), "--gpus", str(n),
+            total = max(8 * frames, 24)                                  # a fresh process per rank: the first frames allocate and run on a GPU that is still clocking up
+            cmd = [exe, "--scene", kind, "--w", "1920", "--h", "1080", "--spp", str(spp), "--bounces", "8", "--nee", "1", "--frames", str(total), "--gpus", str(n),
                    "--devices", ",".join(["0"] * n), "--only-rank", str(r), "--gather", "copy"] + (["--force-gather"] if n == 1 else [])
             out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
             ms = [float(m) for m in re.findall(r"frame \d+ on \d+ GPUs: ([0-9.]+) ms", out.stdout)]
-            if out.returncode != 0 or len(ms) != frames + 1:
+            if out.returncode != 0 or len(ms) != total:
                 raise SystemExit(f"{cmd}: rc {out.returncode}\n{out.stderr[-2000:]}")
-            per.append(float(np.mean(ms[1:])))                       # the first frame allocates
+            per.append(float(np.mean(ms[total // 2:])))                  # the second half of the run
         mx, mean = max(per), float(np.mean(per))
         t1 = t1 or mx
         eff = f"{t1 / (n * mx):.3f}" if ns[0] == 1 else "-"
