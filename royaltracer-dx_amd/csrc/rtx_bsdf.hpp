@@ -167,6 +167,62 @@ RTX_HD void bsdf_mixture(const MatGPU& m, uint32_t flags, f3 normal, f3 L, f3 ou
     F = safe_mul(pd, f0) + safe_mul(ps, f1);
     P = safe_mul(pd, q0) + safe_mul(ps, q1);
 }
+// ---- the part of the mixture that depends on (material, normal, outgoing) only, computed ONCE per shading point -----------------------------------------------
+// k_shade evaluates bsdf_mixture for every NEE sample and again for the sampled continuation, and draws the strategy in between — three times the strategy
+// probabilities (Schlick at the view angle), and per mixture the two normalisations of N and V, the Ess look-up with its division, and Smith's G1 of the view
+// direction with its square root and division (~110 VALU instructions per call).  MixView holds them; bsdf_mixture_v / select_strategy_v are bsdf_mixture /
+// select_strategy with those terms handed in: the SAME operations on the same operands in the same order, so every result is the same bits
+// (tests: test_bsdf_eval_and_sample_bit_exact runs the *_v forms; full-size frames unchanged).
+struct MixView { float pd, ps, pt; f3 N, V; float NdotV, alpha, g1v, kms; };
+RTX_HD MixView mix_view(const MatGPU& m, uint32_t flags, f3 normal, f3 outgoing, float eta_p = 0.0f) {
+    MixView mv;
+    strategy_probs(m, outgoing, normal, flags, mv.pd, mv.ps, eta_p, mv.pt);
+    mv.N = mk3(0.0f, 0.0f, 1.0f); mv.V = mv.N; mv.NdotV = 0.0f; mv.alpha = 0.0f; mv.g1v = 0.0f; mv.kms = 0.0f;
+    if (flags & 1u) return mv;
+    mv.N = normalize(normal); mv.V = normalize(outgoing);
+    mv.NdotV = dot(mv.N, mv.V);
+    mv.alpha = m.Pr * m.Pr;
+    mv.g1v = g1_smith(mv.NdotV, mv.alpha);
+    const float Ess = ess_lut(m, mv.NdotV);
+    mv.kms = (1.0f - Ess) / Ess;
+    return mv;
+}
+// ggx_eval / ggx_pdf with the view terms of mv (GGX_v6.hlsl:174-224)
+RTX_HD void ggx_eval_pdf_v(const MatGPU& m, const MixView& mv, f3 Lin, f3& f1, float& q1) {
+    const f3 L = normalize(Lin);
+    const f3 H = normalize(mv.V + L);
+    const float NdotL = dot(mv.N, L), NdotH = dot(mv.N, H), VdotH = dot(mv.V, H);
+    const f3 Ks = mk3(m.Ks[0], m.Ks[1], m.Ks[2]);
+    const f3 F = schlick(Ks, VdotH);
+    const float D = d_ggx(NdotH, m.Pr);
+    const float G = g2_smith(mv.NdotV, NdotL, m.Pr * m.Pr);
+    const float den = 4.0f * mv.NdotV * NdotL;
+    q1 = mv.g1v * D / (mv.NdotV * 4.0f);
+    if (den < kEps) { f1 = mk3(0.0f, 0.0f, 0.0f); return; }
+    const f3 spec = mk3(F.x * D * G / den, F.y * D * G / den, F.z * D * G / den);
+    const f3 r = mk3(spec.x * (1.0f + Ks.x * mv.kms), spec.y * (1.0f + Ks.y * mv.kms), spec.z * (1.0f + Ks.z * mv.kms));
+    f1 = finite3(r) ? r : mk3(0.0f, 0.0f, 0.0f);
+}
+RTX_HD void bsdf_mixture_v(const MatGPU& m, uint32_t flags, const MixView& mv, f3 normal, f3 L, f3 outgoing, f3& F, float& P, float eta_p = 0.0f) {
+    f3 f0 = lambert_eval(m); float q0 = lambert_pdf(normal, L);
+    if (flags & 1u) { F = safe_mul(mv.pd, f0); P = safe_mul(mv.pd, q0); return; }
+    if (eta_p != 0.0f && dot(normal, L) < 0.0f) {
+        float q3; f3 f3_ = btdf_eval(m, normal, L, outgoing, eta_p, q3);
+        F = safe_mul(mv.pt, f3_); P = safe_mul(mv.pt, q3);
+        return;
+    }
+    f3 f1; float q1; ggx_eval_pdf_v(m, mv, L, f1, q1);
+    F = safe_mul(mv.pd, f0) + safe_mul(mv.ps, f1);
+    P = safe_mul(mv.pd, q0) + safe_mul(mv.ps, q1);
+}
+RTX_HD uint32_t select_strategy_v(const MatGPU& m, const MixView& mv, uint32_t flags, uint32_t& s0, uint32_t& s1, float eta_p = 0.0f) {
+    if (flags & 1u) return 0u;
+    const float r = tea_next(s0, s1);
+    const float p_s = mv.ps;
+    if (r <= p_s) return m.Pr < 0.04f ? 0u : 1u;
+    if (eta_p != 0.0f) return r <= p_s + mv.pd ? 0u : 3u;             // mv.pd = (1 - p_s) alpha here (strategy_probs with eta_p != 0)
+    return 0u;
+}
 // RandomUnitVectorInHemisphere, Lambertian_v6.hlsl:2-38
 RTX_HD f3 sample_lambert(f3 normal, uint32_t& s0, uint32_t& s1) {
     float u1 = tea_next(s0, s1), u2 = tea_next(s0, s1);

@@ -322,12 +322,17 @@ __device__ __forceinline__ void shade_item(const DevScene& sc, const DevFrame& f
     const MatGPU* mp = sc.mats + (shading ? sf.mat : 0u);
     f3 normal = sf.normal;
     const float eta_p = LAMBERT ? 0.0f : transmission_eta(*mp, f.flags, outgoing, normal);          // (extension) hits from behind a dielectric flip the shading normal
+    // the view-dependent terms of the mixture BSDF, once per shading point: the NEE samples and the continuation share them (rtx_bsdf.hpp: MixView)
+    MixView mvs; const MixView* mv = nullptr;
+#ifndef RTX_NO_MIXVIEW          // (A/B build: make VARIANT=nomv VARFLAGS=-DRTX_NO_MIXVIEW)
+    if (!LAMBERT) { mvs = mix_view(*mp, f.flags, normal, outgoing, eta_p); mv = &mvs; }
+#endif
     PF_MARK(2);
     for (uint32_t j = 0; j < nee; j++) {                                  // NEE: visibility deferred to k_trace_shadow
         bool push = false;
         F4 so = {0, 0, 0, 0}, sd = {0, 0, 0, 0}; f3 con = mk3(0, 0, 0);
         if (shading) { PF_COUNT(3); }
-        if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con, sc.nsmall != 0u && sf.near_hull, eta_p);
+        if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con, sc.nsmall != 0u && sf.near_hull, eta_p, mv);
         PF_MARK(3);
         if (push) { PF_COUNT(4); }
         const size_t seg = (size_t)j * f.qcap * gridDim.x + qb;           // NEE slot j, this workgroup's sub-queue
@@ -338,7 +343,7 @@ __device__ __forceinline__ void shade_item(const DevScene& sc, const DevFrame& f
     bool alive = false;
     f3 smp = mk3(0, 0, 1); float P = 0.0f;
     if (shading && !last) { PF_COUNT(5); }
-    if (shading && !last) alive = bsdf_continue(*mp, f, bounce, S, normal, outgoing, smp, P, eta_p);
+    if (shading && !last) alive = bsdf_continue(*mp, f, bounce, S, normal, outgoing, smp, P, eta_p, mv);
     PF_MARK(5);
     if (alive) { PF_COUNT(6); }
     const uint32_t slot = block_push(alive, &s_cnt[0]);
@@ -955,7 +960,11 @@ __global__ __launch_bounds__(kBlock) void k_dbg_bsdf_eval(DevScene sc, uint32_t 
     f3 F; float P, pd, ps;
     f3 nrm = mk3(q[0], q[1], q[2]); const f3 wo = mk3(q[3], q[4], q[5]);
     const float eta_p = transmission_eta(sc.mats[mat], flags, wo, nrm);
-    bsdf_mixture(sc.mats[mat], flags, nrm, mk3(q[6], q[7], q[8]), wo, F, P, pd, ps, eta_p);
+    if (flags & 0x80000000u) {                       // the form k_shade runs: view terms computed once (MixView), mixture evaluated against them — must give the same bits
+        const uint32_t fl = flags & 0x7FFFFFFFu;
+        const MixView mv = mix_view(sc.mats[mat], fl, nrm, wo, eta_p);
+        bsdf_mixture_v(sc.mats[mat], fl, mv, nrm, mk3(q[6], q[7], q[8]), wo, F, P, eta_p); pd = mv.pd; ps = mv.ps;
+    } else bsdf_mixture(sc.mats[mat], flags, nrm, mk3(q[6], q[7], q[8]), wo, F, P, pd, ps, eta_p);
     o[0] = F.x; o[1] = F.y; o[2] = F.z; o[3] = P; o[4] = pd; o[5] = ps; o[6] = eta_p; o[7] = 0.0f;
 }
 __global__ __launch_bounds__(kBlock) void k_dbg_bsdf_sample(DevScene sc, uint32_t mat, uint32_t flags, const float* __restrict__ in8, uint32_t n, float* __restrict__ out8) {
@@ -965,7 +974,8 @@ __global__ __launch_bounds__(kBlock) void k_dbg_bsdf_sample(DevScene sc, uint32_
     uint32_t s0 = f2u(q[6]), s1 = f2u(q[7]);
     f3 nrm = mk3(q[0], q[1], q[2]); const f3 wo = mk3(q[3], q[4], q[5]);
     const float eta_p = transmission_eta(sc.mats[mat], flags, wo, nrm);
-    const uint32_t st = select_strategy(sc.mats[mat], wo, nrm, flags, s0, s1, eta_p);
+    const uint32_t fl = flags & 0x7FFFFFFFu;
+    const uint32_t st = (flags & 0x80000000u) ? select_strategy_v(sc.mats[mat], mix_view(sc.mats[mat], fl, nrm, wo, eta_p), fl, s0, s1, eta_p) : select_strategy(sc.mats[mat], wo, nrm, flags, s0, s1, eta_p);
     const f3 wi = sample_bsdf(sc.mats[mat], st, wo, nrm, s0, s1, eta_p);
     o[0] = wi.x; o[1] = wi.y; o[2] = wi.z; o[3] = u2f(st); o[4] = u2f(s0); o[5] = u2f(s1); o[6] = 0.0f; o[7] = 0.0f;
 }

@@ -101,8 +101,9 @@ __device__ __forceinline__ void add_emissive(const DevScene& sc, const DevPaths&
 }
 
 // one NEE sample: SampleLightNEE_GI, Sampler_v6.hlsl:508-647.  Returns true when a shadow ray is needed.
+// mv: the view terms of the shading point (mix_view), shared with the continuation's mixture by k_shade; nullptr = computed here
 __device__ __forceinline__ bool nee_sample(const DevScene& sc, const MatGPU& m, uint32_t flags, uint32_t nee, PathState& S, f3 pos, f3 normal, f3 outgoing,
-                                           F4& so, F4& sd, f3& con, bool near_hull = false, float eta_p = 0.0f) {
+                                           F4& so, F4& sd, f3& con, bool near_hull = false, float eta_p = 0.0f, const MixView* mv = nullptr) {
     const float rv = tea_next(S.s0, S.s1);
     int left = 0, right = (int)sc.nlights - 1, sel = 0;
     while (left <= right) {                                   // :523-537
@@ -125,7 +126,9 @@ __device__ __forceinline__ bool nee_sample(const DevScene& sc, const MatGPU& m, 
     const float cos_y = fabsf(dot(nl, -Ln));
     if (cos_x < kEps || cos_y < kEps) return false;           // :580-585
     const float pdf_light = lt.pdf_l * dist2 / cos_y;         // :629-630
-    f3 F; float P, pd, ps; bsdf_mixture(m, flags, normal, Ln, outgoing, F, P, pd, ps, eta_p);     // (Ln is on the reflection side: cos_x >= EPS; eta_p only rescales p_d)
+    f3 F; float P, pd, ps;
+    if (mv) bsdf_mixture_v(m, flags, *mv, normal, Ln, outgoing, F, P, eta_p);
+    else bsdf_mixture(m, flags, normal, Ln, outgoing, F, P, pd, ps, eta_p);     // (Ln is on the reflection side: cos_x >= EPS; eta_p only rescales p_d)
     const float mi = pdf_light / ((float)nee * pdf_light + P);   // Path_Sampler_v6.hlsl:164
     const float g = cos_x / pdf_light * mi;
     con = mk3(lt.em[0] * (S.thr.x * F.x) * g, lt.em[1] * (S.thr.y * F.y) * g, lt.em[2] * (S.thr.z * F.z) * g);
@@ -138,11 +141,13 @@ __device__ __forceinline__ bool nee_sample(const DevScene& sc, const MatGPU& m, 
 
 // BSDF sampling + throughput + Russian roulette: Path_Sampler_v6.hlsl:205-229, Sampler_v6.hlsl:423-457,482-497,
 // Hit.hlsl:366-369, RayGen.hlsl:118-130.  Returns true when the path continues (state updated in S, smp, P).
-__device__ __forceinline__ bool bsdf_continue(const MatGPU& m, const DevFrame& f, uint32_t bounce, PathState& S, f3 normal, f3 outgoing, f3& smp, float& P, float eta_p = 0.0f) {
-    const uint32_t st = select_strategy(m, outgoing, normal, f.flags, S.s0, S.s1, eta_p);
+__device__ __forceinline__ bool bsdf_continue(const MatGPU& m, const DevFrame& f, uint32_t bounce, PathState& S, f3 normal, f3 outgoing, f3& smp, float& P, float eta_p = 0.0f, const MixView* mv = nullptr) {
+    const uint32_t st = mv ? select_strategy_v(m, *mv, f.flags, S.s0, S.s1, eta_p) : select_strategy(m, outgoing, normal, f.flags, S.s0, S.s1, eta_p);
     smp = sample_bsdf(m, st, outgoing, normal, S.s0, S.s1, eta_p);
     if (st == 3u && is_zero3(smp)) return false;              // (extension) total internal reflection ends the path
-    f3 F; float pd, ps; bsdf_mixture(m, f.flags, normal, smp, outgoing, F, P, pd, ps, eta_p);
+    f3 F; float pd, ps;
+    if (mv) bsdf_mixture_v(m, f.flags, *mv, normal, smp, outgoing, F, P, eta_p);
+    else bsdf_mixture(m, f.flags, normal, smp, outgoing, F, P, pd, ps, eta_p);
     float NdotL = dot(normal, smp);                           // unclamped, Sampler_v6.hlsl:455
     if (st == 3u) NdotL = fabsf(NdotL);                       // (extension) the transmitted direction lies on the far side
     if (!(P > 0.0f)) return false;

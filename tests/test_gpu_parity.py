@@ -130,6 +130,10 @@ def test_bsdf_eval_and_sample_bit_exact(rt, cornell_pair, flags):
         q2 = np.concatenate([nrm, wo, seeds], axis=1)
         gs, cs = ctx.bsdf_sample(mat, flags, q2), o.bsdf_sample(mat, flags, q2)
         assert np.array_equal(bits(gs), bits(cs)), f"sample differs for material {mat}"
+        # the form k_shade runs since round 4 (MixView: the view-dependent terms computed once per shading point and shared by the NEE samples, the strategy draw and the
+        # continuation): bit 31 of the debug flags selects it; same bits
+        assert np.array_equal(bits(ctx.bsdf_eval(mat, flags | 0x80000000, q)), bits(ge)), f"MixView eval differs for material {mat}"
+        assert np.array_equal(bits(ctx.bsdf_sample(mat, flags | 0x80000000, q2)), bits(gs)), f"MixView sample differs for material {mat}"
 
 
 @pytest.mark.parametrize("cfg", [
