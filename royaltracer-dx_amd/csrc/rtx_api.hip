@@ -169,7 +169,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
         return RTX_OK;
     case RTX_OPT_BVH_REINSERT: if (value < 0 || value > 16) { c->err = "bvh_reinsert must be in [0, 16]"; return RTX_ERR_INVALID; } c->host.bvh.reinsert_passes = (int)value; c->host.topo_dirty = true; c->committed = false; return RTX_OK;
     case RTX_OPT_BVH_SPLIT: if (value < 0 || value > 1000000000) { c->err = "bvh_split must be in [0, 1e9] (parts per billion of the scene's surface area)"; return RTX_ERR_INVALID; } c->host.bvh.split_alpha = (double)value * 1e-9; c->host.topo_dirty = true; c->committed = false; return RTX_OK;
-    case RTX_OPT_ANYHIT_ORDER: if (value < -1 || value > 2) { c->err = "anyhit_order must be -1 (probe), 0, 1 or 2"; return RTX_ERR_INVALID; } c->any_order_opt = (int)value; if (c->committed) c->dsc.any_order = value < 0 ? c->built.any_order : (uint32_t)value; return RTX_OK;
+    case RTX_OPT_ANYHIT_ORDER: if (value < -1 || value > 2) { c->err = "anyhit_order must be -1 (probe), 0, 1 or 2"; return RTX_ERR_INVALID; } c->any_order_opt = (int)value; if (c->committed) { c->dsc.any_order = value < 0 ? c->built.any_order : (uint32_t)value; c->dsc.any_order_occ = value < 0 ? 0u : (uint32_t)value; } return RTX_OK;
     case RTX_OPT_PATHS_PER_BATCH: if (value < 4096) { c->err = "paths_per_batch must be >= 4096"; return RTX_ERR_INVALID; } c->paths_per_batch = (uint64_t)value; return RTX_OK;
     case RTX_OPT_SORT_MATERIALS: c->sort_materials = value != 0; c->dsc.sort_materials = c->sort_materials; return RTX_OK;
     case RTX_OPT_LDS_NODES: c->lds_nodes_opt = (int)value; c->committed = false; return RTX_OK;
@@ -338,6 +338,7 @@ static int finalise_scene(rtx_ctx* c) {
     s.lds_tris = (size_t)want_tris * 48 <= budget ? want_tris : 0u;
     s.nsmall = 0; s.nsmall_occ = 0;
     s.any_order = c->any_order_opt < 0 ? B.any_order : (uint32_t)c->any_order_opt;
+    s.any_order_occ = c->any_order_opt < 0 ? 0u : (uint32_t)c->any_order_opt;
     s.trace_cnt = c->trace_counters ? (unsigned long long*)c->d_trace_cnt.p : nullptr;
     s.refill_min = c->refill_min; s.trace_sched = c->trace_sched; s.sort_materials = c->sort_materials; s.occluder_cache = c->occluder_cache; s.shade_dense = c->shade_dense > 0 ? 1u : 0u;
     if (c->small_scene && B.small_nrec && B.small_tris.size() * 48 <= budget + (size_t)s.lds_tris * 48) {

@@ -1217,8 +1217,11 @@ void launch_restir_pass3(hipStream_t st, uint32_t max_blocks, const DevScene& sc
     hipLaunchKernelGGL(k_restir_pass3, dim3(grid_for(f.npl, max_blocks)), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, cam, B, accum, counters);
 }
 // ---- wavefront ReSTIR stages ----
-void launch_trace_occ(hipStream_t st, const DevScene& sc, const RsQ& q, const uint32_t* shcnt) {
+void launch_trace_occ(hipStream_t st, const DevScene& sc_in, const RsQ& q, const uint32_t* shcnt) {
     DevPaths none{};
+    // the visibility rays of the ReSTIR stages run between arbitrary scene points (reconnections, last frame's samples), not towards sampled lights: the NEE probe's
+    // order does not carry over — slot order measured best on all three scenes (atrium 8.28 vs 8.38 ms, garage 6.74 vs 6.84, street 7.99 vs 8.02-8.12 per frame with orders 1 / 2)
+    DevScene sc = sc_in; sc.any_order = sc_in.any_order_occ;
 #define RTX_LAUNCH_TO(CC) hipLaunchKernelGGL((k_trace_shadow<0, false, CC, 1>), dim3(q.G), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, none, q.sh_o, q.sh_d, (const F4*)nullptr, shcnt, q.rcap, sc.refill_min, sc.trace_sched, (uint32_t*)nullptr, q.G, 1u, q.sh_pay, q.occ)
     if (sc.trace_sched == 6u && !sc.nsmall && !sc.trace_cnt) RTX_LAUNCH_TO(6); else RTX_LAUNCH_TO(-1);
 #undef RTX_LAUNCH_TO
@@ -1243,7 +1246,12 @@ void launch_rs_p1_emit_final(hipStream_t st, const DevScene& sc, const DevFrame&
     hipLaunchKernelGGL(k_rs_p1_emit_final, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, cam, bufs ? rs_bufs(bufs) : RestirBufs{}, bufs ? 1u : 0u, shcnt);
 }
 void launch_rs_p1_finish(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, F4* accum, uint32_t* res_di, uint32_t* res_gi, uint32_t* sdata, const CameraGPU* cam, uint32_t* const* bufs) {
-    hipLaunchKernelGGL(k_rs_p1_finish, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, accum, res_di, res_gi, sdata, cam, bufs ? rs_bufs(bufs) : RestirBufs{}, bufs ? 1u : 0u);
+#ifdef RTX_RS_FUSED_FINISH       // (A/B build: make VARIANT=ffin VARFLAGS=-DRTX_RS_FUSED_FINISH — the round-3 form, both halves in one kernel)
+    hipLaunchKernelGGL((k_rs_p1_finish<true, true>), dim3(q.G), dim3(kBlock), 0, st, sc, f, q, accum, res_di, res_gi, sdata, cam, bufs ? rs_bufs(bufs) : RestirBufs{}, bufs ? 1u : 0u);
+#else
+    hipLaunchKernelGGL((k_rs_p1_finish<true, false>), dim3(q.G), dim3(kBlock), 0, st, sc, f, q, accum, res_di, res_gi, sdata, cam, RestirBufs{}, 0u);
+    if (bufs) hipLaunchKernelGGL((k_rs_p1_finish<false, true>), dim3(q.G), dim3(kBlock), 0, st, sc, f, q, accum, res_di, res_gi, sdata, cam, rs_bufs(bufs), 1u);
+#endif
 }
 void launch_rs_p3_select(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, const CameraGPU* cam, uint32_t* const bufs[6], uint32_t* shcnt) {
     hipLaunchKernelGGL(k_rs_p3_select, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, cam, rs_bufs(bufs), shcnt);

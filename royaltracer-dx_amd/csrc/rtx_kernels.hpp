@@ -27,6 +27,7 @@ struct DevScene {
     uint32_t refill_min, trace_sched;   // persistent traversal: idle lanes that trigger a refill; wave schedule (rtx_kernels.hip)
     uint32_t shade_dense;               // general path: k_shade compacts the hits of its sub-queue through an LDS ring before shading them (k_shade_dense)
     uint32_t any_order;                 // any-hit rays: visiting order of a node's hit children, 0 slot order / 1 nearest octant first / 2 farthest first (rtx_traverse.hpp: node8_hits)
+    uint32_t any_order_occ;             // ... of the ReSTIR stages' visibility rays (k_trace_shadow<.., SINK 1>): 0 unless RTX_OPT_ANYHIT_ORDER forces an order
     unsigned long long* trace_cnt;      // RTX_OPT_TRACE_COUNTERS: [0] node steps, [1] triangle tests of closest-hit rays, [2], [3] of any-hit rays, summed by the generic traversal instantiations; nullptr = off
     uint32_t occluder_cache;            // any-hit rays: a lane tests the triangle that occluded its previous ray first (rtx_traverse.hpp: ray_begin)
 };

@@ -327,6 +327,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_emit_final(DevScene sc, Dev
 
 // stage 6: the visibility answers are in: W of the DI reservoir, w_sum / W of the GI reservoir, the pixel's estimate (pass1:140-190) — and, in a ReSTIR frame
 // (with_p2), the pixel's TEMPORAL pass right behind it (RayGen_v6_pass2.hlsl:46-204: it reads this pixel's own pass-1 records and last frame's buffers only)
+// (round 4) P1 / P2: which halves an instantiation runs.  As ONE kernel (<true, true>, round 3) the two halves' live ranges added up to 128 VGPRs + 55 spilled (148 B of scratch
+// per lane) at 0.96 waves per SIMD resident and 75 % of the wave time parked (profiles/r03_pmc_restir.md); as two launches, <true, false> then <false, true>, each half fits
+// its registers (profiles/r04_kernel_resources.md).  The temporal pass of a pixel reads that pixel's own pass-1 records: the kernel boundary orders them.
+template <bool P1, bool P2>
 __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_finish(DevScene sc, DevFrame f, RsQ q, F4* __restrict__ accum, uint32_t* __restrict__ res_di, uint32_t* __restrict__ res_gi,
                                                             uint32_t* __restrict__ sdata, const CameraGPU* __restrict__ cam_p, RestirBufs B, uint32_t with_p2) {
     __shared__ CameraGPU cam;
@@ -338,9 +342,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_finish(DevScene sc, DevFram
         const uint32_t it = c * kBlock + threadIdx.x;
         uint32_t x, y;
         if (!(it < q.nitems) || !rs_item_pixel(f, q, it, x, y)) continue;
-        const uint32_t cl = q.cls[it];
+        const uint32_t cl = P1 ? q.cls[it] : 0u;
         const uint8_t* oc = q.occ + (size_t)it * kRsOcc;
-        if (cl) {
+        if (P1 && cl) {
             const MatGPU& m = sc.mats[cl - 1u];
             const size_t slot = map_pixel_id(f.width, x, y);
             const uint32_t* sp = sdata + slot * 15;
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_finish(DevScene sc, DevFram
             d[12] = f2u(debug.x); d[13] = f2u(debug.y); d[14] = f2u(debug.z);
             rs_accumulate(accum, f.width, x, y, debug);
         }
-        if (with_p2) {                                                  // every pixel, as the literal pass does (a pixel that sampled nothing leaves at p2_gather's first test)
+        if (P2 && with_p2) {                                            // every pixel, as the literal pass does (a pixel that sampled nothing leaves at p2_gather's first test)
             P2Pix I;
             if (p2_gather(sc, f, cam, B, x, y, I, true)) p2_merge(sc, f, B, x, y, I, VisLookup{oc + 2});
         }
