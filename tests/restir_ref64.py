@@ -287,3 +287,255 @@ def temporal_pass_pixel(x, y, w, h, frame_seed, cam_pos, prev_view, prev_proj, i
             pg = length(reconnect_gi(m, sd["x1"], sd["n1"], gc["x2"], gc["L2"], sd["o"]))
             gc["W"] = gc["w_sum"] / pg if pg > EPS else 0.0
     return dict(di=rc, gi=gc, acc_di=bool(acc_di), acc_gi=bool(acc_gi), pixel=(px, py))
+
+
+# ---- PASS 1 (RayGen_v6_pass1.hlsl:48-190): SampleRIS (Sampler_v6.hlsl:653-736) with SampleLightNEE (:276-395) and SampleLightBSDF (:199-274), GetP_Hat / GetW
+# (:163-188), SamplePathSimple (Path_Sampler_v6.hlsl:3-285) with SampleLightNEE_GI (Sampler_v6.hlsl:509-647) and SampleLightBSDF_GI (:397-506), UpdateReservoir /
+# UpdateReservoir_GI (Reservoir_v6.hlsl:33-80) — restated in float64 from the HLSL text, round 4.  The camera ray is NOT restated (it is pinned bit for bit elsewhere): the
+# pixel's primary hit (x1, n1, o, mID) is taken from the SampleData record the pass wrote.  Rays are answered by callbacks (tests hand in the oracle's closest-hit / any-hit
+# queries); random numbers are the reference's TEA stream, so every draw happens in the reference's order or the pixel diverges visibly.
+NEE_SAMPLES_DI, BSDF_SAMPLES_DI = 4, 1                                # Common_v6.hlsl:8-12 (nee_samples_DI = nee_samples)
+
+
+def half3(v):
+    return np.asarray(v, np.float64).astype(np.float32).astype(np.float16).astype(np.float64)
+
+
+class Light:
+    """LightTriangle (Renderer.h:113-124) as rtx_get_lights / orc_get_lights hand it out: 20 floats"""
+    def __init__(self, rec20):
+        f = np.asarray(rec20, np.float32); u = f.view(np.uint32)
+        self.x, self.y, self.z = f[0:3].astype(np.float64), f[4:7].astype(np.float64), f[8:11].astype(np.float64)
+        self.cdf, self.weight, self.emission = float(f[3]), float(f[11]), f[12:15].astype(np.float64)
+        self.inst, self.count, self.total_weight = int(u[7]), int(u[15]), float(f[16])
+
+
+def _lobes(m, normal, L, V_eval, V_pdf):
+    """p_d, p_s (CalculateStrategyProbabilities with V_eval), brdf0 / brdf1 (EvaluateBRDF 0 / 1) and pdf0 / pdf1 (BRDF_PDF 0 / 1, with V_pdf) for the direction L = -incidence"""
+    with np.errstate(all="ignore"):
+        pd, ps = R.strategy_probs(m, V_eval, normal)
+        b0, b1 = R.lambert_eval(m), R.ggx_eval(m, normal, L, V_eval)
+        q0, q1 = R.lambert_pdf(normal, L), R.ggx_pdf(m, normal, L, V_pdf)
+    return float(pd), float(ps), np.asarray(b0, np.float64), np.asarray(b1, np.float64), float(q0), float(q1)
+
+
+def _safe(s, v):                                                      # SafeMultiply, Common_v6.hlsl:151-160
+    with np.errstate(all="ignore"):
+        r = np.float64(s) * np.asarray(v, np.float64)
+    return r if np.isfinite(r).all() else np.zeros_like(np.atleast_1d(r), dtype=np.float64).reshape(np.shape(r))
+
+
+def _select_light(lights, r):                                         # the binary search of SampleLightNEE(_GI)
+    left, right, sel = 0, lights[0].count - 1, 0
+    while left <= right:
+        mid = left + (right - left) // 2
+        if r < lights[mid].cdf:
+            sel, right = mid, mid - 1
+        else:
+            left = mid + 1
+    return lights[sel]
+
+
+def _light_point(lt, o2w, rng):
+    M = o2w[lt.inst]
+    xv, yv, zv = (M @ np.append(lt.x, 1.0))[:3], (M @ np.append(lt.y, 1.0))[:3], (M @ np.append(lt.z, 1.0))[:3]
+    xi1, xi2 = rng.next(), rng.next()
+    if xi1 + xi2 > 1.0:
+        xi1, xi2 = 1.0 - xi1, 1.0 - xi2
+    u, v, w = 1.0 - xi1 - xi2, xi1, xi2
+    return xv, yv, zv, u * xv + v * yv + w * zv
+
+
+def _sample_brdf(m, strategy, outgoing, normal, rng):                 # SampleBRDF, BRDF_v6.hlsl:72-87: both lobes draw two numbers
+    u1, u2 = rng.next(), rng.next()
+    with np.errstate(all="ignore"):
+        return R.sample_lambert(normal, u1, u2) if strategy == 0 else R.sample_ggx(m, outgoing, normal, u1, u2)[0]
+
+
+def pass1_pixel(x, y, w, h, frame_seed, sd, mats, ke_full, lights, o2w, closest, occluded, visible, nee_samples=4, bounces=3):
+    """sd = the pixel's SampleData (load_sd); mats[mID] = ggx_ref64.Mat, ke_full[mID] = materials[mID].Ke (float32 values); lights = [Light]; o2w[inst] = objectToWorld as a
+    4x4 column-vector matrix; closest(origin, direction) -> dict(hit, pos, normal, mID) for a ray with TMin = s_bias (the reference's TraceRay + ClosestHit), occluded(origin,
+    direction, tmin, tmax) -> bool (the shadow ray type), visible(x1, n1, x2) -> 1.0 / 0.0 (VisibilityCheck).
+    -> None for a pixel that samples nothing (light seen directly, miss), else dict(di, gi, debug)"""
+    if sd["mID"] == 0xFFFE or sd["mID"] >= len(mats) or length(ke_full[sd["mID"]]) > 0.0:
+        return None
+    m = mats[sd["mID"]]
+    rng = Rng(x, y, 1, frame_seed)
+    x1, n1, o = sd["x1"], sd["n1"], sd["o"]                            # payload.hitPosition, payload.hitNormal (unit), -direction
+    di = dict(x2=np.zeros(3), w_sum=0.0, n2=np.zeros(3), W=0.0, L2=np.zeros(3), M=0)
+    gi = dict(x2=np.zeros(3), w_sum=0.0, n2=np.zeros(3), W=0.0, L2=np.zeros(3), M=0)      # (xn, nn, E3 under the DI field names)
+    M1, M2 = nee_samples, BSDF_SAMPLES_DI
+
+    def update(res, wi, a, b, c):                                     # UpdateReservoir(_GI): the draw happens whatever wi is
+        res["w_sum"] += wi
+        with np.errstate(all="ignore"):
+            take = rng.next() < np.float64(wi) / np.float64(res["w_sum"])
+        if take:
+            res["x2"], res["n2"], res["L2"] = np.asarray(a, np.float64), np.asarray(b, np.float64), half3(c)
+        return bool(take)
+
+    # ---------------- SampleRIS ----------------
+    strategy = int(R.select_strategy(m, o, n1, rng.next()))
+    for _ in range(M1):                                               # SampleLightNEE, useVisibility = false
+        lt = _select_light(lights, rng.next())
+        xv, yv, zv, sp = _light_point(lt, o2w, rng)
+        L = sp - x1
+        dist2 = float(np.dot(L, L))
+        Ln = normalize(L)
+        cr = np.cross(yv - xv, zv - xv)
+        nl = normalize(cr)
+        if np.dot(nl, -Ln) < 0.0:
+            nl = -nl
+        area = abs(length(cr) * 0.5)
+        pdf_l = lt.weight / max(area, EPS)
+        cos_x, cos_y = float(np.dot(n1, Ln)), float(np.dot(nl, -Ln))
+        G = max(cos_y * cos_x / dist2, EPS)
+        pd, ps, b0, b1, q0, q1 = _lobes(m, n1, Ln, normalize(o), normalize(o))
+        brdf = _safe(pd, b0) + _safe(ps, b1)
+        with np.errstate(all="ignore"):
+            P = float(_safe(pd, q0 * cos_y / dist2)) + float(_safe(ps, q1 * cos_y / dist2))
+            p_hat = length(lt.emission * brdf * G)
+            pdf_light = max(EPS, pdf_l)
+            mi = pdf_light / (M1 * pdf_light + M2 * P)
+            wi = mi * p_hat / pdf_light
+        if p_hat > 0.0:
+            update(di, wi, sp, nl, lt.emission)
+    for _ in range(M2):                                               # SampleLightBSDF
+        smp = _sample_brdf(m, strategy, o, n1, rng)
+        hit = closest(x1, smp)
+        p_hat, pdf_light, P = 0.0, 0.0, 0.0
+        if hit["hit"]:
+            ke = np.asarray(ke_full[hit["mID"]], np.float64)
+            if ke.sum() > EPS:
+                L = hit["pos"] - x1
+                dist = length(L); dist2 = dist * dist
+                cos_t = float(np.dot(hit["normal"], -smp))
+                pdf_light = (ke.sum() / 3.0) / lights[0].total_weight
+                pd, ps, b0, b1, q0, q1 = _lobes(m, n1, smp, normalize(o), o)
+                brdf = _safe(pd, b0) + _safe(ps, b1)
+                with np.errstate(all="ignore"):
+                    P = float(_safe(pd, q0 * cos_t / dist2)) + float(_safe(ps, q1 * cos_t / dist2))
+                    p_hat = length(brdf * ke * float(np.dot(n1, smp)) * cos_t / dist2)
+            if p_hat > 0.0:
+                with np.errstate(all="ignore"):
+                    mi = P / (M1 * pdf_light + M2 * P)
+                    wi = mi * p_hat / P
+                update(di, wi, hit["pos"], hit["normal"], ke)
+    di["M"] = 1
+    # ---------------- the reservoir's visibility and W (pass1:147-151) ----------------
+    f_g = length(reconnect_di(m, x1, n1, di["x2"], di["n2"], di["L2"], o))
+    with np.errstate(all="ignore"):
+        p_hat = f_g * (visible(x1, n1, di["x2"]) if length(di["x2"] - x1) > 0.0 else 1.0)
+    di["W"] = di["w_sum"] / p_hat if p_hat > EPS else 0.0
+    # ---------------- SamplePathSimple ----------------
+    acc_L = _path_simple(m, gi, x1, n1, o, mats, ke_full, lights, o2w, closest, occluded, rng, update, nee_samples, bounces)
+    with np.errstate(all="ignore"):
+        debug = acc_L + reconnect_di(m, x1, n1, di["x2"], di["n2"], di["L2"], o) * di["W"]
+        f_c = length(reconnect_gi(m, x1, n1, gi["x2"], gi["L2"], o))
+    gi["W"] = gi["w_sum"] / f_c if f_c > EPS else 0.0
+    gi["M"] = 1
+    return dict(di=di, gi=gi, debug=debug)
+
+
+def _mat_opt(mats, ke_full, mID):
+    return mats[mID], half3(ke_full[mID])
+
+
+def _path_simple(m0, res, p0, n0, o0, mats, ke_full, lights, o2w, closest, occluded, rng, update, nee_samples, bounces):
+    acc_f, acc_f_rec, acc_pdf = np.ones(3), np.ones(3), 1.0
+    x1s, x2s = np.zeros(3), np.zeros(3)
+    acc_L = np.zeros(3)
+    origin, normal, outgoing, m = np.asarray(p0, np.float64), np.asarray(n0, np.float64), normalize(o0), m0
+    # 1) the first BSDF bounce
+    strategy = int(R.select_strategy(m, outgoing, normal, rng.next()))
+    smp = _sample_brdf(m, strategy, outgoing, normal, rng)
+    hit = closest(origin, smp)
+    if not hit["hit"] or length(ke_full[hit["mID"]]) > 0.0:             # a light (or nothing: sanitised) straight away: no sample
+        return acc_L
+    inc = normalize(-smp)
+    pd, ps, b0, b1, q0, q1 = _lobes(m, normal, -inc, outgoing, outgoing)
+    F = _safe(pd, b0) + _safe(ps, b1)
+    P = float(_safe(pd, q0)) + float(_safe(ps, q1))
+    acc_pdf *= P
+    acc_f = acc_f * (F * float(np.dot(normal, smp)))
+    outgoing = inc
+    m, ke_h = _mat_opt(mats, ke_full, hit["mID"])
+    normal, origin = hit["normal"], hit["pos"]
+    # 2) the reconnection vertex
+    xn, nn = origin.copy(), normalize(normal)
+    # 3) bounces with unshadowed NEE + one BSDF sample each
+    for i in range(bounces):
+        rng.next()                                                    # SelectSamplingStrategy: its result is overwritten before use, its draw is not (:118)
+        for _ in range(nee_samples):                                  # SampleLightNEE_GI, useVisibility = false
+            lt = _select_light(lights, rng.next())
+            xv, yv, zv, sp = _light_point(lt, o2w, rng)
+            L = sp - origin
+            dist2 = float(np.dot(L, L))
+            Ln = normalize(L)
+            cr = np.cross(yv - xv, zv - xv)
+            nl = normalize(cr)
+            if np.dot(nl, -Ln) < 0.0:
+                nl = -nl
+            area = abs(length(cr) * 0.5)
+            pdf_l = lt.weight / max(area, EPS)
+            cos_x = abs(float(np.dot(normal, Ln))); cos_x = 0.0 if cos_x < EPS else cos_x
+            cos_y = abs(float(np.dot(nl, -Ln))); cos_y = 0.0 if cos_y < EPS else cos_y
+            pd, ps, b0, b1, q0, q1 = _lobes(m, normal, Ln, normalize(outgoing), normalize(outgoing))
+            brdf = _safe(pd, b0) + _safe(ps, b1)
+            Pb = float(_safe(pd, q0)) + float(_safe(ps, q1))
+            pdf_light = 1.0                                           # the caller's initial value survives when cos_theta_y == 0 (:610-611)
+            with np.errstate(all="ignore"):
+                if cos_y > 0.0:
+                    pdf_light = max(EPS, pdf_l) * dist2 / cos_y
+                a_pdf = acc_pdf * pdf_light
+                a_l = acc_f * (brdf * cos_x)
+                thr = brdf * cos_x
+                contribution = lt.emission * a_l / a_pdf if a_pdf > 0.0 else np.zeros(3)
+                mi = pdf_light / (nee_samples * pdf_light + Pb)
+                E_rec = acc_f_rec * mi * lt.emission * thr
+                E_path = mi * contribution
+                wi = length(E_path)
+                acc_L = acc_L + mi * contribution
+            if not np.isfinite(wi):
+                wi = 0.0
+            if update(res, wi, xn, normalize(nn), E_rec):
+                x1s, x2s = origin + S_BIAS * normalize(normal), sp
+        strategy = int(R.select_strategy(m, outgoing, normal, rng.next()))
+        smp = _sample_brdf(m, strategy, outgoing, normal, rng)        # SampleLightBSDF_GI
+        hit = closest(origin, smp)
+        if not hit["hit"]:                                            # (sanitised: a miss ends the estimator here)
+            break
+        m2, ke2 = _mat_opt(mats, ke_full, hit["mID"])
+        pd, ps, b0, b1, q0, q1 = _lobes(m, normal, smp, normalize(outgoing), outgoing)
+        brdf = _safe(pd, b0) + _safe(ps, b1)
+        Pb = float(_safe(pd, q0)) + float(_safe(ps, q1))
+        NdotL = float(np.dot(normal, smp))
+        pdf_light, contribution, emission = 1.0, np.zeros(3), np.zeros(3)
+        with np.errstate(all="ignore"):
+            acc_pdf *= Pb
+            acc_f = acc_f * (brdf * NdotL)
+            thr = brdf * NdotL
+            if length(ke2) > 0.0:
+                L = hit["pos"] - origin
+                dist = length(L)
+                cos_t = float(np.dot(hit["normal"], -smp))
+                pdf_light = ((ke2.sum() / 3.0) / lights[0].total_weight) * (dist * dist) / cos_t
+                emission = ke2
+                contribution = ke2 * acc_f / acc_pdf
+            acc_f_rec = acc_f_rec * thr
+            if length(contribution) > 0.0:
+                mi = Pb / (nee_samples * pdf_light + Pb)
+                E_rec = acc_f_rec * mi * emission
+                E_path = mi * contribution
+                wi = length(E_path)
+                acc_L = acc_L + E_path
+                if not np.isfinite(wi):
+                    wi = 0.0
+                update(res, wi, xn, normalize(nn), E_rec)
+                break
+        origin, m, outgoing, normal = hit["pos"], m2, -smp, hit["normal"]
+    if nee_samples > 0 and length(x2s - x1s) > EPS:                   # the reservoir's own shadow ray (:266-281)
+        d = x2s - x1s
+        if occluded(x1s, normalize(d), 0.5 * S_BIAS, max(S_BIAS, length(d) - S_BIAS * 5.0)):
+            res["w_sum"] *= 0.0
+    return acc_L

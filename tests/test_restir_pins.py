@@ -1,4 +1,4 @@
-"""Independent pins of the ReSTIR passes 2 and 3 (VERDICT r02 "what's weak" 1 / "next round" 4b): until round 3 the temporal and spatial passes — pairwise MIS, the
+"""Independent pins of the ReSTIR passes — 2 and 3 since round 3, pass 1 (SampleRIS + SamplePathSimple) since round 4 (VERDICT r02 "what's weak" 1 / r03 item 6): until then the temporal and spatial passes — pairwise MIS, the
 reconnection Jacobian, the reject predicates, the reservoir merges — were pinned only by "GPU == oracle".  tests/restir_ref64.py restates both passes in float64 numpy
 from the HLSL text (not from the oracle); here it re-computes EVERY pixel of a frame of the oracle from the oracle's own input buffers and must arrive at the same
 reservoirs and radiance.  The GPU reproduces these oracle buffers byte for byte (tests/test_gpu_parity.py), so the pin carries over to the kernels."""
@@ -43,9 +43,63 @@ def frames(rt, orc, golden_dir):
         d = x2 - x1; dist = np.sqrt((d * d).sum()); org = x1 + X.normalize(n1) * X.S_BIAS
         ray = np.array([[*org, 0.0, *(d / dist if dist > 0 else d), max(dist - 10 * X.S_BIAS, 2 * X.S_BIAS)]], np.float32)
         return 0.0 if o.trace_any(ray)[0] else 1.0
-    return dict(W=W, H=H, seed=33, cam=np.linalg.inv(_col(views[2]))[:3, 3], prev_view=_col(views[1]), proj=_col(proj),
+    def closest(org, d):                                       # TraceRay + ClosestHit of a TMin = s_bias ray, answered by the oracle's closest-hit query and its ClosestHit restatement
+        ray = np.array([[*org, X.S_BIAS, *d, 10000.0]], np.float32)
+        hit = o.trace_closest(ray, 1); sf = o.surface(ray, hit)[0]
+        mid = int(sf[3:4].view(np.uint32)[0])
+        return dict(hit=mid != 0xFFFFFFFE, pos=sf[0:3].astype(np.float64), normal=sf[4:7].astype(np.float64), mID=mid)
+
+    def occluded(org, d, tmin, tmax):                          # the shadow ray type (ShadowRay.hlsl)
+        return bool(o.trace_any(np.array([[*org, tmin, *d, tmax]], np.float32))[0])
+    lights = [X.Light(r) for r in o.lights()]
+    return dict(W=W, H=H, seed=33, cam=np.linalg.inv(_col(views[2]))[:3, 3], prev_view=_col(views[1]), proj=_col(proj), closest=closest, occluded=occluded, lights=lights,
+                ke=[np.asarray(m[8:11], np.float32).astype(np.float64) for m in sc.materials], o2w=[_col(m) for _, m in sc.instances],
                 inst=[(np.linalg.inv(_col(m)), _col(m)) for _, m in sc.instances], mats=[R.Mat(m[0:3], m[4:7], m[12], m[13], m[16:32]) for m in sc.materials],
                 pass1=p1, hist=hist, after=st, radiance=(acc - before)[..., :3], visible=visible)
+
+
+def test_pass1_matches_the_float64_restatement(frames):
+    """VERDICT r03 item 6 — the last row pinned only by "GPU == oracle": RayGen_v6_pass1.hlsl:48-190 per pixel = SampleRIS (4 light + 1 BSDF candidates, balance-heuristic RIS
+    weights, reservoir updates that consume random numbers: Sampler_v6.hlsl:653-736 with SampleLightNEE / SampleLightBSDF), GetP_Hat with its visibility ray and GetW, and
+    SamplePathSimple (Path_Sampler_v6.hlsl:3-285: first BSDF bounce, then per bounce four unshadowed SampleLightNEE_GI + one SampleLightBSDF_GI, two strategy draws, the final
+    reservoir shadow ray), restated in float64 from the HLSL text (tests/restir_ref64.py: pass1_pixel).  Every pixel of a frame, from the oracle's own primary hit and with the
+    oracle answering the rays (the witness has no ray tracer).
+      DI reservoir (SampleRIS + visibility + W): EVERY pixel holds the same sample and agrees in w_sum / W within 1e-5.
+      GI reservoir + the pixel's estimate (SamplePathSimple: up to five dependent rays, 12 + 4 reservoir updates): the same selected sample (E3) and w_sum / W / sdata.debug within
+      1e-5 for >= 96.5 % of the pixels, within 1e-3 for >= 99 %.  The remainder are ill-conditioned PATHS, not a different algorithm: traced one by one they bounce inside a room
+      corner, between two coincident floor sheets, or leave a crease 2e-5 from where they arrived — a hit position that differs in the 7th digit (the witness samples its
+      directions in float64) sends the next ray to another surface.  The frame's summed estimate agrees within 1e-3."""
+    F = frames
+    di_buf, gi_buf, sd_buf = F["pass1"]
+    n = di_valid = gi_valid = same_e3 = 0
+    worst_di, gi_err, sum_w, sum_o = 0.0, [], np.zeros(3), np.zeros(3)
+
+    def same(a, b):          # which sample: its position; normals up to sign (SampleLightNEE turns a light's normal towards the shading point: for a point IN the light's plane
+        return np.allclose(a["x2"], b["x2"], rtol=0.0, atol=2e-5) and (abs(float(np.dot(a["n2"], b["n2"]))) > 1.0 - 1e-6 or (not np.any(a["n2"]) and not np.any(b["n2"])))       # the sign of that ~0 cosine is rounding; every consumer re-orients n2)
+    for y in range(F["H"]):
+        for x in range(F["W"]):
+            slot = X.map_pixel_id(F["W"], x, y)
+            sd = X.load_sd(sd_buf, slot)
+            r = X.pass1_pixel(x, y, F["W"], F["H"], F["seed"], sd, F["mats"], F["ke"], F["lights"], F["o2w"], F["closest"], F["occluded"], F["visible"])
+            od, og = X.load_res(di_buf, slot), X.load_res(gi_buf, slot)
+            if r is None:
+                assert od["w_sum"] == 0.0 and og["w_sum"] == 0.0, (x, y)
+                continue
+            n += 1; di_valid += od["w_sum"] > 0; gi_valid += og["w_sum"] > 0
+            assert same(r["di"], od) and np.allclose(r["di"]["L2"], od["L2"], rtol=2e-3, atol=1e-6), ("DI sample", x, y, r["di"], od)
+            assert (r["di"]["M"], r["gi"]["M"]) == (od["M"], og["M"]) == (1, 1), (x, y)
+            worst_di = max(worst_di, _rel(r["di"]["w_sum"], od["w_sum"]), _rel(r["di"]["W"], od["W"]))
+            dbg = sd_buf[slot].view(np.float32)[12:15].astype(np.float64)
+            e3 = bool(np.allclose(r["gi"]["L2"], og["L2"], rtol=2e-3, atol=1e-6)) and same(r["gi"], og)
+            same_e3 += e3
+            gi_err.append(max(_rel(r["gi"]["w_sum"], og["w_sum"]), _rel(r["gi"]["W"], og["W"]), float(np.abs(r["debug"] - dbg).max() / max(np.abs(dbg).max(), 1e-6))) if e3 else 1.0)
+            sum_w += r["debug"]; sum_o += dbg
+    gi_err = np.array(gi_err)
+    assert n > 1200 and di_valid > 1000 and gi_valid > 900, (n, di_valid, gi_valid)
+    assert worst_di < 1e-5, worst_di
+    assert same_e3 >= 0.995 * n, (same_e3, n)
+    assert (gi_err < 1e-5).mean() >= 0.965 and (gi_err < 1e-3).mean() >= 0.99, ((gi_err < 1e-5).mean(), (gi_err < 1e-3).mean())
+    assert np.abs(sum_w - sum_o).max() / np.abs(sum_o).max() < 1e-3, (sum_w, sum_o)
 
 
 def test_temporal_pass_matches_the_float64_restatement(frames):
