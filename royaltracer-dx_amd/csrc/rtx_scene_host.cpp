@@ -1109,7 +1109,7 @@ inline bool replay_tri(const float o[3], const float d[3], const TriGPU& Tg, flo
 }
 }  // namespace
 
-ReplayHit replay_trace(const BuiltScene& B, const float o[3], const float d[3], float tmin, float tmax, bool any, uint32_t any_order, float t_known) {
+ReplayHit replay_trace(const BuiltScene& B, const float o[3], const float d[3], float tmin, float tmax, bool any, uint32_t any_order, float t_known, std::vector<uint8_t>* seq) {
     float idir[3]; uint32_t oct = 0;
     for (int a = 0; a < 3; a++) { const float ds = fabsf(d[a]) < 1e-30f ? copysignf(1e-30f, d[a]) : d[a]; idir[a] = 1.0f / ds; if (idir[a] < 0.0f) oct |= 1u << a; }
     const bool ordered = !any || any_order != 0;
@@ -1127,6 +1127,7 @@ ReplayHit replay_trace(const BuiltScene& B, const float o[3], const float d[3], 
             const uint32_t idx = G.base + (uint32_t)__builtin_popcount((G.bits >> 8) & ((1u << slot) - 1u));
             replay_node(B.nodes8[idx], o, idir, oct, ordered, oct_order, tmin, H.t, G, T);
             H.steps++;
+            if (seq) seq->push_back((uint8_t)__builtin_popcount(T.bits));          // triangles this node step hands to the triangle steps
         }
         while (T.bits) {
             const uint32_t bit = (uint32_t)__builtin_ctz(T.bits);
@@ -1135,7 +1136,7 @@ ReplayHit replay_trace(const BuiltScene& B, const float o[3], const float d[3], 
             float t;
             if (replay_tri(o, d, B.tris8[slot], tmin, tmax, t)) {
                 const uint32_t gid = f2u(B.tris8[slot].v0.w);
-                if (any) { H.prim = gid; H.slot = slot; H.t = t; return H; }
+                if (any) { H.prim = gid; H.slot = slot; H.t = t; if (seq && !seq->empty()) seq->back() = (uint8_t)(seq->back() - __builtin_popcount(T.bits)); return H; }   // (the untested rest of the group is dropped)
                 if (t < H.t || (t == H.t && gid < H.prim)) { H.t = t; H.prim = gid; H.slot = slot; }
             }
         }

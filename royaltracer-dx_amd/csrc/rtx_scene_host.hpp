@@ -107,7 +107,8 @@ bool collapse_bvh8(const std::vector<NodeGPU>& nodes2, std::vector<Node8GPU>& no
 // each of a fixed set of 28 points on it (corners, edge thirds, interior lattice) lies inside all boxes above one of its references; otherwise a small positive code
 // host-side replay of the device traversal on B.nodes8 / B.tris8 (counts for tools/bvh_lab.cpp and the any-hit probe; rtx_scene_host.cpp)
 struct ReplayHit { float t; uint32_t slot, prim; uint32_t steps, tris; };     // prim = global triangle id or 0xffffffff; steps = node steps, tris = triangle tests
-ReplayHit replay_trace(const BuiltScene& B, const float o[3], const float d[3], float tmin, float tmax, bool any, uint32_t any_order = 0, float t_known = -1.0f);
+ReplayHit replay_trace(const BuiltScene& B, const float o[3], const float d[3], float tmin, float tmax, bool any, uint32_t any_order = 0, float t_known = -1.0f,
+                       std::vector<uint8_t>* seq = nullptr);      // seq: per node step, the number of triangles it queued (tools/bvh_lab: wave-schedule simulation)
 uint32_t probe_anyhit_order(const BuiltScene& B);
 
 struct CoverCheck {                                         // coverage bookkeeping of the tree validators (rtx_scene_host.cpp)

@@ -113,6 +113,42 @@ struct WhatIf { const BuiltScene& B; V3 o, d, idir; uint32_t oct; float tmin; fl
     }
 };
 
+// ---- wave-schedule simulation (wavesim=1): the speculative voted schedule of csrc/rtx_traverse.hpp spec_step (PEND 2, vote "node step if ni >= 2 nl") replayed on the
+// per-ray step sequences of the host replay, with the persistent refill (>= refill idle SLOTS), for ONE or TWO rays per lane.  Cost model: node iteration 205 + 12, triangle
+// iteration 70 + 12 VALU instructions per wave (a wave instruction costs the same whatever its active lanes).  What it cannot see: culling changes from the order in which
+// pending triangles shorten a ray (the sequences are the non-speculative order), memory stalls, occupancy.
+struct SimRay { const uint8_t* seq; uint32_t n, idx, T, P; bool busy; };
+struct SimOut { double cost = 0, node_it = 0, tri_it = 0, node_lanes = 0, tri_lanes = 0, rays = 0; };
+static SimOut wave_sim(const std::vector<std::vector<uint8_t>>& seqs, size_t first, size_t count, int slots_per_lane, uint32_t refill_min, double vote = 2.0, int pend = 1) {
+    SimOut S; const int NS = 64 * slots_per_lane;
+    std::vector<SimRay> R(NS, SimRay{nullptr, 0, 0, 0, 0, false});
+    size_t next = first; const size_t end = first + count;
+    auto done = [](const SimRay& r) { return r.idx >= r.n && r.T == 0 && r.P == 0; };
+    for (;;) {
+        int idle = 0; for (auto& r : R) if (!r.busy) idle++;
+        if (next < end && (idle >= (int)refill_min * slots_per_lane || idle == NS)) {
+            for (auto& r : R) if (!r.busy && next < end) { const auto& q = seqs[next++]; r = SimRay{q.data(), (uint32_t)q.size(), 0, 0, 0, true}; if (done(r)) r.busy = false; S.rays++; }
+            S.cost += 60;                                              // refill: atomic, loads, ray set-up
+        }
+        int ni = 0, nl = 0;
+        for (int l = 0; l < 64; l++) {
+            bool cn = false, ht = false;
+            for (int k = 0; k < slots_per_lane; k++) { const SimRay& r = R[l * slots_per_lane + k]; if (!r.busy) continue; cn = cn || (r.P == 0 && r.idx < r.n); ht = ht || r.T > 0; }
+            ni += cn; nl += ht;
+        }
+        if (!ni && !nl) { if (next >= end) break; continue; }
+        if ((double)ni >= vote * (double)nl && ni) {
+            S.cost += 217; S.node_it++; S.node_lanes += ni;
+            for (int l = 0; l < 64; l++) for (int k = 0; k < slots_per_lane; k++) { SimRay& r = R[l * slots_per_lane + k]; if (r.busy && r.P == 0 && r.idx < r.n) { r.P = r.seq[r.idx++]; if (!r.T) { r.T = r.P; r.P = 0; } break; } }
+        } else {
+            S.cost += 82; S.tri_it++; S.tri_lanes += nl;
+            for (int l = 0; l < 64; l++) for (int k = 0; k < slots_per_lane; k++) { SimRay& r = R[l * slots_per_lane + k]; if (r.busy && r.T > 0) { r.T--; if (!r.T) { r.T = r.P; r.P = 0; } break; } }
+        }
+        for (auto& r : R) if (r.busy && done(r)) r.busy = false;
+    }
+    return S;
+}
+
 inline uint32_t hash32(uint32_t a, uint32_t b) { uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u; h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15; return h; }
 inline float rnd(uint32_t a, uint32_t b) { return (float)(hash32(a, b) >> 8) * (1.0f / 16777216.0f); }
 
@@ -156,12 +192,12 @@ void wide_sah(const BuiltScene& B, double& node_cost, double& tri_cost, double& 
 
 int main(int argc, char** argv) {
     const std::string which = argc > 1 ? argv[1] : "sponza";
-    int W = 480, Hh = 270, bounces = 4; bool check = false, lower = false; int whatif = 0;
+    int W = 480, Hh = 270, bounces = 4; bool check = false, lower = false, wavesim = false; int whatif = 0;
     for (int i = 2; i < argc; i++) {
         std::string kv = argv[i]; const size_t eq = kv.find('=');
         if (eq == std::string::npos) continue;
         const std::string k = kv.substr(0, eq); const double v = atof(kv.c_str() + eq + 1);
-        if (k == "w") W = (int)v; else if (k == "h") Hh = (int)v; else if (k == "bounces") bounces = (int)v; else if (k == "check") check = v != 0; else if (k == "lower") lower = v != 0; else if (k == "whatif") whatif = (int)v; else if (k == "any_order") g_any_order = (int)v;
+        if (k == "w") W = (int)v; else if (k == "h") Hh = (int)v; else if (k == "bounces") bounces = (int)v; else if (k == "check") check = v != 0; else if (k == "lower") lower = v != 0; else if (k == "wavesim") wavesim = v != 0; else if (k == "whatif") whatif = (int)v; else if (k == "any_order") g_any_order = (int)v;
         else if (!bvh_build_option(k.c_str(), v)) { fprintf(stderr, "unknown key %s\n", k.c_str()); return 2; }
     }
     Scene s;
@@ -193,6 +229,7 @@ int main(int argc, char** argv) {
     // a point on the first light for shadow rays
     V3 lightp{0, 0, 0}; bool have_light = !B.lights.empty();
     const auto t1 = std::chrono::steady_clock::now();
+    std::vector<std::vector<uint8_t>> seq_closest(wavesim ? (size_t)npx : 0);
     size_t mism = 0; double low_steps = 0, low_tris = 0; double lev_all[16] = {0}, zero_all[16] = {0}; double g_occ[4] = {0, 0, 0, 0};
 #pragma omp parallel
     {
@@ -207,7 +244,9 @@ int main(int argc, char** argv) {
             V3 o{org[0], org[1], org[2]}, d = nrm(V3{dir4[0], dir4[1], dir4[2]});
             float tmin = 1e-4f;
             for (int bnc = 0; bnc <= bounces; bnc++) {
-                const Hit H = traverse<false>(B, o, d, tmin, 1e30f);
+                std::vector<uint8_t> sq;
+                const Hit H = wavesim ? [&] { const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}; const ReplayHit Rh = replay_trace(B, oo, dd, tmin, 1e30f, false, 0u, -1.0f, &sq); return Hit{Rh.t, Rh.slot, Rh.prim, Rh.steps, Rh.tris}; }() : traverse<false>(B, o, d, tmin, 1e30f);
+                if (wavesim && bnc == 1) seq_closest[px] = sq;
                 a[bnc] += H.steps; b[bnc] += H.tris; c[bnc]++;
                 if (whatif) { const float dxs = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x, dys = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y, dzs = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
                     const V3 idir{1.0f / dxs, 1.0f / dys, 1.0f / dzs};
@@ -257,6 +296,16 @@ int main(int argc, char** argv) {
     printf("  ALL closest: steps/ray %.3f tris/ray %.3f cost %.0f | shadow: steps/ray %.3f tris/ray %.3f cost %.0f | sim %.1fs%s\n", cs, ct, cs * 205 * 64 / 47 + ct * 70 * 64 / 24, hs, ht, hs * 205 * 64 / 47 + ht * 70 * 64 / 24, sim_s,
            check ? (mism ? "  BRUTE-FORCE MISMATCH" : "  brute force: equal") : "");
     printf("  shadow rays: occluded %.3f (steps/ray %.2f), visible steps/ray %.2f\n", g_occ[0] / std::max(1.0, g_occ[0] + g_occ[2]), g_occ[1] / std::max(1.0, g_occ[0]), g_occ[3] / std::max(1.0, g_occ[2]));
+    if (wavesim) {
+        std::vector<std::vector<uint8_t>> qs; for (auto& q : seq_closest) if (!q.empty()) qs.push_back(q);
+        // queue order = pixel order (neighbouring pixels' bounce-1 rays, like a sub-queue); one wave owns 2 048 consecutive rays
+        for (int spl = 1; spl <= 3; spl++) for (double vote : {2.0, 1.0, 0.5, 0.25}) { const uint32_t rf = 12u;
+            SimOut T; const size_t per = 2048;
+            for (size_t f = 0; f + per <= qs.size(); f += per) { const SimOut S = wave_sim(qs, f, per, spl, rf, vote); T.cost += S.cost; T.node_it += S.node_it; T.tri_it += S.tri_it; T.node_lanes += S.node_lanes; T.tri_lanes += S.tri_lanes; T.rays += S.rays; }
+            printf("  wave sim, bounce-1 closest-hit rays, %d ray(s) per lane, refill at %u idle, node step if ni >= %.2f nl: cost %.0f VALU wave-instructions per ray x64 = %.1f per ray; node iterations %.1f lanes, triangle iterations %.1f lanes, %.2f / %.2f iterations per ray\n",
+                   spl, rf, vote, T.cost / T.rays * 64, T.cost / T.rays, T.node_lanes / T.node_it, T.tri_lanes / T.tri_it, T.node_it * 64 / T.rays, T.tri_it * 64 / T.rays);
+        }
+    }
     if (whatif) printf("  what-if %d (1: skip popped children beyond the best hit; 2: + visit by entry distance): steps/ray %.3f tris/ray %.3f mismatches %zu\n", whatif, low_steps / tc_, low_tris / tc_, mism);
     if (whatif) { printf("  steps per ray by depth (zero-hit share):"); for (int i = 0; i < 16 && lev_all[i] > 0; i++) printf(" %d: %.2f (%.0f%%)", i, lev_all[i] / tc_, 100.0 * zero_all[i] / lev_all[i]); printf("\n"); }
     if (lower) printf("  with the closest distance known in advance (bound for any visiting order): steps/ray %.3f tris/ray %.3f\n", low_steps / tc_, low_tris / tc_);
