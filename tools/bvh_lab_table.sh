@@ -36,6 +36,12 @@ for sc in sponza bistro; do
 done
 echo '```'
 echo
+echo "## One, two or three rays per lane?  The wave schedule simulated on the replay's step sequences (atrium, bounce-1 closest-hit rays, 2 048 rays per wave)"
+echo
+echo '```'
+tools/bvh_lab sponza wavesim=1 | grep "wave sim"
+echo '```'
+echo
 echo "(what-if rows: the hit differs from the device order's on 4 / 9 of 648 000 rays — float-sliver hits that only the device order's extra visits find, DESIGN.md section 2.)"
 echo
 echo "Reading: 27 % of the node steps hit none of the node's eight children (the ray crossed the node's box but no child's); with the closest distance known in advance the same tree needs"
