@@ -87,6 +87,8 @@ int  rtxh_scene_small_records(const rtxh_scene*, float* recs20, int32_t* tri_ids
 /* of those records, [0, *nocc_out) can lie between two scene points; the rest are faces of the scene's convex hull, which NEE
    shadow segments skip */
 int  rtxh_scene_small_occluders(const rtxh_scene*, uint32_t* nocc_out);
+/* the visiting order of any-hit rays rtx_commit_scene's probe picks for this scene (RTX_OPT_ANYHIT_ORDER -1): 0 slot order, 1 nearest octant first, 2 farthest first; no GPU needed */
+int  rtxh_scene_anyhit_order(const rtxh_scene*, uint32_t* order_out);
 
 /* the headless Renderer facade (Renderer.h:46-51) for FFI callers */
 typedef struct rtxh_renderer rtxh_renderer;

@@ -172,6 +172,7 @@ _sig("rtxh_bvh8_stats", C.c_int, _vp, _u32, _vp, _u32p)
 _sig("rtxh_bvh_option", C.c_int, C.c_char_p, C.c_double)
 _sig("rtxh_bvh_replay", C.c_int, _vp, _u32, _vp, _u32, C.c_int, _u32, _vp, _u32p)
 _sig("rtxh_scene_small_occluders", C.c_int, _vp, _u32p)
+_sig("rtxh_scene_anyhit_order", C.c_int, _vp, _u32p)
 _sig("rtxh_write_png", C.c_int, C.c_char_p, _vp, _u32, _u32)
 _sig("rtxh_write_ppm", C.c_int, C.c_char_p, _vp, _u32, _u32)
 _sig("rtxh_write_exr", C.c_int, C.c_char_p, _vp, _u32, _u32)
@@ -323,6 +324,13 @@ class Scene:
         n = _u32()
         if lib.rtxh_scene_small_occluders(self._h, C.byref(n)) != RTX_OK:
             raise RtxError("rtxh_scene_small_occluders failed")
+        return n.value
+
+    def anyhit_order(self):
+        """the any-hit visiting order the commit-time probe picks for this scene (0 slot order, 1 nearest octant first, 2 farthest first); host only"""
+        n = _u32()
+        if lib.rtxh_scene_anyhit_order(self._h, C.byref(n)) != RTX_OK:
+            raise RtxError("rtxh_scene_anyhit_order failed")
         return n.value
 
     def view_proj(self, aspect):

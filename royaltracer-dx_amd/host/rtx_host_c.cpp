@@ -294,6 +294,13 @@ int rtxh_scene_small_occluders(const rtxh_scene* sc, uint32_t* nocc_out) {
     *nocc_out = B.small_nocc;
     return RTX_OK;
 }
+// what rtx_commit_scene's probe would choose for this scene (csrc/rtx_scene_host.cpp: probe_anyhit_order), and the replayed cost of the probe's segments per order
+int rtxh_scene_anyhit_order(const rtxh_scene* sc, uint32_t* order_out) {
+    rtx::BuiltScene B;
+    if (!sc || !order_out || !build_for_inspection(sc, B)) return RTX_ERR_INVALID;
+    *order_out = B.any_order;
+    return RTX_OK;
+}
 static bool build_for_inspection(const rtxh_scene* sc, rtx::BuiltScene& B) {
     rtx::SceneHost H;
     const Scene& s = sc->s;
