@@ -124,7 +124,7 @@ enum : uint32_t { T_SCAL = 1, T_MATS128, T_MATIDS, T_INSTH, T_MESHV, T_MESHI, T_
 
 bool save_scene_cache(const SceneHost& H, const BuiltScene& B, const char* path, std::string& err, const float* cam12, const CacheAux* aux) {
     if (!path || !*path) { err = "scene cache: empty path"; return false; }
-    if (H.topo_dirty || H.mats_dirty || B.shade.size() != B.tris8.size() || (!B.tris8.empty() && B.nodes8.empty())) { err = "scene cache: scene not built"; return false; }
+    if (H.topo_dirty || H.mats_dirty || B.tris8.size() < B.shade.size() || B.tris8.size() != B.tri_slots8.size() || (!B.tris8.empty() && B.nodes8.empty())) { err = "scene cache: scene not built"; return false; }
     Writer w;
     Scalars sc{}; sc.stack8 = B.stack8; sc.small_nrec = B.small_nrec; sc.small_nocc = B.small_nocc; sc.max_depth = B.max_depth; sc.nmesh = (uint32_t)H.meshes.size();
     sc.bvh_pad = B.bvh_pad; sc.small_cm = B.small_cm; sc.small_delta = B.small_delta; sc.small_hull_margin = B.small_hull_margin; sc.total_weight = B.total_weight;

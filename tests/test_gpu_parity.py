@@ -895,20 +895,26 @@ def test_material_edit_after_commit(rt, orc, cornell, gpu_refit, tris):
     c.close()
 
 
-@pytest.mark.parametrize("kind", ["cornell", "garage", "atrium"])
+@pytest.mark.parametrize("kind", ["cornell", "garage", "atrium", "garage_split"])
 def test_scene_cache_renders_bit_identically(rt, orc, cornell, golden_dir, tmp_path, kind):
     """a scene loaded from the binary cache (prebuilt BVH, shading records, LUTs, light CDF: no build at commit) renders the
     same bits and traces the same rays as the scene committed from scratch — through the context-level pair rtx_save_scene_cache /
     rtx_load_scene_cache and through the host-level rtxh_scene_save / rtxh_scene_load; the loaded scene can still be edited (a
-    transform-only commit refits on the GPU from object-space triangles re-derived at that point, a material edit re-derives the table)."""
+    transform-only commit refits on the GPU from object-space triangles re-derived at that point, a material edit re-derives the table).
+    garage_split: the tree was built with spatial splits (RTX_OPT_BVH_SPLIT): the file then holds more leaf entries than triangles."""
+    split = kind == "garage_split"
     sc = {"cornell": lambda: cornell, "atrium": lambda: rt.Scene.sponza_class(60000, 260),
-          "garage": lambda: rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")}[kind]()
+          "garage": lambda: rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")}[kind.split("_")[0]]()
     W, H = 128, 72
     p = rt.Params(width=W, height=H, spp=2, max_bounces=5, nee_samples=1, flags=0, frame_seed=3)
-    a = rt.Context(0); a.upload(sc, W / H); a.clear(W, H); a.render(p); ref = a.read_accum(); sa = a.stats()
+    a = rt.Context(0)
+    if split:
+        a.set_option(rt.OPT_BVH_SPLIT, 10000)
+    a.upload(sc, W / H); a.clear(W, H); a.render(p); ref = a.read_accum(); sa = a.stats()
+    assert (sa.bvh_refs > sa.triangles) == split
     a.save_scene_cache(tmp_path / "ctx.rtxscn")
     sc.save(tmp_path / "host.rtxscn")
-    for how in ("ctx", "host"):
+    for how in (("ctx",) if split else ("ctx", "host")):            # (the host-level file is built with the process-wide builder defaults)
         b = rt.Context(0)
         if how == "ctx":
             b.load_scene_cache(tmp_path / "ctx.rtxscn"); b.set_camera(*sc.view_proj(W / H))
@@ -916,8 +922,8 @@ def test_scene_cache_renders_bit_identically(rt, orc, cornell, golden_dir, tmp_p
             b.upload(rt.Scene.load(tmp_path / "host.rtxscn"), W / H)
         b.clear(W, H); b.render(p); sb = b.stats()
         assert np.array_equal(bits(b.read_accum()), bits(ref)), (kind, how)
-        assert (sb.rays_primary, sb.rays_extension, sb.rays_shadow, sb.triangles, sb.bvh_nodes, sb.lights, sb.materials) == \
-               (sa.rays_primary, sa.rays_extension, sa.rays_shadow, sa.triangles, sa.bvh_nodes, sa.lights, sa.materials)
+        assert (sb.rays_primary, sb.rays_extension, sb.rays_shadow, sb.triangles, sb.bvh_refs, sb.bvh_nodes, sb.lights, sb.materials) == \
+               (sa.rays_primary, sa.rays_extension, sa.rays_shadow, sa.triangles, sa.bvh_refs, sa.bvh_nodes, sa.lights, sa.materials)
         assert np.array_equal(bits(b.lights()), bits(a.lights()))
         if kind != "cornell":
             assert b.validate_bvh() == 0
