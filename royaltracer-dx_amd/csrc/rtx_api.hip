@@ -48,6 +48,7 @@ struct rtx_ctx {
     // RTX_OPT_ASYNC: what finish_render needs of the frame that rtx_render enqueued
     struct Pending { bool active = false; size_t ncnt = 0; uint32_t nbatches = 0, G = 0, mb = 0, nee = 0, nee1 = 1; bool fused = false, fused_bvh = false; } pending;
     bool async = false;
+    bool octant_sort = false; DevBuf d_oct[2], d_perm;    // RTX_OPT_OCTANT_SORT
     bool trace_counters = false; DevBuf d_trace_cnt;      // RTX_OPT_TRACE_COUNTERS
     int any_order_opt = -1;         // RTX_OPT_ANYHIT_ORDER: -1 = what the commit-time probe chose (BuiltScene::any_order)
     bool lpt_order = true;          // RTX_OPT_LPT_ORDER: fused kernels take their sub-queues longest first
@@ -142,7 +143,7 @@ void rtx_destroy(rtx_ctx* c) {
     else (void)hipDeviceSynchronize();
     DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_small_poly, &c->d_objtris, &c->d_node_aabb, &c->d_scale, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cdf, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
                      &c->d_thr, &c->d_rad, &c->d_hit, &c->d_hitmask, &c->d_order, &c->d_pmask, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
-                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq, &c->d_halo, &c->d_own, &c->d_heads, &c->d_alt_o, &c->d_alt_d, &c->d_alt_thr};
+                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq, &c->d_halo, &c->d_own, &c->d_heads, &c->d_alt_o, &c->d_alt_d, &c->d_alt_thr, &c->d_oct[0], &c->d_oct[1], &c->d_perm, &c->d_trace_cnt};
     for (auto& A : c->rs_area) for (DevBuf* b : {&A.state, &A.hit, &A.cls, &A.fin, &A.cold, &A.occ, &A.cand, &A.sho, &A.shd, &A.pay, &A.cnt}) b->release();
     for (hipStream_t& ls : c->lane_stream) if (ls) { (void)hipStreamDestroy(ls); ls = nullptr; }
     for (DevBuf* b : all) b->release();
@@ -162,6 +163,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     switch (option) {
     case RTX_OPT_KERNEL_TIMING: c->timing = value != 0; return RTX_OK;
     case RTX_OPT_ASYNC: c->async = value != 0; return RTX_OK;
+    case RTX_OPT_OCTANT_SORT: c->octant_sort = value != 0; return RTX_OK;
     case RTX_OPT_TRACE_COUNTERS:
         c->trace_counters = value != 0;
         if (c->trace_counters) { HIPCHK(c, c->d_trace_cnt.ensure(4 * sizeof(unsigned long long))); HIPCHK(c, hipMemsetAsync(c->d_trace_cnt.p, 0, 32, c->stream)); }
@@ -552,7 +554,9 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     DevPaths P;
     P.ray_o = (F4*)c->d_ray_o.p; P.ray_d = (F4*)c->d_ray_d.p; P.thr = (F4*)c->d_thr.p; P.rad = (F4*)c->d_rad.p; P.hit = (F4*)c->d_hit.p;
     P.hitmask = nullptr;
-    P.out_o = P.out_d = P.out_thr = nullptr;
+    P.out_o = P.out_d = P.out_thr = nullptr; P.oct_out = nullptr; P.oct_in = nullptr; P.perm = nullptr;
+    const bool osort = c->octant_sort && compact && !stealing;
+    if (osort) { HIPCHK(c, c->d_oct[0].ensure(qtot)); HIPCHK(c, c->d_oct[1].ensure(qtot)); HIPCHK(c, c->d_perm.ensure(qtot * 4)); }
     if (c->dsc.nsmall && c->fused) { HIPCHK(c, c->d_hitmask.ensure(((size_t)cap / 64 + 1) * 8)); P.hitmask = (unsigned long long*)c->d_hitmask.p; }
     P.sh_o = (F4*)c->d_sh_o.p; P.sh_d = (F4*)c->d_sh_d.p; P.sh_c = (F4*)c->d_sh_c.p;
     uint32_t* queue[2] = {(uint32_t*)c->d_queue[0].p, (uint32_t*)c->d_queue[1].p};
@@ -630,6 +634,10 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
                 F4* set[2][3] = {{(F4*)c->d_ray_o.p, (F4*)c->d_ray_d.p, (F4*)c->d_thr.p}, {(F4*)c->d_alt_o.p, (F4*)c->d_alt_d.p, (F4*)c->d_alt_thr.p}};
                 Pb.ray_o = set[b & 1][0]; Pb.ray_d = set[b & 1][1]; Pb.thr = set[b & 1][2];
                 Pb.out_o = set[(b + 1) & 1][0]; Pb.out_d = set[(b + 1) & 1][1]; Pb.out_thr = set[(b + 1) & 1][2];
+                if (osort) {           // shade(b) notes the survivors' octants for bounce b + 1; trace(b), b >= 1, sorts by what shade(b - 1) noted (camera rays of one block share their octant anyway)
+                    Pb.oct_out = (uint8_t*)c->d_oct[(b + 1) & 1].p;
+                    if (b >= 1) { Pb.oct_in = (const uint8_t*)c->d_oct[b & 1].p; Pb.perm = (uint32_t*)c->d_perm.p; }
+                }
             }
             { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, fb, c->dsc, Pb, b, q, Q(b), Hd(b, 0), merge_for(b < c->pred_q.size() ? c->pred_q[b] : 0, b < c->pred_q.size())); }
             if (ovl && ev_shadow_done) HIPCHK(c, hipStreamWaitEvent(st, ev_shadow_done, 0));      // shade(b) overwrites the shadow entries and touches rad: after shadow(b - 1)

@@ -171,6 +171,7 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevSc
                                                                        uint32_t nq, uint32_t merge) {           // nq sub-queues in the launch, `merge` of them per workgroup (MergedQ; 1 with STEAL and on the tiny-scene test path)
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_head;
+    __shared__ uint32_t s_oct[16];
 #ifdef RTX_WAVE_CLOCK
     #define RTX_WAVE_STAMP(K) do { const uint32_t w_ = blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6); if (tmin != kTMinCam && lane_id() == 0 && w_ < 65536u) g_wgt[2u * w_ + (K)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     RTX_WAVE_STAMP(0u);
@@ -181,6 +182,8 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevSc
     if (threadIdx.x == 0) s_head = 0;
     const TraceLds L = stage_lds(sc, lds);
     __syncthreads();
+    const bool sorted = !STEAL && p.perm != nullptr && p.oct_in != nullptr && p.out_o != nullptr;      // RTX_OPT_OCTANT_SORT: every sub-queue of this workgroup grouped by direction octant
+    if (sorted) for (uint32_t t = 0; t < merge && M.q0 + t < nq; t++) sort_by_octant(p.oct_in + (size_t)(M.q0 + t) * qcap, p.perm + (size_t)(M.q0 + t) * qcap, qcount[M.q0 + t], s_oct);
     const uint32_t* myq = queue + (size_t)blockIdx.x * qcap;
     if (SCHED < 0 && sc.nsmall) {                          // tiny scene, un-fused kernels (test path)
         for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
@@ -200,6 +203,7 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevSc
     uint32_t rng = steal_seed();
     uint32_t cnt_nodes = 0, cnt_tris = 0;
     auto fetch = [&](uint32_t q, uint32_t idx) {
+        if (sorted) idx = p.perm[(size_t)q * qcap + idx];
         const uint32_t pid = p.out_o ? q * qcap + idx : queue[(size_t)q * qcap + idx];
         const F4 ro = ld_stream(p.ray_o + pid), rd = ld_stream(p.ray_d + pid);
         ray_begin(R, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, kTMax, pid, true);
@@ -350,6 +354,7 @@ __device__ __forceinline__ void shade_item(const DevScene& sc, const DevFrame& f
     if (alive) {
         if (p.out_o) store_path_at_stream(p.out_o, p.out_d, p.out_thr, (uint32_t)qb + slot, S, pos, smp, P);     // densely, at its place in the next queue
         else store_path(p, S, pos, smp, P);
+        if (p.oct_out) p.oct_out[qb + slot] = (uint8_t)((f2u(smp.x) >> 31) | ((f2u(smp.y) >> 31) << 1) | ((f2u(smp.z) >> 31) << 2));   // RTX_OPT_OCTANT_SORT: what ray_octant() will see (sign bits)
         mynext[slot] = S.pid;
     }
 }

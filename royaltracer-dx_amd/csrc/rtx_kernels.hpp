@@ -106,6 +106,10 @@ struct DevPaths {
     // bounces after Russian roulette touched one 16-B record per 128-B line), and the trace kernels need no queue read before they can
     // fetch a ray.  rad stays indexed by path id.
     F4* out_o; F4* out_d; F4* out_thr;        // nullptr: state indexed by path id, updated in place
+    // RTX_OPT_OCTANT_SORT (compact state only): k_shade notes the direction octant of every survivor at its place in the next queue (oct_out); the closest-hit kernel of the
+    // next bounce sorts its sub-queue's entries by that byte in a prologue (perm: entry order -> queue position) and fetches its rays through perm, so that a wave's lanes
+    // hold rays of one octant for long runs.  Hit records are still written at the entry's own position: k_shade reads its streams in order as before.  nullptr = off
+    uint8_t* oct_out; const uint8_t* oct_in; uint32_t* perm;
 };
 
 // work area of the wavefront ReSTIR stages (rtx_restir_wave.hpp), device pointers; one pass at a time

@@ -709,6 +709,37 @@ struct MergedQ {
     }
 };
 
+// RTX_OPT_OCTANT_SORT: counting sort of ONE sub-queue's entries by their octant byte, by the whole workgroup (two passes of ballots; one LDS atomic per octant and wave
+// iteration): perm[0 .. n) = the entries grouped by octant.  s_cnt: 16 words of LDS.  Ends with a barrier; perm is read back by the same workgroup only.
+__device__ __forceinline__ void sort_by_octant(const uint8_t* __restrict__ oct, uint32_t* __restrict__ perm, uint32_t n, uint32_t* s_cnt) {
+    if (threadIdx.x < 16u) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    for (uint32_t base = threadIdx.x & ~63u; base < n; base += kBlock) {
+        const uint32_t i = base + lane_id();
+        const uint32_t o = i < n ? (uint32_t)oct[i] & 7u : 8u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) { const unsigned long long m = __ballot(o == k); if (m && lane_id() == 0) atomicAdd(&s_cnt[k], (uint32_t)__popcll(m)); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t acc = 0; for (uint32_t k = 0; k < 8u; k++) { const uint32_t c = s_cnt[k]; s_cnt[8u + k] = acc; acc += c; } }
+    __syncthreads();
+    for (uint32_t base = threadIdx.x & ~63u; base < n; base += kBlock) {
+        const uint32_t i = base + lane_id();
+        const uint32_t o = i < n ? (uint32_t)oct[i] & 7u : 8u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) {
+            const unsigned long long m = __ballot(o == k);
+            if (!m) continue;
+            uint32_t b = 0;
+            if (lane_id() == 0) b = atomicAdd(&s_cnt[8u + k], (uint32_t)__popcll(m));
+            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+            if (o == k) perm[b + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = i;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
 // wave-level refill: returns false when the wave may exit (queue exhausted and nothing in flight)
 template <bool MASKS, class Fetch>      // MASKS: keep R.om current (closest-hit kernels; the any-hit kernel measured 5 % SLOWER with the masks on C3 and derives the conditions from the octant)
 __device__ __forceinline__ bool refill(RayLane& R, uint32_t* s_head, uint32_t n, bool& drained, uint32_t refill_min, Fetch fetch) {

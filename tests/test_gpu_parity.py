@@ -738,6 +738,28 @@ def test_restir_wavefront_equals_literal_on_a_bvh_scene_at_scale(rt, orc):
     assert total[2] > 4 * W * H and total[1] > 2 * W * H
 
 
+def test_octant_sorted_fetch_changes_nothing(rt):
+    """RTX_OPT_OCTANT_SORT (measured slower and off by default: docs/REJECTED.md): k_shade notes every survivor's direction octant, the closest-hit kernel of the next
+    bounce counting-sorts its sub-queue's entries by it in a prologue and fetches through the permutation.  Hit records still land at the entries' own positions, so the frame is the
+    same bits with the option on, off, and switched on a live context (sub-queue merging of the thin late bounces included)."""
+    import hashlib
+    sc = rt.Scene.sponza_class(60000, 260)
+    W, H = 640, 360
+    p = rt.Params(width=W, height=H, spp=4, max_bounces=8, nee_samples=1, rr_start=3, sample_base=1, flags=1, frame_seed=3)
+
+    def run(c):
+        c.clear(W, H); c.render(p); st = c.stats()
+        return (st.rays_primary, st.rays_extension, st.rays_shadow), hashlib.sha1(c.read_accum().tobytes()).hexdigest()
+    a = rt.Context(0); a.upload(sc, W / H)
+    ref = run(a)
+    assert run(a) == ref                                     # (second frame: launch sizes predicted, thin launches merged)
+    b = rt.Context(0); b.set_option(rt.OPT_OCTANT_SORT, 1); b.upload(sc, W / H)
+    assert run(b) == ref and run(b) == ref
+    b.set_option(rt.OPT_OCTANT_SORT, 0); assert run(b) == ref
+    a.set_option(rt.OPT_OCTANT_SORT, 1); assert run(a) == ref
+    a.close(); b.close()
+
+
 def test_trace_counters_report_work_per_ray_and_change_nothing(rt):
     """RTX_OPT_TRACE_COUNTERS (bench.py: extra.*.work_per_ray): the persistent traversal kernels tally node steps and triangle tests; same image and ray counts with the
     counters on, and per closest-hit ray the tally lies within a few per cent of the one-ray-per-thread statistics kernel's (rtx_debug_trace_stats on the frame's own primary
