@@ -133,7 +133,8 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
                                         this many rays per sub-queue gives each workgroup 2 / 4 / 8 consecutive sub-queues, down to one round of resident workgroups (the late bounces of
                                         a frame, after Russian roulette).  Default 1024; 0 = one sub-queue per workgroup always.  Never changes a result */
        RTX_OPT_OCTANT_SORT = 32,     /* 1: general scenes, compact state: the closest-hit kernel of bounce b >= 1 fetches the rays of its sub-queue grouped by direction octant (k_shade notes a survivor's
-                                        octant, a prologue of the traversal kernel counting-sorts the sub-queue's entries by it).  Never changes a result; MEASURED: see DESIGN.md section 6c.  Default 0 */
+                                        octant, a prologue of the traversal kernel counting-sorts the sub-queue's entries by it).  3: the key is the cell of the ray's ORIGIN on a 256-cell grid over the scene's box, from bounce 2.
+                                        2 and 5 are measurement variants (all keys zero; hashed keys).  Never changes a result; MEASURED slower in every form: profiles/r04_octsort_ab.md.  Default 0 */
        RTX_OPT_ASYNC = 31,           /* 1: on a caller-bound stream (rtx_set_stream) rtx_render returns once the frame is ENQUEUED; rtx_pack_tiles / rtx_unpack_tiles (and the caller's collective)
                                         follow it in stream order with no host join in between.  Statistics (rtx_get_stats) and every other entry point join the frame first.  Default 0:
                                         rtx_render returns with the frame finished.  On the context's own stream the option is ignored */

@@ -48,7 +48,7 @@ struct rtx_ctx {
     // RTX_OPT_ASYNC: what finish_render needs of the frame that rtx_render enqueued
     struct Pending { bool active = false; size_t ncnt = 0; uint32_t nbatches = 0, G = 0, mb = 0, nee = 0, nee1 = 1; bool fused = false, fused_bvh = false; } pending;
     bool async = false;
-    bool octant_sort = false; DevBuf d_oct[2], d_perm;    // RTX_OPT_OCTANT_SORT
+    int octant_sort = 0; DevBuf d_oct[2], d_perm;    // RTX_OPT_OCTANT_SORT (2 = tooling: all keys zero, i.e. the machinery's overhead without a re-ordering)
     bool trace_counters = false; DevBuf d_trace_cnt;      // RTX_OPT_TRACE_COUNTERS
     int any_order_opt = -1;         // RTX_OPT_ANYHIT_ORDER: -1 = what the commit-time probe chose (BuiltScene::any_order)
     bool lpt_order = true;          // RTX_OPT_LPT_ORDER: fused kernels take their sub-queues longest first
@@ -163,7 +163,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     switch (option) {
     case RTX_OPT_KERNEL_TIMING: c->timing = value != 0; return RTX_OK;
     case RTX_OPT_ASYNC: c->async = value != 0; return RTX_OK;
-    case RTX_OPT_OCTANT_SORT: c->octant_sort = value != 0; return RTX_OK;
+    case RTX_OPT_OCTANT_SORT: c->octant_sort = (int)value; return RTX_OK;
     case RTX_OPT_TRACE_COUNTERS:
         c->trace_counters = value != 0;
         if (c->trace_counters) { HIPCHK(c, c->d_trace_cnt.ensure(4 * sizeof(unsigned long long))); HIPCHK(c, hipMemsetAsync(c->d_trace_cnt.p, 0, 32, c->stream)); }
@@ -341,6 +341,18 @@ static int finalise_scene(rtx_ctx* c) {
     s.nsmall = 0; s.nsmall_occ = 0;
     s.any_order = c->any_order_opt < 0 ? B.any_order : (uint32_t)c->any_order_opt;
     s.any_order_occ = c->any_order_opt < 0 ? 0u : (uint32_t)c->any_order_opt;
+    {   // grid of RTX_OPT_OCTANT_SORT 3 over the root's box: 8 bits handed to the axes one at a time, always to the axis whose cells are longest
+        float ext[3] = {1.0f, 1.0f, 1.0f}; uint32_t bits[3] = {0, 0, 0};
+        s.cell_o[0] = s.cell_o[1] = s.cell_o[2] = 0.0f;
+        if (!B.nodes8.empty()) {
+            const Node8GPU& R0 = B.nodes8[0];
+            s.cell_o[0] = R0.px; s.cell_o[1] = R0.py; s.cell_o[2] = R0.pz;
+            for (int a = 0; a < 3; a++) ext[a] = std::max(1e-20f, 255.0f * std::ldexp(1.0f, (int)((R0.e_imask >> (8 * a)) & 0xffu) - 127));
+        }
+        for (int k = 0; k < 8; k++) { int best = 0; for (int a = 1; a < 3; a++) if (ext[a] / (float)(1u << bits[a]) > ext[best] / (float)(1u << bits[best])) best = a; bits[best]++; }
+        for (int a = 0; a < 3; a++) s.cell_s[a] = (float)(1u << bits[a]) / ext[a];
+        s.cell_bits = bits[0] | (bits[1] << 4) | (bits[2] << 8);
+    }
     s.trace_cnt = c->trace_counters ? (unsigned long long*)c->d_trace_cnt.p : nullptr;
     s.refill_min = c->refill_min; s.trace_sched = c->trace_sched; s.sort_materials = c->sort_materials; s.occluder_cache = c->occluder_cache; s.shade_dense = c->shade_dense > 0 ? 1u : 0u;
     if (c->small_scene && B.small_nrec && B.small_tris.size() * 48 <= budget + (size_t)s.lds_tris * 48) {
@@ -554,9 +566,10 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
     DevPaths P;
     P.ray_o = (F4*)c->d_ray_o.p; P.ray_d = (F4*)c->d_ray_d.p; P.thr = (F4*)c->d_thr.p; P.rad = (F4*)c->d_rad.p; P.hit = (F4*)c->d_hit.p;
     P.hitmask = nullptr;
-    P.out_o = P.out_d = P.out_thr = nullptr; P.oct_out = nullptr; P.oct_in = nullptr; P.perm = nullptr;
+    P.out_o = P.out_d = P.out_thr = nullptr; P.oct_out = nullptr; P.oct_in = nullptr; P.perm = nullptr; P.key_mode = (uint32_t)c->octant_sort;
     const bool osort = c->octant_sort && compact && !stealing;
     if (osort) { HIPCHK(c, c->d_oct[0].ensure(qtot)); HIPCHK(c, c->d_oct[1].ensure(qtot)); HIPCHK(c, c->d_perm.ensure(qtot * 4)); }
+    if (osort && c->octant_sort == 2) { HIPCHK(c, hipMemsetAsync(c->d_oct[0].p, 0, qtot, c->stream)); HIPCHK(c, hipMemsetAsync(c->d_oct[1].p, 0, qtot, c->stream)); }
     if (c->dsc.nsmall && c->fused) { HIPCHK(c, c->d_hitmask.ensure(((size_t)cap / 64 + 1) * 8)); P.hitmask = (unsigned long long*)c->d_hitmask.p; }
     P.sh_o = (F4*)c->d_sh_o.p; P.sh_d = (F4*)c->d_sh_d.p; P.sh_c = (F4*)c->d_sh_c.p;
     uint32_t* queue[2] = {(uint32_t*)c->d_queue[0].p, (uint32_t*)c->d_queue[1].p};
@@ -635,8 +648,8 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
                 Pb.ray_o = set[b & 1][0]; Pb.ray_d = set[b & 1][1]; Pb.thr = set[b & 1][2];
                 Pb.out_o = set[(b + 1) & 1][0]; Pb.out_d = set[(b + 1) & 1][1]; Pb.out_thr = set[(b + 1) & 1][2];
                 if (osort) {           // shade(b) notes the survivors' octants for bounce b + 1; trace(b), b >= 1, sorts by what shade(b - 1) noted (camera rays of one block share their octant anyway)
-                    Pb.oct_out = (uint8_t*)c->d_oct[(b + 1) & 1].p;
-                    if (b >= 1) { Pb.oct_in = (const uint8_t*)c->d_oct[b & 1].p; Pb.perm = (uint32_t*)c->d_perm.p; }
+                    Pb.oct_out = c->octant_sort == 2 ? nullptr : (uint8_t*)c->d_oct[(b + 1) & 1].p;
+                    if (b >= (c->octant_sort == 3 ? 2u : 1u)) { Pb.oct_in = (const uint8_t*)c->d_oct[b & 1].p; Pb.perm = (uint32_t*)c->d_perm.p; }     // (origin cells: bounce 1 starts at the camera rays' hits, already in image order)
                 }
             }
             { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, fb, c->dsc, Pb, b, q, Q(b), Hd(b, 0), merge_for(b < c->pred_q.size() ? c->pred_q[b] : 0, b < c->pred_q.size())); }

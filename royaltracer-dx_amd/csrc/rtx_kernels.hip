@@ -171,7 +171,6 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevSc
                                                                        uint32_t nq, uint32_t merge) {           // nq sub-queues in the launch, `merge` of them per workgroup (MergedQ; 1 with STEAL and on the tiny-scene test path)
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_head;
-    __shared__ uint32_t s_oct[16];
 #ifdef RTX_WAVE_CLOCK
     #define RTX_WAVE_STAMP(K) do { const uint32_t w_ = blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6); if (tmin != kTMinCam && lane_id() == 0 && w_ < 65536u) g_wgt[2u * w_ + (K)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     RTX_WAVE_STAMP(0u);
@@ -183,7 +182,7 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevSc
     const TraceLds L = stage_lds(sc, lds);
     __syncthreads();
     const bool sorted = !STEAL && p.perm != nullptr && p.oct_in != nullptr && p.out_o != nullptr;      // RTX_OPT_OCTANT_SORT: every sub-queue of this workgroup grouped by direction octant
-    if (sorted) for (uint32_t t = 0; t < merge && M.q0 + t < nq; t++) sort_by_octant(p.oct_in + (size_t)(M.q0 + t) * qcap, p.perm + (size_t)(M.q0 + t) * qcap, qcount[M.q0 + t], s_oct);
+    if (sorted) for (uint32_t t = 0; t < merge && M.q0 + t < nq; t++) sort_by_key(p.oct_in + (size_t)(M.q0 + t) * qcap, p.perm + (size_t)(M.q0 + t) * qcap, qcount[M.q0 + t], (lds_u32*)L.stack);
     const uint32_t* myq = queue + (size_t)blockIdx.x * qcap;
     if (SCHED < 0 && sc.nsmall) {                          // tiny scene, un-fused kernels (test path)
         for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
@@ -354,7 +353,18 @@ __device__ __forceinline__ void shade_item(const DevScene& sc, const DevFrame& f
     if (alive) {
         if (p.out_o) store_path_at_stream(p.out_o, p.out_d, p.out_thr, (uint32_t)qb + slot, S, pos, smp, P);     // densely, at its place in the next queue
         else store_path(p, S, pos, smp, P);
-        if (p.oct_out) p.oct_out[qb + slot] = (uint8_t)((f2u(smp.x) >> 31) | ((f2u(smp.y) >> 31) << 1) | ((f2u(smp.z) >> 31) << 2));   // RTX_OPT_OCTANT_SORT: what ray_octant() will see (sign bits)
+        if (p.oct_out) {                                              // RTX_OPT_OCTANT_SORT: the key the next bounce's closest-hit kernel groups its fetches by
+            uint32_t key = (f2u(smp.x) >> 31) | ((f2u(smp.y) >> 31) << 1) | ((f2u(smp.z) >> 31) << 2);            // 1: the direction octant (what ray_octant() will see: sign bits)
+            if (p.key_mode == 3u) {                                   // 3: the cell of the ray's ORIGIN on a grid over the scene's box (sc.cell_*: 8 bits in all, split by the box's extents)
+                const uint32_t bx = sc.cell_bits & 15u, by = (sc.cell_bits >> 4) & 15u, bz = (sc.cell_bits >> 8) & 15u;
+                const uint32_t cx = (uint32_t)fminf(fmaxf((pos.x - sc.cell_o[0]) * sc.cell_s[0], 0.0f), (float)((1u << bx) - 1u));
+                const uint32_t cy = (uint32_t)fminf(fmaxf((pos.y - sc.cell_o[1]) * sc.cell_s[1], 0.0f), (float)((1u << by) - 1u));
+                const uint32_t cz = (uint32_t)fminf(fmaxf((pos.z - sc.cell_o[2]) * sc.cell_s[2], 0.0f), (float)((1u << bz) - 1u));
+                key = cx | (cy << bx) | (cz << (bx + by));
+            }
+            if (p.key_mode == 5u) key = ((uint32_t)slot * 2654435761u) >> 24;      // 5 (tooling): a hashed key — the scattered fetch without any grouping, to price the fetch alone
+            p.oct_out[qb + slot] = (uint8_t)key;
+        }
         mynext[slot] = S.pid;
     }
 }

@@ -27,6 +27,7 @@ struct DevScene {
     uint32_t refill_min, trace_sched;   // persistent traversal: idle lanes that trigger a refill; wave schedule (rtx_kernels.hip)
     uint32_t shade_dense;               // general path: k_shade compacts the hits of its sub-queue through an LDS ring before shading them (k_shade_dense)
     uint32_t any_order;                 // any-hit rays: visiting order of a node's hit children, 0 slot order / 1 nearest octant first / 2 farthest first (rtx_traverse.hpp: node8_hits)
+    float cell_o[3], cell_s[3]; uint32_t cell_bits;     // RTX_OPT_OCTANT_SORT 3: grid over the scene's box, cell = (pos - cell_o) * cell_s per axis, bits per axis x | y << 4 | z << 8 (8 in all)
     uint32_t any_order_occ;             // ... of the ReSTIR stages' visibility rays (k_trace_shadow<.., SINK 1>): 0 unless RTX_OPT_ANYHIT_ORDER forces an order
     unsigned long long* trace_cnt;      // RTX_OPT_TRACE_COUNTERS: [0] node steps, [1] triangle tests of closest-hit rays, [2], [3] of any-hit rays, summed by the generic traversal instantiations; nullptr = off
     uint32_t occluder_cache;            // any-hit rays: a lane tests the triangle that occluded its previous ray first (rtx_traverse.hpp: ray_begin)
@@ -109,7 +110,7 @@ struct DevPaths {
     // RTX_OPT_OCTANT_SORT (compact state only): k_shade notes the direction octant of every survivor at its place in the next queue (oct_out); the closest-hit kernel of the
     // next bounce sorts its sub-queue's entries by that byte in a prologue (perm: entry order -> queue position) and fetches its rays through perm, so that a wave's lanes
     // hold rays of one octant for long runs.  Hit records are still written at the entry's own position: k_shade reads its streams in order as before.  nullptr = off
-    uint8_t* oct_out; const uint8_t* oct_in; uint32_t* perm;
+    uint8_t* oct_out; const uint8_t* oct_in; uint32_t* perm; uint32_t key_mode;     // key_mode: RTX_OPT_OCTANT_SORT's value (1 octant, 3 origin cell)
 };
 
 // work area of the wavefront ReSTIR stages (rtx_restir_wave.hpp), device pointers; one pass at a time

@@ -709,33 +709,26 @@ struct MergedQ {
     }
 };
 
-// RTX_OPT_OCTANT_SORT: counting sort of ONE sub-queue's entries by their octant byte, by the whole workgroup (two passes of ballots; one LDS atomic per octant and wave
-// iteration): perm[0 .. n) = the entries grouped by octant.  s_cnt: 16 words of LDS.  Ends with a barrier; perm is read back by the same workgroup only.
-__device__ __forceinline__ void sort_by_octant(const uint8_t* __restrict__ oct, uint32_t* __restrict__ perm, uint32_t n, uint32_t* s_cnt) {
-    if (threadIdx.x < 16u) s_cnt[threadIdx.x] = 0u;
+// RTX_OPT_OCTANT_SORT: counting sort of ONE sub-queue's entries by their key byte (direction octant, or the cell of the ray's origin), by the whole workgroup: LDS atomics into a
+// 256-bin histogram, an exclusive scan by one wave, a second pass that hands out ranks.  perm[0 .. n) = the entries grouped by key (not stable: no result depends on the order).
+// scratch: 512 words of LDS (the traversal stack's area, idle before the first ray).  Ends with a barrier; perm is read back by the same workgroup only.
+__device__ __forceinline__ void sort_by_key(const uint8_t* __restrict__ key, uint32_t* __restrict__ perm, uint32_t n, lds_u32* scratch) {
+    lds_u32* hist = scratch; lds_u32* off = scratch + 256;
+    hist[threadIdx.x] = 0u;                                      // kBlock = 256 threads, 256 bins
     __syncthreads();
-    for (uint32_t base = threadIdx.x & ~63u; base < n; base += kBlock) {
-        const uint32_t i = base + lane_id();
-        const uint32_t o = i < n ? (uint32_t)oct[i] & 7u : 8u;
+    for (uint32_t i = threadIdx.x; i < n; i += kBlock) atomicAdd((uint32_t*)(hist + key[i]), 1u);
+    __syncthreads();
+    if (threadIdx.x < 64u) {                                     // exclusive scan of 256 counts by one wave: four bins per lane
+        const uint32_t l = threadIdx.x;
+        const uint32_t c0 = hist[4u * l], c1 = hist[4u * l + 1u], c2 = hist[4u * l + 2u], c3 = hist[4u * l + 3u];
+        uint32_t incl = c0 + c1 + c2 + c3;
 #pragma unroll
-        for (uint32_t k = 0; k < 8u; k++) { const unsigned long long m = __ballot(o == k); if (m && lane_id() == 0) atomicAdd(&s_cnt[k], (uint32_t)__popcll(m)); }
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if ((int)l >= d) incl += t; }
+        const uint32_t base = incl - (c0 + c1 + c2 + c3);
+        off[4u * l] = base; off[4u * l + 1u] = base + c0; off[4u * l + 2u] = base + c0 + c1; off[4u * l + 3u] = base + c0 + c1 + c2;
     }
     __syncthreads();
-    if (threadIdx.x == 0) { uint32_t acc = 0; for (uint32_t k = 0; k < 8u; k++) { const uint32_t c = s_cnt[k]; s_cnt[8u + k] = acc; acc += c; } }
-    __syncthreads();
-    for (uint32_t base = threadIdx.x & ~63u; base < n; base += kBlock) {
-        const uint32_t i = base + lane_id();
-        const uint32_t o = i < n ? (uint32_t)oct[i] & 7u : 8u;
-#pragma unroll
-        for (uint32_t k = 0; k < 8u; k++) {
-            const unsigned long long m = __ballot(o == k);
-            if (!m) continue;
-            uint32_t b = 0;
-            if (lane_id() == 0) b = atomicAdd(&s_cnt[8u + k], (uint32_t)__popcll(m));
-            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-            if (o == k) perm[b + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = i;
-        }
-    }
+    for (uint32_t i = threadIdx.x; i < n; i += kBlock) perm[atomicAdd((uint32_t*)(off + key[i]), 1u)] = i;
     __threadfence_block();
     __syncthreads();
 }

@@ -741,7 +741,8 @@ def test_restir_wavefront_equals_literal_on_a_bvh_scene_at_scale(rt, orc):
 def test_octant_sorted_fetch_changes_nothing(rt):
     """RTX_OPT_OCTANT_SORT (measured slower and off by default: docs/REJECTED.md): k_shade notes every survivor's direction octant, the closest-hit kernel of the next
     bounce counting-sorts its sub-queue's entries by it in a prologue and fetches through the permutation.  Hit records still land at the entries' own positions, so the frame is the
-    same bits with the option on, off, and switched on a live context (sub-queue merging of the thin late bounces included)."""
+    same bits with the option on, off, and switched on a live context (sub-queue merging of the thin late bounces included).  Values 3 (key = the cell of the ray's origin on
+    a 256-cell grid over the scene's box, from bounce 2), 2 (all keys zero) and 5 (hashed keys) are the variants the measurement in profiles/r04_octsort_ab.md compares."""
     import hashlib
     sc = rt.Scene.sponza_class(60000, 260)
     W, H = 640, 360
@@ -757,6 +758,8 @@ def test_octant_sorted_fetch_changes_nothing(rt):
     assert run(b) == ref and run(b) == ref
     b.set_option(rt.OPT_OCTANT_SORT, 0); assert run(b) == ref
     a.set_option(rt.OPT_OCTANT_SORT, 1); assert run(a) == ref
+    for mode in (3, 2, 5):
+        a.set_option(rt.OPT_OCTANT_SORT, mode); assert run(a) == ref, mode
     a.close(); b.close()
 
 
