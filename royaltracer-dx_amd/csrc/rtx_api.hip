@@ -48,6 +48,7 @@ struct rtx_ctx {
     // RTX_OPT_ASYNC: what finish_render needs of the frame that rtx_render enqueued
     struct Pending { bool active = false; size_t ncnt = 0; uint32_t nbatches = 0, G = 0, mb = 0, nee = 0, nee1 = 1; bool fused = false, fused_bvh = false; } pending;
     bool async = false;
+    int sample_interleave = 1;                       // RTX_OPT_SAMPLE_INTERLEAVE
     int octant_sort = 0; DevBuf d_oct[2], d_perm;    // RTX_OPT_OCTANT_SORT (2 = tooling: all keys zero, i.e. the machinery's overhead without a re-ordering)
     bool trace_counters = false; DevBuf d_trace_cnt;      // RTX_OPT_TRACE_COUNTERS
     int any_order_opt = -1;         // RTX_OPT_ANYHIT_ORDER: -1 = what the commit-time probe chose (BuiltScene::any_order)
@@ -164,6 +165,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_KERNEL_TIMING: c->timing = value != 0; return RTX_OK;
     case RTX_OPT_ASYNC: c->async = value != 0; return RTX_OK;
     case RTX_OPT_OCTANT_SORT: c->octant_sort = (int)value; return RTX_OK;
+    case RTX_OPT_SAMPLE_INTERLEAVE: c->sample_interleave = value != 0; return RTX_OK;
     case RTX_OPT_TRACE_COUNTERS:
         c->trace_counters = value != 0;
         if (c->trace_counters) { HIPCHK(c, c->d_trace_cnt.ensure(4 * sizeof(unsigned long long))); HIPCHK(c, hipMemsetAsync(c->d_trace_cnt.p, 0, 32, c->stream)); }
@@ -460,7 +462,7 @@ static int make_frame(rtx_ctx* c, const rtx_params* p, DevFrame& f) {
     if (const char* e = validate_tiling(p, ts, cnt, npl64, &f.blk_gx, &f.blk_gy)) { c->err = e; return RTX_ERR_INVALID; }
     f.width = p->width; f.height = p->height; f.tile_size = ts;
     f.tile_shift = 0; while ((1u << f.tile_shift) < ts) f.tile_shift++;
-    f.nblocks = 1; f.qcap = 0; f.chunks_per_sample = 0; f.taper_levels = 0;
+    f.nblocks = 1; f.qcap = 0; f.chunks_per_sample = 0; f.taper_levels = 0; f.interleave = 0;
     f.tiles_x = (p->width + ts - 1) / ts; f.tiles_y = (p->height + ts - 1) / ts;
     f.shard_rank = p->shard_rank; f.shard_count = cnt;
     f.npl = (uint32_t)npl64;
@@ -603,6 +605,8 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
         DevFrame fb = f;
         fb.sample_first = p->sample_base + bi * bspp;
         fb.batch_spp = std::min(bspp, p->spp - bi * bspp);
+        fb.interleave = 0;                                     // (k_raygen only: the tiny-scene raygen keeps its packet order)
+        if (c->sample_interleave) while (fb.interleave < 4u && !((fb.batch_spp >> fb.interleave) & 1u)) fb.interleave++;       // S = the largest power of two <= 16 dividing the batch's sample count
         const bool fused = c->dsc.nsmall && c->fused;
         uint32_t* gen_row = cnt + ((size_t)(mb + 1) + (size_t)mb * nee1) * G;
         if (fused) { Timed t(c, RTX_K_RAYGEN); launch_raygen_trace_small(st, c->dsc, fb, P, cam, queue[0], Q(0), gen_row, (const unsigned long long*)c->d_pmask.p); }

@@ -58,8 +58,14 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DevFrame f, DevPaths p, const
         const uint32_t c = row0 + pos;
         row0 += nk;
         if (blockIdx.x >= nk || c >= nchunks) continue;                                   // wave-uniform
-        const uint32_t sl = c / f.chunks_per_sample, cl = c - sl * f.chunks_per_sample;   // wave-uniform (SALU)
-        const uint32_t pl = cl * kBlock + threadIdx.x;
+        uint32_t sl = c / f.chunks_per_sample, cl = c - sl * f.chunks_per_sample;         // wave-uniform (SALU)
+        uint32_t pl = cl * kBlock + threadIdx.x;
+        if (f.interleave) {                                                               // RTX_OPT_SAMPLE_INTERLEAVE: chunk = 256 / S pixel slots x S consecutive samples, the samples of a pixel in neighbouring
+            const uint32_t sh = f.interleave, S = 1u << sh;                                  // lanes (S = 2 .. 16 divides batch_spp).  Changes no path (seeds come from pixel and sample id) and no sum (rad[] is per path)
+            const uint32_t per = S * f.chunks_per_sample, sg = c / per, r = c - sg * per;
+            sl = sg * S + (threadIdx.x & (S - 1u));
+            pl = r * (kBlock >> sh) + (threadIdx.x >> sh);
+        }
         const uint32_t pid = sl * f.npl + pl;
         uint32_t x = 0, y = 0;
         const bool valid = slot_to_pixel(f, pl, x, y);

@@ -45,6 +45,7 @@ struct DevFrame {
     uint32_t max_bounces, nee_samples, rr_start, frame_seed, flags;
     // work distribution: `nblocks` workgroups, each owning a private sub-queue of `qcap` entries
     uint32_t nblocks, qcap, chunks_per_sample;   // chunks_per_sample = npl / 256
+    uint32_t interleave;     // RTX_OPT_SAMPLE_INTERLEAVE (k_raygen): 0 = a chunk of 256 queue entries is 256 pixel slots of ONE sample; s > 0 = 256 >> s pixel slots x 2^s consecutive samples, a pixel's samples in neighbouring lanes
     uint32_t taper_levels;   // k_raygen: 0 = chunks dealt evenly (chunk c -> sub-queue c mod nblocks); L > 0 = tapered deal with L weight classes (taper_row_width below)
 };
 

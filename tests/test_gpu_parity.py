@@ -763,6 +763,29 @@ def test_octant_sorted_fetch_changes_nothing(rt):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("spp", [1, 4, 6, 16, 24])
+def test_sample_interleaved_queue_order_changes_nothing(rt, spp):
+    """RTX_OPT_SAMPLE_INTERLEAVE (default on): k_raygen fills a chunk of 256 queue entries with 256 / S pixel slots x S consecutive samples (S = the largest power of two <= 16
+    dividing the batch's sample count: 1, 4, 2, 16, 8 here) instead of 256 slots of one sample.  Which path sits where changes no path and no sum: same bits and ray counts as
+    the one-sample chunks, whole frame and a 2-of-3 shard, and with a batch cap that splits the frame into batches of another sample count."""
+    import hashlib
+    sc = rt.Scene.sponza_class(30000, 260)
+    W, H = 256, 144
+
+    def run(c, **kw):
+        p = rt.Params(width=W, height=H, spp=spp, max_bounces=6, nee_samples=1, rr_start=3, sample_base=2, flags=3, frame_seed=5, **kw)
+        c.clear(W, H); c.render(p); st = c.stats()
+        return (st.rays_primary, st.rays_extension, st.rays_shadow), hashlib.sha1(c.read_accum().tobytes()).hexdigest()
+    c = rt.Context(0); c.upload(sc, W / H)
+    on = run(c), run(c, shard_rank=1, shard_count=3, tile_size=16)
+    c.set_option(rt.OPT_SAMPLE_INTERLEAVE, 0)
+    off = run(c), run(c, shard_rank=1, shard_count=3, tile_size=16)
+    assert on == off
+    c.set_option(rt.OPT_SAMPLE_INTERLEAVE, 1); c.set_option(rt.OPT_PATHS_PER_BATCH, 5 * W * H)      # batches of 5 (and the rest) samples: S = 1 / 4 / ...
+    assert run(c) == off[0]
+    c.close()
+
+
 def test_trace_counters_report_work_per_ray_and_change_nothing(rt):
     """RTX_OPT_TRACE_COUNTERS (bench.py: extra.*.work_per_ray): the persistent traversal kernels tally node steps and triangle tests; same image and ray counts with the
     counters on, and per closest-hit ray the tally lies within a few per cent of the one-ray-per-thread statistics kernel's (rtx_debug_trace_stats on the frame's own primary
