@@ -48,6 +48,7 @@ struct rtx_ctx {
     // RTX_OPT_ASYNC: what finish_render needs of the frame that rtx_render enqueued
     struct Pending { bool active = false; size_t ncnt = 0; uint32_t nbatches = 0, G = 0, mb = 0, nee = 0, nee1 = 1; bool fused = false, fused_bvh = false; } pending;
     bool async = false;
+    int node_stride = 80; DevBuf d_nodes_wide;        // RTX_OPT_NODE_STRIDE
     int sample_interleave = 1;                       // RTX_OPT_SAMPLE_INTERLEAVE
     int octant_sort = 0; DevBuf d_oct[2], d_perm;    // RTX_OPT_OCTANT_SORT (2 = tooling: all keys zero, i.e. the machinery's overhead without a re-ordering)
     bool trace_counters = false; DevBuf d_trace_cnt;      // RTX_OPT_TRACE_COUNTERS
@@ -165,6 +166,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_KERNEL_TIMING: c->timing = value != 0; return RTX_OK;
     case RTX_OPT_ASYNC: c->async = value != 0; return RTX_OK;
     case RTX_OPT_OCTANT_SORT: c->octant_sort = (int)value; return RTX_OK;
+    case RTX_OPT_NODE_STRIDE: if (value != 80 && value != 128) { c->err = "node stride must be 80 or 128"; return RTX_ERR_INVALID; } if (c->node_stride != (int)value) { c->node_stride = (int)value; c->committed = false; } return RTX_OK;
     case RTX_OPT_SAMPLE_INTERLEAVE: c->sample_interleave = value != 0; return RTX_OK;
     case RTX_OPT_TRACE_COUNTERS:
         c->trace_counters = value != 0;
@@ -313,6 +315,12 @@ static int finalise_scene(rtx_ctx* c) {
     c->device_scene_valid = true;
     DevScene& s = c->dsc;
     s.nodes = (const Node8GPU*)c->d_nodes.p; s.nnodes = (uint32_t)B.nodes8.size();
+    s.nodes_f = (const F4*)c->d_nodes.p; s.node_v4 = 5u;
+    if (c->node_stride == 128 && s.nnodes) {                  // one node per 128-B line: a copy at the wider stride, refreshed after every build / refit (stream order: before any frame)
+        HIPCHK(c, c->d_nodes_wide.ensure((size_t)s.nnodes * 128));
+        HIPCHK(c, hipMemcpy2DAsync(c->d_nodes_wide.p, 128, c->d_nodes.p, sizeof(Node8GPU), sizeof(Node8GPU), s.nnodes, hipMemcpyDeviceToDevice, c->stream));
+        s.nodes_f = (const F4*)c->d_nodes_wide.p; s.node_v4 = 8u;
+    }
     s.tris = (const TriGPU*)c->d_tris.p; s.ntris = (uint32_t)B.tris8.size();
     s.shade = (const TriShade*)c->d_shade.p;
     s.small = (const SmallRecPair*)c->d_small.p; s.small_tris = (const TriGPU*)c->d_small_tris.p; s.small_poly = (const F4*)c->d_small_poly.p; s.small_cm = B.small_cm; s.small_delta = B.small_delta;

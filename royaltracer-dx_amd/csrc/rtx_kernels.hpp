@@ -8,6 +8,7 @@ namespace rtx {
 // read-only scene in HBM
 struct DevScene {
     const Node8GPU* nodes;  uint32_t nnodes;
+    const F4* nodes_f; uint32_t node_v4;      // what the traversal fetches: the same nodes at a stride of node_v4 x 16 B (5: `nodes` itself; 8 = RTX_OPT_NODE_STRIDE 128: one node per 128-B line)
     const TriGPU*   tris;   uint32_t ntris;
     const TriShade* shade;
     const SmallRecPair* small; uint32_t nsmall;   // nsmall != 0: tiny scene: nsmall pre-test records (planar polygons), no BVH

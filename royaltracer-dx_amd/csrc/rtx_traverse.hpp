@@ -136,7 +136,7 @@ constexpr float kSlabK = 1.00010002f;                 // >= kSlabHi / kSlabLo (1
 __device__ __forceinline__ Node8R load_node8(const DevScene& sc, const TraceLds& L, uint32_t idx) {
     Node8R N;
     if (idx < sc.lds_nodes) { const lds_v4f* n = L.nodes + idx * 5u; N.h0 = n[0]; N.h1 = (v4u)n[1]; N.q0 = (v4u)n[2]; N.q1 = (v4u)n[3]; N.q2 = (v4u)n[4]; }
-    else { const v4f* n = (const v4f*)sc.nodes + (size_t)idx * 5u; N.h0 = n[0]; N.h1 = (v4u)n[1]; N.q0 = (v4u)n[2]; N.q1 = (v4u)n[3]; N.q2 = (v4u)n[4]; }
+    else { const v4f* n = (const v4f*)sc.nodes_f + (size_t)idx * sc.node_v4; N.h0 = n[0]; N.h1 = (v4u)n[1]; N.q0 = (v4u)n[2]; N.q1 = (v4u)n[3]; N.q2 = (v4u)n[4]; }
     return N;
 }
 __device__ __forceinline__ uint32_t ray_octant(f3 idir) { return (idir.x < 0.0f ? 1u : 0u) | (idir.y < 0.0f ? 2u : 0u) | (idir.z < 0.0f ? 4u : 0u); }

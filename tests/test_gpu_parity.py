@@ -786,6 +786,28 @@ def test_sample_interleaved_queue_order_changes_nothing(rt, spp):
     c.close()
 
 
+def test_node_stride_128_changes_nothing_also_after_a_refit(rt, golden_dir):
+    """RTX_OPT_NODE_STRIDE 128 (knob: profiles/r04_node_stride_ab.md): the traversal fetches the nodes from a copy with one node per 128-B line; the copy is refreshed after a
+    build and after every refit.  Same hit records, image and ray counts as the 80-B stride, before and after moving an instance."""
+    import os
+    sc = rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")
+    W, H = 160, 96
+    p = rt.Params(width=W, height=H, spp=4, max_bounces=5, nee_samples=1, flags=3, frame_seed=11)
+    rays = random_rays(30000, 77, -4, 4)
+    m = np.eye(4, dtype=np.float32); m[0, 0] = np.cos(1.9); m[0, 2] = -np.sin(1.9); m[2, 0] = np.sin(1.9); m[2, 2] = np.cos(1.9); m[3, 1] = 0.1
+    out = []
+    for stride in (80, 128):
+        c = rt.Context(0); c.set_option(rt.OPT_NODE_STRIDE, stride); c.upload(sc, W / H)
+        got = []
+        for step in range(2):
+            if step: c.set_instance_transform(1, m.reshape(16)); c.commit(); assert c.stats().bvh_refits == 1
+            c.clear(W, H); c.render(p); st = c.stats()
+            got.append((bits(c.trace_closest(rays)).tobytes(), c.trace_any(rays).tobytes(), c.read_accum().tobytes(), (st.rays_primary, st.rays_extension, st.rays_shadow)))
+        assert got[0][2] != got[1][2]
+        out.append(got); c.close()
+    assert out[0] == out[1]
+
+
 def test_trace_counters_report_work_per_ray_and_change_nothing(rt):
     """RTX_OPT_TRACE_COUNTERS (bench.py: extra.*.work_per_ray): the persistent traversal kernels tally node steps and triangle tests; same image and ray counts with the
     counters on, and per closest-hit ray the tally lies within a few per cent of the one-ray-per-thread statistics kernel's (rtx_debug_trace_stats on the frame's own primary
