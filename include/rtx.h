@@ -135,9 +135,10 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
        RTX_OPT_OCTANT_SORT = 32,     /* 1: general scenes, compact state: the closest-hit kernel of bounce b >= 1 fetches the rays of its sub-queue grouped by direction octant (k_shade notes a survivor's
                                         octant, a prologue of the traversal kernel counting-sorts the sub-queue's entries by it).  3: the key is the cell of the ray's ORIGIN on a 256-cell grid over the scene's box, from bounce 2.
                                         2 and 5 are measurement variants (all keys zero; hashed keys).  Never changes a result; MEASURED slower in every form: profiles/r04_octsort_ab.md.  Default 0 */
-       RTX_OPT_NODE_STRIDE = 34,     /* 80 (default) or 128: bytes from one BVH node to the next in HBM as the traversal fetches them (128: a copy with one node per cache line, refreshed after every
-                                        build / refit).  MEASURED (profiles/r04_node_stride_ab.md): incoherent path-tracing rays on the 3.8 M-triangle street -2.4 % of k_trace_closest, nothing on the
-                                        atrium, ReSTIR frames +0.5-1.5 % (coherent rays like the dense packing).  Takes effect with the next rtx_commit_scene */
+       RTX_OPT_NODE_STRIDE = 34,     /* how the traversal finds a BVH node in HBM.  80: the nodes as built, 80 B apart.  128: a copy with one node per 128-B cache line (no node straddles a line), refreshed
+                                        after every build / refit.  0 (default) = auto: the copy is made for trees above 16 MB and fetched by the path tracer's closest-hit launches of bounces >= 1
+                                        only (street scene, 3.8 M triangles: k_trace_closest -2.4 %; coherent rays and small trees prefer the dense layout: profiles/r04_node_stride_ab.md).
+                                        Never changes a result.  Takes effect with the next rtx_commit_scene */
        RTX_OPT_SAMPLE_INTERLEAVE = 33, /* general scenes (k_raygen): which path sits where in the sub-queues.  0: a chunk of 256 queue entries is 256 pixel slots of ONE sample; 1 (default): 256 / S pixel
                                         slots x S consecutive samples with a pixel's samples in neighbouring lanes, S = the largest power of two <= 16 dividing the batch's sample count: the rays
                                         of a wave start closer together at every bounce (C5 k_trace_closest 18.4 -> 17.5 ms, C3 20.6 -> 20.1: profiles/r04_interleave_ab.md).

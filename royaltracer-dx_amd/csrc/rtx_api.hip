@@ -48,7 +48,7 @@ struct rtx_ctx {
     // RTX_OPT_ASYNC: what finish_render needs of the frame that rtx_render enqueued
     struct Pending { bool active = false; size_t ncnt = 0; uint32_t nbatches = 0, G = 0, mb = 0, nee = 0, nee1 = 1; bool fused = false, fused_bvh = false; } pending;
     bool async = false;
-    int node_stride = 80; DevBuf d_nodes_wide;        // RTX_OPT_NODE_STRIDE
+    int node_stride = 0; DevBuf d_nodes_wide; bool wide_nodes = false;        // RTX_OPT_NODE_STRIDE
     int sample_interleave = 1;                       // RTX_OPT_SAMPLE_INTERLEAVE
     int octant_sort = 0; DevBuf d_oct[2], d_perm;    // RTX_OPT_OCTANT_SORT (2 = tooling: all keys zero, i.e. the machinery's overhead without a re-ordering)
     bool trace_counters = false; DevBuf d_trace_cnt;      // RTX_OPT_TRACE_COUNTERS
@@ -166,7 +166,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_KERNEL_TIMING: c->timing = value != 0; return RTX_OK;
     case RTX_OPT_ASYNC: c->async = value != 0; return RTX_OK;
     case RTX_OPT_OCTANT_SORT: c->octant_sort = (int)value; return RTX_OK;
-    case RTX_OPT_NODE_STRIDE: if (value != 80 && value != 128) { c->err = "node stride must be 80 or 128"; return RTX_ERR_INVALID; } if (c->node_stride != (int)value) { c->node_stride = (int)value; c->committed = false; } return RTX_OK;
+    case RTX_OPT_NODE_STRIDE: if (value != 0 && value != 80 && value != 128) { c->err = "node stride must be 0 (auto), 80 or 128"; return RTX_ERR_INVALID; } if (c->node_stride != (int)value) { c->node_stride = (int)value; c->committed = false; } return RTX_OK;
     case RTX_OPT_SAMPLE_INTERLEAVE: c->sample_interleave = value != 0; return RTX_OK;
     case RTX_OPT_TRACE_COUNTERS:
         c->trace_counters = value != 0;
@@ -316,10 +316,15 @@ static int finalise_scene(rtx_ctx* c) {
     DevScene& s = c->dsc;
     s.nodes = (const Node8GPU*)c->d_nodes.p; s.nnodes = (uint32_t)B.nodes8.size();
     s.nodes_f = (const F4*)c->d_nodes.p; s.node_v4 = 5u;
-    if (c->node_stride == 128 && s.nnodes) {                  // one node per 128-B line: a copy at the wider stride, refreshed after every build / refit (stream order: before any frame)
+    // RTX_OPT_NODE_STRIDE: a second copy of the nodes with ONE node per 128-B line (80-B nodes at an 80-B stride straddle a line in 4 of 8 positions: 1.5 lines per visit),
+    // refreshed after every build / refit (stream order: before any frame).  Auto: made for trees of more than 16 MB, and fetched by the path tracer's closest-hit launches of
+    // bounces >= 1 only — incoherent rays on a tree far larger than L2 gain (street scene, 3.8 M triangles: k_trace_closest -2.4 %), coherent ones (camera rays, ReSTIR's
+    // stages) and the any-hit kernel like neighbours sharing lines (+1 %), small trees do not care (profiles/r04_node_stride_ab.md).  128: every traversal fetches the wide copy.
+    c->wide_nodes = s.nnodes && (c->node_stride == 128 || (c->node_stride == 0 && (size_t)s.nnodes * sizeof(Node8GPU) > ((size_t)16 << 20)));
+    if (c->wide_nodes) {
         HIPCHK(c, c->d_nodes_wide.ensure((size_t)s.nnodes * 128));
         HIPCHK(c, hipMemcpy2DAsync(c->d_nodes_wide.p, 128, c->d_nodes.p, sizeof(Node8GPU), sizeof(Node8GPU), s.nnodes, hipMemcpyDeviceToDevice, c->stream));
-        s.nodes_f = (const F4*)c->d_nodes_wide.p; s.node_v4 = 8u;
+        if (c->node_stride == 128) { s.nodes_f = (const F4*)c->d_nodes_wide.p; s.node_v4 = 8u; }
     }
     s.tris = (const TriGPU*)c->d_tris.p; s.ntris = (uint32_t)B.tris8.size();
     s.shade = (const TriShade*)c->d_shade.p;
@@ -664,7 +669,9 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
                     if (b >= (c->octant_sort == 3 ? 2u : 1u)) { Pb.oct_in = (const uint8_t*)c->d_oct[b & 1].p; Pb.perm = (uint32_t*)c->d_perm.p; }     // (origin cells: bounce 1 starts at the camera rays' hits, already in image order)
                 }
             }
-            { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, fb, c->dsc, Pb, b, q, Q(b), Hd(b, 0), merge_for(b < c->pred_q.size() ? c->pred_q[b] : 0, b < c->pred_q.size())); }
+            DevScene scb = c->dsc;
+            if (c->wide_nodes && b >= 1u) { scb.nodes_f = (const F4*)c->d_nodes_wide.p; scb.node_v4 = 8u; }
+            { Timed t(c, RTX_K_TRACE); launch_trace_closest(st, fb, scb, Pb, b, q, Q(b), Hd(b, 0), merge_for(b < c->pred_q.size() ? c->pred_q[b] : 0, b < c->pred_q.size())); }
             if (ovl && ev_shadow_done) HIPCHK(c, hipStreamWaitEvent(st, ev_shadow_done, 0));      // shade(b) overwrites the shadow entries and touches rad: after shadow(b - 1)
             { Timed t(c, RTX_K_SHADE); launch_shade(st, c->dsc, fb, Pb, b, q, Q(b), qn, Q(b + 1), S(b, 0)); }
             hipStream_t ss = st;

@@ -787,8 +787,9 @@ def test_sample_interleaved_queue_order_changes_nothing(rt, spp):
 
 
 def test_node_stride_128_changes_nothing_also_after_a_refit(rt, golden_dir):
-    """RTX_OPT_NODE_STRIDE 128 (knob: profiles/r04_node_stride_ab.md): the traversal fetches the nodes from a copy with one node per 128-B line; the copy is refreshed after a
-    build and after every refit.  Same hit records, image and ray counts as the 80-B stride, before and after moving an instance."""
+    """RTX_OPT_NODE_STRIDE 128 (profiles/r04_node_stride_ab.md): the traversal fetches the nodes from a copy with one node per 128-B line; the copy is refreshed after a
+    build and after every refit.  Same hit records, image and ray counts as the 80-B stride, before and after moving an instance.  (Auto, the default, makes the copy for
+    trees above 16 MB and hands it to the path tracer's closest-hit launches of bounces >= 1: the street scene of test_full_size_baseline_configs_are_bit_identical.)"""
     import os
     sc = rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")
     W, H = 160, 96
