@@ -440,7 +440,7 @@ class Context:
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and lib is not None:          # (at interpreter shutdown the module globals may already be gone: the process's exit frees the context)
             lib.rtx_destroy(h)
 
     __del__ = close
