@@ -49,6 +49,7 @@ struct rtx_ctx {
     struct Pending { bool active = false; size_t ncnt = 0; uint32_t nbatches = 0, G = 0, mb = 0, nee = 0, nee1 = 1; bool fused = false, fused_bvh = false; } pending;
     bool async = false;
     int node_stride = 0; DevBuf d_nodes_wide; bool wide_nodes = false;        // RTX_OPT_NODE_STRIDE
+    int restir_keys = 1; DevBuf d_rs_key_a, d_rs_key_b;  // RTX_OPT_RESTIR_KEYS
     int sample_interleave = 1;                       // RTX_OPT_SAMPLE_INTERLEAVE
     int octant_sort = 0; DevBuf d_oct[2], d_perm;    // RTX_OPT_OCTANT_SORT (2 = tooling: all keys zero, i.e. the machinery's overhead without a re-ordering)
     bool trace_counters = false; DevBuf d_trace_cnt;      // RTX_OPT_TRACE_COUNTERS
@@ -167,6 +168,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_ASYNC: c->async = value != 0; return RTX_OK;
     case RTX_OPT_OCTANT_SORT: c->octant_sort = (int)value; return RTX_OK;
     case RTX_OPT_NODE_STRIDE: if (value != 0 && value != 80 && value != 128) { c->err = "node stride must be 0 (auto), 80 or 128"; return RTX_ERR_INVALID; } if (c->node_stride != (int)value) { c->node_stride = (int)value; c->committed = false; } return RTX_OK;
+    case RTX_OPT_RESTIR_KEYS: c->restir_keys = value != 0; return RTX_OK;
     case RTX_OPT_SAMPLE_INTERLEAVE: c->sample_interleave = value != 0; return RTX_OK;
     case RTX_OPT_TRACE_COUNTERS:
         c->trace_counters = value != 0;
@@ -798,13 +800,14 @@ static int rs_pass1(rtx_ctx* c, const DevFrame& f, uint32_t sample_id, F4* accum
     { Timed t(c, RTX_K_SHADE, st); launch_rs_p1_emit_final(st, sc, R.fq, q, cam, bufs, shrow); }
     { Timed t(c, RTX_K_SHADOW, st); launch_trace_occ(st, sc, q, shrow); }                                                        // DI visibility, the selected reconnection, the temporal pass's two rays
     { Timed t(c, RTX_K_SHADE, st); launch_rs_p1_finish(st, sc, R.fq, q, accum, res_di, res_gi, sdata, cam, bufs); }
+    if (bufs && c->restir_keys) { Timed t(c, RTX_K_SHADE, st); launch_rs_p3_keys(st, R.fq, q, bufs, (F4*)c->d_rs_key_a.p, (F4*)c->d_rs_key_b.p); }      // what the spatial pass's neighbour tests read
     HIPCHK(c, hipGetLastError());
     return RTX_OK;
 }
 static int rs_pass3(rtx_ctx* c, const DevFrame& f, uint32_t* const bufs[6], F4* accum, const uint32_t* pixels, uint32_t npixels, uint32_t lane, hipStream_t st) {
     RsPlan R; int r = rs_plan(c, f, pixels ? npixels : f.npl, pixels, 2, R, lane); if (r) return r;
     const CameraGPU* cam = (const CameraGPU*)c->d_cam.p;
-    { Timed t(c, RTX_K_SHADE, st); launch_rs_p3_select(st, c->dsc, R.fq, R.q, cam, bufs, R.cnt); }
+    { Timed t(c, RTX_K_SHADE, st); launch_rs_p3_select(st, c->dsc, R.fq, R.q, cam, bufs, R.cnt, c->restir_keys ? (F4*)c->d_rs_key_a.p : nullptr, c->restir_keys ? (F4*)c->d_rs_key_b.p : nullptr); }
     { Timed t(c, RTX_K_SHADOW, st); launch_trace_occ(st, c->dsc, R.q, R.cnt); }
     { Timed t(c, RTX_K_SHADE, st); launch_rs_p3_merge(st, c->dsc, R.fq, R.q, bufs, R.cnt + R.G); }
     { Timed t(c, RTX_K_SHADOW, st); launch_trace_occ(st, c->dsc, R.q, R.cnt + R.G); }
@@ -963,6 +966,7 @@ int rtx_render_restir(rtx_ctx* c, const rtx_params* p) {
     const size_t slots = rtx_pass1_slots(p->width, p->height);
     if ((r = p1_alloc(c, slots))) return r;
     HIPCHK(c, c->d_last_di.ensure(slots * 40)); HIPCHK(c, c->d_last_gi.ensure(slots * 40)); HIPCHK(c, c->d_last_sd.ensure(slots * 60));
+    if (c->restir_wave && c->restir_keys) { HIPCHK(c, c->d_rs_key_a.ensure(slots * 32)); HIPCHK(c, c->d_rs_key_b.ensure(slots * 32)); }
     if (c->last_slots != slots) {
         HIPCHK(c, hipMemsetAsync(c->d_last_di.p, 0, slots * 40, c->stream)); HIPCHK(c, hipMemsetAsync(c->d_last_gi.p, 0, slots * 40, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_last_sd.p, 0, slots * 60, c->stream));

@@ -1274,7 +1274,11 @@ void launch_rs_p1_finish(hipStream_t st, const DevScene& sc, const DevFrame& f, 
     if (bufs) hipLaunchKernelGGL((k_rs_p1_finish<false, true>), dim3(q.G), dim3(kBlock), 0, st, sc, f, q, accum, res_di, res_gi, sdata, cam, rs_bufs(bufs), 1u);
 #endif
 }
-void launch_rs_p3_select(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, const CameraGPU* cam, uint32_t* const bufs[6], uint32_t* shcnt) {
+void launch_rs_p3_keys(hipStream_t st, const DevFrame& f, const RsQ& q, uint32_t* const bufs[6], F4* key_a, F4* key_b) {
+    hipLaunchKernelGGL(k_rs_p3_keys, dim3(q.G), dim3(kBlock), 0, st, f, q, rs_bufs(bufs), RsKeys{key_a, key_b});
+}
+void launch_rs_p3_select(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, const CameraGPU* cam, uint32_t* const bufs[6], uint32_t* shcnt, F4* key_a, F4* key_b) {
+    if (key_a) { hipLaunchKernelGGL(k_rs_p3_select_keys, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, cam, rs_bufs(bufs), RsKeys{key_a, key_b}, shcnt); return; }
     hipLaunchKernelGGL(k_rs_p3_select, dim3(q.G), dim3(kBlock), 0, st, sc, f, q, cam, rs_bufs(bufs), shcnt);
 }
 void launch_rs_p3_merge(hipStream_t st, const DevScene& sc, const DevFrame& f, const RsQ& q, uint32_t* const bufs[6], uint32_t* shcnt) {

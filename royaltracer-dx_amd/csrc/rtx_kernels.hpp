@@ -168,7 +168,8 @@ void launch_rs_p1_loop(hipStream_t, const DevScene&, const DevFrame&, const RsQ&
 // bufs != nullptr: a ReSTIR frame — the temporal pass (pass 2) of a pixel rides on these two stages (its rays join pass 1's shadow rays, its merge follows the pixel's finish)
 void launch_rs_p1_emit_final(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, const CameraGPU* cam, uint32_t* const* bufs, uint32_t* shcnt);
 void launch_rs_p1_finish(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, F4* accum, uint32_t* res_di, uint32_t* res_gi, uint32_t* sdata, const CameraGPU* cam, uint32_t* const* bufs);
-void launch_rs_p3_select(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, const CameraGPU* cam, uint32_t* const bufs[6], uint32_t* shcnt);
+void launch_rs_p3_keys(hipStream_t, const DevFrame&, const RsQ&, uint32_t* const bufs[6], F4* key_a, F4* key_b);      // the compact neighbour records of the spatial pass (rtx_restir_wave.hpp), written after passes 1 + 2
+void launch_rs_p3_select(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, const CameraGPU* cam, uint32_t* const bufs[6], uint32_t* shcnt, F4* key_a = nullptr, F4* key_b = nullptr);   // key_a != nullptr: select on the records
 void launch_rs_p3_merge(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, uint32_t* const bufs[6], uint32_t* shcnt);
 void launch_rs_p3_shade(hipStream_t, const DevScene&, const DevFrame&, const RsQ&, uint32_t* const bufs[6], F4* accum);
 void launch_accumulate(hipStream_t, uint32_t max_blocks, const DevFrame&, const DevPaths&, F4* accum);

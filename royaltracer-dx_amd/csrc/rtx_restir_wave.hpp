@@ -423,6 +423,97 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p3_select(DevScene sc, DevFram
     }
     rs_publish(nullptr, nullptr, shcnt, &s_rn, q, 1);
 }
+// ---- (round 4) compact neighbour records of the spatial pass -------------------------------------------------------------------------------------------------
+// p3_select tests up to 9 + 9 random neighbours per pixel; a test reads 13 of the 25 dwords of the neighbour's sample record (60 B) and DI / GI reservoir (40 B) — three to five
+// 64-B sectors of scattered traffic per attempt (2.2 x what it needs: profiles/r03_pmc_restir.md).  After passes 1 + 2 every pixel of the list writes what a neighbour's
+// test needs into two 32-B records (one sector each): A = x1, n1, material id | "L1 is zero" | DI reservoir valid | DI M; B = the GI reservoir's x2, n2, w_sum, M.  The
+// flags are evaluated with the literal expressions (length(L1) == 0, valid_res_dev), the floats are copies: the keyed selection returns the same candidates, bit for bit.
+struct RsKeys { F4* a; F4* b; };                   // [2 * slot], [2 * slot + 1]; slot = map_pixel_id
+__global__ __launch_bounds__(kBlock) void k_rs_p3_keys(DevFrame f, RsQ q, RestirBufs B, RsKeys Ky) {
+    const uint32_t nchunks = (q.nitems + kBlock - 1) / kBlock;
+    for (uint32_t c = rs_wg(q); c < nchunks; c += gridDim.x) {
+        const uint32_t it = c * kBlock + threadIdx.x;
+        uint32_t x, y;
+        if (!(it < q.nitems) || !rs_item_pixel(f, q, it, x, y)) continue;
+        const size_t slot = map_pixel_id(f.width, x, y);
+        const SData sn = load_sd_dev(B.cur_sd + slot * 15); const Res rn = load_res_dev(B.cur_di + slot * 10), gn = load_res_dev(B.cur_gi + slot * 10);
+        const uint32_t meta = sn.mID | (length(sn.L1) == 0.0f ? 1u << 16 : 0u);
+        const uint32_t di = (rn.M & 0x7FFFFFFFu) | (valid_res_dev(rn) ? 1u << 31 : 0u);
+        Ky.a[2 * slot] = {sn.x1.x, sn.x1.y, sn.x1.z, sn.n1.x}; Ky.a[2 * slot + 1] = {sn.n1.y, sn.n1.z, u2f(meta), u2f(di)};
+        Ky.b[2 * slot] = {gn.x2.x, gn.x2.y, gn.x2.z, gn.n2.x}; Ky.b[2 * slot + 1] = {gn.n2.y, gn.n2.z, gn.w_sum, u2f(gn.M)};
+    }
+}
+// p3_select (rtx_restir.hpp) on the records: same draws, same tests in the same arithmetic, same candidates
+__device__ __forceinline__ void p3_select_keys(const DevFrame& f, const RsKeys& Ky, f3 camo, uint32_t x, uint32_t y, const SData& sd, const MatGPU& m,
+                                               const Res& rcur, const Res& gcur, uint32_t& s0, uint32_t& s1, P3Cand& K) {
+    const uint32_t W = f.width, H = f.height;
+    K.n_di = 0; K.n_gi = 0;
+    K.M_sum_DI = minf_u(128.0f, rcur.M); K.M_sum_GI = minf_u(128.0f, gcur.M);
+    for (int a = 0; a < 9 && K.n_di < 3; a++) {
+        int nx, ny; random_pixel_dev(20u, W, H, x, y, s0, s1, nx, ny);
+        const size_t pr = map_pixel_id(W, (uint32_t)nx, (uint32_t)ny);
+        const F4 a0 = Ky.a[2 * pr], a1 = Ky.a[2 * pr + 1];
+        const f3 nx1 = mk3(a0.x, a0.y, a0.z), nn1 = mk3(a0.w, a1.x, a1.y);
+        const uint32_t meta = f2u(a1.z), di = f2u(a1.w);
+        const bool ok = !(dot(sd.n1, nn1) < 0.9f) && !reject_distance_dev(sd.x1, nx1, camo, 0.1f) && (di >> 31) != 0u && (meta & 0x10000u) != 0u && (meta & 0xFFFFu) == sd.mID;
+        if (ok) { K.di[K.n_di++] = (uint32_t)pr; K.M_sum_DI += minf_u(128.0f, di & 0x7FFFFFFFu); }
+    }
+    for (int a = 0; a < 9 && K.n_gi < 3; a++) {
+        int nx, ny; random_pixel_dev(20u, W, H, x, y, s0, s1, nx, ny);
+        const size_t pr = map_pixel_id(W, (uint32_t)nx, (uint32_t)ny);
+        const F4 a0 = Ky.a[2 * pr], a1 = Ky.a[2 * pr + 1], b0 = Ky.b[2 * pr], b1 = Ky.b[2 * pr + 1];
+        SData sn = zero_sd(); sn.x1 = mk3(a0.x, a0.y, a0.z);                   // (jacobian_dev reads x1 only)
+        const uint32_t meta = f2u(a1.z);
+        Res gn = zero_res(); gn.x2 = mk3(b0.x, b0.y, b0.z); gn.n2 = mk3(b0.w, b1.x, b1.y); gn.w_sum = b1.z; gn.M = f2u(b1.w);
+        const bool ok = m.Pr > 0.3f && !reject_distance_dev(sd.x1, sn.x1, camo, 0.1f) && !(dot(normalize(gn.x2 - sd.x1), sd.n1) < 0.0f) &&
+                        !(gn.w_sum > 5.0f) && valid_res_gi_dev(gn) && !reject_jacobian_dev(jacobian_dev(sn, sd, gn.x2, gn.n2), 5.0f) &&
+                        (meta & 0x10000u) != 0u && (meta & 0xFFFFu) == sd.mID;
+        if (ok) { K.gi[K.n_gi++] = (uint32_t)pr; K.M_sum_GI += minf_u(128.0f, gn.M); }
+    }
+}
+__global__ __launch_bounds__(kBlock, 4) void k_rs_p3_select_keys(DevScene sc, DevFrame f, RsQ q, const CameraGPU* __restrict__ cam_p, RestirBufs B, RsKeys Ky, uint32_t* __restrict__ shcnt) {
+    __shared__ uint32_t s_rn;
+    if (threadIdx.x == 0) s_rn = 0;
+    __syncthreads();
+    const f3 camo = mk3(cam_p->viewI[12], cam_p->viewI[13], cam_p->viewI[14]);
+    const uint32_t nchunks = (q.nitems + kBlock - 1) / kBlock;
+    for (uint32_t c = rs_wg(q); c < nchunks; c += gridDim.x) {
+        const uint32_t it = c * kBlock + threadIdx.x;
+        uint32_t x = 0, y = 0;
+        bool run = it < q.nitems && rs_item_pixel(f, q, it, x, y);
+        SData sd = zero_sd(); Res rcur = zero_res(), gcur = zero_res();
+        P3Cand K; K.n_di = 0; K.n_gi = 0; K.M_sum_DI = 0.0f; K.M_sum_GI = 0.0f;
+        for (int k = 0; k < 3; k++) { K.di[k] = 0xFFFFFFFFu; K.gi[k] = 0xFFFFFFFFu; }
+        if (run) {
+            const size_t slot = map_pixel_id(f.width, x, y);
+            sd = load_sd_dev(B.cur_sd + slot * 15);
+            run = p3_samples(sc, sd);
+            if (run) {
+                uint32_t s0, s1; seed_init(x, y, 3u, f.frame_seed, s0, s1);
+                rcur = load_res_dev(B.cur_di + slot * 10); gcur = load_res_dev(B.cur_gi + slot * 10);
+                p3_select_keys(f, Ky, camo, x, y, sd, sc.mats[sd.mID], rcur, gcur, s0, s1, K);
+                uint32_t* rec = q.cand + (size_t)it * kRsCand;
+                for (int k = 0; k < 3; k++) { rec[k] = k < K.n_di ? K.di[k] : 0xFFFFFFFFu; rec[3 + k] = k < K.n_gi ? K.gi[k] : 0xFFFFFFFFu; }
+                rec[6] = s0; rec[7] = s1; rec[8] = f2u(K.M_sum_DI); rec[9] = f2u(K.M_sum_GI);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) {                                   // every lane takes part in every push (convergent compaction)
+            const int j = k % 3;
+            const bool on = run && (k < 3 ? j < K.n_di : j < K.n_gi);
+            F4 so = {0, 0, 0, 0}, sdv = {0, 0, 1, 0};
+            if (on) {
+                if (k < 6) {
+                    const size_t pr = k < 3 ? K.di[j] : K.gi[j];
+                    const F4 a0 = Ky.a[2 * pr], a1 = Ky.a[2 * pr + 1];
+                    vis_ray(mk3(a0.x, a0.y, a0.z), mk3(a0.w, a1.x, a1.y), k < 3 ? rcur.x2 : gcur.x2, so, sdv);
+                } else { const F4 b0 = Ky.b[2 * (size_t)K.gi[j]]; vis_ray(sd.x1, sd.n1, mk3(b0.x, b0.y, b0.z), so, sdv); }
+            }
+            rs_push_ray(q, &s_rn, on, so, sdv, it * kRsOcc + (uint32_t)k);
+        }
+    }
+    rs_publish(nullptr, nullptr, shcnt, &s_rn, q, 1);
+}
 // GI = false: the DI merge (+ the ray of the selected DI sample); GI = true: the GI merge, whose random numbers continue behind the n_di the DI merge drew.  Two launches
 // of half the register pressure each: as one kernel the merge needed 128 VGPRs with 51 of them spilled (148 B of scratch per lane).
 template <bool GI>
