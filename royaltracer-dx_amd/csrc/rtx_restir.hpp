@@ -428,8 +428,8 @@ __device__ __forceinline__ float p_hat_di(uint32_t flags, const MatGPU& m, f3 x1
     if (k >= 0) v = vis(k, x1, n1, x2);
     return f_g * v;
 }
-template <class V>
-__device__ __forceinline__ f3 p_hat_gi(uint32_t flags, const MatGPU& m, f3 x1, f3 n1, f3 x2, f3 L, f3 o, int k, V&& vis) {
+// the GI target function without its visibility factor (lobes, cosine, radiance; non-finite -> 0)
+__device__ __forceinline__ f3 p_hat_gi_fr(uint32_t flags, const MatGPU& m, f3 x1, f3 n1, f3 x2, f3 L, f3 o) {
     const f3 dir = x2 - x1;
     const float cos1 = fabsf(dot(n1, normalize(dir)));
     f3 f0, f1; float q0, q1, pd, ps;
@@ -437,6 +437,11 @@ __device__ __forceinline__ f3 p_hat_gi(uint32_t flags, const MatGPU& m, f3 x1, f
     const f3 Fx = safe_mul(pd, f0) + safe_mul(ps, f1);
     f3 fr = mk3(Fx.x * cos1 * L.x, Fx.y * cos1 * L.y, Fx.z * cos1 * L.z);
     if (!finite3(fr)) fr = mk3(0, 0, 0);
+    return fr;
+}
+template <class V>
+__device__ __forceinline__ f3 p_hat_gi(uint32_t flags, const MatGPU& m, f3 x1, f3 n1, f3 x2, f3 L, f3 o, int k, V&& vis) {
+    const f3 fr = p_hat_gi_fr(flags, m, x1, n1, x2, L, o);
     float v = 1.0f;
     if (k >= 0) v = vis(k, x1, n1, x2);
     return fr * v;
@@ -525,12 +530,16 @@ __device__ __forceinline__ void p2_merge(const DevScene& sc, const DevFrame& f, 
         float mi_t;
         { const float m_num = M_sum - mc, m_den = m_num + mc; mi_t = m_den > 0.0f ? (ml / M_sum) * m_num / m_den : 0.0f; }
         if (length(rl.n2) == 0.0f) { mi_c = 1.0f; mi_t = 0.0f; }
-        const float w_c = mi_c * p_hat_di(flags, m, sd.x1, sd.n1, rc.x2, rc.n2, rc.L2, sd.o, -1, vis) * rc.W;
-        const float w_t = mi_t * p_hat_di(flags, m, sd.x1, sd.n1, rl.x2, rl.n2, rl.L2, sd.o, 0, vis) * rl.W;
+        // (round 4) the target function of the sample that ends up selected was evaluated above — for the current sample as w_c's factor, for the temporal one as w_t's factor
+        // before its visibility: kept instead of evaluated a third time (same operands, same bits)
+        const float fg_c = length(reconnect_di_dev(m, flags, sd.x1, sd.n1, rc.x2, rc.n2, rc.L2, sd.o));
+        const float fg_t = length(reconnect_di_dev(m, flags, sd.x1, sd.n1, rl.x2, rl.n2, rl.L2, sd.o));
+        const float w_c = mi_c * (fg_c * 1.0f) * rc.W;
+        const float w_t = mi_t * (fg_t * vis(0, sd.x1, sd.n1, rl.x2)) * rl.W;
         rc.M = (uint32_t)mc; rc.w_sum = w_c;
         rc.w_sum += w_t; rc.M = (rc.M + (uint32_t)ml) & 0xFFFFu;
-        if (tea_next(s0, s1) < w_t / rc.w_sum) { rc.x2 = rl.x2; rc.n2 = rl.n2; rc.L2 = rl.L2; }
-        const float p_hat = p_hat_di(flags, m, sd.x1, sd.n1, rc.x2, rc.n2, rc.L2, sd.o, -1, vis);
+        float p_hat = fg_c;
+        if (tea_next(s0, s1) < w_t / rc.w_sum) { rc.x2 = rl.x2; rc.n2 = rl.n2; rc.L2 = rl.L2; p_hat = fg_t; }
         rc.W = get_w_dev(rc.w_sum, p_hat);
     }
     if (I.acc_gi) {
@@ -539,12 +548,15 @@ __device__ __forceinline__ void p2_merge(const DevScene& sc, const DevFrame& f, 
         { const float m_num = mc, m_den = m_num + (M_sum - mc); if (m_den > 0.0f) mi_c += (ml / M_sum) * (m_num / m_den); }
         float mi_t;
         { const float m_num = M_sum - mc, m_den = m_num + mc; mi_t = m_den > 0.0f ? (ml / M_sum) * m_num / m_den : 0.0f; }
-        const float w_c = mi_c * length(p_hat_gi(flags, m, sd.x1, sd.n1, gc.x2, gc.L2, sd.o, -1, vis)) * gc.W;
-        const float w_t = mi_t * length(p_hat_gi(flags, m, sd.x1, sd.n1, gl.x2, gl.L2, sd.o, 1, vis)) * gl.W;
+        const f3 fr_c = p_hat_gi_fr(flags, m, sd.x1, sd.n1, gc.x2, gc.L2, sd.o), fr_t = p_hat_gi_fr(flags, m, sd.x1, sd.n1, gl.x2, gl.L2, sd.o);
+        const float lf_c = length(fr_c * 1.0f);
+        const float w_c = mi_c * lf_c * gc.W;
+        const float w_t = mi_t * length(fr_t * vis(1, sd.x1, sd.n1, gl.x2)) * gl.W;
         gc.M = (uint32_t)mc; gc.w_sum = w_c;
         gc.w_sum += w_t; gc.M = (gc.M + (uint32_t)ml) & 0xFFFFu;
-        if (tea_next(s0, s1) < w_t / gc.w_sum) { gc.x2 = gl.x2; gc.n2 = gl.n2; gc.L2 = gl.L2; }
-        gc.W = get_w_dev(gc.w_sum, length(p_hat_gi(flags, m, sd.x1, sd.n1, gc.x2, gc.L2, sd.o, -1, vis)));
+        float p_hat = lf_c;
+        if (tea_next(s0, s1) < w_t / gc.w_sum) { gc.x2 = gl.x2; gc.n2 = gl.n2; gc.L2 = gl.L2; p_hat = length(fr_t * 1.0f); }
+        gc.W = get_w_dev(gc.w_sum, p_hat);
     }
     store_res(B.cur_di + I.slot * 10, rc); store_res(B.cur_gi + I.slot * 10, gc);
 }
@@ -608,21 +620,28 @@ __device__ __forceinline__ void p3_merge_di(const DevScene& sc, const DevFrame& 
     const int n_di = K.n_di;
     const Res can = rcur;
     const float cMmin = minf_u(128.0f, can.M), cMmax = M_sum_DI - cMmin;
+    // (round 4) every value below that the reference's text evaluates more than once from the same operands is evaluated ONCE and kept: the canonical sample's own target
+    // function (p_c: three more times in the text) and, per neighbour, the canonical sample's unshadowed contribution seen from it (f_g: once with the visibility factor in the
+    // first loop, once without in the second; f_g * 1.0f is f_g).  Pure functions of the same operands give the same bits; the second loop no longer reads the neighbour's
+    // 60-B sample record at all.
     const float p_c = p_hat_di(flags, m, sd.x1, sd.n1, can.x2, can.n2, can.L2, sd.o, -1, vis);
     const float c_m_num = cMmin * p_c; float mi_c = cMmin / M_sum_DI;
+    float fg0 = 0.0f, fg1 = 0.0f, fg2 = 0.0f;
     for (int j = 0; j < n_di; j++) {
         const SData sn = load_sd_dev(B.cur_sd + (size_t)K.di[j] * 15); const Res rn = load_res_dev(B.cur_di + (size_t)K.di[j] * 10);
         const float nM = minf_u(128.0f, rn.M);
-        const float p_from = p_hat_di(flags, m, sn.x1, sn.n1, can.x2, can.n2, can.L2, sn.o, j, vis);
+        const float f_g = length(reconnect_di_dev(m, flags, sn.x1, sn.n1, can.x2, can.n2, can.L2, sn.o));
+        if (j == 0) fg0 = f_g; else if (j == 1) fg1 = f_g; else fg2 = f_g;
+        const float p_from = f_g * vis(j, sn.x1, sn.n1, can.x2);
         const float m_den = c_m_num + (cMmax * p_from);
         if (m_den > 0.0f) mi_c += (nM / M_sum_DI) * (c_m_num / m_den);
     }
-    const float w_c = mi_c * p_hat_di(flags, m, sd.x1, sd.n1, can.x2, can.n2, can.L2, sd.o, -1, vis) * can.W;
+    const float w_c = mi_c * p_c * can.W;
     rcur.M = (uint32_t)cMmin; rcur.w_sum = w_c;
     for (int v = 0; v < n_di; v++) {
-        const SData sn = load_sd_dev(B.cur_sd + (size_t)K.di[v] * 15); const Res rn = load_res_dev(B.cur_di + (size_t)K.di[v] * 10);
-        const float pc2 = p_hat_di(flags, m, sd.x1, sd.n1, can.x2, can.n2, can.L2, sd.o, -1, vis);
-        const float p_from = p_hat_di(flags, m, sn.x1, sn.n1, can.x2, can.n2, can.L2, sn.o, -1, vis);
+        const Res rn = load_res_dev(B.cur_di + (size_t)K.di[v] * 10);
+        const float pc2 = p_c;
+        const float p_from = v == 0 ? fg0 : v == 1 ? fg1 : fg2;
         const float m_num = (M_sum_DI - cMmin) * p_from, m_den = m_num + (cMmin * pc2);
         const float mi_s = m_den > 0.0f ? (minf_u(128.0f, rn.M) / M_sum_DI) * (m_num / m_den) : 0.0f;
         const float w_s = mi_s * p_hat_di(flags, m, sd.x1, sd.n1, rn.x2, rn.n2, rn.L2, sd.o, -1, vis) * rn.W;
@@ -638,24 +657,29 @@ __device__ __forceinline__ void p3_merge_gi(const DevScene& sc, const DevFrame& 
     const int n_gi = K.n_gi;
     const Res can_gi = gcur;
     const float gMmin = minf_u(128.0f, can_gi.M), gMmax = M_sum_GI - gMmin;
+    // (round 4) evaluated once and kept, as in the DI merge: pg_c (twice more in the text) and, per neighbour, the canonical GI sample's unshadowed target function seen from
+    // it and the Jacobian of that shift (lf, jac: the second loop's p_from is length(fr * 1.0f) * jj with the same fr and jj).  The second loop reads x1 of the neighbour only.
     const float pg_c = length(p_hat_gi(flags, m, sd.x1, sd.n1, can_gi.x2, can_gi.L2, sd.o, -1, vis));
     const float g_m_num = gMmin * pg_c; float mi_c_gi = gMmin / M_sum_GI;
+    float lf0 = 0.0f, lf1 = 0.0f, lf2 = 0.0f, jc0 = 0.0f, jc1 = 0.0f, jc2 = 0.0f;
     for (int j = 0; j < n_gi; j++) {
         const SData sn = load_sd_dev(B.cur_sd + (size_t)K.gi[j] * 15); const Res gn = load_res_dev(B.cur_gi + (size_t)K.gi[j] * 10);
         const float nM = minf_u(128.0f, gn.M);
         const float j_gi = jacobian_dev(sd, sn, can_gi.x2, can_gi.n2);
-        const float p_from = length(p_hat_gi(flags, m, sn.x1, sn.n1, can_gi.x2, can_gi.L2, sn.o, 3 + j, vis)) * j_gi;
+        const f3 fr = p_hat_gi_fr(flags, m, sn.x1, sn.n1, can_gi.x2, can_gi.L2, sn.o);
+        const float lf = length(fr);
+        if (j == 0) { lf0 = lf; jc0 = j_gi; } else if (j == 1) { lf1 = lf; jc1 = j_gi; } else { lf2 = lf; jc2 = j_gi; }
+        const float p_from = length(fr * vis(3 + j, sn.x1, sn.n1, can_gi.x2)) * j_gi;
         const float m_den = g_m_num + (gMmax * p_from);
         if (m_den > 0.0f) mi_c_gi += (nM / M_sum_GI) * (g_m_num / m_den);
     }
     mi_c_gi = minf_(maxf_(mi_c_gi, 0.0f), 1.0f);
-    const float w_c_gi = mi_c_gi * length(p_hat_gi(flags, m, sd.x1, sd.n1, can_gi.x2, can_gi.L2, sd.o, -1, vis)) * can_gi.W;
+    const float w_c_gi = mi_c_gi * pg_c * can_gi.W;
     gcur.M = (uint32_t)gMmin; gcur.w_sum = w_c_gi;
     for (int v = 0; v < n_gi; v++) {
         const SData sn = load_sd_dev(B.cur_sd + (size_t)K.gi[v] * 15); const Res gn = load_res_dev(B.cur_gi + (size_t)K.gi[v] * 10);
-        const float pc2 = length(p_hat_gi(flags, m, sd.x1, sd.n1, can_gi.x2, can_gi.L2, sd.o, -1, vis));
-        const float jj = jacobian_dev(sd, sn, can_gi.x2, can_gi.n2);
-        const float p_from = length(p_hat_gi(flags, m, sn.x1, sn.n1, can_gi.x2, can_gi.L2, sn.o, -1, vis)) * jj;
+        const float pc2 = pg_c;
+        const float p_from = (v == 0 ? lf0 : v == 1 ? lf1 : lf2) * (v == 0 ? jc0 : v == 1 ? jc1 : jc2);
         const float m_num = (M_sum_GI - gMmin) * p_from, m_den = m_num + (gMmin * pc2);
         const float mi_s = m_den > 0.0f ? minf_(maxf_((minf_u(128.0f, gn.M) / M_sum_GI) * (m_num / m_den), 0.0f), 1.0f) : 0.0f;
         const float j_gi = jacobian_dev(sn, sd, gn.x2, gn.n2);
