@@ -44,6 +44,14 @@ __device__ __forceinline__ void lobes_dev(const MatGPU& m, uint32_t flags, f3 no
     if (flags & 1u) { f1 = mk3(0.0f, 0.0f, 0.0f); q1 = 0.0f; }
     else { f1 = ggx_eval(m, normal, L, out_eval); q1 = ggx_pdf(m, normal, L, out_pdf); }
 }
+// lobes_dev with the terms that depend on (material, normal, view direction) only taken from mv = mix_view(m, flags, normal, V) (rtx_bsdf.hpp): for the nee light
+// candidates of ONE shading point, which all call lobes_dev(m, flags, normal, L_i, V, V).  Same operations on the same operands (strategy_probs, normalize(N), normalize(V),
+// N.V, Smith's G1 of V, the Ess look-up): the same bits; pd / ps are mv.pd / mv.ps.
+__device__ __forceinline__ void lobes_dev_v(const MatGPU& m, uint32_t flags, const MixView& mv, f3 normal, f3 L, f3& f0, f3& f1, float& q0, float& q1) {
+    f0 = lambert_eval(m); q0 = lambert_pdf(normal, L);
+    if (flags & 1u) { f1 = mk3(0.0f, 0.0f, 0.0f); q1 = 0.0f; }
+    else ggx_eval_pdf_v(m, mv, L, f1, q1);
+}
 struct LSample { f3 sp, Ln, nl; float dist2, dist, pdf_l; f3 em; };
 __device__ __forceinline__ LSample light_point_dev(const DevScene& sc, f3 origin, uint32_t& s0, uint32_t& s1) {
     LSample r;
@@ -81,6 +89,20 @@ __device__ __forceinline__ f3 reconnect_di_dev(const MatGPU& m, uint32_t flags, 
     const float d2 = dist * dist;
     return mk3(F.x * L.x * cos1 * cos2 / d2, F.y * L.y * cos1 * cos2 / d2, F.z * L.z * cos1 * cos2 / d2);
 }
+// reconnect_di_dev with the view terms of the shading point (x1, n1, outgoing) handed in: mv = mix_view(m, flags, n1, normalize(outgoing)).  For the passes that evaluate
+// several samples from ONE shading point (the merges, the final shade): same operations on the same operands, the same bits.
+__device__ __forceinline__ f3 reconnect_di_dev_v(const MatGPU& m, uint32_t flags, const MixView& mv, f3 x1, f3 n1, f3 x2, f3 n2, f3 L) {
+    const f3 dir = x2 - x1;
+    const float dist = length(dir);
+    const float cos1 = maxf_(0.0f, dot(n1, normalize(dir)));
+    if (dot(n2, normalize(-dir)) < 0.0f) n2 = -n2;
+    const float cos2 = maxf_(0.0f, dot(n2, normalize(-dir)));
+    f3 f0, f1; float q0, q1;
+    lobes_dev_v(m, flags, mv, n1, normalize(dir), f0, f1, q0, q1);
+    const f3 F = safe_mul(mv.pd, f0) + safe_mul(mv.ps, f1);
+    const float d2 = dist * dist;
+    return mk3(F.x * L.x * cos1 * cos2 / d2, F.y * L.y * cos1 * cos2 / d2, F.z * L.z * cos1 * cos2 / d2);
+}
 __device__ __forceinline__ bool p1_any(P1Ctx& C, f3 o, f3 d, float tmin, float tmax) {
     float t, u, v; uint32_t prim;
     trace_ray<true>(*C.sc, C.small, *C.L, o, d, tmin, tmax, t, u, v, prim);
@@ -102,12 +124,14 @@ constexpr uint32_t kRisM2 = 1u;
 __device__ __forceinline__ f3 ris_front(const DevScene& sc, uint32_t flags, uint32_t M1, f3 outgoing, Res& rs, f3 origin, f3 normal, uint32_t mat, uint32_t& s0, uint32_t& s1) {
     const MatGPU& m = sc.mats[mat];
     const uint32_t strategy = select_strategy(m, outgoing, normal, flags, s0, s1);
+    MixView mv;
+    if (M1 && sc.nlights) mv = mix_view(m, flags, normal, normalize(outgoing));        // (round 4) the view terms of the M1 candidates' mixtures, once
     for (uint32_t i = 0; i < M1 && sc.nlights; i++) {
         const LSample ls = light_point_dev(sc, origin, s0, s1);
         const float cos_x = dot(normal, ls.Ln), cos_y = dot(ls.nl, -ls.Ln);
         const float G = maxf_(cos_y * cos_x / ls.dist2, kEps);
-        f3 f0, f1; float q0, q1, pd, ps;
-        lobes_dev(m, flags, normal, ls.Ln, normalize(outgoing), normalize(outgoing), f0, f1, q0, q1, pd, ps);
+        f3 f0, f1; float q0, q1; const float pd = mv.pd, ps = mv.ps;
+        lobes_dev_v(m, flags, mv, normal, ls.Ln, f0, f1, q0, q1);
         const f3 F = safe_mul(pd, f0) + safe_mul(ps, f1);
         const float P = safe_mul(pd, q0 * cos_y / ls.dist2) + safe_mul(ps, q1 * cos_y / ls.dist2);
         const float p_hat = length(mk3(ls.em.x * F.x * G * 1.0f, ls.em.y * F.y * G * 1.0f, ls.em.z * F.z * G * 1.0f));
@@ -183,12 +207,14 @@ __device__ __forceinline__ bool gi_update(GiHot& H, float wi, uint32_t& s0, uint
 template <class Sel>
 __device__ __forceinline__ f3 gi_front(const DevScene& sc, uint32_t flags, uint32_t nee, GiHot& H, uint32_t& s0, uint32_t& s1, Sel&& sel) {
     (void)select_strategy(sc.mats[H.mat], H.outgoing, H.normal, flags, s0, s1);
+    MixView mv;
+    if (nee) mv = mix_view(sc.mats[H.mat], flags, H.normal, normalize(H.outgoing));   // (round 4) the view terms of the nee light samples' mixtures, once
     for (uint32_t j = 0; j < nee; j++) {
         const LSample ls = light_point_dev(sc, H.origin, s0, s1);
         float cos_x = fabsf(dot(H.normal, ls.Ln)); if (cos_x < kEps) cos_x = 0.0f;
         float cos_y = fabsf(dot(ls.nl, -ls.Ln)); if (cos_y < kEps) cos_y = 0.0f;
-        f3 f0, f1; float q0, q1, pd, ps;
-        lobes_dev(sc.mats[H.mat], flags, H.normal, ls.Ln, normalize(H.outgoing), normalize(H.outgoing), f0, f1, q0, q1, pd, ps);
+        f3 f0, f1; float q0, q1; const float pd = mv.pd, ps = mv.ps;
+        lobes_dev_v(sc.mats[H.mat], flags, mv, H.normal, ls.Ln, f0, f1, q0, q1);
         const f3 F = safe_mul(pd, f0) + safe_mul(ps, f1);
         const float pdf_bsdf = safe_mul(pd, q0) + safe_mul(ps, q1);
         float pdf_light = 1.0f;
@@ -439,6 +465,16 @@ __device__ __forceinline__ f3 p_hat_gi_fr(uint32_t flags, const MatGPU& m, f3 x1
     if (!finite3(fr)) fr = mk3(0, 0, 0);
     return fr;
 }
+__device__ __forceinline__ f3 p_hat_gi_fr_v(uint32_t flags, const MatGPU& m, const MixView& mv, f3 x1, f3 n1, f3 x2, f3 L) {      // ... with mv = mix_view(m, flags, n1, normalize(o))
+    const f3 dir = x2 - x1;
+    const float cos1 = fabsf(dot(n1, normalize(dir)));
+    f3 f0, f1; float q0, q1;
+    lobes_dev_v(m, flags, mv, n1, normalize(dir), f0, f1, q0, q1);
+    const f3 Fx = safe_mul(mv.pd, f0) + safe_mul(mv.ps, f1);
+    f3 fr = mk3(Fx.x * cos1 * L.x, Fx.y * cos1 * L.y, Fx.z * cos1 * L.z);
+    if (!finite3(fr)) fr = mk3(0, 0, 0);
+    return fr;
+}
 template <class V>
 __device__ __forceinline__ f3 p_hat_gi(uint32_t flags, const MatGPU& m, f3 x1, f3 n1, f3 x2, f3 L, f3 o, int k, V&& vis) {
     const f3 fr = p_hat_gi_fr(flags, m, x1, n1, x2, L, o);
@@ -624,7 +660,8 @@ __device__ __forceinline__ void p3_merge_di(const DevScene& sc, const DevFrame& 
     // function (p_c: three more times in the text) and, per neighbour, the canonical sample's unshadowed contribution seen from it (f_g: once with the visibility factor in the
     // first loop, once without in the second; f_g * 1.0f is f_g).  Pure functions of the same operands give the same bits; the second loop no longer reads the neighbour's
     // 60-B sample record at all.
-    const float p_c = p_hat_di(flags, m, sd.x1, sd.n1, can.x2, can.n2, can.L2, sd.o, -1, vis);
+    const MixView mv = mix_view(m, flags, sd.n1, normalize(sd.o));                    // the view terms of this pixel's own 1 + n_di evaluations, once
+    const float p_c = length(reconnect_di_dev_v(m, flags, mv, sd.x1, sd.n1, can.x2, can.n2, can.L2)) * 1.0f;
     const float c_m_num = cMmin * p_c; float mi_c = cMmin / M_sum_DI;
     float fg0 = 0.0f, fg1 = 0.0f, fg2 = 0.0f;
     for (int j = 0; j < n_di; j++) {
@@ -644,7 +681,7 @@ __device__ __forceinline__ void p3_merge_di(const DevScene& sc, const DevFrame& 
         const float p_from = v == 0 ? fg0 : v == 1 ? fg1 : fg2;
         const float m_num = (M_sum_DI - cMmin) * p_from, m_den = m_num + (cMmin * pc2);
         const float mi_s = m_den > 0.0f ? (minf_u(128.0f, rn.M) / M_sum_DI) * (m_num / m_den) : 0.0f;
-        const float w_s = mi_s * p_hat_di(flags, m, sd.x1, sd.n1, rn.x2, rn.n2, rn.L2, sd.o, -1, vis) * rn.W;
+        const float w_s = mi_s * (length(reconnect_di_dev_v(m, flags, mv, sd.x1, sd.n1, rn.x2, rn.n2, rn.L2)) * 1.0f) * rn.W;
         rcur.w_sum += w_s; rcur.M = (rcur.M + (uint32_t)minf_u(128.0f, rn.M)) & 0xFFFFu;
         if (tea_next(s0, s1) < w_s / rcur.w_sum) { rcur.x2 = rn.x2; rcur.n2 = rn.n2; rcur.L2 = rn.L2; }
     }
@@ -659,7 +696,8 @@ __device__ __forceinline__ void p3_merge_gi(const DevScene& sc, const DevFrame& 
     const float gMmin = minf_u(128.0f, can_gi.M), gMmax = M_sum_GI - gMmin;
     // (round 4) evaluated once and kept, as in the DI merge: pg_c (twice more in the text) and, per neighbour, the canonical GI sample's unshadowed target function seen from
     // it and the Jacobian of that shift (lf, jac: the second loop's p_from is length(fr * 1.0f) * jj with the same fr and jj).  The second loop reads x1 of the neighbour only.
-    const float pg_c = length(p_hat_gi(flags, m, sd.x1, sd.n1, can_gi.x2, can_gi.L2, sd.o, -1, vis));
+    const MixView mv = mix_view(m, flags, sd.n1, normalize(sd.o));
+    const float pg_c = length(p_hat_gi_fr_v(flags, m, mv, sd.x1, sd.n1, can_gi.x2, can_gi.L2) * 1.0f);
     const float g_m_num = gMmin * pg_c; float mi_c_gi = gMmin / M_sum_GI;
     float lf0 = 0.0f, lf1 = 0.0f, lf2 = 0.0f, jc0 = 0.0f, jc1 = 0.0f, jc2 = 0.0f;
     for (int j = 0; j < n_gi; j++) {
@@ -683,7 +721,7 @@ __device__ __forceinline__ void p3_merge_gi(const DevScene& sc, const DevFrame& 
         const float m_num = (M_sum_GI - gMmin) * p_from, m_den = m_num + (gMmin * pc2);
         const float mi_s = m_den > 0.0f ? minf_(maxf_((minf_u(128.0f, gn.M) / M_sum_GI) * (m_num / m_den), 0.0f), 1.0f) : 0.0f;
         const float j_gi = jacobian_dev(sn, sd, gn.x2, gn.n2);
-        const f3 f_gi = p_hat_gi(flags, m, sd.x1, sd.n1, gn.x2, gn.L2, sd.o, 6 + v, vis);
+        const f3 f_gi = p_hat_gi_fr_v(flags, m, mv, sd.x1, sd.n1, gn.x2, gn.L2) * vis(6 + v, sd.x1, sd.n1, gn.x2);
         const float w_s = mi_s * length(f_gi) * gn.W * j_gi;
         if (j_gi != 0.0f) {
             gcur.w_sum += w_s; gcur.M = (gcur.M + (uint32_t)minf_u(128.0f, gn.M)) & 0xFFFFu;
@@ -700,10 +738,12 @@ __device__ __forceinline__ void p3_merge(const DevScene& sc, const DevFrame& f, 
 // final W of both reservoirs and the pixel's radiance ReconnectDI * W + f_gi * W_gi (pass3:353-372)
 template <class V>
 __device__ __forceinline__ f3 p3_shade(const DevFrame& f, const SData& sd, const MatGPU& m, Res& rcur, Res& gcur, V&& vis) {
-    const float p_hat = p_hat_di(f.flags, m, sd.x1, sd.n1, rcur.x2, rcur.n2, rcur.L2, sd.o, 9, vis);
+    const MixView mv = mix_view(m, f.flags, sd.n1, normalize(sd.o));
+    const f3 rc = reconnect_di_dev_v(m, f.flags, mv, sd.x1, sd.n1, rcur.x2, rcur.n2, rcur.L2);       // once: the target function's length and the radiance term
+    const float p_hat = length(rc) * vis(9, sd.x1, sd.n1, rcur.x2);
     rcur.W = get_w_dev(rcur.w_sum, p_hat);
-    f3 acc = reconnect_di_dev(m, f.flags, sd.x1, sd.n1, rcur.x2, rcur.n2, rcur.L2, sd.o) * rcur.W;
-    const f3 f_fin = p_hat_gi(f.flags, m, sd.x1, sd.n1, gcur.x2, gcur.L2, sd.o, -1, vis);
+    f3 acc = rc * rcur.W;
+    const f3 f_fin = p_hat_gi_fr_v(f.flags, m, mv, sd.x1, sd.n1, gcur.x2, gcur.L2) * 1.0f;
     gcur.W = get_w_dev(gcur.w_sum, length(f_fin));
     acc = acc + f_fin * gcur.W;
     return acc;
