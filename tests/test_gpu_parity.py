@@ -856,6 +856,7 @@ def test_restir_pipeline_lanes_equal_the_literal_form(rt, orc, golden_dir, lanes
 
     def ctx():
         c = rt.Context(0); c.set_option(rt.OPT_RESTIR_LANES, lanes); c.set_option(rt.OPT_RESTIR_LANE_MIN, 256)
+        c.set_option(rt.OPT_RESTIR_KEYS, lanes & 1)              # lanes 1 / 3: the selection stage of pass 3 on the compact neighbour records (the default); 2 / 4: on the full records
         c.upload(sc, W / H); c.restir_reset(); c.clear(W, H)
         return c
     c = ctx()
