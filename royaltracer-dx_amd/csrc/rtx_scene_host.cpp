@@ -3,6 +3,7 @@
 #include "rtx_scene_host.hpp"
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -197,6 +198,8 @@ void SceneHost::build_materials(BuiltScene& B) {
 }
 
 bool SceneHost::build(BuiltScene& B) {
+    // tooling: RTX_BUILD_TIMES=1 prints the phases of a commit to stderr (tools/bvh_lab, tools/build_time.py)
+    const bool TT = getenv("RTX_BUILD_TIMES") != nullptr; auto T0 = std::chrono::steady_clock::now(); auto lap = [&](const char* w) { if (TT) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[build] %-28s %.3f s\n", w, std::chrono::duration<double>(t - T0).count()); T0 = t; } };
     build_materials(B);
     // ---- flatten instances to world-space triangles; per-triangle shade records (Hit_v6.hlsl:12-61) ----
     uint32_t nt = 0;
@@ -238,7 +241,9 @@ bool SceneHost::build(BuiltScene& B) {
             s.guard_tau = 0.0f;
         }
     }
+    lap("flatten + shade records");
     build_lights(B);
+    lap("lights");
     // ---- BVH: full binned-SAH build, or a REFIT when only instance transforms changed since the last build
     //      (the reference refits its TLAS every frame: Renderer.cpp:594, TopLevelASGenerator.cpp:149-250) ----
     std::vector<uint32_t>& leaf_order = B.leaf_order;
@@ -246,6 +251,7 @@ bool SceneHost::build(BuiltScene& B) {
     const float bvh_pad = 2e-6f * scale; B.bvh_pad = bvh_pad;                  // absolute box padding (1e-5 measured 3 % slower; the relative margins kSlabLo / kSlabHi carry the triangle-test error)
     if (refit) refit_bvh(wtri, bvh_pad, B.nodes, leaf_order);
     else { build_bvh(wtri, bvh_pad, B.nodes, leaf_order, B.max_depth, bvh); B.built_tris = nt; }
+    lap("build_bvh");
     B.refit_count = refit ? B.refit_count + 1 : 0;
     topo_dirty = false;
     B.tris.resize(leaf_order.size());
@@ -261,6 +267,7 @@ bool SceneHost::build(BuiltScene& B) {
     }
     // device traversal form: derived data, redone after a refit too (O(nodes))
     if (!collapse_bvh8(B.nodes, B.nodes8, B.tri_slots8, B.stack8, &B.level_start8, bvh)) { err = "build: BVH collapse failed"; return false; }
+    lap("collapse_bvh8");
     B.tris8.resize(B.tri_slots8.size());
     for (size_t i = 0; i < B.tri_slots8.size(); i++) B.tris8[i] = B.tris[B.tri_slots8[i]];
     // ---- tiny scenes: merge triangles into planar convex quads and build the conservative pre-test records ----
@@ -420,7 +427,9 @@ bool SceneHost::build(BuiltScene& B) {
             B.small_recs.push_back(P);
         }
     }
+    lap("tris8 / small scene");
     B.any_order = probe_anyhit_order(B);
+    lap("probe");
     return true;
 }
 
