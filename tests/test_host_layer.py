@@ -167,7 +167,7 @@ def test_bvh_builder_invariants(rt, cornell):
     assert rt.bvh8_check(np.zeros((0, 9), np.float32))[0] == 0
 
 
-BUILDER_DEFAULTS = {"bins": 16, "sweep": 0, "leaf_stop": 2, "split": 0.0, "split_budget": 0.3, "reinsert": 2, "reinsert_frac": 1.0, "reinsert_cap": 200000, "slot_assign": 0, "tri_cost": 0.7}
+BUILDER_DEFAULTS = {"bins": 16, "sweep": 0, "leaf_stop": 2, "split": 0.0, "split_budget": 0.3, "reinsert": 2, "reinsert_frac": 1.0, "reinsert_cap": 200000, "slot_assign": 0, "tri_cost": 0.7, "threads": 0}
 
 
 @pytest.fixture
@@ -191,6 +191,31 @@ def _lab_soup(kind, n, rng):
         big = rng.uniform(-1.2, 1.2, (12, 3, 3))
         return np.concatenate([small, big]).astype(np.float32)
     return (c + rng.normal(scale=0.03, size=(n, 3, 3))).astype(np.float32)
+
+
+def test_parallel_build_gives_the_serial_tree(rt, builder_options):
+    """build_bvh cuts subtrees of at most max(4096, n / 256) references out of its top-down loop and builds them in a thread pool (scenes of >= 65 536 triangles), splices them
+    back in cutting order and renumbers the nodes into the serial loop's creation order; the re-insertion passes select their candidates (largest boxes first, ties by index)
+    by nth_element + sort instead of a full stable sort.  Neither may change the tree: the replayed traversal of 20 000 rays takes the same node steps and triangle tests, ray
+    for ray, with 1, 3 and the default number of threads, and the validators accept it."""
+    rng = np.random.default_rng(41)
+    n = 90000
+    c = rng.uniform(-1, 1, (n, 1, 3)) * np.array([4.0, 1.0, 4.0])
+    t = (c + rng.normal(scale=0.03, size=(n, 3, 3))).astype(np.float32)
+    t[::7] = np.round(t[::7] * 8) / 8                      # exact ties: coincident and grid-aligned triangles
+    m = 20000
+    org = rng.uniform(-4, 4, (m, 3)) * np.array([1.0, 0.3, 1.0]); d = rng.normal(size=(m, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros((m, 8), np.float32); rays[:, 0:3], rays[:, 3], rays[:, 4:7], rays[:, 7] = org, 1e-5, d, 1e30
+    out = []
+    for threads in (1, 3, 0):
+        builder_options(threads=threads)
+        got, refs = rt.bvh_replay(t, rays)
+        assert refs == n
+        out.append(bits(got).tobytes())
+    assert out[0] == out[1] == out[2]
+    assert (bits(np.frombuffer(out[0], np.uint32).reshape(-1, 4))[:, 3] != 0xFFFFFFFF).mean() > 0.2
+    rc8, nodes8, stack8 = rt.bvh8_check(t.reshape(-1, 9))
+    assert rc8 == 0 and stack8 <= 30
 
 
 @pytest.mark.parametrize("opts", [dict(), dict(reinsert=0), dict(split=1e-5, sweep=64), dict(split=1e-7, split_budget=2.0, reinsert=3), dict(bins=8, leaf_stop=1, slot_assign=1)],
