@@ -52,7 +52,8 @@ def run(c, seed0):
 
 res = {v: [] for v in vals}
 for v in vals:
-    ctxs[v].set_option(opt, v)
+    if same:
+        ctxs[v].set_option(opt, v)               # (one context per value: set before its upload — options that change the commit must not be touched again)
     run(ctxs[v], 1)                              # warm-up (allocations)
 for r in range(rounds):
     for v in vals:
