@@ -162,6 +162,7 @@ void rtx_destroy(rtx_ctx* c) {
 
 const char* rtx_last_error(rtx_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
+static void pick_lds_closest(rtx_ctx* c);
 int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     if (!c) return RTX_ERR_INVALID;
     switch (option) {
@@ -182,7 +183,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_PATHS_PER_BATCH: if (value < 4096) { c->err = "paths_per_batch must be >= 4096"; return RTX_ERR_INVALID; } c->paths_per_batch = (uint64_t)value; return RTX_OK;
     case RTX_OPT_SORT_MATERIALS: c->sort_materials = value != 0; c->dsc.sort_materials = c->sort_materials; return RTX_OK;
     case RTX_OPT_LDS_NODES: c->lds_nodes_opt = (int)value; c->committed = false; return RTX_OK;
-    case RTX_OPT_LDS_NODES_CLOSEST: if (c->lds_closest_opt != (int)value) { c->lds_closest_opt = (int)value; c->committed = false; } return RTX_OK;
+    case RTX_OPT_LDS_NODES_CLOSEST: c->lds_closest_opt = (int)value; if (c->committed) pick_lds_closest(c); return RTX_OK;
     case RTX_OPT_SMALL_SCENE: c->small_scene = value != 0; c->committed = false; return RTX_OK;
     case RTX_OPT_FUSED_BOUNCE: c->fused = value != 0; return RTX_OK;
     case RTX_OPT_BOUNCE_VARIANT: c->bounce_ring = value == 0; return RTX_OK;     // 0 (default): LDS hit ring between trace and shading; 1: trace and shade the same 256 entries
@@ -313,6 +314,27 @@ int rtx_load_scene_cache(rtx_ctx* c, const char* path) {
     return finalise_scene(c);
 }
 
+static void pick_lds_closest(rtx_ctx* c) {
+    DevScene& s = c->dsc;
+    // ... and the CLOSEST-HIT launches of the path tracer take the other side of that trade (round 4, after the queue order was tightened): with the first three levels of the
+    // wide tree in LDS (73 nodes) and six workgroups per CU they run C3 20.5 -> 19.6 ms and C5 17.3 -> 17.0 ms per frame against eight / seven workgroups with 24 / 31 nodes,
+    // while the shadow launches lose (11.1 -> 12.2 ms on C3): a closest-hit ray crosses the top of the tree at every step of its front-to-back walk, an any-hit ray leaves at
+    // its first occluder.  So the count is per kind of launch (DevScene goes by value).  Fewer than six workgroups lose again (128 nodes on C3: 20.4 ms; 80 on C5: 17.6).
+    // LDS granule: the measurements fit 1 KB (80 nodes on C5 "fit" six workgroups at 512 B and ran like five).
+    c->lds_nodes_closest = 0;
+    // In a frame the shadow launch of bounce b runs BESIDE the closest-hit launch of bounce b + 1 (RTX_OPT_OVERLAP_SHADOW), and six closest-hit workgroups of 25 KB leave it
+    // no LDS on that CU: the street scene (30 MB of nodes, closest-hit kernel co-limited by memory, so the overlap is worth more there) LOSES 0.4 ms per frame with 73
+    // nodes although the kernel alone gains 0.3; the atrium (2.2 MB of nodes) keeps 0.15-0.2 of the kernel's 0.9 ms (one context, option switched between rounds).  Auto therefore applies to trees that fit L2 (<= 16 MB,
+    // the same line the wide node copy draws); RTX_OPT_LDS_NODES_CLOSEST sets it by hand.
+    const bool small_tree = (size_t)s.nnodes * sizeof(Node8GPU) <= ((size_t)16 << 20);
+    if (!s.nsmall && s.nnodes > s.lds_nodes && c->lds_nodes_opt < 0 && (c->lds_closest_opt >= 0 || small_tree)) {
+        auto fit1k = [&](uint32_t nodes) { DevScene t = s; t.lds_nodes = nodes; return (160u * 1024u) / (uint32_t)((trace_lds_bytes(t) + 64 + 1023) & ~(size_t)1023); };
+        uint32_t n = c->lds_closest_opt >= 0 ? std::min<uint32_t>((uint32_t)c->lds_closest_opt, s.nnodes) : std::min<uint32_t>(73u, s.nnodes);
+        if (c->lds_closest_opt < 0) while (n > s.lds_nodes && fit1k(n) < 6u) n--;
+        DevScene t = s; t.lds_nodes = n;
+        if (n > s.lds_nodes && trace_lds_bytes(t) <= 64 * 1024) c->lds_nodes_closest = n;
+    }
+}
 static int finalise_scene(rtx_ctx* c) {
     BuiltScene& B = c->built;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -392,24 +414,7 @@ static int finalise_scene(rtx_ctx* c) {
         while (s.lds_nodes > 9u && fit(s.lds_nodes) < target) s.lds_nodes--;
         if (getenv("RTX_DEBUG_LDS")) fprintf(stderr, "[rtx] stack_depth %u workgroups per CU %u, %u nodes staged, %zu B of LDS\n", s.stack_depth, target, s.lds_nodes, trace_lds_bytes(s));
     }
-    // ... and the CLOSEST-HIT launches of the path tracer take the other side of that trade (round 4, after the queue order was tightened): with the first three levels of the
-    // wide tree in LDS (73 nodes) and six workgroups per CU they run C3 20.5 -> 19.6 ms and C5 17.3 -> 17.0 ms per frame against eight / seven workgroups with 24 / 31 nodes,
-    // while the shadow launches lose (11.1 -> 12.2 ms on C3): a closest-hit ray crosses the top of the tree at every step of its front-to-back walk, an any-hit ray leaves at
-    // its first occluder.  So the count is per kind of launch (DevScene goes by value).  Fewer than six workgroups lose again (128 nodes on C3: 20.4 ms; 80 on C5: 17.6).
-    // LDS granule: the measurements fit 1 KB (80 nodes on C5 "fit" six workgroups at 512 B and ran like five).
-    c->lds_nodes_closest = 0;
-    // In a frame the shadow launch of bounce b runs BESIDE the closest-hit launch of bounce b + 1 (RTX_OPT_OVERLAP_SHADOW), and six closest-hit workgroups of 25 KB leave it
-    // no LDS on that CU: the street scene (30 MB of nodes, closest-hit kernel co-limited by memory, so the overlap is worth more there) LOSES 0.4 ms per frame with 73
-    // nodes although the kernel alone gains 0.3; the atrium (2.2 MB of nodes) keeps 0.55 of the kernel's 0.9 ms.  Auto therefore applies to trees that fit L2 (<= 16 MB,
-    // the same line the wide node copy draws); RTX_OPT_LDS_NODES_CLOSEST sets it by hand.
-    const bool small_tree = (size_t)s.nnodes * sizeof(Node8GPU) <= ((size_t)16 << 20);
-    if (!s.nsmall && s.nnodes > s.lds_nodes && c->lds_nodes_opt < 0 && (c->lds_closest_opt >= 0 || small_tree)) {
-        auto fit1k = [&](uint32_t nodes) { DevScene t = s; t.lds_nodes = nodes; return (160u * 1024u) / (uint32_t)((trace_lds_bytes(t) + 64 + 1023) & ~(size_t)1023); };
-        uint32_t n = c->lds_closest_opt >= 0 ? std::min<uint32_t>((uint32_t)c->lds_closest_opt, s.nnodes) : std::min<uint32_t>(73u, s.nnodes);
-        if (c->lds_closest_opt < 0) while (n > s.lds_nodes && fit1k(n) < 6u) n--;
-        DevScene t = s; t.lds_nodes = n;
-        if (n > s.lds_nodes && trace_lds_bytes(t) <= 64 * 1024) c->lds_nodes_closest = n;
-    }
+    pick_lds_closest(c);
     c->stats.bvh_refits = B.refit_count; c->stats.bvh_nodes = s.nnodes; c->stats.triangles = (uint32_t)B.shade.size(); c->stats.bvh_refs = s.ntris; c->stats.lights = s.nlights; c->stats.materials = s.nmat;
     c->committed = true;
     return RTX_OK;
