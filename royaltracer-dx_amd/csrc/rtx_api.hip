@@ -361,13 +361,13 @@ static int finalise_scene(rtx_ctx* c) {
     s.total_weight = B.total_weight;
     // LDS budget per workgroup: stack + top of tree + first triangles, kept <= 64 KiB
     // exact bound of the 8-wide tree, no slack: a level adds ONE entry (the rest of its hit siblings) and only where a node has >= 2 internal
-    // children (collapse_bvh8: need[]); a pop precedes every descent from an exhausted group.  Each entry costs 2 KB of LDS per workgroup, and
+    // children (collapse_bvh8: need[]); a pop precedes every descent from an exhausted group.  Each entry costs 1.5 KB of LDS per workgroup (6 B per lane: kStackEntryBytes), and
     // LDS decides how many workgroups live on a CU: two entries of slack cost C3 2.3 % (5 instead of 6 workgroups) and C5 1.3 %.
     s.stack_depth = B.stack8;
     s.stack_private = c->stack_private == 1 ? 1u : 0u;    // 1 (private / scratch) is a tuning knob; it measured slower than the LDS column
     if (s.stack_depth > 30) { c->err = "commit: BVH too deep for the traversal stack (more than 30 levels of 8-wide nodes with two or more internal children)"; return RTX_ERR_INVALID; }
-    // LDS per workgroup = traversal stack (8 B per entry and lane) + top of the tree (+ all triangles of a small scene), <= 64 KiB.
-    const size_t stack_bytes = (size_t)s.stack_depth * 256 * 8;
+    // LDS per workgroup = traversal stack (6 B per entry and lane) + top of the tree (+ all triangles of a small scene), <= 64 KiB.
+    const size_t stack_bytes = (size_t)s.stack_depth * 256 * kStackEntryBytes;
     const size_t hard = 64 * 1024;
     size_t budget = hard > stack_bytes ? hard - stack_bytes : 0;
     uint32_t want_nodes;
@@ -407,7 +407,7 @@ static int finalise_scene(rtx_ctx* c) {
     // (LDS is granted in 512-B granules, which the runtime's occupancy query does not count: 33 nodes on C5 "fit" seven workgroups by its answer and
     // ran like six.  Hence the model below, with the query only as the upper bound the registers set.)
     if (c->lds_nodes_opt < 0 && !s.nsmall && s.lds_nodes > 9u) {
-        auto fit = [&](uint32_t nodes) { DevScene t = s; t.lds_nodes = nodes; return (160u * 1024u) / (uint32_t)((trace_lds_bytes(t) + 64 + 511) & ~(size_t)511); };
+        auto fit = [&](uint32_t nodes) { DevScene t = s; t.lds_nodes = nodes; return (160u * 1024u) / (uint32_t)((trace_lds_bytes(t) + 64 + 1023) & ~(size_t)1023); };      // (1-KB granule: what round 4's sweeps fit, profiles/r04_lds_closest_ab.md)
         DevScene t9 = s; t9.lds_nodes = 9;
         const int by_regs = trace_workgroups_per_cu(t9);
         const uint32_t target = std::min<uint32_t>(fit(9), by_regs > 0 ? (uint32_t)by_regs : 8u);

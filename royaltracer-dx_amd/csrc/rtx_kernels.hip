@@ -168,12 +168,14 @@ __device__ __forceinline__ void trace_count_flush(unsigned long long* cnt, uint3
     if (lane_id() == 0) { atomicAdd(cnt, a); atomicAdd(cnt + 1, b); }
 }
 #ifndef RTX_TRACE_WAVES
-#define RTX_TRACE_WAVES 1          // waves per SIMD the persistent traversal kernels are compiled for (1 = no cap: the default-schedule instantiations take 64 / 63 VGPRs, 8 waves per SIMD)
+#define RTX_TRACE_WAVES 8          // waves per SIMD the DEFAULT-schedule instantiations (SCHED >= 0) of the persistent traversal kernels are compiled for: 62 VGPRs, no spills.  (Uncapped, the
+                                  // closest-hit kernel took 69 VGPRs = 7 waves once the 6-B stack entries let eight workgroups fit a CU's LDS.)  The generic instantiations (SCHED -1: experiment
+                                  // knobs, work counters) stay uncapped: capped they spill
 #endif
 // closest hit for every path in this workgroup's sub-queue: reads ray_o/ray_d, writes hit
 template <int STK, bool STEAL, int SCHED>   // traversal stack: 0 = LDS column, 1 = private (scratch); STEAL: work stealing between sub-queues (refill_steal);
                                             // SCHED: the wave schedule as a compile-time constant (the default, 6), or -1 = the run-time parameter (experiment knobs)
-__global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin, uint32_t refill_min, uint32_t sched, uint32_t* heads,
+__global__ __launch_bounds__(kBlock, (SCHED >= 0 ? RTX_TRACE_WAVES : 1)) void k_trace_closest(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qcount, uint32_t qcap, float tmin, uint32_t refill_min, uint32_t sched, uint32_t* heads,
                                                                        uint32_t nq, uint32_t merge) {           // nq sub-queues in the launch, `merge` of them per workgroup (MergedQ; 1 with STEAL and on the tiny-scene test path)
     extern __shared__ F4 lds[];
     __shared__ uint32_t s_head;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevSc
     const TraceLds L = stage_lds(sc, lds);
     __syncthreads();
     const bool sorted = !STEAL && p.perm != nullptr && p.oct_in != nullptr && p.out_o != nullptr;      // RTX_OPT_OCTANT_SORT: every sub-queue of this workgroup grouped by direction octant
-    if (sorted) for (uint32_t t = 0; t < merge && M.q0 + t < nq; t++) sort_by_key(p.oct_in + (size_t)(M.q0 + t) * qcap, p.perm + (size_t)(M.q0 + t) * qcap, qcount[M.q0 + t], (lds_u32*)L.stack);
+    if (sorted) for (uint32_t t = 0; t < merge && M.q0 + t < nq; t++) sort_by_key(p.oct_in + (size_t)(M.q0 + t) * qcap, p.perm + (size_t)(M.q0 + t) * qcap, qcount[M.q0 + t], L.stack);
     const uint32_t* myq = queue + (size_t)blockIdx.x * qcap;
     if (SCHED < 0 && sc.nsmall) {                          // tiny scene, un-fused kernels (test path)
         for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevSc
         return;
     }
     typename std::conditional<STK == 1, StackPriv, StackLds>::type stk;
-    if constexpr (STK != 1) stk.col = L.stack + threadIdx.x;
+    if constexpr (STK != 1) stk.init(L);
     RayLane R; ray_idle(R);
     bool drained = false;
     RaySource W{heads, qcount, gridDim.x, blockIdx.x, n, 0u, 0u};
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_closest(DevSc
 // SINK 0: the path tracer's NEE rays (visible contributions are added to the path's radiance).  SINK 1: visibility rays of the ReSTIR stages (rtx_restir_wave.hpp):
 // the answer goes to occ[pay[entry]] as a byte, 1 = occluded; end points may be anywhere (last frame's samples), so the tiny-scene path tests every record.
 template <int STK, bool STEAL, int SCHED, int SINK = 0>
-__global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_shadow(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const F4* __restrict__ sh_o, const F4* __restrict__ sh_d,
+__global__ __launch_bounds__(kBlock, (SCHED >= 0 ? RTX_TRACE_WAVES : 1)) void k_trace_shadow(DevScene sc, const SmallRecPair* __restrict__ small, DevPaths p, const F4* __restrict__ sh_o, const F4* __restrict__ sh_d,
                                                          const F4* __restrict__ sh_c, const uint32_t* __restrict__ shcount, uint32_t qcap, uint32_t refill_min, uint32_t sched, uint32_t* heads,
                                                          uint32_t nq, uint32_t merge, const uint32_t* __restrict__ pay = nullptr, uint8_t* __restrict__ occ = nullptr) {
     extern __shared__ F4 lds[];
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(kBlock, RTX_TRACE_WAVES) void k_trace_shadow(DevSce
         return;
     }
     typename std::conditional<STK == 1, StackPriv, StackLds>::type stk;
-    if constexpr (STK != 1) stk.col = L.stack + threadIdx.x;
+    if constexpr (STK != 1) stk.init(L);
     RayLane R; ray_idle(R);
     bool drained = false;
     RaySource W{heads, shcount, gridDim.x, blockIdx.x, n, 0u, 0u};
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_bounce_bvh(DevScene sc, DevFrame 
     uint32_t* myhits = hitq + qb;
     uint32_t n = qrows[(size_t)bounce_first * G + qid];
     typename std::conditional<STK == 1, StackPriv, StackLds>::type stk;
-    if constexpr (STK != 1) stk.col = L.stack + threadIdx.x;
+    if constexpr (STK != 1) stk.init(L);
     for (uint32_t bounce = bounce_first; bounce < bounce_end; bounce++) {
         const bool last = (bounce + 1u == f.max_bounces);
         const float tmin = bounce_tmin(bounce);
@@ -1130,10 +1132,10 @@ static inline uint32_t grid_for(uint32_t items, uint32_t max_blocks) {
 }
 static inline size_t small_planes_bytes(const DevScene& sc) { return sc.nsmall ? (size_t)small_planes_count(sc.nsmall) * 16 : 0; }   // stage_lds
 size_t trace_lds_bytes(const DevScene& sc) {      // the LDS column stack is always reserved: debug / pass-1 kernels use it
-    return (size_t)sc.lds_nodes * 80 + (size_t)sc.lds_tris * 48 + small_planes_bytes(sc) + (size_t)sc.stack_depth * kBlock * 8;
+    return (size_t)sc.lds_nodes * 80 + (size_t)sc.lds_tris * 48 + small_planes_bytes(sc) + (size_t)sc.stack_depth * kBlock * kStackEntryBytes;
 }
 size_t trace_lds_bytes_queue(const DevScene& sc) {   // queue kernels with a private stack need no LDS stack
-    const size_t stack = sc.stack_private == 1 ? 0 : (size_t)sc.stack_depth * kBlock * 8;
+    const size_t stack = sc.stack_private == 1 ? 0 : (size_t)sc.stack_depth * kBlock * kStackEntryBytes;
     return (size_t)sc.lds_nodes * 80 + (size_t)sc.lds_tris * 48 + small_planes_bytes(sc) + stack;
 }
 

@@ -53,11 +53,13 @@ __device__ __forceinline__ float margin_t(float cm, float ind, float t) {
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v2u lds_u2;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
 struct TraceLds {
     const lds_v4f* nodes;   // LDS copy of nodes [0, lds_nodes)
     const lds_v4f* tris;    // LDS copy of tris  [0, lds_tris)
     const lds_v4f* planes;  // tiny scenes: plane (n, n.p0) of every pre-test record
-    lds_u2* stack;          // [depth][kBlock] sibling-group entries
+    lds_u32* stack;         // [depth][kBlock] sibling-group entries: the group's base index ...
+    lds_u16* stack_bits;    // [depth][kBlock] ... and its 16 bits (ordered internal hits | internal mask << 8): 6 B per entry and lane (kStackEntryBytes)
 };
 __host__ __device__ inline uint32_t small_planes_count(uint32_t nsmall) { return (nsmall + 1u) & ~1u; }
 
@@ -76,7 +78,8 @@ __device__ __forceinline__ TraceLds stage_lds(const DevScene& sc, F4* lds_generi
         lp[i] = pl;
     }
     L.nodes = ln; L.tris = lt; L.planes = lp;
-    L.stack = (lds_u2*)(lp + npl);
+    L.stack = (lds_u32*)(lp + npl);
+    L.stack_bits = (lds_u16*)(L.stack + (size_t)sc.stack_depth * kBlock);
     return L;
 }
 
@@ -203,8 +206,12 @@ __device__ __forceinline__ void node8_hits(const Node8R& N, f3 o, f3 idir, bool 
 }
 
 // traversal stack of sibling groups: per-lane column in LDS (conflict-free 8-byte accesses), or a private array (scratch)
-struct StackLds { lds_u2* col; __device__ __forceinline__ void put(int i, Grp g) { v2u v = {g.base, g.bits}; col[i * kBlock] = v; }
-                  __device__ __forceinline__ Grp get(int i) const { const v2u v = col[i * kBlock]; return Grp{v.x, v.y}; } };
+// (round 4) 6 B per entry: a 32-bit base and the 16 bits that are used of `bits`, in two arrays.  Two bytes per lane and level less than the 8-B entry are 4.5-5 KB per
+// workgroup on the benchmark scenes: the first three levels of the wide tree (73 nodes, 5.8 KB) now fit beside the stack WITHOUT giving up a workgroup per CU.
+struct StackLds { lds_u32* cb; lds_u16* ck;
+                  __device__ __forceinline__ void init(const TraceLds& L) { cb = L.stack + threadIdx.x; ck = L.stack_bits + threadIdx.x; }
+                  __device__ __forceinline__ void put(int i, Grp g) { cb[i * kBlock] = g.base; ck[i * kBlock] = (uint16_t)g.bits; }
+                  __device__ __forceinline__ Grp get(int i) const { return Grp{cb[i * kBlock], (uint32_t)ck[i * kBlock]}; } };
 constexpr int kPrivStack = 32;
 struct StackPriv { Grp a[kPrivStack]; __device__ __forceinline__ void put(int i, Grp g) { a[i] = g; } __device__ __forceinline__ Grp get(int i) const { return a[i]; } };
 
@@ -241,7 +248,7 @@ __device__ __forceinline__ void traverse(const DevScene& sc, const TraceLds& L, 
     const f3 idir = mk3(__builtin_amdgcn_rcpf(dxs), __builtin_amdgcn_rcpf(dys), __builtin_amdgcn_rcpf(dzs));
     const uint32_t oct = ray_octant(idir);
     bt = tmax; bu = 0.0f; bv = 0.0f; bprim = kMissPrim;
-    StackLds stk; stk.col = L.stack + threadIdx.x;
+    StackLds stk; stk.init(L);
     int sp = 0;
     Grp G{0u, (ANY ? (sc.any_order ? 1u << (oct ^ (sc.any_order == 2u ? 7u : 0u)) : 1u) : (1u << oct)) | (1u << 8)};    // the root as slot 0 of a virtual parent (any-hit rays: DevScene::any_order)
     TriGrp T{0u, 0u, 0u};
@@ -280,7 +287,7 @@ __device__ __forceinline__ void traverse_stats(const DevScene& sc, const TraceLd
     const f3 idir = mk3(__builtin_amdgcn_rcpf(dxs), __builtin_amdgcn_rcpf(dys), __builtin_amdgcn_rcpf(dzs));
     const uint32_t oct = ray_octant(idir);
     bt = tmax; bu = 0.0f; bv = 0.0f; bprim = kMissPrim;
-    StackLds stk; stk.col = L.stack + threadIdx.x;
+    StackLds stk; stk.init(L);
     int sp = 0;
     Grp G{0u, (ANY ? 1u : (1u << oct)) | (1u << 8)};    // the root as slot 0 of a virtual parent (any-hit rays visit unordered)
     TriGrp T{0u, 0u, 0u};

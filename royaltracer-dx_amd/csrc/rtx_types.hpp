@@ -28,6 +28,7 @@ constexpr int32_t kEmptyChild = 0x7FFFFFFF;   // never visited (box is inverted)
 //   q[12]     : qlo_x, qlo_y, qlo_z, qhi_x, qhi_y, qhi_z as two dwords each (byte k of the pair = slot k)
 // Slots are assigned so that visiting hit children in increasing (slot ^ octant) — octant bit a = ray goes negative
 // along axis a — approximates front-to-back order without sorting.  Breadth-first: children follow their parents.
+constexpr uint32_t kStackEntryBytes = 6;      // LDS traversal stack: bytes per entry (one per tree level) and lane (rtx_traverse.hpp: StackLds)
 struct alignas(16) Node8GPU { float px, py, pz; uint32_t e_imask; uint32_t child_base, tri_base, trivalid, pad; uint32_t q[12]; };
 static_assert(sizeof(Node8GPU) == 80, "Node8GPU must be 80 bytes");
 
