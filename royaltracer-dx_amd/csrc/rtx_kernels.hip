@@ -379,8 +379,8 @@ __device__ __forceinline__ void shade_item(const DevScene& sc, const DevFrame& f
 
 constexpr uint32_t kSortChunk = 2048, kSortKeys = 64;
 #ifndef RTX_SHADE_WAVES
-#define RTX_SHADE_WAVES 6          // waves per SIMD k_shade is compiled for: 6 = 80 VGPRs, no spills (uncapped: 94 VGPRs, 5 waves; 8: 64 VGPRs, 8 spilled).  k_shade
-                                   // per frame, C3 / C5: 7.42 / 8.77 ms uncapped, 6.93 / 8.54 at 6, 7.50 / 8.83 at 8
+#define RTX_SHADE_WAVES 7          // waves per SIMD k_shade is compiled for: 7 = 72 VGPRs + 1 spilled (GGX) / 66 (Lambert); uncapped: 94 VGPRs, 5 waves; 6: 80, no spills; 8: 64, 9 spilled.
+                                   // k_shade per frame, C3 / C5: 7.42 / 8.77 ms uncapped, 6.93 / 8.54 at 6, 7.50 / 8.83 at 8 (round 2); round 4: 6.27 / 6.85 at 6, 6.28 / 6.72 at 7
 #endif
 template <bool SORT, bool LAMBERT>     // LAMBERT: RTX_FLAG_LAMBERT_ONLY as a compile-time constant (no GGX / transmission code in that instantiation)
 __global__ __launch_bounds__(kBlock, RTX_SHADE_WAVES) void k_shade(DevScene sc, DevFrame f_in, DevPaths p, uint32_t bounce,
