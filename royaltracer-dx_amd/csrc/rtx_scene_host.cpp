@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <system_error>
 #include <thread>
 #include <atomic>
 #include <cstdio>
@@ -835,7 +836,7 @@ void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGP
         const unsigned hw = std::thread::hardware_concurrency();
         const size_t nthreads = std::min<size_t>(tasks.size(), opt.threads > 1 ? (unsigned)opt.threads : std::min<unsigned>(hw ? hw : 4u, 16u));
         std::vector<std::thread> pool;
-        for (size_t t = 1; t < nthreads; t++) pool.emplace_back(work);
+        for (size_t t = 1; t < nthreads; t++) { try { pool.emplace_back(work); } catch (const std::system_error&) { break; } }      // (no more threads to be had: the ones that started and this one do the work)
         work();
         for (std::thread& t : pool) t.join();
         lap("top-down, tasks");
