@@ -135,6 +135,8 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
        RTX_OPT_OCTANT_SORT = 32,     /* 1: general scenes, compact state: the closest-hit kernel of bounce b >= 1 fetches the rays of its sub-queue grouped by direction octant (k_shade notes a survivor's
                                         octant, a prologue of the traversal kernel counting-sorts the sub-queue's entries by it).  3: the key is the cell of the ray's ORIGIN on a 256-cell grid over the scene's box, from bounce 2.
                                         2 and 5 are measurement variants (all keys zero; hashed keys).  Never changes a result; MEASURED slower in every form: profiles/r04_octsort_ab.md.  Default 0 */
+       RTX_OPT_PARTIAL_REFIT = 37,   /* 1 (default): a transform-only commit re-derives the triangles of the instances whose transform changed and re-quantises only the nodes above them
+                                        (the first refit after a build is a full one); 0: every refit touches the whole tree */
        RTX_OPT_LDS_NODES_CLOSEST = 36, /* BVH nodes staged in LDS by the path tracer's CLOSEST-HIT launches; default -1 = auto: for trees of at most 16 MB the first three levels of the wide tree (73 nodes)
                                         while six workgroups per CU remain (the shadow launches keep RTX_OPT_LDS_NODES' choice: more workgroups, fewer nodes); 0 = as the shadow launches.  Takes effect with the next rtx_commit_scene */
        RTX_OPT_RESTIR_KEYS = 35,     /* 1 (default): after passes 1 + 2 every pixel writes what a NEIGHBOUR's test of the spatial pass reads (x1, n1, material, validity flags, M; the GI sample) into

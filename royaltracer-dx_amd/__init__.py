@@ -40,7 +40,7 @@ KERNEL_NAMES = {K_RAYGEN: "raygen", K_TRACE: "trace_closest", K_SHADE: "shade", 
 OPT_KERNEL_TIMING, OPT_PATHS_PER_BATCH, OPT_SORT_MATERIALS, OPT_LDS_NODES, OPT_SMALL_SCENE, OPT_FUSED_BOUNCE, OPT_BOUNCE_VARIANT = 1, 2, 3, 4, 5, 6, 7
 OPT_REFILL_MIN, OPT_STACK_PRIVATE, OPT_TRACE_SCHED, OPT_GPU_REFIT, OPT_BLOCKS_PER_CU, OPT_LPT_ORDER, OPT_FUSED_BVH, OPT_WORK_STEALING, OPT_COMPACT_STATE, OPT_OVERLAP_SHADOW = 8, 9, 10, 11, 12, 13, 14, 15, 16, 18
 OPT_RESTIR_WAVEFRONT, OPT_RESTIR_CHUNKS, OPT_OCCLUDER_CACHE, OPT_RESTIR_LANES, OPT_SHADE_DENSE, OPT_MERGE_RAYS, OPT_TAPER = 19, 20, 21, 22, 23, 24, 25
-OPT_BVH_REINSERT, OPT_BVH_SPLIT, OPT_ANYHIT_ORDER, OPT_RESTIR_LANE_MIN, OPT_TRACE_COUNTERS, OPT_ASYNC, OPT_OCTANT_SORT, OPT_SAMPLE_INTERLEAVE, OPT_NODE_STRIDE, OPT_RESTIR_KEYS, OPT_LDS_NODES_CLOSEST = 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36
+OPT_BVH_REINSERT, OPT_BVH_SPLIT, OPT_ANYHIT_ORDER, OPT_RESTIR_LANE_MIN, OPT_TRACE_COUNTERS, OPT_ASYNC, OPT_OCTANT_SORT, OPT_SAMPLE_INTERLEAVE, OPT_NODE_STRIDE, OPT_RESTIR_KEYS, OPT_LDS_NODES_CLOSEST, OPT_PARTIAL_REFIT = 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37
 
 
 class RtxError(RuntimeError):

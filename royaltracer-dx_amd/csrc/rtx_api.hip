@@ -38,6 +38,8 @@ struct rtx_ctx {
     SceneHost host; BuiltScene built;
     bool committed = false, camera_set = false;
     DevBuf d_nodes, d_tris, d_small, d_small_tris, d_small_poly, d_shade, d_mats, d_insts, d_lights, d_cdf, d_cam;
+    bool committed_once = false;
+    DevBuf d_inst_moved, d_tri_dirty, d_node_dirty; bool node_aabb_valid = false; int partial_refit = 1;     // partial GPU refit (RTX_OPT_PARTIAL_REFIT): node_aabb / d_scale hold the last full refit's state
     DevBuf d_objtris, d_node_aabb, d_scale;          // GPU refit: object-space vertices (uploaded on first use), per-node float boxes, max |coordinate|
     bool gpu_refit = true, device_scene_valid = false, objtris_uploaded = false;
     uint32_t refill_min = 12, trace_sched = 6, sort_materials = 0, blocks_per_cu = 0 /* 0 = auto */, occluder_cache = 0; int shade_dense = 0;       // persistent-traversal knobs (RTX_OPT_REFILL_MIN, RTX_OPT_TRACE_SCHED)
@@ -147,7 +149,8 @@ void rtx_destroy(rtx_ctx* c) {
     else (void)hipDeviceSynchronize();
     DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_small_poly, &c->d_objtris, &c->d_node_aabb, &c->d_scale, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cdf, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
                      &c->d_thr, &c->d_rad, &c->d_hit, &c->d_hitmask, &c->d_order, &c->d_pmask, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
-                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq, &c->d_halo, &c->d_own, &c->d_heads, &c->d_alt_o, &c->d_alt_d, &c->d_alt_thr, &c->d_oct[0], &c->d_oct[1], &c->d_perm, &c->d_trace_cnt};
+                     &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq, &c->d_halo, &c->d_own, &c->d_heads, &c->d_alt_o, &c->d_alt_d, &c->d_alt_thr, &c->d_oct[0], &c->d_oct[1], &c->d_perm, &c->d_trace_cnt,
+                     &c->d_nodes_wide, &c->d_rs_key_a, &c->d_rs_key_b, &c->d_inst_moved, &c->d_tri_dirty, &c->d_node_dirty};
     for (auto& A : c->rs_area) for (DevBuf* b : {&A.state, &A.hit, &A.cls, &A.fin, &A.cold, &A.occ, &A.cand, &A.sho, &A.shd, &A.pay, &A.cnt}) b->release();
     for (hipStream_t& ls : c->lane_stream) if (ls) { (void)hipStreamDestroy(ls); ls = nullptr; }
     for (DevBuf* b : all) b->release();
@@ -183,6 +186,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_PATHS_PER_BATCH: if (value < 4096) { c->err = "paths_per_batch must be >= 4096"; return RTX_ERR_INVALID; } c->paths_per_batch = (uint64_t)value; return RTX_OK;
     case RTX_OPT_SORT_MATERIALS: c->sort_materials = value != 0; c->dsc.sort_materials = c->sort_materials; return RTX_OK;
     case RTX_OPT_LDS_NODES: c->lds_nodes_opt = (int)value; c->committed = false; return RTX_OK;
+    case RTX_OPT_PARTIAL_REFIT: c->partial_refit = value != 0; return RTX_OK;
     case RTX_OPT_LDS_NODES_CLOSEST: c->lds_closest_opt = (int)value; if (c->committed) pick_lds_closest(c); return RTX_OK;
     case RTX_OPT_SMALL_SCENE: c->small_scene = value != 0; c->committed = false; return RTX_OK;
     case RTX_OPT_FUSED_BOUNCE: c->fused = value != 0; return RTX_OK;
@@ -265,8 +269,10 @@ static int finalise_scene(rtx_ctx* c);
 
 int rtx_commit_scene(rtx_ctx* c) {
     BIND(c);
-    for (size_t i = 0; i < c->host.matids.size(); i++)
-        if (c->host.matids[i] >= c->host.mats128.size() / 32) { c->err = "commit: material id out of range"; return RTX_ERR_INVALID; }
+    if (c->host.topo_dirty || c->host.mats_dirty || !c->committed_once)      // (a transform-only commit changes neither the ids nor the table: not 11 M comparisons per frame)
+        for (size_t i = 0; i < c->host.matids.size(); i++)
+            if (c->host.matids[i] >= c->host.mats128.size() / 32) { c->err = "commit: material id out of range"; return RTX_ERR_INVALID; }
+    c->committed_once = true;
     BuiltScene& B = c->built;
     int r;
     // Transform-only commit of a scene that is already resident (and not a tiny one, whose pre-test records depend on world
@@ -284,13 +290,23 @@ int rtx_commit_scene(rtx_ctx* c) {
             if ((r = upload(c, c->d_objtris, B.objtris))) return r; c->objtris_uploaded = true;
         }
         HIPCHK(c, c->d_node_aabb.ensure(B.nodes8.size() * 32));
-        const std::vector<uint32_t> one(1, 0x3f800000u);      // scale starts at 1.0 like the host's max(1, |coordinates|)
-        if ((r = upload(c, c->d_scale, one))) return r;
+        // the first refit after a build is a full one (it fills node_aabb); later ones touch the moved instances only, unless every instance moved anyway
+        size_t nmoved = 0; for (uint32_t m : B.inst_moved) nmoved += m;
+        const bool partial = c->partial_refit && c->node_aabb_valid && B.inst_moved.size() == B.insts.size() && nmoved < B.insts.size();
+        if (partial) {
+            if ((r = upload(c, c->d_inst_moved, B.inst_moved))) return r;
+            HIPCHK(c, c->d_tri_dirty.ensure(B.tris8.size())); HIPCHK(c, c->d_node_dirty.ensure(B.nodes8.size()));
+        } else {
+            const std::vector<uint32_t> one(1, 0x3f800000u);      // scale starts at 1.0 like the host's max(1, |coordinates|)
+            if ((r = upload(c, c->d_scale, one))) return r;
+        }
         launch_refit(c->stream, (Node8GPU*)c->d_nodes.p, B.level_start8.data(), (uint32_t)B.level_start8.size() - 1, (TriGPU*)c->d_tris.p, (uint32_t)B.tris8.size(),
-                     (const TriShade*)c->d_shade.p, (const InstGPU*)c->d_insts.p, (const F4*)c->d_objtris.p, (F4*)c->d_node_aabb.p, (uint32_t*)c->d_scale.p);
+                     (const TriShade*)c->d_shade.p, (const InstGPU*)c->d_insts.p, (const F4*)c->d_objtris.p, (F4*)c->d_node_aabb.p, (uint32_t*)c->d_scale.p,
+                     partial ? (const uint32_t*)c->d_inst_moved.p : nullptr, (uint8_t*)c->d_tri_dirty.p, (uint8_t*)c->d_node_dirty.p);
         HIPCHK(c, hipGetLastError());
+        c->node_aabb_valid = true;
     } else {
-        c->device_scene_valid = false; c->objtris_uploaded = false;
+        c->device_scene_valid = false; c->objtris_uploaded = false; c->node_aabb_valid = false;
         if (!c->host.build(B)) { c->err = c->host.err; return RTX_ERR_INVALID; }
         if ((r = upload_built(c))) return r;
     }
@@ -308,7 +324,7 @@ int rtx_save_scene_cache(rtx_ctx* c, const char* path) {
 int rtx_load_scene_cache(rtx_ctx* c, const char* path) {
     BIND(c);
     if (!load_scene_cache(path, c->host, c->built, c->err)) return RTX_ERR_INVALID;     // on failure the previous scene is untouched
-    c->committed = false; c->device_scene_valid = false; c->objtris_uploaded = false;
+    c->committed = false; c->device_scene_valid = false; c->objtris_uploaded = false; c->node_aabb_valid = false;
     int r = upload_built(c);
     if (r) return r;
     return finalise_scene(c);

@@ -1038,16 +1038,23 @@ __device__ __forceinline__ float next_above(float x) { uint32_t b = f2u(x); if (
 __device__ __forceinline__ float sub_down(float a, float b) { return next_below(a - b); }
 __device__ __forceinline__ float sub_up(float a, float b) { return next_above(a - b); }
 
+// PARTIAL refit (round 4): `moved` != nullptr names the instances whose transform changed since the last commit.  Only their triangles are re-derived (tri_dirty[s] says
+// which leaf entries those were), and k_refit_nodes re-quantises only nodes with a dirty triangle or a dirty child (node_dirty), taking the float box of a clean child
+// from node_aabb, which the previous refit left there.  A frame that moves one small instance of a large scene (the reference's own loop: Renderer.cpp:444-452) then costs
+// the launches, not the scene.  The padding scale only grows in a partial refit (the untouched boxes keep the padding they were built with: still conservative).
 __global__ __launch_bounds__(kBlock) void k_refit_tris(TriGPU* __restrict__ tris, uint32_t ntris, const TriShade* __restrict__ shade, const InstGPU* __restrict__ insts,
-                                                       const F4* __restrict__ objtris, uint32_t* __restrict__ scale_bits) {
+                                                       const F4* __restrict__ objtris, uint32_t* __restrict__ scale_bits, const uint32_t* __restrict__ moved, uint8_t* __restrict__ tri_dirty) {
     __shared__ uint32_t s_max;
     if (threadIdx.x == 0) s_max = 0;
     __syncthreads();
     const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
     float amax = 0.0f;
-    if (s < ntris) {
-        const uint32_t g = f2u(tris[s].v0.w);
-        const float* M = insts[shade[g].inst].o2w;
+    bool work = s < ntris;
+    uint32_t g = 0, inst = 0;
+    if (work) { g = f2u(tris[s].v0.w); inst = shade[g].inst; }
+    if (work && moved) { work = moved[inst] != 0u; tri_dirty[s] = work ? 1 : 0; }
+    if (work) {
+        const float* M = insts[inst].o2w;
         const F4 a = objtris[(size_t)g * 3], b = objtris[(size_t)g * 3 + 1], c = objtris[(size_t)g * 3 + 2];
         const f3 w0 = xform_point(M, mk3(a.x, a.y, a.z)), w1 = xform_point(M, mk3(b.x, b.y, b.z)), w2 = xform_point(M, mk3(c.x, c.y, c.z));
         const f3 e1 = w1 - w0, e2 = w2 - w0;
@@ -1062,13 +1069,23 @@ __global__ __launch_bounds__(kBlock) void k_refit_tris(TriGPU* __restrict__ tris
 }
 
 __global__ __launch_bounds__(kBlock) void k_refit_nodes(Node8GPU* __restrict__ nodes, uint32_t first, uint32_t count, const TriGPU* __restrict__ tris,
-                                                        F4* __restrict__ node_aabb /* 2 per node: min, max */, const uint32_t* __restrict__ scale_bits) {
+                                                        F4* __restrict__ node_aabb /* 2 per node: min, max */, const uint32_t* __restrict__ scale_bits,
+                                                        const uint8_t* __restrict__ tri_dirty, uint8_t* __restrict__ node_dirty) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= count) return;
     const uint32_t n = first + i;
     Node8GPU N = nodes[n];
     const float pad = 2e-6f * u2f(*scale_bits);          // the host build's bvh_pad (rtx_scene_host.cpp)
     const uint32_t imask = N.e_imask >> 24;
+    if (tri_dirty) {                                      // partial refit: anything below this node touched?
+        bool dirty = false;
+        const uint32_t nint = (uint32_t)__builtin_popcount(imask);
+        for (uint32_t k = 0; k < nint; k++) dirty = dirty || node_dirty[N.child_base + k] != 0;
+        const uint32_t nleaf = (uint32_t)__builtin_popcount(N.trivalid);
+        for (uint32_t k = 0; k < nleaf; k++) dirty = dirty || tri_dirty[N.tri_base + k] != 0;
+        node_dirty[n] = dirty ? 1 : 0;
+        if (!dirty) return;                               // node_aabb[n] and the quantised node stay what the last refit made them
+    }
     float cmn[8][3], cmx[8][3];
     float bmn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, bmx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     uint32_t rank = 0, tri_at = N.tri_base, used = 0;
@@ -1306,11 +1323,12 @@ void launch_unpack_tiles(hipStream_t st, uint32_t max_blocks, const DevFrame& f,
     hipLaunchKernelGGL(k_unpack_tiles, dim3(grid_for(f.npl * nshards, max_blocks)), dim3(kBlock), 0, st, f, nshards, slabs, accum);
 }
 void launch_refit(hipStream_t st, Node8GPU* nodes, const uint32_t* level_start, uint32_t nlevels, TriGPU* tris, uint32_t ntris, const TriShade* shade,
-                  const InstGPU* insts, const F4* objtris, F4* node_aabb, uint32_t* scale_bits) {
-    if (ntris) hipLaunchKernelGGL(k_refit_tris, dim3((ntris + kBlock - 1) / kBlock), dim3(kBlock), 0, st, tris, ntris, shade, insts, objtris, scale_bits);
+                  const InstGPU* insts, const F4* objtris, F4* node_aabb, uint32_t* scale_bits, const uint32_t* moved, uint8_t* tri_dirty, uint8_t* node_dirty) {
+    if (!moved) tri_dirty = nullptr;                              // full refit
+    if (ntris) hipLaunchKernelGGL(k_refit_tris, dim3((ntris + kBlock - 1) / kBlock), dim3(kBlock), 0, st, tris, ntris, shade, insts, objtris, scale_bits, moved, tri_dirty);
     for (uint32_t l = nlevels; l-- > 0;) {                       // deepest level first: children are refitted before their parents
         const uint32_t first = level_start[l], count = level_start[l + 1] - first;
-        if (count) hipLaunchKernelGGL(k_refit_nodes, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, st, nodes, first, count, tris, node_aabb, scale_bits);
+        if (count) hipLaunchKernelGGL(k_refit_nodes, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, st, nodes, first, count, tris, node_aabb, scale_bits, (const uint8_t*)tri_dirty, node_dirty);
     }
 }
 void launch_dbg_trace(hipStream_t st, const DevScene& sc, const F4* rays, uint32_t n, int any, F4* hits) {

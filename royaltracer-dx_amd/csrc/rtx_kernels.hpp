@@ -179,7 +179,8 @@ void launch_pack_tiles(hipStream_t, uint32_t max_blocks, const DevFrame&, const 
 void launch_unpack_tiles(hipStream_t, uint32_t max_blocks, const DevFrame&, uint32_t nshards, const F4* slabs, F4* accum);
 // transform-only commit: re-derive world triangles and re-quantise the wide nodes on the GPU (level_start: host array, nlevels + 1 entries)
 void launch_refit(hipStream_t, Node8GPU* nodes, const uint32_t* level_start, uint32_t nlevels, TriGPU* tris, uint32_t ntris, const TriShade* shade,
-                  const InstGPU* insts, const F4* objtris, F4* node_aabb, uint32_t* scale_bits);
+                  const InstGPU* insts, const F4* objtris, F4* node_aabb, uint32_t* scale_bits,
+                  const uint32_t* moved = nullptr, uint8_t* tri_dirty = nullptr, uint8_t* node_dirty = nullptr);   // moved != nullptr: PARTIAL refit of the instances flagged in it (node_aabb must hold the previous refit's boxes)
 void launch_dbg_trace(hipStream_t, const DevScene&, const F4* rays, uint32_t n, int any, F4* hits);
 void launch_dbg_surface(hipStream_t, const DevScene&, const F4* rays, const F4* hits, uint32_t n, F4* out);
 void launch_dbg_bsdf_eval(hipStream_t, const DevScene&, uint32_t mat, uint32_t flags, const float* in9, uint32_t n, float* out8);

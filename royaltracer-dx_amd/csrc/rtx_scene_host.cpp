@@ -152,17 +152,29 @@ void SceneHost::build_lights(BuiltScene& B) const {
         r[8] = L.p2.x; r[9] = L.p2.y; r[10] = L.p2.z; r[11] = wn;
         r[12] = L.em[0]; r[13] = L.em[1]; r[14] = L.em[2]; memcpy(&r[15], &nl, 4);
         r[16] = total;
-        // sample-independent part of SampleLightNEE_GI (Sampler_v6.hlsl:540-545, 566-575)
+    }
+    refresh_lights(B);
+}
+// the world-space half of the light records (the sample-independent part of SampleLightNEE_GI, Sampler_v6.hlsl:540-545, 566-575) from the 80-byte records, which hold the
+// object-space corners, the instance, the weight and the CDF: all a TRANSFORM-only commit has to redo (which triangles emit, their weights and their order do not depend on
+// the instance matrices — scanning the 11 M material ids of the street scene for them again was 3 ms of every refit commit)
+void SceneHost::refresh_lights(BuiltScene& B) const {
+    B.lights.resize(B.lights80.size() / 20);
+    for (size_t i = 0; i < B.lights.size(); i++) {
+        const float* r = &B.lights80[i * 20];
+        uint32_t inst; memcpy(&inst, &r[7], 4);
+        const f3 p0 = mk3(r[0], r[1], r[2]), p1 = mk3(r[4], r[5], r[6]), p2 = mk3(r[8], r[9], r[10]);
+        const float cdf = r[3], wn = r[11];
         LightGPU& G = B.lights[i];
-        const float* M = insts[L.inst].o2w;
-        f3 xv = xform_point(M, L.p0), yv = xform_point(M, L.p1), zv = xform_point(M, L.p2);
+        const float* M = insts[inst].o2w;
+        f3 xv = xform_point(M, p0), yv = xform_point(M, p1), zv = xform_point(M, p2);
         f3 cl = cross(yv - xv, zv - xv);
         f3 nrm = normalize(cl);
         float area_l = fabsf(length(cl) * 0.5f);
         G.xv[0] = xv.x; G.xv[1] = xv.y; G.xv[2] = xv.z; G.cdf = cdf;
         G.yv[0] = yv.x; G.yv[1] = yv.y; G.yv[2] = yv.z; G.pdf_l = maxf_(kEps, wn / maxf_(area_l, kEps));
         G.zv[0] = zv.x; G.zv[1] = zv.y; G.zv[2] = zv.z; G.pad0 = 0.0f;
-        G.em[0] = L.em[0]; G.em[1] = L.em[1]; G.em[2] = L.em[2]; G.pad1 = 0.0f;
+        G.em[0] = r[12]; G.em[1] = r[13]; G.em[2] = r[14]; G.pad1 = 0.0f;
         G.nl[0] = nrm.x; G.nl[1] = nrm.y; G.nl[2] = nrm.z; G.pad2 = 0.0f;
     }
 }
@@ -170,12 +182,15 @@ void SceneHost::build_lights(BuiltScene& B) const {
 // transform-only commit on the GPU-refit path: the kernels re-derive triangles and boxes; the host re-derives what is small
 bool SceneHost::refresh_transforms(BuiltScene& B) {
     if (topo_dirty || B.insts.size() != insts.size()) { err = "refresh_transforms: topology changed"; return false; }
+    const bool mats_changed = mats_dirty;
     if (mats_dirty) build_materials(B);          // rtx_set_materials since the last commit: new table (the light list below reads the new Ke)
+    B.inst_moved.assign(insts.size(), 0u);
     for (size_t ii = 0; ii < insts.size(); ii++) {
         const InstHost& in = insts[ii];
+        B.inst_moved[ii] = memcmp(B.insts[ii].o2w, in.o2w, 64) != 0 ? 1u : 0u;
         memcpy(B.insts[ii].o2w, in.o2w, 64); memcpy(B.insts[ii].nrm, in.nrm, 64); memcpy(B.insts[ii].o2w_inv, in.o2w_inv, 64); memcpy(B.insts[ii].prev_o2w, in.prev_o2w, 64);
     }
-    build_lights(B);
+    if (mats_changed) build_lights(B); else refresh_lights(B);       // (new materials can change WHICH triangles emit: full scan)
     B.refit_count++;
     return true;
 }

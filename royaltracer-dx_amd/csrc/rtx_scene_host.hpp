@@ -61,6 +61,7 @@ struct BuiltScene {
     float total_weight = 0.0f;
     uint32_t max_depth = 0;
     uint32_t refit_count = 0;           // commits since the last full build that only refitted the boxes
+    std::vector<uint32_t> inst_moved;   // refresh_transforms: 1 = the instance's objectToWorld differs from the last commit's (the GPU refit touches the triangles and nodes of these only)
 };
 
 struct SceneHost {
@@ -82,6 +83,7 @@ struct SceneHost {
     // transform-only update of the records the GPU refit does not derive itself: instance matrices and the light list
     bool refresh_transforms(BuiltScene& out);
     void build_lights(BuiltScene& out) const;
+    void refresh_lights(BuiltScene& out) const; // the world-space half of the light records from lights80 (transform-only commits)
     void fill_objtris(BuiltScene& out) const;   // object-space triangles for the GPU refit (rtx_scene_cache.cpp: not stored in a cache file)
 };
 

@@ -1086,6 +1086,56 @@ def test_gpu_refit_large_scene_stays_conservative(rt, orc):
     c.close()
 
 
+class _TwoScenes:
+    """a large scene and a small one as ONE scene: the small one's meshes, materials and instances appended (duck-typed like rt.Scene for Context.upload / Oracle.load)"""
+    def __init__(self, big, small, place):
+        nm = len(big.materials)
+        self.materials = np.concatenate([np.asarray(big.materials, np.float32), np.asarray(small.materials, np.float32)])
+        self.meshes = list(big.meshes)
+        base = sum(len(m) for _, _, m in big.meshes)
+        for v, i, m in small.meshes:                             # Vertex.normal.w carries the mesh's base offset into the scene's materialIDs (SURVEY a4)
+            v = np.array(v, np.float32, copy=True).reshape(-1, 7); v[:, 6] = float(base)
+            self.meshes.append((v, i, np.asarray(m, np.uint32) + np.uint32(nm))); base += len(m)
+        self.instances = list(big.instances) + [(len(big.meshes) + mesh, place) for mesh, _ in small.instances]
+        self._big = big
+    def view_proj(self, aspect):
+        return self._big.view_proj(aspect)
+
+
+@pytest.mark.parametrize("partial", [1, 0])
+def test_partial_refit_of_one_small_instance_in_a_large_scene(rt, orc, golden_dir, partial):
+    """RTX_OPT_PARTIAL_REFIT (default): after the first (full) refit a transform-only commit re-derives the triangles of the MOVED instances only and re-quantises only the
+    nodes above them (clean children keep the float boxes the previous refit left in node_aabb).  A 60 k-triangle atrium with monke.obj flying through it: after every move
+    the resident tree validates on the host and the hit records of camera + random rays equal the oracle's (which rebuilds); then the atrium itself moves while monke
+    stays, and finally both — the three dirty patterns.  partial=0: every refit touches the whole tree."""
+    import os
+    big = rt.Scene.sponza_class(60000, 260)
+    small = rt.Scene.from_obj([os.path.join(golden_dir, "monke.obj")], golden_dir + "/")
+    def at(x, y, z, ang, s=0.25):
+        m = np.eye(4, dtype=np.float32); m[0, 0] = s * np.cos(ang); m[0, 2] = -s * np.sin(ang); m[2, 0] = s * np.sin(ang); m[2, 2] = s * np.cos(ang); m[1, 1] = s
+        m[3, 0], m[3, 1], m[3, 2] = x, y, z
+        return m.reshape(16)
+    sc = _TwoScenes(big, small, at(0.0, 0.3, 0.0, 0.0))
+    W, H = 96, 54
+    c = rt.Context(0); c.set_option(rt.OPT_PARTIAL_REFIT, partial); c.upload(sc, W / H)
+    o = orc.Oracle().load(sc, W / H)
+    mk = len(sc.instances) - 1
+    assert c.validate_bvh() == 0
+    moves = [(mk, at(0.2, 0.35, 0.1, 0.4)), (mk, at(-0.3, 0.5, -0.2, 1.1)), (mk, at(0.6, 0.2, 0.3, 2.0, 0.4)),
+             (0, np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0.05, 0.0, -0.03, 1]], np.float32).reshape(16)), (mk, at(0.0, 0.3, 0.0, 0.0))]
+    for k, (inst, M) in enumerate(moves):
+        c.set_instance_transform(inst, M); o.set_instance_transform(inst, M)
+        if k == 4:                                                  # the last commit moves both instances at once
+            I = np.eye(4, dtype=np.float32).reshape(16); c.set_instance_transform(0, I); o.set_instance_transform(0, I)
+        c.commit()
+        assert c.stats().bvh_refits == k + 1 and c.validate_bvh() == 0, k
+        rays = np.concatenate([o.primary_rays(rt.Params(width=W, height=H)), random_rays(20000, 90 + k, -1.5, 1.5)])
+        g, b = c.trace_closest(rays), o.trace_closest(rays, 1)
+        assert np.array_equal(bits(g), bits(b)), k
+        assert np.array_equal(c.trace_any(rays), o.trace_any(rays, 1)), k
+    c.close()
+
+
 def test_c4_sizes_4k_shards_and_stack_variants(rt, orc):
     """C4-shaped run (Sponza-class, 3840x2160, pixel-tile shards) at 1 spp: memory sizing of the queues at 8.3 M pixels,
     shard reassembly at full size, and every traversal-stack placement and wave schedule gives the same image"""
