@@ -809,6 +809,23 @@ def test_node_stride_128_changes_nothing_also_after_a_refit(rt, golden_dir):
     assert out[0] == out[1]
 
 
+def test_staged_node_count_per_kind_of_launch_changes_nothing(rt):
+    """RTX_OPT_LDS_NODES_CLOSEST: the path tracer's closest-hit launches may stage another number of BVH nodes in LDS than the shadow launches (DevScene goes by value per
+    launch); switched on a live context, the frame is the same bits for 0 (as the shadow launches), 9, 40, 73 and the automatic choice."""
+    import hashlib
+    sc = rt.Scene.sponza_class(60000, 260)
+    W, H = 320, 180
+    p = rt.Params(width=W, height=H, spp=4, max_bounces=6, nee_samples=1, flags=1, frame_seed=4)
+    c = rt.Context(0); c.upload(sc, W / H)
+    out = []
+    for n in (-1, 0, 9, 40, 73, -1):
+        c.set_option(rt.OPT_LDS_NODES_CLOSEST, n)
+        c.clear(W, H); c.render(p); st = c.stats()
+        out.append(((st.rays_primary, st.rays_extension, st.rays_shadow), hashlib.sha1(c.read_accum().tobytes()).hexdigest()))
+    assert all(o == out[0] for o in out)
+    c.close()
+
+
 def test_trace_counters_report_work_per_ray_and_change_nothing(rt):
     """RTX_OPT_TRACE_COUNTERS (bench.py: extra.*.work_per_ray): the persistent traversal kernels tally node steps and triangle tests; same image and ray counts with the
     counters on, and per closest-hit ray the tally lies within a few per cent of the one-ray-per-thread statistics kernel's (rtx_debug_trace_stats on the frame's own primary
