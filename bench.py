@@ -249,7 +249,9 @@ def time_extra(rt, dev_index, workload, steps=2):
     scene, source = make_scene(rt, kind)
     ctx = rt.Context(dev_index)
     try:
+        t_up = time.perf_counter()
         ctx.upload(scene, W / H)
+        commit_s = time.perf_counter() - t_up                   # scene hand-over + rtx_commit_scene (BVH build) + upload
         ctx.clear(W, H)
         params = rt.Params(width=W, height=H, spp=spp, sample_base=1, max_bounces=bounces, nee_samples=nee, rr_start=3, frame_seed=1, flags=flags)
         ctx.render(params)                                        # warm-up (allocations)
@@ -273,6 +275,13 @@ def time_extra(rt, dev_index, workload, steps=2):
         dt_timed = time.perf_counter() - t1
         roof = roofline_record(rt, workload, kms, None, kl, rays, float(W) * H * spp * steps, steps)
         work = trace_work(rt, ctx, params, roof)
+        # what a transform-only commit (instance 0 moved: GPU refit of the resident tree) costs, wall time; the first one uploads the object-space triangles
+        refit = []
+        for k in range(4):
+            m = np.eye(4, dtype=np.float32); m[3, 0] = 0.001 * (k + 1)
+            ctx.set_instance_transform(0, m.reshape(16))
+            t2 = time.perf_counter(); ctx.commit(); refit.append((time.perf_counter() - t2) * 1e3)
+        refit_ms = round(min(refit[1:]), 3)
         rec = {"ms_per_frame": round(dt * 1e3 / steps, 3), "Mrays_s": round(float(rays.sum()) / dt / 1e6, 1), "triangles": int(scene.num_triangles), "scene": source,
                "rays_per_frame": int(rays.sum() / steps), "dominant_kernel": roof["kernel"] if roof else None,
                "frac": roof["frac"] if roof else None, "bound": roof["bound"] if roof else None,
@@ -280,6 +289,7 @@ def time_extra(rt, dev_index, workload, steps=2):
                "lanes_per_inst": roof.get("compute", {}).get("lanes_per_inst") if roof else None,
                "kernel_ms_per_frame": {k: round(v / steps, 3) for k, v in roof["kernel_ms_by_class"].items()} if roof else None,
                "work_per_ray": work,
+               "commit_s": round(commit_s, 3), "refit_commit_ms": refit_ms,
                "ms_per_frame_kernels_timed": round(dt_timed * 1e3 / steps, 3),
                "note": "ms_per_frame / Mrays_s: kernel timing off (shadow rays of bounce b overlap the closest-hit rays of bounce b + 1); kernel_ms_per_frame, frac: a second pass with per-kernel HIP events, which runs the launches one after the other"}
         return rec
