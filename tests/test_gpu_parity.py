@@ -1306,7 +1306,8 @@ def test_random_tiny_scenes_fused_path_equals_oracle(rt, orc):
 def test_random_midsize_scenes_general_path_and_refit_equal_oracle(rt, orc):
     """fuzz of the general BVH kernels on random scenes of 65 ... 3000 triangles: image, ray counts, closest-hit queries, then a
     transform-only commit of one instance (mirroring, non-uniform scale) through the GPU refit and the host refit; the oracle rebuilds.
-    (600 scenes pass with RTX_FUZZ_SCENES=600.)"""
+    (600 scenes pass with RTX_FUZZ_SCENES=600.  Round 4: RTX_FUZZ_SEED=200000 RTX_FUZZ_SCENES=1500 over all five random tests reported ONE mismatch — seed 817, host-refit
+    context — in the first of three identical runs and none in the other two nor in isolation (tools/repro_fuzz.py); the loop now records WHICH comparison differs.)"""
     W, H = 48, 32
     bad = []
     for seed in range(int(os.environ.get("RTX_FUZZ_SCENES", "12"))):
@@ -1325,14 +1326,18 @@ def test_random_midsize_scenes_general_path_and_refit_equal_oracle(rt, orc):
             c = rt.Context(0); c.set_option(rt.OPT_GPU_REFIT, refit); c.upload(sc, W / H)
             assert c.stats().triangles > 64
             c.clear(W, H); c.render(p); st = c.stats()
-            ok = np.array_equal(bits(c.read_accum()), bits(oa)) and (st.rays_primary, st.rays_extension, st.rays_shadow) == oc \
-                and np.array_equal(bits(c.trace_closest(rays)), bits(ob))
+            why = []
+            if not np.array_equal(bits(c.read_accum()), bits(oa)): why.append("image")
+            if (st.rays_primary, st.rays_extension, st.rays_shadow) != oc: why.append(f"counts {(st.rays_primary, st.rays_extension, st.rays_shadow)} != {oc}")
+            if not np.array_equal(bits(c.trace_closest(rays)), bits(ob)): why.append("closest")
             c.set_instance_transform(inst, M2); c.commit()
             c.clear(W, H); c.render(p); st2 = c.stats()
-            ok = ok and np.array_equal(bits(c.read_accum()), bits(oa2)) and (st2.rays_primary, st2.rays_extension, st2.rays_shadow) == oc2 and c.validate_bvh() == 0
+            if not np.array_equal(bits(c.read_accum()), bits(oa2)): why.append("image after the move")
+            if (st2.rays_primary, st2.rays_extension, st2.rays_shadow) != oc2: why.append(f"counts after the move {(st2.rays_primary, st2.rays_extension, st2.rays_shadow)} != {oc2}")
+            if c.validate_bvh() != 0: why.append("validate")
             c.close()
-            if not ok:
-                bad.append((seed, refit))
+            if why:
+                bad.append((seed, refit, why))
     assert not bad, f"scenes that differ from the oracle: {bad}"
 
 
