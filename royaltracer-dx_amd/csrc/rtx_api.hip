@@ -39,6 +39,7 @@ struct rtx_ctx {
     bool committed = false, camera_set = false;
     DevBuf d_nodes, d_tris, d_small, d_small_tris, d_small_poly, d_shade, d_mats, d_insts, d_lights, d_cdf, d_cam;
     bool committed_once = false;
+    std::vector<float> h_cdf; std::vector<uint32_t> h_one;     // host sources of small asynchronous uploads
     DevBuf d_inst_moved, d_tri_dirty, d_node_dirty; bool node_aabb_valid = false; int partial_refit = 1;     // partial GPU refit (RTX_OPT_PARTIAL_REFIT): node_aabb / d_scale hold the last full refit's state
     DevBuf d_objtris, d_node_aabb, d_scale;          // GPU refit: object-space vertices (uploaded on first use), per-node float boxes, max |coordinate|
     bool gpu_refit = true, device_scene_valid = false, objtris_uploaded = false;
@@ -246,7 +247,8 @@ int rtx_set_instance_transform(rtx_ctx* c, uint32_t inst, const float o2w[16]) {
 
 static int upload_lights(rtx_ctx* c) {         // the light records and their CDF as a dense float array (DevScene::cdf)
     const BuiltScene& B = c->built;
-    std::vector<float> cdf(B.lights.size());
+    std::vector<float>& cdf = c->h_cdf;           // (a member: the source of an asynchronous copy must outlive the call)
+    cdf.resize(B.lights.size());
     for (size_t i = 0; i < cdf.size(); i++) cdf[i] = B.lights[i].cdf;
     int r = upload(c, c->d_lights, B.lights);
     if (r) return r;
@@ -297,8 +299,8 @@ int rtx_commit_scene(rtx_ctx* c) {
             if ((r = upload(c, c->d_inst_moved, B.inst_moved))) return r;
             HIPCHK(c, c->d_tri_dirty.ensure(B.tris8.size())); HIPCHK(c, c->d_node_dirty.ensure(B.nodes8.size()));
         } else {
-            const std::vector<uint32_t> one(1, 0x3f800000u);      // scale starts at 1.0 like the host's max(1, |coordinates|)
-            if ((r = upload(c, c->d_scale, one))) return r;
+            c->h_one.assign(1, 0x3f800000u);                       // scale starts at 1.0 like the host's max(1, |coordinates|)
+            if ((r = upload(c, c->d_scale, c->h_one))) return r;
         }
         launch_refit(c->stream, (Node8GPU*)c->d_nodes.p, B.level_start8.data(), (uint32_t)B.level_start8.size() - 1, (TriGPU*)c->d_tris.p, (uint32_t)B.tris8.size(),
                      (const TriShade*)c->d_shade.p, (const InstGPU*)c->d_insts.p, (const F4*)c->d_objtris.p, (F4*)c->d_node_aabb.p, (uint32_t*)c->d_scale.p,
