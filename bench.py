@@ -119,6 +119,62 @@ def spawn_ranks(n, argv):
     return worst
 
 
+def step_stats(ms):
+    """min / median / max / mean of per-step times: a 20-step MEAN cannot tell a slow box from one disturbed step"""
+    a = np.asarray(ms, dtype=np.float64)
+    if a.size == 0:
+        return None
+    return {"min": round(float(a.min()), 3), "median": round(float(np.median(a)), 3), "max": round(float(a.max()), 3), "mean": round(float(a.mean()), 3), "n": int(a.size)}
+
+
+def gpu_env(dev_index=0):
+    """What explains box-to-box variance, read ONCE before the timed region (never inside it): shader / memory clocks in force, power cap and draw, temperatures, driver
+    and ROCm versions — from sysfs where an ordinary user may read it, else from rocm-smi.  Every field is best-effort; a missing one is simply absent."""
+    import glob, re
+    env = {}
+
+    def rd(path):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except OSError:
+            return None
+    try:
+        env["rocm"] = rd("/opt/rocm/.info/version")
+        env["amdgpu_driver"] = rd("/sys/module/amdgpu/version") or rd("/sys/module/amdgpu/srcversion")
+        env["kernel"] = os.uname().release
+        # the dev_index-th render-capable AMD card in sysfs order
+        cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if (rd(os.path.join(d, "vendor")) or "") == "0x1002" and os.path.exists(os.path.join(d, "pp_dpm_sclk")))
+        if cards:
+            d = cards[min(dev_index, len(cards) - 1)]
+            for key, f in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk"), ("fclk", "pp_dpm_fclk")):
+                t = rd(os.path.join(d, f))
+                if t:
+                    lv = [ln.strip() for ln in t.splitlines()]
+                    cur = [ln for ln in lv if ln.endswith("*")]
+                    env[key] = {"current": cur[0].rstrip("* ").split(":")[-1].strip() if cur else None, "levels": [ln.rstrip("* ").split(":")[-1].strip() for ln in lv][:8]}
+            env["perf_level"] = rd(os.path.join(d, "power_dpm_force_performance_level"))
+            for hw in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
+                for key, f, scale in (("power_cap_w", "power1_cap", 1e-6), ("power_avg_w", "power1_average", 1e-6), ("power_input_w", "power1_input", 1e-6),
+                                      ("temp_edge_c", "temp1_input", 1e-3), ("temp_junction_c", "temp2_input", 1e-3), ("temp_mem_c", "temp3_input", 1e-3)):
+                    v = rd(os.path.join(hw, f))
+                    if v and re.fullmatch(r"-?\d+", v):
+                        env[key] = round(int(v) * scale, 1)
+        if "sclk" not in env:                                  # sysfs not readable: ask the tool (a child process; nothing is exec'ed in place)
+            for cmd in (["rocm-smi", "-d", str(dev_index), "--showclocks", "--showtemp", "--showpower", "--showmaxpower", "--showperflevel", "--json"],
+                        ["amd-smi", "metric", "-g", str(dev_index), "--clock", "--power", "--temperature", "--json"]):
+                try:
+                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=20)
+                    if r.returncode == 0 and r.stdout.strip().startswith(("{", "[")):
+                        env[cmd[0].replace("-", "_")] = json.loads(r.stdout)
+                        break
+                except Exception:
+                    continue
+    except Exception as e:                                      # the bench line must survive whatever a box forbids
+        env["error"] = str(e)[:120]
+    return {k: v for k, v in env.items() if v is not None}
+
+
 def kernel_source_hash():
     """hash of the kernel sources (tools/valu_calib.py writes the same into a profile): tells whether a tracked counter profile still describes the loaded kernels"""
     import hashlib
@@ -242,7 +298,7 @@ def trace_work(rt, ctx, params, roof):
     return out
 
 
-def time_extra(rt, dev_index, workload, steps=2):
+def time_extra(rt, dev_index, workload, steps=5):
     """one BVH workload, GPU only: warm-up + `steps` timed frames on a context of its own -> small record for the JSON line"""
     import torch
     kind, W, H, spp, bounces, nee, flags = WORKLOADS[workload]
@@ -257,10 +313,10 @@ def time_extra(rt, dev_index, workload, steps=2):
         ctx.render(params)                                        # warm-up (allocations)
         # frame time first, as a caller gets it (kernel timing off: the shadow-ray kernel of a bounce overlaps the closest-hit kernel of the next) ...
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        t0 = time.perf_counter(); per_step = []
         for i in range(steps):
             params.frame_seed = 2 + i
-            ctx.render(params)
+            ts = time.perf_counter(); ctx.render(params); per_step.append((time.perf_counter() - ts) * 1e3)       # rtx_render returns after its own stream synchronise
         dt = time.perf_counter() - t0
         # ... then the same frames once more with per-kernel HIP events (no overlap: a launch needs the GPU to itself to have a duration)
         ctx.set_option(rt.OPT_KERNEL_TIMING, 1)
@@ -282,7 +338,7 @@ def time_extra(rt, dev_index, workload, steps=2):
             ctx.set_instance_transform(0, m.reshape(16))
             t2 = time.perf_counter(); ctx.commit(); refit.append((time.perf_counter() - t2) * 1e3)
         refit_ms = round(min(refit[1:]), 3)
-        rec = {"ms_per_frame": round(dt * 1e3 / steps, 3), "Mrays_s": round(float(rays.sum()) / dt / 1e6, 1), "triangles": int(scene.num_triangles), "scene": source,
+        rec = {"ms_per_frame": round(dt * 1e3 / steps, 3), "ms_per_frame_stats": step_stats(per_step), "Mrays_s": round(float(rays.sum()) / dt / 1e6, 1), "triangles": int(scene.num_triangles), "scene": source,
                "rays_per_frame": int(rays.sum() / steps), "dominant_kernel": roof["kernel"] if roof else None,
                "frac": roof["frac"] if roof else None, "bound": roof["bound"] if roof else None,
                "compute_frac": roof.get("compute", {}).get("frac") if roof else None,
@@ -323,9 +379,9 @@ def time_restir(rt, dev_index, kind, frames=6):
         for f in range(2):
             ctx.render_restir(p.copy(frame_seed=1 + f))          # allocations + a history for the temporal pass
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        t0 = time.perf_counter(); per_step = []
         for f in range(frames):
-            ctx.render_restir(p.copy(frame_seed=3 + f))
+            ts = time.perf_counter(); ctx.render_restir(p.copy(frame_seed=3 + f)); per_step.append((time.perf_counter() - ts) * 1e3)
         dt = time.perf_counter() - t0
         ctx.set_option(rt.OPT_KERNEL_TIMING, 1)
         kms = np.zeros(rt.K_COUNT); rays = np.zeros(3)
@@ -342,7 +398,7 @@ def time_restir(rt, dev_index, kind, frames=6):
         alg = {"trace_closest": 48.0 * (rays[0] + rays[1]) / frames, "trace_shadow": 48.0 * rays[2] / frames, "shade": float(px_bytes) * W * H}
         frac = alg[dom] / (by[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS if dom in alg else None
         frame_alg = (224.0 * rays[1] + 96.0 * rays[2]) / frames + float(px_bytes) * W * H            # the path tracer's per-ray prices + the records
-        return {"ms_per_frame": round(dt * 1e3 / frames, 3), "Mrays_s": round(float(rays.sum()) / frames / (dt / frames) / 1e6, 1), "triangles": int(scene.num_triangles), "scene": source,
+        return {"ms_per_frame": round(dt * 1e3 / frames, 3), "ms_per_frame_stats": step_stats(per_step), "Mrays_s": round(float(rays.sum()) / frames / (dt / frames) / 1e6, 1), "triangles": int(scene.num_triangles), "scene": source,
                 "rays_per_frame": {"primary": int(rays[0] / frames), "extension": int(rays[1] / frames), "shadow": int(rays[2] / frames)},
                 "kernel_ms_per_frame": {k: round(v, 3) for k, v in by.items()}, "dominant_kernel": dom, "frac": round(frac, 5) if frac else None,
                 "frame_frac": round(frame_alg / (dt / frames) / 1e9 / HBM_PEAK_GBS, 5),
@@ -440,10 +496,15 @@ def main():
         frame(i)
     kms = np.zeros(rt.K_COUNT); kitems = np.zeros(rt.K_COUNT); klaunch = np.zeros(rt.K_COUNT)
     rays = np.zeros(3)
+    env = gpu_env(dev_index) if rank == 0 else None            # clocks / power / temperature / versions: once, BEFORE the timed region
+    # per-step times from events on the stream the frames run on (recording an event costs no synchronise; they are read after the closing barrier)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        ev[i][0].record(stream)
         st = frame(args.warmup + i)
+        ev[i][1].record(stream)
         kms += np.array(st.kernel_ms[:]); kitems += np.array(st.kernel_items[:], dtype=np.float64); klaunch += np.array(st.kernel_launches[:], dtype=np.float64)
         rays += np.array([st.rays_primary, st.rays_extension, st.rays_shadow], dtype=np.float64)
     barrier()
@@ -457,6 +518,7 @@ def main():
         dt_ranks = list(sharding.sum_over_ranks(dist, per, cdev))
     ms_per_step = dt_max * 1e3 / max(args.steps, 1)
     value = float(rays_all.sum()) / dt_max / 1e6 if dt_max > 0 else 0.0
+    step_ms = [a.elapsed_time(b) for a, b in ev]               # this rank's frames, GPU time on the frames' stream
 
     if rank == 0:
         sha = None
@@ -522,6 +584,9 @@ def main():
         out = {"metric": "Mrays/s + ms/frame at 1080p, 8-bounce Cornell Box" if kind == "cornell" else f"Mrays/s + ms/frame, {args.workload}",
                "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "ms_per_step_by_rank": [round(t * 1e3 / max(args.steps, 1), 3) for t in dt_ranks],
+               "ms_per_step_min": step_stats(step_ms)["min"] if step_ms else None, "ms_per_step_median": step_stats(step_ms)["median"] if step_ms else None,
+               "ms_per_step_stats": dict(step_stats(step_ms), source="HIP events around every step on rank 0's stream (ms_per_step itself is wall time over all steps, max over ranks)") if step_ms else None,
+               "env": env,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f32", "data": "asset (assets/*.obj loaded through the OBJ / MTL reader)" if scene_source.startswith("asset:") else "synthetic",
                "config": {"workload": args.workload, "scene": scene_source, "width": W, "height": H, "spp": spp,

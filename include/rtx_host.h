@@ -17,6 +17,10 @@ typedef struct rtxh_scene rtxh_scene;
 rtxh_scene* rtxh_scene_cornell(void);                                      /* SURVEY §8d Cornell Box, 32 triangles */
 rtxh_scene* rtxh_scene_sponza_class(uint32_t target_tris, uint32_t seed);  /* C3/C4 */
 rtxh_scene* rtxh_scene_bistro_class(uint32_t target_tris, uint32_t seed);  /* C5 */
+/* the same two scenes with the triangle-size distribution of the real assets (walls of a few large triangles beside millimetre ornament, long thin trims, overlapping
+   cloth, foliage; host/Scenes.h): what BVH-builder quality is measured on */
+rtxh_scene* rtxh_scene_sponza_class_hard(uint32_t target_tris, uint32_t seed);
+rtxh_scene* rtxh_scene_bistro_class_hard(uint32_t target_tris, uint32_t seed);
 /* files: nfiles OBJ paths, each loaded through ObjLoader::loadObjFile (ObjLoader.h:393-495) as the reference's
    Renderer does (Renderer.cpp:363-407); returns NULL on parse error (message via rtxh_last_error) */
 rtxh_scene* rtxh_scene_from_obj(const char* const* files, uint32_t nfiles, const char* mtl_dir);

@@ -230,7 +230,7 @@ struct orc_ctx {
     uint32_t* matids; uint32_t nmatids;
     inst_t* insts; uint32_t ninst;
     /* flattened world-space triangles */
-    uint32_t ntri; float* wtri; uint32_t* tri_inst; uint32_t* tri_prim;
+    uint32_t ntri; float* wtri; float* tri_floor; uint32_t* tri_inst; uint32_t* tri_prim;   /* tri_floor: the hit definition's determinant floor per triangle (tri_det_floor) */
     /* lights (80-byte records as 20 floats) */
     float* lights; uint32_t nlights; float total_weight;
     /* bvh */
@@ -246,7 +246,7 @@ void orc_destroy(orc_ctx* c) {
     free(c->mats); free(c->mopt);
     for (uint32_t i = 0; i < c->nmesh; i++) { free(c->meshes[i].verts); free(c->meshes[i].idx); }
     free(c->meshes); free(c->matids); free(c->insts);
-    free(c->wtri); free(c->tri_inst); free(c->tri_prim); free(c->lights); free(c->nodes); free(c->order);
+    free(c->wtri); free(c->tri_floor); free(c->tri_inst); free(c->tri_prim); free(c->lights); free(c->nodes); free(c->order);
     free(c);
 }
 int orc_set_threads(orc_ctx* c, int n) { c->nthreads = n; return 0; }
@@ -413,12 +413,14 @@ static uint32_t build_node(orc_ctx* c, uint32_t first, uint32_t count, float pad
     return id;
 }
 
+static inline float tri_det_floor(const float* t9);
 int orc_commit(orc_ctx* c) {
     uint32_t nt = 0;
     for (uint32_t i = 0; i < c->ninst; i++) { c->insts[i].tri_base = nt; nt += c->meshes[c->insts[i].mesh].nidx / 3; }
-    free(c->wtri); free(c->tri_inst); free(c->tri_prim); free(c->nodes); free(c->order);
+    free(c->wtri); free(c->tri_floor); free(c->tri_inst); free(c->tri_prim); free(c->nodes); free(c->order);
     c->ntri = nt;
     c->wtri = (float*)malloc((size_t)(nt ? nt : 1) * 36);
+    c->tri_floor = (float*)malloc((size_t)(nt ? nt : 1) * 4);
     c->tri_inst = (uint32_t*)malloc((size_t)(nt ? nt : 1) * 4);
     c->tri_prim = (uint32_t*)malloc((size_t)(nt ? nt : 1) * 4);
     float scale = 1.0f;
@@ -432,6 +434,7 @@ int orc_commit(orc_ctx* c) {
                 scale = maxf(scale, maxf(fabsf(w.x), maxf(fabsf(w.y), fabsf(w.z))));
             }
             c->tri_inst[g] = i; c->tri_prim[g] = t;
+            c->tri_floor[g] = tri_det_floor(c->wtri + (size_t)g * 9);
         }
     }
     build_lights(c);
@@ -462,13 +465,22 @@ int orc_get_lights(orc_ctx* c, void* out80, uint32_t max_count) {
 typedef struct { float t, u, v; uint32_t prim; } hit_t;
 
 /* Moeller-Trumbore, no culling (geometry opaque, RAY_FLAG_NONE).  The BVH format and the intersection
-   arithmetic of DXR are driver-opaque; this fixed operation order IS the definition both backends share. */
-static inline int tri_hit(v3 o, v3 d, const float* t9, float tmin, float tmax, float* to, float* uo, float* vo) {
+   arithmetic of DXR are driver-opaque; this fixed operation order IS the definition both backends share.
+   det_floor (DEVIATION from plain Moeller-Trumbore, which only excludes det == 0; csrc/rtx_math.hpp: tri_det_floor): det = -d . (e1 x e2) is rounding noise — at most
+   ~7 ulp(|e1| |e2|) for a unit d — when the ray lies in the triangle's plane, and u, v, t are then 0 / 0: u = v = -0 is accepted with an arbitrary t, a "hit" outside every
+   bounding volume that brute force reports and a BVH culls or not depending on its boxes.  A triangle is hit only if |det| > 2^-16 |e1| |e2| (32 x that bound of 2^-21 |e1| |e2|). */
+#define DET_REL 1.52587890625e-05f
+static inline float tri_det_floor(const float* t9) {
+    v3 v0 = V3(t9[0], t9[1], t9[2]);
+    v3 e1 = sub3(V3(t9[3], t9[4], t9[5]), v0), e2 = sub3(V3(t9[6], t9[7], t9[8]), v0);
+    return DET_REL * (sqrtf(dot3(e1, e1)) * sqrtf(dot3(e2, e2)));
+}
+static inline int tri_hit(v3 o, v3 d, const float* t9, float det_floor, float tmin, float tmax, float* to, float* uo, float* vo) {
     v3 v0 = V3(t9[0], t9[1], t9[2]);
     v3 e1 = sub3(V3(t9[3], t9[4], t9[5]), v0), e2 = sub3(V3(t9[6], t9[7], t9[8]), v0);
     v3 p = cross3(d, e2);
     float det = dot3(e1, p);
-    if (det == 0.0f) return 0;
+    if (!(fabsf(det) > det_floor)) return 0;
     float inv = 1.0f / det;
     v3 s = sub3(o, v0);
     float u = dot3(s, p) * inv;
@@ -489,7 +501,7 @@ static hit_t closest_brute(const orc_ctx* c, v3 o, v3 d, float tmin, float tmax)
     hit_t h = {tmax, 0, 0, MISS_PRIM};
     for (uint32_t i = 0; i < c->ntri; i++) {
         float t, u, v;
-        if (tri_hit(o, d, c->wtri + (size_t)i * 9, tmin, tmax, &t, &u, &v)) closest_update(&h, t, u, v, i);
+        if (tri_hit(o, d, c->wtri + (size_t)i * 9, c->tri_floor[i], tmin, tmax, &t, &u, &v)) closest_update(&h, t, u, v, i);
     }
     return h;
 }
@@ -520,14 +532,14 @@ static hit_t closest_bvh(const orc_ctx* c, v3 o, v3 d, float tmin, float tmax) {
         if (n->count) {
             for (uint32_t i = 0; i < n->count; i++) {
                 uint32_t g = c->order[n->first + i]; float t, u, v;
-                if (tri_hit(o, d, c->wtri + (size_t)g * 9, tmin, tmax, &t, &u, &v)) closest_update(&h, t, u, v, g);
+                if (tri_hit(o, d, c->wtri + (size_t)g * 9, c->tri_floor[g], tmin, tmax, &t, &u, &v)) closest_update(&h, t, u, v, g);
             }
         } else { stack[sp++] = n->left; stack[sp++] = n->right; }
     }
     return h;
 }
 static int any_brute(const orc_ctx* c, v3 o, v3 d, float tmin, float tmax) {
-    for (uint32_t i = 0; i < c->ntri; i++) { float t, u, v; if (tri_hit(o, d, c->wtri + (size_t)i * 9, tmin, tmax, &t, &u, &v)) return 1; }
+    for (uint32_t i = 0; i < c->ntri; i++) { float t, u, v; if (tri_hit(o, d, c->wtri + (size_t)i * 9, c->tri_floor[i], tmin, tmax, &t, &u, &v)) return 1; }
     return 0;
 }
 static int any_bvh(const orc_ctx* c, v3 o, v3 d, float tmin, float tmax) {
@@ -540,7 +552,7 @@ static int any_bvh(const orc_ctx* c, v3 o, v3 d, float tmin, float tmax) {
         if (n->count) {
             for (uint32_t i = 0; i < n->count; i++) {
                 float t, u, v;
-                if (tri_hit(o, d, c->wtri + (size_t)c->order[n->first + i] * 9, tmin, tmax, &t, &u, &v)) return 1;
+                if (tri_hit(o, d, c->wtri + (size_t)c->order[n->first + i] * 9, c->tri_floor[c->order[n->first + i]], tmin, tmax, &t, &u, &v)) return 1;
             }
         } else { stack[sp++] = n->left; stack[sp++] = n->right; }
     }

@@ -135,6 +135,8 @@ _sig("rtx_debug_tea", C.c_int, _vp, _u32p, _u32, _vp)
 _sig("rtxh_scene_cornell", _vp)
 _sig("rtxh_scene_sponza_class", _vp, _u32, _u32)
 _sig("rtxh_scene_bistro_class", _vp, _u32, _u32)
+_sig("rtxh_scene_sponza_class_hard", _vp, _u32, _u32)
+_sig("rtxh_scene_bistro_class_hard", _vp, _u32, _u32)
 _sig("rtxh_scene_from_obj", _vp, C.POINTER(C.c_char_p), _u32, C.c_char_p)
 _sig("rtxh_scene_free", None, _vp)
 _sig("rtxh_scene_save", C.c_int, _vp, C.c_char_p)
@@ -260,12 +262,13 @@ class Scene:
         return cls(lib.rtxh_scene_cornell())
 
     @classmethod
-    def sponza_class(cls, target_tris=262144, seed=260):
-        return cls(lib.rtxh_scene_sponza_class(target_tris, seed))
+    def sponza_class(cls, target_tris=262144, seed=260, hard=False):
+        """the Sponza-class atrium; hard=True: the size distribution of the real asset (host/Scenes.h)"""
+        return cls((lib.rtxh_scene_sponza_class_hard if hard else lib.rtxh_scene_sponza_class)(target_tris, seed))
 
     @classmethod
-    def bistro_class(cls, target_tris=3800000, seed=3800):
-        return cls(lib.rtxh_scene_bistro_class(target_tris, seed))
+    def bistro_class(cls, target_tris=3800000, seed=3800, hard=False):
+        return cls((lib.rtxh_scene_bistro_class_hard if hard else lib.rtxh_scene_bistro_class)(target_tris, seed))
 
     @classmethod
     def from_obj(cls, files, mtl_dir):

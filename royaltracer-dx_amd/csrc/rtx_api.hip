@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -16,6 +17,10 @@ using namespace rtx;
 // the native multi-GPU frame (host/MultiGpu.cpp) that ask for their slab sizes at once never write the same string; rtx_last_error(NULL) reads the caller's own
 static thread_local std::string g_create_err;
 
+// RTX_DEBUG_POISON=<byte> in the environment (tooling: the hunt for reads of memory no kernel of the frame wrote): every fresh device allocation is filled with that byte —
+// 255 makes stale floats NaN and stale indices huge, 127 large finite values — so that a result which depends on what a previous context (or process) left in HBM turns
+// from a once-in-20 000 mismatch into a reproducible one.  Unset (the product): allocations stay as hipMalloc returns them.
+static int poison_byte() { static const int b = [] { const char* e = getenv("RTX_DEBUG_POISON"); return e && *e ? atoi(e) & 255 : -1; }(); return b; }
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
     hipError_t ensure(size_t n) {
@@ -23,7 +28,7 @@ struct DevBuf {
         if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
         if (!n) n = 16;
         hipError_t e = hipMalloc(&p, n);
-        if (e == hipSuccess) bytes = n;
+        if (e == hipSuccess) { bytes = n; if (poison_byte() >= 0) e = hipMemset(p, poison_byte(), n); }
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
@@ -39,6 +44,7 @@ struct rtx_ctx {
     bool committed = false, camera_set = false;
     DevBuf d_nodes, d_tris, d_small, d_small_tris, d_small_poly, d_shade, d_mats, d_insts, d_lights, d_cdf, d_cam;
     bool committed_once = false;
+    int upload_scopes = 0;                                      // UploadScope nesting: upload() synchronises unless a scope will
     std::vector<float> h_cdf; std::vector<uint32_t> h_one;     // host sources of small asynchronous uploads
     DevBuf d_inst_moved, d_tri_dirty, d_node_dirty; bool node_aabb_valid = false; int partial_refit = 1;     // partial GPU refit (RTX_OPT_PARTIAL_REFIT): node_aabb / d_scale hold the last full refit's state
     DevBuf d_objtris, d_node_aabb, d_scale;          // GPU refit: object-space vertices (uploaded on first use), per-node float boxes, max |coordinate|
@@ -108,9 +114,21 @@ static int finish_render(rtx_ctx* c);
 #define BIND_NOWAIT(c) do { if (!(c)) return RTX_ERR_INVALID; HIPCHK(c, hipSetDevice((c)->device)); } while (0)
 #define BIND(c) do { BIND_NOWAIT(c); if ((c)->pending.active) { const int r_ = finish_render(c); if (r_ != RTX_OK) return r_; } } while (0)
 
+// EVERY host-to-device copy of a host array goes through upload().  The source of an asynchronous copy from pageable memory must stay valid until the stream has passed
+// the copy (above a few MB the runtime pins the user pages and the DMA engine reads them directly), so upload() is safe by construction: it SYNCHRONISES the stream before
+// it returns — unless the caller holds an UploadScope, which batches several uploads behind ONE synchronise in its destructor, i.e. on every way out of the scope, early
+// error returns included.  Inside a scope only sources that outlive it may be uploaded (context members: `built`, `h_cdf`, `h_one`); a block-local vector is uploaded
+// without one (the ReSTIR pixel lists: once per image size).
+struct UploadScope {
+    rtx_ctx* c;
+    explicit UploadScope(rtx_ctx* c_) : c(c_) { c->upload_scopes++; }
+    ~UploadScope() { if (--c->upload_scopes == 0 && c->stream) (void)hipStreamSynchronize(c->stream); }
+    UploadScope(const UploadScope&) = delete; UploadScope& operator=(const UploadScope&) = delete;
+};
 template <class T> static int upload(rtx_ctx* c, DevBuf& b, const std::vector<T>& v) {
     HIPCHK(c, b.ensure(v.size() * sizeof(T)));
     if (!v.empty()) HIPCHK(c, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    if (!v.empty() && c->upload_scopes == 0) HIPCHK(c, hipStreamSynchronize(c->stream));
     return RTX_OK;
 }
 
@@ -271,6 +289,7 @@ static int finalise_scene(rtx_ctx* c);
 
 int rtx_commit_scene(rtx_ctx* c) {
     BIND(c);
+    UploadScope uploads(c);                 // sources below are members of c->built / c->h_*: one synchronise on every way out
     if (c->host.topo_dirty || c->host.mats_dirty || !c->committed_once)      // (a transform-only commit changes neither the ids nor the table: not 11 M comparisons per frame)
         for (size_t i = 0; i < c->host.matids.size(); i++)
             if (c->host.matids[i] >= c->host.mats128.size() / 32) { c->err = "commit: material id out of range"; return RTX_ERR_INVALID; }
@@ -325,6 +344,7 @@ int rtx_save_scene_cache(rtx_ctx* c, const char* path) {
 }
 int rtx_load_scene_cache(rtx_ctx* c, const char* path) {
     BIND(c);
+    UploadScope uploads(c);
     if (!load_scene_cache(path, c->host, c->built, c->err)) return RTX_ERR_INVALID;     // on failure the previous scene is untouched
     c->committed = false; c->device_scene_valid = false; c->objtris_uploaded = false; c->node_aabb_valid = false;
     int r = upload_built(c);

@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(kBlock) void k_refit_tris(TriGPU* __restrict__ tris
         const f3 w0 = xform_point(M, mk3(a.x, a.y, a.z)), w1 = xform_point(M, mk3(b.x, b.y, b.z)), w2 = xform_point(M, mk3(c.x, c.y, c.z));
         const f3 e1 = w1 - w0, e2 = w2 - w0;
         tris[s].v0 = {w0.x, w0.y, w0.z, u2f(g)};
-        tris[s].e1 = {e1.x, e1.y, e1.z, 0.0f};
+        tris[s].e1 = {e1.x, e1.y, e1.z, tri_det_floor(e1, e2)};        // (as the host build: same operations, same bits)
         tris[s].e2 = {e2.x, e2.y, e2.z, 0.0f};
         amax = fmaxf(fmaxf(fmaxf(fabsf(w0.x), fabsf(w0.y)), fmaxf(fabsf(w0.z), fabsf(w1.x))), fmaxf(fmaxf(fabsf(w1.y), fabsf(w1.z)), fmaxf(fmaxf(fabsf(w2.x), fabsf(w2.y)), fabsf(w2.z))));
     }

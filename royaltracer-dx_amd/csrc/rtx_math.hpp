@@ -49,6 +49,23 @@ RTX_HD f3 lincomb3(f3 x, float a, f3 y, float b, f3 z, float c) {
     return mk3(__builtin_fmaf(z.x, c, __builtin_fmaf(y.x, b, x.x * a)), __builtin_fmaf(z.y, c, __builtin_fmaf(y.y, b, x.y * a)), __builtin_fmaf(z.z, c, __builtin_fmaf(y.z, b, x.z * a)));
 }
 RTX_HD float length(f3 a) { return sqrtf(dot(a, a)); }
+// THE HIT DEFINITION'S GUARD AGAINST 0 / 0 (a11; oracle/rt_oracle.c: tri_det_floor).  Moeller-Trumbore divides by det = e1 . (d x e2) = -d . (e1 x e2).  For a ray in (or
+// within rounding of) the triangle's plane the exact value is 0 and the float value is rounding noise — at most ~7 ulp(|e1| |e2|) = 2^-21 |e1| |e2| for a unit direction
+// (one rounding per product of the cross product, three of the fused dot) — and the quotients are then 0 / 0: u = v = -0 is accepted and t is arbitrary, a "hit" outside
+// every bounding volume, which a culling structure reports or not depending on the boxes it happens to visit.  That hole was known since round 2
+// (test_wide_bvh_equals_brute_force_on_hostile_soups counted and excluded such rays) and it is what made round 4's one-in-20 000 mismatch non-reproducible: the four waves of
+// a workgroup of the persistent kernels draw their rays from one LDS cursor, so which rays share a wave — hence WHEN the speculative schedule lets a lane's pending triangles
+// shorten its ray, hence which boxes it still visits — depends on timing.  So a triangle is hit only if |det| > kDetRel |e1| |e2| (32 x that noise bound): a ray closer
+// than 1.5e-5 rad / sin(corner angle) to the triangle's plane passes it — 2e-10 of cosine-distributed directions; a sliver with a corner angle below 1.5e-5 rad is never hit.
+// The floor is a per-triangle constant kept in TriGPU::e1.w, so the test costs what `det != 0` cost.  Measured on the host replay of the device traversal against brute
+// force (tools/soup_lab.cpp, 600 000 hostile rays per soup: aimed at vertices / edges, lying in triangle planes, axis-parallel): needles (aspect 750) 7 closest-hit and
+// 6 any-hit mismatches without the floor, 0 / 0 with it; slivers of aspect 10 .. 1e5: 8 / 7 -> 0 / 0 (at 2^-18: 0 / 1 — a legitimate but inaccurate t next to tmax).
+// What the floor does NOT bound is the error of an accepted t for slivers thinner than that test's (relative error ~ 2^-23 / sin(corner angle)); the slab margins carry it.
+#ifndef RTX_DET_REL                 // (tooling: `make VARIANT=nofloor VARFLAGS=-DRTX_DET_REL=0.0f` builds the definition of rounds 1-4, det != 0, for tools/order_fuzz.py's A/B)
+#define RTX_DET_REL 1.52587890625e-05f
+#endif
+constexpr float kDetRel = RTX_DET_REL;      // 2^-16
+RTX_HD float tri_det_floor(f3 e1, f3 e2) { return kDetRel * (sqrtf(dot(e1, e1)) * sqrtf(dot(e2, e2))); }
 RTX_HD uint32_t f2u(float f);
 RTX_HD float u2f(uint32_t u);
 // rsqrt(x), x > 0 normal.  HLSL's rsqrt is a 1-ULP implementation-defined approximation; this is a deterministic one of the same quality

@@ -32,7 +32,7 @@ namespace rtx {
 namespace {
 
 constexpr char kMagic[8] = {'R', 'T', 'X', 'S', 'C', 'N', '0', '1'};
-constexpr uint32_t kVersion = 2;              // 2: + the host layer's MaterialExt records and texture names (two sections at the end)
+constexpr uint32_t kVersion = 3;              // 2: + the host layer's MaterialExt records and texture names (two sections at the end); 3: TriGPU::e1.w carries the determinant floor of the hit definition
 struct Header { char magic[8]; uint32_t version, endian; uint32_t layout[8]; uint64_t payload, checksum, nsections; };
 struct SecHead { uint32_t tag, elem; uint64_t count; };
 static_assert(sizeof(Header) == 72 && sizeof(SecHead) == 16, "cache header layout");

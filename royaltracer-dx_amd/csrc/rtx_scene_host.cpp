@@ -280,7 +280,7 @@ bool SceneHost::build(BuiltScene& B) {
         f3 e1 = mk3(t[3], t[4], t[5]) - v0, e2 = mk3(t[6], t[7], t[8]) - v0;
         TriGPU& T = B.tris[s];
         T.v0 = {v0.x, v0.y, v0.z, u2f(g)};
-        T.e1 = {e1.x, e1.y, e1.z, 0.0f};
+        T.e1 = {e1.x, e1.y, e1.z, tri_det_floor(e1, e2)};       // the hit definition's determinant floor (rtx_math.hpp)
         T.e2 = {e2.x, e2.y, e2.z, 0.0f};
     }
     // device traversal form: derived data, redone after a refit too (O(nodes))
@@ -1194,7 +1194,7 @@ inline bool replay_tri(const float o[3], const float d[3], const TriGPU& Tg, flo
     const f3 v0 = mk3(Tg.v0.x, Tg.v0.y, Tg.v0.z), e1 = mk3(Tg.e1.x, Tg.e1.y, Tg.e1.z), e2 = mk3(Tg.e2.x, Tg.e2.y, Tg.e2.z), dd = mk3(d[0], d[1], d[2]);
     const f3 pv = cross(dd, e2);
     const float det = dot(e1, pv);
-    if (det == 0.0f) return false;
+    if (!(fabsf(det) > Tg.e1.w)) return false;
     const float inv = 1.0f / det;
     const f3 sv = mk3(o[0], o[1], o[2]) - v0;
     const float u = dot(sv, pv) * inv;
@@ -1206,6 +1206,8 @@ inline bool replay_tri(const float o[3], const float d[3], const TriGPU& Tg, flo
     return t > tmin && t < tmax;
 }
 }  // namespace
+
+bool replay_tri_test(const float o[3], const float d[3], const TriGPU& Tg, float tmin, float tmax, float& t) { return replay_tri(o, d, Tg, tmin, tmax, t); }
 
 ReplayHit replay_trace(const BuiltScene& B, const float o[3], const float d[3], float tmin, float tmax, bool any, uint32_t any_order, float t_known, std::vector<uint8_t>* seq) {
     float idir[3]; uint32_t oct = 0;

@@ -112,6 +112,7 @@ bool collapse_bvh8(const std::vector<NodeGPU>& nodes2, std::vector<Node8GPU>& no
 struct ReplayHit { float t; uint32_t slot, prim; uint32_t steps, tris; };     // prim = global triangle id or 0xffffffff; steps = node steps, tris = triangle tests
 ReplayHit replay_trace(const BuiltScene& B, const float o[3], const float d[3], float tmin, float tmax, bool any, uint32_t any_order = 0, float t_known = -1.0f,
                        std::vector<uint8_t>* seq = nullptr);      // seq: per node step, the number of triangles it queued (tools/bvh_lab: wave-schedule simulation)
+bool replay_tri_test(const float o[3], const float d[3], const TriGPU& Tg, float tmin, float tmax, float& t);     // the replay's triangle test alone (tools/soup_lab.cpp: brute force in the same arithmetic)
 uint32_t probe_anyhit_order(const BuiltScene& B);
 
 struct CoverCheck {                                         // coverage bookkeeping of the tree validators (rtx_scene_host.cpp)

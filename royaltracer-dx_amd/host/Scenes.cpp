@@ -70,6 +70,18 @@ struct MeshBuilder {
     void sphere(P3 c, float rad, int seg, int rings, UINT mat) {
         revolve({c.x, c.y - rad, c.z}, seg, rings, [rad](float t) { return rad * sinf(3.14159265f * t); }, [rad](float t) { return rad * (1.0f - cosf(3.14159265f * t)); }, mat);
     }
+    // n small flat triangles ("leaves") of edge ~size, randomly placed inside the ellipsoid (c, radii r) and randomly oriented: foliage — incoherent, overlapping boxes
+    void leaves(P3 c, P3 r, size_t n, float size, UINT mat0, UINT nmat, uint32_t seed);
+    // prism with `seg` sides from a to b (a thin bar: 2 seg long thin triangles, no caps)
+    void bar(P3 a, P3 b, float rad, int seg, UINT mat) {
+        if (count_only) { tri_count += (size_t)2 * seg; return; }
+        const P3 ax = norm(b - a), t0 = norm(fabsf(ax.y) < 0.9f ? cross(ax, P3{0, 1, 0}) : cross(ax, P3{1, 0, 0})), t1 = cross(ax, t0);
+        for (int i = 0; i < seg; i++) {
+            const float a0 = 6.2831853f * (float)i / seg, a1 = 6.2831853f * (float)(i + 1) / seg;
+            const P3 d0 = t0 * (rad * cosf(a0)) + t1 * (rad * sinf(a0)), d1 = t0 * (rad * cosf(a1)) + t1 * (rad * sinf(a1));
+            quad(a + d0, a + d1, b + d1, b + d0, (d0 + d1) * 0.5f, mat);
+        }
+    }
 };
 
 Material make_mat(float r, float g, float b, float ks, float pr, float pm, float ke_r = 0, float ke_g = 0, float ke_b = 0) {
@@ -93,6 +105,19 @@ inline float hash01(uint32_t a, uint32_t b, uint32_t seed) {
     uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ seed * 0xC2B2AE3Du;
     h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
     return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+void MeshBuilder::leaves(P3 c, P3 r, size_t n, float size, UINT mat0, UINT nmat, uint32_t seed) {
+    if (count_only) { tri_count += n; return; }
+    for (size_t k = 0; k < n; k++) {
+        const uint32_t a = (uint32_t)k, b = (uint32_t)(k >> 32) + 17u;
+        // a point in the unit ball by rejection-free warping (cube root radius), scaled to the ellipsoid
+        const float u = hash01(a, b, seed), v = hash01(a, b + 1, seed), w = hash01(a, b + 2, seed);
+        const float z = 2.0f * u - 1.0f, ph = 6.2831853f * v, rr = cbrtf(w), sxy = sqrtf(std::max(0.0f, 1.0f - z * z));
+        const P3 p{c.x + r.x * rr * sxy * cosf(ph), c.y + r.y * rr * z, c.z + r.z * rr * sxy * sinf(ph)};
+        P3 e1{hash01(a, b + 3, seed) - 0.5f, hash01(a, b + 4, seed) - 0.5f, hash01(a, b + 5, seed) - 0.5f}, e2{hash01(a, b + 6, seed) - 0.5f, hash01(a, b + 7, seed) - 0.5f, hash01(a, b + 8, seed) - 0.5f};
+        e1 = norm(e1) * (size * (0.6f + 0.8f * hash01(a, b + 9, seed))); e2 = norm(e2) * (size * (0.6f + 0.8f * hash01(a, b + 10, seed)));
+        flat_tri(p, p + e1, p + e2, cross(e1, e2), mat0 + (UINT)(hash01(a, b + 11, seed) * (float)nmat) % nmat);
+    }
 }
 }  // namespace
 
@@ -208,7 +233,120 @@ static void sponza_build(MeshBuilder& mb, float detail, int floor_n, uint32_t se
     }
 }
 
-Scene MakeSponzaClass(uint32_t target, uint32_t seed) {
+// ------------------------------------------------------------------------------------------------
+// The HARD variant of the atrium (round 5).  The scene above is tessellated uniformly — every wall is a grid of centimetre quads — and on such input a
+// median-quality tree is already good: sweep SAH, spatial splits and re-insertion change nothing (profiles/r04_bvh_lab.md), while on the reference's real model
+// (garage.obj + monke.obj) the same knobs take 11 % each.  The real Sponza is of the second kind: walls, floors and the gallery are a few triangles METRES long, beside
+// ornament tessellated to millimetres (lion heads, capitals, vases and plants), long thin trims (flutes, cornices, balusters) and curtains hanging in overlapping layers.
+// This variant has the same shell, materials, light, camera and triangle budget, but that distribution: size ratio > 1000 : 1 between the largest and the smallest
+// triangle, > 100 : 1 aspect ratios, overlapping cloth.  `leaf_n` (foliage triangles of the potted plants) absorbs the remainder of the budget.
+// ------------------------------------------------------------------------------------------------
+static void sponza_hard_build(MeshBuilder& mb, float detail, size_t leaf_n, uint32_t seed) {
+    auto D = [detail](float base) { int v = (int)lroundf(base * detail); return v < 2 ? 2 : v; };
+    const float L = 2.0f, Wd = 0.9f, Hh = 1.5f;
+    // shell: a handful of triangles metres long
+    mb.grid({-L, 0, -Wd}, {2 * L, 0, 0}, {0, 0, 2 * Wd}, 4, 2, {0, 1, 0}, [](int i, int j) { return (UINT)(1 + ((i + j) & 1)); });
+    auto m3 = [](int, int) { return (UINT)3; };
+    mb.grid({-L, 0, -Wd}, {2 * L, 0, 0}, {0, Hh, 0}, 2, 1, {0, 0, 1}, m3);
+    mb.grid({-L, 0, Wd}, {2 * L, 0, 0}, {0, Hh, 0}, 2, 1, {0, 0, -1}, m3);
+    mb.grid({-L, 0, -Wd}, {0, 0, 2 * Wd}, {0, Hh, 0}, 1, 1, {1, 0, 0}, m3);
+    mb.grid({L, 0, -Wd}, {0, 0, 2 * Wd}, {0, Hh, 0}, 1, 1, {-1, 0, 0}, m3);
+    const float ox = 1.2f, oz = 0.35f;
+    auto m4 = [](int, int) { return (UINT)4; };
+    mb.grid({-L, Hh, -Wd}, {L - ox, 0, 0}, {0, 0, 2 * Wd}, 1, 1, {0, -1, 0}, m4);
+    mb.grid({ox, Hh, -Wd}, {L - ox, 0, 0}, {0, 0, 2 * Wd}, 1, 1, {0, -1, 0}, m4);
+    mb.grid({-ox, Hh, -Wd}, {2 * ox, 0, 0}, {0, 0, Wd - oz}, 1, 1, {0, -1, 0}, m4);
+    mb.grid({-ox, Hh, oz}, {2 * ox, 0, 0}, {0, 0, Wd - oz}, 1, 1, {0, -1, 0}, m4);
+    mb.quad({-ox, Hh + 0.05f, -oz}, {ox, Hh + 0.05f, -oz}, {ox, Hh + 0.05f, oz}, {-ox, Hh + 0.05f, oz}, {0, -1, 0}, 12);          // the sky quad: the scene's one light
+    mb.grid({-ox, Hh, -oz}, {2 * ox, 0, 0}, {0, 0.05f, 0}, 1, 1, {0, 0, 1}, m4);
+    mb.grid({-ox, Hh, oz}, {2 * ox, 0, 0}, {0, 0.05f, 0}, 1, 1, {0, 0, -1}, m4);
+    mb.grid({-ox, Hh, -oz}, {0, 0, 2 * oz}, {0, 0.05f, 0}, 1, 1, {1, 0, 0}, m4);
+    mb.grid({ox, Hh, -oz}, {0, 0, 2 * oz}, {0, 0.05f, 0}, 1, 1, {-1, 0, 0}, m4);
+    // cornices and ledges: boxes as long as the hall, 2-3 cm thick (12 triangles each, aspect > 100 : 1)
+    for (int side = 0; side < 2; side++) {
+        const float zw = side ? Wd : -Wd, zi = side ? -1.0f : 1.0f;
+        for (int k = 0; k < 5; k++) {
+            const float y = 0.30f + 0.27f * k, th = 0.012f + 0.004f * k;
+            mb.box({-L, y, std::min(zw, zw + zi * (0.02f + 0.01f * k))}, {L, y + th, std::max(zw, zw + zi * (0.02f + 0.01f * k))}, 5, 1);
+        }
+    }
+    // two colonnades: FLUTED shafts (many sides, one or two rings: triangles 0.4-0.7 m long and millimetres wide), dense capitals, coarse bases
+    const int ncol = 8;
+    for (int side = 0; side < 2; side++) {
+        const float z = side ? 0.5f : -0.5f;
+        for (int c = 0; c < ncol; c++) {
+            const float x = -L + 0.25f + (2 * L - 0.5f) * (float)c / (ncol - 1);
+            mb.box({x - 0.07f, 0, z - 0.07f}, {x + 0.07f, 0.06f, z + 0.07f}, 5, 1);
+            mb.revolve({x, 0.06f, z}, D(64), 2, [](float t) { return 0.05f - 0.008f * t; }, [](float t) { return 0.74f * t; }, 6);
+            for (int f = 0; f < 12; f++) {                                                    // applied flutes: thin bars standing proud of the shaft
+                const float a = 6.2831853f * (float)f / 12.0f;
+                mb.bar({x + 0.047f * cosf(a), 0.08f, z + 0.047f * sinf(a)}, {x + 0.043f * cosf(a), 0.78f, z + 0.043f * sinf(a)}, 0.003f, 4, 6);
+            }
+            mb.box({x - 0.075f, 0.80f, z - 0.075f}, {x + 0.075f, 0.86f, z + 0.075f}, 5, 1);
+            mb.revolve({x, 0.86f, z}, D(40), D(24), [](float t) { return 0.05f + 0.03f * sinf(3.14159265f * t) + 0.004f * sinf(37.0f * t); }, [](float t) { return 0.05f * t; }, 7);   // carved capital
+            mb.sphere({x, 0.935f, z}, 0.03f, D(24), D(16), 7);
+            if (c + 1 < ncol) {
+                const float x1 = -L + 0.25f + (2 * L - 0.5f) * (float)(c + 1) / (ncol - 1);
+                const float cx = 0.5f * (x + x1), r0 = 0.5f * (x1 - x) - 0.07f, r1 = r0 + 0.05f;
+                const int na = 12;
+                for (int a = 0; a < na; a++) {
+                    const float a0 = 3.14159265f * (float)a / na, a1 = 3.14159265f * (float)(a + 1) / na;
+                    auto pt = [&](float ang, float r, float dz) { return P3{cx + r * cosf(ang), 0.86f + r * sinf(ang), z + dz}; };
+                    mb.quad(pt(a0, r0, -0.05f), pt(a1, r0, -0.05f), pt(a1, r0, 0.05f), pt(a0, r0, 0.05f), P3{cx, 0.86f, z} - pt(0.5f * (a0 + a1), r0, 0), 8);
+                    mb.quad(pt(a0, r1, -0.05f), pt(a1, r1, -0.05f), pt(a1, r1, 0.05f), pt(a0, r1, 0.05f), pt(0.5f * (a0 + a1), r1, 0) - P3{cx, 0.86f, z}, 8);
+                    mb.quad(pt(a0, r0, -0.05f), pt(a1, r0, -0.05f), pt(a1, r1, -0.05f), pt(a0, r1, -0.05f), {0, 0, -1}, 8);
+                    mb.quad(pt(a0, r0, 0.05f), pt(a1, r0, 0.05f), pt(a1, r1, 0.05f), pt(a0, r1, 0.05f), {0, 0, 1}, 8);
+                }
+            }
+        }
+        // gallery slab (two big boxes) and its balustrade: a rail as long as the hall on ~130 thin balusters
+        mb.box({-L, 1.05f, side ? 0.42f : -Wd}, {L, 1.10f, side ? Wd : -0.42f}, 4, 1);
+        const float zr = side ? 0.44f : -0.44f;
+        mb.box({-L, 1.24f, zr - 0.01f}, {L, 1.26f, zr + 0.01f}, 5, 1);
+        for (int k = 0; k < 130; k++) { const float x = -L + 0.02f + (2 * L - 0.04f) * (float)k / 129.0f; mb.bar({x, 1.10f, zr}, {x, 1.24f, zr}, 0.004f, 6, 5); }
+    }
+    // "lion heads": small patches of deeply carved relief on the side walls, tessellated to ~2 mm
+    for (int side = 0; side < 2; side++) for (int k = 0; k < 6; k++) {
+        const float x = -1.6f + 0.64f * k, zw = side ? Wd - 0.001f : -Wd + 0.001f, zi = side ? -1.0f : 1.0f;
+        mb.grid({x - 0.09f, 0.55f, zw}, {0.18f, 0, 0}, {0, 0.18f, 0}, D(56), D(56), {0, 0, zi}, [](int, int) { return (UINT)8; },
+                [k, side, seed](float u, float v) { const float r2 = (u - 0.5f) * (u - 0.5f) + (v - 0.5f) * (v - 0.5f);
+                                                    return (0.035f * expf(-14.0f * r2) + 0.006f * sinf(31.0f * u + k) * sinf(27.0f * v + side)) * (r2 < 0.24f ? 1.0f : 0.0f) + 0.0015f * hash01((uint32_t)(u * 977), (uint32_t)(v * 991), seed + k); });
+    }
+    // drapes: three OVERLAPPING layers of fine cloth a few millimetres apart, six hangings
+    for (int k = 0; k < 6; k++) for (int layer = 0; layer < 3; layer++) {
+        const float x = -1.5f + 0.6f * k - 0.01f * layer; const UINT mat = 9 + ((k + layer) % 3);
+        mb.grid({x, 1.04f, -0.42f + 0.004f * layer}, {0.4f + 0.02f * layer, 0, 0}, {0, -0.55f - 0.03f * layer, 0}, D(36), D(44), {0, 0, 1}, [mat](int, int) { return mat; },
+                [k, layer](float u, float v) { return 0.03f * sinf(25.0f * u + k + 1.7f * layer) * (0.3f + v) + 0.01f * sinf(60.0f * v + layer); });
+    }
+    // vases with plants along the nave: dense pottery, and foliage — thousands of centimetre leaves in overlapping clouds (the remainder of the triangle budget)
+    const int nvase = 10;
+    for (int v = 0; v < nvase; v++) {
+        const float x = -1.7f + 3.4f * (float)v / (nvase - 1), z = (v & 1) ? 0.28f : -0.28f;
+        mb.revolve({x, 0, z}, D(40), D(36), [](float t) { return 0.035f + 0.03f * sinf(3.14159265f * (0.15f + 0.8f * t)) + 0.002f * sinf(50.0f * t); }, [](float t) { return 0.16f * t; }, 7);
+        const size_t n0 = leaf_n * (size_t)v / nvase, n1 = leaf_n * (size_t)(v + 1) / nvase;
+        mb.leaves({x, 0.32f, z}, {0.10f, 0.16f, 0.10f}, n1 - n0, 0.006f, 10, 2, seed + 31u * (uint32_t)v);
+    }
+}
+
+Scene MakeSponzaClass(uint32_t target, uint32_t seed, bool hard) {
+    if (hard) {
+        Scene s; s.name = "sponza_class_hard";
+        s.materials.push_back(default_material());
+        const float c[12][3] = {{.62f, .58f, .50f}, {.42f, .40f, .36f}, {.70f, .62f, .50f}, {.55f, .52f, .48f}, {.50f, .46f, .40f}, {.66f, .62f, .55f},
+                                {.58f, .50f, .38f}, {.60f, .56f, .50f}, {.62f, .10f, .10f}, {.10f, .28f, .55f}, {.12f, .45f, .18f}, {0, 0, 0}};
+        for (int i = 0; i < 12; i++) s.materials.push_back(i == 11 ? make_mat(0, 0, 0, 0, 1, 0, 24.0f, 22.0f, 18.0f) : make_mat(c[i][0], c[i][1], c[i][2], 0.0f, 1.0f, 0.0f));
+        fill_luts(s.materials);
+        auto count = [&](float detail, size_t leaf_n) { MeshBuilder mb; mb.count_only = true; mb.mat_base = 0; mb.normal_w = 0; sponza_hard_build(mb, detail, leaf_n, seed); return mb.tri_count; };
+        float lo = 0.05f, hi = 8.0f;                      // ornament, cloth and pottery take ~70 % of the budget, the foliage the rest
+        for (int it = 0; it < 40; it++) { float mid = 0.5f * (lo + hi); if (count(mid, 0) < (size_t)(0.70 * target)) lo = mid; else hi = mid; }
+        const size_t rest = count(lo, 0);
+        MeshBuilder mb; mb.mat_base = 0; mb.normal_w = 0.0f;
+        sponza_hard_build(mb, lo, target > rest ? target - rest : 0, seed);
+        s.models.push_back(std::move(mb.m));
+        s.instances.push_back({0, XMMatrixIdentity()});
+        s.eye = XMFLOAT3(-1.8f, 0.45f, 0.0f); s.center = XMFLOAT3(0.5f, 0.55f, 0.0f); s.up = XMFLOAT3(0, 1, 0);
+        return s;
+    }
     Scene s; s.name = "sponza_class";
     s.materials.push_back(default_material());
     const float c[12][3] = {{.62f, .58f, .50f}, {.42f, .40f, .36f}, {.70f, .62f, .50f}, {.55f, .52f, .48f}, {.50f, .46f, .40f}, {.66f, .62f, .55f},
@@ -286,8 +424,79 @@ static void bistro_build(MeshBuilder& mb, float detail, int street_n, uint32_t s
     }
 }
 
-Scene MakeBistroClass(uint32_t target, uint32_t seed) {
-    Scene s; s.name = "bistro_class";
+// The HARD variant of the street (see sponza_hard_build): facades and paving as a few large triangles, window frames / mullions / cables / balusters as long thin
+// ones, carved cornices and cafe furniture tessellated to millimetres, awnings as fine cloth, and street trees whose foliage — centimetre leaves in overlapping
+// clouds — takes the remainder of the 3.8 M-triangle budget (in the real Bistro the vegetation is the largest single part).  Same materials, lamps and camera.
+static void bistro_hard_build(MeshBuilder& mb, float detail, size_t leaf_n, uint32_t seed) {
+    auto D = [detail](float base) { int v = (int)lroundf(base * detail); return v < 1 ? 1 : v; };
+    const float L = 3.0f, Wd = 0.6f;
+    mb.grid({-L, 0, -Wd}, {2 * L, 0, 0}, {0, 0, 2 * Wd}, 3, 1, {0, 1, 0}, [seed](int i, int j) { return (UINT)(1 + (uint32_t)(hash01(i, j, seed) * 3.0f)); });      // paving: 6 triangles
+    for (int k = 0; k < 8; k++) {              // a few patches of real cobbles (dense relief), flush above the paving
+        const float x = -L + 0.3f + (2 * L - 0.9f) * hash01(k, 40, seed), z = -0.25f + 0.5f * hash01(k, 41, seed);
+        mb.grid({x, 0.001f, z}, {0.3f, 0, 0}, {0, 0, 0.2f}, D(60), D(40), {0, 1, 0}, [](int i, int j) { return (UINT)(1 + ((i / 3 + j / 3) % 3)); },
+                [k, seed](float u, float v) { return 0.004f * hash01((uint32_t)(u * 20) + 31u * k, (uint32_t)(v * 13), seed + 1) + 0.002f * sinf(120.0f * u) * sinf(80.0f * v); });
+    }
+    const int nb = 12;
+    for (int side = 0; side < 2; side++) {
+        const float z0 = side ? Wd : -Wd, zn = side ? -1.0f : 1.0f;
+        for (int b = 0; b < nb; b++) {
+            const float x0 = -L + 2 * L * (float)b / nb, x1 = -L + 2 * L * (float)(b + 1) / nb;
+            const float h = 0.9f + 0.6f * hash01(b, side, seed + 2);
+            const UINT wall_mat = 4 + (UINT)(hash01(b, side, seed + 3) * 8.0f);
+            mb.grid({x0, 0, z0}, {x1 - x0, 0, 0}, {0, h, 0}, 1, 1, {0, 0, zn}, [wall_mat](int, int) { return wall_mat; });                       // the facade: two triangles
+            mb.grid({x0, h, z0}, {x1 - x0, 0, 0}, {0, 0, -zn * 0.5f}, 1, 1, {0, 1, 0}, [](int, int) { return (UINT)12; });                      // the roof: two
+            // carved cornice under the roof line: a strip of dense relief as long as the building
+            mb.grid({x0, h - 0.05f, z0 + zn * 0.004f}, {x1 - x0, 0, 0}, {0, 0.05f, 0}, D(120), D(12), {0, 0, zn}, [](int, int) { return (UINT)13; },
+                    [b, side](float u, float v) { return 0.008f * fabsf(sinf(60.0f * u + b)) * sinf(3.14159265f * v) + 0.002f * sinf(200.0f * u + side); });
+            const int floors = (int)(h / 0.3f), wins = 4;
+            for (int f = 0; f < floors; f++) for (int w = 0; w < wins; w++) {
+                const float wx = x0 + (x1 - x0) * ((float)w + 0.5f) / wins, wy = 0.12f + 0.3f * f;
+                const float zz = z0 + zn * 0.012f;
+                const UINT glass = 28 + (UINT)(hash01(b * 16 + w, f * 2 + side, seed + 5) * 4.0f);
+                const UINT frame = 20 + (UINT)(hash01(b, w, seed + 6) * 8.0f);
+                mb.grid({wx - 0.04f, wy, zz}, {0.08f, 0, 0}, {0, 0.14f, 0}, 1, 1, {0, 0, zn}, [glass](int, int) { return glass; });             // a pane: two triangles
+                mb.box({wx - 0.05f, wy - 0.01f, zz - 0.004f}, {wx + 0.05f, wy, zz + 0.02f}, frame, 1);
+                mb.box({wx - 0.05f, wy + 0.14f, zz - 0.004f}, {wx + 0.05f, wy + 0.15f, zz + 0.02f}, frame, 1);
+                mb.bar({wx, wy, zz + zn * 0.002f}, {wx, wy + 0.14f, zz + zn * 0.002f}, 0.002f, 4, frame);                                       // mullion and transom: thin bars
+                mb.bar({wx - 0.04f, wy + 0.07f, zz + zn * 0.002f}, {wx + 0.04f, wy + 0.07f, zz + zn * 0.002f}, 0.002f, 4, frame);
+                if (f > 0 && ((b + w + f) & 1)) {      // balcony: a slab, a rail and nine thin spindles
+                    mb.box({wx - 0.06f, wy - 0.02f, std::min(z0 + zn * 0.01f, z0 + zn * 0.07f)}, {wx + 0.06f, wy - 0.012f, std::max(z0 + zn * 0.01f, z0 + zn * 0.07f)}, 13, 1);
+                    mb.bar({wx - 0.06f, wy + 0.04f, z0 + zn * 0.068f}, {wx + 0.06f, wy + 0.04f, z0 + zn * 0.068f}, 0.003f, 5, frame);
+                    for (int k = 0; k < 9; k++) mb.bar({wx - 0.056f + 0.014f * k, wy - 0.012f, z0 + zn * 0.068f}, {wx - 0.056f + 0.014f * k, wy + 0.04f, z0 + zn * 0.068f}, 0.0015f, 4, frame);
+                }
+            }
+            if (b & 1) mb.grid({x0 + 0.03f, 0.30f, z0}, {x1 - x0 - 0.06f, 0, 0}, {0, -0.06f, zn * 0.16f}, D(60), D(36), {0, 1, zn * 0.4f},               // awning: fine cloth
+                               [b](int i, int) { return (UINT)(14 + ((i / 6 + b) & 1) * 2); }, [](float u, float v) { return 0.004f * sinf(50.0f * u) + 0.002f * sinf(90.0f * v); });
+        }
+    }
+    // cables across the street: 1.2 m long, 3 mm thick
+    for (int k = 0; k < 40; k++) { const float x = -L + 0.1f + (2 * L - 0.2f) * (float)k / 39.0f, y = 0.62f + 0.2f * hash01(k, 50, seed); mb.bar({x, y, -Wd + 0.01f}, {x + 0.05f, y + 0.03f, Wd - 0.01f}, 0.0015f, 4, 24); }
+    for (int l = 0; l < 17; l++) {             // street lamps: 12 emissive triangles each, as in the plain variant
+        const float x = -L + 0.2f + (2 * L - 0.4f) * (float)l / 16.0f, z = (l & 1) ? 0.45f : -0.45f;
+        mb.bar({x, 0, z}, {x, 0.5f, z}, 0.01f, 8, 24);
+        mb.box({x - 0.02f, 0.50f, z - 0.02f}, {x + 0.02f, 0.54f, z + 0.02f}, 39, 1);
+        mb.sphere({x, 0.56f, z}, 0.012f, D(8), D(6), 24);
+    }
+    for (int k = 0; k < 60; k++) {             // cafe furniture: turned table legs and barrels (dense), table tops (coarse), chair legs (thin)
+        const float x = -L + 0.1f + (2 * L - 0.2f) * hash01(k, 1, seed + 7), z = (k & 1 ? 1.0f : -1.0f) * (0.30f + 0.1f * hash01(k, 2, seed + 8));
+        const UINT mat = 32 + (UINT)(hash01(k, 3, seed + 9) * 7.0f);
+        mb.revolve({x, 0, z}, D(28), D(40), [](float t) { return 0.012f + 0.02f * fabsf(sinf(9.0f * t)) * (1.0f - t) + 0.015f * t; }, [](float t) { return 0.09f * t; }, mat);
+        mb.box({x - 0.04f, 0.09f, z - 0.04f}, {x + 0.04f, 0.10f, z + 0.04f}, mat, 1);
+        for (int q = 0; q < 4; q++) mb.bar({x + 0.07f + 0.02f * (q & 1), 0, z + 0.02f * (q >> 1)}, {x + 0.07f + 0.02f * (q & 1), 0.05f, z + 0.02f * (q >> 1)}, 0.0015f, 4, mat);
+    }
+    // street trees: a trunk, a few branches, and the foliage that takes the rest of the budget
+    const int ntree = 14;
+    for (int t = 0; t < ntree; t++) {
+        const float x = -L + 0.25f + (2 * L - 0.5f) * (float)t / (ntree - 1), z = (t & 1) ? -0.32f : 0.32f;
+        mb.revolve({x, 0, z}, D(12), D(10), [](float u) { return 0.018f - 0.008f * u; }, [](float u) { return 0.45f * u; }, 34);
+        for (int q = 0; q < 5; q++) { const float a = 1.2566f * q + 0.3f * t; mb.bar({x, 0.40f, z}, {x + 0.12f * cosf(a), 0.55f + 0.03f * q, z + 0.12f * sinf(a)}, 0.004f, 5, 34); }
+        const size_t n0 = leaf_n * (size_t)t / ntree, n1 = leaf_n * (size_t)(t + 1) / ntree;
+        mb.leaves({x, 0.62f, z}, {0.20f, 0.16f, 0.18f}, n1 - n0, 0.009f, 15, 3, seed + 131u * (uint32_t)t);
+    }
+}
+
+Scene MakeBistroClass(uint32_t target, uint32_t seed, bool hard) {
+    Scene s; s.name = hard ? "bistro_class_hard" : "bistro_class";
     s.materials.push_back(default_material());
     for (int i = 1; i <= 39; i++) {
         const float r = 0.25f + 0.6f * hash01(i, 1, seed), g = 0.25f + 0.6f * hash01(i, 2, seed), b = 0.25f + 0.6f * hash01(i, 3, seed);
@@ -301,6 +510,18 @@ Scene MakeBistroClass(uint32_t target, uint32_t seed) {
         else s.materials.push_back(make_mat(r, g, b, 0.04f, 1.0f, 0.0f));
     }
     fill_luts(s.materials);
+    if (hard) {
+        auto counth = [&](float detail, size_t leaf_n) { MeshBuilder mb; mb.count_only = true; mb.mat_base = 0; mb.normal_w = 0; bistro_hard_build(mb, detail, leaf_n, seed); return mb.tri_count; };
+        float lo = 0.05f, hi = 16.0f;                     // carving, cloth and furniture take ~55 % of the budget, the trees the rest
+        for (int it = 0; it < 40; it++) { float mid = 0.5f * (lo + hi); if (counth(mid, 0) < (size_t)(0.55 * target)) lo = mid; else hi = mid; }
+        const size_t rest = counth(lo, 0);
+        MeshBuilder mb; mb.mat_base = 0; mb.normal_w = 0.0f;
+        bistro_hard_build(mb, lo, target > rest ? target - rest : 0, seed);
+        s.models.push_back(std::move(mb.m));
+        s.instances.push_back({0, XMMatrixIdentity()});
+        s.eye = XMFLOAT3(-2.7f, 0.35f, 0.05f); s.center = XMFLOAT3(0.0f, 0.45f, 0.0f); s.up = XMFLOAT3(0, 1, 0);
+        return s;
+    }
     auto count = [&](float detail, int street_n) { MeshBuilder mb; mb.count_only = true; mb.mat_base = 0; mb.normal_w = 0; bistro_build(mb, detail, street_n, seed); return mb.tri_count; };
     float lo = 0.05f, hi = 16.0f;
     for (int it = 0; it < 40; it++) { float mid = 0.5f * (lo + hi); if (count(mid, 1) < (size_t)(0.9 * target)) lo = mid; else hi = mid; }

@@ -24,8 +24,11 @@ struct Scene {
 };
 
 Scene MakeCornellBox();                                             // 32 triangles, 2 emissive
-Scene MakeSponzaClass(uint32_t target_tris = 262144, uint32_t seed = 260);
-Scene MakeBistroClass(uint32_t target_tris = 3800000, uint32_t seed = 3800);
+// hard = false: uniformly tessellated stand-ins (every surface a grid of centimetre quads: the EASY case for a BVH builder); hard = true: the same shell, materials, light,
+// camera and triangle budget with the size distribution of the real assets — a few triangles metres long beside ornament tessellated to millimetres, long thin trims,
+// overlapping cloth, foliage (size ratio > 1000 : 1) — the case tree quality is FOR (Scenes.cpp: sponza_hard_build)
+Scene MakeSponzaClass(uint32_t target_tris = 262144, uint32_t seed = 260, bool hard = false);
+Scene MakeBistroClass(uint32_t target_tris = 3800000, uint32_t seed = 3800, bool hard = false);
 // the reference's own startup scene: each file through ObjLoader::loadObjFile, one instance per model,
 // instance 1 rotated 1.57 rad about Y (Renderer.cpp:363-407, 444-449)
 Scene LoadObjScene(const std::vector<std::string>& files, const std::string& mtl_dir);

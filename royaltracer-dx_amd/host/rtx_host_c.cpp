@@ -31,6 +31,8 @@ extern "C" {
 rtxh_scene* rtxh_scene_cornell(void) { return guarded([] { return MakeCornellBox(); }); }
 rtxh_scene* rtxh_scene_sponza_class(uint32_t t, uint32_t seed) { return guarded([=] { return MakeSponzaClass(t, seed); }); }
 rtxh_scene* rtxh_scene_bistro_class(uint32_t t, uint32_t seed) { return guarded([=] { return MakeBistroClass(t, seed); }); }
+rtxh_scene* rtxh_scene_sponza_class_hard(uint32_t t, uint32_t seed) { return guarded([=] { return MakeSponzaClass(t, seed, true); }); }
+rtxh_scene* rtxh_scene_bistro_class_hard(uint32_t t, uint32_t seed) { return guarded([=] { return MakeBistroClass(t, seed, true); }); }
 rtxh_scene* rtxh_scene_from_obj(const char* const* files, uint32_t n, const char* mtl_dir) {
     std::vector<std::string> f; for (uint32_t i = 0; i < n; i++) f.emplace_back(files[i]);
     std::string dir = mtl_dir ? mtl_dir : "./";
@@ -232,7 +234,8 @@ int rtxh_bvh_replay(const float* wt, uint32_t ntris, const float* rays8, uint32_
     B.tris8.resize(B.tri_slots8.size());
     for (size_t i = 0; i < B.tri_slots8.size(); i++) {
         const uint32_t g = B.leaf_order[B.tri_slots8[i]]; const float* t = &w[(size_t)g * 9];
-        B.tris8[i].v0 = {t[0], t[1], t[2], rtx::u2f(g)}; B.tris8[i].e1 = {t[3] - t[0], t[4] - t[1], t[5] - t[2], 0.0f}; B.tris8[i].e2 = {t[6] - t[0], t[7] - t[1], t[8] - t[2], 0.0f};
+        const rtx::f3 e1 = rtx::mk3(t[3] - t[0], t[4] - t[1], t[5] - t[2]), e2 = rtx::mk3(t[6] - t[0], t[7] - t[1], t[8] - t[2]);
+        B.tris8[i].v0 = {t[0], t[1], t[2], rtx::u2f(g)}; B.tris8[i].e1 = {e1.x, e1.y, e1.z, rtx::tri_det_floor(e1, e2)}; B.tris8[i].e2 = {e2.x, e2.y, e2.z, 0.0f};
     }
     if (refs_out) *refs_out = (uint32_t)B.tris8.size();
     for (uint32_t i = 0; i < nrays; i++) {

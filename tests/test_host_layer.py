@@ -238,6 +238,12 @@ def test_builder_variants_keep_the_tree_valid_and_the_replayed_traversal_exact(r
     pick = rng.integers(0, len(t), m // 2); w = rng.dirichlet((1, 1, 1), m // 2); w[: m // 8] = np.eye(3)[rng.integers(0, 3, m // 8)]
     d[: m // 2] = (t[pick] * w[:, :, None]).sum(1) - org[: m // 2]
     d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)
+    # a sixth of the rays LIE IN the plane of a triangle (origin and direction are combinations of its edges): Moeller-Trumbore's 0 / 0 case
+    k = m // 6; pl = rng.integers(0, len(t), k); T = t[pl].astype(np.float64)
+    a = rng.normal(scale=3.0, size=(k, 2)); b = rng.normal(size=(k, 2))
+    org[-k:] = T[:, 0] + a[:, :1] * (T[:, 1] - T[:, 0]) + a[:, 1:] * (T[:, 2] - T[:, 0])
+    d[-k:] = b[:, :1] * (T[:, 1] - T[:, 0]) + b[:, 1:] * (T[:, 2] - T[:, 0])
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)
     rays = np.zeros((m, 8), np.float32); rays[:, 0:3], rays[:, 3], rays[:, 4:7], rays[:, 7] = org, 1e-5, d, 1e30
 
     class Soup:
@@ -257,20 +263,72 @@ def test_builder_variants_keep_the_tree_valid_and_the_replayed_traversal_exact(r
         assert refs == len(t)
     hit = bits(ref)[:, 3] != 0xFFFFFFFF
     assert hit.mean() > 0.3
-    # float Moeller-Trumbore can accept a point nowhere near a sliver: brute force reports it, every BVH culls it; excluded like in the GPU test
-    P = rays[hit, 0:3].astype(np.float64) + ref[hit, 0:1].astype(np.float64) * rays[hit, 4:7].astype(np.float64)
-    tv = t[bits(ref)[hit, 3].astype(np.int64)].astype(np.float64)
-    Q = tv[:, 0] + ref[hit, 1:2] * (tv[:, 1] - tv[:, 0]) + ref[hit, 2:3] * (tv[:, 2] - tv[:, 0])
-    bogus = np.zeros(m, bool); bogus[np.nonzero(hit)[0]] = np.abs(P - Q).max(1) > 0.02 * float((hi - lo).max())
-    assert bogus.sum() <= 3
-    ok = ~bogus
-    assert np.array_equal(bits(got)[ok, 3], bits(ref)[ok, 3]), "closest-hit triangle ids differ from brute force"
-    assert np.array_equal(bits(got)[hit & ok, 0], bits(ref)[hit & ok, 0]), "closest-hit distances differ from brute force"
+    # EVERY ray: since round 5 the hit definition carries a determinant floor (csrc/rtx_math.hpp: tri_det_floor), so the 0 / 0 "hits" of rays lying in a sliver's plane, which
+    # brute force reported and every tree culled, no longer exist and nothing is excluded from the comparison
+    assert np.array_equal(bits(got)[:, 3], bits(ref)[:, 3]), "closest-hit triangle ids differ from brute force"
+    assert np.array_equal(bits(got)[hit, 0], bits(ref)[hit, 0]), "closest-hit distances differ from brute force"
     # any-hit: the same answer in every visiting order
     sh = rays.copy(); sh[:, 7] = rng.uniform(0.05, 2.0, m).astype(np.float32)
     occ = [bits(rt.bvh_replay(t, sh, any_hit=True, any_order=k)[0])[:, 3] != 0xFFFFFFFF for k in (0, 1, 2)]
     assert np.array_equal(occ[0], occ[1]) and np.array_equal(occ[0], occ[2])
     assert occ[0].mean() > 0.02
+
+
+@pytest.mark.parametrize("kind", ["needles", "slivers"])
+def test_rays_in_a_triangle_plane_never_hit_it_and_no_tree_changes_an_answer(rt, orc, builder_options, kind):
+    """The hit definition's determinant floor (csrc/rtx_math.hpp: tri_det_floor; oracle tri_hit): for a ray lying in a triangle's plane Moeller-Trumbore is 0 / 0 — without the
+    floor float arithmetic accepts u = v = -0 with an arbitrary t there, a hit that brute force reports and a tree finds or not depending on the boxes it visits (the hole
+    VERDICT r04 named; tools/soup_lab.cpp measures 7-8 such rays per 600 000 on these soups).  With it: (1) a triangle is never hit by a ray constructed inside its own plane,
+    (2) the oracle's brute force, the oracle's own BVH and the host replay of the device traversal on the product's tree — default builder and spatial splits — agree on
+    EVERY ray, ids and distances, closest hit and any hit, (3) every reported hit point lies on its triangle (float64)."""
+    rng = np.random.default_rng(17 + len(kind))
+    n = 3000
+    if kind == "needles":
+        t = _lab_soup("needles", n, rng)
+    else:                                # aspect ratios 10 ... 1e5, lengths 0.01 ... 0.3
+        c = rng.uniform(-1, 1, (n, 3)); dd = rng.normal(size=(n, 3)); dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+        L = 10.0 ** rng.uniform(-2, -0.5, (n, 1)); w = L * 10.0 ** rng.uniform(-5, -1, (n, 1))
+        t = np.stack([c, c + L * dd, c + 0.5 * L * dd + w * rng.normal(size=(n, 3))], axis=1).astype(np.float32)
+    m = 30000
+    lo, hi = t.reshape(-1, 3).min(0), t.reshape(-1, 3).max(0)
+    org = rng.uniform(lo - 0.1, hi + 0.1, (m, 3)); d = rng.normal(size=(m, 3))
+    pick = rng.integers(0, n, m // 3); w3 = rng.dirichlet((1, 1, 1), m // 3); w3[: m // 12] = np.eye(3)[rng.integers(0, 3, m // 12)]
+    d[: m // 3] = (t[pick] * w3[:, :, None]).sum(1) - org[: m // 3]
+    k = m // 3; pl = rng.integers(0, n, k); T = t[pl].astype(np.float64)              # in-plane rays
+    a = rng.normal(scale=3.0, size=(k, 2)); b = rng.normal(size=(k, 2))
+    org[-k:] = T[:, 0] + a[:, :1] * (T[:, 1] - T[:, 0]) + a[:, 1:] * (T[:, 2] - T[:, 0])
+    d[-k:] = b[:, :1] * (T[:, 1] - T[:, 0]) + b[:, 1:] * (T[:, 2] - T[:, 0])
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)
+    rays = np.zeros((m, 8), np.float32); rays[:, 0:3], rays[:, 3], rays[:, 4:7], rays[:, 7] = org, 1e-5, d, 1e30
+
+    class Soup:
+        materials = np.zeros((2, 32), np.float32)
+        def __init__(self, tris):
+            nn = len(tris); v = np.zeros((3 * nn, 7), np.float32); v[:, 0:3] = tris.reshape(-1, 3)
+            self.meshes = [(v, np.arange(3 * nn, dtype=np.uint32), np.ones(3 * nn, np.uint32))]
+            self.instances = [(0, np.eye(4, dtype=np.float32).reshape(16))]
+        def view_proj(self, aspect):
+            e = np.eye(4, dtype=np.float32).reshape(16); return e, e
+
+    o = orc.Oracle().load(Soup(t), 1.0)
+    ref = o.trace_closest(rays, mode=0)
+    hit = bits(ref)[:, 3] != 0xFFFFFFFF
+    assert hit.mean() > 0.1
+    assert not (bits(ref)[-k:, 3] == pl).any(), "a ray lying in a triangle's plane hit that triangle"
+    P = rays[hit, 0:3].astype(np.float64) + ref[hit, 0:1].astype(np.float64) * rays[hit, 4:7].astype(np.float64)
+    tv = t[bits(ref)[hit, 3].astype(np.int64)].astype(np.float64)
+    Q = tv[:, 0] + ref[hit, 1:2] * (tv[:, 1] - tv[:, 0]) + ref[hit, 2:3] * (tv[:, 2] - tv[:, 0])
+    assert (np.abs(P - Q).max(1) <= 0.02 * float((hi - lo).max())).all(), "a reported hit point lies nowhere near its triangle"
+    assert np.array_equal(bits(o.trace_closest(rays, mode=1)), bits(ref)), "the oracle's BVH differs from its brute force"
+    sh = rays.copy(); sh[:, 7] = rng.uniform(0.02, 2.0, m).astype(np.float32)
+    occ = o.trace_any(sh, mode=0)
+    assert np.array_equal(o.trace_any(sh, mode=1), occ)
+    for opts in (dict(), dict(split=1e-6, reinsert=3)):
+        builder_options(**opts)
+        got, refs = rt.bvh_replay(t, rays)
+        assert np.array_equal(bits(got)[:, 3], bits(ref)[:, 3]) and np.array_equal(bits(got)[hit, 0], bits(ref)[hit, 0]), opts
+        for order in (0, 1, 2):
+            assert np.array_equal(bits(rt.bvh_replay(t, sh, any_hit=True, any_order=order)[0])[:, 3] != 0xFFFFFFFF, occ != 0), (opts, order)
 
 
 def test_anyhit_order_probe_is_deterministic_and_scene_dependent(rt, cornell):
@@ -462,6 +520,30 @@ def test_host_layer_under_asan_ubsan(tmp_path, golden_dir):
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "done" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+def test_parallel_builder_under_tsan(tmp_path):
+    """"same tree for any thread count" is a correctness premise of the parallel top-down build, so the threaded host code runs under ThreadSanitizer
+    (g++ -fsanitize=thread, CPU only, device API stubbed): build + re-insertion + wide collapse with 1 / 3 / 16 builder threads on 66 000 triangles — the three trees replay
+    the same traversal ray for ray —, and a whole scene build with the commit-time any-hit probe.  No data race may be reported."""
+    import subprocess, shutil
+    if not shutil.which("g++"):
+        pytest.skip("g++ not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pk = os.path.join(root, "royaltracer-dx_amd")
+    srcs = [os.path.join(root, "tests", "sanitize", f) for f in ("tsan_main.cpp", "device_stubs.cpp")]
+    srcs += [os.path.join(pk, "csrc", "rtx_scene_host.cpp"), os.path.join(pk, "csrc", "rtx_scene_cache.cpp")] + [os.path.join(pk, "host", f) for f in
+             ("DirectXMathLite.cpp", "manipulator.cpp", "ObjLoader.cpp", "Scenes.cpp", "Renderer.cpp", "ImageIO.cpp", "rtx_host_c.cpp")]
+    exe = str(tmp_path / "tsan_host")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer", "-ffp-contract=off",
+           "-I" + os.path.join(root, "include"), "-I" + os.path.join(pk, "csrc"), "-I" + os.path.join(pk, "host"), "-pthread", "-o", exe] + srcs
+    b = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if b.returncode != 0 and "tsan" in b.stderr.lower() and "cannot find" in b.stderr.lower():
+        pytest.skip("libtsan not installed")
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0:second_deadlock_stack=1"), cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "done" in r.stdout and "ThreadSanitizer" not in r.stderr and "data race" not in r.stderr, r.stderr[-3000:]
 
 
 def test_scene_cache_round_trip_and_rejects_damaged_files(rt, cornell, tmp_path, golden_dir):

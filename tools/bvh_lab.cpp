@@ -42,19 +42,22 @@ inline uint32_t f2u_(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 constexpr float kPlaneEps = 2.384185791015625e-07f, kSlabK = 1.00010002f;
 
 
+// the product's triangle test (csrc/rtx_traverse.hpp: tri_test) in the product's own arithmetic — rtx_math.hpp's FUSED dot / cross and the determinant floor in e1.w.
+// (Until round 5 this was an unfused restatement: the what-if rows then "found" 4 / 9 mismatching rays per 648 000 against the replay, which were nothing but
+// hits on an edge — u or v exactly 0, u + v one ulp past 1 — decided differently by the two roundings.  With one arithmetic they are 0.)
 inline bool tri_test(V3 o, V3 d, const TriGPU& Tg, float tmin, float tmax, float& t, float& u, float& v) {
-    const V3 v0{Tg.v0.x, Tg.v0.y, Tg.v0.z}, e1{Tg.e1.x, Tg.e1.y, Tg.e1.z}, e2{Tg.e2.x, Tg.e2.y, Tg.e2.z};
-    const V3 p = crs(d, e2);
-    const float det = dt(e1, p);
-    if (det == 0.0f) return false;
+    const f3 v0 = mk3(Tg.v0.x, Tg.v0.y, Tg.v0.z), e1 = mk3(Tg.e1.x, Tg.e1.y, Tg.e1.z), e2 = mk3(Tg.e2.x, Tg.e2.y, Tg.e2.z), dd = mk3(d.x, d.y, d.z);
+    const f3 p = cross(dd, e2);
+    const float det = dot(e1, p);
+    if (!(fabsf(det) > Tg.e1.w)) return false;
     const float inv = 1.0f / det;
-    const V3 s = o - v0;
-    u = dt(s, p) * inv;
+    const f3 s = mk3(o.x, o.y, o.z) - v0;
+    u = dot(s, p) * inv;
     if (!(u >= 0.0f && u <= 1.0f)) return false;
-    const V3 q = crs(s, e1);
-    v = dt(d, q) * inv;
+    const f3 q = cross(s, e1);
+    v = dot(dd, q) * inv;
     if (!(v >= 0.0f && u + v <= 1.0f)) return false;
-    t = dt(e2, q) * inv;
+    t = dot(e2, q) * inv;
     return t > tmin && t < tmax;
 }
 
@@ -112,6 +115,36 @@ struct WhatIf { const BuiltScene& B; V3 o, d, idir; uint32_t oct; float tmin; fl
         }
     }
 };
+
+// flat=1 — sizing of VERDICT r04 item 2: "replace the three dependent steps at the top of the tree by ONE flat, wave-uniform slab test of the <= 64 level-2 boxes".
+// The 64 boxes are the child slots of the root's <= 8 children; a flat test of them stands for the node steps at depths 0 and 1 (which test exactly these boxes — the step
+// at depth 2 tests the level-3 boxes and stays).  It runs once per ray, before any hit is known, so it cannot cull by the closest distance: counted here are the slots a ray's
+// box test accepts over (tmin, inf) — internal ones (each costs a node step at depth 2 unless re-tested against the best hit when it is popped) and leaf slots.
+inline void flat_level2(const BuiltScene& B, V3 o, V3 idir, uint32_t oct, float tmin, uint32_t& boxes, uint32_t& hit_internal, uint32_t& hit_leaf) {
+    boxes = hit_internal = hit_leaf = 0;
+    if (B.nodes8.empty()) return;
+    const Node8GPU& R = B.nodes8[0];
+    const uint32_t rmask = R.e_imask >> 24;
+    for (uint32_t r = 0; r < (uint32_t)__builtin_popcount(rmask); r++) {
+        const Node8GPU& N = B.nodes8[R.child_base + r];
+        const uint32_t w = N.e_imask, imask = w >> 24;
+        const float s[3] = {u2f_((w & 0xffu) << 23) * idir.x, u2f_((w & 0xff00u) << 15) * idir.y, u2f_((w & 0xff0000u) << 7) * idir.z};
+        const float a3[3] = {(N.px - o.x) * idir.x, (N.py - o.y) * idir.y, (N.pz - o.z) * idir.z};
+        for (int k = 0; k < 8; k++) {
+            const bool internal = (imask >> k) & 1u; const uint32_t nib = (N.trivalid >> (4 * k)) & 0xfu;
+            if (!internal && !nib) continue;
+            boxes++;
+            float lo = tmin, hi = 1e30f;
+            for (int a = 0; a < 3; a++) {
+                const uint32_t qlo = (N.q[2 * a + (k >> 2)] >> (8 * (k & 3))) & 0xffu, qhi = (N.q[2 * (3 + a) + (k >> 2)] >> (8 * (k & 3))) & 0xffu;
+                const bool neg = (oct >> a) & 1u;
+                const float an = fmaf(-fabsf(a3[a]), kPlaneEps, a3[a]), af = fmaf(fabsf(a3[a]), kPlaneEps, a3[a]);
+                lo = fmaxf(lo, fmaf((float)(neg ? qhi : qlo), s[a], an)); hi = fminf(hi, fmaf((float)(neg ? qlo : qhi), s[a], af));
+            }
+            if (!(f2u_(fmaf(hi, kSlabK, -lo)) >> 31)) { if (internal) hit_internal++; else hit_leaf++; }
+        }
+    }
+}
 
 // ---- wave-schedule simulation (wavesim=1): the speculative voted schedule of csrc/rtx_traverse.hpp spec_step (PEND 2, vote "node step if ni >= 2 nl") replayed on the
 // per-ray step sequences of the host replay, with the persistent refill (>= refill idle SLOTS), for ONE or TWO rays per lane.  Cost model: node iteration 205 + 12, triangle
@@ -192,17 +225,19 @@ void wide_sah(const BuiltScene& B, double& node_cost, double& tri_cost, double& 
 
 int main(int argc, char** argv) {
     const std::string which = argc > 1 ? argv[1] : "sponza";
-    int W = 480, Hh = 270, bounces = 4; bool check = false, lower = false, wavesim = false; int whatif = 0;
+    int W = 480, Hh = 270, bounces = 4; bool check = false, lower = false, wavesim = false, flat = false; int whatif = 0;
     for (int i = 2; i < argc; i++) {
         std::string kv = argv[i]; const size_t eq = kv.find('=');
         if (eq == std::string::npos) continue;
         const std::string k = kv.substr(0, eq); const double v = atof(kv.c_str() + eq + 1);
-        if (k == "w") W = (int)v; else if (k == "h") Hh = (int)v; else if (k == "bounces") bounces = (int)v; else if (k == "check") check = v != 0; else if (k == "lower") lower = v != 0; else if (k == "wavesim") wavesim = v != 0; else if (k == "whatif") whatif = (int)v; else if (k == "any_order") g_any_order = (int)v;
+        if (k == "w") W = (int)v; else if (k == "h") Hh = (int)v; else if (k == "bounces") bounces = (int)v; else if (k == "check") check = v != 0; else if (k == "lower") lower = v != 0; else if (k == "wavesim") wavesim = v != 0; else if (k == "whatif") whatif = (int)v; else if (k == "flat") { flat = v != 0; if (flat && !whatif) whatif = 3; } else if (k == "any_order") g_any_order = (int)v;
         else if (!bvh_build_option(k.c_str(), v)) { fprintf(stderr, "unknown key %s\n", k.c_str()); return 2; }
     }
     Scene s;
     if (which == "sponza") s = MakeSponzaClass();
     else if (which == "bistro") s = MakeBistroClass();
+    else if (which == "sponza_hard") s = MakeSponzaClass(262144, 260, true);       // the size distribution of the real asset (host/Scenes.h)
+    else if (which == "bistro_hard") s = MakeBistroClass(3800000, 3800, true);
     else if (which == "garage") s = LoadObjScene({"tests/golden/garage.obj", "tests/golden/monke.obj"}, "tests/golden/");
     else if (which == "cornell") s = MakeCornellBox();
     else { fprintf(stderr, "scene?\n"); return 2; }
@@ -230,10 +265,10 @@ int main(int argc, char** argv) {
     V3 lightp{0, 0, 0}; bool have_light = !B.lights.empty();
     const auto t1 = std::chrono::steady_clock::now();
     std::vector<std::vector<uint8_t>> seq_closest(wavesim ? (size_t)npx : 0);
-    size_t mism = 0; double low_steps = 0, low_tris = 0; double lev_all[16] = {0}, zero_all[16] = {0}; double g_occ[4] = {0, 0, 0, 0};
+    size_t mism = 0; double low_steps = 0, low_tris = 0; double lev_all[16] = {0}, zero_all[16] = {0}; double g_occ[4] = {0, 0, 0, 0}; double flat_all[3] = {0, 0, 0};
 #pragma omp parallel
     {
-        std::vector<double> a(bounces + 1, 0), b(bounces + 1, 0), sa(bounces + 1, 0), sb(bounces + 1, 0); std::vector<size_t> c(bounces + 1, 0), sc(bounces + 1, 0), hc(bounces + 1, 0); size_t mm = 0; double la = 0, lb = 0; double levl[16] = {0}, zerol[16] = {0}; double occ_n = 0, occ_steps = 0, vis_n = 0, vis_steps = 0;
+        std::vector<double> a(bounces + 1, 0), b(bounces + 1, 0), sa(bounces + 1, 0), sb(bounces + 1, 0); std::vector<size_t> c(bounces + 1, 0), sc(bounces + 1, 0), hc(bounces + 1, 0); size_t mm = 0; double la = 0, lb = 0; double levl[16] = {0}, zerol[16] = {0}; double occ_n = 0, occ_steps = 0, vis_n = 0, vis_steps = 0; double flatl[3] = {0, 0, 0};
 #pragma omp for schedule(dynamic, 64)
         for (int px = 0; px < npx; px++) {
             const int x = px % W, y = px / W;
@@ -251,7 +286,8 @@ int main(int argc, char** argv) {
                 if (whatif) { const float dxs = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x, dys = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y, dzs = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
                     const V3 idir{1.0f / dxs, 1.0f / dys, 1.0f / dzs};
                     WhatIf Wf{B, o, d, idir, (idir.x < 0 ? 1u : 0u) | (idir.y < 0 ? 2u : 0u) | (idir.z < 0 ? 4u : 0u), tmin, 1e30f, 0xffffffffu, 0, 0, whatif == 3 ? 0 : whatif, levl, zerol};      // 3: the device's order and culling (depth statistics), 4: visit by entry distance, no skip
-                    Wf.node(0); la += Wf.steps; lb += Wf.tris; if (Wf.bprim != H.prim) mm++; }
+                    Wf.node(0); la += Wf.steps; lb += Wf.tris; if (Wf.bprim != H.prim) mm++;
+                    if (flat) { uint32_t nb, hi_, hl_; flat_level2(B, o, idir, Wf.oct, tmin, nb, hi_, hl_); flatl[0] += nb; flatl[1] += hi_; flatl[2] += hl_; } }
                 if (lower) { const Hit H2 = traverse<false>(B, o, d, tmin, 1e30f, H.prim == 0xffffffffu ? 1e30f : H.t); la += H2.steps; lb += H2.tris; }
                 if (H.prim == 0xffffffffu) break;
                 hc[bnc]++;
@@ -282,7 +318,7 @@ int main(int argc, char** argv) {
             }
         }
 #pragma omp critical
-        { for (int i = 0; i <= bounces; i++) { st_steps[i] += a[i]; st_tris[i] += b[i]; cnt[i] += c[i]; sh_steps[i] += sa[i]; sh_tris[i] += sb[i]; shc[i] += sc[i]; hitc[i] += hc[i]; } mism += mm; low_steps += la; low_tris += lb; g_occ[0] += occ_n; g_occ[1] += occ_steps; g_occ[2] += vis_n; g_occ[3] += vis_steps; for (int i = 0; i < 16; i++) { lev_all[i] += levl[i]; zero_all[i] += zerol[i]; } }
+        { for (int i = 0; i <= bounces; i++) { st_steps[i] += a[i]; st_tris[i] += b[i]; cnt[i] += c[i]; sh_steps[i] += sa[i]; sh_tris[i] += sb[i]; shc[i] += sc[i]; hitc[i] += hc[i]; } mism += mm; low_steps += la; low_tris += lb; g_occ[0] += occ_n; g_occ[1] += occ_steps; g_occ[2] += vis_n; g_occ[3] += vis_steps; for (int i = 0; i < 16; i++) { lev_all[i] += levl[i]; zero_all[i] += zerol[i]; } for (int i = 0; i < 3; i++) flat_all[i] += flatl[i]; }
     }
     const double sim_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
     double ts = 0, tt = 0, ss = 0, stt = 0; size_t tc_ = 0, sc_ = 0;
@@ -308,6 +344,16 @@ int main(int argc, char** argv) {
     }
     if (whatif) printf("  what-if %d (1: skip popped children beyond the best hit; 2: + visit by entry distance): steps/ray %.3f tris/ray %.3f mismatches %zu\n", whatif, low_steps / tc_, low_tris / tc_, mism);
     if (whatif) { printf("  steps per ray by depth (zero-hit share):"); for (int i = 0; i < 16 && lev_all[i] > 0; i++) printf(" %d: %.2f (%.0f%%)", i, lev_all[i] / tc_, 100.0 * zero_all[i] / lev_all[i]); printf("\n"); }
+    if (flat) {
+        const double d01 = (lev_all[0] + lev_all[1]) / tc_, d2 = lev_all[2] / tc_, fb = flat_all[0] / tc_, fi = flat_all[1] / tc_, fl = flat_all[2] / tc_;
+        printf("  flat test of the level-2 boxes (children of the root's children): %.1f boxes per ray; accepted over (tmin, inf): %.2f internal + %.2f leaf slots per ray\n", fb, fi, fl);
+        printf("    the traversal as it is: %.2f node steps per ray at depths 0 + 1 (what the flat test replaces), %.2f at depth 2 (culled by the closest hit so far)\n", d01, d2);
+        // VALU wave-instructions per ray: a node step is 217 (205 + 12 of loop) at 47 of 64 lanes; the flat test ~13 per box (3 packed FMA + 6 min / max + min3 / max3 + compare + v_addc_co), wave-uniform
+        const double cur = (d01 + d2) * 217.0 / 47.0;
+        const double at64 = fb * 13.0 / 64.0 + fi * 217.0 / 47.0, at16 = fb * 13.0 / 16.0 + fi * 217.0 / 47.0, retest = fb * 13.0 / 64.0 + fi * 30.0 / 47.0 + d2 * 217.0 / 47.0;
+        printf("    VALU wave-instructions per ray for depths 0-2: as it is %.1f | flat at 64 lanes (a pre-pass over the whole sub-queue), every accepted slot stepped %.1f | flat inside the persistent loop, where rays arrive %u at a time (refill threshold) %.1f | flat at 64 lanes + a 30-instruction re-test of every accepted slot against the best hit at pop (lower bound: as many depth-2 steps as today) %.1f\n",
+               cur, at64, 16u, at16, retest);
+    }
     if (lower) printf("  with the closest distance known in advance (bound for any visiting order): steps/ray %.3f tris/ray %.3f\n", low_steps / tc_, low_tris / tc_);
     if (check && mism) { printf("  mismatches: %zu\n", mism); return 1; }
     return 0;

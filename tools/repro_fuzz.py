@@ -1,12 +1,13 @@
 import os, sys
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 os.environ["RTX_FUZZ_SEED"] = "200000"
 import numpy as np
 import __graft_entry__ as g
 rt = g.load_package()
 import importlib.util
-spec = importlib.util.spec_from_file_location("tgp", "/root/repo/tests/test_gpu_parity.py"); tgp = importlib.util.module_from_spec(spec); spec.loader.exec_module(tgp)
-sys.path.insert(0, '/root/repo/oracle'); import orc
+spec = importlib.util.spec_from_file_location("tgp", os.path.join(ROOT, "tests", "test_gpu_parity.py")); tgp = importlib.util.module_from_spec(spec); spec.loader.exec_module(tgp)
+sys.path.insert(0, os.path.join(ROOT, 'oracle')); import orc
 bits = tgp.bits
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 817
 W, H = 48, 32
