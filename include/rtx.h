@@ -80,6 +80,8 @@ typedef struct rtx_stats {
     uint64_t primary_hits;                                /* camera rays that hit the scene (items of the bounce-0 shading launch) */
     uint32_t bvh_refits, bvh_refs;                        /* commits since the last full BVH build that only refitted boxes; leaf entries of the tree (= triangles unless
                                                              spatial splits, RTX_OPT_BVH_SPLIT, reference some from several leaves) */
+    uint64_t restir_stale_history_reads;                  /* rtx_render_restir on shards: temporal-pass reads of last frame's history at a pixel where this context does not hold it
+                                                             (outside own rectangle + exchanged halo): must be 0, see rtx_restir_pack_halo */
 } rtx_stats;
 
 enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents (rtx_stats.kernel_ms) */
@@ -228,6 +230,27 @@ int  rtx_render_restir(rtx_ctx*, const rtx_params*);
 int  rtx_restir_state_slab_bytes(const rtx_params*, size_t* bytes_per_shard);
 int  rtx_restir_pack_state(rtx_ctx*, const rtx_params*, void* device_slab);                       /* u3 / u5 / u7 of my tiles -> slab */
 int  rtx_restir_unpack_state(rtx_ctx*, const rtx_params*, const void* device_slabs_all_shards);   /* all shards' slabs -> my u3 / u5 / u7 */
+/* HALO EXCHANGE of the history ("halo exchange (20 px) if tiles are sharded"; round 5) — instead of all-gathering every rank's 140 B per pixel (326 MB received
+   per rank and frame at 1080p on 8 ranks), a rank of the RTX_FLAG_BLOCK_TILES deal sends each neighbour only the part of its own rectangle that lies within `halo_px` of the
+   neighbour's rectangle, and receives the mirror image: <= 8 peers (point-to-point, one xGMI link each), ~10 MB sent per rank.  What makes it sufficient: passes 1 + 2 of the
+   next frame run on the rank's rectangle dilated by the 20-px radius of the spatial pass, and the temporal pass reads the history at the REPROJECTED pixel — so the history must
+   be valid in the rectangle dilated by 20 px + the largest reprojection displacement of a frame, i.e. halo_px >= 20 + that displacement (32 = one tile edge of the sharded deal
+   covers 12 px of motion per frame).  The context KNOWS where its history is valid (own rectangle after a frame, + halo_px after rtx_restir_unpack_halo, the whole image after
+   rtx_restir_unpack_state / rtx_restir_reset) and COUNTS every temporal read that lands outside it: rtx_stats.restir_stale_history_reads of the frame must be 0 — a caller that
+   sees it rise (a camera cut) falls back to the all-gather (rtx_restir_pack_state / unpack_state) and repeats the frame.  With the count at 0, images and the history inside
+   the valid region are bit-identical to the unsharded run.
+   rtx_restir_halo_plan needs no context (message via rtx_last_error(NULL)): peers in ascending rank order, regions as pixel rectangles [x0, x1) x [y0, y1), records in
+   row-major order, 140 B each (Reservoir_DI 40 | Reservoir_GI 40 | SampleData 60), offsets into ONE send and ONE receive buffer per rank.  send region of (me -> q) ==
+   receive region of (q <- me) by construction (tests/test_multigpu_gloo.py pins the symmetry). */
+typedef struct rtx_halo_peer {
+    uint32_t rank;
+    uint32_t send_x0, send_y0, send_x1, send_y1;     /* part of MY rectangle within halo_px of the peer's */
+    uint32_t recv_x0, recv_y0, recv_x1, recv_y1;     /* part of the PEER's rectangle within halo_px of mine */
+    uint64_t send_offset, send_bytes, recv_offset, recv_bytes;
+} rtx_halo_peer;
+int  rtx_restir_halo_plan(const rtx_params*, uint32_t halo_px, rtx_halo_peer* peers, uint32_t max_peers, uint32_t* npeers, uint64_t* send_bytes_total, uint64_t* recv_bytes_total);
+int  rtx_restir_pack_halo(rtx_ctx*, const rtx_params*, uint32_t halo_px, void* device_send_buffer);            /* u3 / u5 / u7 of every send region -> send buffer (enqueued) */
+int  rtx_restir_unpack_halo(rtx_ctx*, const rtx_params*, uint32_t halo_px, const void* device_recv_buffer);    /* receive buffer -> my u3 / u5 / u7; the history is valid in my rectangle + halo_px afterwards */
 int  rtx_restir_reset(rtx_ctx*);
 int  rtx_read_restir_last(rtx_ctx*, void* reservoirs_di40, void* reservoirs_gi40, void* samples60, size_t slots);   /* u3 / u5 / u7 */
 int  rtx_read_accum(rtx_ctx*, float* rgba32f, size_t bytes);       /* copy of u1 to the host */

@@ -69,7 +69,7 @@ class Stats(C.Structure):
                 ("paths", C.c_uint64), ("kernel_ms", C.c_double * K_COUNT), ("kernel_launches", C.c_uint64 * K_COUNT),
                 ("kernel_items", C.c_uint64 * K_COUNT), ("render_ms", C.c_double),
                 ("bvh_nodes", C.c_uint32), ("triangles", C.c_uint32), ("lights", C.c_uint32), ("materials", C.c_uint32),
-                ("primary_hits", C.c_uint64), ("bvh_refits", C.c_uint32), ("bvh_refs", C.c_uint32)]
+                ("primary_hits", C.c_uint64), ("bvh_refits", C.c_uint32), ("bvh_refs", C.c_uint32), ("restir_stale_history_reads", C.c_uint64)]
 
     @property
     def rays(self):
@@ -111,6 +111,15 @@ _sig("rtx_restir_reset", C.c_int, _vp)
 _sig("rtx_restir_state_slab_bytes", C.c_int, C.POINTER(Params), C.POINTER(C.c_size_t))
 _sig("rtx_restir_pack_state", C.c_int, _vp, C.POINTER(Params), _vp)
 _sig("rtx_restir_unpack_state", C.c_int, _vp, C.POINTER(Params), _vp)
+class HaloPeer(C.Structure):
+    """rtx_halo_peer (include/rtx.h): one neighbour of a rank in the halo exchange of the ReSTIR history"""
+    _fields_ = [(n, C.c_uint32) for n in ("rank", "send_x0", "send_y0", "send_x1", "send_y1", "recv_x0", "recv_y0", "recv_x1", "recv_y1")] + \
+               [(n, C.c_uint64) for n in ("send_offset", "send_bytes", "recv_offset", "recv_bytes")]
+
+
+_sig("rtx_restir_halo_plan", C.c_int, C.POINTER(Params), _u32, C.POINTER(HaloPeer), _u32, _u32p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+_sig("rtx_restir_pack_halo", C.c_int, _vp, C.POINTER(Params), _u32, _vp)
+_sig("rtx_restir_unpack_halo", C.c_int, _vp, C.POINTER(Params), _u32, _vp)
 _sig("rtx_read_restir_last", C.c_int, _vp, _vp, _vp, _vp, C.c_size_t)
 _sig("rtx_pass1_slots", C.c_size_t, _u32, _u32)
 _sig("rtx_read_pass1_buffers", C.c_int, _vp, _vp, _vp, _vp, C.c_size_t)
@@ -403,6 +412,14 @@ def bvh8_stats(world_tris):
     return rc, hist, nodes.value
 
 
+def restir_halo_plan(params, halo_px):
+    """rtx_restir_halo_plan (no context, no GPU): ([HaloPeer ...] in ascending rank order, send bytes, receive bytes) of params.shard_rank in the RTX_FLAG_BLOCK_TILES deal"""
+    peers = (HaloPeer * 64)(); n = _u32(); st, rt_ = C.c_uint64(), C.c_uint64()
+    if lib.rtx_restir_halo_plan(C.byref(params), halo_px, peers, 64, C.byref(n), C.byref(st), C.byref(rt_)) != 0:
+        raise RtxError("rtx_restir_halo_plan: " + (lib.rtx_last_error(None) or b"").decode())
+    return [peers[i] for i in range(n.value)], st.value, rt_.value
+
+
 def bvh_option(key, value):
     """process-wide builder default (csrc/rtx_scene_host.hpp BvhBuildOptions); contexts created afterwards start with it"""
     if lib.rtxh_bvh_option(key.encode(), float(value)) != 0:
@@ -544,6 +561,12 @@ class Context:
 
     def restir_unpack_state(self, params, device_ptr):
         self._ck(lib.rtx_restir_unpack_state(self._h, C.byref(params), _vp(device_ptr)), "rtx_restir_unpack_state")
+
+    def restir_pack_halo(self, params, halo_px, device_ptr):
+        self._ck(lib.rtx_restir_pack_halo(self._h, C.byref(params), halo_px, _vp(device_ptr)), "rtx_restir_pack_halo")
+
+    def restir_unpack_halo(self, params, halo_px, device_ptr):
+        self._ck(lib.rtx_restir_unpack_halo(self._h, C.byref(params), halo_px, _vp(device_ptr)), "rtx_restir_unpack_halo")
 
     def restir_reset(self):
         self._ck(lib.rtx_restir_reset(self._h), "rtx_restir_reset")

@@ -28,7 +28,7 @@ struct DevBuf {
         if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
         if (!n) n = 16;
         hipError_t e = hipMalloc(&p, n);
-        if (e == hipSuccess) { bytes = n; if (poison_byte() >= 0) e = hipMemset(p, poison_byte(), n); }
+        if (e == hipSuccess) { bytes = n; if (poison_byte() >= 0) { e = hipMemset(p, poison_byte(), n); if (e == hipSuccess) e = hipDeviceSynchronize(); } }     // (the fill runs on the null stream, the context's streams are non-blocking: join before anything is uploaded)
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
@@ -68,6 +68,9 @@ struct rtx_ctx {
     // ReSTIR work lists (x | y << 16 per pixel, 8 x 8 pixel blocks in MORTON order so that consecutive chunks are compact screen regions): the shard's own pixels
     // (pass 3) and — on shards — its tiles dilated by the 20-px radius of the spatial pass (passes 1 and 2); key = (width, height, tile, rank, count, deal)
     DevBuf d_halo, d_own; uint32_t halo_count = 0, own_count = 0; uint32_t halo_key[6] = {0, 0, 0, 0, 0, 0};
+    // where this context holds last frame's ReSTIR history (pixel rectangle, exclusive upper bounds): the whole image after a reset / an unsharded frame / rtx_restir_unpack_state,
+    // the own rectangle after a sharded frame, + halo_px after rtx_restir_unpack_halo; hist_all = the whole image whatever its size
+    uint32_t hist[4] = {0, 0, 0, 0}; bool hist_all = true;
     bool bounce_ring = true;        // RTX_OPT_BOUNCE_VARIANT
     bool fused_bvh = false;         // RTX_OPT_FUSED_BVH: general path = one k_bounce_bvh launch per batch (trace -> shade -> shadow per sub-queue and bounce); measured SLOWER, default off
     DevBuf d_hitq;
@@ -548,7 +551,14 @@ static int make_frame(rtx_ctx* c, const rtx_params* p, DevFrame& f) {
     f.batch_spp = 1; f.sample_first = p->sample_base;
     f.max_bounces = p->max_bounces; f.nee_samples = p->nee_samples; f.rr_start = p->rr_start;
     f.frame_seed = p->frame_seed; f.flags = p->flags;
+    f.hist_x0 = f.hist_y0 = 0; f.hist_x1 = p->width; f.hist_y1 = p->height; f.hist_stale = nullptr;
     return RTX_OK;
+}
+// pixel rectangle [x0, x1) x [y0, y1) of rank r in the RTX_FLAG_BLOCK_TILES deal (shard_tile's rule, clipped to the image)
+static void block_rect(uint32_t W, uint32_t H, uint32_t ts, uint32_t TX, uint32_t TY, uint32_t gx, uint32_t gy, uint32_t r, uint32_t out[4]) {
+    const uint32_t bx = r % gx, by = r / gx;
+    out[0] = std::min(W, (bx * TX / gx) * ts); out[2] = std::min(W, ((bx + 1u) * TX / gx) * ts);
+    out[1] = std::min(H, (by * TY / gy) * ts); out[3] = std::min(H, ((by + 1u) * TY / gy) * ts);
 }
 
 static hipEvent_t take_event(rtx_ctx* c) {
@@ -949,7 +959,7 @@ int rtx_render_v6_pass1(rtx_ctx* c, const rtx_params* p) {
 
 static int p1_alloc(rtx_ctx* c, size_t slots) {
     HIPCHK(c, c->d_res_di.ensure(slots * 40)); HIPCHK(c, c->d_res_gi.ensure(slots * 40)); HIPCHK(c, c->d_sdata.ensure(slots * 60));
-    HIPCHK(c, c->d_p1cnt.ensure(24));
+    HIPCHK(c, c->d_p1cnt.ensure(32));          // rays by type (3 x u64) + stale history reads
     if (c->p1_slots != slots) {
         HIPCHK(c, hipMemsetAsync(c->d_res_di.p, 0, slots * 40, c->stream)); HIPCHK(c, hipMemsetAsync(c->d_res_gi.p, 0, slots * 40, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_sdata.p, 0, slots * 60, c->stream));
@@ -961,6 +971,7 @@ static int p1_alloc(rtx_ctx* c, size_t slots) {
 int rtx_restir_reset(rtx_ctx* c) {
     BIND(c);
     c->last_slots = 0;           // the next frame starts from zeroed g_*_last buffers
+    c->hist_all = true;          // ... which is what every rank holds then: valid everywhere
     return RTX_OK;
 }
 
@@ -1040,8 +1051,12 @@ int rtx_render_restir(rtx_ctx* c, const rtx_params* p) {
     DevBuf& scratch = c->d_p1scratch; HIPCHK(c, scratch.ensure((size_t)p->width * p->height * 16));     // context-owned: no per-call hipMalloc / hipFree, nothing to leak on an early return
     stats_begin(c);
     struct LaneJoin { rtx_ctx* c; ~LaneJoin() { for (hipStream_t ls : c->lane_stream) if (ls) (void)hipStreamSynchronize(ls); } } lane_join{c};      // no early return leaves another lane running
-    HIPCHK(c, hipMemsetAsync(c->d_p1cnt.p, 0, 24, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_p1cnt.p, 0, 32, c->stream));
     uint32_t* bufs[6] = {(uint32_t*)c->d_res_di.p, (uint32_t*)c->d_res_gi.p, (uint32_t*)c->d_sdata.p, (uint32_t*)c->d_last_di.p, (uint32_t*)c->d_last_gi.p, (uint32_t*)c->d_last_sd.p};
+    if (!c->hist_all) {                       // the history this context holds does not cover the image (a sharded frame came before, and no all-gather since): count reads outside it
+        f.hist_x0 = c->hist[0]; f.hist_y0 = c->hist[1]; f.hist_x1 = c->hist[2]; f.hist_y1 = c->hist[3];
+        f.hist_stale = (unsigned long long*)c->d_p1cnt.p + 3;
+    }
     const uint32_t mbk = (uint32_t)c->num_cus * 8u;
     const CameraGPU* cam = (const CameraGPU*)c->d_cam.p;
     HIPCHK(c, hipEventRecord(c->ev_begin, c->stream));
@@ -1059,10 +1074,18 @@ int rtx_render_restir(rtx_ctx* c, const rtx_params* p) {
     }
     HIPCHK(c, hipEventRecord(c->ev_end, c->stream));
     HIPCHK(c, hipGetLastError());
-    unsigned long long cnt[3] = {0, 0, 0};
-    HIPCHK(c, hipMemcpyAsync(cnt, c->d_p1cnt.p, 24, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long cnt[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(cnt, c->d_p1cnt.p, 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     stats_end_restir(c, cnt);
+    c->stats.restir_stale_history_reads = cnt[3];
+    // pass 3 wrote this frame's history for the pixels it ran on: the whole image, or — on shards — the own tiles (one rectangle in the block deal; the round-robin deal
+    // has no rectangle to describe them: every temporal read counts as stale until rtx_restir_unpack_state has brought the other ranks' tiles)
+    c->hist_all = !sharded;
+    if (sharded) {
+        if (f.blk_gx) block_rect(p->width, p->height, f.tile_size, f.tiles_x, f.tiles_y, f.blk_gx, f.blk_gy, f.shard_rank, c->hist);
+        else c->hist[0] = c->hist[1] = c->hist[2] = c->hist[3] = 0;
+    }
     return RTX_OK;
 }
 
@@ -1100,8 +1123,80 @@ int rtx_restir_unpack_state(rtx_ctx* c, const rtx_params* p, const void* slabs) 
     launch_restir_unpack_state(c->stream, (uint32_t)c->num_cus * 8u, f, f.shard_count, (const uint32_t*)slabs, bufs);
     HIPCHK(c, hipGetLastError());
     if (c->own_stream) HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->hist_all = true;                     // every rank's tiles are here now
     return RTX_OK;
 }
+
+// ---- ... or of its border strips only (rtx.h: rtx_restir_pack_halo) ----
+// Peers of rank r in the block deal: every rank q != r whose rectangle comes within halo_px of r's.  send = rect(r) ∩ dilate(rect(q)), recv = rect(q) ∩ dilate(rect(r)).
+struct HaloPlan { std::vector<rtx_halo_peer> peers; uint64_t send_total = 0, recv_total = 0; uint32_t own[4] = {0, 0, 0, 0}; };
+static const char* halo_plan(const rtx_params* p, uint32_t halo, HaloPlan& P) {
+    uint32_t ts = 0, cnt = 0, gx = 0, gy = 0; uint64_t npl = 0;
+    if (const char* e = validate_tiling(p, ts, cnt, npl, &gx, &gy)) return e;
+    if (cnt < 2 || !gx) return "halo exchange: needs shard_count > 1 and RTX_FLAG_BLOCK_TILES (one rectangle of tiles per rank)";
+    if (halo == 0 || halo > 4096) return "halo exchange: halo_px must be in [1, 4096]";
+    const uint32_t W = p->width, H = p->height, TX = (W + ts - 1) / ts, TY = (H + ts - 1) / ts;
+    block_rect(W, H, ts, TX, TY, gx, gy, p->shard_rank, P.own);
+    auto clip = [](const uint32_t a[4], const uint32_t b[4], uint32_t grow, uint32_t W_, uint32_t H_, uint32_t out[4]) {      // a ∩ dilate(b, grow); false: empty
+        const uint32_t bx0 = b[0] > grow ? b[0] - grow : 0u, by0 = b[1] > grow ? b[1] - grow : 0u, bx1 = std::min(W_, b[2] + grow), by1 = std::min(H_, b[3] + grow);
+        out[0] = std::max(a[0], bx0); out[1] = std::max(a[1], by0); out[2] = std::min(a[2], bx1); out[3] = std::min(a[3], by1);
+        return out[0] < out[2] && out[1] < out[3];
+    };
+    P.peers.clear(); P.send_total = P.recv_total = 0;
+    if (P.own[0] >= P.own[2] || P.own[1] >= P.own[3]) return nullptr;                          // a rank without pixels (more ranks than tile columns): no peers
+    for (uint32_t q = 0; q < cnt; q++) {
+        if (q == p->shard_rank) continue;
+        uint32_t rq[4], sr[4], rr[4]; block_rect(W, H, ts, TX, TY, gx, gy, q, rq);
+        if (rq[0] >= rq[2] || rq[1] >= rq[3]) continue;
+        if (!clip(P.own, rq, halo, W, H, sr) || !clip(rq, P.own, halo, W, H, rr)) continue;         // (both are empty or neither is: the dilation is symmetric)
+        rtx_halo_peer e{}; e.rank = q;
+        e.send_x0 = sr[0]; e.send_y0 = sr[1]; e.send_x1 = sr[2]; e.send_y1 = sr[3]; e.recv_x0 = rr[0]; e.recv_y0 = rr[1]; e.recv_x1 = rr[2]; e.recv_y1 = rr[3];
+        e.send_offset = P.send_total; e.send_bytes = (uint64_t)(sr[2] - sr[0]) * (sr[3] - sr[1]) * 140u; P.send_total += e.send_bytes;
+        e.recv_offset = P.recv_total; e.recv_bytes = (uint64_t)(rr[2] - rr[0]) * (rr[3] - rr[1]) * 140u; P.recv_total += e.recv_bytes;
+        P.peers.push_back(e);
+    }
+    if (P.send_total / 140u > 0xFFFFFFFFull || P.recv_total / 140u > 0xFFFFFFFFull) return "halo exchange: regions too large";
+    return nullptr;
+}
+int rtx_restir_halo_plan(const rtx_params* p, uint32_t halo_px, rtx_halo_peer* peers, uint32_t max_peers, uint32_t* npeers, uint64_t* send_total, uint64_t* recv_total) {
+    HaloPlan P;
+    if (const char* e = halo_plan(p, halo_px, P)) { g_create_err = e; return RTX_ERR_INVALID; }
+    if (npeers) *npeers = (uint32_t)P.peers.size();
+    if (send_total) *send_total = P.send_total;
+    if (recv_total) *recv_total = P.recv_total;
+    if (peers) {
+        if (P.peers.size() > max_peers) { g_create_err = "halo plan: more peers than the caller's array holds"; return RTX_ERR_INVALID; }
+        for (size_t i = 0; i < P.peers.size(); i++) peers[i] = P.peers[i];
+    }
+    return RTX_OK;
+}
+static int halo_move(rtx_ctx* c, const rtx_params* p, uint32_t halo_px, void* buf, bool pack) {
+    DevFrame f; uint32_t* bufs[6];
+    int r = restir_state_bufs(c, p, f, bufs); if (r) return r;
+    HaloPlan P;
+    if (const char* e = halo_plan(p, halo_px, P)) { c->err = e; return RTX_ERR_INVALID; }
+    if (!buf && (pack ? P.send_total : P.recv_total)) return RTX_ERR_INVALID;
+    for (size_t i = 0; i < P.peers.size(); i += kHaloPeers) {                                  // (<= 8 peers in practice: one launch)
+        uint32_t rects[4 * kHaloPeers]; uint32_t n = 0;
+        for (; n < kHaloPeers && i + n < P.peers.size(); n++) {
+            const rtx_halo_peer& e = P.peers[i + n];
+            rects[4 * n] = pack ? e.send_x0 : e.recv_x0; rects[4 * n + 1] = pack ? e.send_y0 : e.recv_y0;
+            rects[4 * n + 2] = pack ? e.send_x1 - e.send_x0 : e.recv_x1 - e.recv_x0; rects[4 * n + 3] = pack ? e.send_y1 - e.send_y0 : e.recv_y1 - e.recv_y0;
+        }
+        const uint64_t off = pack ? P.peers[i].send_offset : P.peers[i].recv_offset;
+        launch_restir_halo(c->stream, (uint32_t)c->num_cus * 8u, p->width, pack, rects, n, bufs, (uint32_t*)((char*)buf + off));
+    }
+    HIPCHK(c, hipGetLastError());
+    if (c->own_stream) HIPCHK(c, hipStreamSynchronize(c->stream));      // on a caller-bound stream the exchange that follows is stream-ordered
+    if (!pack) {                                                        // the history now covers my rectangle + the halo (clipped to the image)
+        c->hist_all = false;
+        c->hist[0] = P.own[0] > halo_px ? P.own[0] - halo_px : 0u; c->hist[1] = P.own[1] > halo_px ? P.own[1] - halo_px : 0u;
+        c->hist[2] = std::min(p->width, P.own[2] + halo_px); c->hist[3] = std::min(p->height, P.own[3] + halo_px);
+    }
+    return RTX_OK;
+}
+int rtx_restir_pack_halo(rtx_ctx* c, const rtx_params* p, uint32_t halo_px, void* send) { BIND(c); return halo_move(c, p, halo_px, send, true); }
+int rtx_restir_unpack_halo(rtx_ctx* c, const rtx_params* p, uint32_t halo_px, const void* recv) { BIND(c); return halo_move(c, p, halo_px, const_cast<void*>(recv), false); }
 
 int rtx_read_restir_last(rtx_ctx* c, void* di, void* gi, void* sd, size_t slots) {
     BIND(c);

@@ -1252,6 +1252,15 @@ void launch_restir_unpack_state(hipStream_t st, uint32_t max_blocks, const DevFr
     RestirBufs B = {bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], bufs[5]};
     hipLaunchKernelGGL(k_restir_unpack_state, dim3(grid_for(f.npl * nshards, max_blocks)), dim3(kBlock), 0, st, f, nshards, slabs, B);
 }
+// history records of n <= 16 pixel rectangles <-> one buffer (rtx_restir_pack_halo / unpack_halo): rect k = (x0, y0, w, h), records of all rectangles back to back
+void launch_restir_halo(hipStream_t st, uint32_t max_blocks, uint32_t width, bool pack, const uint32_t* rects4, uint32_t n, uint32_t* const bufs[6], uint32_t* buf) {
+    RestirBufs B = {bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], bufs[5]};
+    HaloRects R{}; R.n = n; R.first[0] = 0;
+    for (uint32_t k = 0; k < n; k++) { R.x0[k] = rects4[4 * k]; R.y0[k] = rects4[4 * k + 1]; R.w[k] = rects4[4 * k + 2]; R.first[k + 1] = R.first[k] + rects4[4 * k + 2] * rects4[4 * k + 3]; }
+    if (!R.first[n]) return;
+    if (pack) hipLaunchKernelGGL(k_restir_halo<true>, dim3(grid_for(R.first[n], max_blocks)), dim3(kBlock), 0, st, width, R, B, buf);
+    else hipLaunchKernelGGL(k_restir_halo<false>, dim3(grid_for(R.first[n], max_blocks)), dim3(kBlock), 0, st, width, R, B, buf);
+}
 void launch_restir_pass3(hipStream_t st, uint32_t max_blocks, const DevScene& sc, const DevFrame& f, const CameraGPU* cam, uint32_t* const bufs[6], F4* accum, unsigned long long* counters) {
     RestirBufs B = {bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], bufs[5]};
     hipLaunchKernelGGL(k_restir_pass3, dim3(grid_for(f.npl, max_blocks)), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, f, cam, B, accum, counters);

@@ -48,6 +48,9 @@ struct DevFrame {
     uint32_t nblocks, qcap, chunks_per_sample;   // chunks_per_sample = npl / 256
     uint32_t interleave;     // RTX_OPT_SAMPLE_INTERLEAVE (k_raygen): 0 = a chunk of 256 queue entries is 256 pixel slots of ONE sample; s > 0 = 256 >> s pixel slots x 2^s consecutive samples, a pixel's samples in neighbouring lanes
     uint32_t taper_levels;   // k_raygen: 0 = chunks dealt evenly (chunk c -> sub-queue c mod nblocks); L > 0 = tapered deal with L weight classes (taper_row_width below)
+    // ReSTIR on shards: the pixel rectangle [hist_x0, hist_x1) x [hist_y0, hist_y1) in which this context holds last frame's history (rtx_api.hip: rtx_ctx::hist); the temporal
+    // pass counts its reads outside it in *hist_stale (nullptr: not counted — unsharded frames hold the whole image)
+    uint32_t hist_x0, hist_y0, hist_x1, hist_y1; unsigned long long* hist_stale;
 };
 
 // TAPERED sub-queue sizes (RTX_OPT_TAPER).  Workgroups are dispatched in index order and every launch of a bounce ends when its LAST workgroup does; with equal sub-queues
@@ -157,6 +160,8 @@ void launch_restir_pass2(hipStream_t, uint32_t max_blocks, const DevScene&, cons
 // the ReSTIR history (u3 / u5 / u7) of the shard's own tiles <-> [local slot][35 dwords] slab, for the per-frame all-gather of sharded ReSTIR
 void launch_restir_pack_state(hipStream_t, uint32_t max_blocks, const DevFrame&, uint32_t* const bufs[6], uint32_t* slab);
 void launch_restir_unpack_state(hipStream_t, uint32_t max_blocks, const DevFrame&, uint32_t nshards, const uint32_t* slabs, uint32_t* const bufs[6]);
+constexpr uint32_t kHaloPeers = 16;      // rectangles per launch of k_restir_halo (a rank of the block deal has <= 8 neighbours)
+void launch_restir_halo(hipStream_t, uint32_t max_blocks, uint32_t width, bool pack, const uint32_t* rects4 /* x0, y0, w, h per rectangle */, uint32_t n /* <= 16 */, uint32_t* const bufs[6], uint32_t* buf);
 void launch_restir_pass3(hipStream_t, uint32_t max_blocks, const DevScene&, const DevFrame&, const CameraGPU* cam, uint32_t* const bufs[6], F4* accum, unsigned long long* counters);
 // ---- the ReSTIR frame as wavefront stages (rtx_restir_wave.hpp); every launch has q.G workgroups unless noted; cnt_* / shcnt: one entry per workgroup ----
 void launch_trace_occ(hipStream_t, const DevScene&, const RsQ&, const uint32_t* shcnt);                  // any-hit rays of the ray queue -> q.occ bytes

@@ -545,6 +545,8 @@ __device__ __forceinline__ bool p2_gather(const DevScene& sc, const DevFrame& f,
         else { const float ux = (cp.x / w3) * 0.5f + 0.5f; float uy = (cp.y / w3) * 0.5f + 0.5f; uy = 1.0f - uy; px = (int)rintf(ux * (float)f.width); py = (int)rintf(uy * (float)f.height); }
     }
     const bool inside = px >= 0 && py >= 0 && px < (int)f.width && py < (int)f.height;
+    // on shards: a read of the history where this context does not hold it (outside its rectangle + the exchanged halo) is counted, once per pixel (rtx_stats.restir_stale_history_reads)
+    if (with_cur && f.hist_stale && inside && ((uint32_t)px < f.hist_x0 || (uint32_t)px >= f.hist_x1 || (uint32_t)py < f.hist_y0 || (uint32_t)py >= f.hist_y1)) atomicAdd(f.hist_stale, 1ull);
     const size_t ts = inside ? map_pixel_id(f.width, (uint32_t)px, (uint32_t)py) : 0;
     I.rl = inside ? load_res_dev(B.last_di + ts * 10) : zero_res(); I.gl = inside ? load_res_dev(B.last_gi + ts * 10) : zero_res();
     const SData sl = inside ? load_sd_dev(B.last_sd + ts * 15) : zero_sd();
@@ -811,6 +813,29 @@ __global__ __launch_bounds__(kBlock) void k_restir_unpack_state(DevFrame f, uint
         const uint32_t* in = slabs + (size_t)i * kStateDwords;
         for (int k = 0; k < 10; k++) { B.last_di[slot * 10 + k] = in[k]; B.last_gi[slot * 10 + k] = in[10 + k]; }
         for (int k = 0; k < 15; k++) B.last_sd[slot * 15 + k] = in[20 + k];
+    }
+}
+
+// HALO EXCHANGE (rtx.h: rtx_restir_pack_halo): the history records of up to kHaloPeers pixel rectangles, row-major, 35 dwords each, packed back to back into one buffer
+// (and scattered from one).  first[k] = index of rectangle k's first record; rectangles are disjoint parts of the own rectangle (pack) or of the peers' (unpack).
+struct HaloRects { uint32_t n; uint32_t x0[kHaloPeers], y0[kHaloPeers], w[kHaloPeers]; uint32_t first[kHaloPeers + 1]; };
+template <bool PACK>
+__global__ __launch_bounds__(kBlock) void k_restir_halo(uint32_t width, HaloRects R, RestirBufs B, uint32_t* __restrict__ buf) {
+    const uint32_t stride = gridDim.x * kBlock, total = R.first[R.n];
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
+        uint32_t k = 0;
+#pragma unroll
+        for (uint32_t j = 1; j < kHaloPeers; j++) if (j < R.n && i >= R.first[j]) k = j;
+        const uint32_t r = i - R.first[k], x = R.x0[k] + r % R.w[k], y = R.y0[k] + r / R.w[k];
+        const size_t slot = map_pixel_id(width, x, y);
+        uint32_t* o = buf + (size_t)i * kStateDwords;
+        if (PACK) {
+            for (int q = 0; q < 10; q++) { o[q] = B.last_di[slot * 10 + q]; o[10 + q] = B.last_gi[slot * 10 + q]; }
+            for (int q = 0; q < 15; q++) o[20 + q] = B.last_sd[slot * 15 + q];
+        } else {
+            for (int q = 0; q < 10; q++) { B.last_di[slot * 10 + q] = o[q]; B.last_gi[slot * 10 + q] = o[10 + q]; }
+            for (int q = 0; q < 15; q++) B.last_sd[slot * 15 + q] = o[20 + q];
+        }
     }
 }
 

@@ -478,6 +478,8 @@ bool bvh_build_option(BvhBuildOptions& o, const char* key, double v) {
     else if (k == "sweep") o.sweep_below = (uint32_t)v;
     else if (k == "tri_cost") o.tri_cost = v;
     else if (k == "threads") o.threads = (int)v;
+    else if (k == "ploc") o.ploc_radius = (int)v;
+    else if (k == "ploc_top") o.ploc_top = (uint32_t)v;
     else if (k == "leaf_stop") o.leaf_stop = (uint32_t)v;
     else if (k == "split") o.split_alpha = v;
     else if (k == "slot_assign") o.slot_assign = (int)v;
@@ -631,7 +633,81 @@ void reinsert_pass(std::vector<TmpNode>& tn, std::vector<int32_t>& parent, doubl
 }
 }  // namespace
 
-void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGPU>& nodes, std::vector<uint32_t>& order, uint32_t& max_depth, const BvhBuildOptions& opt) {
+// ---- PLOC: parallel locally-ordered clustering (Meister & Bittner, "Parallel Locally-Ordered Clustering for Bounding Volume Hierarchy Construction", TVCG 2018) — the
+//      BOTTOM-UP builder of the GPU build (csrc/rtx_build.hip: RTX_OPT_GPU_BUILD), restated here so that its trees can be judged by work per ray without a GPU
+//      (tools/bvh_lab: ploc=<radius>) and so that the device code has a host twin to be compared with node for node.  Triangles are sorted along the Morton curve of
+//      their box centres (63 bits, ties by triangle id); every cluster looks `radius` places to either side for the neighbour whose union with it has the smallest
+//      surface area; mutual nearest neighbours merge; repeat until one cluster is left.  Everything is a pure function of the input order, so host and device agree. ----
+namespace {
+inline uint64_t spread21(uint32_t v) {            // 21 bits -> every third bit of 63
+    uint64_t x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull; x = (x | x << 16) & 0x1f0000ff0000ffull; x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull; x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+struct PlocNode { Box box; int32_t left, right; uint32_t tri; };
+// clusters until at most `stop_at` are left; pool: [0, n) leaves in Morton order, internal nodes appended in creation order (iteration by iteration, left partners in cluster order)
+void ploc_clusters(const std::vector<Ref>& refs, const Box& scene, int radius, uint32_t stop_at, std::vector<PlocNode>& pn, std::vector<int32_t>& cl) {
+    const uint32_t n = (uint32_t)refs.size();
+    // Morton keys of the box centres on a 2^21 grid over the scene's box (float arithmetic, the device's formula: rtx_build.hip k_gb_morton)
+    std::vector<std::pair<uint64_t, uint32_t>> keyed(n);
+    float lo[3], inv[3];
+    for (int a = 0; a < 3; a++) { lo[a] = scene.mn[a]; const float ext = scene.mx[a] - scene.mn[a]; inv[a] = ext > 0.0f ? 2097151.0f / ext : 0.0f; }
+    for (uint32_t i = 0; i < n; i++) {
+        uint64_t code = 0;
+        for (int a = 0; a < 3; a++) {
+            const float c = 0.5f * (refs[i].box.mn[a] + refs[i].box.mx[a]);
+            float q = (c - lo[a]) * inv[a]; q = q < 0.0f ? 0.0f : (q > 2097151.0f ? 2097151.0f : q);
+            code |= spread21((uint32_t)q) << a;
+        }
+        keyed[i] = {code, i};
+    }
+    std::sort(keyed.begin(), keyed.end());
+    pn.clear(); pn.reserve((size_t)2 * n);
+    for (uint32_t i = 0; i < n; i++) { const Ref& r = refs[keyed[i].second]; pn.push_back(PlocNode{r.box, -1, -1, r.tri}); }
+    cl.resize(n); for (uint32_t i = 0; i < n; i++) cl[i] = (int32_t)i;
+    std::vector<int32_t> nn, nxt;
+    auto uarea = [&](int32_t a, int32_t b) { Box u = pn[a].box; grow(u, pn[b].box); return half_area(u); };
+    while (cl.size() > std::max<size_t>(1, stop_at)) {
+        const int m = (int)cl.size();
+        nn.assign(m, -1);
+        for (int i = 0; i < m; i++) {                         // nearest neighbour within the window: smallest union area
+            float best = INFINITY; int bj = -1;                // scanned outwards (i - 1, i + 1, i - 2, ...): of equally good partners the nearest place along the curve wins — on regular
+            for (int d = 1; d <= radius; d++) {                 // tessellations most candidates tie, and "lowest place wins" pairs almost nobody (few mutual pairs, stringy clusters)
+                if (i - d >= 0) { const float a = uarea(cl[i], cl[i - d]); if (a < best) { best = a; bj = i - d; } }
+                if (i + d < m) { const float a = uarea(cl[i], cl[i + d]); if (a < best) { best = a; bj = i + d; } }
+            }
+            nn[i] = bj;
+        }
+        nxt.clear();
+        for (int i = 0; i < m; i++) {
+            const int j = nn[i];
+            if (j >= 0 && nn[j] == i) {                       // mutual: the lower position becomes the new node, the higher one disappears
+                if (i < j) { PlocNode N; N.box = pn[cl[i]].box; grow(N.box, pn[cl[j]].box); N.left = cl[i]; N.right = cl[j]; N.tri = 0; pn.push_back(N); nxt.push_back((int32_t)pn.size() - 1); }
+            } else nxt.push_back(cl[i]);
+        }
+        cl.swap(nxt);
+    }
+}
+// hang the PLOC subtree `src` of the pool below node `dst` of the build's tree (leaves of ONE triangle each, depth-first left to right)
+void ploc_expand(const std::vector<PlocNode>& pn, int32_t src0, int32_t dst0, uint32_t depth0, std::vector<TmpNode>& tn, std::vector<uint32_t>& order, uint32_t& max_depth) {
+    struct It { int32_t src, dst; uint32_t depth; };
+    std::vector<It> st; st.push_back({src0, dst0, depth0});
+    while (!st.empty()) {
+        const It it = st.back(); st.pop_back();
+        max_depth = std::max(max_depth, it.depth);
+        const PlocNode& N = pn[it.src];
+        tn[it.dst].box = N.box;
+        if (N.left < 0) { tn[it.dst].first = (uint32_t)order.size(); tn[it.dst].count = 1; tn[it.dst].left = tn[it.dst].right = -1; order.push_back(N.tri); continue; }
+        const int32_t l = (int32_t)tn.size(); tn.emplace_back(); const int32_t r = (int32_t)tn.size(); tn.emplace_back();
+        tn[it.dst].left = l; tn[it.dst].right = r; tn[it.dst].count = 0;
+        st.push_back({N.right, r, it.depth + 1}); st.push_back({N.left, l, it.depth + 1});
+    }
+}
+}  // namespace
+
+void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGPU>& nodes, std::vector<uint32_t>& order, uint32_t& max_depth, const BvhBuildOptions& opt_in) {
+    BvhBuildOptions opt = opt_in;
     const uint32_t nt = (uint32_t)(wtri.size() / 9);
     const bool TT = getenv("RTX_BUILD_TIMES") != nullptr; auto T0 = std::chrono::steady_clock::now(); auto lap = [&](const char* w) { if (TT) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[build]   bvh2: %-20s %.3f s\n", w, std::chrono::duration<double>(t - T0).count()); T0 = t; } };
     std::vector<Ref> refs(nt);
@@ -648,6 +724,19 @@ void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGP
     order.clear(); order.reserve(nt);
     std::vector<TmpNode> tn; tn.reserve((size_t)2 * nt + 2);
     max_depth = 0;
+    // PLOC (the GPU build's bottom-up half, restated on the host): clusters of triangles become the REFERENCES of the top-down builder below — which then only builds the
+    // top of the tree, over <= ploc_top clusters, with single clusters as leaves —, the re-insertion passes run on that top, and the clusters' subtrees are hung in afterwards.
+    // The top of a tree is where every ray passes (5.7 of 12.4 node steps in the first three wide levels on the atrium): it gets the expensive builder, the bottom the parallel one.
+    const bool ploc = opt.ploc_radius > 0 && nt > kSmallSceneMaxTris;
+    std::vector<PlocNode> ploc_pool; std::vector<int32_t> ploc_cl;
+    if (ploc) {
+        ploc_clusters(refs, scene, opt.ploc_radius, std::max(1u, opt.ploc_top), ploc_pool, ploc_cl);
+        refs.resize(ploc_cl.size());
+        for (size_t i = 0; i < ploc_cl.size(); i++) { refs[i].box = ploc_pool[ploc_cl[i]].box; refs[i].tri = (uint32_t)i; }
+        opt.leaf_stop = 1; opt.split_alpha = 0.0;
+        lap("ploc clusters");
+    }
+    const uint32_t ntop = (uint32_t)refs.size();
     // spatial splits only for scenes that take the BVH path (the tiny-scene records are built from the leaf order as a permutation of the triangles)
     const bool spatial = opt.split_alpha > 0.0 && nt > kSmallSceneMaxTris;
     const float spatial_min = (float)(opt.split_alpha * (double)half_area(scene));
@@ -663,7 +752,7 @@ void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGP
     // is THE SAME tree, node for node, as the serial build's, whatever the number of threads.
     struct Task { int32_t node; uint32_t depth; std::vector<Ref> refs; std::vector<TmpNode> tn; std::vector<uint32_t> order; uint32_t max_depth = 0; };
     std::vector<Task> tasks;
-    const uint32_t cutoff = (!spatial && nt >= 65536u && opt.threads != 1) ? std::max<uint32_t>(4096u, nt / 256u) : 0u;
+    const uint32_t cutoff = (!spatial && !ploc && nt >= 65536u && opt.threads != 1) ? std::max<uint32_t>(4096u, nt / 256u) : 0u;
     auto run = [&](std::vector<Ref>& refs, std::vector<TmpNode>& tn, std::vector<uint32_t>& order, std::vector<Job>& st, uint32_t& max_depth, size_t& refs_total, bool may_defer) {
     std::vector<uint32_t> sweep_ids; std::vector<float> sweep_ra; std::vector<Ref> tmp;
     while (!st.empty()) {
@@ -833,7 +922,7 @@ void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGP
     }
     };
     {
-        std::vector<Job> st; tn.emplace_back(); st.push_back({0, nt, 0u});
+        std::vector<Job> st; tn.emplace_back(); st.push_back({0, ntop, 0u});
         run(refs, tn, order, st, max_depth, refs_total, cutoff != 0u);
     }
     lap("top-down, serial part");
@@ -892,6 +981,27 @@ void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGP
         while (!dst.empty()) { const auto it = dst.back(); dst.pop_back(); max_depth = std::max(max_depth, it.second); if (!tn[it.first].count) { dst.push_back({tn[it.first].left, it.second + 1}); dst.push_back({tn[it.first].right, it.second + 1}); } }
     }
     lap("re-insertion");
+    if (ploc) {                                     // every leaf of the top tree holds cluster indices: hang the clusters' subtrees in (a leaf of several clusters becomes a chain)
+        std::vector<uint32_t> tri_order; tri_order.reserve(nt);
+        std::vector<std::pair<int32_t, uint32_t>> dfs; dfs.push_back({0, 0u});
+        std::vector<std::pair<int32_t, uint32_t>> leaves;
+        while (!dfs.empty()) { const auto it = dfs.back(); dfs.pop_back(); if (tn[it.first].count) leaves.push_back(it); else { dfs.push_back({tn[it.first].right, it.second + 1}); dfs.push_back({tn[it.first].left, it.second + 1}); } }
+        for (const auto& lf : leaves) {
+            int32_t at = lf.first; uint32_t depth = lf.second;
+            const uint32_t f = tn[at].first, k = tn[at].count;
+            for (uint32_t q = 0; q < k; q++) {
+                const int32_t src = ploc_cl[order[f + q]];
+                if (q + 1 == k) { ploc_expand(ploc_pool, src, at, depth, tn, tri_order, max_depth); break; }
+                const int32_t l = (int32_t)tn.size(); tn.emplace_back(); const int32_t r = (int32_t)tn.size(); tn.emplace_back();
+                Box rest = empty_box(); for (uint32_t z = q + 1; z < k; z++) grow(rest, ploc_pool[ploc_cl[order[f + z]]].box);
+                tn[at].left = l; tn[at].right = r; tn[at].count = 0; tn[r].box = rest;
+                ploc_expand(ploc_pool, src, l, depth + 1, tn, tri_order, max_depth);
+                at = r; depth++;
+            }
+        }
+        order.swap(tri_order);
+        lap("ploc expand");
+    }
     // ---- leaf order: depth-first, left to right, so that every subtree owns ONE contiguous range of references (collapse_bvh8 merges small subtrees into a
     //      leaf slot by range; the build emits the right side first and the re-insertion moves subtrees) ----
     {

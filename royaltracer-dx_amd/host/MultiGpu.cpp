@@ -2,6 +2,7 @@
 #include "MultiGpu.h"
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -18,6 +19,7 @@ struct MultiGpuFrame::Impl {
     std::vector<hipStream_t> stream;
     std::vector<void*> slab, gathered;          // per rank: its own slab, the slabs of all ranks
     std::vector<void*> state_slab, state_gathered;      // ReSTIR frames: the history records (u3 / u5 / u7) of the rank's own tiles, 140 B per pixel
+    std::vector<void*> halo_send, halo_recv; std::vector<size_t> halo_send_cap, halo_recv_cap;       // ... or, with SetHaloExchange, only the border strips (rtx_restir_pack_halo)
     std::vector<ncclComm_t> comm;
     size_t slab_bytes = 0, state_bytes = 0;
     // persistent per-rank worker threads (round 4: a frame used to create and join N std::threads): a worker sleeps on `cv` until `gen` moves, runs `job(rank)`, counts itself done
@@ -36,6 +38,7 @@ MultiGpuFrame::MultiGpuFrame(const std::vector<int>& devices, Gather g, bool alw
         if (only_rank >= n || (only_rank >= 0 && g != Gather::COPY)) throw std::runtime_error("MultiGpuFrame: only_rank needs a rank of the list and Gather::COPY");
         m->ctx.assign(n, nullptr); m->stream.assign(n, nullptr); m->slab.assign(n, nullptr); m->gathered.assign(n, nullptr);
         m->state_slab.assign(n, nullptr); m->state_gathered.assign(n, nullptr);
+        m->halo_send.assign(n, nullptr); m->halo_recv.assign(n, nullptr); m->halo_send_cap.assign(n, 0); m->halo_recv_cap.assign(n, 0);
         for (int r = 0; r < n; r++) {
             if (only_rank >= 0 && r != only_rank) continue;
             if (rtx_create(devices[r], &m->ctx[r]) != RTX_OK) throw std::runtime_error(std::string("rtx_create: ") + rtx_last_error(nullptr));
@@ -85,7 +88,7 @@ void MultiGpuFrame::Teardown() {
         if (m->stream[r]) (void)hipStreamSynchronize(m->stream[r]);
         if (r < m->comm.size() && m->comm[r]) (void)ncclCommDestroy(m->comm[r]);
         if (m->ctx[r]) rtx_destroy(m->ctx[r]);
-        for (std::vector<void*>* v : {&m->slab, &m->gathered, &m->state_slab, &m->state_gathered}) if (r < v->size() && (*v)[r]) (void)hipFree((*v)[r]);
+        for (std::vector<void*>* v : {&m->slab, &m->gathered, &m->state_slab, &m->state_gathered, &m->halo_send, &m->halo_recv}) if (r < v->size() && (*v)[r]) (void)hipFree((*v)[r]);
         if (m->stream[r]) (void)hipStreamDestroy(m->stream[r]);
     }
     delete m; m = nullptr;
@@ -180,29 +183,74 @@ void MultiGpuFrame::RenderRestir(const rtx_params& p0) {
     size_t bytes = 0, sbytes = 0;
     if (rtx_shard_slab_bytes(&probe, &bytes) != RTX_OK || rtx_restir_state_slab_bytes(&probe, &sbytes) != RTX_OK) throw std::runtime_error(std::string("slab bytes: ") + rtx_last_error(nullptr));
     const bool gather = n > 1 || m_always;
-    if (gather) { EnsureSlabs(m->slab, m->gathered, m->slab_bytes, bytes); EnsureSlabs(m->state_slab, m->state_gathered, m->state_bytes, sbytes); }
+    const bool halo = gather && n > 1 && m_halo > 0;                    // border strips between neighbours instead of the all-gather of the history
+    if (halo && !(p0.flags & RTX_FLAG_BLOCK_TILES)) throw std::runtime_error("MultiGpuFrame::RenderRestir: the halo exchange needs RTX_FLAG_BLOCK_TILES");
+    std::vector<std::vector<rtx_halo_peer>> peers(n);
+    std::vector<uint64_t> send_tot(n, 0), recv_tot(n, 0);
+    if (halo) for (int r = 0; r < n; r++) {                             // the plan of EVERY rank (also of the ranks this process does not hold: only_rank)
+        rtx_params p = p0; p.shard_rank = (uint32_t)r; p.shard_count = (uint32_t)n;
+        uint32_t np = 0;
+        if (rtx_restir_halo_plan(&p, m_halo, nullptr, 0, &np, &send_tot[r], &recv_tot[r]) != RTX_OK) throw std::runtime_error(std::string("halo plan: ") + rtx_last_error(nullptr));
+        peers[r].resize(np);
+        if (np && rtx_restir_halo_plan(&p, m_halo, peers[r].data(), np, &np, nullptr, nullptr) != RTX_OK) throw std::runtime_error(std::string("halo plan: ") + rtx_last_error(nullptr));
+    }
+    if (gather) { EnsureSlabs(m->slab, m->gathered, m->slab_bytes, bytes); if (!halo) EnsureSlabs(m->state_slab, m->state_gathered, m->state_bytes, sbytes); }
+    if (halo) for (int r = 0; r < n; r++) {
+        if (!m->ctx[r]) continue;
+        hipck(hipSetDevice(m_devices[r]), "hipSetDevice");
+        auto grow = [&](void*& p, size_t& cap, size_t need) { if (need <= cap && p) return; if (p) { (void)hipFree(p); p = nullptr; cap = 0; } hipck(hipMalloc(&p, std::max<size_t>(need, 16)), "hipMalloc halo"); cap = need; };
+        grow(m->halo_send[r], m->halo_send_cap[r], (size_t)send_tot[r]); grow(m->halo_recv[r], m->halo_recv_cap[r], (size_t)recv_tot[r]);
+    }
+    m_xbytes = 0;
+    for (int r = 0; r < n; r++) m_xbytes = std::max<uint64_t>(m_xbytes, halo ? send_tot[r] : (gather ? sbytes : 0));
     m_w = p0.width; m_h = p0.height;
     const auto t0 = std::chrono::steady_clock::now();
-    RunOnRanks([&](int r) {                                             // phase 1: the three passes on my tiles, then both packs enqueued behind them
+    RunOnRanks([&](int r) {                                             // phase 1: the three passes on my tiles, then the packs enqueued behind them
         rtx_params p = p0; p.shard_rank = (uint32_t)r; p.shard_count = (uint32_t)n;
         if (rtx_render_restir(m->ctx[r], &p) != RTX_OK) throw std::runtime_error(std::string("MultiGpuFrame::RenderRestir: ") + rtx_last_error(m->ctx[r]));
         (void)rtx_get_stats(m->ctx[r], &m_stats[r]);
-        if (gather && (rtx_restir_pack_state(m->ctx[r], &p, m->state_slab[r]) != RTX_OK || rtx_pack_tiles(m->ctx[r], &p, m->slab[r]) != RTX_OK)) throw std::runtime_error(std::string("MultiGpuFrame::RenderRestir: ") + rtx_last_error(m->ctx[r]));
+        if (!gather) return;
+        const int rc = halo ? rtx_restir_pack_halo(m->ctx[r], &p, m_halo, m->halo_send[r]) : rtx_restir_pack_state(m->ctx[r], &p, m->state_slab[r]);
+        if (rc != RTX_OK || rtx_pack_tiles(m->ctx[r], &p, m->slab[r]) != RTX_OK) throw std::runtime_error(std::string("MultiGpuFrame::RenderRestir: ") + rtx_last_error(m->ctx[r]));
     });
     if (gather) {
-        if (m_gather == Gather::RCCL) {                                 // phase 2: the frame's ONE exchange: history + framebuffer tiles in one group
+        if (m_gather == Gather::RCCL) {                                 // phase 2: the frame's ONE exchange: history (all-gather, or a send + receive per neighbour) + framebuffer tiles in one group
             ncclck(ncclGroupStart(), "ncclGroupStart");
             for (int r = 0; r < n; r++) {
-                ncclck(ncclAllGather(m->state_slab[r], m->state_gathered[r], sbytes / sizeof(float), ncclFloat, m->comm[r], m->stream[r]), "ncclAllGather state");
+                if (halo) for (const rtx_halo_peer& e : peers[r]) {
+                    ncclck(ncclSend((const char*)m->halo_send[r] + e.send_offset, e.send_bytes, ncclChar, (int)e.rank, m->comm[r], m->stream[r]), "ncclSend halo");
+                    ncclck(ncclRecv((char*)m->halo_recv[r] + e.recv_offset, e.recv_bytes, ncclChar, (int)e.rank, m->comm[r], m->stream[r]), "ncclRecv halo");
+                }
+                else ncclck(ncclAllGather(m->state_slab[r], m->state_gathered[r], sbytes / sizeof(float), ncclFloat, m->comm[r], m->stream[r]), "ncclAllGather state");
                 ncclck(ncclAllGather(m->slab[r], m->gathered[r], bytes / sizeof(float), ncclFloat, m->comm[r], m->stream[r]), "ncclAllGather tiles");
             }
             ncclck(ncclGroupEnd(), "ncclGroupEnd");
-        } else { AllGather(m->state_slab, m->state_gathered, sbytes); AllGather(m->slab, m->gathered, bytes); }
-        for (int r = 0; r < n; r++) {                                   // phase 3: scatter both, stream-ordered behind the gathers
+        } else {
+            if (!halo) AllGather(m->state_slab, m->state_gathered, sbytes);
+            else if (m_only >= 0) {                                     // one rank of N measured alone: as many bytes as it would receive, copied from its own strips
+                hipck(hipSetDevice(m_devices[m_only]), "hipSetDevice");
+                const size_t nb = (size_t)std::min(send_tot[m_only], recv_tot[m_only]);
+                if (nb) hipck(hipMemcpyAsync(m->halo_recv[m_only], m->halo_send[m_only], nb, hipMemcpyDeviceToDevice, m->stream[m_only]), "copy strips");
+            } else {                                                    // testing stand-in (one GPU, several ranks): what the peer sends me == what I receive from it
+                for (int r = 0; r < n; r++) { hipck(hipSetDevice(m_devices[r]), "hipSetDevice"); hipck(hipStreamSynchronize(m->stream[r]), "sync pack"); }
+                for (int r = 0; r < n; r++) {
+                    hipck(hipSetDevice(m_devices[r]), "hipSetDevice");
+                    for (const rtx_halo_peer& e : peers[r]) {
+                        const rtx_halo_peer* back = nullptr;
+                        for (const rtx_halo_peer& q : peers[e.rank]) if (q.rank == (uint32_t)r) back = &q;
+                        if (!back || back->send_bytes != e.recv_bytes) throw std::runtime_error("MultiGpuFrame::RenderRestir: halo plans of two ranks do not mirror each other");
+                        hipck(hipMemcpyAsync((char*)m->halo_recv[r] + e.recv_offset, (const char*)m->halo_send[e.rank] + back->send_offset, e.recv_bytes, hipMemcpyDeviceToDevice, m->stream[r]), "copy strip");
+                    }
+                }
+            }
+            AllGather(m->slab, m->gathered, bytes);
+        }
+        for (int r = 0; r < n; r++) {                                   // phase 3: scatter both, stream-ordered behind the exchange
             if (!m->ctx[r]) continue;
             rtx_params p = p0; p.shard_rank = (uint32_t)r; p.shard_count = (uint32_t)n;
             hipck(hipSetDevice(m_devices[r]), "hipSetDevice");
-            if (rtx_restir_unpack_state(m->ctx[r], &p, m->state_gathered[r]) != RTX_OK || rtx_unpack_tiles(m->ctx[r], &p, m->gathered[r]) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));
+            const int rc = halo ? rtx_restir_unpack_halo(m->ctx[r], &p, m_halo, m->halo_recv[r]) : rtx_restir_unpack_state(m->ctx[r], &p, m->state_gathered[r]);
+            if (rc != RTX_OK || rtx_unpack_tiles(m->ctx[r], &p, m->gathered[r]) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));
         }
         for (int r = 0; r < n; r++) { if (!m->ctx[r]) continue; hipck(hipSetDevice(m_devices[r]), "hipSetDevice"); hipck(hipStreamSynchronize(m->stream[r]), "sync frame"); }
     }

@@ -29,6 +29,13 @@ public:
     // the 20-px spatial radius, pass 3 on its own), then ONE group of collectives ends the frame: the all-gather of the history records of the own tiles (u3 / u5 / u7,
     // 140 B per pixel: the next frame's temporal pass reprojects to arbitrary pixels) and the all-gather of the framebuffer tiles.  p.spp must be 1.
     void RenderRestir(const rtx_params& p);
+    // halo_px > 0 (needs RTX_FLAG_BLOCK_TILES in the params): the history is exchanged as BORDER STRIPS between neighbouring rectangles — rtx_restir_pack_halo, one ncclSend +
+    // ncclRecv per peer (<= 8, each pair on its own xGMI link) in the frame's one group of collectives, rtx_restir_unpack_halo — instead of all-gathered: ~5-7 MB sent per rank
+    // at 1080p on 8 ranks where the all-gather delivers 292 MB to every rank.  Valid while a frame's reprojection displacement stays below halo_px - 20 (32 = one tile: 12 px
+    // of motion per frame); StaleHistoryReads() of the last frame says whether it did.  0 (default): all-gather.
+    void SetHaloExchange(uint32_t halo_px) { m_halo = halo_px; }
+    uint64_t StaleHistoryReads() const { uint64_t s = 0; for (const rtx_stats& st : m_stats) s += st.restir_stale_history_reads; return s; }   // of the last RenderRestir, all ranks: must be 0
+    uint64_t LastExchangeBytes() const { return m_xbytes; }    // history bytes the busiest rank SENT in the last RenderRestir (all-gather: its slab; halo: its strips)
     // a moving instance (the reference re-sets instance 1 and refits its TLAS every frame: Renderer.cpp:444-452, 594): rtx_set_instance_transform + a transform-only
     // rtx_commit_scene on EVERY rank — the scene is replicated, so every rank refits its own copy of the tree on its GPU (k_refit_tris / k_refit_nodes)
     void SetInstanceTransform(uint32_t instance, const float o2w[16]);
@@ -55,5 +62,6 @@ private:
     bool m_always = false;
     double m_lastMs = 0.0, m_refitMs = 0.0;
     int m_only = -1;
-    uint32_t m_w = 0, m_h = 0;
+    uint32_t m_w = 0, m_h = 0, m_halo = 0;
+    uint64_t m_xbytes = 0;
 };

@@ -4,6 +4,8 @@
 //                   [--mode pt|restir]   restir = the reference's shipping frame (3 DispatchRays, Renderer.cpp:646-673: pass 1 + temporal + spatial reuse), one per --frames,
 //                   nee 4 / bounces 3 as in Common_v6.hlsl:8-12 unless --nee / --bounces are given; with --gpus N the shards own one tile rectangle each (RTX_FLAG_BLOCK_TILES,
 //                   32-px tiles) and exchange history + framebuffer tiles once per frame; [--literal] = the thread-per-pixel kernels instead of the wavefront stages;
+//                   [--halo px] with --gpus N --mode restir: the history travels as border strips of `px` pixels between neighbouring rectangles (one send + receive per
+//                   neighbour, rtx_restir_pack_halo) instead of the all-gather of 140 B per pixel; the frame line then reports the bytes the busiest rank sent and the stale reads (must be 0);
 //                   [--force-gather] with --gpus 1: pack -> RCCL all-gather of a one-rank communicator -> unpack all the same (exercises the collective path on one GPU);
 //                   [--orbit deg] moves the camera about the look-at point between frames (exercises the reprojection)
 //                   [--spin deg] turns instance 1 (the reference's moving instance, Renderer.cpp:444-449) by `deg` about the vertical axis before every frame after the first: a
@@ -26,14 +28,14 @@
 int main(int argc, char** argv) {
     std::string scene = "cornell", out, objs, mtl = "./";
     UINT w = 1920, h = 1080, spp = 1, frames = 1, bounces = 8, nee = 1; int device = 0; bool lambert = false;
-    int gpus = 1; std::string devlist, gather = "rccl", mode = "pt"; bool literal = false, nee_set = false, bounces_set = false, force_gather = false; float orbit = 0.0f, spin = 0.0f; int only_rank = -1;
+    int gpus = 1; std::string devlist, gather = "rccl", mode = "pt"; bool literal = false, nee_set = false, bounces_set = false, force_gather = false; float orbit = 0.0f, spin = 0.0f; int only_rank = -1; UINT halo = 0;
     for (int i = 1; i < argc; i++) {
         auto arg = [&](const char* k) { return !strcmp(argv[i], k) && i + 1 < argc; };
         if (arg("--scene")) scene = argv[++i]; else if (arg("--obj")) { objs = argv[++i]; scene = "obj"; } else if (arg("--mtl")) mtl = argv[++i];
         else if (arg("--w")) w = atoi(argv[++i]); else if (arg("--h")) h = atoi(argv[++i]); else if (arg("--spp")) spp = atoi(argv[++i]);
         else if (arg("--frames")) frames = atoi(argv[++i]); else if (arg("--bounces")) { bounces = atoi(argv[++i]); bounces_set = true; } else if (arg("--nee")) { nee = atoi(argv[++i]); nee_set = true; }
         else if (arg("--mode")) mode = argv[++i]; else if (arg("--orbit")) orbit = (float)atof(argv[++i]); else if (arg("--spin")) spin = (float)atof(argv[++i]); else if (arg("--only-rank")) only_rank = atoi(argv[++i]); else if (!strcmp(argv[i], "--literal")) literal = true; else if (!strcmp(argv[i], "--force-gather")) force_gather = true;
-        else if (arg("--gpus")) gpus = atoi(argv[++i]); else if (arg("--devices")) devlist = argv[++i]; else if (arg("--gather")) gather = argv[++i];
+        else if (arg("--halo")) halo = (UINT)atoi(argv[++i]); else if (arg("--gpus")) gpus = atoi(argv[++i]); else if (arg("--devices")) devlist = argv[++i]; else if (arg("--gather")) gather = argv[++i];
         else if (arg("--out")) out = argv[++i]; else if (arg("--device")) device = atoi(argv[++i]); else if (!strcmp(argv[i], "--lambert")) lambert = true;
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
@@ -67,7 +69,7 @@ int main(int argc, char** argv) {
             rtx_params p{}; p.width = w; p.height = h; p.spp = spp; p.max_bounces = bounces; p.nee_samples = nee; p.rr_start = 3;
             p.tile_size = gpus > 1 ? 32 : 64;      // round-robin deal: 32-px tiles even out the background across 8 ranks (max / mean 1.04 instead of 1.15, tools/shard_time.py)
             p.flags = lambert ? RTX_FLAG_LAMBERT_ONLY : (scene == "bistro" ? RTX_FLAG_TRANSMISSION : 0);
-            if (restir) { p.spp = 1; p.flags = (lambert ? RTX_FLAG_LAMBERT_ONLY : 0u) | RTX_FLAG_BLOCK_TILES; p.tile_size = 32; mg.SetOption(RTX_OPT_RESTIR_WAVEFRONT, literal ? 0 : 1); mg.ResetRestir(); }
+            if (restir) { p.spp = 1; p.flags = (lambert ? RTX_FLAG_LAMBERT_ONLY : 0u) | RTX_FLAG_BLOCK_TILES; p.tile_size = 32; mg.SetOption(RTX_OPT_RESTIR_WAVEFRONT, literal ? 0 : 1); mg.ResetRestir(); mg.SetHaloExchange(halo); }
             float prev_view[16] = {0};
             if (spin != 0.0f && sc.instances.size() < 2) { fprintf(stderr, "--spin needs a scene with an instance 1\n"); return 2; }
             for (UINT f = 0; f < frames; f++) {
@@ -86,6 +88,7 @@ int main(int argc, char** argv) {
                 } else mg.Render(p);
                 double rays = 0; for (int r = 0; r < gpus; r++) { if (only_rank >= 0 && r != only_rank) continue; rtx_stats s = mg.Stats(r); rays += (double)(s.rays_primary + s.rays_extension + s.rays_shadow); }
                 printf("frame %u on %d GPUs: %.3f ms (gather included), %.1f Mrays/s\n", f, gpus, mg.LastFrameMs(), rays / (mg.LastFrameMs() * 1e3));
+                if (restir && gpus > 1) printf("  history exchange: %s, %.2f MB sent by the busiest rank, stale history reads %llu\n", halo ? "border strips (halo)" : "all-gather", (double)mg.LastExchangeBytes() / 1e6, (unsigned long long)mg.StaleHistoryReads());
             }
             const int rr = only_rank >= 0 ? only_rank : 0;
             if (!out.empty() && !write_image(mg.ReadAccumulation(rr), mg.ReadOutput(rr))) { fprintf(stderr, "error: could not write %s\n", out.c_str()); return 1; }

@@ -100,6 +100,70 @@ def owner_map(width, height, tile_size, world, blocks=False):
     return ((yy // ts) * tiles_x + (xx // ts)) % world
 
 
+# ---- ReSTIR on shards: halo exchange of the history (include/rtx.h: rtx_restir_halo_plan / pack_halo / unpack_halo) ----
+def block_rect(L, width, height, rank):
+    """pixel rectangle (x0, y0, x1, y1) of `rank` in the block deal — the same rule as shard_tiles, clipped to the image"""
+    gx, gy, TX, TY, ts = L["gx"], L["gy"], L["tiles_x"], L["tiles_y"], L["ts"]
+    bx, by = rank % gx, rank // gx
+    return (min(width, (bx * TX // gx) * ts), min(height, (by * TY // gy) * ts), min(width, ((bx + 1) * TX // gx) * ts), min(height, ((by + 1) * TY // gy) * ts))
+
+
+HALO_RECORD_BYTES = 140          # Reservoir_DI 40 | Reservoir_GI 40 | SampleData 60
+
+
+def halo_plan(width, height, tile_size, rank, world, halo):
+    """numpy-side mirror of rtx_restir_halo_plan (csrc/rtx_api.hip: halo_plan): [dict(rank, send=(x0, y0, x1, y1), recv=(...), send_offset, send_bytes, recv_offset,
+    recv_bytes)] in ascending rank order, total send bytes, total receive bytes.  send = my rectangle ∩ the peer's dilated by `halo`; recv = the peer's ∩ mine dilated."""
+    L = layout(width, height, tile_size, world, True)
+    if world < 2 or not L["gx"]:
+        raise ValueError("halo exchange needs world > 1 (block deal)")
+    own = block_rect(L, width, height, rank)
+
+    def clip(a, b):            # a ∩ dilate(b, halo)
+        r = (max(a[0], max(b[0] - halo, 0)), max(a[1], max(b[1] - halo, 0)), min(a[2], min(width, b[2] + halo)), min(a[3], min(height, b[3] + halo)))
+        return r if r[0] < r[2] and r[1] < r[3] else None
+    peers, so, ro = [], 0, 0
+    if own[0] >= own[2] or own[1] >= own[3]:
+        return peers, 0, 0
+    for q in range(world):
+        if q == rank:
+            continue
+        rq = block_rect(L, width, height, q)
+        if rq[0] >= rq[2] or rq[1] >= rq[3]:
+            continue
+        sr, rr = clip(own, rq), clip(rq, own)
+        if sr is None or rr is None:
+            continue
+        sb, rb = (sr[2] - sr[0]) * (sr[3] - sr[1]) * HALO_RECORD_BYTES, (rr[2] - rr[0]) * (rr[3] - rr[1]) * HALO_RECORD_BYTES
+        peers.append(dict(rank=q, send=sr, recv=rr, send_offset=so, send_bytes=sb, recv_offset=ro, recv_bytes=rb))
+        so += sb; ro += rb
+    return peers, so, ro
+
+
+def halo_pack(history, peers):
+    """history: (H, W, 140) uint8 records by pixel -> the rank's send buffer (what rtx_restir_pack_halo writes, records row-major per region)"""
+    return np.concatenate([history[p["send"][1]:p["send"][3], p["send"][0]:p["send"][2]].reshape(-1) for p in peers]) if peers else np.zeros(0, np.uint8)
+
+
+def halo_unpack(history, peers, recv):
+    for p in peers:
+        x0, y0, x1, y1 = p["recv"]
+        history[y0:y1, x0:x1] = np.asarray(recv[p["recv_offset"]:p["recv_offset"] + p["recv_bytes"]]).reshape(y1 - y0, x1 - x0, HALO_RECORD_BYTES)
+    return history
+
+
+def exchange_halo(dist, peers, send, recv):
+    """the frame's point-to-point exchange: one isend + one irecv per peer in ONE batch (RCCL groups them: every pair uses its own xGMI link); send / recv are 1-D uint8
+    tensors on the device of the backend (cuda for nccl, cpu for gloo)"""
+    ops = []
+    for p in peers:
+        ops.append(dist.P2POp(dist.isend, send[p["send_offset"]:p["send_offset"] + p["send_bytes"]], p["rank"]))
+        ops.append(dist.P2POp(dist.irecv, recv[p["recv_offset"]:p["recv_offset"] + p["recv_bytes"]], p["rank"]))
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    return recv
+
+
 # ---- torch.distributed plumbing (backend "nccl" is RCCL on ROCm; "gloo" for the CPU tests) ----
 def init_process_group(backend, device=None):
     import torch.distributed as dist

@@ -705,6 +705,86 @@ def test_restir_on_shards_equals_the_unsharded_frames(rt, orc, golden_dir, nshar
     ref.close()
 
 
+@pytest.mark.parametrize("nshards,wave,halo", [(2, 1, 32), (4, 1, 32), (4, 0, 32), (3, 1, 24), (6, 1, 32)])
+def test_restir_halo_exchange_equals_the_unsharded_frames(rt, golden_dir, nshards, wave, halo):
+    """SURVEY 8(f1) as it names it: "halo exchange (20 px) if tiles are sharded".  In the block deal every rank sends each neighbour only the part of its rectangle within `halo`
+    px of the neighbour's (rtx_restir_halo_plan / pack_halo / unpack_halo; the point-to-point exchange is a device-side slice copy here, the ranks being contexts on one GPU) instead
+    of all-gathering 140 B per pixel of the whole image.  Three frames with a moving camera on garage.obj + monke.obj: every rank's tiles of the image equal the unsharded run's,
+    its history equals the unsharded history everywhere inside its rectangle + halo, and no temporal read left that region (rtx_stats.restir_stale_history_reads == 0).  Then a
+    camera CUT: the reprojection leaves the halo, the count says so, and the documented fallback — all-gather of the previous history, repeat the frame — is exact again."""
+    import torch
+    from royaltracer_dx_amd import sharding
+    sc = rt.Scene.from_obj([os.path.join(golden_dir, "garage.obj"), os.path.join(golden_dir, "monke.obj")], golden_dir + "/")
+    W, H, TS = 192, 128, 32
+    cams = [rt.lookat((-1.5 + 0.05 * k, 1.5, 3.5 - 0.04 * k), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0)) for k in range(3)]
+    cut = rt.lookat((1.2, 1.1, 3.0), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0))
+    proj = rt.perspective_fov_rh(np.radians(60.0), W / H, 0.1, 1000.0)
+    base = dict(width=W, height=H, spp=1, max_bounces=3, nee_samples=4, flags=rt.FLAG_BLOCK_TILES, tile_size=TS)
+    P = lambda k, r: rt.Params(frame_seed=70 + k, shard_rank=r, shard_count=nshards, **base)
+    ref = rt.Context(0); ref.upload(sc, W / H); ref.restir_reset(); ref.clear(W, H)
+    for k, v in enumerate(cams):
+        ref.set_camera(v, proj); ref.render_restir(rt.Params(frame_seed=70 + k, **base))
+    ref_img, ref_last = ref.read_accum(), ref.read_restir_last()
+    ranks = []
+    for r in range(nshards):
+        c = rt.Context(0); c.set_option(rt.OPT_RESTIR_WAVEFRONT, wave); c.upload(sc, W / H); c.restir_reset(); c.clear(W, H); ranks.append(c)
+    plans = [rt.restir_halo_plan(P(0, r), halo) for r in range(nshards)]
+    assert all(len(pl[0]) <= 8 for pl in plans)
+
+    def exchange(k):
+        send = []
+        for r, c in enumerate(ranks):
+            b = torch.zeros(max(plans[r][1], 4), dtype=torch.uint8, device="cuda:0"); c.restir_pack_halo(P(k, r), halo, b.data_ptr()); send.append(b)
+        torch.cuda.synchronize()
+        for r, c in enumerate(ranks):
+            recv = torch.zeros(max(plans[r][2], 4), dtype=torch.uint8, device="cuda:0")
+            for e in plans[r][0]:
+                back = [q for q in plans[e.rank][0] if q.rank == r][0]          # what the peer sends me == what I receive from it
+                assert back.send_bytes == e.recv_bytes
+                recv[e.recv_offset:e.recv_offset + e.recv_bytes] = send[e.rank][back.send_offset:back.send_offset + back.send_bytes]
+            torch.cuda.synchronize()
+            c.restir_unpack_halo(P(k, r), halo, recv.data_ptr())
+    for k, v in enumerate(cams):
+        for r, c in enumerate(ranks):
+            c.set_camera(v, proj); c.render_restir(P(k, r))
+            assert c.stats().restir_stale_history_reads == 0, (k, r)
+        exchange(k)
+    L = sharding.layout(W, H, TS, nshards, True)
+    own = sharding.owner_map(W, H, TS, nshards, True)
+    yy, xx = np.mgrid[0:H, 0:W]
+    slot = (((yy >> 2) * ((W + 3) >> 2) + (xx >> 2)) * 16 + (yy & 3) * 4 + (xx & 3))            # MapPixelID, Common_v6.hlsl:173-198
+    for r, c in enumerate(ranks):
+        img = c.read_accum()
+        assert np.array_equal(bits(img[own == r]), bits(ref_img[own == r])), r
+        x0, y0, x1, y1 = sharding.block_rect(L, W, H, r)
+        valid = slot[max(y0 - halo, 0):min(H, y1 + halo), max(x0 - halo, 0):min(W, x1 + halo)].reshape(-1)
+        for a, b in zip(c.read_restir_last(), ref_last):
+            assert np.array_equal(a[valid], b[valid]), r
+    # a camera cut: pixels reproject far outside the halo
+    ref.set_camera(cut, proj); ref.render_restir(rt.Params(frame_seed=99, **base)); ref_img2 = ref.read_accum()
+    slabs = []
+    for r, c in enumerate(ranks):          # keep the pre-cut history for the fallback: every rank's own tiles (the all-gather's input)
+        slab = torch.empty(c.restir_state_slab_bytes(P(3, r)) // 4, dtype=torch.float32, device="cuda:0"); c.restir_pack_state(P(3, r), slab.data_ptr()); slabs.append(slab)
+    torch.cuda.synchronize(); gathered = torch.cat(slabs); torch.cuda.synchronize()
+    before = [c.read_accum() for c in ranks]
+    stale = 0
+    for r, c in enumerate(ranks):
+        c.set_camera(cut, proj); c.render_restir(P(29, r)); stale += c.stats().restir_stale_history_reads
+    assert stale > 0, "a camera cut must be reported: the temporal pass read history this rank does not hold"
+    # fallback: restore the image, all-gather the history the frame should have seen, repeat the frame (the cut camera is already set: set it again so that the
+    # previous-view matrices are the cut frame's own predecessor as in the reference run — rtx_set_camera shifts them)
+    for r, c in enumerate(ranks):
+        acc = torch.from_numpy(before[r]).to("cuda:0"); c.bind_accum(acc.data_ptr(), acc.numel() * 4)
+        c.restir_unpack_state(P(3, r), gathered.data_ptr())
+        c.set_camera(cams[2], proj); c.set_camera(cut, proj)
+        c.render_restir(P(29, r))
+        assert c.stats().restir_stale_history_reads == 0
+        img = acc.cpu().numpy()
+        assert np.array_equal(bits(img[own == r]), bits(ref_img2[own == r])), r
+        c.bind_accum(0, 0); c.close()
+    ref.close()
+
+
 def test_restir_wavefront_equals_literal_on_a_bvh_scene_at_scale(rt, orc):
     """The wavefront stages at a size where their machinery is exercised — many workgroups with several 256-pixel chunks per sub-queue, persistent traversal
     kernels that refill their lanes, a ray queue of several rays per pixel — on a 20 k-triangle atrium (compressed wide BVH): three frames with a moving camera,
@@ -1790,14 +1870,19 @@ def test_native_multi_gpu_restir_frames_of_the_cli(tmp_path):
     for name, sargs in scenes.items():
         blobs = {}
         for tag, extra in (("facade", []), ("n1", ["--gpus", "1", "--devices", "0"]), ("n2", ["--gpus", "2", "--devices", "0,0"]), ("n3", ["--gpus", "3", "--devices", "0,0,0"]),
-                           ("n4", ["--gpus", "4", "--devices", "0,0,0,0"]), ("n2_literal", ["--gpus", "2", "--devices", "0,0", "--literal"])):
-            if name == "sponza" and tag in ("n3", "n4"):
+                           ("n4", ["--gpus", "4", "--devices", "0,0,0,0"]), ("n2_literal", ["--gpus", "2", "--devices", "0,0", "--literal"]),
+                           # round 5: the history as border strips between neighbouring rectangles (rtx_restir_pack_halo: send / receive per peer) instead of the all-gather
+                           ("n2_halo", ["--gpus", "2", "--devices", "0,0", "--halo", "40"]), ("n4_halo", ["--gpus", "4", "--devices", "0,0,0,0", "--halo", "40"]),
+                           ("n3_halo_literal", ["--gpus", "3", "--devices", "0,0,0", "--halo", "40", "--literal"])):
+            if name == "sponza" and tag in ("n3", "n4", "n3_halo_literal"):
                 continue
             out = tmp_path / f"{name}_{tag}.exr"
             cmd = [exe] + sargs + ["--mode", "restir", "--w", "256", "--h", "144", "--frames", "3", "--orbit", "2", "--gather", "copy", "--out", str(out)] + extra
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
             assert r.returncode == 0, (cmd, r.stderr[-2000:])
             assert r.stdout.count("frame ") == 3
+            if "halo" in tag:
+                assert r.stdout.count("border strips (halo)") == 3 and r.stdout.count("stale history reads 0") == 3, r.stdout[-1500:]
             blobs[tag] = out.read_bytes()
         for tag, b in blobs.items():
             assert b == blobs["facade"], (name, tag)

@@ -87,6 +87,83 @@ def test_two_rank_gloo_frame_assembly(tmp_path):
     assert "GLOO_OK 2" in outs[0], outs[0]
 
 
+def test_halo_plan_is_symmetric_covers_the_dilated_rectangle_and_matches_the_c_abi(rt):
+    """SURVEY 8(f1) halo exchange of the ReSTIR history (include/rtx.h: rtx_restir_halo_plan): for every pair of ranks the region r sends to q is the region q receives from r
+    (same rectangle, same byte count); what a rank receives plus its own rectangle covers its rectangle dilated by the halo exactly once; the numpy mirror in
+    sharding.halo_plan and the C-ABI agree peer by peer; a rank of the 8-rank 1080p deal has at most 8 peers and sends < 8 MB where the all-gather moves 292 MB of history to every rank."""
+    from royaltracer_dx_amd import sharding
+    for (w, h, ts, world, halo) in [(1920, 1080, 32, 8, 32), (1920, 1080, 32, 4, 20), (160, 96, 32, 4, 32), (200, 120, 16, 6, 24), (3840, 2160, 64, 8, 40), (96, 80, 32, 2, 32), (70, 33, 16, 5, 30)]:
+        plans = [sharding.halo_plan(w, h, ts, r, world, halo) for r in range(world)]
+        L = sharding.layout(w, h, ts, world, True)
+        for r in range(world):
+            peers, sb, rb = plans[r]
+            cp, csb, crb = rt.restir_halo_plan(rt.Params(width=w, height=h, tile_size=ts, shard_rank=r, shard_count=world, flags=rt.FLAG_BLOCK_TILES), halo)
+            assert (csb, crb) == (sb, rb) and len(cp) == len(peers)
+            for a, b in zip(cp, peers):
+                assert (a.rank, (a.send_x0, a.send_y0, a.send_x1, a.send_y1), (a.recv_x0, a.recv_y0, a.recv_x1, a.recv_y1), a.send_offset, a.send_bytes, a.recv_offset, a.recv_bytes) == \
+                       (b["rank"], b["send"], b["recv"], b["send_offset"], b["send_bytes"], b["recv_offset"], b["recv_bytes"])
+            own = sharding.block_rect(L, w, h, r)
+            cover = np.zeros((h, w), np.int32)
+            cover[own[1]:own[3], own[0]:own[2]] += 1
+            for p in peers:
+                back = [q for q in plans[p["rank"]][0] if q["rank"] == r]
+                assert len(back) == 1 and back[0]["send"] == p["recv"] and back[0]["recv"] == p["send"] and back[0]["send_bytes"] == p["recv_bytes"]
+                cover[p["recv"][1]:p["recv"][3], p["recv"][0]:p["recv"][2]] += 1
+            want = np.zeros((h, w), np.int32)
+            if own[0] < own[2] and own[1] < own[3]:
+                want[max(own[1] - halo, 0):min(h, own[3] + halo), max(own[0] - halo, 0):min(w, own[2] + halo)] = 1
+            assert np.array_equal(cover, want), (w, h, world, r)
+    peers, sb, rb = sharding.halo_plan(1920, 1080, 32, 1, 8, 32)
+    assert len(peers) <= 8 and sb < 8e6 and sharding.layout(1920, 1080, 32, 8, True)["npl"] * 140 * 8 > 2.9e8
+    with pytest.raises(rt.RtxError):
+        rt.restir_halo_plan(rt.Params(width=64, height=64, tile_size=32, shard_rank=0, shard_count=2), 32)        # not the block deal
+
+
+HALO_WORKER = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import __graft_entry__ as graft
+rt = graft.load_package()
+from royaltracer_dx_amd import sharding
+dist, rank, world = sharding.init_process_group("gloo")
+W, H, TS, HALO = 160, 96, 32, 32
+truth = np.random.default_rng(5).integers(0, 256, (H, W, 140), dtype=np.uint8)          # the whole image's history records (what an unsharded run would hold)
+L = sharding.layout(W, H, TS, world, True); own = sharding.block_rect(L, W, H, rank)
+mine = np.zeros_like(truth); mine[own[1]:own[3], own[0]:own[2]] = truth[own[1]:own[3], own[0]:own[2]]      # a rank holds its own rectangle after a frame
+peers, sb, rb = sharding.halo_plan(W, H, TS, rank, world, HALO)
+send = torch.from_numpy(sharding.halo_pack(mine, peers)); recv = torch.zeros(rb, dtype=torch.uint8)
+assert send.numel() == sb
+sharding.exchange_halo(dist, peers, send, recv)
+sharding.halo_unpack(mine, peers, recv.numpy())
+y0, y1, x0, x1 = max(own[1] - HALO, 0), min(H, own[3] + HALO), max(own[0] - HALO, 0), min(W, own[2] + HALO)
+assert np.array_equal(mine[y0:y1, x0:x1], truth[y0:y1, x0:x1]), "the history is not valid in the rectangle + halo"
+out = mine.copy(); out[y0:y1, x0:x1] = 0
+assert not out.any(), "records outside the rectangle + halo were written"
+print("HALO_OK", rank, len(peers), sb)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_halo_exchange_between_gloo_ranks(tmp_path, world):
+    """the point-to-point exchange itself (sharding.exchange_halo: one isend + irecv per peer in one batch) with `world` gloo ranks on the CPU: after pack -> exchange -> unpack
+    every rank holds the true records in its rectangle dilated by the halo and nothing elsewhere"""
+    script = tmp_path / "halo_worker.py"
+    script.write_text(HALO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29551 + world), OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            pr.kill(); out, _ = pr.communicate()
+        outs.append(out)
+    assert all(pr.returncode == 0 for pr in procs), "\n".join(outs)
+    assert all("HALO_OK" in o for o in outs), outs
+
+
 def test_bench_self_launch_plumbing_without_a_gpu():
     """`python bench.py --gpus N` with no launcher must start its own ranks BEFORE importing torch / touching the GPU, relay rank 0 and
     exit with the worst child code.  Without a GPU the children fail (rtx has no CPU fallback): the parent must reap them, not hang, and

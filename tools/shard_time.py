@@ -3,7 +3,9 @@
 of an N-GPU frame costs (max over ranks decides the frame), how uneven the tile deal is (max / mean) and how large the slab of the frame's one all-gather is.
 usage: python tools/shard_time.py [cornell|sponza|bistro|sponza4k] [pt|restir] [N ...] [blocks=0|1] [tile=64] [frames=4] [option_id=value ...]
    pt      BASELINE's path-traced frame of that scene (cornell: 1080p 64 spp 8 bounces; sponza / bistro: 1080p 16 spp; sponza4k: C4, 3840x2160 64 spp)
-   restir  the reference's ReSTIR frame (nee 4, bounces 3), 1080p; blocks=1 (RTX_FLAG_BLOCK_TILES, one tile rectangle per rank) is the deal meant for it
+   restir  the reference's ReSTIR frame (nee 4, bounces 3), 1080p; blocks=1 (RTX_FLAG_BLOCK_TILES, one tile rectangle per rank) is the deal meant for it;
+           halo=32 adds what the HALO exchange of the history moves (rtx_restir_halo_plan: border strips to <= 8 neighbours) beside the all-gather's slab, with a link-rate
+           estimate of both (7 xGMI links of ~153 GB/s per GPU; NO N > 1 RCCL run exists: estimates, not measurements)
    native=1  (pt, cornell | sponza | bistro) every rank THROUGH THE HOST PATH of the native N-GPU frame: `rtx_render --gpus N --only-rank r --gather copy` = MultiGpuFrame with
              its persistent worker thread, the enqueue-only render (RTX_OPT_ASYNC), pack, the rank's own slab copied into the gathered buffer, unpack, ONE host wait per frame"""
 import os
@@ -94,6 +96,19 @@ def main():
             slab += ctx.restir_state_slab_bytes(rt.Params(shard_rank=0, shard_count=n, **base)) / 1e6
         ideal, eff = (f"{t1 / n:.3f}", f"{t1 / (n * mx):.3f}") if ns[0] == 1 else ("-", "-")          # (needs the N = 1 frame of the same run)
         print(f"| {n} | {mx:.3f} | {mean:.3f} | {mx / mean:.3f} | {ideal} | {eff} | {slab:.2f} | " + " ".join(f"{t:.2f}" for t in per) + " |", flush=True)
+        if mode == "restir" and n > 1:
+            LINK = 153e9                                          # bytes / s per xGMI link, 7 links per GPU (MI355X_MICROARCH.md / SURVEY section 5)
+            hist = ctx.restir_state_slab_bytes(rt.Params(shard_rank=0, shard_count=n, **base))
+            ag_ms = hist * (n - 1) / min(n - 1, 7) / LINK * 1e3    # all-gather: every rank receives the other n - 1 slabs, over min(n - 1, 7) links in parallel
+            line = f"|   | history exchange, ESTIMATED from the link rate | all-gather: {hist / 1e6:.1f} MB per rank slab, {hist * (n - 1) / 1e6:.0f} MB received per rank, ~{ag_ms:.3f} ms (+{100 * ag_ms / mx:.0f} % of the slowest rank's frame)"
+            if named.get("halo") and blocks:
+                worst = (0, 0, 0)
+                for r in range(n):
+                    peers, sb, rb = rt.restir_halo_plan(rt.Params(shard_rank=r, shard_count=n, **base), named["halo"])
+                    worst = max(worst, (sb, len(peers), max([e.send_bytes for e in peers] or [0])))
+                h_ms = worst[2] / LINK * 1e3 + 0.01               # every pair on its own link: the largest strip decides; + ~10 us of launch / protocol latency
+                line += f" | halo {named['halo']} px: {worst[0] / 1e6:.2f} MB sent by the busiest rank to {worst[1]} peers, largest strip {worst[2] / 1e6:.2f} MB, ~{h_ms:.3f} ms (+{100 * h_ms / mx:.1f} %)"
+            print(line + " |", flush=True)
     ctx.close()
 
 
