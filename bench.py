@@ -51,11 +51,15 @@ WORKLOADS = {
     "sponza_1080p_16spp_8b": ("sponza", 1920, 1080, 16, 8, 1, 1),
     "sponza_4k_64spp_8b": ("sponza", 3840, 2160, 64, 8, 1, 1),
     "bistro_1080p_16spp_8b": ("bistro", 1920, 1080, 16, 8, 1, 4),     # flags 4 = RTX_FLAG_TRANSMISSION: GGX microfacet + dielectric panes (strategy 3) + NEE
+    # the HARD stand-ins (round 5, host/Scenes.h): the same shells, materials, lights, cameras and triangle budgets with the size distribution of the real assets — a few
+    # triangles metres long beside millimetre ornament, long thin trims, overlapping cloth, foliage (> 1000 : 1) — where a BVH builder's quality shows
+    "sponza_hard_1080p_16spp_8b": ("sponza_hard", 1920, 1080, 16, 8, 1, 1),
+    "bistro_hard_1080p_16spp_8b": ("bistro_hard", 1920, 1080, 16, 8, 1, 4),
 }
-EXTRA_WORKLOADS = ("sponza_1080p_16spp_8b", "bistro_1080p_16spp_8b")    # the general BVH path, timed beside the headline (GPU only)
+EXTRA_WORKLOADS = ("sponza_1080p_16spp_8b", "bistro_1080p_16spp_8b", "sponza_hard_1080p_16spp_8b", "bistro_hard_1080p_16spp_8b")    # the general BVH path, timed beside the headline (GPU only)
 
 
-ASSETS = {"sponza": "sponza.obj", "bistro": "bistro.obj"}       # SURVEY 8(d) / BASELINE.md: the real asset if it lies under assets/, else the procedural stand-in of its class
+ASSETS = {"sponza": "sponza.obj", "bistro": "bistro.obj", "sponza_hard": "sponza.obj", "bistro_hard": "bistro.obj"}       # SURVEY 8(d) / BASELINE.md: the real asset if it lies under assets/, else the procedural stand-in of its class
 
 
 def asset_path(kind):
@@ -80,6 +84,10 @@ def make_scene(rt, kind):
         return rt.Scene.sponza_class(), "generated: Sponza-class procedural atrium (no assets/sponza.obj)"
     if kind == "bistro":
         return rt.Scene.bistro_class(), "generated: Bistro-class procedural street (no assets/bistro.obj)"
+    if kind == "sponza_hard":
+        return rt.Scene.sponza_class(hard=True), "generated: Sponza-class procedural atrium, HARD variant: the real asset's triangle-size distribution (no assets/sponza.obj)"
+    if kind == "bistro_hard":
+        return rt.Scene.bistro_class(hard=True), "generated: Bistro-class procedural street, HARD variant: the real asset's triangle-size distribution (no assets/bistro.obj)"
     raise ValueError(kind)
 
 
@@ -338,6 +346,23 @@ def time_extra(rt, dev_index, workload, steps=5):
             ctx.set_instance_transform(0, m.reshape(16))
             t2 = time.perf_counter(); ctx.commit(); refit.append((time.perf_counter() - t2) * 1e3)
         refit_ms = round(min(refit[1:]), 3)
+        # the same scene committed with the tree built ON THE GPU (RTX_OPT_GPU_BUILD): commit wall time, phases, and the frame on that tree
+        gpu_build = None
+        try:
+            cg = rt.Context(dev_index); cg.set_option(rt.OPT_GPU_BUILD, 1)
+            t3 = time.perf_counter(); cg.upload(scene, W / H); commit_g = time.perf_counter() - t3
+            bi = cg.build_info()
+            cg.clear(W, H); cg.render(params)
+            gms = []
+            for i in range(3):
+                params.frame_seed = 2 + i
+                ts = time.perf_counter(); cg.render(params); gms.append((time.perf_counter() - ts) * 1e3)
+            gpu_build = {"commit_s": round(commit_g, 3), "build_phases_ms": {k: round(v, 2) for k, v in zip(("boxes_keys", "sort", "ploc", "top_on_host", "layout"), bi["ms"])},
+                         "ploc_rounds": bi["ploc_rounds"], "clusters_to_host": bi["clusters_top"], "wide_nodes": bi["nodes"], "ms_per_frame_stats": step_stats(gms),
+                         "frame_vs_host_tree": round(min(gms) / min(per_step), 4)}
+            cg.close()
+        except Exception as e:
+            gpu_build = {"error": str(e)[:200]}
         rec = {"ms_per_frame": round(dt * 1e3 / steps, 3), "ms_per_frame_stats": step_stats(per_step), "Mrays_s": round(float(rays.sum()) / dt / 1e6, 1), "triangles": int(scene.num_triangles), "scene": source,
                "rays_per_frame": int(rays.sum() / steps), "dominant_kernel": roof["kernel"] if roof else None,
                "frac": roof["frac"] if roof else None, "bound": roof["bound"] if roof else None,
@@ -345,7 +370,7 @@ def time_extra(rt, dev_index, workload, steps=5):
                "lanes_per_inst": roof.get("compute", {}).get("lanes_per_inst") if roof else None,
                "kernel_ms_per_frame": {k: round(v / steps, 3) for k, v in roof["kernel_ms_by_class"].items()} if roof else None,
                "work_per_ray": work,
-               "commit_s": round(commit_s, 3), "refit_commit_ms": refit_ms,
+               "commit_s": round(commit_s, 3), "refit_commit_ms": refit_ms, "gpu_build": gpu_build,
                "ms_per_frame_kernels_timed": round(dt_timed * 1e3 / steps, 3),
                "note": "ms_per_frame / Mrays_s: kernel timing off (shadow rays of bounce b overlap the closest-hit rays of bounce b + 1); kernel_ms_per_frame, frac: a second pass with per-kernel HIP events, which runs the launches one after the other"}
         return rec

@@ -164,6 +164,10 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
                                         so no result changes.  The next rtx_commit_scene rebuilds */
        RTX_OPT_ANYHIT_ORDER = 28,    /* any-hit (shadow / visibility) rays visit the hit children of a node in 0 = slot order, 1 = nearest octant first, 2 = farthest octant first;
                                         -1 (default) = what a commit-time probe of 2 048 NEE-like segments on the host found cheapest for this scene and its lights.  Never changes a result */
+       RTX_OPT_GPU_BUILD = 38,       /* 1: a geometry-changing rtx_commit_scene builds the BVH ON THE GPU (csrc/rtx_build.hip: Morton sort, PLOC clustering down to <= 8 192 clusters, the top
+                                        of the tree by the host's SAH builder + re-insertion over those clusters, SAH collapse to 8-wide nodes and layout on the device, then the refit
+                                        kernels) instead of on the host: what the reference's driver does for it in BottomLevelASGenerator.cpp:178-247 / TopLevelASGenerator.cpp:149-250.
+                                        0 (default): host build.  Results never depend on the tree; the host-side mirror of the tree (scene cache save, host refit) is not kept */
        RTX_OPT_BLOCKS_PER_CU = 12    /* tuning: workgroups (= private sub-queues) per compute unit; default 0 = auto: 40 (tiny scenes) / 32 at full frame size (8 measured 4-7 % slower there: tail imbalance), fewer — down to 8 — when a batch is so
                                         small (a shard) that a sub-queue would start with fewer than ~16 / ~8 chunks of 256 paths */ };
 
@@ -287,6 +291,21 @@ int  rtx_debug_trace_counters(rtx_ctx*, uint64_t out4[4]);
 /* downloads the resident wide BVH and checks it on the host: 0 = every triangle is in exactly one leaf slot and inside all the
    decoded boxes above it (what the GPU refit must preserve); > 0 = validator code; < 0 = RTX_ERR_* */
 int  rtx_debug_validate_bvh(rtx_ctx*);
+/* FNV-1a hashes of the wide tree as the device holds it: out[0] the node records, out[1] the leaf-ordered triangle records — two contexts hold the same tree iff both agree
+   (the GPU build against its host twin, a loaded scene cache against the build it was saved from) */
+int  rtx_debug_tree_hash(rtx_ctx*, uint64_t out2[2]);
+/* the wide tree itself (tooling: diffing two trees that should be equal): which = 0 the device's records, 1 the host builder's mirror of them (RTX_ERR_STATE when the tree was
+   built on the device).  nodes: rtx_stats.bvh_nodes x 80 bytes, tris: rtx_stats.bvh_refs x 48 bytes; either may be NULL */
+int  rtx_debug_read_tree(rtx_ctx*, int which, void* nodes, uint64_t nodes_bytes, void* tris, uint64_t tris_bytes);
+/* what the HOST builder keeps between commits for its refits (tooling): the binary tree (64-byte records) and the leaf order (uint32 per leaf reference).  In: the capacities
+   of the two buffers, out: the sizes in bytes; a buffer that is too small (or NULL) is left alone */
+int  rtx_debug_read_host_build(rtx_ctx*, void* nodes2, uint64_t* nodes2_bytes, void* leaf_order, uint64_t* leaf_order_bytes);
+/* FNV-1a hashes of what the host side holds between commits (tooling: which call changed something it should not have): {mesh indices, mesh vertices, material ids +
+   materials, instance records, leaf order, binary tree, wide tree mirror, shade records + object-space triangles + leaf slots} */
+int  rtx_debug_host_checksums(rtx_ctx*, uint64_t out8[8]);
+/* the last geometry-changing rtx_commit_scene: ms5 = {GPU build: boxes + keys, sort, PLOC rounds, top of the tree on the host, layout} (all 0 after a host build),
+   counts4 = {wide nodes, leaf entries, PLOC rounds, clusters handed to the host} */
+int  rtx_debug_build_info(rtx_ctx*, double ms5[5], uint32_t counts4[4]);
 /* out16 per hit = pos3, matID bits, normal3, area, inst bits, flat3, pad4 (ClosestHit, Hit_v6.hlsl:12-61) */
 int  rtx_debug_surface(rtx_ctx*, const float* rays8, const float* hits4, uint32_t n, float* out16);
 /* in9 = n(3) wo(3) wi(3); out8 = f(3), pdf, p_d, p_s, 0, 0 */

@@ -41,6 +41,7 @@ OPT_KERNEL_TIMING, OPT_PATHS_PER_BATCH, OPT_SORT_MATERIALS, OPT_LDS_NODES, OPT_S
 OPT_REFILL_MIN, OPT_STACK_PRIVATE, OPT_TRACE_SCHED, OPT_GPU_REFIT, OPT_BLOCKS_PER_CU, OPT_LPT_ORDER, OPT_FUSED_BVH, OPT_WORK_STEALING, OPT_COMPACT_STATE, OPT_OVERLAP_SHADOW = 8, 9, 10, 11, 12, 13, 14, 15, 16, 18
 OPT_RESTIR_WAVEFRONT, OPT_RESTIR_CHUNKS, OPT_OCCLUDER_CACHE, OPT_RESTIR_LANES, OPT_SHADE_DENSE, OPT_MERGE_RAYS, OPT_TAPER = 19, 20, 21, 22, 23, 24, 25
 OPT_BVH_REINSERT, OPT_BVH_SPLIT, OPT_ANYHIT_ORDER, OPT_RESTIR_LANE_MIN, OPT_TRACE_COUNTERS, OPT_ASYNC, OPT_OCTANT_SORT, OPT_SAMPLE_INTERLEAVE, OPT_NODE_STRIDE, OPT_RESTIR_KEYS, OPT_LDS_NODES_CLOSEST, OPT_PARTIAL_REFIT = 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37
+OPT_GPU_BUILD = 38
 
 
 class RtxError(RuntimeError):
@@ -120,6 +121,11 @@ class HaloPeer(C.Structure):
 _sig("rtx_restir_halo_plan", C.c_int, C.POINTER(Params), _u32, C.POINTER(HaloPeer), _u32, _u32p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 _sig("rtx_restir_pack_halo", C.c_int, _vp, C.POINTER(Params), _u32, _vp)
 _sig("rtx_restir_unpack_halo", C.c_int, _vp, C.POINTER(Params), _u32, _vp)
+_sig("rtx_debug_tree_hash", C.c_int, _vp, C.POINTER(C.c_uint64))
+_sig("rtx_debug_read_host_build", C.c_int, _vp, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64))
+_sig("rtx_debug_host_checksums", C.c_int, _vp, C.POINTER(C.c_uint64))
+_sig("rtx_debug_read_tree", C.c_int, _vp, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64)
+_sig("rtx_debug_build_info", C.c_int, _vp, C.POINTER(C.c_double), _u32p)
 _sig("rtx_read_restir_last", C.c_int, _vp, _vp, _vp, _vp, C.c_size_t)
 _sig("rtx_pass1_slots", C.c_size_t, _u32, _u32)
 _sig("rtx_read_pass1_buffers", C.c_int, _vp, _vp, _vp, _vp, C.c_size_t)
@@ -637,6 +643,39 @@ class Context:
         out = np.zeros(len(r), np.uint8)
         self._ck(lib.rtx_debug_trace_any(self._h, _ptr(r), len(r), _ptr(out)), "rtx_debug_trace_any")
         return out
+
+    def tree_hash(self):
+        """(hash of the node records, hash of the leaf-ordered triangle records) of the wide tree as the device holds it"""
+        h = (C.c_uint64 * 2)()
+        self._ck(lib.rtx_debug_tree_hash(self._h, h), "rtx_debug_tree_hash")
+        return int(h[0]), int(h[1])
+
+    def read_tree(self, which=0):
+        """(node records (n, 80) uint8, leaf-ordered triangle records (m, 12) float32) of the device (which=0) or of the host builder's mirror (which=1)"""
+        st = self.stats()
+        nodes, tris = np.empty((st.bvh_nodes, 80), np.uint8), np.empty((st.bvh_refs, 12), np.float32)
+        self._ck(lib.rtx_debug_read_tree(self._h, int(which), nodes.ctypes.data_as(C.c_void_p), C.c_uint64(nodes.nbytes), tris.ctypes.data_as(C.c_void_p), C.c_uint64(tris.nbytes)), "rtx_debug_read_tree")
+        return nodes, tris
+
+    def read_host_build(self):
+        """(binary tree (n, 16) float32, leaf order (m,) uint32) as the host builder keeps them for refits; empty after a GPU build"""
+        nb, lb = C.c_uint64(0), C.c_uint64(0)
+        self._ck(lib.rtx_debug_read_host_build(self._h, None, C.byref(nb), None, C.byref(lb)), "rtx_debug_read_host_build")
+        nodes, order = np.empty((nb.value // 64, 16), np.float32), np.empty(lb.value // 4, np.uint32)
+        self._ck(lib.rtx_debug_read_host_build(self._h, nodes.ctypes.data_as(C.c_void_p), C.byref(nb), order.ctypes.data_as(C.c_void_p), C.byref(lb)), "rtx_debug_read_host_build")
+        return nodes, order
+
+    def host_checksums(self):
+        """hashes of the host-side scene and build state: (mesh indices, mesh vertices, materials, instances, leaf order, binary tree, wide mirror, shade + objtris + slots)"""
+        h = (C.c_uint64 * 8)()
+        self._ck(lib.rtx_debug_host_checksums(self._h, h), "rtx_debug_host_checksums")
+        return tuple(int(x) for x in h)
+
+    def build_info(self):
+        """the last geometry-changing commit: dict(ms=(boxes + keys, sort, PLOC, top on the host, layout), nodes, refs, ploc_rounds, clusters_top); ms all 0 after a host build"""
+        ms, cn = (C.c_double * 5)(), (C.c_uint32 * 4)()
+        self._ck(lib.rtx_debug_build_info(self._h, ms, cn), "rtx_debug_build_info")
+        return dict(ms=tuple(ms), nodes=cn[0], refs=cn[1], ploc_rounds=cn[2], clusters_top=cn[3])
 
     def trace_counters(self):
         """(node steps, triangle tests) of the closest-hit rays and of the any-hit rays since the last call (OPT_TRACE_COUNTERS 1)"""

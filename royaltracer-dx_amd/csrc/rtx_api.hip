@@ -10,6 +10,9 @@
 #include "../../include/rtx.h"
 #include "rtx_kernels.hpp"
 #include "rtx_scene_host.hpp"
+#include <mutex>
+#include "rtx_build.hpp"
+#include "rtx_staging.hpp"
 
 using namespace rtx;
 
@@ -36,6 +39,25 @@ struct DevBuf {
 
 struct TimedLaunch { int cls; hipEvent_t a, b; };
 
+// Streams are BORROWED from a process-wide pool and returned idle; the library never calls hipStreamDestroy.  Round 5 (profiles/r05_determinism.md): in a process that creates
+// and destroys thousands of contexts, once in ~700 contexts two words of a live 912-byte heap block — a mesh's index array, the builder's leaf order — changed during a later
+// rtx_commit_scene: a write through a stale pointer by code OUTSIDE this library (with the library's own allocations of that size on fenced pages, nothing of ours touched freed
+// memory and nothing of ours was hit).  Not releasing events, device or pinned memory left the rate unchanged; not destroying the two streams of a context made it vanish
+// (0 findings in 5 500 x 2 contexts against 25 in 17 700 x 2).  A pooled stream also saves the ~50 us its creation costs.
+struct StreamPool {
+    std::mutex mu; std::vector<std::pair<int, hipStream_t>> idle;
+    hipError_t acquire(int device, hipStream_t* out) {
+        { std::lock_guard<std::mutex> g(mu); for (size_t i = 0; i < idle.size(); i++) if (idle[i].first == device) { *out = idle[i].second; idle.erase(idle.begin() + (long)i); return hipSuccess; } }
+        return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    }
+    void release(int device, hipStream_t st) {             // the caller has the device bound
+        if (!st) return;
+        (void)hipStreamSynchronize(st);
+        std::lock_guard<std::mutex> g(mu); idle.emplace_back(device, st);
+    }
+};
+static StreamPool& stream_pool() { static StreamPool* p = new StreamPool(); return *p; }      // (never destructed: no order of static destructors to get wrong at exit)
+
 struct rtx_ctx {
     int device = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
@@ -44,7 +66,9 @@ struct rtx_ctx {
     bool committed = false, camera_set = false;
     DevBuf d_nodes, d_tris, d_small, d_small_tris, d_small_poly, d_shade, d_mats, d_insts, d_lights, d_cdf, d_cam;
     bool committed_once = false;
-    int upload_scopes = 0;                                      // UploadScope nesting: upload() synchronises unless a scope will
+    // the wide tree as the DEVICE holds it (the host mirror B.nodes8 / B.tris8 is empty after a GPU build): counts, the root record (octant-sort grid), who built it
+    uint32_t n_nodes8 = 0, n_tris8 = 0; Node8GPU root8{}; bool dev_built = false; int gpu_build = 0; GpuBvhBuilder* builder = nullptr; GpuBuildResult build_info;
+    Staging staging;                                            // the two pinned chunks every copy from / to caller memory passes through (rtx_staging.hpp)
     std::vector<float> h_cdf; std::vector<uint32_t> h_one;     // host sources of small asynchronous uploads
     DevBuf d_inst_moved, d_tri_dirty, d_node_dirty; bool node_aabb_valid = false; int partial_refit = 1;     // partial GPU refit (RTX_OPT_PARTIAL_REFIT): node_aabb / d_scale hold the last full refit's state
     DevBuf d_objtris, d_node_aabb, d_scale;          // GPU refit: object-space vertices (uploaded on first use), per-node float boxes, max |coordinate|
@@ -117,21 +141,13 @@ static int finish_render(rtx_ctx* c);
 #define BIND_NOWAIT(c) do { if (!(c)) return RTX_ERR_INVALID; HIPCHK(c, hipSetDevice((c)->device)); } while (0)
 #define BIND(c) do { BIND_NOWAIT(c); if ((c)->pending.active) { const int r_ = finish_render(c); if (r_ != RTX_OK) return r_; } } while (0)
 
-// EVERY host-to-device copy of a host array goes through upload().  The source of an asynchronous copy from pageable memory must stay valid until the stream has passed
-// the copy (above a few MB the runtime pins the user pages and the DMA engine reads them directly), so upload() is safe by construction: it SYNCHRONISES the stream before
-// it returns — unless the caller holds an UploadScope, which batches several uploads behind ONE synchronise in its destructor, i.e. on every way out of the scope, early
-// error returns included.  Inside a scope only sources that outlive it may be uploaded (context members: `built`, `h_cdf`, `h_one`); a block-local vector is uploaded
-// without one (the ReSTIR pixel lists: once per image size).
-struct UploadScope {
-    rtx_ctx* c;
-    explicit UploadScope(rtx_ctx* c_) : c(c_) { c->upload_scopes++; }
-    ~UploadScope() { if (--c->upload_scopes == 0 && c->stream) (void)hipStreamSynchronize(c->stream); }
-    UploadScope(const UploadScope&) = delete; UploadScope& operator=(const UploadScope&) = delete;
-};
+// EVERY copy between host arrays and the device goes through these two (rtx_staging.hpp: pinned chunks of the context).  to_device: the source is consumed when it returns
+// and the copy is ordered on the context's stream — no lifetime rule, no synchronise.  to_host: complete when it returns (it waits for the stream up to the copy).
+#define TO_DEVICE(c, dst, src, bytes) HIPCHK(c, (c)->staging.to_device((c)->stream, (dst), (src), (bytes)))
+#define TO_HOST(c, dst, src, bytes) HIPCHK(c, (c)->staging.to_host((c)->stream, (dst), (src), (bytes)))
 template <class T> static int upload(rtx_ctx* c, DevBuf& b, const std::vector<T>& v) {
     HIPCHK(c, b.ensure(v.size() * sizeof(T)));
-    if (!v.empty()) HIPCHK(c, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
-    if (!v.empty() && c->upload_scopes == 0) HIPCHK(c, hipStreamSynchronize(c->stream));
+    TO_DEVICE(c, b.p, v.data(), v.size() * sizeof(T));
     return RTX_OK;
 }
 
@@ -153,7 +169,7 @@ int rtx_create(int device_ordinal, rtx_ctx** out) {
     c->device = device_ordinal;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess) c->num_cus = prop.multiProcessorCount;
-    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+    if ((e = stream_pool().acquire(device_ordinal, &c->stream)) != hipSuccess) {
         g_create_err = hipGetErrorString(e); delete c; return RTX_ERR_HIP;
     }
     c->own_stream = true;
@@ -174,14 +190,16 @@ void rtx_destroy(rtx_ctx* c) {
                      &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq, &c->d_halo, &c->d_own, &c->d_heads, &c->d_alt_o, &c->d_alt_d, &c->d_alt_thr, &c->d_oct[0], &c->d_oct[1], &c->d_perm, &c->d_trace_cnt,
                      &c->d_nodes_wide, &c->d_rs_key_a, &c->d_rs_key_b, &c->d_inst_moved, &c->d_tri_dirty, &c->d_node_dirty};
     for (auto& A : c->rs_area) for (DevBuf* b : {&A.state, &A.hit, &A.cls, &A.fin, &A.cold, &A.occ, &A.cand, &A.sho, &A.shd, &A.pay, &A.cnt}) b->release();
-    for (hipStream_t& ls : c->lane_stream) if (ls) { (void)hipStreamDestroy(ls); ls = nullptr; }
+    for (hipStream_t& ls : c->lane_stream) if (ls) { stream_pool().release(c->device, ls); ls = nullptr; }
     for (DevBuf* b : all) b->release();
+    delete c->builder; c->builder = nullptr;
+    c->staging.release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
-    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->aux) (void)hipStreamDestroy(c->aux);
+    if (c->own_stream && c->stream) stream_pool().release(c->device, c->stream);
+    if (c->aux) stream_pool().release(c->device, c->aux);
     delete c;
 }
 
@@ -223,6 +241,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_TAPER: if (value < 0 || value > 8) { c->err = "taper must be in [0, 8]"; return RTX_ERR_INVALID; } c->taper = value != 0; c->taper_levels = value == 1 ? 4u : (uint32_t)std::max<long long>(value, 1); return RTX_OK;
     case RTX_OPT_MERGE_RAYS: if (value < 0 || value > (1 << 20)) { c->err = "merge_rays must be in [0, 2^20]"; return RTX_ERR_INVALID; } c->merge_rays = (uint32_t)value; return RTX_OK;
     case RTX_OPT_GPU_REFIT: c->gpu_refit = value != 0; return RTX_OK;
+    case RTX_OPT_GPU_BUILD: c->gpu_build = value != 0; return RTX_OK;
     case RTX_OPT_SHADE_DENSE: c->shade_dense = (int)value; c->dsc.shade_dense = value > 0 ? 1u : 0u; return RTX_OK;
     case RTX_OPT_OCCLUDER_CACHE: c->occluder_cache = value != 0; c->dsc.occluder_cache = c->occluder_cache; return RTX_OK;
     case RTX_OPT_RESTIR_WAVEFRONT: c->restir_wave = value != 0; return RTX_OK;
@@ -239,9 +258,9 @@ int rtx_set_stream(rtx_ctx* c, void* s) {
     BIND(c);
     if (c->own_stream && c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
     else HIPCHK(c, hipDeviceSynchronize());                // the old caller-owned stream may no longer exist: drain the device instead of touching it
-    if (c->own_stream && c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; c->own_stream = false; }
+    if (c->own_stream && c->stream) { stream_pool().release(c->device, c->stream); c->stream = nullptr; c->own_stream = false; }
     if (s) { c->stream = (hipStream_t)s; c->own_stream = false; }
-    else { HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    else { HIPCHK(c, stream_pool().acquire(c->device, &c->stream)); c->own_stream = true; }
     return RTX_OK;
 }
 
@@ -280,6 +299,8 @@ static int upload_built(rtx_ctx* c) {          // every device array of a freshl
     int r;
     if ((r = upload(c, c->d_nodes, B.nodes8))) return r;
     if ((r = upload(c, c->d_tris, B.tris8))) return r;
+    c->n_nodes8 = (uint32_t)B.nodes8.size(); c->n_tris8 = (uint32_t)B.tris8.size(); c->dev_built = false;
+    if (!B.nodes8.empty()) c->root8 = B.nodes8[0]; else memset(&c->root8, 0, sizeof(c->root8));
     if ((r = upload(c, c->d_shade, B.shade))) return r;
     if ((r = upload(c, c->d_small, B.small_recs))) return r;
     if ((r = upload(c, c->d_small_tris, B.small_tris))) return r;
@@ -290,9 +311,58 @@ static int upload_built(rtx_ctx* c) {          // every device array of a freshl
 }
 static int finalise_scene(rtx_ctx* c);
 
+struct Scratch { DevBuf a, b, c; ~Scratch() { a.release(); b.release(); c.release(); } };
+
+// probe_anyhit_order (csrc/rtx_scene_host.cpp) for a tree the host holds no mirror of (RTX_OPT_GPU_BUILD): the same 2 048 NEE-like segments — a point on a random triangle to a
+// CDF-sampled point on a light —, traced ON THE DEVICE in the three visiting orders by the counting form of the any-hit traversal, judged by the same cost model
+static int probe_anyhit_order_on_device(rtx_ctx* c, uint32_t& best_out) {
+    const BuiltScene& B = c->built;
+    best_out = 0u;
+    const uint32_t nt = (uint32_t)B.shade.size();
+    if (B.lights.empty() || !nt || B.objtris.size() != (size_t)nt * 3) return RTX_OK;
+    auto h32 = [](uint32_t a, uint32_t b) { uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u; h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15; return h; };
+    auto r01 = [&](uint32_t a, uint32_t b) { return (float)(h32(a, b) >> 8) * (1.0f / 16777216.0f); };
+    std::vector<float> rays; rays.reserve(2048 * 8);
+    for (uint32_t i = 0; i < 2048u; i++) {
+        const uint32_t g = h32(i, 1u) % nt;
+        const float* M = B.insts[B.shade[g].inst].o2w;
+        f3 w[3]; for (int k = 0; k < 3; k++) { const F4& o = B.objtris[(size_t)g * 3 + k]; w[k] = xform_point(M, mk3(o.x, o.y, o.z)); }
+        const f3 e1 = w[1] - w[0], e2 = w[2] - w[0];
+        float u = r01(i, 2u), v = r01(i, 3u); if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+        const f3 p = mk3(w[0].x + u * e1.x + v * e2.x, w[0].y + u * e1.y + v * e2.y, w[0].z + u * e1.z + v * e2.z);
+        f3 n = normalize(cross(e1, e2));
+        const float xi = r01(i, 4u);
+        size_t li = 0; while (li + 1 < B.lights.size() && B.lights[li].cdf < xi) li++;
+        const LightGPU& Lg = B.lights[li];
+        float a = r01(i, 5u), b = r01(i, 6u); if (a + b > 1.0f) { a = 1.0f - a; b = 1.0f - b; }
+        const f3 lp = mk3(Lg.xv[0] + a * (Lg.yv[0] - Lg.xv[0]) + b * (Lg.zv[0] - Lg.xv[0]), Lg.xv[1] + a * (Lg.yv[1] - Lg.xv[1]) + b * (Lg.zv[1] - Lg.xv[1]), Lg.xv[2] + a * (Lg.yv[2] - Lg.xv[2]) + b * (Lg.zv[2] - Lg.xv[2]));
+        f3 dir = lp - p;
+        if (dot(n, dir) < 0.0f) n = mk3(-n.x, -n.y, -n.z);
+        const f3 org = mk3(p.x + kSBias * n.x, p.y + kSBias * n.y, p.z + kSBias * n.z);
+        dir = lp - org;
+        const float dist = length(dir);
+        if (!(dist > 10.0f * kSBias)) continue;
+        const float r8[8] = {org.x, org.y, org.z, 0.5f * kSBias, dir.x / dist, dir.y / dist, dir.z / dist, dist - 5.0f * kSBias};
+        rays.insert(rays.end(), r8, r8 + 8);
+    }
+    const uint32_t n = (uint32_t)(rays.size() / 8);
+    if (!n) return RTX_OK;
+    Scratch s;
+    HIPCHK(c, s.a.ensure((size_t)n * 32)); HIPCHK(c, s.b.ensure((size_t)n * 16 * 3));
+    TO_DEVICE(c, s.a.p, rays.data(), (size_t)n * 32);
+    for (uint32_t ord = 0; ord < 3u; ord++) { DevScene sc = c->dsc; sc.any_order = ord; launch_dbg_trace(c->stream, sc, (const F4*)s.a.p, n, 3, (F4*)s.b.p + (size_t)ord * n); }
+    HIPCHK(c, hipGetLastError());
+    std::vector<float> h((size_t)n * 4 * 3);
+    TO_HOST(c, h.data(), s.b.p, h.size() * 4);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double cost[3] = {0.0, 0.0, 0.0};
+    for (uint32_t ord = 0; ord < 3u; ord++) for (uint32_t i = 0; i < n; i++) { const float* q = &h[((size_t)ord * n + i) * 4]; cost[ord] += (double)q[1] * (205.0 * 64.0 / 47.0) + (double)q[2] * (70.0 * 64.0 / 24.0); }
+    for (uint32_t ord = 1; ord < 3u; ord++) if (cost[ord] < 0.95 * cost[0] && cost[ord] < cost[best_out]) best_out = ord;
+    return RTX_OK;
+}
+
 int rtx_commit_scene(rtx_ctx* c) {
     BIND(c);
-    UploadScope uploads(c);                 // sources below are members of c->built / c->h_*: one synchronise on every way out
     if (c->host.topo_dirty || c->host.mats_dirty || !c->committed_once)      // (a transform-only commit changes neither the ids nor the table: not 11 M comparisons per frame)
         for (size_t i = 0; i < c->host.matids.size(); i++)
             if (c->host.matids[i] >= c->host.mats128.size() / 32) { c->err = "commit: material id out of range"; return RTX_ERR_INVALID; }
@@ -302,7 +372,7 @@ int rtx_commit_scene(rtx_ctx* c) {
     // Transform-only commit of a scene that is already resident (and not a tiny one, whose pre-test records depend on world
     // positions): refit ON THE GPU — the kernels re-derive the world triangles and re-quantise the wide nodes bottom-up; the host
     // only re-derives the instance matrices and the light list.  Anything else: host build (or host refit) + upload.
-    const bool gpu_path = c->gpu_refit && c->device_scene_valid && !c->host.topo_dirty && B.small_nrec == 0 && !B.nodes8.empty() && B.level_start8.size() >= 2;
+    const bool gpu_path = c->gpu_refit && c->device_scene_valid && !c->host.topo_dirty && B.small_nrec == 0 && c->n_nodes8 != 0 && B.level_start8.size() >= 2;
     if (gpu_path) {
         const bool mats_changed = c->host.mats_dirty;
         if (!c->host.refresh_transforms(B)) { c->err = c->host.err; return RTX_ERR_INVALID; }
@@ -313,28 +383,69 @@ int rtx_commit_scene(rtx_ctx* c) {
             if (B.objtris.empty()) c->host.fill_objtris(B);             // scene came from a cache file: derive them from the meshes now
             if ((r = upload(c, c->d_objtris, B.objtris))) return r; c->objtris_uploaded = true;
         }
-        HIPCHK(c, c->d_node_aabb.ensure(B.nodes8.size() * 32));
+        HIPCHK(c, c->d_node_aabb.ensure((size_t)c->n_nodes8 * 32));
         // the first refit after a build is a full one (it fills node_aabb); later ones touch the moved instances only, unless every instance moved anyway
         size_t nmoved = 0; for (uint32_t m : B.inst_moved) nmoved += m;
         const bool partial = c->partial_refit && c->node_aabb_valid && B.inst_moved.size() == B.insts.size() && nmoved < B.insts.size();
         if (partial) {
             if ((r = upload(c, c->d_inst_moved, B.inst_moved))) return r;
-            HIPCHK(c, c->d_tri_dirty.ensure(B.tris8.size())); HIPCHK(c, c->d_node_dirty.ensure(B.nodes8.size()));
+            HIPCHK(c, c->d_tri_dirty.ensure(c->n_tris8)); HIPCHK(c, c->d_node_dirty.ensure(c->n_nodes8));
         } else {
             c->h_one.assign(1, 0x3f800000u);                       // scale starts at 1.0 like the host's max(1, |coordinates|)
             if ((r = upload(c, c->d_scale, c->h_one))) return r;
         }
-        launch_refit(c->stream, (Node8GPU*)c->d_nodes.p, B.level_start8.data(), (uint32_t)B.level_start8.size() - 1, (TriGPU*)c->d_tris.p, (uint32_t)B.tris8.size(),
+        launch_refit(c->stream, (Node8GPU*)c->d_nodes.p, B.level_start8.data(), (uint32_t)B.level_start8.size() - 1, (TriGPU*)c->d_tris.p, c->n_tris8,
                      (const TriShade*)c->d_shade.p, (const InstGPU*)c->d_insts.p, (const F4*)c->d_objtris.p, (F4*)c->d_node_aabb.p, (uint32_t*)c->d_scale.p,
                      partial ? (const uint32_t*)c->d_inst_moved.p : nullptr, (uint8_t*)c->d_tri_dirty.p, (uint8_t*)c->d_node_dirty.p);
         HIPCHK(c, hipGetLastError());
         c->node_aabb_valid = true;
     } else {
         c->device_scene_valid = false; c->objtris_uploaded = false; c->node_aabb_valid = false;
-        if (!c->host.build(B)) { c->err = c->host.err; return RTX_ERR_INVALID; }
-        if ((r = upload_built(c))) return r;
+        size_t ntri_all = 0; for (const InstHost& in : c->host.insts) ntri_all += c->host.meshes[in.mesh].idx.size() / 3;
+        // RTX_OPT_GPU_BUILD: the tree on the device (csrc/rtx_build.hip).  Not for tiny scenes (their pre-test records are built from the host tree's leaf order) nor with
+        // spatial splits (a host-builder feature); there the host builds as before.
+        const bool on_gpu = c->gpu_build && ntri_all > 4096u && c->host.bvh.split_alpha <= 0.0;
+        if (!c->host.build(B, !on_gpu)) { c->err = c->host.err; return RTX_ERR_INVALID; }
+        if (!on_gpu) { if ((r = upload_built(c))) return r; }
+        else {
+            const uint32_t nt = (uint32_t)B.shade.size();
+            if ((r = upload(c, c->d_shade, B.shade))) return r;
+            if ((r = upload(c, c->d_mats, B.mats))) return r;
+            if ((r = upload(c, c->d_insts, B.insts))) return r;
+            if ((r = upload_lights(c))) return r;
+            if ((r = upload(c, c->d_objtris, B.objtris))) return r; c->objtris_uploaded = true;
+            for (DevBuf* b : {&c->d_small, &c->d_small_tris, &c->d_small_poly}) HIPCHK(c, b->ensure(16));
+            HIPCHK(c, c->d_tris.ensure((size_t)nt * sizeof(TriGPU)));
+            if (!c->builder) c->builder = new GpuBvhBuilder();
+            BvhBuildOptions bo = c->host.bvh; if (bo.ploc_radius <= 0) bo.ploc_radius = 16;
+            const std::string e = c->builder->build(c->stream, (const F4*)c->d_objtris.p, (const TriShade*)c->d_shade.p, (const InstGPU*)c->d_insts.p, nt, bo, (TriGPU*)c->d_tris.p, c->build_info);
+            if (!e.empty()) { c->err = e; return RTX_ERR_HIP; }
+            const GpuBuildResult& G = c->build_info;
+            HIPCHK(c, c->d_nodes.ensure((size_t)G.nnodes8 * sizeof(Node8GPU)));
+            HIPCHK(c, hipMemcpyAsync(c->d_nodes.p, c->builder->nodes(), (size_t)G.nnodes8 * sizeof(Node8GPU), hipMemcpyDeviceToDevice, c->stream));
+            c->n_nodes8 = G.nnodes8; c->n_tris8 = G.ntris8; c->dev_built = true;
+            B.level_start8 = G.level_start8; B.stack8 = G.stack8;
+            // the boxes: a FULL refit — world triangles from the object-space ones, every node quantised bottom-up (what a transform-only commit runs)
+            HIPCHK(c, c->d_node_aabb.ensure((size_t)c->n_nodes8 * 32));
+            c->h_one.assign(1, 0x3f800000u);
+            if ((r = upload(c, c->d_scale, c->h_one))) return r;
+            launch_refit(c->stream, (Node8GPU*)c->d_nodes.p, B.level_start8.data(), (uint32_t)B.level_start8.size() - 1, (TriGPU*)c->d_tris.p, c->n_tris8,
+                         (const TriShade*)c->d_shade.p, (const InstGPU*)c->d_insts.p, (const F4*)c->d_objtris.p, (F4*)c->d_node_aabb.p, (uint32_t*)c->d_scale.p, nullptr, nullptr, nullptr);
+            HIPCHK(c, hipGetLastError());
+            TO_HOST(c, &c->root8, c->d_nodes.p, sizeof(Node8GPU));
+            c->node_aabb_valid = true;
+            if (getenv("RTX_BUILD_TIMES")) fprintf(stderr, "[build] GPU: prims %.2f ms, sort %.2f ms, PLOC %.2f ms (%u rounds -> %u clusters), top on the host %.2f ms, layout %.2f ms: %u wide nodes, stack %u\n",
+                                                   G.ms_prims, G.ms_sort, G.ms_ploc, G.ploc_iterations, G.clusters_top, G.ms_top_host, G.ms_layout, G.nnodes8, G.stack8);
+        }
     }
-    return finalise_scene(c);
+    r = finalise_scene(c);
+    if (r == RTX_OK && c->dev_built && c->n_nodes8) {          // the visiting order of any-hit rays, probed on the device (the host probe replays its mirror of the tree)
+        uint32_t best = 0;
+        if ((r = probe_anyhit_order_on_device(c, best))) return r;
+        c->built.any_order = best;
+        if (c->any_order_opt < 0) c->dsc.any_order = best;
+    }
+    return r;
 }
 
 // the binary scene cache.  Save = the committed scene (inputs + everything rtx_commit_scene derived); load = replace the
@@ -342,12 +453,12 @@ int rtx_commit_scene(rtx_ctx* c) {
 int rtx_save_scene_cache(rtx_ctx* c, const char* path) {
     if (!c) return RTX_ERR_INVALID;
     if (!c->committed) { c->err = "save_scene_cache: scene not committed"; return RTX_ERR_STATE; }
+    if (c->dev_built) { c->err = "save_scene_cache: the tree was built on the GPU (RTX_OPT_GPU_BUILD) and has no host mirror; commit with the host builder to save a cache"; return RTX_ERR_STATE; }
     if (!save_scene_cache(c->host, c->built, path, c->err)) return RTX_ERR_INVALID;
     return RTX_OK;
 }
 int rtx_load_scene_cache(rtx_ctx* c, const char* path) {
     BIND(c);
-    UploadScope uploads(c);
     if (!load_scene_cache(path, c->host, c->built, c->err)) return RTX_ERR_INVALID;     // on failure the previous scene is untouched
     c->committed = false; c->device_scene_valid = false; c->objtris_uploaded = false; c->node_aabb_valid = false;
     int r = upload_built(c);
@@ -381,7 +492,7 @@ static int finalise_scene(rtx_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->device_scene_valid = true;
     DevScene& s = c->dsc;
-    s.nodes = (const Node8GPU*)c->d_nodes.p; s.nnodes = (uint32_t)B.nodes8.size();
+    s.nodes = (const Node8GPU*)c->d_nodes.p; s.nnodes = c->n_nodes8;
     s.nodes_f = (const F4*)c->d_nodes.p; s.node_v4 = 5u;
     // RTX_OPT_NODE_STRIDE: a second copy of the nodes with ONE node per 128-B line (80-B nodes at an 80-B stride straddle a line in 4 of 8 positions: 1.5 lines per visit),
     // refreshed after every build / refit (stream order: before any frame).  Auto: made for trees of more than 16 MB, and fetched by the path tracer's closest-hit launches of
@@ -393,7 +504,7 @@ static int finalise_scene(rtx_ctx* c) {
         HIPCHK(c, hipMemcpy2DAsync(c->d_nodes_wide.p, 128, c->d_nodes.p, sizeof(Node8GPU), sizeof(Node8GPU), s.nnodes, hipMemcpyDeviceToDevice, c->stream));
         if (c->node_stride == 128) { s.nodes_f = (const F4*)c->d_nodes_wide.p; s.node_v4 = 8u; }
     }
-    s.tris = (const TriGPU*)c->d_tris.p; s.ntris = (uint32_t)B.tris8.size();
+    s.tris = (const TriGPU*)c->d_tris.p; s.ntris = c->n_tris8;
     s.shade = (const TriShade*)c->d_shade.p;
     s.small = (const SmallRecPair*)c->d_small.p; s.small_tris = (const TriGPU*)c->d_small_tris.p; s.small_poly = (const F4*)c->d_small_poly.p; s.small_cm = B.small_cm; s.small_delta = B.small_delta;
     s.mats = (const MatGPU*)c->d_mats.p; s.nmat = (uint32_t)B.mats.size();
@@ -426,8 +537,8 @@ static int finalise_scene(rtx_ctx* c) {
     {   // grid of RTX_OPT_OCTANT_SORT 3 over the root's box: 8 bits handed to the axes one at a time, always to the axis whose cells are longest
         float ext[3] = {1.0f, 1.0f, 1.0f}; uint32_t bits[3] = {0, 0, 0};
         s.cell_o[0] = s.cell_o[1] = s.cell_o[2] = 0.0f;
-        if (!B.nodes8.empty()) {
-            const Node8GPU& R0 = B.nodes8[0];
+        if (c->n_nodes8) {
+            const Node8GPU& R0 = c->root8;
             s.cell_o[0] = R0.px; s.cell_o[1] = R0.py; s.cell_o[2] = R0.pz;
             for (int a = 0; a < 3; a++) ext[a] = std::max(1e-20f, 255.0f * std::ldexp(1.0f, (int)((R0.e_imask >> (8 * a)) & 0xffu) - 127));
         }
@@ -472,7 +583,7 @@ int rtx_set_camera(rtx_ctx* c, const float view[16], const float proj[16]) {
     mat4_inverse(view, cam.viewI); mat4_inverse(proj, cam.projI);     // Renderer.cpp:1735-1736
     memcpy(cam.prev_view, c->prev_view, 64); memcpy(cam.prev_proj, c->prev_proj, 64);
     HIPCHK(c, c->d_cam.ensure(sizeof(cam)));
-    HIPCHK(c, hipMemcpyAsync(c->d_cam.p, &cam, sizeof(cam), hipMemcpyHostToDevice, c->stream));
+    TO_DEVICE(c, c->d_cam.p, &cam, sizeof(cam));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->camera_set = true;
     return RTX_OK;
@@ -719,7 +830,7 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
         // persistent kernels fill each other's tails and memory stalls: C3 40.8 -> 40.3 ms, C5 38.3 -> 36.9 ms per frame, images unchanged.  Not while
         // kernels are timed (RTX_OPT_KERNEL_TIMING): overlapping launches have no per-kernel time.
         const bool ovl = c->overlap_shadow && !c->timing && !fused && !fused_bvh;
-        if (ovl && !c->aux) HIPCHK(c, hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+        if (ovl && !c->aux) HIPCHK(c, stream_pool().acquire(c->device, &c->aux));
         hipEvent_t ev_shadow_done = nullptr;
         auto Hd = [&](uint32_t b, uint32_t k) { return stealing ? (uint32_t*)c->d_heads.p + ((size_t)b * (1 + nee1) + k) * hstride : nullptr; };
         // sub-queues per workgroup of a traversal launch predicted to hold `rays` rays: double while a workgroup would start with fewer than merge_rays and at least one full
@@ -906,7 +1017,7 @@ static int rs_lanes(rtx_ctx* c, const uint32_t* pixels, uint32_t npixels, F&& pa
         if (lo == hi) continue;
         hipStream_t st = c->stream;
         if (l) {
-            if (!c->lane_stream[l - 1]) HIPCHK(c, hipStreamCreateWithFlags(&c->lane_stream[l - 1], hipStreamNonBlocking));
+            if (!c->lane_stream[l - 1]) HIPCHK(c, stream_pool().acquire(c->device, &c->lane_stream[l - 1]));
             st = c->lane_stream[l - 1];
             HIPCHK(c, hipStreamWaitEvent(st, e0, 0));
         }
@@ -951,7 +1062,7 @@ int rtx_render_v6_pass1(rtx_ctx* c, const rtx_params* p) {
     HIPCHK(c, hipEventRecord(c->ev_end, c->stream));
     HIPCHK(c, hipGetLastError());
     unsigned long long cnt[3] = {0, 0, 0};
-    HIPCHK(c, hipMemcpyAsync(cnt, c->d_p1cnt.p, 24, hipMemcpyDeviceToHost, c->stream));
+    TO_HOST(c, cnt, c->d_p1cnt.p, 24);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     stats_end_restir(c, cnt);
     return RTX_OK;
@@ -1075,7 +1186,7 @@ int rtx_render_restir(rtx_ctx* c, const rtx_params* p) {
     HIPCHK(c, hipEventRecord(c->ev_end, c->stream));
     HIPCHK(c, hipGetLastError());
     unsigned long long cnt[4] = {0, 0, 0, 0};
-    HIPCHK(c, hipMemcpyAsync(cnt, c->d_p1cnt.p, 32, hipMemcpyDeviceToHost, c->stream));
+    TO_HOST(c, cnt, c->d_p1cnt.p, 32);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     stats_end_restir(c, cnt);
     c->stats.restir_stale_history_reads = cnt[3];
@@ -1201,9 +1312,9 @@ int rtx_restir_unpack_halo(rtx_ctx* c, const rtx_params* p, uint32_t halo_px, co
 int rtx_read_restir_last(rtx_ctx* c, void* di, void* gi, void* sd, size_t slots) {
     BIND(c);
     if (!c->last_slots || slots < c->last_slots) { c->err = "read_restir_last: no ReSTIR state or too few slots"; return RTX_ERR_INVALID; }
-    if (di) HIPCHK(c, hipMemcpyAsync(di, c->d_last_di.p, c->last_slots * 40, hipMemcpyDeviceToHost, c->stream));
-    if (gi) HIPCHK(c, hipMemcpyAsync(gi, c->d_last_gi.p, c->last_slots * 40, hipMemcpyDeviceToHost, c->stream));
-    if (sd) HIPCHK(c, hipMemcpyAsync(sd, c->d_last_sd.p, c->last_slots * 60, hipMemcpyDeviceToHost, c->stream));
+    if (di) TO_HOST(c, di, c->d_last_di.p, c->last_slots * 40);
+    if (gi) TO_HOST(c, gi, c->d_last_gi.p, c->last_slots * 40);
+    if (sd) TO_HOST(c, sd, c->d_last_sd.p, c->last_slots * 60);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RTX_OK;
 }
@@ -1211,9 +1322,9 @@ int rtx_read_restir_last(rtx_ctx* c, void* di, void* gi, void* sd, size_t slots)
 int rtx_read_pass1_buffers(rtx_ctx* c, void* di, void* gi, void* sd, size_t slots) {
     BIND(c);
     if (!c->p1_slots || slots < c->p1_slots) { c->err = "read_pass1_buffers: no pass-1 data or too few slots"; return RTX_ERR_INVALID; }
-    if (di) HIPCHK(c, hipMemcpyAsync(di, c->d_res_di.p, c->p1_slots * 40, hipMemcpyDeviceToHost, c->stream));
-    if (gi) HIPCHK(c, hipMemcpyAsync(gi, c->d_res_gi.p, c->p1_slots * 40, hipMemcpyDeviceToHost, c->stream));
-    if (sd) HIPCHK(c, hipMemcpyAsync(sd, c->d_sdata.p, c->p1_slots * 60, hipMemcpyDeviceToHost, c->stream));
+    if (di) TO_HOST(c, di, c->d_res_di.p, c->p1_slots * 40);
+    if (gi) TO_HOST(c, gi, c->d_res_gi.p, c->p1_slots * 40);
+    if (sd) TO_HOST(c, sd, c->d_sdata.p, c->p1_slots * 60);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RTX_OK;
 }
@@ -1222,7 +1333,7 @@ int rtx_read_accum(rtx_ctx* c, float* out, size_t bytes) {
     BIND(c);
     const size_t need = (size_t)c->acc_w * c->acc_h * 16;
     if (!out || !need || bytes < need || !c->accum_ptr()) { c->err = "read_accum: no image or buffer too small"; return RTX_ERR_INVALID; }
-    HIPCHK(c, hipMemcpyAsync(out, c->accum_ptr(), need, hipMemcpyDeviceToHost, c->stream));
+    TO_HOST(c, out, c->accum_ptr(), need);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RTX_OK;
 }
@@ -1233,7 +1344,7 @@ int rtx_read_srgb8(rtx_ctx* c, uint8_t* out, size_t bytes) {
     if (!out || !npix || bytes < (size_t)npix * 4 || !c->accum_ptr()) { c->err = "read_srgb8: no image or buffer too small"; return RTX_ERR_INVALID; }
     HIPCHK(c, c->d_srgb.ensure((size_t)npix * 4));
     launch_srgb8(c->stream, c->accum_ptr(), npix, (uint32_t*)c->d_srgb.p);
-    HIPCHK(c, hipMemcpyAsync(out, c->d_srgb.p, (size_t)npix * 4, hipMemcpyDeviceToHost, c->stream));
+    TO_HOST(c, out, c->d_srgb.p, (size_t)npix * 4);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RTX_OK;
 }
@@ -1251,7 +1362,7 @@ int rtx_read_layer(rtx_ctx* c, uint32_t layer, uint32_t width, uint32_t height, 
     HIPCHK(c, c->d_srgb.ensure(npix * 4));
     launch_debug_layer(c->stream, (uint32_t)c->num_cus * 8u, c->dsc, width, height, (const CameraGPU*)c->d_cam.p, layer, (uint32_t*)c->d_srgb.p);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(out, c->d_srgb.p, npix * 4, hipMemcpyDeviceToHost, c->stream));
+    TO_HOST(c, out, c->d_srgb.p, npix * 4);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RTX_OK;
 }
@@ -1295,7 +1406,6 @@ int rtx_unpack_tiles(rtx_ctx* c, const rtx_params* p, const void* slabs) {
 }
 
 // ---- kernel-level debug entry points ----
-struct Scratch { DevBuf a, b, c; ~Scratch() { a.release(); b.release(); c.release(); } };
 
 int rtx_debug_primary_rays(rtx_ctx* c, const rtx_params* p, uint32_t sample_id, float* rays8) {
     BIND(c);
@@ -1304,7 +1414,7 @@ int rtx_debug_primary_rays(rtx_ctx* c, const rtx_params* p, uint32_t sample_id, 
     Scratch s; const size_t n = (size_t)p->width * p->height;
     HIPCHK(c, s.a.ensure(n * 32));
     launch_dbg_primary(c->stream, f, (const CameraGPU*)c->d_cam.p, sample_id, (F4*)s.a.p);
-    HIPCHK(c, hipMemcpyAsync(rays8, s.a.p, n * 32, hipMemcpyDeviceToHost, c->stream));
+    TO_HOST(c, rays8, s.a.p, n * 32);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RTX_OK;
 }
@@ -1314,11 +1424,11 @@ static int dbg_trace(rtx_ctx* c, const float* rays8, uint32_t n, int any, float*
     if (!n) return RTX_OK;
     Scratch s;
     HIPCHK(c, s.a.ensure((size_t)n * 32)); HIPCHK(c, s.b.ensure((size_t)n * 16));
-    HIPCHK(c, hipMemcpyAsync(s.a.p, rays8, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+    TO_DEVICE(c, s.a.p, rays8, (size_t)n * 32);
     launch_dbg_trace(c->stream, c->dsc, (const F4*)s.a.p, n, any, (F4*)s.b.p);
     HIPCHK(c, hipGetLastError());
     std::vector<float> h((size_t)n * 4);
-    HIPCHK(c, hipMemcpyAsync(h.data(), s.b.p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+    TO_HOST(c, h.data(), s.b.p, (size_t)n * 16);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (hits4) memcpy(hits4, h.data(), (size_t)n * 16);
     if (occ) for (uint32_t i = 0; i < n; i++) { uint32_t prim; memcpy(&prim, &h[(size_t)i * 4 + 3], 4); occ[i] = prim != kMissPrim; }
@@ -1330,8 +1440,8 @@ int rtx_debug_validate_bvh(rtx_ctx* c) {
     BIND(c);
     if (!c->committed) { c->err = "scene not committed"; return RTX_ERR_STATE; }
     std::vector<Node8GPU> nodes(c->dsc.nnodes); std::vector<TriGPU> tris(c->dsc.ntris);
-    if (!nodes.empty()) HIPCHK(c, hipMemcpyAsync(nodes.data(), c->d_nodes.p, nodes.size() * sizeof(Node8GPU), hipMemcpyDeviceToHost, c->stream));
-    if (!tris.empty()) HIPCHK(c, hipMemcpyAsync(tris.data(), c->d_tris.p, tris.size() * sizeof(TriGPU), hipMemcpyDeviceToHost, c->stream));
+    if (!nodes.empty()) TO_HOST(c, nodes.data(), c->d_nodes.p, nodes.size() * sizeof(Node8GPU));
+    if (!tris.empty()) TO_HOST(c, tris.data(), c->d_tris.p, tris.size() * sizeof(TriGPU));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // the triangle the kernels intersect: (v0, v0 + e1, v0 + e2), filed under its global id (v0.w): a spatial split references a triangle from several leaf entries
     uint32_t ng = 0;
@@ -1343,6 +1453,64 @@ int rtx_debug_validate_bvh(rtx_ctx* c) {
     }
     return validate_bvh8(w, nodes, gid, ident, nullptr);
 }
+int rtx_debug_tree_hash(rtx_ctx* c, uint64_t out2[2]) {
+    BIND(c);
+    if (!c->committed || !out2) { if (c) c->err = "scene not committed"; return RTX_ERR_STATE; }
+    std::vector<uint8_t> nodes((size_t)c->n_nodes8 * sizeof(Node8GPU)), tris((size_t)c->n_tris8 * sizeof(TriGPU));
+    if (!nodes.empty()) TO_HOST(c, nodes.data(), c->d_nodes.p, nodes.size());
+    if (!tris.empty()) TO_HOST(c, tris.data(), c->d_tris.p, tris.size());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    auto fnv = [](const std::vector<uint8_t>& v) { uint64_t h = 1469598103934665603ull; for (uint8_t b : v) { h ^= b; h *= 1099511628211ull; } return h; };
+    out2[0] = fnv(nodes); out2[1] = fnv(tris);
+    return RTX_OK;
+}
+int rtx_debug_read_tree(rtx_ctx* c, int which, void* nodes, uint64_t nodes_bytes, void* tris, uint64_t tris_bytes) {
+    BIND(c);
+    if (!c->committed) { c->err = "scene not committed"; return RTX_ERR_STATE; }
+    const size_t nb = (size_t)c->n_nodes8 * sizeof(Node8GPU), tb = (size_t)c->n_tris8 * sizeof(TriGPU);
+    if ((nodes && nodes_bytes != nb) || (tris && tris_bytes != tb)) { c->err = "read_tree: buffers must hold rtx_stats.bvh_nodes * 80 and bvh_refs * 48 bytes"; return RTX_ERR_INVALID; }
+    if (which == 0) {
+        if (nodes) TO_HOST(c, nodes, c->d_nodes.p, nb);
+        if (tris) TO_HOST(c, tris, c->d_tris.p, tb);
+        return RTX_OK;
+    }
+    const BuiltScene& B = c->built;
+    if (B.nodes8.size() != c->n_nodes8 || B.tris8.size() != c->n_tris8) { c->err = "read_tree: the host holds no mirror of this tree (built on the device, or loaded without one)"; return RTX_ERR_STATE; }
+    if (nodes) memcpy(nodes, B.nodes8.data(), nb);
+    if (tris) memcpy(tris, B.tris8.data(), tb);
+    return RTX_OK;
+}
+int rtx_debug_read_host_build(rtx_ctx* c, void* nodes2, uint64_t* nodes2_bytes, void* leaf_order, uint64_t* leaf_order_bytes) {
+    if (!c || !nodes2_bytes || !leaf_order_bytes) return RTX_ERR_INVALID;
+    const BuiltScene& B = c->built;
+    const uint64_t nb = (uint64_t)B.nodes.size() * sizeof(NodeGPU), lb = (uint64_t)B.leaf_order.size() * 4u;
+    if (nodes2 && *nodes2_bytes >= nb) memcpy(nodes2, B.nodes.data(), (size_t)nb);
+    if (leaf_order && *leaf_order_bytes >= lb) memcpy(leaf_order, B.leaf_order.data(), (size_t)lb);
+    *nodes2_bytes = nb; *leaf_order_bytes = lb;
+    return RTX_OK;
+}
+int rtx_debug_host_checksums(rtx_ctx* c, uint64_t out8[8]) {
+    if (!c || !out8) return RTX_ERR_INVALID;
+    auto fnv = [](uint64_t h, const void* d, size_t n) { const uint8_t* q = (const uint8_t*)d; for (size_t i = 0; i < n; i++) { h ^= q[i]; h *= 1099511628211ull; } return h; };
+    for (int k = 0; k < 8; k++) out8[k] = 1469598103934665603ull;
+    const SceneHost& H = c->host; const BuiltScene& B = c->built;
+    for (const MeshHost& m : H.meshes) { out8[0] = fnv(out8[0], m.idx.data(), m.idx.size() * 4); out8[1] = fnv(out8[1], m.verts.data(), m.verts.size() * 4); }
+    out8[2] = fnv(fnv(out8[2], H.matids.data(), H.matids.size() * 4), H.mats128.data(), H.mats128.size() * 4);
+    out8[3] = fnv(out8[3], H.insts.data(), H.insts.size() * sizeof(InstHost));
+    out8[4] = fnv(out8[4], B.leaf_order.data(), B.leaf_order.size() * 4);
+    out8[5] = fnv(out8[5], B.nodes.data(), B.nodes.size() * sizeof(NodeGPU));
+    out8[6] = fnv(fnv(out8[6], B.nodes8.data(), B.nodes8.size() * sizeof(Node8GPU)), B.tris8.data(), B.tris8.size() * sizeof(TriGPU));
+    out8[7] = fnv(fnv(fnv(out8[7], B.shade.data(), B.shade.size() * sizeof(TriShade)), B.objtris.data(), B.objtris.size() * sizeof(F4)), B.tri_slots8.data(), B.tri_slots8.size() * 4);
+    return RTX_OK;
+}
+int rtx_debug_build_info(rtx_ctx* c, double ms5[5], uint32_t counts4[4]) {
+    if (!c || !ms5 || !counts4) return RTX_ERR_INVALID;
+    const GpuBuildResult& G = c->build_info;
+    const bool g = c->dev_built;
+    ms5[0] = g ? G.ms_prims : 0; ms5[1] = g ? G.ms_sort : 0; ms5[2] = g ? G.ms_ploc : 0; ms5[3] = g ? G.ms_top_host : 0; ms5[4] = g ? G.ms_layout : 0;
+    counts4[0] = c->n_nodes8; counts4[1] = c->n_tris8; counts4[2] = g ? G.ploc_iterations : 0; counts4[3] = g ? G.clusters_top : 0;
+    return RTX_OK;
+}
 // work counters of the persistent traversal kernels since they were last read (RTX_OPT_TRACE_COUNTERS 1): out4 = node steps and triangle tests of closest-hit rays, node steps and
 // triangle tests of any-hit rays; reading resets them.  Rays per class: rtx_stats (rays_primary + rays_extension, rays_shadow)
 int rtx_debug_trace_counters(rtx_ctx* c, uint64_t out4[4]) {
@@ -1351,7 +1519,7 @@ int rtx_debug_trace_counters(rtx_ctx* c, uint64_t out4[4]) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->aux) HIPCHK(c, hipStreamSynchronize(c->aux));
     unsigned long long h[4];
-    HIPCHK(c, hipMemcpy(h, c->d_trace_cnt.p, 32, hipMemcpyDeviceToHost));
+    TO_HOST(c, h, c->d_trace_cnt.p, 32);
     HIPCHK(c, hipMemset(c->d_trace_cnt.p, 0, 32));
     for (int i = 0; i < 4; i++) out4[i] = h[i];
     return RTX_OK;
@@ -1364,12 +1532,12 @@ int rtx_debug_surface(rtx_ctx* c, const float* rays8, const float* hits4, uint32
     if (!n) return RTX_OK;
     Scratch s;
     HIPCHK(c, s.a.ensure((size_t)n * 32)); HIPCHK(c, s.b.ensure((size_t)n * 16)); HIPCHK(c, s.c.ensure((size_t)n * 64));
-    HIPCHK(c, hipMemcpyAsync(s.a.p, rays8, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(s.b.p, hits4, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    TO_DEVICE(c, s.a.p, rays8, (size_t)n * 32);
+    TO_DEVICE(c, s.b.p, hits4, (size_t)n * 16);
     launch_dbg_surface(c->stream, c->dsc, (const F4*)s.a.p, (const F4*)s.b.p, n, (F4*)s.c.p);
     HIPCHK(c, hipGetLastError());
     std::vector<float> h((size_t)n * 16);
-    HIPCHK(c, hipMemcpyAsync(h.data(), s.c.p, (size_t)n * 64, hipMemcpyDeviceToHost, c->stream));
+    TO_HOST(c, h.data(), s.c.p, (size_t)n * 64);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // device layout: pos3,mat | normal3,area | inst,flat3 | 0  ->  API layout: pos3,mat,normal3,area,inst,flat3,pad4
     memcpy(out16, h.data(), (size_t)n * 64);
@@ -1382,11 +1550,11 @@ static int dbg_bsdf(rtx_ctx* c, bool sample, uint32_t mat, uint32_t flags, const
     if (!n) return RTX_OK;
     Scratch s;
     HIPCHK(c, s.a.ensure((size_t)n * stride_in * 4)); HIPCHK(c, s.b.ensure((size_t)n * 32));
-    HIPCHK(c, hipMemcpyAsync(s.a.p, in, (size_t)n * stride_in * 4, hipMemcpyHostToDevice, c->stream));
+    TO_DEVICE(c, s.a.p, in, (size_t)n * stride_in * 4);
     if (sample) launch_dbg_bsdf_sample(c->stream, c->dsc, mat, flags, (const float*)s.a.p, n, (float*)s.b.p);
     else launch_dbg_bsdf_eval(c->stream, c->dsc, mat, flags, (const float*)s.a.p, n, (float*)s.b.p);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(out8, s.b.p, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
+    TO_HOST(c, out8, s.b.p, (size_t)n * 32);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RTX_OK;
 }
@@ -1400,8 +1568,8 @@ int rtx_debug_tea(rtx_ctx* c, uint32_t seed[2], uint32_t n, float* out) {
     HIPCHK(c, s.a.ensure((size_t)std::max<uint32_t>(n, 1) * 4)); HIPCHK(c, s.b.ensure(8));
     launch_dbg_tea(c->stream, seed[0], seed[1], n, (float*)s.a.p, (uint32_t*)s.b.p);
     HIPCHK(c, hipGetLastError());
-    if (n) HIPCHK(c, hipMemcpyAsync(out, s.a.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(seed, s.b.p, 8, hipMemcpyDeviceToHost, c->stream));
+    if (n) TO_HOST(c, out, s.a.p, (size_t)n * 4);
+    TO_HOST(c, seed, s.b.p, 8);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RTX_OK;
 }

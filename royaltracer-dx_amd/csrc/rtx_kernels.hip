@@ -957,7 +957,8 @@ __global__ __launch_bounds__(kBlock) void k_dbg_trace(DevScene sc, const SmallRe
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const F4 ro = rays[2 * i], rd = rays[2 * i + 1];
         float t, u, v; uint32_t prim;
-        if (any == 2) traverse_stats(sc, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w, t, u, v, prim);
+        if (any == 2) traverse_stats<false>(sc, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w, t, u, v, prim);
+        else if (any == 3) traverse_stats<true>(sc, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w, t, u, v, prim);      // any-hit in the order sc.any_order, counted (u = node steps, v = triangle tests)
         else if (any) trace_ray<true>(sc, small, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w, t, u, v, prim);
         else trace_ray<false>(sc, small, L, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w, t, u, v, prim);
         hits[i] = {t, u, v, u2f(prim)};

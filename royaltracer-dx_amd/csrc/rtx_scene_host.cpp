@@ -1,6 +1,7 @@
 // rtx_scene_host.cpp — host-side scene assembly: material packing, world-space flattening, shade records,
 // emissive-triangle CDF and the binned-SAH BVH build.  No HIP calls in this file.
 #include "rtx_scene_host.hpp"
+#include "rtx_wide.hpp"
 #include <algorithm>
 #include <array>
 #include <chrono>
@@ -9,6 +10,7 @@
 #include <numeric>
 #include <system_error>
 #include <thread>
+#include <functional>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -215,7 +217,7 @@ void SceneHost::build_materials(BuiltScene& B) {
     mats_dirty = false;
 }
 
-bool SceneHost::build(BuiltScene& B) {
+bool SceneHost::build(BuiltScene& B, bool host_bvh) {
     // tooling: RTX_BUILD_TIMES=1 prints the phases of a commit to stderr (tools/bvh_lab, tools/build_time.py)
     const bool TT = getenv("RTX_BUILD_TIMES") != nullptr; auto T0 = std::chrono::steady_clock::now(); auto lap = [&](const char* w) { if (TT) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[build] %-28s %.3f s\n", w, std::chrono::duration<double>(t - T0).count()); T0 = t; } };
     build_materials(B);
@@ -230,7 +232,14 @@ bool SceneHost::build(BuiltScene& B) {
     for (size_t ii = 0; ii < insts.size(); ii++) {
         const InstHost& in = insts[ii]; const MeshHost& m = meshes[in.mesh];
         memcpy(B.insts[ii].o2w, in.o2w, 64); memcpy(B.insts[ii].nrm, in.nrm, 64); memcpy(B.insts[ii].o2w_inv, in.o2w_inv, 64); memcpy(B.insts[ii].prev_o2w, in.prev_o2w, 64);
-        for (uint32_t t = 0; t < m.idx.size() / 3; t++) {
+        // (round 5) the triangles of a large mesh on up to 16 threads — every triangle writes its own records, the coordinate scale is a maximum: 0.26 s of the 3.8 M-triangle
+        // street's commit on one core, and what is left of the host's work when the tree is built on the GPU
+        const uint32_t ntm = (uint32_t)(m.idx.size() / 3);
+        const unsigned hwc = std::thread::hardware_concurrency();
+        const uint32_t nth = ntm >= 65536u ? std::min<uint32_t>(16u, std::max(1u, hwc ? hwc : 4u)) : 1u;
+        std::vector<float> tscale(nth, 1.0f);
+        auto flatten_range = [&](uint32_t t_lo, uint32_t t_hi, float& scale) {
+        for (uint32_t t = t_lo; t < t_hi; t++) {
             uint32_t g = in.tri_base + t;
             uint32_t i0 = m.idx[t * 3], i1 = m.idx[t * 3 + 1], i2 = m.idx[t * 3 + 2];
             const uint32_t vi[3] = {i0, i1, i2};
@@ -258,10 +267,27 @@ bool SceneHost::build(BuiltScene& B) {
             }
             s.guard_tau = 0.0f;
         }
+        };
+        if (nth <= 1) flatten_range(0, ntm, tscale[0]);
+        else {
+            std::vector<std::thread> pool;
+            for (uint32_t k = 0; k < nth; k++) {
+                const uint32_t lo_t = (uint32_t)((uint64_t)ntm * k / nth), hi_t = (uint32_t)((uint64_t)ntm * (k + 1) / nth);
+                try { pool.emplace_back([&, lo_t, hi_t, k] { flatten_range(lo_t, hi_t, tscale[k]); }); } catch (const std::system_error&) { flatten_range(lo_t, hi_t, tscale[k]); }
+            }
+            for (std::thread& th : pool) th.join();
+        }
+        for (float v : tscale) scale = std::max(scale, v);
     }
     lap("flatten + shade records");
     build_lights(B);
     lap("lights");
+    if (!host_bvh) {                    // RTX_OPT_GPU_BUILD: the tree is the device's business (csrc/rtx_build.hip); nothing of it is mirrored on the host
+        B.bvh_pad = 2e-6f * scale; B.nodes.clear(); B.nodes8.clear(); B.tri_slots8.clear(); B.tris8.clear(); B.tris.clear(); B.leaf_order.clear(); B.level_start8.clear();
+        B.small_recs.clear(); B.small_tris.clear(); B.small_poly.clear(); B.small_nrec = 0; B.small_nocc = 0; B.built_tris = nt; B.refit_count = 0; B.any_order = 0;
+        topo_dirty = false;
+        return true;
+    }
     // ---- BVH: full binned-SAH build, or a REFIT when only instance transforms changed since the last build
     //      (the reference refits its TLAS every frame: Renderer.cpp:594, TopLevelASGenerator.cpp:149-250) ----
     std::vector<uint32_t>& leaf_order = B.leaf_order;
@@ -639,46 +665,25 @@ void reinsert_pass(std::vector<TmpNode>& tn, std::vector<int32_t>& parent, doubl
 //      their box centres (63 bits, ties by triangle id); every cluster looks `radius` places to either side for the neighbour whose union with it has the smallest
 //      surface area; mutual nearest neighbours merge; repeat until one cluster is left.  Everything is a pure function of the input order, so host and device agree. ----
 namespace {
-inline uint64_t spread21(uint32_t v) {            // 21 bits -> every third bit of 63
-    uint64_t x = v & 0x1fffffu;
-    x = (x | x << 32) & 0x1f00000000ffffull; x = (x | x << 16) & 0x1f0000ff0000ffull; x = (x | x << 8) & 0x100f00f00f00f00full;
-    x = (x | x << 4) & 0x10c30c30c30c30c3ull; x = (x | x << 2) & 0x1249249249249249ull;
-    return x;
-}
 struct PlocNode { Box box; int32_t left, right; uint32_t tri; };
 // clusters until at most `stop_at` are left; pool: [0, n) leaves in Morton order, internal nodes appended in creation order (iteration by iteration, left partners in cluster order)
 void ploc_clusters(const std::vector<Ref>& refs, const Box& scene, int radius, uint32_t stop_at, std::vector<PlocNode>& pn, std::vector<int32_t>& cl) {
     const uint32_t n = (uint32_t)refs.size();
-    // Morton keys of the box centres on a 2^21 grid over the scene's box (float arithmetic, the device's formula: rtx_build.hip k_gb_morton)
+    // Morton keys of the box centres on a 2^21 grid over the scene's box (float arithmetic, the device's formula: rtx_wide.hpp ploc_morton)
     std::vector<std::pair<uint64_t, uint32_t>> keyed(n);
     float lo[3], inv[3];
-    for (int a = 0; a < 3; a++) { lo[a] = scene.mn[a]; const float ext = scene.mx[a] - scene.mn[a]; inv[a] = ext > 0.0f ? 2097151.0f / ext : 0.0f; }
-    for (uint32_t i = 0; i < n; i++) {
-        uint64_t code = 0;
-        for (int a = 0; a < 3; a++) {
-            const float c = 0.5f * (refs[i].box.mn[a] + refs[i].box.mx[a]);
-            float q = (c - lo[a]) * inv[a]; q = q < 0.0f ? 0.0f : (q > 2097151.0f ? 2097151.0f : q);
-            code |= spread21((uint32_t)q) << a;
-        }
-        keyed[i] = {code, i};
-    }
+    ploc_grid(scene.mn, scene.mx, lo, inv);
+    auto wb = [](const Box& b) { WBox w; for (int a = 0; a < 3; a++) { w.mn[a] = b.mn[a]; w.mx[a] = b.mx[a]; } return w; };
+    for (uint32_t i = 0; i < n; i++) keyed[i] = {ploc_morton(wb(refs[i].box), lo, inv), i};
     std::sort(keyed.begin(), keyed.end());
     pn.clear(); pn.reserve((size_t)2 * n);
     for (uint32_t i = 0; i < n; i++) { const Ref& r = refs[keyed[i].second]; pn.push_back(PlocNode{r.box, -1, -1, r.tri}); }
     cl.resize(n); for (uint32_t i = 0; i < n; i++) cl[i] = (int32_t)i;
     std::vector<int32_t> nn, nxt;
-    auto uarea = [&](int32_t a, int32_t b) { Box u = pn[a].box; grow(u, pn[b].box); return half_area(u); };
     while (cl.size() > std::max<size_t>(1, stop_at)) {
         const int m = (int)cl.size();
         nn.assign(m, -1);
-        for (int i = 0; i < m; i++) {                         // nearest neighbour within the window: smallest union area
-            float best = INFINITY; int bj = -1;                // scanned outwards (i - 1, i + 1, i - 2, ...): of equally good partners the nearest place along the curve wins — on regular
-            for (int d = 1; d <= radius; d++) {                 // tessellations most candidates tie, and "lowest place wins" pairs almost nobody (few mutual pairs, stringy clusters)
-                if (i - d >= 0) { const float a = uarea(cl[i], cl[i - d]); if (a < best) { best = a; bj = i - d; } }
-                if (i + d < m) { const float a = uarea(cl[i], cl[i + d]); if (a < best) { best = a; bj = i + d; } }
-            }
-            nn[i] = bj;
-        }
+        for (int i = 0; i < m; i++) nn[i] = ploc_nearest(i, m, radius, [&](int j) { return wb(pn[cl[j]].box); });      // nearest neighbour within the window (rtx_wide.hpp)
         nxt.clear();
         for (int i = 0; i < m; i++) {
             const int j = nn[i];
@@ -706,39 +711,15 @@ void ploc_expand(const std::vector<PlocNode>& pn, int32_t src0, int32_t dst0, ui
 }
 }  // namespace
 
-void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGPU>& nodes, std::vector<uint32_t>& order, uint32_t& max_depth, const BvhBuildOptions& opt_in) {
-    BvhBuildOptions opt = opt_in;
-    const uint32_t nt = (uint32_t)(wtri.size() / 9);
-    const bool TT = getenv("RTX_BUILD_TIMES") != nullptr; auto T0 = std::chrono::steady_clock::now(); auto lap = [&](const char* w) { if (TT) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[build]   bvh2: %-20s %.3f s\n", w, std::chrono::duration<double>(t - T0).count()); T0 = t; } };
-    std::vector<Ref> refs(nt);
-    Box scene = empty_box();
-    for (uint32_t i = 0; i < nt; i++) {
-        const float* t = &wtri[(size_t)i * 9];
-        for (int a = 0; a < 3; a++) {
-            refs[i].box.mn[a] = std::min(t[a], std::min(t[3 + a], t[6 + a]));
-            refs[i].box.mx[a] = std::max(t[a], std::max(t[3 + a], t[6 + a]));
-        }
-        refs[i].tri = i;
-        grow(scene, refs[i].box);
-    }
+// the top-down builder (+ the re-insertion passes) over a set of references: fills the temporary tree `tn` (root = node 0; leaves hold [first, first + count) of `order`)
+static void build_tmp_tree(std::vector<Ref>& refs, const Box& scene, const BvhBuildOptions& opt, std::vector<TmpNode>& tn, std::vector<uint32_t>& order, uint32_t& max_depth,
+                           const std::function<void(const char*)>& lap, const float* wtri /* 9 floats per triangle: spatial splits clip against them (nullptr: no splits) */) {
+    const uint32_t nt = (uint32_t)refs.size();
     order.clear(); order.reserve(nt);
-    std::vector<TmpNode> tn; tn.reserve((size_t)2 * nt + 2);
+    tn.clear(); tn.reserve((size_t)2 * nt + 2);
     max_depth = 0;
-    // PLOC (the GPU build's bottom-up half, restated on the host): clusters of triangles become the REFERENCES of the top-down builder below — which then only builds the
-    // top of the tree, over <= ploc_top clusters, with single clusters as leaves —, the re-insertion passes run on that top, and the clusters' subtrees are hung in afterwards.
-    // The top of a tree is where every ray passes (5.7 of 12.4 node steps in the first three wide levels on the atrium): it gets the expensive builder, the bottom the parallel one.
-    const bool ploc = opt.ploc_radius > 0 && nt > kSmallSceneMaxTris;
-    std::vector<PlocNode> ploc_pool; std::vector<int32_t> ploc_cl;
-    if (ploc) {
-        ploc_clusters(refs, scene, opt.ploc_radius, std::max(1u, opt.ploc_top), ploc_pool, ploc_cl);
-        refs.resize(ploc_cl.size());
-        for (size_t i = 0; i < ploc_cl.size(); i++) { refs[i].box = ploc_pool[ploc_cl[i]].box; refs[i].tri = (uint32_t)i; }
-        opt.leaf_stop = 1; opt.split_alpha = 0.0;
-        lap("ploc clusters");
-    }
-    const uint32_t ntop = (uint32_t)refs.size();
     // spatial splits only for scenes that take the BVH path (the tiny-scene records are built from the leaf order as a permutation of the triangles)
-    const bool spatial = opt.split_alpha > 0.0 && nt > kSmallSceneMaxTris;
+    const bool spatial = opt.split_alpha > 0.0 && nt > kSmallSceneMaxTris && wtri != nullptr;
     const float spatial_min = (float)(opt.split_alpha * (double)half_area(scene));
     const size_t ref_budget = (size_t)((double)nt * (1.0 + opt.split_budget)) + 8;
     size_t refs_total = nt;                                                       // references handed out so far (leaves made + still on the stack)
@@ -752,7 +733,7 @@ void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGP
     // is THE SAME tree, node for node, as the serial build's, whatever the number of threads.
     struct Task { int32_t node; uint32_t depth; std::vector<Ref> refs; std::vector<TmpNode> tn; std::vector<uint32_t> order; uint32_t max_depth = 0; };
     std::vector<Task> tasks;
-    const uint32_t cutoff = (!spatial && !ploc && nt >= 65536u && opt.threads != 1) ? std::max<uint32_t>(4096u, nt / 256u) : 0u;
+    const uint32_t cutoff = (!spatial && nt >= 65536u && opt.threads != 1) ? std::max<uint32_t>(4096u, nt / 256u) : 0u;
     auto run = [&](std::vector<Ref>& refs, std::vector<TmpNode>& tn, std::vector<uint32_t>& order, std::vector<Job>& st, uint32_t& max_depth, size_t& refs_total, bool may_defer) {
     std::vector<uint32_t> sweep_ids; std::vector<float> sweep_ra; std::vector<Ref> tmp;
     while (!st.empty()) {
@@ -922,7 +903,7 @@ void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGP
     }
     };
     {
-        std::vector<Job> st; tn.emplace_back(); st.push_back({0, ntop, 0u});
+        std::vector<Job> st; tn.emplace_back(); st.push_back({0, nt, 0u});
         run(refs, tn, order, st, max_depth, refs_total, cutoff != 0u);
     }
     lap("top-down, serial part");
@@ -981,27 +962,98 @@ void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGP
         while (!dst.empty()) { const auto it = dst.back(); dst.pop_back(); max_depth = std::max(max_depth, it.second); if (!tn[it.first].count) { dst.push_back({tn[it.first].left, it.second + 1}); dst.push_back({tn[it.first].right, it.second + 1}); } }
     }
     lap("re-insertion");
-    if (ploc) {                                     // every leaf of the top tree holds cluster indices: hang the clusters' subtrees in (a leaf of several clusters becomes a chain)
-        std::vector<uint32_t> tri_order; tri_order.reserve(nt);
-        std::vector<std::pair<int32_t, uint32_t>> dfs; dfs.push_back({0, 0u});
-        std::vector<std::pair<int32_t, uint32_t>> leaves;
-        while (!dfs.empty()) { const auto it = dfs.back(); dfs.pop_back(); if (tn[it.first].count) leaves.push_back(it); else { dfs.push_back({tn[it.first].right, it.second + 1}); dfs.push_back({tn[it.first].left, it.second + 1}); } }
-        for (const auto& lf : leaves) {
-            int32_t at = lf.first; uint32_t depth = lf.second;
-            const uint32_t f = tn[at].first, k = tn[at].count;
-            for (uint32_t q = 0; q < k; q++) {
-                const int32_t src = ploc_cl[order[f + q]];
-                if (q + 1 == k) { ploc_expand(ploc_pool, src, at, depth, tn, tri_order, max_depth); break; }
+}
+
+// The TOP of a PLOC tree (host twin and GPU build alike): the top-down SAH builder and the re-insertion passes over the clusters PLOC stopped at, single clusters as leaves
+// (a leaf the builder refuses to split becomes a chain).  out: root first; left / right >= 0: index into out, < 0: ~cluster index; boxes unpadded.
+void build_cluster_top(const float* boxes6, uint32_t m, const BvhBuildOptions& opt_in, std::vector<ClusterTopNode>& out) {
+    BvhBuildOptions opt = opt_in; opt.leaf_stop = 1; opt.split_alpha = 0.0; opt.ploc_radius = 0;
+    std::vector<Ref> refs(m); Box scene = empty_box();
+    for (uint32_t i = 0; i < m; i++) { for (int a = 0; a < 3; a++) { refs[i].box.mn[a] = boxes6[(size_t)i * 6 + a]; refs[i].box.mx[a] = boxes6[(size_t)i * 6 + 3 + a]; } refs[i].tri = i; grow(scene, refs[i].box); }
+    const std::vector<Ref> cref = refs;                                         // (the builder consumes its reference stack)
+    std::vector<TmpNode> tn; std::vector<uint32_t> order; uint32_t depth = 0;
+    build_tmp_tree(refs, scene, opt, tn, order, depth, [](const char*) {}, nullptr);
+    out.clear();
+    if (m == 0) return;
+    struct It { int32_t src, dst; };
+    std::vector<It> st; out.emplace_back(); st.push_back({0, 0});
+    auto setbox = [](ClusterTopNode& N, const Box& b) { for (int a = 0; a < 3; a++) { N.mn[a] = b.mn[a]; N.mx[a] = b.mx[a]; } };
+    while (!st.empty()) {
+        const It it = st.back(); st.pop_back();
+        const TmpNode T = tn[it.src];
+        if (!T.count) {
+            setbox(out[it.dst], T.box);
+            int32_t child[2];
+            for (int w = 0; w < 2; w++) {
+                const int32_t c = w ? T.right : T.left;
+                if (tn[c].count == 1) child[w] = ~(int32_t)order[tn[c].first];
+                else { child[w] = (int32_t)out.size(); out.emplace_back(); st.push_back({c, child[w]}); }
+            }
+            out[it.dst].left = child[0]; out[it.dst].right = child[1];
+            continue;
+        }
+        // a leaf of k >= 2 clusters (or the root as a leaf): a chain  (c0, (c1, (c2, ...)))
+        const uint32_t f = T.first, k = T.count;
+        if (k == 1) { setbox(out[it.dst], T.box); out[it.dst].left = ~(int32_t)order[f]; out[it.dst].right = ~(int32_t)order[f]; continue; }      // (m == 1: the caller does not call)
+        int32_t at = it.dst;
+        for (uint32_t q = 0; q + 1 < k; q++) {
+            Box rest = empty_box(); for (uint32_t z = q; z < k; z++) grow(rest, cref[order[f + z]].box);
+            setbox(out[at], rest);
+            out[at].left = ~(int32_t)order[f + q];
+            if (q + 2 == k) out[at].right = ~(int32_t)order[f + q + 1];
+            else { const int32_t nx = (int32_t)out.size(); out.emplace_back(); out[at].right = nx; at = nx; }
+        }
+    }
+}
+
+void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGPU>& nodes, std::vector<uint32_t>& order, uint32_t& max_depth, const BvhBuildOptions& opt) {
+    const uint32_t nt = (uint32_t)(wtri.size() / 9);
+    const bool TT = getenv("RTX_BUILD_TIMES") != nullptr; auto T0 = std::chrono::steady_clock::now(); auto lap = [&](const char* w) { if (TT) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[build]   bvh2: %-20s %.3f s\n", w, std::chrono::duration<double>(t - T0).count()); T0 = t; } };
+    std::vector<Ref> refs(nt);
+    Box scene = empty_box();
+    for (uint32_t i = 0; i < nt; i++) {
+        const float* t = &wtri[(size_t)i * 9];
+        for (int a = 0; a < 3; a++) {
+            refs[i].box.mn[a] = std::min(t[a], std::min(t[3 + a], t[6 + a]));
+            refs[i].box.mx[a] = std::max(t[a], std::max(t[3 + a], t[6 + a]));
+        }
+        refs[i].tri = i;
+        grow(scene, refs[i].box);
+    }
+    order.clear(); order.reserve(nt);
+    std::vector<TmpNode> tn; tn.reserve((size_t)2 * nt + 2);
+    max_depth = 0;
+    // PLOC (the GPU build's bottom-up half, restated on the host): bottom-up clusters, then the top of the tree — over <= ploc_top clusters, with single clusters as leaves —
+    // by the top-down builder and the re-insertion passes (build_cluster_top), and the clusters' subtrees hung in below.  The top of a tree is where every ray passes
+    // (5.7 of 12.4 node steps in the first three wide levels on the atrium): it gets the expensive builder, the bottom the parallel one.
+    const bool ploc = opt.ploc_radius > 0 && nt > kSmallSceneMaxTris;
+    if (ploc) {
+        std::vector<PlocNode> pool; std::vector<int32_t> cl;
+        ploc_clusters(refs, scene, opt.ploc_radius, std::max(1u, opt.ploc_top), pool, cl);
+        lap("ploc clusters");
+        if (cl.size() == 1) { tn.emplace_back(); ploc_expand(pool, cl[0], 0, 0u, tn, order, max_depth); }
+        else {
+            std::vector<float> boxes(cl.size() * 6);
+            for (size_t i = 0; i < cl.size(); i++) for (int a = 0; a < 3; a++) { boxes[i * 6 + a] = pool[cl[i]].box.mn[a]; boxes[i * 6 + 3 + a] = pool[cl[i]].box.mx[a]; }
+            std::vector<ClusterTopNode> top; build_cluster_top(boxes.data(), (uint32_t)cl.size(), opt, top);
+            lap("ploc top");
+            struct It { int32_t src, dst; uint32_t depth; };
+            std::vector<It> st; tn.emplace_back(); st.push_back({0, 0, 0u});
+            while (!st.empty()) {
+                const It it = st.back(); st.pop_back();
+                const ClusterTopNode N = top[it.src];
+                for (int a = 0; a < 3; a++) { tn[it.dst].box.mn[a] = N.mn[a]; tn[it.dst].box.mx[a] = N.mx[a]; }
                 const int32_t l = (int32_t)tn.size(); tn.emplace_back(); const int32_t r = (int32_t)tn.size(); tn.emplace_back();
-                Box rest = empty_box(); for (uint32_t z = q + 1; z < k; z++) grow(rest, ploc_pool[ploc_cl[order[f + z]]].box);
-                tn[at].left = l; tn[at].right = r; tn[at].count = 0; tn[r].box = rest;
-                ploc_expand(ploc_pool, src, l, depth + 1, tn, tri_order, max_depth);
-                at = r; depth++;
+                tn[it.dst].left = l; tn[it.dst].right = r; tn[it.dst].count = 0;
+                // (right first on the stack so that the left subtree is expanded first: leaf order = depth-first left to right)
+                if (N.right >= 0) st.push_back({N.right, r, it.depth + 1}); 
+                if (N.left >= 0) st.push_back({N.left, l, it.depth + 1});
+                if (N.left < 0) ploc_expand(pool, cl[~N.left], l, it.depth + 1, tn, order, max_depth);
+                if (N.right < 0) ploc_expand(pool, cl[~N.right], r, it.depth + 1, tn, order, max_depth);
             }
         }
-        order.swap(tri_order);
         lap("ploc expand");
-    }
+    } else build_tmp_tree(refs, scene, opt, tn, order, max_depth, lap, wtri.data());
     // ---- leaf order: depth-first, left to right, so that every subtree owns ONE contiguous range of references (collapse_bvh8 merges small subtrees into a
     //      leaf slot by range; the build emits the right side first and the re-insertion moves subtrees) ----
     {
@@ -1085,57 +1137,34 @@ bool collapse_bvh8(const std::vector<NodeGPU>& n2, std::vector<Node8GPU>& n8, st
     // (profiles/r02_traversal.md), so per ray it costs more than the 0.45 the instruction counts say: measured k_trace_closest
     // 23.80 / 21.31 ms (C3 / C5) at 0.45, 23.39 / 20.93 at 0.7, 23.49 / 21.00 at 1.0, 23.53 / 20.95 at 1.5, 24.30 / 21.82 at 0.3
     const double kNodeCost = 1.0, kTriCost = opt.tri_cost;
-    struct Sub { double area; uint32_t prims, first; };
+    // (the program itself, the gathering of a wide node's children and the greedy slot assignment live in rtx_wide.hpp: the GPU build runs the same code)
+    struct Sub { uint32_t first; };
     std::vector<Sub> sub(nn);
-    std::vector<std::array<double, 8>> cost(nn);           // index 1..7
-    std::vector<std::array<uint8_t, 9>> choice(nn);        // [1]: 0 leaf slot / 1 internal slot; [i >= 2]: 0 = as i-1, k = left gets k slots; [8]: split of the node's own 8 slots
+    std::vector<WideDp> dp(nn);
     auto is_leaf = [](int32_t c) { return c < 0; };
     auto leaf_cnt = [](int32_t c) { return ((~(uint32_t)c) & 7u) + 1u; };
     auto leaf_first = [](int32_t c) { return (~(uint32_t)c) >> 3; };
-    auto child_cost = [&](const Ch& c, int i) -> double {   // cost of a child reference given i slots
-        if (is_leaf(c.c)) return (double)area(c) * kTriCost * leaf_cnt(c.c);
-        return cost[(size_t)c.c][std::min(i, 7)];
-    };
+    auto wb = [](const Ch& c) { WBox b; for (int a = 0; a < 3; a++) { b.mn[a] = c.mn[a]; b.mx[a] = c.mx[a]; } return b; };
     for (size_t n = nn; n-- > 0;) {
         const Ch L = get(n2[n], 0), R = get(n2[n], 1);
         if (L.c == kEmptyChild || R.c == kEmptyChild) {      // only the root may have an unused child (scenes with < 2 leaves)
             if (n != 0) return false;
-            sub[n] = Sub{0.0, 0u, 0u}; cost[n].fill(0.0); choice[n].fill(0); continue;
+            sub[n] = Sub{0u}; memset(&dp[n], 0, sizeof(WideDp)); continue;
         }
         if ((L.c >= 0 && (size_t)L.c <= n) || (R.c >= 0 && (size_t)R.c <= n) || (L.c >= 0 && (size_t)L.c >= nn) || (R.c >= 0 && (size_t)R.c >= nn)) return false;
-        Ch U = L; for (int a = 0; a < 3; a++) { U.mn[a] = std::min(L.mn[a], R.mn[a]); U.mx[a] = std::max(L.mx[a], R.mx[a]); }
-        const uint32_t pl = is_leaf(L.c) ? leaf_cnt(L.c) : sub[(size_t)L.c].prims, pr = is_leaf(R.c) ? leaf_cnt(R.c) : sub[(size_t)R.c].prims;
-        sub[n] = Sub{(double)area(U), pl + pr, is_leaf(L.c) ? leaf_first(L.c) : sub[(size_t)L.c].first};
-        auto distribute = [&](int j, uint8_t& kbest) {
-            double best = INFINITY; kbest = 1;
-            for (int k = 1; k < j; k++) { const double c = child_cost(L, k) + child_cost(R, j - k); if (c < best) { best = c; kbest = (uint8_t)k; } }
-            return best;
-        };
-        const double c_int = distribute(8, choice[n][8]) + sub[n].area * kNodeCost;
-        const double c_leaf = sub[n].prims <= 4 ? sub[n].area * kTriCost * sub[n].prims : INFINITY;
-        cost[n][1] = std::min(c_leaf, c_int); choice[n][1] = c_leaf <= c_int ? 0 : 1;
-        for (int i = 2; i <= 7; i++) {
-            uint8_t k; const double d = distribute(i, k);
-            if (d < cost[n][i - 1]) { cost[n][i] = d; choice[n][i] = k; } else { cost[n][i] = cost[n][i - 1]; choice[n][i] = 0; }
-        }
+        const WideDpChild dl{area(L), is_leaf(L.c) ? leaf_cnt(L.c) : 0u, is_leaf(L.c) ? nullptr : &dp[(size_t)L.c]}, dr{area(R), is_leaf(R.c) ? leaf_cnt(R.c) : 0u, is_leaf(R.c) ? nullptr : &dp[(size_t)R.c]};
+        wide_dp_combine(dl, dr, wbox_area(wbox_union(wb(L), wb(R))), kNodeCost, kTriCost, dp[n]);
+        sub[n] = Sub{is_leaf(L.c) ? leaf_first(L.c) : sub[(size_t)L.c].first};
     }
     // children of the wide node made from binary node x, following the recorded decisions
-    struct Gather {
-        const std::vector<NodeGPU>& n2; const std::vector<Sub>& sub; const std::vector<std::array<uint8_t, 9>>& choice;
-        Ch* out; int m = 0;
-        void add(const Ch& c, int budget, const decltype(get)& get_) {
-            if (c.c < 0) { out[m++] = c; return; }
-            int i = std::min(budget, 7);
-            while (i > 1 && choice[(size_t)c.c][i] == 0) i--;
-            if (i == 1) {
-                Ch r = c;
-                if (choice[(size_t)c.c][1] == 0) r.c = (int32_t)~((sub[(size_t)c.c].first << 3) | (sub[(size_t)c.c].prims - 1u));   // merged leaf slot
-                out[m++] = r; return;
-            }
-            const int k = choice[(size_t)c.c][i];
-            add(get_(n2[(size_t)c.c], 0), k, get_); add(get_(n2[(size_t)c.c], 1), i - k, get_);
-        }
+    struct Acc {
+        const std::vector<NodeGPU>& n2; const std::vector<Sub>& sub; const std::vector<WideDp>& dp; decltype(get)& get_;
+        bool is_leaf(const Ch& c) const { return c.c < 0; }
+        void children(const Ch& c, Ch& L, Ch& R) const { L = get_(n2[(size_t)c.c], 0); R = get_(n2[(size_t)c.c], 1); }
+        uint8_t choice(const Ch& c, int i) const { return dp[(size_t)c.c].choice[i]; }
+        Ch merged(const Ch& c) const { Ch r = c; r.c = (int32_t)~((sub[(size_t)c.c].first << 3) | (dp[(size_t)c.c].prims - 1u)); return r; }      // a leaf slot holding the subtree's <= 4 triangles (contiguous in leaf order)
     };
+    const Acc acc{n2, sub, dp, get};
     std::vector<int32_t> src; src.push_back(0);            // binary node behind each wide node, breadth-first
     for (size_t h = 0; h < src.size(); h++) {
         Ch ch[8]; int m = 0;
@@ -1143,42 +1172,27 @@ bool collapse_bvh8(const std::vector<NodeGPU>& n2, std::vector<Node8GPU>& n8, st
         {
             const Ch L = get(N, 0), R = get(N, 1);
             if (L.c == kEmptyChild || R.c == kEmptyChild) { if (L.c != kEmptyChild) ch[m++] = L; if (R.c != kEmptyChild) ch[m++] = R; }
-            else {
-                Gather G{n2, sub, choice, ch};
-                const int k = choice[(size_t)src[h]][8];
-                G.add(L, k, get); G.add(R, 8 - k, get);
-                m = G.m;
-            }
+            else { bool internal[8]; m = wide_children(acc, L, R, (int)dp[(size_t)src[h]].choice[8], ch, internal); }
             if (m > 8) return false;
         }
         Node8GPU W{};
         float bmn[3] = {0, 0, 0}, bmx[3] = {0, 0, 0};
-        for (int a = 0; a < 3; a++) {
-            float lo = INFINITY, hi = -INFINITY;
-            for (int k = 0; k < m; k++) { lo = std::min(lo, ch[k].mn[a]); hi = std::max(hi, ch[k].mx[a]); }
-            if (m == 0) { lo = 0.0f; hi = 0.0f; }
-            bmn[a] = lo; bmx[a] = hi;
-        }
         // ---- slots: child with the largest projection on an octant's diagonal gets that octant's slot (greedy assignment) ----
         int slot_of[8]; bool slot_used[8] = {false, false, false, false, false, false, false, false};
         {
-            double cost[8][8];
-            for (int k = 0; k < m; k++) for (int sl = 0; sl < 8; sl++) {
-                double c = 0.0;
-                for (int a = 0; a < 3; a++) {
-                    const double rel = 0.5 * ((double)ch[k].mn[a] + (double)ch[k].mx[a]) - 0.5 * ((double)bmn[a] + (double)bmx[a]);
-                    c += ((sl >> a) & 1) ? rel : -rel;
+            WBox cb[8]; for (int k = 0; k < m; k++) cb[k] = wb(ch[k]);
+            wide_assign_slots(cb, m, bmn, bmx, slot_of);           // (node bounds + the greedy assignment)
+            if (opt.slot_assign == 0) { for (int k = 0; k < m; k++) slot_used[slot_of[k]] = true; }
+            else {
+                double cost[8][8];
+                for (int k = 0; k < m; k++) for (int sl = 0; sl < 8; sl++) {
+                    double c = 0.0;
+                    for (int a = 0; a < 3; a++) {
+                        const double rel = 0.5 * ((double)ch[k].mn[a] + (double)ch[k].mx[a]) - 0.5 * ((double)bmn[a] + (double)bmx[a]);
+                        c += ((sl >> a) & 1) ? rel : -rel;
+                    }
+                    cost[k][sl] = c;
                 }
-                cost[k][sl] = c;
-            }
-            if (opt.slot_assign == 0) {
-            bool done[8] = {false, false, false, false, false, false, false, false};
-            for (int it = 0; it < m; it++) {
-                int bk = -1, bs = -1; double bc = 0.0;
-                for (int k = 0; k < m; k++) if (!done[k]) for (int sl = 0; sl < 8; sl++) if (!slot_used[sl]) if (bk < 0 || cost[k][sl] > bc) { bc = cost[k][sl]; bk = k; bs = sl; }
-                done[bk] = true; slot_used[bs] = true; slot_of[bk] = bs;
-            }
-            } else {
                 // the assignment that maximises the summed projections (Ylitie et al. solve it by auction; with eight slots a subset table is exact): best[k][S] = children
                 // k.. placed into the free slots of S
                 double best[9][256]; int8_t pick[9][256];

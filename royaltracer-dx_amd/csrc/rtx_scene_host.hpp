@@ -17,7 +17,8 @@ void  normal_matrix(const float* o2w16, float* out16);   // Renderer.cpp:2104-21
 struct BvhBuildOptions {
     int      bins = 16;           // binned SAH: bins per axis for nodes above `sweep_below`
     uint32_t sweep_below = 0;     // nodes with at most this many references use the full-sweep SAH (every centroid position) instead of bins
-    uint32_t leaf_stop = 2;       // nodes with at most this many references are not split further (the wide collapse merges small subtrees into leaf slots anyway)
+    uint32_t leaf_stop = 1;       // nodes with at most this many references are not split further (the wide collapse merges small subtrees into leaf slots anyway).  1 since round 5:
+                                  // chosen on the HARD stand-ins (profiles/r05_bvh_lab.md: closest-hit cost -2.1 % / -2.8 %, any-hit -1.1 % / -0.7 %; nothing on the uniform ones)
     double   split_alpha = 0.0;   // spatial splits where the object split's two sides overlap by more than this fraction of the scene's surface area (0 = never)
     double   split_budget = 0.3;  // ... and at most this many extra references, as a fraction of the triangle count
     int      reinsert_passes = 2; // passes of the insertion-based topology optimisation
@@ -80,7 +81,7 @@ struct SceneHost {
     bool add_mesh(const void* verts28, uint32_t nverts, const uint32_t* idx, uint32_t nidx, const uint32_t* matids, uint32_t* out);
     bool add_instance(uint32_t mesh, const float* o2w, uint32_t* out);
     bool set_instance_transform(uint32_t inst, const float* o2w);
-    bool build(BuiltScene& out);
+    bool build(BuiltScene& out, bool host_bvh = true);      // host_bvh = false (RTX_OPT_GPU_BUILD): everything but the tree — materials, shade records, object-space triangles, lights
     void build_materials(BuiltScene& out);      // mats128 -> MatGPU table (clears mats_dirty)
     // transform-only update of the records the GPU refit does not derive itself: instance matrices and the light list
     bool refresh_transforms(BuiltScene& out);
@@ -102,6 +103,9 @@ bool load_scene_cache(const char* path, SceneHost& H, BuiltScene& B, std::string
 void refit_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGPU>& nodes, const std::vector<uint32_t>& leaf_order);
 void build_bvh(const std::vector<float>& wtri, float pad_abs, std::vector<NodeGPU>& nodes,
                std::vector<uint32_t>& leaf_order, uint32_t& max_depth, const BvhBuildOptions& opt = bvh_build_options());
+// the top of a PLOC tree over m cluster boxes (mn.xyz, mx.xyz each): top-down SAH + re-insertion, root first; child >= 0: node index, < 0: ~cluster (host twin and GPU build share it)
+struct ClusterTopNode { float mn[3], mx[3]; int32_t left, right; };
+void build_cluster_top(const float* boxes6, uint32_t m, const BvhBuildOptions& opt, std::vector<ClusterTopNode>& out);
 // collapse the binary tree into the compressed 8-wide device form (largest-area internal child opened first, octant-ordered
 // slots, outward-rounded byte quantisation); tri_slots = leaf-order slots in the wide tree's triangle order; max_stack =
 // bound on the sibling-group entries a traversal can hold (one per level).  Returns false on a malformed input tree.

@@ -276,10 +276,10 @@ __device__ __forceinline__ void traverse(const DevScene& sc, const TraceLds& L, 
     }
 }
 
-// closest-hit traversal that also counts node steps and triangle tests (rtx_debug_trace_stats: tree-quality measurements)
+// traversal that also counts node steps and triangle tests (rtx_debug_trace_stats: tree-quality measurements; ANY: the any-hit order probe of a GPU-built tree, rtx_api.hip)
+template <bool ANY = false>
 __device__ __forceinline__ void traverse_stats(const DevScene& sc, const TraceLds& L, f3 o, f3 d, float tmin, float tmax,
                                          float& bt, float& bu, float& bv, uint32_t& bprim) {
-    constexpr bool ANY = false;
     uint32_t nsteps = 0, ntris = 0;
     // zero direction components -> huge finite reciprocal (keeps the slab test NaN-free and conservative)
     const float dxs = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
@@ -290,7 +290,7 @@ __device__ __forceinline__ void traverse_stats(const DevScene& sc, const TraceLd
     bt = tmax; bu = 0.0f; bv = 0.0f; bprim = kMissPrim;
     StackLds stk; stk.init(L);
     int sp = 0;
-    Grp G{0u, (ANY ? 1u : (1u << oct)) | (1u << 8)};    // the root as slot 0 of a virtual parent (any-hit rays visit unordered)
+    Grp G{0u, (ANY ? (sc.any_order ? 1u << (oct ^ (sc.any_order == 2u ? 7u : 0u)) : 1u) : (1u << oct)) | (1u << 8)};    // the root as slot 0 of a virtual parent (any-hit rays: DevScene::any_order)
     TriGrp T{0u, 0u, 0u};
     while (true) {
         if (G.bits & 0xffu) { descend8<!ANY>(sc, L, o, idir, oct, tmin, bt, G, T, stk, sp); nsteps++; }
@@ -303,7 +303,7 @@ __device__ __forceinline__ void traverse_stats(const DevScene& sc, const TraceLd
             else { const v4f* t = (const v4f*)(sc.tris + slot); v0 = t[0]; e1 = t[1]; e2 = t[2]; }
             float t, u, w;
             if (tri_test(o, d, v0, e1, e2, tmin, tmax, t, u, w)) {
-                if (ANY) { bprim = 0u; return; }
+                if (ANY) { bprim = 0u; bu = (float)nsteps; bv = (float)ntris; return; }
                 const uint32_t gid = f2u(v0.w);
                 if (t < bt || (t == bt && gid < bprim)) { bt = t; bu = u; bv = w; bprim = gid; }
             }

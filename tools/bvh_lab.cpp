@@ -252,6 +252,9 @@ int main(int argc, char** argv) {
     double nc, tc, fill; uint32_t hist[5];
     wide_sah(B, nc, tc, fill, hist);
     printf("any-hit order chosen by the commit-time probe: %u\n", B.any_order);
+    { uint64_t h = 1469598103934665603ull; auto mix = [&](const void* d, size_t nb) { const uint8_t* q = (const uint8_t*)d; for (size_t i = 0; i < nb; i++) { h ^= q[i]; h *= 1099511628211ull; } };
+      if (!B.nodes8.empty()) mix(B.nodes8.data(), B.nodes8.size() * sizeof(Node8GPU)); if (!B.tris8.empty()) mix(B.tris8.data(), B.tris8.size() * sizeof(TriGPU));
+      printf("tree hash (nodes8 + tris8, FNV-1a) %016llx\n", (unsigned long long)h); }
     printf("%s: tris %zu refs %zu nodes2 %zu nodes8 %zu stack %u build %.2fs | wide SAH node %.2f tri %.2f | slots/node %.2f leaf hist 1:%u 2:%u 3:%u 4:%u\n", which.c_str(), B.shade.size(), B.tris8.size(),
            B.nodes.size(), B.nodes8.size(), B.stack8, build_s, nc, tc, fill, hist[1], hist[2], hist[3], hist[4]);
     // camera

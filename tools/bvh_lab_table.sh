@@ -17,13 +17,15 @@ row() { # scene label args...
   echo "| $sc | $label | $(echo $h | sed -E 's/.*refs ([0-9]+).*/\1/') | $(echo $h | sed -E 's/.*nodes8 ([0-9]+).*/\1/') | $(echo $h | sed -E 's/.*stack ([0-9]+).*/\1/') | $(echo $h | sed -E 's/.*SAH node ([0-9.]+).*/\1/') | $(echo $a | sed -E 's/.*closest: steps\/ray ([0-9.]+) tris\/ray ([0-9.]+) cost ([0-9]+).*/\1 | \2 | \3/') | $(echo $a | sed -E 's/.*shadow: steps\/ray ([0-9.]+) tris\/ray ([0-9.]+) cost ([0-9]+).*/\1 | \2 | \3/') | $(echo $h | sed -E 's/.*build ([0-9.]+)s.*/\1/') |"
 }
 for sc in sponza sponza_hard bistro bistro_hard garage; do
-  row $sc "round-3 builder (16 bins, no re-insertion)" reinsert=0
-  row $sc "**default**: + 2 re-insertion passes over the <= 200 000 largest nodes" 
+  row $sc "round-3 builder (16 bins, leaf_stop 2, no re-insertion)" reinsert=0 leaf_stop=2
+  row $sc "**default**: 16 bins, split down to single references, 2 re-insertion passes over the <= 200 000 largest nodes" 
   row $sc "full-sweep SAH everywhere, no re-insertion" reinsert=0 sweep=100000000
   row $sc "spatial splits alpha 1e-5, no re-insertion" reinsert=0 split=1e-5
   row $sc "spatial splits + re-insertion" split=1e-5
   row $sc "exact slot assignment, no re-insertion" reinsert=0 slot_assign=1
-  row $sc "default + leaf_stop 1 (split down to single references)" leaf_stop=1
+  row $sc "default with leaf_stop 2 (the default until round 5)" leaf_stop=2
+  row $sc "the GPU build's host twin: PLOC radius 16 down to 8 192 clusters, SAH + re-insertion on top" ploc=16
+  row $sc "PLOC radius 16 to the root, no re-insertion" ploc=16 ploc_top=1 reinsert=0
   row $sc "default, any-hit NEAREST octant first" any_order=1
   row $sc "default, any-hit FARTHEST octant first" any_order=2
 done
