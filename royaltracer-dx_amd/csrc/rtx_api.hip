@@ -44,16 +44,23 @@ struct TimedLaunch { int cls; hipEvent_t a, b; };
 // rtx_commit_scene: a write through a stale pointer by code OUTSIDE this library (with the library's own allocations of that size on fenced pages, nothing of ours touched freed
 // memory and nothing of ours was hit).  Not releasing events, device or pinned memory left the rate unchanged; not destroying the two streams of a context made it vanish
 // (0 findings in 5 500 x 2 contexts against 25 in 17 700 x 2).  A pooled stream also saves the ~50 us its creation costs.
+// A context borrows a SET of five streams (its own, the shadow-overlap stream, ReSTIR lanes 1 .. 3) that were created back to back: the runtime spreads streams over its
+// (four) hardware queues in creation order, so the streams of one set run concurrently — two streams picked from a pool one by one may share a queue and serialise
+// (measured: the two-lane ReSTIR frame of the atrium 8.08 -> 9.82 ms with single pooled streams, kernel times unchanged).
+struct StreamSet { int device = -1; hipStream_t s[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; };
 struct StreamPool {
-    std::mutex mu; std::vector<std::pair<int, hipStream_t>> idle;
-    hipError_t acquire(int device, hipStream_t* out) {
-        { std::lock_guard<std::mutex> g(mu); for (size_t i = 0; i < idle.size(); i++) if (idle[i].first == device) { *out = idle[i].second; idle.erase(idle.begin() + (long)i); return hipSuccess; } }
-        return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    std::mutex mu; std::vector<StreamSet> idle;
+    hipError_t acquire(int device, StreamSet& out) {        // the caller has the device bound
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t i = 0; i < idle.size(); i++) if (idle[i].device == device) { out = idle[i]; idle.erase(idle.begin() + (long)i); return hipSuccess; }
+        out = StreamSet(); out.device = device;
+        for (hipStream_t& st : out.s) { const hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking); if (e != hipSuccess) return e; }
+        return hipSuccess;
     }
-    void release(int device, hipStream_t st) {             // the caller has the device bound
-        if (!st) return;
-        (void)hipStreamSynchronize(st);
-        std::lock_guard<std::mutex> g(mu); idle.emplace_back(device, st);
+    void release(StreamSet& set) {
+        if (set.device < 0) return;
+        for (hipStream_t st : set.s) if (st) (void)hipStreamSynchronize(st);
+        std::lock_guard<std::mutex> g(mu); idle.push_back(set); set = StreamSet();
     }
 };
 static StreamPool& stream_pool() { static StreamPool* p = new StreamPool(); return *p; }      // (never destructed: no order of static destructors to get wrong at exit)
@@ -68,6 +75,9 @@ struct rtx_ctx {
     bool committed_once = false;
     // the wide tree as the DEVICE holds it (the host mirror B.nodes8 / B.tris8 is empty after a GPU build): counts, the root record (octant-sort grid), who built it
     uint32_t n_nodes8 = 0, n_tris8 = 0; Node8GPU root8{}; bool dev_built = false; int gpu_build = 0; GpuBvhBuilder* builder = nullptr; GpuBuildResult build_info;
+    // RTX_OPT_GPU_BUILD: the meshes as they were handed over, resident on the device (append-only like the host's list: a commit uploads only what was added since the last one),
+    // and the per-instance ranges k_flatten reads (csrc/rtx_build.hip)
+    DevBuf d_pool_verts, d_pool_idx, d_pool_matids, d_flat_insts; size_t pool_verts = 0, pool_idx = 0, pool_matids = 0, pool_meshes = 0; std::vector<uint32_t> pool_vert_base, pool_idx_base; std::vector<FlatInst> h_flat;
     Staging staging;                                            // the two pinned chunks every copy from / to caller memory passes through (rtx_staging.hpp)
     std::vector<float> h_cdf; std::vector<uint32_t> h_one;     // host sources of small asynchronous uploads
     DevBuf d_inst_moved, d_tri_dirty, d_node_dirty; bool node_aabb_valid = false; int partial_refit = 1;     // partial GPU refit (RTX_OPT_PARTIAL_REFIT): node_aabb / d_scale hold the last full refit's state
@@ -119,6 +129,7 @@ struct rtx_ctx {
     uint32_t restir_chunks = 4;     // RTX_OPT_RESTIR_CHUNKS: 256-item chunks per sub-queue (= workgroup) of the ReSTIR stages
     struct RsArea { DevBuf state, hit, cls, fin, cold, occ, cand, sho, shd, pay, cnt; } rs_area[4];      // one per pipeline lane (RTX_OPT_RESTIR_LANES)
     hipStream_t lane_stream[3] = {nullptr, nullptr, nullptr};      // lanes 1 .. 3 (lane 0 runs on the context's stream)
+    StreamSet streams;              // borrowed from the process-wide pool: [0] the context's own stream, [1] aux, [2 .. 4] the lanes
     uint32_t restir_lane_min = 1u << 16;   // RTX_OPT_RESTIR_LANE_MIN: pixel lists shorter than this run as one chain
     uint32_t restir_lanes = 2;      // RTX_OPT_RESTIR_LANES: the work list of a ReSTIR frame as 1 .. 4 independent parts on as many streams (the tails of one part's many short launches fill with the others' work)
     // options
@@ -169,10 +180,10 @@ int rtx_create(int device_ordinal, rtx_ctx** out) {
     c->device = device_ordinal;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess) c->num_cus = prop.multiProcessorCount;
-    if ((e = stream_pool().acquire(device_ordinal, &c->stream)) != hipSuccess) {
+    if ((e = stream_pool().acquire(device_ordinal, c->streams)) != hipSuccess) {
         g_create_err = hipGetErrorString(e); delete c; return RTX_ERR_HIP;
     }
-    c->own_stream = true;
+    c->stream = c->streams.s[0]; c->own_stream = true;
     (void)hipEventCreate(&c->ev_begin); (void)hipEventCreate(&c->ev_end);
     *out = c;
     return RTX_OK;
@@ -188,9 +199,8 @@ void rtx_destroy(rtx_ctx* c) {
     DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_small_poly, &c->d_objtris, &c->d_node_aabb, &c->d_scale, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cdf, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
                      &c->d_thr, &c->d_rad, &c->d_hit, &c->d_hitmask, &c->d_order, &c->d_pmask, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
                      &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq, &c->d_halo, &c->d_own, &c->d_heads, &c->d_alt_o, &c->d_alt_d, &c->d_alt_thr, &c->d_oct[0], &c->d_oct[1], &c->d_perm, &c->d_trace_cnt,
-                     &c->d_nodes_wide, &c->d_rs_key_a, &c->d_rs_key_b, &c->d_inst_moved, &c->d_tri_dirty, &c->d_node_dirty};
+                     &c->d_nodes_wide, &c->d_rs_key_a, &c->d_rs_key_b, &c->d_inst_moved, &c->d_tri_dirty, &c->d_node_dirty, &c->d_pool_verts, &c->d_pool_idx, &c->d_pool_matids, &c->d_flat_insts};
     for (auto& A : c->rs_area) for (DevBuf* b : {&A.state, &A.hit, &A.cls, &A.fin, &A.cold, &A.occ, &A.cand, &A.sho, &A.shd, &A.pay, &A.cnt}) b->release();
-    for (hipStream_t& ls : c->lane_stream) if (ls) { stream_pool().release(c->device, ls); ls = nullptr; }
     for (DevBuf* b : all) b->release();
     delete c->builder; c->builder = nullptr;
     c->staging.release();
@@ -198,8 +208,7 @@ void rtx_destroy(rtx_ctx* c) {
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
-    if (c->own_stream && c->stream) stream_pool().release(c->device, c->stream);
-    if (c->aux) stream_pool().release(c->device, c->aux);
+    stream_pool().release(c->streams);
     delete c;
 }
 
@@ -258,9 +267,9 @@ int rtx_set_stream(rtx_ctx* c, void* s) {
     BIND(c);
     if (c->own_stream && c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
     else HIPCHK(c, hipDeviceSynchronize());                // the old caller-owned stream may no longer exist: drain the device instead of touching it
-    if (c->own_stream && c->stream) { stream_pool().release(c->device, c->stream); c->stream = nullptr; c->own_stream = false; }
+    if (c->own_stream) { c->stream = nullptr; c->own_stream = false; }
     if (s) { c->stream = (hipStream_t)s; c->own_stream = false; }
-    else { HIPCHK(c, stream_pool().acquire(c->device, &c->stream)); c->own_stream = true; }
+    else { c->stream = c->streams.s[0]; c->own_stream = true; }
     return RTX_OK;
 }
 
@@ -313,20 +322,64 @@ static int finalise_scene(rtx_ctx* c);
 
 struct Scratch { DevBuf a, b, c; ~Scratch() { a.release(); b.release(); c.release(); } };
 
+// a device array that only grows at its end: capacity in steps of 1.5 x, the `used` bytes survive a reallocation
+static int grow_keep(rtx_ctx* c, DevBuf& b, size_t used, size_t need) {
+    if (need <= b.bytes && b.p) return RTX_OK;
+    DevBuf nb; HIPCHK(c, nb.ensure(std::max(need, b.bytes + b.bytes / 2)));
+    if (used && b.p) HIPCHK(c, hipMemcpyAsync(nb.p, b.p, used, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    b.release(); b = nb;
+    return RTX_OK;
+}
+// the meshes added since the last commit -> the device pool; the per-instance ranges; then the flatten itself
+static int flatten_on_device(rtx_ctx* c, uint32_t ntri) {
+    const SceneHost& H = c->host;
+    if (H.meshes.size() < c->pool_meshes) { c->pool_meshes = 0; c->pool_verts = c->pool_idx = c->pool_matids = 0; c->pool_vert_base.clear(); c->pool_idx_base.clear(); }     // (another scene: start over)
+    size_t nv = c->pool_verts, ni = c->pool_idx;
+    for (size_t m = c->pool_meshes; m < H.meshes.size(); m++) { nv += H.meshes[m].verts.size() / 7; ni += H.meshes[m].idx.size(); }
+    if (nv > 0xFFFFFFFFull || ni > 0xFFFFFFFFull) { c->err = "commit: more than 2^32 vertices or indices"; return RTX_ERR_INVALID; }
+    int r;
+    if ((r = grow_keep(c, c->d_pool_verts, c->pool_verts * 28, nv * 28))) return r;
+    if ((r = grow_keep(c, c->d_pool_idx, c->pool_idx * 4, ni * 4))) return r;
+    if ((r = grow_keep(c, c->d_pool_matids, c->pool_matids * 4, H.matids.size() * 4))) return r;
+    for (size_t m = c->pool_meshes; m < H.meshes.size(); m++) {
+        const MeshHost& M = H.meshes[m];
+        c->pool_vert_base.push_back((uint32_t)c->pool_verts); c->pool_idx_base.push_back((uint32_t)c->pool_idx);
+        TO_DEVICE(c, (char*)c->d_pool_verts.p + c->pool_verts * 28, M.verts.data(), M.verts.size() * 4);
+        TO_DEVICE(c, (char*)c->d_pool_idx.p + c->pool_idx * 4, M.idx.data(), M.idx.size() * 4);
+        c->pool_verts += M.verts.size() / 7; c->pool_idx += M.idx.size();
+    }
+    c->pool_meshes = H.meshes.size();
+    if (H.matids.size() > c->pool_matids) { TO_DEVICE(c, (char*)c->d_pool_matids.p + c->pool_matids * 4, H.matids.data() + c->pool_matids, (H.matids.size() - c->pool_matids) * 4); c->pool_matids = H.matids.size(); }
+    c->h_flat.resize(H.insts.size());
+    for (size_t ii = 0; ii < H.insts.size(); ii++) {
+        const InstHost& in = H.insts[ii]; const MeshHost& M = H.meshes[in.mesh];
+        c->h_flat[ii] = FlatInst{in.tri_base, (uint32_t)(M.idx.size() / 3), c->pool_vert_base[in.mesh], c->pool_idx_base[in.mesh], M.matid_base, {0u, 0u, 0u}};
+    }
+    if ((r = upload(c, c->d_flat_insts, c->h_flat))) return r;
+    HIPCHK(c, c->d_objtris.ensure((size_t)ntri * 3 * sizeof(F4))); HIPCHK(c, c->d_shade.ensure((size_t)ntri * sizeof(TriShade)));
+    launch_flatten(c->stream, (const float*)c->d_pool_verts.p, (const uint32_t*)c->d_pool_idx.p, (const uint32_t*)c->d_pool_matids.p, (uint32_t)H.matids.size(), (const FlatInst*)c->d_flat_insts.p,
+                   (uint32_t)c->h_flat.size(), ntri, (F4*)c->d_objtris.p, (TriShade*)c->d_shade.p);
+    HIPCHK(c, hipGetLastError());
+    return RTX_OK;
+}
+
 // probe_anyhit_order (csrc/rtx_scene_host.cpp) for a tree the host holds no mirror of (RTX_OPT_GPU_BUILD): the same 2 048 NEE-like segments — a point on a random triangle to a
 // CDF-sampled point on a light —, traced ON THE DEVICE in the three visiting orders by the counting form of the any-hit traversal, judged by the same cost model
 static int probe_anyhit_order_on_device(rtx_ctx* c, uint32_t& best_out) {
     const BuiltScene& B = c->built;
     best_out = 0u;
-    const uint32_t nt = (uint32_t)B.shade.size();
-    if (B.lights.empty() || !nt || B.objtris.size() != (size_t)nt * 3) return RTX_OK;
+    const uint32_t nt = B.built_tris;
+    if (B.lights.empty() || !nt || c->h_flat.empty()) return RTX_OK;
     auto h32 = [](uint32_t a, uint32_t b) { uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u; h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15; return h; };
     auto r01 = [&](uint32_t a, uint32_t b) { return (float)(h32(a, b) >> 8) * (1.0f / 16777216.0f); };
     std::vector<float> rays; rays.reserve(2048 * 8);
     for (uint32_t i = 0; i < 2048u; i++) {
         const uint32_t g = h32(i, 1u) % nt;
-        const float* M = B.insts[B.shade[g].inst].o2w;
-        f3 w[3]; for (int k = 0; k < 3; k++) { const F4& o = B.objtris[(size_t)g * 3 + k]; w[k] = xform_point(M, mk3(o.x, o.y, o.z)); }
+        size_t ii = (size_t)(std::upper_bound(c->h_flat.begin(), c->h_flat.end(), g, [](uint32_t v, const FlatInst& F) { return v < F.tri_base; }) - c->h_flat.begin()) - 1;      // the last instance starting at or before g
+        const float* M = B.insts[ii].o2w; const MeshHost& mesh = c->host.meshes[c->host.insts[ii].mesh];
+        const uint32_t t = g - c->h_flat[ii].tri_base;
+        f3 w[3]; for (int k = 0; k < 3; k++) { const float* o = &mesh.verts[(size_t)mesh.idx[(size_t)t * 3 + k] * 7]; w[k] = xform_point(M, mk3(o[0], o[1], o[2])); }
         const f3 e1 = w[1] - w[0], e2 = w[2] - w[0];
         float u = r01(i, 2u), v = r01(i, 3u); if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
         const f3 p = mk3(w[0].x + u * e1.x + v * e2.x, w[0].y + u * e1.y + v * e2.y, w[0].z + u * e1.z + v * e2.z);
@@ -405,15 +458,14 @@ int rtx_commit_scene(rtx_ctx* c) {
         // RTX_OPT_GPU_BUILD: the tree on the device (csrc/rtx_build.hip).  Not for tiny scenes (their pre-test records are built from the host tree's leaf order) nor with
         // spatial splits (a host-builder feature); there the host builds as before.
         const bool on_gpu = c->gpu_build && ntri_all > 4096u && c->host.bvh.split_alpha <= 0.0;
-        if (!c->host.build(B, !on_gpu)) { c->err = c->host.err; return RTX_ERR_INVALID; }
+        if (!(on_gpu ? c->host.prepare_device_build(B) : c->host.build(B))) { c->err = c->host.err; return RTX_ERR_INVALID; }
         if (!on_gpu) { if ((r = upload_built(c))) return r; }
         else {
-            const uint32_t nt = (uint32_t)B.shade.size();
-            if ((r = upload(c, c->d_shade, B.shade))) return r;
+            const uint32_t nt = B.built_tris;
             if ((r = upload(c, c->d_mats, B.mats))) return r;
             if ((r = upload(c, c->d_insts, B.insts))) return r;
             if ((r = upload_lights(c))) return r;
-            if ((r = upload(c, c->d_objtris, B.objtris))) return r; c->objtris_uploaded = true;
+            if ((r = flatten_on_device(c, nt))) return r; c->objtris_uploaded = true;          // object-space triangles + shade records, from the resident meshes
             for (DevBuf* b : {&c->d_small, &c->d_small_tris, &c->d_small_poly}) HIPCHK(c, b->ensure(16));
             HIPCHK(c, c->d_tris.ensure((size_t)nt * sizeof(TriGPU)));
             if (!c->builder) c->builder = new GpuBvhBuilder();
@@ -423,7 +475,7 @@ int rtx_commit_scene(rtx_ctx* c) {
             const GpuBuildResult& G = c->build_info;
             HIPCHK(c, c->d_nodes.ensure((size_t)G.nnodes8 * sizeof(Node8GPU)));
             HIPCHK(c, hipMemcpyAsync(c->d_nodes.p, c->builder->nodes(), (size_t)G.nnodes8 * sizeof(Node8GPU), hipMemcpyDeviceToDevice, c->stream));
-            c->n_nodes8 = G.nnodes8; c->n_tris8 = G.ntris8; c->dev_built = true;
+            c->n_nodes8 = G.nnodes8; c->n_tris8 = G.ntris8; c->dev_built = true; B.bvh_pad = 2e-6f * G.scale;
             B.level_start8 = G.level_start8; B.stack8 = G.stack8;
             // the boxes: a FULL refit — world triangles from the object-space ones, every node quantised bottom-up (what a transform-only commit runs)
             HIPCHK(c, c->d_node_aabb.ensure((size_t)c->n_nodes8 * 32));
@@ -567,7 +619,7 @@ static int finalise_scene(rtx_ctx* c) {
         if (getenv("RTX_DEBUG_LDS")) fprintf(stderr, "[rtx] stack_depth %u workgroups per CU %u, %u nodes staged, %zu B of LDS\n", s.stack_depth, target, s.lds_nodes, trace_lds_bytes(s));
     }
     pick_lds_closest(c);
-    c->stats.bvh_refits = B.refit_count; c->stats.bvh_nodes = s.nnodes; c->stats.triangles = (uint32_t)B.shade.size(); c->stats.bvh_refs = s.ntris; c->stats.lights = s.nlights; c->stats.materials = s.nmat;
+    c->stats.bvh_refits = B.refit_count; c->stats.bvh_nodes = s.nnodes; c->stats.triangles = B.shade.empty() ? B.built_tris : (uint32_t)B.shade.size(); c->stats.bvh_refs = s.ntris; c->stats.lights = s.nlights; c->stats.materials = s.nmat;
     c->committed = true;
     return RTX_OK;
 }
@@ -830,7 +882,7 @@ int rtx_render(rtx_ctx* c, const rtx_params* p) {
         // persistent kernels fill each other's tails and memory stalls: C3 40.8 -> 40.3 ms, C5 38.3 -> 36.9 ms per frame, images unchanged.  Not while
         // kernels are timed (RTX_OPT_KERNEL_TIMING): overlapping launches have no per-kernel time.
         const bool ovl = c->overlap_shadow && !c->timing && !fused && !fused_bvh;
-        if (ovl && !c->aux) HIPCHK(c, stream_pool().acquire(c->device, &c->aux));
+        if (ovl && !c->aux) c->aux = c->streams.s[1];
         hipEvent_t ev_shadow_done = nullptr;
         auto Hd = [&](uint32_t b, uint32_t k) { return stealing ? (uint32_t*)c->d_heads.p + ((size_t)b * (1 + nee1) + k) * hstride : nullptr; };
         // sub-queues per workgroup of a traversal launch predicted to hold `rays` rays: double while a workgroup would start with fewer than merge_rays and at least one full
@@ -1017,7 +1069,7 @@ static int rs_lanes(rtx_ctx* c, const uint32_t* pixels, uint32_t npixels, F&& pa
         if (lo == hi) continue;
         hipStream_t st = c->stream;
         if (l) {
-            if (!c->lane_stream[l - 1]) HIPCHK(c, stream_pool().acquire(c->device, &c->lane_stream[l - 1]));
+            if (!c->lane_stream[l - 1]) c->lane_stream[l - 1] = c->streams.s[1 + l];
             st = c->lane_stream[l - 1];
             HIPCHK(c, hipStreamWaitEvent(st, e0, 0));
         }

@@ -253,7 +253,7 @@ std::string GpuBvhBuilder::build(hipStream_t st, const F4* d_objtris, const TriS
     GBCHK(hipGetLastError());
     uint32_t hb[8];
     GBCHK(B.staging.to_host(st, hb, B.bounds.p, 32)); GBCHK(hipStreamSynchronize(st));
-    float scale; memcpy(&scale, &hb[6], 4);
+    float scale; memcpy(&scale, &hb[6], 4); R.scale = scale;
     const float pad = 2e-6f * scale;                                    // the host build's bvh_pad (rtx_scene_host.cpp)
     R.ms_prims = ms_since(t0); t0 = clk::now();
     {
@@ -356,6 +356,44 @@ std::string GpuBvhBuilder::build(hipStream_t st, const F4* d_objtris, const TriS
     R.stack8 = B.h_counts[0];
     R.ms_layout = ms_since(t0);
     return "";
+}
+
+// ---- flatten (rtx_build.hpp) ----
+__global__ void __launch_bounds__(256) k_flatten(const float* __restrict__ verts7, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ matids, uint32_t nmatids,
+                                                 const FlatInst* __restrict__ insts, uint32_t ninst, uint32_t ntri, F4* __restrict__ objtris, TriShade* __restrict__ shade) {
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= ntri) return;
+    uint32_t lo = 0, hi = ninst - 1u;                       // the LAST instance whose first triangle is <= g (instances without triangles share a base with their successor)
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1u) >> 1; if (insts[mid].tri_base <= g) lo = mid; else hi = mid - 1u; }
+    const FlatInst F = insts[lo];
+    const uint32_t t = g - F.tri_base;
+    const uint32_t vi[3] = {idx[(size_t)F.idx_base + 3u * t], idx[(size_t)F.idx_base + 3u * t + 1u], idx[(size_t)F.idx_base + 3u * t + 2u]};
+    f3 p[3], n[3];
+    for (int k = 0; k < 3; k++) {
+        const float* v = verts7 + ((size_t)F.vert_base + vi[k]) * 7u;
+        p[k] = mk3(v[0], v[1], v[2]); n[k] = mk3(v[3], v[4], v[5]);
+        objtris[(size_t)g * 3u + k] = F4{p[k].x, p[k].y, p[k].z, 0.0f};
+    }
+    TriShade s;
+    const uint32_t mi = F.matid_base + 3u * t;              // == 3*PrimitiveIndex() + uint(v0.normal.w), Hit_v6.hlsl:16-17
+    s.mat = mi < nmatids ? matids[mi] : kMissMat;
+    s.inst = lo;
+    const f3 cr = cross(p[1] - p[0], p[2] - p[0]);          // :28-30
+    s.area = fabsf(length(cr) * 0.5f);                      // :31
+    const f3 flat = normalize(cr);                          // :32
+    s.flat[0] = flat.x; s.flat[1] = flat.y; s.flat[2] = flat.z;
+    float* dst[3] = {s.n0, s.n1, s.n2};
+    for (int k = 0; k < 3; k++) {                           // :40-46 (all(n != 0) is per component)
+        const f3 use = (n[k].x != 0.0f && n[k].y != 0.0f && n[k].z != 0.0f) ? n[k] : flat;
+        dst[k][0] = use.x; dst[k][1] = use.y; dst[k][2] = use.z;
+    }
+    s.guard_tau = 0.0f;
+    shade[g] = s;
+}
+void launch_flatten(hipStream_t st, const float* verts7, const uint32_t* idx, const uint32_t* matids, uint32_t nmatids, const FlatInst* insts, uint32_t ninst, uint32_t ntri,
+                    F4* objtris_out, TriShade* shade_out) {
+    if (!ntri || !ninst) return;
+    hipLaunchKernelGGL(k_flatten, dim3((ntri + 255u) / 256u), dim3(256), 0, st, verts7, idx, matids, nmatids, insts, ninst, ntri, objtris_out, shade_out);
 }
 
 }  // namespace rtx

@@ -14,6 +14,7 @@ struct GpuBuildResult {
     uint32_t nnodes8 = 0, ntris8 = 0, stack8 = 0;
     std::vector<uint32_t> level_start8;            // breadth-first levels of the wide tree (the refit sweeps them bottom-up)
     uint32_t ploc_iterations = 0, clusters_top = 0;
+    float scale = 1.0f;                            // max(1, largest |world coordinate|): the host build's `scale` (box padding 2e-6 x scale)
     double ms_prims = 0, ms_sort = 0, ms_ploc = 0, ms_top_host = 0, ms_layout = 0;      // wall time of the phases (host clock around stream synchronises)
 };
 
@@ -32,5 +33,11 @@ public:
 private:
     struct Impl; Impl* m;
 };
+
+// ---- the flatten of a geometry-changing commit ON THE DEVICE (RTX_OPT_GPU_BUILD): object-space triangles and shade records (Hit_v6.hlsl:12-61) of every instanced triangle from
+//      the meshes as they were handed over.  The host twin is SceneHost::build's flatten loop (csrc/rtx_scene_host.cpp) — same functions of rtx_math.hpp, same order. ----
+struct FlatInst { uint32_t tri_base, ntri, vert_base, idx_base, matid_base, pad_[3]; };       // one per instance, in instance order (tri_base ascending)
+void launch_flatten(hipStream_t st, const float* verts7, const uint32_t* idx, const uint32_t* matids, uint32_t nmatids, const FlatInst* insts, uint32_t ninst, uint32_t ntri,
+                    F4* objtris_out, TriShade* shade_out);
 
 }  // namespace rtx

@@ -217,6 +217,23 @@ void SceneHost::build_materials(BuiltScene& B) {
     mats_dirty = false;
 }
 
+bool SceneHost::prepare_device_build(BuiltScene& B) {
+    const bool TT = getenv("RTX_BUILD_TIMES") != nullptr; auto T0 = std::chrono::steady_clock::now(); auto lap = [&](const char* w) { if (TT) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[build] %-28s %.3f s\n", w, std::chrono::duration<double>(t - T0).count()); T0 = t; } };
+    build_materials(B);
+    uint32_t nt = 0;
+    for (auto& in : insts) { in.tri_base = nt; nt += (uint32_t)(meshes[in.mesh].idx.size() / 3); }
+    B.insts.resize(insts.size());
+    for (size_t ii = 0; ii < insts.size(); ii++) { const InstHost& in = insts[ii]; memcpy(B.insts[ii].o2w, in.o2w, 64); memcpy(B.insts[ii].nrm, in.nrm, 64); memcpy(B.insts[ii].o2w_inv, in.o2w_inv, 64); memcpy(B.insts[ii].prev_o2w, in.prev_o2w, 64); }
+    lap("materials + instances");
+    build_lights(B);
+    lap("lights");
+    B.shade.clear(); B.shade.shrink_to_fit(); B.objtris.clear(); B.objtris.shrink_to_fit();
+    B.bvh_pad = 2e-6f; B.nodes.clear(); B.nodes8.clear(); B.tri_slots8.clear(); B.tris8.clear(); B.tris.clear(); B.leaf_order.clear(); B.level_start8.clear();
+    B.small_recs.clear(); B.small_tris.clear(); B.small_poly.clear(); B.small_nrec = 0; B.small_nocc = 0; B.built_tris = nt; B.refit_count = 0; B.any_order = 0;
+    topo_dirty = false;
+    return true;
+}
+
 bool SceneHost::build(BuiltScene& B, bool host_bvh) {
     // tooling: RTX_BUILD_TIMES=1 prints the phases of a commit to stderr (tools/bvh_lab, tools/build_time.py)
     const bool TT = getenv("RTX_BUILD_TIMES") != nullptr; auto T0 = std::chrono::steady_clock::now(); auto lap = [&](const char* w) { if (TT) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[build] %-28s %.3f s\n", w, std::chrono::duration<double>(t - T0).count()); T0 = t; } };

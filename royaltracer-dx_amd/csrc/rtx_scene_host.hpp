@@ -87,6 +87,9 @@ struct SceneHost {
     bool refresh_transforms(BuiltScene& out);
     void build_lights(BuiltScene& out) const;
     void refresh_lights(BuiltScene& out) const; // the world-space half of the light records from lights80 (transform-only commits)
+    // RTX_OPT_GPU_BUILD: everything of a geometry-changing commit EXCEPT the per-triangle work (flatten, shade records, tree), which the device does from the meshes themselves
+    // (csrc/rtx_build.hip: k_flatten): materials, instance records and triangle ranges, lights.  out.shade / objtris / trees are left empty, out.built_tris = the triangle count
+    bool prepare_device_build(BuiltScene& out);
     void fill_objtris(BuiltScene& out) const;   // object-space triangles for the GPU refit (rtx_scene_cache.cpp: not stored in a cache file)
 };
 
