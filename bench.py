@@ -38,9 +38,9 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measu
 # SATURATED REPLAY LOOP of the kernel's own instruction-class mix reaches on this chip (tools/gen_mix.py + tools/valu_peak.hip, 8 waves / SIMD) — a fraction that cannot
 # exceed 1 by construction.  (Round 2 reported 4 * SQ_ACTIVE_INST_VALU / SIMD-cycles, which read 1.05-1.10: that counter charges every VALU instruction 4 cycles, while
 # v_fma_f32 / VOP2 integer ops take 2.3 / 3.0; and per-opcode costs do not add up either — profiles/r03_valu_calib.md — so the peak of a mix has to be measured.)
-# The counters come from tracked profiles/r04_roof_<workload>.json (tools/roofline_run.sh: separate rocprofv3 --pmc passes of this command); each file carries the hash
+# The counters come from tracked profiles/r05_roof_<workload>.json (tools/roofline_run.sh: separate rocprofv3 --pmc passes of this command); each file carries the hash
 # of the kernel sources it was recorded with, and a profile that no longer matches the loaded kernels is reported as stale instead of being priced.
-ROOF_PROFILE = {"cornell_1080p_64spp_8b": "r04_roof_cornell.json", "sponza_1080p_16spp_8b": "r04_roof_sponza.json", "bistro_1080p_16spp_8b": "r04_roof_bistro.json"}
+ROOF_PROFILE = {"cornell_1080p_64spp_8b": "r05_roof_cornell.json", "sponza_1080p_16spp_8b": "r05_roof_sponza.json", "bistro_1080p_16spp_8b": "r05_roof_bistro.json"}
 KERNEL_SYMBOL = {"bounce_fused": ("k_bounce_small", "k_bounce_bvh"), "trace_closest": ("k_trace_closest",), "shade": ("k_shade",),
                  "trace_shadow": ("k_trace_shadow",), "accumulate": ("k_accumulate",), "raygen": ("k_raygen", "k_raygen_trace_small")}
 

@@ -330,8 +330,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_emit_final(DevScene sc, Dev
 // (round 4) P1 / P2: which halves an instantiation runs.  As ONE kernel (<true, true>, round 3) the two halves' live ranges added up to 128 VGPRs + 55 spilled (148 B of scratch
 // per lane) at 0.96 waves per SIMD resident and 75 % of the wave time parked (profiles/r03_pmc_restir.md); as two launches, <true, false> then <false, true>, each half fits
 // its registers (profiles/r04_kernel_resources.md).  The temporal pass of a pixel reads that pixel's own pass-1 records: the kernel boundary orders them.
+// (round 5) the temporal half alone asks for 3 waves per SIMD: 128 VGPRs + 23 spilled (96 B of scratch per lane) at 4, 0 spilled at 3 — and the launch never had more than one
+// resident wave per SIMD anyway (profiles/r04_pmc_restir.md: 0.64)
 template <bool P1, bool P2>
-__global__ __launch_bounds__(kBlock, 4) void k_rs_p1_finish(DevScene sc, DevFrame f, RsQ q, F4* __restrict__ accum, uint32_t* __restrict__ res_di, uint32_t* __restrict__ res_gi,
+__global__ __launch_bounds__(kBlock, (P2 && !P1) ? 3 : 4) void k_rs_p1_finish(DevScene sc, DevFrame f, RsQ q, F4* __restrict__ accum, uint32_t* __restrict__ res_di, uint32_t* __restrict__ res_gi,
                                                             uint32_t* __restrict__ sdata, const CameraGPU* __restrict__ cam_p, RestirBufs B, uint32_t with_p2) {
     __shared__ CameraGPU cam;
     if (threadIdx.x < 64) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];

@@ -9,7 +9,7 @@ out=gpurun_out/${tag}_shard_time.md
   echo
   python3 tools/shard_time.py cornell pt 1 2 4 8 tile=32 && python3 tools/shard_time.py cornell pt 8 tile=64 &&
   python3 tools/shard_time.py sponza pt 1 2 4 8 tile=32 && python3 tools/shard_time.py bistro pt 1 8 tile=32 &&
-  python3 tools/shard_time.py sponza restir 1 2 4 8 blocks=1 tile=32 && python3 tools/shard_time.py sponza restir 8 tile=64 &&
+  python3 tools/shard_time.py sponza restir 1 2 4 8 blocks=1 tile=32 halo=32 && python3 tools/shard_time.py sponza restir 8 tile=64 &&
   python3 tools/shard_time.py sponza4k pt 8 tile=64 frames=2 &&
   python3 tools/shard_time.py cornell pt 1 2 4 8 native=1 && python3 tools/shard_time.py sponza pt 1 2 4 8 native=1
 } > $out 2> gpurun_out/${tag}_shard_time.err
