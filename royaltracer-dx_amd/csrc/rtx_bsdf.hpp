@@ -224,11 +224,9 @@ RTX_HD uint32_t select_strategy_v(const MatGPU& m, const MixView& mv, uint32_t f
     return 0u;
 }
 // RandomUnitVectorInHemisphere, Lambertian_v6.hlsl:2-38
-RTX_HD f3 sample_lambert(f3 normal, uint32_t& s0, uint32_t& s1) {
-    float u1 = tea_next(s0, s1), u2 = tea_next(s0, s1);
-    float r = sqrtf(u1);
-    float theta = kTwoPi * u2;
-    float sn, cs; sincos_(theta, sn, cs);
+// (round 5) the disk sample (two draws, sqrt, sine / cosine) is separated from the geometry that uses it: sample_bsdf takes it ONCE for whatever strategy a lane drew, so a wave
+// whose lanes drew different strategies does not run the generator and the trigonometry once per strategy branch (same operations per lane, same bits)
+RTX_HD f3 sample_lambert_disk(f3 normal, float r, float sn, float cs) {
     float x = r * cs, y = r * sn;
     float z = sqrtf(maxf_(0.0f, 1.0f - x * x - y * y));
     f3 h = normal;
@@ -240,6 +238,13 @@ RTX_HD f3 sample_lambert(f3 normal, uint32_t& s0, uint32_t& s1) {
     if (dot(s, normal) < 0.0f) s = -s;
     return s;
 }
+RTX_HD f3 sample_lambert(f3 normal, uint32_t& s0, uint32_t& s1) {
+    float u1 = tea_next(s0, s1), u2 = tea_next(s0, s1);
+    float r = sqrtf(u1);
+    float theta = kTwoPi * u2;
+    float sn, cs; sincos_(theta, sn, cs);
+    return sample_lambert_disk(normal, r, sn, cs);
+}
 // CoordinateSystem, GGX_v6.hlsl:65-76
 RTX_HD void coord_system(f3 N, f3& T, f3& B) {
     if (fabsf(N.z) < 0.999f) T = normalize(cross(mk3(0.0f, 0.0f, 1.0f), N));
@@ -247,7 +252,7 @@ RTX_HD void coord_system(f3 N, f3& T, f3& B) {
     B = cross(N, T);
 }
 // SampleBRDF_GGX (Heitz 2018 VNDF), GGX_v6.hlsl:93-169: the visible half vector H (:104-157) ...
-RTX_HD f3 sample_ggx_h(const MatGPU& m, f3 outgoing, f3 normal, uint32_t& s0, uint32_t& s1, f3& V) {
+RTX_HD f3 sample_ggx_h_disk(const MatGPU& m, f3 outgoing, f3 normal, float r, float sn, float cs, f3& V) {
     float alpha = m.Pr * m.Pr;
     f3 N = normalize(normal), T1, T2;
     V = normalize(outgoing);
@@ -259,10 +264,6 @@ RTX_HD f3 sample_ggx_h(const MatGPU& m, f3 outgoing, f3 normal, uint32_t& s0, ui
     if (lensq > 0.0f) { float rs = 1.0f / sqrtf(lensq); T1h = mk3(-Ve.y * rs, Ve.x * rs, 0.0f * rs); }
     else T1h = mk3(1.0f, 0.0f, 0.0f);
     f3 T2h = cross(Ve, T1h);
-    float U1 = tea_next(s0, s1), U2 = tea_next(s0, s1);
-    float r = sqrtf(U1);
-    float phi = 2.0f * kPI * U2;
-    float sn, cs; sincos_(phi, sn, cs);
     float t1 = r * cs, t2 = r * sn;
     float s = 0.5f * (1.0f + Ve.z);
     t2 = (1.0f - s) * sqrtf(saturate(1.0f - t1 * t1)) + s * t2;
@@ -271,7 +272,21 @@ RTX_HD f3 sample_ggx_h(const MatGPU& m, f3 outgoing, f3 normal, uint32_t& s0, ui
     f3 Ne = normalize(mk3(alpha * Nh.x, alpha * Nh.y, maxf_(0.0f, Nh.z)));
     return mk3(Ne.x * T1.x + Ne.y * T2.x + Ne.z * N.x, Ne.x * T1.y + Ne.y * T2.y + Ne.z * N.y, Ne.x * T1.z + Ne.y * T2.z + Ne.z * N.z);
 }
+RTX_HD f3 sample_ggx_h(const MatGPU& m, f3 outgoing, f3 normal, uint32_t& s0, uint32_t& s1, f3& V) {
+    float U1 = tea_next(s0, s1), U2 = tea_next(s0, s1);
+    float r = sqrtf(U1);
+    float phi = 2.0f * kPI * U2;
+    float sn, cs; sincos_(phi, sn, cs);
+    return sample_ggx_h_disk(m, outgoing, normal, r, sn, cs, V);
+}
 // ... and the direction reflected about it (:159-165)
+RTX_HD f3 ggx_reflect(f3 H, f3 V, f3 normal) {
+    f3 I = -V;
+    float k = 2.0f * dot(H, I);
+    f3 smp = mk3(I.x - k * H.x, I.y - k * H.y, I.z - k * H.z);
+    if (dot(smp, normal) < 0.0f) smp = -smp;   // :164-165: flipped, not rejected
+    return smp;
+}
 RTX_HD f3 sample_ggx(const MatGPU& m, f3 outgoing, f3 normal, uint32_t& s0, uint32_t& s1) {
     f3 V; f3 H = sample_ggx_h(m, outgoing, normal, s0, s1, V);
     f3 I = -V;
@@ -281,6 +296,14 @@ RTX_HD f3 sample_ggx(const MatGPU& m, f3 outgoing, f3 normal, uint32_t& s0, uint
     return smp;
 }
 // EXTENSION, strategy 3: refract about the same visible half vector (`//SampleBTDF_GGX`, BRDF_v6.hlsl:85-87); total internal reflection ends the path (zero vector)
+RTX_HD f3 btdf_refract(f3 H, f3 V, float eta_p) {
+    float eta = 1.0f / eta_p;
+    float c = dot(V, H);
+    float s2 = eta * eta * (1.0f - c * c);
+    if (!(s2 < 1.0f)) return mk3(0.0f, 0.0f, 0.0f);
+    float k = eta * c - sqrtf(1.0f - s2);
+    return normalize(mk3(k * H.x - eta * V.x, k * H.y - eta * V.y, k * H.z - eta * V.z));
+}
 RTX_HD f3 sample_btdf(const MatGPU& m, f3 outgoing, f3 normal, float eta_p, uint32_t& s0, uint32_t& s1) {
     f3 V; f3 H = sample_ggx_h(m, outgoing, normal, s0, s1, V);
     float eta = 1.0f / eta_p;
@@ -292,8 +315,21 @@ RTX_HD f3 sample_btdf(const MatGPU& m, f3 outgoing, f3 normal, float eta_p, uint
 }
 // SampleBRDF, BRDF_v6.hlsl:74-88
 RTX_HD f3 sample_bsdf(const MatGPU& m, uint32_t strategy, f3 outgoing, f3 normal, uint32_t& s0, uint32_t& s1, float eta_p = 0.0f) {
+#ifdef RTX_SAMPLE_PER_BRANCH    // (A/B build: every strategy branch with its own draws, as until round 4)
     if (strategy == 3u) return sample_btdf(m, outgoing, normal, eta_p, s0, s1);
     return strategy == 1u ? sample_ggx(m, outgoing, normal, s0, s1) : sample_lambert(normal, s0, s1);
+#else
+    // every strategy starts from the same disk sample: two draws, r = sqrt(U1), sine and cosine of 2 pi U2 — with the reference's two different values of "2 pi"
+    // (Lambertian_v6.hlsl:10 against GGX_v6.hlsl's 2 * PI with PI = 3.1415), selected per lane before the one evaluation
+    const float U1 = tea_next(s0, s1), U2 = tea_next(s0, s1);
+    const float r = sqrtf(U1);
+    const bool lambert = strategy != 1u && strategy != 3u;
+    const float ang = lambert ? kTwoPi * U2 : 2.0f * kPI * U2;
+    float sn, cs; sincos_(ang, sn, cs);
+    if (lambert) return sample_lambert_disk(normal, r, sn, cs);
+    f3 V; const f3 H = sample_ggx_h_disk(m, outgoing, normal, r, sn, cs, V);       // strategies 1 and 3 share the visible half vector
+    return strategy == 3u ? btdf_refract(H, V, eta_p) : ggx_reflect(H, V, normal);
+#endif
 }
 
 }  // namespace rtx
