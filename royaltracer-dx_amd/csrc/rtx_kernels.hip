@@ -308,10 +308,15 @@ __global__ __launch_bounds__(kBlock, (SCHED >= 0 ? RTX_TRACE_WAVES : 1)) void k_
 // One item of k_shade / k_shade_dense: entry `qi` of the workgroup's sub-queue (valid = the lane has one).  Every lane of the wave goes through the compactions.
 template <bool LAMBERT>
 __device__ __forceinline__ void shade_item(const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce, uint32_t nee, bool last, size_t qb,
-                                           const uint32_t* __restrict__ myq, uint32_t* __restrict__ mynext, uint32_t* s_cnt, bool valid, uint32_t qi, Prof* pf) {
+                                           const uint32_t* __restrict__ myq, uint32_t* __restrict__ mynext, uint32_t* s_cnt, bool valid, uint32_t qi, Prof* pf, const float* lds_cdf = nullptr, const LightGPU* lds_lights = nullptr, const MatGPU* lds_mats = nullptr) {
     PathState S; S.pid = 0; S.o = mk3(0, 0, 0); S.d = mk3(0, 0, 1); S.thr = mk3(0, 0, 0); S.prev_pdf = 1.0f; S.s0 = S.s1 = 0;
     Surf sf; sf.mat = 0; sf.normal = mk3(0, 0, 1); sf.pos = mk3(0, 0, 0);
     bool shading = false;
+#ifndef RTX_NO_LDS_MATS
+    const MatGPU* mats = lds_mats ? lds_mats : sc.mats;      // (uniform; k_shade stages a short material table beside the light list)
+#else
+    const MatGPU* mats = sc.mats;
+#endif
     if (valid) {
         const uint32_t pid = myq[qi];
         const uint32_t src = p.out_o ? (uint32_t)qb + qi : pid;               // compact state: hit and path state live at the queue position
@@ -323,14 +328,14 @@ __device__ __forceinline__ void shade_item(const DevScene& sc, const DevFrame& f
             sf = surface(sc, S.o, S.d, h.x, h.y, h.z, prim);
             PF_MARK(1);
             if (sf.mat < sc.nmat) {
-                const MatGPU& m = sc.mats[sf.mat];
+                const MatGPU& m = mats[sf.mat];
                 if (m.Ke_len > 0.0f) add_emissive(sc, p, S, sf, m, bounce, nee);   // Hit.hlsl:126, Sampler_v6.hlsl:457
                 else shading = true;
             }
         }
     }
     const f3 outgoing = -S.d, pos = sf.pos;
-    const MatGPU* mp = sc.mats + (shading ? sf.mat : 0u);
+    const MatGPU* mp = mats + (shading ? sf.mat : 0u);
     f3 normal = sf.normal;
     const float eta_p = LAMBERT ? 0.0f : transmission_eta(*mp, f.flags, outgoing, normal);          // (extension) hits from behind a dielectric flip the shading normal
     // the view-dependent terms of the mixture BSDF, once per shading point: the NEE samples and the continuation share them (rtx_bsdf.hpp: MixView)
@@ -343,7 +348,7 @@ __device__ __forceinline__ void shade_item(const DevScene& sc, const DevFrame& f
         bool push = false;
         F4 so = {0, 0, 0, 0}, sd = {0, 0, 0, 0}; f3 con = mk3(0, 0, 0);
         if (shading) { PF_COUNT(3); }
-        if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con, sc.nsmall != 0u && sf.near_hull, eta_p, mv);
+        if (shading) push = nee_sample(sc, *mp, f.flags, nee, S, pos, normal, outgoing, so, sd, con, sc.nsmall != 0u && sf.near_hull, eta_p, mv, lds_cdf, lds_lights);
         PF_MARK(3);
         if (push) { PF_COUNT(4); }
         const size_t seg = (size_t)j * f.qcap * gridDim.x + qb;           // NEE slot j, this workgroup's sub-queue
@@ -377,7 +382,18 @@ __device__ __forceinline__ void shade_item(const DevScene& sc, const DevFrame& f
     }
 }
 
-constexpr uint32_t kSortChunk = 2048, kSortKeys = 64;
+constexpr uint32_t kSortChunk = 2048, kSortKeys = 64, kLdsCdf = 256;
+// k_shade's dynamic LDS (launch and kernel agree through this one function): the light list (records + CDF) when it has <= 256 entries, the material table behind it while
+// both stay within kShadeLds bytes.  RTX_SHADE_LDS (A/B builds) moves the budget; 0 = lights only.
+#ifndef RTX_SHADE_LDS
+#define RTX_SHADE_LDS 24576
+#endif
+constexpr uint32_t kShadeLds = RTX_SHADE_LDS;
+__host__ __device__ inline void shade_lds_plan(uint32_t nlights, uint32_t nmat, bool sort, uint32_t& lights_bytes, uint32_t& mats_bytes) {
+    lights_bytes = (!sort && nlights <= kLdsCdf) ? ((nlights * 84u + 15u) & ~15u) : 0u;
+    mats_bytes = (!sort && nmat && lights_bytes + nmat * 160u <= kShadeLds) ? nmat * 160u : 0u;
+}
+static size_t shade_lds_bytes(const DevScene& sc, bool sort) { uint32_t lb, mb; shade_lds_plan(sc.nlights, sc.nmat, sort, lb, mb); return (size_t)lb + mb; }
 #ifndef RTX_SHADE_WAVES
 #define RTX_SHADE_WAVES 7          // waves per SIMD k_shade is compiled for: 7 = 72 VGPRs + 1 spilled (GGX) / 66 (Lambert); uncapped: 94 VGPRs, 5 waves; 6: 80, no spills; 8: 64, 9 spilled.
                                    // k_shade per frame, C3 / C5: 7.42 / 8.77 ms uncapped, 6.93 / 8.54 at 6, 7.50 / 8.83 at 8 (round 2); round 4: 6.27 / 6.85 at 6, 6.28 / 6.72 at 7
@@ -392,8 +408,27 @@ __global__ __launch_bounds__(kBlock, RTX_SHADE_WAVES) void k_shade(DevScene sc, 
     __shared__ uint32_t s_cnt[1 + kMaxNee];                 // [0] next-queue length, [1 + j] shadow queue j length
     __shared__ uint32_t s_pid[SORT ? kSortChunk : 1], s_sorted[SORT ? kSortChunk : 1], s_hist[SORT ? kSortKeys : 1];
     __shared__ uint8_t s_key[SORT ? kSortChunk : 1];
+    // (round 5) a light list of <= 256 entries in LDS — the records (80 B each) and behind them the CDF: NEE's binary search is 1-8 DEPENDENT reads per sample (street scene:
+    // 204 lights), the record one more.  Dynamic LDS, sized by the list at launch (shade_lds_bytes): a scene with two lights pays 168 bytes, not a workgroup per CU
+    extern __shared__ F4 s_lights[];
+    float* s_cdf = (float*)(s_lights + (size_t)sc.nlights * 5u);
+    uint32_t lights_bytes, mats_bytes; shade_lds_plan(sc.nlights, sc.nmat, SORT, lights_bytes, mats_bytes);
+    const bool cdf_in_lds = lights_bytes != 0u;
+    if (cdf_in_lds) {
+        for (uint32_t i = threadIdx.x; i < sc.nlights * 5u; i += kBlock) s_lights[i] = ((const F4*)sc.lights)[i];
+        for (uint32_t i = threadIdx.x; i < sc.nlights; i += kBlock) s_cdf[i] = sc.cdf[i];
+    }
     if (threadIdx.x <= kMaxNee) s_cnt[threadIdx.x] = 0;
     __syncthreads();
+    const float* lds_cdf = cdf_in_lds ? s_cdf : nullptr;
+    const LightGPU* lds_lights = cdf_in_lds ? (const LightGPU*)s_lights : nullptr;
+    // ... and the material table (160 B each) behind the CDF when launch_shade found room for it (mats_in_lds: what it sized the dynamic LDS for)
+    const MatGPU* lds_mats = nullptr;
+    if (mats_bytes) {
+        F4* dst = (F4*)((char*)s_lights + lights_bytes);
+        for (uint32_t i = threadIdx.x; i < sc.nmat * 10u; i += kBlock) dst[i] = ((const F4*)sc.mats)[i];
+        lds_mats = (const MatGPU*)dst;
+    }
     const uint32_t n = qcount[blockIdx.x];
     const uint32_t nee = sc.nlights ? f.nee_samples : 0u;
     const bool last = (bounce + 1u == f.max_bounces);
@@ -427,7 +462,7 @@ __global__ __launch_bounds__(kBlock, RTX_SHADE_WAVES) void k_shade(DevScene sc, 
         }
         for (uint32_t base = threadIdx.x & ~63u; base < cn; base += kBlock) {
             const uint32_t i = base + (threadIdx.x & 63u);
-            shade_item<LAMBERT>(sc, f, p, bounce, nee, last, qb, myq, mynext, s_cnt, i < cn, cb + (SORT ? s_sorted[i] : i), pf);
+            shade_item<LAMBERT>(sc, f, p, bounce, nee, last, qb, myq, mynext, s_cnt, i < cn, cb + (SORT ? s_sorted[i] : i), pf, lds_cdf, lds_lights, lds_mats);
         }
         if (SORT) __syncthreads();                              // the next chunk overwrites the LDS buffers
     }
@@ -1226,7 +1261,7 @@ void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, 
 void launch_shade(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce,
                   const uint32_t* queue, const uint32_t* qcount, uint32_t* next_queue, uint32_t* next_count, uint32_t* shcounts) {
     // material-sorted variant: measured slower (see k_shade), the permutation un-coalesces the per-path state streams
-#define RTX_LAUNCH_SHADE(SS, LL) hipLaunchKernelGGL((k_shade<SS, LL>), dim3(f.nblocks), dim3(kBlock), 0, st, sc, f, p, bounce, queue, qcount, next_queue, next_count, shcounts)
+#define RTX_LAUNCH_SHADE(SS, LL) hipLaunchKernelGGL((k_shade<SS, LL>), dim3(f.nblocks), dim3(kBlock), shade_lds_bytes(sc, SS), st, sc, f, p, bounce, queue, qcount, next_queue, next_count, shcounts)
     const bool lam = (f.flags & 1u) != 0u;
     if (sc.shade_dense && !sc.sort_materials) {
         if (lam) hipLaunchKernelGGL((k_shade_dense<true>), dim3(f.nblocks), dim3(kBlock), 0, st, sc, f, p, bounce, queue, qcount, next_queue, next_count, shcounts);

@@ -103,14 +103,26 @@ __device__ __forceinline__ void add_emissive(const DevScene& sc, const DevPaths&
 // one NEE sample: SampleLightNEE_GI, Sampler_v6.hlsl:508-647.  Returns true when a shadow ray is needed.
 // mv: the view terms of the shading point (mix_view), shared with the continuation's mixture by k_shade; nullptr = computed here
 __device__ __forceinline__ bool nee_sample(const DevScene& sc, const MatGPU& m, uint32_t flags, uint32_t nee, PathState& S, f3 pos, f3 normal, f3 outgoing,
-                                           F4& so, F4& sd, f3& con, bool near_hull = false, float eta_p = 0.0f, const MixView* mv = nullptr) {
+                                           F4& so, F4& sd, f3& con, bool near_hull = false, float eta_p = 0.0f, const MixView* mv = nullptr, const float* lds_cdf = nullptr, const LightGPU* lds_lights = nullptr) {
     const float rv = tea_next(S.s0, S.s1);
     int left = 0, right = (int)sc.nlights - 1, sel = 0;
+#ifndef RTX_NO_LDS_CDF
+    if (lds_cdf) {                                            // (round 5, uniform) k_shade staged the CDF of a short light list in LDS: the same search, its dependent reads from LDS
+        while (left <= right) {
+            const int mid = left + (right - left) / 2;
+            if (rv < lds_cdf[mid]) { sel = mid; right = mid - 1; } else left = mid + 1;
+        }
+    } else
+#endif
     while (left <= right) {                                   // :523-537
         const int mid = left + (right - left) / 2;
         if (rv < sc.cdf[mid]) { sel = mid; right = mid - 1; } else left = mid + 1;
     }
+#ifndef RTX_NO_LDS_LIGHTS
+    const LightGPU& lt = lds_lights ? lds_lights[sel] : sc.lights[sel];     // (uniform choice; k_shade stages a list of <= 256 records)
+#else
     const LightGPU& lt = sc.lights[sel];
+#endif
     const f3 xv = mk3(lt.xv[0], lt.xv[1], lt.xv[2]), yv = mk3(lt.yv[0], lt.yv[1], lt.yv[2]), zv = mk3(lt.zv[0], lt.zv[1], lt.zv[2]);
     float xi1 = tea_next(S.s0, S.s1), xi2 = tea_next(S.s0, S.s1);
     if (xi1 + xi2 > 1.0f) { xi1 = 1.0f - xi1; xi2 = 1.0f - xi2; }
