@@ -83,9 +83,33 @@ __global__ __launch_bounds__(kBlock) void k_rs_raygen(DevFrame f, RsQ q, const C
     rs_publish(cnt_out, &s_n, nullptr, nullptr, q, 0);
 }
 
+// (round 5) a short material table (<= 16 records) and light list (<= 32 records + CDF) in LDS for the stage kernels: every stage reads the pixel's material record behind its
+// sample record, pass 1 also runs NEE (CDF search, light record) per candidate — dependent global reads at 4-5 waves per SIMD.  The kernel sees a COPY of the scene
+// descriptor whose table pointers aim at LDS (everything is inlined, so the rest of the code is untouched); longer tables stay in global memory.
+#ifndef RTX_RS_P1_WAVES
+#define RTX_RS_P1_WAVES 5      // k_rs_p1_first / _loop: 96 VGPRs (5 waves / SIMD) before the LDS tables, 101-105 with them unless asked for 5
+#endif
+struct RsTables { F4 mats[16 * 10]; F4 lights[32 * 5]; float cdf[32]; };
+__device__ __forceinline__ DevScene rs_stage_tables(const DevScene& in, RsTables& T) {
+    DevScene sc = in;
+    if (in.nmat && in.nmat <= 16u) { for (uint32_t i = threadIdx.x; i < in.nmat * 10u; i += kBlock) T.mats[i] = ((const F4*)in.mats)[i]; sc.mats = (const MatGPU*)T.mats; }
+    if (in.nlights && in.nlights <= 32u) {
+        for (uint32_t i = threadIdx.x; i < in.nlights * 5u; i += kBlock) T.lights[i] = ((const F4*)in.lights)[i];
+        if (threadIdx.x < in.nlights) T.cdf[threadIdx.x] = in.cdf[threadIdx.x];
+        sc.lights = (const LightGPU*)T.lights; sc.cdf = T.cdf;
+    }
+    return sc;
+}
+#ifndef RTX_NO_RS_LDS_TABLES
+#define RS_STAGE_SCENE(sc_in) __shared__ RsTables rs_tab_; const DevScene sc = rs_stage_tables(sc_in, rs_tab_); __syncthreads()
+#else
+#define RS_STAGE_SCENE(sc_in) const DevScene& sc = sc_in
+#endif
+
 // stage 1: primary hit -> pixels that sample nothing are finished here; the others run SampleRIS up to its BSDF-candidate ray (set 0 -> set 1)
-__global__ __launch_bounds__(kBlock, 4) void k_rs_p1_ris(DevScene sc, DevFrame f, RsQ q, const uint32_t* __restrict__ cnt_in, uint32_t* __restrict__ cnt_out,
+__global__ __launch_bounds__(kBlock, 4) void k_rs_p1_ris(DevScene sc_in, DevFrame f, RsQ q, const uint32_t* __restrict__ cnt_in, uint32_t* __restrict__ cnt_out,
                                                          F4* __restrict__ accum, uint32_t* __restrict__ res_di, uint32_t* __restrict__ res_gi, uint32_t* __restrict__ sdata) {
+    RS_STAGE_SCENE(sc_in);
     __shared__ uint32_t s_n;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
@@ -141,8 +165,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_ris(DevScene sc, DevFrame f
 // stage 2: the BSDF candidate's hit closes SampleRIS: the DI reservoir and the pixel's sample record are written, the DI visibility ray goes to the ray queue
 // (it only decides whether W becomes 0, which k_rs_p1_finish applies: it is traced later, together with the rays of k_rs_p1_emit_final), and the path sampler's first
 // BSDF ray starts (set 1 -> set 0)
-__global__ __launch_bounds__(kBlock, 4) void k_rs_p1_ris_finish(DevScene sc, DevFrame f, RsQ q, const uint32_t* __restrict__ cnt_in, uint32_t* __restrict__ cnt_out, uint32_t* __restrict__ shcnt,
+__global__ __launch_bounds__(kBlock, 4) void k_rs_p1_ris_finish(DevScene sc_in, DevFrame f, RsQ q, const uint32_t* __restrict__ cnt_in, uint32_t* __restrict__ cnt_out, uint32_t* __restrict__ shcnt,
                                                                 uint32_t* __restrict__ res_di, uint32_t* __restrict__ sdata) {
+    RS_STAGE_SCENE(sc_in);
     __shared__ uint32_t s_n, s_rn;
     if (threadIdx.x == 0) { s_n = 0; s_rn = 0; }
     __syncthreads();
@@ -214,7 +239,8 @@ __device__ __forceinline__ void rs_store_hot(const RsQ& q, uint32_t set, size_t 
 }
 
 // stage 3: first path vertex (set 0 -> set 1).  A path that ends here contributes nothing; the others record (xn, nn) and run the loop body up to its ray
-__global__ __launch_bounds__(kBlock, 4) void k_rs_p1_first(DevScene sc, DevFrame f, RsQ q, const uint32_t* __restrict__ cnt_in, uint32_t* __restrict__ cnt_out) {
+__global__ __launch_bounds__(kBlock, RTX_RS_P1_WAVES) void k_rs_p1_first(DevScene sc_in, DevFrame f, RsQ q, const uint32_t* __restrict__ cnt_in, uint32_t* __restrict__ cnt_out) {
+    RS_STAGE_SCENE(sc_in);
     __shared__ uint32_t s_n;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
@@ -251,7 +277,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_first(DevScene sc, DevFrame
 }
 
 // stage 4, once per loop iteration `iter`: the hit closes iteration `iter`; a surviving path runs iteration iter + 1 up to its ray (set `set` -> the other)
-__global__ __launch_bounds__(kBlock, 4) void k_rs_p1_loop(DevScene sc, DevFrame f, RsQ q, uint32_t set, uint32_t iter, const uint32_t* __restrict__ cnt_in, uint32_t* __restrict__ cnt_out) {
+__global__ __launch_bounds__(kBlock, RTX_RS_P1_WAVES) void k_rs_p1_loop(DevScene sc_in, DevFrame f, RsQ q, uint32_t set, uint32_t iter, const uint32_t* __restrict__ cnt_in, uint32_t* __restrict__ cnt_out) {
+    RS_STAGE_SCENE(sc_in);
     __shared__ uint32_t s_n;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
@@ -288,7 +315,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_loop(DevScene sc, DevFrame 
 // (the ray sub-queues are workgroup-private and a pixel stays with its workgroup, so the counter simply continues).  In a ReSTIR frame (with_p2) the two visibility
 // rays of the TEMPORAL pass join them: they depend on this frame's primary hit (written by stages 1 / 2) and on last frame's records only, so all four rays of a
 // pixel are traversed by ONE persistent launch.  Occlusion bytes of a pixel: 0 DI, 1 GI reconnection, 2 / 3 temporal DI / GI.
-__global__ __launch_bounds__(kBlock, 4) void k_rs_p1_emit_final(DevScene sc, DevFrame f, RsQ q, const CameraGPU* __restrict__ cam_p, RestirBufs B, uint32_t with_p2, uint32_t* __restrict__ shcnt) {
+__global__ __launch_bounds__(kBlock, 4) void k_rs_p1_emit_final(DevScene sc_in, DevFrame f, RsQ q, const CameraGPU* __restrict__ cam_p, RestirBufs B, uint32_t with_p2, uint32_t* __restrict__ shcnt) {
+    RS_STAGE_SCENE(sc_in);
     __shared__ CameraGPU cam;
     __shared__ uint32_t s_rn;
     if (threadIdx.x < 64) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
@@ -333,8 +361,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p1_emit_final(DevScene sc, Dev
 // (round 5) the temporal half alone asks for 3 waves per SIMD: 128 VGPRs + 23 spilled (96 B of scratch per lane) at 4, 0 spilled at 3 — and the launch never had more than one
 // resident wave per SIMD anyway (profiles/r04_pmc_restir.md: 0.64)
 template <bool P1, bool P2>
-__global__ __launch_bounds__(kBlock, (P2 && !P1) ? 3 : 4) void k_rs_p1_finish(DevScene sc, DevFrame f, RsQ q, F4* __restrict__ accum, uint32_t* __restrict__ res_di, uint32_t* __restrict__ res_gi,
+__global__ __launch_bounds__(kBlock, (P2 && !P1) ? 3 : 4) void k_rs_p1_finish(DevScene sc_in, DevFrame f, RsQ q, F4* __restrict__ accum, uint32_t* __restrict__ res_di, uint32_t* __restrict__ res_gi,
                                                             uint32_t* __restrict__ sdata, const CameraGPU* __restrict__ cam_p, RestirBufs B, uint32_t with_p2) {
+    RS_STAGE_SCENE(sc_in);
     __shared__ CameraGPU cam;
     if (threadIdx.x < 64) ((float*)&cam)[threadIdx.x] = ((const float*)cam_p)[threadIdx.x];
     __syncthreads();
@@ -384,7 +413,8 @@ __global__ __launch_bounds__(kBlock, (P2 && !P1) ? 3 : 4) void k_rs_p1_finish(De
 __device__ __forceinline__ bool p3_samples(const DevScene& sc, const SData& sd) {      // the pixel runs the spatial pass (not a light seen directly, not a miss)
     return (sd.L1.x == 0.0f && sd.L1.y == 0.0f && sd.L1.z == 0.0f) && !(sd.mID == 0xFFFEu || sd.mID >= sc.nmat);
 }
-__global__ __launch_bounds__(kBlock, 4) void k_rs_p3_select(DevScene sc, DevFrame f, RsQ q, const CameraGPU* __restrict__ cam_p, RestirBufs B, uint32_t* __restrict__ shcnt) {
+__global__ __launch_bounds__(kBlock, 4) void k_rs_p3_select(DevScene sc_in, DevFrame f, RsQ q, const CameraGPU* __restrict__ cam_p, RestirBufs B, uint32_t* __restrict__ shcnt) {
+    RS_STAGE_SCENE(sc_in);
     __shared__ uint32_t s_rn;
     if (threadIdx.x == 0) s_rn = 0;
     __syncthreads();
@@ -473,7 +503,8 @@ __device__ __forceinline__ void p3_select_keys(const DevFrame& f, const RsKeys& 
         if (ok) { K.gi[K.n_gi++] = (uint32_t)pr; K.M_sum_GI += minf_u(128.0f, gn.M); }
     }
 }
-__global__ __launch_bounds__(kBlock, 4) void k_rs_p3_select_keys(DevScene sc, DevFrame f, RsQ q, const CameraGPU* __restrict__ cam_p, RestirBufs B, RsKeys Ky, uint32_t* __restrict__ shcnt) {
+__global__ __launch_bounds__(kBlock, 4) void k_rs_p3_select_keys(DevScene sc_in, DevFrame f, RsQ q, const CameraGPU* __restrict__ cam_p, RestirBufs B, RsKeys Ky, uint32_t* __restrict__ shcnt) {
+    RS_STAGE_SCENE(sc_in);
     __shared__ uint32_t s_rn;
     if (threadIdx.x == 0) s_rn = 0;
     __syncthreads();
@@ -519,7 +550,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p3_select_keys(DevScene sc, De
 // GI = false: the DI merge (+ the ray of the selected DI sample); GI = true: the GI merge, whose random numbers continue behind the n_di the DI merge drew.  Two launches
 // of half the register pressure each: as one kernel the merge needed 128 VGPRs with 51 of them spilled (148 B of scratch per lane).
 template <bool GI>
-__global__ __launch_bounds__(kBlock, 4) void k_rs_p3_merge(DevScene sc, DevFrame f, RsQ q, RestirBufs B, uint32_t* __restrict__ shcnt) {
+__global__ __launch_bounds__(kBlock, 4) void k_rs_p3_merge(DevScene sc_in, DevFrame f, RsQ q, RestirBufs B, uint32_t* __restrict__ shcnt) {
+    RS_STAGE_SCENE(sc_in);
     __shared__ uint32_t s_rn;
     if (threadIdx.x == 0) s_rn = 0;
     __syncthreads();
@@ -555,7 +587,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_rs_p3_merge(DevScene sc, DevFrame
     }
     if (!GI) rs_publish(nullptr, nullptr, shcnt, &s_rn, q, 1);
 }
-__global__ __launch_bounds__(kBlock, 4) void k_rs_p3_shade(DevScene sc, DevFrame f, RsQ q, RestirBufs B, F4* __restrict__ accum) {
+__global__ __launch_bounds__(kBlock, 4) void k_rs_p3_shade(DevScene sc_in, DevFrame f, RsQ q, RestirBufs B, F4* __restrict__ accum) {
+    RS_STAGE_SCENE(sc_in);
     const uint32_t nchunks = (q.nitems + kBlock - 1) / kBlock;
     for (uint32_t c = rs_wg(q); c < nchunks; c += gridDim.x) {
         const uint32_t it = c * kBlock + threadIdx.x;
