@@ -537,6 +537,36 @@ def test_wide_bvh_equals_brute_force_on_hostile_soups(rt, orc, kind, builder):
     c.close()
 
 
+def test_host_state_survives_hundreds_of_contexts(rt):
+    """Round 5 (profiles/r05_determinism.md): the once-in-700-contexts mismatch of the fuzz tests was two words of a live 912-byte host vector (a mesh's index array, the
+    builder's leaf order) changing during a later rtx_commit_scene — a stray write that came with hipStreamDestroy in a process that creates and destroys many contexts.  The
+    library pools its streams now.  This is tools/flaky_bisect.py in small: the failing flow on the two scenes it hit (their 228-entry vectors), RTX_CONTEXT_REPS contexts each
+    (default 400; the hunt ran 20 000), host checksums after every call: nothing the host holds may change between commits, and every context ends with the same tree."""
+    reps = int(os.environ.get("RTX_CONTEXT_REPS", 400))
+    W, H = 48, 32
+    for seed in (817, 148):
+        sc = RandomTinyScene(rt, 9000 + 200000 + seed, max_tris=[200, 800, 3000][seed % 3])
+        M = np.eye(4); M[:3, :3] = np.diag([1.1, 0.9, -1.05]) @ np.array([[np.cos(.3), 0, np.sin(.3)], [0, 1, 0], [-np.sin(.3), 0, np.cos(.3)]]); M[:3, 3] = (0.05, -0.02, 0.03)
+        inst = len(sc.instances) - 1
+        M2 = (M @ np.asarray(sc.instances[inst][1], np.float64).reshape(4, 4).T).T.astype(np.float32).reshape(16)
+        rays = random_rays(3000, seed, -1.2, 1.2)
+        p = rt.Params(width=W, height=H, spp=2, max_bounces=5, nee_samples=1 + seed % 2, flags=seed & 1, frame_seed=seed)
+        built = refit = tree = None
+        for rep in range(reps):
+            c = rt.Context(0); c.set_option(rt.OPT_GPU_REFIT, 0); c.upload(sc, W / H)
+            h0 = c.host_checksums()
+            c.clear(W, H); c.render(p); c.trace_closest(rays); assert c.validate_bvh() == 0
+            assert c.host_checksums() == h0, f"seed {seed} context {rep}: host state changed between two commits"
+            c.set_instance_transform(inst, M2); c.commit()
+            h1 = c.host_checksums()
+            assert h1[:3] == h0[:3] and h1[4] == h0[4], f"seed {seed} context {rep}: meshes, materials or the leaf order changed in a transform-only commit"
+            c.clear(W, H); c.render(p); assert c.validate_bvh() == 0
+            t = c.tree_hash()
+            if rep == 0: built, refit, tree = h0, h1, t
+            assert (h0, h1, t) == (built, refit, tree), f"seed {seed} context {rep}: not the state of the first context"
+            c.close()
+
+
 @pytest.mark.parametrize("kind", ["atrium", "atrium_hard", "street", "soup", "needles"])
 def test_gpu_build_equals_its_host_twin_and_renders_the_oracle_image(rt, orc, kind):
     """RTX_OPT_GPU_BUILD (csrc/rtx_build.hip; VERDICT r04 item 6: the reference's driver builds its BLAS / TLAS on the device, BottomLevelASGenerator.cpp:178-247,

@@ -356,6 +356,20 @@ def test_library_exports_every_declared_symbol(rt):
             assert hasattr(rt.lib, n), f"{n} declared in include/{h} but not exported by librtx_hip.so"
 
 
+def test_product_library_keeps_the_process_allocator_and_never_destroys_streams():
+    """Round 5 (profiles/r05_determinism.md): (1) the heap fence that hunted the stray write (csrc/rtx_heap_fence.cpp) is an EMPTY translation unit in the product — librtx_hip.so
+    must not define operator new / delete; (2) the cure: the library borrows its HIP streams from a process-wide pool and never destroys one — no call to hipStreamDestroy is
+    left in the C-ABI sources (host/MultiGpu.cpp, the executable's per-frame-object streams, is outside the library's contexts)."""
+    pkg = os.path.join(ROOT, "royaltracer-dx_amd")
+    nm = subprocess.run(["nm", "-DC", "--defined-only", os.path.join(pkg, "librtx_hip.so")], capture_output=True, text=True).stdout
+    assert "operator new" not in nm and "operator delete" not in nm
+    for f in ("rtx_api.hip", "rtx_build.hip", "rtx_kernels.hip", "rtx_staging.hpp"):
+        src = re.sub(r"//[^\n]*", "", open(os.path.join(pkg, "csrc", f)).read())
+        assert "hipStreamDestroy(" not in src, f
+    api = open(os.path.join(pkg, "csrc", "rtx_api.hip")).read()
+    assert "hipMemcpyHostToDevice" not in api and api.count("hipMemcpyDeviceToHost") == 1        # host copies go through rtx_staging.hpp; the one left fills the PINNED counter block of a frame
+
+
 def test_no_cpu_fallback_without_a_gpu(rt):
     import torch
     if torch.cuda.is_available():
