@@ -168,6 +168,9 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
                                         of the tree by the host's SAH builder + re-insertion over those clusters, SAH collapse to 8-wide nodes and layout on the device, then the refit
                                         kernels) instead of on the host: what the reference's driver does for it in BottomLevelASGenerator.cpp:178-247 / TopLevelASGenerator.cpp:149-250.
                                         0 (default): host build.  Results never depend on the tree; the host-side mirror of the tree (scene cache save, host refit) is not kept */
+       RTX_OPT_STACK_CAP = 39,       /* 11 (default): traversal-stack entries per lane that live in LDS; a tree whose exact stack bound is deeper keeps the rest in per-lane columns in
+                                        global memory, so that LDS (the staged top of the tree, workgroups per CU) is sized for what almost every ray needs.  0 = the whole stack in LDS (until round 5).
+                                        Never changes a result.  Takes effect with the next rtx_commit_scene */
        RTX_OPT_BLOCKS_PER_CU = 12    /* tuning: workgroups (= private sub-queues) per compute unit; default 0 = auto: 40 (tiny scenes) / 32 at full frame size (8 measured 4-7 % slower there: tail imbalance), fewer — down to 8 — when a batch is so
                                         small (a shard) that a sub-queue would start with fewer than ~16 / ~8 chunks of 256 paths */ };
 

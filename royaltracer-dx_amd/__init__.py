@@ -42,6 +42,7 @@ OPT_REFILL_MIN, OPT_STACK_PRIVATE, OPT_TRACE_SCHED, OPT_GPU_REFIT, OPT_BLOCKS_PE
 OPT_RESTIR_WAVEFRONT, OPT_RESTIR_CHUNKS, OPT_OCCLUDER_CACHE, OPT_RESTIR_LANES, OPT_SHADE_DENSE, OPT_MERGE_RAYS, OPT_TAPER = 19, 20, 21, 22, 23, 24, 25
 OPT_BVH_REINSERT, OPT_BVH_SPLIT, OPT_ANYHIT_ORDER, OPT_RESTIR_LANE_MIN, OPT_TRACE_COUNTERS, OPT_ASYNC, OPT_OCTANT_SORT, OPT_SAMPLE_INTERLEAVE, OPT_NODE_STRIDE, OPT_RESTIR_KEYS, OPT_LDS_NODES_CLOSEST, OPT_PARTIAL_REFIT = 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37
 OPT_GPU_BUILD = 38
+OPT_STACK_CAP = 39
 
 
 class RtxError(RuntimeError):

@@ -97,6 +97,7 @@ struct rtx_ctx {
     int sample_interleave = 1;                       // RTX_OPT_SAMPLE_INTERLEAVE
     int octant_sort = 0; DevBuf d_oct[2], d_perm;    // RTX_OPT_OCTANT_SORT (2 = tooling: all keys zero, i.e. the machinery's overhead without a re-ordering)
     bool trace_counters = false; DevBuf d_trace_cnt;      // RTX_OPT_TRACE_COUNTERS
+    uint32_t stack_cap = 11; DevBuf d_stack_ovf;           // RTX_OPT_STACK_CAP: traversal-stack entries kept in LDS (0 = all of them); the overflow columns of deeper trees
     int any_order_opt = -1;         // RTX_OPT_ANYHIT_ORDER: -1 = what the commit-time probe chose (BuiltScene::any_order)
     bool lpt_order = true;          // RTX_OPT_LPT_ORDER: fused kernels take their sub-queues longest first
     // ReSTIR work lists (x | y << 16 per pixel, 8 x 8 pixel blocks in MORTON order so that consecutive chunks are compact screen regions): the shard's own pixels
@@ -199,7 +200,7 @@ void rtx_destroy(rtx_ctx* c) {
     DevBuf* all[] = {&c->d_nodes, &c->d_tris, &c->d_small, &c->d_small_tris, &c->d_small_poly, &c->d_objtris, &c->d_node_aabb, &c->d_scale, &c->d_shade, &c->d_mats, &c->d_insts, &c->d_lights, &c->d_cdf, &c->d_cam, &c->d_ray_o, &c->d_ray_d,
                      &c->d_thr, &c->d_rad, &c->d_hit, &c->d_hitmask, &c->d_order, &c->d_pmask, &c->d_sh_o, &c->d_sh_d, &c->d_sh_c, &c->d_queue[0], &c->d_queue[1], &c->d_counters,
                      &c->d_accum, &c->d_srgb, &c->d_res_di, &c->d_res_gi, &c->d_sdata, &c->d_last_di, &c->d_last_gi, &c->d_last_sd, &c->d_p1cnt, &c->d_p1scratch, &c->d_hitq, &c->d_halo, &c->d_own, &c->d_heads, &c->d_alt_o, &c->d_alt_d, &c->d_alt_thr, &c->d_oct[0], &c->d_oct[1], &c->d_perm, &c->d_trace_cnt,
-                     &c->d_nodes_wide, &c->d_rs_key_a, &c->d_rs_key_b, &c->d_inst_moved, &c->d_tri_dirty, &c->d_node_dirty, &c->d_pool_verts, &c->d_pool_idx, &c->d_pool_matids, &c->d_flat_insts};
+                     &c->d_nodes_wide, &c->d_rs_key_a, &c->d_rs_key_b, &c->d_inst_moved, &c->d_tri_dirty, &c->d_node_dirty, &c->d_pool_verts, &c->d_pool_idx, &c->d_pool_matids, &c->d_flat_insts, &c->d_stack_ovf};
     for (auto& A : c->rs_area) for (DevBuf* b : {&A.state, &A.hit, &A.cls, &A.fin, &A.cold, &A.occ, &A.cand, &A.sho, &A.shd, &A.pay, &A.cnt}) b->release();
     for (DevBuf* b : all) b->release();
     delete c->builder; c->builder = nullptr;
@@ -251,6 +252,7 @@ int rtx_set_option(rtx_ctx* c, int option, int64_t value) {
     case RTX_OPT_MERGE_RAYS: if (value < 0 || value > (1 << 20)) { c->err = "merge_rays must be in [0, 2^20]"; return RTX_ERR_INVALID; } c->merge_rays = (uint32_t)value; return RTX_OK;
     case RTX_OPT_GPU_REFIT: c->gpu_refit = value != 0; return RTX_OK;
     case RTX_OPT_GPU_BUILD: c->gpu_build = value != 0; return RTX_OK;
+    case RTX_OPT_STACK_CAP: if (value < 0 || value > 30 || (value > 0 && value < 4)) { c->err = "stack_cap must be 0 (the whole stack in LDS) or in [4, 30]"; return RTX_ERR_INVALID; } c->stack_cap = (uint32_t)value; c->committed = false; return RTX_OK;
     case RTX_OPT_SHADE_DENSE: c->shade_dense = (int)value; c->dsc.shade_dense = value > 0 ? 1u : 0u; return RTX_OK;
     case RTX_OPT_OCCLUDER_CACHE: c->occluder_cache = value != 0; c->dsc.occluder_cache = c->occluder_cache; return RTX_OK;
     case RTX_OPT_RESTIR_WAVEFRONT: c->restir_wave = value != 0; return RTX_OK;
@@ -568,6 +570,18 @@ static int finalise_scene(rtx_ctx* c) {
     // children (collapse_bvh8: need[]); a pop precedes every descent from an exhausted group.  Each entry costs 1.5 KB of LDS per workgroup (6 B per lane: kStackEntryBytes), and
     // LDS decides how many workgroups live on a CU: two entries of slack cost C3 2.3 % (5 instead of 6 workgroups) and C5 1.3 %.
     s.stack_depth = B.stack8;
+    // RTX_OPT_STACK_CAP (round 5): LDS pays for `stack_cap` entries at most; a tree whose exact bound is deeper keeps its remaining entries in per-lane columns in global memory
+    // (StackLdsT<true>, rtx_traverse.hpp).  The bound is reached by a handful of rays, the LDS it costs is paid by every workgroup as staged nodes (73 at a bound of 9, 44 at 11,
+    // 24 at 12).  Measured (tools/frame_ms.py, hard street scene): GPU-built tree, bound 12: 40.2 -> 39.4 ms with a cap of 9; host-built, bound 11: 39.75 -> 40.0; the
+    // street stand-in, bound 10: 30.2 -> 30.4 — the overflow test on every push and pop costs about what 30 more staged nodes bring, so the default cap of 11 only catches the
+    // deep trees, for which it is also the difference between running and "BVH too deep for the LDS traversal stack".  Columns: 2^22 lanes (16 384 workgroups: more than any
+    // launch of this library keeps resident) x 8 B per entry beyond the cap.
+    s.stack_ovf = nullptr; s.stack_ovf_stride = 0;
+    if (c->stack_cap && B.stack8 > c->stack_cap && B.stack8 <= 30) {
+        const uint32_t stride = 1u << 22;
+        HIPCHK(c, c->d_stack_ovf.ensure((size_t)(B.stack8 - c->stack_cap) * stride * 8));
+        s.stack_depth = c->stack_cap; s.stack_ovf = (unsigned long long*)c->d_stack_ovf.p; s.stack_ovf_stride = stride;
+    }
     s.stack_private = c->stack_private == 1 ? 1u : 0u;    // 1 (private / scratch) is a tuning knob; it measured slower than the LDS column
     if (s.stack_depth > 30) { c->err = "commit: BVH too deep for the traversal stack (more than 30 levels of 8-wide nodes with two or more internal children)"; return RTX_ERR_INVALID; }
     // LDS per workgroup = traversal stack (6 B per entry and lane) + top of the tree (+ all triangles of a small scene), <= 64 KiB.

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kBlock, (SCHED >= 0 ? RTX_TRACE_WAVES : 1)) void k_
         }
         return;
     }
-    typename std::conditional<STK == 1, StackPriv, StackLds>::type stk;
+    typename std::conditional<STK == 1, StackPriv, StackLdsT<STK == 2>>::type stk;
     if constexpr (STK != 1) stk.init(L);
     RayLane R; ray_idle(R);
     bool drained = false;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kBlock, (SCHED >= 0 ? RTX_TRACE_WAVES : 1)) void k_
         }
         return;
     }
-    typename std::conditional<STK == 1, StackPriv, StackLds>::type stk;
+    typename std::conditional<STK == 1, StackPriv, StackLdsT<STK == 2>>::type stk;
     if constexpr (STK != 1) stk.init(L);
     RayLane R; ray_idle(R);
     bool drained = false;
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_bounce_bvh(DevScene sc, DevFrame 
     const size_t qb = (size_t)qid * f.qcap;
     uint32_t* myhits = hitq + qb;
     uint32_t n = qrows[(size_t)bounce_first * G + qid];
-    typename std::conditional<STK == 1, StackPriv, StackLds>::type stk;
+    typename std::conditional<STK == 1, StackPriv, StackLdsT<STK == 2>>::type stk;
     if constexpr (STK != 1) stk.init(L);
     for (uint32_t bounce = bounce_first; bounce < bounce_end; bounce++) {
         const bool last = (bounce + 1u == f.max_bounces);
@@ -1231,6 +1231,11 @@ void launch_trace_closest(hipStream_t st, const DevFrame& f, const DevScene& sc,
     const uint32_t grid = (f.nblocks + merge - 1u) / merge;
 #define RTX_LAUNCH_TC(SS, TT, CC, LDSB) hipLaunchKernelGGL((k_trace_closest<SS, TT, CC>), dim3(grid), dim3(kBlock), LDSB, st, sc, sc.small, p, queue, qcount, f.qcap, tmin, sc.refill_min, sc.trace_sched, heads, f.nblocks, merge)
     if (sc.stack_private == 1) { if (heads) RTX_LAUNCH_TC(1, true, -1, trace_lds_bytes_queue(sc)); else RTX_LAUNCH_TC(1, false, -1, trace_lds_bytes_queue(sc)); }
+    else if (sc.stack_ovf) {                                // RTX_OPT_STACK_CAP: the tree needs more entries than the LDS column holds (StackLdsT<true>)
+        if (heads) RTX_LAUNCH_TC(2, true, -1, trace_lds_bytes(sc));
+        else if (sc.trace_sched == 6u && !sc.nsmall && !sc.trace_cnt) RTX_LAUNCH_TC(2, false, 6, trace_lds_bytes(sc));
+        else RTX_LAUNCH_TC(2, false, -1, trace_lds_bytes(sc));
+    }
     else if (heads) RTX_LAUNCH_TC(0, true, -1, trace_lds_bytes(sc));
 #ifndef RTX_NO_SCHED_SPECIAL
     else if (sc.trace_sched == 6u && !sc.nsmall && !sc.trace_cnt) RTX_LAUNCH_TC(0, false, 6, trace_lds_bytes(sc));      // the default configuration: schedule compiled in (the work counters live in the generic one)
@@ -1252,6 +1257,7 @@ void launch_bounce_small(hipStream_t st, const DevScene& sc, const DevFrame& f, 
 void launch_bounce_bvh(hipStream_t st, const DevScene& sc, const DevFrame& f, const DevPaths& p, uint32_t bounce_first, uint32_t bounce_end,
                        uint32_t* queue_a, uint32_t* queue_b, uint32_t* hitq, uint32_t* qrows, uint32_t* srows, const uint32_t* order) {
     if (sc.stack_private == 1) hipLaunchKernelGGL(k_bounce_bvh<1>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes_queue(sc), st, sc, f, p, bounce_first, bounce_end, queue_a, queue_b, hitq, qrows, srows, order);
+    else if (sc.stack_ovf) hipLaunchKernelGGL(k_bounce_bvh<2>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, f, p, bounce_first, bounce_end, queue_a, queue_b, hitq, qrows, srows, order);
     else hipLaunchKernelGGL(k_bounce_bvh<0>, dim3(f.nblocks), dim3(kBlock), trace_lds_bytes(sc), st, sc, f, p, bounce_first, bounce_end, queue_a, queue_b, hitq, qrows, srows, order);
 }
 void launch_order_queues(hipStream_t st, const uint32_t* qcount, uint32_t G, uint32_t* order) {
@@ -1265,6 +1271,11 @@ void launch_trace_shadow(hipStream_t st, const DevFrame& f, const DevScene& sc, 
     const uint32_t grid = (f.nblocks + merge - 1u) / merge;
 #define RTX_LAUNCH_TS(SS, TT, CC, LDSB) hipLaunchKernelGGL((k_trace_shadow<SS, TT, CC>), dim3(grid), dim3(kBlock), LDSB, st, sc, sc.small, p, p.sh_o + seg, p.sh_d + seg, p.sh_c + seg, shcount, f.qcap, sc.refill_min, sc.trace_sched, heads, f.nblocks, merge)
     if (sc.stack_private == 1) { if (heads) RTX_LAUNCH_TS(1, true, -1, trace_lds_bytes_queue(sc)); else RTX_LAUNCH_TS(1, false, -1, trace_lds_bytes_queue(sc)); }
+    else if (sc.stack_ovf) {
+        if (heads) RTX_LAUNCH_TS(2, true, -1, trace_lds_bytes(sc));
+        else if (sc.trace_sched == 6u && !sc.nsmall && !sc.trace_cnt) RTX_LAUNCH_TS(2, false, 6, trace_lds_bytes(sc));
+        else RTX_LAUNCH_TS(2, false, -1, trace_lds_bytes(sc));
+    }
     else if (heads) RTX_LAUNCH_TS(0, true, -1, trace_lds_bytes(sc));
 #ifndef RTX_NO_SCHED_SPECIAL
     else if (sc.trace_sched == 6u && !sc.nsmall && !sc.trace_cnt) RTX_LAUNCH_TS(0, false, 6, trace_lds_bytes(sc));
@@ -1321,8 +1332,9 @@ void launch_trace_occ(hipStream_t st, const DevScene& sc_in, const RsQ& q, const
     // the visibility rays of the ReSTIR stages run between arbitrary scene points (reconnections, last frame's samples), not towards sampled lights: the NEE probe's
     // order does not carry over — slot order measured best on all three scenes (atrium 8.28 vs 8.38 ms, garage 6.74 vs 6.84, street 7.99 vs 8.02-8.12 per frame with orders 1 / 2)
     DevScene sc = sc_in; sc.any_order = sc_in.any_order_occ;
-#define RTX_LAUNCH_TO(CC) hipLaunchKernelGGL((k_trace_shadow<0, false, CC, 1>), dim3(q.G), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, none, q.sh_o, q.sh_d, (const F4*)nullptr, shcnt, q.rcap, sc.refill_min, sc.trace_sched, (uint32_t*)nullptr, q.G, 1u, q.sh_pay, q.occ)
-    if (sc.trace_sched == 6u && !sc.nsmall && !sc.trace_cnt) RTX_LAUNCH_TO(6); else RTX_LAUNCH_TO(-1);
+#define RTX_LAUNCH_TO(CC) hipLaunchKernelGGL((k_trace_shadow<SL_, false, CC, 1>), dim3(q.G), dim3(kBlock), trace_lds_bytes(sc), st, sc, sc.small, none, q.sh_o, q.sh_d, (const F4*)nullptr, shcnt, q.rcap, sc.refill_min, sc.trace_sched, (uint32_t*)nullptr, q.G, 1u, q.sh_pay, q.occ)
+    if (sc.stack_ovf) { constexpr int SL_ = 2; if (sc.trace_sched == 6u && !sc.nsmall && !sc.trace_cnt) RTX_LAUNCH_TO(6); else RTX_LAUNCH_TO(-1); }
+    else { constexpr int SL_ = 0; if (sc.trace_sched == 6u && !sc.nsmall && !sc.trace_cnt) RTX_LAUNCH_TO(6); else RTX_LAUNCH_TO(-1); }
 #undef RTX_LAUNCH_TO
 }
 static inline RestirBufs rs_bufs(uint32_t* const* b) { return RestirBufs{b[0], b[1], b[2], b[3], b[4], b[5]}; }

@@ -22,7 +22,8 @@ struct DevScene {
     const float* cdf;               // lights[i].cdf as a dense array: the binary search of the light selection probes 4-byte entries side by side instead of one 80-byte record per probe
     float total_weight;
     uint32_t lds_nodes, lds_tris;   // how many nodes / triangles each workgroup stages in LDS
-    uint32_t stack_depth;           // per-lane traversal stack entries (LDS)
+    uint32_t stack_depth;           // per-lane traversal stack entries IN LDS
+    unsigned long long* stack_ovf; uint32_t stack_ovf_stride;   // RTX_OPT_STACK_CAP: entries beyond stack_depth live here, entry k of lane l at [k * stride + (l & (stride - 1))] (nullptr: the tree needs no more than stack_depth)
     uint32_t stack_private;         // queue kernels: 0 = stack in the LDS column, 1 = private (scratch) array
     uint32_t sort_materials;        // 1 = material-sorted shading in k_shade (general path; tuning knob, default 0)
     uint32_t refill_min, trace_sched;   // persistent traversal: idle lanes that trigger a refill; wave schedule (rtx_kernels.hip)

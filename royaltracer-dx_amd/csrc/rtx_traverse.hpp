@@ -60,6 +60,7 @@ struct TraceLds {
     const lds_v4f* planes;  // tiny scenes: plane (n, n.p0) of every pre-test record
     lds_u32* stack;         // [depth][kBlock] sibling-group entries: the group's base index ...
     lds_u16* stack_bits;    // [depth][kBlock] ... and its 16 bits (ordered internal hits | internal mask << 8): 6 B per entry and lane (kStackEntryBytes)
+    unsigned long long* ovf; uint32_t cap, ovf_stride;      // this lane's column of the overflow area (DevScene::stack_ovf), entries in LDS, stride between overflow entries
 };
 __host__ __device__ inline uint32_t small_planes_count(uint32_t nsmall) { return (nsmall + 1u) & ~1u; }
 
@@ -80,6 +81,8 @@ __device__ __forceinline__ TraceLds stage_lds(const DevScene& sc, F4* lds_generi
     L.nodes = ln; L.tris = lt; L.planes = lp;
     L.stack = (lds_u32*)(lp + npl);
     L.stack_bits = (lds_u16*)(L.stack + (size_t)sc.stack_depth * kBlock);
+    L.cap = sc.stack_depth; L.ovf_stride = sc.stack_ovf_stride;
+    L.ovf = sc.stack_ovf ? sc.stack_ovf + ((blockIdx.x * kBlock + threadIdx.x) & (sc.stack_ovf_stride - 1u)) : nullptr;
     return L;
 }
 
@@ -209,10 +212,22 @@ __device__ __forceinline__ void node8_hits(const Node8R& N, f3 o, f3 idir, bool 
 // traversal stack of sibling groups: per-lane column in LDS (conflict-free 8-byte accesses), or a private array (scratch)
 // (round 4) 6 B per entry: a 32-bit base and the 16 bits that are used of `bits`, in two arrays.  Two bytes per lane and level less than the 8-B entry are 4.5-5 KB per
 // workgroup on the benchmark scenes: the first three levels of the wide tree (73 nodes, 5.8 KB) now fit beside the stack WITHOUT giving up a workgroup per CU.
-struct StackLds { lds_u32* cb; lds_u16* ck;
-                  __device__ __forceinline__ void init(const TraceLds& L) { cb = L.stack + threadIdx.x; ck = L.stack_bits + threadIdx.x; }
-                  __device__ __forceinline__ void put(int i, Grp g) { cb[i * kBlock] = g.base; ck[i * kBlock] = (uint16_t)g.bits; }
-                  __device__ __forceinline__ Grp get(int i) const { return Grp{cb[i * kBlock], (uint32_t)ck[i * kBlock]}; } };
+// (round 5) RTX_OPT_STACK_CAP: the LDS column holds the first `cap` entries only — what almost every ray needs — and deeper entries go to a per-lane column in global memory
+// (OVF).  A tree whose exact stack bound is 12 then costs the LDS of 9 entries like every other tree, i.e. the first three levels of the wide tree (73 nodes) stay staged at
+// eight workgroups per CU (hard street scene, GPU-built tree: 24 staged nodes at a bound of 12 -> 73).  OVF = false (the hot kernels of trees within the cap): no test at all.
+template <bool OVF>
+struct StackLdsT { lds_u32* cb; lds_u16* ck; unsigned long long* ov; int cap; uint32_t os;
+                   __device__ __forceinline__ void init(const TraceLds& L) { cb = L.stack + threadIdx.x; ck = L.stack_bits + threadIdx.x; ov = L.ovf; cap = (int)L.cap; os = L.ovf_stride; }
+                   __device__ __forceinline__ void put(int i, Grp g) {
+                       if (!OVF || i < cap) { cb[i * kBlock] = g.base; ck[i * kBlock] = (uint16_t)g.bits; }
+                       else ov[(size_t)(i - cap) * os] = (unsigned long long)g.base | ((unsigned long long)g.bits << 32);
+                   }
+                   __device__ __forceinline__ Grp get(int i) const {
+                       if (!OVF || i < cap) return Grp{cb[i * kBlock], (uint32_t)ck[i * kBlock]};
+                       const unsigned long long e = ov[(size_t)(i - cap) * os];
+                       return Grp{(uint32_t)e, (uint32_t)(e >> 32)};
+                   } };
+using StackLds = StackLdsT<true>;          // the general-purpose paths (debug queries, literal ReSTIR kernels, fused experiments): always safe, whatever the scene's cap
 constexpr int kPrivStack = 32;
 struct StackPriv { Grp a[kPrivStack]; __device__ __forceinline__ void put(int i, Grp g) { a[i] = g; } __device__ __forceinline__ Grp get(int i) const { return a[i]; } };
 

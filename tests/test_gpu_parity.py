@@ -537,6 +537,37 @@ def test_wide_bvh_equals_brute_force_on_hostile_soups(rt, orc, kind, builder):
     c.close()
 
 
+@pytest.mark.parametrize("kind", ["atrium", "needles"])
+def test_traversal_stack_overflow_columns_change_nothing(rt, orc, kind):
+    """RTX_OPT_STACK_CAP (round 5): traversal-stack entries beyond the cap live in per-lane columns in global memory instead of LDS.  With a cap of 4 (every tree here needs more)
+    the persistent closest-hit and any-hit kernels, the ReSTIR stages' visibility kernel and the debug queries all run through the overflow path: image, ray counts, closest hits
+    and occlusion answers must equal the uncapped context's and the oracle's."""
+    rng = np.random.default_rng(5)
+    sc = rt.Scene.sponza_class(60000, 260) if kind == "atrium" else SoupScene(soup("needles", 20000, rng))
+    W, H = 96, 54
+    vp = sc.view_proj(W / H) if kind == "atrium" else (rt.lookat((0.2, 0.3, 2.6), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)), rt.perspective_fov_rh(np.radians(60.0), W / H, 0.1, 1000.0))
+    p = rt.Params(width=W, height=H, spp=2, max_bounces=5, nee_samples=1, flags=1)
+    o = orc.Oracle().load(sc, W / H); o.set_camera(*vp)
+    oa, oc = o.render(p)
+    rays = np.concatenate([o.primary_rays(rt.Params(width=W, height=H), 1)[:2000], random_rays(3000, 5, -1.5, 1.5)])
+    ob = o.trace_closest(rays, 1)
+    sh = rays.copy(); sh[:, 7] = rng.uniform(0.05, 1.0, len(sh)).astype(np.float32) * 3.0
+    oany = o.trace_any(sh, mode=1)
+    for cap in (0, 4, 6):
+        c = rt.Context(0); c.set_option(rt.OPT_STACK_CAP, cap); c.upload(sc, W / H); c.set_camera(*vp)
+        assert c.validate_bvh() == 0
+        c.clear(W, H); c.render(p); st = c.stats()
+        assert np.array_equal(bits(c.read_accum()), bits(oa)) and (st.rays_primary, st.rays_extension, st.rays_shadow) == oc, f"cap {cap}"
+        assert np.array_equal(bits(c.trace_closest(rays)), bits(ob)) and np.array_equal(c.trace_any(sh), oany), f"cap {cap}"
+        if kind == "atrium":                                 # a ReSTIR frame: its stages' traversal launches take the same columns
+            pr = rt.Params(width=W, height=H, spp=1, max_bounces=3, nee_samples=2, flags=0)
+            c.restir_reset(); c.clear(W, H); c.render_restir(pr)
+            img = c.read_accum()
+            if cap == 0: ref_restir = img
+            else: assert np.array_equal(bits(img), bits(ref_restir)), f"ReSTIR frame, cap {cap}"
+        c.close()
+
+
 def test_host_state_survives_hundreds_of_contexts(rt):
     """Round 5 (profiles/r05_determinism.md): the once-in-700-contexts mismatch of the fuzz tests was two words of a live 912-byte host vector (a mesh's index array, the
     builder's leaf order) changing during a later rtx_commit_scene — a stray write that came with hipStreamDestroy in a process that creates and destroys many contexts.  The
