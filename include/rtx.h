@@ -164,7 +164,7 @@ enum { RTX_OPT_KERNEL_TIMING = 1,    /* 0/1: bracket every launch with hipEvents
                                         so no result changes.  The next rtx_commit_scene rebuilds */
        RTX_OPT_ANYHIT_ORDER = 28,    /* any-hit (shadow / visibility) rays visit the hit children of a node in 0 = slot order, 1 = nearest octant first, 2 = farthest octant first;
                                         -1 (default) = what a commit-time probe of 2 048 NEE-like segments on the host found cheapest for this scene and its lights.  Never changes a result */
-       RTX_OPT_GPU_BUILD = 38,       /* 1: a geometry-changing rtx_commit_scene builds the BVH ON THE GPU (csrc/rtx_build.hip: Morton sort, PLOC clustering down to <= 8 192 clusters, the top
+       RTX_OPT_GPU_BUILD = 38,       /* 1: a geometry-changing rtx_commit_scene builds the BVH ON THE GPU (csrc/rtx_build.hip: Morton sort, PLOC clustering down to <= 16 384 clusters, the top
                                         of the tree by the host's SAH builder + re-insertion over those clusters, SAH collapse to 8-wide nodes and layout on the device, then the refit
                                         kernels) instead of on the host: what the reference's driver does for it in BottomLevelASGenerator.cpp:178-247 / TopLevelASGenerator.cpp:149-250.
                                         0 (default): host build.  Results never depend on the tree; the host-side mirror of the tree (scene cache save, host refit) is not kept */

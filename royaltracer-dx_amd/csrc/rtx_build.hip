@@ -6,7 +6,7 @@
 //     -> PLOC           parallel locally-ordered clustering (Meister & Bittner, TVCG 2018): per round  k_ploc_nn (nearest neighbour within +- radius places, boxes
 //                       staged through LDS) | k_ploc_flags | exclusive scan | k_ploc_merge (mutual pairs become nodes; the SAH dynamic program's record of every new
 //                       node is computed right there — its children are older nodes), until at most `ploc_top` clusters are left
-//     -> HOST           the top of the tree over those <= 8 192 clusters: top-down binned SAH + re-insertion passes (build_cluster_top, milliseconds) and its records;
+//     -> HOST           the top of the tree over those <= 16 384 clusters: top-down binned SAH + re-insertion passes (build_cluster_top, milliseconds) and its records;
 //                       the top is where every ray passes (5.7 of 12.4 node steps in the first three wide levels of the atrium), so it gets the expensive builder
 //     -> layout         level by level from the root: k_lay_count (the children of each wide node by the recorded decisions, their octant slots) | scan | k_lay_emit
 //                       (Node8GPU topology, the next level's nodes, the leaf-slot order of the triangles); k_lay_need (traversal stack bound, bottom-up)

@@ -28,7 +28,7 @@ struct BvhBuildOptions {
     double   tri_cost = 0.7;      // collapse_bvh8: cost of a triangle test relative to a node step
     int      threads = 0;         // build_bvh: threads of the top-down phase (0 = up to 16 of the machine's; 1 = serial).  The tree does not depend on it
     int      ploc_radius = 0;     // > 0: the bottom-up PLOC builder with this search radius below the top-down SAH builder (the host twin of the GPU build, csrc/rtx_build.hip)
-    uint32_t ploc_top = 8192;     // ... which stops at this many clusters; the SAH builder (+ re-insertion) then builds the top of the tree over them (1: PLOC to the root)
+    uint32_t ploc_top = 16384;    // ... which stops at this many clusters; the SAH builder (+ re-insertion) then builds the top of the tree over them (1: PLOC to the root)
 };
 BvhBuildOptions& bvh_build_options();                      // process-wide defaults: what a new SceneHost starts with (RTX_BVH="key=value,..." in the environment edits them once)
 bool bvh_build_option(const char* key, double value);      // edits the defaults; false: unknown key

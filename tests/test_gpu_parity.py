@@ -601,7 +601,7 @@ def test_host_state_survives_hundreds_of_contexts(rt):
 @pytest.mark.parametrize("kind", ["atrium", "atrium_hard", "street", "soup", "needles"])
 def test_gpu_build_equals_its_host_twin_and_renders_the_oracle_image(rt, orc, kind):
     """RTX_OPT_GPU_BUILD (csrc/rtx_build.hip; VERDICT r04 item 6: the reference's driver builds its BLAS / TLAS on the device, BottomLevelASGenerator.cpp:178-247,
-    TopLevelASGenerator.cpp:149-250): a geometry-changing commit builds the wide tree ON THE GPU — Morton sort, PLOC rounds, the top over <= 8 192 clusters by the host's SAH builder,
+    TopLevelASGenerator.cpp:149-250): a geometry-changing commit builds the wide tree ON THE GPU — Morton sort, PLOC rounds, the top over <= 16 384 clusters by the host's SAH builder,
     SAH collapse and layout on the device, boxes by the refit kernels.  (1) The tree is valid (every triangle in exactly one leaf slot, inside every decoded box above it).
     (2) It is the tree its HOST TWIN builds (the host builder with BvhBuildOptions::ploc_radius, same decisions from shared code: rtx_wide.hpp) node for node and triangle
     for triangle, once both have been quantised by the same refit kernels.  (3) Image, ray counts and closest-hit records equal the oracle's — results do not depend on the
@@ -618,7 +618,7 @@ def test_gpu_build_equals_its_host_twin_and_renders_the_oracle_image(rt, orc, ki
     vp = sc.view_proj(W / H) if kind in ("atrium", "atrium_hard", "street") else (rt.lookat((0.2, 0.3, 2.6), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)), rt.perspective_fov_rh(np.radians(60.0), W / H, 0.1, 1000.0))
     a = rt.Context(0); a.set_option(rt.OPT_GPU_BUILD, 1); a.upload(sc, W / H); a.set_camera(*vp)
     info = a.build_info()
-    assert info["ploc_rounds"] >= (2 if a.stats().triangles > 16384 else 0) and 1 <= info["clusters_top"] <= 8192 and info["refs"] == a.stats().triangles and sum(info["ms"]) > 0
+    assert info["ploc_rounds"] >= (2 if a.stats().triangles > 40000 else 0) and 1 <= info["clusters_top"] <= 16384 and info["refs"] == a.stats().triangles and sum(info["ms"]) > 0
     assert a.validate_bvh() == 0
     rt.bvh_option("ploc", 16)
     try:
