@@ -35,6 +35,28 @@ int main(int argc, char** argv) {
         printf("nt=%u bvh2 rc=%d nodes=%u depth=%u leaf=%u | bvh8 rc=%d nodes=%u stack=%u | stats rc=%d | refit rc=%d\n", nt, r1, nodes, depth, leaf, r2, n8, st, r3, r4);
         if (r1 || r2 || r3 || r4) return 2;
     }
+    // (round 5) the builder's other modes on a soup that exercises them: the GPU build's host twin (PLOC rounds + the SAH top over clusters + expansion), spatial splits with
+    // re-insertion, leaves of one reference / of up to four, and the hard stand-in scenes' generators
+    {
+        const uint32_t nt = 40000u;
+        std::vector<float> w((size_t)nt * 9);
+        for (uint32_t i = 0; i < nt; i++) { float cx = U(rng), cy = U(rng), cz = U(rng), sz = (i % 97u == 0u) ? 0.6f : 1.0f; for (int k = 0; k < 3; k++) { w[i * 9 + k * 3] = cx + sz * N(rng) * (i % 97u == 0u ? 20.0f : 1.0f); w[i * 9 + k * 3 + 1] = cy + N(rng); w[i * 9 + k * 3 + 2] = cz + N(rng); } }
+        struct Mode { const char* key; double on, off; };
+        const Mode modes[] = {{"ploc", 16.0, 0.0}, {"split", 1e-5, 0.0}, {"leaf_stop", 4.0, 1.0}, {"sweep", 64.0, 0.0}, {"slot_assign", 1.0, 0.0}};
+        for (const Mode& m : modes) {
+            if (rtxh_bvh_option(m.key, m.on) != 0) { printf("unknown builder option %s\n", m.key); return 6; }
+            if (std::string(m.key) == "ploc") rtxh_bvh_option("ploc_top", 2048.0);            // several PLOC rounds on 40 000 triangles
+            uint32_t n8 = 0, st = 0, hist[6];
+            const int r2 = rtxh_bvh8_check(w.data(), nt, &n8, &st), r3 = rtxh_bvh8_stats(w.data(), nt, hist, &n8);
+            printf("builder %s=%g: bvh8 rc=%d nodes=%u stack=%u stats rc=%d\n", m.key, m.on, r2, n8, st, r3);
+            rtxh_bvh_option(m.key, m.off); rtxh_bvh_option("ploc_top", 16384.0);
+            if (r2 || r3) return 6;
+        }
+        rtxh_scene* sh = rtxh_scene_sponza_class_hard(60000, 260); rtxh_scene* bh = rtxh_scene_bistro_class_hard(120000, 3800);
+        if (!sh || !bh) { printf("hard scene creation failed\n"); return 6; }
+        printf("hard scenes: %u / %u triangles\n", rtxh_scene_num_triangles(sh), rtxh_scene_num_triangles(bh));
+        rtxh_scene_free(sh); rtxh_scene_free(bh);
+    }
     // image writers
     const std::string out = argc > 2 ? argv[2] : "/tmp";
     std::vector<uint8_t> img(37 * 21 * 4, 128); std::vector<float> acc(37 * 21 * 4, 1.5f);
