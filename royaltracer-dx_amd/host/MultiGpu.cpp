@@ -8,6 +8,19 @@
 #include <mutex>
 #include <stdexcept>
 #include <thread>
+#include <mutex>
+#include <utility>
+
+// The ranks' streams are borrowed from a process-wide list and handed back idle, never destroyed — as the library does with its own (csrc/rtx_api.hip: StreamPool;
+// profiles/r05_determinism.md: a process that creates and destroys HIP streams by the thousand gets, rarely, a stray write into its heap).
+static std::mutex g_rank_stream_mu; static std::vector<std::pair<int, hipStream_t>> g_rank_streams;
+static hipStream_t rank_stream_acquire(int device) {
+    { std::lock_guard<std::mutex> g(g_rank_stream_mu); for (size_t i = 0; i < g_rank_streams.size(); i++) if (g_rank_streams[i].first == device) { hipStream_t st = g_rank_streams[i].second; g_rank_streams.erase(g_rank_streams.begin() + (long)i); return st; } }
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) throw std::runtime_error("MultiGpuFrame: hipStreamCreate failed");
+    return st;
+}
+static void rank_stream_release(int device, hipStream_t st) { (void)hipStreamSynchronize(st); std::lock_guard<std::mutex> g(g_rank_stream_mu); g_rank_streams.emplace_back(device, st); }
 
 namespace {
 void hipck(hipError_t e, const char* what) { if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e)); }
@@ -43,7 +56,7 @@ MultiGpuFrame::MultiGpuFrame(const std::vector<int>& devices, Gather g, bool alw
             if (only_rank >= 0 && r != only_rank) continue;
             if (rtx_create(devices[r], &m->ctx[r]) != RTX_OK) throw std::runtime_error(std::string("rtx_create: ") + rtx_last_error(nullptr));
             hipck(hipSetDevice(devices[r]), "hipSetDevice");
-            hipck(hipStreamCreateWithFlags(&m->stream[r], hipStreamNonBlocking), "hipStreamCreate");
+            m->stream[r] = rank_stream_acquire(devices[r]);
             if (rtx_set_stream(m->ctx[r], m->stream[r]) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));   // render -> pack -> gather -> unpack run stream-ordered
             if (rtx_set_option(m->ctx[r], RTX_OPT_ASYNC, 1) != RTX_OK) throw std::runtime_error(rtx_last_error(m->ctx[r]));   // rtx_render only enqueues: no host join before the pack
         }
@@ -89,7 +102,7 @@ void MultiGpuFrame::Teardown() {
         if (r < m->comm.size() && m->comm[r]) (void)ncclCommDestroy(m->comm[r]);
         if (m->ctx[r]) rtx_destroy(m->ctx[r]);
         for (std::vector<void*>* v : {&m->slab, &m->gathered, &m->state_slab, &m->state_gathered, &m->halo_send, &m->halo_recv}) if (r < v->size() && (*v)[r]) (void)hipFree((*v)[r]);
-        if (m->stream[r]) (void)hipStreamDestroy(m->stream[r]);
+        if (m->stream[r]) rank_stream_release(m_devices[r], m->stream[r]);        // (never destroyed: see rank_stream_acquire)
     }
     delete m; m = nullptr;
 }

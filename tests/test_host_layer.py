@@ -359,13 +359,14 @@ def test_library_exports_every_declared_symbol(rt):
 def test_product_library_keeps_the_process_allocator_and_never_destroys_streams():
     """Round 5 (profiles/r05_determinism.md): (1) the heap fence that hunted the stray write (csrc/rtx_heap_fence.cpp) is an EMPTY translation unit in the product — librtx_hip.so
     must not define operator new / delete; (2) the cure: the library borrows its HIP streams from a process-wide pool and never destroys one — no call to hipStreamDestroy is
-    left in the C-ABI sources (host/MultiGpu.cpp, the executable's per-frame-object streams, is outside the library's contexts)."""
+    left in the C-ABI sources, nor in host/MultiGpu.cpp (the native N-GPU frame keeps its ranks' streams in a list of its own)."""
     pkg = os.path.join(ROOT, "royaltracer-dx_amd")
     nm = subprocess.run(["nm", "-DC", "--defined-only", os.path.join(pkg, "librtx_hip.so")], capture_output=True, text=True).stdout
     assert "operator new" not in nm and "operator delete" not in nm
     for f in ("rtx_api.hip", "rtx_build.hip", "rtx_kernels.hip", "rtx_staging.hpp"):
         src = re.sub(r"//[^\n]*", "", open(os.path.join(pkg, "csrc", f)).read())
         assert "hipStreamDestroy(" not in src, f
+    assert "hipStreamDestroy(" not in re.sub(r"//[^\n]*", "", open(os.path.join(pkg, "host", "MultiGpu.cpp")).read())
     api = open(os.path.join(pkg, "csrc", "rtx_api.hip")).read()
     assert "hipMemcpyHostToDevice" not in api and api.count("hipMemcpyDeviceToHost") == 1        # host copies go through rtx_staging.hpp; the one left fills the PINNED counter block of a frame
 
